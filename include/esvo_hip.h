@@ -1,0 +1,272 @@
+/*
+ * esvo_hip.h — C-ABI of the MI355X-native ESVO hot path (Time-Surface raster +
+ * semi-dense stereo mapper).
+ *
+ * This header is the drop-in boundary.  The reference (ESVO) has
+ * no FFI/plugin interface: its algorithms are C++ classes called directly by the
+ * ROS nodes.  Every entry point below therefore names the reference *seam* it
+ * stands behind (file:line relative to the ESVO repository) — the call a
+ * maintainer replaces in esvo_time_surface/src/TimeSurface.cpp and
+ * esvo_core/src/esvo_Mapping.cpp / esvo_MVStereo.cpp.
+ *
+ * Conventions
+ *   - plain C, opaque handle, no exceptions, no exit(): every call returns
+ *     ESVO_OK (0) or a negative esvo_status_t; esvo_last_error() gives text.
+ *   - all input buffers are borrowed for the duration of the call only.
+ *   - outputs go to caller-allocated arrays (capacity + returned count).
+ *   - one handle is not thread-safe; distinct handles are independent.
+ *   - every call is synchronous w.r.t. its host-visible outputs; calls without
+ *     host outputs only enqueue work on the handle's HIP stream.
+ *   - pointers named d_* are DEVICE pointers (HBM), everything else is host.
+ *   - there is no CPU fallback: esvo_create() fails with ESVO_ERR_NO_DEVICE
+ *     when no gfx950 device is visible.
+ */
+#ifndef ESVO_HIP_H
+#define ESVO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ESVO_HIP_ABI_VERSION 1
+
+typedef enum esvo_status_t {
+  ESVO_OK = 0,
+  ESVO_ERR_INVALID_ARG = -1,
+  ESVO_ERR_NO_DEVICE = -2,
+  ESVO_ERR_HIP = -3,
+  ESVO_ERR_CAPACITY = -4,
+  ESVO_ERR_UNSUPPORTED = -5,
+  ESVO_ERR_STATE = -6
+} esvo_status_t;
+
+typedef struct esvo_context* esvo_handle;
+
+enum { ESVO_CAM_LEFT = 0, ESVO_CAM_RIGHT = 1 };
+enum { ESVO_FUSION_CONST_FRAMES = 0, ESVO_FUSION_CONST_POINTS = 1 };
+enum { ESVO_LSNORM_TDIST = 0, ESVO_LSNORM_L2 = 1 /* unsupported: no shipped config uses it */ };
+
+/* Layout-identical to the in-memory dvs_msgs::Event (uint16 x, uint16 y,
+ * ros::Time{uint32 sec, uint32 nsec}, bool polarity; sizeof == 16), so ROS glue
+ * passes msg->events.data() without a copy. */
+typedef struct esvo_event_t {
+  uint16_t x, y;
+  uint32_t sec, nsec;
+  uint8_t polarity;
+  uint8_t _pad[3];
+} esvo_event_t;
+
+/* Per-camera calibration products.  They are what the reference's
+ * PerspectiveCamera::preComputeRectifiedCoordinate (CameraSystem.cpp:36-111) and
+ * TimeSurface::cameraInfoCallback (TimeSurface.cpp:313-401) compute once with
+ * OpenCV; the caller passes them in (ROS glue: straight from its CameraSystem;
+ * ROS-free harness: esvo_amd/calib.py). */
+typedef struct esvo_calib_t {
+  int32_t width, height;
+  double P[12];              /* rectified 3x4 projection matrix, row-major (CameraSystem.cpp:31) */
+  const float* rect_lut;     /* [H*W*2] raw pixel -> rectified (x,y), float32 as returned by
+                                cv::undistortPoints (CameraSystem.cpp:62,106-110) */
+  const uint8_t* rect_mask;  /* [H*W] 0/255 UndistortRectify_mask_ (CameraSystem.cpp:67-72);
+                                may be NULL for the right camera */
+  const float* map_x;        /* [H*W] undistort_map1_ CV_32FC1 (TimeSurface.cpp:341-351) */
+  const float* map_y;        /* [H*W] undistort_map2_ */
+} esvo_calib_t;
+
+/* One POD carrying every yaml key the hot path reads. */
+typedef struct esvo_params_t {
+  /* esvo_time_surface (cfg/time_surface/ts_parameters.yaml; TimeSurface.cpp:23-30) */
+  double decay_ms;                 /* 30 */
+  int32_t median_blur_kernel_size; /* 1 -> 3x3; 0 disables; >1 unsupported */
+  int32_t ignore_polarity;         /* 1 */
+  /* DepthProblemConfig (DepthProblem.h:15-51) */
+  int32_t patch_size_x;            /* 15 */
+  int32_t patch_size_y;            /* 7 */
+  int32_t ls_norm;                 /* ESVO_LSNORM_TDIST */
+  double td_nu;                    /* Tdist_nu */
+  double td_scale;                 /* Tdist_scale */
+  int32_t lm_max_iteration;        /* ITERATION_OPTIMIZATION (10); maxfev = 3x */
+  int32_t reg_radius;              /* RegularizationRadius */
+  int32_t reg_min_neighbours;      /* RegularizationMinNeighbours */
+  int32_t reg_min_close_neighbours;/* RegularizationMinCloseNeighbours */
+  /* EventBM (EventBM.cpp:34-54).  min/max are the EFFECTIVE range after the
+   * depth-range clamp of esvo_Mapping.cpp:110-116 (esvo_amd/params.py does it). */
+  int32_t bm_min_disparity;
+  int32_t bm_max_disparity;
+  int32_t bm_step;                 /* 1 in every shipped config */
+  double bm_zncc_threshold;        /* 0.1 */
+  int32_t bm_updown;               /* BM_bUpDownConfiguration; only 0 supported */
+  int32_t smooth_time_surface;     /* SmoothTimeSurface: 5x5 Gaussian before BM (DSEC) */
+  /* mapping node (esvo_Mapping.cpp:63-99) */
+  double invdepth_min, invdepth_max;
+  double stdvar_vis_threshold;     /* sigma; culling/clean compare against its square */
+  double residual_vis_threshold;   /* cost threshold = thr^2 * patch area */
+  double age_vis_threshold;
+  int32_t fusion_radius;           /* 0 -> 2x2, !=0 -> 3x3 (DepthFusion.cpp:98-117) */
+  int32_t fusion_strategy;         /* ESVO_FUSION_CONST_FRAMES / _CONST_POINTS */
+  int32_t max_fusion_frames;
+  int32_t max_fusion_points;
+  int32_t clean_requires_full_window; /* 1: esvo_Mapping.cpp:385; 0: esvo_MVStereo.cpp:496 */
+  int32_t regularization;          /* Regularization */
+  int32_t process_event_num;       /* PROCESS_EVENT_NUM (events block-matched per tick) */
+  double bm_half_slice_thickness;  /* 0.001 s; event window = 10x (esvo_Mapping.cpp:563) */
+  int32_t num_threads;             /* NUM_THREAD_MAPPING (4): reproduces the stride-N output
+                                      permutation of EventBM.cpp:289-308 and
+                                      DepthProblemSolver.cpp:75-90 */
+  /* capacities (device allocations; 288 GB of HBM makes generous defaults cheap) */
+  int32_t max_events_per_tick;     /* >= process_event_num */
+  int32_t max_window_points;       /* total DepthPoints the fusion window may hold */
+  int32_t max_poses_per_tick;      /* >= 201 */
+  int64_t event_ring_capacity;     /* staged events per camera */
+} esvo_params_t;
+
+/* What flows EventBM -> DepthProblemSolver.  The reference's EventMatchPair
+ * (EventMatchPair.h:16-38) carries a full pose; consumers read only x_left_,
+ * trans_, invDepth_ (DepthProblemSolver.cpp:92-94) and cost_/disp_ in BM-only mode. */
+typedef struct esvo_match_t {
+  double x_left[2];   /* rectified left coordinate */
+  double inv_depth;   /* disparity / (baseline * P(0,0)) */
+  double cost;        /* ZNCC cost of the best candidate */
+  double disp;
+  uint32_t event_idx; /* index into the events passed to the call */
+  uint32_t pose_idx;  /* index into the tick's pose table (first stamp >= event ts) */
+} esvo_match_t;
+
+/* Every field of DepthPoint (DepthPoint.h:70-88); the 4x4 T_world_cam_ is
+ * carried as an index into the pose table of the frame the point came from. */
+typedef struct esvo_depth_point_t {
+  uint32_t row, col;
+  double x[2];
+  double inv_depth;
+  double scale2;
+  double nu;
+  double variance;
+  double residual;
+  uint64_t age;
+  double p_cam[3];
+  uint32_t pose_idx;
+  uint32_t seq;       /* DepthMap outputs: creation order in the reference's element list */
+} esvo_depth_point_t;
+
+/* Stage timings use the reference's own stage boundaries (esvo_Mapping.cpp:405-430). */
+typedef struct esvo_stats_t {
+  uint64_t ticks;
+  uint64_t events_staged[2];
+  uint64_t events_scattered[2];
+  uint64_t ts_frames[2];
+  uint32_t last_events_in;      /* events handed to block matching in the last tick */
+  uint32_t last_matches;        /* BM successes */
+  uint32_t last_solved;         /* LM problems solved */
+  uint32_t last_points;         /* after pointCulling */
+  uint32_t last_window_frames;
+  uint32_t last_window_points;
+  uint32_t last_fusions;        /* DepthFusion::update return, summed over the window */
+  uint32_t last_map_size;       /* DepthMap::size() after clean/regularisation */
+  float ms_ts_scatter, ms_ts_render;
+  float ms_bm, ms_refine, ms_fusion, ms_regularization, ms_tick_total;
+} esvo_stats_t;
+
+/* ---- lifecycle -------------------------------------------------------------------- */
+
+/* Fill *p with the reference's code defaults (esvo_Mapping.cpp:37-99, TimeSurface.cpp:23-30). */
+void esvo_default_params(esvo_params_t* p);
+
+/* Replaces: TimeSurface ctor + cameraInfoCallback (TimeSurface.cpp:12-50,313-401) and the
+ * esvo_Mapping ctor's CameraSystem/EventBM/DepthProblemSolver/DepthFusion setup
+ * (esvo_Mapping.cpp:26-128).  `device` is the HIP device ordinal. */
+int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esvo_calib_t* right,
+                int device, esvo_handle* out);
+int esvo_destroy(esvo_handle h);
+/* Replaces esvo_Mapping::reset (esvo_Mapping.cpp:764-804): clears SAE, event rings, window, map. */
+int esvo_reset(esvo_handle h);
+/* Replaces EventBM::resetParameters (EventBM.cpp:34-54) + onlineParameterChangeCallback
+ * (esvo_Mapping.cpp:806-866).  Capacities and image size cannot change. */
+int esvo_set_params(esvo_handle h, const esvo_params_t* params);
+const char* esvo_last_error(esvo_handle h); /* h may be NULL for create-time errors */
+/* Run the handle's kernels on an external HIP stream (e.g. torch's current stream). */
+int esvo_set_stream(esvo_handle h, void* hip_stream);
+int esvo_synchronize(esvo_handle h);
+
+/* ---- Time Surface ------------------------------------------------------------------ */
+
+/* Replaces TimeSurface::eventsCallback + EventQueueMat::insertEvent (TimeSurface.cpp:403-425,
+ * TimeSurface.h:39-50) and, for the left camera, esvo_Mapping::eventsCallback
+ * (esvo_Mapping.cpp:669-703).  Events must be time-sorted (Appendix A-1). */
+int esvo_ts_push_events(esvo_handle h, int cam, const esvo_event_t* ev, size_t n);
+/* Replaces TimeSurface::createTimeSurfaceAtTime (TimeSurface.cpp:52-152), BACKWARD mode.
+ * Uses every staged event with ts < t_ns.  out_mono8 (W*H) may be NULL: the rectified TS
+ * also stays device-resident as the camera's latest frame. */
+int esvo_ts_render(esvo_handle h, int cam, uint64_t t_ns, uint8_t* out_mono8);
+
+/* ---- Mapper: stage-wise seams ------------------------------------------------------ */
+
+/* Replaces the TS_obs_ selection of dataTransferring (esvo_Mapping.cpp:501-534) +
+ * DepthFrame setup (esvo_Mapping.cpp:268-272).  ts_left/ts_right: host mono8 W*H, or NULL
+ * to use the device-resident frames rendered last by esvo_ts_render. */
+int esvo_map_set_observation(esvo_handle h, uint64_t t_ns, const uint8_t* ts_left,
+                             const uint8_t* ts_right, const double T_world_cam[16]);
+/* Replaces EventBM::createMatchProblem + match_all_HyperThread (EventBM.cpp:56-78,269-315).
+ * pose_t_ns/pose_T: the st_map_ of esvo_Mapping.cpp:585-599 (m stamps, m row-major 4x4). */
+int esvo_map_match(esvo_handle h, const esvo_event_t* ev, size_t n, const uint64_t* pose_t_ns,
+                   const double* pose_T, size_t m, esvo_match_t* out, size_t cap, size_t* n_out);
+/* Replaces DepthProblemSolver::solve (+ pointCulling when cull != 0)
+ * (DepthProblemSolver.cpp:28-136,216-244).  Uses the pose table of the last esvo_map_match
+ * or esvo_map_set_poses call. */
+int esvo_map_set_poses(esvo_handle h, const uint64_t* pose_t_ns, const double* pose_T, size_t m);
+int esvo_map_refine(esvo_handle h, const esvo_match_t* matches, size_t n, int cull,
+                    esvo_depth_point_t* out, size_t cap, size_t* n_out);
+/* Replaces dqvDepthPoints_.push_back(vdp) + window policy (esvo_Mapping.cpp:341-368). */
+int esvo_map_push_frame(esvo_handle h, const esvo_depth_point_t* pts, size_t n,
+                        const double* pose_T, size_t m);
+/* Replaces the fusion loop + clean + regularisation (esvo_Mapping.cpp:370-395;
+ * DepthFusion.cpp:71-192; SmartGrid.h:222-243; DepthRegularization.cpp:19-110). */
+int esvo_map_fuse(esvo_handle h, size_t* n_fusions);
+
+/* ---- Mapper: fused tick (everything stays in HBM) ---------------------------------- */
+
+/* Replaces dataTransferring's event selection (esvo_Mapping.cpp:555-575) + MappingAtTime
+ * (esvo_Mapping.cpp:261-431) on the staged left events and the current observation. */
+int esvo_map_tick(esvo_handle h, uint64_t t_ns, const uint64_t* pose_t_ns, const double* pose_T,
+                  size_t m);
+
+/* ---- Outputs ------------------------------------------------------------------------ */
+
+/* DepthMap iteration (SmartGrid.h:346-358) as consumed by the publishers
+ * (esvo_Mapping.cpp:925-932).  Elements are returned in the reference's list order. */
+int esvo_map_get_depth_points(esvo_handle h, esvo_depth_point_t* out, size_t cap, size_t* n);
+/* Replaces the loop of publishPointCloud (esvo_Mapping.cpp:925-932): p_world = R p_cam + t
+ * as float32 xyz triples, the payload of /esvo_mapping/pointcloud_local. */
+int esvo_map_get_pointcloud_xyz(esvo_handle h, float* out_xyz, size_t cap_points, size_t* n);
+/* The newest frame of the fusion window (culled DepthPoints of the last tick). */
+int esvo_map_get_last_frame(esvo_handle h, esvo_depth_point_t* out, size_t cap, size_t* n);
+int esvo_get_stats(esvo_handle h, esvo_stats_t* out);
+
+/* ---- Multi-GPU row-band sharding ----------------------------------- */
+
+/* Restrict this handle's per-event work (match + refine) to events whose rectified row
+ * floor(y) lies in [row_begin,row_end) and its per-cell work (fuse/clean/regularise) to the
+ * same rows.  (0,H) = unsharded. */
+int esvo_shard_set_band(esvo_handle h, int row_begin, int row_end);
+/* Three-phase tick for sharded operation; the caller runs the collectives between phases on
+ * the buffers exposed by esvo_shard_buffers (torch.distributed / RCCL on the same stream):
+ *   phase 0: select + match (local band)            -> all-reduce(sum) match_flags
+ *   phase 1: order + refine + cull (local matches)  -> all-reduce(sum) point_flags, point_slots
+ *   phase 2: frame assembly + window + fuse + clean -> all-gather map band
+ *   phase 3: regularise own band                    -> all-gather map band (again) */
+typedef struct esvo_shard_buffers_t {
+  void* d_match_flags;  size_t match_flags_bytes;
+  void* d_point_flags;  size_t point_flags_bytes;
+  void* d_point_slots;  size_t point_slots_bytes;
+  void* d_map_cells;    size_t map_cells_bytes;   /* full map, row-major, band = contiguous rows */
+  size_t map_cell_stride;                         /* bytes per cell */
+} esvo_shard_buffers_t;
+int esvo_shard_buffers(esvo_handle h, esvo_shard_buffers_t* out);
+int esvo_shard_tick_phase(esvo_handle h, int phase, uint64_t t_ns, const uint64_t* pose_t_ns,
+                          const double* pose_T, size_t m);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ESVO_HIP_H */

@@ -1,0 +1,1284 @@
+// esvo_oracle.cpp — CPU oracle (TEST INFRASTRUCTURE ONLY; see esvo_oracle.h).
+//
+// A dependency-free, double-precision restatement of the ESVO reference hot path.  Every
+// function cites the reference file:line it follows (paths relative to the ESVO repository).
+// PARITY UNPINNED: the reference has no tests or golden vectors and cannot be built here; the
+// third-party pieces (Eigen LM / NumericalDiff, OpenCV image ops) are restated from their
+// published algorithms.
+//
+// Build: g++ -O2 -std=c++17 -ffp-contract=off -fPIC -shared   (see oracle/Makefile)
+// -ffp-contract=off matters: the GPU kernels are built the same way so that identical
+// expression sequences give identical IEEE-754 results.
+
+#include "esvo_oracle.h"
+
+#include <algorithm>
+#include <cassert>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <limits>
+#include <map>
+#include <thread>
+#include <vector>
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// ros::Time / ros::Duration arithmetic (roscpp time.h)
+// ---------------------------------------------------------------------------------------------
+inline double time_to_sec(uint32_t sec, uint32_t nsec) { return (double)sec + 1e-9 * (double)nsec; }
+inline double ns_to_sec(uint64_t ns) {
+  return time_to_sec((uint32_t)(ns / 1000000000ull), (uint32_t)(ns % 1000000000ull));
+}
+inline uint64_t ev_ns(const esvo_event_t& e) { return (uint64_t)e.sec * 1000000000ull + e.nsec; }
+inline double ev_sec(const esvo_event_t& e) { return time_to_sec(e.sec, e.nsec); }
+// ros::Time(double): TimeBase::fromSec
+inline uint64_t ros_time_from_sec(double t) {
+  int64_t sec64 = (int64_t)std::floor(t);
+  uint32_t sec = (uint32_t)sec64;
+  uint32_t nsec = (uint32_t)std::round((t - sec) * 1e9);
+  sec += (nsec / 1000000000ul);
+  nsec %= 1000000000ul;
+  return (uint64_t)sec * 1000000000ull + nsec;
+}
+// (T - t).toSec() for T > t: Duration{sec,nsec normalised}.toSec()
+inline double duration_to_sec(uint64_t later_ns, uint64_t earlier_ns) {
+  int64_t d = (int64_t)(later_ns - earlier_ns);
+  int64_t sec = d / 1000000000ll, nsec = d % 1000000000ll;
+  if (nsec < 0) { nsec += 1000000000ll; sec -= 1; }
+  return (double)sec + 1e-9 * (double)nsec;
+}
+
+// cvRound: round half to even (OpenCV uses lrint/SSE cvtsd2si under the default rounding mode)
+inline int cv_round(double v) { return (int)std::nearbyint(v); }
+inline int cv_round_f(float v) { return (int)std::nearbyintf(v); }
+// x*x stands for the reference's sq(x) (identical up to libm's last bit; the GPU uses x*x)
+inline double sq(double x) { return x * x; }
+inline uint8_t sat_u8(int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+
+// ---------------------------------------------------------------------------------------------
+// OpenCV image primitives
+// ---------------------------------------------------------------------------------------------
+void median3_u8(const uint8_t* src, uint8_t* dst, int w, int h) {
+  // cv::medianBlur(ksize=3): exact 3x3 median, BORDER_REPLICATE
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x) {
+      uint8_t v[9];
+      int k = 0;
+      for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+          int yy = std::min(std::max(y + dy, 0), h - 1);
+          int xx = std::min(std::max(x + dx, 0), w - 1);
+          v[k++] = src[yy * w + xx];
+        }
+      std::nth_element(v, v + 4, v + 9);
+      dst[y * w + x] = v[4];
+    }
+}
+
+void remap_bilinear_u8(const uint8_t* src, uint8_t* dst, int w, int h, const float* map_x,
+                       const float* map_y) {
+  // cv::remap(CV_8U, CV_32FC1 maps, INTER_LINEAR, BORDER_CONSTANT 0): coordinates quantised
+  // to 1/32 px (INTER_BITS=5), 15-bit fixed-point weights (INTER_REMAP_COEF_SCALE=32768).
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x) {
+      int i = y * w + x;
+      int sx = cv_round_f(map_x[i] * 32.f);
+      int sy = cv_round_f(map_y[i] * 32.f);
+      int ix = sx >> 5, iy = sy >> 5;
+      int fx = sx & 31, fy = sy & 31;
+      int w00 = (32 - fx) * (32 - fy) * 32, w01 = fx * (32 - fy) * 32;
+      int w10 = (32 - fx) * fy * 32, w11 = fx * fy * 32;
+      auto tap = [&](int xx, int yy) -> int {
+        return (xx >= 0 && xx < w && yy >= 0 && yy < h) ? src[yy * w + xx] : 0;
+      };
+      int v = w00 * tap(ix, iy) + w01 * tap(ix + 1, iy) + w10 * tap(ix, iy + 1) +
+              w11 * tap(ix + 1, iy + 1);
+      dst[i] = (uint8_t)((v + 16384) >> 15);
+    }
+}
+
+inline int reflect101(int p, int n) {
+  if (n == 1) return 0;
+  while (p < 0 || p >= n) {
+    if (p < 0) p = -p;
+    if (p >= n) p = 2 * (n - 1) - p;
+  }
+  return p;
+}
+
+void gaussian5_u8(const uint8_t* src, uint8_t* dst, int w, int h) {
+  // cv::GaussianBlur(8u, 5x5, sigma=0): separable [1 4 6 4 1]/16, BORDER_REFLECT_101; the
+  // oracle's documented choice for the version-dependent last bit: integer accumulate,
+  // (sum + 128) >> 8 once at the end.
+  static const int k[5] = {1, 4, 6, 4, 1};
+  std::vector<int> tmp((size_t)w * h);
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x) {
+      int s = 0;
+      for (int d = -2; d <= 2; ++d) s += k[d + 2] * src[y * w + reflect101(x + d, w)];
+      tmp[y * w + x] = s;
+    }
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x) {
+      int s = 0;
+      for (int d = -2; d <= 2; ++d) s += k[d + 2] * tmp[reflect101(y + d, h) * w + x];
+      dst[y * w + x] = sat_u8((s + 128) >> 8);
+    }
+}
+
+}  // namespace
+
+// =============================================================================================
+// Time Surface (esvo_time_surface/)
+// =============================================================================================
+struct orc_ts {
+  int W, H, qlen;
+  std::vector<std::deque<esvo_event_t>> q;  // EventQueueMat::eqMat_, TimeSurface.h:95
+};
+
+extern "C" orc_ts_handle orc_ts_create(int width, int height, int queue_len) {
+  orc_ts* t = new orc_ts();
+  t->W = width; t->H = height; t->qlen = queue_len;
+  t->q.assign((size_t)width * height, {});
+  return t;
+}
+extern "C" void orc_ts_destroy(orc_ts_handle h) { delete h; }
+extern "C" void orc_ts_clear(orc_ts_handle h) { h->q.assign((size_t)h->W * h->H, {}); }
+
+extern "C" void orc_ts_push(orc_ts_handle h, const esvo_event_t* ev, size_t n) {
+  // TimeSurface::eventsCallback (TimeSurface.cpp:403-425) for time-sorted input (Appendix A-1:
+  // the global insertion sort is the identity then) + EventQueueMat::insertEvent
+  // (TimeSurface.h:39-50): bounds check, push_back, trim the per-pixel queue to qlen.
+  for (size_t i = 0; i < n; ++i) {
+    const esvo_event_t& e = ev[i];
+    if (e.x >= h->W || e.y >= h->H) continue;
+    auto& eq = h->q[(size_t)e.x + (size_t)h->W * e.y];
+    eq.push_back(e);
+    while ((int)eq.size() > h->qlen) eq.pop_front();
+  }
+}
+
+extern "C" void orc_ts_render(orc_ts_handle h, uint64_t t_ns, double decay_ms, int ignore_polarity,
+                              int median_blur_kernel_size, const float* map_x, const float* map_y,
+                              uint8_t* out, uint8_t* out_prefilter) {
+  // TimeSurface::createTimeSurfaceAtTime, TimeSurface.cpp:52-152, BACKWARD mode
+  const int W = h->W, H = h->H;
+  const double decay_sec = decay_ms / 1000.0;  // :60
+  std::vector<double> ts((size_t)W * H, 0.0);  // :62
+  for (int y = 0; y < H; ++y)
+    for (int x = 0; x < W; ++x) {
+      // EventQueueMat::getMostRecentEventBeforeT, TimeSurface.h:52-75: reverse scan, strict <
+      const auto& eq = h->q[(size_t)x + (size_t)W * y];
+      const esvo_event_t* found = nullptr;
+      for (auto it = eq.rbegin(); it != eq.rend(); ++it)
+        if (ev_ns(*it) < t_ns) { found = &*it; break; }
+      if (!found) continue;
+      if (!(ev_sec(*found) > 0)) continue;  // :73
+      const double dt = duration_to_sec(t_ns, ev_ns(*found));  // :75
+      double polarity = found->polarity ? 1.0 : -1.0;          // :76
+      double expVal = std::exp(-dt / decay_sec);               // :77
+      if (!ignore_polarity) expVal *= polarity;                // :78-79
+      ts[(size_t)y * W + x] = expVal;                          // :83
+    }
+  std::vector<uint8_t> img((size_t)W * H), med((size_t)W * H);
+  for (size_t i = 0; i < ts.size(); ++i) {
+    double v = ignore_polarity ? 255.0 * ts[i] : 255.0 * (ts[i] + 1.0) / 2.0;  // :123-126
+    img[i] = sat_u8(cv_round(v));                                               // :127 convertTo
+  }
+  if (out_prefilter) std::memcpy(out_prefilter, img.data(), img.size());
+  const uint8_t* cur = img.data();
+  if (median_blur_kernel_size > 0) {  // :130-131 (kernel 2k+1; only k=1 shipped)
+    median3_u8(img.data(), med.data(), W, H);
+    cur = med.data();
+  }
+  if (map_x && map_y)
+    remap_bilinear_u8(cur, out, W, H, map_x, map_y);  // :149
+  else
+    std::memcpy(out, cur, (size_t)W * H);
+}
+
+extern "C" void orc_median3_u8(const uint8_t* s, uint8_t* d, int w, int h) { median3_u8(s, d, w, h); }
+extern "C" void orc_remap_bilinear_u8(const uint8_t* s, uint8_t* d, int w, int h, const float* mx,
+                                      const float* my) { remap_bilinear_u8(s, d, w, h, mx, my); }
+extern "C" void orc_gaussian5_u8(const uint8_t* s, uint8_t* d, int w, int h) { gaussian5_u8(s, d, w, h); }
+
+// =============================================================================================
+// Mapper (esvo_core/)
+// =============================================================================================
+namespace {
+
+struct Mat4 { double m[16]; };
+
+inline Mat4 mat4_mul(const Mat4& a, const Mat4& b) {
+  Mat4 c;
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j)
+      c.m[i * 4 + j] = ((a.m[i * 4 + 0] * b.m[0 * 4 + j] + a.m[i * 4 + 1] * b.m[1 * 4 + j]) +
+                        a.m[i * 4 + 2] * b.m[2 * 4 + j]) + a.m[i * 4 + 3] * b.m[3 * 4 + j];
+  return c;
+}
+// kindr QuatTransformation::inverse(): rigid inverse [R^T | -R^T t]
+inline Mat4 rigid_inverse(const Mat4& a) {
+  Mat4 c;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) c.m[i * 4 + j] = a.m[j * 4 + i];
+  for (int i = 0; i < 3; ++i)
+    c.m[i * 4 + 3] = -((c.m[i * 4 + 0] * a.m[3] + c.m[i * 4 + 1] * a.m[7]) + c.m[i * 4 + 2] * a.m[11]);
+  c.m[12] = c.m[13] = c.m[14] = 0.0; c.m[15] = 1.0;
+  return c;
+}
+
+// PerspectiveCamera (CameraSystem.cpp:114-148)
+struct Camera {
+  int W = 0, H = 0;
+  double P[12];
+  double Kinv[9];   // inverse of P[:, :3]
+  double Kinv_t[3]; // Kinv * P[:, 3]
+  std::vector<float> lut;     // 2*W*H
+  std::vector<uint8_t> mask;  // W*H
+  void init(const esvo_calib_t* c) {
+    W = c->width; H = c->height;
+    std::memcpy(P, c->P, sizeof(P));
+    const double a = P[0], b = P[1], cc = P[2], d = P[4], e = P[5], f = P[6], g = P[8], hh = P[9], i = P[10];
+    const double det = a * (e * i - f * hh) - b * (d * i - f * g) + cc * (d * hh - e * g);
+    const double id = 1.0 / det;
+    Kinv[0] = (e * i - f * hh) * id; Kinv[1] = (cc * hh - b * i) * id; Kinv[2] = (b * f - cc * e) * id;
+    Kinv[3] = (f * g - d * i) * id;  Kinv[4] = (a * i - cc * g) * id;  Kinv[5] = (cc * d - a * f) * id;
+    Kinv[6] = (d * hh - e * g) * id; Kinv[7] = (b * g - a * hh) * id;  Kinv[8] = (a * e - b * d) * id;
+    for (int r = 0; r < 3; ++r)
+      Kinv_t[r] = (Kinv[r * 3 + 0] * P[3] + Kinv[r * 3 + 1] * P[7]) + Kinv[r * 3 + 2] * P[11];
+    if (c->rect_lut) lut.assign(c->rect_lut, c->rect_lut + (size_t)2 * W * H);
+    if (c->rect_mask) mask.assign(c->rect_mask, c->rect_mask + (size_t)W * H);
+  }
+  // cam2World (CameraSystem.cpp:121-139).  The reference inverts the 4x4 [P; 0 0 0 z] per call;
+  // the oracle (and the GPU) use the algebraically identical closed form
+  //   p = z * K'^-1 [u v 1]^T - K'^-1 P[:,3]
+  void cam2World(const double x[2], double invDepth, double p[3]) const {
+    const double z = 1.0 / invDepth;
+    for (int r = 0; r < 3; ++r) {
+      const double ray = (Kinv[r * 3 + 0] * x[0] + Kinv[r * 3 + 1] * x[1]) + Kinv[r * 3 + 2];
+      p[r] = z * ray - Kinv_t[r];
+    }
+  }
+  // world2Cam (CameraSystem.cpp:142-148)
+  void world2Cam(const double p[3], double x[2]) const {
+    double hmg[3];
+    for (int r = 0; r < 3; ++r)
+      hmg[r] = ((P[r * 4 + 0] * p[0] + P[r * 4 + 1] * p[1]) + P[r * 4 + 2] * p[2]) + P[r * 4 + 3];
+    x[0] = hmg[0] / hmg[2];
+    x[1] = hmg[1] / hmg[2];
+  }
+};
+
+// DepthPoint (DepthPoint.h:70-88, DepthPoint.cpp)
+struct DP {
+  size_t row = 0, col = 0;
+  double x[2] = {0.5, 0.5};
+  double invDepth = -1.0, scale2 = 0.0, nu = 0.0, variance = 0.0, residual = 0.0;
+  size_t age = 0;
+  double p_cam[3] = {0, 0, 0};
+  uint32_t pose_idx = 0;
+  DP() {}
+  DP(size_t r, size_t c) : row(r), col(c) { x[0] = c + 0.5; x[1] = r + 0.5; }
+  // DepthPoint::update_studentT, DepthPoint.cpp:167-188
+  void update_studentT(double invD, double s2, double var, double nu_in) {
+    if (invDepth > -1e-6) {
+      double nu_update = std::min(nu_in, nu);
+      double invDepth_update = (s2 * invDepth + scale2 * invD) / (scale2 + s2);
+      double scale2_update = (nu_update + sq(invDepth - invD) / (scale2 + s2)) /
+                             (nu_update + 1) * (scale2 * s2) / (scale2 + s2);
+      invDepth = invDepth_update;
+      scale2 = scale2_update;
+      nu = nu_update + 1;
+      variance = nu / (nu - 2) * scale2;
+      age++;
+    } else {
+      invDepth = invD; scale2 = s2; variance = var; nu = nu_in;
+    }
+  }
+  bool valid() const { return invDepth > -1e-6; }  // DepthPoint.cpp:215-218
+  bool valid(double var_thr, double age_thr, double dmax, double dmin) const {  // :221-230
+    return invDepth > -1e-6 && (double)age >= age_thr && variance <= var_thr && invDepth <= dmax &&
+           invDepth >= dmin;
+  }
+  // DepthPoint::copy (DepthPoint.cpp:233-245): everything except row/col
+  void copy_from(const DP& o) {
+    invDepth = o.invDepth; variance = o.variance; scale2 = o.scale2; nu = o.nu;
+    x[0] = o.x[0]; x[1] = o.x[1];
+    p_cam[0] = o.p_cam[0]; p_cam[1] = o.p_cam[1]; p_cam[2] = o.p_cam[2];
+    pose_idx = o.pose_idx; residual = o.residual; age = o.age;
+  }
+};
+
+// SmartGrid<DepthPoint> (SmartGrid.h).  std::list is emulated by a vector + alive flags +
+// creation order; the pointer grid by int indices.  A cell whose element was erased reads as
+// empty (the oracle's definition for the dangling pointer of Appendix A-7).
+struct Grid {
+  int W = 0, H = 0;
+  std::vector<DP> elems;
+  std::vector<char> alive;
+  std::vector<int> grid;  // -1 = NULL
+  void init(int w, int h) { W = w; H = h; elems.clear(); alive.clear(); grid.assign((size_t)w * h, -1); }
+  bool exists(size_t r, size_t c) const { return grid[r * W + c] >= 0; }  // SmartGrid.h:318-325
+  DP& get(size_t r, size_t c) { return elems[grid[r * W + c]]; }
+  void set(size_t r, size_t c, const DP& v) {  // SmartGrid.h:306-316
+    if (grid[r * W + c] < 0) {
+      elems.push_back(DP(r, c));
+      alive.push_back(1);
+      grid[r * W + c] = (int)elems.size() - 1;
+    }
+    elems[grid[r * W + c]].copy_from(v);
+  }
+  size_t size() const { size_t n = 0; for (char a : alive) n += a; return n; }
+  // SmartGrid::clean, SmartGrid.h:222-243
+  void clean(double var_thr, double age_thr, double dmax, double dmin) {
+    for (size_t i = 0; i < elems.size(); ++i) {
+      if (!alive[i]) continue;
+      if (!elems[i].valid(var_thr, age_thr, dmax, dmin)) {
+        grid[elems[i].row * W + elems[i].col] = -1;  // the cell the element BELIEVES it is in
+        alive[i] = 0;
+      }
+    }
+    // resolve dangling pointers: any grid entry that points to an erased element is empty
+    for (auto& g : grid) if (g >= 0 && !alive[g]) g = -1;
+  }
+  // SmartGrid::getNeighbourhood, SmartGrid.h:367-386.  NOTE the loop bounds mix int and
+  // size_t: `for (int r = row - radius; r <= row + radius; r++)` compares r converted to
+  // size_t, so for row < radius (r negative) the row loop body never runs, and likewise the
+  // column loop for col < radius.  Pixels within `radius` of the top/left border therefore get
+  // NO neighbours.  Reproduced literally.
+  void neighbourhood(size_t row, size_t col, size_t radius, std::vector<const DP*>& out) const {
+    out.clear();
+    for (int r = (int)(row - radius); (size_t)(int64_t)r <= row + radius; r++) {
+      for (int c = (int)(col - radius); (size_t)(int64_t)c <= col + radius; c++) {
+        if (r >= 0 && r < H && c >= 0 && c < W) {
+          int g = grid[(size_t)r * W + c];
+          if (g >= 0 && elems[g].valid()) out.push_back(&elems[g]);
+        }
+      }
+    }
+  }
+};
+
+struct Frame {
+  std::vector<DP> pts;
+  std::vector<Mat4> poses;  // T_world_cam table, indexed by DP::pose_idx
+};
+
+}  // namespace
+
+struct orc_mapper {
+  esvo_params_t prm;
+  Camera camL, camR;
+  double baseline = 0;
+  int real_threads = 1;
+  // observation
+  uint64_t obs_t_ns = 0;
+  std::vector<double> tsL, tsR;  // row-major W*H doubles 0..255 (TimeSurfaceObservation.h:68-69)
+  Mat4 T_world_obs;
+  // pose table (st_map_)
+  std::vector<uint64_t> pose_t;
+  std::vector<Mat4> pose_T;
+  // window + map
+  std::deque<Frame> window;  // dqvDepthPoints_
+  Grid map;
+  Mat4 T_world_frame;
+  // counters
+  uint64_t n_replace = 0, n_replace_displaced = 0, max_scale_iters = 0, n_evals = 0;
+
+  int W() const { return camL.W; }
+  int H() const { return camL.H; }
+};
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// EventBM (EventBM.cpp)
+// ---------------------------------------------------------------------------------------------
+// tools::meanStdDev + normalizePatch (utils.h:74-92) on a wy x wx patch stored row-major.
+// Eigen's MatrixXd is column-major and .sum() is a (vectorised) reduction whose order is not
+// specified; the oracle sums in Eigen's storage order (column-major, sequential).
+void normalize_patch(const double* p, int wx, int wy, double* out) {
+  const size_t n = (size_t)wx * wy;
+  double sum = 0;
+  for (int x = 0; x < wx; ++x) for (int y = 0; y < wy; ++y) sum += p[y * wx + x];
+  const double mean = sum / n;
+  double ss = 0;
+  for (int x = 0; x < wx; ++x) for (int y = 0; y < wy; ++y) { double s = p[y * wx + x] - mean; ss += s * s; }
+  const double sigma = std::sqrt(ss / n) + 1e-6;
+  for (size_t i = 0; i < n; ++i) out[i] = (p[i] - mean) / sigma;
+}
+// EventBM::zncc_cost, EventBM.cpp:317-333 (normalized == false)
+double zncc_cost(const double* l, const double* r, int wx, int wy, double* tmpl, double* tmpr) {
+  normalize_patch(l, wx, wy, tmpl);
+  normalize_patch(r, wx, wy, tmpr);
+  double s = 0;
+  for (int x = 0; x < wx; ++x) for (int y = 0; y < wy; ++y) s += tmpl[y * wx + x] * tmpr[y * wx + x];
+  return 0.5 * (1 - s / ((double)wy * wx));
+}
+// The same quantity from exact integer moments (TS values are integers 0..255): used by the
+// GPU kernel; exposed through orc_mapper_match_costs(exact_int=1) to bound the difference.
+//   sum((l-ml)(r-mr)) = Slr - Sl*Sr/N ;  sigma = sqrt(Sxx/N - (Sx/N)^2) + 1e-6
+double zncc_cost_int(int64_t Sl, int64_t Sll, int64_t Sr, int64_t Srr, int64_t Slr, int N) {
+  const double n = (double)N;
+  const double varl = (double)(N * Sll - Sl * Sl) / (n * n);
+  const double varr = (double)(N * Srr - Sr * Sr) / (n * n);
+  const double sigl = std::sqrt(varl) + 1e-6, sigr = std::sqrt(varr) + 1e-6;
+  const double cov = (double)(N * Slr - Sl * Sr) / n;  // = sum((l-ml)(r-mr))
+  return 0.5 * (1 - cov / (sigl * sigr) / n);
+}
+
+struct BM {
+  const orc_mapper* M;
+  int wx, wy, W, H;
+  // EventBM::isValidPatch, EventBM.cpp:251-267
+  bool isValidPatch(int x, int y, int& ltx, int& lty) const {
+    int hx = (wx - 1) / 2, hy = (wy - 1) / 2;
+    ltx = x - hx; lty = y - hy;
+    int rbx = x + hx, rby = y + hy;
+    if (ltx < 1 || lty < 1 || rbx >= W - 1 || rby >= H - 1) return false;
+    return true;
+  }
+  void block(const std::vector<double>& img, int ltx, int lty, double* out) const {
+    for (int y = 0; y < wy; ++y)
+      for (int x = 0; x < wx; ++x) out[y * wx + x] = img[(size_t)(lty + y) * W + (ltx + x)];
+  }
+  // EventBM::epipolarSearching, EventBM.cpp:170-226
+  bool epipolarSearching(double& min_cost, int& bestX, int& bestY, size_t& bestDisp, size_t start,
+                         size_t end, size_t step, int x1x, int x1y, const double* patch_src,
+                         double* all_costs /*nullable*/, int exact_int) const {
+    bool found = false;
+    std::map<size_t, double> mDispCost;
+    std::vector<double> patch_dst((size_t)wx * wy), t1((size_t)wx * wy), t2((size_t)wx * wy);
+    const double ZNCC_MAX = 1.0, thr = M->prm.bm_zncc_threshold;
+    for (size_t disp = start; disp <= end; disp += step) {
+      int x2x = (int)((size_t)x1x - disp), x2y = x1y;  // bUpDownConfiguration == false
+      int ltx, lty;
+      if (!isValidPatch(x2x, x2y, ltx, lty)) {
+        mDispCost.emplace(disp, ZNCC_MAX);
+        if (all_costs) all_costs[disp - start] = ZNCC_MAX;
+        continue;
+      }
+      block(M->tsR, ltx, lty, patch_dst.data());
+      double cost;
+      if (!exact_int) {
+        cost = zncc_cost(patch_src, patch_dst.data(), wx, wy, t1.data(), t2.data());
+      } else {
+        int64_t Sl = 0, Sll = 0, Sr = 0, Srr = 0, Slr = 0;
+        for (int i = 0; i < wx * wy; ++i) {
+          int64_t l = (int64_t)patch_src[i], r = (int64_t)patch_dst[i];
+          Sl += l; Sll += l * l; Sr += r; Srr += r * r; Slr += l * r;
+        }
+        cost = zncc_cost_int(Sl, Sll, Sr, Srr, Slr, wx * wy);
+      }
+      mDispCost.emplace(disp, cost);
+      if (all_costs) all_costs[disp - start] = cost;
+      if (cost <= min_cost) { min_cost = cost; bestX = x2x; bestY = x2y; bestDisp = disp; }
+    }
+    if (step > 1) {  // coarse
+      if (mDispCost.find(bestDisp - step) != mDispCost.end() &&
+          mDispCost.find(bestDisp + step) != mDispCost.end()) {
+        if (mDispCost[bestDisp - step] < ZNCC_MAX && mDispCost[bestDisp + step] < ZNCC_MAX)
+          if (min_cost < thr) found = true;
+      }
+    } else {
+      if (min_cost < thr) found = true;
+    }
+    return found;
+  }
+  // EventBM::match_an_event, EventBM.cpp:80-168
+  bool match_an_event(const esvo_event_t& e, uint32_t event_idx, esvo_match_t& out,
+                      double* all_costs = nullptr, int exact_int = 0) const {
+    const Camera& cam = M->camL;
+    if (e.x >= W || e.y >= H) return false;  // (the reference would index out of bounds)
+    const size_t li = ((size_t)e.y * W + e.x) * 2;
+    const double xr[2] = {(double)cam.lut[li], (double)cam.lut[li + 1]};  // :88
+    if (xr[0] < 0 || xr[0] > (double)(W - 1) || xr[1] < 0 || xr[1] > (double)(H - 1)) return false;  // :90-92
+    if (!cam.mask.empty() && cam.mask[(size_t)((long)xr[1]) * W + (size_t)((long)xr[0])] <= 125) return false;  // :94 (truncation)
+    const int x1x = (int)std::floor(xr[0]), x1y = (int)std::floor(xr[1]);  // :96
+    int ltx, lty;
+    if (!isValidPatch(x1x, x1y, ltx, lty)) return false;  // :98
+    std::vector<double> patch_src((size_t)wx * wy);
+    block(M->tsL, ltx, lty, patch_src.data());  // :101
+    size_t cnt = 0;
+    for (double v : patch_src) cnt += (v < 1);
+    if ((double)cnt > 0.95 * (double)patch_src.size()) return false;  // :104-109
+    double min_cost = 1.0;
+    int bx = 0, by = 0;
+    size_t bestDisp = 0;
+    bool any = false;
+    const size_t lo = (size_t)M->prm.bm_min_disparity, hi = (size_t)M->prm.bm_max_disparity;
+    const size_t step = (size_t)M->prm.bm_step;
+    // coarse :119-126
+    {
+      // (bestDisp is uninitialised in the reference if no candidate is valid; then min_cost
+      //  stays 1.0 and the search fails for step==1.  For step>1 the oracle also fails.)
+      size_t bd = (size_t)-1;
+      double mc = min_cost;
+      if (!epipolarSearching(mc, bx, by, bd, lo, hi, step, x1x, x1y, patch_src.data(), all_costs, exact_int))
+        return false;
+      min_cost = mc; bestDisp = bd; any = true;
+    }
+    (void)any;
+    // fine :128-138   (size_t arithmetic; `>= 0` is always true, Appendix A-9)
+    size_t fine_start = bestDisp - (step - 1);
+    if (!epipolarSearching(min_cost, bx, by, bestDisp, fine_start, bestDisp + (step - 1), 1, x1x, x1y,
+                           patch_src.data(), nullptr, exact_int))
+      return false;
+    if (min_cost <= M->prm.bm_zncc_threshold) {  // :141
+      const double disparity = (double)(x1x - bx);            // :151
+      const double depth = M->baseline * cam.P[0] / disparity;  // :152
+      // StampTransformationMap_lower_bound (utils.h:66-71): first stamp with toSec >= event toSec
+      const double te = ev_sec(e);
+      size_t k = 0;
+      {
+        size_t lo_i = 0, hi_i = M->pose_t.size();
+        while (lo_i < hi_i) {
+          size_t mid = (lo_i + hi_i) / 2;
+          if (ns_to_sec(M->pose_t[mid]) < te) lo_i = mid + 1; else hi_i = mid;
+        }
+        k = lo_i;
+      }
+      if (k == M->pose_t.size()) return false;  // :155-156
+      out.x_left[0] = xr[0]; out.x_left[1] = xr[1];
+      out.inv_depth = 1.0 / depth;  // :158
+      out.cost = min_cost;
+      out.disp = disparity;
+      out.event_idx = event_idx;
+      out.pose_idx = (uint32_t)k;
+      return true;
+    }
+    return false;
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// DepthProblem (DepthProblem.cpp) — the residual functor
+// ---------------------------------------------------------------------------------------------
+struct DepthProblem {
+  orc_mapper* M;
+  int wx, wy;
+  double coor[2];
+  double T_left_virtual[12];  // 3x4
+
+  // DepthProblem::setProblem, DepthProblem.cpp:17-32
+  void setProblem(const double c[2], const Mat4& T_world_virtual) {
+    coor[0] = c[0]; coor[1] = c[1];
+    Mat4 T_left_world = rigid_inverse(M->T_world_obs);
+    Mat4 T = mat4_mul(T_left_world, T_world_virtual);
+    std::memcpy(T_left_virtual, T.m, sizeof(T_left_virtual));
+  }
+  // DepthProblem::warping, DepthProblem.cpp:162-191
+  bool warping(double d, double x1[2], double x2[2]) const {
+    double p_rv[3];
+    M->camL.cam2World(coor, d, p_rv);
+    double pl[3];
+    for (int r = 0; r < 3; ++r)
+      pl[r] = ((T_left_virtual[r * 4 + 0] * p_rv[0] + T_left_virtual[r * 4 + 1] * p_rv[1]) +
+               T_left_virtual[r * 4 + 2] * p_rv[2]) + T_left_virtual[r * 4 + 3];
+    M->camL.world2Cam(pl, x1);
+    M->camR.world2Cam(pl, x2);
+    const int W = M->W(), H = M->H();
+    const int hx = (wx - 1) / 2, hy = (wy - 1) / 2;
+    // oracle definition for non-finite coordinates (UB in the reference): warping fails
+    if (!std::isfinite(x1[0]) || !std::isfinite(x1[1]) || !std::isfinite(x2[0]) || !std::isfinite(x2[1]))
+      return false;
+    if (x1[0] < hx || x1[0] > W - hx || x1[1] < hy || x1[1] > H - hy) return false;
+    if (x2[0] < hx || x2[0] > W - hx || x2[1] < hy || x2[1] > H - hy) return false;
+    return true;
+  }
+  // DepthProblem::patchInterpolation, DepthProblem.cpp:193-262
+  bool patchInterpolation(const std::vector<double>& img, const double loc[2], double* patch) const {
+    const int W = M->W(), H = M->H();
+    const int ulx = (int)std::floor(loc[0]) - (wx - 1) / 2, uly = (int)std::floor(loc[1]) - (wy - 1) / 2;
+    const int drx = (int)std::floor(loc[0]) + (wx - 1) / 2, dry = (int)std::floor(loc[1]) + (wy - 1) / 2;
+    if (ulx < 0 || uly < 0) return false;
+    if (drx >= W || dry >= H) return false;
+    const double di0 = loc[1], di1 = loc[0];
+    const int l0 = (int)std::floor(di0), l1 = (int)std::floor(di1);
+    const int u0 = l0 + 1, u1 = l1 + 1;
+    const double q1 = u1 - di1, q2 = di1 - l1, q3 = u0 - di0, q4 = di0 - l0;
+    if (uly + wy >= H || ulx + wx >= W) return false;
+    // R = q1*Src[:, 0:wx] + q2*Src[:, 1:wx+1]   ((wy+1) x wx);  F = q3*R[0:wy] + q4*R[1:wy+1]
+    std::vector<double> R((size_t)(wy + 1) * wx);
+    for (int y = 0; y <= wy; ++y)
+      for (int x = 0; x < wx; ++x)
+        R[y * wx + x] = q1 * img[(size_t)(uly + y) * W + ulx + x] + q2 * img[(size_t)(uly + y) * W + ulx + x + 1];
+    for (int y = 0; y < wy; ++y)
+      for (int x = 0; x < wx; ++x) patch[y * wx + x] = q3 * R[y * wx + x] + q4 * R[(y + 1) * wx + x];
+    return true;
+  }
+  // DepthProblem::operator(), DepthProblem.cpp:34-160, LSnorm == "Tdist"
+  int operator()(double x, double* fvec) const {
+    M->n_evals++;
+    const int N = wx * wy;
+    const double nu = M->prm.td_nu, scale = M->prm.td_scale;
+    auto fail_fill = [&]() {
+      for (int i = 0; i < N; ++i) {
+        double residual = 255;
+        double weight = (nu + 1) / (nu + sq(residual / scale));
+        fvec[i] = std::sqrt(weight) * residual;
+      }
+    };
+    double x1[2], x2[2];
+    if (!warping(x, x1, x2)) { fail_fill(); return 0; }
+    std::vector<double> tau1(N), tau2(N);
+    if (patchInterpolation(M->tsL, x1, tau1.data()) && patchInterpolation(M->tsR, x2, tau2.data())) {
+      std::vector<double> vR(N), vR2(N);
+      const double scale2_0 = sq(scale);  // td_scaleSquared_
+      double s1 = scale2_0, s2 = -1.0;
+      bool first = true;
+      uint64_t iters = 0;
+      while (std::fabs(s2 - s1) / s1 > 0.05 || first) {  // :96
+        if (!first) s1 = s2;
+        double sum = 0;
+        for (int i = 0; i < N; ++i) {  // y-major then x == index order
+          if (first) { vR[i] = tau1[i] - tau2[i]; vR2[i] = sq(vR[i]); }
+          if (vR[i] != 0) sum += vR2[i] * (nu + 1) / (nu + vR2[i] / s1);
+        }
+        if (sum == 0) { s2 = scale2_0; break; }
+        s2 = sum / N;
+        first = false;
+        ++iters;
+      }
+      if (iters > M->max_scale_iters) M->max_scale_iters = iters;
+      for (int i = 0; i < N; ++i) {
+        double weight = (nu + 1) / (nu + vR2[i] / s2);
+        fvec[i] = std::sqrt(weight) * vR[i];
+      }
+      return 1;
+    }
+    fail_fill();
+    return 0;
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Eigen::LevenbergMarquardt<NumericalDiff<DepthProblem>> for n = 1
+// ---------------------------------------------------------------------------------------------
+struct LM1 {
+  const DepthProblem& F;
+  int m;
+  // parameters (resetParameters() + the reference's overrides, DepthProblemSolver.cpp:147-150)
+  double factor = 100., ftol, xtol, gtol = 0., epsfcn = 0.;
+  int maxfev;
+  // state
+  std::vector<double> fvec, fjac, wa4, val2;
+  double diag = 0, qtf = 0, r = 0;  // r = R(0,0) of the QR of the m x 1 Jacobian (|r| = ||J||)
+  double par = 0, fnorm = 0, gnorm = 0, xnorm = 0, delta = 0;
+  int nfev = 0, iter = 0;
+  LM1(const DepthProblem& f, int m_, double ftol_, double xtol_, int maxfev_)
+      : F(f), m(m_), ftol(ftol_), xtol(xtol_), maxfev(maxfev_), fvec(m_), fjac(m_), wa4(m_), val2(m_) {}
+
+  static double norm(const double* v, int n) { double s = 0; for (int i = 0; i < n; ++i) s += v[i] * v[i]; return std::sqrt(s); }
+
+  int minimizeInit(double& x) {
+    nfev = 1;
+    F(x, fvec.data());
+    fnorm = norm(fvec.data(), m);
+    par = 0.; iter = 1;
+    return -2;  // NotStarted
+  }
+  // internal::lmpar2 for n == 1
+  void lmpar2(double& x_out) {
+    const double dwarf = std::numeric_limits<double>::min();
+    double x = qtf / r;  // Gauss-Newton direction (rank == 1; r != 0 guaranteed by the caller)
+    double wa2 = diag * x;
+    double dxnorm = std::fabs(wa2);
+    double fp = dxnorm - delta;
+    if (fp <= 0.1 * delta) { par = 0; x_out = x; return; }
+    double wa1 = diag * wa2 / dxnorm;
+    wa1 = wa1 / r;
+    double temp = std::fabs(wa1);
+    double parl = fp / delta / temp / temp;
+    wa1 = r * qtf / diag;
+    double gn = std::fabs(wa1);
+    double paru = gn / delta;
+    if (paru == 0.) paru = dwarf / std::min(delta, 0.1);
+    par = std::max(par, parl);
+    par = std::min(par, paru);
+    if (par == 0.) par = gn / dxnorm;
+    int it = 0;
+    while (true) {
+      ++it;
+      if (par == 0.) par = std::max(dwarf, 0.001 * paru);
+      const double ds = std::sqrt(par) * diag;
+      // qrsolv, n == 1: one Givens rotation eliminates ds against r
+      const double sdiag2 = r * r + ds * ds;
+      const double sdiag = std::sqrt(sdiag2);
+      x = r * qtf / sdiag2;
+      wa2 = diag * x;
+      dxnorm = std::fabs(wa2);
+      temp = fp;
+      fp = dxnorm - delta;
+      if (std::fabs(fp) <= 0.1 * delta || (parl == 0. && fp <= temp && temp < 0.) || it == 10) break;
+      wa1 = diag * (wa2 / dxnorm);
+      wa1 = wa1 / sdiag;
+      temp = std::fabs(wa1);
+      const double parc = fp / delta / temp / temp;
+      if (fp > 0.) parl = std::max(parl, par);
+      if (fp < 0.) paru = std::min(paru, par);
+      par = std::max(parl, par + parc);
+    }
+    x_out = x;
+  }
+  int minimizeOneStep(double& x) {
+    // NumericalDiff<Forward>::df: 2 evaluations
+    {
+      const double eps = std::sqrt(std::max(epsfcn, std::numeric_limits<double>::epsilon()));
+      F(x, wa4.data());  // val1 (== fvec numerically; re-evaluated as Eigen does)
+      double h = eps * std::fabs(x);
+      if (h == 0.) h = eps;
+      F(x + h, val2.data());
+      for (int i = 0; i < m; ++i) fjac[i] = (val2[i] - wa4[i]) / h;
+      nfev += 2;
+    }
+    const double wa2n = norm(fjac.data(), m);  // column norm
+    double jtf = 0;
+    for (int i = 0; i < m; ++i) jtf += fjac[i] * fvec[i];
+    r = wa2n;  // sign convention: +||J|| (results are sign-invariant)
+    qtf = (r != 0.) ? jtf / r : fvec[0];
+    if (iter == 1) {
+      diag = (wa2n == 0.) ? 1. : wa2n;
+      xnorm = std::fabs(diag * x);
+      delta = factor * xnorm;
+      if (delta == 0.) delta = factor;
+    }
+    gnorm = 0.;
+    if (fnorm != 0.)
+      if (wa2n != 0.) gnorm = std::max(gnorm, std::fabs(r * (qtf / fnorm) / wa2n));
+    if (gnorm <= gtol) return 4;  // CosinusTooSmall
+    diag = std::max(diag, wa2n);
+    double ratio;
+    do {
+      double p;
+      lmpar2(p);
+      const double wa1 = -p;
+      const double xnew = x + wa1;
+      const double pnorm = std::fabs(diag * wa1);
+      if (iter == 1) delta = std::min(delta, pnorm);
+      F(xnew, wa4.data());
+      ++nfev;
+      const double fnorm1 = norm(wa4.data(), m);
+      double actred = -1.;
+      if (0.1 * fnorm1 < fnorm) actred = 1. - (fnorm1 / fnorm) * (fnorm1 / fnorm);
+      const double wa3 = r * wa1;
+      const double t1 = std::fabs(wa3) / fnorm, temp1 = t1 * t1;
+      const double t2 = std::sqrt(par) * pnorm / fnorm, temp2 = t2 * t2;
+      const double prered = temp1 + temp2 / 0.5;
+      const double dirder = -(temp1 + temp2);
+      ratio = 0.;
+      if (prered != 0.) ratio = actred / prered;
+      if (ratio <= 0.25) {
+        double temp = 0.5;
+        if (actred >= 0.) temp = 0.5;
+        if (actred < 0.) temp = 0.5 * dirder / (dirder + 0.5 * actred);
+        if (0.1 * fnorm1 >= fnorm || temp < 0.1) temp = 0.1;
+        delta = temp * std::min(delta, pnorm / 0.1);
+        par /= temp;
+      } else if (!(par != 0. && ratio < 0.75)) {
+        delta = pnorm / 0.5;
+        par = 0.5 * par;
+      }
+      if (ratio >= 1e-4) {
+        x = xnew;
+        fvec.swap(wa4);
+        xnorm = std::fabs(diag * x);
+        fnorm = fnorm1;
+        ++iter;
+      }
+      const double eps = std::numeric_limits<double>::epsilon();
+      if (std::fabs(actred) <= ftol && prered <= ftol && 0.5 * ratio <= 1. && delta <= xtol * xnorm) return 3;
+      if (std::fabs(actred) <= ftol && prered <= ftol && 0.5 * ratio <= 1.) return 1;
+      if (delta <= xtol * xnorm) return 2;
+      if (nfev >= maxfev) return 5;
+      if (std::fabs(actred) <= eps && prered <= eps && 0.5 * ratio <= 1.) return 6;
+      if (delta <= eps * xnorm) return 7;
+      if (gnorm <= eps) return 8;
+    } while (ratio < 1e-4);
+    return -1;  // Running
+  }
+};
+
+// DepthProblemSolver::solve_single_problem_numerical, DepthProblemSolver.cpp:138-214
+bool solve_single(orc_mapper* M, const DepthProblem& prob, double d_init, double result[3], double info[4]) {
+  const int N = M->prm.patch_size_x * M->prm.patch_size_y;
+  LM1 lm(prob, N, 1e-6, 1e-6, M->prm.lm_max_iteration * 3);
+  double x = d_init;
+  lm.minimizeInit(x);
+  size_t iteration = 0;
+  int optimizationState = 0, status = -2;
+  while (true) {
+    status = lm.minimizeOneStep(x);
+    iteration++;
+    if (iteration >= (size_t)M->prm.lm_max_iteration) break;
+    bool terminate = false;
+    if (status == 2 || status == 3) {
+      if (optimizationState == 0) optimizationState++;
+      else terminate = true;
+    }
+    if (terminate) break;
+  }
+  if (info) { info[0] = (double)iteration; info[1] = lm.nfev; info[2] = status; info[3] = 0; }
+  if (x <= 0.001) return false;  // :192
+  result[0] = x;
+  // internal::covar for n == 1 -> 1/r^2 (0 if r == 0); Tdist: variance = td_stdvar^2 * that
+  const double nu = M->prm.td_nu;
+  const double td_stdvar = std::sqrt(nu / (nu - 2) * sq(M->prm.td_scale));  // DepthProblem.h:34
+  const double invJtJ = (lm.r != 0.) ? (1. / lm.r) * (1. / lm.r) : 0.;
+  result[1] = sq(td_stdvar) * invJtJ;  // :210
+  result[2] = lm.fnorm * lm.fnorm;              // :212
+  if (info) info[3] = 1;
+  return true;
+}
+
+// stride-N thread emulation: indices i_thread, i_thread+N, ... per thread, threads concatenated
+std::vector<size_t> stride_order(size_t n, int T) {
+  std::vector<size_t> o;
+  o.reserve(n);
+  for (int t = 0; t < T; ++t) for (size_t i = t; i < n; i += T) o.push_back(i);
+  return o;
+}
+
+// ---------------------------------------------------------------------------------------------
+// DepthFusion (DepthFusion.cpp)
+// ---------------------------------------------------------------------------------------------
+inline bool boundaryCheck(double x, double y, size_t w, size_t h) {  // :194-205
+  return !(x < 0 || x >= (double)w || y < 0 || y >= (double)h);
+}
+inline bool studentTCompatibleTest(double d1, double d2, double v1, double v2) {  // :220-231
+  double s1 = std::sqrt(v1), s2 = std::sqrt(v2), diff = std::fabs(d1 - d2);
+  return diff < 2 * s1 || diff < 2 * s2;
+}
+
+// DepthFusion::propagate_one_point, DepthFusion.cpp:18-68 (Tdist)
+bool propagate_one_point(const orc_mapper* M, const DP& prior, DP& prop, const Mat4& T) {
+  double pp[3];
+  for (int r = 0; r < 3; ++r)
+    pp[r] = ((T.m[r * 4 + 0] * prior.p_cam[0] + T.m[r * 4 + 1] * prior.p_cam[1]) + T.m[r * 4 + 2] * prior.p_cam[2]) + T.m[r * 4 + 3];
+  double xp[2];
+  M->camL.world2Cam(pp, xp);
+  if (!boundaryCheck(xp[0], xp[1], M->W(), M->H())) return false;
+  prop = DP((size_t)std::floor(xp[1]), (size_t)std::floor(xp[0]));
+  prop.x[0] = xp[0]; prop.x[1] = xp[1];
+  const double invDepth = 1.0 / pp[2];
+  double denominator = (T.m[8] * prior.p_cam[0] + T.m[9] * prior.p_cam[1]) + T.m[11];
+  denominator /= prior.p_cam[2];
+  denominator += T.m[10];
+  const double J = T.m[10] / sq(denominator);
+  const double scale2 = J * J * prior.scale2;
+  const double nu = prior.nu;
+  const double variance = nu / (nu - 2) * scale2;
+  prop.update_studentT(invDepth, scale2, variance, nu);
+  prop.p_cam[0] = pp[0]; prop.p_cam[1] = pp[1]; prop.p_cam[2] = pp[2];
+  prop.residual = prior.residual;
+  prop.age = prior.age;
+  return true;
+}
+
+// DepthFusion::fusion, DepthFusion.cpp:90-192 (Tdist)
+int fusion(orc_mapper* M, const DP& prop, int fusion_radius) {
+  int numFusion = 0;
+  Grid& dm = M->map;
+  std::vector<std::pair<size_t, size_t>> coords;
+  if (fusion_radius == 0) {
+    for (int dy = 0; dy <= 1; dy++) for (int dx = 0; dx <= 1; dx++) coords.emplace_back(prop.row + dy, prop.col + dx);
+  } else {
+    for (int dy = -1; dy <= 1; dy++) for (int dx = -1; dx <= 1; dx++) coords.emplace_back(prop.row + dy, prop.col + dx);
+  }
+  for (auto& rc : coords) {
+    const size_t row = rc.first, col = rc.second;
+    if (!boundaryCheck((double)col, (double)row, M->W(), M->H())) continue;
+    if (!dm.exists(row, col)) {  // case 1
+      DP dp_new(row, col);
+      dp_new.update_studentT(prop.invDepth, prop.scale2, prop.variance, prop.nu);
+      dp_new.residual = prop.residual;
+      dp_new.age = prop.age;
+      M->camL.cam2World(dp_new.x, prop.invDepth, dp_new.p_cam);
+      dm.set(row, col, dp_new);
+    } else {
+      DP& c = dm.get(row, col);
+      if (studentTCompatibleTest(prop.invDepth, c.invDepth, prop.variance, c.variance)) {  // 2.1
+        c.update_studentT(prop.invDepth, prop.scale2, prop.variance, prop.nu);
+        c.age++;
+        c.residual = std::min(c.residual, prop.residual);
+        M->camL.cam2World(c.x, prop.invDepth, c.p_cam);
+        numFusion++;
+      } else {  // 2.2
+        if (c.invDepth - 2 * std::sqrt(c.variance) > prop.invDepth) continue;
+        if (prop.variance < c.variance && prop.residual < c.residual) {
+          M->n_replace++;
+          if (prop.row != row || prop.col != col) M->n_replace_displaced++;
+          c = prop;  // operator=: row/col/x of the propagated point travel too (Appendix A-7)
+        }
+      }
+    }
+  }
+  return numFusion;
+}
+
+// DepthFusion::update, DepthFusion.cpp:71-87
+int fusion_update(orc_mapper* M, const Frame& fr, int fusion_radius) {
+  int numFusion = 0;
+  Mat4 T_frame_world = rigid_inverse(M->T_world_frame);
+  for (size_t i = 0; i < fr.pts.size(); ++i) {
+    Mat4 T_frame_obs = mat4_mul(T_frame_world, fr.poses[fr.pts[i].pose_idx]);
+    DP prop;
+    if (!propagate_one_point(M, fr.pts[i], prop, T_frame_obs)) continue;
+    numFusion += fusion(M, prop, fusion_radius);
+  }
+  return numFusion;
+}
+
+// DepthRegularization::apply, DepthRegularization.cpp:19-110 (Tdist)
+void regularize(orc_mapper* M) {
+  Grid& dm = M->map;
+  Grid tmp;
+  tmp.init(dm.W, dm.H);
+  const size_t radius = (size_t)M->prm.reg_radius;
+  const size_t minN = (size_t)M->prm.reg_min_neighbours, minClose = (size_t)M->prm.reg_min_close_neighbours;
+  std::vector<const DP*> nb, close;
+  for (size_t e = 0; e < dm.elems.size(); ++e) {
+    if (!dm.alive[e]) continue;
+    const DP& it = dm.elems[e];
+    tmp.set(it.row, it.col, it);
+    DP& newDp = tmp.get(it.row, it.col);
+    if (it.valid()) {
+      dm.neighbourhood(it.row, it.col, radius, nb);
+      bool isSet = false;
+      if (nb.size() > minN) {
+        close.clear();
+        for (const DP* n : nb)
+          if (n->valid()) {
+            double diff = std::fabs(it.invDepth - n->invDepth);
+            if (diff < 2.0 * std::sqrt(it.variance) || diff < 2.0 * std::sqrt(n->variance)) close.push_back(n);
+          }
+        if (close.size() > minClose) {
+          double nu_post = close[0]->nu, invDepth_post = close[0]->invDepth, scale2_post = close[0]->scale2;
+          for (size_t i = 1; i < close.size(); ++i) {
+            double nu_prior = nu_post, invDepth_prior = invDepth_post, scale2_prior = scale2_post;
+            double nu_obs = close[i]->nu, invDepth_obs = close[i]->invDepth, scale2_obs = close[i]->scale2;
+            nu_post = std::min(nu_prior, nu_obs);
+            invDepth_post = (scale2_obs * invDepth_prior + scale2_prior * invDepth_obs) / (scale2_obs + scale2_prior);
+            scale2_post = (nu_post + sq(invDepth_prior - invDepth_obs) / (scale2_prior + scale2_obs)) /
+                          (nu_post + 1) * (scale2_prior * scale2_obs) / (scale2_prior + scale2_obs);
+          }
+          newDp.invDepth = invDepth_post;
+          isSet = true;
+        }
+      }
+      if (!isSet) newDp.invDepth = -1.0;
+    }
+  }
+  dm = tmp;  // SmartGrid::operator= : elements copied, grid rebuilt from the elements' row/col
+}
+
+void set_ts(std::vector<double>& dst, const uint8_t* src, int W, int H, bool smooth) {
+  std::vector<uint8_t> tmp;
+  if (smooth) {  // TimeSurfaceObservation::GaussianBlurTS(5), TimeSurfaceObservation.h:107-116
+    tmp.resize((size_t)W * H);
+    gaussian5_u8(src, tmp.data(), W, H);
+    src = tmp.data();
+  }
+  dst.resize((size_t)W * H);
+  for (size_t i = 0; i < dst.size(); ++i) dst[i] = (double)src[i];
+}
+
+inline void dp_to_pod(const DP& d, esvo_depth_point_t& o, uint32_t seq) {
+  o.row = (uint32_t)d.row; o.col = (uint32_t)d.col;
+  o.x[0] = d.x[0]; o.x[1] = d.x[1];
+  o.inv_depth = d.invDepth; o.scale2 = d.scale2; o.nu = d.nu; o.variance = d.variance; o.residual = d.residual;
+  o.age = d.age;
+  o.p_cam[0] = d.p_cam[0]; o.p_cam[1] = d.p_cam[1]; o.p_cam[2] = d.p_cam[2];
+  o.pose_idx = d.pose_idx; o.seq = seq;
+}
+inline DP pod_to_dp(const esvo_depth_point_t& o) {
+  DP d((size_t)o.row, (size_t)o.col);
+  d.x[0] = o.x[0]; d.x[1] = o.x[1];
+  d.invDepth = o.inv_depth; d.scale2 = o.scale2; d.nu = o.nu; d.variance = o.variance; d.residual = o.residual;
+  d.age = (size_t)o.age;
+  d.p_cam[0] = o.p_cam[0]; d.p_cam[1] = o.p_cam[1]; d.p_cam[2] = o.p_cam[2];
+  d.pose_idx = o.pose_idx;
+  return d;
+}
+
+}  // namespace
+
+// =============================================================================================
+// C API
+// =============================================================================================
+extern "C" orc_mapper_handle orc_mapper_create(const esvo_params_t* p, const esvo_calib_t* left,
+                                               const esvo_calib_t* right) {
+  orc_mapper* M = new orc_mapper();
+  M->prm = *p;
+  M->camL.init(left);
+  M->camR.init(right);
+  // CameraSystem::computeBaseline, CameraSystem.cpp:161-166: || P_r[:, :3]^-1 P_r[:, 3] ||
+  M->baseline = std::sqrt((M->camR.Kinv_t[0] * M->camR.Kinv_t[0] + M->camR.Kinv_t[1] * M->camR.Kinv_t[1]) +
+                          M->camR.Kinv_t[2] * M->camR.Kinv_t[2]);
+  M->map.init(M->camL.W, M->camL.H);
+  for (int i = 0; i < 16; ++i) M->T_world_obs.m[i] = M->T_world_frame.m[i] = (i % 5 == 0) ? 1.0 : 0.0;
+  return M;
+}
+extern "C" void orc_mapper_destroy(orc_mapper_handle h) { delete h; }
+extern "C" void orc_mapper_reset(orc_mapper_handle h) {
+  h->window.clear();
+  h->map.init(h->W(), h->H());
+  h->n_replace = h->n_replace_displaced = h->max_scale_iters = h->n_evals = 0;
+}
+extern "C" void orc_mapper_set_params(orc_mapper_handle h, const esvo_params_t* p) { h->prm = *p; }
+extern "C" void orc_mapper_set_threads(orc_mapper_handle h, int t) { h->real_threads = t < 1 ? 1 : t; }
+extern "C" double orc_mapper_baseline(orc_mapper_handle h) { return h->baseline; }
+
+extern "C" void orc_mapper_set_observation(orc_mapper_handle h, uint64_t t_ns, const uint8_t* l,
+                                           const uint8_t* r, const double T[16]) {
+  h->obs_t_ns = t_ns;
+  // createMatchProblem applies GaussianBlurTS when SmoothTimeSurface (EventBM.cpp:68-72); the
+  // blurred matrices are then also what DepthProblem reads (TS_left_/TS_right_ are replaced).
+  set_ts(h->tsL, l, h->W(), h->H(), h->prm.smooth_time_surface != 0);
+  set_ts(h->tsR, r, h->W(), h->H(), h->prm.smooth_time_surface != 0);
+  std::memcpy(h->T_world_obs.m, T, sizeof(double) * 16);
+}
+extern "C" void orc_mapper_set_poses(orc_mapper_handle h, const uint64_t* t, const double* T, size_t m) {
+  h->pose_t.assign(t, t + m);
+  h->pose_T.resize(m);
+  for (size_t i = 0; i < m; ++i) std::memcpy(h->pose_T[i].m, T + 16 * i, sizeof(double) * 16);
+}
+
+extern "C" size_t orc_select_events(const esvo_event_t* ev, size_t n, uint64_t t_ns, double half_slice,
+                                    size_t max_num, uint32_t* out_idx, size_t cap) {
+  // esvo_Mapping::dataTransferring, esvo_Mapping.cpp:562-574 (Appendix A-3)
+  const double t_end = ns_to_sec(t_ns);
+  const uint64_t t_begin_ns = ros_time_from_sec(std::max(0.0, t_end - 10 * half_slice));
+  const double t_begin = ns_to_sec(t_begin_ns);
+  auto lb = [&](double t) {  // tools::EventBuffer_lower_bound, utils.h:51-56
+    size_t lo = 0, hi = n;
+    while (lo < hi) { size_t mid = (lo + hi) / 2; if (ev_sec(ev[mid]) < t) lo = mid + 1; else hi = mid; }
+    return lo;
+  };
+  size_t it_end = lb(t_end), it_begin = lb(t_begin);
+  size_t cnt = 0;
+  while (it_end != it_begin && cnt < max_num) {
+    // the reference dereferences end() here when it_end == n (UB); the oracle skips that slot
+    if (it_end < n) { if (cnt < cap) out_idx[cnt] = (uint32_t)it_end; cnt++; }
+    it_end--;
+  }
+  return cnt;
+}
+
+extern "C" size_t orc_denoise_events(const esvo_event_t* ev, const uint32_t* idx, size_t n, int w, int h,
+                                     size_t max_num, uint32_t* out_idx) {
+  // createDenoisingMask (esvo_Mapping.cpp:1046-1054, Visualization.cpp:96-104) +
+  // extractDenoisedEvents (:1056-1072); the mask is indexed by the RAW pixel (Appendix A-15)
+  std::vector<uint8_t> em((size_t)w * h, 0), mask((size_t)w * h);
+  for (size_t i = 0; i < n; ++i) { const esvo_event_t& e = ev[idx[i]]; if (e.x < w && e.y < h) em[(size_t)e.y * w + e.x] = 255; }
+  median3_u8(em.data(), mask.data(), w, h);
+  size_t cnt = 0;
+  for (size_t i = 0; i < n; ++i) {
+    if (cnt >= max_num) break;
+    const esvo_event_t& e = ev[idx[i]];
+    if (e.x < w && e.y < h && mask[(size_t)e.y * w + e.x] == 255) out_idx[cnt++] = idx[i];
+  }
+  return cnt;
+}
+
+extern "C" size_t orc_mapper_match(orc_mapper_handle h, const esvo_event_t* ev, size_t n, esvo_match_t* out,
+                                   size_t cap) {
+  // EventBM::match_all_HyperThread + match, EventBM.cpp:269-315: thread t handles events
+  // t, t+N, ...; the per-thread result vectors are concatenated in thread order.
+  BM bm{h, h->prm.patch_size_x, h->prm.patch_size_y, h->W(), h->H()};
+  const int T = std::max(1, h->prm.num_threads);
+  std::vector<std::vector<esvo_match_t>> per(T);
+  auto job = [&](int t) {
+    for (size_t i = t; i < n; i += T) {
+      esvo_match_t m;
+      if (bm.match_an_event(ev[i], (uint32_t)i, m)) per[t].push_back(m);
+    }
+  };
+  if (h->real_threads > 1) {
+    // real threads only change wall time: each logical thread's list is still built in order
+    std::vector<std::thread> th;
+    int R = h->real_threads;
+    // split every logical thread's stride list into R contiguous chunks
+    std::vector<std::vector<std::vector<esvo_match_t>>> parts(T, std::vector<std::vector<esvo_match_t>>(R));
+    for (int rt = 0; rt < R; ++rt)
+      th.emplace_back([&, rt]() {
+        for (int t = 0; t < T; ++t) {
+          size_t cnt = (n > (size_t)t) ? (n - t + T - 1) / T : 0;
+          size_t b = cnt * rt / R, e = cnt * (rt + 1) / R;
+          for (size_t k = b; k < e; ++k) {
+            size_t i = t + k * T;
+            esvo_match_t m;
+            if (bm.match_an_event(ev[i], (uint32_t)i, m)) parts[t][rt].push_back(m);
+          }
+        }
+      });
+    for (auto& t : th) t.join();
+    for (int t = 0; t < T; ++t) for (int rt = 0; rt < R; ++rt) per[t].insert(per[t].end(), parts[t][rt].begin(), parts[t][rt].end());
+  } else {
+    for (int t = 0; t < T; ++t) job(t);
+  }
+  size_t cnt = 0;
+  for (int t = 0; t < T; ++t) for (auto& m : per[t]) { if (cnt < cap) out[cnt] = m; cnt++; }
+  return cnt;
+}
+
+extern "C" int orc_mapper_match_costs(orc_mapper_handle h, const esvo_event_t* ev, double* costs, int exact_int) {
+  BM bm{h, h->prm.patch_size_x, h->prm.patch_size_y, h->W(), h->H()};
+  const int nd = h->prm.bm_max_disparity - h->prm.bm_min_disparity + 1;
+  for (int i = 0; i < nd; ++i) costs[i] = std::numeric_limits<double>::quiet_NaN();
+  esvo_match_t m;
+  // run the search with cost capture (returns whether the event got far enough to search)
+  bool ok = bm.match_an_event(*ev, 0, m, costs, exact_int);
+  (void)ok;
+  return std::isnan(costs[0]) ? 0 : 1;
+}
+
+extern "C" size_t orc_mapper_refine(orc_mapper_handle h, const esvo_match_t* matches, size_t n, int cull,
+                                    esvo_depth_point_t* out, size_t cap, double* lm_info) {
+  // DepthProblemSolver::solve + solve_multiple_problems, DepthProblemSolver.cpp:28-136
+  const int T = std::max(1, h->prm.num_threads);
+  const double nu = h->prm.td_nu;
+  std::vector<char> solved(n, 0);
+  std::vector<DP> res(n);
+  auto solve_one = [&](size_t i, orc_mapper* ctx) {
+    DepthProblem prob{ctx, h->prm.patch_size_x, h->prm.patch_size_y, {0, 0}, {0}};
+    const esvo_match_t& m = matches[i];
+    prob.setProblem(m.x_left, h->pose_T[m.pose_idx]);
+    double result[3];
+    if (solve_single(ctx, prob, m.inv_depth, result, lm_info ? lm_info + 4 * i : nullptr)) {
+      DP dp((size_t)std::floor(m.x_left[1]), (size_t)std::floor(m.x_left[0]));  // :116
+      dp.x[0] = m.x_left[0]; dp.x[1] = m.x_left[1];
+      h->camL.cam2World(m.x_left, result[0], dp.p_cam);  // :119
+      const double scale2_rho = result[1] * (nu - 2) / nu;  // :125
+      dp.update_studentT(result[0], scale2_rho, result[1], nu);
+      dp.residual = result[2];
+      dp.pose_idx = m.pose_idx;
+      res[i] = dp;
+      solved[i] = 1;
+    }
+  };
+  if (h->real_threads > 1) {
+    int R = h->real_threads;
+    std::vector<std::thread> th;
+    for (int rt = 0; rt < R; ++rt)
+      th.emplace_back([&, rt]() {
+        orc_mapper local;  // only the counters are written through ctx; share read-only data
+        local.prm = h->prm; local.camL = h->camL; local.camR = h->camR;
+        local.tsL = h->tsL; local.tsR = h->tsR; local.T_world_obs = h->T_world_obs;
+        for (size_t i = rt; i < n; i += R) solve_one(i, &local);
+      });
+    for (auto& t : th) t.join();
+  } else {
+    for (size_t i = 0; i < n; ++i) solve_one(i, h);
+  }
+  // concatenate in the reference's order: thread t -> matches t, t+N, ...
+  std::vector<DP> vdp;
+  for (size_t i : stride_order(n, T)) if (solved[i]) vdp.push_back(res[i]);
+  if (cull) {  // DepthProblemSolver::pointCulling, DepthProblemSolver.cpp:216-244
+    const double var_thr = sq(h->prm.stdvar_vis_threshold);
+    const double cost_thr = sq(h->prm.residual_vis_threshold) * (h->prm.patch_size_x * h->prm.patch_size_y);
+    std::vector<DP> c;
+    for (auto& d : vdp)
+      if (d.variance <= var_thr && d.residual <= cost_thr && d.valid() && d.invDepth >= h->prm.invdepth_min &&
+          d.invDepth <= h->prm.invdepth_max)
+        c.push_back(d);
+    vdp.swap(c);
+  }
+  for (size_t i = 0; i < vdp.size() && i < cap; ++i) dp_to_pod(vdp[i], out[i], (uint32_t)i);
+  return vdp.size();
+}
+
+extern "C" void orc_mapper_push_frame(orc_mapper_handle h, const esvo_depth_point_t* pts, size_t n,
+                                      const double* pose_T, size_t m) {
+  Frame f;
+  f.pts.reserve(n);
+  for (size_t i = 0; i < n; ++i) f.pts.push_back(pod_to_dp(pts[i]));
+  f.poses.resize(m);
+  for (size_t i = 0; i < m; ++i) std::memcpy(f.poses[i].m, pose_T + 16 * i, sizeof(double) * 16);
+  h->window.push_back(std::move(f));
+  // window policy, esvo_Mapping.cpp:341-368
+  if (h->prm.fusion_strategy == ESVO_FUSION_CONST_POINTS) {
+    auto total = [&]() { size_t s = 0; for (auto& fr : h->window) s += fr.pts.size(); return s; };
+    size_t np = total();
+    while ((double)np > 1.5 * (double)h->prm.max_fusion_points) { h->window.pop_front(); np = total(); }
+  } else {
+    while (h->window.size() > (size_t)h->prm.max_fusion_frames) h->window.pop_front();
+  }
+}
+
+extern "C" size_t orc_mapper_fuse(orc_mapper_handle h) {
+  // new DepthFrame at the TS pose (esvo_Mapping.cpp:268-272) + fusion newest -> oldest (:372-377)
+  h->map.init(h->W(), h->H());
+  h->T_world_frame = h->T_world_obs;
+  size_t numFusion = 0;
+  for (auto it = h->window.rbegin(); it != h->window.rend(); ++it) numFusion += fusion_update(h, *it, h->prm.fusion_radius);
+  const bool do_clean = h->prm.clean_requires_full_window ? (h->window.size() >= (size_t)h->prm.max_fusion_frames) : true;
+  if (do_clean)  // esvo_Mapping.cpp:385-386 / esvo_MVStereo.cpp:496-497
+    h->map.clean(sq(h->prm.stdvar_vis_threshold), h->prm.age_vis_threshold, h->prm.invdepth_max, h->prm.invdepth_min);
+  if (h->prm.regularization) regularize(h);  // :390-395
+  return numFusion;
+}
+
+extern "C" size_t orc_mapper_tick(orc_mapper_handle h, const esvo_event_t* ev, size_t n) {
+  // esvo_Mapping::MappingAtTime, esvo_Mapping.cpp:261-431 (events already selected / denoised)
+  std::vector<esvo_match_t> vEMP(n);
+  size_t nm = orc_mapper_match(h, ev, n, vEMP.data(), n);
+  std::vector<esvo_depth_point_t> vdp(nm ? nm : 1);
+  size_t np = orc_mapper_refine(h, vEMP.data(), nm, 1, vdp.data(), nm, nullptr);
+  std::vector<double> poses(h->pose_T.size() * 16);
+  for (size_t i = 0; i < h->pose_T.size(); ++i) std::memcpy(&poses[16 * i], h->pose_T[i].m, sizeof(double) * 16);
+  orc_mapper_push_frame(h, vdp.data(), np, poses.data(), h->pose_T.size());
+  return orc_mapper_fuse(h);
+}
+
+extern "C" size_t orc_mapper_map_size(orc_mapper_handle h) { return h->map.size(); }
+extern "C" size_t orc_mapper_get_map(orc_mapper_handle h, esvo_depth_point_t* out, size_t cap) {
+  size_t k = 0;
+  for (size_t i = 0; i < h->map.elems.size(); ++i) {
+    if (!h->map.alive[i]) continue;
+    if (k < cap) dp_to_pod(h->map.elems[i], out[k], (uint32_t)k);
+    ++k;
+  }
+  return k;
+}
+extern "C" size_t orc_mapper_get_map_cells(orc_mapper_handle h, int32_t* out, size_t cap) {
+  std::vector<int32_t> cell_of(h->map.elems.size(), -1);
+  for (size_t c = 0; c < h->map.grid.size(); ++c) if (h->map.grid[c] >= 0) cell_of[h->map.grid[c]] = (int32_t)c;
+  size_t k = 0;
+  for (size_t i = 0; i < h->map.elems.size(); ++i) {
+    if (!h->map.alive[i]) continue;
+    if (k < cap) out[k] = cell_of[i];
+    ++k;
+  }
+  return k;
+}
+extern "C" size_t orc_mapper_get_last_frame(orc_mapper_handle h, esvo_depth_point_t* out, size_t cap) {
+  if (h->window.empty()) return 0;
+  const Frame& f = h->window.back();
+  for (size_t i = 0; i < f.pts.size() && i < cap; ++i) dp_to_pod(f.pts[i], out[i], (uint32_t)i);
+  return f.pts.size();
+}
+extern "C" size_t orc_mapper_get_pointcloud_xyz(orc_mapper_handle h, float* out_xyz, size_t cap_points) {
+  // publishPointCloud loop, esvo_Mapping.cpp:925-932
+  const Mat4& T = h->T_world_frame;
+  size_t k = 0;
+  for (size_t i = 0; i < h->map.elems.size(); ++i) {
+    if (!h->map.alive[i]) continue;
+    const DP& d = h->map.elems[i];
+    if (k < cap_points)
+      for (int r = 0; r < 3; ++r)
+        out_xyz[3 * k + r] = (float)(((T.m[r * 4 + 0] * d.p_cam[0] + T.m[r * 4 + 1] * d.p_cam[1]) + T.m[r * 4 + 2] * d.p_cam[2]) + T.m[r * 4 + 3]);
+    ++k;
+  }
+  return k;
+}
+extern "C" void orc_mapper_counters(orc_mapper_handle h, uint64_t out[8]) {
+  size_t np = 0;
+  for (auto& f : h->window) np += f.pts.size();
+  out[0] = h->window.size(); out[1] = np; out[2] = h->n_replace; out[3] = h->n_replace_displaced;
+  out[4] = h->max_scale_iters; out[5] = h->n_evals; out[6] = out[7] = 0;
+}

@@ -1,0 +1,106 @@
+/*
+ * esvo_oracle.h — C API of the CPU oracle (TEST INFRASTRUCTURE, NOT PRODUCT).
+ *
+ * The oracle is a dependency-free C++17 restatement of the ESVO reference's hot
+ * path (Time-Surface raster + stereo mapper).  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load it.  The product library
+ * (esvo_amd/csrc -> libesvo_hip.so) never links, loads or calls anything in here.
+ *
+ * PARITY UNPINNED: the reference ships no tests / golden vectors and cannot be built
+ * in this environment (ROS, Eigen, OpenCV absent).  Third-party
+ * arithmetic (Eigen's MINPACK-style LevenbergMarquardt + NumericalDiff, OpenCV's
+ * convertTo/medianBlur/remap/GaussianBlur) is restated from the published
+ * algorithms and validated by self-consistency tests
+ * (tests/test_oracle_*.py), e.g. against scipy's MINPACK wrapper.
+ *
+ * POD types (events, params, matches, depth points) are shared with the boundary
+ * header include/esvo_hip.h so that tests compare like with like.
+ */
+#ifndef ESVO_ORACLE_H
+#define ESVO_ORACLE_H
+
+#include "../include/esvo_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------- Time Surface (esvo_time_surface/) ---------- */
+typedef struct orc_ts* orc_ts_handle;
+orc_ts_handle orc_ts_create(int width, int height, int queue_len);
+void orc_ts_destroy(orc_ts_handle h);
+void orc_ts_clear(orc_ts_handle h);
+/* EventQueueMat::insertEvent, TimeSurface.h:39-50 (events must be time sorted) */
+void orc_ts_push(orc_ts_handle h, const esvo_event_t* ev, size_t n);
+/* TimeSurface::createTimeSurfaceAtTime, TimeSurface.cpp:52-152 (BACKWARD mode).
+ * map_x/map_y may be NULL -> out is the un-rectified (median-filtered) image.
+ * out_prefilter (nullable) receives the u8 image before the median filter. */
+void orc_ts_render(orc_ts_handle h, uint64_t t_ns, double decay_ms, int ignore_polarity,
+                   int median_blur_kernel_size, const float* map_x, const float* map_y,
+                   uint8_t* out, uint8_t* out_prefilter);
+
+/* OpenCV-style image primitives restated in Appendix B.2 (exposed for unit tests) */
+void orc_median3_u8(const uint8_t* src, uint8_t* dst, int w, int h);
+void orc_remap_bilinear_u8(const uint8_t* src, uint8_t* dst, int w, int h, const float* map_x,
+                           const float* map_y);
+void orc_gaussian5_u8(const uint8_t* src, uint8_t* dst, int w, int h);
+
+/* ---------- Mapper (esvo_core/) ---------- */
+typedef struct orc_mapper* orc_mapper_handle;
+orc_mapper_handle orc_mapper_create(const esvo_params_t* p, const esvo_calib_t* left,
+                                    const esvo_calib_t* right);
+void orc_mapper_destroy(orc_mapper_handle h);
+void orc_mapper_reset(orc_mapper_handle h);
+void orc_mapper_set_params(orc_mapper_handle h, const esvo_params_t* p);
+void orc_mapper_set_threads(orc_mapper_handle h, int real_threads); /* >1: run BM / LM on
+        real std::threads (same outputs; used only for the timed CPU baseline) */
+double orc_mapper_baseline(orc_mapper_handle h);
+
+/* TS_obs_ : mono8 left/right + T_world_cam (row-major 4x4) */
+void orc_mapper_set_observation(orc_mapper_handle h, uint64_t t_ns, const uint8_t* ts_left,
+                                const uint8_t* ts_right, const double T_world_cam[16]);
+void orc_mapper_set_poses(orc_mapper_handle h, const uint64_t* pose_t_ns, const double* pose_T,
+                          size_t m);
+/* dataTransferring's event selection, esvo_Mapping.cpp:555-575; returns count; out_idx gets
+ * indices into ev (newest first). */
+size_t orc_select_events(const esvo_event_t* ev, size_t n, uint64_t t_ns, double half_slice,
+                         size_t max_num, uint32_t* out_idx, size_t cap);
+/* createDenoisingMask + extractDenoisedEvents, esvo_Mapping.cpp:1046-1072 */
+size_t orc_denoise_events(const esvo_event_t* ev, const uint32_t* idx, size_t n, int w, int h,
+                          size_t max_num, uint32_t* out_idx);
+
+/* EventBM::match_all_HyperThread, EventBM.cpp:269-315 (output in the reference's
+ * thread-stride order).  Uses the current observation + pose table. */
+size_t orc_mapper_match(orc_mapper_handle h, const esvo_event_t* ev, size_t n, esvo_match_t* out,
+                        size_t cap);
+/* per-event diagnostic: all candidate costs of one event (for near-tie analysis).
+ * costs[d - dmin]; returns 0 if the event is rejected before the search. */
+int orc_mapper_match_costs(orc_mapper_handle h, const esvo_event_t* ev, double* costs,
+                           int exact_int);
+/* DepthProblemSolver::solve (+pointCulling if cull), DepthProblemSolver.cpp:28-136,216-244.
+ * lm_info (nullable, 4 doubles per input match): iterations, nfev, last status, solved flag */
+size_t orc_mapper_refine(orc_mapper_handle h, const esvo_match_t* matches, size_t n, int cull,
+                         esvo_depth_point_t* out, size_t cap, double* lm_info);
+/* window policy, esvo_Mapping.cpp:341-368 */
+void orc_mapper_push_frame(orc_mapper_handle h, const esvo_depth_point_t* pts, size_t n,
+                           const double* pose_T, size_t m);
+/* fusion loop + clean + regularisation, esvo_Mapping.cpp:370-395; returns numFusionCount */
+size_t orc_mapper_fuse(orc_mapper_handle h);
+/* whole MappingAtTime on already-selected events (esvo_Mapping.cpp:261-431) */
+size_t orc_mapper_tick(orc_mapper_handle h, const esvo_event_t* ev, size_t n);
+
+size_t orc_mapper_map_size(orc_mapper_handle h);
+size_t orc_mapper_get_map(orc_mapper_handle h, esvo_depth_point_t* out, size_t cap);
+/* true grid cell of every returned element (row*W+col), same order as get_map; -1 if the
+ * element is orphaned (Appendix A-7) */
+size_t orc_mapper_get_map_cells(orc_mapper_handle h, int32_t* out, size_t cap);
+size_t orc_mapper_get_last_frame(orc_mapper_handle h, esvo_depth_point_t* out, size_t cap);
+size_t orc_mapper_get_pointcloud_xyz(orc_mapper_handle h, float* out_xyz, size_t cap_points);
+/* counters: [0] window frames [1] window points [2] replace-branch hits [3] replace hits with
+ * a displaced cell (row/col differ) [4] max t-scale loop iterations seen [5] LM evaluations */
+void orc_mapper_counters(orc_mapper_handle h, uint64_t out[8]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

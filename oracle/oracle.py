@@ -1,0 +1,266 @@
+"""ctypes bindings of the CPU oracle (TEST INFRASTRUCTURE ONLY).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from esvo_amd.abi import (DEPTH_POINT_DTYPE, EVENT_DTYPE, MATCH_DTYPE, CalibStruct, ParamsStruct)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def build(fast=False, force=False):
+    """Compile the oracle with g++ (oracle/Makefile)."""
+    target = "libesvo_oracle_fast.so" if fast else "libesvo_oracle.so"
+    path = os.path.join(_HERE, target)
+    src = os.path.join(_HERE, "esvo_oracle.cpp")
+    if force or not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, target], stdout=subprocess.DEVNULL)
+    return path
+
+
+_libs = {}
+
+
+def load(fast=False):
+    key = bool(fast)
+    if key in _libs:
+        return _libs[key]
+    target = "libesvo_oracle_fast.so" if fast else "libesvo_oracle.so"
+    path = os.path.join(_HERE, target)
+    if not os.path.exists(path):
+        path = build(fast=fast)
+    lib = C.CDLL(path)
+    vp, u64, sz, dbl, i32 = C.c_void_p, C.c_uint64, C.c_size_t, C.c_double, C.c_int
+    lib.orc_ts_create.restype = vp
+    lib.orc_ts_create.argtypes = [i32, i32, i32]
+    lib.orc_ts_destroy.argtypes = [vp]
+    lib.orc_ts_clear.argtypes = [vp]
+    lib.orc_ts_push.argtypes = [vp, vp, sz]
+    lib.orc_ts_render.argtypes = [vp, u64, dbl, i32, i32, vp, vp, vp, vp]
+    lib.orc_median3_u8.argtypes = [vp, vp, i32, i32]
+    lib.orc_remap_bilinear_u8.argtypes = [vp, vp, i32, i32, vp, vp]
+    lib.orc_gaussian5_u8.argtypes = [vp, vp, i32, i32]
+    lib.orc_mapper_create.restype = vp
+    lib.orc_mapper_create.argtypes = [vp, vp, vp]
+    lib.orc_mapper_destroy.argtypes = [vp]
+    lib.orc_mapper_reset.argtypes = [vp]
+    lib.orc_mapper_set_params.argtypes = [vp, vp]
+    lib.orc_mapper_set_threads.argtypes = [vp, i32]
+    lib.orc_mapper_baseline.restype = dbl
+    lib.orc_mapper_baseline.argtypes = [vp]
+    lib.orc_mapper_set_observation.argtypes = [vp, u64, vp, vp, vp]
+    lib.orc_mapper_set_poses.argtypes = [vp, vp, vp, sz]
+    lib.orc_select_events.restype = sz
+    lib.orc_select_events.argtypes = [vp, sz, u64, dbl, sz, vp, sz]
+    lib.orc_denoise_events.restype = sz
+    lib.orc_denoise_events.argtypes = [vp, vp, sz, i32, i32, sz, vp]
+    lib.orc_mapper_match.restype = sz
+    lib.orc_mapper_match.argtypes = [vp, vp, sz, vp, sz]
+    lib.orc_mapper_match_costs.restype = i32
+    lib.orc_mapper_match_costs.argtypes = [vp, vp, vp, i32]
+    lib.orc_mapper_refine.restype = sz
+    lib.orc_mapper_refine.argtypes = [vp, vp, sz, i32, vp, sz, vp]
+    lib.orc_mapper_push_frame.argtypes = [vp, vp, sz, vp, sz]
+    lib.orc_mapper_fuse.restype = sz
+    lib.orc_mapper_fuse.argtypes = [vp]
+    lib.orc_mapper_tick.restype = sz
+    lib.orc_mapper_tick.argtypes = [vp, vp, sz]
+    lib.orc_mapper_map_size.restype = sz
+    lib.orc_mapper_map_size.argtypes = [vp]
+    lib.orc_mapper_get_map.restype = sz
+    lib.orc_mapper_get_map.argtypes = [vp, vp, sz]
+    lib.orc_mapper_get_map_cells.restype = sz
+    lib.orc_mapper_get_map_cells.argtypes = [vp, vp, sz]
+    lib.orc_mapper_get_last_frame.restype = sz
+    lib.orc_mapper_get_last_frame.argtypes = [vp, vp, sz]
+    lib.orc_mapper_get_pointcloud_xyz.restype = sz
+    lib.orc_mapper_get_pointcloud_xyz.argtypes = [vp, vp, sz]
+    lib.orc_mapper_counters.argtypes = [vp, vp]
+    _libs[key] = lib
+    return lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data
+
+
+class OracleTS:
+    """esvo_time_surface node state: per-pixel event queues + raster."""
+
+    def __init__(self, width, height, queue_len=20, fast=False):
+        self.lib = load(fast)
+        self.W, self.H = width, height
+        self.h = self.lib.orc_ts_create(width, height, queue_len)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.orc_ts_destroy(self.h)
+            self.h = None
+
+    def push(self, ev):
+        ev = np.ascontiguousarray(ev, dtype=EVENT_DTYPE)
+        self.lib.orc_ts_push(self.h, ev.ctypes.data, ev.shape[0])
+
+    def render(self, t_ns, decay_ms=30.0, ignore_polarity=True, median_k=1, map_x=None, map_y=None,
+               want_prefilter=False):
+        out = np.empty((self.H, self.W), np.uint8)
+        pre = np.empty((self.H, self.W), np.uint8) if want_prefilter else None
+        self.lib.orc_ts_render(self.h, int(t_ns), float(decay_ms), int(ignore_polarity), int(median_k),
+                               _p(map_x), _p(map_y), out.ctypes.data, _p(pre))
+        return (out, pre) if want_prefilter else out
+
+
+def median3(img):
+    lib = load()
+    img = np.ascontiguousarray(img, np.uint8)
+    out = np.empty_like(img)
+    lib.orc_median3_u8(img.ctypes.data, out.ctypes.data, img.shape[1], img.shape[0])
+    return out
+
+
+def remap_bilinear(img, map_x, map_y):
+    lib = load()
+    img = np.ascontiguousarray(img, np.uint8)
+    out = np.empty_like(img)
+    lib.orc_remap_bilinear_u8(img.ctypes.data, out.ctypes.data, img.shape[1], img.shape[0],
+                              map_x.ctypes.data, map_y.ctypes.data)
+    return out
+
+
+def gaussian5(img):
+    lib = load()
+    img = np.ascontiguousarray(img, np.uint8)
+    out = np.empty_like(img)
+    lib.orc_gaussian5_u8(img.ctypes.data, out.ctypes.data, img.shape[1], img.shape[0])
+    return out
+
+
+def select_events(ev, t_ns, half_slice, max_num, fast=False):
+    lib = load(fast)
+    ev = np.ascontiguousarray(ev, dtype=EVENT_DTYPE)
+    cap = min(max_num, ev.shape[0]) + 1
+    idx = np.empty(cap, np.uint32)
+    n = lib.orc_select_events(ev.ctypes.data, ev.shape[0], int(t_ns), float(half_slice), int(max_num),
+                              idx.ctypes.data, cap)
+    return idx[:n]
+
+
+def denoise_events(ev, idx, width, height, max_num):
+    lib = load()
+    ev = np.ascontiguousarray(ev, dtype=EVENT_DTYPE)
+    idx = np.ascontiguousarray(idx, np.uint32)
+    out = np.empty(max(idx.shape[0], 1), np.uint32)
+    n = lib.orc_denoise_events(ev.ctypes.data, idx.ctypes.data, idx.shape[0], width, height, int(max_num),
+                               out.ctypes.data)
+    return out[:n]
+
+
+class OracleMapper:
+    """esvo_Mapping / esvo_MVStereo mapper state (EventBM + DepthProblemSolver + DepthFusion + ...)."""
+
+    def __init__(self, params: ParamsStruct, rig, fast=False):
+        self.lib = load(fast)
+        self.rig, self.params = rig, params
+        self._cl, self._cr = rig.left.as_struct(), rig.right.as_struct()
+        self.h = self.lib.orc_mapper_create(C.addressof(params), C.addressof(self._cl), C.addressof(self._cr))
+        self.W, self.H = rig.width, rig.height
+        self._poses = None
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.orc_mapper_destroy(self.h)
+            self.h = None
+
+    def reset(self):
+        self.lib.orc_mapper_reset(self.h)
+
+    def set_params(self, params):
+        self.params = params
+        self.lib.orc_mapper_set_params(self.h, C.addressof(params))
+
+    def set_threads(self, n):
+        self.lib.orc_mapper_set_threads(self.h, int(n))
+
+    @property
+    def baseline(self):
+        return self.lib.orc_mapper_baseline(self.h)
+
+    def set_observation(self, t_ns, ts_left, ts_right, T_world_cam):
+        l = np.ascontiguousarray(ts_left, np.uint8)
+        r = np.ascontiguousarray(ts_right, np.uint8)
+        T = np.ascontiguousarray(T_world_cam, np.float64).reshape(16)
+        self.lib.orc_mapper_set_observation(self.h, int(t_ns), l.ctypes.data, r.ctypes.data, T.ctypes.data)
+
+    def set_poses(self, stamps, poses):
+        st = np.ascontiguousarray(stamps, np.uint64)
+        T = np.ascontiguousarray(poses, np.float64).reshape(-1, 16)
+        self._poses = T
+        self.lib.orc_mapper_set_poses(self.h, st.ctypes.data, T.ctypes.data, st.shape[0])
+
+    def match(self, ev):
+        ev = np.ascontiguousarray(ev, dtype=EVENT_DTYPE)
+        out = np.zeros(max(ev.shape[0], 1), MATCH_DTYPE)
+        n = self.lib.orc_mapper_match(self.h, ev.ctypes.data, ev.shape[0], out.ctypes.data, out.shape[0])
+        return out[:n]
+
+    def match_costs(self, ev_one, exact_int=False):
+        ev = np.ascontiguousarray(ev_one, dtype=EVENT_DTYPE).reshape(1)
+        nd = self.params.bm_max_disparity - self.params.bm_min_disparity + 1
+        costs = np.empty(nd, np.float64)
+        ok = self.lib.orc_mapper_match_costs(self.h, ev.ctypes.data, costs.ctypes.data, int(exact_int))
+        return costs if ok else None
+
+    def refine(self, matches, cull=True, want_info=False):
+        m = np.ascontiguousarray(matches, dtype=MATCH_DTYPE)
+        out = np.zeros(max(m.shape[0], 1), DEPTH_POINT_DTYPE)
+        info = np.zeros((max(m.shape[0], 1), 4), np.float64) if want_info else None
+        n = self.lib.orc_mapper_refine(self.h, m.ctypes.data, m.shape[0], int(cull), out.ctypes.data,
+                                       out.shape[0], _p(info))
+        return (out[:n], info[: m.shape[0]]) if want_info else out[:n]
+
+    def push_frame(self, pts, poses=None):
+        pts = np.ascontiguousarray(pts, dtype=DEPTH_POINT_DTYPE)
+        T = self._poses if poses is None else np.ascontiguousarray(poses, np.float64).reshape(-1, 16)
+        self.lib.orc_mapper_push_frame(self.h, pts.ctypes.data, pts.shape[0], T.ctypes.data, T.shape[0])
+
+    def fuse(self):
+        return self.lib.orc_mapper_fuse(self.h)
+
+    def tick(self, ev):
+        ev = np.ascontiguousarray(ev, dtype=EVENT_DTYPE)
+        return self.lib.orc_mapper_tick(self.h, ev.ctypes.data, ev.shape[0])
+
+    def get_map(self):
+        n = self.lib.orc_mapper_map_size(self.h)
+        out = np.zeros(max(n, 1), DEPTH_POINT_DTYPE)
+        n = self.lib.orc_mapper_get_map(self.h, out.ctypes.data, out.shape[0])
+        return out[:n]
+
+    def get_map_cells(self):
+        n = self.lib.orc_mapper_map_size(self.h)
+        out = np.zeros(max(n, 1), np.int32)
+        n = self.lib.orc_mapper_get_map_cells(self.h, out.ctypes.data, out.shape[0])
+        return out[:n]
+
+    def get_last_frame(self):
+        cap = max(int(self.params.max_events_per_tick), 1)
+        out = np.zeros(cap, DEPTH_POINT_DTYPE)
+        n = self.lib.orc_mapper_get_last_frame(self.h, out.ctypes.data, cap)
+        return out[:n]
+
+    def get_pointcloud(self):
+        n = self.lib.orc_mapper_map_size(self.h)
+        out = np.zeros((max(n, 1), 3), np.float32)
+        n = self.lib.orc_mapper_get_pointcloud_xyz(self.h, out.ctypes.data, out.shape[0])
+        return out[:n]
+
+    def counters(self):
+        c = np.zeros(8, np.uint64)
+        self.lib.orc_mapper_counters(self.h, c.ctypes.data)
+        return dict(window_frames=int(c[0]), window_points=int(c[1]), replace=int(c[2]),
+                    replace_displaced=int(c[3]), max_scale_iters=int(c[4]), lm_evals=int(c[5]))
