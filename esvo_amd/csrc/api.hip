@@ -1,0 +1,923 @@
+// api.hip — host side of the C-ABI declared in include/esvo_hip.h.
+//
+// One esvo_context owns every device buffer of one GPU: SAE + staged event rings (Time
+// Surface), the observation pair, per-tick BM/LM scratch, the fusion window ring and the dense
+// DepthMap.  Each entry point replays, on the handle's HIP stream, the call sequence of the
+// reference seam it replaces (cited in esvo_hip.h); nothing here computes on the CPU except
+// bookkeeping (time-stamp binary searches, window policy, output ordering).
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+
+using namespace esvo;
+
+namespace {
+thread_local std::string g_create_error;
+}
+
+struct FrameRec {
+  u32 off;    // offset in the window ring
+  u32 count;  // points
+  u32 slot;   // pose-table slot
+};
+
+struct esvo_context {
+  esvo_params_t prm;
+  DevParams dp;
+  int W = 0, H = 0, device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+  double baseline = 0;
+
+  // calibration
+  float2* d_lut = nullptr;
+  uint8_t* d_mask = nullptr;
+  int2* d_fixmap[2] = {nullptr, nullptr};
+
+  // Time Surface
+  u64* d_sae[2] = {nullptr, nullptr};
+  uint8_t* d_raw = nullptr;
+  uint8_t* d_ts[2] = {nullptr, nullptr};
+  bool ts_valid[2] = {false, false};
+  esvo_event_t* d_ring[2] = {nullptr, nullptr};
+  u64 ring_cap = 0;
+  std::deque<u64> ts_host[2];   // time stamps of staged events [ring_base, ring_base + size)
+  u64 ring_base[2] = {0, 0};    // absolute index of ts_host[cam].front()
+  u64 ring_next[2] = {0, 0};    // absolute index of the next event to stage
+  u64 scattered[2] = {0, 0};    // absolute index of the first event not yet in the SAE
+
+  // observation
+  uint8_t* d_obs[2] = {nullptr, nullptr};
+  uint8_t* d_obs_tmp = nullptr;
+  double T_world_obs[16];
+  double* d_T_world_obs = nullptr;
+  u64 obs_t_ns = 0;
+  bool obs_set = false;
+
+  // pose table of the tick
+  double* d_pose_sec = nullptr;
+  double* d_pose_T = nullptr;
+  std::vector<double> h_pose_T;
+  u32 n_pose = 0;
+
+  // per-tick scratch
+  u32 max_ev = 0;
+  esvo_event_t* d_tick_ev = nullptr;
+  esvo_match_t* d_match_slots = nullptr;
+  u32* d_match_flags = nullptr;
+  u32* d_match_prefix = nullptr;
+  esvo_match_t* d_matches = nullptr;
+  DevPoint* d_pt_slots = nullptr;
+  u32* d_pt_flags = nullptr;
+  u32* d_pt_prefix = nullptr;
+  DevPoint* d_pts_tmp = nullptr;  // stage-wise refine output
+  u32* d_counters = nullptr;      // [0] n_matches [1] n_points [2] n_solved [3] n_fusion [4] n_records [5] n_map
+  u32* h_counters = nullptr;      // pinned
+  u32* d_scan_tmp = nullptr;
+
+  // fusion window
+  DevPoint* d_win = nullptr;
+  u32 win_cap = 0;
+  std::deque<FrameRec> frames;    // oldest first
+  u32 n_pose_slots = 0;
+  std::vector<char> slot_used;
+  double* d_frame_pose_T = nullptr;
+  u32 max_poses = 0;
+  u32* d_fr_table = nullptr;      // fr_cum | fr_off | fr_slot
+  u32* h_fr_table = nullptr;      // pinned
+  u32 max_frames = 0;
+
+  // DepthMap
+  DevPoint* d_prop = nullptr;
+  u32* d_cell_count = nullptr;
+  u32* d_cell_offset = nullptr;
+  u32* d_cell_fill = nullptr;
+  u32* d_rec_ids = nullptr;
+  MapCell* d_map = nullptr;
+  MapCell* d_map2 = nullptr;
+  MapCell* d_map_cur = nullptr;
+  u32* d_owner_max = nullptr;
+  u32* d_owner_min = nullptr;
+  double T_world_frame[16];
+  // export
+  u32* d_exp_flags = nullptr;
+  u32* d_exp_prefix = nullptr;
+  esvo_depth_point_t* d_export = nullptr;
+  u32* d_export_cell = nullptr;
+
+  hipEvent_t evt[8];
+  bool evt_ok = false;
+  esvo_stats_t stats;
+};
+
+#define HIPCHK(call)                                                                              \
+  do {                                                                                            \
+    hipError_t _e = (call);                                                                       \
+    if (_e != hipSuccess) {                                                                       \
+      char _b[512];                                                                               \
+      snprintf(_b, sizeof(_b), "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
+      if (h) h->err = _b; else g_create_error = _b;                                               \
+      return ESVO_ERR_HIP;                                                                        \
+    }                                                                                             \
+  } while (0)
+
+#define FAIL(code, msg)                      \
+  do {                                       \
+    if (h) h->err = (msg); else g_create_error = (msg); \
+    return (code);                           \
+  } while (0)
+
+namespace {
+
+void invert3x3(const double* P, double* Kinv, double* Kinv_t) {
+  const double a = P[0], b = P[1], cc = P[2], d = P[4], e = P[5], f = P[6], g = P[8], hh = P[9], i = P[10];
+  const double det = a * (e * i - f * hh) - b * (d * i - f * g) + cc * (d * hh - e * g);
+  const double id = 1.0 / det;
+  Kinv[0] = (e * i - f * hh) * id; Kinv[1] = (cc * hh - b * i) * id; Kinv[2] = (b * f - cc * e) * id;
+  Kinv[3] = (f * g - d * i) * id;  Kinv[4] = (a * i - cc * g) * id;  Kinv[5] = (cc * d - a * f) * id;
+  Kinv[6] = (d * hh - e * g) * id; Kinv[7] = (b * g - a * hh) * id;  Kinv[8] = (a * e - b * d) * id;
+  for (int r = 0; r < 3; ++r) Kinv_t[r] = (Kinv[r * 3 + 0] * P[3] + Kinv[r * 3 + 1] * P[7]) + Kinv[r * 3 + 2] * P[11];
+}
+
+int validate_params(const esvo_params_t* p, std::string& why) {
+  if (p->ls_norm != ESVO_LSNORM_TDIST) { why = "only LSnorm == Tdist is supported (every shipped config uses it)"; return ESVO_ERR_UNSUPPORTED; }
+  if (p->bm_updown) { why = "BM_bUpDownConfiguration is not supported"; return ESVO_ERR_UNSUPPORTED; }
+  if (p->bm_step != 1) { why = "BM_step != 1 is not supported (every shipped config uses 1)"; return ESVO_ERR_UNSUPPORTED; }
+  if (p->patch_size_x != 15 || p->patch_size_y != 7) { why = "patch size must be 15x7 (every shipped config)"; return ESVO_ERR_UNSUPPORTED; }
+  if (p->median_blur_kernel_size < 0 || p->median_blur_kernel_size > 1) { why = "median_blur_kernel_size must be 0 or 1"; return ESVO_ERR_UNSUPPORTED; }
+  if (p->bm_max_disparity < p->bm_min_disparity || p->bm_min_disparity < 0) { why = "bad disparity range"; return ESVO_ERR_INVALID_ARG; }
+  if (p->td_nu <= 2.0 || p->td_scale <= 0) { why = "Tdist_nu must be > 2 and Tdist_scale > 0"; return ESVO_ERR_INVALID_ARG; }
+  if (p->num_threads < 1 || p->num_threads > 64) { why = "num_threads out of range"; return ESVO_ERR_INVALID_ARG; }
+  if (p->lm_max_iteration < 1) { why = "lm_max_iteration must be >= 1"; return ESVO_ERR_INVALID_ARG; }
+  return ESVO_OK;
+}
+
+void fill_dev_params(esvo_context* h) {
+  const esvo_params_t& p = h->prm;
+  DevParams& d = h->dp;
+  d.W = h->W; d.H = h->H;
+  d.wx = p.patch_size_x; d.wy = p.patch_size_y;
+  d.dmin = p.bm_min_disparity; d.dmax = p.bm_max_disparity; d.step = p.bm_step;
+  d.zncc_thr = p.bm_zncc_threshold;
+  d.baseline_f = h->baseline * d.camL.P[0];
+  d.td_nu = p.td_nu; d.td_scale = p.td_scale; d.td_scale2 = p.td_scale * p.td_scale;
+  const double td_stdvar = std::sqrt(p.td_nu / (p.td_nu - 2) * (p.td_scale * p.td_scale));  // DepthProblem.h:34
+  d.td_stdvar2 = td_stdvar * td_stdvar;
+  d.lm_max_iter = p.lm_max_iteration; d.lm_maxfev = p.lm_max_iteration * 3;
+  d.invdepth_min = p.invdepth_min; d.invdepth_max = p.invdepth_max;
+  d.var_thr = p.stdvar_vis_threshold * p.stdvar_vis_threshold;
+  d.cost_thr = (p.residual_vis_threshold * p.residual_vis_threshold) * (double)(p.patch_size_x * p.patch_size_y);
+  d.age_thr = p.age_vis_threshold;
+  d.fusion_radius = p.fusion_radius;
+  d.reg_radius = p.reg_radius; d.reg_min_nb = p.reg_min_neighbours; d.reg_min_close = p.reg_min_close_neighbours;
+  d.num_threads = p.num_threads;
+}
+
+template <typename T>
+hipError_t dalloc(T** p, size_t n) { return hipMalloc(reinterpret_cast<void**>(p), (n ? n : 1) * sizeof(T)); }
+
+// lower_bound over the staged time stamps with the reference's toSec() comparison
+// (tools::EventBuffer_lower_bound, utils.h:51-56); returns an absolute index
+u64 lower_bound_sec(const esvo_context* h, int cam, double t) {
+  const auto& v = h->ts_host[cam];
+  size_t lo = 0, hi = v.size();
+  while (lo < hi) {
+    size_t mid = (lo + hi) / 2;
+    if (ns_to_sec(v[mid]) < t) lo = mid + 1; else hi = mid;
+  }
+  return h->ring_base[cam] + lo;
+}
+// ros::Time(double)  (TimeBase::fromSec)
+u64 ros_time_from_sec(double t) {
+  long long sec64 = (long long)std::floor(t);
+  u32 sec = (u32)sec64;
+  u32 nsec = (u32)std::round((t - sec) * 1e9);
+  sec += (nsec / 1000000000ul);
+  nsec %= 1000000000ul;
+  return (u64)sec * 1000000000ull + nsec;
+}
+
+int upload_poses(esvo_context* h, const uint64_t* pose_t_ns, const double* pose_T, size_t m) {
+  if (m > h->max_poses) FAIL(ESVO_ERR_CAPACITY, "pose table larger than max_poses_per_tick");
+  std::vector<double> sec(m);
+  for (size_t i = 0; i < m; ++i) sec[i] = ns_to_sec(pose_t_ns[i]);
+  h->h_pose_T.assign(pose_T, pose_T + 16 * m);
+  h->n_pose = (u32)m;
+  if (m) {
+    HIPCHK(hipMemcpyAsync(h->d_pose_sec, sec.data(), sizeof(double) * m, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_pose_T, pose_T, sizeof(double) * 16 * m, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));  // `sec` is a stack temporary
+  }
+  return ESVO_OK;
+}
+
+// BM over n events starting at absolute ring index `first` (reverse walk) or over d_tick_ev
+int run_match(esvo_context* h, const esvo_event_t* d_ev, u64 first, u64 cap, int reverse, u32 n) {
+  BmArgs a;
+  a.ev = d_ev; a.n = n; a.ev_first = first; a.ev_cap = cap; a.ev_reverse = reverse;
+  a.tsL = h->d_obs[0]; a.tsR = h->d_obs[1];
+  a.lut = h->d_lut; a.mask = h->d_mask;
+  a.pose_sec = h->d_pose_sec; a.n_pose = h->n_pose;
+  a.out_slots = h->d_match_slots; a.out_flags = h->d_match_flags;
+  launch_bm_match(a, h->dp, h->stream);
+  launch_exclusive_scan_u32(h->d_match_flags, h->d_match_prefix, h->d_counters + 0, h->d_scan_tmp, n, h->stream);
+  launch_compact_matches(h->d_match_slots, h->d_match_flags, h->d_match_prefix, n, h->d_matches, h->stream);
+  HIPCHK(hipGetLastError());
+  return ESVO_OK;
+}
+
+// LM (+cull) over the compacted matches; the culled points go to `dst` in the reference's order
+int run_refine(esvo_context* h, u32 max_matches, int cull, DevPoint* dst) {
+  HIPCHK(hipMemsetAsync(h->d_pt_flags, 0, sizeof(u32) * (max_matches ? max_matches : 1), h->stream));
+  HIPCHK(hipMemsetAsync(h->d_counters + 2, 0, sizeof(u32), h->stream));
+  LmArgs a;
+  a.matches = h->d_matches; a.n_matches = h->d_counters + 0; a.max_matches = max_matches;
+  a.tsL = h->d_obs[0]; a.tsR = h->d_obs[1];
+  a.pose_T = h->d_pose_T; a.T_world_obs = h->d_T_world_obs;
+  a.out_slots = h->d_pt_slots; a.out_flags = h->d_pt_flags; a.cull = cull;
+  launch_lm_refine(a, h->dp, h->d_counters + 2, h->stream);
+  launch_exclusive_scan_u32(h->d_pt_flags, h->d_pt_prefix, h->d_counters + 1, h->d_scan_tmp, max_matches, h->stream);
+  launch_compact_points(h->d_pt_slots, h->d_pt_flags, h->d_pt_prefix, h->d_counters + 0, max_matches, dst, h->stream);
+  HIPCHK(hipGetLastError());
+  return ESVO_OK;
+}
+
+int read_counters(esvo_context* h) {
+  HIPCHK(hipMemcpyAsync(h->h_counters, h->d_counters, sizeof(u32) * 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return ESVO_OK;
+}
+
+// place a frame of up to n points in the window ring (frames stay contiguous)
+int window_reserve(esvo_context* h, u32 n, u32* off_out) {
+  u32 off = 0;
+  if (!h->frames.empty()) {
+    const FrameRec& back = h->frames.back();
+    const FrameRec& front = h->frames.front();
+    u32 tail = back.off + back.count;
+    if (tail >= front.off + 0 && back.off >= front.off) {  // not wrapped: [front.off, tail)
+      if (tail + n <= h->win_cap) off = tail;
+      else if (n <= front.off) off = 0;
+      else FAIL(ESVO_ERR_CAPACITY, "fusion window ring full (raise max_window_points)");
+    } else {  // wrapped: free space is [tail, front.off)
+      if (tail + n <= front.off) off = tail;
+      else FAIL(ESVO_ERR_CAPACITY, "fusion window ring full (raise max_window_points)");
+    }
+  } else if (n > h->win_cap) {
+    FAIL(ESVO_ERR_CAPACITY, "frame larger than the fusion window ring");
+  }
+  *off_out = off;
+  return ESVO_OK;
+}
+int alloc_pose_slot(esvo_context* h, u32* slot) {
+  for (u32 i = 0; i < h->n_pose_slots; ++i)
+    if (!h->slot_used[i]) { h->slot_used[i] = 1; *slot = i; return ESVO_OK; }
+  FAIL(ESVO_ERR_CAPACITY, "no free pose-table slot (too many frames in the fusion window)");
+}
+void pop_front_frame(esvo_context* h) {
+  h->slot_used[h->frames.front().slot] = 0;
+  h->frames.pop_front();
+}
+// window policy, esvo_Mapping.cpp:341-368
+void apply_window_policy(esvo_context* h) {
+  if (h->prm.fusion_strategy == ESVO_FUSION_CONST_POINTS) {
+    auto total = [&]() { size_t s = 0; for (auto& f : h->frames) s += f.count; return s; };
+    size_t np = total();
+    while ((double)np > 1.5 * (double)h->prm.max_fusion_points) { pop_front_frame(h); np = total(); }
+  } else {
+    while (h->frames.size() > (size_t)h->prm.max_fusion_frames) pop_front_frame(h);
+  }
+}
+
+int commit_frame(esvo_context* h, u32 off, u32 count, const double* pose_T_host, u32 m) {
+  u32 slot;
+  int rc = alloc_pose_slot(h, &slot);
+  if (rc) return rc;
+  if (m)
+    HIPCHK(hipMemcpyAsync(h->d_frame_pose_T + (size_t)slot * h->max_poses * 16, pose_T_host, sizeof(double) * 16 * m,
+                          hipMemcpyHostToDevice, h->stream));
+  h->frames.push_back(FrameRec{off, count, slot});
+  apply_window_policy(h);
+  if (h->frames.size() > h->max_frames) FAIL(ESVO_ERR_CAPACITY, "too many frames in the fusion window");
+  return ESVO_OK;
+}
+
+// fusion loop + clean + regularisation on the current window
+int run_fuse(esvo_context* h) {
+  // frames newest -> oldest (esvo_Mapping.cpp:372-377)
+  const u32 nf = (u32)h->frames.size();
+  u32* cum = h->h_fr_table;
+  u32* off = cum + (h->max_frames + 1);
+  u32* slot = off + h->max_frames;
+  u32 total = 0;
+  for (u32 i = 0; i < nf; ++i) {
+    const FrameRec& f = h->frames[nf - 1 - i];
+    cum[i] = total; off[i] = f.off; slot[i] = f.slot;
+    total += f.count;
+  }
+  cum[nf] = total;
+  HIPCHK(hipMemcpyAsync(h->d_fr_table, h->h_fr_table, sizeof(u32) * (3 * h->max_frames + 1), hipMemcpyHostToDevice, h->stream));
+  std::memcpy(h->T_world_frame, h->T_world_obs, sizeof(double) * 16);  // new DepthFrame at the TS pose (:268-272)
+  FuseArgs a;
+  a.win = h->d_win;
+  a.fr_cum = h->d_fr_table; a.fr_off = h->d_fr_table + (h->max_frames + 1); a.fr_slot = a.fr_off + h->max_frames;
+  a.n_frames = nf; a.n_pts = total;
+  a.frame_pose_T = h->d_frame_pose_T; a.max_poses = h->max_poses;
+  rigid_inverse(h->T_world_frame, a.T_frame_world);
+  a.prop = h->d_prop;
+  a.cell_count = h->d_cell_count; a.cell_offset = h->d_cell_offset; a.cell_fill = h->d_cell_fill;
+  a.rec_ids = h->d_rec_ids; a.scan_tmp = h->d_scan_tmp; a.d_total = h->d_counters + 4;
+  a.map = h->d_map; a.d_num_fusion = h->d_counters + 3;
+  if (total > h->win_cap) FAIL(ESVO_ERR_CAPACITY, "window points exceed capacity");
+  launch_fuse(a, h->dp, h->stream);
+  h->d_map_cur = h->d_map;
+  const bool do_clean = h->prm.clean_requires_full_window ? (h->frames.size() >= (size_t)h->prm.max_fusion_frames) : true;
+  if (do_clean) launch_clean(h->d_map, h->dp, h->stream);
+  if (h->evt_ok) hipEventRecord(h->evt[4], h->stream);
+  if (h->prm.regularization) {
+    launch_regularize(h->d_map, h->d_map2, h->d_owner_max, h->d_owner_min, h->dp, h->stream);
+    h->d_map_cur = h->d_map2;
+  }
+  if (h->evt_ok) hipEventRecord(h->evt[5], h->stream);
+  HIPCHK(hipGetLastError());
+  return ESVO_OK;
+}
+
+int export_map(esvo_context* h, std::vector<esvo_depth_point_t>& out, std::vector<u32>* cells) {
+  launch_map_compact(h->d_map_cur, h->d_exp_flags, h->d_exp_prefix, h->d_counters + 5, h->d_scan_tmp, h->d_export,
+                     h->d_export_cell, h->dp, h->stream);
+  int rc = read_counters(h);
+  if (rc) return rc;
+  const u32 n = h->h_counters[5];
+  out.resize(n);
+  std::vector<u32> cell(n);
+  if (n) {
+    HIPCHK(hipMemcpy(out.data(), h->d_export, sizeof(esvo_depth_point_t) * n, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(cell.data(), h->d_export_cell, sizeof(u32) * n, hipMemcpyDeviceToHost));
+  }
+  // the reference iterates its element list in creation order
+  std::vector<u32> order(n);
+  for (u32 i = 0; i < n; ++i) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](u32 a, u32 b) { return out[a].seq < out[b].seq; });
+  std::vector<esvo_depth_point_t> sorted(n);
+  if (cells) cells->resize(n);
+  for (u32 i = 0; i < n; ++i) {
+    sorted[i] = out[order[i]];
+    sorted[i].seq = i;
+    if (cells) (*cells)[i] = cell[order[i]];
+  }
+  out.swap(sorted);
+  h->stats.last_map_size = n;
+  return ESVO_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+void esvo_default_params(esvo_params_t* p) {
+  std::memset(p, 0, sizeof(*p));
+  p->decay_ms = 30; p->median_blur_kernel_size = 1; p->ignore_polarity = 1;
+  p->patch_size_x = 25; p->patch_size_y = 25; p->ls_norm = ESVO_LSNORM_TDIST;
+  p->td_nu = 0; p->td_scale = 0; p->lm_max_iteration = 10;
+  p->reg_radius = 5; p->reg_min_neighbours = 8; p->reg_min_close_neighbours = 8;
+  p->bm_min_disparity = 3; p->bm_max_disparity = 40; p->bm_step = 1; p->bm_zncc_threshold = 0.1;
+  p->invdepth_min = 0.16; p->invdepth_max = 2.0; p->stdvar_vis_threshold = 0.005; p->residual_vis_threshold = 15;
+  p->age_vis_threshold = 0; p->fusion_radius = 0; p->fusion_strategy = ESVO_FUSION_CONST_FRAMES;
+  p->max_fusion_frames = 10; p->max_fusion_points = 2000; p->clean_requires_full_window = 1;
+  p->process_event_num = 500; p->bm_half_slice_thickness = 0.001; p->num_threads = 4;
+  p->max_events_per_tick = 1024; p->max_window_points = 20000; p->max_poses_per_tick = 256;
+  p->event_ring_capacity = 1 << 24;
+}
+
+const char* esvo_last_error(esvo_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esvo_calib_t* right, int device,
+                esvo_handle* out) {
+  esvo_context* h = nullptr;
+  if (!params || !left || !right || !out) FAIL(ESVO_ERR_INVALID_ARG, "null argument");
+  if (left->width != right->width || left->height != right->height || left->width <= 0 || left->height <= 0)
+    FAIL(ESVO_ERR_INVALID_ARG, "left/right image sizes differ or are empty");
+  if (!left->rect_lut || !left->map_x || !left->map_y || !right->map_x || !right->map_y)
+    FAIL(ESVO_ERR_INVALID_ARG, "calibration arrays missing");
+  {
+    std::string why;
+    int rc = validate_params(params, why);
+    if (rc) FAIL(rc, why);
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    FAIL(ESVO_ERR_NO_DEVICE, "no HIP device visible: the ESVO hot path has no CPU fallback");
+  if (device < 0 || device >= ndev) FAIL(ESVO_ERR_INVALID_ARG, "device ordinal out of range");
+  HIPCHK(hipSetDevice(device));
+  h = new esvo_context();
+  h->prm = *params;
+  h->device = device;
+  h->W = left->width; h->H = left->height;
+  const size_t npx = (size_t)h->W * h->H;
+  std::memset(&h->stats, 0, sizeof(h->stats));
+  std::memcpy(h->dp.camL.P, left->P, sizeof(double) * 12);
+  std::memcpy(h->dp.camR.P, right->P, sizeof(double) * 12);
+  invert3x3(left->P, h->dp.camL.Kinv, h->dp.camL.Kinv_t);
+  invert3x3(right->P, h->dp.camR.Kinv, h->dp.camR.Kinv_t);
+  {  // CameraSystem::computeBaseline, CameraSystem.cpp:161-166
+    const double* t = h->dp.camR.Kinv_t;
+    h->baseline = std::sqrt((t[0] * t[0] + t[1] * t[1]) + t[2] * t[2]);
+  }
+  h->dp.band_y0 = 0; h->dp.band_y1 = h->H;
+  fill_dev_params(h);
+
+#define CK(call) do { hipError_t _e = (call); if (_e != hipSuccess) { g_create_error = std::string(#call) + ": " + hipGetErrorString(_e); esvo_destroy(h); return ESVO_ERR_HIP; } } while (0)
+  CK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  h->own_stream = true;
+  // calibration -> device
+  CK(dalloc(&h->d_lut, npx));
+  CK(hipMemcpy(h->d_lut, left->rect_lut, sizeof(float2) * npx, hipMemcpyHostToDevice));
+  if (left->rect_mask) {
+    CK(dalloc(&h->d_mask, npx));
+    CK(hipMemcpy(h->d_mask, left->rect_mask, npx, hipMemcpyHostToDevice));
+  }
+  for (int cam = 0; cam < 2; ++cam) {
+    const esvo_calib_t* c = cam ? right : left;
+    std::vector<int2> fm(npx);
+    for (size_t i = 0; i < npx; ++i) {  // OpenCV remap's INTER_BITS=5 coordinate quantisation (Appendix B.2)
+      fm[i].x = (int)std::nearbyintf(c->map_x[i] * 32.f);
+      fm[i].y = (int)std::nearbyintf(c->map_y[i] * 32.f);
+    }
+    CK(dalloc(&h->d_fixmap[cam], npx));
+    CK(hipMemcpy(h->d_fixmap[cam], fm.data(), sizeof(int2) * npx, hipMemcpyHostToDevice));
+    CK(dalloc(&h->d_sae[cam], npx));
+    CK(hipMemset(h->d_sae[cam], 0, sizeof(u64) * npx));
+    CK(dalloc(&h->d_ts[cam], npx));
+    CK(dalloc(&h->d_obs[cam], npx));
+  }
+  CK(dalloc(&h->d_raw, npx));
+  CK(dalloc(&h->d_obs_tmp, npx));
+  h->ring_cap = (u64)std::max<int64_t>(params->event_ring_capacity, 1024);
+  for (int cam = 0; cam < 2; ++cam) CK(dalloc(&h->d_ring[cam], h->ring_cap));
+  CK(dalloc(&h->d_T_world_obs, 16));
+  h->max_poses = (u32)std::max(params->max_poses_per_tick, 2);
+  CK(dalloc(&h->d_pose_sec, h->max_poses));
+  CK(dalloc(&h->d_pose_T, (size_t)h->max_poses * 16));
+  h->max_ev = (u32)std::max(params->max_events_per_tick, params->process_event_num);
+  if (h->max_ev > 4000000u) { g_create_error = "max_events_per_tick too large (scan limit 4M)"; esvo_destroy(h); return ESVO_ERR_CAPACITY; }
+  if (npx > 4000000u) { g_create_error = "image too large (scan limit 4M pixels)"; esvo_destroy(h); return ESVO_ERR_CAPACITY; }
+  const size_t E = h->max_ev;
+  CK(dalloc(&h->d_tick_ev, E));
+  CK(dalloc(&h->d_match_slots, E));
+  CK(dalloc(&h->d_match_flags, E));
+  CK(dalloc(&h->d_match_prefix, E));
+  CK(dalloc(&h->d_matches, E));
+  CK(dalloc(&h->d_pt_slots, E));
+  CK(dalloc(&h->d_pt_flags, E));
+  CK(dalloc(&h->d_pt_prefix, E));
+  CK(dalloc(&h->d_pts_tmp, E));
+  CK(dalloc(&h->d_counters, 8));
+  CK(hipMemset(h->d_counters, 0, sizeof(u32) * 8));
+  CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_counters), sizeof(u32) * 8));
+  CK(dalloc(&h->d_scan_tmp, scan_scratch_elems(std::max(E, npx)) + 8));
+  // fusion window
+  h->win_cap = (u32)std::max<int64_t>((int64_t)params->max_window_points, (int64_t)E) + (u32)E;
+  CK(dalloc(&h->d_win, h->win_cap));
+  h->max_frames = (u32)std::max(params->max_fusion_frames + 2, 512);
+  h->n_pose_slots = h->max_frames + 1;
+  h->slot_used.assign(h->n_pose_slots, 0);
+  CK(dalloc(&h->d_frame_pose_T, (size_t)h->n_pose_slots * h->max_poses * 16));
+  CK(dalloc(&h->d_fr_table, 3 * (size_t)h->max_frames + 1));
+  CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_fr_table), sizeof(u32) * (3 * (size_t)h->max_frames + 1)));
+  // map
+  CK(dalloc(&h->d_prop, h->win_cap));
+  CK(dalloc(&h->d_cell_count, npx));
+  CK(dalloc(&h->d_cell_offset, npx));
+  CK(dalloc(&h->d_cell_fill, npx));
+  CK(dalloc(&h->d_rec_ids, (size_t)h->win_cap * 9));
+  CK(dalloc(&h->d_map, npx));
+  CK(dalloc(&h->d_map2, npx));
+  CK(hipMemset(h->d_map, 0, sizeof(MapCell) * npx));
+  CK(hipMemset(h->d_map2, 0, sizeof(MapCell) * npx));
+  h->d_map_cur = h->d_map;
+  CK(dalloc(&h->d_owner_max, npx));
+  CK(dalloc(&h->d_owner_min, npx));
+  CK(dalloc(&h->d_exp_flags, npx));
+  CK(dalloc(&h->d_exp_prefix, npx));
+  CK(dalloc(&h->d_export, npx));
+  CK(dalloc(&h->d_export_cell, npx));
+  for (int i = 0; i < 8; ++i) CK(hipEventCreate(&h->evt[i]));
+  h->evt_ok = true;
+  for (int i = 0; i < 16; ++i) h->T_world_obs[i] = h->T_world_frame[i] = (i % 5 == 0) ? 1.0 : 0.0;
+  CK(hipMemcpy(h->d_T_world_obs, h->T_world_obs, sizeof(double) * 16, hipMemcpyHostToDevice));
+#undef CK
+  *out = h;
+  return ESVO_OK;
+}
+
+int esvo_destroy(esvo_handle h) {
+  if (!h) return ESVO_OK;
+  hipSetDevice(h->device);
+  if (h->stream) hipStreamSynchronize(h->stream);
+  void* ptrs[] = {h->d_lut, h->d_mask, h->d_fixmap[0], h->d_fixmap[1], h->d_sae[0], h->d_sae[1], h->d_raw, h->d_ts[0],
+                  h->d_ts[1], h->d_ring[0], h->d_ring[1], h->d_obs[0], h->d_obs[1], h->d_obs_tmp, h->d_T_world_obs,
+                  h->d_pose_sec, h->d_pose_T, h->d_tick_ev, h->d_match_slots, h->d_match_flags, h->d_match_prefix,
+                  h->d_matches, h->d_pt_slots, h->d_pt_flags, h->d_pt_prefix, h->d_pts_tmp, h->d_counters, h->d_scan_tmp,
+                  h->d_win, h->d_frame_pose_T, h->d_fr_table, h->d_prop, h->d_cell_count, h->d_cell_offset,
+                  h->d_cell_fill, h->d_rec_ids, h->d_map, h->d_map2, h->d_owner_max, h->d_owner_min, h->d_exp_flags,
+                  h->d_exp_prefix, h->d_export, h->d_export_cell};
+  for (void* p : ptrs) if (p) hipFree(p);
+  if (h->h_counters) hipHostFree(h->h_counters);
+  if (h->h_fr_table) hipHostFree(h->h_fr_table);
+  if (h->evt_ok) for (int i = 0; i < 8; ++i) hipEventDestroy(h->evt[i]);
+  if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+  delete h;
+  return ESVO_OK;
+}
+
+int esvo_reset(esvo_handle h) {
+  if (!h) return ESVO_ERR_INVALID_ARG;
+  HIPCHK(hipSetDevice(h->device));
+  const size_t npx = (size_t)h->W * h->H;
+  for (int cam = 0; cam < 2; ++cam) {
+    HIPCHK(hipMemsetAsync(h->d_sae[cam], 0, sizeof(u64) * npx, h->stream));
+    h->ts_host[cam].clear();
+    h->ring_base[cam] = h->ring_next[cam] = h->scattered[cam] = 0;
+    h->ts_valid[cam] = false;
+  }
+  h->frames.clear();
+  std::fill(h->slot_used.begin(), h->slot_used.end(), 0);
+  HIPCHK(hipMemsetAsync(h->d_map, 0, sizeof(MapCell) * npx, h->stream));
+  HIPCHK(hipMemsetAsync(h->d_map2, 0, sizeof(MapCell) * npx, h->stream));
+  h->d_map_cur = h->d_map;
+  h->obs_set = false;
+  h->n_pose = 0;
+  std::memset(&h->stats, 0, sizeof(h->stats));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return ESVO_OK;
+}
+
+int esvo_set_params(esvo_handle h, const esvo_params_t* params) {
+  if (!h || !params) return ESVO_ERR_INVALID_ARG;
+  std::string why;
+  int rc = validate_params(params, why);
+  if (rc) FAIL(rc, why);
+  if ((u32)std::max(params->max_events_per_tick, params->process_event_num) > h->max_ev)
+    FAIL(ESVO_ERR_CAPACITY, "process_event_num exceeds the capacity fixed at esvo_create");
+  esvo_params_t np = *params;
+  np.max_events_per_tick = h->prm.max_events_per_tick;
+  np.max_window_points = h->prm.max_window_points;
+  np.max_poses_per_tick = h->prm.max_poses_per_tick;
+  np.event_ring_capacity = h->prm.event_ring_capacity;
+  h->prm = np;
+  fill_dev_params(h);
+  return ESVO_OK;
+}
+
+int esvo_set_stream(esvo_handle h, void* hip_stream) {
+  if (!h) return ESVO_ERR_INVALID_ARG;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+  h->stream = reinterpret_cast<hipStream_t>(hip_stream);
+  h->own_stream = false;
+  return ESVO_OK;
+}
+
+int esvo_synchronize(esvo_handle h) {
+  if (!h) return ESVO_ERR_INVALID_ARG;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return ESVO_OK;
+}
+
+// ---- Time Surface ---------------------------------------------------------------------------------
+int esvo_ts_push_events(esvo_handle h, int cam, const esvo_event_t* ev, size_t n) {
+  if (!h || cam < 0 || cam > 1 || (n && !ev)) return ESVO_ERR_INVALID_ARG;
+  if (n == 0) return ESVO_OK;
+  if (n > h->ring_cap) FAIL(ESVO_ERR_CAPACITY, "event block larger than the event ring");
+  HIPCHK(hipSetDevice(h->device));
+  auto& tsq = h->ts_host[cam];
+  u64 last = tsq.empty() ? 0 : tsq.back();
+  for (size_t i = 0; i < n; ++i) {
+    const u64 t = (u64)ev[i].sec * 1000000000ull + ev[i].nsec;
+    if (t < last) FAIL(ESVO_ERR_INVALID_ARG, "events must be sorted by time stamp (SURVEY Appendix A-1)");
+    last = t;
+  }
+  // the ring must not overwrite events that are not yet scattered into the SAE
+  if (h->ring_next[cam] + n - h->scattered[cam] > h->ring_cap)
+    FAIL(ESVO_ERR_CAPACITY, "event ring full: render (scatter) before staging more events");
+  const u64 slot = h->ring_next[cam] % h->ring_cap;
+  const size_t first = (size_t)std::min<u64>(n, h->ring_cap - slot);
+  HIPCHK(hipMemcpyAsync(h->d_ring[cam] + slot, ev, sizeof(esvo_event_t) * first, hipMemcpyHostToDevice, h->stream));
+  if (first < n)
+    HIPCHK(hipMemcpyAsync(h->d_ring[cam], ev + first, sizeof(esvo_event_t) * (n - first), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));  // `ev` is borrowed for the duration of the call only
+  for (size_t i = 0; i < n; ++i) tsq.push_back((u64)ev[i].sec * 1000000000ull + ev[i].nsec);
+  h->ring_next[cam] += n;
+  while (tsq.size() > h->ring_cap) { tsq.pop_front(); h->ring_base[cam]++; }
+  h->stats.events_staged[cam] += n;
+  return ESVO_OK;
+}
+
+int esvo_ts_render(esvo_handle h, int cam, uint64_t t_ns, uint8_t* out_mono8) {
+  if (!h || cam < 0 || cam > 1) return ESVO_ERR_INVALID_ARG;
+  HIPCHK(hipSetDevice(h->device));
+  // events with ts < T (strict, TimeSurface.h:68) that are not in the SAE yet
+  const auto& tsq = h->ts_host[cam];
+  const size_t k = std::lower_bound(tsq.begin(), tsq.end(), (u64)t_ns) - tsq.begin();
+  const u64 upto = h->ring_base[cam] + k;
+  if (h->evt_ok) hipEventRecord(h->evt[0], h->stream);
+  if (upto > h->scattered[cam]) {
+    u64 a = h->scattered[cam];
+    const u64 total = upto - a;
+    while (a < upto) {
+      const u64 slot = a % h->ring_cap;
+      const u64 cnt = std::min<u64>(upto - a, h->ring_cap - slot);
+      launch_ts_scatter(h->d_ring[cam] + slot, (size_t)cnt, h->d_sae[cam], h->W, h->H, h->stream);
+      a += cnt;
+    }
+    h->scattered[cam] = upto;
+    h->stats.events_scattered[cam] += total;
+  }
+  if (h->evt_ok) hipEventRecord(h->evt[1], h->stream);
+  launch_ts_render(h->d_sae[cam], h->d_fixmap[cam], h->d_raw, h->d_ts[cam], h->W, h->H, (u64)t_ns, h->prm.decay_ms / 1000.0,
+                   h->prm.ignore_polarity, h->prm.median_blur_kernel_size, h->stream);
+  if (h->evt_ok) hipEventRecord(h->evt[2], h->stream);
+  HIPCHK(hipGetLastError());
+  h->ts_valid[cam] = true;
+  h->stats.ts_frames[cam]++;
+  if (out_mono8) {
+    HIPCHK(hipMemcpyAsync(out_mono8, h->d_ts[cam], (size_t)h->W * h->H, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->evt_ok) {
+      hipEventElapsedTime(&h->stats.ms_ts_scatter, h->evt[0], h->evt[1]);
+      hipEventElapsedTime(&h->stats.ms_ts_render, h->evt[1], h->evt[2]);
+    }
+  }
+  return ESVO_OK;
+}
+
+// ---- Mapper: stage-wise ---------------------------------------------------------------------------
+int esvo_map_set_observation(esvo_handle h, uint64_t t_ns, const uint8_t* ts_left, const uint8_t* ts_right,
+                             const double T_world_cam[16]) {
+  if (!h || !T_world_cam) return ESVO_ERR_INVALID_ARG;
+  HIPCHK(hipSetDevice(h->device));
+  const size_t npx = (size_t)h->W * h->H;
+  const uint8_t* src[2] = {ts_left, ts_right};
+  for (int cam = 0; cam < 2; ++cam) {
+    uint8_t* dst = h->prm.smooth_time_surface ? h->d_obs_tmp : h->d_obs[cam];
+    if (src[cam]) {
+      HIPCHK(hipMemcpyAsync(dst, src[cam], npx, hipMemcpyHostToDevice, h->stream));
+      HIPCHK(hipStreamSynchronize(h->stream));
+    } else {
+      if (!h->ts_valid[cam]) FAIL(ESVO_ERR_STATE, "no device-resident Time Surface: call esvo_ts_render first");
+      HIPCHK(hipMemcpyAsync(dst, h->d_ts[cam], npx, hipMemcpyDeviceToDevice, h->stream));
+    }
+    // createMatchProblem applies GaussianBlurTS(5) when SmoothTimeSurface (EventBM.cpp:68-72)
+    if (h->prm.smooth_time_surface) launch_gaussian5(h->d_obs_tmp, h->d_obs[cam], h->W, h->H, h->stream);
+  }
+  std::memcpy(h->T_world_obs, T_world_cam, sizeof(double) * 16);
+  HIPCHK(hipMemcpyAsync(h->d_T_world_obs, h->T_world_obs, sizeof(double) * 16, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->obs_t_ns = t_ns;
+  h->obs_set = true;
+  return ESVO_OK;
+}
+
+int esvo_map_set_poses(esvo_handle h, const uint64_t* pose_t_ns, const double* pose_T, size_t m) {
+  if (!h || (m && (!pose_t_ns || !pose_T))) return ESVO_ERR_INVALID_ARG;
+  HIPCHK(hipSetDevice(h->device));
+  return upload_poses(h, pose_t_ns, pose_T, m);
+}
+
+int esvo_map_match(esvo_handle h, const esvo_event_t* ev, size_t n, const uint64_t* pose_t_ns, const double* pose_T,
+                   size_t m, esvo_match_t* out, size_t cap, size_t* n_out) {
+  if (!h || (n && !ev) || !n_out) return ESVO_ERR_INVALID_ARG;
+  if (!h->obs_set) FAIL(ESVO_ERR_STATE, "esvo_map_set_observation has not been called");
+  if (n > h->max_ev) FAIL(ESVO_ERR_CAPACITY, "more events than max_events_per_tick");
+  HIPCHK(hipSetDevice(h->device));
+  if (pose_t_ns) { int rc = upload_poses(h, pose_t_ns, pose_T, m); if (rc) return rc; }
+  *n_out = 0;
+  if (n == 0) { HIPCHK(hipMemsetAsync(h->d_counters, 0, sizeof(u32), h->stream)); return ESVO_OK; }
+  HIPCHK(hipMemcpyAsync(h->d_tick_ev, ev, sizeof(esvo_event_t) * n, hipMemcpyHostToDevice, h->stream));
+  int rc = run_match(h, h->d_tick_ev, 0, (u64)h->max_ev, 0, (u32)n);
+  if (rc) return rc;
+  rc = read_counters(h);
+  if (rc) return rc;
+  const u32 nm = h->h_counters[0];
+  *n_out = nm;
+  h->stats.last_events_in = (u32)n;
+  h->stats.last_matches = nm;
+  if (out && nm) {
+    if (nm > cap) FAIL(ESVO_ERR_CAPACITY, "output array too small for the matches");
+    HIPCHK(hipMemcpy(out, h->d_matches, sizeof(esvo_match_t) * nm, hipMemcpyDeviceToHost));
+  }
+  return ESVO_OK;
+}
+
+int esvo_map_refine(esvo_handle h, const esvo_match_t* matches, size_t n, int cull, esvo_depth_point_t* out, size_t cap,
+                    size_t* n_out) {
+  if (!h || (n && !matches) || !n_out) return ESVO_ERR_INVALID_ARG;
+  if (!h->obs_set) FAIL(ESVO_ERR_STATE, "esvo_map_set_observation has not been called");
+  if (n > h->max_ev) FAIL(ESVO_ERR_CAPACITY, "more matches than max_events_per_tick");
+  for (size_t i = 0; i < n; ++i)
+    if (matches[i].pose_idx >= h->n_pose) FAIL(ESVO_ERR_INVALID_ARG, "match refers to a pose outside the pose table");
+  HIPCHK(hipSetDevice(h->device));
+  *n_out = 0;
+  if (n == 0) return ESVO_OK;
+  const u32 n32 = (u32)n;
+  HIPCHK(hipMemcpyAsync(h->d_matches, matches, sizeof(esvo_match_t) * n, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->d_counters, &n32, sizeof(u32), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  int rc = run_refine(h, n32, cull, h->d_pts_tmp);
+  if (rc) return rc;
+  rc = read_counters(h);
+  if (rc) return rc;
+  const u32 np = h->h_counters[1];
+  *n_out = np;
+  h->stats.last_solved = h->h_counters[2];
+  h->stats.last_points = np;
+  if (out && np) {
+    if (np > cap) FAIL(ESVO_ERR_CAPACITY, "output array too small for the depth points");
+    HIPCHK(hipMemcpy(out, h->d_pts_tmp, sizeof(esvo_depth_point_t) * np, hipMemcpyDeviceToHost));
+  }
+  return ESVO_OK;
+}
+
+int esvo_map_push_frame(esvo_handle h, const esvo_depth_point_t* pts, size_t n, const double* pose_T, size_t m) {
+  if (!h || (n && !pts) || (m && !pose_T)) return ESVO_ERR_INVALID_ARG;
+  if (m > h->max_poses) FAIL(ESVO_ERR_CAPACITY, "pose table larger than max_poses_per_tick");
+  for (size_t i = 0; i < n; ++i)
+    if (pts[i].pose_idx >= m) FAIL(ESVO_ERR_INVALID_ARG, "depth point refers to a pose outside the frame's pose table");
+  HIPCHK(hipSetDevice(h->device));
+  u32 off;
+  int rc = window_reserve(h, (u32)n, &off);
+  if (rc) return rc;
+  if (n) HIPCHK(hipMemcpyAsync(h->d_win + off, pts, sizeof(esvo_depth_point_t) * n, hipMemcpyHostToDevice, h->stream));
+  rc = commit_frame(h, off, (u32)n, pose_T, (u32)m);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return ESVO_OK;
+}
+
+int esvo_map_fuse(esvo_handle h, size_t* n_fusions) {
+  if (!h) return ESVO_ERR_INVALID_ARG;
+  if (!h->obs_set) FAIL(ESVO_ERR_STATE, "esvo_map_set_observation has not been called");
+  HIPCHK(hipSetDevice(h->device));
+  if (h->evt_ok) hipEventRecord(h->evt[3], h->stream);
+  int rc = run_fuse(h);
+  if (rc) return rc;
+  rc = read_counters(h);
+  if (rc) return rc;
+  h->stats.last_fusions = h->h_counters[3];
+  h->stats.last_window_frames = (u32)h->frames.size();
+  u32 np = 0;
+  for (auto& f : h->frames) np += f.count;
+  h->stats.last_window_points = np;
+  if (h->evt_ok) {
+    hipEventElapsedTime(&h->stats.ms_fusion, h->evt[3], h->evt[4]);
+    hipEventElapsedTime(&h->stats.ms_regularization, h->evt[4], h->evt[5]);
+  }
+  if (n_fusions) *n_fusions = h->h_counters[3];
+  return ESVO_OK;
+}
+
+// ---- Mapper: fused tick ---------------------------------------------------------------------------
+int esvo_map_tick(esvo_handle h, uint64_t t_ns, const uint64_t* pose_t_ns, const double* pose_T, size_t m) {
+  if (!h || !pose_t_ns || !pose_T) return ESVO_ERR_INVALID_ARG;
+  if (!h->obs_set) FAIL(ESVO_ERR_STATE, "esvo_map_set_observation has not been called");
+  HIPCHK(hipSetDevice(h->device));
+  int rc = upload_poses(h, pose_t_ns, pose_T, m);
+  if (rc) return rc;
+  // ---- event selection, esvo_Mapping.cpp:562-574 (Appendix A-3): walk back from
+  // lower_bound(t_end) to lower_bound(t_begin), newest first, at most PROCESS_EVENT_NUM ----
+  const double t_end = ns_to_sec(t_ns);
+  const u64 t_begin_ns = ros_time_from_sec(std::max(0.0, t_end - 10 * h->prm.bm_half_slice_thickness));
+  const double t_begin = ns_to_sec(t_begin_ns);
+  u64 it_end = lower_bound_sec(h, 0, t_end);
+  const u64 it_begin = lower_bound_sec(h, 0, t_begin);
+  const u64 staged_end = h->ring_base[0] + h->ts_host[0].size();
+  u64 avail = it_end - it_begin;
+  u64 first = it_end;
+  if (it_end == staged_end && avail > 0) { first = it_end - 1; avail -= 1; }  // end() is skipped (oracle definition)
+  const u32 n = (u32)std::min<u64>(avail, (u64)h->prm.process_event_num);
+  if (n > h->max_ev) FAIL(ESVO_ERR_CAPACITY, "more events than max_events_per_tick");
+  if (n && first - (n - 1) < h->ring_next[0] - std::min<u64>(h->ring_next[0], h->ring_cap))
+    FAIL(ESVO_ERR_STATE, "selected events were already overwritten in the event ring");
+
+  hipEventRecord(h->evt[6], h->stream);
+  HIPCHK(hipMemsetAsync(h->d_counters, 0, sizeof(u32) * 8, h->stream));
+  if (n) { rc = run_match(h, h->d_ring[0], first, h->ring_cap, 1, n); if (rc) return rc; }
+  hipEventRecord(h->evt[7], h->stream);
+  // the new frame goes straight into the window ring (capacity for the worst case: n points)
+  u32 off;
+  rc = window_reserve(h, n, &off);
+  if (rc) return rc;
+  if (n) { rc = run_refine(h, n, 1, h->d_win + off); if (rc) return rc; }
+  hipEventRecord(h->evt[3], h->stream);
+  rc = read_counters(h);  // the window policy needs the point count (one small D2H per tick)
+  if (rc) return rc;
+  const u32 n_matches = h->h_counters[0], n_points = n ? h->h_counters[1] : 0, n_solved = h->h_counters[2];
+  rc = commit_frame(h, off, n_points, h->h_pose_T.data(), h->n_pose);
+  if (rc) return rc;
+  rc = run_fuse(h);
+  if (rc) return rc;
+  rc = read_counters(h);
+  if (rc) return rc;
+  esvo_stats_t& s = h->stats;
+  s.ticks++;
+  s.last_events_in = n; s.last_matches = n_matches; s.last_solved = n_solved; s.last_points = n_points;
+  s.last_fusions = h->h_counters[3];
+  s.last_window_frames = (u32)h->frames.size();
+  u32 np = 0;
+  for (auto& f : h->frames) np += f.count;
+  s.last_window_points = np;
+  hipEventElapsedTime(&s.ms_bm, h->evt[6], h->evt[7]);
+  hipEventElapsedTime(&s.ms_refine, h->evt[7], h->evt[3]);
+  hipEventElapsedTime(&s.ms_fusion, h->evt[3], h->evt[4]);
+  hipEventElapsedTime(&s.ms_regularization, h->evt[4], h->evt[5]);
+  hipEventElapsedTime(&s.ms_tick_total, h->evt[6], h->evt[5]);
+  return ESVO_OK;
+}
+
+// ---- Outputs -----------------------------------------------------------------------------------------
+int esvo_map_get_depth_points(esvo_handle h, esvo_depth_point_t* out, size_t cap, size_t* n) {
+  if (!h || !n) return ESVO_ERR_INVALID_ARG;
+  HIPCHK(hipSetDevice(h->device));
+  std::vector<esvo_depth_point_t> v;
+  int rc = export_map(h, v, nullptr);
+  if (rc) return rc;
+  *n = v.size();
+  if (out) {
+    if (v.size() > cap) FAIL(ESVO_ERR_CAPACITY, "output array too small for the DepthMap");
+    if (!v.empty()) std::memcpy(out, v.data(), sizeof(esvo_depth_point_t) * v.size());
+  }
+  return ESVO_OK;
+}
+
+int esvo_map_get_pointcloud_xyz(esvo_handle h, float* out_xyz, size_t cap_points, size_t* n) {
+  if (!h || !n) return ESVO_ERR_INVALID_ARG;
+  HIPCHK(hipSetDevice(h->device));
+  std::vector<esvo_depth_point_t> v;
+  int rc = export_map(h, v, nullptr);
+  if (rc) return rc;
+  *n = v.size();
+  if (out_xyz) {
+    if (v.size() > cap_points) FAIL(ESVO_ERR_CAPACITY, "output array too small for the point cloud");
+    const double* T = h->T_world_frame;  // publishPointCloud, esvo_Mapping.cpp:925-932
+    for (size_t i = 0; i < v.size(); ++i)
+      for (int r = 0; r < 3; ++r)
+        out_xyz[3 * i + r] = (float)(((T[r * 4 + 0] * v[i].p_cam[0] + T[r * 4 + 1] * v[i].p_cam[1]) + T[r * 4 + 2] * v[i].p_cam[2]) + T[r * 4 + 3]);
+  }
+  return ESVO_OK;
+}
+
+int esvo_map_get_last_frame(esvo_handle h, esvo_depth_point_t* out, size_t cap, size_t* n) {
+  if (!h || !n) return ESVO_ERR_INVALID_ARG;
+  HIPCHK(hipSetDevice(h->device));
+  *n = 0;
+  if (h->frames.empty()) return ESVO_OK;
+  const FrameRec& f = h->frames.back();
+  *n = f.count;
+  if (out && f.count) {
+    if (f.count > cap) FAIL(ESVO_ERR_CAPACITY, "output array too small for the frame");
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(out, h->d_win + f.off, sizeof(esvo_depth_point_t) * f.count, hipMemcpyDeviceToHost));
+  }
+  return ESVO_OK;
+}
+
+int esvo_get_stats(esvo_handle h, esvo_stats_t* out) {
+  if (!h || !out) return ESVO_ERR_INVALID_ARG;
+  *out = h->stats;
+  return ESVO_OK;
+}
+
+// ---- Multi-GPU row-band sharding ------------------------------------------------------------------
+int esvo_shard_set_band(esvo_handle h, int row_begin, int row_end) {
+  if (!h || row_begin < 0 || row_end > h->H || row_begin >= row_end) return ESVO_ERR_INVALID_ARG;
+  h->dp.band_y0 = row_begin;
+  h->dp.band_y1 = row_end;
+  return ESVO_OK;
+}
+
+int esvo_shard_buffers(esvo_handle h, esvo_shard_buffers_t* out) {
+  if (!h || !out) return ESVO_ERR_INVALID_ARG;
+  out->d_match_flags = h->d_match_flags; out->match_flags_bytes = sizeof(u32) * h->max_ev;
+  out->d_point_flags = h->d_pt_flags;    out->point_flags_bytes = sizeof(u32) * h->max_ev;
+  out->d_point_slots = h->d_pt_slots;    out->point_slots_bytes = sizeof(DevPoint) * h->max_ev;
+  out->d_map_cells = h->d_map_cur;       out->map_cells_bytes = sizeof(MapCell) * (size_t)h->W * h->H;
+  out->map_cell_stride = sizeof(MapCell);
+  return ESVO_OK;
+}
+
+int esvo_shard_tick_phase(esvo_handle h, int phase, uint64_t t_ns, const uint64_t* pose_t_ns, const double* pose_T,
+                          size_t m) {
+  (void)phase; (void)t_ns; (void)pose_t_ns; (void)pose_T; (void)m;
+  FAIL(ESVO_ERR_UNSUPPORTED, "esvo_shard_tick_phase: not implemented yet");
+}
+
+}  // extern "C"

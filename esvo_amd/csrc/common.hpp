@@ -1,0 +1,212 @@
+// common.hpp — shared host/device definitions of the MI355X ESVO hot path (gfx950 only).
+//
+// Build flags (see __graft_entry__.build): hipcc --offload-arch=gfx950 -O3 -std=c++17
+// -ffp-contract=off.  Contraction is off on purpose: the f64 stages restate the reference's
+// arithmetic expression by expression so that results are reproducible against the CPU oracle.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/esvo_hip.h"
+
+#define ESVO_WAVE 64
+
+namespace esvo {
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+// Rectified pin-hole model of one camera + the closed-form cam2World constants
+// (PerspectiveCamera::cam2World / world2Cam, CameraSystem.cpp:121-148).
+struct CamConst {
+  double P[12];      // 3x4 projection, row-major
+  double Kinv[9];    // inverse of P[:, :3]
+  double Kinv_t[3];  // Kinv * P[:, 3]
+};
+
+// Parameters the kernels read (a by-value kernel argument: lives in SGPRs / kernarg segment).
+struct DevParams {
+  int W, H;
+  int wx, wy;                    // patch size
+  int dmin, dmax, step;          // effective disparity range
+  double zncc_thr;               // BM_ZNCC_Threshold
+  double baseline_f;             // baseline * P_left(0,0)
+  double td_nu, td_scale, td_scale2, td_stdvar2;
+  int lm_max_iter, lm_maxfev;
+  double invdepth_min, invdepth_max;
+  double var_thr;                // stdVar_vis_threshold^2
+  double cost_thr;               // residual_vis_threshold^2 * patch area
+  double age_thr;
+  int fusion_radius;
+  int reg_radius, reg_min_nb, reg_min_close;
+  int num_threads;               // stride-N output permutation
+  int band_y0, band_y1;          // row band owned by this handle (0,H when unsharded)
+  CamConst camL, camR;
+};
+
+// ---- ros::Time arithmetic (roscpp) ---------------------------------------------------------
+__host__ __device__ inline double time_to_sec(u32 sec, u32 nsec) { return (double)sec + 1e-9 * (double)nsec; }
+__host__ __device__ inline double ns_to_sec(u64 ns) {
+  return time_to_sec((u32)(ns / 1000000000ull), (u32)(ns % 1000000000ull));
+}
+__host__ __device__ inline double duration_to_sec(u64 later_ns, u64 earlier_ns) {
+  long long d = (long long)(later_ns - earlier_ns);
+  long long sec = d / 1000000000ll, nsec = d % 1000000000ll;
+  if (nsec < 0) { nsec += 1000000000ll; sec -= 1; }
+  return (double)sec + 1e-9 * (double)nsec;
+}
+
+// ---- stride-N thread emulation (EventBM.cpp:289-308, DepthProblemSolver.cpp:75-90) ---------
+// The reference hands item i to thread i % T and concatenates the per-thread outputs.  Slot w
+// of that concatenation holds item stride_item(w, n, T).
+__host__ __device__ inline u32 stride_item(u32 w, u32 n, u32 T) {
+  u32 off = 0;
+  for (u32 t = 0; t < T; ++t) {
+    u32 cnt = (n > t) ? (n - t + T - 1) / T : 0;
+    if (w < off + cnt) return t + (w - off) * T;
+    off += cnt;
+  }
+  return n;  // out of range
+}
+// inverse: the slot of item i
+__host__ __device__ inline u32 stride_slot(u32 i, u32 n, u32 T) {
+  u32 t = i % T, off = 0;
+  for (u32 q = 0; q < t; ++q) off += (n > q) ? (n - q + T - 1) / T : 0;
+  return off + i / T;
+}
+
+// ---- camera -------------------------------------------------------------------------------
+__device__ inline void cam2World(const CamConst& c, double x, double y, double invDepth, double p[3]) {
+  const double z = 1.0 / invDepth;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const double ray = (c.Kinv[r * 3 + 0] * x + c.Kinv[r * 3 + 1] * y) + c.Kinv[r * 3 + 2];
+    p[r] = z * ray - c.Kinv_t[r];
+  }
+}
+__device__ inline void world2Cam(const CamConst& c, const double p[3], double& u, double& v) {
+  double h[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+    h[r] = ((c.P[r * 4 + 0] * p[0] + c.P[r * 4 + 1] * p[1]) + c.P[r * 4 + 2] * p[2]) + c.P[r * 4 + 3];
+  u = h[0] / h[2];
+  v = h[1] / h[2];
+}
+
+// 4x4 row-major helpers (same association order as the oracle's mat4_mul / rigid_inverse)
+__host__ __device__ inline void mat4_mul(const double* a, const double* b, double* c) {
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j)
+      c[i * 4 + j] = ((a[i * 4 + 0] * b[0 * 4 + j] + a[i * 4 + 1] * b[1 * 4 + j]) + a[i * 4 + 2] * b[2 * 4 + j]) +
+                     a[i * 4 + 3] * b[3 * 4 + j];
+}
+__host__ __device__ inline void rigid_inverse(const double* a, double* c) {
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) c[i * 4 + j] = a[j * 4 + i];
+  for (int i = 0; i < 3; ++i)
+    c[i * 4 + 3] = -((c[i * 4 + 0] * a[3] + c[i * 4 + 1] * a[7]) + c[i * 4 + 2] * a[11]);
+  c[12] = c[13] = c[14] = 0.0;
+  c[15] = 1.0;
+}
+
+// Dense DepthMap cell (one per pixel).  `flags` bit0: element alive; bit1: grid pointer valid
+// (SmartGrid's pointer grid, see kernels_fuse.hip); row/col are the coordinates the element
+// BELIEVES it has (they differ from the true cell only after DepthFusion's replace branch,
+// SURVEY Appendix A-7).
+struct MapCell {
+  double x[2];
+  double inv_depth, scale2, nu, variance, residual;
+  double p_cam[3];
+  u64 age;
+  u32 row, col;
+  u32 seq;     // creation order (id of the record that created the element)
+  u32 flags;
+};
+static_assert(sizeof(MapCell) == 104, "MapCell layout");
+enum { CELL_ALIVE = 1u, CELL_GRID = 2u };
+
+// Window point (what DepthFusion::update reads from a stored DepthPoint)
+typedef esvo_depth_point_t DevPoint;
+
+// ---- launchers (one per kernel file) --------------------------------------------------------
+// scan.hip
+void launch_exclusive_scan_u32(const u32* d_in, u32* d_out, u32* d_total, u32* d_block_sums, size_t n,
+                               hipStream_t s);
+size_t scan_scratch_elems(size_t n);
+
+// kernels_ts.hip
+void launch_ts_scatter(const esvo_event_t* d_ev, size_t n, u64* d_sae, int W, int H, hipStream_t s);
+void launch_ts_render(const u64* d_sae, const int2* d_fixmap, uint8_t* d_raw, uint8_t* d_out, int W, int H,
+                      u64 t_ns, double decay_sec, int ignore_polarity, int median_k, hipStream_t s);
+void launch_gaussian5(const uint8_t* d_in, uint8_t* d_out, int W, int H, hipStream_t s);
+
+// kernels_bm.hip
+struct BmArgs {
+  const esvo_event_t* ev;   // event buffer (ring of ev_cap slots)
+  u32 n;                    // number of events handed to BM this tick
+  u64 ev_first;             // absolute index of tick event 0
+  u64 ev_cap;               // ring capacity (slot = absolute index % ev_cap)
+  int ev_reverse;           // 1: newest-first walk (dataTransferring): event k = ev_first - k; 0: ev_first + k
+  const uint8_t* tsL;
+  const uint8_t* tsR;
+  const float2* lut;
+  const uint8_t* mask;      // may be null
+  const double* pose_sec;   // toSec() of the pose stamps
+  u32 n_pose;
+  esvo_match_t* out_slots;  // [n] slot w (thread-stride order)
+  u32* out_flags;           // [n]
+};
+void launch_bm_match(const BmArgs& a, const DevParams& p, hipStream_t s);
+void launch_compact_matches(const esvo_match_t* slots, const u32* flags, const u32* prefix, u32 n,
+                            esvo_match_t* out, hipStream_t s);
+
+// kernels_lm.hip
+struct LmArgs {
+  const esvo_match_t* matches;  // compacted vEMP (thread-stride order of BM)
+  const u32* n_matches;         // device count
+  u32 max_matches;
+  const uint8_t* tsL;
+  const uint8_t* tsR;
+  const double* pose_T;         // [n_pose][16] T_world_virtual
+  const double* T_world_obs;    // [16]
+  DevPoint* out_slots;          // [max_matches] slot s (thread-stride order of the solver)
+  u32* out_flags;               // [max_matches] 1 = solved (and kept when cull)
+  int cull;
+};
+void launch_lm_refine(const LmArgs& a, const DevParams& p, u32* n_solved, hipStream_t s);
+void launch_compact_points(const DevPoint* slots, const u32* flags, const u32* prefix, const u32* n_in,
+                           u32 max_n, DevPoint* out, hipStream_t s);
+
+// kernels_fuse.hip
+struct FuseArgs {
+  const DevPoint* win;          // window point ring
+  // frames in FUSION order (newest -> oldest): point q belongs to frame f with
+  // fr_cum[f] <= q < fr_cum[f+1]; its record is win[fr_off[f] + (q - fr_cum[f])]
+  const u32* fr_cum;            // [n_frames + 1]
+  const u32* fr_off;            // [n_frames]
+  const u32* fr_slot;           // [n_frames] pose-table slot
+  u32 n_frames;
+  u32 n_pts;
+  const double* frame_pose_T;   // [n_pose_slots][max_poses][16]
+  u32 max_poses;
+  double T_frame_world[16];     // inverse of the depth frame's pose
+  // scratch
+  DevPoint* prop;               // [n_pts] propagated points (row == 0xffffffff: rejected)
+  u32* cell_count;              // [W*H]
+  u32* cell_offset;             // [W*H]
+  u32* cell_fill;               // [W*H]
+  u32* rec_ids;                 // [n_pts * K]
+  u32* scan_tmp;                // scan scratch
+  u32* d_total;                 // total records
+  MapCell* map;                 // [W*H]
+  u32* d_num_fusion;            // fusion counter
+};
+void launch_fuse(const FuseArgs& a, const DevParams& p, hipStream_t s);
+void launch_clean(MapCell* map, const DevParams& p, hipStream_t s);
+void launch_regularize(const MapCell* map_in, MapCell* map_out, u32* owner_max, u32* owner_min,
+                       const DevParams& p, hipStream_t s);
+void launch_map_compact(const MapCell* map, u32* flags, u32* prefix, u32* d_total, u32* scan_tmp,
+                        esvo_depth_point_t* out, u32* out_cell, const DevParams& p, hipStream_t s);
+
+}  // namespace esvo

@@ -1,0 +1,330 @@
+// kernels_fuse.hip — K5/K6: depth-point propagation, per-pixel probabilistic fusion, clean and
+// regularisation on a dense DepthMap (gfx950).
+//
+// Replaces DepthFusion::update / propagate_one_point / fusion
+// (esvo_core/src/core/DepthFusion.cpp:18-192), DepthPoint::update_studentT
+// (esvo_core/src/container/DepthPoint.cpp:167-188), SmartGrid::clean
+// (esvo_core/include/esvo_core/container/SmartGrid.h:222-243) and
+// DepthRegularization::apply (esvo_core/src/core/DepthRegularization.cpp:19-110).
+//
+// The reference fuses sequentially: frames newest -> oldest, points in stored order, and for
+// each point its 2x2 (or 3x3) cells in (dy,dx) order; the result of a cell depends on the
+// order of the observations that hit it.  On the GPU every (point, cell) pair gets the record
+// id  q*K + k  (q = position of the point in fusion order) which IS that sequential order.
+// Records are bucketed by cell with a counting sort (atomic histogram -> scan -> scatter), each
+// cell's short list is sorted by id, and one thread walks it applying the reference's state
+// machine.  Cells are independent, so the result equals the sequential one exactly.
+//
+// DepthMap layout: one 104-byte MapCell per pixel (dense; the reference's list + pointer grid
+// is re-created every tick anyway, esvo_Mapping.cpp:268-272).  MapCell::row/col are the
+// coordinates the element believes it has; they differ from the true cell only after the
+// replace branch (DepthFusion.cpp:186), whose side effects on
+// clean/regularisation are reproduced through the ALIVE/GRID flag pair.
+#include "common.hpp"
+
+namespace esvo {
+
+__device__ inline bool boundaryCheck(double x, double y, int W, int H) {  // DepthFusion.cpp:194-205
+  return !(x < 0 || x >= (double)W || y < 0 || y >= (double)H);
+}
+
+// cell k of a propagated point (DepthFusion.cpp:98-117); returns false when outside the image
+__device__ inline bool fusion_cell(u32 prow, u32 pcol, int k, int radius, int W, int H, int& row, int& col) {
+  int dy, dx;
+  if (radius == 0) { dy = k >> 1; dx = k & 1; }
+  else { dy = k / 3 - 1; dx = k % 3 - 1; }
+  row = (int)prow + dy;
+  col = (int)pcol + dx;
+  return row >= 0 && row < H && col >= 0 && col < W;
+}
+
+// ---- propagate (+ histogram) ------------------------------------------------------------------
+__global__ void __launch_bounds__(256) propagate_kernel(FuseArgs a, DevParams p, int K) {
+  const u32 q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= a.n_pts) return;
+  u32 f = 0;  // frame of point q (binary search in the cumulative counts)
+  {
+    u32 lo = 0, hi = a.n_frames;
+    while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (a.fr_cum[mid] <= q) lo = mid; else hi = mid; }
+    f = lo;
+  }
+  const DevPoint prior = a.win[a.fr_off[f] + (q - a.fr_cum[f])];
+  const double* pose = a.frame_pose_T + ((size_t)a.fr_slot[f] * a.max_poses + prior.pose_idx) * 16;
+  double T[16];
+  mat4_mul(a.T_frame_world, pose, T);  // T_frame_obs, DepthFusion.cpp:80
+  DevPoint prop;
+  double pp[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+    pp[r] = ((T[r * 4 + 0] * prior.p_cam[0] + T[r * 4 + 1] * prior.p_cam[1]) + T[r * 4 + 2] * prior.p_cam[2]) + T[r * 4 + 3];
+  double u, v;
+  world2Cam(p.camL, pp, u, v);
+  if (!boundaryCheck(u, v, p.W, p.H)) {  // also rejects NaN coordinates?  NaN passes the reference's
+    // test (all comparisons false) and then floor(NaN) -> size_t is undefined; treat as rejected.
+    prop.row = 0xffffffffu;
+    prop.col = 0;
+    a.prop[q] = prop;
+    return;
+  }
+  if (!(u == u) || !(v == v)) { prop.row = 0xffffffffu; prop.col = 0; a.prop[q] = prop; return; }
+  prop.row = (u32)(size_t)floor(v);
+  prop.col = (u32)(size_t)floor(u);
+  prop.x[0] = u;
+  prop.x[1] = v;
+  const double invDepth = 1.0 / pp[2];
+  double denominator = (T[8] * prior.p_cam[0] + T[9] * prior.p_cam[1]) + T[11];
+  denominator /= prior.p_cam[2];
+  denominator += T[10];
+  const double J = T[10] / (denominator * denominator);
+  const double scale2 = J * J * prior.scale2;
+  const double nu = prior.nu;
+  const double variance = nu / (nu - 2) * scale2;
+  prop.inv_depth = invDepth;  // update_studentT on a fresh DepthPoint: plain assignment
+  prop.scale2 = scale2;
+  prop.variance = variance;
+  prop.nu = nu;
+  prop.p_cam[0] = pp[0]; prop.p_cam[1] = pp[1]; prop.p_cam[2] = pp[2];
+  prop.residual = prior.residual;
+  prop.age = prior.age;
+  prop.pose_idx = 0;
+  prop.seq = q;
+  a.prop[q] = prop;
+  for (int k = 0; k < K; ++k) {
+    int row, col;
+    if (!fusion_cell(prop.row, prop.col, k, p.fusion_radius, p.W, p.H, row, col)) continue;
+    if (row < p.band_y0 || row >= p.band_y1) continue;
+    atomicAdd(&a.cell_count[row * p.W + col], 1u);
+  }
+}
+
+__global__ void __launch_bounds__(256) scatter_records_kernel(FuseArgs a, DevParams p, int K) {
+  const u32 q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= a.n_pts) return;
+  const u32 prow = a.prop[q].row, pcol = a.prop[q].col;
+  if (prow == 0xffffffffu) return;
+  for (int k = 0; k < K; ++k) {
+    int row, col;
+    if (!fusion_cell(prow, pcol, k, p.fusion_radius, p.W, p.H, row, col)) continue;
+    if (row < p.band_y0 || row >= p.band_y1) continue;
+    const int cell = row * p.W + col;
+    const u32 pos = a.cell_offset[cell] + atomicAdd(&a.cell_fill[cell], 1u);
+    a.rec_ids[pos] = q * (u32)K + (u32)k;
+  }
+}
+
+// DepthPoint::update_studentT, DepthPoint.cpp:167-188
+__device__ inline void update_studentT(MapCell& c, double invD, double s2, double var, double nu_in) {
+  if (c.inv_depth > -1e-6) {
+    const double nu_update = (c.nu < nu_in) ? c.nu : nu_in;  // std::min(nu, nu_)
+    const double invDepth_update = (s2 * c.inv_depth + c.scale2 * invD) / (c.scale2 + s2);
+    const double dd = c.inv_depth - invD;
+    const double scale2_update = (nu_update + dd * dd / (c.scale2 + s2)) / (nu_update + 1) * (c.scale2 * s2) / (c.scale2 + s2);
+    c.inv_depth = invDepth_update;
+    c.scale2 = scale2_update;
+    c.nu = nu_update + 1;
+    c.variance = c.nu / (c.nu - 2) * c.scale2;
+    c.age++;
+  } else {
+    c.inv_depth = invD; c.scale2 = s2; c.variance = var; c.nu = nu_in;
+  }
+}
+
+// One thread per cell: sort the cell's record ids, then walk them (DepthFusion::fusion).
+__global__ void __launch_bounds__(256) fuse_cells_kernel(FuseArgs a, DevParams p, int K) {
+  const int cell = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cell >= p.W * p.H) return;
+  const int crow = cell / p.W, ccol = cell - crow * p.W;
+  if (crow < p.band_y0 || crow >= p.band_y1) return;
+  const u32 n = a.cell_count[cell];
+  if (n == 0) { a.map[cell].flags = 0; return; }
+  u32* ids = a.rec_ids + a.cell_offset[cell];
+  // insertion sort in place (lists are short: a handful of records per touched cell)
+  for (u32 i = 1; i < n; ++i) {
+    const u32 key = ids[i];
+    int j = (int)i - 1;
+    while (j >= 0 && ids[j] > key) { ids[j + 1] = ids[j]; --j; }
+    ids[j + 1] = key;
+  }
+  MapCell c;
+  bool exists = false;
+  u32 numFusion = 0;
+  for (u32 i = 0; i < n; ++i) {
+    const u32 id = ids[i];
+    const DevPoint& prop = a.prop[id / (u32)K];
+    if (!exists) {  // case 1: DepthFusion.cpp:127-146
+      c.row = (u32)crow; c.col = (u32)ccol;
+      c.x[0] = (double)ccol + 0.5; c.x[1] = (double)crow + 0.5;
+      c.inv_depth = prop.inv_depth; c.scale2 = prop.scale2; c.variance = prop.variance; c.nu = prop.nu;
+      c.residual = prop.residual;
+      c.age = prop.age;
+      cam2World(p.camL, c.x[0], c.x[1], prop.inv_depth, c.p_cam);
+      c.seq = id;
+      exists = true;
+    } else {
+      const double s1 = sqrt(prop.variance), s2 = sqrt(c.variance), diff = fabs(prop.inv_depth - c.inv_depth);
+      if (diff < 2 * s1 || diff < 2 * s2) {  // studentTCompatibleTest, :220-231 -> case 2.1
+        update_studentT(c, prop.inv_depth, prop.scale2, prop.variance, prop.nu);
+        c.age++;                                                        // :171
+        c.residual = (prop.residual < c.residual) ? prop.residual : c.residual;  // std::min
+        cam2World(p.camL, c.x[0], c.x[1], prop.inv_depth, c.p_cam);     // :173-175
+        numFusion++;
+      } else {  // case 2.2
+        if (c.inv_depth - 2 * sqrt(c.variance) > prop.inv_depth) continue;  // occluded
+        if (prop.variance < c.variance && prop.residual < c.residual) {
+          // operator=: the propagated point's row/col/x travel with it (Appendix A-7)
+          c.row = prop.row; c.col = prop.col;
+          c.x[0] = prop.x[0]; c.x[1] = prop.x[1];
+          c.inv_depth = prop.inv_depth; c.scale2 = prop.scale2; c.nu = prop.nu; c.variance = prop.variance;
+          c.residual = prop.residual; c.age = prop.age;
+          c.p_cam[0] = prop.p_cam[0]; c.p_cam[1] = prop.p_cam[1]; c.p_cam[2] = prop.p_cam[2];
+        }
+      }
+    }
+  }
+  c.flags = CELL_ALIVE | CELL_GRID;
+  a.map[cell] = c;
+  if (numFusion) atomicAdd(a.d_num_fusion, numFusion);
+}
+
+void launch_fuse(const FuseArgs& a, const DevParams& p, hipStream_t s) {
+  const int ncell = p.W * p.H;
+  const int K = (p.fusion_radius == 0) ? 4 : 9;
+  hipMemsetAsync(a.cell_count, 0, sizeof(u32) * ncell, s);
+  hipMemsetAsync(a.cell_fill, 0, sizeof(u32) * ncell, s);
+  hipMemsetAsync(a.d_num_fusion, 0, sizeof(u32), s);
+  if (a.n_pts) hipLaunchKernelGGL(propagate_kernel, dim3((a.n_pts + 255) / 256), dim3(256), 0, s, a, p, K);
+  launch_exclusive_scan_u32(a.cell_count, a.cell_offset, a.d_total, a.scan_tmp, (size_t)ncell, s);
+  if (a.n_pts) hipLaunchKernelGGL(scatter_records_kernel, dim3((a.n_pts + 255) / 256), dim3(256), 0, s, a, p, K);
+  hipLaunchKernelGGL(fuse_cells_kernel, dim3((ncell + 255) / 256), dim3(256), 0, s, a, p, K);
+}
+
+// ---- SmartGrid::clean ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) clean_kernel(MapCell* __restrict__ map, DevParams p) {
+  const int cell = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cell >= p.W * p.H) return;
+  MapCell& c = map[cell];
+  if (!(c.flags & CELL_ALIVE)) return;
+  // DepthPoint::valid(var, age, max, min), DepthPoint.cpp:221-230
+  const bool valid = c.inv_depth > -1e-6 && (double)c.age >= p.age_thr && c.variance <= p.var_thr &&
+                     c.inv_depth <= p.invdepth_max && c.inv_depth >= p.invdepth_min;
+  if (valid) return;
+  // erase the element: its true cell reads empty; the reference also NULLs the grid entry of the
+  // cell the element believes it occupies (SmartGrid.h:239), orphaning that cell's element.
+  atomicAnd(&c.flags, ~(CELL_ALIVE | CELL_GRID));
+  const u32 b = c.row * (u32)p.W + c.col;
+  if (b != (u32)cell && c.row < (u32)p.H && c.col < (u32)p.W) atomicAnd(&map[b].flags, ~CELL_GRID);
+}
+void launch_clean(MapCell* map, const DevParams& p, hipStream_t s) {
+  const int ncell = p.W * p.H;
+  hipLaunchKernelGGL(clean_kernel, dim3((ncell + 255) / 256), dim3(256), 0, s, map, p);
+}
+
+// ---- DepthRegularization::apply -------------------------------------------------------------------
+__global__ void __launch_bounds__(256) reg_owner_kernel(const MapCell* __restrict__ map, u32* __restrict__ owner_max,
+                                                        u32* __restrict__ owner_min, DevParams p) {
+  const int cell = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cell >= p.W * p.H) return;
+  const MapCell& c = map[cell];
+  if (!(c.flags & CELL_ALIVE)) return;
+  const u32 b = c.row * (u32)p.W + c.col;  // dmTmp.set(it->row(), it->col(), *it)
+  atomicMax(&owner_max[b], c.seq + 1u);
+  atomicMin(&owner_min[b], c.seq);
+}
+
+__device__ inline bool nb_valid(const MapCell& n) {
+  return (n.flags & CELL_ALIVE) && (n.flags & CELL_GRID) && n.inv_depth > -1e-6;
+}
+
+__global__ void __launch_bounds__(256) reg_apply_kernel(const MapCell* __restrict__ map, MapCell* __restrict__ out,
+                                                        const u32* __restrict__ owner_max, const u32* __restrict__ owner_min,
+                                                        DevParams p) {
+  const int cell = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cell >= p.W * p.H) return;
+  const int crow = cell / p.W;
+  if (crow < p.band_y0 || crow >= p.band_y1) return;
+  MapCell c = map[cell];
+  if (!(c.flags & CELL_ALIVE)) { out[cell].flags = 0; return; }
+  const u32 b = c.row * (u32)p.W + c.col;
+  if (owner_max[b] != c.seq + 1u) { out[cell].flags = 0; return; }  // overwritten by a later element
+  if (c.inv_depth > -1e-6) {  // it->valid()
+    const int R = p.reg_radius;
+    const int row = (int)c.row, col = (int)c.col;
+    u32 n_nb = 0, n_close = 0;
+    double nu_post = 0, inv_post = 0, s2_post = 0;
+    // SmartGrid::getNeighbourhood's loop bounds mix int and size_t (SmartGrid.h:373-375): for
+    // row < radius or col < radius the loops never execute -> no neighbours at all.
+    if (row >= R && col >= R) {
+      const double sd_self2 = 2.0 * sqrt(c.variance);
+      for (int r = row - R; r <= row + R; ++r) {
+        if (r >= p.H) break;
+        for (int cc = col - R; cc <= col + R; ++cc) {
+          if (cc >= p.W) break;
+          const MapCell& n = map[r * p.W + cc];
+          if (!nb_valid(n)) continue;
+          n_nb++;
+          const double diff = fabs(c.inv_depth - n.inv_depth);
+          if (diff < sd_self2 || diff < 2.0 * sqrt(n.variance)) {
+            if (n_close == 0) {
+              nu_post = n.nu; inv_post = n.inv_depth; s2_post = n.scale2;
+            } else {  // DepthRegularization.cpp:72-86
+              const double nu_prior = nu_post, inv_prior = inv_post, s2_prior = s2_post;
+              const double nu_obs = n.nu, inv_obs = n.inv_depth, s2_obs = n.scale2;
+              nu_post = (nu_obs < nu_prior) ? nu_obs : nu_prior;
+              inv_post = (s2_obs * inv_prior + s2_prior * inv_obs) / (s2_obs + s2_prior);
+              const double dd = inv_prior - inv_obs;
+              s2_post = (nu_post + dd * dd / (s2_prior + s2_obs)) / (nu_post + 1) * (s2_prior * s2_obs) / (s2_prior + s2_obs);
+            }
+            n_close++;
+          }
+        }
+      }
+    }
+    if (n_nb > (u32)p.reg_min_nb && n_close > (u32)p.reg_min_close) c.inv_depth = inv_post;
+    else c.inv_depth = -1.0;
+  }
+  c.seq = owner_min[b];  // position of the first element set at that cell in dmTmp's list
+  c.flags = CELL_ALIVE | CELL_GRID;
+  out[cell] = c;
+}
+
+void launch_regularize(const MapCell* map_in, MapCell* map_out, u32* owner_max, u32* owner_min, const DevParams& p,
+                       hipStream_t s) {
+  const int ncell = p.W * p.H;
+  hipMemsetAsync(owner_max, 0, sizeof(u32) * ncell, s);
+  hipMemsetAsync(owner_min, 0xff, sizeof(u32) * ncell, s);
+  hipLaunchKernelGGL(reg_owner_kernel, dim3((ncell + 255) / 256), dim3(256), 0, s, map_in, owner_max, owner_min, p);
+  hipLaunchKernelGGL(reg_apply_kernel, dim3((ncell + 255) / 256), dim3(256), 0, s, map_in, map_out, owner_max, owner_min, p);
+}
+
+// ---- export: alive cells -> esvo_depth_point_t list (cell order; host orders by seq) --------------
+__global__ void __launch_bounds__(256) map_flags_kernel(const MapCell* __restrict__ map, u32* __restrict__ flags, int ncell) {
+  const int cell = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cell >= ncell) return;
+  flags[cell] = (map[cell].flags & CELL_ALIVE) ? 1u : 0u;
+}
+__global__ void __launch_bounds__(256) map_export_kernel(const MapCell* __restrict__ map, const u32* __restrict__ flags,
+                                                         const u32* __restrict__ prefix, esvo_depth_point_t* __restrict__ out,
+                                                         u32* __restrict__ out_cell, int ncell) {
+  const int cell = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cell >= ncell || !flags[cell]) return;
+  const MapCell& c = map[cell];
+  esvo_depth_point_t o;
+  o.row = c.row; o.col = c.col;
+  o.x[0] = c.x[0]; o.x[1] = c.x[1];
+  o.inv_depth = c.inv_depth; o.scale2 = c.scale2; o.nu = c.nu; o.variance = c.variance; o.residual = c.residual;
+  o.age = c.age;
+  o.p_cam[0] = c.p_cam[0]; o.p_cam[1] = c.p_cam[1]; o.p_cam[2] = c.p_cam[2];
+  o.pose_idx = 0;
+  o.seq = c.seq;
+  out[prefix[cell]] = o;
+  if (out_cell) out_cell[prefix[cell]] = (c.flags & CELL_GRID) ? (u32)cell : 0xffffffffu;
+}
+void launch_map_compact(const MapCell* map, u32* flags, u32* prefix, u32* d_total, u32* scan_tmp,
+                        esvo_depth_point_t* out, u32* out_cell, const DevParams& p, hipStream_t s) {
+  const int ncell = p.W * p.H;
+  hipLaunchKernelGGL(map_flags_kernel, dim3((ncell + 255) / 256), dim3(256), 0, s, map, flags, ncell);
+  launch_exclusive_scan_u32(flags, prefix, d_total, scan_tmp, (size_t)ncell, s);
+  hipLaunchKernelGGL(map_export_kernel, dim3((ncell + 255) / 256), dim3(256), 0, s, map, flags, prefix, out, out_cell, ncell);
+}
+
+}  // namespace esvo

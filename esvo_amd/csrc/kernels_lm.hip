@@ -1,0 +1,397 @@
+// kernels_lm.hip — K4: per-match inverse-depth refinement (1-D Levenberg-Marquardt, f64) on gfx950.
+//
+// Replaces DepthProblemSolver::solve_multiple_problems / solve_single_problem_numerical
+// (esvo_core/src/core/DepthProblemSolver.cpp:80-214), DepthProblem::operator() / warping /
+// patchInterpolation (esvo_core/src/core/DepthProblem.cpp:34-262) and the third-party
+// Eigen::LevenbergMarquardt<NumericalDiff<...>> for one unknown (MINPACK lmdif logic,
+// SURVEY.md Appendix B.1), plus DepthProblemSolver::pointCulling (:216-244).
+//
+// Work decomposition: the 15x7 patch needs a 16x8 source block per image, so a match maps
+// onto a 16-lane group: lane c loads column c of the block (8 rows, both images), takes
+// column c+1 from its neighbour with a 16-wide shuffle, and owns the 7 residuals of patch
+// column c (lane 15 only feeds its neighbour).  Four matches share one wave64; the LM control
+// flow is uniform inside a group and diverges between groups via the exec mask.  Patch sums
+// (t-scale update, |f|, |J|, J^T f) are reduced in a fixed order: per-lane over rows, then an
+// xor butterfly over the 16 lanes — the oracle's "canonical" order, so results match the CPU
+// oracle bit for bit.  All arithmetic is f64 (the forward-difference step is sqrt(eps)*|x|).
+//
+// The Student-t scale iteration (DepthProblem.cpp:96-124) has no iteration cap in the
+// reference.  When at most floor(0.94*N/(nu+1)) residuals are non-zero (and none is below
+// 1e-6 in magnitude) the update s2 <- mean(...) contracts by > 6% per step for ever, s2
+// underflows to 0, the sum becomes exactly 0 and the reference resets s2 to Tdist_scale^2
+// after ~10^4 iterations; that provable outcome is taken directly.  Every
+// other case runs the literal loop.
+#include "common.hpp"
+
+namespace esvo {
+
+#define LM_ROWS 7
+#define LM_COLS 15
+
+__device__ inline double grp_sum(double v) {  // xor butterfly over the 16-lane group
+  v = v + __shfl_xor(v, 1, 16);
+  v = v + __shfl_xor(v, 2, 16);
+  v = v + __shfl_xor(v, 4, 16);
+  v = v + __shfl_xor(v, 8, 16);
+  return v;
+}
+__device__ inline double col_sum(const double t[LM_ROWS]) {
+  double a = t[0];
+#pragma unroll
+  for (int y = 1; y < LM_ROWS; ++y) a = a + t[y];
+  return a;
+}
+__device__ inline double patch_dot(const double a[LM_ROWS], const double b[LM_ROWS]) {
+  double t[LM_ROWS];
+#pragma unroll
+  for (int y = 0; y < LM_ROWS; ++y) t[y] = a[y] * b[y];
+  return grp_sum(col_sum(t));
+}
+
+struct LmProblem {
+  double cx, cy;           // rectified left coordinate of the event
+  double T[12];            // T_left_virtual (3x4)
+  const uint8_t* tsL;
+  const uint8_t* tsR;
+  int c;                   // lane within the group
+};
+
+// bilinear 15x7 patch column for this lane; returns false like patchInterpolation
+__device__ inline bool interp_geom(const DevParams& p, double lx, double ly, int& ulx, int& uly, double& q1, double& q2,
+                                   double& q3, double& q4) {
+  const int hx = (LM_COLS - 1) / 2, hy = (LM_ROWS - 1) / 2;
+  const double fx = floor(lx), fy = floor(ly);
+  ulx = (int)fx - hx;
+  uly = (int)fy - hy;
+  const int drx = (int)fx + hx, dry = (int)fy + hy;
+  if (ulx < 0 || uly < 0) return false;
+  if (drx >= p.W || dry >= p.H) return false;
+  const int l0 = (int)fy, l1 = (int)fx;
+  const int u0 = l0 + 1, u1 = l1 + 1;
+  q1 = (double)u1 - lx;
+  q2 = lx - (double)l1;
+  q3 = (double)u0 - ly;
+  q4 = ly - (double)l0;
+  if (uly + LM_ROWS >= p.H || ulx + LM_COLS >= p.W) return false;
+  return true;
+}
+__device__ inline void interp_column(const uint8_t* __restrict__ img, int W, int ulx, int uly, int c, double q1, double q2,
+                                     double q3, double q4, double tau[LM_ROWS]) {
+  double R[LM_ROWS + 1];
+#pragma unroll
+  for (int y = 0; y <= LM_ROWS; ++y) {
+    const int s0 = img[(uly + y) * W + ulx + c];
+    const int s1 = __shfl_down(s0, 1, 16);
+    R[y] = q1 * (double)s0 + q2 * (double)s1;
+  }
+#pragma unroll
+  for (int y = 0; y < LM_ROWS; ++y) tau[y] = q3 * R[y] + q4 * R[y + 1];
+}
+
+// DepthProblem::operator(), Tdist norm.  fv[y] = residual of patch element (y, c); lane 15 -> 0.
+__device__ void lm_eval(const DevParams& p, const LmProblem& pr, double x, double fv[LM_ROWS]) {
+  const double nu = p.td_nu;
+  double prv[3], pl[3];
+  cam2World(p.camL, pr.cx, pr.cy, x, prv);
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+    pl[r] = ((pr.T[r * 4 + 0] * prv[0] + pr.T[r * 4 + 1] * prv[1]) + pr.T[r * 4 + 2] * prv[2]) + pr.T[r * 4 + 3];
+  double x1u, x1v, x2u, x2v;
+  world2Cam(p.camL, pl, x1u, x1v);
+  world2Cam(p.camR, pl, x2u, x2v);
+  const int hx = (LM_COLS - 1) / 2, hy = (LM_ROWS - 1) / 2;
+  bool okw = isfinite(x1u) && isfinite(x1v) && isfinite(x2u) && isfinite(x2v);
+  if (okw) {  // warping bounds, DepthProblem.cpp:186-189
+    if (x1u < hx || x1u > p.W - hx || x1v < hy || x1v > p.H - hy) okw = false;
+    if (x2u < hx || x2u > p.W - hx || x2v < hy || x2v > p.H - hy) okw = false;
+  }
+  int ulx1 = 0, uly1 = 0, ulx2 = 0, uly2 = 0;
+  double a1 = 0, a2 = 0, a3 = 0, a4 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0;
+  if (okw) okw = interp_geom(p, x1u, x1v, ulx1, uly1, a1, a2, a3, a4);
+  if (okw) okw = interp_geom(p, x2u, x2v, ulx2, uly2, b1, b2, b3, b4);
+  if (!okw) {  // failure fill, DepthProblem.cpp:49-56 / :149-155
+    const double residual = 255;
+    const double q = residual / p.td_scale;
+    const double weight = (nu + 1) / (nu + q * q);
+    const double f = sqrt(weight) * residual;
+#pragma unroll
+    for (int y = 0; y < LM_ROWS; ++y) fv[y] = (pr.c < LM_COLS) ? f : 0.0;
+    return;
+  }
+  double tau1[LM_ROWS], tau2[LM_ROWS], r[LM_ROWS], r2[LM_ROWS];
+  interp_column(pr.tsL, p.W, ulx1, uly1, pr.c, a1, a2, a3, a4, tau1);
+  interp_column(pr.tsR, p.W, ulx2, uly2, pr.c, b1, b2, b3, b4, tau2);
+  int knz = 0;
+  double minabs = 1e300;
+#pragma unroll
+  for (int y = 0; y < LM_ROWS; ++y) {
+    r[y] = (pr.c < LM_COLS) ? (tau1[y] - tau2[y]) : 0.0;
+    r2[y] = r[y] * r[y];
+    if (r[y] != 0) { knz++; minabs = fmin(minabs, fabs(r[y])); }
+  }
+#pragma unroll
+  for (int d = 1; d < 16; d <<= 1) {
+    knz += __shfl_xor(knz, d, 16);
+    minabs = fmin(minabs, __shfl_xor(minabs, d, 16));
+  }
+  const double scale2_0 = p.td_scale2;
+  double s2;
+  const int N = LM_ROWS * LM_COLS;
+  if ((double)knz * (nu + 1) / (double)N <= 0.94 && minabs >= 1e-6) {
+    s2 = scale2_0;  // provable outcome of the uncapped loop (header comment)
+  } else {
+    double s1 = scale2_0;
+    s2 = -1.0;
+    bool first = true;
+    while (fabs(s2 - s1) / s1 > 0.05 || first) {  // DepthProblem.cpp:96
+      if (!first) s1 = s2;
+      double t[LM_ROWS];
+#pragma unroll
+      for (int y = 0; y < LM_ROWS; ++y) t[y] = (r[y] != 0) ? r2[y] * (nu + 1) / (nu + r2[y] / s1) : 0.0;
+      const double sum = grp_sum(col_sum(t));
+      if (sum == 0) { s2 = scale2_0; break; }
+      s2 = sum / (double)N;
+      first = false;
+    }
+  }
+#pragma unroll
+  for (int y = 0; y < LM_ROWS; ++y) {
+    const double weight = (nu + 1) / (nu + r2[y] / s2);
+    fv[y] = sqrt(weight) * r[y];
+  }
+}
+
+// internal::lmpar2 for n == 1 (Appendix B.1)
+__device__ inline double lm_lmpar2(double r, double diag, double qtf, double delta, double& par) {
+  const double dwarf = 2.2250738585072014e-308;
+  double x = qtf / r;
+  double wa2 = diag * x;
+  double dxnorm = fabs(wa2);
+  double fp = dxnorm - delta;
+  if (fp <= 0.1 * delta) { par = 0; return x; }
+  double wa1 = diag * wa2 / dxnorm;
+  wa1 = wa1 / r;
+  double temp = fabs(wa1);
+  double parl = fp / delta / temp / temp;
+  wa1 = r * qtf / diag;
+  const double gn = fabs(wa1);
+  double paru = gn / delta;
+  if (paru == 0.) paru = dwarf / ((delta < 0.1) ? delta : 0.1);
+  par = (par < parl) ? parl : par;   // std::max(par, parl)
+  par = (paru < par) ? paru : par;   // std::min(par, paru)
+  if (par == 0.) par = gn / dxnorm;
+  int it = 0;
+  while (true) {
+    ++it;
+    if (par == 0.) { const double c = 0.001 * paru; par = (dwarf < c) ? c : dwarf; }
+    const double ds = sqrt(par) * diag;
+    const double sdiag2 = r * r + ds * ds;
+    const double sdiag = sqrt(sdiag2);
+    x = r * qtf / sdiag2;
+    wa2 = diag * x;
+    dxnorm = fabs(wa2);
+    temp = fp;
+    fp = dxnorm - delta;
+    if (fabs(fp) <= 0.1 * delta || (parl == 0. && fp <= temp && temp < 0.) || it == 10) break;
+    wa1 = diag * (wa2 / dxnorm);
+    wa1 = wa1 / sdiag;
+    temp = fabs(wa1);
+    const double parc = fp / delta / temp / temp;
+    if (fp > 0.) parl = (parl < par) ? par : parl;
+    if (fp < 0.) paru = (par < paru) ? par : paru;
+    const double pc = par + parc;
+    par = (parl < pc) ? pc : parl;
+  }
+  return x;
+}
+
+__global__ void __launch_bounds__(256) lm_refine_kernel(LmArgs a, DevParams p, u32* n_solved) {
+  const u32 s = (blockIdx.x * 256 + threadIdx.x) >> 4;  // solver slot (thread-stride order)
+  const int c = threadIdx.x & 15;
+  u32 M = *a.n_matches;
+  if (M > a.max_matches) M = a.max_matches;
+  const bool active = s < M;
+  // inactive groups still run the (cheap, failing) code path below with a dummy problem so that
+  // the wave's shuffles stay convergent; they write nothing.
+  u32 j = 0;
+  esvo_match_t m;
+  m.x_left[0] = m.x_left[1] = -1e9; m.inv_depth = 1.0; m.pose_idx = 0; m.cost = 0; m.disp = 0; m.event_idx = 0;
+  if (active) {
+    j = stride_item(s, M, (u32)p.num_threads);  // DepthProblemSolver.cpp:90
+    m = a.matches[j];
+  }
+  LmProblem pr;
+  pr.cx = m.x_left[0];
+  pr.cy = m.x_left[1];
+  pr.tsL = a.tsL;
+  pr.tsR = a.tsR;
+  pr.c = c;
+  {  // DepthProblem::setProblem, DepthProblem.cpp:17-32
+    double Tlw[16], Tlv[16];
+    rigid_inverse(a.T_world_obs, Tlw);
+    mat4_mul(Tlw, a.pose_T + (size_t)m.pose_idx * 16, Tlv);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) pr.T[i] = Tlv[i];
+  }
+  const int N = LM_ROWS * LM_COLS;
+  const double ftol = 1e-6, xtol = 1e-6, gtol = 0., factor = 100.;
+  const double eps = 2.220446049250313e-16;
+  const double sqrt_eps = 1.4901161193847656e-08;  // sqrt(DBL_EPSILON), exact
+  const int maxfev = p.lm_maxfev;
+
+  double x = m.inv_depth;
+  double fvec[LM_ROWS], fjac[LM_ROWS], wa4[LM_ROWS];
+  // minimizeInit
+  int nfev = 1;
+  lm_eval(p, pr, x, fvec);
+  double fnorm = sqrt(patch_dot(fvec, fvec));
+  double par = 0., diag = 0., xnorm = 0., delta = 0., r = 0.;
+  int iter = 1;
+  int iteration = 0, optState = 0;
+  while (true) {  // DepthProblemSolver.cpp:161-188
+    // ---- minimizeOneStep ----
+    int status = -1;
+    {
+      // NumericalDiff<Forward>::df (2 evaluations)
+      lm_eval(p, pr, x, wa4);
+      double h = sqrt_eps * fabs(x);
+      if (h == 0.) h = sqrt_eps;
+      double val2[LM_ROWS];
+      lm_eval(p, pr, x + h, val2);
+#pragma unroll
+      for (int y = 0; y < LM_ROWS; ++y) fjac[y] = (val2[y] - wa4[y]) / h;
+      nfev += 2;
+    }
+    const double wa2n = sqrt(patch_dot(fjac, fjac));
+    const double jtf = patch_dot(fjac, fvec);
+    r = wa2n;
+    const double fvec0 = __shfl(fvec[0], 0, 16);
+    const double qtf = (r != 0.) ? jtf / r : fvec0;
+    if (iter == 1) {
+      diag = (wa2n == 0.) ? 1. : wa2n;
+      xnorm = fabs(diag * x);
+      delta = factor * xnorm;
+      if (delta == 0.) delta = factor;
+    }
+    double gnorm = 0.;
+    if (fnorm != 0.)
+      if (wa2n != 0.) { const double g = fabs(r * (qtf / fnorm) / wa2n); gnorm = (gnorm < g) ? g : gnorm; }
+    if (gnorm <= gtol) {
+      status = 4;
+    } else {
+      diag = (diag < wa2n) ? wa2n : diag;
+      double ratio;
+      do {
+        const double pstep = lm_lmpar2(r, diag, qtf, delta, par);
+        const double wa1 = -pstep;
+        const double xnew = x + wa1;
+        const double pnorm = fabs(diag * wa1);
+        if (iter == 1) delta = (pnorm < delta) ? pnorm : delta;
+        lm_eval(p, pr, xnew, wa4);
+        ++nfev;
+        const double fnorm1 = sqrt(patch_dot(wa4, wa4));
+        double actred = -1.;
+        if (0.1 * fnorm1 < fnorm) actred = 1. - (fnorm1 / fnorm) * (fnorm1 / fnorm);
+        const double wa3 = r * wa1;
+        const double t1 = fabs(wa3) / fnorm, temp1 = t1 * t1;
+        const double t2 = sqrt(par) * pnorm / fnorm, temp2 = t2 * t2;
+        const double prered = temp1 + temp2 / 0.5;
+        const double dirder = -(temp1 + temp2);
+        ratio = 0.;
+        if (prered != 0.) ratio = actred / prered;
+        if (ratio <= 0.25) {
+          double temp = 0.5;
+          if (actred >= 0.) temp = 0.5;
+          if (actred < 0.) temp = 0.5 * dirder / (dirder + 0.5 * actred);
+          if (0.1 * fnorm1 >= fnorm || temp < 0.1) temp = 0.1;
+          const double pn = pnorm / 0.1;
+          delta = temp * ((pn < delta) ? pn : delta);
+          par /= temp;
+        } else if (!(par != 0. && ratio < 0.75)) {
+          delta = pnorm / 0.5;
+          par = 0.5 * par;
+        }
+        if (ratio >= 1e-4) {
+          x = xnew;
+#pragma unroll
+          for (int y = 0; y < LM_ROWS; ++y) fvec[y] = wa4[y];
+          xnorm = fabs(diag * x);
+          fnorm = fnorm1;
+          ++iter;
+        }
+        if (fabs(actred) <= ftol && prered <= ftol && 0.5 * ratio <= 1. && delta <= xtol * xnorm) { status = 3; break; }
+        if (fabs(actred) <= ftol && prered <= ftol && 0.5 * ratio <= 1.) { status = 1; break; }
+        if (delta <= xtol * xnorm) { status = 2; break; }
+        if (nfev >= maxfev) { status = 5; break; }
+        if (fabs(actred) <= eps && prered <= eps && 0.5 * ratio <= 1.) { status = 6; break; }
+        if (delta <= eps * xnorm) { status = 7; break; }
+        if (gnorm <= eps) { status = 8; break; }
+      } while (ratio < 1e-4);
+    }
+    // ---- the reference's outer loop ----
+    iteration++;
+    if (iteration >= p.lm_max_iter) break;
+    bool terminate = false;
+    if (status == 2 || status == 3) {
+      if (optState == 0) optState++;
+      else terminate = true;
+    }
+    if (terminate) break;
+  }
+
+  if (!active || c != 0) return;
+  const bool solved = !(x <= 0.001);  // DepthProblemSolver.cpp:192
+  bool keep = solved;
+  if (solved) {
+    atomicAdd(n_solved, 1u);
+    const double invJtJ = (r != 0.) ? (1. / r) * (1. / r) : 0.;  // internal::covar, n == 1
+    const double variance = p.td_stdvar2 * invJtJ;               // :210
+    const double residual = fnorm * fnorm;                       // :212
+    DevPoint o;
+    o.row = (u32)(size_t)floor(pr.cy);  // :116
+    o.col = (u32)(size_t)floor(pr.cx);
+    o.x[0] = pr.cx;
+    o.x[1] = pr.cy;
+    cam2World(p.camL, pr.cx, pr.cy, x, o.p_cam);                 // :119
+    o.inv_depth = x;                                             // update_studentT, new-point branch
+    o.scale2 = variance * (p.td_nu - 2) / p.td_nu;               // :125
+    o.nu = p.td_nu;
+    o.variance = variance;
+    o.residual = residual;
+    o.age = 0;
+    o.pose_idx = m.pose_idx;
+    o.seq = j;
+    if (a.cull)  // pointCulling, :230-234
+      keep = variance <= p.var_thr && residual <= p.cost_thr && x > -1e-6 && x >= p.invdepth_min && x <= p.invdepth_max;
+    if (keep) a.out_slots[s] = o;
+  }
+  a.out_flags[s] = keep ? 1u : 0u;
+}
+
+void launch_lm_refine(const LmArgs& a, const DevParams& p, u32* n_solved, hipStream_t s) {
+  if (a.max_matches == 0) return;
+  const u32 groups_per_block = 256 / 16;
+  const u32 blocks = (a.max_matches + groups_per_block - 1) / groups_per_block;
+  hipLaunchKernelGGL(lm_refine_kernel, dim3(blocks), dim3(256), 0, s, a, p, n_solved);
+}
+
+// stable compaction of the solver slots into a frame buffer
+__global__ void __launch_bounds__(256) compact_points_kernel(const DevPoint* __restrict__ slots, const u32* __restrict__ flags,
+                                                             const u32* __restrict__ prefix, const u32* __restrict__ n_in,
+                                                             u32 max_n, DevPoint* __restrict__ out) {
+  const u32 s = blockIdx.x * blockDim.x + threadIdx.x;
+  u32 n = *n_in;
+  if (n > max_n) n = max_n;
+  if (s >= n || !flags[s]) return;
+  DevPoint o = slots[s];
+  o.seq = prefix[s];
+  out[prefix[s]] = o;
+}
+void launch_compact_points(const DevPoint* slots, const u32* flags, const u32* prefix, const u32* n_in, u32 max_n,
+                           DevPoint* out, hipStream_t s) {
+  if (max_n == 0) return;
+  hipLaunchKernelGGL(compact_points_kernel, dim3((max_n + 255) / 256), dim3(256), 0, s, slots, flags, prefix, n_in, max_n,
+                     out);
+}
+
+}  // namespace esvo

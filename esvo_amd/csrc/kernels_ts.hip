@@ -1,0 +1,149 @@
+// kernels_ts.hip — Time-Surface raster on gfx950.
+//
+//   K1 ts_scatter : esvo_time_surface eventsCallback / EventQueueMat::insertEvent
+//                   (esvo_time_surface/src/TimeSurface.cpp:403-425, TimeSurface.h:39-50)
+//   K2 ts_decay + ts_median_remap : TimeSurface::createTimeSurfaceAtTime, BACKWARD mode
+//                   (TimeSurface.cpp:52-152): exp decay -> x255 -> u8 -> 3x3 median -> rectifying remap
+//   gaussian5     : TimeSurfaceObservation::GaussianBlurTS(5) (TimeSurfaceObservation.h:107-116)
+//
+// Data layout: the per-pixel event queues of the reference (std::deque, length 20) collapse to a
+// Surface of Active Events: one u64 per pixel holding (t_ns << 1 | polarity) of the newest
+// event, updated with atomicMax.  The host only scatters events with ts < T before rendering at
+// T, which is exactly what getMostRecentEventBeforeT (TimeSurface.h:52-75) returns.
+#include "common.hpp"
+
+namespace esvo {
+
+// ---- K1 -----------------------------------------------------------------------------------------
+// One thread per event, 16-byte coalesced loads (the reference's in-memory dvs_msgs::Event),
+// 8-byte atomicMax into the SAE.  HBM-bound: 16 B read + 8 B atomic per event.
+__global__ void __launch_bounds__(256) ts_scatter_kernel(const uint4* __restrict__ ev, size_t n, u64* __restrict__ sae,
+                                                         int W, int H) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const uint4 e = ev[i];  // {x | y<<16, sec, nsec, polarity | pad}
+    const u32 x = e.x & 0xffffu, y = e.x >> 16;
+    if (x >= (u32)W || y >= (u32)H) continue;  // EventQueueMat::insideImage
+    const u64 t_ns = (u64)e.y * 1000000000ull + (u64)e.z;
+    const u64 key = (t_ns << 1) | (u64)((e.w & 0xffu) ? 1u : 0u);
+    atomicMax(&sae[(size_t)y * W + x], key);
+  }
+}
+
+void launch_ts_scatter(const esvo_event_t* d_ev, size_t n, u64* d_sae, int W, int H, hipStream_t s) {
+  if (n == 0) return;
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;  // grid-stride above 8 blocks/CU
+  hipLaunchKernelGGL(ts_scatter_kernel, dim3((u32)blocks), dim3(256), 0, s, reinterpret_cast<const uint4*>(d_ev), n,
+                     d_sae, W, H);
+}
+
+// ---- K2a: decay + quantise ------------------------------------------------------------------------
+// TimeSurface.cpp:65-127.  dt is formed like ros::Duration::toSec() (Appendix A-17); the u8
+// conversion is cv::Mat::convertTo = saturate_cast<uchar>(cvRound(v)) = round-half-even.
+__global__ void __launch_bounds__(256) ts_decay_kernel(const u64* __restrict__ sae, uint8_t* __restrict__ raw, int n_px,
+                                                       u64 t_ns, double decay_sec, int ignore_polarity) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_px) return;
+  const u64 key = sae[i];
+  const u64 te = key >> 1;
+  double v = 0.0;
+  if (key != 0 && te < t_ns && ns_to_sec(te) > 0) {
+    const double dt = duration_to_sec(t_ns, te);
+    double e = exp(-dt / decay_sec);
+    if (!ignore_polarity) e *= (key & 1ull) ? 1.0 : -1.0;
+    v = e;
+  }
+  const double g = ignore_polarity ? 255.0 * v : 255.0 * (v + 1.0) / 2.0;
+  int q = (int)rint(g);
+  q = q < 0 ? 0 : (q > 255 ? 255 : q);
+  raw[i] = (uint8_t)q;
+}
+
+// ---- K2b: 3x3 median (BORDER_REPLICATE) fused with the fixed-point bilinear remap --------------------
+__device__ inline void cswap(int& a, int& b) { int lo = min(a, b), hi = max(a, b); a = lo; b = hi; }
+__device__ inline int median9(int p0, int p1, int p2, int p3, int p4, int p5, int p6, int p7, int p8) {
+  // 19-exchange median network
+  cswap(p1, p2); cswap(p4, p5); cswap(p7, p8); cswap(p0, p1); cswap(p3, p4); cswap(p6, p7);
+  cswap(p1, p2); cswap(p4, p5); cswap(p7, p8); cswap(p0, p3); cswap(p5, p8); cswap(p4, p7);
+  cswap(p3, p6); cswap(p1, p4); cswap(p2, p5); cswap(p4, p7); cswap(p4, p2); cswap(p6, p4);
+  cswap(p4, p2);
+  return p4;
+}
+__device__ inline int median_tap(const uint8_t* __restrict__ raw, int W, int H, int x, int y, int median_k) {
+  if (x < 0 || x >= W || y < 0 || y >= H) return 0;  // BORDER_CONSTANT 0 of cv::remap
+  if (median_k <= 0) return raw[y * W + x];
+  const int xm = max(x - 1, 0), xp = min(x + 1, W - 1), ym = max(y - 1, 0), yp = min(y + 1, H - 1);
+  const uint8_t* r0 = raw + ym * W;
+  const uint8_t* r1 = raw + y * W;
+  const uint8_t* r2 = raw + yp * W;
+  return median9(r0[xm], r0[x], r0[xp], r1[xm], r1[x], r1[xp], r2[xm], r2[x], r2[xp]);
+}
+
+// fixmap[i] = (cvRound(map_x*32), cvRound(map_y*32)): OpenCV's INTER_BITS=5 coordinate
+// quantisation, precomputed once on the host (Appendix B.2).  Weights are the exact 15-bit
+// integers (32-fx)(32-fy)*32 ...; dst = (sum + 16384) >> 15.
+__global__ void __launch_bounds__(256) ts_median_remap_kernel(const uint8_t* __restrict__ raw, const int2* __restrict__ fixmap,
+                                                              uint8_t* __restrict__ out, int W, int H, int median_k) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= W || y >= H) return;
+  const int i = y * W + x;
+  int v;
+  if (fixmap) {
+    const int2 m = fixmap[i];
+    const int ix = m.x >> 5, iy = m.y >> 5, fx = m.x & 31, fy = m.y & 31;
+    const int w00 = (32 - fx) * (32 - fy) * 32, w01 = fx * (32 - fy) * 32, w10 = (32 - fx) * fy * 32, w11 = fx * fy * 32;
+    int acc = 0;
+    if (w00) acc += w00 * median_tap(raw, W, H, ix, iy, median_k);
+    if (w01) acc += w01 * median_tap(raw, W, H, ix + 1, iy, median_k);
+    if (w10) acc += w10 * median_tap(raw, W, H, ix, iy + 1, median_k);
+    if (w11) acc += w11 * median_tap(raw, W, H, ix + 1, iy + 1, median_k);
+    v = (acc + 16384) >> 15;
+  } else {
+    v = median_tap(raw, W, H, x, y, median_k);
+  }
+  out[i] = (uint8_t)v;
+}
+
+void launch_ts_render(const u64* d_sae, const int2* d_fixmap, uint8_t* d_raw, uint8_t* d_out, int W, int H, u64 t_ns,
+                      double decay_sec, int ignore_polarity, int median_k, hipStream_t s) {
+  const int n = W * H;
+  hipLaunchKernelGGL(ts_decay_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_sae, d_raw, n, t_ns, decay_sec,
+                     ignore_polarity);
+  hipLaunchKernelGGL(ts_median_remap_kernel, dim3((W + 63) / 64, (H + 3) / 4), dim3(256), 0, s, d_raw, d_fixmap, d_out, W,
+                     H, median_k);
+}
+
+// ---- 5x5 Gaussian, [1 4 6 4 1]^2 / 256, BORDER_REFLECT_101, round-to-nearest once ------------------
+__device__ inline int reflect101(int p, int n) {
+  if (n == 1) return 0;
+  while (p < 0 || p >= n) {
+    if (p < 0) p = -p;
+    if (p >= n) p = 2 * (n - 1) - p;
+  }
+  return p;
+}
+__global__ void __launch_bounds__(256) gaussian5_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int W, int H) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= W || y >= H) return;
+  const int k[5] = {1, 4, 6, 4, 1};
+  int acc = 0;
+#pragma unroll
+  for (int dy = -2; dy <= 2; ++dy) {
+    const uint8_t* row = in + reflect101(y + dy, H) * W;
+    int r = 0;
+#pragma unroll
+    for (int dx = -2; dx <= 2; ++dx) r += k[dx + 2] * row[reflect101(x + dx, W)];
+    acc += k[dy + 2] * r;
+  }
+  int v = (acc + 128) >> 8;
+  out[y * W + x] = (uint8_t)(v > 255 ? 255 : v);
+}
+void launch_gaussian5(const uint8_t* d_in, uint8_t* d_out, int W, int H, hipStream_t s) {
+  hipLaunchKernelGGL(gaussian5_kernel, dim3((W + 63) / 64, (H + 3) / 4), dim3(256), 0, s, d_in, d_out, W, H);
+}
+
+}  // namespace esvo

@@ -1,0 +1,108 @@
+// scan.hip — device-wide exclusive prefix sum of u32 (stable compaction / counting sort support).
+//
+// Three launches (reduce -> scan of block sums -> down-sweep), 256-thread blocks, 8 items per
+// thread, wave64 shuffles + one LDS hop per block.  n <= 2048*2048 elements.
+#include "common.hpp"
+
+namespace esvo {
+
+static constexpr int SCAN_B = 256;            // threads per block (4 waves)
+static constexpr int SCAN_V = 8;              // items per thread
+static constexpr int SCAN_TILE = SCAN_B * SCAN_V;
+
+__device__ inline u32 wave_incl_scan(u32 v, int lane) {
+#pragma unroll
+  for (int d = 1; d < ESVO_WAVE; d <<= 1) {
+    u32 t = __shfl_up(v, d, ESVO_WAVE);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
+
+// exclusive scan of one value per thread across the block; returns block total in *total
+__device__ inline u32 block_excl_scan(u32 v, u32* total, u32* lds /*>= 4*/) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  u32 incl = wave_incl_scan(v, lane);
+  if (lane == 63) lds[wave] = incl;
+  __syncthreads();
+  u32 base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < SCAN_B / ESVO_WAVE; ++w) {
+    u32 s = lds[w];
+    if (w < wave) base += s;
+    tot += s;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + incl - v;
+}
+
+__global__ void __launch_bounds__(SCAN_B) scan_reduce_kernel(const u32* __restrict__ in, u32* __restrict__ block_sums, size_t n) {
+  __shared__ u32 lds[4];
+  const size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_V;
+  u32 s = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_V; ++k)
+    if (base + k < n) s += in[base + k];
+  u32 tot;
+  block_excl_scan(s, &tot, lds);
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+}
+
+__global__ void __launch_bounds__(SCAN_B) scan_sums_kernel(u32* __restrict__ block_sums, u32 nb, u32* __restrict__ total) {
+  __shared__ u32 lds[4];
+  u32 v[SCAN_V];
+  u32 s = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_V; ++k) {
+    u32 i = threadIdx.x * SCAN_V + k;
+    v[k] = (i < nb) ? block_sums[i] : 0u;
+    s += v[k];
+  }
+  u32 tot;
+  u32 ex = block_excl_scan(s, &tot, lds);
+#pragma unroll
+  for (int k = 0; k < SCAN_V; ++k) {
+    u32 i = threadIdx.x * SCAN_V + k;
+    if (i < nb) block_sums[i] = ex;
+    ex += v[k];
+  }
+  if (threadIdx.x == 0 && total) *total = tot;
+}
+
+__global__ void __launch_bounds__(SCAN_B) scan_down_kernel(const u32* __restrict__ in, u32* __restrict__ out,
+                                                           const u32* __restrict__ block_sums, size_t n) {
+  __shared__ u32 lds[4];
+  const size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_V;
+  u32 v[SCAN_V];
+  u32 s = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_V; ++k) {
+    v[k] = (base + k < n) ? in[base + k] : 0u;
+    s += v[k];
+  }
+  u32 tot;
+  u32 ex = block_excl_scan(s, &tot, lds) + block_sums[blockIdx.x];
+#pragma unroll
+  for (int k = 0; k < SCAN_V; ++k) {
+    if (base + k < n) out[base + k] = ex;
+    ex += v[k];
+  }
+}
+
+size_t scan_scratch_elems(size_t n) { return (n + SCAN_TILE - 1) / SCAN_TILE + 1; }
+
+// d_out may alias d_in.  d_total (nullable) receives the sum.  d_block_sums: scan_scratch_elems(n).
+void launch_exclusive_scan_u32(const u32* d_in, u32* d_out, u32* d_total, u32* d_block_sums, size_t n,
+                               hipStream_t s) {
+  if (n == 0) {
+    if (d_total) hipMemsetAsync(d_total, 0, sizeof(u32), s);
+    return;
+  }
+  const u32 nb = (u32)((n + SCAN_TILE - 1) / SCAN_TILE);
+  hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(SCAN_B), 0, s, d_in, d_block_sums, n);
+  hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SCAN_B), 0, s, d_block_sums, nb, d_total);
+  hipLaunchKernelGGL(scan_down_kernel, dim3(nb), dim3(SCAN_B), 0, s, d_in, d_out, d_block_sums, n);
+}
+
+}  // namespace esvo

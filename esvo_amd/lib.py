@@ -1,0 +1,223 @@
+"""ctypes bindings of libesvo_hip.so (the C-ABI of include/esvo_hip.h) and a thin Python host
+mirror of the reference's call sequence (TimeSurface node + mapper node) for tests/bench.
+
+There is NO fallback: if the HIP extension is missing or no MI355X is visible, loading /
+creating a handle raises.  Nothing in this module touches oracle/.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from .abi import (DEPTH_POINT_DTYPE, EVENT_DTYPE, MATCH_DTYPE, CalibStruct, ParamsStruct, ShardBuffersStruct,
+                  StatsStruct)
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+_LIB_PATH = os.path.join(_CSRC, "libesvo_hip.so")
+_SOURCES = ["api.hip", "scan.hip", "kernels_ts.hip", "kernels_bm.hip", "kernels_lm.hip", "kernels_fuse.hip"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+               "-Wno-unused-value", "-Wno-unused-result"]
+
+SYMBOLS = [
+    "esvo_default_params", "esvo_create", "esvo_destroy", "esvo_reset", "esvo_set_params", "esvo_last_error",
+    "esvo_set_stream", "esvo_synchronize", "esvo_ts_push_events", "esvo_ts_render", "esvo_map_set_observation",
+    "esvo_map_match", "esvo_map_set_poses", "esvo_map_refine", "esvo_map_push_frame", "esvo_map_fuse",
+    "esvo_map_tick", "esvo_map_get_depth_points", "esvo_map_get_pointcloud_xyz", "esvo_map_get_last_frame",
+    "esvo_get_stats", "esvo_shard_set_band", "esvo_shard_buffers", "esvo_shard_tick_phase",
+]
+
+
+class EsvoError(RuntimeError):
+    pass
+
+
+def build(force=False, verbose=False):
+    """hipcc cross-compiles the extension for gfx950 in-tree (works without a GPU)."""
+    srcs = [os.path.join(_CSRC, s) for s in _SOURCES]
+    deps = srcs + [os.path.join(_CSRC, "common.hpp"), os.path.join(_CSRC, "..", "..", "include", "esvo_hip.h")]
+    if not force and os.path.exists(_LIB_PATH) and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return _LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + HIPCC_FLAGS + ["-I", os.path.join(_CSRC, "..", "..", "include"), "-o", _LIB_PATH] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise EsvoError(f"{_LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(the ESVO hot path has no CPU fallback)")
+    lib = C.CDLL(_LIB_PATH)
+    vp, u64, sz, i32 = C.c_void_p, C.c_uint64, C.c_size_t, C.c_int
+    psz = C.POINTER(C.c_size_t)
+    lib.esvo_default_params.argtypes = [vp]
+    lib.esvo_default_params.restype = None
+    lib.esvo_create.argtypes = [vp, vp, vp, i32, C.POINTER(vp)]
+    lib.esvo_destroy.argtypes = [vp]
+    lib.esvo_reset.argtypes = [vp]
+    lib.esvo_set_params.argtypes = [vp, vp]
+    lib.esvo_last_error.argtypes = [vp]
+    lib.esvo_last_error.restype = C.c_char_p
+    lib.esvo_set_stream.argtypes = [vp, vp]
+    lib.esvo_synchronize.argtypes = [vp]
+    lib.esvo_ts_push_events.argtypes = [vp, i32, vp, sz]
+    lib.esvo_ts_render.argtypes = [vp, i32, u64, vp]
+    lib.esvo_map_set_observation.argtypes = [vp, u64, vp, vp, vp]
+    lib.esvo_map_match.argtypes = [vp, vp, sz, vp, vp, sz, vp, sz, psz]
+    lib.esvo_map_set_poses.argtypes = [vp, vp, vp, sz]
+    lib.esvo_map_refine.argtypes = [vp, vp, sz, i32, vp, sz, psz]
+    lib.esvo_map_push_frame.argtypes = [vp, vp, sz, vp, sz]
+    lib.esvo_map_fuse.argtypes = [vp, psz]
+    lib.esvo_map_tick.argtypes = [vp, u64, vp, vp, sz]
+    lib.esvo_map_get_depth_points.argtypes = [vp, vp, sz, psz]
+    lib.esvo_map_get_pointcloud_xyz.argtypes = [vp, vp, sz, psz]
+    lib.esvo_map_get_last_frame.argtypes = [vp, vp, sz, psz]
+    lib.esvo_get_stats.argtypes = [vp, vp]
+    lib.esvo_shard_set_band.argtypes = [vp, i32, i32]
+    lib.esvo_shard_buffers.argtypes = [vp, vp]
+    lib.esvo_shard_tick_phase.argtypes = [vp, i32, u64, vp, vp, sz]
+    for s in SYMBOLS:
+        if s not in ("esvo_default_params", "esvo_last_error"):
+            getattr(lib, s).restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data
+
+
+class Esvo:
+    """One handle = one GPU: TS-left, TS-right and the mapper behind the same device state."""
+
+    def __init__(self, params: ParamsStruct, rig, device=0):
+        self.lib = load()
+        self.rig, self.params = rig, params
+        self.W, self.H = rig.width, rig.height
+        self._cl, self._cr = rig.left.as_struct(), rig.right.as_struct()
+        h = C.c_void_p()
+        rc = self.lib.esvo_create(C.addressof(params), C.addressof(self._cl), C.addressof(self._cr), int(device), C.byref(h))
+        if rc != 0:
+            raise EsvoError(f"esvo_create failed ({rc}): {self.lib.esvo_last_error(None).decode()}")
+        self.h = h
+        self._poses = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.esvo_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise EsvoError(f"esvo call failed ({rc}): {self.lib.esvo_last_error(self.h).decode()}")
+
+    # ---- lifecycle
+    def reset(self):
+        self._ck(self.lib.esvo_reset(self.h))
+
+    def set_params(self, params):
+        self._ck(self.lib.esvo_set_params(self.h, C.addressof(params)))
+        self.params = params
+
+    def set_stream(self, stream_ptr):
+        self._ck(self.lib.esvo_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    def synchronize(self):
+        self._ck(self.lib.esvo_synchronize(self.h))
+
+    # ---- Time Surface (esvo_time_surface node: eventsCallback / createTimeSurfaceAtTime)
+    def ts_push_events(self, cam, ev):
+        ev = np.ascontiguousarray(ev, dtype=EVENT_DTYPE)
+        self._ck(self.lib.esvo_ts_push_events(self.h, int(cam), ev.ctypes.data, ev.shape[0]))
+
+    def ts_render(self, cam, t_ns, download=True):
+        out = np.empty((self.H, self.W), np.uint8) if download else None
+        self._ck(self.lib.esvo_ts_render(self.h, int(cam), int(t_ns), _p(out)))
+        return out
+
+    # ---- mapper, stage-wise (EventBM / DepthProblemSolver / DepthFusion seams)
+    def set_observation(self, t_ns, ts_left, ts_right, T_world_cam):
+        l = None if ts_left is None else np.ascontiguousarray(ts_left, np.uint8)
+        r = None if ts_right is None else np.ascontiguousarray(ts_right, np.uint8)
+        T = np.ascontiguousarray(T_world_cam, np.float64).reshape(16)
+        self._ck(self.lib.esvo_map_set_observation(self.h, int(t_ns), _p(l), _p(r), T.ctypes.data))
+
+    def set_poses(self, stamps, poses):
+        st = np.ascontiguousarray(stamps, np.uint64)
+        T = np.ascontiguousarray(poses, np.float64).reshape(-1, 16)
+        self._poses = T
+        self._ck(self.lib.esvo_map_set_poses(self.h, st.ctypes.data, T.ctypes.data, st.shape[0]))
+
+    def match(self, ev, stamps=None, poses=None):
+        ev = np.ascontiguousarray(ev, dtype=EVENT_DTYPE)
+        if stamps is not None:
+            self.set_poses(stamps, poses)
+        out = np.zeros(max(ev.shape[0], 1), MATCH_DTYPE)
+        n = C.c_size_t(0)
+        self._ck(self.lib.esvo_map_match(self.h, ev.ctypes.data, ev.shape[0], None, None, 0, out.ctypes.data,
+                                         out.shape[0], C.byref(n)))
+        return out[: n.value]
+
+    def refine(self, matches, cull=True):
+        m = np.ascontiguousarray(matches, dtype=MATCH_DTYPE)
+        out = np.zeros(max(m.shape[0], 1), DEPTH_POINT_DTYPE)
+        n = C.c_size_t(0)
+        self._ck(self.lib.esvo_map_refine(self.h, m.ctypes.data, m.shape[0], int(cull), out.ctypes.data, out.shape[0],
+                                          C.byref(n)))
+        return out[: n.value]
+
+    def push_frame(self, pts, poses=None):
+        pts = np.ascontiguousarray(pts, dtype=DEPTH_POINT_DTYPE)
+        T = self._poses if poses is None else np.ascontiguousarray(poses, np.float64).reshape(-1, 16)
+        self._ck(self.lib.esvo_map_push_frame(self.h, pts.ctypes.data, pts.shape[0], T.ctypes.data, T.shape[0]))
+
+    def fuse(self):
+        n = C.c_size_t(0)
+        self._ck(self.lib.esvo_map_fuse(self.h, C.byref(n)))
+        return n.value
+
+    # ---- mapper, fused tick (MappingAtTime on device-resident data)
+    def tick(self, t_ns, stamps, poses):
+        st = np.ascontiguousarray(stamps, np.uint64)
+        T = np.ascontiguousarray(poses, np.float64).reshape(-1, 16)
+        self._ck(self.lib.esvo_map_tick(self.h, int(t_ns), st.ctypes.data, T.ctypes.data, st.shape[0]))
+
+    # ---- outputs
+    def get_map(self):
+        n = C.c_size_t(0)
+        out = np.zeros(self.W * self.H, DEPTH_POINT_DTYPE)
+        self._ck(self.lib.esvo_map_get_depth_points(self.h, out.ctypes.data, out.shape[0], C.byref(n)))
+        return out[: n.value].copy()
+
+    def get_pointcloud(self):
+        n = C.c_size_t(0)
+        out = np.zeros((self.W * self.H, 3), np.float32)
+        self._ck(self.lib.esvo_map_get_pointcloud_xyz(self.h, out.ctypes.data, out.shape[0], C.byref(n)))
+        return out[: n.value].copy()
+
+    def get_last_frame(self):
+        n = C.c_size_t(0)
+        cap = max(int(self.params.max_events_per_tick), int(self.params.process_event_num), 1)
+        out = np.zeros(cap, DEPTH_POINT_DTYPE)
+        self._ck(self.lib.esvo_map_get_last_frame(self.h, out.ctypes.data, cap, C.byref(n)))
+        return out[: n.value].copy()
+
+    def stats(self):
+        s = StatsStruct()
+        self._ck(self.lib.esvo_get_stats(self.h, C.addressof(s)))
+        return s
+
+    def set_band(self, y0, y1):
+        self._ck(self.lib.esvo_shard_set_band(self.h, int(y0), int(y1)))

@@ -375,6 +375,8 @@ struct orc_mapper {
   Camera camL, camR;
   double baseline = 0;
   int real_threads = 1;
+  int bm_exact_int = 0;   // 1: ZNCC cost from exact integer moments (what the GPU computes)
+  int lm_canonical = 0;   // 1: canonical reduction order for the LM sums (see reduce_patch)
   // observation
   uint64_t obs_t_ns = 0;
   std::vector<double> tsL, tsR;  // row-major W*H doubles 0..255 (TimeSurfaceObservation.h:68-69)
@@ -429,6 +431,36 @@ double zncc_cost_int(int64_t Sl, int64_t Sll, int64_t Sr, int64_t Srr, int64_t S
   const double sigl = std::sqrt(varl) + 1e-6, sigr = std::sqrt(varr) + 1e-6;
   const double cov = (double)(N * Slr - Sl * Sr) / n;  // = sum((l-ml)(r-mr))
   return 0.5 * (1 - cov / (sigl * sigr) / n);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Patch reductions.  The reference sums residuals either with Eigen reductions (stableNorm,
+// blueNorm, dot: vectorised, order unspecified) or with a plain (y,x) loop (t-scale update,
+// DepthProblem.cpp:101-116).  mode 0 = sequential in index order (the literal loop order).
+// mode 1 = "canonical": per-column partial sums over the rows (top to bottom), then a fixed
+// pairwise tree over the columns padded with zeros to a power of two.  The GPU kernel reduces
+// in exactly the canonical order, so oracle(mode 1) == GPU bit for bit; tests bound
+// |mode 0 - mode 1|.
+// ---------------------------------------------------------------------------------------------
+double reduce_patch(const double* v, int wx, int wy, int mode) {
+  if (mode == 0) {
+    double s = 0;
+    for (int i = 0; i < wx * wy; ++i) s += v[i];
+    return s;
+  }
+  int P = 1;
+  while (P < wx) P <<= 1;
+  double col[64];
+  for (int x = 0; x < P; ++x) {
+    double a = 0.0;
+    if (x < wx) { a = v[x]; for (int y = 1; y < wy; ++y) a = a + v[y * wx + x]; }
+    col[x] = a;
+  }
+  for (int w = 1; w < P; w <<= 1)            // xor-butterfly: lane x gets col[x] + col[x ^ w]
+    for (int x = 0; x < P; x += 2 * w)
+      for (int k = 0; k < w; ++k) { double t = col[x + k] + col[x + k + w]; col[x + k] = t; col[x + k + w] = t; }
+  return col[0];
 }
 
 struct BM {
@@ -627,7 +659,7 @@ struct DepthProblem {
     if (!warping(x, x1, x2)) { fail_fill(); return 0; }
     std::vector<double> tau1(N), tau2(N);
     if (patchInterpolation(M->tsL, x1, tau1.data()) && patchInterpolation(M->tsR, x2, tau2.data())) {
-      std::vector<double> vR(N), vR2(N);
+      std::vector<double> vR(N), vR2(N), terms(N);
       const double scale2_0 = sq(scale);  // td_scaleSquared_
       double s1 = scale2_0, s2 = -1.0;
       bool first = true;
@@ -635,9 +667,17 @@ struct DepthProblem {
       while (std::fabs(s2 - s1) / s1 > 0.05 || first) {  // :96
         if (!first) s1 = s2;
         double sum = 0;
-        for (int i = 0; i < N; ++i) {  // y-major then x == index order
-          if (first) { vR[i] = tau1[i] - tau2[i]; vR2[i] = sq(vR[i]); }
-          if (vR[i] != 0) sum += vR2[i] * (nu + 1) / (nu + vR2[i] / s1);
+        if (!M->lm_canonical) {
+          for (int i = 0; i < N; ++i) {  // y-major then x == index order
+            if (first) { vR[i] = tau1[i] - tau2[i]; vR2[i] = sq(vR[i]); }
+            if (vR[i] != 0) sum += vR2[i] * (nu + 1) / (nu + vR2[i] / s1);
+          }
+        } else {
+          for (int i = 0; i < N; ++i) {
+            if (first) { vR[i] = tau1[i] - tau2[i]; vR2[i] = sq(vR[i]); }
+            terms[i] = (vR[i] != 0) ? vR2[i] * (nu + 1) / (nu + vR2[i] / s1) : 0.0;
+          }
+          sum = reduce_patch(terms.data(), wx, wy, 1);
         }
         if (sum == 0) { s2 = scale2_0; break; }
         s2 = sum / N;
@@ -673,7 +713,13 @@ struct LM1 {
   LM1(const DepthProblem& f, int m_, double ftol_, double xtol_, int maxfev_)
       : F(f), m(m_), ftol(ftol_), xtol(xtol_), maxfev(maxfev_), fvec(m_), fjac(m_), wa4(m_), val2(m_) {}
 
-  static double norm(const double* v, int n) { double s = 0; for (int i = 0; i < n; ++i) s += v[i] * v[i]; return std::sqrt(s); }
+  int wx = 0, wy = 0, mode = 0;  // reduction geometry/mode (see reduce_patch)
+  double dotp(const double* a, const double* b) const {
+    std::vector<double> t(m);
+    for (int i = 0; i < m; ++i) t[i] = a[i] * b[i];
+    return reduce_patch(t.data(), wx, wy, mode);
+  }
+  double norm(const double* v, int) const { return std::sqrt(dotp(v, v)); }
 
   int minimizeInit(double& x) {
     nfev = 1;
@@ -737,8 +783,7 @@ struct LM1 {
       nfev += 2;
     }
     const double wa2n = norm(fjac.data(), m);  // column norm
-    double jtf = 0;
-    for (int i = 0; i < m; ++i) jtf += fjac[i] * fvec[i];
+    const double jtf = dotp(fjac.data(), fvec.data());
     r = wa2n;  // sign convention: +||J|| (results are sign-invariant)
     qtf = (r != 0.) ? jtf / r : fvec[0];
     if (iter == 1) {
@@ -807,6 +852,7 @@ struct LM1 {
 bool solve_single(orc_mapper* M, const DepthProblem& prob, double d_init, double result[3], double info[4]) {
   const int N = M->prm.patch_size_x * M->prm.patch_size_y;
   LM1 lm(prob, N, 1e-6, 1e-6, M->prm.lm_max_iteration * 3);
+  lm.wx = M->prm.patch_size_x; lm.wy = M->prm.patch_size_y; lm.mode = M->lm_canonical;
   double x = d_init;
   lm.minimizeInit(x);
   size_t iteration = 0;
@@ -862,6 +908,7 @@ bool propagate_one_point(const orc_mapper* M, const DP& prior, DP& prop, const M
   double xp[2];
   M->camL.world2Cam(pp, xp);
   if (!boundaryCheck(xp[0], xp[1], M->W(), M->H())) return false;
+  if (!(xp[0] == xp[0]) || !(xp[1] == xp[1])) return false;  // NaN passes the reference's test (UB after); defined: rejected
   prop = DP((size_t)std::floor(xp[1]), (size_t)std::floor(xp[0]));
   prop.x[0] = xp[0]; prop.x[1] = xp[1];
   const double invDepth = 1.0 / pp[2];
@@ -1032,6 +1079,9 @@ extern "C" void orc_mapper_reset(orc_mapper_handle h) {
 extern "C" void orc_mapper_set_params(orc_mapper_handle h, const esvo_params_t* p) { h->prm = *p; }
 extern "C" void orc_mapper_set_threads(orc_mapper_handle h, int t) { h->real_threads = t < 1 ? 1 : t; }
 extern "C" double orc_mapper_baseline(orc_mapper_handle h) { return h->baseline; }
+extern "C" void orc_mapper_set_mode(orc_mapper_handle h, int bm_exact_int, int lm_canonical) {
+  h->bm_exact_int = bm_exact_int; h->lm_canonical = lm_canonical;
+}
 
 extern "C" void orc_mapper_set_observation(orc_mapper_handle h, uint64_t t_ns, const uint8_t* l,
                                            const uint8_t* r, const double T[16]) {
@@ -1095,7 +1145,7 @@ extern "C" size_t orc_mapper_match(orc_mapper_handle h, const esvo_event_t* ev, 
   auto job = [&](int t) {
     for (size_t i = t; i < n; i += T) {
       esvo_match_t m;
-      if (bm.match_an_event(ev[i], (uint32_t)i, m)) per[t].push_back(m);
+      if (bm.match_an_event(ev[i], (uint32_t)i, m, nullptr, h->bm_exact_int)) per[t].push_back(m);
     }
   };
   if (h->real_threads > 1) {
@@ -1112,7 +1162,7 @@ extern "C" size_t orc_mapper_match(orc_mapper_handle h, const esvo_event_t* ev, 
           for (size_t k = b; k < e; ++k) {
             size_t i = t + k * T;
             esvo_match_t m;
-            if (bm.match_an_event(ev[i], (uint32_t)i, m)) parts[t][rt].push_back(m);
+            if (bm.match_an_event(ev[i], (uint32_t)i, m, nullptr, h->bm_exact_int)) parts[t][rt].push_back(m);
           }
         }
       });
@@ -1169,6 +1219,7 @@ extern "C" size_t orc_mapper_refine(orc_mapper_handle h, const esvo_match_t* mat
         orc_mapper local;  // only the counters are written through ctx; share read-only data
         local.prm = h->prm; local.camL = h->camL; local.camR = h->camR;
         local.tsL = h->tsL; local.tsR = h->tsR; local.T_world_obs = h->T_world_obs;
+        local.lm_canonical = h->lm_canonical; local.bm_exact_int = h->bm_exact_int;
         for (size_t i = rt; i < n; i += R) solve_one(i, &local);
       });
     for (auto& t : th) t.join();

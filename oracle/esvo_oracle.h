@@ -55,6 +55,10 @@ void orc_mapper_set_params(orc_mapper_handle h, const esvo_params_t* p);
 void orc_mapper_set_threads(orc_mapper_handle h, int real_threads); /* >1: run BM / LM on
         real std::threads (same outputs; used only for the timed CPU baseline) */
 double orc_mapper_baseline(orc_mapper_handle h);
+/* bm_exact_int=1: ZNCC cost from exact integer moments; lm_canonical=1: canonical reduction
+ * order in the LM sums.  (0,0) = literal restatement (default).  (1,1) = bit-comparable with the
+ * GPU; tests bound the difference between the two. */
+void orc_mapper_set_mode(orc_mapper_handle h, int bm_exact_int, int lm_canonical);
 
 /* TS_obs_ : mono8 left/right + T_world_cam (row-major 4x4) */
 void orc_mapper_set_observation(orc_mapper_handle h, uint64_t t_ns, const uint8_t* ts_left,

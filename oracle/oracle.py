@@ -51,6 +51,7 @@ def load(fast=False):
     lib.orc_mapper_reset.argtypes = [vp]
     lib.orc_mapper_set_params.argtypes = [vp, vp]
     lib.orc_mapper_set_threads.argtypes = [vp, i32]
+    lib.orc_mapper_set_mode.argtypes = [vp, i32, i32]
     lib.orc_mapper_baseline.restype = dbl
     lib.orc_mapper_baseline.argtypes = [vp]
     lib.orc_mapper_set_observation.argtypes = [vp, u64, vp, vp, vp]
@@ -185,6 +186,9 @@ class OracleMapper:
 
     def set_threads(self, n):
         self.lib.orc_mapper_set_threads(self.h, int(n))
+
+    def set_mode(self, bm_exact_int=False, lm_canonical=False):
+        self.lib.orc_mapper_set_mode(self.h, int(bm_exact_int), int(lm_canonical))
 
     @property
     def baseline(self):

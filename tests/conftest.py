@@ -1,0 +1,37 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def upenn_rig():
+    from esvo_amd import calib
+    return calib.dataset_rig("upenn")
+
+
+@pytest.fixture(scope="session")
+def upenn_stream(upenn_rig):
+    from esvo_amd import synth
+    return synth.make_stream(upenn_rig, 6000, 0.2, 0.16, 1.0, seed=20250419)
+
+
+@pytest.fixture(scope="session")
+def dsec_rig():
+    from esvo_amd import calib
+    return calib.dataset_rig("dsec")
+
+
+@pytest.fixture(scope="session")
+def dsec_stream(dsec_rig):
+    from esvo_amd import synth
+    # DSEC geometry: f*b = 320 px*m, rho in [0.001, 0.25] -> disparity 0..80
+    return synth.make_stream(dsec_rig, 20000, 0.12, 0.02, 0.25, seed=20250421, speed=2.0)
