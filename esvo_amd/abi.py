@@ -97,6 +97,7 @@ class StatsStruct(C.Structure):
         ("ms_ts_scatter", C.c_float), ("ms_ts_render", C.c_float),
         ("ms_bm", C.c_float), ("ms_refine", C.c_float), ("ms_fusion", C.c_float),
         ("ms_regularization", C.c_float), ("ms_tick_total", C.c_float),
+        ("ms_kernel", C.c_float * 8),
     ]
 
 

@@ -21,6 +21,8 @@ namespace {
 thread_local std::string g_create_error;
 }
 
+enum { EV_SC0 = 0, EV_SC1, EV_R1, EV_T0, EV_BM0, EV_BM1, EV_S1, EV_LM0, EV_LM1, EV_S2, EV_FU0, EV_FU1, EV_CL1, EV_RG1, EV_N };
+
 struct FrameRec {
   u32 off;    // offset in the window ring
   u32 count;  // points
@@ -112,9 +114,10 @@ struct esvo_context {
   esvo_depth_point_t* d_export = nullptr;
   u32* d_export_cell = nullptr;
 
-  hipEvent_t evt[8];
+  hipEvent_t evt[16];
   bool evt_ok = false;
   esvo_stats_t stats;
+  bool ts_timing_pending = false;
 };
 
 #define HIPCHK(call)                                                                              \
@@ -226,9 +229,12 @@ int run_match(esvo_context* h, const esvo_event_t* d_ev, u64 first, u64 cap, int
   a.lut = h->d_lut; a.mask = h->d_mask;
   a.pose_sec = h->d_pose_sec; a.n_pose = h->n_pose;
   a.out_slots = h->d_match_slots; a.out_flags = h->d_match_flags;
+  hipEventRecord(h->evt[EV_BM0], h->stream);
   launch_bm_match(a, h->dp, h->stream);
+  hipEventRecord(h->evt[EV_BM1], h->stream);
   launch_exclusive_scan_u32(h->d_match_flags, h->d_match_prefix, h->d_counters + 0, h->d_scan_tmp, n, h->stream);
   launch_compact_matches(h->d_match_slots, h->d_match_flags, h->d_match_prefix, n, h->d_matches, h->stream);
+  hipEventRecord(h->evt[EV_S1], h->stream);
   HIPCHK(hipGetLastError());
   return ESVO_OK;
 }
@@ -242,11 +248,24 @@ int run_refine(esvo_context* h, u32 max_matches, int cull, DevPoint* dst) {
   a.tsL = h->d_obs[0]; a.tsR = h->d_obs[1];
   a.pose_T = h->d_pose_T; a.T_world_obs = h->d_T_world_obs;
   a.out_slots = h->d_pt_slots; a.out_flags = h->d_pt_flags; a.cull = cull;
+  hipEventRecord(h->evt[EV_LM0], h->stream);
   launch_lm_refine(a, h->dp, h->d_counters + 2, h->stream);
+  hipEventRecord(h->evt[EV_LM1], h->stream);
   launch_exclusive_scan_u32(h->d_pt_flags, h->d_pt_prefix, h->d_counters + 1, h->d_scan_tmp, max_matches, h->stream);
   launch_compact_points(h->d_pt_slots, h->d_pt_flags, h->d_pt_prefix, h->d_counters + 0, max_matches, dst, h->stream);
+  hipEventRecord(h->evt[EV_S2], h->stream);
   HIPCHK(hipGetLastError());
   return ESVO_OK;
+}
+
+void collect_ts_timing(esvo_context* h) {
+  if (!h->ts_timing_pending) return;
+  if (hipEventElapsedTime(&h->stats.ms_ts_scatter, h->evt[EV_SC0], h->evt[EV_SC1]) == hipSuccess &&
+      hipEventElapsedTime(&h->stats.ms_ts_render, h->evt[EV_SC1], h->evt[EV_R1]) == hipSuccess) {
+    h->stats.ms_kernel[0] = h->stats.ms_ts_scatter;
+    h->stats.ms_kernel[1] = h->stats.ms_ts_render;
+  }
+  h->ts_timing_pending = false;
 }
 
 int read_counters(esvo_context* h) {
@@ -336,16 +355,18 @@ int run_fuse(esvo_context* h) {
   a.rec_ids = h->d_rec_ids; a.scan_tmp = h->d_scan_tmp; a.d_total = h->d_counters + 4;
   a.map = h->d_map; a.d_num_fusion = h->d_counters + 3;
   if (total > h->win_cap) FAIL(ESVO_ERR_CAPACITY, "window points exceed capacity");
+  hipEventRecord(h->evt[EV_FU0], h->stream);
   launch_fuse(a, h->dp, h->stream);
+  hipEventRecord(h->evt[EV_FU1], h->stream);
   h->d_map_cur = h->d_map;
   const bool do_clean = h->prm.clean_requires_full_window ? (h->frames.size() >= (size_t)h->prm.max_fusion_frames) : true;
   if (do_clean) launch_clean(h->d_map, h->dp, h->stream);
-  if (h->evt_ok) hipEventRecord(h->evt[4], h->stream);
+  hipEventRecord(h->evt[EV_CL1], h->stream);
   if (h->prm.regularization) {
     launch_regularize(h->d_map, h->d_map2, h->d_owner_max, h->d_owner_min, h->dp, h->stream);
     h->d_map_cur = h->d_map2;
   }
-  if (h->evt_ok) hipEventRecord(h->evt[5], h->stream);
+  hipEventRecord(h->evt[EV_RG1], h->stream);
   HIPCHK(hipGetLastError());
   return ESVO_OK;
 }
@@ -510,7 +531,7 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
   CK(dalloc(&h->d_exp_prefix, npx));
   CK(dalloc(&h->d_export, npx));
   CK(dalloc(&h->d_export_cell, npx));
-  for (int i = 0; i < 8; ++i) CK(hipEventCreate(&h->evt[i]));
+  for (int i = 0; i < EV_N; ++i) CK(hipEventCreate(&h->evt[i]));
   h->evt_ok = true;
   for (int i = 0; i < 16; ++i) h->T_world_obs[i] = h->T_world_frame[i] = (i % 5 == 0) ? 1.0 : 0.0;
   CK(hipMemcpy(h->d_T_world_obs, h->T_world_obs, sizeof(double) * 16, hipMemcpyHostToDevice));
@@ -533,7 +554,7 @@ int esvo_destroy(esvo_handle h) {
   for (void* p : ptrs) if (p) hipFree(p);
   if (h->h_counters) hipHostFree(h->h_counters);
   if (h->h_fr_table) hipHostFree(h->h_fr_table);
-  if (h->evt_ok) for (int i = 0; i < 8; ++i) hipEventDestroy(h->evt[i]);
+  if (h->evt_ok) for (int i = 0; i < EV_N; ++i) hipEventDestroy(h->evt[i]);
   if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
   delete h;
   return ESVO_OK;
@@ -629,7 +650,7 @@ int esvo_ts_render(esvo_handle h, int cam, uint64_t t_ns, uint8_t* out_mono8) {
   const auto& tsq = h->ts_host[cam];
   const size_t k = std::lower_bound(tsq.begin(), tsq.end(), (u64)t_ns) - tsq.begin();
   const u64 upto = h->ring_base[cam] + k;
-  if (h->evt_ok) hipEventRecord(h->evt[0], h->stream);
+  hipEventRecord(h->evt[EV_SC0], h->stream);
   if (upto > h->scattered[cam]) {
     u64 a = h->scattered[cam];
     const u64 total = upto - a;
@@ -642,20 +663,18 @@ int esvo_ts_render(esvo_handle h, int cam, uint64_t t_ns, uint8_t* out_mono8) {
     h->scattered[cam] = upto;
     h->stats.events_scattered[cam] += total;
   }
-  if (h->evt_ok) hipEventRecord(h->evt[1], h->stream);
+  hipEventRecord(h->evt[EV_SC1], h->stream);
   launch_ts_render(h->d_sae[cam], h->d_fixmap[cam], h->d_raw, h->d_ts[cam], h->W, h->H, (u64)t_ns, h->prm.decay_ms / 1000.0,
                    h->prm.ignore_polarity, h->prm.median_blur_kernel_size, h->stream);
-  if (h->evt_ok) hipEventRecord(h->evt[2], h->stream);
+  hipEventRecord(h->evt[EV_R1], h->stream);
   HIPCHK(hipGetLastError());
   h->ts_valid[cam] = true;
+  h->ts_timing_pending = true;
   h->stats.ts_frames[cam]++;
   if (out_mono8) {
     HIPCHK(hipMemcpyAsync(out_mono8, h->d_ts[cam], (size_t)h->W * h->H, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    if (h->evt_ok) {
-      hipEventElapsedTime(&h->stats.ms_ts_scatter, h->evt[0], h->evt[1]);
-      hipEventElapsedTime(&h->stats.ms_ts_render, h->evt[1], h->evt[2]);
-    }
+    collect_ts_timing(h);
   }
   return ESVO_OK;
 }
@@ -767,7 +786,6 @@ int esvo_map_fuse(esvo_handle h, size_t* n_fusions) {
   if (!h) return ESVO_ERR_INVALID_ARG;
   if (!h->obs_set) FAIL(ESVO_ERR_STATE, "esvo_map_set_observation has not been called");
   HIPCHK(hipSetDevice(h->device));
-  if (h->evt_ok) hipEventRecord(h->evt[3], h->stream);
   int rc = run_fuse(h);
   if (rc) return rc;
   rc = read_counters(h);
@@ -777,10 +795,8 @@ int esvo_map_fuse(esvo_handle h, size_t* n_fusions) {
   u32 np = 0;
   for (auto& f : h->frames) np += f.count;
   h->stats.last_window_points = np;
-  if (h->evt_ok) {
-    hipEventElapsedTime(&h->stats.ms_fusion, h->evt[3], h->evt[4]);
-    hipEventElapsedTime(&h->stats.ms_regularization, h->evt[4], h->evt[5]);
-  }
+  hipEventElapsedTime(&h->stats.ms_fusion, h->evt[EV_FU0], h->evt[EV_CL1]);
+  hipEventElapsedTime(&h->stats.ms_regularization, h->evt[EV_CL1], h->evt[EV_RG1]);
   if (n_fusions) *n_fusions = h->h_counters[3];
   return ESVO_OK;
 }
@@ -808,16 +824,14 @@ int esvo_map_tick(esvo_handle h, uint64_t t_ns, const uint64_t* pose_t_ns, const
   if (n && first - (n - 1) < h->ring_next[0] - std::min<u64>(h->ring_next[0], h->ring_cap))
     FAIL(ESVO_ERR_STATE, "selected events were already overwritten in the event ring");
 
-  hipEventRecord(h->evt[6], h->stream);
+  hipEventRecord(h->evt[EV_T0], h->stream);
   HIPCHK(hipMemsetAsync(h->d_counters, 0, sizeof(u32) * 8, h->stream));
   if (n) { rc = run_match(h, h->d_ring[0], first, h->ring_cap, 1, n); if (rc) return rc; }
-  hipEventRecord(h->evt[7], h->stream);
   // the new frame goes straight into the window ring (capacity for the worst case: n points)
   u32 off;
   rc = window_reserve(h, n, &off);
   if (rc) return rc;
   if (n) { rc = run_refine(h, n, 1, h->d_win + off); if (rc) return rc; }
-  hipEventRecord(h->evt[3], h->stream);
   rc = read_counters(h);  // the window policy needs the point count (one small D2H per tick)
   if (rc) return rc;
   const u32 n_matches = h->h_counters[0], n_points = n ? h->h_counters[1] : 0, n_solved = h->h_counters[2];
@@ -835,11 +849,21 @@ int esvo_map_tick(esvo_handle h, uint64_t t_ns, const uint64_t* pose_t_ns, const
   u32 np = 0;
   for (auto& f : h->frames) np += f.count;
   s.last_window_points = np;
-  hipEventElapsedTime(&s.ms_bm, h->evt[6], h->evt[7]);
-  hipEventElapsedTime(&s.ms_refine, h->evt[7], h->evt[3]);
-  hipEventElapsedTime(&s.ms_fusion, h->evt[3], h->evt[4]);
-  hipEventElapsedTime(&s.ms_regularization, h->evt[4], h->evt[5]);
-  hipEventElapsedTime(&s.ms_tick_total, h->evt[6], h->evt[5]);
+  collect_ts_timing(h);
+  s.ms_bm = s.ms_refine = 0;
+  s.ms_kernel[2] = s.ms_kernel[3] = 0;
+  if (n) {
+    hipEventElapsedTime(&s.ms_bm, h->evt[EV_T0], h->evt[EV_S1]);
+    hipEventElapsedTime(&s.ms_refine, h->evt[EV_S1], h->evt[EV_S2]);
+    hipEventElapsedTime(&s.ms_kernel[2], h->evt[EV_BM0], h->evt[EV_BM1]);
+    hipEventElapsedTime(&s.ms_kernel[3], h->evt[EV_LM0], h->evt[EV_LM1]);
+  }
+  hipEventElapsedTime(&s.ms_fusion, h->evt[EV_FU0], h->evt[EV_CL1]);
+  hipEventElapsedTime(&s.ms_regularization, h->evt[EV_CL1], h->evt[EV_RG1]);
+  hipEventElapsedTime(&s.ms_kernel[4], h->evt[EV_FU0], h->evt[EV_FU1]);
+  hipEventElapsedTime(&s.ms_kernel[5], h->evt[EV_FU1], h->evt[EV_CL1]);
+  hipEventElapsedTime(&s.ms_kernel[6], h->evt[EV_CL1], h->evt[EV_RG1]);
+  hipEventElapsedTime(&s.ms_tick_total, h->evt[EV_T0], h->evt[EV_RG1]);
   return ESVO_OK;
 }
 

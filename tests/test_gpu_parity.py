@@ -57,7 +57,7 @@ def test_time_surface_bit_exact(rig_name):
     O = _oracle()
     rig = calib.ideal_rig(346, 260, 200.0, 0.1) if rig_name == "ideal" else calib.dataset_rig(rig_name)
     st = synth.make_stream(rig, 8000, 0.1, 0.05, 0.5, seed=7 + len(rig_name))
-    p, _ = params.make_params(params.PRESETS["mvstereo_upenn"], rig)
+    p, _ = params.make_params(params.PRESETS["mapping_dsec" if rig_name == "dsec" else "mvstereo_upenn"], rig)
     dev = _dev(p, rig)
     ots = [O.OracleTS(rig.width, rig.height), O.OracleTS(rig.width, rig.height)]
     # push in 1 ms blocks like events_repacking_helper, render at 100 Hz ticks
