@@ -945,3 +945,10 @@ int esvo_shard_tick_phase(esvo_handle h, int phase, uint64_t t_ns, const uint64_
 }
 
 }  // extern "C"
+
+// sizeof() of every POD of the ABI (binding self-check)
+extern "C" void esvo_abi_sizes(size_t out[8]) {
+  out[0] = sizeof(esvo_event_t); out[1] = sizeof(esvo_calib_t); out[2] = sizeof(esvo_params_t);
+  out[3] = sizeof(esvo_match_t); out[4] = sizeof(esvo_depth_point_t); out[5] = sizeof(esvo_stats_t);
+  out[6] = sizeof(esvo_shard_buffers_t); out[7] = ESVO_HIP_ABI_VERSION;
+}

@@ -24,7 +24,7 @@ SYMBOLS = [
     "esvo_set_stream", "esvo_synchronize", "esvo_ts_push_events", "esvo_ts_render", "esvo_map_set_observation",
     "esvo_map_match", "esvo_map_set_poses", "esvo_map_refine", "esvo_map_push_frame", "esvo_map_fuse",
     "esvo_map_tick", "esvo_map_get_depth_points", "esvo_map_get_pointcloud_xyz", "esvo_map_get_last_frame",
-    "esvo_get_stats", "esvo_shard_set_band", "esvo_shard_buffers", "esvo_shard_tick_phase",
+    "esvo_get_stats", "esvo_shard_set_band", "esvo_shard_buffers", "esvo_shard_tick_phase", "esvo_abi_sizes",
 ]
 
 
@@ -86,10 +86,18 @@ def load():
     lib.esvo_shard_buffers.argtypes = [vp, vp]
     lib.esvo_shard_tick_phase.argtypes = [vp, i32, u64, vp, vp, sz]
     for s in SYMBOLS:
-        if s not in ("esvo_default_params", "esvo_last_error"):
+        if s not in ("esvo_default_params", "esvo_last_error", "esvo_abi_sizes"):
             getattr(lib, s).restype = C.c_int
+    lib.esvo_abi_sizes.argtypes = [vp]
+    lib.esvo_abi_sizes.restype = None
     _lib = lib
     return lib
+
+
+def abi_sizes():
+    out = (C.c_size_t * 8)()
+    load().esvo_abi_sizes(out)
+    return list(out)
 
 
 def _p(a):

@@ -246,6 +246,9 @@ int esvo_map_get_pointcloud_xyz(esvo_handle h, float* out_xyz, size_t cap_points
 /* The newest frame of the fusion window (culled DepthPoints of the last tick). */
 int esvo_map_get_last_frame(esvo_handle h, esvo_depth_point_t* out, size_t cap, size_t* n);
 int esvo_get_stats(esvo_handle h, esvo_stats_t* out);
+/* sizeof() of {event, calib, params, match, depth_point, stats, shard_buffers} + ABI version:
+ * lets a foreign-language binding check its struct mirrors. */
+void esvo_abi_sizes(size_t out[8]);
 
 /* ---- Multi-GPU row-band sharding ----------------------------------- */
 

@@ -1333,3 +1333,30 @@ extern "C" void orc_mapper_counters(orc_mapper_handle h, uint64_t out[8]) {
   out[0] = h->window.size(); out[1] = np; out[2] = h->n_replace; out[3] = h->n_replace_displaced;
   out[4] = h->max_scale_iters; out[5] = h->n_evals; out[6] = out[7] = 0;
 }
+
+// residual vector of DepthProblem::operator() for one match at inverse depth rho (unit tests:
+// comparison of the restated LM against scipy's MINPACK wrapper)
+extern "C" int orc_mapper_eval_residual(orc_mapper_handle h, const double x_left[2], uint32_t pose_idx, double rho,
+                                        double* fvec) {
+  DepthProblem prob{h, h->prm.patch_size_x, h->prm.patch_size_y, {0, 0}, {0}};
+  prob.setProblem(x_left, h->pose_T[pose_idx]);
+  return prob(rho, fvec);
+}
+// ZNCC cost of two wy x wx patches (row-major doubles), literal and integer-moment forms
+extern "C" double orc_zncc_cost(const double* l, const double* r, int wx, int wy, int exact_int) {
+  if (!exact_int) {
+    std::vector<double> t1((size_t)wx * wy), t2((size_t)wx * wy);
+    return zncc_cost(l, r, wx, wy, t1.data(), t2.data());
+  }
+  int64_t Sl = 0, Sll = 0, Sr = 0, Srr = 0, Slr = 0;
+  for (int i = 0; i < wx * wy; ++i) {
+    int64_t a = (int64_t)l[i], b = (int64_t)r[i];
+    Sl += a; Sll += a * a; Sr += b; Srr += b * b; Slr += a * b;
+  }
+  return zncc_cost_int(Sl, Sll, Sr, Srr, Slr, wx * wy);
+}
+extern "C" void orc_abi_sizes(size_t out[8]) {
+  out[0] = sizeof(esvo_event_t); out[1] = sizeof(esvo_calib_t); out[2] = sizeof(esvo_params_t);
+  out[3] = sizeof(esvo_match_t); out[4] = sizeof(esvo_depth_point_t); out[5] = sizeof(esvo_stats_t);
+  out[6] = sizeof(esvo_shard_buffers_t); out[7] = 0;
+}

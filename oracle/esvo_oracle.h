@@ -103,6 +103,10 @@ size_t orc_mapper_get_pointcloud_xyz(orc_mapper_handle h, float* out_xyz, size_t
 /* counters: [0] window frames [1] window points [2] replace-branch hits [3] replace hits with
  * a displaced cell (row/col differ) [4] max t-scale loop iterations seen [5] LM evaluations */
 void orc_mapper_counters(orc_mapper_handle h, uint64_t out[8]);
+/* unit-test hooks */
+int orc_mapper_eval_residual(orc_mapper_handle h, const double x_left[2], uint32_t pose_idx, double rho, double* fvec);
+double orc_zncc_cost(const double* l, const double* r, int wx, int wy, int exact_int);
+void orc_abi_sizes(size_t out[8]);
 
 #ifdef __cplusplus
 }

@@ -82,6 +82,11 @@ def load(fast=False):
     lib.orc_mapper_get_pointcloud_xyz.restype = sz
     lib.orc_mapper_get_pointcloud_xyz.argtypes = [vp, vp, sz]
     lib.orc_mapper_counters.argtypes = [vp, vp]
+    lib.orc_mapper_eval_residual.restype = i32
+    lib.orc_mapper_eval_residual.argtypes = [vp, vp, C.c_uint32, dbl, vp]
+    lib.orc_zncc_cost.restype = dbl
+    lib.orc_zncc_cost.argtypes = [vp, vp, i32, i32, i32]
+    lib.orc_abi_sizes.argtypes = [vp]
     _libs[key] = lib
     return lib
 
@@ -263,8 +268,28 @@ class OracleMapper:
         n = self.lib.orc_mapper_get_pointcloud_xyz(self.h, out.ctypes.data, out.shape[0])
         return out[:n]
 
+    def eval_residual(self, x_left, pose_idx, rho):
+        x = np.ascontiguousarray(x_left, np.float64)
+        f = np.empty(self.params.patch_size_x * self.params.patch_size_y, np.float64)
+        ok = self.lib.orc_mapper_eval_residual(self.h, x.ctypes.data, int(pose_idx), float(rho), f.ctypes.data)
+        return f, ok
+
     def counters(self):
         c = np.zeros(8, np.uint64)
         self.lib.orc_mapper_counters(self.h, c.ctypes.data)
         return dict(window_frames=int(c[0]), window_points=int(c[1]), replace=int(c[2]),
                     replace_displaced=int(c[3]), max_scale_iters=int(c[4]), lm_evals=int(c[5]))
+
+
+def zncc_cost(l, r, exact_int=False):
+    lib = load()
+    l = np.ascontiguousarray(l, np.float64)
+    r = np.ascontiguousarray(r, np.float64)
+    return lib.orc_zncc_cost(l.ctypes.data, r.ctypes.data, l.shape[1], l.shape[0], int(exact_int))
+
+
+def abi_sizes():
+    lib = load()
+    out = (C.c_size_t * 8)()
+    lib.orc_abi_sizes(out)
+    return list(out)
