@@ -107,6 +107,9 @@ struct esvo_context {
   MapCell* d_map_cur = nullptr;
   u32* d_owner_max = nullptr;
   u32* d_owner_min = nullptr;
+  u64* d_reg_bits = nullptr;
+  double2* d_reg_ab = nullptr;
+  double2* d_reg_cd = nullptr;
   double T_world_frame[16];
   // export
   u32* d_exp_flags = nullptr;
@@ -363,7 +366,8 @@ int run_fuse(esvo_context* h) {
   if (do_clean) launch_clean(h->d_map, h->dp, h->stream);
   hipEventRecord(h->evt[EV_CL1], h->stream);
   if (h->prm.regularization) {
-    launch_regularize(h->d_map, h->d_map2, h->d_owner_max, h->d_owner_min, h->dp, h->stream);
+    launch_regularize(h->d_map, h->d_map2, h->d_owner_max, h->d_owner_min, h->d_reg_bits, h->d_reg_ab, h->d_reg_cd, h->dp,
+                      h->stream);
     h->d_map_cur = h->d_map2;
   }
   hipEventRecord(h->evt[EV_RG1], h->stream);
@@ -477,11 +481,11 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
     CK(hipMemcpy(h->d_fixmap[cam], fm.data(), sizeof(int2) * npx, hipMemcpyHostToDevice));
     CK(dalloc(&h->d_sae[cam], npx));
     CK(hipMemset(h->d_sae[cam], 0, sizeof(u64) * npx));
-    CK(dalloc(&h->d_ts[cam], npx));
-    CK(dalloc(&h->d_obs[cam], npx));
+    CK(dalloc(&h->d_ts[cam], npx + 64));
+    CK(dalloc(&h->d_obs[cam], npx + 64));
   }
-  CK(dalloc(&h->d_raw, npx));
-  CK(dalloc(&h->d_obs_tmp, npx));
+  CK(dalloc(&h->d_raw, npx + 64));
+  CK(dalloc(&h->d_obs_tmp, npx + 64));
   h->ring_cap = (u64)std::max<int64_t>(params->event_ring_capacity, 1024);
   for (int cam = 0; cam < 2; ++cam) CK(dalloc(&h->d_ring[cam], h->ring_cap));
   CK(dalloc(&h->d_T_world_obs, 16));
@@ -527,6 +531,9 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
   h->d_map_cur = h->d_map;
   CK(dalloc(&h->d_owner_max, npx));
   CK(dalloc(&h->d_owner_min, npx));
+  CK(dalloc(&h->d_reg_bits, npx / 64 + 2));
+  CK(dalloc(&h->d_reg_ab, npx));
+  CK(dalloc(&h->d_reg_cd, npx));
   CK(dalloc(&h->d_exp_flags, npx));
   CK(dalloc(&h->d_exp_prefix, npx));
   CK(dalloc(&h->d_export, npx));
@@ -550,7 +557,7 @@ int esvo_destroy(esvo_handle h) {
                   h->d_matches, h->d_pt_slots, h->d_pt_flags, h->d_pt_prefix, h->d_pts_tmp, h->d_counters, h->d_scan_tmp,
                   h->d_win, h->d_frame_pose_T, h->d_fr_table, h->d_prop, h->d_cell_count, h->d_cell_offset,
                   h->d_cell_fill, h->d_rec_ids, h->d_map, h->d_map2, h->d_owner_max, h->d_owner_min, h->d_exp_flags,
-                  h->d_exp_prefix, h->d_export, h->d_export_cell};
+                  h->d_exp_prefix, h->d_export, h->d_export_cell, h->d_reg_bits, h->d_reg_ab, h->d_reg_cd};
   for (void* p : ptrs) if (p) hipFree(p);
   if (h->h_counters) hipHostFree(h->h_counters);
   if (h->h_fr_table) hipHostFree(h->h_fr_table);

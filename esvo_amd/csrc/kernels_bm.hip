@@ -3,10 +3,11 @@
 // Replaces EventBM::match_an_event + epipolarSearching + zncc_cost
 // (esvo_core/src/core/EventBM.cpp:80-226,317-333; tools::normalizePatch utils.h:74-92).
 //
-// Work decomposition: one wave64 per event, 4 events per 256-thread workgroup.  The wave stages
-// the event's left patch (wx*wy bytes) and the right epipolar strip (wy rows x (wx + Nd - 1)
-// columns, u8) in LDS; lane l then owns disparity candidate dmin + l (+64k) and accumulates the
-// integer moments Sr, Srr, Slr of its window (the left moments are wave-reduced once).  Time
+// Work decomposition: G lanes per event (G in {8,16,32,64}, chosen so that the candidate slots
+// ceil(Nd/G)*G waste the least; 256/G events per workgroup).  The group stages the event's left
+// patch and the right epipolar strip (7 rows x (15 + Nd - 1) columns, u8) in LDS; lane l owns the
+// disparity candidates dmin + l (+G...) and accumulates the integer moments Sr, Srr, Slr of its
+// window with packed v_dot4_u32_u8 (the left moments are group-reduced once).  Time
 // Surface values are integers 0..255, so the ZNCC cost follows exactly from integer moments:
 //   cost = 0.5 * (1 - (Slr - Sl*Sr/N) / ((sig_l + 1e-6)(sig_r + 1e-6)) / N)
 // evaluated in f64 with the same expression sequence as the oracle's zncc_cost_int.  The
@@ -41,15 +42,32 @@ __device__ inline double zncc_from_moments(long long Sl, long long Sll, long lon
 
 extern __shared__ __attribute__((aligned(16))) unsigned char bm_smem[];
 
-__global__ void __launch_bounds__(256) bm_match_kernel(BmArgs a, DevParams p, int lds_per_wave, int left_bytes) {
-  const int wave_in_block = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const u32 w = blockIdx.x * 4 + wave_in_block;  // slot in thread-stride order
-  unsigned char* ldsL = bm_smem + wave_in_block * lds_per_wave;
-  unsigned char* ldsR = ldsL + left_bytes;
+template <int G>
+__device__ inline int grp_sum_i32(int v) {
+#pragma unroll
+  for (int d = G / 2; d >= 1; d >>= 1) v += __shfl_xor(v, d, G);
+  return v;
+}
 
-  const int W = p.W, H = p.H, wx = p.wx, wy = p.wy, N = wx * wy;
-  const int hx = (wx - 1) / 2, hy = (wy - 1) / 2;
-  const int Ws = (p.dmax - p.dmin) + wx;
+// G lanes per event (64/G events per wave, 256/G per workgroup).  Inside a group, lane l owns
+// the disparity candidates dmin + l, dmin + l + G, ...
+//
+// LDS per event: the right strip as RD aligned dwords per row (a dword-aligned copy of global
+// memory: no shifting while staging) and the left patch as 4 dwords per row (15 pixels + a zero
+// pad byte).  A candidate's 15-pixel window starts at an arbitrary byte offset of its row, so
+// each lane reads 5 dwords per row, re-aligns them with v_alignbyte_b32 and accumulates
+// S_r, S_rr and S_lr with v_dot4_u32_u8 (the pad byte of the left patch is zero and the 16th
+// byte of the window is masked out).
+template <int G>
+__global__ void __launch_bounds__(256) bm_match_kernel(BmArgs a, DevParams p, int RD, int lds_per_event) {
+  constexpr int EPB = 256 / G;  // events per block
+  const int grp = threadIdx.x / G, l = threadIdx.x % G;
+  const u32 w = blockIdx.x * EPB + grp;  // slot in thread-stride order
+  u32* ldsL = reinterpret_cast<u32*>(bm_smem + grp * lds_per_event);  // [7][4] dwords
+  u32* ldsR = ldsL + 28;                                              // [7][RD] dwords
+
+  const int W = p.W, H = p.H;
+  constexpr int wx = 15, wy = 7, N = wx * wy, hx = 7, hy = 3;
 
   bool ok = w < a.n;
   u32 k = 0;
@@ -64,9 +82,9 @@ __global__ void __launch_bounds__(256) bm_match_kernel(BmArgs a, DevParams p, in
   int x1 = 0, y1 = 0;
   if (ok) ok = ex < W && ey < H;
   if (ok) {
-    const float2 l = a.lut[ey * W + ex];  // getRectifiedUndistortedCoordinate, EventBM.cpp:88
-    xr = (double)l.x;
-    yr = (double)l.y;
+    const float2 q = a.lut[ey * W + ex];  // getRectifiedUndistortedCoordinate, EventBM.cpp:88
+    xr = (double)q.x;
+    yr = (double)q.y;
     ok = !(xr < 0 || xr > (double)(W - 1) || yr < 0 || yr > (double)(H - 1));  // :90-92
   }
   if (ok && a.mask) ok = a.mask[(int)yr * W + (int)xr] > 125;  // :94 (index truncation)
@@ -75,68 +93,95 @@ __global__ void __launch_bounds__(256) bm_match_kernel(BmArgs a, DevParams p, in
     y1 = (int)floor(yr);
     ok = (y1 >= p.band_y0 && y1 < p.band_y1);  // row-band sharding
   }
-  if (ok) {  // isValidPatch, EventBM.cpp:251-267
-    ok = !(x1 - hx < 1 || y1 - hy < 1 || x1 + hx >= W - 1 || y1 + hy >= H - 1);
-  }
+  if (ok) ok = !(x1 - hx < 1 || y1 - hy < 1 || x1 + hx >= W - 1 || y1 + hy >= H - 1);  // isValidPatch, :251-267
 
-  // ---- stage the left patch, left moments, low-texture test (:101-109) ----
+  // ---- stage the left patch (bytes -> LDS), left moments, low-texture test (:101-109) ----
   long long Sl = 0, Sll = 0;
   if (ok) {
-    int cnt = 0, sl = 0;
-    long long sll = 0;
-    for (int i = lane; i < N; i += ESVO_WAVE) {
+    for (int i = l; i < 28; i += G) ldsL[i] = 0u;  // zero incl. the pad bytes (same lane order as below: in-order LDS)
+  }
+  __syncthreads();
+  if (ok) {
+    int cnt = 0, sl = 0, sll = 0;
+    unsigned char* lb = reinterpret_cast<unsigned char*>(ldsL);
+    for (int i = l; i < N; i += G) {
       const int py = i / wx, px = i - py * wx;
       const int v = a.tsL[(y1 - hy + py) * W + (x1 - hx + px)];
-      ldsL[i] = (unsigned char)v;
+      lb[py * 16 + px] = (unsigned char)v;
       cnt += (v < 1);
       sl += v;
       sll += v * v;
     }
-    cnt = wave_sum_i32(cnt);
-    Sl = wave_sum_i32(sl);
-    Sll = wave_sum_i64(sll);
+    cnt = grp_sum_i32<G>(cnt);
+    Sl = grp_sum_i32<G>(sl);
+    Sll = grp_sum_i32<G>(sll);  // <= 105 * 255^2 < 2^31
     if ((double)cnt > 0.95 * (double)N) ok = false;
   }
-  // ---- stage the right strip ----
+  // ---- stage the right strip: aligned dwords straight from the (dword-padded) image ----
   const int xs0 = x1 - p.dmax - hx;
+  int o_row[wy];  // byte offset of column xs0 inside the first staged dword of each row
   if (ok) {
-    for (int i = lane; i < wy * Ws; i += ESVO_WAVE) {
-      const int ry = i / Ws, rx = i - ry * Ws;
-      const int gx = xs0 + rx, gy = y1 - hy + ry;
-      ldsR[i] = (gx >= 0 && gx < W) ? a.tsR[gy * W + gx] : (unsigned char)0;
+    const u32* ts32 = reinterpret_cast<const u32*>(a.tsR);
+    const int n_dw = (W * H + 3) >> 2;
+#pragma unroll
+    for (int py = 0; py < wy; ++py) {
+      const int A = (y1 - hy + py) * W + xs0;
+      const int a0 = A >> 2;  // arithmetic shift = floor
+      o_row[py] = A - (a0 << 2);
+      for (int j = l; j < RD; j += G) {
+        int idx = a0 + j;
+        idx = idx < 0 ? 0 : (idx >= n_dw ? n_dw - 1 : idx);  // only bytes of invalid candidates can be clamped
+        ldsR[py * RD + j] = ts32[idx];
+      }
     }
   }
-  __syncthreads();  // all four waves reach this (no early exits); makes the LDS tiles visible
+  __syncthreads();
 
   double best = 1.0;  // ZNCC_MAX_
   int bestd = -1;
   if (ok) {
-    for (int d = p.dmin + lane; d <= p.dmax; d += ESVO_WAVE) {
+    u32 L[wy][4];
+#pragma unroll
+    for (int py = 0; py < wy; ++py) {
+      const uint4 v = *reinterpret_cast<const uint4*>(ldsL + py * 4);
+      L[py][0] = v.x; L[py][1] = v.y; L[py][2] = v.z; L[py][3] = v.w;
+    }
+    for (int d = p.dmin + l; d <= p.dmax; d += G) {
       const int x2 = x1 - d;
       if (x2 - hx < 1 || x2 + hx >= W - 1) continue;  // invalid candidates never update (:186-190)
       const int col0 = p.dmax - d;
-      int sr = 0, slr = 0;
-      long long srr = 0;
+      u32 sr = 0, srr = 0, slr = 0;
+#pragma unroll
       for (int py = 0; py < wy; ++py) {
-        const unsigned char* rrow = ldsR + py * Ws + col0;
-        const unsigned char* lrow = ldsL + py * wx;
-        int rr = 0;
-        for (int px = 0; px < wx; ++px) {
-          const int r = rrow[px], l = lrow[px];
-          sr += r;
-          rr += r * r;
-          slr += l * r;
-        }
-        srr += rr;
+        const int b = o_row[py] + col0;
+        const u32* row = ldsR + py * RD + (b >> 2);
+        const u32 sh = (u32)(b & 3);
+        const u32 d0 = row[0], d1 = row[1], d2 = row[2], d3 = row[3], d4 = row[4];
+        const u32 w0 = __builtin_amdgcn_alignbyte(d1, d0, sh);
+        const u32 w1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+        const u32 w2 = __builtin_amdgcn_alignbyte(d3, d2, sh);
+        const u32 w3 = __builtin_amdgcn_alignbyte(d4, d3, sh) & 0x00ffffffu;
+        slr = __builtin_amdgcn_udot4(L[py][0], w0, slr, false);
+        slr = __builtin_amdgcn_udot4(L[py][1], w1, slr, false);
+        slr = __builtin_amdgcn_udot4(L[py][2], w2, slr, false);
+        slr = __builtin_amdgcn_udot4(L[py][3], w3, slr, false);
+        sr = __builtin_amdgcn_udot4(w0, 0x01010101u, sr, false);
+        sr = __builtin_amdgcn_udot4(w1, 0x01010101u, sr, false);
+        sr = __builtin_amdgcn_udot4(w2, 0x01010101u, sr, false);
+        sr = __builtin_amdgcn_udot4(w3, 0x01010101u, sr, false);
+        srr = __builtin_amdgcn_udot4(w0, w0, srr, false);
+        srr = __builtin_amdgcn_udot4(w1, w1, srr, false);
+        srr = __builtin_amdgcn_udot4(w2, w2, srr, false);
+        srr = __builtin_amdgcn_udot4(w3, w3, srr, false);
       }
-      const double cost = zncc_from_moments(Sl, Sll, sr, srr, slr, N);
+      const double cost = zncc_from_moments(Sl, Sll, (long long)sr, (long long)srr, (long long)slr, N);
       if (cost <= best) { best = cost; bestd = d; }  // :198 (lane scans increasing d)
     }
-    // wave argmin; ties -> larger disparity
+    // group argmin; ties -> larger disparity
 #pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) {
-      const double oc = __shfl_xor(best, s, ESVO_WAVE);
-      const int od = __shfl_xor(bestd, s, ESVO_WAVE);
+    for (int s = G / 2; s >= 1; s >>= 1) {
+      const double oc = __shfl_xor(best, s, G);
+      const int od = __shfl_xor(bestd, s, G);
       if (od >= 0 && (bestd < 0 || oc < best || (oc == best && od > bestd))) { best = oc; bestd = od; }
     }
     ok = bestd >= 0 && best < p.zncc_thr;  // :222 (fine search re-evaluates the same candidate)
@@ -152,7 +197,7 @@ __global__ void __launch_bounds__(256) bm_match_kernel(BmArgs a, DevParams p, in
     pose_idx = lo;
     ok = lo < a.n_pose;  // EventBM.cpp:155-156
   }
-  if (w < a.n && lane == 0) {
+  if (w < a.n && l == 0) {
     a.out_flags[w] = ok ? 1u : 0u;
     if (ok) {
       esvo_match_t m;
@@ -170,14 +215,30 @@ __global__ void __launch_bounds__(256) bm_match_kernel(BmArgs a, DevParams p, in
   }
 }
 
+template <int G>
+static void launch_bm_g(const BmArgs& a, const DevParams& p, int RD, hipStream_t s) {
+  const int per_event = (28 + 7 * RD) * 4;
+  const int epb = 256 / G;
+  const u32 blocks = (a.n + epb - 1) / epb;
+  hipLaunchKernelGGL(bm_match_kernel<G>, dim3(blocks), dim3(256), (size_t)per_event * epb, s, a, p, RD, per_event);
+}
+
 void launch_bm_match(const BmArgs& a, const DevParams& p, hipStream_t s) {
   if (a.n == 0) return;
-  const int left_bytes = ((p.wx * p.wy + 15) / 16) * 16;
-  const int Ws = (p.dmax - p.dmin) + p.wx;
-  const int right_bytes = ((p.wy * Ws + 15) / 16) * 16;
-  const int per_wave = left_bytes + right_bytes;
-  const u32 blocks = (a.n + 3) / 4;
-  hipLaunchKernelGGL(bm_match_kernel, dim3(blocks), dim3(256), (size_t)per_wave * 4, s, a, p, per_wave, left_bytes);
+  const int nd = p.dmax - p.dmin + 1;
+  const int RD = ((nd + 2) >> 2) + 5;  // dwords staged per strip row
+  // lanes per event: the group size that wastes the fewest candidate slots (ties -> wider)
+  int bestG = 64, bestSlots = 1 << 30;
+  for (int G = 64; G >= 8; G >>= 1) {
+    const int slots = ((nd + G - 1) / G) * G;
+    if (slots < bestSlots) { bestSlots = slots; bestG = G; }
+  }
+  switch (bestG) {
+    case 64: launch_bm_g<64>(a, p, RD, s); break;
+    case 32: launch_bm_g<32>(a, p, RD, s); break;
+    case 16: launch_bm_g<16>(a, p, RD, s); break;
+    default: launch_bm_g<8>(a, p, RD, s); break;
+  }
 }
 
 // stable compaction: slot w -> position prefix[w]

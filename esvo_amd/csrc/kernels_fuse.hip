@@ -138,18 +138,34 @@ __global__ void __launch_bounds__(256) fuse_cells_kernel(FuseArgs a, DevParams p
   const u32 n = a.cell_count[cell];
   if (n == 0) { a.map[cell].flags = 0; return; }
   u32* ids = a.rec_ids + a.cell_offset[cell];
-  // insertion sort in place (lists are short: a handful of records per touched cell)
-  for (u32 i = 1; i < n; ++i) {
-    const u32 key = ids[i];
-    int j = (int)i - 1;
-    while (j >= 0 && ids[j] > key) { ids[j + 1] = ids[j]; --j; }
-    ids[j + 1] = key;
+  // Records must be applied in increasing id order.  Short lists (the common case) are walked by
+  // repeated minimum selection straight from the (cached) id list; long ones are insertion-sorted
+  // in place first.
+  const bool presorted = n > 12;
+  if (presorted) {
+    for (u32 i = 1; i < n; ++i) {
+      const u32 key = ids[i];
+      int j = (int)i - 1;
+      while (j >= 0 && ids[j] > key) { ids[j + 1] = ids[j]; --j; }
+      ids[j + 1] = key;
+    }
   }
   MapCell c;
   bool exists = false;
   u32 numFusion = 0;
+  u32 last = 0;
   for (u32 i = 0; i < n; ++i) {
-    const u32 id = ids[i];
+    u32 id;
+    if (presorted) {
+      id = ids[i];
+    } else {
+      id = 0xffffffffu;
+      for (u32 j = 0; j < n; ++j) {
+        const u32 v = ids[j];
+        if ((i == 0 || v > last) && v < id) id = v;
+      }
+      last = id;
+    }
     const DevPoint& prop = a.prop[id / (u32)K];
     if (!exists) {  // case 1: DepthFusion.cpp:127-146
       c.row = (u32)crow; c.col = (u32)ccol;
@@ -231,13 +247,32 @@ __global__ void __launch_bounds__(256) reg_owner_kernel(const MapCell* __restric
   atomicMin(&owner_min[b], c.seq);
 }
 
-__device__ inline bool nb_valid(const MapCell& n) {
-  return (n.flags & CELL_ALIVE) && (n.flags & CELL_GRID) && n.inv_depth > -1e-6;
+// Compact "regularisation view" of the map: what the (2r+1)^2 neighbourhood scan reads.
+//   bits  : 1 bit per cell (u64 words over the linear cell index): exists(r,c) && at(r,c).valid()
+//   ab[c] : (inv_depth, 2*sqrt(variance))     -- the closeness test operands
+//   cd[c] : (nu, scale2)                      -- read only for close neighbours
+// 16 B per tap instead of a 104 B MapCell, empty cells are skipped 64 at a time, and the
+// neighbour's sqrt is computed once per cell instead of once per tap.
+__global__ void __launch_bounds__(256) reg_view_kernel(const MapCell* __restrict__ map, u64* __restrict__ bits,
+                                                       double2* __restrict__ ab, double2* __restrict__ cd, int ncell) {
+  const int cell = blockIdx.x * blockDim.x + threadIdx.x;
+  bool v = false;
+  if (cell < ncell) {
+    const MapCell& n = map[cell];
+    v = (n.flags & CELL_ALIVE) && (n.flags & CELL_GRID) && n.inv_depth > -1e-6;
+    if (v) {
+      ab[cell] = make_double2(n.inv_depth, 2.0 * sqrt(n.variance));
+      cd[cell] = make_double2(n.nu, n.scale2);
+    }
+  }
+  const u64 m = __ballot(v);
+  if ((threadIdx.x & 63) == 0 && cell < ncell) bits[cell >> 6] = m;
 }
 
 __global__ void __launch_bounds__(256) reg_apply_kernel(const MapCell* __restrict__ map, MapCell* __restrict__ out,
                                                         const u32* __restrict__ owner_max, const u32* __restrict__ owner_min,
-                                                        DevParams p) {
+                                                        const u64* __restrict__ bits, const double2* __restrict__ ab,
+                                                        const double2* __restrict__ cd, DevParams p) {
   const int cell = blockIdx.x * blockDim.x + threadIdx.x;
   if (cell >= p.W * p.H) return;
   const int crow = cell / p.W;
@@ -255,27 +290,39 @@ __global__ void __launch_bounds__(256) reg_apply_kernel(const MapCell* __restric
     // row < radius or col < radius the loops never execute -> no neighbours at all.
     if (row >= R && col >= R) {
       const double sd_self2 = 2.0 * sqrt(c.variance);
-      for (int r = row - R; r <= row + R; ++r) {
-        if (r >= p.H) break;
-        for (int cc = col - R; cc <= col + R; ++cc) {
-          if (cc >= p.W) break;
-          const MapCell& n = map[r * p.W + cc];
-          if (!nb_valid(n)) continue;
-          n_nb++;
-          const double diff = fabs(c.inv_depth - n.inv_depth);
-          if (diff < sd_self2 || diff < 2.0 * sqrt(n.variance)) {
-            if (n_close == 0) {
-              nu_post = n.nu; inv_post = n.inv_depth; s2_post = n.scale2;
-            } else {  // DepthRegularization.cpp:72-86
-              const double nu_prior = nu_post, inv_prior = inv_post, s2_prior = s2_post;
-              const double nu_obs = n.nu, inv_obs = n.inv_depth, s2_obs = n.scale2;
-              nu_post = (nu_obs < nu_prior) ? nu_obs : nu_prior;
-              inv_post = (s2_obs * inv_prior + s2_prior * inv_obs) / (s2_obs + s2_prior);
-              const double dd = inv_prior - inv_obs;
-              s2_post = (nu_post + dd * dd / (s2_prior + s2_obs)) / (nu_post + 1) * (s2_prior * s2_obs) / (s2_prior + s2_obs);
+      const int c1 = min(col + R, p.W - 1);  // last column (inclusive)
+      const int r1 = min(row + R, p.H - 1);
+      for (int r = row - R; r <= r1; ++r) {
+        int idx = r * p.W + (col - R);        // linear index of the first tap of this row
+        const int last = r * p.W + c1;
+        while (idx <= last) {
+          const int word = idx >> 6, bit = idx & 63;
+          u64 m = bits[word] >> bit;
+          const int span = min(64 - bit, last - idx + 1);
+          if (span < 64) m &= ((1ull << span) - 1ull);
+          while (m) {
+            const int k = __builtin_ctzll(m);
+            m &= m - 1;
+            const int nc = idx + k;
+            const double2 q = ab[nc];
+            n_nb++;
+            const double diff = fabs(c.inv_depth - q.x);
+            if (diff < sd_self2 || diff < q.y) {
+              const double2 t = cd[nc];
+              if (n_close == 0) {
+                nu_post = t.x; inv_post = q.x; s2_post = t.y;
+              } else {  // DepthRegularization.cpp:72-86
+                const double nu_prior = nu_post, inv_prior = inv_post, s2_prior = s2_post;
+                const double nu_obs = t.x, inv_obs = q.x, s2_obs = t.y;
+                nu_post = (nu_obs < nu_prior) ? nu_obs : nu_prior;
+                inv_post = (s2_obs * inv_prior + s2_prior * inv_obs) / (s2_obs + s2_prior);
+                const double dd = inv_prior - inv_obs;
+                s2_post = (nu_post + dd * dd / (s2_prior + s2_obs)) / (nu_post + 1) * (s2_prior * s2_obs) / (s2_prior + s2_obs);
+              }
+              n_close++;
             }
-            n_close++;
           }
+          idx += span;
         }
       }
     }
@@ -287,13 +334,15 @@ __global__ void __launch_bounds__(256) reg_apply_kernel(const MapCell* __restric
   out[cell] = c;
 }
 
-void launch_regularize(const MapCell* map_in, MapCell* map_out, u32* owner_max, u32* owner_min, const DevParams& p,
-                       hipStream_t s) {
+void launch_regularize(const MapCell* map_in, MapCell* map_out, u32* owner_max, u32* owner_min, u64* bits, double2* ab,
+                       double2* cd, const DevParams& p, hipStream_t s) {
   const int ncell = p.W * p.H;
   hipMemsetAsync(owner_max, 0, sizeof(u32) * ncell, s);
   hipMemsetAsync(owner_min, 0xff, sizeof(u32) * ncell, s);
-  hipLaunchKernelGGL(reg_owner_kernel, dim3((ncell + 255) / 256), dim3(256), 0, s, map_in, owner_max, owner_min, p);
-  hipLaunchKernelGGL(reg_apply_kernel, dim3((ncell + 255) / 256), dim3(256), 0, s, map_in, map_out, owner_max, owner_min, p);
+  const int nb = (ncell + 255) / 256;
+  hipLaunchKernelGGL(reg_owner_kernel, dim3(nb), dim3(256), 0, s, map_in, owner_max, owner_min, p);
+  hipLaunchKernelGGL(reg_view_kernel, dim3(nb), dim3(256), 0, s, map_in, bits, ab, cd, ncell);
+  hipLaunchKernelGGL(reg_apply_kernel, dim3(nb), dim3(256), 0, s, map_in, map_out, owner_max, owner_min, bits, ab, cd, p);
 }
 
 // ---- export: alive cells -> esvo_depth_point_t list (cell order; host orders by seq) --------------

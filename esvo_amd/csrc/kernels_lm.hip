@@ -252,14 +252,15 @@ __global__ void __launch_bounds__(256) lm_refine_kernel(LmArgs a, DevParams p, u
     // ---- minimizeOneStep ----
     int status = -1;
     {
-      // NumericalDiff<Forward>::df (2 evaluations)
-      lm_eval(p, pr, x, wa4);
+      // NumericalDiff<Forward>::df: the reference evaluates F(x) again (val1) and F(x + h); F is a
+      // pure function and fvec already holds F(x) at the current x, so val1 == fvec bit for bit and
+      // only F(x + h) is computed.  nfev still advances by 2 (it drives the maxfev test).
       double h = sqrt_eps * fabs(x);
       if (h == 0.) h = sqrt_eps;
       double val2[LM_ROWS];
       lm_eval(p, pr, x + h, val2);
 #pragma unroll
-      for (int y = 0; y < LM_ROWS; ++y) fjac[y] = (val2[y] - wa4[y]) / h;
+      for (int y = 0; y < LM_ROWS; ++y) fjac[y] = (val2[y] - fvec[y]) / h;
       nfev += 2;
     }
     const double wa2n = sqrt(patch_dot(fjac, fjac));
