@@ -107,6 +107,8 @@ struct esvo_context {
   MapCell* d_map_cur = nullptr;
   u32* d_owner_max = nullptr;
   u32* d_owner_min = nullptr;
+  u32* d_bucket = nullptr;
+  u32* d_cell_list = nullptr;
   u64* d_reg_bits = nullptr;
   double2* d_reg_ab = nullptr;
   double2* d_reg_cd = nullptr;
@@ -357,6 +359,7 @@ int run_fuse(esvo_context* h) {
   a.cell_count = h->d_cell_count; a.cell_offset = h->d_cell_offset; a.cell_fill = h->d_cell_fill;
   a.rec_ids = h->d_rec_ids; a.scan_tmp = h->d_scan_tmp; a.d_total = h->d_counters + 4;
   a.map = h->d_map; a.d_num_fusion = h->d_counters + 3;
+  a.bucket = h->d_bucket; a.cell_list = h->d_cell_list; a.n_touched = h->d_counters + 6;
   if (total > h->win_cap) FAIL(ESVO_ERR_CAPACITY, "window points exceed capacity");
   hipEventRecord(h->evt[EV_FU0], h->stream);
   launch_fuse(a, h->dp, h->stream);
@@ -531,6 +534,8 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
   h->d_map_cur = h->d_map;
   CK(dalloc(&h->d_owner_max, npx));
   CK(dalloc(&h->d_owner_min, npx));
+  CK(dalloc(&h->d_bucket, 3 * 128));
+  CK(dalloc(&h->d_cell_list, npx));
   CK(dalloc(&h->d_reg_bits, npx / 64 + 2));
   CK(dalloc(&h->d_reg_ab, npx));
   CK(dalloc(&h->d_reg_cd, npx));
@@ -557,7 +562,7 @@ int esvo_destroy(esvo_handle h) {
                   h->d_matches, h->d_pt_slots, h->d_pt_flags, h->d_pt_prefix, h->d_pts_tmp, h->d_counters, h->d_scan_tmp,
                   h->d_win, h->d_frame_pose_T, h->d_fr_table, h->d_prop, h->d_cell_count, h->d_cell_offset,
                   h->d_cell_fill, h->d_rec_ids, h->d_map, h->d_map2, h->d_owner_max, h->d_owner_min, h->d_exp_flags,
-                  h->d_exp_prefix, h->d_export, h->d_export_cell, h->d_reg_bits, h->d_reg_ab, h->d_reg_cd};
+                  h->d_exp_prefix, h->d_export, h->d_export_cell, h->d_reg_bits, h->d_reg_ab, h->d_reg_cd, h->d_bucket, h->d_cell_list};
   for (void* p : ptrs) if (p) hipFree(p);
   if (h->h_counters) hipHostFree(h->h_counters);
   if (h->h_fr_table) hipHostFree(h->h_fr_table);

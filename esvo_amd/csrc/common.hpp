@@ -201,6 +201,9 @@ struct FuseArgs {
   u32* d_total;                 // total records
   MapCell* map;                 // [W*H]
   u32* d_num_fusion;            // fusion counter
+  u32* bucket;                  // [3*128] load-balancing buckets: count | offset | fill
+  u32* cell_list;               // [W*H] touched cells, longest record lists first
+  u32* n_touched;               // number of touched cells
 };
 void launch_fuse(const FuseArgs& a, const DevParams& p, hipStream_t s);
 void launch_clean(MapCell* map, const DevParams& p, hipStream_t s);

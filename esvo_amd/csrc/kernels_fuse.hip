@@ -129,44 +129,139 @@ __device__ inline void update_studentT(MapCell& c, double invD, double s2, doubl
   }
 }
 
-// One thread per cell: sort the cell's record ids, then walk them (DepthFusion::fusion).
-__global__ void __launch_bounds__(256) fuse_cells_kernel(FuseArgs a, DevParams p, int K) {
+// ---- load balancing: touched cells ordered by record count (longest lists first) ----------------
+// The per-cell walk is sequential, so a wave lasts as long as its longest list.  Bucketing the
+// touched cells by min(n, NB-1) (block-local LDS histogram -> one global reservation per bucket
+// and block -> LDS-ranked scatter) gives waves of near-uniform length; cells are independent, so
+// their processing order is free.
+#define FUSE_NB 16
+// bucket = ceil(log2(n)): lists in a wave differ by at most 2x while cells stay in (block-)spatial
+// order inside a bucket, which keeps the propagated points they share in L1/L2.
+__device__ inline u32 fuse_bucket(u32 n) {  // n >= 1: 1->0, 2->1, 3..4->2, 5..8->3, ...
+  const u32 b = (n <= 1u) ? 0u : 32u - (u32)__builtin_clz(n - 1u);
+  return b < FUSE_NB - 1u ? b : FUSE_NB - 1u;
+}
+__global__ void __launch_bounds__(256) bucket_count_kernel(const u32* __restrict__ cell_count, u32* __restrict__ bucket_cnt,
+                                                           MapCell* __restrict__ map, int ncell, int band0, int band1, int W) {
+  __shared__ u32 h[FUSE_NB];
+  if (threadIdx.x < FUSE_NB) h[threadIdx.x] = 0;
+  __syncthreads();
   const int cell = blockIdx.x * blockDim.x + threadIdx.x;
-  if (cell >= p.W * p.H) return;
-  const int crow = cell / p.W, ccol = cell - crow * p.W;
-  if (crow < p.band_y0 || crow >= p.band_y1) return;
-  const u32 n = a.cell_count[cell];
-  if (n == 0) { a.map[cell].flags = 0; return; }
-  u32* ids = a.rec_ids + a.cell_offset[cell];
-  // Records must be applied in increasing id order.  Short lists (the common case) are walked by
-  // repeated minimum selection straight from the (cached) id list; long ones are insertion-sorted
-  // in place first.
-  const bool presorted = n > 12;
-  if (presorted) {
-    for (u32 i = 1; i < n; ++i) {
-      const u32 key = ids[i];
-      int j = (int)i - 1;
-      while (j >= 0 && ids[j] > key) { ids[j + 1] = ids[j]; --j; }
-      ids[j + 1] = key;
+  if (cell < ncell) {
+    const int row = cell / W;
+    if (row >= band0 && row < band1) {
+      const u32 n = cell_count[cell];
+      if (n == 0) map[cell].flags = 0;
+      else atomicAdd(&h[fuse_bucket(n)], 1u);
     }
   }
+  __syncthreads();
+  if (threadIdx.x < FUSE_NB && h[threadIdx.x]) atomicAdd(&bucket_cnt[threadIdx.x], h[threadIdx.x]);
+}
+// bucket_off[b] = number of cells in buckets > b (descending order); single block
+__global__ void __launch_bounds__(FUSE_NB) bucket_offsets_kernel(const u32* __restrict__ bucket_cnt, u32* __restrict__ bucket_off,
+                                                                 u32* __restrict__ n_touched) {
+  __shared__ u32 c[FUSE_NB];
+  c[threadIdx.x] = bucket_cnt[threadIdx.x];
+  __syncthreads();
+  u32 off = 0;
+  for (int b = FUSE_NB - 1; b > (int)threadIdx.x; --b) off += c[b];
+  bucket_off[threadIdx.x] = off;
+  if (threadIdx.x == 0) *n_touched = off + c[0];
+}
+__global__ void __launch_bounds__(256) bucket_scatter_kernel(const u32* __restrict__ cell_count, const u32* __restrict__ bucket_off,
+                                                             u32* __restrict__ bucket_fill, u32* __restrict__ cell_list, int ncell,
+                                                             int band0, int band1, int W) {
+  __shared__ u32 h[FUSE_NB];
+  __shared__ u32 base[FUSE_NB];
+  if (threadIdx.x < FUSE_NB) h[threadIdx.x] = 0;
+  __syncthreads();
+  const int cell = blockIdx.x * blockDim.x + threadIdx.x;
+  u32 b = 0, rank = 0;
+  bool on = false;
+  if (cell < ncell) {
+    const int row = cell / W;
+    if (row >= band0 && row < band1) {
+      const u32 n = cell_count[cell];
+      if (n) { on = true; b = fuse_bucket(n); rank = atomicAdd(&h[b], 1u); }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < FUSE_NB && h[threadIdx.x]) base[threadIdx.x] = bucket_off[threadIdx.x] + atomicAdd(&bucket_fill[threadIdx.x], h[threadIdx.x]);
+  __syncthreads();
+  if (on) cell_list[base[b] + rank] = (u32)cell;
+}
+
+// Long record lists (n > 8: every bucket >= 4, i.e. the first bucket_off[3] entries of the cell
+// list) are ordered by a wave-cooperative rank sort: the wave copies the ids to LDS, lane j counts
+// how many ids are smaller than its own (ids are unique) and writes it to that slot.  The atomic
+// scatter leaves the lists in essentially random order, and an in-place insertion sort by a single
+// thread (O(n^2) dependent global round trips) was the tail of the whole tick.
+#define SORT_CAP 2048
+__global__ void __launch_bounds__(64) sort_long_lists_kernel(const u32* __restrict__ cell_list, const u32* __restrict__ n_long_ptr,
+                                                             const u32* __restrict__ cell_count, const u32* __restrict__ cell_offset,
+                                                             u32* __restrict__ rec_ids) {
+  __shared__ u32 l[SORT_CAP];
+  const u32 n_long = *n_long_ptr;
+  for (u32 w = blockIdx.x; w < n_long; w += gridDim.x) {
+    const u32 cell = cell_list[w];
+    const u32 n = cell_count[cell];
+    u32* ids = rec_ids + cell_offset[cell];
+    if (n > SORT_CAP) {  // absurdly long list: serial fallback
+      if (threadIdx.x == 0)
+        for (u32 i = 1; i < n; ++i) {
+          const u32 key = ids[i];
+          int j = (int)i - 1;
+          while (j >= 0 && ids[j] > key) { ids[j + 1] = ids[j]; --j; }
+          ids[j + 1] = key;
+        }
+      continue;
+    }
+    __syncthreads();  // previous iteration's readers are done
+    for (u32 i = threadIdx.x; i < n; i += 64) l[i] = ids[i];
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < n; i += 64) {
+      const u32 v = l[i];
+      u32 rank = 0;
+      for (u32 j = 0; j < n; ++j) rank += (l[j] < v);
+      ids[rank] = v;
+    }
+  }
+}
+
+// One thread per touched cell: order the cell's record ids, then walk them (DepthFusion::fusion).
+__global__ void __launch_bounds__(256) fuse_cells_kernel(FuseArgs a, DevParams p, int K) {
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= *a.n_touched) return;
+  const int cell = (int)a.cell_list[t];
+  const int crow = cell / p.W, ccol = cell - crow * p.W;
+  const u32 n = a.cell_count[cell];
+  u32* ids = a.rec_ids + a.cell_offset[cell];
+  // Records must be applied in increasing id order.  Short lists (the common case) are walked by
+  // repeated minimum selection straight from the (cached) id list; long ones were ordered by
+  // sort_long_lists_kernel.
+  const bool presorted = n > 8;  // ordered by sort_long_lists_kernel
   MapCell c;
   bool exists = false;
   u32 numFusion = 0;
-  u32 last = 0;
-  for (u32 i = 0; i < n; ++i) {
-    u32 id;
-    if (presorted) {
-      id = ids[i];
-    } else {
-      id = 0xffffffffu;
-      for (u32 j = 0; j < n; ++j) {
-        const u32 v = ids[j];
-        if ((i == 0 || v > last) && v < id) id = v;
-      }
-      last = id;
+  auto next_id = [&](u32 i, u32 last) -> u32 {
+    if (presorted) return ids[i];
+    u32 id = 0xffffffffu;
+    for (u32 j = 0; j < n; ++j) {
+      const u32 v = ids[j];
+      if ((i == 0 || v > last) && v < id) id = v;
     }
-    const DevPoint& prop = a.prop[id / (u32)K];
+    return id;
+  };
+  u32 id_nxt = next_id(0, 0);
+  DevPoint nxt = a.prop[id_nxt / (u32)K];
+  for (u32 i = 0; i < n; ++i) {
+    const u32 id = id_nxt;
+    const DevPoint prop = nxt;
+    if (i + 1 < n) {  // software prefetch: the next record does not depend on the cell state
+      id_nxt = next_id(i + 1, id);
+      nxt = a.prop[id_nxt / (u32)K];
+    }
     if (!exists) {  // case 1: DepthFusion.cpp:127-146
       c.row = (u32)crow; c.col = (u32)ccol;
       c.x[0] = (double)ccol + 0.5; c.x[1] = (double)crow + 0.5;
@@ -205,13 +300,21 @@ __global__ void __launch_bounds__(256) fuse_cells_kernel(FuseArgs a, DevParams p
 void launch_fuse(const FuseArgs& a, const DevParams& p, hipStream_t s) {
   const int ncell = p.W * p.H;
   const int K = (p.fusion_radius == 0) ? 4 : 9;
+  const int nb = (ncell + 255) / 256;
   hipMemsetAsync(a.cell_count, 0, sizeof(u32) * ncell, s);
   hipMemsetAsync(a.cell_fill, 0, sizeof(u32) * ncell, s);
+  hipMemsetAsync(a.bucket, 0, sizeof(u32) * 3 * 128, s);  // cnt | off | fill
   hipMemsetAsync(a.d_num_fusion, 0, sizeof(u32), s);
   if (a.n_pts) hipLaunchKernelGGL(propagate_kernel, dim3((a.n_pts + 255) / 256), dim3(256), 0, s, a, p, K);
   launch_exclusive_scan_u32(a.cell_count, a.cell_offset, a.d_total, a.scan_tmp, (size_t)ncell, s);
   if (a.n_pts) hipLaunchKernelGGL(scatter_records_kernel, dim3((a.n_pts + 255) / 256), dim3(256), 0, s, a, p, K);
-  hipLaunchKernelGGL(fuse_cells_kernel, dim3((ncell + 255) / 256), dim3(256), 0, s, a, p, K);
+  hipLaunchKernelGGL(bucket_count_kernel, dim3(nb), dim3(256), 0, s, a.cell_count, a.bucket, a.map, ncell, p.band_y0, p.band_y1, p.W);
+  hipLaunchKernelGGL(bucket_offsets_kernel, dim3(1), dim3(FUSE_NB), 0, s, a.bucket, a.bucket + FUSE_NB, a.n_touched);
+  hipLaunchKernelGGL(bucket_scatter_kernel, dim3(nb), dim3(256), 0, s, a.cell_count, a.bucket + FUSE_NB, a.bucket + 2 * FUSE_NB,
+                     a.cell_list, ncell, p.band_y0, p.band_y1, p.W);
+  hipLaunchKernelGGL(sort_long_lists_kernel, dim3(8192), dim3(64), 0, s, a.cell_list, a.bucket + FUSE_NB + 3, a.cell_count,
+                     a.cell_offset, a.rec_ids);
+  hipLaunchKernelGGL(fuse_cells_kernel, dim3(nb), dim3(256), 0, s, a, p, K);
 }
 
 // ---- SmartGrid::clean ---------------------------------------------------------------------------
@@ -301,25 +404,37 @@ __global__ void __launch_bounds__(256) reg_apply_kernel(const MapCell* __restric
           const int span = min(64 - bit, last - idx + 1);
           if (span < 64) m &= ((1ull << span) - 1ull);
           while (m) {
-            const int k = __builtin_ctzll(m);
-            m &= m - 1;
-            const int nc = idx + k;
-            const double2 q = ab[nc];
-            n_nb++;
-            const double diff = fabs(c.inv_depth - q.x);
-            if (diff < sd_self2 || diff < q.y) {
-              const double2 t = cd[nc];
-              if (n_close == 0) {
-                nu_post = t.x; inv_post = q.x; s2_post = t.y;
-              } else {  // DepthRegularization.cpp:72-86
-                const double nu_prior = nu_post, inv_prior = inv_post, s2_prior = s2_post;
-                const double nu_obs = t.x, inv_obs = q.x, s2_obs = t.y;
-                nu_post = (nu_obs < nu_prior) ? nu_obs : nu_prior;
-                inv_post = (s2_obs * inv_prior + s2_prior * inv_obs) / (s2_obs + s2_prior);
-                const double dd = inv_prior - inv_obs;
-                s2_post = (nu_post + dd * dd / (s2_prior + s2_obs)) / (nu_post + 1) * (s2_prior * s2_obs) / (s2_prior + s2_obs);
+            // up to 4 neighbours per batch: their loads are issued together instead of one
+            // dependent round trip per neighbour
+            int ks[4];
+            double2 qa[4], qc[4];
+            int cnt = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (m) { ks[j] = __builtin_ctzll(m); m &= m - 1; cnt = j + 1; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (j < cnt) { qa[j] = ab[idx + ks[j]]; qc[j] = cd[idx + ks[j]]; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              if (j >= cnt) break;
+              const double2 q = qa[j];
+              n_nb++;
+              const double diff = fabs(c.inv_depth - q.x);
+              if (diff < sd_self2 || diff < q.y) {
+                const double2 t = qc[j];
+                if (n_close == 0) {
+                  nu_post = t.x; inv_post = q.x; s2_post = t.y;
+                } else {  // DepthRegularization.cpp:72-86
+                  const double nu_prior = nu_post, inv_prior = inv_post, s2_prior = s2_post;
+                  const double nu_obs = t.x, inv_obs = q.x, s2_obs = t.y;
+                  nu_post = (nu_obs < nu_prior) ? nu_obs : nu_prior;
+                  inv_post = (s2_obs * inv_prior + s2_prior * inv_obs) / (s2_obs + s2_prior);
+                  const double dd = inv_prior - inv_obs;
+                  s2_post = (nu_post + dd * dd / (s2_prior + s2_obs)) / (nu_post + 1) * (s2_prior * s2_obs) / (s2_prior + s2_obs);
+                }
+                n_close++;
               }
-              n_close++;
             }
           }
           idx += span;

@@ -205,7 +205,7 @@ __device__ inline double lm_lmpar2(double r, double diag, double qtf, double del
   return x;
 }
 
-__global__ void __launch_bounds__(256) lm_refine_kernel(LmArgs a, DevParams p, u32* n_solved) {
+__global__ void __launch_bounds__(256, 3) lm_refine_kernel(LmArgs a, DevParams p, u32* n_solved) {
   const u32 s = (blockIdx.x * 256 + threadIdx.x) >> 4;  // solver slot (thread-stride order)
   const int c = threadIdx.x & 15;
   u32 M = *a.n_matches;
