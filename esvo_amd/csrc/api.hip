@@ -964,3 +964,52 @@ extern "C" void esvo_abi_sizes(size_t out[8]) {
   out[3] = sizeof(esvo_match_t); out[4] = sizeof(esvo_depth_point_t); out[5] = sizeof(esvo_stats_t);
   out[6] = sizeof(esvo_shard_buffers_t); out[7] = ESVO_HIP_ABI_VERSION;
 }
+
+// ---- device self-test: div_by(a, make_recip(b)) == a / b bit for bit ---------------------------------
+#include "fdiv.hpp"
+namespace {
+__device__ inline unsigned long long sm64(unsigned long long& s) {
+  unsigned long long z = (s += 0x9e3779b97f4a7c15ull);
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  return z ^ (z >> 31);
+}
+__global__ void selftest_div_kernel(unsigned long long n_per_thread, unsigned long long seed, unsigned long long* mismatches) {
+  unsigned long long s = seed + 0x1234567ull * (blockIdx.x * blockDim.x + threadIdx.x + 1);
+  unsigned long long bad = 0;
+  for (unsigned long long i = 0; i < n_per_thread; ++i) {
+    const unsigned long long ra = sm64(s), rb = sm64(s);
+    // mantissas random; exponents: mostly moderate, sometimes extreme / zero / denormal
+    const int mode = (int)(sm64(s) & 15);
+    int ea = (int)(ra % 600) - 300 + 1023, eb = (int)(rb % 600) - 300 + 1023;
+    if (mode == 0) ea = (int)(ra % 2046) + 1;
+    if (mode == 1) eb = (int)(rb % 2046) + 1;
+    if (mode == 2) ea = 0;
+    if (mode == 3) eb = 0;
+    unsigned long long ba = ((unsigned long long)ea << 52) | (ra >> 12);
+    unsigned long long bb = ((unsigned long long)eb << 52) | (rb >> 12);
+    if (mode == 4) ba = 0;  // a == 0
+    if (mode == 5) ba |= 1ull << 63;
+    if (mode == 6) bb |= 1ull << 63;
+    const double a = __longlong_as_double((long long)ba), b = __longlong_as_double((long long)bb);
+    const double q_ref = a / b;
+    const double q = esvo::div_by(a, esvo::make_recip(b));
+    const bool same = (__double_as_longlong(q) == __double_as_longlong(q_ref)) || (q != q && q_ref != q_ref);
+    bad += !same;
+  }
+  if (bad) atomicAdd(mismatches, bad);
+}
+}  // namespace
+extern "C" int esvo_selftest_division(unsigned long long n, unsigned long long seed, unsigned long long* mismatches) {
+  esvo_context* h = nullptr;
+  unsigned long long* d = nullptr;
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(&d), sizeof(unsigned long long)));
+  HIPCHK(hipMemset(d, 0, sizeof(unsigned long long)));
+  const unsigned threads = 256, blocks = 1024;
+  const unsigned long long per = (n + (unsigned long long)threads * blocks - 1) / ((unsigned long long)threads * blocks);
+  hipLaunchKernelGGL(selftest_div_kernel, dim3(blocks), dim3(threads), 0, 0, per, seed, d);
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(mismatches, d, sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  hipFree(d);
+  return ESVO_OK;
+}

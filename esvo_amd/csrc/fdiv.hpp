@@ -1,0 +1,55 @@
+// fdiv.hpp — IEEE-identical f64 division with a shared divisor.
+//
+// hipcc lowers a / b on gfx950 to
+//     bs = v_div_scale(b,b,a); as = v_div_scale(a,b,a); y = v_rcp(bs);
+//     y = fma(y, fma(-bs,y,1), y)  (twice);  q0 = as*y;  r = fma(-bs,q0,as);
+//     q = v_div_fmas(r,y,q0);  result = v_div_fixup(q,b,a)
+// (11 VALU instructions).  v_div_scale / v_div_fmas / v_div_fixup are the identity unless an
+// operand is 0/inf/nan/denormal or the exponents are extreme, so for moderate magnitudes
+// the quotient is  fma(fma(-b, a*y, a), y, a*y)  with y depending on b only.  When several
+// numbers are divided by the same b (the t-scale update divides 7 residuals per lane by s^2; the
+// Student-t fusion divides three terms by s1^2 + s2^2) the refined reciprocal is computed once
+// and each further quotient costs 3 instructions — bit for bit the compiler's result.
+// Outside the safe window the plain division is used.  esvo_selftest_division() checks the
+// equivalence on the device over random and edge-case operands.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace esvo {
+
+struct Recip {
+  double b;   // divisor
+  double y;   // refined reciprocal (valid iff fast)
+  bool fast;  // |b| in [1e-100, 1e100]
+};
+
+// v == 0, or |v| in [2^-332, 2^333) (about 1e-100 .. 1e100): decided on the exponent bits
+__device__ inline bool fdiv_ok(double v) {
+  const unsigned hi = (unsigned)__double2hiint(v) & 0x7fffffffu;
+  return ((hi >> 20) - 691u) <= 664u || (hi | (unsigned)__double2loint(v)) == 0u;
+}
+
+__device__ inline Recip make_recip(double b) {
+  Recip R;
+  R.b = b;
+  const unsigned hi = (unsigned)__double2hiint(b) & 0x7fffffffu;
+  R.fast = ((hi >> 20) - 691u) <= 664u;
+  double y = __builtin_amdgcn_rcp(b);
+  y = __builtin_fma(y, __builtin_fma(-b, y, 1.0), y);
+  y = __builtin_fma(y, __builtin_fma(-b, y, 1.0), y);
+  R.y = y;
+  return R;
+}
+
+// quotient for operands already known to be in the safe window (R.fast && fdiv_ok(a))
+__device__ inline double div_fast(double a, const Recip& R) {
+  const double q0 = a * R.y;
+  const double r = __builtin_fma(-R.b, q0, a);
+  return __builtin_fma(r, R.y, q0);
+}
+
+__device__ inline double div_by(double a, const Recip& R) {
+  return (R.fast && fdiv_ok(a)) ? div_fast(a, R) : a / R.b;
+}
+
+}  // namespace esvo

@@ -21,6 +21,7 @@
 // replace branch (DepthFusion.cpp:186), whose side effects on
 // clean/regularisation are reproduced through the ALIVE/GRID flag pair.
 #include "common.hpp"
+#include "fdiv.hpp"
 
 namespace esvo {
 
@@ -116,9 +117,12 @@ __global__ void __launch_bounds__(256) scatter_records_kernel(FuseArgs a, DevPar
 __device__ inline void update_studentT(MapCell& c, double invD, double s2, double var, double nu_in) {
   if (c.inv_depth > -1e-6) {
     const double nu_update = (c.nu < nu_in) ? c.nu : nu_in;  // std::min(nu, nu_)
-    const double invDepth_update = (s2 * c.inv_depth + c.scale2 * invD) / (c.scale2 + s2);
+    const Recip rsum = make_recip(c.scale2 + s2);  // three quotients share this divisor (fdiv.hpp)
+    const double n1 = s2 * c.inv_depth + c.scale2 * invD;
     const double dd = c.inv_depth - invD;
-    const double scale2_update = (nu_update + dd * dd / (c.scale2 + s2)) / (nu_update + 1) * (c.scale2 * s2) / (c.scale2 + s2);
+    const double n2 = dd * dd;
+    const double invDepth_update = div_by(n1, rsum);
+    const double scale2_update = div_by((nu_update + div_by(n2, rsum)) / (nu_update + 1) * (c.scale2 * s2), rsum);
     c.inv_depth = invDepth_update;
     c.scale2 = scale2_update;
     c.nu = nu_update + 1;
@@ -429,9 +433,10 @@ __global__ void __launch_bounds__(256) reg_apply_kernel(const MapCell* __restric
                   const double nu_prior = nu_post, inv_prior = inv_post, s2_prior = s2_post;
                   const double nu_obs = t.x, inv_obs = q.x, s2_obs = t.y;
                   nu_post = (nu_obs < nu_prior) ? nu_obs : nu_prior;
-                  inv_post = (s2_obs * inv_prior + s2_prior * inv_obs) / (s2_obs + s2_prior);
+                  const Recip rsum = make_recip(s2_obs + s2_prior);  // == s2_prior + s2_obs
+                  inv_post = div_by(s2_obs * inv_prior + s2_prior * inv_obs, rsum);
                   const double dd = inv_prior - inv_obs;
-                  s2_post = (nu_post + dd * dd / (s2_prior + s2_obs)) / (nu_post + 1) * (s2_prior * s2_obs) / (s2_prior + s2_obs);
+                  s2_post = div_by((nu_post + div_by(dd * dd, rsum)) / (nu_post + 1) * (s2_prior * s2_obs), rsum);
                 }
                 n_close++;
               }

@@ -22,17 +22,53 @@
 // after ~10^4 iterations; that provable outcome is taken directly.  Every
 // other case runs the literal loop.
 #include "common.hpp"
+#include "fdiv.hpp"
 
 namespace esvo {
 
 #define LM_ROWS 7
 #define LM_COLS 15
 
-__device__ inline double grp_sum(double v) {  // xor butterfly over the 16-lane group
-  v = v + __shfl_xor(v, 1, 16);
-  v = v + __shfl_xor(v, 2, 16);
-  v = v + __shfl_xor(v, 4, 16);
-  v = v + __shfl_xor(v, 8, 16);
+// ---- 16-lane (DPP row) cross-lane helpers ---------------------------------------------------------
+// A DPP row is 16 lanes = one match group, so group reductions need no LDS (ds_bpermute) round
+// trip.  The all-reduce adds partner values in four steps: lane^1 and lane^2 by quad_perm, then
+// the other quad of the 8-lane half (row_half_mirror) and the other half (row_mirror).  After each
+// step all lanes of the combined sub-group hold the same value, so the sums are exactly those of
+// the xor butterfly (lane^1, ^2, ^4, ^8) the oracle's canonical order prescribes.
+template <int CTRL>
+__device__ inline double dpp_f64(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+  const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi2, lo2);
+}
+template <int CTRL>
+__device__ inline int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+#define DPP_XOR1 0xB1         // quad_perm [1,0,3,2]
+#define DPP_XOR2 0x4E         // quad_perm [2,3,0,1]
+#define DPP_HALF_MIRROR 0x141 // lane i <-> 7-i inside each 8-lane half
+#define DPP_MIRROR 0x140      // lane i <-> 15-i inside the row
+#define DPP_SHL1 0x101        // lane i <- lane i+1 (lane 15 gets 0)
+
+__device__ inline double grp_sum(double v) {
+  v = v + dpp_f64<DPP_XOR1>(v);
+  v = v + dpp_f64<DPP_XOR2>(v);
+  v = v + dpp_f64<DPP_HALF_MIRROR>(v);
+  v = v + dpp_f64<DPP_MIRROR>(v);
+  return v;
+}
+__device__ inline int grp_sum_int(int v) {
+  v += dpp_i32<DPP_XOR1>(v);
+  v += dpp_i32<DPP_XOR2>(v);
+  v += dpp_i32<DPP_HALF_MIRROR>(v);
+  v += dpp_i32<DPP_MIRROR>(v);
+  return v;
+}
+__device__ inline double grp_min(double v) {
+  v = fmin(v, dpp_f64<DPP_XOR1>(v));
+  v = fmin(v, dpp_f64<DPP_XOR2>(v));
+  v = fmin(v, dpp_f64<DPP_HALF_MIRROR>(v));
+  v = fmin(v, dpp_f64<DPP_MIRROR>(v));
   return v;
 }
 __device__ inline double col_sum(const double t[LM_ROWS]) {
@@ -81,7 +117,7 @@ __device__ inline void interp_column(const uint8_t* __restrict__ img, int W, int
 #pragma unroll
   for (int y = 0; y <= LM_ROWS; ++y) {
     const int s0 = img[(uly + y) * W + ulx + c];
-    const int s1 = __shfl_down(s0, 1, 16);
+    const int s1 = dpp_i32<DPP_SHL1>(s0);  // column c+1 from the neighbour lane
     R[y] = q1 * (double)s0 + q2 * (double)s1;
   }
 #pragma unroll
@@ -123,17 +159,16 @@ __device__ void lm_eval(const DevParams& p, const LmProblem& pr, double x, doubl
   interp_column(pr.tsR, p.W, ulx2, uly2, pr.c, b1, b2, b3, b4, tau2);
   int knz = 0;
   double minabs = 1e300;
+  bool r2_ok = true;  // every r^2 is 0 or of moderate magnitude: shared-divisor quotients allowed
 #pragma unroll
   for (int y = 0; y < LM_ROWS; ++y) {
     r[y] = (pr.c < LM_COLS) ? (tau1[y] - tau2[y]) : 0.0;
     r2[y] = r[y] * r[y];
+    r2_ok = r2_ok && fdiv_ok(r2[y]);
     if (r[y] != 0) { knz++; minabs = fmin(minabs, fabs(r[y])); }
   }
-#pragma unroll
-  for (int d = 1; d < 16; d <<= 1) {
-    knz += __shfl_xor(knz, d, 16);
-    minabs = fmin(minabs, __shfl_xor(minabs, d, 16));
-  }
+  knz = grp_sum_int(knz);
+  minabs = grp_min(minabs);
   const double scale2_0 = p.td_scale2;
   double s2;
   const int N = LM_ROWS * LM_COLS;
@@ -146,17 +181,25 @@ __device__ void lm_eval(const DevParams& p, const LmProblem& pr, double x, doubl
     while (fabs(s2 - s1) / s1 > 0.05 || first) {  // DepthProblem.cpp:96
       if (!first) s1 = s2;
       double t[LM_ROWS];
+      const Recip rs1 = make_recip(s1);  // the 7 residuals of this lane share the divisor s1 (fdiv.hpp)
+      if (r2_ok && rs1.fast) {
 #pragma unroll
-      for (int y = 0; y < LM_ROWS; ++y) t[y] = (r[y] != 0) ? r2[y] * (nu + 1) / (nu + r2[y] / s1) : 0.0;
+        for (int y = 0; y < LM_ROWS; ++y) t[y] = (r[y] != 0) ? r2[y] * (nu + 1) / (nu + div_fast(r2[y], rs1)) : 0.0;
+      } else {
+#pragma unroll
+        for (int y = 0; y < LM_ROWS; ++y) t[y] = (r[y] != 0) ? r2[y] * (nu + 1) / (nu + r2[y] / s1) : 0.0;
+      }
       const double sum = grp_sum(col_sum(t));
       if (sum == 0) { s2 = scale2_0; break; }
       s2 = sum / (double)N;
       first = false;
     }
   }
+  const Recip rs2 = make_recip(s2);
+  const bool fast2 = r2_ok && rs2.fast;
 #pragma unroll
   for (int y = 0; y < LM_ROWS; ++y) {
-    const double weight = (nu + 1) / (nu + r2[y] / s2);
+    const double weight = (nu + 1) / (nu + (fast2 ? div_fast(r2[y], rs2) : r2[y] / s2));
     fv[y] = sqrt(weight) * r[y];
   }
 }
@@ -205,7 +248,7 @@ __device__ inline double lm_lmpar2(double r, double diag, double qtf, double del
   return x;
 }
 
-__global__ void __launch_bounds__(256, 3) lm_refine_kernel(LmArgs a, DevParams p, u32* n_solved) {
+__global__ void __launch_bounds__(256, 2) lm_refine_kernel(LmArgs a, DevParams p, u32* n_solved) {
   const u32 s = (blockIdx.x * 256 + threadIdx.x) >> 4;  // solver slot (thread-stride order)
   const int c = threadIdx.x & 15;
   u32 M = *a.n_matches;
@@ -239,105 +282,127 @@ __global__ void __launch_bounds__(256, 3) lm_refine_kernel(LmArgs a, DevParams p
   const double sqrt_eps = 1.4901161193847656e-08;  // sqrt(DBL_EPSILON), exact
   const int maxfev = p.lm_maxfev;
 
+  // The solver is written as a state machine around ONE call site of the residual evaluator
+  // (phase 0: F(x0) of minimizeInit; phase 1: F(x+h) of NumericalDiff; phase 2: F(x+p) of the
+  // trust-region trial).  Arithmetic and control flow are those of Eigen's
+  // minimizeInit/minimizeOneStep driven by the loop of DepthProblemSolver.cpp:161-188; a single
+  // inlined evaluator keeps the kernel ~3x smaller (I-cache, register pressure).
   double x = m.inv_depth;
-  double fvec[LM_ROWS], fjac[LM_ROWS], wa4[LM_ROWS];
-  // minimizeInit
-  int nfev = 1;
-  lm_eval(p, pr, x, fvec);
-  double fnorm = sqrt(patch_dot(fvec, fvec));
-  double par = 0., diag = 0., xnorm = 0., delta = 0., r = 0.;
-  int iter = 1;
-  int iteration = 0, optState = 0;
-  while (true) {  // DepthProblemSolver.cpp:161-188
-    // ---- minimizeOneStep ----
+  double fvec[LM_ROWS], out[LM_ROWS];
+  double fnorm = 0., par = 0., diag = 0., xnorm = 0., delta = 0., r = 0., qtf = 0., gnorm = 0.;
+  double h = 0., xnew = 0., wa1 = 0., pnorm = 0.;
+  int nfev = 1, iter = 1, iteration = 0, optState = 0;
+  int phase = 0;
+  bool need_step = false;
+  double xe = x;
+  while (true) {
+    if (need_step) {  // determine the LM parameter and the trial point (minimizeOneStep, inner loop head)
+      const double pstep = lm_lmpar2(r, diag, qtf, delta, par);
+      wa1 = -pstep;
+      xnew = x + wa1;
+      pnorm = fabs(diag * wa1);
+      if (iter == 1) delta = (pnorm < delta) ? pnorm : delta;
+      xe = xnew;
+      need_step = false;
+    }
+    lm_eval(p, pr, xe, out);
     int status = -1;
-    {
+    bool outer_tail = false;
+    if (phase == 0) {  // minimizeInit
+#pragma unroll
+      for (int y = 0; y < LM_ROWS; ++y) fvec[y] = out[y];
+      fnorm = sqrt(patch_dot(fvec, fvec));
+      par = 0.;
+      iter = 1;
+    } else if (phase == 1) {
       // NumericalDiff<Forward>::df: the reference evaluates F(x) again (val1) and F(x + h); F is a
       // pure function and fvec already holds F(x) at the current x, so val1 == fvec bit for bit and
       // only F(x + h) is computed.  nfev still advances by 2 (it drives the maxfev test).
-      double h = sqrt_eps * fabs(x);
-      if (h == 0.) h = sqrt_eps;
-      double val2[LM_ROWS];
-      lm_eval(p, pr, x + h, val2);
+      double fjac[LM_ROWS];
 #pragma unroll
-      for (int y = 0; y < LM_ROWS; ++y) fjac[y] = (val2[y] - fvec[y]) / h;
+      for (int y = 0; y < LM_ROWS; ++y) fjac[y] = (out[y] - fvec[y]) / h;
       nfev += 2;
-    }
-    const double wa2n = sqrt(patch_dot(fjac, fjac));
-    const double jtf = patch_dot(fjac, fvec);
-    r = wa2n;
-    const double fvec0 = __shfl(fvec[0], 0, 16);
-    const double qtf = (r != 0.) ? jtf / r : fvec0;
-    if (iter == 1) {
-      diag = (wa2n == 0.) ? 1. : wa2n;
-      xnorm = fabs(diag * x);
-      delta = factor * xnorm;
-      if (delta == 0.) delta = factor;
-    }
-    double gnorm = 0.;
-    if (fnorm != 0.)
-      if (wa2n != 0.) { const double g = fabs(r * (qtf / fnorm) / wa2n); gnorm = (gnorm < g) ? g : gnorm; }
-    if (gnorm <= gtol) {
-      status = 4;
-    } else {
-      diag = (diag < wa2n) ? wa2n : diag;
-      double ratio;
-      do {
-        const double pstep = lm_lmpar2(r, diag, qtf, delta, par);
-        const double wa1 = -pstep;
-        const double xnew = x + wa1;
-        const double pnorm = fabs(diag * wa1);
-        if (iter == 1) delta = (pnorm < delta) ? pnorm : delta;
-        lm_eval(p, pr, xnew, wa4);
-        ++nfev;
-        const double fnorm1 = sqrt(patch_dot(wa4, wa4));
-        double actred = -1.;
-        if (0.1 * fnorm1 < fnorm) actred = 1. - (fnorm1 / fnorm) * (fnorm1 / fnorm);
-        const double wa3 = r * wa1;
-        const double t1 = fabs(wa3) / fnorm, temp1 = t1 * t1;
-        const double t2 = sqrt(par) * pnorm / fnorm, temp2 = t2 * t2;
-        const double prered = temp1 + temp2 / 0.5;
-        const double dirder = -(temp1 + temp2);
-        ratio = 0.;
-        if (prered != 0.) ratio = actred / prered;
-        if (ratio <= 0.25) {
-          double temp = 0.5;
-          if (actred >= 0.) temp = 0.5;
-          if (actred < 0.) temp = 0.5 * dirder / (dirder + 0.5 * actred);
-          if (0.1 * fnorm1 >= fnorm || temp < 0.1) temp = 0.1;
-          const double pn = pnorm / 0.1;
-          delta = temp * ((pn < delta) ? pn : delta);
-          par /= temp;
-        } else if (!(par != 0. && ratio < 0.75)) {
-          delta = pnorm / 0.5;
-          par = 0.5 * par;
-        }
-        if (ratio >= 1e-4) {
-          x = xnew;
+      const double wa2n = sqrt(patch_dot(fjac, fjac));
+      const double jtf = patch_dot(fjac, fvec);
+      r = wa2n;
+      const double fvec0 = __shfl(fvec[0], 0, 16);
+      qtf = (r != 0.) ? jtf / r : fvec0;
+      if (iter == 1) {
+        diag = (wa2n == 0.) ? 1. : wa2n;
+        xnorm = fabs(diag * x);
+        delta = factor * xnorm;
+        if (delta == 0.) delta = factor;
+      }
+      gnorm = 0.;
+      if (fnorm != 0.)
+        if (wa2n != 0.) { const double g = fabs(r * (qtf / fnorm) / wa2n); gnorm = (gnorm < g) ? g : gnorm; }
+      if (gnorm <= gtol) {
+        status = 4;
+        outer_tail = true;
+      } else {
+        diag = (diag < wa2n) ? wa2n : diag;
+        need_step = true;
+        phase = 2;
+      }
+    } else {  // phase 2: trust-region trial at xnew
+      ++nfev;
+      const double fnorm1 = sqrt(patch_dot(out, out));
+      double actred = -1.;
+      if (0.1 * fnorm1 < fnorm) actred = 1. - (fnorm1 / fnorm) * (fnorm1 / fnorm);
+      const double wa3 = r * wa1;
+      const double t1 = fabs(wa3) / fnorm, temp1 = t1 * t1;
+      const double t2 = sqrt(par) * pnorm / fnorm, temp2 = t2 * t2;
+      const double prered = temp1 + temp2 / 0.5;
+      const double dirder = -(temp1 + temp2);
+      double ratio = 0.;
+      if (prered != 0.) ratio = actred / prered;
+      if (ratio <= 0.25) {
+        double temp = 0.5;
+        if (actred >= 0.) temp = 0.5;
+        if (actred < 0.) temp = 0.5 * dirder / (dirder + 0.5 * actred);
+        if (0.1 * fnorm1 >= fnorm || temp < 0.1) temp = 0.1;
+        const double pn = pnorm / 0.1;
+        delta = temp * ((pn < delta) ? pn : delta);
+        par /= temp;
+      } else if (!(par != 0. && ratio < 0.75)) {
+        delta = pnorm / 0.5;
+        par = 0.5 * par;
+      }
+      if (ratio >= 1e-4) {
+        x = xnew;
 #pragma unroll
-          for (int y = 0; y < LM_ROWS; ++y) fvec[y] = wa4[y];
-          xnorm = fabs(diag * x);
-          fnorm = fnorm1;
-          ++iter;
-        }
-        if (fabs(actred) <= ftol && prered <= ftol && 0.5 * ratio <= 1. && delta <= xtol * xnorm) { status = 3; break; }
-        if (fabs(actred) <= ftol && prered <= ftol && 0.5 * ratio <= 1.) { status = 1; break; }
-        if (delta <= xtol * xnorm) { status = 2; break; }
-        if (nfev >= maxfev) { status = 5; break; }
-        if (fabs(actred) <= eps && prered <= eps && 0.5 * ratio <= 1.) { status = 6; break; }
-        if (delta <= eps * xnorm) { status = 7; break; }
-        if (gnorm <= eps) { status = 8; break; }
-      } while (ratio < 1e-4);
+        for (int y = 0; y < LM_ROWS; ++y) fvec[y] = out[y];
+        xnorm = fabs(diag * x);
+        fnorm = fnorm1;
+        ++iter;
+      }
+      if (fabs(actred) <= ftol && prered <= ftol && 0.5 * ratio <= 1. && delta <= xtol * xnorm) status = 3;
+      else if (fabs(actred) <= ftol && prered <= ftol && 0.5 * ratio <= 1.) status = 1;
+      else if (delta <= xtol * xnorm) status = 2;
+      else if (nfev >= maxfev) status = 5;
+      else if (fabs(actred) <= eps && prered <= eps && 0.5 * ratio <= 1.) status = 6;
+      else if (delta <= eps * xnorm) status = 7;
+      else if (gnorm <= eps) status = 8;
+      if (status >= 0 || !(ratio < 1e-4)) outer_tail = true;  // minimizeOneStep returns (status or Running)
+      else need_step = true;                                   // do { ... } while (ratio < 1e-4)
     }
-    // ---- the reference's outer loop ----
-    iteration++;
-    if (iteration >= p.lm_max_iter) break;
-    bool terminate = false;
-    if (status == 2 || status == 3) {
-      if (optState == 0) optState++;
-      else terminate = true;
+    if (phase == 0) {
+      phase = 1;
+    } else if (outer_tail) {
+      // ---- the reference's outer loop, DepthProblemSolver.cpp:161-188 ----
+      iteration++;
+      if (iteration >= p.lm_max_iter) break;
+      if (status == 2 || status == 3) {
+        if (optState == 0) optState++;
+        else break;
+      }
+      phase = 1;
     }
-    if (terminate) break;
+    if (phase == 1) {  // next evaluation: F(x + h) for the forward difference
+      h = sqrt_eps * fabs(x);
+      if (h == 0.) h = sqrt_eps;
+      xe = x + h;
+    }
   }
 
   if (!active || c != 0) return;

@@ -94,6 +94,19 @@ def load():
     return lib
 
 
+def selftest_division(n=1 << 28, seed=1):
+    """device self-test of fdiv.hpp: returns the number of (a, b) pairs where the shared-divisor
+    quotient differs from a / b (must be 0)"""
+    lib = load()
+    bad = C.c_ulonglong(0)
+    lib.esvo_selftest_division.argtypes = [C.c_ulonglong, C.c_ulonglong, C.POINTER(C.c_ulonglong)]
+    lib.esvo_selftest_division.restype = C.c_int
+    rc = lib.esvo_selftest_division(int(n), int(seed), C.byref(bad))
+    if rc != 0:
+        raise EsvoError(f"selftest failed ({rc}): {lib.esvo_last_error(None).decode()}")
+    return bad.value
+
+
 def abi_sizes():
     out = (C.c_size_t * 8)()
     load().esvo_abi_sizes(out)

@@ -343,3 +343,9 @@ def test_end_to_end_tick(request, preset, rig_fix, stream_fix, n_ev):
         assert iou > 0.99 and rmse < 1e-4, (iou, rmse)
     pc_g, pc_o = dev.get_pointcloud(), m.get_pointcloud()
     assert pc_g.shape == pc_o.shape and np.array_equal(pc_g, pc_o)
+
+
+def test_shared_divisor_division_is_ieee_identical():
+    """fdiv.hpp: div_by(a, make_recip(b)) must equal a / b bit for bit (2^28 random + edge-case pairs)."""
+    from esvo_amd import lib
+    assert lib.selftest_division(1 << 28, seed=7) == 0
