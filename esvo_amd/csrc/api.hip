@@ -369,8 +369,8 @@ int run_fuse(esvo_context* h) {
   if (do_clean) launch_clean(h->d_map, h->dp, h->stream);
   hipEventRecord(h->evt[EV_CL1], h->stream);
   if (h->prm.regularization) {
-    launch_regularize(h->d_map, h->d_map2, h->d_owner_max, h->d_owner_min, h->d_reg_bits, h->d_reg_ab, h->d_reg_cd, h->dp,
-                      h->stream);
+    launch_regularize(h->d_map, h->d_map2, h->d_owner_max, h->d_owner_min, h->d_reg_bits, h->d_reg_ab, h->d_reg_cd,
+                      h->d_cell_list, h->d_counters + 7, h->dp, h->stream);
     h->d_map_cur = h->d_map2;
   }
   hipEventRecord(h->evt[EV_RG1], h->stream);

@@ -208,7 +208,7 @@ struct FuseArgs {
 void launch_fuse(const FuseArgs& a, const DevParams& p, hipStream_t s);
 void launch_clean(MapCell* map, const DevParams& p, hipStream_t s);
 void launch_regularize(const MapCell* map_in, MapCell* map_out, u32* owner_max, u32* owner_min, u64* bits,
-                       double2* ab, double2* cd, const DevParams& p, hipStream_t s);
+                       double2* ab, double2* cd, u32* elem_list, u32* n_elems, const DevParams& p, hipStream_t s);
 void launch_map_compact(const MapCell* map, u32* flags, u32* prefix, u32* d_total, u32* scan_tmp,
                         esvo_depth_point_t* out, u32* out_cell, const DevParams& p, hipStream_t s);
 

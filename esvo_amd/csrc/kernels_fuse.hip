@@ -360,32 +360,44 @@ __global__ void __launch_bounds__(256) reg_owner_kernel(const MapCell* __restric
 //   cd[c] : (nu, scale2)                      -- read only for close neighbours
 // 16 B per tap instead of a 104 B MapCell, empty cells are skipped 64 at a time, and the
 // neighbour's sqrt is computed once per cell instead of once per tap.
-__global__ void __launch_bounds__(256) reg_view_kernel(const MapCell* __restrict__ map, u64* __restrict__ bits,
-                                                       double2* __restrict__ ab, double2* __restrict__ cd, int ncell) {
+__global__ void __launch_bounds__(256) reg_view_kernel(const MapCell* __restrict__ map, MapCell* __restrict__ out,
+                                                       u64* __restrict__ bits, double2* __restrict__ ab, double2* __restrict__ cd,
+                                                       u32* __restrict__ elem_list, u32* __restrict__ n_elems, int ncell, int W,
+                                                       int band0, int band1) {
   const int cell = blockIdx.x * blockDim.x + threadIdx.x;
-  bool v = false;
+  bool v = false, alive = false;
   if (cell < ncell) {
     const MapCell& n = map[cell];
-    v = (n.flags & CELL_ALIVE) && (n.flags & CELL_GRID) && n.inv_depth > -1e-6;
+    alive = (n.flags & CELL_ALIVE) != 0;
+    v = alive && (n.flags & CELL_GRID) && n.inv_depth > -1e-6;
     if (v) {
       ab[cell] = make_double2(n.inv_depth, 2.0 * sqrt(n.variance));
       cd[cell] = make_double2(n.nu, n.scale2);
     }
+    const int row = cell / W;
+    if (row < band0 || row >= band1) alive = false;
+    else if (!alive) out[cell].flags = 0;
   }
   const u64 m = __ballot(v);
   if ((threadIdx.x & 63) == 0 && cell < ncell) bits[cell >> 6] = m;
+  // compact the alive elements (apply kernel: one thread per element, full waves); order is free
+  const u64 am = __ballot(alive);
+  const int lane = threadIdx.x & 63;
+  u32 base = 0;
+  if (lane == 0 && am) base = atomicAdd(n_elems, (u32)__popcll(am));
+  base = __shfl(base, 0, 64);
+  if (alive) elem_list[base + (u32)__popcll(am & ((1ull << lane) - 1ull))] = (u32)cell;
 }
 
 __global__ void __launch_bounds__(256) reg_apply_kernel(const MapCell* __restrict__ map, MapCell* __restrict__ out,
                                                         const u32* __restrict__ owner_max, const u32* __restrict__ owner_min,
                                                         const u64* __restrict__ bits, const double2* __restrict__ ab,
-                                                        const double2* __restrict__ cd, DevParams p) {
-  const int cell = blockIdx.x * blockDim.x + threadIdx.x;
-  if (cell >= p.W * p.H) return;
-  const int crow = cell / p.W;
-  if (crow < p.band_y0 || crow >= p.band_y1) return;
+                                                        const double2* __restrict__ cd, const u32* __restrict__ elem_list,
+                                                        const u32* __restrict__ n_elems, DevParams p) {
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= *n_elems) return;
+  const int cell = (int)elem_list[t];
   MapCell c = map[cell];
-  if (!(c.flags & CELL_ALIVE)) { out[cell].flags = 0; return; }
   const u32 b = c.row * (u32)p.W + c.col;
   if (owner_max[b] != c.seq + 1u) { out[cell].flags = 0; return; }  // overwritten by a later element
   if (c.inv_depth > -1e-6) {  // it->valid()
@@ -455,14 +467,17 @@ __global__ void __launch_bounds__(256) reg_apply_kernel(const MapCell* __restric
 }
 
 void launch_regularize(const MapCell* map_in, MapCell* map_out, u32* owner_max, u32* owner_min, u64* bits, double2* ab,
-                       double2* cd, const DevParams& p, hipStream_t s) {
+                       double2* cd, u32* elem_list, u32* n_elems, const DevParams& p, hipStream_t s) {
   const int ncell = p.W * p.H;
   hipMemsetAsync(owner_max, 0, sizeof(u32) * ncell, s);
   hipMemsetAsync(owner_min, 0xff, sizeof(u32) * ncell, s);
   const int nb = (ncell + 255) / 256;
   hipLaunchKernelGGL(reg_owner_kernel, dim3(nb), dim3(256), 0, s, map_in, owner_max, owner_min, p);
-  hipLaunchKernelGGL(reg_view_kernel, dim3(nb), dim3(256), 0, s, map_in, bits, ab, cd, ncell);
-  hipLaunchKernelGGL(reg_apply_kernel, dim3(nb), dim3(256), 0, s, map_in, map_out, owner_max, owner_min, bits, ab, cd, p);
+  hipMemsetAsync(n_elems, 0, sizeof(u32), s);
+  hipLaunchKernelGGL(reg_view_kernel, dim3(nb), dim3(256), 0, s, map_in, map_out, bits, ab, cd, elem_list, n_elems, ncell, p.W,
+                     p.band_y0, p.band_y1);
+  hipLaunchKernelGGL(reg_apply_kernel, dim3(nb), dim3(256), 0, s, map_in, map_out, owner_max, owner_min, bits, ab, cd, elem_list,
+                     n_elems, p);
 }
 
 // ---- export: alive cells -> esvo_depth_point_t list (cell order; host orders by seq) --------------

@@ -182,7 +182,11 @@ __device__ void lm_eval(const DevParams& p, const LmProblem& pr, double x, doubl
       if (!first) s1 = s2;
       double t[LM_ROWS];
       const Recip rs1 = make_recip(s1);  // the 7 residuals of this lane share the divisor s1 (fdiv.hpp)
+#ifdef LM_PLAIN_DIV
+      if (false) {
+#else
       if (r2_ok && rs1.fast) {
+#endif
 #pragma unroll
         for (int y = 0; y < LM_ROWS; ++y) t[y] = (r[y] != 0) ? r2[y] * (nu + 1) / (nu + div_fast(r2[y], rs1)) : 0.0;
       } else {
@@ -196,7 +200,11 @@ __device__ void lm_eval(const DevParams& p, const LmProblem& pr, double x, doubl
     }
   }
   const Recip rs2 = make_recip(s2);
+#ifdef LM_PLAIN_DIV
+  const bool fast2 = false;
+#else
   const bool fast2 = r2_ok && rs2.fast;
+#endif
 #pragma unroll
   for (int y = 0; y < LM_ROWS; ++y) {
     const double weight = (nu + 1) / (nu + (fast2 ? div_fast(r2[y], rs2) : r2[y] / s2));
@@ -248,7 +256,7 @@ __device__ inline double lm_lmpar2(double r, double diag, double qtf, double del
   return x;
 }
 
-__global__ void __launch_bounds__(256, 2) lm_refine_kernel(LmArgs a, DevParams p, u32* n_solved) {
+__global__ void __launch_bounds__(256, 3) lm_refine_kernel(LmArgs a, DevParams p, u32* n_solved) {
   const u32 s = (blockIdx.x * 256 + threadIdx.x) >> 4;  // solver slot (thread-stride order)
   const int c = threadIdx.x & 15;
   u32 M = *a.n_matches;

@@ -39,7 +39,8 @@ def build(force=False, verbose=False):
     if not force and os.path.exists(_LIB_PATH) and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return _LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + HIPCC_FLAGS + ["-I", os.path.join(_CSRC, "..", "..", "include"), "-o", _LIB_PATH] + srcs
+    extra = os.environ.get("ESVO_EXTRA_HIPCC_FLAGS", "").split()  # A/B experiments only
+    cmd = [hipcc] + HIPCC_FLAGS + extra + ["-I", os.path.join(_CSRC, "..", "..", "include"), "-o", _LIB_PATH] + srcs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
