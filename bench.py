@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--workload", default="dsec640x480", choices=sorted(WORKLOADS))
     ap.add_argument("--events-per-tick", type=int, default=0, help="cap on block-matched events per tick (0 = all)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check", action="store_true", help="also print a checksum of the final DepthMap (sharded == unsharded check)")
     args = ap.parse_args()
 
     import torch
@@ -76,11 +77,17 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
+    if os.environ.get("ESVO_SHARED_GPU"):  # functional test of the N>1 path on a single GPU (with gloo)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("ESVO_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     wl = WORKLOADS[args.workload]
     rig = calib.dataset_rig(wl["rig"])
@@ -188,6 +195,13 @@ def main():
         },
     }
 
+    if args.check:
+        mp_ = runner.get_map()
+        if rank == 0:
+            import hashlib
+            key = np.ascontiguousarray(np.stack([mp_["row"].astype(np.float64), mp_["col"].astype(np.float64), mp_["inv_depth"],
+                                                 mp_["variance"], mp_["age"].astype(np.float64)], axis=1))
+            out["check"] = {"map_size": int(len(mp_)), "sha1": hashlib.sha1(key.tobytes()).hexdigest()}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(rig, stream, p, ticks, Wm)
     if rank == 0:

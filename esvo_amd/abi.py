@@ -103,11 +103,9 @@ class StatsStruct(C.Structure):
 
 class ShardBuffersStruct(C.Structure):
     _fields_ = [
-        ("d_match_flags", C.c_void_p), ("match_flags_bytes", C.c_size_t),
-        ("d_point_flags", C.c_void_p), ("point_flags_bytes", C.c_size_t),
-        ("d_point_slots", C.c_void_p), ("point_slots_bytes", C.c_size_t),
-        ("d_map_cells", C.c_void_p), ("map_cells_bytes", C.c_size_t),
-        ("map_cell_stride", C.c_size_t),
+        ("d_match_flags", C.c_void_p), ("d_point_flags", C.c_void_p), ("d_point_slots", C.c_void_p),
+        ("d_reg_valid", C.c_void_p), ("d_reg_ab", C.c_void_p), ("d_reg_cd", C.c_void_p),
+        ("max_events", C.c_size_t), ("n_cells", C.c_size_t),
     ]
 
 

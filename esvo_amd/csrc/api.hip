@@ -108,6 +108,12 @@ struct esvo_context {
   u32* d_owner_max = nullptr;
   u32* d_owner_min = nullptr;
   u32* d_bucket = nullptr;
+  u32* d_mflags_local = nullptr;  // sharded mode: this rank's own BM flags (before the all-reduce)
+  u32* d_own = nullptr;           // sharded mode: own[j] = 1 if match j belongs to this rank's band
+  uint8_t* d_reg_valid = nullptr; // regulariser view: 1 byte per cell (exchanged between ranks)
+  bool sharded = false;
+  u32 sh_n = 0, sh_off = 0;       // state carried between the phases of a sharded tick
+  u64 sh_first = 0;
   u32* d_cell_list = nullptr;
   u64* d_reg_bits = nullptr;
   double2* d_reg_ab = nullptr;
@@ -226,8 +232,9 @@ int upload_poses(esvo_context* h, const uint64_t* pose_t_ns, const double* pose_
   return ESVO_OK;
 }
 
-// BM over n events starting at absolute ring index `first` (reverse walk) or over d_tick_ev
-int run_match(esvo_context* h, const esvo_event_t* d_ev, u64 first, u64 cap, int reverse, u32 n) {
+// BM over n events starting at absolute ring index `first` (reverse walk) or over d_tick_ev:
+// flags + match records in slot (thread-stride) order
+int run_bm(esvo_context* h, const esvo_event_t* d_ev, u64 first, u64 cap, int reverse, u32 n) {
   BmArgs a;
   a.ev = d_ev; a.n = n; a.ev_first = first; a.ev_cap = cap; a.ev_reverse = reverse;
   a.tsL = h->d_obs[0]; a.tsR = h->d_obs[1];
@@ -237,30 +244,54 @@ int run_match(esvo_context* h, const esvo_event_t* d_ev, u64 first, u64 cap, int
   hipEventRecord(h->evt[EV_BM0], h->stream);
   launch_bm_match(a, h->dp, h->stream);
   hipEventRecord(h->evt[EV_BM1], h->stream);
+  HIPCHK(hipGetLastError());
+  return ESVO_OK;
+}
+// stable compaction of the match slots into vEMP order.  `local_flags` (sharded mode): the slots
+// this rank produced itself; d_match_flags then holds the all-reduced (global) flags.
+int run_order_matches(esvo_context* h, u32 n, const u32* local_flags) {
   launch_exclusive_scan_u32(h->d_match_flags, h->d_match_prefix, h->d_counters + 0, h->d_scan_tmp, n, h->stream);
-  launch_compact_matches(h->d_match_slots, h->d_match_flags, h->d_match_prefix, n, h->d_matches, h->stream);
+  if (local_flags) HIPCHK(hipMemsetAsync(h->d_own, 0, sizeof(u32) * (n ? n : 1), h->stream));
+  launch_compact_matches(h->d_match_slots, local_flags ? local_flags : h->d_match_flags, h->d_match_prefix, n, h->d_matches,
+                         local_flags ? h->d_own : nullptr, h->stream);
   hipEventRecord(h->evt[EV_S1], h->stream);
   HIPCHK(hipGetLastError());
   return ESVO_OK;
 }
+int run_match(esvo_context* h, const esvo_event_t* d_ev, u64 first, u64 cap, int reverse, u32 n) {
+  int rc = run_bm(h, d_ev, first, cap, reverse, n);
+  if (rc) return rc;
+  return run_order_matches(h, n, nullptr);
+}
 
-// LM (+cull) over the compacted matches; the culled points go to `dst` in the reference's order
-int run_refine(esvo_context* h, u32 max_matches, int cull, DevPoint* dst) {
+// LM (+cull) over the compacted matches: point records + flags in solver-slot order
+int run_lm(esvo_context* h, u32 max_matches, int cull, const u32* own) {
   HIPCHK(hipMemsetAsync(h->d_pt_flags, 0, sizeof(u32) * (max_matches ? max_matches : 1), h->stream));
+  if (own) HIPCHK(hipMemsetAsync(h->d_pt_slots, 0, sizeof(DevPoint) * (max_matches ? max_matches : 1), h->stream));
   HIPCHK(hipMemsetAsync(h->d_counters + 2, 0, sizeof(u32), h->stream));
   LmArgs a;
   a.matches = h->d_matches; a.n_matches = h->d_counters + 0; a.max_matches = max_matches;
   a.tsL = h->d_obs[0]; a.tsR = h->d_obs[1];
   a.pose_T = h->d_pose_T; a.T_world_obs = h->d_T_world_obs;
-  a.out_slots = h->d_pt_slots; a.out_flags = h->d_pt_flags; a.cull = cull;
+  a.out_slots = h->d_pt_slots; a.out_flags = h->d_pt_flags; a.cull = cull; a.own = own;
   hipEventRecord(h->evt[EV_LM0], h->stream);
   launch_lm_refine(a, h->dp, h->d_counters + 2, h->stream);
   hipEventRecord(h->evt[EV_LM1], h->stream);
+  HIPCHK(hipGetLastError());
+  return ESVO_OK;
+}
+// stable compaction of the solver slots: the culled points go to `dst` in the reference's order
+int run_order_points(esvo_context* h, u32 max_matches, DevPoint* dst) {
   launch_exclusive_scan_u32(h->d_pt_flags, h->d_pt_prefix, h->d_counters + 1, h->d_scan_tmp, max_matches, h->stream);
   launch_compact_points(h->d_pt_slots, h->d_pt_flags, h->d_pt_prefix, h->d_counters + 0, max_matches, dst, h->stream);
   hipEventRecord(h->evt[EV_S2], h->stream);
   HIPCHK(hipGetLastError());
   return ESVO_OK;
+}
+int run_refine(esvo_context* h, u32 max_matches, int cull, DevPoint* dst) {
+  int rc = run_lm(h, max_matches, cull, nullptr);
+  if (rc) return rc;
+  return run_order_points(h, max_matches, dst);
 }
 
 void collect_ts_timing(esvo_context* h) {
@@ -368,9 +399,16 @@ int run_fuse(esvo_context* h) {
   const bool do_clean = h->prm.clean_requires_full_window ? (h->frames.size() >= (size_t)h->prm.max_fusion_frames) : true;
   if (do_clean) launch_clean(h->d_map, h->dp, h->stream);
   hipEventRecord(h->evt[EV_CL1], h->stream);
+  if (h->prm.regularization)  // the band's part of the neighbourhood view (exchanged between ranks when sharded)
+    launch_reg_view(h->d_map, h->d_map2, h->d_owner_max, h->d_owner_min, h->d_reg_valid, h->d_reg_ab, h->d_reg_cd,
+                    h->d_cell_list, h->d_counters + 7, h->dp, h->stream);
+  HIPCHK(hipGetLastError());
+  return ESVO_OK;
+}
+int run_regularize(esvo_context* h) {
   if (h->prm.regularization) {
-    launch_regularize(h->d_map, h->d_map2, h->d_owner_max, h->d_owner_min, h->d_reg_bits, h->d_reg_ab, h->d_reg_cd,
-                      h->d_cell_list, h->d_counters + 7, h->dp, h->stream);
+    launch_reg_apply(h->d_map, h->d_map2, h->d_owner_max, h->d_owner_min, h->d_reg_valid, h->d_reg_bits, h->d_reg_ab,
+                     h->d_reg_cd, h->d_cell_list, h->d_counters + 7, h->dp, h->stream);
     h->d_map_cur = h->d_map2;
   }
   hipEventRecord(h->evt[EV_RG1], h->stream);
@@ -398,7 +436,7 @@ int export_map(esvo_context* h, std::vector<esvo_depth_point_t>& out, std::vecto
   if (cells) cells->resize(n);
   for (u32 i = 0; i < n; ++i) {
     sorted[i] = out[order[i]];
-    sorted[i].seq = i;
+    if (!h->sharded) sorted[i].seq = i;  // sharded: keep the global creation id so that bands can be merged
     if (cells) (*cells)[i] = cell[order[i]];
   }
   out.swap(sorted);
@@ -461,6 +499,7 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
     h->baseline = std::sqrt((t[0] * t[0] + t[1] * t[1]) + t[2] * t[2]);
   }
   h->dp.band_y0 = 0; h->dp.band_y1 = h->H;
+  h->dp.cband_y0 = 0; h->dp.cband_y1 = h->H;
   fill_dev_params(h);
 
 #define CK(call) do { hipError_t _e = (call); if (_e != hipSuccess) { g_create_error = std::string(#call) + ": " + hipGetErrorString(_e); esvo_destroy(h); return ESVO_ERR_HIP; } } while (0)
@@ -535,6 +574,10 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
   CK(dalloc(&h->d_owner_max, npx));
   CK(dalloc(&h->d_owner_min, npx));
   CK(dalloc(&h->d_bucket, 3 * 128));
+  CK(dalloc(&h->d_mflags_local, E));
+  CK(dalloc(&h->d_own, E));
+  CK(dalloc(&h->d_reg_valid, npx + 64));
+  CK(hipMemset(h->d_reg_valid, 0, npx + 64));
   CK(dalloc(&h->d_cell_list, npx));
   CK(dalloc(&h->d_reg_bits, npx / 64 + 2));
   CK(dalloc(&h->d_reg_ab, npx));
@@ -562,7 +605,8 @@ int esvo_destroy(esvo_handle h) {
                   h->d_matches, h->d_pt_slots, h->d_pt_flags, h->d_pt_prefix, h->d_pts_tmp, h->d_counters, h->d_scan_tmp,
                   h->d_win, h->d_frame_pose_T, h->d_fr_table, h->d_prop, h->d_cell_count, h->d_cell_offset,
                   h->d_cell_fill, h->d_rec_ids, h->d_map, h->d_map2, h->d_owner_max, h->d_owner_min, h->d_exp_flags,
-                  h->d_exp_prefix, h->d_export, h->d_export_cell, h->d_reg_bits, h->d_reg_ab, h->d_reg_cd, h->d_bucket, h->d_cell_list};
+                  h->d_exp_prefix, h->d_export, h->d_export_cell, h->d_reg_bits, h->d_reg_ab, h->d_reg_cd, h->d_bucket, h->d_cell_list, h->d_mflags_local, h->d_own,
+                  h->d_reg_valid};
   for (void* p : ptrs) if (p) hipFree(p);
   if (h->h_counters) hipHostFree(h->h_counters);
   if (h->h_fr_table) hipHostFree(h->h_fr_table);
@@ -800,6 +844,8 @@ int esvo_map_fuse(esvo_handle h, size_t* n_fusions) {
   HIPCHK(hipSetDevice(h->device));
   int rc = run_fuse(h);
   if (rc) return rc;
+  rc = run_regularize(h);
+  if (rc) return rc;
   rc = read_counters(h);
   if (rc) return rc;
   h->stats.last_fusions = h->h_counters[3];
@@ -813,15 +859,13 @@ int esvo_map_fuse(esvo_handle h, size_t* n_fusions) {
   return ESVO_OK;
 }
 
+}  // extern "C"
+
 // ---- Mapper: fused tick ---------------------------------------------------------------------------
-int esvo_map_tick(esvo_handle h, uint64_t t_ns, const uint64_t* pose_t_ns, const double* pose_T, size_t m) {
-  if (!h || !pose_t_ns || !pose_T) return ESVO_ERR_INVALID_ARG;
-  if (!h->obs_set) FAIL(ESVO_ERR_STATE, "esvo_map_set_observation has not been called");
-  HIPCHK(hipSetDevice(h->device));
-  int rc = upload_poses(h, pose_t_ns, pose_T, m);
-  if (rc) return rc;
-  // ---- event selection, esvo_Mapping.cpp:562-574 (Appendix A-3): walk back from
-  // lower_bound(t_end) to lower_bound(t_begin), newest first, at most PROCESS_EVENT_NUM ----
+namespace {
+// event selection, esvo_Mapping.cpp:562-574 (Appendix A-3): walk back from lower_bound(t_end) to
+// lower_bound(t_begin), newest first, at most PROCESS_EVENT_NUM
+int select_events(esvo_context* h, uint64_t t_ns, u64* first_out, u32* n_out) {
   const double t_end = ns_to_sec(t_ns);
   const u64 t_begin_ns = ros_time_from_sec(std::max(0.0, t_end - 10 * h->prm.bm_half_slice_thickness));
   const double t_begin = ns_to_sec(t_begin_ns);
@@ -835,27 +879,72 @@ int esvo_map_tick(esvo_handle h, uint64_t t_ns, const uint64_t* pose_t_ns, const
   if (n > h->max_ev) FAIL(ESVO_ERR_CAPACITY, "more events than max_events_per_tick");
   if (n && first - (n - 1) < h->ring_next[0] - std::min<u64>(h->ring_next[0], h->ring_cap))
     FAIL(ESVO_ERR_STATE, "selected events were already overwritten in the event ring");
+  *first_out = first;
+  *n_out = n;
+  return ESVO_OK;
+}
 
+// phase 0: poses, event selection, block matching of the events of this handle's band
+int tick_phase0(esvo_context* h, uint64_t t_ns, const uint64_t* pose_t_ns, const double* pose_T, size_t m) {
+  int rc = upload_poses(h, pose_t_ns, pose_T, m);
+  if (rc) return rc;
+  rc = select_events(h, t_ns, &h->sh_first, &h->sh_n);
+  if (rc) return rc;
+  const u32 n = h->sh_n;
   hipEventRecord(h->evt[EV_T0], h->stream);
   HIPCHK(hipMemsetAsync(h->d_counters, 0, sizeof(u32) * 8, h->stream));
-  if (n) { rc = run_match(h, h->d_ring[0], first, h->ring_cap, 1, n); if (rc) return rc; }
+  if (n) {
+    rc = run_bm(h, h->d_ring[0], h->sh_first, h->ring_cap, 1, n);
+    if (rc) return rc;
+    if (h->sharded)
+      HIPCHK(hipMemcpyAsync(h->d_mflags_local, h->d_match_flags, sizeof(u32) * n, hipMemcpyDeviceToDevice, h->stream));
+  }
+  h->stats.last_events_in = n;
+  return ESVO_OK;
+}
+// phase 1: order the matches (global flags), refine + cull the ones of this band
+int tick_phase1(esvo_context* h) {
+  const u32 n = h->sh_n;
+  int rc;
+  if (n) {
+    rc = run_order_matches(h, n, h->sharded ? h->d_mflags_local : nullptr);
+    if (rc) return rc;
+    rc = run_lm(h, n, 1, h->sharded ? h->d_own : nullptr);
+    if (rc) return rc;
+  }
+  if (h->sharded) {  // the caller sizes its collectives with the match count
+    rc = read_counters(h);
+    if (rc) return rc;
+    h->stats.last_matches = h->h_counters[0];
+  }
+  return ESVO_OK;
+}
+// phase 2: assemble the frame, window policy, fusion + clean of this band, regulariser view
+int tick_phase2(esvo_context* h) {
+  const u32 n = h->sh_n;
   // the new frame goes straight into the window ring (capacity for the worst case: n points)
-  u32 off;
-  rc = window_reserve(h, n, &off);
+  int rc = window_reserve(h, n, &h->sh_off);
   if (rc) return rc;
-  if (n) { rc = run_refine(h, n, 1, h->d_win + off); if (rc) return rc; }
+  if (n) { rc = run_order_points(h, n, h->d_win + h->sh_off); if (rc) return rc; }
   rc = read_counters(h);  // the window policy needs the point count (one small D2H per tick)
   if (rc) return rc;
-  const u32 n_matches = h->h_counters[0], n_points = n ? h->h_counters[1] : 0, n_solved = h->h_counters[2];
-  rc = commit_frame(h, off, n_points, h->h_pose_T.data(), h->n_pose);
+  const u32 n_points = n ? h->h_counters[1] : 0;
+  h->stats.last_matches = h->h_counters[0];
+  h->stats.last_solved = h->h_counters[2];
+  h->stats.last_points = n_points;
+  rc = commit_frame(h, h->sh_off, n_points, h->h_pose_T.data(), h->n_pose);
   if (rc) return rc;
-  rc = run_fuse(h);
+  return run_fuse(h);
+}
+// phase 3: regularisation of this band; statistics
+int tick_phase3(esvo_context* h) {
+  int rc = run_regularize(h);
   if (rc) return rc;
   rc = read_counters(h);
   if (rc) return rc;
+  const u32 n = h->sh_n;
   esvo_stats_t& s = h->stats;
   s.ticks++;
-  s.last_events_in = n; s.last_matches = n_matches; s.last_solved = n_solved; s.last_points = n_points;
   s.last_fusions = h->h_counters[3];
   s.last_window_frames = (u32)h->frames.size();
   u32 np = 0;
@@ -878,7 +967,40 @@ int esvo_map_tick(esvo_handle h, uint64_t t_ns, const uint64_t* pose_t_ns, const
   hipEventElapsedTime(&s.ms_tick_total, h->evt[EV_T0], h->evt[EV_RG1]);
   return ESVO_OK;
 }
+}  // namespace
 
+extern "C" int esvo_map_tick(esvo_handle h, uint64_t t_ns, const uint64_t* pose_t_ns, const double* pose_T, size_t m) {
+  if (!h || !pose_t_ns || !pose_T) return ESVO_ERR_INVALID_ARG;
+  if (!h->obs_set) FAIL(ESVO_ERR_STATE, "esvo_map_set_observation has not been called");
+  if (h->sharded) FAIL(ESVO_ERR_STATE, "handle is sharded: drive it with esvo_shard_tick_phase");
+  HIPCHK(hipSetDevice(h->device));
+  int rc = tick_phase0(h, t_ns, pose_t_ns, pose_T, m);
+  if (rc) return rc;
+  rc = tick_phase1(h);
+  if (rc) return rc;
+  rc = tick_phase2(h);
+  if (rc) return rc;
+  return tick_phase3(h);
+}
+
+extern "C" int esvo_shard_tick_phase(esvo_handle h, int phase, uint64_t t_ns, const uint64_t* pose_t_ns, const double* pose_T,
+                                     size_t m) {
+  if (!h) return ESVO_ERR_INVALID_ARG;
+  if (!h->obs_set) FAIL(ESVO_ERR_STATE, "esvo_map_set_observation has not been called");
+  if (!h->sharded) FAIL(ESVO_ERR_STATE, "call esvo_shard_set_band first");
+  HIPCHK(hipSetDevice(h->device));
+  switch (phase) {
+    case 0:
+      if (!pose_t_ns || !pose_T) return ESVO_ERR_INVALID_ARG;
+      return tick_phase0(h, t_ns, pose_t_ns, pose_T, m);
+    case 1: return tick_phase1(h);
+    case 2: return tick_phase2(h);
+    case 3: return tick_phase3(h);
+    default: FAIL(ESVO_ERR_INVALID_ARG, "phase must be 0..3");
+  }
+}
+
+extern "C" {
 // ---- Outputs -----------------------------------------------------------------------------------------
 int esvo_map_get_depth_points(esvo_handle h, esvo_depth_point_t* out, size_t cap, size_t* n) {
   if (!h || !n) return ESVO_ERR_INVALID_ARG;
@@ -937,23 +1059,23 @@ int esvo_shard_set_band(esvo_handle h, int row_begin, int row_end) {
   if (!h || row_begin < 0 || row_end > h->H || row_begin >= row_end) return ESVO_ERR_INVALID_ARG;
   h->dp.band_y0 = row_begin;
   h->dp.band_y1 = row_end;
+  h->dp.cband_y0 = std::max(0, row_begin - 2);
+  h->dp.cband_y1 = std::min(h->H, row_end + 2);
+  h->sharded = !(row_begin == 0 && row_end == h->H);
   return ESVO_OK;
 }
 
 int esvo_shard_buffers(esvo_handle h, esvo_shard_buffers_t* out) {
   if (!h || !out) return ESVO_ERR_INVALID_ARG;
-  out->d_match_flags = h->d_match_flags; out->match_flags_bytes = sizeof(u32) * h->max_ev;
-  out->d_point_flags = h->d_pt_flags;    out->point_flags_bytes = sizeof(u32) * h->max_ev;
-  out->d_point_slots = h->d_pt_slots;    out->point_slots_bytes = sizeof(DevPoint) * h->max_ev;
-  out->d_map_cells = h->d_map_cur;       out->map_cells_bytes = sizeof(MapCell) * (size_t)h->W * h->H;
-  out->map_cell_stride = sizeof(MapCell);
+  out->d_match_flags = h->d_match_flags;
+  out->d_point_flags = h->d_pt_flags;
+  out->d_point_slots = h->d_pt_slots;
+  out->d_reg_valid = h->d_reg_valid;
+  out->d_reg_ab = h->d_reg_ab;
+  out->d_reg_cd = h->d_reg_cd;
+  out->max_events = h->max_ev;
+  out->n_cells = (size_t)h->W * h->H;
   return ESVO_OK;
-}
-
-int esvo_shard_tick_phase(esvo_handle h, int phase, uint64_t t_ns, const uint64_t* pose_t_ns, const double* pose_T,
-                          size_t m) {
-  (void)phase; (void)t_ns; (void)pose_t_ns; (void)pose_T; (void)m;
-  FAIL(ESVO_ERR_UNSUPPORTED, "esvo_shard_tick_phase: not implemented yet");
 }
 
 }  // extern "C"

@@ -42,6 +42,8 @@ struct DevParams {
   int reg_radius, reg_min_nb, reg_min_close;
   int num_threads;               // stride-N output permutation
   int band_y0, band_y1;          // row band owned by this handle (0,H when unsharded)
+  int cband_y0, cband_y1;        // compute band of the fusion stage: the owned band + 2 halo rows, so that
+                                 // the 1-row side effects of displaced elements (Appendix A-7) are exact
   CamConst camL, camR;
 };
 
@@ -159,7 +161,7 @@ struct BmArgs {
 };
 void launch_bm_match(const BmArgs& a, const DevParams& p, hipStream_t s);
 void launch_compact_matches(const esvo_match_t* slots, const u32* flags, const u32* prefix, u32 n,
-                            esvo_match_t* out, hipStream_t s);
+                            esvo_match_t* out, u32* own, hipStream_t s);
 
 // kernels_lm.hip
 struct LmArgs {
@@ -173,6 +175,7 @@ struct LmArgs {
   DevPoint* out_slots;          // [max_matches] slot s (thread-stride order of the solver)
   u32* out_flags;               // [max_matches] 1 = solved (and kept when cull)
   int cull;
+  const u32* own;               // sharded mode: own[j] != 0 <=> match j belongs to this rank (else nullptr)
 };
 void launch_lm_refine(const LmArgs& a, const DevParams& p, u32* n_solved, hipStream_t s);
 void launch_compact_points(const DevPoint* slots, const u32* flags, const u32* prefix, const u32* n_in,
@@ -207,8 +210,11 @@ struct FuseArgs {
 };
 void launch_fuse(const FuseArgs& a, const DevParams& p, hipStream_t s);
 void launch_clean(MapCell* map, const DevParams& p, hipStream_t s);
-void launch_regularize(const MapCell* map_in, MapCell* map_out, u32* owner_max, u32* owner_min, u64* bits,
-                       double2* ab, double2* cd, u32* elem_list, u32* n_elems, const DevParams& p, hipStream_t s);
+void launch_reg_view(const MapCell* map_in, MapCell* map_out, u32* owner_max, u32* owner_min, uint8_t* valid, double2* ab,
+                     double2* cd, u32* elem_list, u32* n_elems, const DevParams& p, hipStream_t s);
+void launch_reg_apply(const MapCell* map_in, MapCell* map_out, const u32* owner_max, const u32* owner_min,
+                      const uint8_t* valid, u64* bits, const double2* ab, const double2* cd, const u32* elem_list,
+                      const u32* n_elems, const DevParams& p, hipStream_t s);
 void launch_map_compact(const MapCell* map, u32* flags, u32* prefix, u32* d_total, u32* scan_tmp,
                         esvo_depth_point_t* out, u32* out_cell, const DevParams& p, hipStream_t s);
 

@@ -241,18 +241,20 @@ void launch_bm_match(const BmArgs& a, const DevParams& p, hipStream_t s) {
   }
 }
 
-// stable compaction: slot w -> position prefix[w]
+// stable compaction: slot w -> position prefix[w] (prefix over the GLOBAL flags; `flags` selects the
+// slots this rank owns and `own`, when given, marks their positions)
 __global__ void __launch_bounds__(256) compact_matches_kernel(const esvo_match_t* __restrict__ slots, const u32* __restrict__ flags,
                                                               const u32* __restrict__ prefix, u32 n,
-                                                              esvo_match_t* __restrict__ out) {
+                                                              esvo_match_t* __restrict__ out, u32* __restrict__ own) {
   const u32 w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= n || !flags[w]) return;
   out[prefix[w]] = slots[w];
+  if (own) own[prefix[w]] = 1u;
 }
 void launch_compact_matches(const esvo_match_t* slots, const u32* flags, const u32* prefix, u32 n, esvo_match_t* out,
-                            hipStream_t s) {
+                            u32* own, hipStream_t s) {
   if (n == 0) return;
-  hipLaunchKernelGGL(compact_matches_kernel, dim3((n + 255) / 256), dim3(256), 0, s, slots, flags, prefix, n, out);
+  hipLaunchKernelGGL(compact_matches_kernel, dim3((n + 255) / 256), dim3(256), 0, s, slots, flags, prefix, n, out, own);
 }
 
 }  // namespace esvo

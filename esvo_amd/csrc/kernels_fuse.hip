@@ -93,7 +93,7 @@ __global__ void __launch_bounds__(256) propagate_kernel(FuseArgs a, DevParams p,
   for (int k = 0; k < K; ++k) {
     int row, col;
     if (!fusion_cell(prop.row, prop.col, k, p.fusion_radius, p.W, p.H, row, col)) continue;
-    if (row < p.band_y0 || row >= p.band_y1) continue;
+    if (row < p.cband_y0 || row >= p.cband_y1) continue;
     atomicAdd(&a.cell_count[row * p.W + col], 1u);
   }
 }
@@ -106,7 +106,7 @@ __global__ void __launch_bounds__(256) scatter_records_kernel(FuseArgs a, DevPar
   for (int k = 0; k < K; ++k) {
     int row, col;
     if (!fusion_cell(prow, pcol, k, p.fusion_radius, p.W, p.H, row, col)) continue;
-    if (row < p.band_y0 || row >= p.band_y1) continue;
+    if (row < p.cband_y0 || row >= p.cband_y1) continue;
     const int cell = row * p.W + col;
     const u32 pos = a.cell_offset[cell] + atomicAdd(&a.cell_fill[cell], 1u);
     a.rec_ids[pos] = q * (u32)K + (u32)k;
@@ -312,10 +312,10 @@ void launch_fuse(const FuseArgs& a, const DevParams& p, hipStream_t s) {
   if (a.n_pts) hipLaunchKernelGGL(propagate_kernel, dim3((a.n_pts + 255) / 256), dim3(256), 0, s, a, p, K);
   launch_exclusive_scan_u32(a.cell_count, a.cell_offset, a.d_total, a.scan_tmp, (size_t)ncell, s);
   if (a.n_pts) hipLaunchKernelGGL(scatter_records_kernel, dim3((a.n_pts + 255) / 256), dim3(256), 0, s, a, p, K);
-  hipLaunchKernelGGL(bucket_count_kernel, dim3(nb), dim3(256), 0, s, a.cell_count, a.bucket, a.map, ncell, p.band_y0, p.band_y1, p.W);
+  hipLaunchKernelGGL(bucket_count_kernel, dim3(nb), dim3(256), 0, s, a.cell_count, a.bucket, a.map, ncell, p.cband_y0, p.cband_y1, p.W);
   hipLaunchKernelGGL(bucket_offsets_kernel, dim3(1), dim3(FUSE_NB), 0, s, a.bucket, a.bucket + FUSE_NB, a.n_touched);
   hipLaunchKernelGGL(bucket_scatter_kernel, dim3(nb), dim3(256), 0, s, a.cell_count, a.bucket + FUSE_NB, a.bucket + 2 * FUSE_NB,
-                     a.cell_list, ncell, p.band_y0, p.band_y1, p.W);
+                     a.cell_list, ncell, p.cband_y0, p.cband_y1, p.W);
   hipLaunchKernelGGL(sort_long_lists_kernel, dim3(8192), dim3(64), 0, s, a.cell_list, a.bucket + FUSE_NB + 3, a.cell_count,
                      a.cell_offset, a.rec_ids);
   hipLaunchKernelGGL(fuse_cells_kernel, dim3(nb), dim3(256), 0, s, a, p, K);
@@ -325,6 +325,7 @@ void launch_fuse(const FuseArgs& a, const DevParams& p, hipStream_t s) {
 __global__ void __launch_bounds__(256) clean_kernel(MapCell* __restrict__ map, DevParams p) {
   const int cell = blockIdx.x * blockDim.x + threadIdx.x;
   if (cell >= p.W * p.H) return;
+  { const int row = cell / p.W; if (row < p.cband_y0 || row >= p.cband_y1) return; }
   MapCell& c = map[cell];
   if (!(c.flags & CELL_ALIVE)) return;
   // DepthPoint::valid(var, age, max, min), DepthPoint.cpp:221-230
@@ -347,6 +348,7 @@ __global__ void __launch_bounds__(256) reg_owner_kernel(const MapCell* __restric
                                                         u32* __restrict__ owner_min, DevParams p) {
   const int cell = blockIdx.x * blockDim.x + threadIdx.x;
   if (cell >= p.W * p.H) return;
+  { const int row = cell / p.W; if (row < p.cband_y0 || row >= p.cband_y1) return; }
   const MapCell& c = map[cell];
   if (!(c.flags & CELL_ALIVE)) return;
   const u32 b = c.row * (u32)p.W + c.col;  // dmTmp.set(it->row(), it->col(), *it)
@@ -361,14 +363,16 @@ __global__ void __launch_bounds__(256) reg_owner_kernel(const MapCell* __restric
 // 16 B per tap instead of a 104 B MapCell, empty cells are skipped 64 at a time, and the
 // neighbour's sqrt is computed once per cell instead of once per tap.
 __global__ void __launch_bounds__(256) reg_view_kernel(const MapCell* __restrict__ map, MapCell* __restrict__ out,
-                                                       u64* __restrict__ bits, double2* __restrict__ ab, double2* __restrict__ cd,
+                                                       uint8_t* __restrict__ valid, double2* __restrict__ ab, double2* __restrict__ cd,
                                                        u32* __restrict__ elem_list, u32* __restrict__ n_elems, int ncell, int W,
                                                        int band0, int band1) {
   const int cell = blockIdx.x * blockDim.x + threadIdx.x;
   bool v = false, alive = false;
   if (cell < ncell) {
     const MapCell& n = map[cell];
-    alive = (n.flags & CELL_ALIVE) != 0;
+    const int row0 = cell / W;
+    const bool in_band = row0 >= band0 && row0 < band1;
+    alive = in_band && (n.flags & CELL_ALIVE) != 0;
     v = alive && (n.flags & CELL_GRID) && n.inv_depth > -1e-6;
     if (v) {
       ab[cell] = make_double2(n.inv_depth, 2.0 * sqrt(n.variance));
@@ -376,10 +380,11 @@ __global__ void __launch_bounds__(256) reg_view_kernel(const MapCell* __restrict
     }
     const int row = cell / W;
     if (row < band0 || row >= band1) alive = false;
-    else if (!alive) out[cell].flags = 0;
+    else {
+      valid[cell] = v ? 1 : 0;  // only the band's bytes: the other bands come from their ranks
+      if (!alive) out[cell].flags = 0;
+    }
   }
-  const u64 m = __ballot(v);
-  if ((threadIdx.x & 63) == 0 && cell < ncell) bits[cell >> 6] = m;
   // compact the alive elements (apply kernel: one thread per element, full waves); order is free
   const u64 am = __ballot(alive);
   const int lane = threadIdx.x & 63;
@@ -466,25 +471,42 @@ __global__ void __launch_bounds__(256) reg_apply_kernel(const MapCell* __restric
   out[cell] = c;
 }
 
-void launch_regularize(const MapCell* map_in, MapCell* map_out, u32* owner_max, u32* owner_min, u64* bits, double2* ab,
-                       double2* cd, u32* elem_list, u32* n_elems, const DevParams& p, hipStream_t s) {
+// validity bytes (own band + the bands received from the other ranks) -> 64-cell bit words
+__global__ void __launch_bounds__(256) reg_bits_kernel(const uint8_t* __restrict__ valid, u64* __restrict__ bits, int ncell) {
+  const int cell = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool v = cell < ncell && valid[cell] != 0;
+  const u64 m = __ballot(v);
+  if ((threadIdx.x & 63) == 0 && cell < ncell) bits[cell >> 6] = m;
+}
+
+void launch_reg_view(const MapCell* map_in, MapCell* map_out, u32* owner_max, u32* owner_min, uint8_t* valid, double2* ab,
+                     double2* cd, u32* elem_list, u32* n_elems, const DevParams& p, hipStream_t s) {
   const int ncell = p.W * p.H;
   hipMemsetAsync(owner_max, 0, sizeof(u32) * ncell, s);
   hipMemsetAsync(owner_min, 0xff, sizeof(u32) * ncell, s);
+  hipMemsetAsync(n_elems, 0, sizeof(u32), s);
   const int nb = (ncell + 255) / 256;
   hipLaunchKernelGGL(reg_owner_kernel, dim3(nb), dim3(256), 0, s, map_in, owner_max, owner_min, p);
-  hipMemsetAsync(n_elems, 0, sizeof(u32), s);
-  hipLaunchKernelGGL(reg_view_kernel, dim3(nb), dim3(256), 0, s, map_in, map_out, bits, ab, cd, elem_list, n_elems, ncell, p.W,
+  hipLaunchKernelGGL(reg_view_kernel, dim3(nb), dim3(256), 0, s, map_in, map_out, valid, ab, cd, elem_list, n_elems, ncell, p.W,
                      p.band_y0, p.band_y1);
+}
+void launch_reg_apply(const MapCell* map_in, MapCell* map_out, const u32* owner_max, const u32* owner_min, const uint8_t* valid,
+                      u64* bits, const double2* ab, const double2* cd, const u32* elem_list, const u32* n_elems,
+                      const DevParams& p, hipStream_t s) {
+  const int ncell = p.W * p.H;
+  const int nb = (ncell + 255) / 256;
+  hipLaunchKernelGGL(reg_bits_kernel, dim3(nb), dim3(256), 0, s, valid, bits, ncell);
   hipLaunchKernelGGL(reg_apply_kernel, dim3(nb), dim3(256), 0, s, map_in, map_out, owner_max, owner_min, bits, ab, cd, elem_list,
                      n_elems, p);
 }
 
 // ---- export: alive cells -> esvo_depth_point_t list (cell order; host orders by seq) --------------
-__global__ void __launch_bounds__(256) map_flags_kernel(const MapCell* __restrict__ map, u32* __restrict__ flags, int ncell) {
+__global__ void __launch_bounds__(256) map_flags_kernel(const MapCell* __restrict__ map, u32* __restrict__ flags, int ncell, int W,
+                                                        int band0, int band1) {
   const int cell = blockIdx.x * blockDim.x + threadIdx.x;
   if (cell >= ncell) return;
-  flags[cell] = (map[cell].flags & CELL_ALIVE) ? 1u : 0u;
+  const int row = cell / W;
+  flags[cell] = (row >= band0 && row < band1 && (map[cell].flags & CELL_ALIVE)) ? 1u : 0u;
 }
 __global__ void __launch_bounds__(256) map_export_kernel(const MapCell* __restrict__ map, const u32* __restrict__ flags,
                                                          const u32* __restrict__ prefix, esvo_depth_point_t* __restrict__ out,
@@ -506,7 +528,7 @@ __global__ void __launch_bounds__(256) map_export_kernel(const MapCell* __restri
 void launch_map_compact(const MapCell* map, u32* flags, u32* prefix, u32* d_total, u32* scan_tmp,
                         esvo_depth_point_t* out, u32* out_cell, const DevParams& p, hipStream_t s) {
   const int ncell = p.W * p.H;
-  hipLaunchKernelGGL(map_flags_kernel, dim3((ncell + 255) / 256), dim3(256), 0, s, map, flags, ncell);
+  hipLaunchKernelGGL(map_flags_kernel, dim3((ncell + 255) / 256), dim3(256), 0, s, map, flags, ncell, p.W, p.band_y0, p.band_y1);
   launch_exclusive_scan_u32(flags, prefix, d_total, scan_tmp, (size_t)ncell, s);
   hipLaunchKernelGGL(map_export_kernel, dim3((ncell + 255) / 256), dim3(256), 0, s, map, flags, prefix, out, out_cell, ncell);
 }

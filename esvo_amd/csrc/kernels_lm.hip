@@ -261,7 +261,7 @@ __global__ void __launch_bounds__(256, 3) lm_refine_kernel(LmArgs a, DevParams p
   const int c = threadIdx.x & 15;
   u32 M = *a.n_matches;
   if (M > a.max_matches) M = a.max_matches;
-  const bool active = s < M;
+  bool active = s < M;
   // inactive groups still run the (cheap, failing) code path below with a dummy problem so that
   // the wave's shuffles stay convergent; they write nothing.
   u32 j = 0;
@@ -269,7 +269,8 @@ __global__ void __launch_bounds__(256, 3) lm_refine_kernel(LmArgs a, DevParams p
   m.x_left[0] = m.x_left[1] = -1e9; m.inv_depth = 1.0; m.pose_idx = 0; m.cost = 0; m.disp = 0; m.event_idx = 0;
   if (active) {
     j = stride_item(s, M, (u32)p.num_threads);  // DepthProblemSolver.cpp:90
-    m = a.matches[j];
+    if (a.own && !a.own[j]) active = false;     // another rank's band refines this match
+    else m = a.matches[j];
   }
   LmProblem pr;
   pr.cx = m.x_left[0];

@@ -243,3 +243,16 @@ class Esvo:
 
     def set_band(self, y0, y1):
         self._ck(self.lib.esvo_shard_set_band(self.h, int(y0), int(y1)))
+
+    def shard_buffers(self):
+        b = ShardBuffersStruct()
+        self._ck(self.lib.esvo_shard_buffers(self.h, C.addressof(b)))
+        return b
+
+    def shard_phase(self, phase, t_ns=0, stamps=None, poses=None):
+        if phase == 0:
+            st = np.ascontiguousarray(stamps, np.uint64)
+            T = np.ascontiguousarray(poses, np.float64).reshape(-1, 16)
+            self._ck(self.lib.esvo_shard_tick_phase(self.h, 0, int(t_ns), st.ctypes.data, T.ctypes.data, st.shape[0]))
+        else:
+            self._ck(self.lib.esvo_shard_tick_phase(self.h, int(phase), 0, None, None, 0))

@@ -256,18 +256,29 @@ void esvo_abi_sizes(size_t out[8]);
  * floor(y) lies in [row_begin,row_end) and its per-cell work (fuse/clean/regularise) to the
  * same rows.  (0,H) = unsharded. */
 int esvo_shard_set_band(esvo_handle h, int row_begin, int row_end);
-/* Three-phase tick for sharded operation; the caller runs the collectives between phases on
- * the buffers exposed by esvo_shard_buffers (torch.distributed / RCCL on the same stream):
- *   phase 0: select + match (local band)            -> all-reduce(sum) match_flags
- *   phase 1: order + refine + cull (local matches)  -> all-reduce(sum) point_flags, point_slots
- *   phase 2: frame assembly + window + fuse + clean -> all-gather map band
- *   phase 3: regularise own band                    -> all-gather map band (again) */
+/* Four-phase tick for sharded operation.  Every rank stages ALL events and renders the full Time
+ * Surfaces (replicated, ~1 % of a tick); per-event and per-cell work is split by band.  The caller
+ * runs the collectives between phases on the device buffers exposed by esvo_shard_buffers
+ * (torch.distributed / RCCL, issued on the handle's stream, see esvo_amd/dist.py):
+ *   phase 0: poses + event selection + block matching of the band's events
+ *            -> all-reduce(SUM) match_flags[0..n)            n = stats.last_events_in
+ *   phase 1: global match order + LM refinement + culling of the band's matches
+ *            -> all-reduce(SUM) point_flags[0..M), point_slots[0..M) (as integers; foreign slots are 0)
+ *                                                            M = stats.last_matches
+ *   phase 2: frame assembly + window policy (identical on every rank) + fusion + clean of the band,
+ *            regulariser view of the band
+ *            -> all-gather reg_valid / reg_ab / reg_cd row bands (only when Regularization is on)
+ *   phase 3: regularisation of the band.
+ * The DepthMap stays sharded; esvo_map_get_depth_points returns the band's elements. */
 typedef struct esvo_shard_buffers_t {
-  void* d_match_flags;  size_t match_flags_bytes;
-  void* d_point_flags;  size_t point_flags_bytes;
-  void* d_point_slots;  size_t point_slots_bytes;
-  void* d_map_cells;    size_t map_cells_bytes;   /* full map, row-major, band = contiguous rows */
-  size_t map_cell_stride;                         /* bytes per cell */
+  void* d_match_flags;  /* uint32[max_events] */
+  void* d_point_flags;  /* uint32[max_events] */
+  void* d_point_slots;  /* esvo_depth_point_t[max_events] */
+  void* d_reg_valid;    /* uint8[n_cells]    neighbour validity */
+  void* d_reg_ab;       /* double[n_cells*2] (inv_depth, 2*sigma) */
+  void* d_reg_cd;       /* double[n_cells*2] (nu, scale^2) */
+  size_t max_events;
+  size_t n_cells;
 } esvo_shard_buffers_t;
 int esvo_shard_buffers(esvo_handle h, esvo_shard_buffers_t* out);
 int esvo_shard_tick_phase(esvo_handle h, int phase, uint64_t t_ns, const uint64_t* pose_t_ns,
