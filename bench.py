@@ -58,6 +58,31 @@ def algorithmic_bytes(kernel, st, W, H, nd, fusion_radius=1):
     return 0
 
 
+def measured_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary
+    (profiles/*_hbm_traffic.csv: separate FETCH_SIZE / WRITE_SIZE passes of this same command;
+    FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction).  None if no profile exists."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.csv")))
+    if not files:
+        return None
+    sym = {"lm_refine": "lm_refine_kernel", "bm_match": "bm_match_kernel", "fuse": "fuse_cells_kernel",
+           "regularize": "reg_apply_kernel", "ts_render": "ts_decay_kernel", "ts_scatter": "ts_scatter_kernel"}.get(kernel)
+    fetch = write = None
+    with open(files[-1]) as f:
+        for row in csv.DictReader(f):
+            if sym and sym in row["kernel"]:
+                v = float(row["avg_value_per_dispatch_KB"]) * 1024.0
+                if row["counter"] == "FETCH_SIZE":
+                    fetch = 2.0 * v
+                elif row["counter"] == "WRITE_SIZE":
+                    write = v
+    if fetch is None or write is None:
+        return None
+    return fetch + write
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -189,7 +214,7 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": measured_traffic(dom_name),
             "algorithmic_bytes_per_launch": dom_bytes,
             "avg_launch_ms": float(kavg[dom]),
         },
