@@ -112,10 +112,12 @@ struct esvo_context {
   u32* d_own = nullptr;           // sharded mode: own[j] = 1 if match j belongs to this rank's band
   uint8_t* d_reg_valid = nullptr; // regulariser view: 1 byte per cell (exchanged between ranks)
   bool sharded = false;
+  u32 reg_words = 0;
   u32 sh_n = 0, sh_off = 0;       // state carried between the phases of a sharded tick
   u64 sh_first = 0;
   u32* d_cell_list = nullptr;
-  u64* d_reg_bits = nullptr;
+  u64* d_reg_bits = nullptr;    // close-neighbour masks of the regulariser scan: [elements][words]
+  u32* d_reg_counts = nullptr;  // (n_neighbours, n_close) per element
   double2* d_reg_ab = nullptr;
   double2* d_reg_cd = nullptr;
   double T_world_frame[16];
@@ -170,6 +172,7 @@ int validate_params(const esvo_params_t* p, std::string& why) {
   if (p->td_nu <= 2.0 || p->td_scale <= 0) { why = "Tdist_nu must be > 2 and Tdist_scale > 0"; return ESVO_ERR_INVALID_ARG; }
   if (p->num_threads < 1 || p->num_threads > 64) { why = "num_threads out of range"; return ESVO_ERR_INVALID_ARG; }
   if (p->lm_max_iteration < 1) { why = "lm_max_iteration must be >= 1"; return ESVO_ERR_INVALID_ARG; }
+  if (p->reg_radius < 0 || p->reg_radius > 64) { why = "RegularizationRadius out of range [0,64]"; return ESVO_ERR_INVALID_ARG; }
   return ESVO_OK;
 }
 
@@ -407,8 +410,9 @@ int run_fuse(esvo_context* h) {
 }
 int run_regularize(esvo_context* h) {
   if (h->prm.regularization) {
-    launch_reg_apply(h->d_map, h->d_map2, h->d_owner_max, h->d_owner_min, h->d_reg_valid, h->d_reg_bits, h->d_reg_ab,
-                     h->d_reg_cd, h->d_cell_list, h->d_counters + 7, h->dp, h->stream);
+    launch_reg_apply(h->d_map, h->d_map2, h->d_owner_max, h->d_owner_min, h->d_reg_valid, h->d_reg_bits, h->d_reg_counts,
+                     h->d_reg_ab, h->d_reg_cd, h->d_cell_list, h->d_counters + 7,
+                     (u32)((size_t)(h->dp.band_y1 - h->dp.band_y0) * h->W), h->dp, h->stream);
     h->d_map_cur = h->d_map2;
   }
   hipEventRecord(h->evt[EV_RG1], h->stream);
@@ -579,7 +583,12 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
   CK(dalloc(&h->d_reg_valid, npx + 64));
   CK(hipMemset(h->d_reg_valid, 0, npx + 64));
   CK(dalloc(&h->d_cell_list, npx));
-  CK(dalloc(&h->d_reg_bits, npx / 64 + 2));
+  {
+    const int wn = 2 * std::max(params->reg_radius, 1) + 1;
+    h->reg_words = (u32)((wn * wn + 63) / 64);
+    CK(dalloc(&h->d_reg_bits, npx * (size_t)h->reg_words));
+    CK(dalloc(&h->d_reg_counts, 2 * npx));
+  }
   CK(dalloc(&h->d_reg_ab, npx));
   CK(dalloc(&h->d_reg_cd, npx));
   CK(dalloc(&h->d_exp_flags, npx));
@@ -606,7 +615,7 @@ int esvo_destroy(esvo_handle h) {
                   h->d_win, h->d_frame_pose_T, h->d_fr_table, h->d_prop, h->d_cell_count, h->d_cell_offset,
                   h->d_cell_fill, h->d_rec_ids, h->d_map, h->d_map2, h->d_owner_max, h->d_owner_min, h->d_exp_flags,
                   h->d_exp_prefix, h->d_export, h->d_export_cell, h->d_reg_bits, h->d_reg_ab, h->d_reg_cd, h->d_bucket, h->d_cell_list, h->d_mflags_local, h->d_own,
-                  h->d_reg_valid};
+                  h->d_reg_valid, h->d_reg_counts};
   for (void* p : ptrs) if (p) hipFree(p);
   if (h->h_counters) hipHostFree(h->h_counters);
   if (h->h_fr_table) hipHostFree(h->h_fr_table);
@@ -645,6 +654,10 @@ int esvo_set_params(esvo_handle h, const esvo_params_t* params) {
   if (rc) FAIL(rc, why);
   if ((u32)std::max(params->max_events_per_tick, params->process_event_num) > h->max_ev)
     FAIL(ESVO_ERR_CAPACITY, "process_event_num exceeds the capacity fixed at esvo_create");
+  {
+    const int wn = 2 * std::max(params->reg_radius, 1) + 1;
+    if ((u32)((wn * wn + 63) / 64) > h->reg_words) FAIL(ESVO_ERR_CAPACITY, "RegularizationRadius exceeds the capacity fixed at esvo_create");
+  }
   esvo_params_t np = *params;
   np.max_events_per_tick = h->prm.max_events_per_tick;
   np.max_window_points = h->prm.max_window_points;

@@ -394,89 +394,111 @@ __global__ void __launch_bounds__(256) reg_view_kernel(const MapCell* __restrict
   if (alive) elem_list[base + (u32)__popcll(am & ((1ull << lane) - 1ull))] = (u32)cell;
 }
 
-__global__ void __launch_bounds__(256) reg_apply_kernel(const MapCell* __restrict__ map, MapCell* __restrict__ out,
+// ---- regulariser pass A: neighbourhood scan, one wave per element -----------------------------------
+// The (2r+1)^2 taps are enumerated in the reference's row-major order, 64 per step; lane = tap.
+// A tap counts as neighbour if its cell is valid (exists && valid()), as CLOSE neighbour if
+// |rho_self - rho_n| < 2 sigma_self or < 2 sigma_n.  The wave ballots give the neighbour counts and,
+// per step, a 64-bit mask of the close taps (kept in tap order), which is all pass B needs.
+__global__ void __launch_bounds__(256) reg_scan_kernel(const MapCell* __restrict__ map, const uint8_t* __restrict__ valid,
+                                                       const double2* __restrict__ ab, const u32* __restrict__ elem_list,
+                                                       const u32* __restrict__ n_elems, u64* __restrict__ masks,
+                                                       u32* __restrict__ counts, int words, DevParams p) {
+  const u32 e = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (e >= *n_elems) return;
+  const int lane = threadIdx.x & 63;
+  const int cell = (int)elem_list[e];
+  const MapCell& c = map[cell];
+  const int R = p.reg_radius, Wn = 2 * R + 1, taps = Wn * Wn;
+  const int row = (int)c.row, col = (int)c.col;
+  const double inv = c.inv_depth;
+  u32 n_nb = 0, n_close = 0;
+  // SmartGrid::getNeighbourhood's loop bounds mix int and size_t (SmartGrid.h:373-375): for
+  // row < radius or col < radius the loops never execute -> no neighbours at all.
+  const bool scan = inv > -1e-6 && row >= R && col >= R;
+  const double sd_self2 = 2.0 * sqrt(c.variance);
+  for (int w = 0; w < words; ++w) {
+    bool close = false, v = false;
+    const int t = w * 64 + lane;
+    if (scan && t < taps) {
+      const int dr = t / Wn, dc = t - dr * Wn;
+      const int r = row - R + dr, cc = col - R + dc;
+      if (r < p.H && cc < p.W) {
+        const int nc = r * p.W + cc;
+        v = valid[nc] != 0;
+        if (v) {
+          const double2 q = ab[nc];
+          const double diff = fabs(inv - q.x);
+          close = diff < sd_self2 || diff < q.y;
+        }
+      }
+    }
+    const u64 vm = __ballot(v), cm = __ballot(close);
+    n_nb += (u32)__popcll(vm);
+    n_close += (u32)__popcll(cm);
+    if (lane == 0) masks[(size_t)e * words + w] = cm;
+  }
+  if (lane == 0) { counts[2 * e] = n_nb; counts[2 * e + 1] = n_close; }
+}
+
+// ---- regulariser pass B: sequential Student-t fusion of the close neighbours, one thread per element --
+// DepthRegularization.cpp:66-98.  The order is fixed by the masks, so the neighbour data of the next
+// step is loaded while the current (dependent) fusion step computes.
+__global__ void __launch_bounds__(256) reg_chain_kernel(const MapCell* __restrict__ map, MapCell* __restrict__ out,
                                                         const u32* __restrict__ owner_max, const u32* __restrict__ owner_min,
-                                                        const u64* __restrict__ bits, const double2* __restrict__ ab,
-                                                        const double2* __restrict__ cd, const u32* __restrict__ elem_list,
-                                                        const u32* __restrict__ n_elems, DevParams p) {
-  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= *n_elems) return;
-  const int cell = (int)elem_list[t];
+                                                        const double2* __restrict__ ab, const double2* __restrict__ cd,
+                                                        const u32* __restrict__ elem_list, const u32* __restrict__ n_elems,
+                                                        const u64* __restrict__ masks, const u32* __restrict__ counts, int words,
+                                                        DevParams p) {
+  const u32 e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= *n_elems) return;
+  const int cell = (int)elem_list[e];
   MapCell c = map[cell];
   const u32 b = c.row * (u32)p.W + c.col;
   if (owner_max[b] != c.seq + 1u) { out[cell].flags = 0; return; }  // overwritten by a later element
   if (c.inv_depth > -1e-6) {  // it->valid()
-    const int R = p.reg_radius;
-    const int row = (int)c.row, col = (int)c.col;
-    u32 n_nb = 0, n_close = 0;
-    double nu_post = 0, inv_post = 0, s2_post = 0;
-    // SmartGrid::getNeighbourhood's loop bounds mix int and size_t (SmartGrid.h:373-375): for
-    // row < radius or col < radius the loops never execute -> no neighbours at all.
-    if (row >= R && col >= R) {
-      const double sd_self2 = 2.0 * sqrt(c.variance);
-      const int c1 = min(col + R, p.W - 1);  // last column (inclusive)
-      const int r1 = min(row + R, p.H - 1);
-      for (int r = row - R; r <= r1; ++r) {
-        int idx = r * p.W + (col - R);        // linear index of the first tap of this row
-        const int last = r * p.W + c1;
-        while (idx <= last) {
-          const int word = idx >> 6, bit = idx & 63;
-          u64 m = bits[word] >> bit;
-          const int span = min(64 - bit, last - idx + 1);
-          if (span < 64) m &= ((1ull << span) - 1ull);
-          while (m) {
-            // up to 4 neighbours per batch: their loads are issued together instead of one
-            // dependent round trip per neighbour
-            int ks[4];
-            double2 qa[4], qc[4];
-            int cnt = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              if (m) { ks[j] = __builtin_ctzll(m); m &= m - 1; cnt = j + 1; }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              if (j < cnt) { qa[j] = ab[idx + ks[j]]; qc[j] = cd[idx + ks[j]]; }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              if (j >= cnt) break;
-              const double2 q = qa[j];
-              n_nb++;
-              const double diff = fabs(c.inv_depth - q.x);
-              if (diff < sd_self2 || diff < q.y) {
-                const double2 t = qc[j];
-                if (n_close == 0) {
-                  nu_post = t.x; inv_post = q.x; s2_post = t.y;
-                } else {  // DepthRegularization.cpp:72-86
-                  const double nu_prior = nu_post, inv_prior = inv_post, s2_prior = s2_post;
-                  const double nu_obs = t.x, inv_obs = q.x, s2_obs = t.y;
-                  nu_post = (nu_obs < nu_prior) ? nu_obs : nu_prior;
-                  const Recip rsum = make_recip(s2_obs + s2_prior);  // == s2_prior + s2_obs
-                  inv_post = div_by(s2_obs * inv_prior + s2_prior * inv_obs, rsum);
-                  const double dd = inv_prior - inv_obs;
-                  s2_post = div_by((nu_post + div_by(dd * dd, rsum)) / (nu_post + 1) * (s2_prior * s2_obs), rsum);
-                }
-                n_close++;
-              }
-            }
-          }
-          idx += span;
+    const u32 n_nb = counts[2 * e], n_close = counts[2 * e + 1];
+    if (n_nb > (u32)p.reg_min_nb && n_close > (u32)p.reg_min_close) {
+      const int R = p.reg_radius, Wn = 2 * R + 1;
+      const int row0 = (int)c.row - R, col0 = (int)c.col - R;
+      const u64* mk = masks + (size_t)e * words;
+      int w = 0;
+      u64 m = mk[0];
+      auto next_cell = [&]() -> int {  // next close tap in row-major order, -1 when exhausted
+        while (m == 0) {
+          if (++w >= words) return -1;
+          m = mk[w];
         }
+        const int k = __builtin_ctzll(m);
+        m &= m - 1;
+        const int t = w * 64 + k;
+        const int dr = t / Wn, dc = t - dr * Wn;
+        return (row0 + dr) * p.W + col0 + dc;
+      };
+      int nc = next_cell();  // n_close > 0 here
+      double inv_n = ab[nc].x;
+      double2 t_n = cd[nc];
+      double nu_post = t_n.x, inv_post = inv_n, s2_post = t_n.y;
+      nc = next_cell();
+      if (nc >= 0) { inv_n = ab[nc].x; t_n = cd[nc]; }
+      while (nc >= 0) {
+        const double nu_obs = t_n.x, inv_obs = inv_n, s2_obs = t_n.y;
+        nc = next_cell();
+        if (nc >= 0) { inv_n = ab[nc].x; t_n = cd[nc]; }  // prefetch: independent of the fusion state
+        const double nu_prior = nu_post, inv_prior = inv_post, s2_prior = s2_post;  // DepthRegularization.cpp:72-86
+        nu_post = (nu_obs < nu_prior) ? nu_obs : nu_prior;
+        const Recip rsum = make_recip(s2_obs + s2_prior);  // == s2_prior + s2_obs
+        inv_post = div_by(s2_obs * inv_prior + s2_prior * inv_obs, rsum);
+        const double dd = inv_prior - inv_obs;
+        s2_post = div_by((nu_post + div_by(dd * dd, rsum)) / (nu_post + 1) * (s2_prior * s2_obs), rsum);
       }
+      c.inv_depth = inv_post;
+    } else {
+      c.inv_depth = -1.0;
     }
-    if (n_nb > (u32)p.reg_min_nb && n_close > (u32)p.reg_min_close) c.inv_depth = inv_post;
-    else c.inv_depth = -1.0;
   }
   c.seq = owner_min[b];  // position of the first element set at that cell in dmTmp's list
   c.flags = CELL_ALIVE | CELL_GRID;
   out[cell] = c;
-}
-
-// validity bytes (own band + the bands received from the other ranks) -> 64-cell bit words
-__global__ void __launch_bounds__(256) reg_bits_kernel(const uint8_t* __restrict__ valid, u64* __restrict__ bits, int ncell) {
-  const int cell = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool v = cell < ncell && valid[cell] != 0;
-  const u64 m = __ballot(v);
-  if ((threadIdx.x & 63) == 0 && cell < ncell) bits[cell >> 6] = m;
 }
 
 void launch_reg_view(const MapCell* map_in, MapCell* map_out, u32* owner_max, u32* owner_min, uint8_t* valid, double2* ab,
@@ -491,13 +513,15 @@ void launch_reg_view(const MapCell* map_in, MapCell* map_out, u32* owner_max, u3
                      p.band_y0, p.band_y1);
 }
 void launch_reg_apply(const MapCell* map_in, MapCell* map_out, const u32* owner_max, const u32* owner_min, const uint8_t* valid,
-                      u64* bits, const double2* ab, const double2* cd, const u32* elem_list, const u32* n_elems,
-                      const DevParams& p, hipStream_t s) {
-  const int ncell = p.W * p.H;
-  const int nb = (ncell + 255) / 256;
-  hipLaunchKernelGGL(reg_bits_kernel, dim3(nb), dim3(256), 0, s, valid, bits, ncell);
-  hipLaunchKernelGGL(reg_apply_kernel, dim3(nb), dim3(256), 0, s, map_in, map_out, owner_max, owner_min, bits, ab, cd, elem_list,
-                     n_elems, p);
+                      u64* masks, u32* counts, const double2* ab, const double2* cd, const u32* elem_list, const u32* n_elems,
+                      u32 max_elems, const DevParams& p, hipStream_t s) {
+  const int Wn = 2 * p.reg_radius + 1;
+  const int words = (Wn * Wn + 63) / 64;
+  if (max_elems == 0) return;
+  hipLaunchKernelGGL(reg_scan_kernel, dim3((max_elems + 3) / 4), dim3(256), 0, s, map_in, valid, ab, elem_list, n_elems, masks,
+                     counts, words, p);
+  hipLaunchKernelGGL(reg_chain_kernel, dim3((max_elems + 255) / 256), dim3(256), 0, s, map_in, map_out, owner_max, owner_min, ab,
+                     cd, elem_list, n_elems, masks, counts, words, p);
 }
 
 // ---- export: alive cells -> esvo_depth_point_t list (cell order; host orders by seq) --------------
