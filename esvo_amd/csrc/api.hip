@@ -67,6 +67,9 @@ struct esvo_context {
   double* d_pose_sec = nullptr;
   double* d_pose_T = nullptr;
   std::vector<double> h_pose_T;
+  double* h_pin = nullptr;        // pinned staging: 2 slots x (max_poses x 17 + 16) doubles
+  int pin_slot = 0;
+  bool stats_pending = false;     // the last tick's counters / timings have not been read back yet
   u32 n_pose = 0;
 
   // per-tick scratch
@@ -223,14 +226,18 @@ u64 ros_time_from_sec(double t) {
 
 int upload_poses(esvo_context* h, const uint64_t* pose_t_ns, const double* pose_T, size_t m) {
   if (m > h->max_poses) FAIL(ESVO_ERR_CAPACITY, "pose table larger than max_poses_per_tick");
-  std::vector<double> sec(m);
+  // staged through pinned memory (two alternating slots): no host synchronisation on the tick path
+  h->pin_slot ^= 1;
+  double* pin = h->h_pin + (size_t)h->pin_slot * ((size_t)h->max_poses * 17 + 16);
+  double* sec = pin;
+  double* T = pin + h->max_poses;
   for (size_t i = 0; i < m; ++i) sec[i] = ns_to_sec(pose_t_ns[i]);
+  std::memcpy(T, pose_T, sizeof(double) * 16 * m);
   h->h_pose_T.assign(pose_T, pose_T + 16 * m);
   h->n_pose = (u32)m;
   if (m) {
-    HIPCHK(hipMemcpyAsync(h->d_pose_sec, sec.data(), sizeof(double) * m, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->d_pose_T, pose_T, sizeof(double) * 16 * m, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));  // `sec` is a stack temporary
+    HIPCHK(hipMemcpyAsync(h->d_pose_sec, sec, sizeof(double) * m, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_pose_T, T, sizeof(double) * 16 * m, hipMemcpyHostToDevice, h->stream));
   }
   return ESVO_OK;
 }
@@ -554,6 +561,7 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
   CK(dalloc(&h->d_counters, 8));
   CK(hipMemset(h->d_counters, 0, sizeof(u32) * 8));
   CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_counters), sizeof(u32) * 8));
+  CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_pin), sizeof(double) * 2 * ((size_t)h->max_poses * 17 + 16)));
   CK(dalloc(&h->d_scan_tmp, scan_scratch_elems(std::max(E, npx)) + 8));
   // fusion window
   h->win_cap = (u32)std::max<int64_t>((int64_t)params->max_window_points, (int64_t)E) + (u32)E;
@@ -618,6 +626,7 @@ int esvo_destroy(esvo_handle h) {
                   h->d_reg_valid, h->d_reg_counts};
   for (void* p : ptrs) if (p) hipFree(p);
   if (h->h_counters) hipHostFree(h->h_counters);
+  if (h->h_pin) hipHostFree(h->h_pin);
   if (h->h_fr_table) hipHostFree(h->h_fr_table);
   if (h->evt_ok) for (int i = 0; i < EV_N; ++i) hipEventDestroy(h->evt[i]);
   if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
@@ -768,8 +777,11 @@ int esvo_map_set_observation(esvo_handle h, uint64_t t_ns, const uint8_t* ts_lef
     if (h->prm.smooth_time_surface) launch_gaussian5(h->d_obs_tmp, h->d_obs[cam], h->W, h->H, h->stream);
   }
   std::memcpy(h->T_world_obs, T_world_cam, sizeof(double) * 16);
-  HIPCHK(hipMemcpyAsync(h->d_T_world_obs, h->T_world_obs, sizeof(double) * 16, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
+  {
+    double* pinT = h->h_pin + (size_t)(h->pin_slot ^ 1) * ((size_t)h->max_poses * 17 + 16) + (size_t)h->max_poses * 17;
+    std::memcpy(pinT, T_world_cam, sizeof(double) * 16);
+    HIPCHK(hipMemcpyAsync(h->d_T_world_obs, pinT, sizeof(double) * 16, hipMemcpyHostToDevice, h->stream));
+  }
   h->obs_t_ns = t_ns;
   h->obs_set = true;
   return ESVO_OK;
@@ -949,20 +961,27 @@ int tick_phase2(esvo_context* h) {
   if (rc) return rc;
   return run_fuse(h);
 }
-// phase 3: regularisation of this band; statistics
+// phase 3: regularisation of this band.  Counters and HIP-event timings of the tick are read back
+// lazily (finalize_tick_stats) so that the tick path ends without a host synchronisation.
 int tick_phase3(esvo_context* h) {
   int rc = run_regularize(h);
   if (rc) return rc;
-  rc = read_counters(h);
+  h->stats.ticks++;
+  h->stats.last_window_frames = (u32)h->frames.size();
+  u32 np = 0;
+  for (auto& f : h->frames) np += f.count;
+  h->stats.last_window_points = np;
+  h->stats_pending = true;
+  return ESVO_OK;
+}
+int finalize_tick_stats(esvo_context* h) {
+  if (!h->stats_pending) return ESVO_OK;
+  h->stats_pending = false;
+  int rc = read_counters(h);
   if (rc) return rc;
   const u32 n = h->sh_n;
   esvo_stats_t& s = h->stats;
-  s.ticks++;
   s.last_fusions = h->h_counters[3];
-  s.last_window_frames = (u32)h->frames.size();
-  u32 np = 0;
-  for (auto& f : h->frames) np += f.count;
-  s.last_window_points = np;
   collect_ts_timing(h);
   s.ms_bm = s.ms_refine = 0;
   s.ms_kernel[2] = s.ms_kernel[3] = 0;
@@ -1063,6 +1082,9 @@ int esvo_map_get_last_frame(esvo_handle h, esvo_depth_point_t* out, size_t cap, 
 
 int esvo_get_stats(esvo_handle h, esvo_stats_t* out) {
   if (!h || !out) return ESVO_ERR_INVALID_ARG;
+  HIPCHK(hipSetDevice(h->device));
+  int rc = finalize_tick_stats(h);
+  if (rc) return rc;
   *out = h->stats;
   return ESVO_OK;
 }
