@@ -68,7 +68,7 @@ def measured_traffic(kernel):
     if not files:
         return None
     sym = {"lm_refine": "lm_refine_kernel", "bm_match": "bm_match_kernel", "fuse": "fuse_cells_kernel",
-           "regularize": "reg_apply_kernel", "ts_render": "ts_decay_kernel", "ts_scatter": "ts_scatter_kernel"}.get(kernel)
+           "regularize": "reg_chain_kernel", "ts_render": "ts_decay_kernel", "ts_scatter": "ts_scatter_kernel"}.get(kernel)
     fetch = write = None
     with open(files[-1]) as f:
         for row in csv.DictReader(f):
