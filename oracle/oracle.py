@@ -17,9 +17,9 @@ def build(fast=False, force=False):
     """Compile the oracle with g++ (oracle/Makefile)."""
     target = "libesvo_oracle_fast.so" if fast else "libesvo_oracle.so"
     path = os.path.join(_HERE, target)
-    src = os.path.join(_HERE, "esvo_oracle.cpp")
-    if force or not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, target], stdout=subprocess.DEVNULL)
+    if force and os.path.exists(path):
+        os.remove(path)
+    subprocess.check_call(["make", "-C", _HERE, target], stdout=subprocess.DEVNULL)  # make tracks the header deps
     return path
 
 
