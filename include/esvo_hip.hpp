@@ -1,0 +1,214 @@
+// esvo_hip.hpp — C++ host layer over the C-ABI (esvo_hip.h), mirroring the reference's own
+// class interface for the hot path so that ESVO's node code (and tests written like it) keeps
+// its shape:
+//
+//   esvo_time_surface::TimeSurface::eventsCallback / createTimeSurfaceAtTime
+//                                     (esvo_time_surface/src/TimeSurface.cpp:403-425, :52-152)
+//   esvo_core::core::EventBM::resetParameters / createMatchProblem / match_all_HyperThread
+//                                     (esvo_core/src/core/EventBM.cpp:34-78, :269-315)
+//   esvo_core::core::DepthProblemSolver::solve / pointCulling
+//                                     (esvo_core/src/core/DepthProblemSolver.cpp:28-78, :216-244)
+//   esvo_core::core::DepthFusion (window push + update loop) / DepthMap::clean /
+//   DepthRegularization::apply        (esvo_core/src/esvo_Mapping.cpp:341-395)
+//
+// Header only, C++14, no ROS / Eigen / OpenCV types: poses are row-major 4x4 doubles, images are
+// mono8 pointers, events are esvo_event_t (layout-identical to dvs_msgs::Event).  Every method
+// throws esvo_hip::Error carrying esvo_last_error() — the reference's failure mode for these calls
+// is exit(-1) or a silent return.  All compute happens in libesvo_hip.so on the GPU.
+#ifndef ESVO_HIP_HPP
+#define ESVO_HIP_HPP
+
+#include <cmath>
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "esvo_hip.h"
+
+namespace esvo_hip {
+
+struct Error : std::runtime_error {
+  int code;
+  Error(int c, const std::string& what) : std::runtime_error(what), code(c) {}
+};
+
+using Event = esvo_event_t;
+using EventMatchPair = esvo_match_t;   // x_left, invDepth, cost, disp, pose index (EventMatchPair.h:16-38)
+using DepthPoint = esvo_depth_point_t; // every field of DepthPoint.h:70-88
+
+// std::map<ros::Time, Transformation> st_map_ (esvo_Mapping.cpp:585-599), flattened
+struct StampTransformationMap {
+  std::vector<uint64_t> stamps_ns;
+  std::vector<double> T_world_virtual;  // 16 per stamp, row-major
+  size_t size() const { return stamps_ns.size(); }
+  void emplace(uint64_t t_ns, const double T[16]) {
+    stamps_ns.push_back(t_ns);
+    T_world_virtual.insert(T_world_virtual.end(), T, T + 16);
+  }
+  void clear() { stamps_ns.clear(); T_world_virtual.clear(); }
+};
+
+// StampedTimeSurfaceObs (TimeSurfaceObservation.h:27-157): mono8 pair + pose.  left/right may be
+// null: the pair rendered last on the device is used.
+struct StampedTimeSurfaceObs {
+  uint64_t t_ns = 0;
+  const uint8_t* TS_left = nullptr;
+  const uint8_t* TS_right = nullptr;
+  double T_world_cam[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+};
+
+// One GPU context shared by the TimeSurface nodes and the mapper (RAII over esvo_handle).
+class Context {
+ public:
+  Context(const esvo_params_t& params, const esvo_calib_t& left, const esvo_calib_t& right, int device = 0)
+      : params_(params), width_(left.width), height_(left.height) {
+    int rc = esvo_create(&params_, &left, &right, device, &h_);
+    if (rc != ESVO_OK) throw Error(rc, std::string("esvo_create: ") + esvo_last_error(nullptr));
+  }
+  ~Context() { if (h_) esvo_destroy(h_); }
+  Context(const Context&) = delete;
+  Context& operator=(const Context&) = delete;
+  esvo_handle handle() const { return h_; }
+  const esvo_params_t& params() const { return params_; }
+  int width() const { return width_; }
+  int height() const { return height_; }
+  void check(int rc, const char* what) const {
+    if (rc != ESVO_OK) throw Error(rc, std::string(what) + ": " + esvo_last_error(h_));
+  }
+  void setParams(const esvo_params_t& p) { check(esvo_set_params(h_, &p), "esvo_set_params"); params_ = p; }
+  void reset() { check(esvo_reset(h_), "esvo_reset"); }  // esvo_Mapping::reset, esvo_Mapping.cpp:764-804
+
+ private:
+  esvo_params_t params_;
+  int width_, height_;
+  esvo_handle h_ = nullptr;
+};
+using ContextPtr = std::shared_ptr<Context>;
+
+// esvo_time_surface::TimeSurface for one camera
+class TimeSurface {
+ public:
+  TimeSurface(ContextPtr ctx, int cam) : ctx_(std::move(ctx)), cam_(cam) {}
+  // TimeSurface::eventsCallback: events of one EventArray message, time sorted
+  void eventsCallback(const Event* events, size_t n) {
+    ctx_->check(esvo_ts_push_events(ctx_->handle(), cam_, events, n), "esvo_ts_push_events");
+  }
+  // TimeSurface::createTimeSurfaceAtTime: the rectified mono8 Time Surface at the sync time
+  void createTimeSurfaceAtTime(uint64_t external_sync_time_ns, uint8_t* out_mono8 /*nullable*/) {
+    ctx_->check(esvo_ts_render(ctx_->handle(), cam_, external_sync_time_ns, out_mono8), "esvo_ts_render");
+  }
+
+ private:
+  ContextPtr ctx_;
+  int cam_;
+};
+
+// esvo_core::core::EventBM
+class EventBM {
+ public:
+  explicit EventBM(ContextPtr ctx) : ctx_(std::move(ctx)) {}
+  void resetParameters(size_t patch_size_X, size_t patch_size_Y, size_t min_disparity, size_t max_disparity, size_t step,
+                       double ZNCC_Threshold, bool bUpDownConfiguration) {
+    esvo_params_t p = ctx_->params();
+    p.patch_size_x = (int32_t)patch_size_X; p.patch_size_y = (int32_t)patch_size_Y;
+    p.bm_min_disparity = (int32_t)min_disparity; p.bm_max_disparity = (int32_t)max_disparity;
+    p.bm_step = (int32_t)step; p.bm_zncc_threshold = ZNCC_Threshold; p.bm_updown = bUpDownConfiguration;
+    ctx_->setParams(p);
+  }
+  void createMatchProblem(const StampedTimeSurfaceObs* pStampedTsObs, const StampTransformationMap* pSt_map,
+                          const std::vector<Event>* pvEvents) {
+    obs_ = pStampedTsObs; st_map_ = pSt_map; events_ = pvEvents;
+    ctx_->check(esvo_map_set_observation(ctx_->handle(), obs_->t_ns, obs_->TS_left, obs_->TS_right, obs_->T_world_cam),
+                "esvo_map_set_observation");
+  }
+  void match_all_HyperThread(std::vector<EventMatchPair>& vEMP) {
+    vEMP.resize(events_->size());
+    size_t n = 0;
+    ctx_->check(esvo_map_match(ctx_->handle(), events_->data(), events_->size(), st_map_->stamps_ns.data(),
+                               st_map_->T_world_virtual.data(), st_map_->size(), vEMP.data(), vEMP.size(), &n),
+                "esvo_map_match");
+    vEMP.resize(n);
+  }
+
+ private:
+  ContextPtr ctx_;
+  const StampedTimeSurfaceObs* obs_ = nullptr;
+  const StampTransformationMap* st_map_ = nullptr;
+  const std::vector<Event>* events_ = nullptr;
+};
+
+// esvo_core::core::DepthProblemSolver (NUMERICAL problem type, Tdist norm)
+class DepthProblemSolver {
+ public:
+  explicit DepthProblemSolver(ContextPtr ctx) : ctx_(std::move(ctx)) {}
+  void solve(const std::vector<EventMatchPair>* pvEMP, const StampedTimeSurfaceObs* /*the observation set by EventBM*/,
+             std::vector<DepthPoint>& vdp) {
+    vdp.resize(pvEMP->size());
+    size_t n = 0;
+    ctx_->check(esvo_map_refine(ctx_->handle(), pvEMP->data(), pvEMP->size(), /*cull*/ 0, vdp.data(), vdp.size(), &n),
+                "esvo_map_refine");
+    vdp.resize(n);
+  }
+  // DepthProblemSolver::pointCulling (DepthProblemSolver.cpp:216-244): a stable host-side filter
+  static void pointCulling(std::vector<DepthPoint>& vdp, double std_variance_threshold, double cost_threshold,
+                           double invDepth_min_range, double invDepth_max_range) {
+    std::vector<DepthPoint> kept;
+    kept.reserve(vdp.size());
+    for (const DepthPoint& d : vdp)
+      if (d.variance <= std::pow(std_variance_threshold, 2) && d.residual <= cost_threshold && d.inv_depth > -1e-6 &&
+          d.inv_depth >= invDepth_min_range && d.inv_depth <= invDepth_max_range)
+        kept.push_back(d);
+    vdp.swap(kept);
+  }
+
+ private:
+  ContextPtr ctx_;
+};
+
+// The fusion stage of MappingAtTime (esvo_Mapping.cpp:341-395): dqvDepthPoints_.push_back(vdp) + window
+// policy, then DepthFusion::update over the window (newest -> oldest) on a fresh DepthFrame,
+// DepthMap::clean and DepthRegularization::apply.
+class DepthFusion {
+ public:
+  explicit DepthFusion(ContextPtr ctx) : ctx_(std::move(ctx)) {}
+  void pushFrame(const std::vector<DepthPoint>& vdp, const StampTransformationMap& st_map) {
+    ctx_->check(esvo_map_push_frame(ctx_->handle(), vdp.data(), vdp.size(), st_map.T_world_virtual.data(), st_map.size()),
+                "esvo_map_push_frame");
+  }
+  // returns numFusionCount
+  size_t update() {
+    size_t n = 0;
+    ctx_->check(esvo_map_fuse(ctx_->handle(), &n), "esvo_map_fuse");
+    return n;
+  }
+  // DepthMap iteration (SmartGrid::begin()/end()) in the reference's list order
+  void getDepthMap(std::vector<DepthPoint>& out) {
+    out.resize((size_t)ctx_->width() * ctx_->height());
+    size_t n = 0;
+    ctx_->check(esvo_map_get_depth_points(ctx_->handle(), out.data(), out.size(), &n), "esvo_map_get_depth_points");
+    out.resize(n);
+  }
+  // publishPointCloud's payload (esvo_Mapping.cpp:925-932): float32 xyz in the world frame
+  void getPointCloud(std::vector<float>& xyz) {
+    xyz.resize((size_t)ctx_->width() * ctx_->height() * 3);
+    size_t n = 0;
+    ctx_->check(esvo_map_get_pointcloud_xyz(ctx_->handle(), xyz.data(), xyz.size() / 3, &n), "esvo_map_get_pointcloud_xyz");
+    xyz.resize(n * 3);
+  }
+
+ private:
+  ContextPtr ctx_;
+};
+
+// esvo_Mapping::MappingAtTime on device-resident events / Time Surfaces (the fused path)
+inline void MappingAtTime(Context& ctx, const StampedTimeSurfaceObs& obs, const StampTransformationMap& st_map) {
+  ctx.check(esvo_map_set_observation(ctx.handle(), obs.t_ns, obs.TS_left, obs.TS_right, obs.T_world_cam),
+            "esvo_map_set_observation");
+  ctx.check(esvo_map_tick(ctx.handle(), obs.t_ns, st_map.stamps_ns.data(), st_map.T_world_virtual.data(), st_map.size()),
+            "esvo_map_tick");
+}
+
+}  // namespace esvo_hip
+#endif  // ESVO_HIP_HPP

@@ -1,0 +1,129 @@
+"""Edge cases of the C-ABI on the GPU: empty inputs, ring wrap-around, reset, run-time parameter
+changes, window eviction (CONST_POINTS), capacity errors."""
+import numpy as np
+import pytest
+
+from esvo_amd import calib, params, rostime, synth
+
+pytestmark = pytest.mark.gpu
+F64 = ["inv_depth", "scale2", "nu", "variance", "residual", "x", "p_cam"]
+
+
+def _same_map(a, b):
+    assert len(a) == len(b), (len(a), len(b))
+    for f in ("row", "col", "age"):
+        assert np.array_equal(a[f], b[f]), f
+    for f in F64:
+        assert np.array_equal(a[f], b[f]), f
+
+
+def _oracle_tick(O, m, ots, rig, stream, p, t):
+    l = ots[0].render(t, map_x=rig.left.map_x, map_y=rig.left.map_y)
+    r = ots[1].render(t, map_x=rig.right.map_x, map_y=rig.right.map_y)
+    stamps, poses = rostime.pose_table(stream.pose, t, p.bm_half_slice_thickness)
+    m.set_observation(t, l, r, stream.pose(t))
+    m.set_poses(stamps, poses)
+    return stamps, poses
+
+
+def test_empty_and_tiny_inputs(upenn_rig, upenn_stream):
+    from esvo_amd import lib
+    p, _ = params.make_params(params.PRESETS["mvstereo_upenn"], upenn_rig)
+    dev = lib.Esvo(p, upenn_rig)
+    t = upenn_stream.t0_ns + 5_000_000
+    dev.ts_push_events(0, upenn_stream.ev_left[:0])          # empty block
+    img = dev.ts_render(0, t)                                 # no events at all -> all-zero TS
+    assert img.shape == (upenn_rig.height, upenn_rig.width) and not img.any()
+    dev.ts_render(1, t, download=False)
+    stamps, poses = rostime.pose_table(upenn_stream.pose, t, p.bm_half_slice_thickness)
+    dev.set_observation(t, None, None, upenn_stream.pose(t))
+    dev.tick(t, stamps, poses)                                # nothing staged: zero events selected
+    s = dev.stats()
+    assert (s.last_events_in, s.last_matches, s.last_points) == (0, 0, 0) and len(dev.get_map()) == 0
+    assert len(dev.get_last_frame()) == 0 and len(dev.get_pointcloud()) == 0
+    assert len(dev.refine(np.zeros(0, dtype=[("x_left", "<f8", (2,)), ("inv_depth", "<f8"), ("cost", "<f8"), ("disp", "<f8"),
+                                             ("event_idx", "<u4"), ("pose_idx", "<u4")]))) == 0
+    with pytest.raises(lib.EsvoError, match="sorted"):
+        dev.ts_push_events(0, upenn_stream.ev_left[:100][::-1])  # unsorted block is rejected (Appendix A-1)
+
+
+def test_ring_wraparound_reset_and_window_eviction(upenn_rig, upenn_stream):
+    """A 16k-event ring wraps many times over 12 ticks; the CONST_POINTS window evicts old frames; after
+    esvo_reset the same stream gives the same maps again.  Everything against the oracle, bit-exact."""
+    from esvo_amd import lib
+    from oracle import oracle as O
+    p, _ = params.make_params(params.PRESETS["mapping_upenn"], upenn_rig, event_ring_capacity=16384,
+                              max_fusion_points=1200)
+    dev = lib.Esvo(p, upenn_rig)
+    maps = []
+    for rep in range(2):
+        m = O.OracleMapper(p, upenn_rig)
+        m.set_mode(True, True)
+        ots = [O.OracleTS(upenn_rig.width, upenn_rig.height), O.OracleTS(upenn_rig.width, upenn_rig.height)]
+        t_prev = upenn_stream.t0_ns
+        evicted = False
+        for k in range(12):
+            t = upenn_stream.t0_ns + int((0.06 + 0.01 * k) * 1e9)
+            for cam in (0, 1):
+                ev = upenn_stream.slice(cam, t_prev, t)
+                for blk in np.array_split(ev, 4):
+                    dev.ts_push_events(cam, blk)
+                    dev.ts_render(cam, int(blk["sec"][-1]) * 10**9 + int(blk["nsec"][-1]) + 1, download=False) if len(blk) else None
+                ots[cam].push(ev)
+            t_prev = t
+            gl, gr = dev.ts_render(0, t), dev.ts_render(1, t)
+            stamps, poses = _oracle_tick(O, m, ots, upenn_rig, upenn_stream, p, t)
+            # the mapper walks back over the last 10 ms of LEFT events: they must still be in the ring
+            idx = O.select_events(upenn_stream.ev_left[upenn_stream.ns_left < t], t, p.bm_half_slice_thickness, p.process_event_num)
+            m.tick(upenn_stream.ev_left[upenn_stream.ns_left < t][idx])
+            dev.set_observation(t, None, None, upenn_stream.pose(t))
+            dev.tick(t, stamps, poses)
+            c = m.counters()
+            s = dev.stats()
+            assert (s.last_window_frames, s.last_window_points) == (c["window_frames"], c["window_points"])
+            evicted |= c["window_frames"] < k + 1
+            _same_map(dev.get_map(), m.get_map())
+        assert evicted and upenn_stream.ns_left.searchsorted(t) > 4 * 16384  # eviction happened, ring wrapped
+        maps.append(dev.get_map())
+        dev.reset()
+    _same_map(maps[0], maps[1])
+
+
+def test_set_params_at_run_time(upenn_rig, upenn_stream):
+    from esvo_amd import lib
+    from oracle import oracle as O
+    p, _ = params.make_params(params.PRESETS["mvstereo_upenn"], upenn_rig)
+    dev = lib.Esvo(p, upenn_rig)
+    t = upenn_stream.t0_ns + int(0.1e9)
+    ots = [O.OracleTS(upenn_rig.width, upenn_rig.height), O.OracleTS(upenn_rig.width, upenn_rig.height)]
+    ots[0].push(upenn_stream.ev_left); ots[1].push(upenn_stream.ev_right)
+    l = ots[0].render(t, map_x=upenn_rig.left.map_x, map_y=upenn_rig.left.map_y)
+    r = ots[1].render(t, map_x=upenn_rig.right.map_x, map_y=upenn_rig.right.map_y)
+    stamps, poses = rostime.pose_table(upenn_stream.pose, t, p.bm_half_slice_thickness)
+    ev = upenn_stream.ev_left[O.select_events(upenn_stream.ev_left, t, p.bm_half_slice_thickness, 1000)]
+    for kw in (dict(bm_zncc_threshold=0.03), dict(bm_min_disparity=5, bm_max_disparity=15), dict(invdepth_min=0.3, stdvar_vis_threshold=0.05)):
+        p2, _ = params.make_params(params.PRESETS["mvstereo_upenn"], upenn_rig, **kw)
+        dev.set_params(p2)                      # EventBM::resetParameters / onlineParameterChangeCallback
+        dev.set_observation(t, l, r, upenn_stream.pose(t))
+        g = dev.refine(dev.match(ev, stamps, poses), cull=True)
+        m = O.OracleMapper(p2, upenn_rig)
+        m.set_mode(True, True)
+        m.set_observation(t, l, r, upenn_stream.pose(t))
+        m.set_poses(stamps, poses)
+        o = m.refine(m.match(ev), cull=True)
+        assert len(g) == len(o) and len(o) > 10 and np.array_equal(g["inv_depth"], o["inv_depth"]), kw
+
+
+def test_capacity_and_state_errors(upenn_rig, upenn_stream):
+    from esvo_amd import lib
+    p, _ = params.make_params(params.PRESETS["mvstereo_upenn"], upenn_rig, event_ring_capacity=4096)
+    dev = lib.Esvo(p, upenn_rig)
+    with pytest.raises(lib.EsvoError, match="ring"):
+        dev.ts_push_events(0, upenn_stream.ev_left[:5000])           # larger than the ring
+    with pytest.raises(lib.EsvoError, match="set_observation"):
+        dev.match(upenn_stream.ev_left[:10], *rostime.pose_table(upenn_stream.pose, upenn_stream.t0_ns, 0.001))
+    with pytest.raises(lib.EsvoError, match="esvo_ts_render"):
+        dev.set_observation(upenn_stream.t0_ns, None, None, np.eye(4))  # no device-resident TS yet
+    with pytest.raises(lib.EsvoError, match="max_events_per_tick"):
+        dev.set_observation(upenn_stream.t0_ns, np.zeros((260, 346), np.uint8), np.zeros((260, 346), np.uint8), np.eye(4))
+        dev.match(upenn_stream.ev_left[:3000], *rostime.pose_table(upenn_stream.pose, upenn_stream.t0_ns, 0.001))
