@@ -511,6 +511,7 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
   }
   h->dp.band_y0 = 0; h->dp.band_y1 = h->H;
   h->dp.cband_y0 = 0; h->dp.cband_y1 = h->H;
+  h->dp.ev_shard = 0; h->dp.ev_nshards = 1;
   fill_dev_params(h);
 
 #define CK(call) do { hipError_t _e = (call); if (_e != hipSuccess) { g_create_error = std::string(#call) + ": " + hipGetErrorString(_e); esvo_destroy(h); return ESVO_ERR_HIP; } } while (0)
@@ -1090,13 +1091,16 @@ int esvo_get_stats(esvo_handle h, esvo_stats_t* out) {
 }
 
 // ---- Multi-GPU row-band sharding ------------------------------------------------------------------
-int esvo_shard_set_band(esvo_handle h, int row_begin, int row_end) {
-  if (!h || row_begin < 0 || row_end > h->H || row_begin >= row_end) return ESVO_ERR_INVALID_ARG;
+int esvo_shard_set_band(esvo_handle h, int row_begin, int row_end, int shard, int n_shards) {
+  if (!h || row_begin < 0 || row_end > h->H || row_begin >= row_end || n_shards < 1 || shard < 0 || shard >= n_shards)
+    return ESVO_ERR_INVALID_ARG;
+  h->dp.ev_shard = shard;
+  h->dp.ev_nshards = n_shards;
   h->dp.band_y0 = row_begin;
   h->dp.band_y1 = row_end;
   h->dp.cband_y0 = std::max(0, row_begin - 2);
   h->dp.cband_y1 = std::min(h->H, row_end + 2);
-  h->sharded = !(row_begin == 0 && row_end == h->H);
+  h->sharded = !(row_begin == 0 && row_end == h->H) || n_shards > 1;
   return ESVO_OK;
 }
 

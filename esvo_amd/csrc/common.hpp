@@ -42,6 +42,8 @@ struct DevParams {
   int reg_radius, reg_min_nb, reg_min_close;
   int num_threads;               // stride-N output permutation
   int band_y0, band_y1;          // row band owned by this handle (0,H when unsharded)
+  int ev_shard, ev_nshards;      // per-event work (BM, LM) of slot w belongs to shard w % ev_nshards (balanced
+                                 // whatever the scene; every rank holds the full Time Surfaces)
   int cband_y0, cband_y1;        // compute band of the fusion stage: the owned band + 2 halo rows, so that
                                  // the 1-row side effects of displaced elements (Appendix A-7) are exact
   CamConst camL, camR;

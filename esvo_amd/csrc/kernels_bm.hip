@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(256) bm_match_kernel(BmArgs a, DevParams p, in
   const int W = p.W, H = p.H;
   constexpr int wx = 15, wy = 7, N = wx * wy, hx = 7, hy = 3;
 
-  bool ok = w < a.n;
+  bool ok = w < a.n && (int)(w % (u32)p.ev_nshards) == p.ev_shard;  // multi-GPU: slots are dealt round-robin
   u32 k = 0;
   uint4 e = make_uint4(0, 0, 0, 0);
   if (ok) {
@@ -91,7 +91,6 @@ __global__ void __launch_bounds__(256) bm_match_kernel(BmArgs a, DevParams p, in
   if (ok) {
     x1 = (int)floor(xr);
     y1 = (int)floor(yr);
-    ok = (y1 >= p.band_y0 && y1 < p.band_y1);  // row-band sharding
   }
   if (ok) ok = !(x1 - hx < 1 || y1 - hy < 1 || x1 + hx >= W - 1 || y1 + hy >= H - 1);  // isValidPatch, :251-267
 

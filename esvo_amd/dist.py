@@ -4,8 +4,8 @@ device buffers the C-ABI exposes (esvo_shard_buffers).  PyTorch is plumbing here
 views + collectives; every kernel is in libesvo_hip.so.
 
 Per tick (see esvo_shard_tick_phase in include/esvo_hip.h):
-    phase 0 (BM of the band's events)      -> all-reduce(SUM) match flags
-    phase 1 (order, LM + cull of the band) -> all-reduce(SUM) point flags + point slots
+    phase 0 (BM of every world-th event)   -> all-reduce(SUM) match flags
+    phase 1 (order, LM + cull of own ones) -> all-reduce(SUM) point flags + point slots
     phase 2 (frame, window, fuse, clean)   -> all-gather of the regulariser view's row bands
     phase 3 (regularise the band)
 Foreign entries of the summed buffers are zero, so SUM on integer views is an exact union.
@@ -76,7 +76,7 @@ class ShardedEsvo:
         self.y0, self.y1 = band_of(rank, world, self.H)
         if self.y1 <= self.y0:
             raise lib.EsvoError(f"rank {rank} of {world} would own no image rows (H={self.H})")
-        self.dev.set_band(self.y0, self.y1)
+        self.dev.set_band(self.y0, self.y1, rank, world)
         b = self.dev.shard_buffers()
         self.t_mflags = device_tensor(b.d_match_flags, b.max_events, "<i4")
         self.t_pflags = device_tensor(b.d_point_flags, b.max_events, "<i4")

@@ -83,7 +83,7 @@ def load():
     lib.esvo_map_get_pointcloud_xyz.argtypes = [vp, vp, sz, psz]
     lib.esvo_map_get_last_frame.argtypes = [vp, vp, sz, psz]
     lib.esvo_get_stats.argtypes = [vp, vp]
-    lib.esvo_shard_set_band.argtypes = [vp, i32, i32]
+    lib.esvo_shard_set_band.argtypes = [vp, i32, i32, i32, i32]
     lib.esvo_shard_buffers.argtypes = [vp, vp]
     lib.esvo_shard_tick_phase.argtypes = [vp, i32, u64, vp, vp, sz]
     for s in SYMBOLS:
@@ -241,8 +241,8 @@ class Esvo:
         self._ck(self.lib.esvo_get_stats(self.h, C.addressof(s)))
         return s
 
-    def set_band(self, y0, y1):
-        self._ck(self.lib.esvo_shard_set_band(self.h, int(y0), int(y1)))
+    def set_band(self, y0, y1, shard=0, n_shards=1):
+        self._ck(self.lib.esvo_shard_set_band(self.h, int(y0), int(y1), int(shard), int(n_shards)))
 
     def shard_buffers(self):
         b = ShardBuffersStruct()

@@ -252,17 +252,18 @@ void esvo_abi_sizes(size_t out[8]);
 
 /* ---- Multi-GPU row-band sharding ----------------------------------- */
 
-/* Restrict this handle's per-event work (match + refine) to events whose rectified row
- * floor(y) lies in [row_begin,row_end) and its per-cell work (fuse/clean/regularise) to the
- * same rows.  (0,H) = unsharded. */
-int esvo_shard_set_band(esvo_handle h, int row_begin, int row_end);
+/* Make this handle shard `shard` of `n_shards`: its per-event work (match + refine) is the slots
+ * w with w % n_shards == shard of the tick's thread-stride order (balanced whatever the scene; every
+ * rank holds the full Time Surfaces), its per-cell work (fuse/clean/regularise) the image rows
+ * [row_begin,row_end).  (0, H, 0, 1) = unsharded. */
+int esvo_shard_set_band(esvo_handle h, int row_begin, int row_end, int shard, int n_shards);
 /* Four-phase tick for sharded operation.  Every rank stages ALL events and renders the full Time
  * Surfaces (replicated, ~1 % of a tick); per-event and per-cell work is split by band.  The caller
  * runs the collectives between phases on the device buffers exposed by esvo_shard_buffers
  * (torch.distributed / RCCL, issued on the handle's stream, see esvo_amd/dist.py):
- *   phase 0: poses + event selection + block matching of the band's events
+ *   phase 0: poses + event selection + block matching of the shard's events
  *            -> all-reduce(SUM) match_flags[0..n)            n = stats.last_events_in
- *   phase 1: global match order + LM refinement + culling of the band's matches
+ *   phase 1: global match order + LM refinement + culling of the shard's matches
  *            -> all-reduce(SUM) point_flags[0..M), point_slots[0..M) (as integers; foreign slots are 0)
  *                                                            M = stats.last_matches
  *   phase 2: frame assembly + window policy (identical on every rank) + fusion + clean of the band,

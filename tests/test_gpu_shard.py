@@ -38,8 +38,8 @@ def test_logical_shards_equal_unsharded(request, preset, rig_fix, stream_fix, n_
     ref = lib.Esvo(p, rig)
     shards = [lib.Esvo(p, rig) for _ in range(G)]
     bands = [edist.band_of(g, G, rig.height) for g in range(G)]
-    for d, (y0, y1) in zip(shards, bands):
-        d.set_band(y0, y1)
+    for g, (d, (y0, y1)) in enumerate(zip(shards, bands)):
+        d.set_band(y0, y1, g, G)
     views = [_views(d) for d in shards]
     W = rig.width
     t_prev = stream.t0_ns
@@ -61,7 +61,7 @@ def test_logical_shards_equal_unsharded(request, preset, rig_fix, stream_fix, n_
         for d in shards:
             d.synchronize()
         tot = sum(v["mflags"][:n] for v in views)
-        assert int(tot.max()) <= 1  # bands are disjoint
+        assert int(tot.max()) <= 1  # the event shards are disjoint
         for v in views:
             v["mflags"][:n] = tot
         torch.cuda.synchronize()
