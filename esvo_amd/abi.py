@@ -70,6 +70,7 @@ class ParamsStruct(C.Structure):
         ("max_fusion_points", C.c_int32),
         ("clean_requires_full_window", C.c_int32),
         ("regularization", C.c_int32),
+        ("denoising", C.c_int32),
         ("process_event_num", C.c_int32),
         ("bm_half_slice_thickness", C.c_double),
         ("num_threads", C.c_int32),

@@ -111,6 +111,8 @@ struct esvo_context {
   u32* d_owner_max = nullptr;
   u32* d_owner_min = nullptr;
   u32* d_bucket = nullptr;
+  u32* d_sel = nullptr;           // denoising: walk positions of the kept events
+  uint8_t* d_evmap = nullptr;     // denoising: binary event map
   u32* d_mflags_local = nullptr;  // sharded mode: this rank's own BM flags (before the all-reduce)
   u32* d_own = nullptr;           // sharded mode: own[j] = 1 if match j belongs to this rank's band
   uint8_t* d_reg_valid = nullptr; // regulariser view: 1 byte per cell (exchanged between ranks)
@@ -244,9 +246,9 @@ int upload_poses(esvo_context* h, const uint64_t* pose_t_ns, const double* pose_
 
 // BM over n events starting at absolute ring index `first` (reverse walk) or over d_tick_ev:
 // flags + match records in slot (thread-stride) order
-int run_bm(esvo_context* h, const esvo_event_t* d_ev, u64 first, u64 cap, int reverse, u32 n) {
+int run_bm(esvo_context* h, const esvo_event_t* d_ev, u64 first, u64 cap, int reverse, u32 n, const u32* sel = nullptr) {
   BmArgs a;
-  a.ev = d_ev; a.n = n; a.ev_first = first; a.ev_cap = cap; a.ev_reverse = reverse;
+  a.ev = d_ev; a.n = n; a.ev_first = first; a.ev_cap = cap; a.ev_reverse = reverse; a.sel = sel;
   a.tsL = h->d_obs[0]; a.tsR = h->d_obs[1];
   a.lut = h->d_lut; a.mask = h->d_mask;
   a.pose_sec = h->d_pose_sec; a.n_pose = h->n_pose;
@@ -588,6 +590,8 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
   CK(dalloc(&h->d_owner_min, npx));
   CK(dalloc(&h->d_bucket, 3 * 128));
   CK(dalloc(&h->d_mflags_local, E));
+  CK(dalloc(&h->d_sel, E));
+  CK(dalloc(&h->d_evmap, npx + 64));
   CK(dalloc(&h->d_own, E));
   CK(dalloc(&h->d_reg_valid, npx + 64));
   CK(hipMemset(h->d_reg_valid, 0, npx + 64));
@@ -624,7 +628,7 @@ int esvo_destroy(esvo_handle h) {
                   h->d_win, h->d_frame_pose_T, h->d_fr_table, h->d_prop, h->d_cell_count, h->d_cell_offset,
                   h->d_cell_fill, h->d_rec_ids, h->d_map, h->d_map2, h->d_owner_max, h->d_owner_min, h->d_exp_flags,
                   h->d_exp_prefix, h->d_export, h->d_export_cell, h->d_reg_bits, h->d_reg_ab, h->d_reg_cd, h->d_bucket, h->d_cell_list, h->d_mflags_local, h->d_own,
-                  h->d_reg_valid, h->d_reg_counts};
+                  h->d_reg_valid, h->d_reg_counts, h->d_sel, h->d_evmap};
   for (void* p : ptrs) if (p) hipFree(p);
   if (h->h_counters) hipHostFree(h->h_counters);
   if (h->h_pin) hipHostFree(h->h_pin);
@@ -916,11 +920,23 @@ int tick_phase0(esvo_context* h, uint64_t t_ns, const uint64_t* pose_t_ns, const
   if (rc) return rc;
   rc = select_events(h, t_ns, &h->sh_first, &h->sh_n);
   if (rc) return rc;
-  const u32 n = h->sh_n;
+  u32 n = h->sh_n;
   hipEventRecord(h->evt[EV_T0], h->stream);
   HIPCHK(hipMemsetAsync(h->d_counters, 0, sizeof(u32) * 8, h->stream));
+  const u32* sel = nullptr;
+  if (h->prm.denoising && n) {
+    // Denoising (esvo_Mapping.cpp:282-296): mask from the selected events, keep those on it, in order.
+    // One extra read-back (the kept count sizes the BM launch); only the small DAVIS configs use it.
+    launch_denoise_flags(h->d_ring[0], h->sh_first, h->ring_cap, n, h->d_evmap, h->d_match_flags, h->W, h->H, h->stream);
+    launch_exclusive_scan_u32(h->d_match_flags, h->d_match_prefix, h->d_counters + 5, h->d_scan_tmp, n, h->stream);
+    launch_denoise_select(h->d_match_flags, h->d_match_prefix, n, h->d_sel, h->stream);
+    rc = read_counters(h);
+    if (rc) return rc;
+    n = h->sh_n = h->h_counters[5];
+    sel = h->d_sel;
+  }
   if (n) {
-    rc = run_bm(h, h->d_ring[0], h->sh_first, h->ring_cap, 1, n);
+    rc = run_bm(h, h->d_ring[0], h->sh_first, h->ring_cap, 1, n, sel);
     if (rc) return rc;
     if (h->sharded)
       HIPCHK(hipMemcpyAsync(h->d_mflags_local, h->d_match_flags, sizeof(u32) * n, hipMemcpyDeviceToDevice, h->stream));

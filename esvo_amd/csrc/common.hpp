@@ -144,6 +144,10 @@ void launch_ts_scatter(const esvo_event_t* d_ev, size_t n, u64* d_sae, int W, in
 void launch_ts_render(const u64* d_sae, const int2* d_fixmap, uint8_t* d_raw, uint8_t* d_out, int W, int H,
                       u64 t_ns, double decay_sec, int ignore_polarity, int median_k, hipStream_t s);
 void launch_gaussian5(const uint8_t* d_in, uint8_t* d_out, int W, int H, hipStream_t s);
+// createDenoisingMask + extractDenoisedEvents (esvo_Mapping.cpp:1046-1072) on the n selected events
+void launch_denoise_flags(const esvo_event_t* ring, u64 first, u64 cap, u32 n, uint8_t* evmap, u32* flags, int W, int H,
+                          hipStream_t s);
+void launch_denoise_select(const u32* flags, const u32* prefix, u32 n, u32* sel, hipStream_t s);
 
 // kernels_bm.hip
 struct BmArgs {
@@ -152,6 +156,7 @@ struct BmArgs {
   u64 ev_first;             // absolute index of tick event 0
   u64 ev_cap;               // ring capacity (slot = absolute index % ev_cap)
   int ev_reverse;           // 1: newest-first walk (dataTransferring): event k = ev_first - k; 0: ev_first + k
+  const u32* sel;           // optional indirection (denoised events): tick event k is walk position sel[k]
   const uint8_t* tsL;
   const uint8_t* tsR;
   const float2* lut;

@@ -74,7 +74,8 @@ __global__ void __launch_bounds__(256) bm_match_kernel(BmArgs a, DevParams p, in
   uint4 e = make_uint4(0, 0, 0, 0);
   if (ok) {
     k = stride_item(w, a.n, (u32)p.num_threads);
-    const u64 ei = (a.ev_reverse ? (a.ev_first - k) : (a.ev_first + k)) % a.ev_cap;
+    const u32 kk = a.sel ? a.sel[k] : k;
+    const u64 ei = (a.ev_reverse ? (a.ev_first - kk) : (a.ev_first + kk)) % a.ev_cap;
     e = reinterpret_cast<const uint4*>(a.ev)[ei];
   }
   const int ex = e.x & 0xffffu, ey = e.x >> 16;

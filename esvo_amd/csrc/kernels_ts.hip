@@ -146,4 +146,56 @@ void launch_gaussian5(const uint8_t* d_in, uint8_t* d_out, int W, int H, hipStre
   hipLaunchKernelGGL(gaussian5_kernel, dim3((W + 63) / 64, (H + 3) / 4), dim3(256), 0, s, d_in, d_out, W, H);
 }
 
+
+// ---- event denoising (Denoising: True; rpg / hkust configs) ----------------------------------------
+// createDenoisingMask (esvo_Mapping.cpp:1046-1054, Visualization.cpp:96-104): binary event map of the
+// selected events (indexed by the RAW pixel, Appendix A-15) -> medianBlur(3); extractDenoisedEvents
+// (:1056-1072) keeps the events whose pixel is 255 in the mask, in order.  The 3x3 median of a 0/255
+// image with BORDER_REPLICATE is 255 iff at least 5 of the 9 (replicated) taps are set.
+__global__ void __launch_bounds__(256) denoise_mark_kernel(const uint4* __restrict__ ring, u64 first, u64 cap, u32 n,
+                                                           uint8_t* __restrict__ evmap, int W, int H) {
+  const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const uint4 e = ring[(first - k) % cap];
+  const u32 x = e.x & 0xffffu, y = e.x >> 16;
+  if (x < (u32)W && y < (u32)H) evmap[y * W + x] = 255;
+}
+__global__ void __launch_bounds__(256) denoise_flag_kernel(const uint4* __restrict__ ring, u64 first, u64 cap, u32 n,
+                                                           const uint8_t* __restrict__ evmap, u32* __restrict__ flags, int W, int H) {
+  const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const uint4 e = ring[(first - k) % cap];
+  const int x = e.x & 0xffffu, y = e.x >> 16;
+  u32 keep = 0;
+  if (x < W && y < H) {
+    int cnt = 0;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int yy = min(max(y + dy, 0), H - 1), xx = min(max(x + dx, 0), W - 1);
+        cnt += evmap[yy * W + xx] != 0;
+      }
+    keep = cnt >= 5;
+  }
+  flags[k] = keep;
+}
+__global__ void __launch_bounds__(256) denoise_select_kernel(const u32* __restrict__ flags, const u32* __restrict__ prefix, u32 n,
+                                                             u32* __restrict__ sel) {
+  const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n && flags[k]) sel[prefix[k]] = k;
+}
+void launch_denoise_flags(const esvo_event_t* ring, u64 first, u64 cap, u32 n, uint8_t* evmap, u32* flags, int W, int H,
+                          hipStream_t s) {
+  hipMemsetAsync(evmap, 0, (size_t)W * H, s);
+  if (n == 0) return;
+  const uint4* r = reinterpret_cast<const uint4*>(ring);
+  hipLaunchKernelGGL(denoise_mark_kernel, dim3((n + 255) / 256), dim3(256), 0, s, r, first, cap, n, evmap, W, H);
+  hipLaunchKernelGGL(denoise_flag_kernel, dim3((n + 255) / 256), dim3(256), 0, s, r, first, cap, n, evmap, flags, W, H);
+}
+void launch_denoise_select(const u32* flags, const u32* prefix, u32 n, u32* sel, hipStream_t s) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(denoise_select_kernel, dim3((n + 255) / 256), dim3(256), 0, s, flags, prefix, n, sel);
+}
+
 }  // namespace esvo

@@ -113,6 +113,7 @@ def make_params(cfg, rig, node=None, throughput_events=None, **overrides):
     p.max_fusion_points = int(c["maxNumFusionPoints"])
     p.clean_requires_full_window = 1 if node == "mapping" else 0
     p.regularization = int(bool(c["Regularization"]))
+    p.denoising = int(bool(c["Denoising"]))
     p.process_event_num = int(throughput_events if throughput_events else c["PROCESS_EVENT_NUM"])
     p.bm_half_slice_thickness = float(c["BM_half_slice_thickness"])
     p.num_threads = 4  # NUM_THREAD_MAPPING, esvo_core/include/esvo_core/tools/utils.h:36

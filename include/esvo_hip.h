@@ -110,6 +110,8 @@ typedef struct esvo_params_t {
   int32_t max_fusion_points;
   int32_t clean_requires_full_window; /* 1: esvo_Mapping.cpp:385; 0: esvo_MVStereo.cpp:496 */
   int32_t regularization;          /* Regularization */
+  int32_t denoising;               /* Denoising: event-map median mask on the selected events
+                                      (esvo_Mapping.cpp:282-296,1046-1072); applied by esvo_map_tick */
   int32_t process_event_num;       /* PROCESS_EVENT_NUM (events block-matched per tick) */
   double bm_half_slice_thickness;  /* 0.001 s; event window = 10x (esvo_Mapping.cpp:563) */
   int32_t num_threads;             /* NUM_THREAD_MAPPING (4): reproduces the stride-N output

@@ -18,6 +18,7 @@
 #ifndef ESVO_HIP_HPP
 #define ESVO_HIP_HPP
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <memory>
@@ -201,6 +202,28 @@ class DepthFusion {
  private:
   ContextPtr ctx_;
 };
+
+// esvo_Mapping::createDenoisingMask + extractDenoisedEvents (esvo_Mapping.cpp:1046-1072) for the stage-wise
+// path (esvo_map_tick applies them itself when params.denoising is set): binary map of the selected events
+// at their RAW pixels -> 3x3 median (BORDER_REPLICATE) -> keep the events whose pixel is 255, in order.
+inline void extractDenoisedEvents(const std::vector<Event>& vCloseEvents, std::vector<Event>& vEdgeEvents, int width, int height,
+                                  size_t maxNum) {
+  std::vector<uint8_t> map((size_t)width * height, 0);
+  for (const Event& e : vCloseEvents)
+    if (e.x < width && e.y < height) map[(size_t)e.y * width + e.x] = 1;
+  vEdgeEvents.clear();
+  for (const Event& e : vCloseEvents) {
+    if (vEdgeEvents.size() >= maxNum) break;
+    if (e.x >= width || e.y >= height) continue;
+    int cnt = 0;
+    for (int dy = -1; dy <= 1; ++dy)
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int yy = std::min(std::max((int)e.y + dy, 0), height - 1), xx = std::min(std::max((int)e.x + dx, 0), width - 1);
+        cnt += map[(size_t)yy * width + xx];
+      }
+    if (cnt >= 5) vEdgeEvents.push_back(e);
+  }
+}
 
 // esvo_Mapping::MappingAtTime on device-resident events / Time Surfaces (the fused path)
 inline void MappingAtTime(Context& ctx, const StampedTimeSurfaceObs& obs, const StampTransformationMap& st_map) {
