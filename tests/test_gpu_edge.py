@@ -129,37 +129,40 @@ def test_capacity_and_state_errors(upenn_rig, upenn_stream):
         dev.match(upenn_stream.ev_left[:3000], *rostime.pose_table(upenn_stream.pose, upenn_stream.t0_ns, 0.001))
 
 
-def test_denoising_in_the_fused_tick(upenn_rig, upenn_stream):
+def test_denoising_in_the_fused_tick():
     """Denoising: True (rpg / hkust configs): event-map median mask on the selected events
-    (esvo_Mapping.cpp:282-296,1046-1072) inside esvo_map_tick, against oracle select -> denoise -> tick."""
+    (esvo_Mapping.cpp:282-296,1046-1072) inside esvo_map_tick, against oracle select -> denoise -> tick.
+    A small, densely firing sensor so that the 3x3 median keeps a real fraction of the events."""
     from esvo_amd import lib
     from oracle import oracle as O
-    p, den = params.make_params(params.PRESETS["mvstereo_rpg"], upenn_rig)
+    rig = calib.ideal_rig(240, 180, 156.925, 0.14805)          # rpg geometry (SURVEY §8)
+    stream = synth.make_stream(rig, 30000, 0.16, 0.2, 2.0, seed=77, speed=1.5)
+    p, den = params.make_params(params.PRESETS["mvstereo_rpg"], rig, process_event_num=12000)
     assert den and p.denoising == 1
-    dev = lib.Esvo(p, upenn_rig)
-    m = O.OracleMapper(p, upenn_rig)
+    dev = lib.Esvo(p, rig)
+    m = O.OracleMapper(p, rig)
     m.set_mode(True, True)
-    ots = [O.OracleTS(upenn_rig.width, upenn_rig.height), O.OracleTS(upenn_rig.width, upenn_rig.height)]
-    t_prev = upenn_stream.t0_ns
+    ots = [O.OracleTS(rig.width, rig.height), O.OracleTS(rig.width, rig.height)]
+    t_prev = stream.t0_ns
     kept = []
-    for k in range(5):
-        t = upenn_stream.t0_ns + int((0.07 + 0.02 * k) * 1e9)
+    for k in range(4):
+        t = stream.t0_ns + int((0.07 + 0.02 * k) * 1e9)
         for cam in (0, 1):
-            ev = upenn_stream.slice(cam, t_prev, t + 2_000_000)
+            ev = stream.slice(cam, t_prev, t + 2_000_000)
             dev.ts_push_events(cam, ev)
             ots[cam].push(ev)
         t_prev = t + 2_000_000
         dev.ts_render(0, t, download=False); dev.ts_render(1, t, download=False)
-        stamps, poses = _oracle_tick(O, m, ots, upenn_rig, upenn_stream, p, t)
-        staged = upenn_stream.ev_left[upenn_stream.ns_left < t_prev]
+        stamps, poses = _oracle_tick(O, m, ots, rig, stream, p, t)
+        staged = stream.ev_left[stream.ns_left < t_prev]
         idx = O.select_events(staged, t, p.bm_half_slice_thickness, p.process_event_num)
-        didx = O.denoise_events(staged, idx, upenn_rig.width, upenn_rig.height, p.process_event_num)
+        didx = O.denoise_events(staged, idx, rig.width, rig.height, p.process_event_num)
         kept.append((len(idx), len(didx)))
         m.tick(staged[didx])
-        dev.set_observation(t, None, None, upenn_stream.pose(t))
+        dev.set_observation(t, None, None, stream.pose(t))
         dev.tick(t, stamps, poses)
         assert dev.stats().last_events_in == len(didx)
         g, o = dev.get_last_frame(), m.get_last_frame()
         assert len(g) == len(o) and np.array_equal(g["inv_depth"], o["inv_depth"])
         _same_map(dev.get_map(), m.get_map())
-    assert all(0 < d < n for n, d in kept), kept  # the mask really removes events
+    assert all(0.02 * n < d < n for n, d in kept), kept  # the mask keeps some events and removes others
