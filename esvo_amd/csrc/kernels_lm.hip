@@ -26,6 +26,13 @@
 
 namespace esvo {
 
+#ifdef LM_STATS
+__device__ unsigned long long g_lm_dbg[8];
+#define LM_COUNT(i, cond) do { if (cond) atomicAdd(&g_lm_dbg[i], 1ull); } while (0)
+#else
+#define LM_COUNT(i, cond) do {} while (0)
+#endif
+
 #define LM_ROWS 7
 #define LM_COLS 15
 
@@ -127,6 +134,8 @@ __device__ inline void interp_column(const uint8_t* __restrict__ img, int W, int
 // DepthProblem::operator(), Tdist norm.  fv[y] = residual of patch element (y, c); lane 15 -> 0.
 __device__ void lm_eval(const DevParams& p, const LmProblem& pr, double x, double fv[LM_ROWS]) {
   const double nu = p.td_nu;
+  LM_COUNT(0, pr.c == 0);                                   // evaluations, per group
+  LM_COUNT(1, __lane_id() == __ffsll(__ballot(1)) - 1);     // evaluations, per wave
   double prv[3], pl[3];
   cam2World(p.camL, pr.cx, pr.cy, x, prv);
 #pragma unroll
@@ -158,19 +167,22 @@ __device__ void lm_eval(const DevParams& p, const LmProblem& pr, double x, doubl
   interp_column(pr.tsL, p.W, ulx1, uly1, pr.c, a1, a2, a3, a4, tau1);
   interp_column(pr.tsR, p.W, ulx2, uly2, pr.c, b1, b2, b3, b4, tau2);
   int knz = 0;
-  double minabs = 1e300;
+  double minabs = 1e300, r2max = 0;
   bool r2_ok = true;  // every r^2 is 0 or of moderate magnitude: shared-divisor quotients allowed
 #pragma unroll
   for (int y = 0; y < LM_ROWS; ++y) {
     r[y] = (pr.c < LM_COLS) ? (tau1[y] - tau2[y]) : 0.0;
     r2[y] = r[y] * r[y];
     r2_ok = r2_ok && fdiv_ok(r2[y]);
+    r2max = fmax(r2max, r2[y]);
     if (r[y] != 0) { knz++; minabs = fmin(minabs, fabs(r[y])); }
   }
   knz = grp_sum_int(knz);
   minabs = grp_min(minabs);
   const double scale2_0 = p.td_scale2;
   double s2;
+  const bool lane_ok = r2_ok && fdiv_ok(nu) && nu > 0 && fdiv_ok(r2max * (nu + 1));
+  const int e_r2max = (__double2hiint(r2max) >> 20) & 0x7ff;
   const int N = LM_ROWS * LM_COLS;
 #ifdef LM_EXPERIMENT_NOLOOP
   if (true) {
@@ -178,40 +190,48 @@ __device__ void lm_eval(const DevParams& p, const LmProblem& pr, double x, doubl
   if ((double)knz * (nu + 1) / (double)N <= 0.94 && minabs >= 1e-6) {
 #endif
     s2 = scale2_0;  // provable outcome of the uncapped loop (header comment)
+    LM_COUNT(4, pr.c == 0);
   } else {
+    // DepthProblem.cpp:96-124: s1 <- s2 until |s2 - s1| / s1 <= 5 %.  Every quotient below is the IEEE quotient
+    // (fdiv.hpp): r^2 / s1 and the convergence test share the divisor s1, sum / N has a constant divisor, and
+    // the weights' own divisors nu + r^2/s1 lie in [nu, 2^333) by the exponent test on the lane's largest r^2.
     double s1 = scale2_0;
-    s2 = -1.0;
-    bool first = true;
-    while (fabs(s2 - s1) / s1 > 0.05 || first) {  // DepthProblem.cpp:96
-      if (!first) s1 = s2;
+    const Recip rN = make_recip((double)N);
+    while (true) {
+      LM_COUNT(2, pr.c == 0);                                 // t-scale iterations, per group
+      LM_COUNT(3, __lane_id() == __ffsll(__ballot(1)) - 1);   // t-scale iterations, per wave
       double t[LM_ROWS];
-      const Recip rs1 = make_recip(s1);  // the 7 residuals of this lane share the divisor s1 (fdiv.hpp)
+      const Recip rs1 = make_recip(s1);
+      const int e_s1 = (__double2hiint(s1) >> 20) & 0x7ff;
 #ifdef LM_PLAIN_DIV
       if (false) {
 #else
-      if (r2_ok && rs1.fast) {
+      if (lane_ok && rs1.fast && s1 > 0 && e_r2max - e_s1 < 300) {
 #endif
 #pragma unroll
-        for (int y = 0; y < LM_ROWS; ++y) t[y] = (r[y] != 0) ? r2[y] * (nu + 1) / (nu + div_fast(r2[y], rs1)) : 0.0;
+        for (int y = 0; y < LM_ROWS; ++y)  // r == 0 gives +0 / nu = +0 as the reference's skip does
+          t[y] = div_fast(r2[y] * (nu + 1), make_recip(nu + div_fast(r2[y], rs1)));
       } else {
 #pragma unroll
         for (int y = 0; y < LM_ROWS; ++y) t[y] = (r[y] != 0) ? r2[y] * (nu + 1) / (nu + r2[y] / s1) : 0.0;
       }
       const double sum = grp_sum(col_sum(t));
       if (sum == 0) { s2 = scale2_0; break; }
-      s2 = sum / (double)N;
-      first = false;
+      s2 = div_by(sum, rN);
+      const double rel = div_by(fabs(s2 - s1), rs1);
+      if (!(rel > 0.05)) break;
+      s1 = s2;
     }
   }
   const Recip rs2 = make_recip(s2);
 #ifdef LM_PLAIN_DIV
   const bool fast2 = false;
 #else
-  const bool fast2 = r2_ok && rs2.fast;
+  const bool fast2 = lane_ok && rs2.fast && s2 > 0 && e_r2max - ((__double2hiint(s2) >> 20) & 0x7ff) < 300;
 #endif
 #pragma unroll
   for (int y = 0; y < LM_ROWS; ++y) {
-    const double weight = (nu + 1) / (nu + (fast2 ? div_fast(r2[y], rs2) : r2[y] / s2));
+    const double weight = fast2 ? div_fast(nu + 1, make_recip(nu + div_fast(r2[y], rs2))) : (nu + 1) / (nu + r2[y] / s2);
     fv[y] = sqrt(weight) * r[y];
   }
 }
@@ -266,8 +286,10 @@ __global__ void __launch_bounds__(256, 3) lm_refine_kernel(LmArgs a, DevParams p
   u32 M = *a.n_matches;
   if (M > a.max_matches) M = a.max_matches;
   bool active = s < M;
-  // inactive groups still run the (cheap, failing) code path below with a dummy problem so that
-  // the wave's shuffles stay convergent; they write nothing.
+  // The grid is sized for the worst case (every event matched): waves without any match leave at once.
+  // Inactive groups of a partially filled wave run the (cheap, failing) code path below with a dummy
+  // problem so that the wave's control flow stays simple; they write nothing.
+  if (__ballot(active) == 0) return;
   u32 j = 0;
   esvo_match_t m;
   m.x_left[0] = m.x_left[1] = -1e9; m.inv_depth = 1.0; m.pose_idx = 0; m.cost = 0; m.disp = 0; m.event_idx = 0;
@@ -447,6 +469,9 @@ __global__ void __launch_bounds__(256, 3) lm_refine_kernel(LmArgs a, DevParams p
   a.out_flags[s] = keep ? 1u : 0u;
 }
 
+#ifdef LM_STATS
+extern "C" void esvo_debug_lm_counters(unsigned long long out[8]) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lm_dbg), 64); }
+#endif
 void launch_lm_refine(const LmArgs& a, const DevParams& p, u32* n_solved, hipStream_t s) {
   if (a.max_matches == 0) return;
   const u32 groups_per_block = 256 / 16;
