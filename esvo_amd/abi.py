@@ -102,14 +102,6 @@ class StatsStruct(C.Structure):
     ]
 
 
-class ShardBuffersStruct(C.Structure):
-    _fields_ = [
-        ("d_match_flags", C.c_void_p), ("d_point_flags", C.c_void_p), ("d_point_slots", C.c_void_p),
-        ("d_reg_valid", C.c_void_p), ("d_reg_ab", C.c_void_p), ("d_reg_cd", C.c_void_p),
-        ("max_events", C.c_size_t), ("n_cells", C.c_size_t),
-    ]
-
-
 def make_events(x, y, t_ns, polarity=None):
     """Build an esvo_event_t array from coordinate / nanosecond-timestamp arrays."""
     t_ns = np.asarray(t_ns, dtype=np.uint64)

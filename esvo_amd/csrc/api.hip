@@ -84,6 +84,7 @@ struct esvo_context {
   u32* d_pt_prefix = nullptr;
   DevPoint* d_pts_tmp = nullptr;  // stage-wise refine output
   u32* d_counters = nullptr;      // [0] n_matches [1] n_points [2] n_solved [3] n_fusion [4] n_records [5] n_map
+                                  // [6] touched cells [7] regulariser elements [8] own matches (sharded)
   u32* h_counters = nullptr;      // pinned
   u32* d_scan_tmp = nullptr;
 
@@ -113,12 +114,17 @@ struct esvo_context {
   u32* d_bucket = nullptr;
   u32* d_sel = nullptr;           // denoising: walk positions of the kept events
   uint8_t* d_evmap = nullptr;     // denoising: binary event map
-  u32* d_mflags_local = nullptr;  // sharded mode: this rank's own BM flags (before the all-reduce)
-  u32* d_own = nullptr;           // sharded mode: own[j] = 1 if match j belongs to this rank's band
-  uint8_t* d_reg_valid = nullptr; // regulariser view: 1 byte per cell (exchanged between ranks)
+  // sharded mode (kernels_shard.hip): dense local lists + the (matched, kept) byte per slot that is exchanged
+  u32* d_own_w = nullptr;         // slot w of the k-th own match
+  u32* d_lkeep = nullptr;         // keep flag of the k-th own match after LM + culling
+  uint8_t* d_codes = nullptr;     // [codes_bytes] one byte per slot, zero for other ranks' slots
+  size_t codes_bytes = 0;
+  void* xchg_ptr = nullptr;       // what the caller must sum across the ranks before the next phase
+  size_t xchg_bytes = 0;
+  uint8_t* d_reg_valid = nullptr; // regulariser view: 1 byte per cell
   bool sharded = false;
   u32 reg_words = 0;
-  u32 sh_n = 0, sh_off = 0;       // state carried between the phases of a sharded tick
+  u32 sh_n = 0, sh_off = 0, sh_points = 0;  // state carried between the phases of a tick
   u64 sh_first = 0;
   u32* d_cell_list = nullptr;
   u64* d_reg_bits = nullptr;    // close-neighbour masks of the regulariser scan: [elements][words]
@@ -226,6 +232,14 @@ u64 ros_time_from_sec(double t) {
   return (u64)sec * 1000000000ull + nsec;
 }
 
+// compute band of the per-cell stages: the owned rows + a halo of 2 rows for the displaced-element side
+// effects (+ the regulariser's radius), see DevParams::cband_y0
+void set_compute_band(esvo_context* h) {
+  const int halo = 2 + (h->prm.regularization ? h->prm.reg_radius : 0);
+  h->dp.cband_y0 = std::max(0, h->dp.band_y0 - halo);
+  h->dp.cband_y1 = std::min(h->H, h->dp.band_y1 + halo);
+}
+
 int upload_poses(esvo_context* h, const uint64_t* pose_t_ns, const double* pose_T, size_t m) {
   if (m > h->max_poses) FAIL(ESVO_ERR_CAPACITY, "pose table larger than max_poses_per_tick");
   // staged through pinned memory (two alternating slots): no host synchronisation on the tick path
@@ -259,13 +273,12 @@ int run_bm(esvo_context* h, const esvo_event_t* d_ev, u64 first, u64 cap, int re
   HIPCHK(hipGetLastError());
   return ESVO_OK;
 }
-// stable compaction of the match slots into vEMP order.  `local_flags` (sharded mode): the slots
-// this rank produced itself; d_match_flags then holds the all-reduced (global) flags.
-int run_order_matches(esvo_context* h, u32 n, const u32* local_flags) {
-  launch_exclusive_scan_u32(h->d_match_flags, h->d_match_prefix, h->d_counters + 0, h->d_scan_tmp, n, h->stream);
-  if (local_flags) HIPCHK(hipMemsetAsync(h->d_own, 0, sizeof(u32) * (n ? n : 1), h->stream));
-  launch_compact_matches(h->d_match_slots, local_flags ? local_flags : h->d_match_flags, h->d_match_prefix, n, h->d_matches,
-                         local_flags ? h->d_own : nullptr, h->stream);
+// stable compaction of the match slots into vEMP order.  Sharded mode: the flags are this rank's own
+// ones, the list is its dense local list (count -> counters[8]) and slot_of remembers each entry's slot.
+int run_order_matches(esvo_context* h, u32 n, bool local) {
+  launch_exclusive_scan_u32(h->d_match_flags, h->d_match_prefix, h->d_counters + (local ? 8 : 0), h->d_scan_tmp, n, h->stream);
+  launch_compact_matches(h->d_match_slots, h->d_match_flags, h->d_match_prefix, n, h->d_matches, local ? h->d_own_w : nullptr,
+                         h->stream);
   hipEventRecord(h->evt[EV_S1], h->stream);
   HIPCHK(hipGetLastError());
   return ESVO_OK;
@@ -273,19 +286,19 @@ int run_order_matches(esvo_context* h, u32 n, const u32* local_flags) {
 int run_match(esvo_context* h, const esvo_event_t* d_ev, u64 first, u64 cap, int reverse, u32 n) {
   int rc = run_bm(h, d_ev, first, cap, reverse, n);
   if (rc) return rc;
-  return run_order_matches(h, n, nullptr);
+  return run_order_matches(h, n, false);
 }
 
-// LM (+cull) over the compacted matches: point records + flags in solver-slot order
-int run_lm(esvo_context* h, u32 max_matches, int cull, const u32* own) {
-  HIPCHK(hipMemsetAsync(h->d_pt_flags, 0, sizeof(u32) * (max_matches ? max_matches : 1), h->stream));
-  if (own) HIPCHK(hipMemsetAsync(h->d_pt_slots, 0, sizeof(DevPoint) * (max_matches ? max_matches : 1), h->stream));
+// LM (+cull) over the compacted matches: point records + flags in solver-slot order (dense: in list order)
+int run_lm(esvo_context* h, u32 max_matches, int cull, bool dense) {
+  u32* flags = dense ? h->d_lkeep : h->d_pt_flags;
+  HIPCHK(hipMemsetAsync(flags, 0, sizeof(u32) * (max_matches ? max_matches : 1), h->stream));
   HIPCHK(hipMemsetAsync(h->d_counters + 2, 0, sizeof(u32), h->stream));
   LmArgs a;
-  a.matches = h->d_matches; a.n_matches = h->d_counters + 0; a.max_matches = max_matches;
+  a.matches = h->d_matches; a.n_matches = h->d_counters + (dense ? 8 : 0); a.max_matches = max_matches;
   a.tsL = h->d_obs[0]; a.tsR = h->d_obs[1];
   a.pose_T = h->d_pose_T; a.T_world_obs = h->d_T_world_obs;
-  a.out_slots = h->d_pt_slots; a.out_flags = h->d_pt_flags; a.cull = cull; a.own = own;
+  a.out_slots = h->d_pt_slots; a.out_flags = flags; a.cull = cull; a.dense = dense ? 1 : 0;
   hipEventRecord(h->evt[EV_LM0], h->stream);
   launch_lm_refine(a, h->dp, h->d_counters + 2, h->stream);
   hipEventRecord(h->evt[EV_LM1], h->stream);
@@ -301,7 +314,7 @@ int run_order_points(esvo_context* h, u32 max_matches, DevPoint* dst) {
   return ESVO_OK;
 }
 int run_refine(esvo_context* h, u32 max_matches, int cull, DevPoint* dst) {
-  int rc = run_lm(h, max_matches, cull, nullptr);
+  int rc = run_lm(h, max_matches, cull, false);
   if (rc) return rc;
   return run_order_points(h, max_matches, dst);
 }
@@ -317,7 +330,7 @@ void collect_ts_timing(esvo_context* h) {
 }
 
 int read_counters(esvo_context* h) {
-  HIPCHK(hipMemcpyAsync(h->h_counters, h->d_counters, sizeof(u32) * 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(h->h_counters, h->d_counters, sizeof(u32) * 16, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   return ESVO_OK;
 }
@@ -561,9 +574,9 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
   CK(dalloc(&h->d_pt_flags, E));
   CK(dalloc(&h->d_pt_prefix, E));
   CK(dalloc(&h->d_pts_tmp, E));
-  CK(dalloc(&h->d_counters, 8));
-  CK(hipMemset(h->d_counters, 0, sizeof(u32) * 8));
-  CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_counters), sizeof(u32) * 8));
+  CK(dalloc(&h->d_counters, 16));
+  CK(hipMemset(h->d_counters, 0, sizeof(u32) * 16));
+  CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_counters), sizeof(u32) * 16));
   CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_pin), sizeof(double) * 2 * ((size_t)h->max_poses * 17 + 16)));
   CK(dalloc(&h->d_scan_tmp, scan_scratch_elems(std::max(E, npx)) + 8));
   // fusion window
@@ -589,10 +602,12 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
   CK(dalloc(&h->d_owner_max, npx));
   CK(dalloc(&h->d_owner_min, npx));
   CK(dalloc(&h->d_bucket, 3 * 128));
-  CK(dalloc(&h->d_mflags_local, E));
+  CK(dalloc(&h->d_own_w, E));
+  CK(dalloc(&h->d_lkeep, E));
+  h->codes_bytes = (E + 7) / 8 * 8;
+  CK(dalloc(&h->d_codes, h->codes_bytes));
   CK(dalloc(&h->d_sel, E));
   CK(dalloc(&h->d_evmap, npx + 64));
-  CK(dalloc(&h->d_own, E));
   CK(dalloc(&h->d_reg_valid, npx + 64));
   CK(hipMemset(h->d_reg_valid, 0, npx + 64));
   CK(dalloc(&h->d_cell_list, npx));
@@ -627,7 +642,7 @@ int esvo_destroy(esvo_handle h) {
                   h->d_matches, h->d_pt_slots, h->d_pt_flags, h->d_pt_prefix, h->d_pts_tmp, h->d_counters, h->d_scan_tmp,
                   h->d_win, h->d_frame_pose_T, h->d_fr_table, h->d_prop, h->d_cell_count, h->d_cell_offset,
                   h->d_cell_fill, h->d_rec_ids, h->d_map, h->d_map2, h->d_owner_max, h->d_owner_min, h->d_exp_flags,
-                  h->d_exp_prefix, h->d_export, h->d_export_cell, h->d_reg_bits, h->d_reg_ab, h->d_reg_cd, h->d_bucket, h->d_cell_list, h->d_mflags_local, h->d_own,
+                  h->d_exp_prefix, h->d_export, h->d_export_cell, h->d_reg_bits, h->d_reg_ab, h->d_reg_cd, h->d_bucket, h->d_cell_list, h->d_own_w, h->d_lkeep, h->d_codes,
                   h->d_reg_valid, h->d_reg_counts, h->d_sel, h->d_evmap};
   for (void* p : ptrs) if (p) hipFree(p);
   if (h->h_counters) hipHostFree(h->h_counters);
@@ -679,6 +694,7 @@ int esvo_set_params(esvo_handle h, const esvo_params_t* params) {
   np.event_ring_capacity = h->prm.event_ring_capacity;
   h->prm = np;
   fill_dev_params(h);
+  set_compute_band(h);
   return ESVO_OK;
 }
 
@@ -922,7 +938,7 @@ int tick_phase0(esvo_context* h, uint64_t t_ns, const uint64_t* pose_t_ns, const
   if (rc) return rc;
   u32 n = h->sh_n;
   hipEventRecord(h->evt[EV_T0], h->stream);
-  HIPCHK(hipMemsetAsync(h->d_counters, 0, sizeof(u32) * 8, h->stream));
+  HIPCHK(hipMemsetAsync(h->d_counters, 0, sizeof(u32) * 16, h->stream));
   const u32* sel = nullptr;
   if (h->prm.denoising && n) {
     // Denoising (esvo_Mapping.cpp:282-296): mask from the selected events, keep those on it, in order.
@@ -935,53 +951,86 @@ int tick_phase0(esvo_context* h, uint64_t t_ns, const uint64_t* pose_t_ns, const
     n = h->sh_n = h->h_counters[5];
     sel = h->d_sel;
   }
-  if (n) {
+  h->xchg_ptr = nullptr;
+  h->xchg_bytes = 0;
+  if (n && !h->sharded) {
     rc = run_bm(h, h->d_ring[0], h->sh_first, h->ring_cap, 1, n, sel);
     if (rc) return rc;
-    if (h->sharded)
-      HIPCHK(hipMemcpyAsync(h->d_mflags_local, h->d_match_flags, sizeof(u32) * n, hipMemcpyDeviceToDevice, h->stream));
+    rc = run_order_matches(h, n, false);
+    if (rc) return rc;
+    rc = run_lm(h, n, 1, false);
+    if (rc) return rc;
+  } else if (n) {
+    // own slots only (w % n_shards == shard): BM, dense local list, LM + cull on it, then the (matched, kept)
+    // byte of every own slot; the other ranks' bytes stay zero and arrive with the caller's sum
+    const u32 N = (u32)h->dp.ev_nshards, r = (u32)h->dp.ev_shard;
+    const u32 own = n > r ? (n - r + N - 1) / N : 0;
+    HIPCHK(hipMemsetAsync(h->d_match_flags, 0, sizeof(u32) * n, h->stream));
+    rc = run_bm(h, h->d_ring[0], h->sh_first, h->ring_cap, 1, n, sel);
+    if (rc) return rc;
+    rc = run_order_matches(h, n, true);
+    if (rc) return rc;
+    rc = run_lm(h, own, 1, true);
+    if (rc) return rc;
+    const size_t nb = ((size_t)n + 7) / 8 * 8;
+    HIPCHK(hipMemsetAsync(h->d_codes, 0, nb, h->stream));
+    launch_shard_codes(h->d_own_w, h->d_lkeep, h->d_counters + 8, own, h->d_codes, h->stream);
+    HIPCHK(hipGetLastError());
+    h->xchg_ptr = h->d_codes;
+    h->xchg_bytes = nb;
   }
   h->stats.last_events_in = n;
   return ESVO_OK;
 }
-// phase 1: order the matches (global flags), refine + cull the ones of this band
+// phase 1: the tick's frame (culled points in the reference's order) goes straight into the window ring
+// (capacity for the worst case: n points); one small D2H per tick for the point count the window policy needs
 int tick_phase1(esvo_context* h) {
   const u32 n = h->sh_n;
-  int rc;
-  if (n) {
-    rc = run_order_matches(h, n, h->sharded ? h->d_mflags_local : nullptr);
-    if (rc) return rc;
-    rc = run_lm(h, n, 1, h->sharded ? h->d_own : nullptr);
-    if (rc) return rc;
-  }
-  if (h->sharded) {  // the caller sizes its collectives with the match count
-    rc = read_counters(h);
-    if (rc) return rc;
-    h->stats.last_matches = h->h_counters[0];
-  }
-  return ESVO_OK;
-}
-// phase 2: assemble the frame, window policy, fusion + clean of this band, regulariser view
-int tick_phase2(esvo_context* h) {
-  const u32 n = h->sh_n;
-  // the new frame goes straight into the window ring (capacity for the worst case: n points)
   int rc = window_reserve(h, n, &h->sh_off);
   if (rc) return rc;
-  if (n) { rc = run_order_points(h, n, h->d_win + h->sh_off); if (rc) return rc; }
-  rc = read_counters(h);  // the window policy needs the point count (one small D2H per tick)
+  DevPoint* frame = h->d_win + h->sh_off;
+  h->xchg_ptr = nullptr;
+  h->xchg_bytes = 0;
+  if (n && !h->sharded) {
+    rc = run_order_points(h, n, frame);
+    if (rc) return rc;
+  } else if (n) {
+    const u32 N = (u32)h->dp.ev_nshards, r = (u32)h->dp.ev_shard, T = (u32)h->dp.num_threads;
+    const u32 own = n > r ? (n - r + N - 1) / N : 0;
+    launch_shard_match_flags(h->d_codes, n, h->d_match_flags, h->stream);
+    launch_exclusive_scan_u32(h->d_match_flags, h->d_match_prefix, h->d_counters + 0, h->d_scan_tmp, n, h->stream);
+    HIPCHK(hipMemsetAsync(h->d_pt_flags, 0, sizeof(u32) * n, h->stream));
+    launch_shard_keep_flags(h->d_codes, h->d_match_prefix, h->d_counters + 0, n, T, h->d_pt_flags, h->stream);
+    launch_exclusive_scan_u32(h->d_pt_flags, h->d_pt_prefix, h->d_counters + 1, h->d_scan_tmp, n, h->stream);
+    launch_shard_place(h->d_own_w, h->d_lkeep, h->d_pt_slots, h->d_counters + 8, own, h->d_match_prefix, h->d_counters + 0,
+                       h->d_pt_prefix, h->d_counters + 1, T, frame, n, h->stream);
+    hipEventRecord(h->evt[EV_S2], h->stream);
+    HIPCHK(hipGetLastError());
+  }
+  rc = read_counters(h);
   if (rc) return rc;
   const u32 n_points = n ? h->h_counters[1] : 0;
   h->stats.last_matches = h->h_counters[0];
-  h->stats.last_solved = h->h_counters[2];
+  h->stats.last_solved = h->h_counters[2];  // sharded: this rank's share
   h->stats.last_points = n_points;
-  rc = commit_frame(h, h->sh_off, n_points, h->h_pose_T.data(), h->n_pose);
-  if (rc) return rc;
-  return run_fuse(h);
+  h->sh_points = n_points;
+  if (h->sharded && n_points) {
+    h->xchg_ptr = frame;
+    h->xchg_bytes = (size_t)n_points * sizeof(DevPoint);
+  }
+  return ESVO_OK;
 }
-// phase 3: regularisation of this band.  Counters and HIP-event timings of the tick are read back
-// lazily (finalize_tick_stats) so that the tick path ends without a host synchronisation.
-int tick_phase3(esvo_context* h) {
-  int rc = run_regularize(h);
+// phase 2: window policy, fusion + clean + regularisation of this band (halo rows recomputed locally).
+// Counters and HIP-event timings of the tick are read back lazily (finalize_tick_stats) so that the tick
+// path ends without a host synchronisation.
+int tick_phase2(esvo_context* h) {
+  h->xchg_ptr = nullptr;
+  h->xchg_bytes = 0;
+  int rc = commit_frame(h, h->sh_off, h->sh_points, h->h_pose_T.data(), h->n_pose);
+  if (rc) return rc;
+  rc = run_fuse(h);
+  if (rc) return rc;
+  rc = run_regularize(h);
   if (rc) return rc;
   h->stats.ticks++;
   h->stats.last_window_frames = (u32)h->frames.size();
@@ -1027,9 +1076,7 @@ extern "C" int esvo_map_tick(esvo_handle h, uint64_t t_ns, const uint64_t* pose_
   if (rc) return rc;
   rc = tick_phase1(h);
   if (rc) return rc;
-  rc = tick_phase2(h);
-  if (rc) return rc;
-  return tick_phase3(h);
+  return tick_phase2(h);
 }
 
 extern "C" int esvo_shard_tick_phase(esvo_handle h, int phase, uint64_t t_ns, const uint64_t* pose_t_ns, const double* pose_T,
@@ -1044,8 +1091,7 @@ extern "C" int esvo_shard_tick_phase(esvo_handle h, int phase, uint64_t t_ns, co
       return tick_phase0(h, t_ns, pose_t_ns, pose_T, m);
     case 1: return tick_phase1(h);
     case 2: return tick_phase2(h);
-    case 3: return tick_phase3(h);
-    default: FAIL(ESVO_ERR_INVALID_ARG, "phase must be 0..3");
+    default: FAIL(ESVO_ERR_INVALID_ARG, "phase must be 0..2");
   }
 }
 
@@ -1114,22 +1160,15 @@ int esvo_shard_set_band(esvo_handle h, int row_begin, int row_end, int shard, in
   h->dp.ev_nshards = n_shards;
   h->dp.band_y0 = row_begin;
   h->dp.band_y1 = row_end;
-  h->dp.cband_y0 = std::max(0, row_begin - 2);
-  h->dp.cband_y1 = std::min(h->H, row_end + 2);
+  set_compute_band(h);
   h->sharded = !(row_begin == 0 && row_end == h->H) || n_shards > 1;
   return ESVO_OK;
 }
 
-int esvo_shard_buffers(esvo_handle h, esvo_shard_buffers_t* out) {
-  if (!h || !out) return ESVO_ERR_INVALID_ARG;
-  out->d_match_flags = h->d_match_flags;
-  out->d_point_flags = h->d_pt_flags;
-  out->d_point_slots = h->d_pt_slots;
-  out->d_reg_valid = h->d_reg_valid;
-  out->d_reg_ab = h->d_reg_ab;
-  out->d_reg_cd = h->d_reg_cd;
-  out->max_events = h->max_ev;
-  out->n_cells = (size_t)h->W * h->H;
+int esvo_shard_exchange(esvo_handle h, void** d_ptr, size_t* n_bytes) {
+  if (!h || !d_ptr || !n_bytes) return ESVO_ERR_INVALID_ARG;
+  *d_ptr = h->xchg_ptr;
+  *n_bytes = h->xchg_bytes;
   return ESVO_OK;
 }
 
@@ -1139,7 +1178,7 @@ int esvo_shard_buffers(esvo_handle h, esvo_shard_buffers_t* out) {
 extern "C" void esvo_abi_sizes(size_t out[8]) {
   out[0] = sizeof(esvo_event_t); out[1] = sizeof(esvo_calib_t); out[2] = sizeof(esvo_params_t);
   out[3] = sizeof(esvo_match_t); out[4] = sizeof(esvo_depth_point_t); out[5] = sizeof(esvo_stats_t);
-  out[6] = sizeof(esvo_shard_buffers_t); out[7] = ESVO_HIP_ABI_VERSION;
+  out[6] = 0; out[7] = ESVO_HIP_ABI_VERSION;
 }
 
 // ---- device self-test: div_by(a, make_recip(b)) == a / b bit for bit ---------------------------------

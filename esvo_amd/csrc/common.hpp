@@ -44,8 +44,11 @@ struct DevParams {
   int band_y0, band_y1;          // row band owned by this handle (0,H when unsharded)
   int ev_shard, ev_nshards;      // per-event work (BM, LM) of slot w belongs to shard w % ev_nshards (balanced
                                  // whatever the scene; every rank holds the full Time Surfaces)
-  int cband_y0, cband_y1;        // compute band of the fusion stage: the owned band + 2 halo rows, so that
-                                 // the 1-row side effects of displaced elements (Appendix A-7) are exact
+  int cband_y0, cband_y1;        // compute band of fusion / clean / regulariser view: the owned band plus a halo of
+                                 // 2 rows (the 1-row side effects of displaced elements, Appendix A-7) and, with
+                                 // regularisation, reg_radius more rows, so that the band's (2r+1)^2 neighbourhoods
+                                 // are computed locally -- the DepthFrame is rebuilt from the window every tick,
+                                 // so halo cells are recomputed, never exchanged
   CamConst camL, camR;
 };
 
@@ -168,7 +171,16 @@ struct BmArgs {
 };
 void launch_bm_match(const BmArgs& a, const DevParams& p, hipStream_t s);
 void launch_compact_matches(const esvo_match_t* slots, const u32* flags, const u32* prefix, u32 n,
-                            esvo_match_t* out, u32* own, hipStream_t s);
+                            esvo_match_t* out, u32* slot_of, hipStream_t s);
+
+// kernels_shard.hip: ordering of a tick's frame from the ranks' (matched, kept) bits
+void launch_shard_codes(const u32* own_w, const u32* keep, const u32* n_local, u32 max_local, uint8_t* codes, hipStream_t s);
+void launch_shard_match_flags(const uint8_t* codes, u32 n, u32* flags, hipStream_t s);
+void launch_shard_keep_flags(const uint8_t* codes, const u32* prefix_f, const u32* n_matches, u32 n, u32 T, u32* keep_by_slot,
+                             hipStream_t s);
+void launch_shard_place(const u32* own_w, const u32* keep, const DevPoint* local_pts, const u32* n_local, u32 max_local,
+                        const u32* prefix_f, const u32* n_matches, const u32* prefix_g, const u32* n_points, u32 T,
+                        DevPoint* frame, u32 frame_cap, hipStream_t s);
 
 // kernels_lm.hip
 struct LmArgs {
@@ -182,7 +194,7 @@ struct LmArgs {
   DevPoint* out_slots;          // [max_matches] slot s (thread-stride order of the solver)
   u32* out_flags;               // [max_matches] 1 = solved (and kept when cull)
   int cull;
-  const u32* own;               // sharded mode: own[j] != 0 <=> match j belongs to this rank (else nullptr)
+  int dense;                    // sharded mode: `matches` is this rank's own dense list; slot s solves match s
 };
 void launch_lm_refine(const LmArgs& a, const DevParams& p, u32* n_solved, hipStream_t s);
 void launch_compact_points(const DevPoint* slots, const u32* flags, const u32* prefix, const u32* n_in,

@@ -62,14 +62,15 @@ template <int G>
 __global__ void __launch_bounds__(256) bm_match_kernel(BmArgs a, DevParams p, int RD, int lds_per_event) {
   constexpr int EPB = 256 / G;  // events per block
   const int grp = threadIdx.x / G, l = threadIdx.x % G;
-  const u32 w = blockIdx.x * EPB + grp;  // slot in thread-stride order
+  // slot in thread-stride order; multi-GPU: slots are dealt round-robin and a rank's launch covers its own ones densely
+  const u32 w = (blockIdx.x * EPB + grp) * (u32)p.ev_nshards + (u32)p.ev_shard;
   u32* ldsL = reinterpret_cast<u32*>(bm_smem + grp * lds_per_event);  // [7][4] dwords
   u32* ldsR = ldsL + 28;                                              // [7][RD] dwords
 
   const int W = p.W, H = p.H;
   constexpr int wx = 15, wy = 7, N = wx * wy, hx = 7, hy = 3;
 
-  bool ok = w < a.n && (int)(w % (u32)p.ev_nshards) == p.ev_shard;  // multi-GPU: slots are dealt round-robin
+  bool ok = w < a.n;
   u32 k = 0;
   uint4 e = make_uint4(0, 0, 0, 0);
   if (ok) {
@@ -219,7 +220,9 @@ template <int G>
 static void launch_bm_g(const BmArgs& a, const DevParams& p, int RD, hipStream_t s) {
   const int per_event = (28 + 7 * RD) * 4;
   const int epb = 256 / G;
-  const u32 blocks = (a.n + epb - 1) / epb;
+  const u32 own = (a.n > (u32)p.ev_shard) ? (a.n - (u32)p.ev_shard + (u32)p.ev_nshards - 1) / (u32)p.ev_nshards : 0;
+  if (own == 0) return;
+  const u32 blocks = (own + epb - 1) / epb;
   hipLaunchKernelGGL(bm_match_kernel<G>, dim3(blocks), dim3(256), (size_t)per_event * epb, s, a, p, RD, per_event);
 }
 
@@ -241,20 +244,19 @@ void launch_bm_match(const BmArgs& a, const DevParams& p, hipStream_t s) {
   }
 }
 
-// stable compaction: slot w -> position prefix[w] (prefix over the GLOBAL flags; `flags` selects the
-// slots this rank owns and `own`, when given, marks their positions)
+// stable compaction: slot w -> position prefix[w]; slot_of (optional) remembers w
 __global__ void __launch_bounds__(256) compact_matches_kernel(const esvo_match_t* __restrict__ slots, const u32* __restrict__ flags,
                                                               const u32* __restrict__ prefix, u32 n,
-                                                              esvo_match_t* __restrict__ out, u32* __restrict__ own) {
+                                                              esvo_match_t* __restrict__ out, u32* __restrict__ slot_of) {
   const u32 w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= n || !flags[w]) return;
   out[prefix[w]] = slots[w];
-  if (own) own[prefix[w]] = 1u;
+  if (slot_of) slot_of[prefix[w]] = w;
 }
 void launch_compact_matches(const esvo_match_t* slots, const u32* flags, const u32* prefix, u32 n, esvo_match_t* out,
-                            u32* own, hipStream_t s) {
+                            u32* slot_of, hipStream_t s) {
   if (n == 0) return;
-  hipLaunchKernelGGL(compact_matches_kernel, dim3((n + 255) / 256), dim3(256), 0, s, slots, flags, prefix, n, out, own);
+  hipLaunchKernelGGL(compact_matches_kernel, dim3((n + 255) / 256), dim3(256), 0, s, slots, flags, prefix, n, out, slot_of);
 }
 
 }  // namespace esvo

@@ -365,23 +365,22 @@ __global__ void __launch_bounds__(256) reg_owner_kernel(const MapCell* __restric
 __global__ void __launch_bounds__(256) reg_view_kernel(const MapCell* __restrict__ map, MapCell* __restrict__ out,
                                                        uint8_t* __restrict__ valid, double2* __restrict__ ab, double2* __restrict__ cd,
                                                        u32* __restrict__ elem_list, u32* __restrict__ n_elems, int ncell, int W,
-                                                       int band0, int band1) {
+                                                       int band0, int band1, int view0, int view1) {
   const int cell = blockIdx.x * blockDim.x + threadIdx.x;
-  bool v = false, alive = false;
+  bool alive = false;
   if (cell < ncell) {
     const MapCell& n = map[cell];
-    const int row0 = cell / W;
-    const bool in_band = row0 >= band0 && row0 < band1;
-    alive = in_band && (n.flags & CELL_ALIVE) != 0;
-    v = alive && (n.flags & CELL_GRID) && n.inv_depth > -1e-6;
-    if (v) {
-      ab[cell] = make_double2(n.inv_depth, 2.0 * sqrt(n.variance));
-      cd[cell] = make_double2(n.nu, n.scale2);
-    }
     const int row = cell / W;
-    if (row < band0 || row >= band1) alive = false;
-    else {
-      valid[cell] = v ? 1 : 0;  // only the band's bytes: the other bands come from their ranks
+    if (row >= view0 && row < view1) {  // the view covers the band's halo as well (multi-GPU: computed, not exchanged)
+      const bool v = (n.flags & CELL_ALIVE) && (n.flags & CELL_GRID) && n.inv_depth > -1e-6;
+      if (v) {
+        ab[cell] = make_double2(n.inv_depth, 2.0 * sqrt(n.variance));
+        cd[cell] = make_double2(n.nu, n.scale2);
+      }
+      valid[cell] = v ? 1 : 0;
+    }
+    if (row >= band0 && row < band1) {
+      alive = (n.flags & CELL_ALIVE) != 0;
       if (!alive) out[cell].flags = 0;
     }
   }
@@ -510,7 +509,7 @@ void launch_reg_view(const MapCell* map_in, MapCell* map_out, u32* owner_max, u3
   const int nb = (ncell + 255) / 256;
   hipLaunchKernelGGL(reg_owner_kernel, dim3(nb), dim3(256), 0, s, map_in, owner_max, owner_min, p);
   hipLaunchKernelGGL(reg_view_kernel, dim3(nb), dim3(256), 0, s, map_in, map_out, valid, ab, cd, elem_list, n_elems, ncell, p.W,
-                     p.band_y0, p.band_y1);
+                     p.band_y0, p.band_y1, p.cband_y0, p.cband_y1);
 }
 void launch_reg_apply(const MapCell* map_in, MapCell* map_out, const u32* owner_max, const u32* owner_min, const uint8_t* valid,
                       u64* masks, u32* counts, const double2* ab, const double2* cd, const u32* elem_list, const u32* n_elems,

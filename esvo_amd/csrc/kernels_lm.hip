@@ -294,9 +294,8 @@ __global__ void __launch_bounds__(256, 3) lm_refine_kernel(LmArgs a, DevParams p
   esvo_match_t m;
   m.x_left[0] = m.x_left[1] = -1e9; m.inv_depth = 1.0; m.pose_idx = 0; m.cost = 0; m.disp = 0; m.event_idx = 0;
   if (active) {
-    j = stride_item(s, M, (u32)p.num_threads);  // DepthProblemSolver.cpp:90
-    if (a.own && !a.own[j]) active = false;     // another rank's band refines this match
-    else m = a.matches[j];
+    j = a.dense ? s : stride_item(s, M, (u32)p.num_threads);  // DepthProblemSolver.cpp:90 (dense: kernels_shard.hip)
+    m = a.matches[j];
   }
   LmProblem pr;
   pr.cx = m.x_left[0];

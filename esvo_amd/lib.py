@@ -10,12 +10,12 @@ import subprocess
 
 import numpy as np
 
-from .abi import (DEPTH_POINT_DTYPE, EVENT_DTYPE, MATCH_DTYPE, CalibStruct, ParamsStruct, ShardBuffersStruct,
+from .abi import (DEPTH_POINT_DTYPE, EVENT_DTYPE, MATCH_DTYPE, CalibStruct, ParamsStruct,
                   StatsStruct)
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 _LIB_PATH = os.path.join(_CSRC, "libesvo_hip.so")
-_SOURCES = ["api.hip", "scan.hip", "kernels_ts.hip", "kernels_bm.hip", "kernels_lm.hip", "kernels_fuse.hip"]
+_SOURCES = ["api.hip", "scan.hip", "kernels_ts.hip", "kernels_bm.hip", "kernels_lm.hip", "kernels_fuse.hip", "kernels_shard.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
                "-Wno-unused-value", "-Wno-unused-result"]
 
@@ -24,7 +24,7 @@ SYMBOLS = [
     "esvo_set_stream", "esvo_synchronize", "esvo_ts_push_events", "esvo_ts_render", "esvo_map_set_observation",
     "esvo_map_match", "esvo_map_set_poses", "esvo_map_refine", "esvo_map_push_frame", "esvo_map_fuse",
     "esvo_map_tick", "esvo_map_get_depth_points", "esvo_map_get_pointcloud_xyz", "esvo_map_get_last_frame",
-    "esvo_get_stats", "esvo_shard_set_band", "esvo_shard_buffers", "esvo_shard_tick_phase", "esvo_abi_sizes",
+    "esvo_get_stats", "esvo_shard_set_band", "esvo_shard_exchange", "esvo_shard_tick_phase", "esvo_abi_sizes",
 ]
 
 
@@ -84,7 +84,7 @@ def load():
     lib.esvo_map_get_last_frame.argtypes = [vp, vp, sz, psz]
     lib.esvo_get_stats.argtypes = [vp, vp]
     lib.esvo_shard_set_band.argtypes = [vp, i32, i32, i32, i32]
-    lib.esvo_shard_buffers.argtypes = [vp, vp]
+    lib.esvo_shard_exchange.argtypes = [vp, vp, vp]
     lib.esvo_shard_tick_phase.argtypes = [vp, i32, u64, vp, vp, sz]
     for s in SYMBOLS:
         if s not in ("esvo_default_params", "esvo_last_error", "esvo_abi_sizes"):
@@ -244,10 +244,11 @@ class Esvo:
     def set_band(self, y0, y1, shard=0, n_shards=1):
         self._ck(self.lib.esvo_shard_set_band(self.h, int(y0), int(y1), int(shard), int(n_shards)))
 
-    def shard_buffers(self):
-        b = ShardBuffersStruct()
-        self._ck(self.lib.esvo_shard_buffers(self.h, C.addressof(b)))
-        return b
+    def shard_exchange(self):
+        """(device pointer, bytes) of the buffer to sum over the ranks before the next phase; bytes == 0: nothing"""
+        ptr, nb = C.c_void_p(), C.c_size_t()
+        self._ck(self.lib.esvo_shard_exchange(self.h, C.byref(ptr), C.byref(nb)))
+        return (ptr.value or 0), int(nb.value)
 
     def shard_phase(self, phase, t_ns=0, stamps=None, poses=None):
         if phase == 0:

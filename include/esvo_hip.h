@@ -248,7 +248,7 @@ int esvo_map_get_pointcloud_xyz(esvo_handle h, float* out_xyz, size_t cap_points
 /* The newest frame of the fusion window (culled DepthPoints of the last tick). */
 int esvo_map_get_last_frame(esvo_handle h, esvo_depth_point_t* out, size_t cap, size_t* n);
 int esvo_get_stats(esvo_handle h, esvo_stats_t* out);
-/* sizeof() of {event, calib, params, match, depth_point, stats, shard_buffers} + ABI version:
+/* sizeof() of {event, calib, params, match, depth_point, stats}, 0, ABI version:
  * lets a foreign-language binding check its struct mirrors. */
 void esvo_abi_sizes(size_t out[8]);
 
@@ -259,33 +259,25 @@ void esvo_abi_sizes(size_t out[8]);
  * rank holds the full Time Surfaces), its per-cell work (fuse/clean/regularise) the image rows
  * [row_begin,row_end).  (0, H, 0, 1) = unsharded. */
 int esvo_shard_set_band(esvo_handle h, int row_begin, int row_end, int shard, int n_shards);
-/* Four-phase tick for sharded operation.  Every rank stages ALL events and renders the full Time
- * Surfaces (replicated, ~1 % of a tick); per-event and per-cell work is split by band.  The caller
- * runs the collectives between phases on the device buffers exposed by esvo_shard_buffers
- * (torch.distributed / RCCL, issued on the handle's stream, see esvo_amd/dist.py):
- *   phase 0: poses + event selection + block matching of the shard's events
- *            -> all-reduce(SUM) match_flags[0..n)            n = stats.last_events_in
- *   phase 1: global match order + LM refinement + culling of the shard's matches
- *            -> all-reduce(SUM) point_flags[0..M), point_slots[0..M) (as integers; foreign slots are 0)
- *                                                            M = stats.last_matches
- *   phase 2: frame assembly + window policy (identical on every rank) + fusion + clean of the band,
- *            regulariser view of the band
- *            -> all-gather reg_valid / reg_ab / reg_cd row bands (only when Regularization is on)
- *   phase 3: regularisation of the band.
- * The DepthMap stays sharded; esvo_map_get_depth_points returns the band's elements. */
-typedef struct esvo_shard_buffers_t {
-  void* d_match_flags;  /* uint32[max_events] */
-  void* d_point_flags;  /* uint32[max_events] */
-  void* d_point_slots;  /* esvo_depth_point_t[max_events] */
-  void* d_reg_valid;    /* uint8[n_cells]    neighbour validity */
-  void* d_reg_ab;       /* double[n_cells*2] (inv_depth, 2*sigma) */
-  void* d_reg_cd;       /* double[n_cells*2] (nu, scale^2) */
-  size_t max_events;
-  size_t n_cells;
-} esvo_shard_buffers_t;
-int esvo_shard_buffers(esvo_handle h, esvo_shard_buffers_t* out);
+/* Three-phase tick for sharded operation.  Every rank stages ALL events, renders the full Time
+ * Surfaces and keeps the full fusion window (replicated, a few % of a tick); the per-event work is dealt by
+ * slot, the per-cell work by row band.  After phase 0 and after phase 1 the caller sums ONE device buffer
+ * over the ranks (esvo_shard_exchange: 64-bit integer words, entries of other ranks are zero, so SUM is an
+ * exact union; torch.distributed / RCCL all-reduce issued on the handle's stream, see esvo_amd/dist.py):
+ *   phase 0: poses + event selection + block matching + LM refinement + culling of the shard's slots
+ *            -> exchange: one byte per slot (bit 0 matched, bit 1 point kept), n rounded up to 8 bytes
+ *   phase 1: the tick's frame in the reference's order (EventBM.cpp:289-308 and
+ *            DepthProblemSolver.cpp:75-90 permutations, derived from the bytes), own points placed
+ *            -> exchange: the frame, last_points x sizeof(esvo_depth_point_t) bytes
+ *   phase 2: window policy (identical on every rank), fusion + clean + regularisation of the band; the
+ *            halo rows the band's neighbourhoods read (2 + RegularizationRadius) are recomputed locally,
+ *            which is exact because the DepthFrame is rebuilt from the window at every tick.
+ * The DepthMap stays sharded; esvo_map_get_depth_points returns the band's elements (seq = global
+ * creation order, so bands merge by sorting on it).  stats.last_solved counts the shard's own problems. */
 int esvo_shard_tick_phase(esvo_handle h, int phase, uint64_t t_ns, const uint64_t* pose_t_ns,
                           const double* pose_T, size_t m);
+/* The buffer to sum over the ranks before the next phase (n_bytes is a multiple of 8; 0 = nothing). */
+int esvo_shard_exchange(esvo_handle h, void** d_ptr, size_t* n_bytes);
 
 #ifdef __cplusplus
 }

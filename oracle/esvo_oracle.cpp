@@ -1358,5 +1358,5 @@ extern "C" double orc_zncc_cost(const double* l, const double* r, int wx, int wy
 extern "C" void orc_abi_sizes(size_t out[8]) {
   out[0] = sizeof(esvo_event_t); out[1] = sizeof(esvo_calib_t); out[2] = sizeof(esvo_params_t);
   out[3] = sizeof(esvo_match_t); out[4] = sizeof(esvo_depth_point_t); out[5] = sizeof(esvo_stats_t);
-  out[6] = sizeof(esvo_shard_buffers_t); out[7] = 0;
+  out[6] = 0; out[7] = 0;
 }

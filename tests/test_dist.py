@@ -1,5 +1,5 @@
-"""world_size-2 tests of the multi-GPU exchange step on CPU (gloo): the collectives ShardedEsvo runs
-between the phases of a sharded tick, and the band bookkeeping."""
+"""world_size-2 tests of the multi-GPU exchange steps on CPU (gloo): the two sums ShardedEsvo runs between
+the phases of a sharded tick (on host tensors here), and the band bookkeeping."""
 import os
 
 import numpy as np
@@ -18,24 +18,23 @@ def _worker(rank, world, port, height, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         rng = np.random.default_rng(5)
-        n = 1000
-        # every "match" is owned by exactly one rank (the band of its row); foreign slots are zero
-        owner = rng.integers(0, world, n)
-        flags_ref = rng.integers(0, 2, n).astype(np.int32)
-        slots_ref = rng.integers(1, 2**62, (n, edist.POINT_WORDS)).astype(np.int64) * flags_ref[:, None]
-        flags = torch.from_numpy(np.where(owner == rank, flags_ref, 0).astype(np.int32))
-        slots = torch.from_numpy(np.where((owner == rank)[:, None], slots_ref, 0)).reshape(-1)
-        edist.merge_disjoint_(flags)
-        edist.merge_disjoint_(slots)
-        ok1 = np.array_equal(flags.numpy(), flags_ref) and np.array_equal(slots.numpy().reshape(n, -1), slots_ref)
-        # row bands (equal and ragged heights), 2 values per cell like the (inv_depth, 2 sigma) view
-        width = 7
-        full_ref = rng.random((height, width, 2))
-        full = torch.zeros(height * width * 2, dtype=torch.float64)
-        y0, y1 = edist.band_of(rank, world, height)
-        full.view(height, width, 2)[y0:y1] = torch.from_numpy(full_ref[y0:y1])
-        edist.gather_row_bands_(full, width, height, rank, world)
-        ok2 = np.array_equal(full.numpy().reshape(height, width, 2), full_ref)
+        n = 1000 + height  # not a multiple of 8: the byte buffer is padded to whole 64-bit words
+        words = DEPTH_POINT_DTYPE.itemsize // 8
+        # exchange 1: one byte per slot (bit 0 matched, bit 1 kept); slot w belongs to rank w % world
+        codes_ref = rng.choice(np.array([0, 1, 3], np.uint8), n)
+        mine = np.zeros((n + 7) // 8 * 8, np.uint8)
+        own = np.arange(n) % world == rank
+        mine[:n][own] = codes_ref[own]
+        t = torch.from_numpy(mine.view(np.int64))
+        edist.merge_disjoint_(t)
+        ok1 = np.array_equal(mine[:n], codes_ref) and not mine[n:].any()
+        # exchange 2: the frame, 13 words per kept point (any bit pattern, negative words included), zero elsewhere
+        kept = np.flatnonzero(codes_ref == 3)
+        frame_ref = rng.integers(-2**63, 2**63 - 1, (len(kept), words), dtype=np.int64)
+        frame = np.where((kept % world == rank)[:, None], frame_ref, 0).astype(np.int64).reshape(-1)
+        t = torch.from_numpy(frame)
+        edist.merge_disjoint_(t)
+        ok2 = np.array_equal(frame.reshape(-1, words), frame_ref)
         q.put((rank, ok1, ok2))
     finally:
         dist.destroy_process_group()

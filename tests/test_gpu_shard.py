@@ -1,6 +1,6 @@
-"""Sharded == unsharded on ONE GPU: G handles with disjoint row bands run the four-phase tick, the
-collectives between the phases are emulated with torch ops on the same device buffers the real
-run hands to RCCL.  The merged DepthMap must equal the unsharded one bit for bit (gpurun exposes a
+"""Sharded == unsharded on ONE GPU: G handles with disjoint event shards / row bands run the three-phase
+tick, the two sums between the phases are emulated with torch ops on the same device buffers the real
+run hands to RCCL (esvo_shard_exchange).  The merged DepthMap must equal the unsharded one bit for bit (gpurun exposes a
 single GPU; the multi-process path itself is covered by tests/test_dist.py with gloo)."""
 import numpy as np
 import pytest
@@ -12,15 +12,31 @@ pytestmark = pytest.mark.gpu
 F64 = ["inv_depth", "scale2", "nu", "variance", "residual", "x", "p_cam"]
 
 
-def _views(dev):
+def _emulated_sum(shards, whole_words=False):
+    """what dist.ShardedEsvo._exchange does with an all-reduce: 64-bit integer SUM of the ranks' buffers"""
+    import torch
     from esvo_amd import dist as edist
-    b = dev.shard_buffers()
-    return dict(mflags=edist.device_tensor(b.d_match_flags, b.max_events, "<i4"),
-                pflags=edist.device_tensor(b.d_point_flags, b.max_events, "<i4"),
-                pslots=edist.device_tensor(b.d_point_slots, b.max_events * edist.POINT_WORDS, "<i8"),
-                valid=edist.device_tensor(b.d_reg_valid, b.n_cells, "|u1"),
-                ab=edist.device_tensor(b.d_reg_ab, b.n_cells * 2, "<f8"),
-                cd=edist.device_tensor(b.d_reg_cd, b.n_cells * 2, "<f8"))
+    for d in shards:
+        d.synchronize()
+    bufs = []
+    for d in shards:
+        ptr, nbytes = d.shard_exchange()
+        bufs.append(edist.device_tensor(ptr, nbytes // 8, "<i8") if nbytes else None)
+    sizes = {0 if b is None else b.numel() for b in bufs}
+    assert len(sizes) == 1, sizes  # every rank derives the same size
+    if bufs[0] is None:
+        return None
+    stack = torch.stack(bufs)
+    by = stack.view(torch.uint8).view(len(bufs), -1)
+    if not whole_words:
+        assert int(((by != 0).sum(0) > 1).sum()) == 0  # byte-wise disjoint: the word sums cannot carry
+    else:
+        assert int(((stack.view(len(bufs), -1, 13) != 0).any(2).sum(0) > 1).sum()) == 0  # every point from ONE shard
+    tot = stack.sum(0)
+    for b in bufs:
+        b.copy_(tot)
+    torch.cuda.synchronize()
+    return tot
 
 
 @pytest.mark.parametrize("preset,rig_fix,stream_fix,n_ev,G", [
@@ -40,8 +56,6 @@ def test_logical_shards_equal_unsharded(request, preset, rig_fix, stream_fix, n_
     bands = [edist.band_of(g, G, rig.height) for g in range(G)]
     for g, (d, (y0, y1)) in enumerate(zip(shards, bands)):
         d.set_band(y0, y1, g, G)
-    views = [_views(d) for d in shards]
-    W = rig.width
     t_prev = stream.t0_ns
     for k in range(5):
         t = stream.t0_ns + int((0.07 + 0.01 * k) * 1e9)
@@ -53,42 +67,18 @@ def test_logical_shards_equal_unsharded(request, preset, rig_fix, stream_fix, n_
             d.set_observation(t, None, None, stream.pose(t))
         t_prev = t + 5_000_000
         ref.tick(t, stamps, poses)
-        # phase 0 + "all-reduce" of the match flags
-        for d in shards:
+        for d in shards:  # BM + LM of the own slots -> sum of the (matched, kept) bytes
             d.shard_phase(0, t, stamps, poses)
         n = shards[0].stats().last_events_in
         assert n == ref.stats().last_events_in
-        for d in shards:
-            d.synchronize()
-        tot = sum(v["mflags"][:n] for v in views)
-        assert int(tot.max()) <= 1  # the event shards are disjoint
-        for v in views:
-            v["mflags"][:n] = tot
-        torch.cuda.synchronize()
-        # phase 1 + "all-reduce" of point flags / slots
-        for d in shards:
+        codes = _emulated_sum(shards)
+        for d in shards:  # frame order, own points placed -> sum of the frame
             d.shard_phase(1)
-        m = shards[0].stats().last_matches
-        assert m == ref.stats().last_matches
-        tf = sum(v["pflags"][:m] for v in views)
-        ts = sum(v["pslots"][: m * edist.POINT_WORDS] for v in views)
-        for v in views:
-            v["pflags"][:m] = tf
-            v["pslots"][: m * edist.POINT_WORDS] = ts
-        torch.cuda.synchronize()
-        # phase 2 + "all-gather" of the regulariser view bands
+        assert shards[0].stats().last_matches == ref.stats().last_matches
+        assert sum(d.stats().last_solved for d in shards) == ref.stats().last_solved
+        _emulated_sum(shards, whole_words=True)
         for d in shards:
             d.shard_phase(2)
-            d.synchronize()
-        if p.regularization:
-            for key, per in (("valid", 1), ("ab", 2), ("cd", 2)):
-                for g, (y0, y1) in enumerate(bands):
-                    src = views[g][key][y0 * W * per:y1 * W * per].clone()
-                    for v in views:
-                        v[key][y0 * W * per:y1 * W * per] = src
-            torch.cuda.synchronize()
-        for d in shards:
-            d.shard_phase(3)
         assert shards[0].stats().last_points == ref.stats().last_points
         merged = edist.merge_band_maps([d.get_map() for d in shards])
         full = ref.get_map()

@@ -25,7 +25,7 @@ def test_abi_struct_sizes_match_bindings():
     assert s[0] == abi.EVENT_DTYPE.itemsize == 16
     assert s[1] == ctypes.sizeof(abi.CalibStruct) and s[2] == ctypes.sizeof(abi.ParamsStruct)
     assert s[3] == abi.MATCH_DTYPE.itemsize == 48 and s[4] == abi.DEPTH_POINT_DTYPE.itemsize == 104
-    assert s[5] == ctypes.sizeof(abi.StatsStruct) and s[6] == ctypes.sizeof(abi.ShardBuffersStruct)
+    assert s[5] == ctypes.sizeof(abi.StatsStruct) and s[6] == 0
     assert s[7] == 1
 
 

@@ -294,4 +294,4 @@ def test_abi_struct_sizes():
     assert s[0] == abi.EVENT_DTYPE.itemsize == 16
     assert s[1] == ctypes.sizeof(abi.CalibStruct) and s[2] == ctypes.sizeof(abi.ParamsStruct)
     assert s[3] == abi.MATCH_DTYPE.itemsize and s[4] == abi.DEPTH_POINT_DTYPE.itemsize
-    assert s[5] == ctypes.sizeof(abi.StatsStruct) and s[6] == ctypes.sizeof(abi.ShardBuffersStruct)
+    assert s[5] == ctypes.sizeof(abi.StatsStruct) and s[6] == 0
