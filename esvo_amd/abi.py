@@ -99,6 +99,9 @@ class StatsStruct(C.Structure):
         ("ms_bm", C.c_float), ("ms_refine", C.c_float), ("ms_fusion", C.c_float),
         ("ms_regularization", C.c_float), ("ms_tick_total", C.c_float),
         ("ms_kernel", C.c_float * 8),
+        ("pad_", C.c_float),
+        ("total_events_in", C.c_uint64), ("total_matches", C.c_uint64), ("total_points", C.c_uint64),
+        ("sum_ms_kernel", C.c_double * 8),
     ]
 
 

@@ -21,7 +21,11 @@ namespace {
 thread_local std::string g_create_error;
 }
 
-enum { EV_SC0 = 0, EV_SC1, EV_R1, EV_T0, EV_BM0, EV_BM1, EV_S1, EV_LM0, EV_LM1, EV_S2, EV_FU0, EV_FU1, EV_CL1, EV_RG1, EV_N };
+// front-stage events live on the front stream; the back-stage set exists once per tick parity (two ticks in flight)
+enum { EV_SC0 = 0, EV_SC1, EV_R1, EV_SC0b, EV_SC1b, EV_R1b, EV_T0, EV_BM0, EV_BM1, EV_S1, EV_LM0, EV_LM1, EV_S2, EV_FRAME,
+       EV_FU0, EV_FU1, EV_CL1, EV_RG1, EV_POSE, EV_FU0b, EV_FU1b, EV_CL1b, EV_RG1b, EV_POSEb, EV_N };
+constexpr int EV_BACK_STRIDE = EV_FU0b - EV_FU0;  // evt[EV_x + par * EV_BACK_STRIDE]
+constexpr int EV_TS_STRIDE = EV_SC0b - EV_SC0;    // evt[EV_x + cam * EV_TS_STRIDE]
 
 struct FrameRec {
   u32 off;    // offset in the window ring
@@ -33,8 +37,15 @@ struct esvo_context {
   esvo_params_t prm;
   DevParams dp;
   int W = 0, H = 0, device = 0;
+  // Two streams, two ticks in flight: the front stage (TS, block matching, LM, frame assembly) of tick k+1 runs on
+  // `stream` while the back stage (propagate, fuse, clean, regularise) of tick k runs on `stream_b`.  The back
+  // stage only reads what the front stage finished (the frame in the window ring, the tick's pose table).
   hipStream_t stream = nullptr;
+  hipStream_t stream_b = nullptr;
   bool own_stream = false;
+  int par = 0;                    // parity of the tick being assembled
+  bool back_pending[2] = {false, false};  // back-stage timings / counters of that parity not collected yet
+  u32 back_frames[2] = {0, 0};
   std::string err;
   double baseline = 0;
 
@@ -65,7 +76,9 @@ struct esvo_context {
 
   // pose table of the tick
   double* d_pose_sec = nullptr;
-  double* d_pose_T = nullptr;
+  double* d_pose_T = nullptr;     // the tick's table (one of d_pose_T2, alternating)
+  double* d_pose_T2[2] = {nullptr, nullptr};
+  int pose_buf = 0;
   std::vector<double> h_pose_T;
   double* h_pin = nullptr;        // pinned staging: 2 slots x (max_poses x 17 + 16) doubles
   int pin_slot = 0;
@@ -87,6 +100,9 @@ struct esvo_context {
                                   // [6] touched cells [7] regulariser elements [8] own matches (sharded)
   u32* h_counters = nullptr;      // pinned
   u32* d_scan_tmp = nullptr;
+  u32* d_cnt_b = nullptr;         // back stage: [3] n_fusion [4] n_records [5] n_map [6] touched cells [7] regulariser elements
+  u32* h_cnt_b = nullptr;         // pinned, one row of 8 per parity + one for exports
+  u32* d_scan_tmp_b = nullptr;
 
   // fusion window
   DevPoint* d_win = nullptr;
@@ -138,10 +154,10 @@ struct esvo_context {
   esvo_depth_point_t* d_export = nullptr;
   u32* d_export_cell = nullptr;
 
-  hipEvent_t evt[16];
+  hipEvent_t evt[EV_N];
   bool evt_ok = false;
   esvo_stats_t stats;
-  bool ts_timing_pending = false;
+  bool ts_timing_pending[2] = {false, false};
 };
 
 #define HIPCHK(call)                                                                              \
@@ -251,6 +267,10 @@ int upload_poses(esvo_context* h, const uint64_t* pose_t_ns, const double* pose_
   std::memcpy(T, pose_T, sizeof(double) * 16 * m);
   h->h_pose_T.assign(pose_T, pose_T + 16 * m);
   h->n_pose = (u32)m;
+  // the back stage copies the previous table of this buffer into its frame slot: not before that is done
+  h->pose_buf ^= 1;
+  h->d_pose_T = h->d_pose_T2[h->pose_buf];
+  HIPCHK(hipStreamWaitEvent(h->stream, h->evt[EV_POSE + h->pose_buf * EV_BACK_STRIDE], 0));
   if (m) {
     HIPCHK(hipMemcpyAsync(h->d_pose_sec, sec, sizeof(double) * m, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_pose_T, T, sizeof(double) * 16 * m, hipMemcpyHostToDevice, h->stream));
@@ -319,20 +339,58 @@ int run_refine(esvo_context* h, u32 max_matches, int cull, DevPoint* dst) {
   return run_order_points(h, max_matches, dst);
 }
 
+// Time-Surface kernel timings of the last render of each camera (their events are complete: call after a
+// synchronisation of the front stream)
 void collect_ts_timing(esvo_context* h) {
-  if (!h->ts_timing_pending) return;
-  if (hipEventElapsedTime(&h->stats.ms_ts_scatter, h->evt[EV_SC0], h->evt[EV_SC1]) == hipSuccess &&
-      hipEventElapsedTime(&h->stats.ms_ts_render, h->evt[EV_SC1], h->evt[EV_R1]) == hipSuccess) {
-    h->stats.ms_kernel[0] = h->stats.ms_ts_scatter;
-    h->stats.ms_kernel[1] = h->stats.ms_ts_render;
+  for (int cam = 0; cam < 2; ++cam) {
+    if (!h->ts_timing_pending[cam]) continue;
+    h->ts_timing_pending[cam] = false;
+    const int o = cam * EV_TS_STRIDE;
+    float sc = 0, rd = 0;
+    if (hipEventElapsedTime(&sc, h->evt[EV_SC0 + o], h->evt[EV_SC1 + o]) == hipSuccess &&
+        hipEventElapsedTime(&rd, h->evt[EV_SC1 + o], h->evt[EV_R1 + o]) == hipSuccess) {
+      h->stats.ms_ts_scatter = h->stats.ms_kernel[0] = sc;
+      h->stats.ms_ts_render = h->stats.ms_kernel[1] = rd;
+      h->stats.sum_ms_kernel[0] += sc;
+      h->stats.sum_ms_kernel[1] += rd;
+      h->stats.sum_ms_kernel[7] += 1;
+    }
   }
-  h->ts_timing_pending = false;
 }
 
 int read_counters(esvo_context* h) {
   HIPCHK(hipMemcpyAsync(h->h_counters, h->d_counters, sizeof(u32) * 16, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   return ESVO_OK;
+}
+// back-stage counters into row `row` of the pinned table (0/1: the tick parities, 2: exports)
+int read_counters_b(esvo_context* h, int row, bool sync) {
+  HIPCHK(hipMemcpyAsync(h->h_cnt_b + 8 * row, h->d_cnt_b, sizeof(u32) * 8, hipMemcpyDeviceToHost, h->stream_b));
+  if (sync) HIPCHK(hipStreamSynchronize(h->stream_b));
+  return ESVO_OK;
+}
+// the back stage starts when everything enqueued on the front stream so far is done
+int back_after_front(esvo_context* h) {
+  HIPCHK(hipEventRecord(h->evt[EV_FRAME], h->stream));
+  HIPCHK(hipStreamWaitEvent(h->stream_b, h->evt[EV_FRAME], 0));
+  return ESVO_OK;
+}
+// timings and counters of a finished back stage
+void collect_back(esvo_context* h, int par) {
+  if (!h->back_pending[par]) return;
+  h->back_pending[par] = false;
+  const int o = par * EV_BACK_STRIDE;
+  esvo_stats_t& s = h->stats;
+  s.last_fusions = h->h_cnt_b[8 * par + 3];
+  if (h->prm.regularization) s.last_map_size = h->h_cnt_b[8 * par + 7];  // alive cells of the band (exports refresh it)
+  float fu = 0, cl = 0, rg = 0;
+  hipEventElapsedTime(&fu, h->evt[EV_FU0 + o], h->evt[EV_FU1 + o]);
+  hipEventElapsedTime(&cl, h->evt[EV_FU1 + o], h->evt[EV_CL1 + o]);
+  hipEventElapsedTime(&rg, h->evt[EV_CL1 + o], h->evt[EV_RG1 + o]);
+  s.ms_fusion = fu + cl;
+  s.ms_regularization = rg;
+  s.ms_kernel[4] = fu; s.ms_kernel[5] = cl; s.ms_kernel[6] = rg;
+  s.sum_ms_kernel[4] += fu; s.sum_ms_kernel[5] += cl; s.sum_ms_kernel[6] += rg;
 }
 
 // place a frame of up to n points in the window ring (frames stay contiguous)
@@ -376,24 +434,33 @@ void apply_window_policy(esvo_context* h) {
   }
 }
 
+// pose table of the frame: from the host (stage-wise API) or, in a tick, the front stage's device table
 int commit_frame(esvo_context* h, u32 off, u32 count, const double* pose_T_host, u32 m) {
   u32 slot;
   int rc = alloc_pose_slot(h, &slot);
   if (rc) return rc;
-  if (m)
-    HIPCHK(hipMemcpyAsync(h->d_frame_pose_T + (size_t)slot * h->max_poses * 16, pose_T_host, sizeof(double) * 16 * m,
-                          hipMemcpyHostToDevice, h->stream));
+  if (m) {
+    double* dst = h->d_frame_pose_T + (size_t)slot * h->max_poses * 16;
+    if (pose_T_host) {
+      HIPCHK(hipMemcpyAsync(dst, pose_T_host, sizeof(double) * 16 * m, hipMemcpyHostToDevice, h->stream_b));
+    } else {
+      HIPCHK(hipMemcpyAsync(dst, h->d_pose_T, sizeof(double) * 16 * m, hipMemcpyDeviceToDevice, h->stream_b));
+      HIPCHK(hipEventRecord(h->evt[EV_POSE + h->pose_buf * EV_BACK_STRIDE], h->stream_b));
+    }
+  }
   h->frames.push_back(FrameRec{off, count, slot});
   apply_window_policy(h);
   if (h->frames.size() > h->max_frames) FAIL(ESVO_ERR_CAPACITY, "too many frames in the fusion window");
   return ESVO_OK;
 }
 
-// fusion loop + clean + regularisation on the current window
-int run_fuse(esvo_context* h) {
+// fusion loop + clean + regularisation on the current window, on the back stream; `par` selects the
+// pinned frame table and the event set (two ticks may be in flight)
+int run_fuse(esvo_context* h, int par) {
   // frames newest -> oldest (esvo_Mapping.cpp:372-377)
   const u32 nf = (u32)h->frames.size();
-  u32* cum = h->h_fr_table;
+  const size_t tab = 3 * (size_t)h->max_frames + 1;
+  u32* cum = h->h_fr_table + (size_t)par * tab;
   u32* off = cum + (h->max_frames + 1);
   u32* slot = off + h->max_frames;
   u32 total = 0;
@@ -403,51 +470,51 @@ int run_fuse(esvo_context* h) {
     total += f.count;
   }
   cum[nf] = total;
-  HIPCHK(hipMemcpyAsync(h->d_fr_table, h->h_fr_table, sizeof(u32) * (3 * h->max_frames + 1), hipMemcpyHostToDevice, h->stream));
+  hipStream_t sb = h->stream_b;
+  u32* dtab = h->d_fr_table + (size_t)par * tab;
+  HIPCHK(hipMemcpyAsync(dtab, cum, sizeof(u32) * tab, hipMemcpyHostToDevice, sb));
   std::memcpy(h->T_world_frame, h->T_world_obs, sizeof(double) * 16);  // new DepthFrame at the TS pose (:268-272)
   FuseArgs a;
   a.win = h->d_win;
-  a.fr_cum = h->d_fr_table; a.fr_off = h->d_fr_table + (h->max_frames + 1); a.fr_slot = a.fr_off + h->max_frames;
+  a.fr_cum = dtab; a.fr_off = dtab + (h->max_frames + 1); a.fr_slot = a.fr_off + h->max_frames;
   a.n_frames = nf; a.n_pts = total;
   a.frame_pose_T = h->d_frame_pose_T; a.max_poses = h->max_poses;
   rigid_inverse(h->T_world_frame, a.T_frame_world);
   a.prop = h->d_prop;
   a.cell_count = h->d_cell_count; a.cell_offset = h->d_cell_offset; a.cell_fill = h->d_cell_fill;
-  a.rec_ids = h->d_rec_ids; a.scan_tmp = h->d_scan_tmp; a.d_total = h->d_counters + 4;
-  a.map = h->d_map; a.d_num_fusion = h->d_counters + 3;
-  a.bucket = h->d_bucket; a.cell_list = h->d_cell_list; a.n_touched = h->d_counters + 6;
+  a.rec_ids = h->d_rec_ids; a.scan_tmp = h->d_scan_tmp_b; a.d_total = h->d_cnt_b + 4;
+  a.map = h->d_map; a.d_num_fusion = h->d_cnt_b + 3;
+  a.bucket = h->d_bucket; a.cell_list = h->d_cell_list; a.n_touched = h->d_cnt_b + 6;
   if (total > h->win_cap) FAIL(ESVO_ERR_CAPACITY, "window points exceed capacity");
-  hipEventRecord(h->evt[EV_FU0], h->stream);
-  launch_fuse(a, h->dp, h->stream);
-  hipEventRecord(h->evt[EV_FU1], h->stream);
+  const int o = par * EV_BACK_STRIDE;
+  hipEventRecord(h->evt[EV_FU0 + o], sb);
+  launch_fuse(a, h->dp, sb);
+  hipEventRecord(h->evt[EV_FU1 + o], sb);
   h->d_map_cur = h->d_map;
   const bool do_clean = h->prm.clean_requires_full_window ? (h->frames.size() >= (size_t)h->prm.max_fusion_frames) : true;
-  if (do_clean) launch_clean(h->d_map, h->dp, h->stream);
-  hipEventRecord(h->evt[EV_CL1], h->stream);
-  if (h->prm.regularization)  // the band's part of the neighbourhood view (exchanged between ranks when sharded)
-    launch_reg_view(h->d_map, h->d_map2, h->d_owner_max, h->d_owner_min, h->d_reg_valid, h->d_reg_ab, h->d_reg_cd,
-                    h->d_cell_list, h->d_counters + 7, h->dp, h->stream);
-  HIPCHK(hipGetLastError());
-  return ESVO_OK;
-}
-int run_regularize(esvo_context* h) {
+  if (do_clean) launch_clean(h->d_map, h->dp, sb);
+  hipEventRecord(h->evt[EV_CL1 + o], sb);
   if (h->prm.regularization) {
+    launch_reg_view(h->d_map, h->d_map2, h->d_owner_max, h->d_owner_min, h->d_reg_valid, h->d_reg_ab, h->d_reg_cd,
+                    h->d_cell_list, h->d_cnt_b + 7, h->dp, sb);
     launch_reg_apply(h->d_map, h->d_map2, h->d_owner_max, h->d_owner_min, h->d_reg_valid, h->d_reg_bits, h->d_reg_counts,
-                     h->d_reg_ab, h->d_reg_cd, h->d_cell_list, h->d_counters + 7,
-                     (u32)((size_t)(h->dp.band_y1 - h->dp.band_y0) * h->W), h->dp, h->stream);
+                     h->d_reg_ab, h->d_reg_cd, h->d_cell_list, h->d_cnt_b + 7,
+                     (u32)((size_t)(h->dp.band_y1 - h->dp.band_y0) * h->W), h->dp, sb);
     h->d_map_cur = h->d_map2;
   }
-  hipEventRecord(h->evt[EV_RG1], h->stream);
+  HIPCHK(hipMemcpyAsync(h->h_cnt_b + 8 * par, h->d_cnt_b, sizeof(u32) * 8, hipMemcpyDeviceToHost, sb));
+  hipEventRecord(h->evt[EV_RG1 + o], sb);  // also "back stage of this parity done"
   HIPCHK(hipGetLastError());
+  h->back_pending[par] = true;
   return ESVO_OK;
 }
 
 int export_map(esvo_context* h, std::vector<esvo_depth_point_t>& out, std::vector<u32>* cells) {
-  launch_map_compact(h->d_map_cur, h->d_exp_flags, h->d_exp_prefix, h->d_counters + 5, h->d_scan_tmp, h->d_export,
-                     h->d_export_cell, h->dp, h->stream);
-  int rc = read_counters(h);
+  launch_map_compact(h->d_map_cur, h->d_exp_flags, h->d_exp_prefix, h->d_cnt_b + 5, h->d_scan_tmp_b, h->d_export,
+                     h->d_export_cell, h->dp, h->stream_b);
+  int rc = read_counters_b(h, 2, true);
   if (rc) return rc;
-  const u32 n = h->h_counters[5];
+  const u32 n = h->h_cnt_b[8 * 2 + 5];
   out.resize(n);
   std::vector<u32> cell(n);
   if (n) {
@@ -532,6 +599,7 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
 #define CK(call) do { hipError_t _e = (call); if (_e != hipSuccess) { g_create_error = std::string(#call) + ": " + hipGetErrorString(_e); esvo_destroy(h); return ESVO_ERR_HIP; } } while (0)
   CK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   h->own_stream = true;
+  CK(hipStreamCreateWithFlags(&h->stream_b, hipStreamNonBlocking));
   // calibration -> device
   CK(dalloc(&h->d_lut, npx));
   CK(hipMemcpy(h->d_lut, left->rect_lut, sizeof(float2) * npx, hipMemcpyHostToDevice));
@@ -560,7 +628,9 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
   CK(dalloc(&h->d_T_world_obs, 16));
   h->max_poses = (u32)std::max(params->max_poses_per_tick, 2);
   CK(dalloc(&h->d_pose_sec, h->max_poses));
-  CK(dalloc(&h->d_pose_T, (size_t)h->max_poses * 16));
+  CK(dalloc(&h->d_pose_T2[0], (size_t)h->max_poses * 16));
+  CK(dalloc(&h->d_pose_T2[1], (size_t)h->max_poses * 16));
+  h->d_pose_T = h->d_pose_T2[0];
   h->max_ev = (u32)std::max(params->max_events_per_tick, params->process_event_num);
   if (h->max_ev > 4000000u) { g_create_error = "max_events_per_tick too large (scan limit 4M)"; esvo_destroy(h); return ESVO_ERR_CAPACITY; }
   if (npx > 4000000u) { g_create_error = "image too large (scan limit 4M pixels)"; esvo_destroy(h); return ESVO_ERR_CAPACITY; }
@@ -579,6 +649,11 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
   CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_counters), sizeof(u32) * 16));
   CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_pin), sizeof(double) * 2 * ((size_t)h->max_poses * 17 + 16)));
   CK(dalloc(&h->d_scan_tmp, scan_scratch_elems(std::max(E, npx)) + 8));
+  CK(dalloc(&h->d_scan_tmp_b, scan_scratch_elems(std::max(E, npx)) + 8));
+  CK(dalloc(&h->d_cnt_b, 8));
+  CK(hipMemset(h->d_cnt_b, 0, sizeof(u32) * 8));
+  CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_cnt_b), sizeof(u32) * 8 * 3));
+  std::memset(h->h_cnt_b, 0, sizeof(u32) * 8 * 3);
   // fusion window
   h->win_cap = (u32)std::max<int64_t>((int64_t)params->max_window_points, (int64_t)E) + (u32)E;
   CK(dalloc(&h->d_win, h->win_cap));
@@ -586,8 +661,8 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
   h->n_pose_slots = h->max_frames + 1;
   h->slot_used.assign(h->n_pose_slots, 0);
   CK(dalloc(&h->d_frame_pose_T, (size_t)h->n_pose_slots * h->max_poses * 16));
-  CK(dalloc(&h->d_fr_table, 3 * (size_t)h->max_frames + 1));
-  CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_fr_table), sizeof(u32) * (3 * (size_t)h->max_frames + 1)));
+  CK(dalloc(&h->d_fr_table, 2 * (3 * (size_t)h->max_frames + 1)));
+  CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_fr_table), sizeof(u32) * 2 * (3 * (size_t)h->max_frames + 1)));
   // map
   CK(dalloc(&h->d_prop, h->win_cap));
   CK(dalloc(&h->d_cell_count, npx));
@@ -636,9 +711,10 @@ int esvo_destroy(esvo_handle h) {
   if (!h) return ESVO_OK;
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
+  if (h->stream_b) hipStreamSynchronize(h->stream_b);
   void* ptrs[] = {h->d_lut, h->d_mask, h->d_fixmap[0], h->d_fixmap[1], h->d_sae[0], h->d_sae[1], h->d_raw, h->d_ts[0],
                   h->d_ts[1], h->d_ring[0], h->d_ring[1], h->d_obs[0], h->d_obs[1], h->d_obs_tmp, h->d_T_world_obs,
-                  h->d_pose_sec, h->d_pose_T, h->d_tick_ev, h->d_match_slots, h->d_match_flags, h->d_match_prefix,
+                  h->d_pose_sec, h->d_pose_T2[0], h->d_pose_T2[1], h->d_scan_tmp_b, h->d_cnt_b, h->d_tick_ev, h->d_match_slots, h->d_match_flags, h->d_match_prefix,
                   h->d_matches, h->d_pt_slots, h->d_pt_flags, h->d_pt_prefix, h->d_pts_tmp, h->d_counters, h->d_scan_tmp,
                   h->d_win, h->d_frame_pose_T, h->d_fr_table, h->d_prop, h->d_cell_count, h->d_cell_offset,
                   h->d_cell_fill, h->d_rec_ids, h->d_map, h->d_map2, h->d_owner_max, h->d_owner_min, h->d_exp_flags,
@@ -646,10 +722,12 @@ int esvo_destroy(esvo_handle h) {
                   h->d_reg_valid, h->d_reg_counts, h->d_sel, h->d_evmap};
   for (void* p : ptrs) if (p) hipFree(p);
   if (h->h_counters) hipHostFree(h->h_counters);
+  if (h->h_cnt_b) hipHostFree(h->h_cnt_b);
   if (h->h_pin) hipHostFree(h->h_pin);
   if (h->h_fr_table) hipHostFree(h->h_fr_table);
   if (h->evt_ok) for (int i = 0; i < EV_N; ++i) hipEventDestroy(h->evt[i]);
   if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+  if (h->stream_b) hipStreamDestroy(h->stream_b);
   delete h;
   return ESVO_OK;
 }
@@ -658,6 +736,8 @@ int esvo_reset(esvo_handle h) {
   if (!h) return ESVO_ERR_INVALID_ARG;
   HIPCHK(hipSetDevice(h->device));
   const size_t npx = (size_t)h->W * h->H;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream_b));
   for (int cam = 0; cam < 2; ++cam) {
     HIPCHK(hipMemsetAsync(h->d_sae[cam], 0, sizeof(u64) * npx, h->stream));
     h->ts_host[cam].clear();
@@ -671,8 +751,12 @@ int esvo_reset(esvo_handle h) {
   h->d_map_cur = h->d_map;
   h->obs_set = false;
   h->n_pose = 0;
-  std::memset(&h->stats, 0, sizeof(h->stats));
   HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream_b));
+  h->back_pending[0] = h->back_pending[1] = false;
+  h->ts_timing_pending[0] = h->ts_timing_pending[1] = false;
+  h->stats_pending = false;
+  std::memset(&h->stats, 0, sizeof(h->stats));
   return ESVO_OK;
 }
 
@@ -701,6 +785,7 @@ int esvo_set_params(esvo_handle h, const esvo_params_t* params) {
 int esvo_set_stream(esvo_handle h, void* hip_stream) {
   if (!h) return ESVO_ERR_INVALID_ARG;
   HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream_b));
   if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
   h->stream = reinterpret_cast<hipStream_t>(hip_stream);
   h->own_stream = false;
@@ -710,6 +795,7 @@ int esvo_set_stream(esvo_handle h, void* hip_stream) {
 int esvo_synchronize(esvo_handle h) {
   if (!h) return ESVO_ERR_INVALID_ARG;
   HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream_b));
   return ESVO_OK;
 }
 
@@ -749,7 +835,8 @@ int esvo_ts_render(esvo_handle h, int cam, uint64_t t_ns, uint8_t* out_mono8) {
   const auto& tsq = h->ts_host[cam];
   const size_t k = std::lower_bound(tsq.begin(), tsq.end(), (u64)t_ns) - tsq.begin();
   const u64 upto = h->ring_base[cam] + k;
-  hipEventRecord(h->evt[EV_SC0], h->stream);
+  const int evo = cam * EV_TS_STRIDE;
+  hipEventRecord(h->evt[EV_SC0 + evo], h->stream);
   if (upto > h->scattered[cam]) {
     u64 a = h->scattered[cam];
     const u64 total = upto - a;
@@ -762,13 +849,13 @@ int esvo_ts_render(esvo_handle h, int cam, uint64_t t_ns, uint8_t* out_mono8) {
     h->scattered[cam] = upto;
     h->stats.events_scattered[cam] += total;
   }
-  hipEventRecord(h->evt[EV_SC1], h->stream);
+  hipEventRecord(h->evt[EV_SC1 + evo], h->stream);
   launch_ts_render(h->d_sae[cam], h->d_fixmap[cam], h->d_raw, h->d_ts[cam], h->W, h->H, (u64)t_ns, h->prm.decay_ms / 1000.0,
                    h->prm.ignore_polarity, h->prm.median_blur_kernel_size, h->stream);
-  hipEventRecord(h->evt[EV_R1], h->stream);
+  hipEventRecord(h->evt[EV_R1 + evo], h->stream);
   HIPCHK(hipGetLastError());
   h->ts_valid[cam] = true;
-  h->ts_timing_pending = true;
+  h->ts_timing_pending[cam] = true;
   h->stats.ts_frames[cam]++;
   if (out_mono8) {
     HIPCHK(hipMemcpyAsync(out_mono8, h->d_ts[cam], (size_t)h->W * h->H, hipMemcpyDeviceToHost, h->stream));
@@ -877,10 +964,13 @@ int esvo_map_push_frame(esvo_handle h, const esvo_depth_point_t* pts, size_t n, 
   u32 off;
   int rc = window_reserve(h, (u32)n, &off);
   if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(h->stream_b));  // the ring space may have been read by a fusion still in flight
   if (n) HIPCHK(hipMemcpyAsync(h->d_win + off, pts, sizeof(esvo_depth_point_t) * n, hipMemcpyHostToDevice, h->stream));
-  rc = commit_frame(h, off, (u32)n, pose_T, (u32)m);
+  static const double ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  rc = commit_frame(h, off, (u32)n, m ? pose_T : ident, (u32)m);
   if (rc) return rc;
   HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream_b));
   return ESVO_OK;
 }
 
@@ -888,20 +978,21 @@ int esvo_map_fuse(esvo_handle h, size_t* n_fusions) {
   if (!h) return ESVO_ERR_INVALID_ARG;
   if (!h->obs_set) FAIL(ESVO_ERR_STATE, "esvo_map_set_observation has not been called");
   HIPCHK(hipSetDevice(h->device));
-  int rc = run_fuse(h);
+  int rc = back_after_front(h);
   if (rc) return rc;
-  rc = run_regularize(h);
+  const int par = h->par;
+  h->par ^= 1;
+  HIPCHK(hipEventSynchronize(h->evt[EV_RG1 + par * EV_BACK_STRIDE]));
+  collect_back(h, par);
+  rc = run_fuse(h, par);
   if (rc) return rc;
-  rc = read_counters(h);
-  if (rc) return rc;
-  h->stats.last_fusions = h->h_counters[3];
+  HIPCHK(hipStreamSynchronize(h->stream_b));
+  collect_back(h, par);
   h->stats.last_window_frames = (u32)h->frames.size();
   u32 np = 0;
   for (auto& f : h->frames) np += f.count;
   h->stats.last_window_points = np;
-  hipEventElapsedTime(&h->stats.ms_fusion, h->evt[EV_FU0], h->evt[EV_CL1]);
-  hipEventElapsedTime(&h->stats.ms_regularization, h->evt[EV_CL1], h->evt[EV_RG1]);
-  if (n_fusions) *n_fusions = h->h_counters[3];
+  if (n_fusions) *n_fusions = h->stats.last_fusions;
   return ESVO_OK;
 }
 
@@ -937,6 +1028,9 @@ int tick_phase0(esvo_context* h, uint64_t t_ns, const uint64_t* pose_t_ns, const
   rc = select_events(h, t_ns, &h->sh_first, &h->sh_n);
   if (rc) return rc;
   u32 n = h->sh_n;
+  // two ticks in flight at most: what this tick's front stage overwrites (ring space of popped frames, the pose
+  // table buffer) was last read by the back stage two ticks ago
+  HIPCHK(hipStreamWaitEvent(h->stream, h->evt[EV_RG1 + h->par * EV_BACK_STRIDE], 0));
   hipEventRecord(h->evt[EV_T0], h->stream);
   HIPCHK(hipMemsetAsync(h->d_counters, 0, sizeof(u32) * 16, h->stream));
   const u32* sel = nullptr;
@@ -1013,24 +1107,45 @@ int tick_phase1(esvo_context* h) {
   h->stats.last_matches = h->h_counters[0];
   h->stats.last_solved = h->h_counters[2];  // sharded: this rank's share
   h->stats.last_points = n_points;
+  h->stats.total_events_in += n;
+  h->stats.total_matches += h->h_counters[0];
+  h->stats.total_points += n_points;
   h->sh_points = n_points;
+  {  // the front stream is drained: its events of this tick (and the TS renders before it) are complete
+    esvo_stats_t& s = h->stats;
+    collect_ts_timing(h);
+    s.ms_bm = s.ms_refine = 0;
+    s.ms_kernel[2] = s.ms_kernel[3] = 0;
+    if (n) {
+      hipEventElapsedTime(&s.ms_bm, h->evt[EV_T0], h->evt[EV_S1]);
+      hipEventElapsedTime(&s.ms_refine, h->evt[EV_S1], h->evt[EV_S2]);
+      hipEventElapsedTime(&s.ms_kernel[2], h->evt[EV_BM0], h->evt[EV_BM1]);
+      hipEventElapsedTime(&s.ms_kernel[3], h->evt[EV_LM0], h->evt[EV_LM1]);
+      s.sum_ms_kernel[2] += s.ms_kernel[2];
+      s.sum_ms_kernel[3] += s.ms_kernel[3];
+    }
+  }
   if (h->sharded && n_points) {
     h->xchg_ptr = frame;
     h->xchg_bytes = (size_t)n_points * sizeof(DevPoint);
   }
   return ESVO_OK;
 }
-// phase 2: window policy, fusion + clean + regularisation of this band (halo rows recomputed locally).
-// Counters and HIP-event timings of the tick are read back lazily (finalize_tick_stats) so that the tick
-// path ends without a host synchronisation.
+// phase 2: window policy, fusion + clean + regularisation of this band (halo rows recomputed locally), enqueued on
+// the back stream behind the front stage of this tick.  Nothing here waits for the GPU except for the back stage
+// of two ticks ago (long finished), whose pinned table and event set are reused; its timings are collected then.
 int tick_phase2(esvo_context* h) {
   h->xchg_ptr = nullptr;
   h->xchg_bytes = 0;
-  int rc = commit_frame(h, h->sh_off, h->sh_points, h->h_pose_T.data(), h->n_pose);
+  int rc = back_after_front(h);  // sharded: the caller's frame sum was issued on the front stream before this call
   if (rc) return rc;
-  rc = run_fuse(h);
+  const int par = h->par;
+  h->par ^= 1;
+  HIPCHK(hipEventSynchronize(h->evt[EV_RG1 + par * EV_BACK_STRIDE]));
+  collect_back(h, par);
+  rc = commit_frame(h, h->sh_off, h->sh_points, nullptr, h->n_pose);
   if (rc) return rc;
-  rc = run_regularize(h);
+  rc = run_fuse(h, par);
   if (rc) return rc;
   h->stats.ticks++;
   h->stats.last_window_frames = (u32)h->frames.size();
@@ -1040,29 +1155,17 @@ int tick_phase2(esvo_context* h) {
   h->stats_pending = true;
   return ESVO_OK;
 }
+// drain the back stream and collect what is pending (older parity first)
 int finalize_tick_stats(esvo_context* h) {
-  if (!h->stats_pending) return ESVO_OK;
+  if (!h->stats_pending && !h->back_pending[0] && !h->back_pending[1]) return ESVO_OK;
+  const bool tick_done = h->stats_pending;
   h->stats_pending = false;
-  int rc = read_counters(h);
-  if (rc) return rc;
-  const u32 n = h->sh_n;
-  esvo_stats_t& s = h->stats;
-  s.last_fusions = h->h_counters[3];
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream_b));
   collect_ts_timing(h);
-  s.ms_bm = s.ms_refine = 0;
-  s.ms_kernel[2] = s.ms_kernel[3] = 0;
-  if (n) {
-    hipEventElapsedTime(&s.ms_bm, h->evt[EV_T0], h->evt[EV_S1]);
-    hipEventElapsedTime(&s.ms_refine, h->evt[EV_S1], h->evt[EV_S2]);
-    hipEventElapsedTime(&s.ms_kernel[2], h->evt[EV_BM0], h->evt[EV_BM1]);
-    hipEventElapsedTime(&s.ms_kernel[3], h->evt[EV_LM0], h->evt[EV_LM1]);
-  }
-  hipEventElapsedTime(&s.ms_fusion, h->evt[EV_FU0], h->evt[EV_CL1]);
-  hipEventElapsedTime(&s.ms_regularization, h->evt[EV_CL1], h->evt[EV_RG1]);
-  hipEventElapsedTime(&s.ms_kernel[4], h->evt[EV_FU0], h->evt[EV_FU1]);
-  hipEventElapsedTime(&s.ms_kernel[5], h->evt[EV_FU1], h->evt[EV_CL1]);
-  hipEventElapsedTime(&s.ms_kernel[6], h->evt[EV_CL1], h->evt[EV_RG1]);
-  hipEventElapsedTime(&s.ms_tick_total, h->evt[EV_T0], h->evt[EV_RG1]);
+  collect_back(h, h->par);
+  collect_back(h, h->par ^ 1);
+  if (tick_done) hipEventElapsedTime(&h->stats.ms_tick_total, h->evt[EV_T0], h->evt[EV_RG1 + (h->par ^ 1) * EV_BACK_STRIDE]);
   return ESVO_OK;
 }
 }  // namespace

@@ -172,6 +172,14 @@ typedef struct esvo_stats_t {
    * [0] ts_scatter [1] ts_decay+median_remap [2] bm_match [3] lm_refine
    * [4] propagate+bucket+fuse_cells [5] clean [6] regularize [7] reserved */
   float ms_kernel[8];
+  float pad_;
+  /* Running totals over all ticks since esvo_create / esvo_reset.  A throughput loop reads them once at its
+   * end: esvo_get_stats drains both streams, so calling it after every tick serialises the overlap of one
+   * tick's fusion stage with the next tick's matching stage. */
+  uint64_t total_events_in;
+  uint64_t total_matches;
+  uint64_t total_points;
+  double sum_ms_kernel[8];      /* same slots as ms_kernel; [7] = launches of ts kernels summed in [0],[1] */
 } esvo_stats_t;
 
 /* ---- lifecycle -------------------------------------------------------------------- */
