@@ -175,6 +175,8 @@ def main():
         dt = float(tt.item())
 
     kavg = ksum / max(K, 1)
+    if ksum[7] > 0:  # TS kernels: per-render samples (some are skipped while their events are in flight), two renders per tick
+        kavg[0], kavg[1] = 2 * ksum[0] / ksum[7], 2 * ksum[1] / ksum[7]
     # roofline of the dominant single kernel (slots 2 = bm_match_kernel, 3 = lm_refine_kernel; the fuse / regularize
     # slots are stages of several kernels and, like every slot, include the slowdown from the other stream's kernels)
     dom = 2 + int(np.argmax(kavg[2:4]))

@@ -22,9 +22,11 @@ thread_local std::string g_create_error;
 }
 
 // front-stage events live on the front stream; the back-stage set exists once per tick parity (two ticks in flight)
-enum { EV_SC0 = 0, EV_SC1, EV_R1, EV_SC0b, EV_SC1b, EV_R1b, EV_T0, EV_BM0, EV_BM1, EV_S1, EV_LM0, EV_LM1, EV_S2, EV_FRAME,
+enum { EV_SC0 = 0, EV_SC1, EV_R1, EV_SC0b, EV_SC1b, EV_R1b, EV_FRAME,
+       EV_T0, EV_BM0, EV_BM1, EV_S1, EV_LM0, EV_LM1, EV_S2, EV_CNT, EV_T0b, EV_BM0b, EV_BM1b, EV_S1b, EV_LM0b, EV_LM1b, EV_S2b, EV_CNTb,
        EV_FU0, EV_FU1, EV_CL1, EV_RG1, EV_POSE, EV_FU0b, EV_FU1b, EV_CL1b, EV_RG1b, EV_POSEb, EV_N };
 constexpr int EV_BACK_STRIDE = EV_FU0b - EV_FU0;  // evt[EV_x + par * EV_BACK_STRIDE]
+constexpr int EV_FRONT_STRIDE = EV_T0b - EV_T0;   // evt[EV_x + fpar * EV_FRONT_STRIDE]
 constexpr int EV_TS_STRIDE = EV_SC0b - EV_SC0;    // evt[EV_x + cam * EV_TS_STRIDE]
 
 struct FrameRec {
@@ -137,10 +139,19 @@ struct esvo_context {
   size_t codes_bytes = 0;
   void* xchg_ptr = nullptr;       // what the caller must sum across the ranks before the next phase
   size_t xchg_bytes = 0;
-  uint8_t* d_reg_valid = nullptr; // regulariser view: 1 byte per cell
+  u64* d_reg_valid = nullptr;     // regulariser view: 1 bit per cell
   bool sharded = false;
   u32 reg_words = 0;
-  u32 sh_n = 0, sh_off = 0, sh_points = 0;  // state carried between the phases of a tick
+  // A tick's state between its phases.  Unsharded ticks are finished lazily: esvo_map_tick(k) enqueues the front
+  // stage of tick k and only then completes tick k-1 (point count -> window policy -> back stage), so the host
+  // never waits on the front stream while it still has work to enqueue there.
+  struct TickState {
+    u32 n = 0, off = 0, points = 0, n_pose = 0;
+    int pose_buf = 0;
+    double T_world_obs[16];
+  } tk[2];
+  int fpar = 0;                   // parity of the newest front stage
+  bool tick_pending = false;      // tk[fpar] has its front stage enqueued but is not committed yet
   u64 sh_first = 0;
   u32* d_cell_list = nullptr;
   u64* d_reg_bits = nullptr;    // close-neighbour masks of the regulariser scan: [elements][words]
@@ -159,6 +170,10 @@ struct esvo_context {
   esvo_stats_t stats;
   bool ts_timing_pending[2] = {false, false};
 };
+
+namespace {
+int flush_pending_tick(esvo_context* h);  // completes a lazily finished tick (see TickState)
+}
 
 #define HIPCHK(call)                                                                              \
   do {                                                                                            \
@@ -199,7 +214,7 @@ int validate_params(const esvo_params_t* p, std::string& why) {
   if (p->td_nu <= 2.0 || p->td_scale <= 0) { why = "Tdist_nu must be > 2 and Tdist_scale > 0"; return ESVO_ERR_INVALID_ARG; }
   if (p->num_threads < 1 || p->num_threads > 64) { why = "num_threads out of range"; return ESVO_ERR_INVALID_ARG; }
   if (p->lm_max_iteration < 1) { why = "lm_max_iteration must be >= 1"; return ESVO_ERR_INVALID_ARG; }
-  if (p->reg_radius < 0 || p->reg_radius > 64) { why = "RegularizationRadius out of range [0,64]"; return ESVO_ERR_INVALID_ARG; }
+  if (p->reg_radius < 0 || p->reg_radius > 31) { why = "RegularizationRadius out of range [0,31] (one 64-bit mask per tap row)"; return ESVO_ERR_INVALID_ARG; }
   return ESVO_OK;
 }
 
@@ -287,9 +302,9 @@ int run_bm(esvo_context* h, const esvo_event_t* d_ev, u64 first, u64 cap, int re
   a.lut = h->d_lut; a.mask = h->d_mask;
   a.pose_sec = h->d_pose_sec; a.n_pose = h->n_pose;
   a.out_slots = h->d_match_slots; a.out_flags = h->d_match_flags;
-  hipEventRecord(h->evt[EV_BM0], h->stream);
+  hipEventRecord(h->evt[EV_BM0 + h->fpar * EV_FRONT_STRIDE], h->stream);
   launch_bm_match(a, h->dp, h->stream);
-  hipEventRecord(h->evt[EV_BM1], h->stream);
+  hipEventRecord(h->evt[EV_BM1 + h->fpar * EV_FRONT_STRIDE], h->stream);
   HIPCHK(hipGetLastError());
   return ESVO_OK;
 }
@@ -299,7 +314,7 @@ int run_order_matches(esvo_context* h, u32 n, bool local) {
   launch_exclusive_scan_u32(h->d_match_flags, h->d_match_prefix, h->d_counters + (local ? 8 : 0), h->d_scan_tmp, n, h->stream);
   launch_compact_matches(h->d_match_slots, h->d_match_flags, h->d_match_prefix, n, h->d_matches, local ? h->d_own_w : nullptr,
                          h->stream);
-  hipEventRecord(h->evt[EV_S1], h->stream);
+  hipEventRecord(h->evt[EV_S1 + h->fpar * EV_FRONT_STRIDE], h->stream);
   HIPCHK(hipGetLastError());
   return ESVO_OK;
 }
@@ -319,9 +334,9 @@ int run_lm(esvo_context* h, u32 max_matches, int cull, bool dense) {
   a.tsL = h->d_obs[0]; a.tsR = h->d_obs[1];
   a.pose_T = h->d_pose_T; a.T_world_obs = h->d_T_world_obs;
   a.out_slots = h->d_pt_slots; a.out_flags = flags; a.cull = cull; a.dense = dense ? 1 : 0;
-  hipEventRecord(h->evt[EV_LM0], h->stream);
+  hipEventRecord(h->evt[EV_LM0 + h->fpar * EV_FRONT_STRIDE], h->stream);
   launch_lm_refine(a, h->dp, h->d_counters + 2, h->stream);
-  hipEventRecord(h->evt[EV_LM1], h->stream);
+  hipEventRecord(h->evt[EV_LM1 + h->fpar * EV_FRONT_STRIDE], h->stream);
   HIPCHK(hipGetLastError());
   return ESVO_OK;
 }
@@ -329,7 +344,7 @@ int run_lm(esvo_context* h, u32 max_matches, int cull, bool dense) {
 int run_order_points(esvo_context* h, u32 max_matches, DevPoint* dst) {
   launch_exclusive_scan_u32(h->d_pt_flags, h->d_pt_prefix, h->d_counters + 1, h->d_scan_tmp, max_matches, h->stream);
   launch_compact_points(h->d_pt_slots, h->d_pt_flags, h->d_pt_prefix, h->d_counters + 0, max_matches, dst, h->stream);
-  hipEventRecord(h->evt[EV_S2], h->stream);
+  hipEventRecord(h->evt[EV_S2 + h->fpar * EV_FRONT_STRIDE], h->stream);
   HIPCHK(hipGetLastError());
   return ESVO_OK;
 }
@@ -339,11 +354,10 @@ int run_refine(esvo_context* h, u32 max_matches, int cull, DevPoint* dst) {
   return run_order_points(h, max_matches, dst);
 }
 
-// Time-Surface kernel timings of the last render of each camera (their events are complete: call after a
-// synchronisation of the front stream)
-void collect_ts_timing(esvo_context* h) {
+// Time-Surface kernel timings of the last render of a camera (-1: both); the caller knows their events are complete
+void collect_ts_timing(esvo_context* h, int only = -1) {
   for (int cam = 0; cam < 2; ++cam) {
-    if (!h->ts_timing_pending[cam]) continue;
+    if (!h->ts_timing_pending[cam] || (only >= 0 && cam != only)) continue;
     h->ts_timing_pending[cam] = false;
     const int o = cam * EV_TS_STRIDE;
     float sc = 0, rd = 0;
@@ -393,19 +407,23 @@ void collect_back(esvo_context* h, int par) {
   s.sum_ms_kernel[4] += fu; s.sum_ms_kernel[5] += cl; s.sum_ms_kernel[6] += rg;
 }
 
-// place a frame of up to n points in the window ring (frames stay contiguous)
+// place a frame of up to n points in the window ring (frames stay contiguous).  The occupied region runs from
+// the oldest frame to the newest reservation -- which is the pending tick's worst-case reservation if there is one.
 int window_reserve(esvo_context* h, u32 n, u32* off_out) {
   u32 off = 0;
-  if (!h->frames.empty()) {
-    const FrameRec& back = h->frames.back();
-    const FrameRec& front = h->frames.front();
-    u32 tail = back.off + back.count;
-    if (tail >= front.off + 0 && back.off >= front.off) {  // not wrapped: [front.off, tail)
+  const bool pend = h->tick_pending && !h->sharded;
+  const esvo_context::TickState& pk = h->tk[h->fpar ^ 1];  // called for tk[fpar]; the pending one is the other
+  if (!h->frames.empty() || pend) {
+    const u32 back_off = pend ? pk.off : h->frames.back().off;
+    const u32 back_cnt = pend ? pk.n : h->frames.back().count;
+    const u32 front_off = h->frames.empty() ? back_off : h->frames.front().off;
+    const u32 tail = back_off + back_cnt;
+    if (back_off >= front_off) {  // not wrapped: [front_off, tail)
       if (tail + n <= h->win_cap) off = tail;
-      else if (n <= front.off) off = 0;
+      else if (n <= front_off) off = 0;
       else FAIL(ESVO_ERR_CAPACITY, "fusion window ring full (raise max_window_points)");
-    } else {  // wrapped: free space is [tail, front.off)
-      if (tail + n <= front.off) off = tail;
+    } else {  // wrapped: free space is [tail, front_off)
+      if (tail + n <= front_off) off = tail;
       else FAIL(ESVO_ERR_CAPACITY, "fusion window ring full (raise max_window_points)");
     }
   } else if (n > h->win_cap) {
@@ -435,7 +453,7 @@ void apply_window_policy(esvo_context* h) {
 }
 
 // pose table of the frame: from the host (stage-wise API) or, in a tick, the front stage's device table
-int commit_frame(esvo_context* h, u32 off, u32 count, const double* pose_T_host, u32 m) {
+int commit_frame(esvo_context* h, u32 off, u32 count, const double* pose_T_host, u32 m, int pose_buf = 0) {
   u32 slot;
   int rc = alloc_pose_slot(h, &slot);
   if (rc) return rc;
@@ -444,8 +462,8 @@ int commit_frame(esvo_context* h, u32 off, u32 count, const double* pose_T_host,
     if (pose_T_host) {
       HIPCHK(hipMemcpyAsync(dst, pose_T_host, sizeof(double) * 16 * m, hipMemcpyHostToDevice, h->stream_b));
     } else {
-      HIPCHK(hipMemcpyAsync(dst, h->d_pose_T, sizeof(double) * 16 * m, hipMemcpyDeviceToDevice, h->stream_b));
-      HIPCHK(hipEventRecord(h->evt[EV_POSE + h->pose_buf * EV_BACK_STRIDE], h->stream_b));
+      HIPCHK(hipMemcpyAsync(dst, h->d_pose_T2[pose_buf], sizeof(double) * 16 * m, hipMemcpyDeviceToDevice, h->stream_b));
+      HIPCHK(hipEventRecord(h->evt[EV_POSE + pose_buf * EV_BACK_STRIDE], h->stream_b));
     }
   }
   h->frames.push_back(FrameRec{off, count, slot});
@@ -456,7 +474,7 @@ int commit_frame(esvo_context* h, u32 off, u32 count, const double* pose_T_host,
 
 // fusion loop + clean + regularisation on the current window, on the back stream; `par` selects the
 // pinned frame table and the event set (two ticks may be in flight)
-int run_fuse(esvo_context* h, int par) {
+int run_fuse(esvo_context* h, int par, const double* T_world_obs) {
   // frames newest -> oldest (esvo_Mapping.cpp:372-377)
   const u32 nf = (u32)h->frames.size();
   const size_t tab = 3 * (size_t)h->max_frames + 1;
@@ -473,7 +491,7 @@ int run_fuse(esvo_context* h, int par) {
   hipStream_t sb = h->stream_b;
   u32* dtab = h->d_fr_table + (size_t)par * tab;
   HIPCHK(hipMemcpyAsync(dtab, cum, sizeof(u32) * tab, hipMemcpyHostToDevice, sb));
-  std::memcpy(h->T_world_frame, h->T_world_obs, sizeof(double) * 16);  // new DepthFrame at the TS pose (:268-272)
+  std::memcpy(h->T_world_frame, T_world_obs, sizeof(double) * 16);  // new DepthFrame at the TS pose (:268-272)
   FuseArgs a;
   a.win = h->d_win;
   a.fr_cum = dtab; a.fr_off = dtab + (h->max_frames + 1); a.fr_slot = a.fr_off + h->max_frames;
@@ -646,7 +664,8 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
   CK(dalloc(&h->d_pts_tmp, E));
   CK(dalloc(&h->d_counters, 16));
   CK(hipMemset(h->d_counters, 0, sizeof(u32) * 16));
-  CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_counters), sizeof(u32) * 16));
+  CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_counters), sizeof(u32) * 16 * 2));
+  std::memset(h->h_counters, 0, sizeof(u32) * 16 * 2);
   CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_pin), sizeof(double) * 2 * ((size_t)h->max_poses * 17 + 16)));
   CK(dalloc(&h->d_scan_tmp, scan_scratch_elems(std::max(E, npx)) + 8));
   CK(dalloc(&h->d_scan_tmp_b, scan_scratch_elems(std::max(E, npx)) + 8));
@@ -655,7 +674,7 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
   CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_cnt_b), sizeof(u32) * 8 * 3));
   std::memset(h->h_cnt_b, 0, sizeof(u32) * 8 * 3);
   // fusion window
-  h->win_cap = (u32)std::max<int64_t>((int64_t)params->max_window_points, (int64_t)E) + (u32)E;
+  h->win_cap = (u32)std::max<int64_t>((int64_t)params->max_window_points, (int64_t)E) + 2 * (u32)E;  // + new and pending frame
   CK(dalloc(&h->d_win, h->win_cap));
   h->max_frames = (u32)std::max(params->max_fusion_frames + 2, 512);
   h->n_pose_slots = h->max_frames + 1;
@@ -683,12 +702,11 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
   CK(dalloc(&h->d_codes, h->codes_bytes));
   CK(dalloc(&h->d_sel, E));
   CK(dalloc(&h->d_evmap, npx + 64));
-  CK(dalloc(&h->d_reg_valid, npx + 64));
-  CK(hipMemset(h->d_reg_valid, 0, npx + 64));
+  CK(dalloc(&h->d_reg_valid, npx / 64 + 8));
+  CK(hipMemset(h->d_reg_valid, 0, sizeof(u64) * (npx / 64 + 8)));
   CK(dalloc(&h->d_cell_list, npx));
   {
-    const int wn = 2 * std::max(params->reg_radius, 1) + 1;
-    h->reg_words = (u32)((wn * wn + 63) / 64);
+    h->reg_words = (u32)(2 * std::max(params->reg_radius, 1) + 1);  // one mask per tap row and element
     CK(dalloc(&h->d_reg_bits, npx * (size_t)h->reg_words));
     CK(dalloc(&h->d_reg_counts, 2 * npx));
   }
@@ -735,6 +753,7 @@ int esvo_destroy(esvo_handle h) {
 int esvo_reset(esvo_handle h) {
   if (!h) return ESVO_ERR_INVALID_ARG;
   HIPCHK(hipSetDevice(h->device));
+  { int rcp = flush_pending_tick(h); if (rcp) return rcp; }
   const size_t npx = (size_t)h->W * h->H;
   HIPCHK(hipStreamSynchronize(h->stream));
   HIPCHK(hipStreamSynchronize(h->stream_b));
@@ -762,14 +781,14 @@ int esvo_reset(esvo_handle h) {
 
 int esvo_set_params(esvo_handle h, const esvo_params_t* params) {
   if (!h || !params) return ESVO_ERR_INVALID_ARG;
+  { int rcp = flush_pending_tick(h); if (rcp) return rcp; }
   std::string why;
   int rc = validate_params(params, why);
   if (rc) FAIL(rc, why);
   if ((u32)std::max(params->max_events_per_tick, params->process_event_num) > h->max_ev)
     FAIL(ESVO_ERR_CAPACITY, "process_event_num exceeds the capacity fixed at esvo_create");
   {
-    const int wn = 2 * std::max(params->reg_radius, 1) + 1;
-    if ((u32)((wn * wn + 63) / 64) > h->reg_words) FAIL(ESVO_ERR_CAPACITY, "RegularizationRadius exceeds the capacity fixed at esvo_create");
+    if ((u32)(2 * std::max(params->reg_radius, 1) + 1) > h->reg_words) FAIL(ESVO_ERR_CAPACITY, "RegularizationRadius exceeds the capacity fixed at esvo_create");
   }
   esvo_params_t np = *params;
   np.max_events_per_tick = h->prm.max_events_per_tick;
@@ -784,6 +803,7 @@ int esvo_set_params(esvo_handle h, const esvo_params_t* params) {
 
 int esvo_set_stream(esvo_handle h, void* hip_stream) {
   if (!h) return ESVO_ERR_INVALID_ARG;
+  { int rcp = flush_pending_tick(h); if (rcp) return rcp; }
   HIPCHK(hipStreamSynchronize(h->stream));
   HIPCHK(hipStreamSynchronize(h->stream_b));
   if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
@@ -794,6 +814,7 @@ int esvo_set_stream(esvo_handle h, void* hip_stream) {
 
 int esvo_synchronize(esvo_handle h) {
   if (!h) return ESVO_ERR_INVALID_ARG;
+  { int rcp = flush_pending_tick(h); if (rcp) return rcp; }
   HIPCHK(hipStreamSynchronize(h->stream));
   HIPCHK(hipStreamSynchronize(h->stream_b));
   return ESVO_OK;
@@ -836,6 +857,7 @@ int esvo_ts_render(esvo_handle h, int cam, uint64_t t_ns, uint8_t* out_mono8) {
   const size_t k = std::lower_bound(tsq.begin(), tsq.end(), (u64)t_ns) - tsq.begin();
   const u64 upto = h->ring_base[cam] + k;
   const int evo = cam * EV_TS_STRIDE;
+  if (h->ts_timing_pending[cam] && hipEventQuery(h->evt[EV_R1 + evo]) == hipSuccess) collect_ts_timing(h, cam);
   hipEventRecord(h->evt[EV_SC0 + evo], h->stream);
   if (upto > h->scattered[cam]) {
     u64 a = h->scattered[cam];
@@ -907,6 +929,7 @@ int esvo_map_match(esvo_handle h, const esvo_event_t* ev, size_t n, const uint64
   if (!h->obs_set) FAIL(ESVO_ERR_STATE, "esvo_map_set_observation has not been called");
   if (n > h->max_ev) FAIL(ESVO_ERR_CAPACITY, "more events than max_events_per_tick");
   HIPCHK(hipSetDevice(h->device));
+  { int rcp = flush_pending_tick(h); if (rcp) return rcp; }
   if (pose_t_ns) { int rc = upload_poses(h, pose_t_ns, pose_T, m); if (rc) return rc; }
   *n_out = 0;
   if (n == 0) { HIPCHK(hipMemsetAsync(h->d_counters, 0, sizeof(u32), h->stream)); return ESVO_OK; }
@@ -934,6 +957,7 @@ int esvo_map_refine(esvo_handle h, const esvo_match_t* matches, size_t n, int cu
   for (size_t i = 0; i < n; ++i)
     if (matches[i].pose_idx >= h->n_pose) FAIL(ESVO_ERR_INVALID_ARG, "match refers to a pose outside the pose table");
   HIPCHK(hipSetDevice(h->device));
+  { int rcp = flush_pending_tick(h); if (rcp) return rcp; }
   *n_out = 0;
   if (n == 0) return ESVO_OK;
   const u32 n32 = (u32)n;
@@ -961,6 +985,7 @@ int esvo_map_push_frame(esvo_handle h, const esvo_depth_point_t* pts, size_t n, 
   for (size_t i = 0; i < n; ++i)
     if (pts[i].pose_idx >= m) FAIL(ESVO_ERR_INVALID_ARG, "depth point refers to a pose outside the frame's pose table");
   HIPCHK(hipSetDevice(h->device));
+  { int rcp = flush_pending_tick(h); if (rcp) return rcp; }
   u32 off;
   int rc = window_reserve(h, (u32)n, &off);
   if (rc) return rc;
@@ -978,13 +1003,14 @@ int esvo_map_fuse(esvo_handle h, size_t* n_fusions) {
   if (!h) return ESVO_ERR_INVALID_ARG;
   if (!h->obs_set) FAIL(ESVO_ERR_STATE, "esvo_map_set_observation has not been called");
   HIPCHK(hipSetDevice(h->device));
+  { int rcp = flush_pending_tick(h); if (rcp) return rcp; }
   int rc = back_after_front(h);
   if (rc) return rc;
   const int par = h->par;
   h->par ^= 1;
   HIPCHK(hipEventSynchronize(h->evt[EV_RG1 + par * EV_BACK_STRIDE]));
   collect_back(h, par);
-  rc = run_fuse(h, par);
+  rc = run_fuse(h, par, h->T_world_obs);
   if (rc) return rc;
   HIPCHK(hipStreamSynchronize(h->stream_b));
   collect_back(h, par);
@@ -1021,17 +1047,22 @@ int select_events(esvo_context* h, uint64_t t_ns, u64* first_out, u32* n_out) {
   return ESVO_OK;
 }
 
-// phase 0: poses, event selection, block matching of the events of this handle's band
+// phase 0 (front stage): poses, event selection, block matching + LM of the events of this handle's shard
 int tick_phase0(esvo_context* h, uint64_t t_ns, const uint64_t* pose_t_ns, const double* pose_T, size_t m) {
   int rc = upload_poses(h, pose_t_ns, pose_T, m);
   if (rc) return rc;
-  rc = select_events(h, t_ns, &h->sh_first, &h->sh_n);
+  u32 n = 0;
+  rc = select_events(h, t_ns, &h->sh_first, &n);
   if (rc) return rc;
-  u32 n = h->sh_n;
+  h->fpar ^= 1;
+  esvo_context::TickState& tk = h->tk[h->fpar];
+  tk.n = n; tk.off = 0; tk.points = 0;
+  tk.pose_buf = h->pose_buf; tk.n_pose = h->n_pose;
+  std::memcpy(tk.T_world_obs, h->T_world_obs, sizeof(double) * 16);
   // two ticks in flight at most: what this tick's front stage overwrites (ring space of popped frames, the pose
   // table buffer) was last read by the back stage two ticks ago
   HIPCHK(hipStreamWaitEvent(h->stream, h->evt[EV_RG1 + h->par * EV_BACK_STRIDE], 0));
-  hipEventRecord(h->evt[EV_T0], h->stream);
+  hipEventRecord(h->evt[EV_T0 + h->fpar * EV_FRONT_STRIDE], h->stream);
   HIPCHK(hipMemsetAsync(h->d_counters, 0, sizeof(u32) * 16, h->stream));
   const u32* sel = nullptr;
   if (h->prm.denoising && n) {
@@ -1042,7 +1073,7 @@ int tick_phase0(esvo_context* h, uint64_t t_ns, const uint64_t* pose_t_ns, const
     launch_denoise_select(h->d_match_flags, h->d_match_prefix, n, h->d_sel, h->stream);
     rc = read_counters(h);
     if (rc) return rc;
-    n = h->sh_n = h->h_counters[5];
+    n = tk.n = h->h_counters[5];
     sel = h->d_sel;
   }
   h->xchg_ptr = nullptr;
@@ -1073,16 +1104,17 @@ int tick_phase0(esvo_context* h, uint64_t t_ns, const uint64_t* pose_t_ns, const
     h->xchg_ptr = h->d_codes;
     h->xchg_bytes = nb;
   }
-  h->stats.last_events_in = n;
   return ESVO_OK;
 }
-// phase 1: the tick's frame (culled points in the reference's order) goes straight into the window ring
-// (capacity for the worst case: n points); one small D2H per tick for the point count the window policy needs
-int tick_phase1(esvo_context* h) {
-  const u32 n = h->sh_n;
-  int rc = window_reserve(h, n, &h->sh_off);
+// phase 1a (front stage, enqueue only): the tick's frame (culled points in the reference's order) goes straight
+// into the window ring (capacity for the worst case: n points); the counters follow into the pinned row of the
+// tick's parity and EV_CNT marks "frame and counters ready"
+int tick_phase1_enqueue(esvo_context* h) {
+  esvo_context::TickState& tk = h->tk[h->fpar];
+  const u32 n = tk.n;
+  int rc = window_reserve(h, n, &tk.off);
   if (rc) return rc;
-  DevPoint* frame = h->d_win + h->sh_off;
+  DevPoint* frame = h->d_win + tk.off;
   h->xchg_ptr = nullptr;
   h->xchg_bytes = 0;
   if (n && !h->sharded) {
@@ -1098,54 +1130,69 @@ int tick_phase1(esvo_context* h) {
     launch_exclusive_scan_u32(h->d_pt_flags, h->d_pt_prefix, h->d_counters + 1, h->d_scan_tmp, n, h->stream);
     launch_shard_place(h->d_own_w, h->d_lkeep, h->d_pt_slots, h->d_counters + 8, own, h->d_match_prefix, h->d_counters + 0,
                        h->d_pt_prefix, h->d_counters + 1, T, frame, n, h->stream);
-    hipEventRecord(h->evt[EV_S2], h->stream);
+    hipEventRecord(h->evt[EV_S2 + h->fpar * EV_FRONT_STRIDE], h->stream);
     HIPCHK(hipGetLastError());
   }
-  rc = read_counters(h);
-  if (rc) return rc;
-  const u32 n_points = n ? h->h_counters[1] : 0;
-  h->stats.last_matches = h->h_counters[0];
-  h->stats.last_solved = h->h_counters[2];  // sharded: this rank's share
-  h->stats.last_points = n_points;
-  h->stats.total_events_in += n;
-  h->stats.total_matches += h->h_counters[0];
-  h->stats.total_points += n_points;
-  h->sh_points = n_points;
-  {  // the front stream is drained: its events of this tick (and the TS renders before it) are complete
-    esvo_stats_t& s = h->stats;
-    collect_ts_timing(h);
-    s.ms_bm = s.ms_refine = 0;
-    s.ms_kernel[2] = s.ms_kernel[3] = 0;
-    if (n) {
-      hipEventElapsedTime(&s.ms_bm, h->evt[EV_T0], h->evt[EV_S1]);
-      hipEventElapsedTime(&s.ms_refine, h->evt[EV_S1], h->evt[EV_S2]);
-      hipEventElapsedTime(&s.ms_kernel[2], h->evt[EV_BM0], h->evt[EV_BM1]);
-      hipEventElapsedTime(&s.ms_kernel[3], h->evt[EV_LM0], h->evt[EV_LM1]);
-      s.sum_ms_kernel[2] += s.ms_kernel[2];
-      s.sum_ms_kernel[3] += s.ms_kernel[3];
-    }
+  HIPCHK(hipMemcpyAsync(h->h_counters + 16 * h->fpar, h->d_counters, sizeof(u32) * 16, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipEventRecord(h->evt[EV_CNT + h->fpar * EV_FRONT_STRIDE], h->stream));
+  h->tick_pending = true;
+  return ESVO_OK;
+}
+// phase 1b (host): wait for the counters of the tick of parity fp (one small D2H per tick: the window policy
+// needs the point count), book-keeping, front-stage timings
+int tick_phase1_collect(esvo_context* h, int fp) {
+  esvo_context::TickState& tk = h->tk[fp];
+  HIPCHK(hipEventSynchronize(h->evt[EV_CNT + fp * EV_FRONT_STRIDE]));
+  const u32* cnt = h->h_counters + 16 * fp;
+  const u32 n = tk.n;
+  const u32 n_points = n ? cnt[1] : 0;
+  esvo_stats_t& s = h->stats;
+  s.last_events_in = n;
+  s.last_matches = cnt[0];
+  s.last_solved = cnt[2];  // sharded: this rank's share
+  s.last_points = n_points;
+  s.total_events_in += n;
+  s.total_matches += cnt[0];
+  s.total_points += n_points;
+  tk.points = n_points;
+  const int o = fp * EV_FRONT_STRIDE;
+  s.ms_bm = s.ms_refine = 0;
+  s.ms_kernel[2] = s.ms_kernel[3] = 0;
+  if (n) {
+    hipEventElapsedTime(&s.ms_bm, h->evt[EV_T0 + o], h->evt[EV_S1 + o]);
+    hipEventElapsedTime(&s.ms_refine, h->evt[EV_S1 + o], h->evt[EV_S2 + o]);
+    hipEventElapsedTime(&s.ms_kernel[2], h->evt[EV_BM0 + o], h->evt[EV_BM1 + o]);
+    hipEventElapsedTime(&s.ms_kernel[3], h->evt[EV_LM0 + o], h->evt[EV_LM1 + o]);
+    s.sum_ms_kernel[2] += s.ms_kernel[2];
+    s.sum_ms_kernel[3] += s.ms_kernel[3];
   }
   if (h->sharded && n_points) {
-    h->xchg_ptr = frame;
+    h->xchg_ptr = h->d_win + tk.off;
     h->xchg_bytes = (size_t)n_points * sizeof(DevPoint);
   }
   return ESVO_OK;
 }
-// phase 2: window policy, fusion + clean + regularisation of this band (halo rows recomputed locally), enqueued on
-// the back stream behind the front stage of this tick.  Nothing here waits for the GPU except for the back stage
-// of two ticks ago (long finished), whose pinned table and event set are reused; its timings are collected then.
-int tick_phase2(esvo_context* h) {
+// phase 2 (back stage): window policy, fusion + clean + regularisation of this band (halo rows recomputed locally),
+// enqueued on the back stream behind the frame of the tick of parity fp.  Nothing here waits for the GPU except for
+// the back stage of two ticks ago (long finished), whose pinned table and event set are reused; its timings are
+// collected then.
+int tick_phase2(esvo_context* h, int fp) {
+  esvo_context::TickState& tk = h->tk[fp];
   h->xchg_ptr = nullptr;
   h->xchg_bytes = 0;
-  int rc = back_after_front(h);  // sharded: the caller's frame sum was issued on the front stream before this call
-  if (rc) return rc;
+  if (h->sharded) {  // the caller's frame sum was issued on the front stream after EV_CNT
+    int rc = back_after_front(h);
+    if (rc) return rc;
+  } else {
+    HIPCHK(hipStreamWaitEvent(h->stream_b, h->evt[EV_CNT + fp * EV_FRONT_STRIDE], 0));
+  }
   const int par = h->par;
   h->par ^= 1;
   HIPCHK(hipEventSynchronize(h->evt[EV_RG1 + par * EV_BACK_STRIDE]));
   collect_back(h, par);
-  rc = commit_frame(h, h->sh_off, h->sh_points, nullptr, h->n_pose);
+  int rc = commit_frame(h, tk.off, tk.points, nullptr, tk.n_pose, tk.pose_buf);
   if (rc) return rc;
-  rc = run_fuse(h, par);
+  rc = run_fuse(h, par, tk.T_world_obs);
   if (rc) return rc;
   h->stats.ticks++;
   h->stats.last_window_frames = (u32)h->frames.size();
@@ -1153,10 +1200,21 @@ int tick_phase2(esvo_context* h) {
   for (auto& f : h->frames) np += f.count;
   h->stats.last_window_points = np;
   h->stats_pending = true;
+  h->tick_pending = false;
   return ESVO_OK;
+}
+// complete the tick whose front stage is enqueued but which is not committed yet (unsharded ticks are lazy)
+int flush_pending_tick(esvo_context* h) {
+  if (!h->tick_pending || h->sharded) return ESVO_OK;
+  const int fp = h->fpar;
+  int rc = tick_phase1_collect(h, fp);
+  if (rc) return rc;
+  return tick_phase2(h, fp);
 }
 // drain the back stream and collect what is pending (older parity first)
 int finalize_tick_stats(esvo_context* h) {
+  int rcf = flush_pending_tick(h);
+  if (rcf) return rcf;
   if (!h->stats_pending && !h->back_pending[0] && !h->back_pending[1]) return ESVO_OK;
   const bool tick_done = h->stats_pending;
   h->stats_pending = false;
@@ -1165,7 +1223,7 @@ int finalize_tick_stats(esvo_context* h) {
   collect_ts_timing(h);
   collect_back(h, h->par);
   collect_back(h, h->par ^ 1);
-  if (tick_done) hipEventElapsedTime(&h->stats.ms_tick_total, h->evt[EV_T0], h->evt[EV_RG1 + (h->par ^ 1) * EV_BACK_STRIDE]);
+  if (tick_done) hipEventElapsedTime(&h->stats.ms_tick_total, h->evt[EV_T0 + h->fpar * EV_FRONT_STRIDE], h->evt[EV_RG1 + (h->par ^ 1) * EV_BACK_STRIDE]);
   return ESVO_OK;
 }
 }  // namespace
@@ -1175,11 +1233,26 @@ extern "C" int esvo_map_tick(esvo_handle h, uint64_t t_ns, const uint64_t* pose_
   if (!h->obs_set) FAIL(ESVO_ERR_STATE, "esvo_map_set_observation has not been called");
   if (h->sharded) FAIL(ESVO_ERR_STATE, "handle is sharded: drive it with esvo_shard_tick_phase");
   HIPCHK(hipSetDevice(h->device));
+  // the previous tick (if still pending) is completed AFTER this tick's front stage is enqueued: its point count
+  // arrived long ago, and the front stream never runs dry while the host works
+  if (h->prm.denoising) {  // its kept-event count is read back inside phase 0: no point in deferring anything
+    int rcp = flush_pending_tick(h);
+    if (rcp) return rcp;
+  }
+  const bool prev = h->tick_pending;
+  const int prev_fp = h->fpar;
   int rc = tick_phase0(h, t_ns, pose_t_ns, pose_T, m);
   if (rc) return rc;
-  rc = tick_phase1(h);
+  rc = tick_phase1_enqueue(h);
   if (rc) return rc;
-  return tick_phase2(h);
+  if (prev) {
+    rc = tick_phase1_collect(h, prev_fp);
+    if (rc) return rc;
+    rc = tick_phase2(h, prev_fp);
+    if (rc) return rc;
+    h->tick_pending = true;  // this tick
+  }
+  return ESVO_OK;
 }
 
 extern "C" int esvo_shard_tick_phase(esvo_handle h, int phase, uint64_t t_ns, const uint64_t* pose_t_ns, const double* pose_T,
@@ -1192,8 +1265,12 @@ extern "C" int esvo_shard_tick_phase(esvo_handle h, int phase, uint64_t t_ns, co
     case 0:
       if (!pose_t_ns || !pose_T) return ESVO_ERR_INVALID_ARG;
       return tick_phase0(h, t_ns, pose_t_ns, pose_T, m);
-    case 1: return tick_phase1(h);
-    case 2: return tick_phase2(h);
+    case 1: {
+      int rc = tick_phase1_enqueue(h);
+      if (rc) return rc;
+      return tick_phase1_collect(h, h->fpar);
+    }
+    case 2: return tick_phase2(h, h->fpar);
     default: FAIL(ESVO_ERR_INVALID_ARG, "phase must be 0..2");
   }
 }
@@ -1203,6 +1280,7 @@ extern "C" {
 int esvo_map_get_depth_points(esvo_handle h, esvo_depth_point_t* out, size_t cap, size_t* n) {
   if (!h || !n) return ESVO_ERR_INVALID_ARG;
   HIPCHK(hipSetDevice(h->device));
+  { int rcp = flush_pending_tick(h); if (rcp) return rcp; }
   std::vector<esvo_depth_point_t> v;
   int rc = export_map(h, v, nullptr);
   if (rc) return rc;
@@ -1217,6 +1295,7 @@ int esvo_map_get_depth_points(esvo_handle h, esvo_depth_point_t* out, size_t cap
 int esvo_map_get_pointcloud_xyz(esvo_handle h, float* out_xyz, size_t cap_points, size_t* n) {
   if (!h || !n) return ESVO_ERR_INVALID_ARG;
   HIPCHK(hipSetDevice(h->device));
+  { int rcp = flush_pending_tick(h); if (rcp) return rcp; }
   std::vector<esvo_depth_point_t> v;
   int rc = export_map(h, v, nullptr);
   if (rc) return rc;
@@ -1234,6 +1313,7 @@ int esvo_map_get_pointcloud_xyz(esvo_handle h, float* out_xyz, size_t cap_points
 int esvo_map_get_last_frame(esvo_handle h, esvo_depth_point_t* out, size_t cap, size_t* n) {
   if (!h || !n) return ESVO_ERR_INVALID_ARG;
   HIPCHK(hipSetDevice(h->device));
+  { int rcp = flush_pending_tick(h); if (rcp) return rcp; }
   *n = 0;
   if (h->frames.empty()) return ESVO_OK;
   const FrameRec& f = h->frames.back();
@@ -1259,6 +1339,7 @@ int esvo_get_stats(esvo_handle h, esvo_stats_t* out) {
 int esvo_shard_set_band(esvo_handle h, int row_begin, int row_end, int shard, int n_shards) {
   if (!h || row_begin < 0 || row_end > h->H || row_begin >= row_end || n_shards < 1 || shard < 0 || shard >= n_shards)
     return ESVO_ERR_INVALID_ARG;
+  { int rcp = flush_pending_tick(h); if (rcp) return rcp; }
   h->dp.ev_shard = shard;
   h->dp.ev_nshards = n_shards;
   h->dp.band_y0 = row_begin;

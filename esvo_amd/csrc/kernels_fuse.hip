@@ -357,86 +357,102 @@ __global__ void __launch_bounds__(256) reg_owner_kernel(const MapCell* __restric
 }
 
 // Compact "regularisation view" of the map: what the (2r+1)^2 neighbourhood scan reads.
-//   bits  : 1 bit per cell (u64 words over the linear cell index): exists(r,c) && at(r,c).valid()
+//   vbits : 1 bit per cell (u64 words over the linear cell index): exists(r,c) && at(r,c).valid()
 //   ab[c] : (inv_depth, 2*sqrt(variance))     -- the closeness test operands
 //   cd[c] : (nu, scale2)                      -- read only for close neighbours
-// 16 B per tap instead of a 104 B MapCell, empty cells are skipped 64 at a time, and the
-// neighbour's sqrt is computed once per cell instead of once per tap.
+// A tap row of the neighbourhood is <= 63 consecutive bits of vbits: empty taps cost nothing, a valid tap costs
+// 16 B instead of a 104 B MapCell, and the neighbour's sqrt is computed once per cell instead of once per tap.
 __global__ void __launch_bounds__(256) reg_view_kernel(const MapCell* __restrict__ map, MapCell* __restrict__ out,
-                                                       uint8_t* __restrict__ valid, double2* __restrict__ ab, double2* __restrict__ cd,
+                                                       u64* __restrict__ vbits, double2* __restrict__ ab, double2* __restrict__ cd,
                                                        u32* __restrict__ elem_list, u32* __restrict__ n_elems, int ncell, int W,
                                                        int band0, int band1, int view0, int view1) {
   const int cell = blockIdx.x * blockDim.x + threadIdx.x;
-  bool alive = false;
+  bool alive = false, v = false;
   if (cell < ncell) {
     const MapCell& n = map[cell];
     const int row = cell / W;
     if (row >= view0 && row < view1) {  // the view covers the band's halo as well (multi-GPU: computed, not exchanged)
-      const bool v = (n.flags & CELL_ALIVE) && (n.flags & CELL_GRID) && n.inv_depth > -1e-6;
+      v = (n.flags & CELL_ALIVE) && (n.flags & CELL_GRID) && n.inv_depth > -1e-6;
       if (v) {
         ab[cell] = make_double2(n.inv_depth, 2.0 * sqrt(n.variance));
         cd[cell] = make_double2(n.nu, n.scale2);
       }
-      valid[cell] = v ? 1 : 0;
     }
     if (row >= band0 && row < band1) {
       alive = (n.flags & CELL_ALIVE) != 0;
       if (!alive) out[cell].flags = 0;
     }
   }
+  const int lane = threadIdx.x & 63;
+  const u64 vm = __ballot(v);
+  if (lane == 0) vbits[cell >> 6] = vm;  // a wave covers 64 consecutive cells; words past the image read as 0
   // compact the alive elements (apply kernel: one thread per element, full waves); order is free
   const u64 am = __ballot(alive);
-  const int lane = threadIdx.x & 63;
   u32 base = 0;
   if (lane == 0 && am) base = atomicAdd(n_elems, (u32)__popcll(am));
   base = __shfl(base, 0, 64);
   if (alive) elem_list[base + (u32)__popcll(am & ((1ull << lane) - 1ull))] = (u32)cell;
 }
 
-// ---- regulariser pass A: neighbourhood scan, one wave per element -----------------------------------
-// The (2r+1)^2 taps are enumerated in the reference's row-major order, 64 per step; lane = tap.
-// A tap counts as neighbour if its cell is valid (exists && valid()), as CLOSE neighbour if
-// |rho_self - rho_n| < 2 sigma_self or < 2 sigma_n.  The wave ballots give the neighbour counts and,
-// per step, a 64-bit mask of the close taps (kept in tap order), which is all pass B needs.
-__global__ void __launch_bounds__(256) reg_scan_kernel(const MapCell* __restrict__ map, const uint8_t* __restrict__ valid,
+// ---- regulariser pass A: neighbourhood scan, G lanes per element, lane = tap column ---------------------
+// Row dr of the neighbourhood is the bit range [r*W + col - R, + 2R+1) of vbits.  A tap counts as neighbour
+// if its bit is set (exists && valid()), as CLOSE neighbour if |rho_self - rho_n| < 2 sigma_self or
+// < 2 sigma_n.  The group walks the rows; lane dc owns column dc, so a row's (inv_depth, 2 sigma) pairs are one
+// coalesced load of the valid lanes, empty rows are skipped, and the ballot of the closeness test IS the row's
+// mask.  Output per element: the neighbour counts and one mask of close taps per row -- rows in order, bits in
+// order = the reference's row-major tap order, which is all pass B needs.  With G = 64 the element is
+// wave-uniform and the row bookkeeping runs on the scalar unit.
+template <int G>
+__global__ void __launch_bounds__(256) reg_scan_kernel(const MapCell* __restrict__ map, const u64* __restrict__ vbits,
                                                        const double2* __restrict__ ab, const u32* __restrict__ elem_list,
                                                        const u32* __restrict__ n_elems, u64* __restrict__ masks,
-                                                       u32* __restrict__ counts, int words, DevParams p) {
-  const u32 e = blockIdx.x * 4 + (threadIdx.x >> 6);
+                                                       u32* __restrict__ counts, DevParams p) {
+  u32 e = (blockIdx.x * 256 + threadIdx.x) / G;
+  if (G == 64) e = (u32)__builtin_amdgcn_readfirstlane((int)e);
+  const int dc = threadIdx.x % G;
+  const int gsh = (threadIdx.x & 63) / G * G;  // first lane of the group inside the wave
   if (e >= *n_elems) return;
-  const int lane = threadIdx.x & 63;
   const int cell = (int)elem_list[e];
   const MapCell& c = map[cell];
-  const int R = p.reg_radius, Wn = 2 * R + 1, taps = Wn * Wn;
-  const int row = (int)c.row, col = (int)c.col;
+  const int R = p.reg_radius, Wn = 2 * R + 1;
+  int row = (int)c.row, col = (int)c.col;
+  if (G == 64) { row = __builtin_amdgcn_readfirstlane(row); col = __builtin_amdgcn_readfirstlane(col); }
   const double inv = c.inv_depth;
-  u32 n_nb = 0, n_close = 0;
   // SmartGrid::getNeighbourhood's loop bounds mix int and size_t (SmartGrid.h:373-375): for
   // row < radius or col < radius the loops never execute -> no neighbours at all.
   const bool scan = inv > -1e-6 && row >= R && col >= R;
   const double sd_self2 = 2.0 * sqrt(c.variance);
-  for (int w = 0; w < words; ++w) {
-    bool close = false, v = false;
-    const int t = w * 64 + lane;
-    if (scan && t < taps) {
-      const int dr = t / Wn, dc = t - dr * Wn;
-      const int r = row - R + dr, cc = col - R + dc;
-      if (r < p.H && cc < p.W) {
-        const int nc = r * p.W + cc;
-        v = valid[nc] != 0;
-        if (v) {
-          const double2 q = ab[nc];
-          const double diff = fabs(inv - q.x);
-          close = diff < sd_self2 || diff < q.y;
-        }
-      }
+  const int col0 = col - R;
+  const int width = min(Wn, p.W - col0);  // taps with cc >= W do not exist (SmartGrid.h:376)
+  const u64 wmask = (width >= 64) ? ~0ull : ((1ull << max(width, 0)) - 1ull);
+  const u64 gmask = (G == 64) ? ~0ull : ((1ull << G) - 1ull);
+  u32 nb = 0, nclose = 0;
+  u64* mk = masks + (size_t)e * Wn;
+  for (int dr = 0; dr < Wn; ++dr) {
+    const int r = row - R + dr;
+    u64 bits = 0;
+    int base = 0;
+    if (scan && r < p.H) {
+      base = r * p.W + col0;
+      const int sh = base & 63;
+      const u64 lo = vbits[base >> 6], hi = vbits[(base >> 6) + 1];
+      bits = ((lo >> sh) | (sh ? (hi << (64 - sh)) : 0ull)) & wmask;
     }
-    const u64 vm = __ballot(v), cm = __ballot(close);
-    n_nb += (u32)__popcll(vm);
-    n_close += (u32)__popcll(cm);
-    if (lane == 0) masks[(size_t)e * words + w] = cm;
+    u64 cm = 0;
+    if (bits) {  // group-uniform
+      bool close = false;
+      if ((bits >> dc) & 1ull) {
+        const double2 q = ab[base + dc];
+        const double diff = fabs(inv - q.x);
+        close = diff < sd_self2 || diff < q.y;
+      }
+      cm = (__ballot(close) >> gsh) & gmask;
+      nb += (u32)__popcll(bits);
+      nclose += (u32)__popcll(cm);
+    }
+    if (dc == 0) mk[dr] = cm;
   }
-  if (lane == 0) { counts[2 * e] = n_nb; counts[2 * e + 1] = n_close; }
+  if (dc == 0) { counts[2 * e] = nb; counts[2 * e + 1] = nclose; }
 }
 
 // ---- regulariser pass B: sequential Student-t fusion of the close neighbours, one thread per element --
@@ -446,7 +462,7 @@ __global__ void __launch_bounds__(256) reg_chain_kernel(const MapCell* __restric
                                                         const u32* __restrict__ owner_max, const u32* __restrict__ owner_min,
                                                         const double2* __restrict__ ab, const double2* __restrict__ cd,
                                                         const u32* __restrict__ elem_list, const u32* __restrict__ n_elems,
-                                                        const u64* __restrict__ masks, const u32* __restrict__ counts, int words,
+                                                        const u64* __restrict__ masks, const u32* __restrict__ counts,
                                                         DevParams p) {
   const u32 e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= *n_elems) return;
@@ -458,20 +474,20 @@ __global__ void __launch_bounds__(256) reg_chain_kernel(const MapCell* __restric
     const u32 n_nb = counts[2 * e], n_close = counts[2 * e + 1];
     if (n_nb > (u32)p.reg_min_nb && n_close > (u32)p.reg_min_close) {
       const int R = p.reg_radius, Wn = 2 * R + 1;
-      const int row0 = (int)c.row - R, col0 = (int)c.col - R;
-      const u64* mk = masks + (size_t)e * words;
-      int w = 0;
+      const int col0 = (int)c.col - R;
+      const u64* mk = masks + (size_t)e * Wn;
+      int dr = 0;
+      int row_base = ((int)c.row - R) * p.W + col0;
       u64 m = mk[0];
       auto next_cell = [&]() -> int {  // next close tap in row-major order, -1 when exhausted
         while (m == 0) {
-          if (++w >= words) return -1;
-          m = mk[w];
+          if (++dr >= Wn) return -1;
+          m = mk[dr];
+          row_base += p.W;
         }
         const int k = __builtin_ctzll(m);
         m &= m - 1;
-        const int t = w * 64 + k;
-        const int dr = t / Wn, dc = t - dr * Wn;
-        return (row0 + dr) * p.W + col0 + dc;
+        return row_base + k;
       };
       int nc = next_cell();  // n_close > 0 here
       double inv_n = ab[nc].x;
@@ -500,7 +516,7 @@ __global__ void __launch_bounds__(256) reg_chain_kernel(const MapCell* __restric
   out[cell] = c;
 }
 
-void launch_reg_view(const MapCell* map_in, MapCell* map_out, u32* owner_max, u32* owner_min, uint8_t* valid, double2* ab,
+void launch_reg_view(const MapCell* map_in, MapCell* map_out, u32* owner_max, u32* owner_min, u64* vbits, double2* ab,
                      double2* cd, u32* elem_list, u32* n_elems, const DevParams& p, hipStream_t s) {
   const int ncell = p.W * p.H;
   hipMemsetAsync(owner_max, 0, sizeof(u32) * ncell, s);
@@ -508,19 +524,26 @@ void launch_reg_view(const MapCell* map_in, MapCell* map_out, u32* owner_max, u3
   hipMemsetAsync(n_elems, 0, sizeof(u32), s);
   const int nb = (ncell + 255) / 256;
   hipLaunchKernelGGL(reg_owner_kernel, dim3(nb), dim3(256), 0, s, map_in, owner_max, owner_min, p);
-  hipLaunchKernelGGL(reg_view_kernel, dim3(nb), dim3(256), 0, s, map_in, map_out, valid, ab, cd, elem_list, n_elems, ncell, p.W,
+  hipLaunchKernelGGL(reg_view_kernel, dim3(nb), dim3(256), 0, s, map_in, map_out, vbits, ab, cd, elem_list, n_elems, ncell, p.W,
                      p.band_y0, p.band_y1, p.cband_y0, p.cband_y1);
 }
-void launch_reg_apply(const MapCell* map_in, MapCell* map_out, const u32* owner_max, const u32* owner_min, const uint8_t* valid,
+template <int G>
+static void launch_reg_scan_g(const MapCell* map_in, const u64* vbits, const double2* ab, const u32* elem_list, const u32* n_elems,
+                              u64* masks, u32* counts, u32 max_elems, const DevParams& p, hipStream_t s) {
+  const u32 per_block = 256 / G;
+  hipLaunchKernelGGL(reg_scan_kernel<G>, dim3((max_elems + per_block - 1) / per_block), dim3(256), 0, s, map_in, vbits, ab,
+                     elem_list, n_elems, masks, counts, p);
+}
+void launch_reg_apply(const MapCell* map_in, MapCell* map_out, const u32* owner_max, const u32* owner_min, const u64* vbits,
                       u64* masks, u32* counts, const double2* ab, const double2* cd, const u32* elem_list, const u32* n_elems,
                       u32 max_elems, const DevParams& p, hipStream_t s) {
-  const int Wn = 2 * p.reg_radius + 1;
-  const int words = (Wn * Wn + 63) / 64;
+  const int Wn = 2 * p.reg_radius + 1;  // <= 63 (validate_params)
   if (max_elems == 0) return;
-  hipLaunchKernelGGL(reg_scan_kernel, dim3((max_elems + 3) / 4), dim3(256), 0, s, map_in, valid, ab, elem_list, n_elems, masks,
-                     counts, words, p);
+  if (Wn <= 16) launch_reg_scan_g<16>(map_in, vbits, ab, elem_list, n_elems, masks, counts, max_elems, p, s);
+  else if (Wn <= 32) launch_reg_scan_g<32>(map_in, vbits, ab, elem_list, n_elems, masks, counts, max_elems, p, s);
+  else launch_reg_scan_g<64>(map_in, vbits, ab, elem_list, n_elems, masks, counts, max_elems, p, s);
   hipLaunchKernelGGL(reg_chain_kernel, dim3((max_elems + 255) / 256), dim3(256), 0, s, map_in, map_out, owner_max, owner_min, ab,
-                     cd, elem_list, n_elems, masks, counts, words, p);
+                     cd, elem_list, n_elems, masks, counts, p);
 }
 
 // ---- export: alive cells -> esvo_depth_point_t list (cell order; host orders by seq) --------------

@@ -69,11 +69,11 @@ def test_logical_shards_equal_unsharded(request, preset, rig_fix, stream_fix, n_
         ref.tick(t, stamps, poses)
         for d in shards:  # BM + LM of the own slots -> sum of the (matched, kept) bytes
             d.shard_phase(0, t, stamps, poses)
-        n = shards[0].stats().last_events_in
-        assert n == ref.stats().last_events_in
         codes = _emulated_sum(shards)
         for d in shards:  # frame order, own points placed -> sum of the frame
             d.shard_phase(1)
+        assert shards[0].stats().last_events_in == ref.stats().last_events_in
+        assert codes.numel() * 8 == (ref.stats().last_events_in + 7) // 8 * 8
         assert shards[0].stats().last_matches == ref.stats().last_matches
         assert sum(d.stats().last_solved for d in shards) == ref.stats().last_solved
         _emulated_sum(shards, whole_words=True)
