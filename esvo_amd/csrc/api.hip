@@ -326,9 +326,7 @@ int run_match(esvo_context* h, const esvo_event_t* d_ev, u64 first, u64 cap, int
 
 // LM (+cull) over the compacted matches: point records + flags in solver-slot order (dense: in list order)
 int run_lm(esvo_context* h, u32 max_matches, int cull, bool dense) {
-  u32* flags = dense ? h->d_lkeep : h->d_pt_flags;
-  HIPCHK(hipMemsetAsync(flags, 0, sizeof(u32) * (max_matches ? max_matches : 1), h->stream));
-  HIPCHK(hipMemsetAsync(h->d_counters + 2, 0, sizeof(u32), h->stream));
+  u32* flags = dense ? h->d_lkeep : h->d_pt_flags;  // the kernel writes every flag of its launch range
   LmArgs a;
   a.matches = h->d_matches; a.n_matches = h->d_counters + (dense ? 8 : 0); a.max_matches = max_matches;
   a.tsL = h->d_obs[0]; a.tsR = h->d_obs[1];
@@ -349,6 +347,7 @@ int run_order_points(esvo_context* h, u32 max_matches, DevPoint* dst) {
   return ESVO_OK;
 }
 int run_refine(esvo_context* h, u32 max_matches, int cull, DevPoint* dst) {
+  HIPCHK(hipMemsetAsync(h->d_counters + 2, 0, sizeof(u32), h->stream));  // n_solved (a tick zeroes all counters at once)
   int rc = run_lm(h, max_matches, cull, false);
   if (rc) return rc;
   return run_order_points(h, max_matches, dst);
@@ -503,6 +502,8 @@ int run_fuse(esvo_context* h, int par, const double* T_world_obs) {
   a.rec_ids = h->d_rec_ids; a.scan_tmp = h->d_scan_tmp_b; a.d_total = h->d_cnt_b + 4;
   a.map = h->d_map; a.d_num_fusion = h->d_cnt_b + 3;
   a.bucket = h->d_bucket; a.cell_list = h->d_cell_list; a.n_touched = h->d_cnt_b + 6;
+  a.owner_max = h->prm.regularization ? h->d_owner_max : nullptr;
+  a.owner_min = h->d_owner_min; a.n_reg_elems = h->prm.regularization ? h->d_cnt_b + 7 : nullptr;
   if (total > h->win_cap) FAIL(ESVO_ERR_CAPACITY, "window points exceed capacity");
   const int o = par * EV_BACK_STRIDE;
   hipEventRecord(h->evt[EV_FU0 + o], sb);

@@ -226,6 +226,9 @@ struct FuseArgs {
   u32* bucket;                  // [3*128] load-balancing buckets: count | offset | fill
   u32* cell_list;               // [W*H] touched cells, longest record lists first
   u32* n_touched;               // number of touched cells
+  u32* owner_max;               // regulariser scratch reset together with the per-cell counters (or nullptr)
+  u32* owner_min;
+  u32* n_reg_elems;
 };
 void launch_fuse(const FuseArgs& a, const DevParams& p, hipStream_t s);
 void launch_clean(MapCell* map, const DevParams& p, hipStream_t s);

@@ -20,6 +20,7 @@
 // coordinates the element believes it has; they differ from the true cell only after the
 // replace branch (DepthFusion.cpp:186), whose side effects on
 // clean/regularisation are reproduced through the ALIVE/GRID flag pair.
+#include <algorithm>
 #include "common.hpp"
 #include "fdiv.hpp"
 
@@ -301,14 +302,26 @@ __global__ void __launch_bounds__(256) fuse_cells_kernel(FuseArgs a, DevParams p
   if (numFusion) atomicAdd(a.d_num_fusion, numFusion);
 }
 
+// one launch instead of seven fills: per-cell counters, load-balancing buckets, counters of the back stage
+__global__ void __launch_bounds__(256) fuse_reset_kernel(FuseArgs a, int ncell) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < ncell) {
+    a.cell_count[i] = 0;
+    a.cell_fill[i] = 0;
+    if (a.owner_max) { a.owner_max[i] = 0; a.owner_min[i] = 0xffffffffu; }
+  }
+  if (i < 3 * 128) a.bucket[i] = 0;  // cnt | off | fill
+  if (i == 0) {
+    *a.d_num_fusion = 0;
+    if (a.n_reg_elems) *a.n_reg_elems = 0;
+  }
+}
+
 void launch_fuse(const FuseArgs& a, const DevParams& p, hipStream_t s) {
   const int ncell = p.W * p.H;
   const int K = (p.fusion_radius == 0) ? 4 : 9;
   const int nb = (ncell + 255) / 256;
-  hipMemsetAsync(a.cell_count, 0, sizeof(u32) * ncell, s);
-  hipMemsetAsync(a.cell_fill, 0, sizeof(u32) * ncell, s);
-  hipMemsetAsync(a.bucket, 0, sizeof(u32) * 3 * 128, s);  // cnt | off | fill
-  hipMemsetAsync(a.d_num_fusion, 0, sizeof(u32), s);
+  hipLaunchKernelGGL(fuse_reset_kernel, dim3(std::max(nb, 2)), dim3(256), 0, s, a, ncell);
   if (a.n_pts) hipLaunchKernelGGL(propagate_kernel, dim3((a.n_pts + 255) / 256), dim3(256), 0, s, a, p, K);
   launch_exclusive_scan_u32(a.cell_count, a.cell_offset, a.d_total, a.scan_tmp, (size_t)ncell, s);
   if (a.n_pts) hipLaunchKernelGGL(scatter_records_kernel, dim3((a.n_pts + 255) / 256), dim3(256), 0, s, a, p, K);
@@ -519,9 +532,7 @@ __global__ void __launch_bounds__(256) reg_chain_kernel(const MapCell* __restric
 void launch_reg_view(const MapCell* map_in, MapCell* map_out, u32* owner_max, u32* owner_min, u64* vbits, double2* ab,
                      double2* cd, u32* elem_list, u32* n_elems, const DevParams& p, hipStream_t s) {
   const int ncell = p.W * p.H;
-  hipMemsetAsync(owner_max, 0, sizeof(u32) * ncell, s);
-  hipMemsetAsync(owner_min, 0xff, sizeof(u32) * ncell, s);
-  hipMemsetAsync(n_elems, 0, sizeof(u32), s);
+  // owner_max / owner_min / n_elems were reset by fuse_reset_kernel (launch_fuse of the same tick)
   const int nb = (ncell + 255) / 256;
   hipLaunchKernelGGL(reg_owner_kernel, dim3(nb), dim3(256), 0, s, map_in, owner_max, owner_min, p);
   hipLaunchKernelGGL(reg_view_kernel, dim3(nb), dim3(256), 0, s, map_in, map_out, vbits, ab, cd, elem_list, n_elems, ncell, p.W,

@@ -29,8 +29,12 @@ namespace esvo {
 #ifdef LM_STATS
 __device__ unsigned long long g_lm_dbg[8];
 #define LM_COUNT(i, cond) do { if (cond) atomicAdd(&g_lm_dbg[i], 1ull); } while (0)
+__device__ unsigned int g_lm_slot[3][1 << 18];  // per solver slot: evaluations, t-scale iterations, those of the first evaluation
+__device__ unsigned int g_lm_cur_slot_dummy;
+#define LM_SLOT(k, s, cond, v) do { if ((cond) && (s) < (1u << 18)) g_lm_slot[k][s] += (v); } while (0)
 #else
 #define LM_COUNT(i, cond) do {} while (0)
+#define LM_SLOT(k, s, cond, v) do {} while (0)
 #endif
 
 #define LM_ROWS 7
@@ -97,6 +101,9 @@ struct LmProblem {
   const uint8_t* tsL;
   const uint8_t* tsR;
   int c;                   // lane within the group
+#ifdef LM_STATS
+  u32 dbg_slot;
+#endif
 };
 
 // bilinear 15x7 patch column for this lane; returns false like patchInterpolation
@@ -135,6 +142,7 @@ __device__ inline void interp_column(const uint8_t* __restrict__ img, int W, int
 __device__ void lm_eval(const DevParams& p, const LmProblem& pr, double x, double fv[LM_ROWS]) {
   const double nu = p.td_nu;
   LM_COUNT(0, pr.c == 0);                                   // evaluations, per group
+  LM_SLOT(0, pr.dbg_slot, pr.c == 0, 1u);
   LM_COUNT(1, __lane_id() == __ffsll(__ballot(1)) - 1);     // evaluations, per wave
   double prv[3], pl[3];
   cam2World(p.camL, pr.cx, pr.cy, x, prv);
@@ -178,6 +186,9 @@ __device__ void lm_eval(const DevParams& p, const LmProblem& pr, double x, doubl
     if (r[y] != 0) { knz++; minabs = fmin(minabs, fabs(r[y])); }
   }
   knz = grp_sum_int(knz);
+#ifdef LM_STATS
+  if (pr.c == 0 && pr.dbg_slot < (1u << 18) && g_lm_slot[0][pr.dbg_slot] == 1u) g_lm_slot[2][pr.dbg_slot] = 1000u * (u32)knz;
+#endif
   minabs = grp_min(minabs);
   const double scale2_0 = p.td_scale2;
   double s2;
@@ -199,6 +210,8 @@ __device__ void lm_eval(const DevParams& p, const LmProblem& pr, double x, doubl
     const Recip rN = make_recip((double)N);
     while (true) {
       LM_COUNT(2, pr.c == 0);                                 // t-scale iterations, per group
+      LM_SLOT(1, pr.dbg_slot, pr.c == 0, 1u);
+      LM_SLOT(2, pr.dbg_slot, pr.c == 0 && g_lm_slot[0][pr.dbg_slot < (1u << 18) ? pr.dbg_slot : 0] == 1u, 1u);
       LM_COUNT(3, __lane_id() == __ffsll(__ballot(1)) - 1);   // t-scale iterations, per wave
       double t[LM_ROWS];
       const Recip rs1 = make_recip(s1);
@@ -289,6 +302,7 @@ __global__ void __launch_bounds__(256, 3) lm_refine_kernel(LmArgs a, DevParams p
   // The grid is sized for the worst case (every event matched): waves without any match leave at once.
   // Inactive groups of a partially filled wave run the (cheap, failing) code path below with a dummy
   // problem so that the wave's control flow stays simple; they write nothing.
+  if (!active && c == 0 && s < a.max_matches) a.out_flags[s] = 0u;  // every slot of the launch gets its flag: no memset
   if (__ballot(active) == 0) return;
   u32 j = 0;
   esvo_match_t m;
@@ -303,6 +317,9 @@ __global__ void __launch_bounds__(256, 3) lm_refine_kernel(LmArgs a, DevParams p
   pr.tsL = a.tsL;
   pr.tsR = a.tsR;
   pr.c = c;
+#ifdef LM_STATS
+  pr.dbg_slot = active ? s : 0xffffffffu;
+#endif
   {  // DepthProblem::setProblem, DepthProblem.cpp:17-32
     double Tlw[16], Tlv[16];
     rigid_inverse(a.T_world_obs, Tlw);
@@ -470,6 +487,11 @@ __global__ void __launch_bounds__(256, 3) lm_refine_kernel(LmArgs a, DevParams p
 
 #ifdef LM_STATS
 extern "C" void esvo_debug_lm_counters(unsigned long long out[8]) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lm_dbg), 64); }
+extern "C" void esvo_debug_lm_slots(unsigned int* out, int clear) {  // out[3][1 << 18]
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(esvo::g_lm_slot), sizeof(unsigned int) * 3 * (1 << 18));
+  if (clear) { void* p = nullptr; hipGetSymbolAddress(&p, HIP_SYMBOL(esvo::g_lm_slot)); hipMemset(p, 0, sizeof(unsigned int) * 3 * (1 << 18)); }
+}
 #endif
 void launch_lm_refine(const LmArgs& a, const DevParams& p, u32* n_solved, hipStream_t s) {
   if (a.max_matches == 0) return;
