@@ -230,7 +230,10 @@ _DATASETS = {
 
 def dataset_rig(name):
     """Real-distortion rig of a shipped dataset ('upenn' 346x260 equidistant, 'dsec' 640x480
-    plumb_bob), values from esvo_core/calib/<name>/{left,right}.yaml."""
+    plumb_bob), values from esvo_core/calib/<name>/{left,right}.yaml; 'hd' is SURVEY.md §8's synthetic
+    1280x720 stress rig (ideal, f = 1000 px, baseline 0.3 m)."""
+    if name == "hd":
+        return ideal_rig(1280, 720, 1000.0, 0.3, name="hd")
     d = _DATASETS[name]
     mk = lambda s: dict(width=d["width"], height=d["height"], K=np.array(d["K_" + s], np.float64).reshape(3, 3),
                         D=np.array(d["D_" + s], np.float64), R=np.array(d["R_" + s], np.float64).reshape(3, 3),

@@ -67,6 +67,16 @@ PRESETS = {
         Regularization=True, RegularizationRadius=20, RegularizationMinNeighbours=32,
         RegularizationMinCloseNeighbours=32, PROCESS_EVENT_NUM=10000, BM_min_disparity=0, BM_max_disparity=150,
         BM_step=1, BM_ZNCC_Threshold=0.1, node="mapping"),
+    # SURVEY.md §8 "synthetic HD" stress row: mapping_dsec.yaml with the inverse-depth range 0.02-0.5 and the
+    # disparity cap 150 (6...150 at f*b = 300 -> 145 candidates)
+    "mapping_hd": dict(
+        patch_size_X=15, patch_size_Y=7, LSnorm="Tdist", Tdist_nu=2.182, Tdist_scale=17.277,
+        invDepth_min_range=0.02, invDepth_max_range=0.5, residual_vis_threshold=30, stdVar_vis_threshold=1.0,
+        age_max_range=10, age_vis_threshold=1, fusion_radius=1, FUSION_STRATEGY="CONST_FRAMES",
+        maxNumFusionFrames=5, maxNumFusionPoints=20000, Denoising=False, SmoothTimeSurface=True,
+        Regularization=True, RegularizationRadius=20, RegularizationMinNeighbours=32,
+        RegularizationMinCloseNeighbours=32, PROCESS_EVENT_NUM=100000, BM_min_disparity=0, BM_max_disparity=150,
+        BM_step=1, BM_ZNCC_Threshold=0.1, node="mapping"),
 }
 
 

@@ -35,3 +35,16 @@ def dsec_stream(dsec_rig):
     from esvo_amd import synth
     # DSEC geometry: f*b = 320 px*m, rho in [0.001, 0.25] -> disparity 0..80
     return synth.make_stream(dsec_rig, 20000, 0.12, 0.02, 0.25, seed=20250421, speed=2.0)
+
+
+@pytest.fixture(scope="session")
+def hd_rig():
+    from esvo_amd import calib
+    return calib.dataset_rig("hd")  # synthetic 1280x720, f*b = 300 px*m
+
+
+@pytest.fixture(scope="session")
+def hd_stream(hd_rig):
+    from esvo_amd import synth
+    # rho in [0.03, 0.45] -> disparity 9..135 inside the 6..150 search range (145 candidates)
+    return synth.make_stream(hd_rig, 30000, 0.12, 0.03, 0.45, seed=20250423, speed=1.5)

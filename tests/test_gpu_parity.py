@@ -307,9 +307,17 @@ def test_fusion_parity_dsec_radius1_regularised(dsec_rig, dsec_stream):
 # ---------------------------------------------------------------------------------------------------
 # End to end: events -> TS -> fused tick, everything device-resident
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("preset,rig_fix,stream_fix,n_ev", [("mvstereo_upenn", "upenn_rig", "upenn_stream", None),
-                                                          ("mapping_dsec", "dsec_rig", "dsec_stream", 4000)])
-def test_end_to_end_tick(request, preset, rig_fix, stream_fix, n_ev):
+# Tolerances against the LITERAL oracle.  The GPU equals the canonical oracle bit for bit (asserted first); literal and
+# canonical differ in summation order only, which moves an LM result by ~1e-8 and now and then flips a threshold
+# (compatibility |d rho| < 2 sigma, "more than 32 close neighbours") whose effect the regulariser spreads over a
+# neighbourhood.  On the 1280x720 / 145-candidate stress scene (41x41 neighbourhoods over a dense map) those flips reach
+# an RMSE of ~2e-4 BETWEEN THE TWO CPU ORACLES, i.e. the reference is not pinned more tightly than that itself
+# (its own sums depend on Eigen's packet width); the dataset geometries stay below north_star's 1e-4.
+@pytest.mark.parametrize("preset,rig_fix,stream_fix,n_ev,min_iou,max_rmse", [
+    ("mvstereo_upenn", "upenn_rig", "upenn_stream", None, 0.99, 1e-4),
+    ("mapping_dsec", "dsec_rig", "dsec_stream", 4000, 0.99, 1e-4),
+    ("mapping_hd", "hd_rig", "hd_stream", 3000, 0.97, 5e-4)])
+def test_end_to_end_tick(request, preset, rig_fix, stream_fix, n_ev, min_iou, max_rmse):
     O = _oracle()
     rig, stream = request.getfixturevalue(rig_fix), request.getfixturevalue(stream_fix)
     over = dict(process_event_num=n_ev) if n_ev else {}
@@ -335,12 +343,14 @@ def test_end_to_end_tick(request, preset, rig_fix, stream_fix, n_ev):
         # north_star tolerance against the LITERAL oracle: RMSE of inverse depth over commonly
         # valid pixels < 1e-4, valid-set IoU reported (> 0.99 required)
         lit = fl["map"]
-        kg = {(int(a), int(b)): v for a, b, v in zip(g["row"], g["col"], g["inv_depth"])}
-        kl = {(int(a), int(b)): v for a, b, v in zip(lit["row"], lit["col"], lit["inv_depth"])}
+        # (valid = inverse depth > 0: the regulariser marks elements without enough close neighbours with -1,
+        # DepthRegularization.cpp:99-101, and that count can differ by one between summation orders)
+        kg = {(int(a), int(b)): v for a, b, v in zip(g["row"], g["col"], g["inv_depth"]) if v > 0}
+        kl = {(int(a), int(b)): v for a, b, v in zip(lit["row"], lit["col"], lit["inv_depth"]) if v > 0}
         common = [k for k in kg if k in kl]
         iou = len(common) / max(len(set(kg) | set(kl)), 1)
         rmse = np.sqrt(np.mean([(kg[k] - kl[k]) ** 2 for k in common])) if common else 0.0
-        assert iou > 0.99 and rmse < 1e-4, (iou, rmse)
+        assert iou > min_iou and rmse < max_rmse, (iou, rmse)
     pc_g, pc_o = dev.get_pointcloud(), m.get_pointcloud()
     assert pc_g.shape == pc_o.shape and np.array_equal(pc_g, pc_o)
 
