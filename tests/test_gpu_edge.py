@@ -166,3 +166,50 @@ def test_denoising_in_the_fused_tick():
         assert len(g) == len(o) and np.array_equal(g["inv_depth"], o["inv_depth"])
         _same_map(dev.get_map(), m.get_map())
     assert all(0.02 * n < d < n for n, d in kept), kept  # the mask keeps some events and removes others
+
+
+@pytest.mark.parametrize("preset,rig_fix,stream_fix,over", [
+    ("mapping_upenn", "upenn_rig", "upenn_stream", dict(max_fusion_points=1200)),   # CONST_POINTS: pops depend on the counts
+    ("mapping_dsec", "dsec_rig", "dsec_stream", dict(process_event_num=4000)),      # CONST_FRAMES, radius 1, regularised
+])
+def test_back_to_back_ticks_without_reads(request, preset, rig_fix, stream_fix, over):
+    """esvo_map_tick completes lazily (tick k is committed while tick k+1's front stage is already enqueued).  Ticks
+    issued back to back with NO call that returns data in between must leave the same window, last frame and DepthMap
+    as the oracle's sequential run; reset / set_params / stage-wise calls arriving while a tick is pending complete it."""
+    from esvo_amd import lib
+    from oracle import oracle as O
+    rig, stream = request.getfixturevalue(rig_fix), request.getfixturevalue(stream_fix)
+    p, _ = params.make_params(params.PRESETS[preset], rig, **over)
+    dev = lib.Esvo(p, rig)
+    for rep in range(2):
+        m = O.OracleMapper(p, rig)
+        m.set_mode(True, True)
+        ots = [O.OracleTS(rig.width, rig.height), O.OracleTS(rig.width, rig.height)]
+        t_prev = stream.t0_ns
+        n_ticks = 8 if rep == 0 else 3
+        for k in range(n_ticks):
+            t = stream.t0_ns + int((0.05 + 0.008 * k) * 1e9)
+            for cam in (0, 1):
+                ev = stream.slice(cam, t_prev, t)
+                dev.ts_push_events(cam, ev)
+                ots[cam].push(ev)
+                dev.ts_render(cam, t, download=False)
+            t_prev = t
+            stamps, poses = _oracle_tick(O, m, ots, rig, stream, p, t)
+            left = stream.ev_left[stream.ns_left < t]
+            m.tick(left[O.select_events(left, t, p.bm_half_slice_thickness, p.process_event_num)])
+            dev.set_observation(t, None, None, stream.pose(t))
+            dev.tick(t, stamps, poses)                      # nothing is read back between the ticks
+        if rep == 0:
+            c, s = m.counters(), dev.stats()                # first read: completes the pending tick
+            assert (s.ticks, s.last_window_frames, s.last_window_points) == (n_ticks, c["window_frames"], c["window_points"])
+            assert s.total_events_in > 0 and s.total_points >= s.last_points > 0
+            og = m.get_map()
+            _same_map(dev.get_map(), og)
+            assert len(og) > 100
+            dev.reset()
+        else:
+            dev.set_params(p)                               # arrives while tick 3 is pending
+            _same_map(dev.get_map(), m.get_map())
+            lf = dev.get_last_frame()
+            assert len(lf) == dev.stats().last_points
