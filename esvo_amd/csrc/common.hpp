@@ -173,6 +173,24 @@ void launch_bm_match(const BmArgs& a, const DevParams& p, hipStream_t s);
 void launch_compact_matches(const esvo_match_t* slots, const u32* flags, const u32* prefix, u32 n,
                             esvo_match_t* out, u32* slot_of, hipStream_t s);
 
+// kernels_track.hip: tracker residual / Jacobian evaluation (RegProblemLM.cpp), SURVEY.md section 8(f).1
+struct TrackRef { double T[16]; };            // T_world_ref
+struct TrackPose { double T[16]; double Jc[6]; };  // T_left_ref; J_constPart (3x2, row-major) for the Jacobian
+struct TrackArgs {
+  const double* pts;      // [n][3] points in the reference camera frame
+  const uint8_t* neg;     // TS_negative_left_
+  const int16_t* du;      // dTS_negative_du_left_
+  const int16_t* dv;      // dTS_negative_dv_left_
+  const uint8_t* mask;    // UndistortRectify_mask_ (or nullptr)
+  double P[12];           // left projection matrix
+  int W, H;
+};
+void launch_track_images(const uint8_t* blurred, uint8_t* neg, int16_t* du, int16_t* dv, int W, int H, hipStream_t s);
+void launch_track_reference(const float* xyz, u32 n, const TrackRef& r, double* pts, hipStream_t s);
+void launch_track_residuals(const TrackArgs& a, const TrackPose& pose, u32 offset, u32 count, int huber, double thr, double* fvec,
+                            hipStream_t s);
+void launch_track_jacobian(const TrackArgs& a, const TrackPose& pose, u32 offset, u32 count, double* fjac, hipStream_t s);
+
 // kernels_shard.hip: ordering of a tick's frame from the ranks' (matched, kept) bits
 void launch_shard_codes(const u32* own_w, const u32* keep, const u32* n_local, u32 max_local, uint8_t* codes, hipStream_t s);
 void launch_shard_match_flags(const uint8_t* codes, u32 n, u32* flags, hipStream_t s);

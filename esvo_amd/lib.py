@@ -15,7 +15,7 @@ from .abi import (DEPTH_POINT_DTYPE, EVENT_DTYPE, MATCH_DTYPE, CalibStruct, Para
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 _LIB_PATH = os.path.join(_CSRC, "libesvo_hip.so")
-_SOURCES = ["api.hip", "scan.hip", "kernels_ts.hip", "kernels_bm.hip", "kernels_lm.hip", "kernels_fuse.hip", "kernels_shard.hip"]
+_SOURCES = ["api.hip", "scan.hip", "kernels_ts.hip", "kernels_bm.hip", "kernels_lm.hip", "kernels_fuse.hip", "kernels_shard.hip", "kernels_track.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
                "-Wno-unused-value", "-Wno-unused-result"]
 
@@ -25,6 +25,7 @@ SYMBOLS = [
     "esvo_map_match", "esvo_map_set_poses", "esvo_map_refine", "esvo_map_push_frame", "esvo_map_fuse",
     "esvo_map_tick", "esvo_map_get_depth_points", "esvo_map_get_pointcloud_xyz", "esvo_map_get_last_frame",
     "esvo_get_stats", "esvo_shard_set_band", "esvo_shard_exchange", "esvo_shard_tick_phase", "esvo_abi_sizes",
+    "esvo_track_set_current", "esvo_track_get_images", "esvo_track_set_reference", "esvo_track_residuals", "esvo_track_jacobian",
 ]
 
 
@@ -86,6 +87,11 @@ def load():
     lib.esvo_shard_set_band.argtypes = [vp, i32, i32, i32, i32]
     lib.esvo_shard_exchange.argtypes = [vp, vp, vp]
     lib.esvo_shard_tick_phase.argtypes = [vp, i32, u64, vp, vp, sz]
+    lib.esvo_track_set_current.argtypes = [vp, vp, i32]
+    lib.esvo_track_get_images.argtypes = [vp, vp, vp, vp]
+    lib.esvo_track_set_reference.argtypes = [vp, vp, sz, vp]
+    lib.esvo_track_residuals.argtypes = [vp, vp, sz, sz, i32, C.c_double, vp, psz]
+    lib.esvo_track_jacobian.argtypes = [vp, vp, vp, sz, sz, vp, psz]
     for s in SYMBOLS:
         if s not in ("esvo_default_params", "esvo_last_error", "esvo_abi_sizes"):
             getattr(lib, s).restype = C.c_int
@@ -240,6 +246,39 @@ class Esvo:
         s = StatsStruct()
         self._ck(self.lib.esvo_get_stats(self.h, C.addressof(s)))
         return s
+
+    # ---- tracker residual / Jacobian evaluation (RegProblemLM.cpp), SURVEY.md section 8(f).1 ----
+    def track_set_current(self, ts_left=None, kernel_size=5):
+        img = None if ts_left is None else np.ascontiguousarray(ts_left, np.uint8)
+        self._ck(self.lib.esvo_track_set_current(self.h, None if img is None else img.ctypes.data, int(kernel_size)))
+
+    def track_images(self):
+        neg = np.empty((self.H, self.W), np.uint8)
+        du = np.empty((self.H, self.W), np.int16)
+        dv = np.empty((self.H, self.W), np.int16)
+        self._ck(self.lib.esvo_track_get_images(self.h, neg.ctypes.data, du.ctypes.data, dv.ctypes.data))
+        return neg, du, dv
+
+    def track_set_reference(self, xyz_world, T_world_ref):
+        xyz = np.ascontiguousarray(xyz_world, np.float32).reshape(-1, 3)
+        T = np.ascontiguousarray(T_world_ref, np.float64).reshape(16)
+        self._ck(self.lib.esvo_track_set_reference(self.h, xyz.ctypes.data, xyz.shape[0], T.ctypes.data))
+
+    def track_residuals(self, T_left_ref, offset, count, huber=True, huber_threshold=50.0):
+        T = np.ascontiguousarray(T_left_ref, np.float64).reshape(16)
+        out = np.empty(max(count, 1), np.float64)
+        n = C.c_size_t()
+        self._ck(self.lib.esvo_track_residuals(self.h, T.ctypes.data, int(offset), int(count), 1 if huber else 0,
+                                               float(huber_threshold), out.ctypes.data, C.byref(n)))
+        return out[:n.value]
+
+    def track_jacobian(self, R, t, offset, count):
+        R = np.ascontiguousarray(R, np.float64).reshape(9)
+        t = np.ascontiguousarray(t, np.float64).reshape(3)
+        out = np.empty(6 * max(count, 1), np.float64)
+        n = C.c_size_t()
+        self._ck(self.lib.esvo_track_jacobian(self.h, R.ctypes.data, t.ctypes.data, int(offset), int(count), out.ctypes.data, C.byref(n)))
+        return out[:6 * n.value].reshape(6, n.value).T  # (n, 6); column-major like Eigen's fjac
 
     def set_band(self, y0, y1, shard=0, n_shards=1):
         self._ck(self.lib.esvo_shard_set_band(self.h, int(y0), int(y1), int(shard), int(n_shards)))

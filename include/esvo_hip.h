@@ -287,6 +287,34 @@ int esvo_shard_tick_phase(esvo_handle h, int phase, uint64_t t_ns, const uint64_
 /* The buffer to sum over the ranks before the next phase (n_bytes is a multiple of 8; 0 = nothing). */
 int esvo_shard_exchange(esvo_handle h, void** d_ptr, size_t* n_bytes);
 
+/* ---- Tracker residual / Jacobian evaluation ---------------------- */
+
+/* The adjacent consumer of the hot path: esvo_Tracking's RegProblemLM evaluates, for <= 2000 map points, a
+ * bilinear fetch on the negated blurred left Time Surface (and on its Sobel derivatives for the analytical
+ * Jacobian).  The device already holds that Time Surface, so these calls replace the per-point loops of
+ * RegProblemLM.cpp and spare the tracker the TS download; the 6-DoF LM driver (Eigen, Cayley + SVD) stays on the
+ * host, as north_star has it.  Supported: patch 1x1, kernelSize 0 or 5, l2 / Huber -- what every shipped
+ * cfg/tracking yaml uses.  All calls are synchronous and run on a stream of their own. */
+#define ESVO_TRACK_L2 0
+#define ESVO_TRACK_HUBER 1
+/* TimeSurfaceObservation::getTimeSurfaceNegative(kernelSize) + computeTsNegativeGrad
+ * (TimeSurfaceObservation.h:118-147).  ts_left == NULL: the device-resident left Time Surface of the last
+ * esvo_ts_render(h, 0, ...). */
+int esvo_track_set_current(esvo_handle h, const uint8_t* ts_left, int kernel_size);
+/* TS_negative_left_ (mono8, what the reprojection-map publisher draws on) and its derivatives as int16. */
+int esvo_track_get_images(esvo_handle h, uint8_t* neg, int16_t* du, int16_t* dv);
+/* The point loop of RegProblemLM::setProblem (RegProblemLM.cpp:44-56): p = R_world_ref^T (p_world - t_world_ref).
+ * xyz_world: n x 3 float32 in the caller's order, i.e. after the stochastic swaps of :48-49 (rand() stays with
+ * the caller). */
+int esvo_track_set_reference(esvo_handle h, const float* xyz_world, size_t n, const double T_world_ref[16]);
+/* RegProblemLM::operator() (:91-136) on the batch [offset, offset+count) of setStochasticSampling (:71-88):
+ * fvec[i] = sqrt(w_i) r_i, r_i = TS_negative(x_i) or 255 when the point does not reproject. */
+int esvo_track_residuals(esvo_handle h, const double T_left_ref[16], size_t offset, size_t count, int ls_norm,
+                         double huber_threshold, double* fvec, size_t* n_out);
+/* RegProblemLM::df at x = 0 (:178-269) for the problem's current R_, t_: fjac is n_out x 6, column-major. */
+int esvo_track_jacobian(esvo_handle h, const double R[9], const double t[3], size_t offset, size_t count,
+                        double* fjac, size_t* n_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,6 +10,8 @@
 //                                     (esvo_core/src/core/DepthProblemSolver.cpp:28-78, :216-244)
 //   esvo_core::core::DepthFusion (window push + update loop) / DepthMap::clean /
 //   DepthRegularization::apply        (esvo_core/src/esvo_Mapping.cpp:341-395)
+//   esvo_core::core::RegProblemLM::setProblem / operator() / df   (the tracker's evaluation side,
+//                                     esvo_core/src/core/RegProblemLM.cpp:26-269)
 //
 // Header only, C++14, no ROS / Eigen / OpenCV types: poses are row-major 4x4 doubles, images are
 // mono8 pointers, events are esvo_event_t (layout-identical to dvs_msgs::Event).  Every method
@@ -232,6 +234,55 @@ inline void MappingAtTime(Context& ctx, const StampedTimeSurfaceObs& obs, const 
   ctx.check(esvo_map_tick(ctx.handle(), obs.t_ns, st_map.stamps_ns.data(), st_map.T_world_virtual.data(), st_map.size()),
             "esvo_map_tick");
 }
+
+// esvo_core::core::RegProblemLM's evaluation side (esvo_core/src/core/RegProblemLM.cpp): the per-point loops of
+// setProblem (:44-56), operator() (:91-136) and df (:178-269) on the device.  The 6-DoF LM driver, the Cayley update and
+// the SVD re-orthonormalisation (getWarpingTransformation / addMotionUpdate, :328-364) stay with the caller, who passes
+// the resulting 4x4 warp (for operator()) or R_, t_ (for df) in row-major doubles.
+struct RegProblemConfig {       // the fields of RegProblemConfig the evaluation reads (cfg/tracking/*.yaml)
+  int kernelSize = 5;
+  bool huber = true;            // LSnorm: "Huber" | "l2"
+  double huber_threshold = 50.0;
+  size_t BATCH_SIZE = 300;
+  size_t MAX_REGISTRATION_POINTS = 2000;
+};
+class RegProblemLM {
+ public:
+  RegProblemLM(ContextPtr ctx, const RegProblemConfig& cfg) : ctx_(std::move(ctx)), cfg_(cfg) {}
+  // setProblem: ref's point cloud (already in the stochastic order of :48-49) + the current frame's left Time Surface
+  // (nullptr = the device-resident one of the last createTimeSurfaceAtTime of the left camera)
+  void setProblem(const float* ref_xyz_world, size_t n_points, const double T_world_ref[16], const uint8_t* cur_TS_left) {
+    numPoints_ = std::min(n_points, cfg_.MAX_REGISTRATION_POINTS);
+    ctx_->check(esvo_track_set_reference(ctx_->handle(), ref_xyz_world, numPoints_, T_world_ref), "esvo_track_set_reference");
+    ctx_->check(esvo_track_set_current(ctx_->handle(), cur_TS_left, cfg_.kernelSize), "esvo_track_set_current");
+    numBatches_ = std::max(numPoints_ / cfg_.BATCH_SIZE, (size_t)1);
+    setStochasticSampling(0, numPoints_);
+  }
+  void setStochasticSampling(size_t offset, size_t N) { offset_ = offset; count_ = N; }
+  // operator(): fvec for the warp T_left_ref the caller derived from x; returns the number of values
+  size_t operator()(const double T_left_ref[16], std::vector<double>& fvec) const {
+    fvec.resize(count_);
+    size_t n = 0;
+    ctx_->check(esvo_track_residuals(ctx_->handle(), T_left_ref, offset_, count_, cfg_.huber ? ESVO_TRACK_HUBER : ESVO_TRACK_L2,
+                                     cfg_.huber_threshold, fvec.data(), &n), "esvo_track_residuals");
+    fvec.resize(n);
+    return n;
+  }
+  // df at x = 0: fjac is n x 6, column-major (Eigen::MatrixXd layout)
+  size_t df(const double R[9], const double t[3], std::vector<double>& fjac) const {
+    fjac.resize(6 * count_);
+    size_t n = 0;
+    ctx_->check(esvo_track_jacobian(ctx_->handle(), R, t, offset_, count_, fjac.data(), &n), "esvo_track_jacobian");
+    fjac.resize(6 * n);
+    return n;
+  }
+  size_t numBatches_ = 1, numPoints_ = 0;
+
+ private:
+  ContextPtr ctx_;
+  RegProblemConfig cfg_;
+  size_t offset_ = 0, count_ = 0;
+};
 
 }  // namespace esvo_hip
 #endif  // ESVO_HIP_HPP

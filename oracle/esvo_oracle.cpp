@@ -1343,6 +1343,160 @@ extern "C" int orc_mapper_eval_residual(orc_mapper_handle h, const double x_left
   return prob(rho, fvec);
 }
 // ZNCC cost of two wy x wx patches (row-major doubles), literal and integer-moment forms
+// =====================================================================================================
+// Tracker: residual and Jacobian evaluation -- esvo_core/src/core/RegProblemLM.cpp with the
+// shipped settings (patch 1x1, kernelSize 5, Huber, analytical Jacobian; cfg/tracking/*.yaml)
+// =====================================================================================================
+struct orc_tracker {
+  Camera camL;
+  int W = 0, H = 0;
+  std::vector<double> neg;      // TS_negative_left_ (row-major)
+  std::vector<double> du, dv;   // dTS_negative_du/dv_left_ (cv::Sobel, CV_64F, ksize 3, BORDER_REFLECT_101)
+  std::vector<double> pts;      // ResItems_[i].p_ : 3 doubles per point, ref camera frame
+};
+
+namespace {
+// RegProblemLM::isValidPatch (:366-385) for wx = wy = 1: (w-1)/2 == 0 in size_t arithmetic; Eigen index = truncation
+bool trk_valid_patch(const orc_tracker* T, const double x[2]) {
+  if (!std::isfinite(x[0]) || !std::isfinite(x[1])) return false;  // oracle definition (UB in the reference)
+  if (x[0] < 0.0 || x[0] > (double)(T->W - 1) || x[1] < 0.0 || x[1] > (double)(T->H - 1)) return false;
+  if (!T->camL.mask.empty() && T->camL.mask[(size_t)(int)x[1] * T->W + (int)x[0]] < 125) return false;
+  return true;
+}
+// RegProblemLM::reprojection (:387-401)
+bool trk_reproject(const orc_tracker* T, const double p[3], const double Tw[16], double x[2]) {
+  double pl[3];
+  for (int r = 0; r < 3; ++r) pl[r] = ((Tw[r * 4 + 0] * p[0] + Tw[r * 4 + 1] * p[1]) + Tw[r * 4 + 2] * p[2]) + Tw[r * 4 + 3];
+  T->camL.world2Cam(pl, x);
+  return trk_valid_patch(T, x);
+}
+// RegProblemLM::patchInterpolation (:403-483) for a 1x1 patch
+bool trk_interp(const orc_tracker* T, const std::vector<double>& img, const double loc[2], double* out) {
+  const int ux = (int)std::floor(loc[0]), uy = (int)std::floor(loc[1]);
+  if (ux < 0 || uy < 0) return false;
+  if (ux >= T->W || uy >= T->H) return false;
+  const double q1 = (double)(ux + 1) - loc[0], q2 = loc[0] - (double)ux;
+  const double q3 = (double)(uy + 1) - loc[1], q4 = loc[1] - (double)uy;
+  if (uy + 1 >= T->H || ux + 1 >= T->W) return false;
+  const double* s = img.data() + (size_t)uy * T->W + ux;
+  const double r0 = q1 * s[0] + q2 * s[1];
+  const double r1 = q1 * s[T->W] + q2 * s[T->W + 1];
+  *out = q3 * r0 + q4 * r1;
+  return true;
+}
+}  // namespace
+
+extern "C" orc_tracker_handle orc_tracker_create(const esvo_calib_t* left) {
+  orc_tracker* T = new orc_tracker();
+  T->camL.init(left);
+  T->W = left->width; T->H = left->height;
+  return T;
+}
+extern "C" void orc_tracker_destroy(orc_tracker_handle T) { delete T; }
+
+// TimeSurfaceObservation::getTimeSurfaceNegative(kernelSize) + computeTsNegativeGrad (TimeSurfaceObservation.h:118-147)
+extern "C" int orc_tracker_set_current(orc_tracker_handle T, const uint8_t* ts_left, int kernel_size) {
+  const int W = T->W, H = T->H;
+  std::vector<uint8_t> blur((size_t)W * H);
+  if (kernel_size == 0) std::memcpy(blur.data(), ts_left, blur.size());
+  else if (kernel_size == 5) gaussian5_u8(ts_left, blur.data(), W, H);  // 8-bit GaussianBlur, sigma 0 (Appendix B.2)
+  else return -1;
+  T->neg.resize((size_t)W * H); T->du.resize(T->neg.size()); T->dv.resize(T->neg.size());
+  for (size_t i = 0; i < T->neg.size(); ++i) T->neg[i] = 255.0 - (double)blur[i];
+  for (int y = 0; y < H; ++y)
+    for (int x = 0; x < W; ++x) {
+      auto at = [&](int yy, int xx) { return T->neg[(size_t)reflect101(yy, H) * W + reflect101(xx, W)]; };
+      // separable Sobel: derivative [-1 0 1] along one axis, smoothing [1 2 1] along the other (exact in f64)
+      T->du[(size_t)y * W + x] = (at(y - 1, x + 1) - at(y - 1, x - 1)) + 2.0 * (at(y, x + 1) - at(y, x - 1)) + (at(y + 1, x + 1) - at(y + 1, x - 1));
+      T->dv[(size_t)y * W + x] = (at(y + 1, x - 1) - at(y - 1, x - 1)) + 2.0 * (at(y + 1, x) - at(y - 1, x)) + (at(y + 1, x + 1) - at(y - 1, x + 1));
+    }
+  return 0;
+}
+extern "C" void orc_tracker_get_images(orc_tracker_handle T, uint8_t* neg, int16_t* du, int16_t* dv) {
+  for (size_t i = 0; i < T->neg.size(); ++i) { neg[i] = (uint8_t)T->neg[i]; du[i] = (int16_t)T->du[i]; dv[i] = (int16_t)T->dv[i]; }
+}
+
+// the point loop of RegProblemLM::setProblem (:44-56): p_cam = R_world_ref^T (p - t_world_ref); the caller has
+// already applied the stochastic swaps (:48-49, rand())
+extern "C" void orc_tracker_set_reference(orc_tracker_handle T, const float* xyz_world, size_t n, const double T_world_ref[16]) {
+  T->pts.resize(3 * n);
+  for (size_t i = 0; i < n; ++i) {
+    double d[3];
+    for (int k = 0; k < 3; ++k) d[k] = (double)xyz_world[3 * i + k] - T_world_ref[k * 4 + 3];
+    for (int r = 0; r < 3; ++r)  // row r of R^T = column r of R
+      T->pts[3 * i + r] = (T_world_ref[0 * 4 + r] * d[0] + T_world_ref[1 * 4 + r] * d[1]) + T_world_ref[2 * 4 + r] * d[2];
+  }
+}
+
+// RegProblemLM::operator() (:91-136) + thread() (:138-176) over ResItems [offset, offset + count)
+extern "C" size_t orc_tracker_residuals(orc_tracker_handle T, const double T_left_ref[16], size_t offset, size_t count,
+                                        int huber, double huber_threshold, double* fvec) {
+  size_t n = 0;
+  for (size_t i = offset; i < offset + count && 3 * i < T->pts.size(); ++i, ++n) {
+    double x[2], r = 255.0, tau;
+    if (trk_reproject(T, &T->pts[3 * i], T_left_ref, x) && trk_interp(T, T->neg, x, &tau)) r = tau;
+    if (huber) {
+      double w = 1.0;
+      if (r > huber_threshold) w = huber_threshold / r;
+      fvec[n] = std::sqrt(w) * r;
+    } else {
+      fvec[n] = r;
+    }
+  }
+  return n;
+}
+
+// RegProblemLM::df at x = 0 (:178-269).  R, t are the problem's R_, t_ (T_ref_left); fjac is count x 6, column-major.
+// Products are taken left to right as written at :236; J_G_0_ (computeJ_G at zero, :271-326) has the entries 0, +-2, 1.
+extern "C" size_t orc_tracker_jacobian(orc_tracker_handle T, const double R[9], const double t[3], size_t offset, size_t count,
+                                       double* fjac) {
+  size_t m = 0;
+  for (size_t i = offset; i < offset + count && 3 * i < T->pts.size(); ++i) ++m;
+  const double* P = T->camL.P;
+  const double P11 = P[0], P12 = P[1], P14 = P[3], P21 = P[4], P22 = P[5], P24 = P[7];
+  double Tlr[16] = {0};  // T_left_ref = [R^T | -R^T t]
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) Tlr[r * 4 + c] = R[c * 3 + r];
+    Tlr[r * 4 + 3] = (-R[0 * 3 + r] * t[0] + -R[1 * 3 + r] * t[1]) + -R[2 * 3 + r] * t[2];
+  }
+  Tlr[15] = 1.0;
+  double Jc[3][2];  // J_constPart = R^T * diag(1/P11, 1/P22; 0)
+  const double iP11 = 1.0 / P11, iP22 = 1.0 / P22;
+  for (int r = 0; r < 3; ++r) { Jc[r][0] = R[0 * 3 + r] * iP11; Jc[r][1] = R[1 * 3 + r] * iP22; }
+  for (size_t k = 0; k < m; ++k) {
+    const double* p = &T->pts[3 * (offset + k)];
+    double e[12];
+    double x[2];
+    if (!trk_reproject(T, p, Tlr, x)) {
+      for (int j = 0; j < 12; ++j) e[j] = 0.0;
+    } else {
+      double gx = 0.0, gy = 0.0;  // the reference ignores patchInterpolation's failure here (border pixel): defined as 0
+      trk_interp(T, T->du, x, &gx);
+      trk_interp(T, T->dv, x, &gy);
+      const double g0 = gx / 8, g1 = gy / 8;  // 8 = normalisation of the 3x3 Sobel filter
+      const double z = p[2], z2 = z * z;
+      double D[2][3];
+      D[0][0] = P11 / z; D[0][1] = P12 / z; D[0][2] = -((P11 * p[0] + P12 * p[1]) + P14) / z2;
+      D[1][0] = P21 / z; D[1][1] = P22 / z; D[1][2] = -((P21 * p[0] + P22 * p[1]) + P24) / z2;
+      double a[3], b[2], c[3];
+      for (int j = 0; j < 3; ++j) a[j] = g0 * D[0][j] + g1 * D[1][j];
+      for (int j = 0; j < 2; ++j) b[j] = (a[0] * Jc[0][j] + a[1] * Jc[1][j]) + a[2] * Jc[2][j];
+      for (int j = 0; j < 3; ++j) c[j] = b[0] * D[0][j] + b[1] * D[1][j];
+      for (int j = 0; j < 3; ++j) {  // dT_dG = [x I, y I, z I, I], then the factor p_z
+        e[j] = (c[j] * p[0]) * z; e[3 + j] = (c[j] * p[1]) * z; e[6 + j] = (c[j] * p[2]) * z; e[9 + j] = c[j] * z;
+      }
+    }
+    // fjac = -fjacBlock * J_G_0_
+    fjac[0 * m + k] = -(2.0 * e[5] - 2.0 * e[7]);
+    fjac[1 * m + k] = -(2.0 * e[6] - 2.0 * e[2]);
+    fjac[2 * m + k] = -(2.0 * e[1] - 2.0 * e[3]);
+    fjac[3 * m + k] = -e[9];
+    fjac[4 * m + k] = -e[10];
+    fjac[5 * m + k] = -e[11];
+  }
+  return m;
+}
+
 extern "C" double orc_zncc_cost(const double* l, const double* r, int wx, int wy, int exact_int) {
   if (!exact_int) {
     std::vector<double> t1((size_t)wx * wy), t2((size_t)wx * wy);

@@ -108,6 +108,19 @@ int orc_mapper_eval_residual(orc_mapper_handle h, const double x_left[2], uint32
 double orc_zncc_cost(const double* l, const double* r, int wx, int wy, int exact_int);
 void orc_abi_sizes(size_t out[8]);
 
+/* ---------- Tracker residual / Jacobian evaluation (esvo_core/src/core/RegProblemLM.cpp) ---------- */
+typedef struct orc_tracker* orc_tracker_handle;
+orc_tracker_handle orc_tracker_create(const esvo_calib_t* left);
+void orc_tracker_destroy(orc_tracker_handle h);
+/* getTimeSurfaceNegative(kernelSize in {0,5}) + computeTsNegativeGrad; returns -1 for another kernel size */
+int orc_tracker_set_current(orc_tracker_handle h, const uint8_t* ts_left, int kernel_size);
+void orc_tracker_get_images(orc_tracker_handle h, uint8_t* neg, int16_t* du, int16_t* dv);
+void orc_tracker_set_reference(orc_tracker_handle h, const float* xyz_world, size_t n, const double T_world_ref[16]);
+size_t orc_tracker_residuals(orc_tracker_handle h, const double T_left_ref[16], size_t offset, size_t count, int huber,
+                             double huber_threshold, double* fvec);
+size_t orc_tracker_jacobian(orc_tracker_handle h, const double R[9], const double t[3], size_t offset, size_t count,
+                            double* fjac);
+
 #ifdef __cplusplus
 }
 #endif

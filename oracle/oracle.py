@@ -86,6 +86,17 @@ def load(fast=False):
     lib.orc_mapper_eval_residual.argtypes = [vp, vp, C.c_uint32, dbl, vp]
     lib.orc_zncc_cost.restype = dbl
     lib.orc_zncc_cost.argtypes = [vp, vp, i32, i32, i32]
+    lib.orc_tracker_create.restype = vp
+    lib.orc_tracker_create.argtypes = [vp]
+    lib.orc_tracker_destroy.argtypes = [vp]
+    lib.orc_tracker_set_current.restype = i32
+    lib.orc_tracker_set_current.argtypes = [vp, vp, i32]
+    lib.orc_tracker_get_images.argtypes = [vp, vp, vp, vp]
+    lib.orc_tracker_set_reference.argtypes = [vp, vp, sz, vp]
+    lib.orc_tracker_residuals.restype = sz
+    lib.orc_tracker_residuals.argtypes = [vp, vp, sz, sz, i32, dbl, vp]
+    lib.orc_tracker_jacobian.restype = sz
+    lib.orc_tracker_jacobian.argtypes = [vp, vp, vp, sz, sz, vp]
     lib.orc_abi_sizes.argtypes = [vp]
     _libs[key] = lib
     return lib
@@ -164,6 +175,53 @@ def denoise_events(ev, idx, width, height, max_num):
     n = lib.orc_denoise_events(ev.ctypes.data, idx.ctypes.data, idx.shape[0], width, height, int(max_num),
                                out.ctypes.data)
     return out[:n]
+
+
+class OracleTracker:
+    """RegProblemLM residual / Jacobian evaluation (esvo_core/src/core/RegProblemLM.cpp), SURVEY.md section 8(f).1."""
+
+    def __init__(self, rig, fast=False):
+        self.lib = load(fast)
+        self.W, self.H = rig.width, rig.height
+        self._cl = rig.left.as_struct()
+        self.h = self.lib.orc_tracker_create(C.addressof(self._cl))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.orc_tracker_destroy(self.h)
+            self.h = None
+
+    def set_current(self, ts_left, kernel_size=5):
+        img = np.ascontiguousarray(ts_left, np.uint8)
+        if self.lib.orc_tracker_set_current(self.h, img.ctypes.data, int(kernel_size)) != 0:
+            raise ValueError("unsupported kernel size")
+
+    def images(self):
+        neg = np.empty((self.H, self.W), np.uint8)
+        du = np.empty((self.H, self.W), np.int16)
+        dv = np.empty((self.H, self.W), np.int16)
+        self.lib.orc_tracker_get_images(self.h, neg.ctypes.data, du.ctypes.data, dv.ctypes.data)
+        return neg, du, dv
+
+    def set_reference(self, xyz_world, T_world_ref):
+        xyz = np.ascontiguousarray(xyz_world, np.float32).reshape(-1, 3)
+        T = np.ascontiguousarray(T_world_ref, np.float64).reshape(16)
+        self.n = xyz.shape[0]
+        self.lib.orc_tracker_set_reference(self.h, xyz.ctypes.data, self.n, T.ctypes.data)
+
+    def residuals(self, T_left_ref, offset, count, huber=True, huber_threshold=50.0):
+        T = np.ascontiguousarray(T_left_ref, np.float64).reshape(16)
+        out = np.empty(count, np.float64)
+        n = self.lib.orc_tracker_residuals(self.h, T.ctypes.data, int(offset), int(count), int(bool(huber)), float(huber_threshold),
+                                           out.ctypes.data)
+        return out[:n]
+
+    def jacobian(self, R, t, offset, count):
+        R = np.ascontiguousarray(R, np.float64).reshape(9)
+        t = np.ascontiguousarray(t, np.float64).reshape(3)
+        out = np.empty(6 * count, np.float64)
+        n = self.lib.orc_tracker_jacobian(self.h, R.ctypes.data, t.ctypes.data, int(offset), int(count), out.ctypes.data)
+        return out[:6 * n].reshape(6, n).T  # (n, 6); the C layout is column-major like Eigen's
 
 
 class OracleMapper:

@@ -3,7 +3,7 @@
 //   ebm_.createMatchProblem / match_all_HyperThread -> dpSolver_.solve / pointCulling ->
 //   dqvDepthPoints_.push_back + dFusor_.update loop -> clean -> regularisation
 // on a fixture dumped by tests/test_cpp_host.py, and writes every stage's output for comparison
-// with the golden vectors.   usage: replay_golden <fixture.bin> <out.bin>
+// with the golden vectors; at the end the tracker's evaluation side (RegProblemLM) runs once on the local map.   usage: replay_golden <fixture.bin> <out.bin>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -51,6 +51,8 @@ int main(int argc, char** argv) {
     DepthProblemSolver dpSolver(ctx);
     DepthFusion dFusor(ctx);
     const double cost_vis_threshold = prm.residual_vis_threshold * prm.residual_vis_threshold * (prm.patch_size_x * prm.patch_size_y);
+    std::vector<uint8_t> last_tsL;
+    double last_T[16] = {0};
     for (int k = 0; k < n_ticks; ++k) {
       StampedTimeSurfaceObs TS_obs;
       rd(in, &TS_obs.t_ns, 1);
@@ -83,6 +85,24 @@ int main(int argc, char** argv) {
       n = vdp.size();  wr(out, &n, 1); wr(out, vdp.data(), vdp.size());
       wr(out, &numFusionCount, 1);
       n = map.size();  wr(out, &n, 1); wr(out, map.data(), map.size());
+      last_tsL = tsL;
+      std::memcpy(last_T, TS_obs.T_world_cam, sizeof(last_T));
+    }
+    {  // the tracker's evaluation side on the local map: RegProblemLM::setProblem / operator() / df (RegProblemLM.cpp)
+      std::vector<float> xyz;
+      dFusor.getPointCloud(xyz);
+      RegProblemConfig cfg;  // cfg/tracking/*.yaml: kernelSize 5, Huber 50, batches of 300
+      RegProblemLM reg(ctx, cfg);
+      reg.setProblem(xyz.data(), xyz.size() / 3, last_T, last_tsL.data());
+      reg.setStochasticSampling(0, cfg.BATCH_SIZE);
+      const double I4[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+      const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, zero3[3] = {0, 0, 0};
+      std::vector<double> fvec, fjac;
+      reg(I4, fvec);
+      reg.df(I3, zero3, fjac);
+      uint64_t n = xyz.size(); wr(out, &n, 1); wr(out, xyz.data(), xyz.size());
+      n = fvec.size(); wr(out, &n, 1); wr(out, fvec.data(), fvec.size());
+      n = fjac.size(); wr(out, &n, 1); wr(out, fjac.data(), fjac.size());
     }
     // error behaviour: unsupported configuration is rejected, not approximated
     try {

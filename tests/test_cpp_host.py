@@ -86,4 +86,17 @@ def test_cpp_replay_matches_golden(tmp_path, name):
         for f in F64:
             assert np.array_equal(pts[f], g[f"points{k}"][f]), f
             assert np.array_equal(mp[f], g[f"map{k}"][f]), f
+    # tracker evaluation through esvo_hip::RegProblemLM, against the oracle on the very same inputs
+    from oracle import oracle as O
+    xyz = take(np.dtype("<f4")).reshape(-1, 3)
+    fvec = take(np.dtype("<f8"))
+    fjac = take(np.dtype("<f8"))
     assert off == len(buf)
+    k = int(g["n_ticks"]) - 1
+    trk = O.OracleTracker(rig)
+    trk.set_current(g[f"tsL{k}"], 5)
+    trk.set_reference(xyz[:2000], np.asarray(g[f"T{k}"], np.float64).reshape(4, 4))
+    o = trk.residuals(np.eye(4), 0, 300, huber=True, huber_threshold=50.0)
+    assert len(fvec) == len(o) > 0 and np.array_equal(fvec, o) and (o < 255).any()
+    oj = trk.jacobian(np.eye(3), np.zeros(3), 0, 300)
+    assert np.array_equal(fjac.reshape(6, -1).T, oj)
