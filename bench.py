@@ -130,9 +130,13 @@ def main():
                               event_ring_capacity=max(1 << 22, int(len(stream.ev_left) * 1.1)))
     nd = p.bm_max_disparity - p.bm_min_disparity + 1
 
+    shard_mode = os.environ.get("ESVO_SHARD_MODE", "tick")
     if world > 1:
         from esvo_amd import dist as edist
-        runner = edist.ShardedEsvo(p, rig, rank, world, local_rank)
+        # "tick": ticks dealt round-robin to the GPUs, one all-gather of frames per round (throughput scaling);
+        # "band": every tick split over the GPUs by slot / image row band (latency of one tick)
+        cls = edist.TickShardedEsvo if shard_mode == "tick" else edist.ShardedEsvo
+        runner = cls(p, rig, rank, world, local_rank)
     else:
         runner = lib.Esvo(p, rig, device=local_rank)
 
@@ -170,22 +174,32 @@ def main():
     st = runner.stats()
     n_events = int(st.total_events_in - base.total_events_in)
     n_points = int(st.total_points - base.total_points)
+    n_matches = int(st.total_matches - base.total_matches)
     ksum = np.array(list(st.sum_ms_kernel)) - np.array(list(base.sum_ms_kernel))
+    launches = max(int(st.ticks - base.ticks), 1)   # ticks THIS rank mapped (all of them unless ticks are interleaved)
     if dist:
         tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        if getattr(runner, "counts_are_local", False):  # tick-interleaved: every rank counted its own ticks
+            cnt = torch.tensor([n_events, n_points], device="cuda", dtype=torch.float64)
+            dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+            ev_rank, mt_rank = n_events, n_matches
+            n_events, n_points = int(cnt[0].item()), int(cnt[1].item())
+        else:
+            ev_rank, mt_rank = n_events / world, n_matches / world
+    else:
+        ev_rank, mt_rank = n_events, n_matches
 
-    kavg = ksum / max(K, 1)
+    kavg = ksum / launches
     if ksum[7] > 0:  # TS kernels: per-render samples (some are skipped while their events are in flight), two renders per tick
         kavg[0], kavg[1] = 2 * ksum[0] / ksum[7], 2 * ksum[1] / ksum[7]
     # roofline of the dominant single kernel (slots 2 = bm_match_kernel, 3 = lm_refine_kernel; the fuse / regularize
     # slots are stages of several kernels and, like every slot, include the slowdown from the other stream's kernels)
     dom = 2 + int(np.argmax(kavg[2:4]))
     dom_name = KERNEL_NAMES[dom]
-    n_matches = int(st.total_matches - base.total_matches)
-    dom_bytes = algorithmic_bytes(dom_name, st, rig.width, rig.height, nd, p.fusion_radius, events=n_events / max(K, 1) / world,
-                                  matches=n_matches / max(K, 1) / world)
+    dom_bytes = algorithmic_bytes(dom_name, st, rig.width, rig.height, nd, p.fusion_radius, events=ev_rank / launches,
+                                  matches=mt_rank / launches)
     achieved = (dom_bytes / (kavg[dom] * 1e-3)) / 1e9 if kavg[dom] > 0 else 0.0
     out = {
         "metric": "mapped events/sec (stereo TS raster + block matching + LM depth refinement + fusion)",
@@ -208,7 +222,8 @@ def main():
             "image": [rig.width, rig.height],
             "events_per_tick": n_events // max(K, 1),
             "disparity_range": [p.bm_min_disparity, p.bm_max_disparity],
-            "parallelism": "1 GPU" if world == 1 else f"{world} GPUs, image row bands",
+            "parallelism": "1 GPU" if world == 1 else (f"{world} GPUs, ticks interleaved, all-gather of frames" if shard_mode == "tick"
+                                                       else f"{world} GPUs, slots + image row bands"),
         },
         "kernel_ms": {KERNEL_NAMES[i]: round(float(kavg[i]), 4) for i in range(7)},
         "roofline": {

@@ -177,6 +177,14 @@ struct esvo_context {
   size_t trk_cap = 0, trk_n = 0;
   bool trk_cur = false;
 
+  // pinned staging slots for frame pose tables that arrive from the host (push_frame variants): a slot is reused only
+  // after the back stream has consumed it
+  static constexpr int POSE_POOL = 32;
+  double* h_pose_pool = nullptr;
+  hipEvent_t pool_evt[POSE_POOL];
+  bool pool_ok = false;
+  int pool_next = 0;
+
   hipEvent_t evt[EV_N];
   bool evt_ok = false;
   esvo_stats_t stats;
@@ -470,8 +478,14 @@ int commit_frame(esvo_context* h, u32 off, u32 count, const double* pose_T_host,
   if (rc) return rc;
   if (m) {
     double* dst = h->d_frame_pose_T + (size_t)slot * h->max_poses * 16;
-    if (pose_T_host) {
-      HIPCHK(hipMemcpyAsync(dst, pose_T_host, sizeof(double) * 16 * m, hipMemcpyHostToDevice, h->stream_b));
+    if (pose_T_host) {  // through a pinned slot: an async copy from pageable memory would stall the host behind the stream
+      const int ps = h->pool_next;
+      h->pool_next = (ps + 1) % esvo_context::POSE_POOL;
+      HIPCHK(hipEventSynchronize(h->pool_evt[ps]));
+      double* pin = h->h_pose_pool + (size_t)ps * h->max_poses * 16;
+      std::memcpy(pin, pose_T_host, sizeof(double) * 16 * m);
+      HIPCHK(hipMemcpyAsync(dst, pin, sizeof(double) * 16 * m, hipMemcpyHostToDevice, h->stream_b));
+      HIPCHK(hipEventRecord(h->pool_evt[ps], h->stream_b));
     } else {
       HIPCHK(hipMemcpyAsync(dst, h->d_pose_T2[pose_buf], sizeof(double) * 16 * m, hipMemcpyDeviceToDevice, h->stream_b));
       HIPCHK(hipEventRecord(h->evt[EV_POSE + pose_buf * EV_BACK_STRIDE], h->stream_b));
@@ -732,6 +746,9 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
   CK(dalloc(&h->d_export_cell, npx));
   for (int i = 0; i < EV_N; ++i) CK(hipEventCreate(&h->evt[i]));
   h->evt_ok = true;
+  CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_pose_pool), sizeof(double) * 16 * (size_t)h->max_poses * esvo_context::POSE_POOL));
+  for (int i = 0; i < esvo_context::POSE_POOL; ++i) CK(hipEventCreate(&h->pool_evt[i]));
+  h->pool_ok = true;
   for (int i = 0; i < 16; ++i) h->T_world_obs[i] = h->T_world_frame[i] = (i % 5 == 0) ? 1.0 : 0.0;
   CK(hipMemcpy(h->d_T_world_obs, h->T_world_obs, sizeof(double) * 16, hipMemcpyHostToDevice));
 #undef CK
@@ -758,6 +775,8 @@ int esvo_destroy(esvo_handle h) {
   if (h->h_pin) hipHostFree(h->h_pin);
   if (h->h_fr_table) hipHostFree(h->h_fr_table);
   if (h->evt_ok) for (int i = 0; i < EV_N; ++i) hipEventDestroy(h->evt[i]);
+  if (h->pool_ok) for (int i = 0; i < esvo_context::POSE_POOL; ++i) hipEventDestroy(h->pool_evt[i]);
+  if (h->h_pose_pool) hipHostFree(h->h_pose_pool);
   if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
   if (h->stream_b) hipStreamDestroy(h->stream_b);
   if (h->stream_t) { hipStreamSynchronize(h->stream_t); hipStreamDestroy(h->stream_t); }
@@ -1270,6 +1289,78 @@ extern "C" int esvo_map_tick(esvo_handle h, uint64_t t_ns, const uint64_t* pose_
     if (rc) return rc;
     h->tick_pending = true;  // this tick
   }
+  return ESVO_OK;
+}
+
+// ---- device-resident stage calls: the building blocks of tick-interleaved multi-GPU operation ---------------------
+// (rank r maps the ticks k with k % N == r completely; a tick needs nothing from the previous DepthMaps -- the
+// DepthFrame is rebuilt from the window at every tick, esvo_Mapping.cpp:266-272 -- only the frames of the last
+// ticks, which the ranks all-gather; see esvo_amd/dist.py)
+extern "C" int esvo_map_front(esvo_handle h, uint64_t t_ns, const uint64_t* pose_t_ns, const double* pose_T, size_t m,
+                              size_t* n_points) {
+  if (!h || !pose_t_ns || !pose_T || !n_points) return ESVO_ERR_INVALID_ARG;
+  if (!h->obs_set) FAIL(ESVO_ERR_STATE, "esvo_map_set_observation has not been called");
+  if (h->sharded) FAIL(ESVO_ERR_STATE, "handle is sharded by slot/band: esvo_map_front maps whole ticks");
+  HIPCHK(hipSetDevice(h->device));
+  int rc = flush_pending_tick(h);
+  if (rc) return rc;
+  rc = tick_phase0(h, t_ns, pose_t_ns, pose_T, m);
+  if (rc) return rc;
+  const u32 n = h->tk[h->fpar].n;
+  if (n) { rc = run_order_points(h, n, h->d_pts_tmp); if (rc) return rc; }
+  HIPCHK(hipMemcpyAsync(h->h_counters + 16 * h->fpar, h->d_counters, sizeof(u32) * 16, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipEventRecord(h->evt[EV_CNT + h->fpar * EV_FRONT_STRIDE], h->stream));
+  rc = tick_phase1_collect(h, h->fpar);
+  if (rc) return rc;
+  *n_points = h->tk[h->fpar].points;
+  return ESVO_OK;
+}
+
+extern "C" int esvo_map_front_frame(esvo_handle h, const esvo_depth_point_t** d_frame) {
+  if (!h || !d_frame) return ESVO_ERR_INVALID_ARG;
+  *d_frame = h->d_pts_tmp;
+  return ESVO_OK;
+}
+
+extern "C" int esvo_map_push_frame_device(esvo_handle h, const esvo_depth_point_t* d_pts, size_t n, const double* pose_T,
+                                          size_t m) {
+  if (!h || (n && !d_pts) || (m && !pose_T)) return ESVO_ERR_INVALID_ARG;
+  if (m > h->max_poses) FAIL(ESVO_ERR_CAPACITY, "pose table larger than max_poses_per_tick");
+  HIPCHK(hipSetDevice(h->device));
+  int rc = flush_pending_tick(h);
+  if (rc) return rc;
+  u32 off;
+  rc = window_reserve(h, (u32)n, &off);
+  if (rc) return rc;
+  // the points were produced on the front stream (or by a collective the caller issued there); the copy runs on the
+  // back stream, behind any fusion that still reads ring space freed by earlier pops
+  rc = back_after_front(h);
+  if (rc) return rc;
+  if (n) HIPCHK(hipMemcpyAsync(h->d_win + off, d_pts, sizeof(esvo_depth_point_t) * n, hipMemcpyDeviceToDevice, h->stream_b));
+  static const double ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  return commit_frame(h, off, (u32)n, m ? pose_T : ident, (u32)m);
+}
+
+extern "C" int esvo_map_fuse_async(esvo_handle h) {
+  if (!h) return ESVO_ERR_INVALID_ARG;
+  if (!h->obs_set) FAIL(ESVO_ERR_STATE, "esvo_map_set_observation has not been called");
+  HIPCHK(hipSetDevice(h->device));
+  int rc = flush_pending_tick(h);
+  if (rc) return rc;
+  rc = back_after_front(h);
+  if (rc) return rc;
+  const int par = h->par;
+  h->par ^= 1;
+  HIPCHK(hipEventSynchronize(h->evt[EV_RG1 + par * EV_BACK_STRIDE]));
+  collect_back(h, par);
+  rc = run_fuse(h, par, h->T_world_obs);
+  if (rc) return rc;
+  h->stats.ticks++;
+  h->stats.last_window_frames = (u32)h->frames.size();
+  u32 np = 0;
+  for (auto& f : h->frames) np += f.count;
+  h->stats.last_window_points = np;
+  h->stats_pending = true;
   return ESVO_OK;
 }
 

@@ -1,6 +1,11 @@
-"""Multi-GPU sharding of the mapper: one process per GPU, the two exchange steps of a
-tick run through torch.distributed (backend "nccl" = RCCL over xGMI) on device buffers the C-ABI hands
-out (esvo_shard_exchange).  PyTorch is plumbing here: device-pointer views + collectives; every
+"""Multi-GPU operation of the mapper, one process per GPU, collectives through torch.distributed
+(backend "nccl" = RCCL over xGMI) on device memory the C-ABI hands out.  Two ways to split the work:
+
+  TickShardedEsvo  ticks dealt round-robin to the ranks, one all-gather of the round's frames (throughput scaling)
+  ShardedEsvo      ONE tick split over the ranks -- per-event work by slot, per-cell work by image row band -- with
+                   the two integer sums of esvo_shard_exchange (latency scaling of a single tick; see below)
+
+ShardedEsvo:  PyTorch is plumbing here: device-pointer views + collectives; every
 kernel is in libesvo_hip.so.
 
 Per tick (see esvo_shard_tick_phase in include/esvo_hip.h):
@@ -95,6 +100,106 @@ class ShardedEsvo:
         parts = [None] * self.world
         dist.all_gather_object(parts, self.get_band_map(), group=self.group)
         return merge_band_maps(parts)
+
+
+class TickShardedEsvo:
+    """Tick-interleaved multi-GPU operation: rank r maps the ticks k with k % world == r completely (Time Surfaces at its
+    tick, block matching, LM, fusion, clean, regularisation).  A tick depends on earlier ticks only through the frames in
+    its fusion window -- the reference builds a new DepthFrame at every tick (esvo_Mapping.cpp:266-272) -- so the one
+    exchange is an all-gather of the round's frames (104 B per kept point, padded to the round's largest frame), after
+    which every rank pushes the `world` frames into its window in tick order and fuses when it reaches its own.  No
+    kernel is split, so per-GPU efficiency is that of the single-GPU tick and throughput grows with the number of
+    GPUs; the latency of one tick does not change.  Same driving interface as lib.Esvo: every rank sees every call.
+
+    The DepthMap of tick k lives on rank k % world (get_map returns the newest one on every rank)."""
+
+    counts_are_local = True   # stats() counts this rank's own ticks
+
+    def __init__(self, params, rig, rank, world, local_rank, group=None):
+        import torch
+        self.rank, self.world, self.group = rank, world, group
+        self.rig, self.params = rig, params
+        self.dev = lib.Esvo(params, rig, device=local_rank)
+        self.dev.set_stream(torch.cuda.current_stream().cuda_stream)
+        self.k = 0                 # index of the next tick
+        self.round = []            # ticks of the current round: (t_ns, stamps, poses)
+        self.mine = None           # (device pointer, points) of this rank's frame in the current round
+        self.last_mine = -1        # index of the last tick this rank fused
+        self.words = DEPTH_POINT_DTYPE.itemsize // 8
+        self._cnt = torch.zeros(world, dtype=torch.int64, device="cuda")
+        self._gather = [None, None]  # two alternating gather buffers (a fusion may still read the previous round's)
+        self._rounds = 0
+
+    def _is_mine(self):
+        return self.k % self.world == self.rank
+
+    # every rank stages all events (the mapper walks back over them, the Time Surfaces need them all)
+    def ts_push_events(self, cam, ev):
+        self.dev.ts_push_events(cam, ev)
+
+    def ts_render(self, cam, t_ns, download=True):
+        if self._is_mine():  # the SAE only has to be current at this rank's own ticks
+            return self.dev.ts_render(cam, t_ns, download)
+        return None
+
+    def set_observation(self, *a):
+        if self._is_mine():
+            self.dev.set_observation(*a)
+
+    def tick(self, t_ns, stamps, poses):
+        if self._is_mine():
+            self.mine = self.dev.front(t_ns, stamps, poses)
+        self.round.append((t_ns, np.ascontiguousarray(stamps), np.ascontiguousarray(poses, np.float64).reshape(-1, 16)))
+        self.k += 1
+        if len(self.round) == self.world:
+            self._finish_round()
+
+    def _finish_round(self):
+        """all-gather the frames of the round, push them in tick order, fuse at the own tick"""
+        import torch
+        import torch.distributed as dist
+        if not self.round:
+            return
+        n_mine = self.mine[1] if self.mine else 0
+        self._cnt.zero_()
+        self._cnt[self.rank] = n_mine
+        dist.all_reduce(self._cnt, op=dist.ReduceOp.SUM, group=self.group)  # world counts (the host sizes the gather)
+        counts = [int(c) for c in self._cnt.tolist()]
+        stride = max(max(counts), 1) * self.words
+        buf = self._gather[self._rounds & 1]
+        if buf is None or buf.numel() < self.world * stride:
+            buf = torch.empty(self.world * stride, dtype=torch.int64, device="cuda")
+            self._gather[self._rounds & 1] = buf
+        send = buf.new_zeros(stride) if not n_mine else torch.empty(stride, dtype=torch.int64, device="cuda")
+        if n_mine:
+            send[: n_mine * self.words] = device_tensor(self.mine[0], n_mine * self.words, "<i8")
+        recv = buf[: self.world * stride]
+        dist.all_gather_into_tensor(recv, send, group=self.group)
+        base = recv.data_ptr()
+        k0 = self.k - len(self.round)
+        for j, (t_ns, stamps, poses) in enumerate(self.round):
+            owner = (k0 + j) % self.world            # a round may start anywhere (partial rounds are flushed at syncs)
+            self.dev.push_frame_device(base + owner * stride * 8, counts[owner], poses)
+            if owner == self.rank:
+                self.dev.fuse_async()
+                self.last_mine = k0 + j
+        self.round, self.mine = [], None
+        self._rounds += 1
+
+    def synchronize(self):
+        self._finish_round()       # a partial last round (collective: every rank calls synchronize at the same points)
+        self.dev.synchronize()
+
+    def stats(self):
+        return self.dev.stats()
+
+    def get_map(self):
+        """the newest DepthMap (of the last tick), on every rank"""
+        import torch.distributed as dist
+        self.synchronize()
+        parts = [None] * self.world
+        dist.all_gather_object(parts, (self.last_mine, self.dev.get_map() if self.last_mine >= 0 else None), group=self.group)
+        return max(parts, key=lambda p: p[0])[1]
 
 
 def merge_band_maps(parts):

@@ -25,6 +25,7 @@ SYMBOLS = [
     "esvo_map_match", "esvo_map_set_poses", "esvo_map_refine", "esvo_map_push_frame", "esvo_map_fuse",
     "esvo_map_tick", "esvo_map_get_depth_points", "esvo_map_get_pointcloud_xyz", "esvo_map_get_last_frame",
     "esvo_get_stats", "esvo_shard_set_band", "esvo_shard_exchange", "esvo_shard_tick_phase", "esvo_abi_sizes",
+    "esvo_map_front", "esvo_map_front_frame", "esvo_map_push_frame_device", "esvo_map_fuse_async",
     "esvo_track_set_current", "esvo_track_get_images", "esvo_track_set_reference", "esvo_track_residuals", "esvo_track_jacobian",
 ]
 
@@ -87,6 +88,10 @@ def load():
     lib.esvo_shard_set_band.argtypes = [vp, i32, i32, i32, i32]
     lib.esvo_shard_exchange.argtypes = [vp, vp, vp]
     lib.esvo_shard_tick_phase.argtypes = [vp, i32, u64, vp, vp, sz]
+    lib.esvo_map_front.argtypes = [vp, u64, vp, vp, sz, psz]
+    lib.esvo_map_front_frame.argtypes = [vp, vp]
+    lib.esvo_map_push_frame_device.argtypes = [vp, vp, sz, vp, sz]
+    lib.esvo_map_fuse_async.argtypes = [vp]
     lib.esvo_track_set_current.argtypes = [vp, vp, i32]
     lib.esvo_track_get_images.argtypes = [vp, vp, vp, vp]
     lib.esvo_track_set_reference.argtypes = [vp, vp, sz, vp]
@@ -246,6 +251,24 @@ class Esvo:
         s = StatsStruct()
         self._ck(self.lib.esvo_get_stats(self.h, C.addressof(s)))
         return s
+
+    # ---- device-resident stage calls (tick-interleaved multi-GPU operation, dist.TickShardedEsvo) ----
+    def front(self, t_ns, stamps, poses):
+        """front stage of a tick on the staged events; returns (device pointer of the frame, number of points)"""
+        st = np.ascontiguousarray(stamps, np.uint64)
+        T = np.ascontiguousarray(poses, np.float64).reshape(-1, 16)
+        n = C.c_size_t()
+        self._ck(self.lib.esvo_map_front(self.h, int(t_ns), st.ctypes.data, T.ctypes.data, st.shape[0], C.byref(n)))
+        ptr = C.c_void_p()
+        self._ck(self.lib.esvo_map_front_frame(self.h, C.byref(ptr)))
+        return (ptr.value or 0), int(n.value)
+
+    def push_frame_device(self, d_ptr, n, poses):
+        T = np.ascontiguousarray(poses, np.float64).reshape(-1, 16)
+        self._ck(self.lib.esvo_map_push_frame_device(self.h, C.c_void_p(int(d_ptr)), int(n), T.ctypes.data, T.shape[0]))
+
+    def fuse_async(self):
+        self._ck(self.lib.esvo_map_fuse_async(self.h))
 
     # ---- tracker residual / Jacobian evaluation (RegProblemLM.cpp), SURVEY.md section 8(f).1 ----
     def track_set_current(self, ts_left=None, kernel_size=5):

@@ -245,6 +245,20 @@ int esvo_map_fuse(esvo_handle h, size_t* n_fusions);
 int esvo_map_tick(esvo_handle h, uint64_t t_ns, const uint64_t* pose_t_ns, const double* pose_T,
                   size_t m);
 
+/* Device-resident variants of the stage-wise calls (no host copies of points): the front stage of a tick on the
+ * events staged by esvo_ts_push_events (selection + match + refine + cull; the frame stays on the device,
+ * esvo_map_front_frame), a frame pushed from device memory, and the fusion stage enqueued without waiting for it.
+ * esvo_map_tick == front + push_frame_device(front_frame) + fuse_async, minus the point-count read-back stall.
+ * They exist for tick-interleaved multi-GPU operation (esvo_amd/dist.py: TickShardedEsvo): a tick depends on the
+ * previous ticks only through the frames in its window (the DepthFrame is rebuilt every tick,
+ * esvo_Mapping.cpp:266-272), so rank r maps the ticks k = r (mod N) and the ranks all-gather their frames. */
+int esvo_map_front(esvo_handle h, uint64_t t_ns, const uint64_t* pose_t_ns, const double* pose_T, size_t m,
+                   size_t* n_points);
+int esvo_map_front_frame(esvo_handle h, const esvo_depth_point_t** d_frame);
+int esvo_map_push_frame_device(esvo_handle h, const esvo_depth_point_t* d_pts, size_t n, const double* pose_T,
+                               size_t m);
+int esvo_map_fuse_async(esvo_handle h);
+
 /* ---- Outputs ------------------------------------------------------------------------ */
 
 /* DepthMap iteration (SmartGrid.h:346-358) as consumed by the publishers
