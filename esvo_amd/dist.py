@@ -61,6 +61,8 @@ class ShardedEsvo:
         if self.y1 <= self.y0:
             raise lib.EsvoError(f"rank {rank} of {world} would own no image rows (H={self.H})")
         self.dev.set_band(self.y0, self.y1, rank, world)
+        merge_disjoint_(torch.zeros(1024, dtype=torch.int64, device="cuda"), group)  # communicator set-up, untimed
+        torch.cuda.synchronize()
     # replicated stages: every rank ingests all events and renders the full Time Surfaces
     def ts_push_events(self, cam, ev):
         self.dev.ts_push_events(cam, ev)
@@ -127,8 +129,15 @@ class TickShardedEsvo:
         self.last_mine = -1        # index of the last tick this rank fused
         self.words = DEPTH_POINT_DTYPE.itemsize // 8
         self._cnt = torch.zeros(world, dtype=torch.int64, device="cuda")
-        self._gather = [None, None]  # two alternating gather buffers (a fusion may still read the previous round's)
+        # two alternating gather buffers (a fusion may still read the previous round's), sized for 64 k points per tick
+        # up front and grown on demand; one untimed round trip of both collectives sets up the communicator's channels
+        prime = 65536 * self.words
+        self._gather = [torch.empty(world * prime, dtype=torch.int64, device="cuda") for _ in range(2)]
         self._rounds = 0
+        import torch.distributed as dist
+        dist.all_reduce(self._cnt, op=dist.ReduceOp.SUM, group=group)
+        dist.all_gather_into_tensor(self._gather[0][: world * 1024], torch.zeros(1024, dtype=torch.int64, device="cuda"), group=group)
+        torch.cuda.synchronize()
 
     def _is_mine(self):
         return self.k % self.world == self.rank
