@@ -87,6 +87,27 @@ def measured_traffic(kernel):
     return fetch + write
 
 
+def measured_valu_busy(kernel):
+    """Fraction of the kernel's duration during which the vector ALUs issue, from the newest committed SQ counter pass
+    (profiles/*_sq_counters.csv): SQ_ACTIVE_INST_VALU counts quad-cycles summed over the 1024 SIMDs, SQ_BUSY_CYCLES
+    counts cycles summed over the 32 shader engines (MI355X_MICROARCH.md).  The hot kernels of this path are bound by
+    f64 VALU issue, not by HBM or MFMA, so this is the utilisation figure that says how close they run to their limit."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq_counters.csv")))
+    if not files:
+        return None
+    sym = {"lm_refine": "lm_refine_kernel", "bm_match": "bm_match_kernel"}.get(kernel)
+    v = {}
+    with open(files[-1]) as f:
+        for row in csv.DictReader(f):
+            if sym and sym in row["kernel"]:
+                v[row["counter"]] = float(row["avg_value_per_dispatch"])
+    if "SQ_ACTIVE_INST_VALU" not in v or "SQ_BUSY_CYCLES" not in v:
+        return None
+    return (v["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0) / (v["SQ_BUSY_CYCLES"] / 32.0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -235,6 +256,9 @@ def main():
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": measured_traffic(dom_name) if args.workload == "dsec640x480" else None,  # the committed PMC passes ran this workload
             "algorithmic_bytes_per_launch": dom_bytes,
+            # not an HBM- or MFMA-bound kernel: f64 vector-ALU issue is its limit
+            "practical_bound": "f64 VALU issue",
+            "valu_busy_frac": measured_valu_busy(dom_name) if args.workload == "dsec640x480" else None,
             "avg_launch_ms": float(kavg[dom]),
         },
     }
