@@ -142,3 +142,17 @@ class Calib:
         s.map_x = self.map_x.ctypes.data
         s.map_y = self.map_y.ctypes.data
         return s
+
+
+def serialize_event_array(ev, width, height, seq=0, stamp_ns=0, frame_id=""):
+    """ROS1 wire format of a dvs_msgs/EventArray carrying `ev` (esvo_event_t array): std_msgs/Header (u32 seq, u32 sec,
+    u32 nsec, u32 len + frame_id), u32 height, u32 width, u32 count, count x {u16 x, u16 y, u32 sec, u32 nsec, u8 polarity}."""
+    import struct
+    fid = frame_id.encode()
+    head = struct.pack("<III", seq, stamp_ns // 1_000_000_000, stamp_ns % 1_000_000_000) + struct.pack("<I", len(fid)) + fid
+    head += struct.pack("<III", height, width, len(ev))
+    wire = np.zeros(len(ev), dtype=np.dtype([("x", "<u2"), ("y", "<u2"), ("sec", "<u4"), ("nsec", "<u4"), ("polarity", "u1")]))
+    for f in ("x", "y", "sec", "nsec", "polarity"):
+        wire[f] = ev[f]
+    assert wire.dtype.itemsize == 13
+    return head + wire.tobytes()

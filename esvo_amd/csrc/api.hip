@@ -62,6 +62,8 @@ struct esvo_context {
   uint8_t* d_ts[2] = {nullptr, nullptr};
   bool ts_valid[2] = {false, false};
   esvo_event_t* d_ring[2] = {nullptr, nullptr};
+  uint8_t* d_wire = nullptr;    // staging of serialised 13-byte event records (esvo_ts_push_event_array)
+  size_t wire_cap = 0;
   u64 ring_cap = 0;
   std::deque<u64> ts_host[2];   // time stamps of staged events [ring_base, ring_base + size)
   u64 ring_base[2] = {0, 0};    // absolute index of ts_host[cam].front()
@@ -777,6 +779,7 @@ int esvo_destroy(esvo_handle h) {
   if (h->evt_ok) for (int i = 0; i < EV_N; ++i) hipEventDestroy(h->evt[i]);
   if (h->pool_ok) for (int i = 0; i < esvo_context::POSE_POOL; ++i) hipEventDestroy(h->pool_evt[i]);
   if (h->h_pose_pool) hipHostFree(h->h_pose_pool);
+  if (h->d_wire) hipFree(h->d_wire);
   if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
   if (h->stream_b) hipStreamDestroy(h->stream_b);
   if (h->stream_t) { hipStreamSynchronize(h->stream_t); hipStreamDestroy(h->stream_t); }
@@ -880,6 +883,56 @@ int esvo_ts_push_events(esvo_handle h, int cam, const esvo_event_t* ev, size_t n
     HIPCHK(hipMemcpyAsync(h->d_ring[cam], ev + first, sizeof(esvo_event_t) * (n - first), hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));  // `ev` is borrowed for the duration of the call only
   for (size_t i = 0; i < n; ++i) tsq.push_back((u64)ev[i].sec * 1000000000ull + ev[i].nsec);
+  h->ring_next[cam] += n;
+  while (tsq.size() > h->ring_cap) { tsq.pop_front(); h->ring_base[cam]++; }
+  h->stats.events_staged[cam] += n;
+  return ESVO_OK;
+}
+
+// A serialised dvs_msgs/EventArray (ROS1 wire format): std_msgs/Header {u32 seq, u32 sec, u32 nsec, string frame_id},
+// u32 height, u32 width, Event[] {u32 count, count x 13 B}.  The 13-byte records go to the device as they are and are
+// widened to esvo_event_t in the ring by a kernel; the host only walks the time stamps (order check + selection index).
+int esvo_ts_push_event_array(esvo_handle h, int cam, const uint8_t* msg, size_t n_bytes, size_t* n_events) {
+  if (!h || cam < 0 || cam > 1 || !msg) return ESVO_ERR_INVALID_ARG;
+  auto rd32 = [&](size_t off) { return (u32)msg[off] | ((u32)msg[off + 1] << 8) | ((u32)msg[off + 2] << 16) | ((u32)msg[off + 3] << 24); };
+  if (n_bytes < 16) FAIL(ESVO_ERR_INVALID_ARG, "EventArray message shorter than its header");
+  const size_t id_len = rd32(12);
+  size_t off = 16 + id_len;
+  if (off < 16 || off + 12 > n_bytes) FAIL(ESVO_ERR_INVALID_ARG, "EventArray message truncated (frame_id / height / width / count)");
+  const u32 height = rd32(off), width = rd32(off + 4), n = rd32(off + 8);
+  off += 12;
+  if (n_events) *n_events = n;
+  if ((size_t)n * 13 != n_bytes - off) FAIL(ESVO_ERR_INVALID_ARG, "EventArray message length does not match its event count");
+  if ((height && (int)height != h->H) || (width && (int)width != h->W)) FAIL(ESVO_ERR_INVALID_ARG, "EventArray sensor size differs from the handle's");
+  if (n == 0) return ESVO_OK;
+  if (n > h->ring_cap) FAIL(ESVO_ERR_CAPACITY, "event block larger than the event ring");
+  HIPCHK(hipSetDevice(h->device));
+  const uint8_t* rec = msg + off;
+  auto stamp = [&](size_t i) {
+    const uint8_t* r = rec + i * 13 + 4;
+    const u32 sec = (u32)r[0] | ((u32)r[1] << 8) | ((u32)r[2] << 16) | ((u32)r[3] << 24);
+    const u32 nsec = (u32)r[4] | ((u32)r[5] << 8) | ((u32)r[6] << 16) | ((u32)r[7] << 24);
+    return (u64)sec * 1000000000ull + nsec;
+  };
+  auto& tsq = h->ts_host[cam];
+  u64 last = tsq.empty() ? 0 : tsq.back();
+  for (size_t i = 0; i < n; ++i) {
+    const u64 t = stamp(i);
+    if (t < last) FAIL(ESVO_ERR_INVALID_ARG, "events must be sorted by time stamp (SURVEY Appendix A-1)");
+    last = t;
+  }
+  if (h->ring_next[cam] + n - h->scattered[cam] > h->ring_cap)
+    FAIL(ESVO_ERR_CAPACITY, "event ring full: render (scatter) before staging more events");
+  if ((size_t)n * 13 > h->wire_cap) {
+    if (h->d_wire) { HIPCHK(hipStreamSynchronize(h->stream)); hipFree(h->d_wire); h->d_wire = nullptr; }
+    h->wire_cap = std::max<size_t>((size_t)n * 13, (size_t)1 << 20);
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&h->d_wire), h->wire_cap));
+  }
+  HIPCHK(hipMemcpyAsync(h->d_wire, rec, (size_t)n * 13, hipMemcpyHostToDevice, h->stream));
+  launch_ts_unpack_wire(h->d_wire, n, h->d_ring[cam], h->ring_next[cam] % h->ring_cap, h->ring_cap, h->stream);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(h->stream));  // `msg` is borrowed for the duration of the call only
+  for (size_t i = 0; i < n; ++i) tsq.push_back(stamp(i));
   h->ring_next[cam] += n;
   while (tsq.size() > h->ring_cap) { tsq.pop_front(); h->ring_base[cam]++; }
   h->stats.events_staged[cam] += n;

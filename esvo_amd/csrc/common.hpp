@@ -143,6 +143,7 @@ void launch_exclusive_scan_u32(const u32* d_in, u32* d_out, u32* d_total, u32* d
 size_t scan_scratch_elems(size_t n);
 
 // kernels_ts.hip
+void launch_ts_unpack_wire(const uint8_t* wire, size_t n, esvo_event_t* ring, u64 first_slot, u64 ring_cap, hipStream_t s);
 void launch_ts_scatter(const esvo_event_t* d_ev, size_t n, u64* d_sae, int W, int H, hipStream_t s);
 void launch_ts_render(const u64* d_sae, const int2* d_fixmap, uint8_t* d_raw, uint8_t* d_out, int W, int H,
                       u64 t_ns, double decay_sec, int ignore_polarity, int median_k, hipStream_t s);

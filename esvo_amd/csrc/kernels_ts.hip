@@ -198,4 +198,25 @@ void launch_denoise_select(const u32* flags, const u32* prefix, u32 n, u32* sel,
   hipLaunchKernelGGL(denoise_select_kernel, dim3((n + 255) / 256), dim3(256), 0, s, flags, prefix, n, sel);
 }
 
+// ---- wire ingest: serialised dvs_msgs/Event records (13 B: u16 x, u16 y, u32 sec, u32 nsec, u8 polarity; ROS1
+// little-endian, no padding) -> esvo_event_t records in the event ring --------------------
+__global__ void __launch_bounds__(256) ts_unpack_wire_kernel(const uint8_t* __restrict__ wire, size_t n, esvo_event_t* __restrict__ ring,
+                                                             u64 first_slot, u64 ring_cap) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t* r = wire + i * 13;
+  esvo_event_t e;
+  e.x = (uint16_t)(r[0] | (r[1] << 8));
+  e.y = (uint16_t)(r[2] | (r[3] << 8));
+  e.sec = (u32)r[4] | ((u32)r[5] << 8) | ((u32)r[6] << 16) | ((u32)r[7] << 24);
+  e.nsec = (u32)r[8] | ((u32)r[9] << 8) | ((u32)r[10] << 16) | ((u32)r[11] << 24);
+  e.polarity = r[12];
+  e._pad[0] = e._pad[1] = e._pad[2] = 0;
+  ring[(first_slot + i) % ring_cap] = e;
+}
+void launch_ts_unpack_wire(const uint8_t* wire, size_t n, esvo_event_t* ring, u64 first_slot, u64 ring_cap, hipStream_t s) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(ts_unpack_wire_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, wire, n, ring, first_slot, ring_cap);
+}
+
 }  // namespace esvo

@@ -21,7 +21,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
 
 SYMBOLS = [
     "esvo_default_params", "esvo_create", "esvo_destroy", "esvo_reset", "esvo_set_params", "esvo_last_error",
-    "esvo_set_stream", "esvo_synchronize", "esvo_ts_push_events", "esvo_ts_render", "esvo_map_set_observation",
+    "esvo_set_stream", "esvo_synchronize", "esvo_ts_push_events", "esvo_ts_push_event_array", "esvo_ts_render", "esvo_map_set_observation",
     "esvo_map_match", "esvo_map_set_poses", "esvo_map_refine", "esvo_map_push_frame", "esvo_map_fuse",
     "esvo_map_tick", "esvo_map_get_depth_points", "esvo_map_get_pointcloud_xyz", "esvo_map_get_last_frame",
     "esvo_get_stats", "esvo_shard_set_band", "esvo_shard_exchange", "esvo_shard_tick_phase", "esvo_abi_sizes",
@@ -73,6 +73,7 @@ def load():
     lib.esvo_set_stream.argtypes = [vp, vp]
     lib.esvo_synchronize.argtypes = [vp]
     lib.esvo_ts_push_events.argtypes = [vp, i32, vp, sz]
+    lib.esvo_ts_push_event_array.argtypes = [vp, i32, vp, sz, psz]
     lib.esvo_ts_render.argtypes = [vp, i32, u64, vp]
     lib.esvo_map_set_observation.argtypes = [vp, u64, vp, vp, vp]
     lib.esvo_map_match.argtypes = [vp, vp, sz, vp, vp, sz, vp, sz, psz]
@@ -174,6 +175,13 @@ class Esvo:
     def ts_push_events(self, cam, ev):
         ev = np.ascontiguousarray(ev, dtype=EVENT_DTYPE)
         self._ck(self.lib.esvo_ts_push_events(self.h, int(cam), ev.ctypes.data, ev.shape[0]))
+
+    def ts_push_event_array(self, cam, msg):
+        """stage one serialised dvs_msgs/EventArray (bytes / uint8 array, ROS1 wire format); returns its event count"""
+        buf = np.frombuffer(msg, np.uint8) if isinstance(msg, (bytes, bytearray, memoryview)) else np.ascontiguousarray(msg, np.uint8)
+        n = C.c_size_t()
+        self._ck(self.lib.esvo_ts_push_event_array(self.h, int(cam), buf.ctypes.data, buf.size, C.byref(n)))
+        return int(n.value)
 
     def ts_render(self, cam, t_ns, download=True):
         out = np.empty((self.H, self.W), np.uint8) if download else None

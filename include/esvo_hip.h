@@ -209,6 +209,13 @@ int esvo_synchronize(esvo_handle h);
  * TimeSurface.h:39-50) and, for the left camera, esvo_Mapping::eventsCallback
  * (esvo_Mapping.cpp:669-703).  Events must be time-sorted (Appendix A-1). */
 int esvo_ts_push_events(esvo_handle h, int cam, const esvo_event_t* ev, size_t n);
+/* The same, straight from the ROS1 wire format: `msg` is one serialised
+ * dvs_msgs/EventArray (Header, u32 height, u32 width, u32 count, count x 13-byte dvs_msgs/Event: u16 x, u16 y,
+ * u32 sec, u32 nsec, u8 polarity) as a rosbag chunk or a TCPROS connection delivers it.  The packed records are copied to
+ * the device as they are (13 instead of 16 B/event over PCIe) and widened into the ring by a kernel; no
+ * std::vector<dvs_msgs::Event> is materialised (rosbag::MessageInstance::instantiate does that at
+ * events_repacking_helper/src/EventMessageEditor.cpp:111).  *n_events (nullable) receives the message's event count. */
+int esvo_ts_push_event_array(esvo_handle h, int cam, const uint8_t* msg, size_t n_bytes, size_t* n_events);
 /* Replaces TimeSurface::createTimeSurfaceAtTime (TimeSurface.cpp:52-152), BACKWARD mode.
  * Uses every staged event with ts < t_ns.  out_mono8 (W*H) may be NULL: the rectified TS
  * also stays device-resident as the camera's latest frame. */

@@ -213,3 +213,41 @@ def test_back_to_back_ticks_without_reads(request, preset, rig_fix, stream_fix, 
             _same_map(dev.get_map(), m.get_map())
             lf = dev.get_last_frame()
             assert len(lf) == dev.stats().last_points
+
+
+def test_wire_ingest_equals_struct_ingest(upenn_rig, upenn_stream):
+    """esvo_ts_push_event_array: serialised dvs_msgs/EventArray messages (13-byte records, 1 ms chunks as
+    events_repacking_helper emits them, ring wrap-around included) must leave the same Time Surfaces and the same mapper
+    output as the struct path; malformed messages are rejected."""
+    from esvo_amd import abi, lib
+    p, _ = params.make_params(params.PRESETS["mvstereo_upenn"], upenn_rig, event_ring_capacity=20000)
+    a, b = lib.Esvo(p, upenn_rig), lib.Esvo(p, upenn_rig)
+    t_prev = upenn_stream.t0_ns
+    for k in range(6):
+        t = upenn_stream.t0_ns + int((0.05 + 0.01 * k) * 1e9)
+        for cam in (0, 1):
+            ev = upenn_stream.slice(cam, t_prev, t)
+            ns = ev["sec"].astype(np.uint64) * 1_000_000_000 + ev["nsec"]
+            cuts = np.searchsorted(ns, np.arange(int(ns[0]), int(ns[-1]) + 1_000_000, 1_000_000)) if len(ev) else [0]
+            total = 0
+            for lo, hi in zip(cuts, list(cuts[1:]) + [len(ev)]):
+                a.ts_push_events(cam, ev[lo:hi])
+                msg = abi.serialize_event_array(ev[lo:hi], upenn_rig.width, upenn_rig.height, seq=k, stamp_ns=t, frame_id="davis")
+                total += b.ts_push_event_array(cam, msg)
+                t_chunk = int(ns[hi - 1]) + 1 if hi > lo else t
+                a.ts_render(cam, t_chunk, download=False); b.ts_render(cam, t_chunk, download=False)   # scatter: frees ring space
+            assert total == len(ev)
+        t_prev = t
+        for cam in (0, 1):
+            assert np.array_equal(a.ts_render(cam, t), b.ts_render(cam, t))
+        stamps, poses = rostime.pose_table(upenn_stream.pose, t, p.bm_half_slice_thickness)
+        for d in (a, b):
+            d.set_observation(t, None, None, upenn_stream.pose(t))
+            d.tick(t, stamps, poses)
+    _same_map(a.get_map(), b.get_map())
+    assert b.stats().events_staged[0] == a.stats().events_staged[0] > 20000      # the ring wrapped
+    good = abi.serialize_event_array(upenn_stream.ev_left[:10], upenn_rig.width, upenn_rig.height)
+    for bad, what in ((good[:-5], "length"), (good[:10], "shorter"), (abi.serialize_event_array(upenn_stream.ev_left[:10], 100, 100), "sensor size"),
+                      (abi.serialize_event_array(upenn_stream.ev_left[:10][::-1], upenn_rig.width, upenn_rig.height), "sorted")):
+        with pytest.raises(lib.EsvoError, match=what):
+            lib.Esvo(p, upenn_rig).ts_push_event_array(0, bad)
