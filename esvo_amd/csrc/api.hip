@@ -44,6 +44,7 @@ struct esvo_context {
   // stage only reads what the front stage finished (the frame in the window ring, the tick's pose table).
   hipStream_t stream = nullptr;
   hipStream_t stream_b = nullptr;
+  hipStream_t stream_i = nullptr;  // event ingest (H2D into the ring): staging new events never waits for a running tick
   bool own_stream = false;
   int par = 0;                    // parity of the tick being assembled
   bool back_pending[2] = {false, false};  // back-stage timings / counters of that parity not collected yet
@@ -69,6 +70,7 @@ struct esvo_context {
   u64 ring_base[2] = {0, 0};    // absolute index of ts_host[cam].front()
   u64 ring_next[2] = {0, 0};    // absolute index of the next event to stage
   u64 scattered[2] = {0, 0};    // absolute index of the first event not yet in the SAE
+  u64 scatter_pending_lo[2] = {~0ull, ~0ull};  // oldest event a possibly still running scatter kernel reads
 
   // observation
   uint8_t* d_obs[2] = {nullptr, nullptr};
@@ -648,6 +650,7 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
   h->own_stream = true;
   CK(hipStreamCreateWithFlags(&h->stream_b, hipStreamNonBlocking));
   CK(hipStreamCreateWithFlags(&h->stream_t, hipStreamNonBlocking));
+  CK(hipStreamCreateWithFlags(&h->stream_i, hipStreamNonBlocking));
   // calibration -> device
   CK(dalloc(&h->d_lut, npx));
   CK(hipMemcpy(h->d_lut, left->rect_lut, sizeof(float2) * npx, hipMemcpyHostToDevice));
@@ -783,6 +786,7 @@ int esvo_destroy(esvo_handle h) {
   if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
   if (h->stream_b) hipStreamDestroy(h->stream_b);
   if (h->stream_t) { hipStreamSynchronize(h->stream_t); hipStreamDestroy(h->stream_t); }
+  if (h->stream_i) { hipStreamSynchronize(h->stream_i); hipStreamDestroy(h->stream_i); }
   for (void* q : {(void*)h->d_trk_blur, (void*)h->d_trk_neg, (void*)h->d_trk_du, (void*)h->d_trk_dv, (void*)h->d_trk_xyz, (void*)h->d_trk_pts,
                   (void*)h->d_trk_out})
     if (q) hipFree(q);
@@ -861,6 +865,22 @@ int esvo_synchronize(esvo_handle h) {
 }
 
 // ---- Time Surface ---------------------------------------------------------------------------------
+namespace {
+// Staging runs on its own stream.  The slots it overwrites hold events older than ring_cap; a front stage still in flight
+// reads at most the max_ev events before its selection point, so only a (nearly) full ring needs the front stream drained.
+int ring_overwrite_guard(esvo_context* h, int cam, size_t n) {
+  if (h->ring_next[cam] + n <= h->ring_cap) return ESVO_OK;
+  const u64 evict_end = h->ring_next[cam] + n - h->ring_cap;  // first absolute index that survives
+  u64 oldest_read = h->scatter_pending_lo[cam];              // scatter kernels enqueued since the last drain
+  if (cam == 0) oldest_read = std::min(oldest_read, h->sh_first > (u64)h->max_ev ? h->sh_first - (u64)h->max_ev : 0);
+  if (evict_end > oldest_read) {
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->scatter_pending_lo[0] = h->scatter_pending_lo[1] = ~0ull;
+  }
+  return ESVO_OK;
+}
+}  // namespace
+
 int esvo_ts_push_events(esvo_handle h, int cam, const esvo_event_t* ev, size_t n) {
   if (!h || cam < 0 || cam > 1 || (n && !ev)) return ESVO_ERR_INVALID_ARG;
   if (n == 0) return ESVO_OK;
@@ -876,12 +896,13 @@ int esvo_ts_push_events(esvo_handle h, int cam, const esvo_event_t* ev, size_t n
   // the ring must not overwrite events that are not yet scattered into the SAE
   if (h->ring_next[cam] + n - h->scattered[cam] > h->ring_cap)
     FAIL(ESVO_ERR_CAPACITY, "event ring full: render (scatter) before staging more events");
+  { int rcg = ring_overwrite_guard(h, cam, n); if (rcg) return rcg; }
   const u64 slot = h->ring_next[cam] % h->ring_cap;
   const size_t first = (size_t)std::min<u64>(n, h->ring_cap - slot);
-  HIPCHK(hipMemcpyAsync(h->d_ring[cam] + slot, ev, sizeof(esvo_event_t) * first, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->d_ring[cam] + slot, ev, sizeof(esvo_event_t) * first, hipMemcpyHostToDevice, h->stream_i));
   if (first < n)
-    HIPCHK(hipMemcpyAsync(h->d_ring[cam], ev + first, sizeof(esvo_event_t) * (n - first), hipMemcpyHostToDevice, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));  // `ev` is borrowed for the duration of the call only
+    HIPCHK(hipMemcpyAsync(h->d_ring[cam], ev + first, sizeof(esvo_event_t) * (n - first), hipMemcpyHostToDevice, h->stream_i));
+  HIPCHK(hipStreamSynchronize(h->stream_i));  // `ev` is borrowed for the duration of the call only; later work sees the copy
   for (size_t i = 0; i < n; ++i) tsq.push_back((u64)ev[i].sec * 1000000000ull + ev[i].nsec);
   h->ring_next[cam] += n;
   while (tsq.size() > h->ring_cap) { tsq.pop_front(); h->ring_base[cam]++; }
@@ -924,14 +945,15 @@ int esvo_ts_push_event_array(esvo_handle h, int cam, const uint8_t* msg, size_t 
   if (h->ring_next[cam] + n - h->scattered[cam] > h->ring_cap)
     FAIL(ESVO_ERR_CAPACITY, "event ring full: render (scatter) before staging more events");
   if ((size_t)n * 13 > h->wire_cap) {
-    if (h->d_wire) { HIPCHK(hipStreamSynchronize(h->stream)); hipFree(h->d_wire); h->d_wire = nullptr; }
+    if (h->d_wire) { hipFree(h->d_wire); h->d_wire = nullptr; }  // the ingest stream is idle between calls
     h->wire_cap = std::max<size_t>((size_t)n * 13, (size_t)1 << 20);
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&h->d_wire), h->wire_cap));
   }
-  HIPCHK(hipMemcpyAsync(h->d_wire, rec, (size_t)n * 13, hipMemcpyHostToDevice, h->stream));
-  launch_ts_unpack_wire(h->d_wire, n, h->d_ring[cam], h->ring_next[cam] % h->ring_cap, h->ring_cap, h->stream);
+  { int rcg = ring_overwrite_guard(h, cam, n); if (rcg) return rcg; }
+  HIPCHK(hipMemcpyAsync(h->d_wire, rec, (size_t)n * 13, hipMemcpyHostToDevice, h->stream_i));
+  launch_ts_unpack_wire(h->d_wire, n, h->d_ring[cam], h->ring_next[cam] % h->ring_cap, h->ring_cap, h->stream_i);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(h->stream));  // `msg` is borrowed for the duration of the call only
+  HIPCHK(hipStreamSynchronize(h->stream_i));  // `msg` is borrowed for the duration of the call only
   for (size_t i = 0; i < n; ++i) tsq.push_back(stamp(i));
   h->ring_next[cam] += n;
   while (tsq.size() > h->ring_cap) { tsq.pop_front(); h->ring_base[cam]++; }
@@ -951,6 +973,7 @@ int esvo_ts_render(esvo_handle h, int cam, uint64_t t_ns, uint8_t* out_mono8) {
   hipEventRecord(h->evt[EV_SC0 + evo], h->stream);
   if (upto > h->scattered[cam]) {
     u64 a = h->scattered[cam];
+    h->scatter_pending_lo[cam] = std::min(h->scatter_pending_lo[cam], a);
     const u64 total = upto - a;
     while (a < upto) {
       const u64 slot = a % h->ring_cap;
