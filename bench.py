@@ -116,6 +116,8 @@ def main():
     ap.add_argument("--workload", default="dsec640x480", choices=sorted(WORKLOADS))
     ap.add_argument("--events-per-tick", type=int, default=0, help="cap on block-matched events per tick (0 = all)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--timed-ingest", action="store_true",
+                    help="stage each tick's events inside the timed loop (PCIe-inclusive rate; the default stages the whole stream first)")
     ap.add_argument("--check", action="store_true", help="also print a checksum of the final DepthMap (sharded == unsharded check)")
     args = ap.parse_args()
 
@@ -161,17 +163,27 @@ def main():
     else:
         runner = lib.Esvo(p, rig, device=local_rank)
 
-    # ---- stage the whole stream in HBM (untimed) ----
-    runner.ts_push_events(0, stream.ev_left)
-    runner.ts_push_events(1, stream.ev_right)
+    # ---- stage the whole stream in HBM (untimed); with --timed-ingest only the history before the first tick ----
     ticks = []
     for k in range(K + Wm):
         t = stream.t0_ns + int((hist_s + (k + 1) * tick_s) * 1e9)
         stamps, poses = rostime.pose_table(stream.pose, t, p.bm_half_slice_thickness)
         ticks.append((t, stamps, poses, stream.pose(t)))
+    if args.timed_ingest:
+        t_first = stream.t0_ns + int(hist_s * 1e9)
+        bounds = [t_first] + [tk[0] for tk in ticks]
+        chunks = [(stream.slice(0, a, b), stream.slice(1, a, b)) for a, b in zip(bounds[:-1], bounds[1:])]
+        runner.ts_push_events(0, stream.slice(0, stream.t0_ns, t_first))
+        runner.ts_push_events(1, stream.slice(1, stream.t0_ns, t_first))
+    else:
+        runner.ts_push_events(0, stream.ev_left)
+        runner.ts_push_events(1, stream.ev_right)
 
     def step(k):
         t, stamps, poses, T = ticks[k]
+        if args.timed_ingest:
+            runner.ts_push_events(0, chunks[k][0])
+            runner.ts_push_events(1, chunks[k][1])
         runner.ts_render(0, t, download=False)
         runner.ts_render(1, t, download=False)
         runner.set_observation(t, None, None, T)
@@ -234,7 +246,7 @@ def main():
         "scaling": "strong",
         "vs_baseline": None,
         "dtype": "f64",
-        "data": "synthetic",
+        "data": "synthetic" + (" (events staged tick by tick inside the timed loop)" if args.timed_ingest else ""),
         "depth_points_per_s": n_points / dt,
         "config": {
             "workload": f"{args.workload} synthetic stereo event stream, {len(stream.ev_left) / duration / 1e6:.1f} Mev/s/camera, "
