@@ -506,6 +506,12 @@ __global__ void __launch_bounds__(256) reg_chain_kernel(const MapCell* __restric
       double inv_n = ab[nc].x;
       double2 t_n = cd[nc];
       double nu_post = t_n.x, inv_post = inv_n, s2_post = t_n.y;
+      // nu_post is a running minimum, so the divisor nu_post + 1 is almost always the previous step's: its refined
+      // reciprocal is kept.  One step = one straight line of fast quotients (fdiv.hpp) validated by a single test at
+      // its end; the plain divisions are the (practically never taken) other side of that one branch -- this kernel
+      // runs about one wave per SIMD, so branches and dependent latency, not throughput, are what it pays for.
+      double nu_div = nu_post + 1;
+      Recip rnu = make_recip(nu_div);
       nc = next_cell();
       if (nc >= 0) { inv_n = ab[nc].x; t_n = cd[nc]; }
       while (nc >= 0) {
@@ -514,10 +520,25 @@ __global__ void __launch_bounds__(256) reg_chain_kernel(const MapCell* __restric
         if (nc >= 0) { inv_n = ab[nc].x; t_n = cd[nc]; }  // prefetch: independent of the fusion state
         const double nu_prior = nu_post, inv_prior = inv_post, s2_prior = s2_post;  // DepthRegularization.cpp:72-86
         nu_post = (nu_obs < nu_prior) ? nu_obs : nu_prior;
-        const Recip rsum = make_recip(s2_obs + s2_prior);  // == s2_prior + s2_obs
-        inv_post = div_by(s2_obs * inv_prior + s2_prior * inv_obs, rsum);
+        if (nu_post + 1 != nu_div) { nu_div = nu_post + 1; rnu = make_recip(nu_div); }
+        const double ssum = s2_obs + s2_prior;  // == s2_prior + s2_obs
+        const Recip rsum = make_recip(ssum);
+        const double a1 = s2_obs * inv_prior + s2_prior * inv_obs;
         const double dd = inv_prior - inv_obs;
-        s2_post = div_by((nu_post + div_by(dd * dd, rsum)) / (nu_post + 1) * (s2_prior * s2_obs), rsum);
+        const double a2 = dd * dd;
+        const double pp = s2_prior * s2_obs;
+        const double q1 = div_fast(a1, rsum);
+        const double a3 = nu_post + div_fast(a2, rsum);
+        const double a4 = div_fast(a3, rnu) * pp;
+        const double q4 = div_fast(a4, rsum);
+        const bool ok = (int)rsum.fast & (int)rnu.fast & (int)fdiv_ok(a1) & (int)fdiv_ok(a2) & (int)fdiv_ok(a3) & (int)fdiv_ok(a4);
+        if (ok) {
+          inv_post = q1;
+          s2_post = q4;
+        } else {
+          inv_post = a1 / ssum;
+          s2_post = ((nu_post + a2 / ssum) / (nu_post + 1) * pp) / ssum;
+        }
       }
       c.inv_depth = inv_post;
     } else {
