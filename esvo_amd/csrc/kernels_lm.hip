@@ -293,7 +293,10 @@ __device__ inline double lm_lmpar2(double r, double diag, double qtf, double del
   return x;
 }
 
-__global__ void __launch_bounds__(256, 3) lm_refine_kernel(LmArgs a, DevParams p, u32* n_solved) {
+#ifndef LM_WAVES
+#define LM_WAVES 3  // waves per SIMD: 4 (<= 128 VGPRs) spills 71 registers into the solver loop and is slower
+#endif
+__global__ void __launch_bounds__(256, LM_WAVES) lm_refine_kernel(LmArgs a, DevParams p, u32* n_solved) {
   const u32 s = (blockIdx.x * 256 + threadIdx.x) >> 4;  // solver slot (thread-stride order)
   const int c = threadIdx.x & 15;
   u32 M = *a.n_matches;
