@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <string>
@@ -646,9 +647,18 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
   fill_dev_params(h);
 
 #define CK(call) do { hipError_t _e = (call); if (_e != hipSuccess) { g_create_error = std::string(#call) + ": " + hipGetErrorString(_e); esvo_destroy(h); return ESVO_ERR_HIP; } } while (0)
-  CK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-  h->own_stream = true;
-  CK(hipStreamCreateWithFlags(&h->stream_b, hipStreamNonBlocking));
+  {
+    int prio_lo = 0, prio_hi = 0;  // numerically lower = higher priority
+    CK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+    // The front stage is the critical path of the two-stream pipeline: its stream gets the high priority, the
+    // (latency-bound, gap-filling) back stage the low one: -2 % per tick; the reverse costs +6 %.  ESVO_STREAM_PRIO
+    // = 0 (no priorities) / 2 (reversed) exist for that A/B.
+    const char* pe = std::getenv("ESVO_STREAM_PRIO");
+    const int mode = pe ? std::atoi(pe) : 1;
+    CK(hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, mode == 1 ? prio_hi : (mode == 2 ? prio_lo : 0)));
+    h->own_stream = true;
+    CK(hipStreamCreateWithPriority(&h->stream_b, hipStreamNonBlocking, mode == 1 ? prio_lo : (mode == 2 ? prio_hi : 0)));
+  }
   CK(hipStreamCreateWithFlags(&h->stream_t, hipStreamNonBlocking));
   CK(hipStreamCreateWithFlags(&h->stream_i, hipStreamNonBlocking));
   // calibration -> device
