@@ -24,7 +24,7 @@ thread_local std::string g_create_error;
 
 // front-stage events live on the front stream; the back-stage set exists once per tick parity (two ticks in flight)
 enum { EV_SC0 = 0, EV_SC1, EV_R1, EV_SC0b, EV_SC1b, EV_R1b, EV_FRAME,
-       EV_T0, EV_BM0, EV_BM1, EV_S1, EV_LM0, EV_LM1, EV_S2, EV_CNT, EV_T0b, EV_BM0b, EV_BM1b, EV_S1b, EV_LM0b, EV_LM1b, EV_S2b, EV_CNTb,
+       EV_T0, EV_BM0, EV_BM1, EV_S1, EV_LM0, EV_LM1, EV_S2, EV_CNT, EV_STG, EV_T0b, EV_BM0b, EV_BM1b, EV_S1b, EV_LM0b, EV_LM1b, EV_S2b, EV_CNTb, EV_STGb,
        EV_FU0, EV_FU1, EV_CL1, EV_RG1, EV_POSE, EV_FU0b, EV_FU1b, EV_CL1b, EV_RG1b, EV_POSEb, EV_N };
 constexpr int EV_BACK_STRIDE = EV_FU0b - EV_FU0;  // evt[EV_x + par * EV_BACK_STRIDE]
 constexpr int EV_FRONT_STRIDE = EV_T0b - EV_T0;   // evt[EV_x + fpar * EV_FRONT_STRIDE]
@@ -103,6 +103,7 @@ struct esvo_context {
   u32* d_pt_flags = nullptr;
   u32* d_pt_prefix = nullptr;
   DevPoint* d_pts_tmp = nullptr;  // stage-wise refine output
+  DevPoint* d_stage[2] = {nullptr, nullptr};  // a lazily completed tick's frame (by parity) until its count is known
   u32* d_counters = nullptr;      // [0] n_matches [1] n_points [2] n_solved [3] n_fusion [4] n_records [5] n_map
                                   // [6] touched cells [7] regulariser elements [8] own matches (sharded)
   u32* h_counters = nullptr;      // pinned
@@ -431,23 +432,19 @@ void collect_back(esvo_context* h, int par) {
   s.sum_ms_kernel[4] += fu; s.sum_ms_kernel[5] += cl; s.sum_ms_kernel[6] += rg;
 }
 
-// place a frame of up to n points in the window ring (frames stay contiguous).  The occupied region runs from
-// the oldest frame to the newest reservation -- which is the pending tick's worst-case reservation if there is one.
+// place a frame of n points in the window ring (frames stay contiguous: [oldest frame, newest frame) modulo the wrap)
 int window_reserve(esvo_context* h, u32 n, u32* off_out) {
   u32 off = 0;
-  const bool pend = h->tick_pending && !h->sharded;
-  const esvo_context::TickState& pk = h->tk[h->fpar ^ 1];  // called for tk[fpar]; the pending one is the other
-  if (!h->frames.empty() || pend) {
-    const u32 back_off = pend ? pk.off : h->frames.back().off;
-    const u32 back_cnt = pend ? pk.n : h->frames.back().count;
-    const u32 front_off = h->frames.empty() ? back_off : h->frames.front().off;
-    const u32 tail = back_off + back_cnt;
-    if (back_off >= front_off) {  // not wrapped: [front_off, tail)
+  if (!h->frames.empty()) {
+    const FrameRec& back = h->frames.back();
+    const FrameRec& front = h->frames.front();
+    const u32 tail = back.off + back.count;
+    if (back.off >= front.off) {  // not wrapped: [front.off, tail)
       if (tail + n <= h->win_cap) off = tail;
-      else if (n <= front_off) off = 0;
+      else if (n <= front.off) off = 0;
       else FAIL(ESVO_ERR_CAPACITY, "fusion window ring full (raise max_window_points)");
-    } else {  // wrapped: free space is [tail, front_off)
-      if (tail + n <= front_off) off = tail;
+    } else {  // wrapped: free space is [tail, front.off)
+      if (tail + n <= front.off) off = tail;
       else FAIL(ESVO_ERR_CAPACITY, "fusion window ring full (raise max_window_points)");
     }
   } else if (n > h->win_cap) {
@@ -705,6 +702,8 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
   CK(dalloc(&h->d_pt_flags, E));
   CK(dalloc(&h->d_pt_prefix, E));
   CK(dalloc(&h->d_pts_tmp, E));
+  CK(dalloc(&h->d_stage[0], E));
+  CK(dalloc(&h->d_stage[1], E));
   CK(dalloc(&h->d_counters, 16));
   CK(hipMemset(h->d_counters, 0, sizeof(u32) * 16));
   CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_counters), sizeof(u32) * 16 * 2));
@@ -717,7 +716,7 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
   CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_cnt_b), sizeof(u32) * 8 * 3));
   std::memset(h->h_cnt_b, 0, sizeof(u32) * 8 * 3);
   // fusion window
-  h->win_cap = (u32)std::max<int64_t>((int64_t)params->max_window_points, (int64_t)E) + 2 * (u32)E;  // + new and pending frame
+  h->win_cap = (u32)std::max<int64_t>((int64_t)params->max_window_points, (int64_t)E) + 2 * (u32)E;
   CK(dalloc(&h->d_win, h->win_cap));
   h->max_frames = (u32)std::max(params->max_fusion_frames + 2, 512);
   h->n_pose_slots = h->max_frames + 1;
@@ -779,7 +778,7 @@ int esvo_destroy(esvo_handle h) {
   void* ptrs[] = {h->d_lut, h->d_mask, h->d_fixmap[0], h->d_fixmap[1], h->d_sae[0], h->d_sae[1], h->d_raw, h->d_ts[0],
                   h->d_ts[1], h->d_ring[0], h->d_ring[1], h->d_obs[0], h->d_obs[1], h->d_obs_tmp, h->d_T_world_obs,
                   h->d_pose_sec, h->d_pose_T2[0], h->d_pose_T2[1], h->d_scan_tmp_b, h->d_cnt_b, h->d_tick_ev, h->d_match_slots, h->d_match_flags, h->d_match_prefix,
-                  h->d_matches, h->d_pt_slots, h->d_pt_flags, h->d_pt_prefix, h->d_pts_tmp, h->d_counters, h->d_scan_tmp,
+                  h->d_matches, h->d_pt_slots, h->d_pt_flags, h->d_pt_prefix, h->d_pts_tmp, h->d_stage[0], h->d_stage[1], h->d_counters, h->d_scan_tmp,
                   h->d_win, h->d_frame_pose_T, h->d_fr_table, h->d_prop, h->d_cell_count, h->d_cell_offset,
                   h->d_cell_fill, h->d_rec_ids, h->d_map, h->d_map2, h->d_owner_max, h->d_owner_min, h->d_exp_flags,
                   h->d_exp_prefix, h->d_export, h->d_export_cell, h->d_reg_bits, h->d_reg_ab, h->d_reg_cd, h->d_bucket, h->d_cell_list, h->d_own_w, h->d_lkeep, h->d_codes,
@@ -1235,13 +1234,20 @@ int tick_phase0(esvo_context* h, uint64_t t_ns, const uint64_t* pose_t_ns, const
 int tick_phase1_enqueue(esvo_context* h) {
   esvo_context::TickState& tk = h->tk[h->fpar];
   const u32 n = tk.n;
-  int rc = window_reserve(h, n, &tk.off);
-  if (rc) return rc;
-  DevPoint* frame = h->d_win + tk.off;
+  int rc = ESVO_OK;
+  DevPoint* frame = nullptr;
+  if (h->sharded) {  // committed right away: straight into the ring (worst case n points)
+    rc = window_reserve(h, n, &tk.off);
+    if (rc) return rc;
+    frame = h->d_win + tk.off;
+  }
   h->xchg_ptr = nullptr;
   h->xchg_bytes = 0;
   if (n && !h->sharded) {
-    rc = run_order_points(h, n, frame);
+    // the frame waits in the staging buffer of its parity until the tick is committed and its size is known; the
+    // buffer's previous frame (two ticks ago) has been copied into the ring by then
+    HIPCHK(hipStreamWaitEvent(h->stream, h->evt[EV_STG + h->fpar * EV_FRONT_STRIDE], 0));
+    rc = run_order_points(h, n, h->d_stage[h->fpar]);
     if (rc) return rc;
   } else if (n) {
     const u32 N = (u32)h->dp.ev_nshards, r = (u32)h->dp.ev_shard, T = (u32)h->dp.num_threads;
@@ -1313,7 +1319,15 @@ int tick_phase2(esvo_context* h, int fp) {
   h->par ^= 1;
   HIPCHK(hipEventSynchronize(h->evt[EV_RG1 + par * EV_BACK_STRIDE]));
   collect_back(h, par);
-  int rc = commit_frame(h, tk.off, tk.points, nullptr, tk.n_pose, tk.pose_buf);
+  int rc;
+  if (!h->sharded) {  // now that the size is known: exact ring space, frame copied behind the fusion that may still read it
+    rc = window_reserve(h, tk.points, &tk.off);
+    if (rc) return rc;
+    if (tk.points)
+      HIPCHK(hipMemcpyAsync(h->d_win + tk.off, h->d_stage[fp], sizeof(DevPoint) * tk.points, hipMemcpyDeviceToDevice, h->stream_b));
+    HIPCHK(hipEventRecord(h->evt[EV_STG + fp * EV_FRONT_STRIDE], h->stream_b));
+  }
+  rc = commit_frame(h, tk.off, tk.points, nullptr, tk.n_pose, tk.pose_buf);
   if (rc) return rc;
   rc = run_fuse(h, par, tk.T_world_obs);
   if (rc) return rc;
