@@ -1344,6 +1344,7 @@ int tick_phase2(esvo_context* h, int fp) {
 int flush_pending_tick(esvo_context* h) {
   if (!h->tick_pending || h->sharded) return ESVO_OK;
   const int fp = h->fpar;
+  h->tick_pending = false;  // also when completing it fails (e.g. window ring full): the error is reported once
   int rc = tick_phase1_collect(h, fp);
   if (rc) return rc;
   return tick_phase2(h, fp);
@@ -1384,10 +1385,9 @@ extern "C" int esvo_map_tick(esvo_handle h, uint64_t t_ns, const uint64_t* pose_
   if (rc) return rc;
   if (prev) {
     rc = tick_phase1_collect(h, prev_fp);
+    if (!rc) rc = tick_phase2(h, prev_fp);
+    h->tick_pending = true;  // this tick (its front stage is enqueued whatever happened to the previous one)
     if (rc) return rc;
-    rc = tick_phase2(h, prev_fp);
-    if (rc) return rc;
-    h->tick_pending = true;  // this tick
   }
   return ESVO_OK;
 }
