@@ -1701,7 +1701,7 @@ extern "C" void esvo_abi_sizes(size_t out[8]) {
   out[6] = 0; out[7] = ESVO_HIP_ABI_VERSION;
 }
 
-// ---- device self-test: div_by(a, make_recip(b)) == a / b bit for bit ---------------------------------
+// ---- device self-test: div_by(a, make_recip(b)) == a / b and sqrt_moderate(x) == sqrt(x), bit for bit ----------
 #include "fdiv.hpp"
 namespace {
 __device__ inline unsigned long long sm64(unsigned long long& s) {
@@ -1732,6 +1732,10 @@ __global__ void selftest_div_kernel(unsigned long long n_per_thread, unsigned lo
     const double q = esvo::div_by(a, esvo::make_recip(b));
     const bool same = (__double_as_longlong(q) == __double_as_longlong(q_ref)) || (q != q && q_ref != q_ref);
     bad += !same;
+    // sqrt_moderate(x) == sqrt(x) for x in [2^-700, 2^700]
+    const int es = (int)(sm64(s) % 1400) - 700 + 1023;
+    const double xs = __longlong_as_double((long long)(((unsigned long long)es << 52) | (ra >> 12)));
+    bad += __double_as_longlong(esvo::sqrt_moderate(xs)) != __double_as_longlong(sqrt(xs));
   }
   if (bad) atomicAdd(mismatches, bad);
 }

@@ -52,4 +52,23 @@ __device__ inline double div_by(double a, const Recip& R) {
   return (R.fast && fdiv_ok(a)) ? div_fast(a, R) : a / R.b;
 }
 
+// IEEE-identical f64 square root for x in [2^-700, 2^700]: hipcc lowers sqrt(x) to
+//     scale x by 2^256 if x < 2^-767;  y = v_rsq(x);  g = x*y;  h = 0.5*y;  r = fma(-h,g,0.5);  g = fma(g,r,g);
+//     h = fma(h,r,h);  d = fma(-g,g,x);  g = fma(d,h,g);  d = fma(-g,g,x);  g = fma(d,h,g);  unscale;  x if x is 0/inf
+// (18 VALU instructions).  For a moderate positive x the scaling and the class select are identities, so the ten
+// core operations below give the same bits.  The caller vouches for the range (the LM weights are (nu+1)/(nu + r^2/s^2)
+// with the exponent of r^2/s^2 already bounded); esvo_selftest_division() checks the equivalence on the device.
+__device__ inline double sqrt_moderate(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y;
+  double h = y * 0.5;
+  const double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  double d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  d = __builtin_fma(-g, g, x);
+  return __builtin_fma(d, h, g);
+}
+
 }  // namespace esvo

@@ -244,8 +244,9 @@ __device__ void lm_eval(const DevParams& p, const LmProblem& pr, double x, doubl
 #endif
 #pragma unroll
   for (int y = 0; y < LM_ROWS; ++y) {
-    const double weight = fast2 ? div_fast(nu + 1, make_recip(nu + div_fast(r2[y], rs2))) : (nu + 1) / (nu + r2[y] / s2);
-    fv[y] = sqrt(weight) * r[y];
+    // fast2 bounds r^2/s2 below 2^301, so the weight lies in (2^-300, (nu+1)/nu]: sqrt_moderate's range (fdiv.hpp)
+    fv[y] = fast2 ? sqrt_moderate(div_fast(nu + 1, make_recip(nu + div_fast(r2[y], rs2)))) * r[y]
+                  : sqrt((nu + 1) / (nu + r2[y] / s2)) * r[y];
   }
 }
 
