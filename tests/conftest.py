@@ -12,6 +12,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """Tests that emulate collectives view library buffers as torch tensors.  torch's lazy CUDA initialisation has been
+    seen to report "No HIP GPUs are available" when it first runs after libesvo_hip.so has created and destroyed several
+    large contexts in the same process, so it is done once, up front, where a GPU exists."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
+
+
 @pytest.fixture(scope="session")
 def upenn_rig():
     from esvo_amd import calib

@@ -1,0 +1,109 @@
+"""Full-size (bench workload: 640x480, ~180 k events per tick, 81 disparity candidates) properties that do not need
+the oracle (it would take minutes at this size): determinism, idempotence of the Time-Surface render, the invariants
+SmartGrid::clean / DepthRegularization guarantee for every element, agreement of the lazy and the eager tick, and
+tick-interleaved == single handle."""
+import numpy as np
+import pytest
+
+import bench
+from esvo_amd import calib, params, rostime, synth
+
+pytestmark = pytest.mark.gpu
+F64 = ["inv_depth", "scale2", "nu", "variance", "residual", "x", "p_cam"]
+
+
+@pytest.fixture(scope="module")
+def full():
+    wl = bench.WORKLOADS["dsec640x480"]
+    rig = calib.dataset_rig(wl["rig"])
+    n_ticks = 6
+    duration = 0.06 + (n_ticks + 1) * 0.01
+    stream = synth.make_stream(rig, wl["points"], duration, wl["rho"][0], wl["rho"][1], seed=20250418 + 3, speed=wl["speed"])
+    cap = int(len(stream.ev_left) / duration * 0.01 * 1.5) + 1024
+    p, _ = params.make_params(params.PRESETS[wl["preset"]], rig, throughput_events=cap, event_ring_capacity=max(1 << 22, int(len(stream.ev_left) * 1.1)))
+    ticks = []
+    for k in range(n_ticks):
+        t = stream.t0_ns + int((0.06 + (k + 1) * 0.01) * 1e9)
+        stamps, poses = rostime.pose_table(stream.pose, t, p.bm_half_slice_thickness)
+        ticks.append((t, stamps, poses, stream.pose(t)))
+    return rig, stream, p, ticks
+
+
+def _run(full, eager):
+    from esvo_amd import lib
+    rig, stream, p, ticks = full
+    dev = lib.Esvo(p, rig)
+    dev.ts_push_events(0, stream.ev_left)
+    dev.ts_push_events(1, stream.ev_right)
+    maps = []
+    for t, stamps, poses, T in ticks:
+        dev.ts_render(0, t, download=False); dev.ts_render(1, t, download=False)
+        dev.set_observation(t, None, None, T)
+        dev.tick(t, stamps, poses)
+        if eager:
+            maps.append(dev.get_map())     # completes the tick at once
+    if not eager:
+        maps.append(dev.get_map())
+    return dev, maps
+
+
+def _same(a, b):
+    assert len(a) == len(b)
+    for f in ("row", "col", "age"):
+        assert np.array_equal(a[f], b[f]), f
+    for f in F64:
+        assert np.array_equal(a[f], b[f]), f
+
+
+def test_full_size_determinism_lazy_vs_eager_and_invariants(full):
+    rig, stream, p, ticks = full
+    dev_e, maps_e = _run(full, eager=True)
+    dev_l, maps_l = _run(full, eager=False)
+    _same(maps_e[-1], maps_l[-1])                      # lazily completed ticks == ticks completed one by one
+    s = dev_l.stats()
+    assert s.ticks == len(ticks) and s.total_events_in > 150000 * len(ticks) and s.total_points > 10000 * len(ticks)
+    m = maps_l[-1]
+    assert len(m) > 30000
+    # SmartGrid::clean (window full from tick 5 on): every element passed valid(); the regulariser then only changes rho
+    reg_invalid = m["inv_depth"] == -1.0             # DepthRegularization.cpp:99-101
+    ok = m[~reg_invalid]
+    assert reg_invalid.sum() < len(m) and len(ok) > 10000
+    assert (ok["inv_depth"] > 0).all() and (m["variance"] <= p.stdvar_vis_threshold ** 2).all() and (m["age"] >= p.age_vis_threshold).all()
+    assert (m["scale2"] > 0).all() and (m["nu"] >= 2.0).all() and np.isfinite(m["p_cam"]).all()
+    assert (m["row"] < rig.height).all() and (m["col"] < rig.width).all()
+    keys = m["row"].astype(np.int64) * rig.width + m["col"]
+    assert len(np.unique(keys)) >= 0.98 * len(keys)    # displaced elements (Appendix A-7) may share a believed cell, rarely
+    # idempotence of the render: same T, same image
+    t = ticks[-1][0]
+    assert np.array_equal(dev_l.ts_render(0, t), dev_l.ts_render(0, t))
+
+
+def test_full_size_tick_interleaved_equals_single(full):
+    import torch
+    from esvo_amd import dist as edist
+    from esvo_amd import lib
+    rig, stream, p, ticks = full
+    _, maps = _run(full, eager=True)
+    G = 2
+    ranks = [lib.Esvo(p, rig) for _ in range(G)]
+    for d in ranks:
+        d.ts_push_events(0, stream.ev_left)
+        d.ts_push_events(1, stream.ev_right)
+    for k0 in range(0, len(ticks), G):
+        rnd = list(range(k0, min(k0 + G, len(ticks))))
+        fronts = {}
+        for kk in rnd:
+            d = ranks[kk % G]
+            t, stamps, poses, T = ticks[kk]
+            d.ts_render(0, t, download=False); d.ts_render(1, t, download=False)
+            d.set_observation(t, None, None, T)
+            fronts[kk] = d.front(t, stamps, poses)
+        frames = {kk: edist.device_tensor(ptr, max(n, 1) * 13, "<i8")[: n * 13].clone() for kk, (ptr, n) in fronts.items()}
+        torch.cuda.synchronize()
+        for g, d in enumerate(ranks):
+            for kk in rnd:
+                d.push_frame_device(frames[kk].data_ptr(), fronts[kk][1], ticks[kk][2])
+                if kk % G == g:
+                    d.fuse_async()
+        for kk in rnd:
+            _same(ranks[kk % G].get_map(), maps[kk])
