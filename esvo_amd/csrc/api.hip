@@ -154,10 +154,12 @@ struct esvo_context {
   struct TickState {
     u32 n = 0, off = 0, points = 0, n_pose = 0;
     int pose_buf = 0;
+    u64 t_ns = 0;
     double T_world_obs[16];
   } tk[2];
   int fpar = 0;                   // parity of the newest front stage
   bool tick_pending = false;      // tk[fpar] has its front stage enqueued but is not committed yet
+  u64 committed_t_ns = 0;         // stamp of the newest tick whose back stage is enqueued (0: none)
   u64 sh_first = 0;
   u32* d_cell_list = nullptr;
   u64* d_reg_bits = nullptr;    // close-neighbour masks of the regulariser scan: [elements][words]
@@ -826,6 +828,7 @@ int esvo_reset(esvo_handle h) {
   HIPCHK(hipStreamSynchronize(h->stream));
   HIPCHK(hipStreamSynchronize(h->stream_b));
   h->back_pending[0] = h->back_pending[1] = false;
+  h->committed_t_ns = 0;
   h->ts_timing_pending[0] = h->ts_timing_pending[1] = false;
   h->stats_pending = false;
   std::memset(&h->stats, 0, sizeof(h->stats));
@@ -1134,6 +1137,7 @@ int esvo_map_fuse(esvo_handle h, size_t* n_fusions) {
   collect_back(h, par);
   rc = run_fuse(h, par, h->T_world_obs);
   if (rc) return rc;
+  h->committed_t_ns = h->obs_t_ns;
   HIPCHK(hipStreamSynchronize(h->stream_b));
   collect_back(h, par);
   h->stats.last_window_frames = (u32)h->frames.size();
@@ -1178,7 +1182,7 @@ int tick_phase0(esvo_context* h, uint64_t t_ns, const uint64_t* pose_t_ns, const
   if (rc) return rc;
   h->fpar ^= 1;
   esvo_context::TickState& tk = h->tk[h->fpar];
-  tk.n = n; tk.off = 0; tk.points = 0;
+  tk.n = n; tk.off = 0; tk.points = 0; tk.t_ns = t_ns;
   tk.pose_buf = h->pose_buf; tk.n_pose = h->n_pose;
   std::memcpy(tk.T_world_obs, h->T_world_obs, sizeof(double) * 16);
   // two ticks in flight at most: what this tick's front stage overwrites (ring space of popped frames, the pose
@@ -1338,6 +1342,7 @@ int tick_phase2(esvo_context* h, int fp) {
   h->stats.last_window_points = np;
   h->stats_pending = true;
   h->tick_pending = false;
+  h->committed_t_ns = tk.t_ns;
   return ESVO_OK;
 }
 // complete the tick whose front stage is enqueued but which is not committed yet (unsharded ticks are lazy)
@@ -1455,6 +1460,7 @@ extern "C" int esvo_map_fuse_async(esvo_handle h) {
   collect_back(h, par);
   rc = run_fuse(h, par, h->T_world_obs);
   if (rc) return rc;
+  h->committed_t_ns = h->obs_t_ns;
   h->stats.ticks++;
   h->stats.last_window_frames = (u32)h->frames.size();
   u32 np = 0;
@@ -1497,6 +1503,23 @@ int esvo_map_get_depth_points(esvo_handle h, esvo_depth_point_t* out, size_t cap
   if (out) {
     if (v.size() > cap) FAIL(ESVO_ERR_CAPACITY, "output array too small for the DepthMap");
     if (!v.empty()) std::memcpy(out, v.data(), sizeof(esvo_depth_point_t) * v.size());
+  }
+  return ESVO_OK;
+}
+
+int esvo_map_get_committed(esvo_handle h, esvo_depth_point_t* out, size_t cap, size_t* n, uint64_t* t_ns) {
+  if (!h || !n) return ESVO_ERR_INVALID_ARG;
+  HIPCHK(hipSetDevice(h->device));
+  if (t_ns) *t_ns = h->committed_t_ns;
+  *n = 0;
+  if (h->committed_t_ns == 0) return ESVO_OK;
+  std::vector<esvo_depth_point_t> v;
+  int rc = export_map(h, v, nullptr);  // back stream only: a pending tick's front stage keeps running
+  if (rc) return rc;
+  *n = v.size();
+  if (out) {
+    if (v.size() > cap) FAIL(ESVO_ERR_CAPACITY, "output array too small for the DepthMap");
+    std::memcpy(out, v.data(), sizeof(esvo_depth_point_t) * v.size());
   }
   return ESVO_OK;
 }

@@ -23,7 +23,7 @@ SYMBOLS = [
     "esvo_default_params", "esvo_create", "esvo_destroy", "esvo_reset", "esvo_set_params", "esvo_last_error",
     "esvo_set_stream", "esvo_synchronize", "esvo_ts_push_events", "esvo_ts_push_event_array", "esvo_ts_render", "esvo_map_set_observation",
     "esvo_map_match", "esvo_map_set_poses", "esvo_map_refine", "esvo_map_push_frame", "esvo_map_fuse",
-    "esvo_map_tick", "esvo_map_get_depth_points", "esvo_map_get_pointcloud_xyz", "esvo_map_get_last_frame",
+    "esvo_map_tick", "esvo_map_get_depth_points", "esvo_map_get_committed", "esvo_map_get_pointcloud_xyz", "esvo_map_get_last_frame",
     "esvo_get_stats", "esvo_shard_set_band", "esvo_shard_exchange", "esvo_shard_tick_phase", "esvo_abi_sizes",
     "esvo_map_front", "esvo_map_front_frame", "esvo_map_push_frame_device", "esvo_map_fuse_async",
     "esvo_track_set_current", "esvo_track_get_images", "esvo_track_set_reference", "esvo_track_residuals", "esvo_track_jacobian",
@@ -83,6 +83,7 @@ def load():
     lib.esvo_map_fuse.argtypes = [vp, psz]
     lib.esvo_map_tick.argtypes = [vp, u64, vp, vp, sz]
     lib.esvo_map_get_depth_points.argtypes = [vp, vp, sz, psz]
+    lib.esvo_map_get_committed.argtypes = [vp, vp, sz, psz, C.POINTER(C.c_uint64)]
     lib.esvo_map_get_pointcloud_xyz.argtypes = [vp, vp, sz, psz]
     lib.esvo_map_get_last_frame.argtypes = [vp, vp, sz, psz]
     lib.esvo_get_stats.argtypes = [vp, vp]
@@ -241,6 +242,13 @@ class Esvo:
         out = np.zeros(self.W * self.H, DEPTH_POINT_DTYPE)
         self._ck(self.lib.esvo_map_get_depth_points(self.h, out.ctypes.data, out.shape[0], C.byref(n)))
         return out[: n.value].copy()
+
+    def get_committed_map(self):
+        """(DepthMap of the newest committed tick, its stamp) without completing a pending tick"""
+        out = np.zeros(self.W * self.H, DEPTH_POINT_DTYPE)
+        n, t = C.c_size_t(), C.c_uint64()
+        self._ck(self.lib.esvo_map_get_committed(self.h, out.ctypes.data, out.shape[0], C.byref(n), C.byref(t)))
+        return out[:n.value].copy(), int(t.value)
 
     def get_pointcloud(self):
         n = C.c_size_t(0)

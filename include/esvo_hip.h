@@ -271,6 +271,10 @@ int esvo_map_fuse_async(esvo_handle h);
 /* DepthMap iteration (SmartGrid.h:346-358) as consumed by the publishers
  * (esvo_Mapping.cpp:925-932).  Elements are returned in the reference's list order. */
 int esvo_map_get_depth_points(esvo_handle h, esvo_depth_point_t* out, size_t cap, size_t* n);
+/* The DepthMap of the newest COMMITTED tick (*t_ns: its stamp, 0 if none) without completing a pending one:
+ * esvo_map_tick(k) commits tick k-1 and leaves tick k's front stage running, so a node that publishes after every
+ * tick reads map k-1 here while tick k computes (one tick of latency for the overlap). */
+int esvo_map_get_committed(esvo_handle h, esvo_depth_point_t* out, size_t cap, size_t* n, uint64_t* t_ns);
 /* Replaces the loop of publishPointCloud (esvo_Mapping.cpp:925-932): p_world = R p_cam + t
  * as float32 xyz triples, the payload of /esvo_mapping/pointcloud_local. */
 int esvo_map_get_pointcloud_xyz(esvo_handle h, float* out_xyz, size_t cap_points, size_t* n);

@@ -253,3 +253,35 @@ def test_wire_ingest_equals_struct_ingest(upenn_rig, upenn_stream):
                       (abi.serialize_event_array(upenn_stream.ev_left[:10][::-1], upenn_rig.width, upenn_rig.height), "sorted")):
         with pytest.raises(lib.EsvoError, match=what):
             lib.Esvo(p, upenn_rig).ts_push_event_array(0, bad)
+
+
+def test_committed_map_lags_one_tick(dsec_rig, dsec_stream):
+    """esvo_map_get_committed after esvo_map_tick(k) returns the DepthMap of tick k-1 (and its stamp) without completing
+    tick k -- the call a node uses to publish every tick and still overlap the stages; it must equal what the eager
+    sequence (tick, get_depth_points) produced for that tick."""
+    from esvo_amd import lib
+    rig, stream = dsec_rig, dsec_stream
+    p, _ = params.make_params(params.PRESETS["mapping_dsec"], rig, process_event_num=4000)
+    eager, lazy = lib.Esvo(p, rig), lib.Esvo(p, rig)
+    for d in (eager, lazy):
+        d.ts_push_events(0, stream.ev_left)
+        d.ts_push_events(1, stream.ev_right)
+    prev, prev_t = None, 0
+    m0, t0 = lazy.get_committed_map()
+    assert len(m0) == 0 and t0 == 0
+    for k in range(6):
+        t = stream.t0_ns + int((0.06 + 0.01 * k) * 1e9)
+        stamps, poses = rostime.pose_table(stream.pose, t, p.bm_half_slice_thickness)
+        for d in (eager, lazy):
+            d.ts_render(0, t, download=False); d.ts_render(1, t, download=False)
+            d.set_observation(t, None, None, stream.pose(t))
+            d.tick(t, stamps, poses)
+        got, got_t = lazy.get_committed_map()
+        if prev is None:
+            assert got_t == 0 and len(got) == 0
+        else:
+            assert got_t == prev_t
+            _same_map(got, prev)
+        prev, prev_t = eager.get_map(), t
+    _same_map(lazy.get_map(), prev)          # completing the pending tick gives the newest map
+    assert lazy.get_committed_map()[1] == prev_t
