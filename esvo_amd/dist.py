@@ -27,8 +27,14 @@ class _DevView:
         self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
 
 
-def device_tensor(ptr, n, typestr):
+def device_tensor(ptr, n, typestr, device="cuda"):
+    """zero-copy int/float view of `n` elements at device address `ptr` (host address when device == "cpu": tests)"""
     import torch
+    if device == "cpu":
+        import ctypes
+        dt = np.dtype(typestr)
+        buf = (ctypes.c_char * (int(n) * dt.itemsize)).from_address(int(ptr))
+        return torch.from_numpy(np.frombuffer(buf, dtype=dt, count=int(n)))
     return torch.as_tensor(_DevView(ptr, n, typestr), device="cuda")
 
 
@@ -50,19 +56,25 @@ class ShardedEsvo:
 
     counts_are_local = False
 
-    def __init__(self, params, rig, rank, world, local_rank, group=None):
+    def __init__(self, params, rig, rank, world, local_rank, group=None, dev=None, device="cuda"):
+        """dev / device: a stand-in for lib.Esvo on host memory (CPU tests of the phase / exchange logic under gloo)"""
         import torch
         self.rank, self.world, self.group = rank, world, group
         self.rig, self.params = rig, params
         self.W, self.H = rig.width, rig.height
-        self.dev = lib.Esvo(params, rig, device=local_rank)
-        self.dev.set_stream(torch.cuda.current_stream().cuda_stream)
+        self.device = device
+        if dev is None:
+            self.dev = lib.Esvo(params, rig, device=local_rank)
+            self.dev.set_stream(torch.cuda.current_stream().cuda_stream)
+        else:
+            self.dev = dev
         self.y0, self.y1 = band_of(rank, world, self.H)
         if self.y1 <= self.y0:
             raise lib.EsvoError(f"rank {rank} of {world} would own no image rows (H={self.H})")
         self.dev.set_band(self.y0, self.y1, rank, world)
-        merge_disjoint_(torch.zeros(1024, dtype=torch.int64, device="cuda"), group)  # communicator set-up, untimed
-        torch.cuda.synchronize()
+        merge_disjoint_(torch.zeros(1024, dtype=torch.int64, device=device), group)  # communicator set-up, untimed
+        if device == "cuda":
+            torch.cuda.synchronize()
     # replicated stages: every rank ingests all events and renders the full Time Surfaces
     def ts_push_events(self, cam, ev):
         self.dev.ts_push_events(cam, ev)
@@ -82,7 +94,7 @@ class ShardedEsvo:
     def _exchange(self):
         ptr, nbytes = self.dev.shard_exchange()
         if nbytes:
-            merge_disjoint_(device_tensor(ptr, nbytes // 8, "<i8"), self.group)
+            merge_disjoint_(device_tensor(ptr, nbytes // 8, "<i8", self.device), self.group)
 
     def tick(self, t_ns, stamps, poses):
         d = self.dev
@@ -117,27 +129,40 @@ class TickShardedEsvo:
 
     counts_are_local = True   # stats() counts this rank's own ticks
 
-    def __init__(self, params, rig, rank, world, local_rank, group=None):
+    def __init__(self, params, rig, rank, world, local_rank, group=None, dev=None, device="cuda"):
+        """dev / device: a stand-in for lib.Esvo on host memory (CPU tests of the round logic under gloo)"""
         import torch
         self.rank, self.world, self.group = rank, world, group
         self.rig, self.params = rig, params
-        self.dev = lib.Esvo(params, rig, device=local_rank)
-        self.dev.set_stream(torch.cuda.current_stream().cuda_stream)
+        self.device = device
+        if dev is None:
+            self.dev = lib.Esvo(params, rig, device=local_rank)
+            self.dev.set_stream(torch.cuda.current_stream().cuda_stream)
+        else:
+            self.dev = dev
         self.k = 0                 # index of the next tick
         self.round = []            # ticks of the current round: (t_ns, stamps, poses)
         self.mine = None           # (device pointer, points) of this rank's frame in the current round
         self.last_mine = -1        # index of the last tick this rank fused
         self.words = DEPTH_POINT_DTYPE.itemsize // 8
-        self._cnt = torch.zeros(world, dtype=torch.int64, device="cuda")
+        self._cnt = torch.zeros(world, dtype=torch.int64, device=device)
         # two alternating gather buffers (a fusion may still read the previous round's), sized for 64 k points per tick
         # up front and grown on demand; one untimed round trip of both collectives sets up the communicator's channels
         prime = 65536 * self.words
-        self._gather = [torch.empty(world * prime, dtype=torch.int64, device="cuda") for _ in range(2)]
+        self._gather = [torch.empty(world * prime, dtype=torch.int64, device=device) for _ in range(2)]
         self._rounds = 0
         import torch.distributed as dist
         dist.all_reduce(self._cnt, op=dist.ReduceOp.SUM, group=group)
-        dist.all_gather_into_tensor(self._gather[0][: world * 1024], torch.zeros(1024, dtype=torch.int64, device="cuda"), group=group)
-        torch.cuda.synchronize()
+        self._all_gather(self._gather[0][: world * 1024], torch.zeros(1024, dtype=torch.int64, device=device))
+        if device == "cuda":
+            torch.cuda.synchronize()
+
+    def _all_gather(self, recv, send):
+        import torch.distributed as dist
+        if dist.get_backend(self.group) == "gloo" and recv.device.type == "cpu":  # gloo has no all_gather_into_tensor on CPU
+            dist.all_gather(list(recv.view(self.world, -1).unbind(0)), send, group=self.group)
+        else:
+            dist.all_gather_into_tensor(recv, send, group=self.group)
 
     def _is_mine(self):
         return self.k % self.world == self.rank
@@ -177,13 +202,13 @@ class TickShardedEsvo:
         stride = max(max(counts), 1) * self.words
         buf = self._gather[self._rounds & 1]
         if buf is None or buf.numel() < self.world * stride:
-            buf = torch.empty(self.world * stride, dtype=torch.int64, device="cuda")
+            buf = torch.empty(self.world * stride, dtype=torch.int64, device=self.device)
             self._gather[self._rounds & 1] = buf
-        send = buf.new_zeros(stride) if not n_mine else torch.empty(stride, dtype=torch.int64, device="cuda")
+        send = buf.new_zeros(stride) if not n_mine else torch.empty(stride, dtype=torch.int64, device=self.device)
         if n_mine:
-            send[: n_mine * self.words] = device_tensor(self.mine[0], n_mine * self.words, "<i8")
+            send[: n_mine * self.words] = device_tensor(self.mine[0], n_mine * self.words, "<i8", self.device)
         recv = buf[: self.world * stride]
-        dist.all_gather_into_tensor(recv, send, group=self.group)
+        self._all_gather(recv, send)
         base = recv.data_ptr()
         k0 = self.k - len(self.round)
         for j, (t_ns, stamps, poses) in enumerate(self.round):

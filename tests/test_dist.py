@@ -62,3 +62,159 @@ def test_band_bookkeeping_and_merge():
     b = np.zeros(2, DEPTH_POINT_DTYPE); b["seq"] = [3, 7]; b["row"] = [5, 6]
     m = edist.merge_band_maps([a, b, np.zeros(0, DEPTH_POINT_DTYPE)])
     assert list(m["row"]) == [0, 5, 0, 6, 1] and list(m["seq"]) == [0, 1, 2, 3, 4]
+
+
+# ---- tick-interleaved driver (dist.TickShardedEsvo) on CPU: two gloo ranks, a host-memory stand-in for lib.Esvo ------
+class _FakeEsvo:
+    """Records what TickShardedEsvo asks of the handle; a tick's frame is n(k) points whose 13 words encode (k, i, w)."""
+
+    def __init__(self):
+        self.log, self.k_seen, self.keep = [], [], []
+
+    def ts_render(self, cam, t_ns, download=True):
+        self.log.append(("render", cam, t_ns))
+
+    def set_observation(self, *a):
+        self.log.append(("obs", a[0]))
+
+    def front(self, t_ns, stamps, poses):
+        k = int(t_ns)                      # the test passes the tick index as time stamp
+        n = 3 + (k * 7) % 5
+        frame = np.empty((n, 13), np.int64)
+        for i in range(n):
+            frame[i] = [k * 1000 + i * 13 + w for w in range(13)]
+        self.keep.append(frame)            # keeps the buffer alive, like d_pts_tmp
+        self.log.append(("front", k, n))
+        return frame.ctypes.data, n
+
+    def push_frame_device(self, ptr, n, poses):
+        import ctypes
+        words = np.frombuffer((ctypes.c_char * (n * 104)).from_address(int(ptr)), np.int64, n * 13).reshape(n, 13).copy() if n else np.zeros((0, 13), np.int64)
+        self.log.append(("push", words, np.asarray(poses).copy()))
+
+    def fuse_async(self):
+        self.log.append(("fuse",))
+
+    def synchronize(self):
+        pass
+
+
+def _tick_worker(rank, world, port, n_ticks, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        fake = _FakeEsvo()
+        drv = edist.TickShardedEsvo(None, None, rank, world, 0, dev=fake, device="cpu")
+        for k in range(n_ticks):
+            drv.ts_render(0, k, download=False)
+            drv.set_observation(k, None, None, None)
+            drv.tick(k, np.arange(2, dtype=np.uint64), np.full((2, 16), float(k)))
+            if k == 2:
+                drv.synchronize()            # a flush in the middle of a round (as bench.py does after its warm-up)
+        drv.synchronize()
+        fronts = [e[1] for e in fake.log if e[0] == "front"]
+        renders = [e[2] for e in fake.log if e[0] == "render"]
+        pushes = [e for e in fake.log if e[0] == "push"]
+        ok = fronts == [k for k in range(n_ticks) if k % world == rank] == renders
+        ok &= len(pushes) == n_ticks
+        for k, (_, words, poses) in enumerate(pushes):       # every tick's frame, in tick order, content intact
+            n = 3 + (k * 7) % 5
+            ok &= words.shape == (n, 13) and bool((words[:, 0] == k * 1000 + 13 * np.arange(n)).all()) and bool((poses == float(k)).all())
+        # the fusion of an own tick follows the push of that tick and precedes the push of the next one
+        order = [("p", i) for i in range(n_ticks)]
+        seq, pi = [], 0
+        for e in fake.log:
+            if e[0] == "push":
+                seq.append(("p", pi)); pi += 1
+            elif e[0] == "fuse":
+                seq.append(("f", pi - 1))
+        fused = [i for tag, i in seq if tag == "f"]
+        ok &= fused == [k for k in range(n_ticks) if k % world == rank] and drv.last_mine == (fused[-1] if fused else -1)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_ticks", [4, 7])
+def test_tick_interleaved_driver_gloo_world2(n_ticks):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_tick_worker, args=(r, 2, 29620 + n_ticks, n_ticks, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res), res
+
+
+# ---- band driver (dist.ShardedEsvo) on CPU: the phase / exchange protocol with a host-memory stand-in ---------------
+class _FakeBand:
+    def __init__(self, rank, world):
+        self.rank, self.world, self.phase_log, self.buf = rank, world, [], None
+
+    def set_band(self, y0, y1, shard, n_shards):
+        self.band = (y0, y1, shard, n_shards)
+
+    def shard_phase(self, phase, t_ns=0, stamps=None, poses=None):
+        self.phase_log.append(phase)
+        if phase == 0:      # one byte per slot, own slots only (w % world == rank), padded to 8
+            n = 21
+            b = np.zeros(24, np.uint8)
+            own = np.arange(n) % self.world == self.rank
+            b[:n][own] = 1 + 2 * (np.arange(n)[own] % 2)
+            self.buf = b.view(np.int64)
+        elif phase == 1:    # the frame: own points at their final indices, zero elsewhere
+            f = np.zeros((5, 13), np.int64)
+            f[self.rank::self.world] = (np.arange(5)[self.rank::self.world, None] + 1) * 100 + np.arange(13)
+            self.buf = f.reshape(-1)
+        else:
+            self.buf = None
+
+    def shard_exchange(self):
+        return (self.buf.ctypes.data, self.buf.nbytes) if self.buf is not None else (0, 0)
+
+
+class _Rig:
+    width, height = 8, 10
+
+
+def _band_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        fake = _FakeBand(rank, world)
+        drv = edist.ShardedEsvo(None, _Rig(), rank, world, 0, dev=fake, device="cpu")
+        ok = fake.band == (*edist.band_of(rank, world, 10), rank, world)
+        snap = {}
+        orig = fake.shard_phase
+
+        def spy(phase, *a, **k):
+            if fake.buf is not None:
+                snap[phase - 1] = fake.buf.copy()      # what the previous phase's buffer looked like after the exchange
+            orig(phase, *a, **k)
+        fake.shard_phase = spy
+        drv.tick(1, np.zeros(1, np.uint64), np.zeros((1, 16)))
+        ok &= fake.phase_log == [0, 1, 2]
+        codes = snap[0].view(np.uint8)[:21]
+        ok &= bool((codes == 1 + 2 * (np.arange(21) % 2)).all())                       # union of both ranks' bytes
+        ok &= bool((snap[1].reshape(5, 13) == (np.arange(5)[:, None] + 1) * 100 + np.arange(13)).all())
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_band_driver_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_band_worker, args=(r, 2, 29641, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res), res
