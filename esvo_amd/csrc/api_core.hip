@@ -1,0 +1,420 @@
+// api_core.hip — lifecycle of the handle, parameters, ABI self-checks (see context.hpp).
+#include "context.hpp"
+
+namespace esvo_host {
+thread_local std::string g_create_error;
+}
+
+namespace {
+
+void invert3x3(const double* P, double* Kinv, double* Kinv_t) {
+  const double a = P[0], b = P[1], cc = P[2], d = P[4], e = P[5], f = P[6], g = P[8], hh = P[9], i = P[10];
+  const double det = a * (e * i - f * hh) - b * (d * i - f * g) + cc * (d * hh - e * g);
+  const double id = 1.0 / det;
+  Kinv[0] = (e * i - f * hh) * id; Kinv[1] = (cc * hh - b * i) * id; Kinv[2] = (b * f - cc * e) * id;
+  Kinv[3] = (f * g - d * i) * id;  Kinv[4] = (a * i - cc * g) * id;  Kinv[5] = (cc * d - a * f) * id;
+  Kinv[6] = (d * hh - e * g) * id; Kinv[7] = (b * g - a * hh) * id;  Kinv[8] = (a * e - b * d) * id;
+  for (int r = 0; r < 3; ++r) Kinv_t[r] = (Kinv[r * 3 + 0] * P[3] + Kinv[r * 3 + 1] * P[7]) + Kinv[r * 3 + 2] * P[11];
+}
+
+int validate_params(const esvo_params_t* p, std::string& why) {
+  if (p->ls_norm != ESVO_LSNORM_TDIST) { why = "only LSnorm == Tdist is supported (every shipped config uses it)"; return ESVO_ERR_UNSUPPORTED; }
+  if (p->bm_updown) { why = "BM_bUpDownConfiguration is not supported"; return ESVO_ERR_UNSUPPORTED; }
+  if (p->bm_step != 1) { why = "BM_step != 1 is not supported (every shipped config uses 1)"; return ESVO_ERR_UNSUPPORTED; }
+  if (p->patch_size_x != 15 || p->patch_size_y != 7) { why = "patch size must be 15x7 (every shipped config)"; return ESVO_ERR_UNSUPPORTED; }
+  if (p->median_blur_kernel_size < 0 || p->median_blur_kernel_size > 1) { why = "median_blur_kernel_size must be 0 or 1"; return ESVO_ERR_UNSUPPORTED; }
+  if (p->bm_max_disparity < p->bm_min_disparity || p->bm_min_disparity < 0) { why = "bad disparity range"; return ESVO_ERR_INVALID_ARG; }
+  if (p->td_nu <= 2.0 || p->td_scale <= 0) { why = "Tdist_nu must be > 2 and Tdist_scale > 0"; return ESVO_ERR_INVALID_ARG; }
+  if (p->num_threads < 1 || p->num_threads > 64) { why = "num_threads out of range"; return ESVO_ERR_INVALID_ARG; }
+  if (p->lm_max_iteration < 1) { why = "lm_max_iteration must be >= 1"; return ESVO_ERR_INVALID_ARG; }
+  if (p->reg_radius < 0 || p->reg_radius > 31) { why = "RegularizationRadius out of range [0,31] (one 64-bit mask per tap row)"; return ESVO_ERR_INVALID_ARG; }
+  return ESVO_OK;
+}
+
+}  // namespace
+
+namespace esvo_host {
+
+void fill_dev_params(esvo_context* h) {
+  const esvo_params_t& p = h->prm;
+  DevParams& d = h->dp;
+  d.W = h->W; d.H = h->H;
+  d.wx = p.patch_size_x; d.wy = p.patch_size_y;
+  d.dmin = p.bm_min_disparity; d.dmax = p.bm_max_disparity; d.step = p.bm_step;
+  d.zncc_thr = p.bm_zncc_threshold;
+  d.baseline_f = h->baseline * d.camL.P[0];
+  d.td_nu = p.td_nu; d.td_scale = p.td_scale; d.td_scale2 = p.td_scale * p.td_scale;
+  const double td_stdvar = std::sqrt(p.td_nu / (p.td_nu - 2) * (p.td_scale * p.td_scale));  // DepthProblem.h:34
+  d.td_stdvar2 = td_stdvar * td_stdvar;
+  d.lm_max_iter = p.lm_max_iteration; d.lm_maxfev = p.lm_max_iteration * 3;
+  d.invdepth_min = p.invdepth_min; d.invdepth_max = p.invdepth_max;
+  d.var_thr = p.stdvar_vis_threshold * p.stdvar_vis_threshold;
+  d.cost_thr = (p.residual_vis_threshold * p.residual_vis_threshold) * (double)(p.patch_size_x * p.patch_size_y);
+  d.age_thr = p.age_vis_threshold;
+  d.fusion_radius = p.fusion_radius;
+  d.reg_radius = p.reg_radius; d.reg_min_nb = p.reg_min_neighbours; d.reg_min_close = p.reg_min_close_neighbours;
+  d.num_threads = p.num_threads;
+}
+
+template <typename T>
+hipError_t dalloc(T** p, size_t n) { return hipMalloc(reinterpret_cast<void**>(p), (n ? n : 1) * sizeof(T)); }
+
+// compute band of the per-cell stages: the owned rows + a halo of 2 rows for the displaced-element side
+// effects (+ the regulariser's radius), see DevParams::cband_y0
+void set_compute_band(esvo_context* h) {
+  const int halo = 2 + (h->prm.regularization ? h->prm.reg_radius : 0);
+  h->dp.cband_y0 = std::max(0, h->dp.band_y0 - halo);
+  h->dp.cband_y1 = std::min(h->H, h->dp.band_y1 + halo);
+}
+
+}  // namespace esvo_host
+
+// =================================================================================================
+extern "C" {
+
+void esvo_default_params(esvo_params_t* p) {
+  std::memset(p, 0, sizeof(*p));
+  p->decay_ms = 30; p->median_blur_kernel_size = 1; p->ignore_polarity = 1;
+  p->patch_size_x = 25; p->patch_size_y = 25; p->ls_norm = ESVO_LSNORM_TDIST;
+  p->td_nu = 0; p->td_scale = 0; p->lm_max_iteration = 10;
+  p->reg_radius = 5; p->reg_min_neighbours = 8; p->reg_min_close_neighbours = 8;
+  p->bm_min_disparity = 3; p->bm_max_disparity = 40; p->bm_step = 1; p->bm_zncc_threshold = 0.1;
+  p->invdepth_min = 0.16; p->invdepth_max = 2.0; p->stdvar_vis_threshold = 0.005; p->residual_vis_threshold = 15;
+  p->age_vis_threshold = 0; p->fusion_radius = 0; p->fusion_strategy = ESVO_FUSION_CONST_FRAMES;
+  p->max_fusion_frames = 10; p->max_fusion_points = 2000; p->clean_requires_full_window = 1;
+  p->process_event_num = 500; p->bm_half_slice_thickness = 0.001; p->num_threads = 4;
+  p->max_events_per_tick = 1024; p->max_window_points = 20000; p->max_poses_per_tick = 256;
+  p->event_ring_capacity = 1 << 24;
+}
+
+const char* esvo_last_error(esvo_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esvo_calib_t* right, int device,
+                esvo_handle* out) {
+  esvo_context* h = nullptr;
+  if (!params || !left || !right || !out) FAIL(ESVO_ERR_INVALID_ARG, "null argument");
+  if (left->width != right->width || left->height != right->height || left->width <= 0 || left->height <= 0)
+    FAIL(ESVO_ERR_INVALID_ARG, "left/right image sizes differ or are empty");
+  if (!left->rect_lut || !left->map_x || !left->map_y || !right->map_x || !right->map_y)
+    FAIL(ESVO_ERR_INVALID_ARG, "calibration arrays missing");
+  {
+    std::string why;
+    int rc = validate_params(params, why);
+    if (rc) FAIL(rc, why);
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    FAIL(ESVO_ERR_NO_DEVICE, "no HIP device visible: the ESVO hot path has no CPU fallback");
+  if (device < 0 || device >= ndev) FAIL(ESVO_ERR_INVALID_ARG, "device ordinal out of range");
+  HIPCHK(hipSetDevice(device));
+  h = new esvo_context();
+  h->prm = *params;
+  h->device = device;
+  h->W = left->width; h->H = left->height;
+  const size_t npx = (size_t)h->W * h->H;
+  std::memset(&h->stats, 0, sizeof(h->stats));
+  std::memcpy(h->dp.camL.P, left->P, sizeof(double) * 12);
+  std::memcpy(h->dp.camR.P, right->P, sizeof(double) * 12);
+  invert3x3(left->P, h->dp.camL.Kinv, h->dp.camL.Kinv_t);
+  invert3x3(right->P, h->dp.camR.Kinv, h->dp.camR.Kinv_t);
+  {  // CameraSystem::computeBaseline, CameraSystem.cpp:161-166
+    const double* t = h->dp.camR.Kinv_t;
+    h->baseline = std::sqrt((t[0] * t[0] + t[1] * t[1]) + t[2] * t[2]);
+  }
+  h->dp.band_y0 = 0; h->dp.band_y1 = h->H;
+  h->dp.cband_y0 = 0; h->dp.cband_y1 = h->H;
+  h->dp.ev_shard = 0; h->dp.ev_nshards = 1;
+  fill_dev_params(h);
+
+#define CK(call) do { hipError_t _e = (call); if (_e != hipSuccess) { g_create_error = std::string(#call) + ": " + hipGetErrorString(_e); esvo_destroy(h); return ESVO_ERR_HIP; } } while (0)
+  {
+    int prio_lo = 0, prio_hi = 0;  // numerically lower = higher priority
+    CK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+    // The front stage is the critical path of the two-stream pipeline: its stream gets the high priority, the
+    // (latency-bound, gap-filling) back stage the low one: -2 % per tick; the reverse costs +6 %.  ESVO_STREAM_PRIO
+    // = 0 (no priorities) / 2 (reversed) exist for that A/B.
+    const char* pe = std::getenv("ESVO_STREAM_PRIO");
+    const int mode = pe ? std::atoi(pe) : 1;
+    CK(hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, mode == 1 ? prio_hi : (mode == 2 ? prio_lo : 0)));
+    h->own_stream = true;
+    CK(hipStreamCreateWithPriority(&h->stream_b, hipStreamNonBlocking, mode == 1 ? prio_lo : (mode == 2 ? prio_hi : 0)));
+  }
+  CK(hipStreamCreateWithFlags(&h->stream_t, hipStreamNonBlocking));
+  CK(hipStreamCreateWithFlags(&h->stream_i, hipStreamNonBlocking));
+  // calibration -> device
+  CK(dalloc(&h->d_lut, npx));
+  CK(hipMemcpy(h->d_lut, left->rect_lut, sizeof(float2) * npx, hipMemcpyHostToDevice));
+  if (left->rect_mask) {
+    CK(dalloc(&h->d_mask, npx));
+    CK(hipMemcpy(h->d_mask, left->rect_mask, npx, hipMemcpyHostToDevice));
+  }
+  for (int cam = 0; cam < 2; ++cam) {
+    const esvo_calib_t* c = cam ? right : left;
+    std::vector<int2> fm(npx);
+    for (size_t i = 0; i < npx; ++i) {  // OpenCV remap's INTER_BITS=5 coordinate quantisation (Appendix B.2)
+      fm[i].x = (int)std::nearbyintf(c->map_x[i] * 32.f);
+      fm[i].y = (int)std::nearbyintf(c->map_y[i] * 32.f);
+    }
+    CK(dalloc(&h->d_fixmap[cam], npx));
+    CK(hipMemcpy(h->d_fixmap[cam], fm.data(), sizeof(int2) * npx, hipMemcpyHostToDevice));
+    CK(dalloc(&h->d_sae[cam], npx));
+    CK(hipMemset(h->d_sae[cam], 0, sizeof(u64) * npx));
+    CK(dalloc(&h->d_ts[cam], npx + 64));
+    CK(dalloc(&h->d_obs[cam], npx + 64));
+  }
+  CK(dalloc(&h->d_raw, npx + 64));
+  CK(dalloc(&h->d_obs_tmp, npx + 64));
+  h->ring_cap = (u64)std::max<int64_t>(params->event_ring_capacity, 1024);
+  for (int cam = 0; cam < 2; ++cam) CK(dalloc(&h->d_ring[cam], h->ring_cap));
+  CK(dalloc(&h->d_T_world_obs, 16));
+  h->max_poses = (u32)std::max(params->max_poses_per_tick, 2);
+  CK(dalloc(&h->d_pose_sec, h->max_poses));
+  CK(dalloc(&h->d_pose_T2[0], (size_t)h->max_poses * 16));
+  CK(dalloc(&h->d_pose_T2[1], (size_t)h->max_poses * 16));
+  h->d_pose_T = h->d_pose_T2[0];
+  h->max_ev = (u32)std::max(params->max_events_per_tick, params->process_event_num);
+  if (h->max_ev > 4000000u) { g_create_error = "max_events_per_tick too large (scan limit 4M)"; esvo_destroy(h); return ESVO_ERR_CAPACITY; }
+  if (npx > 4000000u) { g_create_error = "image too large (scan limit 4M pixels)"; esvo_destroy(h); return ESVO_ERR_CAPACITY; }
+  const size_t E = h->max_ev;
+  CK(dalloc(&h->d_tick_ev, E));
+  CK(dalloc(&h->d_match_slots, E));
+  CK(dalloc(&h->d_match_flags, E));
+  CK(dalloc(&h->d_match_prefix, E));
+  CK(dalloc(&h->d_matches, E));
+  CK(dalloc(&h->d_pt_slots, E));
+  CK(dalloc(&h->d_pt_flags, E));
+  CK(dalloc(&h->d_pt_prefix, E));
+  CK(dalloc(&h->d_pts_tmp, E));
+  CK(dalloc(&h->d_stage[0], E));
+  CK(dalloc(&h->d_stage[1], E));
+  CK(dalloc(&h->d_counters, 16));
+  CK(hipMemset(h->d_counters, 0, sizeof(u32) * 16));
+  CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_counters), sizeof(u32) * 16 * 2));
+  std::memset(h->h_counters, 0, sizeof(u32) * 16 * 2);
+  CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_pin), sizeof(double) * 2 * ((size_t)h->max_poses * 17 + 16)));
+  CK(dalloc(&h->d_scan_tmp, scan_scratch_elems(std::max(E, npx)) + 8));
+  CK(dalloc(&h->d_scan_tmp_b, scan_scratch_elems(std::max(E, npx)) + 8));
+  CK(dalloc(&h->d_cnt_b, 8));
+  CK(hipMemset(h->d_cnt_b, 0, sizeof(u32) * 8));
+  CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_cnt_b), sizeof(u32) * 8 * 3));
+  std::memset(h->h_cnt_b, 0, sizeof(u32) * 8 * 3);
+  // fusion window
+  h->win_cap = (u32)std::max<int64_t>((int64_t)params->max_window_points, (int64_t)E) + 2 * (u32)E;
+  CK(dalloc(&h->d_win, h->win_cap));
+  h->max_frames = (u32)std::max(params->max_fusion_frames + 2, 512);
+  h->n_pose_slots = h->max_frames + 1;
+  h->slot_used.assign(h->n_pose_slots, 0);
+  CK(dalloc(&h->d_frame_pose_T, (size_t)h->n_pose_slots * h->max_poses * 16));
+  CK(dalloc(&h->d_fr_table, 2 * (3 * (size_t)h->max_frames + 1)));
+  CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_fr_table), sizeof(u32) * 2 * (3 * (size_t)h->max_frames + 1)));
+  // map
+  CK(dalloc(&h->d_prop, h->win_cap));
+  CK(dalloc(&h->d_cell_count, npx));
+  CK(dalloc(&h->d_cell_offset, npx));
+  CK(dalloc(&h->d_cell_fill, npx));
+  CK(dalloc(&h->d_rec_ids, (size_t)h->win_cap * 9));
+  CK(dalloc(&h->d_map, npx));
+  CK(dalloc(&h->d_map2, npx));
+  CK(hipMemset(h->d_map, 0, sizeof(MapCell) * npx));
+  CK(hipMemset(h->d_map2, 0, sizeof(MapCell) * npx));
+  h->d_map_cur = h->d_map;
+  CK(dalloc(&h->d_owner_max, npx));
+  CK(dalloc(&h->d_owner_min, npx));
+  CK(dalloc(&h->d_bucket, 3 * 128));
+  CK(dalloc(&h->d_own_w, E));
+  CK(dalloc(&h->d_lkeep, E));
+  h->codes_bytes = (E + 7) / 8 * 8;
+  CK(dalloc(&h->d_codes, h->codes_bytes));
+  CK(dalloc(&h->d_sel, E));
+  CK(dalloc(&h->d_evmap, npx + 64));
+  CK(dalloc(&h->d_reg_valid, npx / 64 + 8));
+  CK(hipMemset(h->d_reg_valid, 0, sizeof(u64) * (npx / 64 + 8)));
+  CK(dalloc(&h->d_cell_list, npx));
+  {
+    h->reg_words = (u32)(2 * std::max(params->reg_radius, 1) + 1);  // one mask per tap row and element
+    CK(dalloc(&h->d_reg_bits, npx * (size_t)h->reg_words));
+    CK(dalloc(&h->d_reg_counts, 2 * npx));
+  }
+  CK(dalloc(&h->d_reg_ab, npx));
+  CK(dalloc(&h->d_reg_cd, npx));
+  CK(dalloc(&h->d_exp_flags, npx));
+  CK(dalloc(&h->d_exp_prefix, npx));
+  CK(dalloc(&h->d_export, npx));
+  CK(dalloc(&h->d_export_cell, npx));
+  for (int i = 0; i < EV_N; ++i) CK(hipEventCreate(&h->evt[i]));
+  h->evt_ok = true;
+  CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_pose_pool), sizeof(double) * 16 * (size_t)h->max_poses * esvo_context::POSE_POOL));
+  for (int i = 0; i < esvo_context::POSE_POOL; ++i) CK(hipEventCreate(&h->pool_evt[i]));
+  h->pool_ok = true;
+  for (int i = 0; i < 16; ++i) h->T_world_obs[i] = h->T_world_frame[i] = (i % 5 == 0) ? 1.0 : 0.0;
+  CK(hipMemcpy(h->d_T_world_obs, h->T_world_obs, sizeof(double) * 16, hipMemcpyHostToDevice));
+#undef CK
+  *out = h;
+  return ESVO_OK;
+}
+
+int esvo_destroy(esvo_handle h) {
+  if (!h) return ESVO_OK;
+  hipSetDevice(h->device);
+  if (h->stream) hipStreamSynchronize(h->stream);
+  if (h->stream_b) hipStreamSynchronize(h->stream_b);
+  void* ptrs[] = {h->d_lut, h->d_mask, h->d_fixmap[0], h->d_fixmap[1], h->d_sae[0], h->d_sae[1], h->d_raw, h->d_ts[0],
+                  h->d_ts[1], h->d_ring[0], h->d_ring[1], h->d_obs[0], h->d_obs[1], h->d_obs_tmp, h->d_T_world_obs,
+                  h->d_pose_sec, h->d_pose_T2[0], h->d_pose_T2[1], h->d_scan_tmp_b, h->d_cnt_b, h->d_tick_ev, h->d_match_slots, h->d_match_flags, h->d_match_prefix,
+                  h->d_matches, h->d_pt_slots, h->d_pt_flags, h->d_pt_prefix, h->d_pts_tmp, h->d_stage[0], h->d_stage[1], h->d_counters, h->d_scan_tmp,
+                  h->d_win, h->d_frame_pose_T, h->d_fr_table, h->d_prop, h->d_cell_count, h->d_cell_offset,
+                  h->d_cell_fill, h->d_rec_ids, h->d_map, h->d_map2, h->d_owner_max, h->d_owner_min, h->d_exp_flags,
+                  h->d_exp_prefix, h->d_export, h->d_export_cell, h->d_reg_bits, h->d_reg_ab, h->d_reg_cd, h->d_bucket, h->d_cell_list, h->d_own_w, h->d_lkeep, h->d_codes,
+                  h->d_reg_valid, h->d_reg_counts, h->d_sel, h->d_evmap};
+  for (void* p : ptrs) if (p) hipFree(p);
+  if (h->h_counters) hipHostFree(h->h_counters);
+  if (h->h_cnt_b) hipHostFree(h->h_cnt_b);
+  if (h->h_pin) hipHostFree(h->h_pin);
+  if (h->h_fr_table) hipHostFree(h->h_fr_table);
+  if (h->evt_ok) for (int i = 0; i < EV_N; ++i) hipEventDestroy(h->evt[i]);
+  if (h->pool_ok) for (int i = 0; i < esvo_context::POSE_POOL; ++i) hipEventDestroy(h->pool_evt[i]);
+  if (h->h_pose_pool) hipHostFree(h->h_pose_pool);
+  if (h->d_wire) hipFree(h->d_wire);
+  if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+  if (h->stream_b) hipStreamDestroy(h->stream_b);
+  if (h->stream_t) { hipStreamSynchronize(h->stream_t); hipStreamDestroy(h->stream_t); }
+  if (h->stream_i) { hipStreamSynchronize(h->stream_i); hipStreamDestroy(h->stream_i); }
+  for (void* q : {(void*)h->d_trk_blur, (void*)h->d_trk_neg, (void*)h->d_trk_du, (void*)h->d_trk_dv, (void*)h->d_trk_xyz, (void*)h->d_trk_pts,
+                  (void*)h->d_trk_out})
+    if (q) hipFree(q);
+  delete h;
+  return ESVO_OK;
+}
+
+int esvo_reset(esvo_handle h) {
+  if (!h) return ESVO_ERR_INVALID_ARG;
+  HIPCHK(hipSetDevice(h->device));
+  { int rcp = flush_pending_tick(h); if (rcp) return rcp; }
+  const size_t npx = (size_t)h->W * h->H;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream_b));
+  for (int cam = 0; cam < 2; ++cam) {
+    HIPCHK(hipMemsetAsync(h->d_sae[cam], 0, sizeof(u64) * npx, h->stream));
+    h->ts_host[cam].clear();
+    h->ring_base[cam] = h->ring_next[cam] = h->scattered[cam] = 0;
+    h->ts_valid[cam] = false;
+  }
+  h->frames.clear();
+  std::fill(h->slot_used.begin(), h->slot_used.end(), 0);
+  HIPCHK(hipMemsetAsync(h->d_map, 0, sizeof(MapCell) * npx, h->stream));
+  HIPCHK(hipMemsetAsync(h->d_map2, 0, sizeof(MapCell) * npx, h->stream));
+  h->d_map_cur = h->d_map;
+  h->obs_set = false;
+  h->n_pose = 0;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream_b));
+  h->back_pending[0] = h->back_pending[1] = false;
+  h->committed_t_ns = 0;
+  h->ts_timing_pending[0] = h->ts_timing_pending[1] = false;
+  h->stats_pending = false;
+  std::memset(&h->stats, 0, sizeof(h->stats));
+  return ESVO_OK;
+}
+
+int esvo_set_params(esvo_handle h, const esvo_params_t* params) {
+  if (!h || !params) return ESVO_ERR_INVALID_ARG;
+  { int rcp = flush_pending_tick(h); if (rcp) return rcp; }
+  std::string why;
+  int rc = validate_params(params, why);
+  if (rc) FAIL(rc, why);
+  if ((u32)std::max(params->max_events_per_tick, params->process_event_num) > h->max_ev)
+    FAIL(ESVO_ERR_CAPACITY, "process_event_num exceeds the capacity fixed at esvo_create");
+  {
+    if ((u32)(2 * std::max(params->reg_radius, 1) + 1) > h->reg_words) FAIL(ESVO_ERR_CAPACITY, "RegularizationRadius exceeds the capacity fixed at esvo_create");
+  }
+  esvo_params_t np = *params;
+  np.max_events_per_tick = h->prm.max_events_per_tick;
+  np.max_window_points = h->prm.max_window_points;
+  np.max_poses_per_tick = h->prm.max_poses_per_tick;
+  np.event_ring_capacity = h->prm.event_ring_capacity;
+  h->prm = np;
+  fill_dev_params(h);
+  set_compute_band(h);
+  return ESVO_OK;
+}
+
+int esvo_set_stream(esvo_handle h, void* hip_stream) {
+  if (!h) return ESVO_ERR_INVALID_ARG;
+  { int rcp = flush_pending_tick(h); if (rcp) return rcp; }
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream_b));
+  if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+  h->stream = reinterpret_cast<hipStream_t>(hip_stream);
+  h->own_stream = false;
+  return ESVO_OK;
+}
+
+int esvo_synchronize(esvo_handle h) {
+  if (!h) return ESVO_ERR_INVALID_ARG;
+  { int rcp = flush_pending_tick(h); if (rcp) return rcp; }
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream_b));
+  return ESVO_OK;
+}
+
+}  // extern "C"
+
+// sizeof() of every POD of the ABI (binding self-check)
+extern "C" void esvo_abi_sizes(size_t out[8]) {
+  out[0] = sizeof(esvo_event_t); out[1] = sizeof(esvo_calib_t); out[2] = sizeof(esvo_params_t);
+  out[3] = sizeof(esvo_match_t); out[4] = sizeof(esvo_depth_point_t); out[5] = sizeof(esvo_stats_t);
+  out[6] = 0; out[7] = ESVO_HIP_ABI_VERSION;
+}
+
+// ---- device self-test: div_by(a, make_recip(b)) == a / b and sqrt_moderate(x) == sqrt(x), bit for bit ----------
+#include "fdiv.hpp"
+namespace {
+__device__ inline unsigned long long sm64(unsigned long long& s) {
+  unsigned long long z = (s += 0x9e3779b97f4a7c15ull);
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  return z ^ (z >> 31);
+}
+__global__ void selftest_div_kernel(unsigned long long n_per_thread, unsigned long long seed, unsigned long long* mismatches) {
+  unsigned long long s = seed + 0x1234567ull * (blockIdx.x * blockDim.x + threadIdx.x + 1);
+  unsigned long long bad = 0;
+  for (unsigned long long i = 0; i < n_per_thread; ++i) {
+    const unsigned long long ra = sm64(s), rb = sm64(s);
+    // mantissas random; exponents: mostly moderate, sometimes extreme / zero / denormal
+    const int mode = (int)(sm64(s) & 15);
+    int ea = (int)(ra % 600) - 300 + 1023, eb = (int)(rb % 600) - 300 + 1023;
+    if (mode == 0) ea = (int)(ra % 2046) + 1;
+    if (mode == 1) eb = (int)(rb % 2046) + 1;
+    if (mode == 2) ea = 0;
+    if (mode == 3) eb = 0;
+    unsigned long long ba = ((unsigned long long)ea << 52) | (ra >> 12);
+    unsigned long long bb = ((unsigned long long)eb << 52) | (rb >> 12);
+    if (mode == 4) ba = 0;  // a == 0
+    if (mode == 5) ba |= 1ull << 63;
+    if (mode == 6) bb |= 1ull << 63;
+    const double a = __longlong_as_double((long long)ba), b = __longlong_as_double((long long)bb);
+    const double q_ref = a / b;
+    const double q = esvo::div_by(a, esvo::make_recip(b));
+    const bool same = (__double_as_longlong(q) == __double_as_longlong(q_ref)) || (q != q && q_ref != q_ref);
+    bad += !same;
+    // sqrt_moderate(x) == sqrt(x) for x in [2^-700, 2^700]
+    const int es = (int)(sm64(s) % 1400) - 700 + 1023;
+    const double xs = __longlong_as_double((long long)(((unsigned long long)es << 52) | (ra >> 12)));
+    bad += __double_as_longlong(esvo::sqrt_moderate(xs)) != __double_as_longlong(sqrt(xs));
+  }
+  if (bad) atomicAdd(mismatches, bad);
+}
+}  // namespace
+extern "C" int esvo_selftest_division(unsigned long long n, unsigned long long seed, unsigned long long* mismatches) {
+  esvo_context* h = nullptr;
+  unsigned long long* d = nullptr;
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(&d), sizeof(unsigned long long)));
+  HIPCHK(hipMemset(d, 0, sizeof(unsigned long long)));
+  const unsigned threads = 256, blocks = 1024;
+  const unsigned long long per = (n + (unsigned long long)threads * blocks - 1) / ((unsigned long long)threads * blocks);
+  hipLaunchKernelGGL(selftest_div_kernel, dim3(blocks), dim3(threads), 0, 0, per, seed, d);
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(mismatches, d, sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  hipFree(d);
+  return ESVO_OK;
+}

@@ -1,0 +1,878 @@
+// api_map.hip — the mapper: stage-wise calls, the fused (lazily completed, two-stream) tick, device-resident stage
+// calls, multi-GPU sharding, outputs and statistics (see context.hpp).
+#include "context.hpp"
+
+namespace {
+
+// lower_bound over the staged time stamps with the reference's toSec() comparison
+// (tools::EventBuffer_lower_bound, utils.h:51-56); returns an absolute index
+u64 lower_bound_sec(const esvo_context* h, int cam, double t) {
+  const auto& v = h->ts_host[cam];
+  size_t lo = 0, hi = v.size();
+  while (lo < hi) {
+    size_t mid = (lo + hi) / 2;
+    if (ns_to_sec(v[mid]) < t) lo = mid + 1; else hi = mid;
+  }
+  return h->ring_base[cam] + lo;
+}
+// ros::Time(double)  (TimeBase::fromSec)
+u64 ros_time_from_sec(double t) {
+  long long sec64 = (long long)std::floor(t);
+  u32 sec = (u32)sec64;
+  u32 nsec = (u32)std::round((t - sec) * 1e9);
+  sec += (nsec / 1000000000ul);
+  nsec %= 1000000000ul;
+  return (u64)sec * 1000000000ull + nsec;
+}
+
+int upload_poses(esvo_context* h, const uint64_t* pose_t_ns, const double* pose_T, size_t m) {
+  if (m > h->max_poses) FAIL(ESVO_ERR_CAPACITY, "pose table larger than max_poses_per_tick");
+  // staged through pinned memory (two alternating slots): no host synchronisation on the tick path
+  h->pin_slot ^= 1;
+  double* pin = h->h_pin + (size_t)h->pin_slot * ((size_t)h->max_poses * 17 + 16);
+  double* sec = pin;
+  double* T = pin + h->max_poses;
+  for (size_t i = 0; i < m; ++i) sec[i] = ns_to_sec(pose_t_ns[i]);
+  std::memcpy(T, pose_T, sizeof(double) * 16 * m);
+  h->h_pose_T.assign(pose_T, pose_T + 16 * m);
+  h->n_pose = (u32)m;
+  // the back stage copies the previous table of this buffer into its frame slot: not before that is done
+  h->pose_buf ^= 1;
+  h->d_pose_T = h->d_pose_T2[h->pose_buf];
+  HIPCHK(hipStreamWaitEvent(h->stream, h->evt[EV_POSE + h->pose_buf * EV_BACK_STRIDE], 0));
+  if (m) {
+    HIPCHK(hipMemcpyAsync(h->d_pose_sec, sec, sizeof(double) * m, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_pose_T, T, sizeof(double) * 16 * m, hipMemcpyHostToDevice, h->stream));
+  }
+  return ESVO_OK;
+}
+
+// BM over n events starting at absolute ring index `first` (reverse walk) or over d_tick_ev:
+// flags + match records in slot (thread-stride) order
+int run_bm(esvo_context* h, const esvo_event_t* d_ev, u64 first, u64 cap, int reverse, u32 n, const u32* sel = nullptr) {
+  BmArgs a;
+  a.ev = d_ev; a.n = n; a.ev_first = first; a.ev_cap = cap; a.ev_reverse = reverse; a.sel = sel;
+  a.tsL = h->d_obs[0]; a.tsR = h->d_obs[1];
+  a.lut = h->d_lut; a.mask = h->d_mask;
+  a.pose_sec = h->d_pose_sec; a.n_pose = h->n_pose;
+  a.out_slots = h->d_match_slots; a.out_flags = h->d_match_flags;
+  hipEventRecord(h->evt[EV_BM0 + h->fpar * EV_FRONT_STRIDE], h->stream);
+  launch_bm_match(a, h->dp, h->stream);
+  hipEventRecord(h->evt[EV_BM1 + h->fpar * EV_FRONT_STRIDE], h->stream);
+  HIPCHK(hipGetLastError());
+  return ESVO_OK;
+}
+// stable compaction of the match slots into vEMP order.  Sharded mode: the flags are this rank's own
+// ones, the list is its dense local list (count -> counters[8]) and slot_of remembers each entry's slot.
+int run_order_matches(esvo_context* h, u32 n, bool local) {
+  launch_exclusive_scan_u32(h->d_match_flags, h->d_match_prefix, h->d_counters + (local ? 8 : 0), h->d_scan_tmp, n, h->stream);
+  launch_compact_matches(h->d_match_slots, h->d_match_flags, h->d_match_prefix, n, h->d_matches, local ? h->d_own_w : nullptr,
+                         h->stream);
+  hipEventRecord(h->evt[EV_S1 + h->fpar * EV_FRONT_STRIDE], h->stream);
+  HIPCHK(hipGetLastError());
+  return ESVO_OK;
+}
+int run_match(esvo_context* h, const esvo_event_t* d_ev, u64 first, u64 cap, int reverse, u32 n) {
+  int rc = run_bm(h, d_ev, first, cap, reverse, n);
+  if (rc) return rc;
+  return run_order_matches(h, n, false);
+}
+
+// LM (+cull) over the compacted matches: point records + flags in solver-slot order (dense: in list order)
+int run_lm(esvo_context* h, u32 max_matches, int cull, bool dense) {
+  u32* flags = dense ? h->d_lkeep : h->d_pt_flags;  // the kernel writes every flag of its launch range
+  LmArgs a;
+  a.matches = h->d_matches; a.n_matches = h->d_counters + (dense ? 8 : 0); a.max_matches = max_matches;
+  a.tsL = h->d_obs[0]; a.tsR = h->d_obs[1];
+  a.pose_T = h->d_pose_T; a.T_world_obs = h->d_T_world_obs;
+  a.out_slots = h->d_pt_slots; a.out_flags = flags; a.cull = cull; a.dense = dense ? 1 : 0;
+  hipEventRecord(h->evt[EV_LM0 + h->fpar * EV_FRONT_STRIDE], h->stream);
+  launch_lm_refine(a, h->dp, h->d_counters + 2, h->stream);
+  hipEventRecord(h->evt[EV_LM1 + h->fpar * EV_FRONT_STRIDE], h->stream);
+  HIPCHK(hipGetLastError());
+  return ESVO_OK;
+}
+// stable compaction of the solver slots: the culled points go to `dst` in the reference's order
+int run_order_points(esvo_context* h, u32 max_matches, DevPoint* dst) {
+  launch_exclusive_scan_u32(h->d_pt_flags, h->d_pt_prefix, h->d_counters + 1, h->d_scan_tmp, max_matches, h->stream);
+  launch_compact_points(h->d_pt_slots, h->d_pt_flags, h->d_pt_prefix, h->d_counters + 0, max_matches, dst, h->stream);
+  hipEventRecord(h->evt[EV_S2 + h->fpar * EV_FRONT_STRIDE], h->stream);
+  HIPCHK(hipGetLastError());
+  return ESVO_OK;
+}
+int run_refine(esvo_context* h, u32 max_matches, int cull, DevPoint* dst) {
+  HIPCHK(hipMemsetAsync(h->d_counters + 2, 0, sizeof(u32), h->stream));  // n_solved (a tick zeroes all counters at once)
+  int rc = run_lm(h, max_matches, cull, false);
+  if (rc) return rc;
+  return run_order_points(h, max_matches, dst);
+}
+
+int read_counters(esvo_context* h) {
+  HIPCHK(hipMemcpyAsync(h->h_counters, h->d_counters, sizeof(u32) * 16, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return ESVO_OK;
+}
+// back-stage counters into row `row` of the pinned table (0/1: the tick parities, 2: exports)
+int read_counters_b(esvo_context* h, int row, bool sync) {
+  HIPCHK(hipMemcpyAsync(h->h_cnt_b + 8 * row, h->d_cnt_b, sizeof(u32) * 8, hipMemcpyDeviceToHost, h->stream_b));
+  if (sync) HIPCHK(hipStreamSynchronize(h->stream_b));
+  return ESVO_OK;
+}
+// the back stage starts when everything enqueued on the front stream so far is done
+int back_after_front(esvo_context* h) {
+  HIPCHK(hipEventRecord(h->evt[EV_FRAME], h->stream));
+  HIPCHK(hipStreamWaitEvent(h->stream_b, h->evt[EV_FRAME], 0));
+  return ESVO_OK;
+}
+// timings and counters of a finished back stage
+void collect_back(esvo_context* h, int par) {
+  if (!h->back_pending[par]) return;
+  h->back_pending[par] = false;
+  const int o = par * EV_BACK_STRIDE;
+  esvo_stats_t& s = h->stats;
+  s.last_fusions = h->h_cnt_b[8 * par + 3];
+  if (h->prm.regularization) s.last_map_size = h->h_cnt_b[8 * par + 7];  // alive cells of the band (exports refresh it)
+  float fu = 0, cl = 0, rg = 0;
+  hipEventElapsedTime(&fu, h->evt[EV_FU0 + o], h->evt[EV_FU1 + o]);
+  hipEventElapsedTime(&cl, h->evt[EV_FU1 + o], h->evt[EV_CL1 + o]);
+  hipEventElapsedTime(&rg, h->evt[EV_CL1 + o], h->evt[EV_RG1 + o]);
+  s.ms_fusion = fu + cl;
+  s.ms_regularization = rg;
+  s.ms_kernel[4] = fu; s.ms_kernel[5] = cl; s.ms_kernel[6] = rg;
+  s.sum_ms_kernel[4] += fu; s.sum_ms_kernel[5] += cl; s.sum_ms_kernel[6] += rg;
+}
+
+// place a frame of n points in the window ring (frames stay contiguous: [oldest frame, newest frame) modulo the wrap)
+int window_reserve(esvo_context* h, u32 n, u32* off_out) {
+  u32 off = 0;
+  if (!h->frames.empty()) {
+    const FrameRec& back = h->frames.back();
+    const FrameRec& front = h->frames.front();
+    const u32 tail = back.off + back.count;
+    if (back.off >= front.off) {  // not wrapped: [front.off, tail)
+      if (tail + n <= h->win_cap) off = tail;
+      else if (n <= front.off) off = 0;
+      else FAIL(ESVO_ERR_CAPACITY, "fusion window ring full (raise max_window_points)");
+    } else {  // wrapped: free space is [tail, front.off)
+      if (tail + n <= front.off) off = tail;
+      else FAIL(ESVO_ERR_CAPACITY, "fusion window ring full (raise max_window_points)");
+    }
+  } else if (n > h->win_cap) {
+    FAIL(ESVO_ERR_CAPACITY, "frame larger than the fusion window ring");
+  }
+  *off_out = off;
+  return ESVO_OK;
+}
+int alloc_pose_slot(esvo_context* h, u32* slot) {
+  for (u32 i = 0; i < h->n_pose_slots; ++i)
+    if (!h->slot_used[i]) { h->slot_used[i] = 1; *slot = i; return ESVO_OK; }
+  FAIL(ESVO_ERR_CAPACITY, "no free pose-table slot (too many frames in the fusion window)");
+}
+void pop_front_frame(esvo_context* h) {
+  h->slot_used[h->frames.front().slot] = 0;
+  h->frames.pop_front();
+}
+// window policy, esvo_Mapping.cpp:341-368
+void apply_window_policy(esvo_context* h) {
+  if (h->prm.fusion_strategy == ESVO_FUSION_CONST_POINTS) {
+    auto total = [&]() { size_t s = 0; for (auto& f : h->frames) s += f.count; return s; };
+    size_t np = total();
+    while ((double)np > 1.5 * (double)h->prm.max_fusion_points) { pop_front_frame(h); np = total(); }
+  } else {
+    while (h->frames.size() > (size_t)h->prm.max_fusion_frames) pop_front_frame(h);
+  }
+}
+
+// pose table of the frame: from the host (stage-wise API) or, in a tick, the front stage's device table
+int commit_frame(esvo_context* h, u32 off, u32 count, const double* pose_T_host, u32 m, int pose_buf = 0) {
+  u32 slot;
+  int rc = alloc_pose_slot(h, &slot);
+  if (rc) return rc;
+  if (m) {
+    double* dst = h->d_frame_pose_T + (size_t)slot * h->max_poses * 16;
+    if (pose_T_host) {  // through a pinned slot: an async copy from pageable memory would stall the host behind the stream
+      const int ps = h->pool_next;
+      h->pool_next = (ps + 1) % esvo_context::POSE_POOL;
+      HIPCHK(hipEventSynchronize(h->pool_evt[ps]));
+      double* pin = h->h_pose_pool + (size_t)ps * h->max_poses * 16;
+      std::memcpy(pin, pose_T_host, sizeof(double) * 16 * m);
+      HIPCHK(hipMemcpyAsync(dst, pin, sizeof(double) * 16 * m, hipMemcpyHostToDevice, h->stream_b));
+      HIPCHK(hipEventRecord(h->pool_evt[ps], h->stream_b));
+    } else {
+      HIPCHK(hipMemcpyAsync(dst, h->d_pose_T2[pose_buf], sizeof(double) * 16 * m, hipMemcpyDeviceToDevice, h->stream_b));
+      HIPCHK(hipEventRecord(h->evt[EV_POSE + pose_buf * EV_BACK_STRIDE], h->stream_b));
+    }
+  }
+  h->frames.push_back(FrameRec{off, count, slot});
+  apply_window_policy(h);
+  if (h->frames.size() > h->max_frames) FAIL(ESVO_ERR_CAPACITY, "too many frames in the fusion window");
+  return ESVO_OK;
+}
+
+// fusion loop + clean + regularisation on the current window, on the back stream; `par` selects the
+// pinned frame table and the event set (two ticks may be in flight)
+int run_fuse(esvo_context* h, int par, const double* T_world_obs) {
+  // frames newest -> oldest (esvo_Mapping.cpp:372-377)
+  const u32 nf = (u32)h->frames.size();
+  const size_t tab = 3 * (size_t)h->max_frames + 1;
+  u32* cum = h->h_fr_table + (size_t)par * tab;
+  u32* off = cum + (h->max_frames + 1);
+  u32* slot = off + h->max_frames;
+  u32 total = 0;
+  for (u32 i = 0; i < nf; ++i) {
+    const FrameRec& f = h->frames[nf - 1 - i];
+    cum[i] = total; off[i] = f.off; slot[i] = f.slot;
+    total += f.count;
+  }
+  cum[nf] = total;
+  hipStream_t sb = h->stream_b;
+  u32* dtab = h->d_fr_table + (size_t)par * tab;
+  HIPCHK(hipMemcpyAsync(dtab, cum, sizeof(u32) * tab, hipMemcpyHostToDevice, sb));
+  std::memcpy(h->T_world_frame, T_world_obs, sizeof(double) * 16);  // new DepthFrame at the TS pose (:268-272)
+  FuseArgs a;
+  a.win = h->d_win;
+  a.fr_cum = dtab; a.fr_off = dtab + (h->max_frames + 1); a.fr_slot = a.fr_off + h->max_frames;
+  a.n_frames = nf; a.n_pts = total;
+  a.frame_pose_T = h->d_frame_pose_T; a.max_poses = h->max_poses;
+  rigid_inverse(h->T_world_frame, a.T_frame_world);
+  a.prop = h->d_prop;
+  a.cell_count = h->d_cell_count; a.cell_offset = h->d_cell_offset; a.cell_fill = h->d_cell_fill;
+  a.rec_ids = h->d_rec_ids; a.scan_tmp = h->d_scan_tmp_b; a.d_total = h->d_cnt_b + 4;
+  a.map = h->d_map; a.d_num_fusion = h->d_cnt_b + 3;
+  a.bucket = h->d_bucket; a.cell_list = h->d_cell_list; a.n_touched = h->d_cnt_b + 6;
+  a.owner_max = h->prm.regularization ? h->d_owner_max : nullptr;
+  a.owner_min = h->d_owner_min; a.n_reg_elems = h->prm.regularization ? h->d_cnt_b + 7 : nullptr;
+  if (total > h->win_cap) FAIL(ESVO_ERR_CAPACITY, "window points exceed capacity");
+  const int o = par * EV_BACK_STRIDE;
+  hipEventRecord(h->evt[EV_FU0 + o], sb);
+  launch_fuse(a, h->dp, sb);
+  hipEventRecord(h->evt[EV_FU1 + o], sb);
+  h->d_map_cur = h->d_map;
+  const bool do_clean = h->prm.clean_requires_full_window ? (h->frames.size() >= (size_t)h->prm.max_fusion_frames) : true;
+  if (do_clean) launch_clean(h->d_map, h->dp, sb);
+  hipEventRecord(h->evt[EV_CL1 + o], sb);
+  if (h->prm.regularization) {
+    launch_reg_view(h->d_map, h->d_map2, h->d_owner_max, h->d_owner_min, h->d_reg_valid, h->d_reg_ab, h->d_reg_cd,
+                    h->d_cell_list, h->d_cnt_b + 7, h->dp, sb);
+    launch_reg_apply(h->d_map, h->d_map2, h->d_owner_max, h->d_owner_min, h->d_reg_valid, h->d_reg_bits, h->d_reg_counts,
+                     h->d_reg_ab, h->d_reg_cd, h->d_cell_list, h->d_cnt_b + 7,
+                     (u32)((size_t)(h->dp.band_y1 - h->dp.band_y0) * h->W), h->dp, sb);
+    h->d_map_cur = h->d_map2;
+  }
+  HIPCHK(hipMemcpyAsync(h->h_cnt_b + 8 * par, h->d_cnt_b, sizeof(u32) * 8, hipMemcpyDeviceToHost, sb));
+  hipEventRecord(h->evt[EV_RG1 + o], sb);  // also "back stage of this parity done"
+  HIPCHK(hipGetLastError());
+  h->back_pending[par] = true;
+  return ESVO_OK;
+}
+
+int export_map(esvo_context* h, std::vector<esvo_depth_point_t>& out, std::vector<u32>* cells) {
+  launch_map_compact(h->d_map_cur, h->d_exp_flags, h->d_exp_prefix, h->d_cnt_b + 5, h->d_scan_tmp_b, h->d_export,
+                     h->d_export_cell, h->dp, h->stream_b);
+  int rc = read_counters_b(h, 2, true);
+  if (rc) return rc;
+  const u32 n = h->h_cnt_b[8 * 2 + 5];
+  out.resize(n);
+  std::vector<u32> cell(n);
+  if (n) {
+    HIPCHK(hipMemcpy(out.data(), h->d_export, sizeof(esvo_depth_point_t) * n, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(cell.data(), h->d_export_cell, sizeof(u32) * n, hipMemcpyDeviceToHost));
+  }
+  // the reference iterates its element list in creation order
+  std::vector<u32> order(n);
+  for (u32 i = 0; i < n; ++i) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](u32 a, u32 b) { return out[a].seq < out[b].seq; });
+  std::vector<esvo_depth_point_t> sorted(n);
+  if (cells) cells->resize(n);
+  for (u32 i = 0; i < n; ++i) {
+    sorted[i] = out[order[i]];
+    if (!h->sharded) sorted[i].seq = i;  // sharded: keep the global creation id so that bands can be merged
+    if (cells) (*cells)[i] = cell[order[i]];
+  }
+  out.swap(sorted);
+  h->stats.last_map_size = n;
+  return ESVO_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+// ---- Mapper: stage-wise ---------------------------------------------------------------------------
+int esvo_map_set_observation(esvo_handle h, uint64_t t_ns, const uint8_t* ts_left, const uint8_t* ts_right,
+                             const double T_world_cam[16]) {
+  if (!h || !T_world_cam) return ESVO_ERR_INVALID_ARG;
+  HIPCHK(hipSetDevice(h->device));
+  const size_t npx = (size_t)h->W * h->H;
+  const uint8_t* src[2] = {ts_left, ts_right};
+  for (int cam = 0; cam < 2; ++cam) {
+    uint8_t* dst = h->prm.smooth_time_surface ? h->d_obs_tmp : h->d_obs[cam];
+    if (src[cam]) {
+      HIPCHK(hipMemcpyAsync(dst, src[cam], npx, hipMemcpyHostToDevice, h->stream));
+      HIPCHK(hipStreamSynchronize(h->stream));
+    } else {
+      if (!h->ts_valid[cam]) FAIL(ESVO_ERR_STATE, "no device-resident Time Surface: call esvo_ts_render first");
+      HIPCHK(hipMemcpyAsync(dst, h->d_ts[cam], npx, hipMemcpyDeviceToDevice, h->stream));
+    }
+    // createMatchProblem applies GaussianBlurTS(5) when SmoothTimeSurface (EventBM.cpp:68-72)
+    if (h->prm.smooth_time_surface) launch_gaussian5(h->d_obs_tmp, h->d_obs[cam], h->W, h->H, h->stream);
+  }
+  std::memcpy(h->T_world_obs, T_world_cam, sizeof(double) * 16);
+  {
+    double* pinT = h->h_pin + (size_t)(h->pin_slot ^ 1) * ((size_t)h->max_poses * 17 + 16) + (size_t)h->max_poses * 17;
+    std::memcpy(pinT, T_world_cam, sizeof(double) * 16);
+    HIPCHK(hipMemcpyAsync(h->d_T_world_obs, pinT, sizeof(double) * 16, hipMemcpyHostToDevice, h->stream));
+  }
+  h->obs_t_ns = t_ns;
+  h->obs_set = true;
+  return ESVO_OK;
+}
+
+int esvo_map_set_poses(esvo_handle h, const uint64_t* pose_t_ns, const double* pose_T, size_t m) {
+  if (!h || (m && (!pose_t_ns || !pose_T))) return ESVO_ERR_INVALID_ARG;
+  HIPCHK(hipSetDevice(h->device));
+  return upload_poses(h, pose_t_ns, pose_T, m);
+}
+
+int esvo_map_match(esvo_handle h, const esvo_event_t* ev, size_t n, const uint64_t* pose_t_ns, const double* pose_T,
+                   size_t m, esvo_match_t* out, size_t cap, size_t* n_out) {
+  if (!h || (n && !ev) || !n_out) return ESVO_ERR_INVALID_ARG;
+  if (!h->obs_set) FAIL(ESVO_ERR_STATE, "esvo_map_set_observation has not been called");
+  if (n > h->max_ev) FAIL(ESVO_ERR_CAPACITY, "more events than max_events_per_tick");
+  HIPCHK(hipSetDevice(h->device));
+  { int rcp = flush_pending_tick(h); if (rcp) return rcp; }
+  if (pose_t_ns) { int rc = upload_poses(h, pose_t_ns, pose_T, m); if (rc) return rc; }
+  *n_out = 0;
+  if (n == 0) { HIPCHK(hipMemsetAsync(h->d_counters, 0, sizeof(u32), h->stream)); return ESVO_OK; }
+  HIPCHK(hipMemcpyAsync(h->d_tick_ev, ev, sizeof(esvo_event_t) * n, hipMemcpyHostToDevice, h->stream));
+  int rc = run_match(h, h->d_tick_ev, 0, (u64)h->max_ev, 0, (u32)n);
+  if (rc) return rc;
+  rc = read_counters(h);
+  if (rc) return rc;
+  const u32 nm = h->h_counters[0];
+  *n_out = nm;
+  h->stats.last_events_in = (u32)n;
+  h->stats.last_matches = nm;
+  if (out && nm) {
+    if (nm > cap) FAIL(ESVO_ERR_CAPACITY, "output array too small for the matches");
+    HIPCHK(hipMemcpy(out, h->d_matches, sizeof(esvo_match_t) * nm, hipMemcpyDeviceToHost));
+  }
+  return ESVO_OK;
+}
+
+int esvo_map_refine(esvo_handle h, const esvo_match_t* matches, size_t n, int cull, esvo_depth_point_t* out, size_t cap,
+                    size_t* n_out) {
+  if (!h || (n && !matches) || !n_out) return ESVO_ERR_INVALID_ARG;
+  if (!h->obs_set) FAIL(ESVO_ERR_STATE, "esvo_map_set_observation has not been called");
+  if (n > h->max_ev) FAIL(ESVO_ERR_CAPACITY, "more matches than max_events_per_tick");
+  for (size_t i = 0; i < n; ++i)
+    if (matches[i].pose_idx >= h->n_pose) FAIL(ESVO_ERR_INVALID_ARG, "match refers to a pose outside the pose table");
+  HIPCHK(hipSetDevice(h->device));
+  { int rcp = flush_pending_tick(h); if (rcp) return rcp; }
+  *n_out = 0;
+  if (n == 0) return ESVO_OK;
+  const u32 n32 = (u32)n;
+  HIPCHK(hipMemcpyAsync(h->d_matches, matches, sizeof(esvo_match_t) * n, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->d_counters, &n32, sizeof(u32), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  int rc = run_refine(h, n32, cull, h->d_pts_tmp);
+  if (rc) return rc;
+  rc = read_counters(h);
+  if (rc) return rc;
+  const u32 np = h->h_counters[1];
+  *n_out = np;
+  h->stats.last_solved = h->h_counters[2];
+  h->stats.last_points = np;
+  if (out && np) {
+    if (np > cap) FAIL(ESVO_ERR_CAPACITY, "output array too small for the depth points");
+    HIPCHK(hipMemcpy(out, h->d_pts_tmp, sizeof(esvo_depth_point_t) * np, hipMemcpyDeviceToHost));
+  }
+  return ESVO_OK;
+}
+
+int esvo_map_push_frame(esvo_handle h, const esvo_depth_point_t* pts, size_t n, const double* pose_T, size_t m) {
+  if (!h || (n && !pts) || (m && !pose_T)) return ESVO_ERR_INVALID_ARG;
+  if (m > h->max_poses) FAIL(ESVO_ERR_CAPACITY, "pose table larger than max_poses_per_tick");
+  for (size_t i = 0; i < n; ++i)
+    if (pts[i].pose_idx >= m) FAIL(ESVO_ERR_INVALID_ARG, "depth point refers to a pose outside the frame's pose table");
+  HIPCHK(hipSetDevice(h->device));
+  { int rcp = flush_pending_tick(h); if (rcp) return rcp; }
+  u32 off;
+  int rc = window_reserve(h, (u32)n, &off);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(h->stream_b));  // the ring space may have been read by a fusion still in flight
+  if (n) HIPCHK(hipMemcpyAsync(h->d_win + off, pts, sizeof(esvo_depth_point_t) * n, hipMemcpyHostToDevice, h->stream));
+  static const double ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  rc = commit_frame(h, off, (u32)n, m ? pose_T : ident, (u32)m);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream_b));
+  return ESVO_OK;
+}
+
+int esvo_map_fuse(esvo_handle h, size_t* n_fusions) {
+  if (!h) return ESVO_ERR_INVALID_ARG;
+  if (!h->obs_set) FAIL(ESVO_ERR_STATE, "esvo_map_set_observation has not been called");
+  HIPCHK(hipSetDevice(h->device));
+  { int rcp = flush_pending_tick(h); if (rcp) return rcp; }
+  int rc = back_after_front(h);
+  if (rc) return rc;
+  const int par = h->par;
+  h->par ^= 1;
+  HIPCHK(hipEventSynchronize(h->evt[EV_RG1 + par * EV_BACK_STRIDE]));
+  collect_back(h, par);
+  rc = run_fuse(h, par, h->T_world_obs);
+  if (rc) return rc;
+  h->committed_t_ns = h->obs_t_ns;
+  HIPCHK(hipStreamSynchronize(h->stream_b));
+  collect_back(h, par);
+  h->stats.last_window_frames = (u32)h->frames.size();
+  u32 np = 0;
+  for (auto& f : h->frames) np += f.count;
+  h->stats.last_window_points = np;
+  if (n_fusions) *n_fusions = h->stats.last_fusions;
+  return ESVO_OK;
+}
+
+}  // extern "C"
+
+// ---- Mapper: fused tick ---------------------------------------------------------------------------
+namespace esvo_host {
+// event selection, esvo_Mapping.cpp:562-574 (Appendix A-3): walk back from lower_bound(t_end) to
+// lower_bound(t_begin), newest first, at most PROCESS_EVENT_NUM
+int select_events(esvo_context* h, uint64_t t_ns, u64* first_out, u32* n_out) {
+  const double t_end = ns_to_sec(t_ns);
+  const u64 t_begin_ns = ros_time_from_sec(std::max(0.0, t_end - 10 * h->prm.bm_half_slice_thickness));
+  const double t_begin = ns_to_sec(t_begin_ns);
+  u64 it_end = lower_bound_sec(h, 0, t_end);
+  const u64 it_begin = lower_bound_sec(h, 0, t_begin);
+  const u64 staged_end = h->ring_base[0] + h->ts_host[0].size();
+  u64 avail = it_end - it_begin;
+  u64 first = it_end;
+  if (it_end == staged_end && avail > 0) { first = it_end - 1; avail -= 1; }  // end() is skipped (oracle definition)
+  const u32 n = (u32)std::min<u64>(avail, (u64)h->prm.process_event_num);
+  if (n > h->max_ev) FAIL(ESVO_ERR_CAPACITY, "more events than max_events_per_tick");
+  if (n && first - (n - 1) < h->ring_next[0] - std::min<u64>(h->ring_next[0], h->ring_cap))
+    FAIL(ESVO_ERR_STATE, "selected events were already overwritten in the event ring");
+  *first_out = first;
+  *n_out = n;
+  return ESVO_OK;
+}
+
+// phase 0 (front stage): poses, event selection, block matching + LM of the events of this handle's shard
+int tick_phase0(esvo_context* h, uint64_t t_ns, const uint64_t* pose_t_ns, const double* pose_T, size_t m) {
+  int rc = upload_poses(h, pose_t_ns, pose_T, m);
+  if (rc) return rc;
+  u32 n = 0;
+  rc = select_events(h, t_ns, &h->sh_first, &n);
+  if (rc) return rc;
+  h->fpar ^= 1;
+  esvo_context::TickState& tk = h->tk[h->fpar];
+  tk.n = n; tk.off = 0; tk.points = 0; tk.t_ns = t_ns;
+  tk.pose_buf = h->pose_buf; tk.n_pose = h->n_pose;
+  std::memcpy(tk.T_world_obs, h->T_world_obs, sizeof(double) * 16);
+  // two ticks in flight at most: what this tick's front stage overwrites (ring space of popped frames, the pose
+  // table buffer) was last read by the back stage two ticks ago
+  HIPCHK(hipStreamWaitEvent(h->stream, h->evt[EV_RG1 + h->par * EV_BACK_STRIDE], 0));
+  hipEventRecord(h->evt[EV_T0 + h->fpar * EV_FRONT_STRIDE], h->stream);
+  HIPCHK(hipMemsetAsync(h->d_counters, 0, sizeof(u32) * 16, h->stream));
+  const u32* sel = nullptr;
+  if (h->prm.denoising && n) {
+    // Denoising (esvo_Mapping.cpp:282-296): mask from the selected events, keep those on it, in order.
+    // One extra read-back (the kept count sizes the BM launch); only the small DAVIS configs use it.
+    launch_denoise_flags(h->d_ring[0], h->sh_first, h->ring_cap, n, h->d_evmap, h->d_match_flags, h->W, h->H, h->stream);
+    launch_exclusive_scan_u32(h->d_match_flags, h->d_match_prefix, h->d_counters + 5, h->d_scan_tmp, n, h->stream);
+    launch_denoise_select(h->d_match_flags, h->d_match_prefix, n, h->d_sel, h->stream);
+    rc = read_counters(h);
+    if (rc) return rc;
+    n = tk.n = h->h_counters[5];
+    sel = h->d_sel;
+  }
+  h->xchg_ptr = nullptr;
+  h->xchg_bytes = 0;
+  if (n && !h->sharded) {
+    rc = run_bm(h, h->d_ring[0], h->sh_first, h->ring_cap, 1, n, sel);
+    if (rc) return rc;
+    rc = run_order_matches(h, n, false);
+    if (rc) return rc;
+    rc = run_lm(h, n, 1, false);
+    if (rc) return rc;
+  } else if (n) {
+    // own slots only (w % n_shards == shard): BM, dense local list, LM + cull on it, then the (matched, kept)
+    // byte of every own slot; the other ranks' bytes stay zero and arrive with the caller's sum
+    const u32 N = (u32)h->dp.ev_nshards, r = (u32)h->dp.ev_shard;
+    const u32 own = n > r ? (n - r + N - 1) / N : 0;
+    HIPCHK(hipMemsetAsync(h->d_match_flags, 0, sizeof(u32) * n, h->stream));
+    rc = run_bm(h, h->d_ring[0], h->sh_first, h->ring_cap, 1, n, sel);
+    if (rc) return rc;
+    rc = run_order_matches(h, n, true);
+    if (rc) return rc;
+    rc = run_lm(h, own, 1, true);
+    if (rc) return rc;
+    const size_t nb = ((size_t)n + 7) / 8 * 8;
+    HIPCHK(hipMemsetAsync(h->d_codes, 0, nb, h->stream));
+    launch_shard_codes(h->d_own_w, h->d_lkeep, h->d_counters + 8, own, h->d_codes, h->stream);
+    HIPCHK(hipGetLastError());
+    h->xchg_ptr = h->d_codes;
+    h->xchg_bytes = nb;
+  }
+  return ESVO_OK;
+}
+// phase 1a (front stage, enqueue only): the tick's frame (culled points in the reference's order) goes straight
+// into the window ring (capacity for the worst case: n points); the counters follow into the pinned row of the
+// tick's parity and EV_CNT marks "frame and counters ready"
+int tick_phase1_enqueue(esvo_context* h) {
+  esvo_context::TickState& tk = h->tk[h->fpar];
+  const u32 n = tk.n;
+  int rc = ESVO_OK;
+  DevPoint* frame = nullptr;
+  if (h->sharded) {  // committed right away: straight into the ring (worst case n points)
+    rc = window_reserve(h, n, &tk.off);
+    if (rc) return rc;
+    frame = h->d_win + tk.off;
+  }
+  h->xchg_ptr = nullptr;
+  h->xchg_bytes = 0;
+  if (n && !h->sharded) {
+    // the frame waits in the staging buffer of its parity until the tick is committed and its size is known; the
+    // buffer's previous frame (two ticks ago) has been copied into the ring by then
+    HIPCHK(hipStreamWaitEvent(h->stream, h->evt[EV_STG + h->fpar * EV_FRONT_STRIDE], 0));
+    rc = run_order_points(h, n, h->d_stage[h->fpar]);
+    if (rc) return rc;
+  } else if (n) {
+    const u32 N = (u32)h->dp.ev_nshards, r = (u32)h->dp.ev_shard, T = (u32)h->dp.num_threads;
+    const u32 own = n > r ? (n - r + N - 1) / N : 0;
+    launch_shard_match_flags(h->d_codes, n, h->d_match_flags, h->stream);
+    launch_exclusive_scan_u32(h->d_match_flags, h->d_match_prefix, h->d_counters + 0, h->d_scan_tmp, n, h->stream);
+    HIPCHK(hipMemsetAsync(h->d_pt_flags, 0, sizeof(u32) * n, h->stream));
+    launch_shard_keep_flags(h->d_codes, h->d_match_prefix, h->d_counters + 0, n, T, h->d_pt_flags, h->stream);
+    launch_exclusive_scan_u32(h->d_pt_flags, h->d_pt_prefix, h->d_counters + 1, h->d_scan_tmp, n, h->stream);
+    launch_shard_place(h->d_own_w, h->d_lkeep, h->d_pt_slots, h->d_counters + 8, own, h->d_match_prefix, h->d_counters + 0,
+                       h->d_pt_prefix, h->d_counters + 1, T, frame, n, h->stream);
+    hipEventRecord(h->evt[EV_S2 + h->fpar * EV_FRONT_STRIDE], h->stream);
+    HIPCHK(hipGetLastError());
+  }
+  HIPCHK(hipMemcpyAsync(h->h_counters + 16 * h->fpar, h->d_counters, sizeof(u32) * 16, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipEventRecord(h->evt[EV_CNT + h->fpar * EV_FRONT_STRIDE], h->stream));
+  h->tick_pending = true;
+  return ESVO_OK;
+}
+// phase 1b (host): wait for the counters of the tick of parity fp (one small D2H per tick: the window policy
+// needs the point count), book-keeping, front-stage timings
+int tick_phase1_collect(esvo_context* h, int fp) {
+  esvo_context::TickState& tk = h->tk[fp];
+  HIPCHK(hipEventSynchronize(h->evt[EV_CNT + fp * EV_FRONT_STRIDE]));
+  const u32* cnt = h->h_counters + 16 * fp;
+  const u32 n = tk.n;
+  const u32 n_points = n ? cnt[1] : 0;
+  esvo_stats_t& s = h->stats;
+  s.last_events_in = n;
+  s.last_matches = cnt[0];
+  s.last_solved = cnt[2];  // sharded: this rank's share
+  s.last_points = n_points;
+  s.total_events_in += n;
+  s.total_matches += cnt[0];
+  s.total_points += n_points;
+  tk.points = n_points;
+  const int o = fp * EV_FRONT_STRIDE;
+  s.ms_bm = s.ms_refine = 0;
+  s.ms_kernel[2] = s.ms_kernel[3] = 0;
+  if (n) {
+    hipEventElapsedTime(&s.ms_bm, h->evt[EV_T0 + o], h->evt[EV_S1 + o]);
+    hipEventElapsedTime(&s.ms_refine, h->evt[EV_S1 + o], h->evt[EV_S2 + o]);
+    hipEventElapsedTime(&s.ms_kernel[2], h->evt[EV_BM0 + o], h->evt[EV_BM1 + o]);
+    hipEventElapsedTime(&s.ms_kernel[3], h->evt[EV_LM0 + o], h->evt[EV_LM1 + o]);
+    s.sum_ms_kernel[2] += s.ms_kernel[2];
+    s.sum_ms_kernel[3] += s.ms_kernel[3];
+  }
+  if (h->sharded && n_points) {
+    h->xchg_ptr = h->d_win + tk.off;
+    h->xchg_bytes = (size_t)n_points * sizeof(DevPoint);
+  }
+  return ESVO_OK;
+}
+// phase 2 (back stage): window policy, fusion + clean + regularisation of this band (halo rows recomputed locally),
+// enqueued on the back stream behind the frame of the tick of parity fp.  Nothing here waits for the GPU except for
+// the back stage of two ticks ago (long finished), whose pinned table and event set are reused; its timings are
+// collected then.
+int tick_phase2(esvo_context* h, int fp) {
+  esvo_context::TickState& tk = h->tk[fp];
+  h->xchg_ptr = nullptr;
+  h->xchg_bytes = 0;
+  if (h->sharded) {  // the caller's frame sum was issued on the front stream after EV_CNT
+    int rc = back_after_front(h);
+    if (rc) return rc;
+  } else {
+    HIPCHK(hipStreamWaitEvent(h->stream_b, h->evt[EV_CNT + fp * EV_FRONT_STRIDE], 0));
+  }
+  const int par = h->par;
+  h->par ^= 1;
+  HIPCHK(hipEventSynchronize(h->evt[EV_RG1 + par * EV_BACK_STRIDE]));
+  collect_back(h, par);
+  int rc;
+  if (!h->sharded) {  // now that the size is known: exact ring space, frame copied behind the fusion that may still read it
+    rc = window_reserve(h, tk.points, &tk.off);
+    if (rc) return rc;
+    if (tk.points)
+      HIPCHK(hipMemcpyAsync(h->d_win + tk.off, h->d_stage[fp], sizeof(DevPoint) * tk.points, hipMemcpyDeviceToDevice, h->stream_b));
+    HIPCHK(hipEventRecord(h->evt[EV_STG + fp * EV_FRONT_STRIDE], h->stream_b));
+  }
+  rc = commit_frame(h, tk.off, tk.points, nullptr, tk.n_pose, tk.pose_buf);
+  if (rc) return rc;
+  rc = run_fuse(h, par, tk.T_world_obs);
+  if (rc) return rc;
+  h->stats.ticks++;
+  h->stats.last_window_frames = (u32)h->frames.size();
+  u32 np = 0;
+  for (auto& f : h->frames) np += f.count;
+  h->stats.last_window_points = np;
+  h->stats_pending = true;
+  h->tick_pending = false;
+  h->committed_t_ns = tk.t_ns;
+  return ESVO_OK;
+}
+// complete the tick whose front stage is enqueued but which is not committed yet (unsharded ticks are lazy)
+int flush_pending_tick(esvo_context* h) {
+  if (!h->tick_pending || h->sharded) return ESVO_OK;
+  const int fp = h->fpar;
+  h->tick_pending = false;  // also when completing it fails (e.g. window ring full): the error is reported once
+  int rc = tick_phase1_collect(h, fp);
+  if (rc) return rc;
+  return tick_phase2(h, fp);
+}
+// drain the back stream and collect what is pending (older parity first)
+int finalize_tick_stats(esvo_context* h) {
+  int rcf = flush_pending_tick(h);
+  if (rcf) return rcf;
+  if (!h->stats_pending && !h->back_pending[0] && !h->back_pending[1]) return ESVO_OK;
+  const bool tick_done = h->stats_pending;
+  h->stats_pending = false;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream_b));
+  collect_ts_timing(h);
+  collect_back(h, h->par);
+  collect_back(h, h->par ^ 1);
+  if (tick_done) hipEventElapsedTime(&h->stats.ms_tick_total, h->evt[EV_T0 + h->fpar * EV_FRONT_STRIDE], h->evt[EV_RG1 + (h->par ^ 1) * EV_BACK_STRIDE]);
+  return ESVO_OK;
+}
+}  // namespace esvo_host
+
+extern "C" int esvo_map_tick(esvo_handle h, uint64_t t_ns, const uint64_t* pose_t_ns, const double* pose_T, size_t m) {
+  if (!h || !pose_t_ns || !pose_T) return ESVO_ERR_INVALID_ARG;
+  if (!h->obs_set) FAIL(ESVO_ERR_STATE, "esvo_map_set_observation has not been called");
+  if (h->sharded) FAIL(ESVO_ERR_STATE, "handle is sharded: drive it with esvo_shard_tick_phase");
+  HIPCHK(hipSetDevice(h->device));
+  // the previous tick (if still pending) is completed AFTER this tick's front stage is enqueued: its point count
+  // arrived long ago, and the front stream never runs dry while the host works
+  if (h->prm.denoising) {  // its kept-event count is read back inside phase 0: no point in deferring anything
+    int rcp = flush_pending_tick(h);
+    if (rcp) return rcp;
+  }
+  const bool prev = h->tick_pending;
+  const int prev_fp = h->fpar;
+  int rc = tick_phase0(h, t_ns, pose_t_ns, pose_T, m);
+  if (rc) return rc;
+  rc = tick_phase1_enqueue(h);
+  if (rc) return rc;
+  if (prev) {
+    rc = tick_phase1_collect(h, prev_fp);
+    if (!rc) rc = tick_phase2(h, prev_fp);
+    h->tick_pending = true;  // this tick (its front stage is enqueued whatever happened to the previous one)
+    if (rc) return rc;
+  }
+  return ESVO_OK;
+}
+
+// ---- device-resident stage calls: the building blocks of tick-interleaved multi-GPU operation ---------------------
+// (rank r maps the ticks k with k % N == r completely; a tick needs nothing from the previous DepthMaps -- the
+// DepthFrame is rebuilt from the window at every tick, esvo_Mapping.cpp:266-272 -- only the frames of the last
+// ticks, which the ranks all-gather; see esvo_amd/dist.py)
+extern "C" int esvo_map_front(esvo_handle h, uint64_t t_ns, const uint64_t* pose_t_ns, const double* pose_T, size_t m,
+                              size_t* n_points) {
+  if (!h || !pose_t_ns || !pose_T || !n_points) return ESVO_ERR_INVALID_ARG;
+  if (!h->obs_set) FAIL(ESVO_ERR_STATE, "esvo_map_set_observation has not been called");
+  if (h->sharded) FAIL(ESVO_ERR_STATE, "handle is sharded by slot/band: esvo_map_front maps whole ticks");
+  HIPCHK(hipSetDevice(h->device));
+  int rc = flush_pending_tick(h);
+  if (rc) return rc;
+  rc = tick_phase0(h, t_ns, pose_t_ns, pose_T, m);
+  if (rc) return rc;
+  const u32 n = h->tk[h->fpar].n;
+  if (n) { rc = run_order_points(h, n, h->d_pts_tmp); if (rc) return rc; }
+  HIPCHK(hipMemcpyAsync(h->h_counters + 16 * h->fpar, h->d_counters, sizeof(u32) * 16, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipEventRecord(h->evt[EV_CNT + h->fpar * EV_FRONT_STRIDE], h->stream));
+  rc = tick_phase1_collect(h, h->fpar);
+  if (rc) return rc;
+  *n_points = h->tk[h->fpar].points;
+  return ESVO_OK;
+}
+
+extern "C" int esvo_map_front_frame(esvo_handle h, const esvo_depth_point_t** d_frame) {
+  if (!h || !d_frame) return ESVO_ERR_INVALID_ARG;
+  *d_frame = h->d_pts_tmp;
+  return ESVO_OK;
+}
+
+extern "C" int esvo_map_push_frame_device(esvo_handle h, const esvo_depth_point_t* d_pts, size_t n, const double* pose_T,
+                                          size_t m) {
+  if (!h || (n && !d_pts) || (m && !pose_T)) return ESVO_ERR_INVALID_ARG;
+  if (m > h->max_poses) FAIL(ESVO_ERR_CAPACITY, "pose table larger than max_poses_per_tick");
+  HIPCHK(hipSetDevice(h->device));
+  int rc = flush_pending_tick(h);
+  if (rc) return rc;
+  u32 off;
+  rc = window_reserve(h, (u32)n, &off);
+  if (rc) return rc;
+  // the points were produced on the front stream (or by a collective the caller issued there); the copy runs on the
+  // back stream, behind any fusion that still reads ring space freed by earlier pops
+  rc = back_after_front(h);
+  if (rc) return rc;
+  if (n) HIPCHK(hipMemcpyAsync(h->d_win + off, d_pts, sizeof(esvo_depth_point_t) * n, hipMemcpyDeviceToDevice, h->stream_b));
+  static const double ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  return commit_frame(h, off, (u32)n, m ? pose_T : ident, (u32)m);
+}
+
+extern "C" int esvo_map_fuse_async(esvo_handle h) {
+  if (!h) return ESVO_ERR_INVALID_ARG;
+  if (!h->obs_set) FAIL(ESVO_ERR_STATE, "esvo_map_set_observation has not been called");
+  HIPCHK(hipSetDevice(h->device));
+  int rc = flush_pending_tick(h);
+  if (rc) return rc;
+  rc = back_after_front(h);
+  if (rc) return rc;
+  const int par = h->par;
+  h->par ^= 1;
+  HIPCHK(hipEventSynchronize(h->evt[EV_RG1 + par * EV_BACK_STRIDE]));
+  collect_back(h, par);
+  rc = run_fuse(h, par, h->T_world_obs);
+  if (rc) return rc;
+  h->committed_t_ns = h->obs_t_ns;
+  h->stats.ticks++;
+  h->stats.last_window_frames = (u32)h->frames.size();
+  u32 np = 0;
+  for (auto& f : h->frames) np += f.count;
+  h->stats.last_window_points = np;
+  h->stats_pending = true;
+  return ESVO_OK;
+}
+
+extern "C" int esvo_shard_tick_phase(esvo_handle h, int phase, uint64_t t_ns, const uint64_t* pose_t_ns, const double* pose_T,
+                                     size_t m) {
+  if (!h) return ESVO_ERR_INVALID_ARG;
+  if (!h->obs_set) FAIL(ESVO_ERR_STATE, "esvo_map_set_observation has not been called");
+  if (!h->sharded) FAIL(ESVO_ERR_STATE, "call esvo_shard_set_band first");
+  HIPCHK(hipSetDevice(h->device));
+  switch (phase) {
+    case 0:
+      if (!pose_t_ns || !pose_T) return ESVO_ERR_INVALID_ARG;
+      return tick_phase0(h, t_ns, pose_t_ns, pose_T, m);
+    case 1: {
+      int rc = tick_phase1_enqueue(h);
+      if (rc) return rc;
+      return tick_phase1_collect(h, h->fpar);
+    }
+    case 2: return tick_phase2(h, h->fpar);
+    default: FAIL(ESVO_ERR_INVALID_ARG, "phase must be 0..2");
+  }
+}
+
+extern "C" {
+// ---- Outputs -----------------------------------------------------------------------------------------
+int esvo_map_get_depth_points(esvo_handle h, esvo_depth_point_t* out, size_t cap, size_t* n) {
+  if (!h || !n) return ESVO_ERR_INVALID_ARG;
+  HIPCHK(hipSetDevice(h->device));
+  { int rcp = flush_pending_tick(h); if (rcp) return rcp; }
+  std::vector<esvo_depth_point_t> v;
+  int rc = export_map(h, v, nullptr);
+  if (rc) return rc;
+  *n = v.size();
+  if (out) {
+    if (v.size() > cap) FAIL(ESVO_ERR_CAPACITY, "output array too small for the DepthMap");
+    if (!v.empty()) std::memcpy(out, v.data(), sizeof(esvo_depth_point_t) * v.size());
+  }
+  return ESVO_OK;
+}
+
+int esvo_map_get_committed(esvo_handle h, esvo_depth_point_t* out, size_t cap, size_t* n, uint64_t* t_ns) {
+  if (!h || !n) return ESVO_ERR_INVALID_ARG;
+  HIPCHK(hipSetDevice(h->device));
+  if (t_ns) *t_ns = h->committed_t_ns;
+  *n = 0;
+  if (h->committed_t_ns == 0) return ESVO_OK;
+  std::vector<esvo_depth_point_t> v;
+  int rc = export_map(h, v, nullptr);  // back stream only: a pending tick's front stage keeps running
+  if (rc) return rc;
+  *n = v.size();
+  if (out) {
+    if (v.size() > cap) FAIL(ESVO_ERR_CAPACITY, "output array too small for the DepthMap");
+    std::memcpy(out, v.data(), sizeof(esvo_depth_point_t) * v.size());
+  }
+  return ESVO_OK;
+}
+
+int esvo_map_get_pointcloud_xyz(esvo_handle h, float* out_xyz, size_t cap_points, size_t* n) {
+  if (!h || !n) return ESVO_ERR_INVALID_ARG;
+  HIPCHK(hipSetDevice(h->device));
+  { int rcp = flush_pending_tick(h); if (rcp) return rcp; }
+  std::vector<esvo_depth_point_t> v;
+  int rc = export_map(h, v, nullptr);
+  if (rc) return rc;
+  *n = v.size();
+  if (out_xyz) {
+    if (v.size() > cap_points) FAIL(ESVO_ERR_CAPACITY, "output array too small for the point cloud");
+    const double* T = h->T_world_frame;  // publishPointCloud, esvo_Mapping.cpp:925-932
+    for (size_t i = 0; i < v.size(); ++i)
+      for (int r = 0; r < 3; ++r)
+        out_xyz[3 * i + r] = (float)(((T[r * 4 + 0] * v[i].p_cam[0] + T[r * 4 + 1] * v[i].p_cam[1]) + T[r * 4 + 2] * v[i].p_cam[2]) + T[r * 4 + 3]);
+  }
+  return ESVO_OK;
+}
+
+int esvo_map_get_last_frame(esvo_handle h, esvo_depth_point_t* out, size_t cap, size_t* n) {
+  if (!h || !n) return ESVO_ERR_INVALID_ARG;
+  HIPCHK(hipSetDevice(h->device));
+  { int rcp = flush_pending_tick(h); if (rcp) return rcp; }
+  *n = 0;
+  if (h->frames.empty()) return ESVO_OK;
+  const FrameRec& f = h->frames.back();
+  *n = f.count;
+  if (out && f.count) {
+    if (f.count > cap) FAIL(ESVO_ERR_CAPACITY, "output array too small for the frame");
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(out, h->d_win + f.off, sizeof(esvo_depth_point_t) * f.count, hipMemcpyDeviceToHost));
+  }
+  return ESVO_OK;
+}
+
+int esvo_get_stats(esvo_handle h, esvo_stats_t* out) {
+  if (!h || !out) return ESVO_ERR_INVALID_ARG;
+  HIPCHK(hipSetDevice(h->device));
+  int rc = finalize_tick_stats(h);
+  if (rc) return rc;
+  *out = h->stats;
+  return ESVO_OK;
+}
+
+// ---- Multi-GPU row-band sharding ------------------------------------------------------------------
+int esvo_shard_set_band(esvo_handle h, int row_begin, int row_end, int shard, int n_shards) {
+  if (!h || row_begin < 0 || row_end > h->H || row_begin >= row_end || n_shards < 1 || shard < 0 || shard >= n_shards)
+    return ESVO_ERR_INVALID_ARG;
+  { int rcp = flush_pending_tick(h); if (rcp) return rcp; }
+  h->dp.ev_shard = shard;
+  h->dp.ev_nshards = n_shards;
+  h->dp.band_y0 = row_begin;
+  h->dp.band_y1 = row_end;
+  set_compute_band(h);
+  h->sharded = !(row_begin == 0 && row_end == h->H) || n_shards > 1;
+  return ESVO_OK;
+}
+
+int esvo_shard_exchange(esvo_handle h, void** d_ptr, size_t* n_bytes) {
+  if (!h || !d_ptr || !n_bytes) return ESVO_ERR_INVALID_ARG;
+  *d_ptr = h->xchg_ptr;
+  *n_bytes = h->xchg_bytes;
+  return ESVO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,129 @@
+// api_track.hip — tracker residual / Jacobian evaluation on the device-resident Time Surface (see context.hpp).
+#include "context.hpp"
+
+// ---- Tracker residual / Jacobian evaluation ---------------------------------------
+extern "C" {
+int esvo_track_set_current(esvo_handle h, const uint8_t* ts_left, int kernel_size) {
+  if (!h) return ESVO_ERR_INVALID_ARG;
+  if (kernel_size != 0 && kernel_size != 5)
+    FAIL(ESVO_ERR_UNSUPPORTED, "tracker kernelSize must be 0 or 5 (the shipped configs); other sizes take OpenCV's float kernel path");
+  HIPCHK(hipSetDevice(h->device));
+  const size_t npx = (size_t)h->W * h->H;
+  if (!h->d_trk_neg) {
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&h->d_trk_blur), npx));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&h->d_trk_neg), npx));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&h->d_trk_du), npx * sizeof(int16_t)));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&h->d_trk_dv), npx * sizeof(int16_t)));
+  }
+  const uint8_t* src = h->d_ts[0];
+  if (ts_left) {  // host image (TS node in another process)
+    HIPCHK(hipMemcpyAsync(h->d_trk_neg, ts_left, npx, hipMemcpyHostToDevice, h->stream_t));
+    src = h->d_trk_neg;  // staged here, consumed by the blur / copy below before track_images writes it
+  } else {
+    if (!h->ts_valid[0]) FAIL(ESVO_ERR_STATE, "no device-resident left Time Surface: call esvo_ts_render(h, 0, ...) first");
+    HIPCHK(hipStreamWaitEvent(h->stream_t, h->evt[EV_R1], 0));  // the render of camera 0 on the front stream
+  }
+  if (kernel_size == 5) launch_gaussian5(src, h->d_trk_blur, h->W, h->H, h->stream_t);
+  else HIPCHK(hipMemcpyAsync(h->d_trk_blur, src, npx, hipMemcpyDeviceToDevice, h->stream_t));
+  launch_track_images(h->d_trk_blur, h->d_trk_neg, h->d_trk_du, h->d_trk_dv, h->W, h->H, h->stream_t);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(h->stream_t));  // the left TS may be re-rendered right after this call
+  h->trk_cur = true;
+  return ESVO_OK;
+}
+
+int esvo_track_get_images(esvo_handle h, uint8_t* neg, int16_t* du, int16_t* dv) {
+  if (!h) return ESVO_ERR_INVALID_ARG;
+  if (!h->trk_cur) FAIL(ESVO_ERR_STATE, "esvo_track_set_current has not been called");
+  HIPCHK(hipSetDevice(h->device));
+  const size_t npx = (size_t)h->W * h->H;
+  if (neg) HIPCHK(hipMemcpyAsync(neg, h->d_trk_neg, npx, hipMemcpyDeviceToHost, h->stream_t));
+  if (du) HIPCHK(hipMemcpyAsync(du, h->d_trk_du, npx * sizeof(int16_t), hipMemcpyDeviceToHost, h->stream_t));
+  if (dv) HIPCHK(hipMemcpyAsync(dv, h->d_trk_dv, npx * sizeof(int16_t), hipMemcpyDeviceToHost, h->stream_t));
+  HIPCHK(hipStreamSynchronize(h->stream_t));
+  return ESVO_OK;
+}
+
+int esvo_track_set_reference(esvo_handle h, const float* xyz_world, size_t n, const double T_world_ref[16]) {
+  if (!h || (n && !xyz_world) || !T_world_ref) return ESVO_ERR_INVALID_ARG;
+  HIPCHK(hipSetDevice(h->device));
+  if (n > h->trk_cap) {
+    HIPCHK(hipStreamSynchronize(h->stream_t));
+    for (void* q : {(void*)h->d_trk_xyz, (void*)h->d_trk_pts, (void*)h->d_trk_out}) if (q) hipFree(q);
+    h->d_trk_xyz = nullptr; h->d_trk_pts = nullptr; h->d_trk_out = nullptr;
+    const size_t cap = std::max<size_t>(n, 4096);
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&h->d_trk_xyz), cap * 3 * sizeof(float)));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&h->d_trk_pts), cap * 3 * sizeof(double)));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&h->d_trk_out), cap * 6 * sizeof(double)));
+    h->trk_cap = cap;
+  }
+  h->trk_n = n;
+  if (n) {
+    TrackRef r;
+    std::memcpy(r.T, T_world_ref, sizeof(r.T));
+    HIPCHK(hipMemcpyAsync(h->d_trk_xyz, xyz_world, n * 3 * sizeof(float), hipMemcpyHostToDevice, h->stream_t));
+    launch_track_reference(h->d_trk_xyz, (u32)n, r, h->d_trk_pts, h->stream_t);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream_t));  // xyz_world is borrowed for the call
+  }
+  return ESVO_OK;
+}
+}  // extern "C"
+
+namespace {
+void fill_track_args(esvo_context* h, TrackArgs& a) {
+  a.pts = h->d_trk_pts; a.neg = h->d_trk_neg; a.du = h->d_trk_du; a.dv = h->d_trk_dv; a.mask = h->d_mask;
+  std::memcpy(a.P, h->dp.camL.P, sizeof(a.P));
+  a.W = h->W; a.H = h->H;
+}
+}  // namespace
+
+extern "C" {
+int esvo_track_residuals(esvo_handle h, const double T_left_ref[16], size_t offset, size_t count, int ls_norm,
+                         double huber_threshold, double* fvec, size_t* n_out) {
+  if (!h || !T_left_ref || !n_out || (ls_norm != ESVO_TRACK_L2 && ls_norm != ESVO_TRACK_HUBER)) return ESVO_ERR_INVALID_ARG;
+  if (!h->trk_cur) FAIL(ESVO_ERR_STATE, "esvo_track_set_current has not been called");
+  HIPCHK(hipSetDevice(h->device));
+  const size_t m = offset >= h->trk_n ? 0 : std::min(count, h->trk_n - offset);  // setStochasticSampling, :71-88
+  *n_out = m;
+  if (m == 0) return ESVO_OK;
+  if (!fvec) return ESVO_ERR_INVALID_ARG;
+  TrackArgs a;
+  fill_track_args(h, a);
+  TrackPose pose;
+  std::memcpy(pose.T, T_left_ref, sizeof(pose.T));
+  std::memset(pose.Jc, 0, sizeof(pose.Jc));
+  launch_track_residuals(a, pose, (u32)offset, (u32)m, ls_norm == ESVO_TRACK_HUBER, huber_threshold, h->d_trk_out, h->stream_t);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(fvec, h->d_trk_out, m * sizeof(double), hipMemcpyDeviceToHost, h->stream_t));
+  HIPCHK(hipStreamSynchronize(h->stream_t));
+  return ESVO_OK;
+}
+
+int esvo_track_jacobian(esvo_handle h, const double R[9], const double t[3], size_t offset, size_t count, double* fjac,
+                        size_t* n_out) {
+  if (!h || !R || !t || !n_out) return ESVO_ERR_INVALID_ARG;
+  if (!h->trk_cur) FAIL(ESVO_ERR_STATE, "esvo_track_set_current has not been called");
+  HIPCHK(hipSetDevice(h->device));
+  const size_t m = offset >= h->trk_n ? 0 : std::min(count, h->trk_n - offset);
+  *n_out = m;
+  if (m == 0) return ESVO_OK;
+  if (!fjac) return ESVO_ERR_INVALID_ARG;
+  TrackArgs a;
+  fill_track_args(h, a);
+  TrackPose pose;  // T_left_ref = [R^T | -R^T t] (:203-205), J_constPart = R^T diag(1/P11, 1/P22; 0) (:189-194)
+  std::memset(pose.T, 0, sizeof(pose.T));
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) pose.T[r * 4 + c] = R[c * 3 + r];
+    pose.T[r * 4 + 3] = (-R[0 * 3 + r] * t[0] + -R[1 * 3 + r] * t[1]) + -R[2 * 3 + r] * t[2];
+  }
+  pose.T[15] = 1.0;
+  const double iP11 = 1.0 / a.P[0], iP22 = 1.0 / a.P[5];
+  for (int r = 0; r < 3; ++r) { pose.Jc[r * 2 + 0] = R[0 * 3 + r] * iP11; pose.Jc[r * 2 + 1] = R[1 * 3 + r] * iP22; }
+  launch_track_jacobian(a, pose, (u32)offset, (u32)m, h->d_trk_out, h->stream_t);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(fjac, h->d_trk_out, m * 6 * sizeof(double), hipMemcpyDeviceToHost, h->stream_t));
+  HIPCHK(hipStreamSynchronize(h->stream_t));
+  return ESVO_OK;
+}
+}  // extern "C"

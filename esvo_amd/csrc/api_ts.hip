@@ -1,0 +1,164 @@
+// api_ts.hip — event ingest and Time-Surface render (see context.hpp).
+#include "context.hpp"
+
+namespace esvo_host {
+
+// Time-Surface kernel timings of the last render of a camera (-1: both); the caller knows their events are complete
+void collect_ts_timing(esvo_context* h, int only) {
+  for (int cam = 0; cam < 2; ++cam) {
+    if (!h->ts_timing_pending[cam] || (only >= 0 && cam != only)) continue;
+    h->ts_timing_pending[cam] = false;
+    const int o = cam * EV_TS_STRIDE;
+    float sc = 0, rd = 0;
+    if (hipEventElapsedTime(&sc, h->evt[EV_SC0 + o], h->evt[EV_SC1 + o]) == hipSuccess &&
+        hipEventElapsedTime(&rd, h->evt[EV_SC1 + o], h->evt[EV_R1 + o]) == hipSuccess) {
+      h->stats.ms_ts_scatter = h->stats.ms_kernel[0] = sc;
+      h->stats.ms_ts_render = h->stats.ms_kernel[1] = rd;
+      h->stats.sum_ms_kernel[0] += sc;
+      h->stats.sum_ms_kernel[1] += rd;
+      h->stats.sum_ms_kernel[7] += 1;
+    }
+  }
+}
+
+}  // namespace esvo_host
+
+extern "C" {
+
+// ---- Time Surface ---------------------------------------------------------------------------------
+namespace {
+// Staging runs on its own stream.  The slots it overwrites hold events older than ring_cap; a front stage still in flight
+// reads at most the max_ev events before its selection point, so only a (nearly) full ring needs the front stream drained.
+int ring_overwrite_guard(esvo_context* h, int cam, size_t n) {
+  if (h->ring_next[cam] + n <= h->ring_cap) return ESVO_OK;
+  const u64 evict_end = h->ring_next[cam] + n - h->ring_cap;  // first absolute index that survives
+  u64 oldest_read = h->scatter_pending_lo[cam];              // scatter kernels enqueued since the last drain
+  if (cam == 0) oldest_read = std::min(oldest_read, h->sh_first > (u64)h->max_ev ? h->sh_first - (u64)h->max_ev : 0);
+  if (evict_end > oldest_read) {
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->scatter_pending_lo[0] = h->scatter_pending_lo[1] = ~0ull;
+  }
+  return ESVO_OK;
+}
+}  // namespace
+
+int esvo_ts_push_events(esvo_handle h, int cam, const esvo_event_t* ev, size_t n) {
+  if (!h || cam < 0 || cam > 1 || (n && !ev)) return ESVO_ERR_INVALID_ARG;
+  if (n == 0) return ESVO_OK;
+  if (n > h->ring_cap) FAIL(ESVO_ERR_CAPACITY, "event block larger than the event ring");
+  HIPCHK(hipSetDevice(h->device));
+  auto& tsq = h->ts_host[cam];
+  u64 last = tsq.empty() ? 0 : tsq.back();
+  for (size_t i = 0; i < n; ++i) {
+    const u64 t = (u64)ev[i].sec * 1000000000ull + ev[i].nsec;
+    if (t < last) FAIL(ESVO_ERR_INVALID_ARG, "events must be sorted by time stamp (SURVEY Appendix A-1)");
+    last = t;
+  }
+  // the ring must not overwrite events that are not yet scattered into the SAE
+  if (h->ring_next[cam] + n - h->scattered[cam] > h->ring_cap)
+    FAIL(ESVO_ERR_CAPACITY, "event ring full: render (scatter) before staging more events");
+  { int rcg = ring_overwrite_guard(h, cam, n); if (rcg) return rcg; }
+  const u64 slot = h->ring_next[cam] % h->ring_cap;
+  const size_t first = (size_t)std::min<u64>(n, h->ring_cap - slot);
+  HIPCHK(hipMemcpyAsync(h->d_ring[cam] + slot, ev, sizeof(esvo_event_t) * first, hipMemcpyHostToDevice, h->stream_i));
+  if (first < n)
+    HIPCHK(hipMemcpyAsync(h->d_ring[cam], ev + first, sizeof(esvo_event_t) * (n - first), hipMemcpyHostToDevice, h->stream_i));
+  HIPCHK(hipStreamSynchronize(h->stream_i));  // `ev` is borrowed for the duration of the call only; later work sees the copy
+  for (size_t i = 0; i < n; ++i) tsq.push_back((u64)ev[i].sec * 1000000000ull + ev[i].nsec);
+  h->ring_next[cam] += n;
+  while (tsq.size() > h->ring_cap) { tsq.pop_front(); h->ring_base[cam]++; }
+  h->stats.events_staged[cam] += n;
+  return ESVO_OK;
+}
+
+// A serialised dvs_msgs/EventArray (ROS1 wire format): std_msgs/Header {u32 seq, u32 sec, u32 nsec, string frame_id},
+// u32 height, u32 width, Event[] {u32 count, count x 13 B}.  The 13-byte records go to the device as they are and are
+// widened to esvo_event_t in the ring by a kernel; the host only walks the time stamps (order check + selection index).
+int esvo_ts_push_event_array(esvo_handle h, int cam, const uint8_t* msg, size_t n_bytes, size_t* n_events) {
+  if (!h || cam < 0 || cam > 1 || !msg) return ESVO_ERR_INVALID_ARG;
+  auto rd32 = [&](size_t off) { return (u32)msg[off] | ((u32)msg[off + 1] << 8) | ((u32)msg[off + 2] << 16) | ((u32)msg[off + 3] << 24); };
+  if (n_bytes < 16) FAIL(ESVO_ERR_INVALID_ARG, "EventArray message shorter than its header");
+  const size_t id_len = rd32(12);
+  size_t off = 16 + id_len;
+  if (off < 16 || off + 12 > n_bytes) FAIL(ESVO_ERR_INVALID_ARG, "EventArray message truncated (frame_id / height / width / count)");
+  const u32 height = rd32(off), width = rd32(off + 4), n = rd32(off + 8);
+  off += 12;
+  if (n_events) *n_events = n;
+  if ((size_t)n * 13 != n_bytes - off) FAIL(ESVO_ERR_INVALID_ARG, "EventArray message length does not match its event count");
+  if ((height && (int)height != h->H) || (width && (int)width != h->W)) FAIL(ESVO_ERR_INVALID_ARG, "EventArray sensor size differs from the handle's");
+  if (n == 0) return ESVO_OK;
+  if (n > h->ring_cap) FAIL(ESVO_ERR_CAPACITY, "event block larger than the event ring");
+  HIPCHK(hipSetDevice(h->device));
+  const uint8_t* rec = msg + off;
+  auto stamp = [&](size_t i) {
+    const uint8_t* r = rec + i * 13 + 4;
+    const u32 sec = (u32)r[0] | ((u32)r[1] << 8) | ((u32)r[2] << 16) | ((u32)r[3] << 24);
+    const u32 nsec = (u32)r[4] | ((u32)r[5] << 8) | ((u32)r[6] << 16) | ((u32)r[7] << 24);
+    return (u64)sec * 1000000000ull + nsec;
+  };
+  auto& tsq = h->ts_host[cam];
+  u64 last = tsq.empty() ? 0 : tsq.back();
+  for (size_t i = 0; i < n; ++i) {
+    const u64 t = stamp(i);
+    if (t < last) FAIL(ESVO_ERR_INVALID_ARG, "events must be sorted by time stamp (SURVEY Appendix A-1)");
+    last = t;
+  }
+  if (h->ring_next[cam] + n - h->scattered[cam] > h->ring_cap)
+    FAIL(ESVO_ERR_CAPACITY, "event ring full: render (scatter) before staging more events");
+  if ((size_t)n * 13 > h->wire_cap) {
+    if (h->d_wire) { hipFree(h->d_wire); h->d_wire = nullptr; }  // the ingest stream is idle between calls
+    h->wire_cap = std::max<size_t>((size_t)n * 13, (size_t)1 << 20);
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&h->d_wire), h->wire_cap));
+  }
+  { int rcg = ring_overwrite_guard(h, cam, n); if (rcg) return rcg; }
+  HIPCHK(hipMemcpyAsync(h->d_wire, rec, (size_t)n * 13, hipMemcpyHostToDevice, h->stream_i));
+  launch_ts_unpack_wire(h->d_wire, n, h->d_ring[cam], h->ring_next[cam] % h->ring_cap, h->ring_cap, h->stream_i);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(h->stream_i));  // `msg` is borrowed for the duration of the call only
+  for (size_t i = 0; i < n; ++i) tsq.push_back(stamp(i));
+  h->ring_next[cam] += n;
+  while (tsq.size() > h->ring_cap) { tsq.pop_front(); h->ring_base[cam]++; }
+  h->stats.events_staged[cam] += n;
+  return ESVO_OK;
+}
+
+int esvo_ts_render(esvo_handle h, int cam, uint64_t t_ns, uint8_t* out_mono8) {
+  if (!h || cam < 0 || cam > 1) return ESVO_ERR_INVALID_ARG;
+  HIPCHK(hipSetDevice(h->device));
+  // events with ts < T (strict, TimeSurface.h:68) that are not in the SAE yet
+  const auto& tsq = h->ts_host[cam];
+  const size_t k = std::lower_bound(tsq.begin(), tsq.end(), (u64)t_ns) - tsq.begin();
+  const u64 upto = h->ring_base[cam] + k;
+  const int evo = cam * EV_TS_STRIDE;
+  if (h->ts_timing_pending[cam] && hipEventQuery(h->evt[EV_R1 + evo]) == hipSuccess) collect_ts_timing(h, cam);
+  hipEventRecord(h->evt[EV_SC0 + evo], h->stream);
+  if (upto > h->scattered[cam]) {
+    u64 a = h->scattered[cam];
+    h->scatter_pending_lo[cam] = std::min(h->scatter_pending_lo[cam], a);
+    const u64 total = upto - a;
+    while (a < upto) {
+      const u64 slot = a % h->ring_cap;
+      const u64 cnt = std::min<u64>(upto - a, h->ring_cap - slot);
+      launch_ts_scatter(h->d_ring[cam] + slot, (size_t)cnt, h->d_sae[cam], h->W, h->H, h->stream);
+      a += cnt;
+    }
+    h->scattered[cam] = upto;
+    h->stats.events_scattered[cam] += total;
+  }
+  hipEventRecord(h->evt[EV_SC1 + evo], h->stream);
+  launch_ts_render(h->d_sae[cam], h->d_fixmap[cam], h->d_raw, h->d_ts[cam], h->W, h->H, (u64)t_ns, h->prm.decay_ms / 1000.0,
+                   h->prm.ignore_polarity, h->prm.median_blur_kernel_size, h->stream);
+  hipEventRecord(h->evt[EV_R1 + evo], h->stream);
+  HIPCHK(hipGetLastError());
+  h->ts_valid[cam] = true;
+  h->ts_timing_pending[cam] = true;
+  h->stats.ts_frames[cam]++;
+  if (out_mono8) {
+    HIPCHK(hipMemcpyAsync(out_mono8, h->d_ts[cam], (size_t)h->W * h->H, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    collect_ts_timing(h);
+  }
+  return ESVO_OK;
+}
+
+}  // extern "C"

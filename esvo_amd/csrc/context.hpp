@@ -1,0 +1,228 @@
+// context.hpp — the state behind an esvo_handle and what the api_*.hip translation units share.
+//
+// One esvo_context owns every device buffer of one GPU: SAE + staged event rings (Time Surface), the observation pair,
+// per-tick BM/LM scratch, the fusion window ring and the dense DepthMap.  Each entry point replays, on the handle's HIP
+// streams, the call sequence of the reference seam it replaces (cited in include/esvo_hip.h); nothing computes on the
+// CPU except bookkeeping (time-stamp binary searches, window policy, output ordering).
+//   api_core.hip   lifecycle, parameters, self-tests           api_ts.hip     event ingest, Time-Surface render
+//   api_map.hip    mapper: stage-wise calls, ticks, sharding   api_track.hip  tracker residual / Jacobian evaluation
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+
+using namespace esvo;
+
+// front-stage events live on the front stream; the back-stage set exists once per tick parity (two ticks in flight)
+enum { EV_SC0 = 0, EV_SC1, EV_R1, EV_SC0b, EV_SC1b, EV_R1b, EV_FRAME,
+       EV_T0, EV_BM0, EV_BM1, EV_S1, EV_LM0, EV_LM1, EV_S2, EV_CNT, EV_STG, EV_T0b, EV_BM0b, EV_BM1b, EV_S1b, EV_LM0b, EV_LM1b, EV_S2b, EV_CNTb, EV_STGb,
+       EV_FU0, EV_FU1, EV_CL1, EV_RG1, EV_POSE, EV_FU0b, EV_FU1b, EV_CL1b, EV_RG1b, EV_POSEb, EV_N };
+constexpr int EV_BACK_STRIDE = EV_FU0b - EV_FU0;  // evt[EV_x + par * EV_BACK_STRIDE]
+constexpr int EV_FRONT_STRIDE = EV_T0b - EV_T0;   // evt[EV_x + fpar * EV_FRONT_STRIDE]
+constexpr int EV_TS_STRIDE = EV_SC0b - EV_SC0;    // evt[EV_x + cam * EV_TS_STRIDE]
+
+struct FrameRec {
+  u32 off;    // offset in the window ring
+  u32 count;  // points
+  u32 slot;   // pose-table slot
+};
+
+struct esvo_context {
+  esvo_params_t prm;
+  DevParams dp;
+  int W = 0, H = 0, device = 0;
+  // Two streams, two ticks in flight: the front stage (TS, block matching, LM, frame assembly) of tick k+1 runs on
+  // `stream` while the back stage (propagate, fuse, clean, regularise) of tick k runs on `stream_b`.  The back
+  // stage only reads what the front stage finished (the frame in the window ring, the tick's pose table).
+  hipStream_t stream = nullptr;
+  hipStream_t stream_b = nullptr;
+  hipStream_t stream_i = nullptr;  // event ingest (H2D into the ring): staging new events never waits for a running tick
+  bool own_stream = false;
+  int par = 0;                    // parity of the tick being assembled
+  bool back_pending[2] = {false, false};  // back-stage timings / counters of that parity not collected yet
+  u32 back_frames[2] = {0, 0};
+  std::string err;
+  double baseline = 0;
+
+  // calibration
+  float2* d_lut = nullptr;
+  uint8_t* d_mask = nullptr;
+  int2* d_fixmap[2] = {nullptr, nullptr};
+
+  // Time Surface
+  u64* d_sae[2] = {nullptr, nullptr};
+  uint8_t* d_raw = nullptr;
+  uint8_t* d_ts[2] = {nullptr, nullptr};
+  bool ts_valid[2] = {false, false};
+  esvo_event_t* d_ring[2] = {nullptr, nullptr};
+  uint8_t* d_wire = nullptr;    // staging of serialised 13-byte event records (esvo_ts_push_event_array)
+  size_t wire_cap = 0;
+  u64 ring_cap = 0;
+  std::deque<u64> ts_host[2];   // time stamps of staged events [ring_base, ring_base + size)
+  u64 ring_base[2] = {0, 0};    // absolute index of ts_host[cam].front()
+  u64 ring_next[2] = {0, 0};    // absolute index of the next event to stage
+  u64 scattered[2] = {0, 0};    // absolute index of the first event not yet in the SAE
+  u64 scatter_pending_lo[2] = {~0ull, ~0ull};  // oldest event a possibly still running scatter kernel reads
+
+  // observation
+  uint8_t* d_obs[2] = {nullptr, nullptr};
+  uint8_t* d_obs_tmp = nullptr;
+  double T_world_obs[16];
+  double* d_T_world_obs = nullptr;
+  u64 obs_t_ns = 0;
+  bool obs_set = false;
+
+  // pose table of the tick
+  double* d_pose_sec = nullptr;
+  double* d_pose_T = nullptr;     // the tick's table (one of d_pose_T2, alternating)
+  double* d_pose_T2[2] = {nullptr, nullptr};
+  int pose_buf = 0;
+  std::vector<double> h_pose_T;
+  double* h_pin = nullptr;        // pinned staging: 2 slots x (max_poses x 17 + 16) doubles
+  int pin_slot = 0;
+  bool stats_pending = false;     // the last tick's counters / timings have not been read back yet
+  u32 n_pose = 0;
+
+  // per-tick scratch
+  u32 max_ev = 0;
+  esvo_event_t* d_tick_ev = nullptr;
+  esvo_match_t* d_match_slots = nullptr;
+  u32* d_match_flags = nullptr;
+  u32* d_match_prefix = nullptr;
+  esvo_match_t* d_matches = nullptr;
+  DevPoint* d_pt_slots = nullptr;
+  u32* d_pt_flags = nullptr;
+  u32* d_pt_prefix = nullptr;
+  DevPoint* d_pts_tmp = nullptr;  // stage-wise refine output
+  DevPoint* d_stage[2] = {nullptr, nullptr};  // a lazily completed tick's frame (by parity) until its count is known
+  u32* d_counters = nullptr;      // [0] n_matches [1] n_points [2] n_solved [3] n_fusion [4] n_records [5] n_map
+                                  // [6] touched cells [7] regulariser elements [8] own matches (sharded)
+  u32* h_counters = nullptr;      // pinned
+  u32* d_scan_tmp = nullptr;
+  u32* d_cnt_b = nullptr;         // back stage: [3] n_fusion [4] n_records [5] n_map [6] touched cells [7] regulariser elements
+  u32* h_cnt_b = nullptr;         // pinned, one row of 8 per parity + one for exports
+  u32* d_scan_tmp_b = nullptr;
+
+  // fusion window
+  DevPoint* d_win = nullptr;
+  u32 win_cap = 0;
+  std::deque<FrameRec> frames;    // oldest first
+  u32 n_pose_slots = 0;
+  std::vector<char> slot_used;
+  double* d_frame_pose_T = nullptr;
+  u32 max_poses = 0;
+  u32* d_fr_table = nullptr;      // fr_cum | fr_off | fr_slot
+  u32* h_fr_table = nullptr;      // pinned
+  u32 max_frames = 0;
+
+  // DepthMap
+  DevPoint* d_prop = nullptr;
+  u32* d_cell_count = nullptr;
+  u32* d_cell_offset = nullptr;
+  u32* d_cell_fill = nullptr;
+  u32* d_rec_ids = nullptr;
+  MapCell* d_map = nullptr;
+  MapCell* d_map2 = nullptr;
+  MapCell* d_map_cur = nullptr;
+  u32* d_owner_max = nullptr;
+  u32* d_owner_min = nullptr;
+  u32* d_bucket = nullptr;
+  u32* d_sel = nullptr;           // denoising: walk positions of the kept events
+  uint8_t* d_evmap = nullptr;     // denoising: binary event map
+  // sharded mode (kernels_shard.hip): dense local lists + the (matched, kept) byte per slot that is exchanged
+  u32* d_own_w = nullptr;         // slot w of the k-th own match
+  u32* d_lkeep = nullptr;         // keep flag of the k-th own match after LM + culling
+  uint8_t* d_codes = nullptr;     // [codes_bytes] one byte per slot, zero for other ranks' slots
+  size_t codes_bytes = 0;
+  void* xchg_ptr = nullptr;       // what the caller must sum across the ranks before the next phase
+  size_t xchg_bytes = 0;
+  u64* d_reg_valid = nullptr;     // regulariser view: 1 bit per cell
+  bool sharded = false;
+  u32 reg_words = 0;
+  // A tick's state between its phases.  Unsharded ticks are finished lazily: esvo_map_tick(k) enqueues the front
+  // stage of tick k and only then completes tick k-1 (point count -> window policy -> back stage), so the host
+  // never waits on the front stream while it still has work to enqueue there.
+  struct TickState {
+    u32 n = 0, off = 0, points = 0, n_pose = 0;
+    int pose_buf = 0;
+    u64 t_ns = 0;
+    double T_world_obs[16];
+  } tk[2];
+  int fpar = 0;                   // parity of the newest front stage
+  bool tick_pending = false;      // tk[fpar] has its front stage enqueued but is not committed yet
+  u64 committed_t_ns = 0;         // stamp of the newest tick whose back stage is enqueued (0: none)
+  u64 sh_first = 0;
+  u32* d_cell_list = nullptr;
+  u64* d_reg_bits = nullptr;    // close-neighbour masks of the regulariser scan: [elements][words]
+  u32* d_reg_counts = nullptr;  // (n_neighbours, n_close) per element
+  double2* d_reg_ab = nullptr;
+  double2* d_reg_cd = nullptr;
+  double T_world_frame[16];
+  // export
+  u32* d_exp_flags = nullptr;
+  u32* d_exp_prefix = nullptr;
+  esvo_depth_point_t* d_export = nullptr;
+  u32* d_export_cell = nullptr;
+
+  // tracker residual / Jacobian evaluation (kernels_track.hip): own stream, own images, synchronous calls
+  hipStream_t stream_t = nullptr;
+  uint8_t* d_trk_blur = nullptr;
+  uint8_t* d_trk_neg = nullptr;
+  int16_t* d_trk_du = nullptr;
+  int16_t* d_trk_dv = nullptr;
+  float* d_trk_xyz = nullptr;
+  double* d_trk_pts = nullptr;
+  double* d_trk_out = nullptr;
+  size_t trk_cap = 0, trk_n = 0;
+  bool trk_cur = false;
+
+  // pinned staging slots for frame pose tables that arrive from the host (push_frame variants): a slot is reused only
+  // after the back stream has consumed it
+  static constexpr int POSE_POOL = 32;
+  double* h_pose_pool = nullptr;
+  hipEvent_t pool_evt[POSE_POOL];
+  bool pool_ok = false;
+  int pool_next = 0;
+
+  hipEvent_t evt[EV_N];
+  bool evt_ok = false;
+  esvo_stats_t stats;
+  bool ts_timing_pending[2] = {false, false};
+};
+
+namespace esvo_host {
+extern thread_local std::string g_create_error;  // esvo_last_error(nullptr): why the last esvo_create failed
+// api_core.hip
+void fill_dev_params(esvo_context* h);
+void set_compute_band(esvo_context* h);
+// api_ts.hip
+void collect_ts_timing(esvo_context* h, int only = -1);
+// api_map.hip
+int flush_pending_tick(esvo_context* h);  // completes a lazily finished tick (see esvo_context::TickState)
+int finalize_tick_stats(esvo_context* h);
+}  // namespace esvo_host
+using namespace esvo_host;
+
+#define HIPCHK(call)                                                                              \
+  do {                                                                                            \
+    hipError_t _e = (call);                                                                       \
+    if (_e != hipSuccess) {                                                                       \
+      char _b[512];                                                                               \
+      snprintf(_b, sizeof(_b), "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
+      if (h) h->err = _b; else g_create_error = _b;                                               \
+      return ESVO_ERR_HIP;                                                                        \
+    }                                                                                             \
+  } while (0)
+
+#define FAIL(code, msg)                      \
+  do {                                       \
+    if (h) h->err = (msg); else g_create_error = (msg); \
+    return (code);                           \
+  } while (0)
