@@ -275,6 +275,15 @@ def main():
         },
     }
 
+    # the same figures for both single-kernel slots (block matching is the one with a meaningful HBM fraction)
+    out["roofline_kernels"] = []
+    for slot in (2, 3):
+        name = KERNEL_NAMES[slot]
+        nbytes = algorithmic_bytes(name, st, rig.width, rig.height, nd, p.fusion_radius, events=ev_rank / launches, matches=mt_rank / launches)
+        gbs = (nbytes / (kavg[slot] * 1e-3)) / 1e9 if kavg[slot] > 0 else 0.0
+        out["roofline_kernels"].append({"kernel": name, "avg_launch_ms": float(kavg[slot]), "algorithmic_bytes_per_launch": nbytes,
+                                        "achieved": gbs, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                        "valu_busy_frac": measured_valu_busy(name) if args.workload == "dsec640x480" else None})
     if args.check:
         mp_ = runner.get_map()
         if rank == 0:
