@@ -471,7 +471,10 @@ __global__ void __launch_bounds__(256) reg_scan_kernel(const MapCell* __restrict
 // ---- regulariser pass B: sequential Student-t fusion of the close neighbours, one thread per element --
 // DepthRegularization.cpp:66-98.  The order is fixed by the masks, so the neighbour data of the next
 // step is loaded while the current (dependent) fusion step computes.
-__global__ void __launch_bounds__(256) reg_chain_kernel(const MapCell* __restrict__ map, MapCell* __restrict__ out,
+#ifndef CHAIN_BLOCK
+#define CHAIN_BLOCK 256
+#endif
+__global__ void __launch_bounds__(CHAIN_BLOCK) reg_chain_kernel(const MapCell* __restrict__ map, MapCell* __restrict__ out,
                                                         const u32* __restrict__ owner_max, const u32* __restrict__ owner_min,
                                                         const double2* __restrict__ ab, const double2* __restrict__ cd,
                                                         const u32* __restrict__ elem_list, const u32* __restrict__ n_elems,
@@ -574,7 +577,7 @@ void launch_reg_apply(const MapCell* map_in, MapCell* map_out, const u32* owner_
   if (Wn <= 16) launch_reg_scan_g<16>(map_in, vbits, ab, elem_list, n_elems, masks, counts, max_elems, p, s);
   else if (Wn <= 32) launch_reg_scan_g<32>(map_in, vbits, ab, elem_list, n_elems, masks, counts, max_elems, p, s);
   else launch_reg_scan_g<64>(map_in, vbits, ab, elem_list, n_elems, masks, counts, max_elems, p, s);
-  hipLaunchKernelGGL(reg_chain_kernel, dim3((max_elems + 255) / 256), dim3(256), 0, s, map_in, map_out, owner_max, owner_min, ab,
+  hipLaunchKernelGGL(reg_chain_kernel, dim3((max_elems + CHAIN_BLOCK - 1) / CHAIN_BLOCK), dim3(CHAIN_BLOCK), 0, s, map_in, map_out, owner_max, owner_min, ab,
                      cd, elem_list, n_elems, masks, counts, p);
 }
 

@@ -297,8 +297,12 @@ __device__ inline double lm_lmpar2(double r, double diag, double qtf, double del
 #ifndef LM_WAVES
 #define LM_WAVES 3  // waves per SIMD: 4 (<= 128 VGPRs) spills 71 registers into the solver loop and is slower
 #endif
-__global__ void __launch_bounds__(256, LM_WAVES) lm_refine_kernel(LmArgs a, DevParams p, u32* n_solved) {
-  const u32 s = (blockIdx.x * 256 + threadIdx.x) >> 4;  // solver slot (thread-stride order)
+#ifndef LM_BLOCK
+#define LM_BLOCK 64   // threads per workgroup (no LDS, no barriers).  One wave per workgroup: a finished wave's slot is
+                      // refilled at once instead of waiting for its three siblings -- 4 % per tick against 256
+#endif
+__global__ void __launch_bounds__(LM_BLOCK, LM_WAVES) lm_refine_kernel(LmArgs a, DevParams p, u32* n_solved) {
+  const u32 s = (blockIdx.x * LM_BLOCK + threadIdx.x) >> 4;  // solver slot (thread-stride order)
   const int c = threadIdx.x & 15;
   u32 M = *a.n_matches;
   if (M > a.max_matches) M = a.max_matches;
@@ -499,9 +503,9 @@ extern "C" void esvo_debug_lm_slots(unsigned int* out, int clear) {  // out[3][1
 #endif
 void launch_lm_refine(const LmArgs& a, const DevParams& p, u32* n_solved, hipStream_t s) {
   if (a.max_matches == 0) return;
-  const u32 groups_per_block = 256 / 16;
+  const u32 groups_per_block = LM_BLOCK / 16;
   const u32 blocks = (a.max_matches + groups_per_block - 1) / groups_per_block;
-  hipLaunchKernelGGL(lm_refine_kernel, dim3(blocks), dim3(256), 0, s, a, p, n_solved);
+  hipLaunchKernelGGL(lm_refine_kernel, dim3(blocks), dim3(LM_BLOCK), 0, s, a, p, n_solved);
 }
 
 // stable compaction of the solver slots into a frame buffer
