@@ -58,9 +58,13 @@ __device__ inline int grp_sum_i32(int v) {
 // each lane reads 5 dwords per row, re-aligns them with v_alignbyte_b32 and accumulates
 // S_r, S_rr and S_lr with v_dot4_u32_u8 (the pad byte of the left patch is zero and the 16th
 // byte of the window is masked out).
+#ifndef BM_BLOCK
+#define BM_BLOCK 64   // threads per workgroup (a multiple of 64; the two barriers are per workgroup).  64 beats 256 by 20 %:
+                      // barriers span one wave and a finished wave frees its slot and LDS at once
+#endif
 template <int G>
-__global__ void __launch_bounds__(256) bm_match_kernel(BmArgs a, DevParams p, int RD, int lds_per_event) {
-  constexpr int EPB = 256 / G;  // events per block
+__global__ void __launch_bounds__(BM_BLOCK) bm_match_kernel(BmArgs a, DevParams p, int RD, int lds_per_event) {
+  constexpr int EPB = BM_BLOCK / G;  // events per block
   const int grp = threadIdx.x / G, l = threadIdx.x % G;
   // slot in thread-stride order; multi-GPU: slots are dealt round-robin and a rank's launch covers its own ones densely
   const u32 w = (blockIdx.x * EPB + grp) * (u32)p.ev_nshards + (u32)p.ev_shard;
@@ -219,11 +223,11 @@ __global__ void __launch_bounds__(256) bm_match_kernel(BmArgs a, DevParams p, in
 template <int G>
 static void launch_bm_g(const BmArgs& a, const DevParams& p, int RD, hipStream_t s) {
   const int per_event = (28 + 7 * RD) * 4;
-  const int epb = 256 / G;
+  const int epb = BM_BLOCK / G;
   const u32 own = (a.n > (u32)p.ev_shard) ? (a.n - (u32)p.ev_shard + (u32)p.ev_nshards - 1) / (u32)p.ev_nshards : 0;
   if (own == 0) return;
   const u32 blocks = (own + epb - 1) / epb;
-  hipLaunchKernelGGL(bm_match_kernel<G>, dim3(blocks), dim3(256), (size_t)per_event * epb, s, a, p, RD, per_event);
+  hipLaunchKernelGGL(bm_match_kernel<G>, dim3(blocks), dim3(BM_BLOCK), (size_t)per_event * epb, s, a, p, RD, per_event);
 }
 
 void launch_bm_match(const BmArgs& a, const DevParams& p, hipStream_t s) {

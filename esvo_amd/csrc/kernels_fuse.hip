@@ -235,7 +235,10 @@ __global__ void __launch_bounds__(64) sort_long_lists_kernel(const u32* __restri
 }
 
 // One thread per touched cell: order the cell's record ids, then walk them (DepthFusion::fusion).
-__global__ void __launch_bounds__(256) fuse_cells_kernel(FuseArgs a, DevParams p, int K) {
+#ifndef FUSE_BLOCK
+#define FUSE_BLOCK 256
+#endif
+__global__ void __launch_bounds__(FUSE_BLOCK) fuse_cells_kernel(FuseArgs a, DevParams p, int K) {
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= *a.n_touched) return;
   const int cell = (int)a.cell_list[t];
@@ -331,7 +334,7 @@ void launch_fuse(const FuseArgs& a, const DevParams& p, hipStream_t s) {
                      a.cell_list, ncell, p.cband_y0, p.cband_y1, p.W);
   hipLaunchKernelGGL(sort_long_lists_kernel, dim3(8192), dim3(64), 0, s, a.cell_list, a.bucket + FUSE_NB + 3, a.cell_count,
                      a.cell_offset, a.rec_ids);
-  hipLaunchKernelGGL(fuse_cells_kernel, dim3(nb), dim3(256), 0, s, a, p, K);
+  hipLaunchKernelGGL(fuse_cells_kernel, dim3((ncell + FUSE_BLOCK - 1) / FUSE_BLOCK), dim3(FUSE_BLOCK), 0, s, a, p, K);
 }
 
 // ---- SmartGrid::clean ---------------------------------------------------------------------------
@@ -415,12 +418,15 @@ __global__ void __launch_bounds__(256) reg_view_kernel(const MapCell* __restrict
 // mask.  Output per element: the neighbour counts and one mask of close taps per row -- rows in order, bits in
 // order = the reference's row-major tap order, which is all pass B needs.  With G = 64 the element is
 // wave-uniform and the row bookkeeping runs on the scalar unit.
+#ifndef SCAN_BLOCK
+#define SCAN_BLOCK 256
+#endif
 template <int G>
-__global__ void __launch_bounds__(256) reg_scan_kernel(const MapCell* __restrict__ map, const u64* __restrict__ vbits,
+__global__ void __launch_bounds__(SCAN_BLOCK) reg_scan_kernel(const MapCell* __restrict__ map, const u64* __restrict__ vbits,
                                                        const double2* __restrict__ ab, const u32* __restrict__ elem_list,
                                                        const u32* __restrict__ n_elems, u64* __restrict__ masks,
                                                        u32* __restrict__ counts, DevParams p) {
-  u32 e = (blockIdx.x * 256 + threadIdx.x) / G;
+  u32 e = (blockIdx.x * SCAN_BLOCK + threadIdx.x) / G;
   if (G == 64) e = (u32)__builtin_amdgcn_readfirstlane((int)e);
   const int dc = threadIdx.x % G;
   const int gsh = (threadIdx.x & 63) / G * G;  // first lane of the group inside the wave
@@ -565,8 +571,8 @@ void launch_reg_view(const MapCell* map_in, MapCell* map_out, u32* owner_max, u3
 template <int G>
 static void launch_reg_scan_g(const MapCell* map_in, const u64* vbits, const double2* ab, const u32* elem_list, const u32* n_elems,
                               u64* masks, u32* counts, u32 max_elems, const DevParams& p, hipStream_t s) {
-  const u32 per_block = 256 / G;
-  hipLaunchKernelGGL(reg_scan_kernel<G>, dim3((max_elems + per_block - 1) / per_block), dim3(256), 0, s, map_in, vbits, ab,
+  const u32 per_block = SCAN_BLOCK / G;
+  hipLaunchKernelGGL(reg_scan_kernel<G>, dim3((max_elems + per_block - 1) / per_block), dim3(SCAN_BLOCK), 0, s, map_in, vbits, ab,
                      elem_list, n_elems, masks, counts, p);
 }
 void launch_reg_apply(const MapCell* map_in, MapCell* map_out, const u32* owner_max, const u32* owner_min, const u64* vbits,
