@@ -54,8 +54,8 @@ void launch_shard_keep_flags(const uint8_t* codes, const u32* prefix_f, const u3
                      keep_by_slot);
 }
 
-// frame[0, K) <- 0, then the own points at their final indices (one launch: the zeroing threads and the
-// placing threads never touch the same words only if ordered, so they are two kernels)
+// frame[0, K) <- 0, then the own points at their final indices: two kernels, because the zeroing must be complete
+// before any point is placed (K is only known on the device, so a hipMemsetAsync cannot be sized by the host)
 __global__ void __launch_bounds__(256) shard_zero_frame_kernel(unsigned long long* __restrict__ words, const u32* __restrict__ n_points,
                                                                u32 frame_cap) {
   u32 K = *n_points;
