@@ -295,7 +295,8 @@ __device__ inline double lm_lmpar2(double r, double diag, double qtf, double del
 }
 
 #ifndef LM_WAVES
-#define LM_WAVES 3  // waves per SIMD: 4 (<= 128 VGPRs) spills 71 registers into the solver loop and is slower
+#define LM_WAVES 2  // waves per SIMD.  2: 175 VGPRs, nothing spilled, kernel 3 % faster than 3 (166 VGPRs, 2 VGPRs + 63
+                    // SGPRs spilled) in interleaved same-box runs; 4 (<= 128 VGPRs) spills 71 registers into the solver loop: 1.7x slower
 #endif
 #ifndef LM_BLOCK
 #define LM_BLOCK 64   // threads per workgroup (no LDS, no barriers).  One wave per workgroup: a finished wave's slot is
