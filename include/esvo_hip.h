@@ -168,9 +168,11 @@ typedef struct esvo_stats_t {
   uint32_t last_map_size;       /* DepthMap::size() after clean/regularisation */
   float ms_ts_scatter, ms_ts_render;
   float ms_bm, ms_refine, ms_fusion, ms_regularization, ms_tick_total;
-  /* HIP-event time of single kernels of the last tick (for roofline accounting):
+  /* HIP-event time of single kernels / stages of the last tick (for roofline accounting):
    * [0] ts_scatter [1] ts_decay+median_remap [2] bm_match [3] lm_refine
-   * [4] propagate+bucket+fuse_cells [5] clean [6] regularize [7] reserved */
+   * [4] propagate+bucket+fuse_cells [5] clean [6] regularize [7] reserved.
+   * The front stage ([0]-[3]) and the back stage ([4]-[6]) of consecutive ticks run on two streams at the same
+   * time, so the values are not additive and each includes the slowdown from the other stream's kernels. */
   float ms_kernel[8];
   float pad_;
   /* Running totals over all ticks since esvo_create / esvo_reset.  A throughput loop reads them once at its
