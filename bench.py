@@ -329,6 +329,16 @@ def cpu_baseline(rig, stream, p, ticks, first):
     t0 = time.perf_counter()
     m.tick(sample)
     t_map = time.perf_counter() - t0
+    # the reference's own threading: NUM_THREAD_MAPPING = 4 (esvo_core/include/esvo_core/tools/utils.h:36), on a smaller sample
+    ref_threads = 4
+    small = sample[: max(len(sample) // 8, 1)]
+    m4 = oracle.OracleMapper(p, rig, fast=fast)
+    m4.set_threads(ref_threads)
+    m4.set_observation(t, l, r, T)
+    m4.set_poses(stamps, poses)
+    t0 = time.perf_counter()
+    m4.tick(small)
+    t_map4 = time.perf_counter() - t0
     return {
         "value": len(sample) / (t_map + t_ts),
         "unit": "events/s",
@@ -337,6 +347,9 @@ def cpu_baseline(rig, stream, p, ticks, first):
         "sample": f"1 tick, {len(sample)} events block-matched (+ both TS renders {t_ts * 1e3:.0f} ms); "
                   f"BM+LM on {cores} threads, fusion/regularisation single-threaded as in the reference; "
                   f"mapper {t_map:.2f} s",
+        "reference_threading": {"value": len(small) / t_map4, "unit": "events/s", "cores": ref_threads,
+                                "sample": f"mapper only (no TS render): {len(small)} events, BM+LM on the reference's {ref_threads} "
+                                          f"threads, {t_map4:.2f} s"},
     }
 
 
