@@ -54,6 +54,39 @@ def make(name, rig_name, preset, n_points, rho, seed, n_ticks, n_events, speed=1
           [len(out[f"map{k}"]) for k in range(n_ticks)])
 
 
+def make_track(name, base):
+    """tracker residual / Jacobian vectors (RegProblemLM.cpp) on the last tick of an existing mapper fixture: the local map's
+    point cloud as reference, that tick's left Time Surface as current frame, a small warp"""
+    g = np.load(os.path.join(HERE, base + ".npz"))
+    rig = calib.dataset_rig(str(g["rig"]))
+    k = int(g["n_ticks"]) - 1
+    mp, T = g[f"map{k}"], np.asarray(g[f"T{k}"], np.float64).reshape(4, 4)
+    xyz = (mp["p_cam"] @ T[:3, :3].T + T[:3, 3]).astype(np.float32)     # publishPointCloud, esvo_Mapping.cpp:925-932
+    rng = np.random.default_rng(20250503)
+    xyz = xyz[rng.permutation(len(xyz))][:2000]
+    c = np.array([0.004, -0.003, 0.002])
+    kk = 1 + c @ c
+    R_ = np.array([[1 + c[0]**2 - c[1]**2 - c[2]**2, 2 * (c[0] * c[1] - c[2]), 2 * (c[0] * c[2] + c[1])],
+                   [2 * (c[0] * c[1] + c[2]), 1 - c[0]**2 + c[1]**2 - c[2]**2, 2 * (c[1] * c[2] - c[0])],
+                   [2 * (c[0] * c[2] - c[1]), 2 * (c[1] * c[2] + c[0]), 1 - c[0]**2 - c[1]**2 + c[2]**2]]) / kk
+    t_ = np.array([0.01, -0.005, 0.008])
+    Tw = np.eye(4)
+    Tw[:3, :3] = R_.T
+    Tw[:3, 3] = -R_.T @ t_
+    trk = O.OracleTracker(rig)
+    trk.set_current(g[f"tsL{k}"], 5)
+    trk.set_reference(xyz, T)
+    neg, du, dv = trk.images()
+    out = dict(rig=str(g["rig"]), tsL=g[f"tsL{k}"], xyz=xyz, T_world_ref=T, T_left_ref=Tw, R=R_, t=t_, neg=neg, du=du, dv=dv,
+               fvec_huber=trk.residuals(Tw, 0, 300, huber=True, huber_threshold=50.0),
+               fvec_l2=trk.residuals(Tw, 300, 300, huber=False), fjac=trk.jacobian(R_, t_, 0, 300))
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(name, os.path.getsize(path) // 1024, "KiB", len(xyz), "points,", int((out["fvec_l2"] < 255).sum()), "of 300 reproject")
+
+
 if __name__ == "__main__":
-    make("upenn_small", "upenn", "mvstereo_upenn", 5000, (0.16, 1.0), 20250501, 3, 600)
-    make("dsec_small", "dsec", "mapping_dsec", 8000, (0.02, 0.25), 20250502, 2, 600, speed=2.0)
+    if "--track-only" not in sys.argv:
+        make("upenn_small", "upenn", "mvstereo_upenn", 5000, (0.16, 1.0), 20250501, 3, 600)
+        make("dsec_small", "dsec", "mapping_dsec", 8000, (0.02, 0.25), 20250502, 2, 600, speed=2.0)
+    make_track("track_small", "upenn_small")
