@@ -214,6 +214,31 @@ _DATASETS = {
         P_r=[199.6530123165822, 0.0, 177.43276376280926, -19.941771812941038, 0.0, 199.6530123165822,
              126.81215684365904, 0.0, 0.0, 0.0, 1.0, 0.0],
     ),
+    "rpg": dict(  # DAVIS240C pair, esvo_core/calib/rpg/{left,right}.yaml
+        width=240, height=180, model="plumb_bob",
+        K_l=[196.639, 0, 105.064, 0, 196.733, 72.4717, 0.0, 0.0, 1.0],
+        D_l=[-0.336733, 0.111789, -0.00140053, -0.000459594],
+        R_l=[0.999791, -0.018779, -0.00802416, 0.0187767, 0.999824, -0.000360707, 0.00802952, 0.000209964, 0.999968],
+        P_l=[156.925, 0, 108.167, 0, 0, 156.925, 78.4205, 0, 0, 0, 1, 0],
+        K_r=[196.426, 0, 110.745, 0, 196.564, 88.1131, 0.0, 0.0, 1.0],
+        D_r=[-0.346294, 0.12772, -0.000272051, -0.000195801],
+        R_r=[0.999589, 0.0222217, -0.0181009, -0.0222166, 0.999753, 0.000486491, 0.0181073, -8.41512e-05, 0.999836],
+        P_r=[156.925, 0, 108.167, -23.2327, 0, 156.925, 78.4205, 0, 0, 0, 1, 0],
+    ),
+    "hkust": dict(  # DAVIS346 pair, esvo_core/calib/hkust/{left,right}.yaml (the right camera_matrix's last row is
+        # not [0 0 1] in the shipped file; OpenCV reads fx, fy, cx, cy only)
+        width=346, height=260, model="plumb_bob",
+        K_l=[263.796, 0, 176.994, 0, 263.738, 124.373, 0, 0, 1],
+        D_l=[-0.386589, 0.157241, 0.000322143, 6.13759e-06],
+        R_l=[0.999809, 0.0161928, 0.0109163, -0.0162088, 0.999868, 0.0013701, -0.0108927, -0.00154678, 0.999939],
+        P_l=[189.705, 0, 165.382, 0, 0, 189.705, 121.295, 0, 0, 0, 1, 0],
+        K_r=[263.485, 0, 162.942, 0, 263.276, 118.029, -0.0151344, 0.00133093, 0.999885],
+        D_r=[-0.383425, 0.152823, -0.000257745, 0.000268432],
+        R_r=[0.9993960957463914, 0.0034732142808621717, -0.03457427641222047,
+             -0.0035085878889783376, 0.9999933816804096, -0.0009625000798637905,
+             0.03457070461958685, 0.0010832257094615543, 0.9994016675011942],
+        P_r=[189.705, 0, 165.382, -13.8634, 0, 189.705, 121.295, 0, 0, 0, 1, 0],
+    ),
     "dsec": dict(
         width=640, height=480, model="plumb_bob",
         K_l=[553.469, 0, 346.653, 0, 553.399, 216.521, 0, 0, 1],
@@ -229,8 +254,8 @@ _DATASETS = {
 
 
 def dataset_rig(name):
-    """Real-distortion rig of a shipped dataset ('upenn' 346x260 equidistant, 'dsec' 640x480
-    plumb_bob), values from esvo_core/calib/<name>/{left,right}.yaml; 'hd' is SURVEY.md §8's synthetic
+    """Real-distortion rig of a shipped dataset ('upenn' 346x260 equidistant, 'rpg' 240x180, 'hkust' 346x260 and
+    'dsec' 640x480 plumb_bob), values from esvo_core/calib/<name>/{left,right}.yaml; 'hd' is SURVEY.md §8's synthetic
     1280x720 stress rig (ideal, f = 1000 px, baseline 0.3 m)."""
     if name == "hd":
         return ideal_rig(1280, 720, 1000.0, 0.3, name="hd")

@@ -51,6 +51,14 @@ PRESETS = {
         Regularization=True, RegularizationRadius=5, RegularizationMinNeighbours=8,
         RegularizationMinCloseNeighbours=8, PROCESS_EVENT_NUM=1000, BM_min_disparity=1, BM_max_disparity=40,
         BM_step=1, BM_ZNCC_Threshold=0.1, node="mvstereo"),
+    "mapping_rpg": dict(  # cfg/mapping/mapping_rpg.yaml (`Lnorm` is misspelt there -> code default Tdist)
+        patch_size_X=15, patch_size_Y=7, LSnorm="Tdist", Tdist_nu=2.1897, Tdist_scale=16.6397,
+        invDepth_min_range=0.2, invDepth_max_range=2.0, residual_vis_threshold=20, stdVar_vis_threshold=0.015,
+        age_max_range=10, age_vis_threshold=1, fusion_radius=0, FUSION_STRATEGY="CONST_POINTS",
+        maxNumFusionFrames=40, maxNumFusionPoints=5000, Denoising=True, SmoothTimeSurface=False,
+        Regularization=True, RegularizationRadius=5, RegularizationMinNeighbours=8,
+        RegularizationMinCloseNeighbours=8, PROCESS_EVENT_NUM=1000, BM_min_disparity=1, BM_max_disparity=40,
+        BM_step=1, BM_ZNCC_Threshold=0.1, node="mapping"),
     "mapping_hkust": dict(
         patch_size_X=15, patch_size_Y=7, LSnorm="Tdist", Tdist_nu=2.1897, Tdist_scale=16.6397,
         invDepth_min_range=0.25, invDepth_max_range=2.0, residual_vis_threshold=20, stdVar_vis_threshold=0.15,

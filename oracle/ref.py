@@ -1,0 +1,242 @@
+"""ctypes bindings of oracle/_ref/libesvo_ref.so (TEST INFRASTRUCTURE ONLY).
+
+libesvo_ref.so is the REFERENCE's own mapper code -- esvo_core/src/{container/DepthPoint, container/CameraSystem,
+core/EventBM, core/DepthProblem, core/DepthProblemSolver, core/DepthFusion, core/DepthRegularization}.cpp and
+SmartGrid.h, compiled unmodified where they lie under /root/reference against the stand-in headers of
+oracle/ref_shim/ (oracle/Makefile, target `ref`).  It exists only in the build container (no /root/reference on the
+GPU box): tests/golden/make_ref_fixtures.py records its outputs, tests/test_ref_pin.py compares the oracle with them.
+
+RefMapper has the interface of oracle.OracleMapper, so one script drives both.
+"""
+import ctypes as C
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+
+from esvo_amd.abi import DEPTH_POINT_DTYPE, EVENT_DTYPE, MATCH_DTYPE, ParamsStruct
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+REFERENCE = os.environ.get("ESVO_REFERENCE", "/root/reference")
+_LIB = os.path.join(_HERE, "_ref", "libesvo_ref.so")
+
+
+def available():
+    """True when the library is built or can be built here (the reference tree is present)."""
+    return os.path.exists(_LIB) or os.path.isdir(os.path.join(REFERENCE, "esvo_core", "src"))
+
+
+def build():
+    subprocess.check_call(["make", "-C", _HERE, "ref", "REF=" + REFERENCE], stdout=subprocess.DEVNULL)
+    return _LIB
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if os.path.isdir(os.path.join(REFERENCE, "esvo_core", "src")):
+        build()  # make tracks the dependencies
+    lib = C.CDLL(_LIB)
+    vp, u64, sz, dbl, i32, u32 = C.c_void_p, C.c_uint64, C.c_size_t, C.c_double, C.c_int, C.c_uint32
+    lib.ref_mapper_create.restype = vp
+    lib.ref_mapper_create.argtypes = [C.c_char_p, vp, vp, vp]
+    lib.ref_mapper_destroy.argtypes = [vp]
+    lib.ref_mapper_reset.argtypes = [vp]
+    lib.ref_mapper_set_params.argtypes = [vp, vp]
+    lib.ref_mapper_baseline.restype = dbl
+    lib.ref_mapper_baseline.argtypes = [vp]
+    lib.ref_cam2world.argtypes = [vp, vp, dbl, vp]
+    lib.ref_world2cam.argtypes = [vp, i32, vp, vp]
+    lib.ref_get_lut_mask.argtypes = [vp, vp, vp]
+    lib.ref_mapper_set_observation.argtypes = [vp, u64, vp, vp, vp]
+    lib.ref_mapper_set_poses.argtypes = [vp, vp, vp, sz]
+    lib.ref_mapper_match.restype = sz
+    lib.ref_mapper_match.argtypes = [vp, vp, sz, vp, sz]
+    lib.ref_mapper_refine.restype = sz
+    lib.ref_mapper_refine.argtypes = [vp, vp, sz, i32, vp, sz]
+    lib.ref_mapper_eval_residual.restype = i32
+    lib.ref_mapper_eval_residual.argtypes = [vp, vp, u32, dbl, vp]
+    lib.ref_mapper_solve_single.restype = i32
+    lib.ref_mapper_solve_single.argtypes = [vp, vp, u32, dbl, vp]
+    lib.ref_zncc_cost.restype = dbl
+    lib.ref_zncc_cost.argtypes = [vp, vp, i32, i32]
+    lib.ref_mapper_push_frame.argtypes = [vp, vp, sz, vp, sz]
+    lib.ref_mapper_fuse.restype = sz
+    lib.ref_mapper_fuse.argtypes = [vp]
+    lib.ref_mapper_tick.restype = sz
+    lib.ref_mapper_tick.argtypes = [vp, vp, sz]
+    lib.ref_mapper_map_size.restype = sz
+    lib.ref_mapper_map_size.argtypes = [vp]
+    lib.ref_mapper_get_map.restype = sz
+    lib.ref_mapper_get_map.argtypes = [vp, vp, sz]
+    lib.ref_mapper_get_map_cells.restype = sz
+    lib.ref_mapper_get_map_cells.argtypes = [vp, vp, sz]
+    lib.ref_mapper_get_last_frame.restype = sz
+    lib.ref_mapper_get_last_frame.argtypes = [vp, vp, sz]
+    lib.ref_mapper_counters.argtypes = [vp, vp]
+    lib.ref_update_student_t.argtypes = [vp, dbl, dbl, dbl, dbl]
+    _lib = lib
+    return lib
+
+
+def _yaml_camera(path, name, intr, T_right_left):
+    """One camera file in the format CameraSystem::loadCalibInfo reads (CameraSystem.cpp:168-212)."""
+    fmt = lambda a: "[" + ", ".join(repr(float(v)) for v in np.asarray(a, np.float64).reshape(-1)) + "]"
+    with open(path, "w") as f:
+        f.write(f"image_width: {int(intr['width'])}\nimage_height: {int(intr['height'])}\ncamera_name: {name}\n")
+        f.write(f"camera_matrix:\n  rows: 3\n  cols: 3\n  data: {fmt(intr['K'])}\n")
+        f.write(f"distortion_model: {intr['model']}\n")
+        f.write(f"distortion_coefficients:\n  rows: 1\n  cols: 4\n  data: {fmt(np.asarray(intr['D'])[:4])}\n")
+        f.write(f"rectification_matrix:\n  rows: 3\n  cols: 3\n  data: {fmt(intr['R'])}\n")
+        f.write(f"projection_matrix:\n  rows: 3\n  cols: 4\n  data: {fmt(intr['P'])}\n")
+        f.write(f"T_right_left:\n  rows: 3\n  cols: 4\n  data: {fmt(T_right_left)}\n")
+
+
+def write_calib_dir(rig, path):
+    T = np.hstack([np.eye(3), np.array([[-rig.baseline], [0.0], [0.0]])])  # read, never used on the mapper path
+    _yaml_camera(os.path.join(path, "left.yaml"), rig.name + "_left", rig.intr_left, T)
+    _yaml_camera(os.path.join(path, "right.yaml"), rig.name + "_right", rig.intr_right, T)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data
+
+
+class RefMapper:
+    """The reference's EventBM + DepthProblemSolver + DepthFusion + DepthRegularization + DepthMap, driven in
+    MappingAtTime's order (esvo_Mapping.cpp:261-431)."""
+
+    def __init__(self, params: ParamsStruct, rig):
+        self.lib = load()
+        self.rig, self.params = rig, params
+        self._cl, self._cr = rig.left.as_struct(), rig.right.as_struct()
+        with tempfile.TemporaryDirectory() as d:
+            write_calib_dir(rig, d)
+            self.h = self.lib.ref_mapper_create(d.encode(), C.addressof(params), C.addressof(self._cl), C.addressof(self._cr))
+        self.W, self.H = rig.width, rig.height
+        self._poses = None
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.ref_mapper_destroy(self.h)
+            self.h = None
+
+    def reset(self):
+        self.lib.ref_mapper_reset(self.h)
+
+    def set_params(self, params):
+        self.params = params
+        self.lib.ref_mapper_set_params(self.h, C.addressof(params))
+
+    @property
+    def baseline(self):
+        return self.lib.ref_mapper_baseline(self.h)
+
+    def cam2world(self, x, inv_depth):
+        x = np.ascontiguousarray(x, np.float64)
+        p = np.empty(3, np.float64)
+        self.lib.ref_cam2world(self.h, x.ctypes.data, float(inv_depth), p.ctypes.data)
+        return p
+
+    def world2cam(self, p, right=False):
+        p = np.ascontiguousarray(p, np.float64)
+        x = np.empty(2, np.float64)
+        self.lib.ref_world2cam(self.h, int(right), p.ctypes.data, x.ctypes.data)
+        return x
+
+    def lut_mask(self):
+        lut = np.empty((self.H, self.W, 2), np.float64)
+        mask = np.empty((self.H, self.W), np.int32)
+        self.lib.ref_get_lut_mask(self.h, lut.ctypes.data, mask.ctypes.data)
+        return lut, mask
+
+    def set_observation(self, t_ns, ts_left, ts_right, T_world_cam):
+        l = np.ascontiguousarray(ts_left, np.uint8)
+        r = np.ascontiguousarray(ts_right, np.uint8)
+        T = np.ascontiguousarray(T_world_cam, np.float64).reshape(16)
+        self.lib.ref_mapper_set_observation(self.h, int(t_ns), l.ctypes.data, r.ctypes.data, T.ctypes.data)
+
+    def set_poses(self, stamps, poses):
+        st = np.ascontiguousarray(stamps, np.uint64)
+        T = np.ascontiguousarray(poses, np.float64).reshape(-1, 16)
+        self._poses = T
+        self.lib.ref_mapper_set_poses(self.h, st.ctypes.data, T.ctypes.data, st.shape[0])
+
+    def match(self, ev):
+        ev = np.ascontiguousarray(ev, dtype=EVENT_DTYPE)
+        out = np.zeros(max(ev.shape[0], 1), MATCH_DTYPE)
+        n = self.lib.ref_mapper_match(self.h, ev.ctypes.data, ev.shape[0], out.ctypes.data, out.shape[0])
+        return out[:n]
+
+    def refine(self, matches, cull=True):
+        m = np.ascontiguousarray(matches, dtype=MATCH_DTYPE)
+        out = np.zeros(max(m.shape[0], 1), DEPTH_POINT_DTYPE)
+        n = self.lib.ref_mapper_refine(self.h, m.ctypes.data, m.shape[0], int(cull), out.ctypes.data, out.shape[0])
+        return out[:n]
+
+    def eval_residual(self, x_left, pose_idx, rho):
+        x = np.ascontiguousarray(x_left, np.float64)
+        f = np.empty(self.params.patch_size_x * self.params.patch_size_y, np.float64)
+        ok = self.lib.ref_mapper_eval_residual(self.h, x.ctypes.data, int(pose_idx), float(rho), f.ctypes.data)
+        return f, ok
+
+    def solve_single(self, x_left, pose_idx, d_init):
+        x = np.ascontiguousarray(x_left, np.float64)
+        res = np.zeros(3, np.float64)
+        ok = self.lib.ref_mapper_solve_single(self.h, x.ctypes.data, int(pose_idx), float(d_init), res.ctypes.data)
+        return res, bool(ok)
+
+    def push_frame(self, pts, poses=None):
+        pts = np.ascontiguousarray(pts, dtype=DEPTH_POINT_DTYPE)
+        T = self._poses if poses is None else np.ascontiguousarray(poses, np.float64).reshape(-1, 16)
+        self.lib.ref_mapper_push_frame(self.h, pts.ctypes.data, pts.shape[0], T.ctypes.data, T.shape[0])
+
+    def fuse(self):
+        return self.lib.ref_mapper_fuse(self.h)
+
+    def tick(self, ev):
+        ev = np.ascontiguousarray(ev, dtype=EVENT_DTYPE)
+        return self.lib.ref_mapper_tick(self.h, ev.ctypes.data, ev.shape[0])
+
+    def get_map(self):
+        n = self.lib.ref_mapper_map_size(self.h)
+        out = np.zeros(max(n, 1), DEPTH_POINT_DTYPE)
+        n = self.lib.ref_mapper_get_map(self.h, out.ctypes.data, out.shape[0])
+        return out[:n]
+
+    def get_map_cells(self):
+        n = self.lib.ref_mapper_map_size(self.h)
+        out = np.zeros(max(n, 1), np.int32)
+        n = self.lib.ref_mapper_get_map_cells(self.h, out.ctypes.data, out.shape[0])
+        return out[:n]
+
+    def get_last_frame(self):
+        cap = max(int(self.params.max_events_per_tick), 1)
+        out = np.zeros(cap, DEPTH_POINT_DTYPE)
+        n = self.lib.ref_mapper_get_last_frame(self.h, out.ctypes.data, cap)
+        return out[:n]
+
+    def counters(self):
+        c = np.zeros(8, np.uint64)
+        self.lib.ref_mapper_counters(self.h, c.ctypes.data)
+        return dict(window_frames=int(c[0]), window_points=int(c[1]), dangling_cells=int(c[2]))
+
+
+def zncc_cost(l, r):
+    lib = load()
+    l = np.ascontiguousarray(l, np.float64)
+    r = np.ascontiguousarray(r, np.float64)
+    return lib.ref_zncc_cost(l.ctypes.data, r.ctypes.data, l.shape[1], l.shape[0])
+
+
+def update_student_t(state, inv_depth, scale2, variance, nu):
+    """DepthPoint::update_studentT on state = (invDepth, scale2, nu, variance, age); returns the new state."""
+    lib = load()
+    s = np.array(state, np.float64)
+    lib.ref_update_student_t(s.ctypes.data, float(inv_depth), float(scale2), float(variance), float(nu))
+    return s

@@ -1,0 +1,1 @@
+// oracle/_ref build shim: nothing from this header is used by the mapper sources that are compiled.

@@ -1,0 +1,117 @@
+#!/usr/bin/env python
+"""Generates tests/golden/ref_*.npz from oracle/_ref/libesvo_ref.so -- the REFERENCE's own mapper sources
+(EventBM, DepthProblem, DepthProblemSolver, DepthFusion, DepthRegularization, DepthPoint, SmartGrid, CameraSystem)
+compiled unmodified from /root/reference against the stand-in headers of oracle/ref_shim/ (see oracle/Makefile,
+oracle/ref_harness.cpp).  Runs only where /root/reference exists (the build container); the fixtures travel.
+
+What the fixtures pin, and what they cannot:
+  * pinned to reference source: block matching (event rejection tests, ZNCC cost, argmin/tie rule, thread-stride
+    order), the residual functor DepthProblem::operator() (warping, bilinear patches, Student-t scale loop), the
+    solver's driver loop / DepthPoint initialisation / culling, DepthPoint::update_studentT, propagation, fusion
+    (incl. the replace branch), SmartGrid::clean / getNeighbourhood, the regulariser;
+  * still restated third-party arithmetic (not in /root/reference): Eigen's LevenbergMarquardt/NumericalDiff (the
+    stand-in is a second, independent MINPACK restatement), Eigen's 4x4 inverse (cofactor form in the stand-in),
+    OpenCV's calibration maps / remap / median / Gaussian (inputs here, computed by esvo_amd/calib.py and the oracle).
+
+    python tests/golden/make_ref_fixtures.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import scenarios as S  # noqa: E402
+from oracle import ref as R  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def run_reference(sc, ticks):
+    """-> (per-tick outputs, unit vectors) of the reference code on a scenario's inputs"""
+    m = R.RefMapper(sc.params, sc.rig)
+    out = []
+    unit = {}
+    rng = np.random.default_rng(sc.spec["seed"] + 7)
+    for k, tk in enumerate(ticks):
+        m.set_observation(tk["t"], tk["tsL"], tk["tsR"], tk["T"])
+        m.set_poses(tk["stamps"], tk["poses"])
+        mt = m.match(tk["ev"])
+        pts = m.refine(mt, cull=True)
+        if k == 0 and len(mt):
+            # residual vectors of DepthProblem::operator() and single-problem solutions on a sample of matches
+            pick = rng.choice(len(mt), size=min(40, len(mt)), replace=False)
+            rho = mt["inv_depth"][pick] * (1 + 2e-3 * rng.standard_normal(len(pick)))
+            rho[::4] = mt["inv_depth"][pick][::4]
+            fv = np.stack([m.eval_residual(mt["x_left"][i], mt["pose_idx"][i], r)[0] for i, r in zip(pick, rho)])
+            sol = [m.solve_single(mt["x_left"][i], mt["pose_idx"][i], mt["inv_depth"][i]) for i in pick]
+            unit.update(res_pick=pick, res_rho=rho, res_fvec=fv, sol_result=np.stack([s[0] for s in sol]),
+                        sol_ok=np.array([s[1] for s in sol]))
+        m.push_frame(pts, tk["poses"])
+        nf = m.fuse()
+        out.append(dict(matches=mt, points=pts, nf=nf, map=m.get_map(), cells=m.get_map_cells()))
+    # cam2World / world2Cam samples (CameraSystem.cpp:121-148)
+    xs = rng.uniform([0, 0], [sc.rig.width, sc.rig.height], size=(64, 2))
+    rhos = rng.uniform(sc.params.invdepth_min, sc.params.invdepth_max, 64)
+    pc = np.stack([m.cam2world(x, r) for x, r in zip(xs, rhos)])
+    unit.update(c2w_x=xs, c2w_rho=rhos, c2w_p=pc, w2c_left=np.stack([m.world2cam(p) for p in pc]),
+                w2c_right=np.stack([m.world2cam(p, right=True) for p in pc]), baseline=m.baseline,
+                dangling=m.counters()["dangling_cells"])
+    return out, unit
+
+
+def make(name):
+    sc = S.Scenario(name)
+    ticks = sc.inputs()
+    res, unit = run_reference(sc, ticks)
+    out = dict(scenario=name, n_ticks=len(ticks), smooth=int(sc.params.smooth_time_surface))
+    for k, (tk, r) in enumerate(zip(ticks, res)):
+        # the un-smoothed pair is stored; consumers re-apply GaussianBlurTS(5) where the preset asks for it
+        out.update({f"t{k}": tk["t"], f"tsL{k}": tk["raw"][0], f"tsR{k}": tk["raw"][1], f"T{k}": tk["T"],
+                    f"stamps{k}": tk["stamps"], f"poses{k}": tk["poses"], f"ev{k}": tk["ev"],
+                    f"matches{k}": r["matches"], f"points{k}": r["points"], f"nf{k}": r["nf"], f"map{k}": r["map"],
+                    f"cells{k}": r["cells"]})
+    out.update({"u_" + k: v for k, v in unit.items()})
+    path = os.path.join(HERE, f"ref_{name}.npz")
+    np.savez_compressed(path, **out)
+    print(name, os.path.getsize(path) // 1024, "KiB", [(len(r["matches"]), len(r["points"]), r["nf"], len(r["map"])) for r in res],
+          "dangling", unit["dangling"])
+
+
+def make_units():
+    """DepthPoint::update_studentT (DepthPoint.cpp:167-188) and EventBM::zncc_cost (EventBM.cpp:317-333, utils.h:74-92) on
+    random inputs"""
+    rng = np.random.default_rng(20250601)
+    states, obs, new = [], [], []
+    for _ in range(400):
+        fresh = rng.random() < 0.2
+        st = np.array([-1.0, 0, 0, 0, 0]) if fresh else np.array(
+            [rng.uniform(0.05, 2), rng.uniform(1e-6, 1e-2), rng.uniform(2.1, 12), 0.0, rng.integers(0, 9)])
+        if not fresh:
+            st[3] = st[2] / (st[2] - 2) * st[1]
+        nu = rng.uniform(2.1, 12)
+        s2 = rng.uniform(1e-6, 1e-2)
+        ob = np.array([rng.uniform(0.05, 2), s2, nu / (nu - 2) * s2, nu])
+        states.append(st)
+        obs.append(ob)
+        new.append(R.update_student_t(st, *ob))
+    patches_l = rng.integers(0, 256, size=(200, 7, 15)).astype(np.float64)
+    patches_r = np.clip(patches_l + rng.normal(0, 25, size=patches_l.shape), 0, 255).round()
+    patches_l[:5] = 0          # flat patches: sigma = 1e-6 (utils.h:80)
+    patches_r[5:10] = 17
+    cost = np.array([R.zncc_cost(l, r) for l, r in zip(patches_l, patches_r)])
+    path = os.path.join(HERE, "ref_units.npz")
+    np.savez_compressed(path, st_state=np.stack(states), st_obs=np.stack(obs), st_new=np.stack(new),
+                        zncc_l=patches_l.astype(np.uint8), zncc_r=patches_r.astype(np.uint8), zncc_cost=cost)
+    print("units", os.path.getsize(path) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    assert R.available(), "needs /root/reference (build container only)"
+    names = [a for a in sys.argv[1:] if not a.startswith("-")] or list(S.SCENARIOS)
+    for n in names:
+        make(n)
+    make_units()

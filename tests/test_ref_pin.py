@@ -1,0 +1,173 @@
+"""Pins the CPU oracle to REFERENCE SOURCE.
+
+tests/golden/ref_*.npz hold the outputs of oracle/_ref/libesvo_ref.so = the reference's own EventBM, DepthProblem,
+DepthProblemSolver, DepthFusion, DepthRegularization, DepthPoint, SmartGrid and CameraSystem sources compiled unmodified
+(tests/golden/make_ref_fixtures.py, oracle/ref_harness.cpp).  Here the oracle (literal mode) is checked against them
+stage by stage -- each stage is fed the REFERENCE's output of the previous one, so a tolerance never cascades:
+
+  block matching        matched set, order, disparity, pose: identical; ZNCC cost: bit-identical
+  residual functor      DepthProblem::operator(): |df| <= 1e-9 grey levels (cam2World's inverse differs in form)
+  LM refinement         same solved/culled set; inverse depth rel <= 1e-4 for all and <= 1e-6 for >= 99 % of every tick (measured
+                        over 12 840 points: median 4e-10, 99.95 % below 1e-6, worst 1.3e-5; the LM stops at xtol = 1e-6);
+                        variance rel <= 1e-3 for >= 98 % (measured 99.98 %; forward differences over the discontinuous
+                        Student-t scale loop make single variances jump; the Eigen LM itself is third-party and is
+                        restated twice, independently: n = 1 closed form in the oracle, general Householder/Givens
+                        form in oracle/ref_shim)
+  fusion/clean/regularise  every element of the DepthMap, list order, believed row/col, true cell, age, nu, inverse
+                        depth, scale, variance, residual: bit-identical; p_cam rel <= 1e-12; fusion count identical
+and end to end (the oracle's own chain): valid-set IoU >= 0.97, inverse-depth RMSE < 1e-4 on the intersection.
+Where the reference tree is present (build container) the library is also run live against the fixtures.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import scenarios as S
+from oracle import oracle as O
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+NAMES = ["upenn", "dsec", "rpg", "hkust"]
+EXACT = ["inv_depth", "scale2", "nu", "variance", "residual", "x"]
+
+
+def load_fixture(name):
+    g = np.load(os.path.join(GOLDEN, f"ref_{name}.npz"))
+    sc = S.Scenario(name)
+    ticks = []
+    for k in range(int(g["n_ticks"])):
+        raw = (g[f"tsL{k}"], g[f"tsR{k}"])
+        sm = (O.gaussian5(raw[0]), O.gaussian5(raw[1])) if int(g["smooth"]) else raw
+        ticks.append(dict(t=int(g[f"t{k}"]), raw=raw, tsL=sm[0], tsR=sm[1], T=g[f"T{k}"], stamps=g[f"stamps{k}"],
+                          poses=g[f"poses{k}"], ev=g[f"ev{k}"]))
+    return g, sc, ticks
+
+
+def same_map(mp, ref, cells=None, ref_cells=None, p_cam_rtol=1e-12):
+    assert len(mp) == len(ref)
+    for f in ("row", "col", "age"):
+        assert np.array_equal(mp[f], ref[f]), f
+    for f in EXACT:
+        assert np.array_equal(mp[f], ref[f]), f
+    assert np.allclose(mp["p_cam"], ref["p_cam"], rtol=p_cam_rtol, atol=1e-13)
+    if cells is not None:
+        assert np.array_equal(cells, ref_cells)
+
+
+def check_matches(mt, ref, cost_exact=True, cost_atol=0.0):
+    assert len(mt) == len(ref)
+    for f in ("event_idx", "pose_idx", "disp", "x_left", "inv_depth"):
+        assert np.array_equal(mt[f], ref[f]), f
+    if cost_exact:
+        assert np.array_equal(mt["cost"], ref["cost"])
+    else:
+        assert np.abs(mt["cost"] - ref["cost"]).max() <= cost_atol
+
+
+def check_points(pts, ref, rho_rtol=1e-4, rho_tight=1e-6, rho_frac=0.99, var_rtol=1e-3, var_frac=0.98):
+    assert len(pts) == len(ref)
+    if not len(ref):
+        return
+    for f in ("row", "col", "pose_idx", "age", "nu", "x"):
+        assert np.array_equal(pts[f], ref[f]), f
+    rel = np.abs(pts["inv_depth"] - ref["inv_depth"]) / ref["inv_depth"]
+    assert rel.max() <= rho_rtol and (rel <= rho_tight).mean() >= rho_frac, (rel.max(), (rel <= rho_tight).mean())
+    rel = np.abs(pts["variance"] - ref["variance"]) / np.maximum(ref["variance"], 1e-300)
+    assert (rel <= var_rtol).mean() >= var_frac, (rel <= var_rtol).mean()
+    assert np.allclose(pts["residual"], ref["residual"], rtol=1e-3)
+
+
+def map_stats(mp, ref, W):
+    """valid-set IoU over believed cells and inverse-depth RMSE on the intersection"""
+    ka = mp["row"].astype(np.int64) * W + mp["col"]
+    kb = ref["row"].astype(np.int64) * W + ref["col"]
+    da = dict(zip(ka.tolist(), mp["inv_depth"].tolist()))
+    db = dict(zip(kb.tolist(), ref["inv_depth"].tolist()))
+    both = [k for k in da if k in db and da[k] > -1e-6 and db[k] > -1e-6]
+    union = len(set(da) | set(db))
+    rmse = float(np.sqrt(np.mean([(da[k] - db[k]) ** 2 for k in both]))) if both else 0.0
+    return (len(set(da) & set(db)) / union if union else 1.0), rmse
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_oracle_stages_match_reference(name):
+    g, sc, ticks = load_fixture(name)
+    m = O.OracleMapper(sc.params, sc.rig)  # literal mode
+    for k, tk in enumerate(ticks):
+        m.set_observation(tk["t"], tk["raw"][0], tk["raw"][1], tk["T"])
+        m.set_poses(tk["stamps"], tk["poses"])
+        check_matches(m.match(tk["ev"]), g[f"matches{k}"])
+        check_points(m.refine(g[f"matches{k}"], cull=True), g[f"points{k}"])
+        m.push_frame(g[f"points{k}"], tk["poses"])
+        assert m.fuse() == int(g[f"nf{k}"])
+        same_map(m.get_map(), g[f"map{k}"], m.get_map_cells(), g[f"cells{k}"])
+    assert int(g["u_dangling"]) > 0 and m.counters()["replace_displaced"] > 0  # Appendix A-7 is exercised
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_oracle_chain_matches_reference_end_to_end(name):
+    g, sc, ticks = load_fixture(name)
+    m = O.OracleMapper(sc.params, sc.rig)
+    res = S.run_stagewise(m, ticks, pre_smoothed=False)
+    for k, r in enumerate(res):
+        iou, rmse = map_stats(r["map"], g[f"map{k}"], sc.rig.width)
+        assert iou >= 0.97 and rmse < 1e-4, (k, iou, rmse)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_oracle_units_match_reference(name):
+    g, sc, ticks = load_fixture(name)
+    m = O.OracleMapper(sc.params, sc.rig)
+    tk = ticks[0]
+    m.set_observation(tk["t"], tk["raw"][0], tk["raw"][1], tk["T"])
+    m.set_poses(tk["stamps"], tk["poses"])
+    mt = g["matches0"]
+    worst = 0.0
+    for i, rho, f_ref in zip(g["u_res_pick"], g["u_res_rho"], g["u_res_fvec"]):
+        f, _ = m.eval_residual(mt["x_left"][i], mt["pose_idx"][i], rho)
+        worst = max(worst, float(np.abs(f - f_ref).max()))
+    assert worst <= 1e-9, worst
+    assert abs(m.baseline - float(g["u_baseline"])) <= 1e-15
+    # cam2World / world2Cam through the oracle's camera: refine() on a zero-iteration problem is not exposed, so use
+    # the DepthPoint initialisation of a fused map instead: p_cam of new cells == cam2World(cell centre, rho)
+    # (DepthFusion.cpp:143-145) is covered by same_map(); here the closed form itself:
+    P = sc.rig.left.P.reshape(3, 4)
+    Kinv = np.linalg.inv(P[:, :3])
+    for x, rho, p_ref in zip(g["u_c2w_x"], g["u_c2w_rho"], g["u_c2w_p"]):
+        p = (1.0 / rho) * (Kinv @ np.array([x[0], x[1], 1.0])) - Kinv @ P[:, 3]
+        assert np.allclose(p, p_ref, rtol=1e-12, atol=1e-13)
+
+
+def test_student_t_and_zncc_units():
+    g = np.load(os.path.join(GOLDEN, "ref_units.npz"))
+    # DepthPoint::update_studentT through the oracle's fusion path is covered bit for bit by the map tests; the unit
+    # vectors pin the closed form used by every implementation here
+    for st, ob, new in zip(g["st_state"], g["st_obs"], g["st_new"]):
+        d, s2, nu, var, age = st
+        if d > -1e-6:
+            nu_u = min(ob[3], nu)
+            d_u = (ob[1] * d + s2 * ob[0]) / (s2 + ob[1])
+            s2_u = (nu_u + (d - ob[0]) ** 2 / (s2 + ob[1])) / (nu_u + 1) * (s2 * ob[1]) / (s2 + ob[1])
+            exp = np.array([d_u, s2_u, nu_u + 1, (nu_u + 1) / (nu_u + 1 - 2) * s2_u, age + 1])
+        else:
+            exp = np.array([ob[0], ob[1], ob[3], ob[2], 0.0])
+        assert np.array_equal(exp, new)
+    for l, r, c in zip(g["zncc_l"], g["zncc_r"], g["zncc_cost"]):
+        lit = O.zncc_cost(l.astype(np.float64), r.astype(np.float64), exact_int=False)
+        assert lit == c
+        assert abs(O.zncc_cost(l.astype(np.float64), r.astype(np.float64), exact_int=True) - c) <= 1e-12
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_live_reference_reproduces_fixture(name):
+    from oracle import ref as R
+    if not os.path.isdir(os.path.join(R.REFERENCE, "esvo_core", "src")):
+        pytest.skip("reference tree not present (GPU box): the fixtures are the pin")
+    g, sc, ticks = load_fixture(name)
+    r = R.RefMapper(sc.params, sc.rig)
+    res = S.run_stagewise(r, ticks, pre_smoothed=True)
+    for k, x in enumerate(res):
+        check_matches(x["matches"], g[f"matches{k}"])
+        assert np.array_equal(x["points"]["inv_depth"], g[f"points{k}"]["inv_depth"])
+        assert x["nf"] == int(g[f"nf{k}"])
+        same_map(x["map"], g[f"map{k}"], p_cam_rtol=0.0)
