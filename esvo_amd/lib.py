@@ -37,7 +37,9 @@ class EsvoError(RuntimeError):
 def build(force=False, verbose=False):
     """hipcc cross-compiles the extension for gfx950 in-tree (works without a GPU)."""
     srcs = [os.path.join(_CSRC, s) for s in _SOURCES]
-    deps = srcs + [os.path.join(_CSRC, "common.hpp"), os.path.join(_CSRC, "..", "..", "include", "esvo_hip.h")]
+    inc = os.path.join(_CSRC, "..", "..", "include")
+    deps = srcs + [os.path.join(_CSRC, f) for f in sorted(os.listdir(_CSRC)) if f.endswith(".hpp")] + [
+        os.path.join(inc, "esvo_hip.h"), os.path.join(inc, "esvo_hip.hpp")]
     if not force and os.path.exists(_LIB_PATH) and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return _LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

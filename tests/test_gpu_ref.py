@@ -1,0 +1,47 @@
+"""The HIP path against REFERENCE SOURCE: tests/golden/ref_*.npz are outputs of the reference's own mapper classes
+(oracle/_ref, see tests/test_ref_pin.py).  Each stage of the C-ABI is fed the reference's output of the previous stage:
+
+  esvo_map_match     matched set / order / disparity / pose / inverse depth identical; ZNCC cost |d| <= 1e-12 (the
+                     device forms it from exact integer moments, the reference from normalised f64 patches)
+  esvo_map_refine    same solved + culled set; inverse depth rel <= 1e-4, <= 1e-6 for >= 99 % per tick; variance rel
+                     <= 1e-3 for >= 98 %
+  esvo_map_fuse      (propagate, fuse, clean, regularise) every DepthMap element bit-identical (p_cam rel <= 1e-12)
+and the chained device run end to end: valid-set IoU >= 0.97, inverse-depth RMSE < 1e-4 vs the reference's map
+(BASELINE.json north_star: "inverse-depth RMSE vs reference < 1e-4").  All four shipped rigs: upenn 346x260 (2x2 fusion,
+CONST_POINTS), DSEC 640x480 (smoothed TS, 3x3 fusion, r = 20), rpg 240x180 and hkust 346x260 (Denoising, r = 5).
+"""
+import numpy as np
+import pytest
+
+import scenarios as S
+from test_ref_pin import NAMES, check_matches, check_points, load_fixture, map_stats, same_map
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_gpu_stages_match_reference(name):
+    from esvo_amd import lib
+    g, sc, ticks = load_fixture(name)
+    dev = lib.Esvo(sc.params, sc.rig, device=0)
+    for k, tk in enumerate(ticks):
+        dev.set_observation(tk["t"], tk["raw"][0], tk["raw"][1], tk["T"])
+        dev.set_poses(tk["stamps"], tk["poses"])
+        check_matches(dev.match(tk["ev"]), g[f"matches{k}"], cost_exact=False, cost_atol=1e-12)
+        check_points(dev.refine(g[f"matches{k}"], cull=True), g[f"points{k}"])
+        dev.push_frame(g[f"points{k}"], tk["poses"])
+        assert dev.fuse() == int(g[f"nf{k}"])
+        same_map(dev.get_map(), g[f"map{k}"])
+    dev.close()
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_gpu_chain_matches_reference_end_to_end(name):
+    from esvo_amd import lib
+    g, sc, ticks = load_fixture(name)
+    dev = lib.Esvo(sc.params, sc.rig, device=0)
+    res = S.run_stagewise(dev, ticks, pre_smoothed=False)
+    for k, r in enumerate(res):
+        iou, rmse = map_stats(r["map"], g[f"map{k}"], sc.rig.width)
+        assert iou >= 0.97 and rmse < 1e-4, (k, iou, rmse)
+    dev.close()
