@@ -252,11 +252,8 @@ int run_fuse(esvo_context* h, int par, const double* T_world_obs) {
   if (do_clean) launch_clean(h->d_map, h->dp, sb);
   hipEventRecord(h->evt[EV_CL1 + o], sb);
   if (h->prm.regularization) {
-    launch_reg_view(h->d_map, h->d_map2, h->d_owner_max, h->d_owner_min, h->d_reg_valid, h->d_reg_ab, h->d_reg_cd,
-                    h->d_cell_list, h->d_cnt_b + 7, h->dp, sb);
-    launch_reg_apply(h->d_map, h->d_map2, h->d_owner_max, h->d_owner_min, h->d_reg_valid, h->d_reg_bits, h->d_reg_counts,
-                     h->d_reg_ab, h->d_reg_cd, h->d_cell_list, h->d_cnt_b + 7,
-                     (u32)((size_t)(h->dp.band_y1 - h->dp.band_y0) * h->W), h->dp, sb);
+    launch_reg_view(h->d_map, h->d_map2, h->d_owner_max, h->d_owner_min, h->d_reg_ab, h->d_reg_cd, h->d_cnt_b + 7, h->dp, sb);
+    launch_reg_apply(h->d_map, h->d_map2, h->d_owner_max, h->d_owner_min, h->d_reg_ab, h->d_reg_cd, h->dp, sb);
     h->d_map_cur = h->d_map2;
   }
   HIPCHK(hipMemcpyAsync(h->h_cnt_b + 8 * par, h->d_cnt_b, sizeof(u32) * 8, hipMemcpyDeviceToHost, sb));

@@ -251,11 +251,10 @@ struct FuseArgs {
 };
 void launch_fuse(const FuseArgs& a, const DevParams& p, hipStream_t s);
 void launch_clean(MapCell* map, const DevParams& p, hipStream_t s);
-void launch_reg_view(const MapCell* map_in, MapCell* map_out, u32* owner_max, u32* owner_min, u64* vbits, double2* ab,
-                     double2* cd, u32* elem_list, u32* n_elems, const DevParams& p, hipStream_t s);
-void launch_reg_apply(const MapCell* map_in, MapCell* map_out, const u32* owner_max, const u32* owner_min,
-                      const u64* vbits, u64* masks, u32* counts, const double2* ab, const double2* cd,
-                      const u32* elem_list, const u32* n_elems, u32 max_elems, const DevParams& p, hipStream_t s);
+void launch_reg_view(const MapCell* map_in, MapCell* map_out, u32* owner_max, u32* owner_min, double2* ab, double2* cd,
+                     u32* n_elems, const DevParams& p, hipStream_t s);
+void launch_reg_apply(const MapCell* map_in, MapCell* map_out, const u32* owner_max, const u32* owner_min, const double2* ab,
+                      const double2* cd, const DevParams& p, hipStream_t s);
 void launch_map_compact(const MapCell* map, u32* flags, u32* prefix, u32* d_total, u32* scan_tmp,
                         esvo_depth_point_t* out, u32* out_cell, const DevParams& p, hipStream_t s);
 

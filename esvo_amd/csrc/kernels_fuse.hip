@@ -372,219 +372,231 @@ __global__ void __launch_bounds__(256) reg_owner_kernel(const MapCell* __restric
   atomicMin(&owner_min[b], c.seq);
 }
 
-// Compact "regularisation view" of the map: what the (2r+1)^2 neighbourhood scan reads.
-//   vbits : 1 bit per cell (u64 words over the linear cell index): exists(r,c) && at(r,c).valid()
-//   ab[c] : (inv_depth, 2*sqrt(variance))     -- the closeness test operands
-//   cd[c] : (nu, scale2)                      -- read only for close neighbours
-// A tap row of the neighbourhood is <= 63 consecutive bits of vbits: empty taps cost nothing, a valid tap costs
-// 16 B instead of a 104 B MapCell, and the neighbour's sqrt is computed once per cell instead of once per tap.
+// "Regularisation view" of the map: what the (2r+1)^2 neighbourhood scan reads, 32 B per cell instead of a 104 B MapCell.
+//   ab[c] : (inv_depth, 2*sqrt(variance))  -- the closeness test operands; (NaN, NaN) where the tap is not a neighbour,
+//                                             i.e. !(exists(r,c) && at(r,c).valid()): every comparison with it is false
+//   cd[c] : (nu, scale2)                   -- read only for close neighbours
+// The neighbour's sqrt is computed once per cell instead of once per tap.
 __global__ void __launch_bounds__(256) reg_view_kernel(const MapCell* __restrict__ map, MapCell* __restrict__ out,
-                                                       u64* __restrict__ vbits, double2* __restrict__ ab, double2* __restrict__ cd,
-                                                       u32* __restrict__ elem_list, u32* __restrict__ n_elems, int ncell, int W,
+                                                       double2* __restrict__ ab, double2* __restrict__ cd,
+                                                       u32* __restrict__ n_elems, int ncell, int W,
                                                        int band0, int band1, int view0, int view1) {
   const int cell = blockIdx.x * blockDim.x + threadIdx.x;
-  bool alive = false, v = false;
+  bool alive = false;
   if (cell < ncell) {
     const MapCell& n = map[cell];
     const int row = cell / W;
     if (row >= view0 && row < view1) {  // the view covers the band's halo as well (multi-GPU: computed, not exchanged)
-      v = (n.flags & CELL_ALIVE) && (n.flags & CELL_GRID) && n.inv_depth > -1e-6;
-      if (v) {
-        ab[cell] = make_double2(n.inv_depth, 2.0 * sqrt(n.variance));
-        cd[cell] = make_double2(n.nu, n.scale2);
-      }
+      const bool v = (n.flags & CELL_ALIVE) && (n.flags & CELL_GRID) && n.inv_depth > -1e-6;
+      const double nan = __longlong_as_double(0x7ff8000000000000ll);
+      ab[cell] = v ? make_double2(n.inv_depth, 2.0 * sqrt(n.variance)) : make_double2(nan, nan);
+      if (v) cd[cell] = make_double2(n.nu, n.scale2);
     }
     if (row >= band0 && row < band1) {
       alive = (n.flags & CELL_ALIVE) != 0;
       if (!alive) out[cell].flags = 0;
     }
   }
-  const int lane = threadIdx.x & 63;
-  const u64 vm = __ballot(v);
-  if (lane == 0) vbits[cell >> 6] = vm;  // a wave covers 64 consecutive cells; words past the image read as 0
-  // compact the alive elements (apply kernel: one thread per element, full waves); order is free
-  const u64 am = __ballot(alive);
-  u32 base = 0;
-  if (lane == 0 && am) base = atomicAdd(n_elems, (u32)__popcll(am));
-  base = __shfl(base, 0, 64);
-  if (alive) elem_list[base + (u32)__popcll(am & ((1ull << lane) - 1ull))] = (u32)cell;
+  const u64 am = __ballot(alive);  // number of elements of the band (a statistic)
+  if ((threadIdx.x & 63) == 0 && am) atomicAdd(n_elems, (u32)__popcll(am));
 }
 
-// ---- regulariser pass A: neighbourhood scan, G lanes per element, lane = tap column ---------------------
-// Row dr of the neighbourhood is the bit range [r*W + col - R, + 2R+1) of vbits.  A tap counts as neighbour
-// if its bit is set (exists && valid()), as CLOSE neighbour if |rho_self - rho_n| < 2 sigma_self or
-// < 2 sigma_n.  The group walks the rows; lane dc owns column dc, so a row's (inv_depth, 2 sigma) pairs are one
-// coalesced load of the valid lanes, empty rows are skipped, and the ballot of the closeness test IS the row's
-// mask.  Output per element: the neighbour counts and one mask of close taps per row -- rows in order, bits in
-// order = the reference's row-major tap order, which is all pass B needs.  With G = 64 the element is
-// wave-uniform and the row bookkeeping runs on the scalar unit.
-#ifndef SCAN_BLOCK
-#define SCAN_BLOCK 256
-#endif
-template <int G>
-__global__ void __launch_bounds__(SCAN_BLOCK) reg_scan_kernel(const MapCell* __restrict__ map, const u64* __restrict__ vbits,
-                                                       const double2* __restrict__ ab, const u32* __restrict__ elem_list,
-                                                       const u32* __restrict__ n_elems, u64* __restrict__ masks,
-                                                       u32* __restrict__ counts, DevParams p) {
-  u32 e = (blockIdx.x * SCAN_BLOCK + threadIdx.x) / G;
-  if (G == 64) e = (u32)__builtin_amdgcn_readfirstlane((int)e);
-  const int dc = threadIdx.x % G;
-  const int gsh = (threadIdx.x & 63) / G * G;  // first lane of the group inside the wave
-  if (e >= *n_elems) return;
-  const int cell = (int)elem_list[e];
-  const MapCell& c = map[cell];
+// ---- DepthRegularization::apply, fused: neighbourhood scan + sequential Student-t fusion ---------------------------------
+// One workgroup per REG_TX x REG_TY tile of the image.  The tile's elements (alive cells) are compacted onto the lanes of
+// its waves -- lane = element -- and the rows of the view the tile's neighbourhoods cover are streamed through LDS one
+// at a time (double-buffered, one barrier per row).  For a staged row every lane tests the (2r+1) taps of its window:
+// a tap is a CLOSE neighbour if |rho_self - rho_n| < 2 sigma_self or < 2 sigma_n (DepthRegularization.cpp:45-48; taps
+// that are no neighbours are NaN in the view and fail both).  The close taps of the row, lowest column first, then go
+// through the sequential Student-t fusion (:66-98) straight away: rows ascend for every element, so each element sees
+// its close neighbours in the reference's row-major order.  Nothing but the result leaves the chip: the per-element row
+// masks that the two-kernel version wrote and re-read (328 B per element) live in a register for the duration of a
+// row, and a view row is fetched once per tile instead of once per element.
+// The counts decide at the end (neighbours > minN, close > minClose), so the fusion runs speculatively.
+#define REG_TX 64
+#define REG_TY 4
+#define REG_MARGIN 1   // an element's believed (row, col) is at most one cell away from its true cell (Appendix A-7)
+#define REG_MAXW (REG_TX + 2 * 31 + 2 * REG_MARGIN)
+__global__ void __launch_bounds__(REG_TX * REG_TY) reg_apply_kernel(const MapCell* __restrict__ map, MapCell* __restrict__ out,
+                                                                    const u32* __restrict__ owner_max,
+                                                                    const u32* __restrict__ owner_min,
+                                                                    const double2* __restrict__ ab,
+                                                                    const double2* __restrict__ cd, DevParams p) {
+  __shared__ double2 s_ab[2][REG_MAXW];
+  __shared__ double2 s_cd[2][REG_MAXW];
+  __shared__ u64 s_vb[2][3];
+  __shared__ u32 s_elem[REG_TX * REG_TY];
+  __shared__ u32 s_wcount[REG_TY + 1];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int tiles_x = (p.W + REG_TX - 1) / REG_TX;
+  const int tile_c0 = (int)(blockIdx.x % tiles_x) * REG_TX, tile_r0 = (int)(blockIdx.x / tiles_x) * REG_TY;
   const int R = p.reg_radius, Wn = 2 * R + 1;
-  int row = (int)c.row, col = (int)c.col;
-  if (G == 64) { row = __builtin_amdgcn_readfirstlane(row); col = __builtin_amdgcn_readfirstlane(col); }
-  const double inv = c.inv_depth;
-  // SmartGrid::getNeighbourhood's loop bounds mix int and size_t (SmartGrid.h:373-375): for
-  // row < radius or col < radius the loops never execute -> no neighbours at all.
-  const bool scan = inv > -1e-6 && row >= R && col >= R;
-  const double sd_self2 = 2.0 * sqrt(c.variance);
-  const int col0 = col - R;
-  const int width = min(Wn, p.W - col0);  // taps with cc >= W do not exist (SmartGrid.h:376)
-  const u64 wmask = (width >= 64) ? ~0ull : ((1ull << max(width, 0)) - 1ull);
-  const u64 gmask = (G == 64) ? ~0ull : ((1ull << G) - 1ull);
+  // ---- the tile's elements, compacted in row-major order ----
+  const int cr = tile_r0 + wv, cc = tile_c0 + lane;
+  bool alive = false;
+  if (cr < p.H && cc < p.W && cr >= p.band_y0 && cr < p.band_y1) alive = (map[cr * p.W + cc].flags & CELL_ALIVE) != 0;
+  const u64 am = __ballot(alive);
+  if (lane == 0) s_wcount[wv] = (u32)__popcll(am);
+  __syncthreads();
+  u32 base = 0, n_el = 0;
+  for (int w = 0; w < REG_TY; ++w) { if (w < wv) base += s_wcount[w]; n_el += s_wcount[w]; }
+  if (n_el == 0) return;  // block-uniform
+  if (alive) s_elem[base + (u32)__popcll(am & ((1ull << lane) - 1ull))] = (u32)(cr * p.W + cc);
+  __syncthreads();
+  const bool has = (u32)t < n_el;
+  int cell = 0, row = 0, col = 0;
+  double inv = -1.0, sd_self2 = 0.0;
+  u32 seq = 0;
+  if (has) {
+    cell = (int)s_elem[t];
+    const MapCell& c = map[cell];
+    row = (int)c.row; col = (int)c.col;
+    inv = c.inv_depth;
+    sd_self2 = 2.0 * sqrt(c.variance);
+    seq = c.seq;
+  }
+  const u32 b = (u32)row * (u32)p.W + (u32)col;  // dmTmp.set(it->row(), it->col(), *it)
+  const bool owner = has && owner_max[b] == seq + 1u;  // else: overwritten by a later element
+  // SmartGrid::getNeighbourhood's loop bounds mix int and size_t (SmartGrid.h:373-375): for row < radius or
+  // col < radius the loops never execute -> no neighbours at all.
+  bool scan = owner && inv > -1e-6 && row >= R && col >= R;
+  // staged window: rows [tile_r0 - M - R, tile_r0 + TY + M + R), columns [tile_c0 - M - R, tile_c0 + TX + M + R)
+  const int sc0 = tile_c0 - REG_MARGIN - R, sr0 = tile_r0 - REG_MARGIN - R;
+  const int sw = REG_TX + 2 * (R + REG_MARGIN), sh = REG_TY + 2 * (R + REG_MARGIN);
+  const int off = col - R - sc0;  // first tap of the lane's window inside a staged row
+  // believed position outside the staged margins (cannot happen with the reference's fusion, see REG_MARGIN): such an
+  // element takes the plain path below, straight from the view in global memory
+  bool slow = scan && (off < 0 || off + Wn > sw || row - R < sr0 || row + R >= sr0 + sh);
+  if (slow) scan = false;
+  const u64 wmask = (Wn >= 64) ? ~0ull : ((1ull << Wn) - 1ull);
   u32 nb = 0, nclose = 0;
-  u64* mk = masks + (size_t)e * Wn;
-  for (int dr = 0; dr < Wn; ++dr) {
-    const int r = row - R + dr;
-    u64 bits = 0;
-    int base = 0;
-    if (scan && r < p.H) {
-      base = r * p.W + col0;
-      const int sh = base & 63;
-      const u64 lo = vbits[base >> 6], hi = vbits[(base >> 6) + 1];
-      bits = ((lo >> sh) | (sh ? (hi << (64 - sh)) : 0ull)) & wmask;
+  double nu_post = 0, inv_post = 0, s2_post = 0, nu_div = 0;
+  Recip rnu = make_recip(1.0);
+  bool first = true;
+  // one Student-t fusion step (DepthRegularization.cpp:72-86); see fdiv.hpp for the quotients
+  auto fuse_step = [&](double inv_obs, double nu_obs, double s2_obs) {
+    if (first) {
+      first = false;
+      nu_post = nu_obs; inv_post = inv_obs; s2_post = s2_obs;
+      nu_div = nu_post + 1;
+      rnu = make_recip(nu_div);
+      return;
     }
-    u64 cm = 0;
-    if (bits) {  // group-uniform
-      bool close = false;
-      if ((bits >> dc) & 1ull) {
-        const double2 q = ab[base + dc];
-        const double diff = fabs(inv - q.x);
-        close = diff < sd_self2 || diff < q.y;
-      }
-      cm = (__ballot(close) >> gsh) & gmask;
-      nb += (u32)__popcll(bits);
-      nclose += (u32)__popcll(cm);
-    }
-    if (dc == 0) mk[dr] = cm;
-  }
-  if (dc == 0) { counts[2 * e] = nb; counts[2 * e + 1] = nclose; }
-}
-
-// ---- regulariser pass B: sequential Student-t fusion of the close neighbours, one thread per element --
-// DepthRegularization.cpp:66-98.  The order is fixed by the masks, so the neighbour data of the next
-// step is loaded while the current (dependent) fusion step computes.
-#ifndef CHAIN_BLOCK
-#define CHAIN_BLOCK 256
-#endif
-__global__ void __launch_bounds__(CHAIN_BLOCK) reg_chain_kernel(const MapCell* __restrict__ map, MapCell* __restrict__ out,
-                                                        const u32* __restrict__ owner_max, const u32* __restrict__ owner_min,
-                                                        const double2* __restrict__ ab, const double2* __restrict__ cd,
-                                                        const u32* __restrict__ elem_list, const u32* __restrict__ n_elems,
-                                                        const u64* __restrict__ masks, const u32* __restrict__ counts,
-                                                        DevParams p) {
-  const u32 e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= *n_elems) return;
-  const int cell = (int)elem_list[e];
-  MapCell c = map[cell];
-  const u32 b = c.row * (u32)p.W + c.col;
-  if (owner_max[b] != c.seq + 1u) { out[cell].flags = 0; return; }  // overwritten by a later element
-  if (c.inv_depth > -1e-6) {  // it->valid()
-    const u32 n_nb = counts[2 * e], n_close = counts[2 * e + 1];
-    if (n_nb > (u32)p.reg_min_nb && n_close > (u32)p.reg_min_close) {
-      const int R = p.reg_radius, Wn = 2 * R + 1;
-      const int col0 = (int)c.col - R;
-      const u64* mk = masks + (size_t)e * Wn;
-      int dr = 0;
-      int row_base = ((int)c.row - R) * p.W + col0;
-      u64 m = mk[0];
-      auto next_cell = [&]() -> int {  // next close tap in row-major order, -1 when exhausted
-        while (m == 0) {
-          if (++dr >= Wn) return -1;
-          m = mk[dr];
-          row_base += p.W;
-        }
-        const int k = __builtin_ctzll(m);
-        m &= m - 1;
-        return row_base + k;
-      };
-      int nc = next_cell();  // n_close > 0 here
-      double inv_n = ab[nc].x;
-      double2 t_n = cd[nc];
-      double nu_post = t_n.x, inv_post = inv_n, s2_post = t_n.y;
-      // nu_post is a running minimum, so the divisor nu_post + 1 is almost always the previous step's: its refined
-      // reciprocal is kept.  One step = one straight line of fast quotients (fdiv.hpp) validated by a single test at
-      // its end; the plain divisions are the (practically never taken) other side of that one branch -- this kernel
-      // runs about one wave per SIMD, so branches and dependent latency, not throughput, are what it pays for.
-      double nu_div = nu_post + 1;
-      Recip rnu = make_recip(nu_div);
-      nc = next_cell();
-      if (nc >= 0) { inv_n = ab[nc].x; t_n = cd[nc]; }
-      while (nc >= 0) {
-        const double nu_obs = t_n.x, inv_obs = inv_n, s2_obs = t_n.y;
-        nc = next_cell();
-        if (nc >= 0) { inv_n = ab[nc].x; t_n = cd[nc]; }  // prefetch: independent of the fusion state
-        const double nu_prior = nu_post, inv_prior = inv_post, s2_prior = s2_post;  // DepthRegularization.cpp:72-86
-        nu_post = (nu_obs < nu_prior) ? nu_obs : nu_prior;
-        if (nu_post + 1 != nu_div) { nu_div = nu_post + 1; rnu = make_recip(nu_div); }
-        const double ssum = s2_obs + s2_prior;  // == s2_prior + s2_obs
-        const Recip rsum = make_recip(ssum);
-        const double a1 = s2_obs * inv_prior + s2_prior * inv_obs;
-        const double dd = inv_prior - inv_obs;
-        const double a2 = dd * dd;
-        const double pp = s2_prior * s2_obs;
-        const double q1 = div_fast(a1, rsum);
-        const double a3 = nu_post + div_fast(a2, rsum);
-        const double a4 = div_fast(a3, rnu) * pp;
-        const double q4 = div_fast(a4, rsum);
-        const bool ok = (int)rsum.fast & (int)rnu.fast & (int)fdiv_ok(a1) & (int)fdiv_ok(a2) & (int)fdiv_ok(a3) & (int)fdiv_ok(a4);
-        if (ok) {
-          inv_post = q1;
-          s2_post = q4;
-        } else {
-          inv_post = a1 / ssum;
-          s2_post = ((nu_post + a2 / ssum) / (nu_post + 1) * pp) / ssum;
-        }
-      }
-      c.inv_depth = inv_post;
+    const double nu_prior = nu_post, inv_prior = inv_post, s2_prior = s2_post;
+    nu_post = (nu_obs < nu_prior) ? nu_obs : nu_prior;
+    // nu_post is a running minimum, so the divisor nu_post + 1 is almost always the previous step's
+    if (nu_post + 1 != nu_div) { nu_div = nu_post + 1; rnu = make_recip(nu_div); }
+    const double ssum = s2_obs + s2_prior;  // == s2_prior + s2_obs
+    const Recip rsum = make_recip(ssum);
+    const double a1 = s2_obs * inv_prior + s2_prior * inv_obs;
+    const double dd = inv_prior - inv_obs;
+    const double a2 = dd * dd;
+    const double pp = s2_prior * s2_obs;
+    const double q1 = div_fast(a1, rsum);
+    const double a3 = nu_post + div_fast(a2, rsum);
+    const double a4 = div_fast(a3, rnu) * pp;
+    const double q4 = div_fast(a4, rsum);
+    const bool ok = (int)rsum.fast & (int)rnu.fast & (int)fdiv_ok(a1) & (int)fdiv_ok(a2) & (int)fdiv_ok(a3) & (int)fdiv_ok(a4);
+    if (ok) {
+      inv_post = q1;
+      s2_post = q4;
     } else {
-      c.inv_depth = -1.0;
+      inv_post = a1 / ssum;
+      s2_post = ((nu_post + a2 / ssum) / (nu_post + 1) * pp) / ssum;
     }
+  };
+  // ---- stream the view rows through LDS ----
+  const double nan = __longlong_as_double(0x7ff8000000000000ll);
+  double2 ld = make_double2(nan, nan);  // threads [0, sw): ab of staged column t; threads [128, 128 + sw): cd
+  const int sj = (t < 128) ? t : t - 128;
+  auto fetch_row = [&](int y) {
+    const int gy = sr0 + y, gx = sc0 + sj;
+    ld = make_double2(nan, nan);
+    if (sj < sw && y < sh && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) ld = (t < 128 ? ab : cd)[gy * p.W + gx];
+  };
+  auto store_row = [&](int buf) {
+    if (sj < sw) (t < 128 ? s_ab : s_cd)[buf][sj] = ld;
+    if (t < 128) {  // waves 0 and 1 hold the ab halves: their ballots are the row's neighbour bits
+      const u64 vm = __ballot(sj < sw && ld.x == ld.x);
+      if (lane == 0) s_vb[buf][wv] = vm;
+    }
+  };
+  fetch_row(0);
+  store_row(0);
+  fetch_row(1);
+  __syncthreads();
+  for (int y = 0; y < sh; ++y) {
+    const int buf = y & 1;
+    const int gy = sr0 + y;
+    if (scan && gy >= row - R && gy <= row + R) {
+      // neighbour bits of the lane's window in this row
+      const u64 w0 = s_vb[buf][0], w1 = s_vb[buf][1];
+      u64 bits = (off < 64) ? (w0 >> off) : 0ull;
+      if (off > 0 && off < 64) bits |= w1 << (64 - off);
+      if (off >= 64) bits = w1 >> (off - 64);
+      bits &= wmask;
+      nb += (u32)__popcll(bits);
+      u64 cm = 0;
+      if (bits) {
+        for (int dc = 0; dc < Wn; ++dc) {
+          const double2 q = s_ab[buf][off + dc];
+          const double diff = fabs(inv - q.x);
+          if (diff < sd_self2 || diff < q.y) cm |= 1ull << dc;
+        }
+      }
+      nclose += (u32)__popcll(cm);
+      while (cm) {
+        const int k = __builtin_ctzll(cm);
+        cm &= cm - 1;
+        const double2 qa = s_ab[buf][off + k], qc = s_cd[buf][off + k];
+        fuse_step(qa.x, qc.x, qc.y);
+      }
+    }
+    if (y + 1 < sh) store_row(buf ^ 1);  // the row fetched one iteration ago
+    fetch_row(y + 2);
+    __syncthreads();
   }
+  if (slow) {  // plain path: the reference's two loops on the view in global memory
+    for (int r = row - R; r <= row + R && r < p.H; ++r)
+      for (int c2 = col - R; c2 <= col + R && c2 < p.W; ++c2) {
+        const double2 q = ab[r * p.W + c2];
+        if (!(q.x == q.x)) continue;
+        nb++;
+        const double diff = fabs(inv - q.x);
+        if (diff < sd_self2 || diff < q.y) {
+          nclose++;
+          const double2 qc = cd[r * p.W + c2];
+          fuse_step(q.x, qc.x, qc.y);
+        }
+      }
+  }
+  if (!has) return;
+  if (!owner) { out[cell].flags = 0; return; }
+  MapCell c = map[cell];
+  if (c.inv_depth > -1e-6)  // it->valid()
+    c.inv_depth = (nb > (u32)p.reg_min_nb && nclose > (u32)p.reg_min_close) ? inv_post : -1.0;
   c.seq = owner_min[b];  // position of the first element set at that cell in dmTmp's list
   c.flags = CELL_ALIVE | CELL_GRID;
   out[cell] = c;
 }
 
-void launch_reg_view(const MapCell* map_in, MapCell* map_out, u32* owner_max, u32* owner_min, u64* vbits, double2* ab,
-                     double2* cd, u32* elem_list, u32* n_elems, const DevParams& p, hipStream_t s) {
+void launch_reg_view(const MapCell* map_in, MapCell* map_out, u32* owner_max, u32* owner_min, double2* ab, double2* cd,
+                     u32* n_elems, const DevParams& p, hipStream_t s) {
   const int ncell = p.W * p.H;
   // owner_max / owner_min / n_elems were reset by fuse_reset_kernel (launch_fuse of the same tick)
   const int nb = (ncell + 255) / 256;
   hipLaunchKernelGGL(reg_owner_kernel, dim3(nb), dim3(256), 0, s, map_in, owner_max, owner_min, p);
-  hipLaunchKernelGGL(reg_view_kernel, dim3(nb), dim3(256), 0, s, map_in, map_out, vbits, ab, cd, elem_list, n_elems, ncell, p.W,
+  hipLaunchKernelGGL(reg_view_kernel, dim3(nb), dim3(256), 0, s, map_in, map_out, ab, cd, n_elems, ncell, p.W,
                      p.band_y0, p.band_y1, p.cband_y0, p.cband_y1);
 }
-template <int G>
-static void launch_reg_scan_g(const MapCell* map_in, const u64* vbits, const double2* ab, const u32* elem_list, const u32* n_elems,
-                              u64* masks, u32* counts, u32 max_elems, const DevParams& p, hipStream_t s) {
-  const u32 per_block = SCAN_BLOCK / G;
-  hipLaunchKernelGGL(reg_scan_kernel<G>, dim3((max_elems + per_block - 1) / per_block), dim3(SCAN_BLOCK), 0, s, map_in, vbits, ab,
-                     elem_list, n_elems, masks, counts, p);
-}
-void launch_reg_apply(const MapCell* map_in, MapCell* map_out, const u32* owner_max, const u32* owner_min, const u64* vbits,
-                      u64* masks, u32* counts, const double2* ab, const double2* cd, const u32* elem_list, const u32* n_elems,
-                      u32 max_elems, const DevParams& p, hipStream_t s) {
-  const int Wn = 2 * p.reg_radius + 1;  // <= 63 (validate_params)
-  if (max_elems == 0) return;
-  if (Wn <= 16) launch_reg_scan_g<16>(map_in, vbits, ab, elem_list, n_elems, masks, counts, max_elems, p, s);
-  else if (Wn <= 32) launch_reg_scan_g<32>(map_in, vbits, ab, elem_list, n_elems, masks, counts, max_elems, p, s);
-  else launch_reg_scan_g<64>(map_in, vbits, ab, elem_list, n_elems, masks, counts, max_elems, p, s);
-  hipLaunchKernelGGL(reg_chain_kernel, dim3((max_elems + CHAIN_BLOCK - 1) / CHAIN_BLOCK), dim3(CHAIN_BLOCK), 0, s, map_in, map_out, owner_max, owner_min, ab,
-                     cd, elem_list, n_elems, masks, counts, p);
+void launch_reg_apply(const MapCell* map_in, MapCell* map_out, const u32* owner_max, const u32* owner_min, const double2* ab,
+                      const double2* cd, const DevParams& p, hipStream_t s) {
+  const int tiles_x = (p.W + REG_TX - 1) / REG_TX;
+  const int ty0 = p.band_y0 / REG_TY, ty1 = (p.band_y1 + REG_TY - 1) / REG_TY;  // tile rows that intersect the band
+  if (ty1 <= ty0) return;
+  // grid = all tile rows (blockIdx -> tile); tiles outside the band find no element and leave at once
+  const int tiles_y = (p.H + REG_TY - 1) / REG_TY;
+  hipLaunchKernelGGL(reg_apply_kernel, dim3(tiles_x * tiles_y), dim3(REG_TX * REG_TY), 0, s, map_in, map_out, owner_max,
+                     owner_min, ab, cd, p);
 }
 
 // ---- export: alive cells -> esvo_depth_point_t list (cell order; host orders by seq) --------------
