@@ -7,15 +7,22 @@ esvo_core/cfg/mapping/mapping_dsec.yaml parameters, throughput mode: every event
 slice is block-matched instead of the reference's PROCESS_EVENT_NUM = 10000):
     TS ingest (scatter of the new events of both cameras) -> TS render (both cameras) ->
     block matching -> LM refinement + culling -> window policy -> fusion -> clean -> regularisation.
-All events are staged in HBM before the timed region starts.
+All events are staged in HBM before the timed region starts.  The stream is STATIONARY (SURVEY.md section 8(d):
+20 Mev/s per camera = 200 k events per tick, whatever --steps is): a periodic scene seen from a rig in uniform motion.
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+With N GPUs the job maps N x K ticks of one stream, K per GPU (weak scaling): ticks are dealt round-robin and the
+ranks all-gather their frames (esvo_amd/dist.py), or, with ESVO_SHARD_MODE=band, every tick is split over the GPUs.
 
 Prints ONE JSON line on rank 0 (see the task contract), including `roofline` for the dominant
 kernel and `cpu_baseline` (the CPU oracle timed on the host cores, N=1 only).
 """
 import argparse
+import csv
+import glob
+import hashlib
 import json
 import os
 import sys
@@ -29,17 +36,44 @@ if ROOT not in sys.path:
 
 from esvo_amd import calib, lib, params, rostime, synth  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+VALU_PEAK_INST_S = 256 * 4 * 2.4e9 / 4.0  # wave64 VALU instructions/s: 1024 SIMDs, one f64/f32 instruction per 4 cycles, 2.4 GHz
 
+TICK_S, HIST_S = 0.010, 0.060
 WORKLOADS = {
-    # name: (rig, preset, rho_min, rho_max, points for ~target rate, speed)
-    "dsec640x480": dict(rig="dsec", preset="mapping_dsec", rho=(0.02, 0.25), points=180000, speed=2.0),
-    "upenn346x260": dict(rig="upenn", preset="mapping_upenn", rho=(0.16, 1.0), points=24000, speed=1.0),
-    # SURVEY.md §8 stress row: 1280x720, 145 disparity candidates, ~100 Mev/s over both cameras
-    "hd1280x720": dict(rig="hd", preset="mapping_hd", rho=(0.03, 0.45), points=185000, speed=1.5),
+    # name: rig, preset, rho range, scene points for the target event rate, rig speed (m/s)
+    "dsec640x480": dict(rig="dsec", preset="mapping_dsec", rho=(0.02, 0.25), points=237500, speed=2.0,
+                        note="DSEC calib + mapping_dsec.yaml params, 20 Mev/s/camera"),
+    "upenn346x260": dict(rig="upenn", preset="mapping_upenn", rho=(0.16, 1.0), points=27800, speed=1.0,
+                         note="upenn calib + mapping_upenn.yaml params, 2 Mev/s/camera"),
+    # SURVEY.md section 8 stress row: 1280x720, 145 disparity candidates, 100 Mev/s over both cameras
+    "hd1280x720": dict(rig="hd", preset="mapping_hd", rho=(0.03, 0.45), points=235000, speed=1.5,
+                       note="synthetic HD rig (f b = 300 px m), mapping_dsec.yaml params with 145 disparities, 50 Mev/s/camera"),
 }
 
 KERNEL_NAMES = ["ts_scatter", "ts_render", "bm_match", "lm_refine", "fuse", "clean", "regularize"]
+KERNEL_SYMBOLS = {"lm_refine": "lm_refine_kernel", "bm_match": "bm_match_kernel", "fuse": "fuse_cells_kernel",
+                  "regularize": "reg_apply_kernel", "ts_render": "ts_decay_kernel", "ts_scatter": "ts_scatter_kernel"}
+
+
+def make_workload(name, n_ticks, events_cap=0):
+    """(rig, stream, params, ticks) of a bench workload: n_ticks ticks of 10 ms after 60 ms of history"""
+    wl = WORKLOADS[name]
+    rig = calib.dataset_rig(wl["rig"])
+    duration = HIST_S + (n_ticks + 1) * TICK_S
+    traj = synth.Trajectory(speed=wl["speed"], sway=0.002, yaw=0.0005, t0_s=10.0)
+    stream = synth.make_stream(rig, wl["points"], duration, wl["rho"][0], wl["rho"][1], seed=20250418 + 3, speed=wl["speed"],
+                               stationary=True, traj=traj)
+    ev_per_tick = int(len(stream.ev_left) / duration * TICK_S)
+    cap = events_cap or int(ev_per_tick * 1.25) + 1024
+    p, _ = params.make_params(params.PRESETS[wl["preset"]], rig, throughput_events=cap,
+                              event_ring_capacity=max(1 << 22, int(len(stream.ev_left) * 1.05) + 4096))
+    ticks = []
+    for k in range(n_ticks):
+        t = stream.t0_ns + int(round((HIST_S + (k + 1) * TICK_S) * 1e9))
+        stamps, poses = rostime.pose_table(stream.pose, t, p.bm_half_slice_thickness)
+        ticks.append((t, stamps, poses, stream.pose(t)))
+    return rig, stream, p, ticks
 
 
 def algorithmic_bytes(kernel, st, W, H, nd, fusion_radius=1, events=None, matches=None):
@@ -57,55 +91,78 @@ def algorithmic_bytes(kernel, st, W, H, nd, fusion_radius=1, events=None, matche
         return st.last_map_size * 52
     if kernel == "ts_render":
         return W * H * 9
-    if kernel == "ts_scatter":
-        return 24 * 0  # per event; events per launch are reported separately
     return 0
 
 
-def measured_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary
-    (profiles/*_hbm_traffic.csv: separate FETCH_SIZE / WRITE_SIZE passes of this same command;
-    FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction).  None if no profile exists."""
-    import csv
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.csv")))
-    if not files:
-        return None
-    sym = {"lm_refine": "lm_refine_kernel", "bm_match": "bm_match_kernel", "fuse": "fuse_cells_kernel",
-           "regularize": "reg_chain_kernel", "ts_render": "ts_decay_kernel", "ts_scatter": "ts_scatter_kernel"}.get(kernel)
-    fetch = write = None
-    with open(files[-1]) as f:
-        for row in csv.DictReader(f):
-            if sym and sym in row["kernel"]:
-                v = float(row["avg_value_per_dispatch_KB"]) * 1024.0
-                if row["counter"] == "FETCH_SIZE":
-                    fetch = 2.0 * v
-                elif row["counter"] == "WRITE_SIZE":
-                    write = v
-    if fetch is None or write is None:
-        return None
-    return fetch + write
+def committed_profile(workload):
+    """The newest committed rocprofv3 round (profiles/<tag>_meta.json names the command and workload it ran): per-kernel
+    HBM bytes (separate FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction) and
+    SQ counters per launch.  Counter values are properties of (build, workload): they are only attached to a bench line of
+    the same workload, and the line says which files they came from."""
+    metas = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_meta.json")))
+    for path in reversed(metas):
+        try:
+            meta = json.load(open(path))
+        except Exception:
+            continue
+        if meta.get("workload") != workload:
+            continue
+        tag = os.path.basename(path)[:-len("_meta.json")]
+        out = {"tag": tag, "hbm": {}, "sq": {}, "files": []}
+        for kind, fn in (("hbm", f"{tag}_hbm_traffic.csv"), ("sq", f"{tag}_sq_counters.csv")):
+            fp = os.path.join(ROOT, "profiles", fn)
+            if not os.path.exists(fp):
+                continue
+            out["files"].append("profiles/" + fn)
+            with open(fp) as f:
+                for row in csv.DictReader(f):
+                    k = row["kernel"]
+                    if kind == "hbm":
+                        out["hbm"].setdefault(k, {})[row["counter"]] = float(row["avg_value_per_dispatch_KB"]) * 1024.0
+                    else:
+                        out["sq"].setdefault(k, {})[row["counter"]] = float(row["avg_value_per_dispatch"])
+        return out
+    return None
 
 
-def measured_valu_busy(kernel):
-    """Fraction of the kernel's duration during which the vector ALUs issue, from the newest committed SQ counter pass
-    (profiles/*_sq_counters.csv): SQ_ACTIVE_INST_VALU counts quad-cycles summed over the 1024 SIMDs, SQ_BUSY_CYCLES
-    counts cycles summed over the 32 shader engines (MI355X_MICROARCH.md).  The hot kernels of this path are bound by
-    f64 VALU issue, not by HBM or MFMA, so this is the utilisation figure that says how close they run to their limit."""
-    import csv
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq_counters.csv")))
-    if not files:
-        return None
-    sym = {"lm_refine": "lm_refine_kernel", "bm_match": "bm_match_kernel"}.get(kernel)
-    v = {}
-    with open(files[-1]) as f:
-        for row in csv.DictReader(f):
-            if sym and sym in row["kernel"]:
-                v[row["counter"]] = float(row["avg_value_per_dispatch"])
-    if "SQ_ACTIVE_INST_VALU" not in v or "SQ_BUSY_CYCLES" not in v:
-        return None
-    return (v["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0) / (v["SQ_BUSY_CYCLES"] / 32.0)
+def profile_figures(prof, kernel, launch_ms):
+    """(traffic bytes per launch, VALU block) of `kernel` from a committed profile, or (None, None)"""
+    if prof is None:
+        return None, None
+    sym = KERNEL_SYMBOLS.get(kernel)
+    traffic = valu = None
+    for k, v in prof["hbm"].items():
+        if sym and sym in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+            traffic = 2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]
+    for k, v in prof["sq"].items():
+        if sym and sym in k and "SQ_INSTS_VALU" in v:
+            insts = v["SQ_INSTS_VALU"]
+            rate = insts / (launch_ms * 1e-3) if launch_ms > 0 else 0.0
+            valu = {"wave_insts_per_launch": insts, "achieved": rate, "peak": VALU_PEAK_INST_S, "unit": "wave64 VALU instructions/s",
+                    "frac": rate / VALU_PEAK_INST_S,
+                    "note": "instruction count per launch from the committed SQ_INSTS_VALU pass of this workload (deterministic for "
+                            "a build), divided by this run's HIP-event launch time; peak = 1024 SIMDs x 2.4 GHz / 4 cycles per "
+                            "f64 instruction"}
+            if "SQ_ACTIVE_INST_VALU" in v and "SQ_BUSY_CYCLES" in v:
+                valu["busy_frac_profiled"] = (v["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0) / (v["SQ_BUSY_CYCLES"] / 32.0)
+    return traffic, valu
+
+
+def map_sha1(mp_):
+    key = np.ascontiguousarray(np.stack([mp_["row"].astype(np.float64), mp_["col"].astype(np.float64), mp_["inv_depth"],
+                                         mp_["variance"], mp_["age"].astype(np.float64)], axis=1))
+    return hashlib.sha1(key.tobytes()).hexdigest()
+
+
+def run_single(dev, stream, ticks, first, last, sync_each=False):
+    for k in range(first, last):
+        t, stamps, poses, T = ticks[k]
+        dev.ts_render(0, t, download=False)
+        dev.ts_render(1, t, download=False)
+        dev.set_observation(t, None, None, T)
+        dev.tick(t, stamps, poses)
+        if sync_each:
+            dev.synchronize()
 
 
 def main():
@@ -116,9 +173,12 @@ def main():
     ap.add_argument("--workload", default="dsec640x480", choices=sorted(WORKLOADS))
     ap.add_argument("--events-per-tick", type=int, default=0, help="cap on block-matched events per tick (0 = all)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary operating points (346x260, reference-faithful ticks)")
     ap.add_argument("--timed-ingest", action="store_true",
                     help="stage each tick's events inside the timed loop (PCIe-inclusive rate; the default stages the whole stream first)")
-    ap.add_argument("--check", action="store_true", help="also print a checksum of the final DepthMap (sharded == unsharded check)")
+    ap.add_argument("--strong", action="store_true", help="N GPUs share K ticks in total instead of mapping K ticks each")
+    ap.add_argument("--check", action="store_true",
+                    help="replay up to the first timed tick on a fresh handle and compare its DepthMap with the CPU oracle's (SHA-1)")
     args = ap.parse_args()
 
     import torch
@@ -142,18 +202,15 @@ def main():
             dist.init_process_group(backend)
 
     wl = WORKLOADS[args.workload]
-    rig = calib.dataset_rig(wl["rig"])
     K, Wm = args.steps, args.warmup
-    tick_s, hist_s = 0.010, 0.060
-    duration = hist_s + (K + Wm + 1) * tick_s
-    stream = synth.make_stream(rig, wl["points"], duration, wl["rho"][0], wl["rho"][1], seed=20250418 + 3, speed=wl["speed"])
-    ev_per_tick = int(len(stream.ev_left) / duration * tick_s)
-    cap = args.events_per_tick or int(ev_per_tick * 1.5) + 1024
-    p, _ = params.make_params(params.PRESETS[wl["preset"]], rig, throughput_events=cap,
-                              event_ring_capacity=max(1 << 22, int(len(stream.ev_left) * 1.1)))
+    shard_mode = os.environ.get("ESVO_SHARD_MODE", "tick")
+    # weak scaling: K timed (and Wm warm-up) ticks PER GPU in the tick-interleaved mode; the band mode splits every tick
+    per_gpu = world if (world > 1 and shard_mode == "tick" and not args.strong) else 1
+    n_ticks = (K + Wm) * per_gpu
+    rig, stream, p, ticks = make_workload(args.workload, n_ticks, args.events_per_tick)
+    duration = HIST_S + (n_ticks + 1) * TICK_S
     nd = p.bm_max_disparity - p.bm_min_disparity + 1
 
-    shard_mode = os.environ.get("ESVO_SHARD_MODE", "tick")
     if world > 1:
         from esvo_amd import dist as edist
         # "tick": ticks dealt round-robin to the GPUs, one all-gather of frames per round (throughput scaling);
@@ -164,13 +221,8 @@ def main():
         runner = lib.Esvo(p, rig, device=local_rank)
 
     # ---- stage the whole stream in HBM (untimed); with --timed-ingest only the history before the first tick ----
-    ticks = []
-    for k in range(K + Wm):
-        t = stream.t0_ns + int((hist_s + (k + 1) * tick_s) * 1e9)
-        stamps, poses = rostime.pose_table(stream.pose, t, p.bm_half_slice_thickness)
-        ticks.append((t, stamps, poses, stream.pose(t)))
     if args.timed_ingest:
-        t_first = stream.t0_ns + int(hist_s * 1e9)
+        t_first = stream.t0_ns + int(HIST_S * 1e9)
         bounds = [t_first] + [tk[0] for tk in ticks]
         chunks = [(stream.slice(0, a, b), stream.slice(1, a, b)) for a, b in zip(bounds[:-1], bounds[1:])]
         runner.ts_push_events(0, stream.slice(0, stream.t0_ns, t_first))
@@ -189,7 +241,8 @@ def main():
         runner.set_observation(t, None, None, T)
         runner.tick(t, stamps, poses)
 
-    for k in range(Wm):
+    n_warm, n_all = Wm * per_gpu, (Wm + K) * per_gpu
+    for k in range(n_warm):
         step(k)
     runner.synchronize()
     torch.cuda.synchronize()
@@ -197,7 +250,7 @@ def main():
     if dist:
         dist.barrier()
     t0 = time.perf_counter()
-    for k in range(Wm, Wm + K):
+    for k in range(n_warm, n_all):
         step(k)
     runner.synchronize()
     torch.cuda.synchronize()
@@ -234,6 +287,11 @@ def main():
     dom_bytes = algorithmic_bytes(dom_name, st, rig.width, rig.height, nd, p.fusion_radius, events=ev_rank / launches,
                                   matches=mt_rank / launches)
     achieved = (dom_bytes / (kavg[dom] * 1e-3)) / 1e9 if kavg[dom] > 0 else 0.0
+    workload_str = (f"{args.workload} synthetic stereo event stream, stationary, {len(stream.ev_left) / duration / 1e6:.1f} Mev/s/camera, "
+                    f"{wl['note']}, throughput mode (all events of each 10 ms slice)")
+    prof = committed_profile(args.workload) if world == 1 else None
+    traffic, valu = profile_figures(prof, dom_name, float(kavg[dom]))
+    total_ticks = K * per_gpu
     out = {
         "metric": "mapped events/sec (stereo TS raster + block matching + LM depth refinement + fusion)",
         "value": n_events / dt,
@@ -243,20 +301,19 @@ def main():
         "warmup": Wm,
         "ms_per_step": dt / K * 1e3,
         "higher_is_better": True,
-        "scaling": "strong",
+        "scaling": "weak" if per_gpu > 1 or world == 1 else "strong",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic" + (" (events staged tick by tick inside the timed loop)" if args.timed_ingest else ""),
         "depth_points_per_s": n_points / dt,
         "config": {
-            "workload": f"{args.workload} synthetic stereo event stream, {len(stream.ev_left) / duration / 1e6:.1f} Mev/s/camera, "
-                        f"DSEC calib + mapping_dsec.yaml params, throughput mode (all events of each 10 ms slice)"
-                        if args.workload == "dsec640x480" else args.workload,
+            "workload": workload_str,
             "image": [rig.width, rig.height],
-            "events_per_tick": n_events // max(K, 1),
+            "events_per_tick": n_events // max(total_ticks, 1),
+            "ticks_timed": total_ticks,
             "disparity_range": [p.bm_min_disparity, p.bm_max_disparity],
-            "parallelism": "1 GPU" if world == 1 else (f"{world} GPUs, ticks interleaved, all-gather of frames" if shard_mode == "tick"
-                                                       else f"{world} GPUs, slots + image row bands"),
+            "parallelism": "1 GPU" if world == 1 else (f"{world} GPUs, {K} ticks per GPU dealt round-robin, all-gather of frames"
+                                                       if shard_mode == "tick" else f"{world} GPUs, slots + image row bands"),
         },
         "kernel_ms": {KERNEL_NAMES[i]: round(float(kavg[i]), 4) for i in range(7)},
         "roofline": {
@@ -266,12 +323,14 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": measured_traffic(dom_name) if args.workload == "dsec640x480" else None,  # the committed PMC passes ran this workload
+            "traffic": traffic,
+            "traffic_source": (prof["files"] if (prof and traffic is not None) else None),
             "algorithmic_bytes_per_launch": dom_bytes,
-            # not an HBM- or MFMA-bound kernel: f64 vector-ALU issue is its limit
-            "practical_bound": "f64 VALU issue",
-            "valu_busy_frac": measured_valu_busy(dom_name) if args.workload == "dsec640x480" else None,
             "avg_launch_ms": float(kavg[dom]),
+            # not an HBM- or MFMA-bound kernel: vector-ALU issue (f64) is its limit, so the figure
+            # that says how close it runs to the chip is its VALU instruction rate against the issue peak
+            "practical_bound": "f64 VALU issue",
+            "valu": valu,
         },
     }
 
@@ -281,27 +340,104 @@ def main():
         name = KERNEL_NAMES[slot]
         nbytes = algorithmic_bytes(name, st, rig.width, rig.height, nd, p.fusion_radius, events=ev_rank / launches, matches=mt_rank / launches)
         gbs = (nbytes / (kavg[slot] * 1e-3)) / 1e9 if kavg[slot] > 0 else 0.0
+        tr, vl = profile_figures(prof, name, float(kavg[slot]))
         out["roofline_kernels"].append({"kernel": name, "avg_launch_ms": float(kavg[slot]), "algorithmic_bytes_per_launch": nbytes,
-                                        "achieved": gbs, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                                        "valu_busy_frac": measured_valu_busy(name) if args.workload == "dsec640x480" else None})
+                                        "achieved": gbs, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": tr,
+                                        "valu_frac": None if vl is None else vl["frac"]})
     if args.check:
-        mp_ = runner.get_map()
+        mp_ = runner.get_map()  # collective at N > 1
         if rank == 0:
-            import hashlib
-            key = np.ascontiguousarray(np.stack([mp_["row"].astype(np.float64), mp_["col"].astype(np.float64), mp_["inv_depth"],
-                                                 mp_["variance"], mp_["age"].astype(np.float64)], axis=1))
-            out["check"] = {"map_size": int(len(mp_)), "sha1": hashlib.sha1(key.tobytes()).hexdigest()}
+            out["check"] = {"final": {"map_size": int(len(mp_)), "sha1": map_sha1(mp_)}}
+            if world == 1:
+                out["check"]["oracle"] = check_against_oracle(rig, stream, p, ticks, Wm, local_rank)
+    if rank == 0 and world == 1 and not args.no_extras:
+        out["other_operating_points"] = other_operating_points(local_rank)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(rig, stream, p, ticks, Wm)
+        out["cpu_baseline"] = cpu_baseline(rig, stream, p, ticks)
     if rank == 0:
         print(json.dumps(out))
     if dist:
         dist.destroy_process_group()
 
 
-def cpu_baseline(rig, stream, p, ticks, first):
-    """The CPU oracle ("port" of the reference mapper) on a bounded sample: one tick of the same
-    workload, block matching + LM on all host cores, fusion single-threaded as in the reference."""
+def check_against_oracle(rig, stream, p, ticks, n_first, device):
+    """Replays ticks 0 .. n_first (the first timed tick) on a fresh handle and on the CPU oracle (GPU-comparable mode) and
+    compares the two DepthMaps of that tick."""
+    from oracle import oracle
+    dev = lib.Esvo(p, rig, device=device)
+    dev.ts_push_events(0, stream.ev_left)
+    dev.ts_push_events(1, stream.ev_right)
+    run_single(dev, stream, ticks, 0, n_first + 1)
+    gm = dev.get_map()
+    dev.close()
+    m = oracle.OracleMapper(p, rig)
+    m.set_mode(True, True)
+    m.set_threads(os.cpu_count() or 1)
+    ts = [oracle.OracleTS(rig.width, rig.height), oracle.OracleTS(rig.width, rig.height)]
+    done = [0, 0]
+    for t, stamps, poses, T in ticks[:n_first + 1]:
+        for cam, (ev, ns) in enumerate(((stream.ev_left, stream.ns_left), (stream.ev_right, stream.ns_right))):
+            hi = int(np.searchsorted(ns, t, side="left"))
+            ts[cam].push(ev[done[cam]:hi])
+            done[cam] = hi
+        l = ts[0].render(t, map_x=rig.left.map_x, map_y=rig.left.map_y)
+        r = ts[1].render(t, map_x=rig.right.map_x, map_y=rig.right.map_y)
+        m.set_observation(t, l, r, T)
+        m.set_poses(stamps, poses)
+        idx = oracle.select_events(stream.ev_left, t, p.bm_half_slice_thickness, p.process_event_num)
+        m.tick(stream.ev_left[idx])
+    om = m.get_map()
+    a, b = map_sha1(gm), map_sha1(om)
+    return {"tick": n_first, "map_size": int(len(gm)), "sha1": a, "oracle_map_size": int(len(om)), "oracle_sha1": b, "equal": a == b}
+
+
+def other_operating_points(device):
+    """Secondary figures of the same JSON line: the 346x260 stream of north_star in throughput mode and the two
+    reference-faithful tick sizes (the mode the ROS node runs: PROCESS_EVENT_NUM 10000 on DSEC, 1000 on upenn), each as
+    the time of one tick completed on its own (latency: nothing is in flight beside it)."""
+    out = {}
+
+    def throughput(name, n):
+        rig, stream, p, ticks = make_workload(name, n + 3)
+        dev = lib.Esvo(p, rig, device=device)
+        dev.ts_push_events(0, stream.ev_left)
+        dev.ts_push_events(1, stream.ev_right)
+        run_single(dev, stream, ticks, 0, 3)
+        dev.synchronize()
+        b = dev.stats()
+        t0 = time.perf_counter()
+        run_single(dev, stream, ticks, 3, n + 3)
+        dev.synchronize()
+        dt = time.perf_counter() - t0
+        s = dev.stats()
+        dev.close()
+        ev = int(s.total_events_in - b.total_events_in)
+        return {"events_per_s": ev / dt, "ms_per_tick": dt / n * 1e3, "events_per_tick": ev // n,
+                "depth_points_per_s": int(s.total_points - b.total_points) / dt}
+
+    def latency(name, n_events, n):
+        rig, stream, p, ticks = make_workload(name, n + 6, events_cap=n_events)
+        dev = lib.Esvo(p, rig, device=device)
+        dev.ts_push_events(0, stream.ev_left)
+        dev.ts_push_events(1, stream.ev_right)
+        run_single(dev, stream, ticks, 0, 6, sync_each=True)
+        t0 = time.perf_counter()
+        run_single(dev, stream, ticks, 6, n + 6, sync_each=True)
+        dt = time.perf_counter() - t0
+        s = dev.stats()
+        dev.close()
+        return {"ms_per_tick": dt / n * 1e3, "events_per_tick": int(s.last_events_in), "points_per_tick": int(s.last_points)}
+
+    out["upenn346x260_throughput"] = throughput("upenn346x260", 20)
+    out["dsec640x480_reference_faithful_10000"] = latency("dsec640x480", 10000, 20)
+    out["upenn346x260_reference_faithful_1000"] = latency("upenn346x260", 1000, 20)
+    return out
+
+
+def cpu_baseline(rig, stream, p, ticks):
+    """The CPU oracle ("port" of the reference mapper) on the SAME stages as `value` (both Time-Surface renders + the
+    mapper tick), in steady state: the fusion window (maxNumFusionFrames) is filled first, then the median of 5 ticks is
+    taken.  Block matching + LM run on all host threads, fusion / regularisation single-threaded as in the reference."""
     from oracle import oracle
     try:
         oracle.build(fast=True, force=True)  # -O3 -march=native for THIS host
@@ -309,47 +445,54 @@ def cpu_baseline(rig, stream, p, ticks, first):
     except Exception:
         fast = False
     cores = os.cpu_count() or 1
-    t, stamps, poses, T = ticks[first]
+    n_fill, n_meas = int(p.max_fusion_frames), 5
+    use = ticks[: n_fill + n_meas]
+    cap = None if cores >= 32 else 60000  # a small host maps a bounded sample of every tick's events
     ts = [oracle.OracleTS(rig.width, rig.height, fast=fast), oracle.OracleTS(rig.width, rig.height, fast=fast)]
-    ts[0].push(stream.ev_left[stream.ns_left < t])
-    ts[1].push(stream.ev_right[stream.ns_right < t])
-    t0 = time.perf_counter()
-    l = ts[0].render(t, map_x=rig.left.map_x, map_y=rig.left.map_y)
-    r = ts[1].render(t, map_x=rig.right.map_x, map_y=rig.right.map_y)
-    t_ts = time.perf_counter() - t0
     m = oracle.OracleMapper(p, rig, fast=fast)
     m.set_threads(cores)
-    m.set_observation(t, l, r, T)
-    m.set_poses(stamps, poses)
-    idx = oracle.select_events(stream.ev_left, t, p.bm_half_slice_thickness, p.process_event_num, fast=fast)
-    sample = stream.ev_left[idx]
-    max_sample = 60000  # keeps the CPU leg around 10-30 s of core time
-    if len(sample) > max_sample:
-        sample = sample[:max_sample]
-    t0 = time.perf_counter()
-    m.tick(sample)
-    t_map = time.perf_counter() - t0
-    # the reference's own threading: NUM_THREAD_MAPPING = 4 (esvo_core/include/esvo_core/tools/utils.h:36), on a smaller sample
-    ref_threads = 4
+    done = [0, 0]
+    per_tick, n_ev = [], []
+    for k, (t, stamps, poses, T) in enumerate(use):
+        t0 = time.perf_counter()
+        for cam, (ev, ns) in enumerate(((stream.ev_left, stream.ns_left), (stream.ev_right, stream.ns_right))):
+            hi = int(np.searchsorted(ns, t, side="left"))
+            ts[cam].push(ev[done[cam]:hi])  # EventQueueMat::insertEvent of the tick's new events (TS ingest)
+            done[cam] = hi
+        l = ts[0].render(t, map_x=rig.left.map_x, map_y=rig.left.map_y)
+        r = ts[1].render(t, map_x=rig.right.map_x, map_y=rig.right.map_y)
+        t_ts = time.perf_counter() - t0
+        m.set_observation(t, l, r, T)
+        m.set_poses(stamps, poses)
+        idx = oracle.select_events(stream.ev_left, t, p.bm_half_slice_thickness, p.process_event_num, fast=fast)
+        sample = stream.ev_left[idx]
+        if cap and len(sample) > cap:
+            sample = sample[:cap]
+        t0 = time.perf_counter()
+        m.tick(sample)
+        t_map = time.perf_counter() - t0
+        if k >= n_fill:
+            per_tick.append(t_ts + t_map)
+            n_ev.append(len(sample))
+    rates = sorted(n / s for n, s in zip(n_ev, per_tick))
+    # the reference's own threading: NUM_THREAD_MAPPING = 4 (esvo_core/include/esvo_core/tools/utils.h:36), mapper only, one more tick
+    m.set_threads(4)
     small = sample[: max(len(sample) // 8, 1)]
-    m4 = oracle.OracleMapper(p, rig, fast=fast)
-    m4.set_threads(ref_threads)
-    m4.set_observation(t, l, r, T)
-    m4.set_poses(stamps, poses)
     t0 = time.perf_counter()
-    m4.tick(small)
+    pts = m.refine(m.match(small), cull=True)
     t_map4 = time.perf_counter() - t0
     return {
-        "value": len(sample) / (t_map + t_ts),
+        "value": rates[len(rates) // 2],
         "unit": "events/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"1 tick, {len(sample)} events block-matched (+ both TS renders {t_ts * 1e3:.0f} ms); "
-                  f"BM+LM on {cores} threads, fusion/regularisation single-threaded as in the reference; "
-                  f"mapper {t_map:.2f} s",
-        "reference_threading": {"value": len(small) / t_map4, "unit": "events/s", "cores": ref_threads,
-                                "sample": f"mapper only (no TS render): {len(small)} events, BM+LM on the reference's {ref_threads} "
-                                          f"threads, {t_map4:.2f} s"},
+        "sample": f"median of {n_meas} steady-state ticks (fusion window of {n_fill} frames filled first), {int(np.mean(n_ev))} events "
+                  f"block-matched per tick, same stages as `value` (TS ingest + both TS renders + mapper tick); BM + LM on {cores} "
+                  f"threads, TS / fusion / regularisation single-threaded as in the reference; {np.median(per_tick):.2f} s per tick, "
+                  f"min/max rate {rates[0]:.0f}/{rates[-1]:.0f} events/s",
+        "reference_threading": {"value": len(small) / t_map4, "unit": "events/s", "cores": 4,
+                                "sample": f"block matching + LM only ({len(small)} events, {len(pts)} points) on the reference's "
+                                          f"NUM_THREAD_MAPPING = 4 threads"},
     }
 
 

@@ -63,9 +63,13 @@ class SynthStream:
         return u, v, 1.0 / z
 
 
-def _project(rig, pw, T_world_cam):
+def _project(rig, pw, T_world_cam, wrap=None):
     R, c = T_world_cam[:3, :3], T_world_cam[:3, 3]
-    pc = (pw - c) @ R  # R^T (p - c)
+    d = pw - c
+    if wrap is not None:  # stationary scene: a point that leaves the (wider than the view) strip re-enters on the other side
+        d = d.copy()
+        d[:, 0] = (d[:, 0] + 0.5 * wrap) % wrap - 0.5 * wrap
+    pc = d @ R  # R^T (p - c)
     P = rig.left.P.reshape(3, 4)
     f, cx, cy = P[0, 0], P[0, 2], P[1, 2]
     z = pc[:, 2]
@@ -111,27 +115,37 @@ def make_scene(rig, n_points, rho_min, rho_max, rng, margin=1.3):
 
 
 def make_stream(rig, n_points, duration_s, rho_min, rho_max, seed, speed=1.0, t0_s=10.0,
-                chunk_s=2e-3, noise_frac=0.05, traj=None):
+                chunk_s=2e-3, noise_frac=0.05, traj=None, stationary=False):
+    """stationary=True: the scene is periodic along the direction of travel (per point, with the width of the strip
+    make_scene fills at that depth), so the event rate does not depend on the duration -- the benchmark stream."""
     rng = np.random.default_rng(seed)
     traj = traj or Trajectory(speed=speed, t0_s=t0_s)
     pw = make_scene(rig, n_points, rho_min, rho_max, rng)
-    # spread the scene along x so that points keep entering the view while the rig moves
-    pw[:, 0] += rng.uniform(0, speed * duration_s, size=pw.shape[0]) * 0.5
+    wrap = None
+    if stationary:
+        P = rig.left.P.reshape(3, 4)
+        wrap = 1.56 * rig.width / P[0, 0] * pw[:, 2]  # make_scene's strip: u0 in [-0.28 W, 1.28 W] at margin 1.3
+        pw[:, 0] -= (P[0, 2] - 0.5 * rig.width) / P[0, 0] * pw[:, 2]  # centre the strip on the optical axis
+    else:
+        # spread the scene along x so that points keep entering the view while the rig moves
+        pw[:, 0] += rng.uniform(0, speed * duration_s, size=pw.shape[0]) * 0.5
     W, H = rig.width, rig.height
     n_chunks = max(int(math.ceil(duration_s / chunk_s)), 1)
     out = {0: [], 1: []}
     t_prev = t0_s
-    u, v, z, ur = _project(rig, pw, traj.T_world_cam(t_prev))
+    u, v, z, ur = _project(rig, pw, traj.T_world_cam(t_prev), wrap)
     prev = {0: _raw_coords(rig, 0, u, v), 1: _raw_coords(rig, 1, ur, v)}
     z_prev = z
     for ci in range(n_chunks):
         t_next = t0_s + (ci + 1) * duration_s / n_chunks
-        u, v, z, ur = _project(rig, pw, traj.T_world_cam(t_next))
+        u, v, z, ur = _project(rig, pw, traj.T_world_cam(t_next), wrap)
         cur = {0: _raw_coords(rig, 0, u, v), 1: _raw_coords(rig, 1, ur, v)}
         for cam in (0, 1):
             ax, ay = prev[cam]
             bx, by = cur[cam]
             ok = (z_prev > 0) & (z > 0) & np.isfinite(ax) & np.isfinite(bx)
+            if wrap is not None:
+                ok &= np.abs(bx - ax) < 0.5 * W  # a point that wrapped around moved outside the view: no event trail
             disp = np.maximum(np.abs(bx - ax), np.abs(by - ay))
             disp = np.where(ok, disp, 0.0)
             n_sub = int(min(max(math.ceil(float(disp.max(initial=0.0)) * 2.0), 1), 64))

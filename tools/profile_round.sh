@@ -1,17 +1,20 @@
 #!/bin/bash
 # usage (on the GPU box, from the repo root): bash tools/profile_round.sh <tag>
-# Writes gpurun_out/<tag>_{bench.json,kernel_stats.csv,hbm_traffic.csv,sq_counters.csv}; copy them into profiles/.
+# usage: bash tools/profile_round.sh <tag> [workload]
+# Writes gpurun_out/<tag>_{bench.json,meta.json,kernel_stats.csv,hbm_traffic.csv,sq_counters.csv}; copy them into profiles/.
 # The counter passes run on their own (no trace domains besides --kernel-trace), one counter group per pass.
 tag=$1
+wl=${2:-dsec640x480}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-cmd="python $root/bench.py --steps 20 --warmup 3"
-$cmd > $out/${tag}_bench.json 2> $out/${tag}_bench.err
-rocprofv3 --kernel-trace --stats -d $out/prof_$tag -o ks -- $cmd --no-cpu-baseline > /dev/null 2>&1
+cmd="python $root/bench.py --steps 20 --warmup 3 --workload $wl"
+$cmd --no-extras > $out/${tag}_bench.json 2> $out/${tag}_bench.err
+echo "{\"workload\": \"$wl\", \"bench_cmd\": \"bench.py --steps 20 --warmup 3 (kernel stats), --steps 5 --warmup 2 (counter passes)\"}" > $out/${tag}_meta.json
+rocprofv3 --kernel-trace --stats -d $out/prof_$tag -o ks -- $cmd --no-cpu-baseline --no-extras > /dev/null 2>&1
 python $root/tools/prof_summary.py $out/prof_$tag/ks_results.db $out/${tag}_kernel_stats.csv
-short="python $root/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+short="python $root/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --workload $wl"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/prof_$tag -o fetch -- $short > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/prof_$tag -o write -- $short > /dev/null 2>&1
 python $root/tools/pmc_summary.py $out/${tag}_hbm_traffic.csv hbm $out/prof_$tag/fetch_results.db $out/prof_$tag/write_results.db
