@@ -215,7 +215,13 @@ def main():
         from esvo_amd import dist as edist
         # "tick": ticks dealt round-robin to the GPUs, one all-gather of frames per round (throughput scaling);
         # "band": every tick split over the GPUs by slot / image row band (latency of one tick)
-        cls = edist.TickShardedEsvo if shard_mode == "tick" else edist.ShardedEsvo
+        # the exchange runs inside libesvo_hip.so (esvo_comm_*: RCCL called from C); the torch.distributed drivers remain
+        # for other backends (gloo on a shared GPU: tests) and with ESVO_NATIVE_COMM=0
+        native = os.environ.get("ESVO_DIST_BACKEND", "nccl") == "nccl" and os.environ.get("ESVO_NATIVE_COMM", "1") != "0"
+        if native:
+            cls = edist.NativeTickSharded if shard_mode == "tick" else edist.NativeBandSharded
+        else:
+            cls = edist.TickShardedEsvo if shard_mode == "tick" else edist.ShardedEsvo
         runner = cls(p, rig, rank, world, local_rank)
     else:
         runner = lib.Esvo(p, rig, device=local_rank)
@@ -310,10 +316,13 @@ def main():
             "workload": workload_str,
             "image": [rig.width, rig.height],
             "events_per_tick": n_events // max(total_ticks, 1),
+            "matches_per_tick": n_matches // max(launches, 1),
+            "depth_points_per_tick": n_points // max(total_ticks, 1),
             "ticks_timed": total_ticks,
             "disparity_range": [p.bm_min_disparity, p.bm_max_disparity],
-            "parallelism": "1 GPU" if world == 1 else (f"{world} GPUs, {K} ticks per GPU dealt round-robin, all-gather of frames"
-                                                       if shard_mode == "tick" else f"{world} GPUs, slots + image row bands"),
+            "parallelism": "1 GPU" if world == 1 else ((f"{world} GPUs, {K} ticks per GPU dealt round-robin, ncclAllGather of frames"
+                                                        if shard_mode == "tick" else f"{world} GPUs, slots + image row bands")
+                                                       + (" (esvo_comm_*: RCCL inside the C library)" if native else " (torch.distributed)")),
         },
         "kernel_ms": {KERNEL_NAMES[i]: round(float(kavg[i]), 4) for i in range(7)},
         "roofline": {

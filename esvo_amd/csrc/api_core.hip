@@ -201,7 +201,11 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
   // fusion window
   h->win_cap = (u32)std::max<int64_t>((int64_t)params->max_window_points, (int64_t)E) + 2 * (u32)E;
   CK(dalloc(&h->d_win, h->win_cap));
+  // CONST_POINTS keeps frames until their points exceed 1.5 maxNumFusionPoints (esvo_Mapping.cpp:346-353): every non-empty
+  // frame holds at least one point, which bounds their number; empty frames are run-length records (context.hpp)
   h->max_frames = (u32)std::max(params->max_fusion_frames + 2, 512);
+  if (params->fusion_strategy == ESVO_FUSION_CONST_POINTS)
+    h->max_frames = std::max(h->max_frames, (u32)(1.5 * params->max_fusion_points) + 4u);
   h->n_pose_slots = h->max_frames + 1;
   h->slot_used.assign(h->n_pose_slots, 0);
   CK(dalloc(&h->d_frame_pose_T, (size_t)h->n_pose_slots * h->max_poses * 16));
@@ -258,6 +262,7 @@ int esvo_destroy(esvo_handle h) {
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
   if (h->stream_b) hipStreamSynchronize(h->stream_b);
+  comm_release(h);
   void* ptrs[] = {h->d_lut, h->d_mask, h->d_fixmap[0], h->d_fixmap[1], h->d_sae[0], h->d_sae[1], h->d_raw, h->d_ts[0],
                   h->d_ts[1], h->d_ring[0], h->d_ring[1], h->d_obs[0], h->d_obs[1], h->d_obs_tmp, h->d_T_world_obs,
                   h->d_pose_sec, h->d_pose_T2[0], h->d_pose_T2[1], h->d_scan_tmp_b, h->d_cnt_b, h->d_tick_ev, h->d_match_slots, h->d_match_flags, h->d_match_prefix,
@@ -300,6 +305,7 @@ int esvo_reset(esvo_handle h) {
     h->ts_valid[cam] = false;
   }
   h->frames.clear();
+  h->n_window_frames = 0;
   std::fill(h->slot_used.begin(), h->slot_used.end(), 0);
   HIPCHK(hipMemsetAsync(h->d_map, 0, sizeof(MapCell) * npx, h->stream));
   HIPCHK(hipMemsetAsync(h->d_map2, 0, sizeof(MapCell) * npx, h->stream));
@@ -326,6 +332,9 @@ int esvo_set_params(esvo_handle h, const esvo_params_t* params) {
     FAIL(ESVO_ERR_CAPACITY, "process_event_num exceeds the capacity fixed at esvo_create");
   {
     if ((u32)(2 * std::max(params->reg_radius, 1) + 1) > h->reg_words) FAIL(ESVO_ERR_CAPACITY, "RegularizationRadius exceeds the capacity fixed at esvo_create");
+    const u32 need = params->fusion_strategy == ESVO_FUSION_CONST_POINTS ? (u32)(1.5 * params->max_fusion_points) + 4u
+                                                                         : (u32)params->max_fusion_frames + 2u;
+    if (need > h->max_frames) FAIL(ESVO_ERR_CAPACITY, "fusion window (frames) exceeds the capacity fixed at esvo_create");
   }
   esvo_params_t np = *params;
   np.max_events_per_tick = h->prm.max_events_per_tick;

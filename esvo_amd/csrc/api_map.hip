@@ -2,7 +2,7 @@
 // calls, multi-GPU sharding, outputs and statistics (see context.hpp).
 #include "context.hpp"
 
-namespace {
+namespace esvo_host {
 
 // lower_bound over the staged time stamps with the reference's toSec() comparison
 // (tools::EventBuffer_lower_bound, utils.h:51-56); returns an absolute index
@@ -49,7 +49,7 @@ int upload_poses(esvo_context* h, const uint64_t* pose_t_ns, const double* pose_
 
 // BM over n events starting at absolute ring index `first` (reverse walk) or over d_tick_ev:
 // flags + match records in slot (thread-stride) order
-int run_bm(esvo_context* h, const esvo_event_t* d_ev, u64 first, u64 cap, int reverse, u32 n, const u32* sel = nullptr) {
+int run_bm(esvo_context* h, const esvo_event_t* d_ev, u64 first, u64 cap, int reverse, u32 n, const u32* sel) {
   BmArgs a;
   a.ev = d_ev; a.n = n; a.ev_first = first; a.ev_cap = cap; a.ev_reverse = reverse; a.sel = sel;
   a.tsL = h->d_obs[0]; a.tsR = h->d_obs[1];
@@ -145,9 +145,13 @@ void collect_back(esvo_context* h, int par) {
 // place a frame of n points in the window ring (frames stay contiguous: [oldest frame, newest frame) modulo the wrap)
 int window_reserve(esvo_context* h, u32 n, u32* off_out) {
   u32 off = 0;
-  if (!h->frames.empty()) {
-    const FrameRec& back = h->frames.back();
-    const FrameRec& front = h->frames.front();
+  const FrameRec* first = nullptr;  // oldest and newest frames that occupy ring space (empty frames hold none)
+  const FrameRec* last = nullptr;
+  for (const FrameRec& f : h->frames)
+    if (f.count) { if (!first) first = &f; last = &f; }
+  if (first) {
+    const FrameRec& back = *last;
+    const FrameRec& front = *first;
     const u32 tail = back.off + back.count;
     if (back.off >= front.off) {  // not wrapped: [front.off, tail)
       if (tail + n <= h->win_cap) off = tail;
@@ -169,7 +173,10 @@ int alloc_pose_slot(esvo_context* h, u32* slot) {
   FAIL(ESVO_ERR_CAPACITY, "no free pose-table slot (too many frames in the fusion window)");
 }
 void pop_front_frame(esvo_context* h) {
-  h->slot_used[h->frames.front().slot] = 0;
+  FrameRec& f = h->frames.front();
+  h->n_window_frames--;
+  if (f.run > 1) { f.run--; return; }
+  if (f.slot != NO_SLOT) h->slot_used[f.slot] = 0;
   h->frames.pop_front();
 }
 // window policy, esvo_Mapping.cpp:341-368
@@ -179,14 +186,21 @@ void apply_window_policy(esvo_context* h) {
     size_t np = total();
     while ((double)np > 1.5 * (double)h->prm.max_fusion_points) { pop_front_frame(h); np = total(); }
   } else {
-    while (h->frames.size() > (size_t)h->prm.max_fusion_frames) pop_front_frame(h);
+    while (h->n_window_frames > (size_t)h->prm.max_fusion_frames) pop_front_frame(h);
   }
 }
 
 // pose table of the frame: from the host (stage-wise API) or, in a tick, the front stage's device table
-int commit_frame(esvo_context* h, u32 off, u32 count, const double* pose_T_host, u32 m, int pose_buf = 0) {
+int commit_frame(esvo_context* h, u32 off, u32 count, const double* pose_T_host, u32 m, int pose_buf) {
+  if (count == 0) {  // an empty frame: no pose table, no ring space; consecutive ones share a record
+    if (!h->frames.empty() && h->frames.back().count == 0) h->frames.back().run++;
+    else h->frames.push_back(FrameRec{off, 0, NO_SLOT, 1});
+    h->n_window_frames++;
+    apply_window_policy(h);
+    return ESVO_OK;
+  }
   u32 slot;
-  int rc = alloc_pose_slot(h, &slot);
+  int rc = alloc_pose_slot(h, &slot);  // before the frame enters the deque: a failure leaves the window as it was
   if (rc) return rc;
   if (m) {
     double* dst = h->d_frame_pose_T + (size_t)slot * h->max_poses * 16;
@@ -203,9 +217,9 @@ int commit_frame(esvo_context* h, u32 off, u32 count, const double* pose_T_host,
       HIPCHK(hipEventRecord(h->evt[EV_POSE + pose_buf * EV_BACK_STRIDE], h->stream_b));
     }
   }
-  h->frames.push_back(FrameRec{off, count, slot});
+  h->frames.push_back(FrameRec{off, count, slot, 1});
+  h->n_window_frames++;
   apply_window_policy(h);
-  if (h->frames.size() > h->max_frames) FAIL(ESVO_ERR_CAPACITY, "too many frames in the fusion window");
   return ESVO_OK;
 }
 
@@ -213,14 +227,16 @@ int commit_frame(esvo_context* h, u32 off, u32 count, const double* pose_T_host,
 // pinned frame table and the event set (two ticks may be in flight)
 int run_fuse(esvo_context* h, int par, const double* T_world_obs) {
   // frames newest -> oldest (esvo_Mapping.cpp:372-377)
-  const u32 nf = (u32)h->frames.size();
   const size_t tab = 3 * (size_t)h->max_frames + 1;
   u32* cum = h->h_fr_table + (size_t)par * tab;
   u32* off = cum + (h->max_frames + 1);
   u32* slot = off + h->max_frames;
-  u32 total = 0;
-  for (u32 i = 0; i < nf; ++i) {
-    const FrameRec& f = h->frames[nf - 1 - i];
+  u32 total = 0, nf = 0;
+  for (size_t q = h->frames.size(); q-- > 0;) {
+    const FrameRec& f = h->frames[q];
+    if (f.count == 0) continue;  // empty frames contribute no point (DepthFusion::update loops over none)
+    if (nf >= h->max_frames) FAIL(ESVO_ERR_CAPACITY, "too many non-empty frames in the fusion window");
+    const u32 i = nf++;
     cum[i] = total; off[i] = f.off; slot[i] = f.slot;
     total += f.count;
   }
@@ -248,7 +264,7 @@ int run_fuse(esvo_context* h, int par, const double* T_world_obs) {
   launch_fuse(a, h->dp, sb);
   hipEventRecord(h->evt[EV_FU1 + o], sb);
   h->d_map_cur = h->d_map;
-  const bool do_clean = h->prm.clean_requires_full_window ? (h->frames.size() >= (size_t)h->prm.max_fusion_frames) : true;
+  const bool do_clean = h->prm.clean_requires_full_window ? (h->n_window_frames >= (size_t)h->prm.max_fusion_frames) : true;
   if (do_clean) launch_clean(h->d_map, h->dp, sb);
   hipEventRecord(h->evt[EV_CL1 + o], sb);
   if (h->prm.regularization) {
@@ -291,7 +307,7 @@ int export_map(esvo_context* h, std::vector<esvo_depth_point_t>& out, std::vecto
   return ESVO_OK;
 }
 
-}  // namespace
+}  // namespace esvo_host
 
 // =================================================================================================
 extern "C" {
@@ -424,7 +440,7 @@ int esvo_map_fuse(esvo_handle h, size_t* n_fusions) {
   h->committed_t_ns = h->obs_t_ns;
   HIPCHK(hipStreamSynchronize(h->stream_b));
   collect_back(h, par);
-  h->stats.last_window_frames = (u32)h->frames.size();
+  h->stats.last_window_frames = (u32)h->n_window_frames;
   u32 np = 0;
   for (auto& f : h->frames) np += f.count;
   h->stats.last_window_points = np;
@@ -620,7 +636,7 @@ int tick_phase2(esvo_context* h, int fp) {
   rc = run_fuse(h, par, tk.T_world_obs);
   if (rc) return rc;
   h->stats.ticks++;
-  h->stats.last_window_frames = (u32)h->frames.size();
+  h->stats.last_window_frames = (u32)h->n_window_frames;
   u32 np = 0;
   for (auto& f : h->frames) np += f.count;
   h->stats.last_window_points = np;
@@ -669,9 +685,11 @@ extern "C" int esvo_map_tick(esvo_handle h, uint64_t t_ns, const uint64_t* pose_
   const bool prev = h->tick_pending;
   const int prev_fp = h->fpar;
   int rc = tick_phase0(h, t_ns, pose_t_ns, pose_T, m);
-  if (rc) return rc;
-  rc = tick_phase1_enqueue(h);
-  if (rc) return rc;
+  if (!rc) rc = tick_phase1_enqueue(h);
+  if (rc) {  // the failed tick leaves no trace: the previous one (if pending) stays pending on ITS parity and is
+    h->fpar = prev_fp;  // completed -- with its own counters and staging buffer -- by the next call that needs it
+    return rc;
+  }
   if (prev) {
     rc = tick_phase1_collect(h, prev_fp);
     if (!rc) rc = tick_phase2(h, prev_fp);
@@ -746,7 +764,7 @@ extern "C" int esvo_map_fuse_async(esvo_handle h) {
   if (rc) return rc;
   h->committed_t_ns = h->obs_t_ns;
   h->stats.ticks++;
-  h->stats.last_window_frames = (u32)h->frames.size();
+  h->stats.last_window_frames = (u32)h->n_window_frames;
   u32 np = 0;
   for (auto& f : h->frames) np += f.count;
   h->stats.last_window_points = np;

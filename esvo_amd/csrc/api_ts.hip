@@ -129,6 +129,10 @@ int esvo_ts_render(esvo_handle h, int cam, uint64_t t_ns, uint8_t* out_mono8) {
   const auto& tsq = h->ts_host[cam];
   const size_t k = std::lower_bound(tsq.begin(), tsq.end(), (u64)t_ns) - tsq.begin();
   const u64 upto = h->ring_base[cam] + k;
+  // The SAE keeps ONE stamp per pixel, the reference a queue of 20 (TimeSurface.h:28-96): rendering at a T that precedes
+  // events already scattered would read pixels as empty where getMostRecentEventBeforeT finds the older event.
+  if (upto < h->scattered[cam])
+    FAIL(ESVO_ERR_STATE, "esvo_ts_render: t_ns precedes events of an earlier render (render times must not decrease; esvo_reset to replay)");
   const int evo = cam * EV_TS_STRIDE;
   if (h->ts_timing_pending[cam] && hipEventQuery(h->evt[EV_R1 + evo]) == hipSuccess) collect_ts_timing(h, cam);
   hipEventRecord(h->evt[EV_SC0 + evo], h->stream);

@@ -31,8 +31,12 @@ constexpr int EV_TS_STRIDE = EV_SC0b - EV_SC0;    // evt[EV_x + cam * EV_TS_STRI
 struct FrameRec {
   u32 off;    // offset in the window ring
   u32 count;  // points
-  u32 slot;   // pose-table slot
+  u32 slot;   // pose-table slot (NO_SLOT for empty frames)
+  u32 run;    // 1, or the number of consecutive EMPTY frames this record stands for: a frame without points adds
+              // nothing to the fusion but counts as a frame of the window (esvo_Mapping.cpp:341-368,385), and a
+              // sparse stretch under CONST_POINTS may queue any number of them
 };
+enum : u32 { NO_SLOT = 0xffffffffu };
 
 struct esvo_context {
   esvo_params_t prm;
@@ -120,7 +124,8 @@ struct esvo_context {
   u32 max_poses = 0;
   u32* d_fr_table = nullptr;      // fr_cum | fr_off | fr_slot
   u32* h_fr_table = nullptr;      // pinned
-  u32 max_frames = 0;
+  u32 max_frames = 0;             // capacity in NON-EMPTY frames (pose slots, frame tables)
+  size_t n_window_frames = 0;     // frames of the window as the reference counts them (empty ones included)
 
   // DepthMap
   DevPoint* d_prop = nullptr;
@@ -191,6 +196,8 @@ struct esvo_context {
   bool pool_ok = false;
   int pool_next = 0;
 
+  struct esvo_comm* comm = nullptr;  // multi-GPU exchange (api_comm.hip), null on single-GPU handles
+
   hipEvent_t evt[EV_N];
   bool evt_ok = false;
   esvo_stats_t stats;
@@ -207,6 +214,20 @@ void collect_ts_timing(esvo_context* h, int only = -1);
 // api_map.hip
 int flush_pending_tick(esvo_context* h);  // completes a lazily finished tick (see esvo_context::TickState)
 int finalize_tick_stats(esvo_context* h);
+int run_bm(esvo_context* h, const esvo_event_t* d_ev, u64 first, u64 cap, int reverse, u32 n, const u32* sel = nullptr);
+int run_order_points(esvo_context* h, u32 max_matches, DevPoint* dst);
+int back_after_front(esvo_context* h);
+void collect_back(esvo_context* h, int par);
+int window_reserve(esvo_context* h, u32 n, u32* off_out);
+int commit_frame(esvo_context* h, u32 off, u32 count, const double* pose_T_host, u32 m, int pose_buf = 0);
+int run_fuse(esvo_context* h, int par, const double* T_world_obs);
+int export_map(esvo_context* h, std::vector<esvo_depth_point_t>& out, std::vector<u32>* cells);
+int tick_phase0(esvo_context* h, uint64_t t_ns, const uint64_t* pose_t_ns, const double* pose_T, size_t m);
+int tick_phase1_enqueue(esvo_context* h);
+int tick_phase1_collect(esvo_context* h, int fp);
+int tick_phase2(esvo_context* h, int fp);
+// api_comm.hip
+void comm_release(esvo_context* h);
 }  // namespace esvo_host
 using namespace esvo_host;
 

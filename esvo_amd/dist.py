@@ -242,3 +242,87 @@ def merge_band_maps(parts):
     out = allp[order].copy()
     out["seq"] = np.arange(len(out), dtype=np.uint32)
     return out
+
+
+# ---- the same two modes with the exchange INSIDE libesvo_hip.so (api_comm.hip: RCCL called from C) ------------------
+# What a C++ ROS node would use: esvo_comm_init(ncclUniqueId ...) + esvo_comm_tick / esvo_comm_shard_tick.  These classes
+# only hand the unique id around (torch.distributed is used for that one broadcast) and forward the driving calls.
+def _native_comm_init(dev, rank, world, group=None):
+    import torch.distributed as dist
+    box = [lib.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0, group=group)
+    dev.comm_init(box[0], rank, world)
+
+
+class NativeTickSharded:
+    """TickShardedEsvo with the round logic and the ncclAllGather of frames in C (esvo_comm_tick)."""
+
+    counts_are_local = True
+
+    def __init__(self, params, rig, rank, world, local_rank, group=None):
+        self.rank, self.world = rank, world
+        self.rig, self.params = rig, params
+        self.dev = lib.Esvo(params, rig, device=local_rank)
+        _native_comm_init(self.dev, rank, world, group)
+        self._T = None
+
+    def ts_push_events(self, cam, ev):
+        self.dev.ts_push_events(cam, ev)
+
+    def ts_render(self, cam, t_ns, download=True):
+        if self.dev.comm_owns_next_tick():  # the SAE only has to be current at this rank's own ticks
+            return self.dev.ts_render(cam, t_ns, download)
+        return None
+
+    def set_observation(self, t_ns, ts_left, ts_right, T_world_cam):
+        self._T = T_world_cam  # esvo_comm_tick sets the observation on the owner (device-resident Time Surfaces)
+
+    def tick(self, t_ns, stamps, poses):
+        self.dev.comm_tick(t_ns, self._T, stamps, poses)
+
+    def synchronize(self):
+        self.dev.comm_flush()
+        self.dev.synchronize()
+
+    def stats(self):
+        return self.dev.stats()
+
+    def get_map(self):
+        return self.dev.comm_newest_map()[0]
+
+
+class NativeBandSharded:
+    """ShardedEsvo with the two sums (ncclAllReduce) and the all-gather of the DepthMap bands in C."""
+
+    counts_are_local = False
+
+    def __init__(self, params, rig, rank, world, local_rank, group=None):
+        self.rank, self.world = rank, world
+        self.rig, self.params = rig, params
+        self.dev = lib.Esvo(params, rig, device=local_rank)
+        y0, y1 = band_of(rank, world, rig.height)
+        if y1 <= y0:
+            raise lib.EsvoError(f"rank {rank} of {world} would own no image rows (H={rig.height})")
+        self.dev.set_band(y0, y1, rank, world)
+        _native_comm_init(self.dev, rank, world, group)
+
+    def ts_push_events(self, cam, ev):
+        self.dev.ts_push_events(cam, ev)
+
+    def ts_render(self, cam, t_ns, download=True):
+        return self.dev.ts_render(cam, t_ns, download)
+
+    def set_observation(self, *a):
+        self.dev.set_observation(*a)
+
+    def tick(self, t_ns, stamps, poses):
+        self.dev.comm_shard_tick(t_ns, stamps, poses)
+
+    def synchronize(self):
+        self.dev.synchronize()
+
+    def stats(self):
+        return self.dev.stats()
+
+    def get_map(self):
+        return self.dev.comm_gather_map()

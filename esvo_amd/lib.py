@@ -15,9 +15,9 @@ from .abi import (DEPTH_POINT_DTYPE, EVENT_DTYPE, MATCH_DTYPE, CalibStruct, Para
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 _LIB_PATH = os.path.join(_CSRC, "libesvo_hip.so")
-_SOURCES = ["api_core.hip", "api_ts.hip", "api_map.hip", "api_track.hip", "scan.hip", "kernels_ts.hip", "kernels_bm.hip", "kernels_lm.hip", "kernels_fuse.hip", "kernels_shard.hip", "kernels_track.hip"]
+_SOURCES = ["api_core.hip", "api_ts.hip", "api_map.hip", "api_comm.hip", "api_track.hip", "scan.hip", "kernels_ts.hip", "kernels_bm.hip", "kernels_lm.hip", "kernels_fuse.hip", "kernels_shard.hip", "kernels_track.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-               "-Wno-unused-value", "-Wno-unused-result"]
+               "-Wno-unused-value", "-Wno-unused-result", "-ldl"]
 
 SYMBOLS = [
     "esvo_default_params", "esvo_create", "esvo_destroy", "esvo_reset", "esvo_set_params", "esvo_last_error",
@@ -27,7 +27,12 @@ SYMBOLS = [
     "esvo_get_stats", "esvo_shard_set_band", "esvo_shard_exchange", "esvo_shard_tick_phase", "esvo_abi_sizes",
     "esvo_map_front", "esvo_map_front_frame", "esvo_map_push_frame_device", "esvo_map_fuse_async",
     "esvo_track_set_current", "esvo_track_get_images", "esvo_track_set_reference", "esvo_track_residuals", "esvo_track_jacobian",
+    "esvo_comm_unique_id", "esvo_comm_init", "esvo_comm_init_callbacks", "esvo_comm_destroy", "esvo_comm_owns_next_tick",
+    "esvo_comm_tick", "esvo_comm_flush", "esvo_comm_newest_map", "esvo_comm_shard_tick", "esvo_comm_gather_map",
 ]
+
+ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+ALL_REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
 
 
 class EsvoError(RuntimeError):
@@ -101,6 +106,16 @@ def load():
     lib.esvo_track_set_reference.argtypes = [vp, vp, sz, vp]
     lib.esvo_track_residuals.argtypes = [vp, vp, sz, sz, i32, C.c_double, vp, psz]
     lib.esvo_track_jacobian.argtypes = [vp, vp, vp, sz, sz, vp, psz]
+    lib.esvo_comm_unique_id.argtypes = [vp]
+    lib.esvo_comm_init.argtypes = [vp, vp, i32, i32]
+    lib.esvo_comm_init_callbacks.argtypes = [vp, i32, i32, ALL_GATHER_FN, ALL_REDUCE_FN, vp]
+    lib.esvo_comm_destroy.argtypes = [vp]
+    lib.esvo_comm_owns_next_tick.argtypes = [vp]
+    lib.esvo_comm_tick.argtypes = [vp, u64, vp, vp, vp, sz]
+    lib.esvo_comm_flush.argtypes = [vp]
+    lib.esvo_comm_newest_map.argtypes = [vp, vp, sz, psz, C.POINTER(C.c_longlong)]
+    lib.esvo_comm_shard_tick.argtypes = [vp, u64, vp, vp, sz]
+    lib.esvo_comm_gather_map.argtypes = [vp, vp, sz, psz]
     for s in SYMBOLS:
         if s not in ("esvo_default_params", "esvo_last_error", "esvo_abi_sizes"):
             getattr(lib, s).restype = C.c_int
@@ -121,6 +136,15 @@ def selftest_division(n=1 << 28, seed=1):
     if rc != 0:
         raise EsvoError(f"selftest failed ({rc}): {lib.esvo_last_error(None).decode()}")
     return bad.value
+
+
+def comm_unique_id():
+    """ncclGetUniqueId through the C-ABI (128 bytes; create on one rank, hand to the others)"""
+    buf = (C.c_uint8 * 128)()
+    rc = load().esvo_comm_unique_id(buf)
+    if rc != 0:
+        raise EsvoError(f"esvo_comm_unique_id failed ({rc}): {load().esvo_last_error(None).decode()}")
+    return bytes(buf)
 
 
 def abi_sizes():
@@ -320,6 +344,49 @@ class Esvo:
         n = C.c_size_t()
         self._ck(self.lib.esvo_track_jacobian(self.h, R.ctypes.data, t.ctypes.data, int(offset), int(count), out.ctypes.data, C.byref(n)))
         return out[:6 * n.value].reshape(6, n.value).T  # (n, 6); column-major like Eigen's fjac
+
+    # ---- multi-GPU exchange behind the C-ABI (api_comm.hip): RCCL, or the two collectives as callbacks ----
+    def comm_init(self, unique_id, rank, world):
+        buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
+        self._ck(self.lib.esvo_comm_init(self.h, buf, int(rank), int(world)))
+
+    def comm_init_callbacks(self, rank, world, all_gather, all_reduce):
+        """all_gather(d_send, d_recv, bytes_per_rank, stream) / all_reduce(d_buf, n_words, stream) -> 0 on success"""
+        self._cb = (ALL_GATHER_FN(lambda user, s, r, n, st: all_gather(s, r, n, st)),
+                    ALL_REDUCE_FN(lambda user, b, n, st: all_reduce(b, n, st)))  # kept alive with the handle
+        self._ck(self.lib.esvo_comm_init_callbacks(self.h, int(rank), int(world), self._cb[0], self._cb[1], None))
+
+    def comm_destroy(self):
+        self._ck(self.lib.esvo_comm_destroy(self.h))
+
+    def comm_owns_next_tick(self):
+        return bool(self.lib.esvo_comm_owns_next_tick(self.h))
+
+    def comm_tick(self, t_ns, T_world_cam, stamps, poses):
+        st = np.ascontiguousarray(stamps, np.uint64)
+        P = np.ascontiguousarray(poses, np.float64).reshape(-1, 16)
+        T = np.ascontiguousarray(T_world_cam, np.float64).reshape(16)
+        self._ck(self.lib.esvo_comm_tick(self.h, int(t_ns), T.ctypes.data, st.ctypes.data, P.ctypes.data, st.shape[0]))
+
+    def comm_flush(self):
+        self._ck(self.lib.esvo_comm_flush(self.h))
+
+    def comm_newest_map(self):
+        out = np.zeros(self.W * self.H, DEPTH_POINT_DTYPE)
+        n, k = C.c_size_t(), C.c_longlong()
+        self._ck(self.lib.esvo_comm_newest_map(self.h, out.ctypes.data, out.shape[0], C.byref(n), C.byref(k)))
+        return out[: n.value].copy(), int(k.value)
+
+    def comm_shard_tick(self, t_ns, stamps, poses):
+        st = np.ascontiguousarray(stamps, np.uint64)
+        P = np.ascontiguousarray(poses, np.float64).reshape(-1, 16)
+        self._ck(self.lib.esvo_comm_shard_tick(self.h, int(t_ns), st.ctypes.data, P.ctypes.data, st.shape[0]))
+
+    def comm_gather_map(self):
+        out = np.zeros(self.W * self.H, DEPTH_POINT_DTYPE)
+        n = C.c_size_t()
+        self._ck(self.lib.esvo_comm_gather_map(self.h, out.ctypes.data, out.shape[0], C.byref(n)))
+        return out[: n.value].copy()
 
     def set_band(self, y0, y1, shard=0, n_shards=1):
         self._ck(self.lib.esvo_shard_set_band(self.h, int(y0), int(y1), int(shard), int(n_shards)))

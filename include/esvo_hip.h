@@ -220,7 +220,15 @@ int esvo_ts_push_events(esvo_handle h, int cam, const esvo_event_t* ev, size_t n
 int esvo_ts_push_event_array(esvo_handle h, int cam, const uint8_t* msg, size_t n_bytes, size_t* n_events);
 /* Replaces TimeSurface::createTimeSurfaceAtTime (TimeSurface.cpp:52-152), BACKWARD mode.
  * Uses every staged event with ts < t_ns.  out_mono8 (W*H) may be NULL: the rectified TS
- * also stays device-resident as the camera's latest frame. */
+ * also stays device-resident as the camera's latest frame.
+ * Deviation from the reference, by construction: the device keeps ONE time stamp per pixel (the newest event with
+ * ts < t_ns at render time) where the reference keeps a queue of the last 20 events per pixel and scans it backwards
+ * (EventQueueMat, TimeSurface.h:28-96).  The two agree whenever renders are requested in non-decreasing time order --
+ * what the sync topic of the ROS graph delivers.  (a) A render at a t_ns EARLIER than events of a previous render is
+ * refused with ESVO_ERR_STATE (the queue would still find the older event, the single stamp cannot); esvo_reset and
+ * re-stage to replay.  (b) The reference's corner case "more than 20 events newer than t_ns are already queued at a
+ * pixel, so it reads as empty" (TimeSurface.h:52-75) cannot occur here: events with ts >= t_ns are never scattered
+ * before the render at t_ns. */
 int esvo_ts_render(esvo_handle h, int cam, uint64_t t_ns, uint8_t* out_mono8);
 
 /* ---- Mapper: stage-wise seams ------------------------------------------------------ */
@@ -313,6 +321,44 @@ int esvo_shard_tick_phase(esvo_handle h, int phase, uint64_t t_ns, const uint64_
                           const double* pose_T, size_t m);
 /* The buffer to sum over the ranks before the next phase (n_bytes is a multiple of 8; 0 = nothing). */
 int esvo_shard_exchange(esvo_handle h, void** d_ptr, size_t* n_bytes);
+
+/* ---- Multi-GPU exchange behind the C-ABI: one process per GPU, RCCL over xGMI ------------------
+
+ * The reference is a single-process CPU program (std::thread fan-out only); these calls exist because this
+ * implementation can spread its per-tick work over the GPUs of a node.  RCCL is loaded (dlopen) by esvo_comm_unique_id /
+ * esvo_comm_init only; every collective is issued on the handle's front stream.  All calls below are COLLECTIVE: every
+ * rank makes them in the same order with the same arguments. */
+#define ESVO_COMM_ID_BYTES 128
+/* ncclGetUniqueId on one rank; hand the bytes to the others by any means (ROS parameter server, MPI, a file). */
+int esvo_comm_unique_id(uint8_t id[ESVO_COMM_ID_BYTES]);
+/* ncclCommInitRank on the handle's device. */
+int esvo_comm_init(esvo_handle h, const uint8_t id[ESVO_COMM_ID_BYTES], int rank, int world);
+/* The same with the two collectives supplied by the caller (another transport; tests that run several ranks on one GPU):
+ * all_gather: bytes_per_rank from d_send into d_recv[rank * bytes_per_rank] on every rank; all_reduce: in-place sum of
+ * n_words 64-bit unsigned integers.  Both must be ordered after the work already enqueued on hip_stream and must have
+ * completed (or be enqueued on hip_stream) when they return 0. */
+typedef int (*esvo_all_gather_fn)(void* user, const void* d_send, void* d_recv, size_t bytes_per_rank, void* hip_stream);
+typedef int (*esvo_all_reduce_u64_fn)(void* user, void* d_buf, size_t n_words, void* hip_stream);
+int esvo_comm_init_callbacks(esvo_handle h, int rank, int world, esvo_all_gather_fn all_gather,
+                             esvo_all_reduce_u64_fn all_reduce, void* user);
+int esvo_comm_destroy(esvo_handle h);
+/* Tick-interleaved operation (throughput scales with the GPUs; the latency of one tick does not change): rank r maps
+ * the ticks k = r (mod world) completely.  A tick depends on earlier ticks only through the frames of its fusion window
+ * (MappingAtTime builds a new DepthFrame at every tick, esvo_Mapping.cpp:266-272,341-377), so after every `world` ticks the
+ * ranks exchange that round's frames with ONE ncclAllGather (each block carries its point count: one host wait per
+ * round), push them into their windows in tick order and fuse at their own tick.
+ * esvo_comm_tick replaces esvo_map_set_observation + esvo_map_tick: every rank calls it for every tick; the rank for which
+ * esvo_comm_owns_next_tick() is 1 must have rendered both Time Surfaces of that tick (esvo_ts_render) beforehand. */
+int esvo_comm_owns_next_tick(esvo_handle h);
+int esvo_comm_tick(esvo_handle h, uint64_t t_ns, const double T_world_cam[16], const uint64_t* pose_t_ns, const double* pose_T,
+                   size_t m);
+int esvo_comm_flush(esvo_handle h);  /* completes a partial round */
+/* The DepthMap of the newest tick on every rank (it lives on the rank that mapped it: all-gather of the newest maps). */
+int esvo_comm_newest_map(esvo_handle h, esvo_depth_point_t* out, size_t cap, size_t* n, long long* tick_index);
+/* One tick split over the ranks (esvo_shard_set_band first): the three phases of esvo_shard_tick_phase with their two
+ * sums as ncclAllReduce(ncclUint64, ncclSum), and the all-gather of the DepthMap bands, merged on the creation order. */
+int esvo_comm_shard_tick(esvo_handle h, uint64_t t_ns, const uint64_t* pose_t_ns, const double* pose_T, size_t m);
+int esvo_comm_gather_map(esvo_handle h, esvo_depth_point_t* out, size_t cap, size_t* n);
 
 /* ---- Tracker residual / Jacobian evaluation ---------------------- */
 

@@ -1,0 +1,195 @@
+"""The multi-GPU exchange behind the C-ABI (esvo_comm_*, esvo_amd/csrc/api_comm.hip) on ONE GPU.
+
+* real RCCL with a one-rank communicator: ncclGetUniqueId / ncclCommInitRank / ncclAllGather run from libesvo_hip.so;
+* several ranks = several handles driven from threads, their collectives supplied as callbacks that rendezvous in-process
+  (esvo_comm_init_callbacks): the round logic, the in-band counts, block growth, partial rounds, buffer reuse, the band
+  mode's two sums and the all-gather of the DepthMap bands are the code a node with one process per GPU runs.
+Every tick's DepthMap must equal the single-handle one bit for bit."""
+import threading
+
+import numpy as np
+import pytest
+
+from esvo_amd import dist as edist
+from esvo_amd import params, rostime
+
+pytestmark = pytest.mark.gpu
+F64 = ["inv_depth", "scale2", "nu", "variance", "residual", "x", "p_cam"]
+
+
+def _same(a, b):
+    assert len(a) == len(b), (len(a), len(b))
+    for f in ("row", "col", "age"):
+        assert np.array_equal(a[f], b[f]), f
+    for f in F64:
+        assert np.array_equal(a[f], b[f]), f
+
+
+def _ticks(stream, p, n, t_first=0.06, dt=0.01):
+    out = []
+    for k in range(n):
+        t = stream.t0_ns + int((t_first + k * dt) * 1e9)
+        stamps, poses = rostime.pose_table(stream.pose, t, p.bm_half_slice_thickness)
+        out.append((t, stamps, poses, stream.pose(t)))
+    return out
+
+
+def _single(p, rig, stream, ticks):
+    from esvo_amd import lib
+    dev = lib.Esvo(p, rig)
+    dev.ts_push_events(0, stream.ev_left)
+    dev.ts_push_events(1, stream.ev_right)
+    maps = []
+    for t, stamps, poses, T in ticks:
+        dev.ts_render(0, t, download=False)
+        dev.ts_render(1, t, download=False)
+        dev.set_observation(t, None, None, T)
+        dev.tick(t, stamps, poses)
+        maps.append(dev.get_map())
+    return maps
+
+
+class LocalTransport:
+    """the two collectives between handles of one process: a rendezvous + device copies"""
+
+    def __init__(self, world):
+        self.world = world
+        self.bar = threading.Barrier(world, timeout=90)
+        self.slots = [None] * world
+
+    def all_gather(self, rank, d_send, d_recv, nbytes):
+        import torch
+        torch.cuda.synchronize()
+        self.slots[rank] = d_send
+        self.bar.wait()
+        for r in range(self.world):
+            src = edist.device_tensor(self.slots[r], nbytes // 8, "<i8")
+            edist.device_tensor(d_recv + r * nbytes, nbytes // 8, "<i8").copy_(src)
+        torch.cuda.synchronize()
+        self.bar.wait()
+        return 0
+
+    def all_reduce(self, rank, d_buf, n_words):
+        import torch
+        torch.cuda.synchronize()
+        self.slots[rank] = d_buf
+        self.bar.wait()
+        total = sum(edist.device_tensor(self.slots[r], n_words, "<i8").clone() for r in range(self.world))
+        torch.cuda.synchronize()
+        self.bar.wait()
+        edist.device_tensor(d_buf, n_words, "<i8").copy_(total)
+        torch.cuda.synchronize()
+        self.bar.wait()
+        return 0
+
+
+def _run_ranks(world, body):
+    errs, outs = [], [None] * world
+
+    def main(r):
+        try:
+            outs[r] = body(r)
+        except BaseException as e:  # noqa: BLE001
+            errs.append((r, e))
+            try:
+                tr_abort()
+            except Exception:
+                pass
+
+    def tr_abort():
+        pass
+
+    th = [threading.Thread(target=main, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert not errs, errs
+    return outs
+
+
+def test_rccl_one_rank_communicator(upenn_rig, upenn_stream):
+    from esvo_amd import lib
+    p, _ = params.make_params(params.PRESETS["mapping_upenn"], upenn_rig)
+    ticks = _ticks(upenn_stream, p, 5)
+    ref = _single(p, upenn_rig, upenn_stream, ticks)
+    dev = lib.Esvo(p, upenn_rig)
+    dev.comm_init(lib.comm_unique_id(), 0, 1)
+    dev.ts_push_events(0, upenn_stream.ev_left)
+    dev.ts_push_events(1, upenn_stream.ev_right)
+    for k, (t, stamps, poses, T) in enumerate(ticks):
+        assert dev.comm_owns_next_tick()
+        dev.ts_render(0, t, download=False)
+        dev.ts_render(1, t, download=False)
+        dev.comm_tick(t, T, stamps, poses)
+        mp, idx = dev.comm_newest_map()
+        assert idx == k
+        _same(mp, ref[k])
+    assert dev.stats().ticks == len(ticks)
+    dev.comm_destroy()
+
+
+@pytest.mark.parametrize("world,preset,rig_fix,stream_fix,n_ticks", [
+    (2, "mapping_upenn", "upenn_rig", "upenn_stream", 7),      # CONST_POINTS window, a partial last round
+    (3, "mapping_dsec", "dsec_rig", "dsec_stream", 7),         # CONST_FRAMES 5, 3x3 fusion, regulariser
+])
+def test_tick_interleaved_ranks_through_the_c_calls(request, world, preset, rig_fix, stream_fix, n_ticks):
+    from esvo_amd import lib
+    rig, stream = request.getfixturevalue(rig_fix), request.getfixturevalue(stream_fix)
+    p, _ = params.make_params(params.PRESETS[preset], rig, process_event_num=3000)
+    ticks = _ticks(stream, p, n_ticks)
+    ref = _single(p, rig, stream, ticks)
+    tr = LocalTransport(world)
+
+    def body(r):
+        dev = lib.Esvo(p, rig)
+        dev.comm_init_callbacks(r, world, lambda s, d, n, st: tr.all_gather(r, s, d, n), lambda b, n, st: tr.all_reduce(r, b, n))
+        dev.ts_push_events(0, stream.ev_left)
+        dev.ts_push_events(1, stream.ev_right)
+        got = {}
+        for k, (t, stamps, poses, T) in enumerate(ticks):
+            if dev.comm_owns_next_tick():
+                dev.ts_render(0, t, download=False)
+                dev.ts_render(1, t, download=False)
+            dev.comm_tick(t, T, stamps, poses)
+            if k % world == world - 1 or k == 3 or k == len(ticks) - 1:   # round ends, one flush inside a round, the tail
+                mp, idx = dev.comm_newest_map()
+                got[idx] = mp
+        s = dev.stats()
+        return got, int(s.ticks)
+
+    outs = _run_ranks(world, body)
+    assert sum(o[1] for o in outs) == n_ticks
+    for got, _ in outs:
+        assert got and (n_ticks - 1) in got
+        for idx, mp in got.items():
+            _same(mp, ref[idx])
+
+
+def test_band_sharded_ranks_through_the_c_calls(dsec_rig, dsec_stream):
+    from esvo_amd import lib
+    world = 2
+    p, _ = params.make_params(params.PRESETS["mapping_dsec"], dsec_rig, process_event_num=3000)
+    ticks = _ticks(dsec_stream, p, 3)
+    ref = _single(p, dsec_rig, dsec_stream, ticks)
+    tr = LocalTransport(world)
+
+    def body(r):
+        dev = lib.Esvo(p, dsec_rig)
+        y0, y1 = edist.band_of(r, world, dsec_rig.height)
+        dev.set_band(y0, y1, r, world)
+        dev.comm_init_callbacks(r, world, lambda s, d, n, st: tr.all_gather(r, s, d, n), lambda b, n, st: tr.all_reduce(r, b, n))
+        dev.ts_push_events(0, dsec_stream.ev_left)
+        dev.ts_push_events(1, dsec_stream.ev_right)
+        maps = []
+        for t, stamps, poses, T in ticks:
+            dev.ts_render(0, t, download=False)
+            dev.ts_render(1, t, download=False)
+            dev.set_observation(t, None, None, T)
+            dev.comm_shard_tick(t, stamps, poses)
+            maps.append(dev.comm_gather_map())
+        return maps
+
+    for maps in _run_ranks(world, body):
+        for k, mp in enumerate(maps):
+            _same(mp, ref[k])

@@ -285,3 +285,54 @@ def test_committed_map_lags_one_tick(dsec_rig, dsec_stream):
         prev, prev_t = eager.get_map(), t
     _same_map(lazy.get_map(), prev)          # completing the pending tick gives the newest map
     assert lazy.get_committed_map()[1] == prev_t
+
+
+def test_render_times_must_not_decrease(upenn_rig, upenn_stream):
+    """The SAE keeps one stamp per pixel (the reference: a queue of 20, TimeSurface.h:28-96): a render EARLIER than events of
+    a previous render is refused, a repeated render at the same time is idempotent, esvo_reset allows a replay."""
+    from esvo_amd import lib
+    p, _ = params.make_params(params.PRESETS["mvstereo_upenn"], upenn_rig)
+    dev = lib.Esvo(p, upenn_rig)
+    dev.ts_push_events(0, upenn_stream.ev_left)
+    t1, t2 = upenn_stream.t0_ns + 50_000_000, upenn_stream.t0_ns + 80_000_000
+    a = dev.ts_render(0, t2)
+    assert np.array_equal(dev.ts_render(0, t2), a)
+    with pytest.raises(lib.EsvoError, match="render times must not decrease"):
+        dev.ts_render(0, t1)
+    assert np.array_equal(dev.ts_render(0, t2), a)          # the refused call left the state alone
+    dev.reset()
+    dev.ts_push_events(0, upenn_stream.ev_left)
+    b = dev.ts_render(0, t1)
+    assert b.any() and not np.array_equal(a, b)
+    assert np.array_equal(dev.ts_render(0, t2), a)
+
+
+def test_sparse_stretch_under_const_points_does_not_exhaust_the_window(upenn_rig, upenn_stream):
+    """CONST_POINTS keeps frames until their POINTS exceed 1.5 maxNumFusionPoints (esvo_Mapping.cpp:341-353): on a sparse
+    stretch the deque grows without bound in the reference.  600 empty and 700 one-point frames must neither fail nor
+    change what the fusion sees; the window's frame count (the clean gate, :385) still counts them."""
+    from esvo_amd import lib
+    from oracle import oracle as O
+    p, _ = params.make_params(params.PRESETS["mapping_upenn"], upenn_rig)
+    dev = lib.Esvo(p, upenn_rig)
+    m = O.OracleMapper(p, upenn_rig)
+    m.set_mode(True, True)
+    ots = [O.OracleTS(upenn_rig.width, upenn_rig.height), O.OracleTS(upenn_rig.width, upenn_rig.height)]
+    ots[0].push(upenn_stream.ev_left)
+    ots[1].push(upenn_stream.ev_right)
+    t = upenn_stream.t0_ns + 100_000_000
+    stamps, poses = _oracle_tick(O, m, ots, upenn_rig, upenn_stream, p, t)
+    idx = O.select_events(upenn_stream.ev_left, t, p.bm_half_slice_thickness, p.process_event_num)
+    pts = m.refine(m.match(upenn_stream.ev_left[idx]), cull=True)
+    assert len(pts) > 50
+    dev.set_observation(t, ots[0].render(t, map_x=upenn_rig.left.map_x, map_y=upenn_rig.left.map_y),
+                        ots[1].render(t, map_x=upenn_rig.right.map_x, map_y=upenn_rig.right.map_y), upenn_stream.pose(t))
+    for mapper in (dev, m):
+        mapper.push_frame(pts, poses)
+        for _ in range(600):
+            mapper.push_frame(pts[:0], poses)
+        for k in range(700):
+            mapper.push_frame(pts[k % len(pts):k % len(pts) + 1], poses)
+    assert dev.fuse() == m.fuse()
+    _same_map(dev.get_map(), m.get_map())
+    assert dev.stats().last_window_frames == 1301 == m.counters()["window_frames"]
