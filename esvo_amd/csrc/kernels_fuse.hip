@@ -416,6 +416,7 @@ __global__ void __launch_bounds__(256) reg_view_kernel(const MapCell* __restrict
 #define REG_TY 4
 #define REG_MARGIN 1   // an element's believed (row, col) is at most one cell away from its true cell (Appendix A-7)
 #define REG_MAXW (REG_TX + 2 * 31 + 2 * REG_MARGIN)
+template <int RT>  // RegularizationRadius when it is one of the shipped values (5, 20): the tap loop unrolls; 0: any radius
 __global__ void __launch_bounds__(REG_TX * REG_TY) reg_apply_kernel(const MapCell* __restrict__ map, MapCell* __restrict__ out,
                                                                     const u32* __restrict__ owner_max,
                                                                     const u32* __restrict__ owner_min,
@@ -429,7 +430,7 @@ __global__ void __launch_bounds__(REG_TX * REG_TY) reg_apply_kernel(const MapCel
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const int tiles_x = (p.W + REG_TX - 1) / REG_TX;
   const int tile_c0 = (int)(blockIdx.x % tiles_x) * REG_TX, tile_r0 = (int)(blockIdx.x / tiles_x) * REG_TY;
-  const int R = p.reg_radius, Wn = 2 * R + 1;
+  const int R = RT > 0 ? RT : p.reg_radius, Wn = 2 * R + 1;
   // ---- the tile's elements, compacted in row-major order ----
   const int cr = tile_r0 + wv, cc = tile_c0 + lane;
   bool alive = false;
@@ -537,11 +538,25 @@ __global__ void __launch_bounds__(REG_TX * REG_TY) reg_apply_kernel(const MapCel
       nb += (u32)__popcll(bits);
       u64 cm = 0;
       if (bits) {
-        for (int dc = 0; dc < Wn; ++dc) {
-          const double2 q = s_ab[buf][off + dc];
-          const double diff = fabs(inv - q.x);
-          if (diff < sd_self2 || diff < q.y) cm |= 1ull << dc;
+        // |rho_self - rho_n| < 2 sigma_self || < 2 sigma_n  ==  < max(2 sigma_self, 2 sigma_n); a NaN tap fails, as
+        // fmax returns the other operand and the difference is NaN.  Bits are collected in two 32-bit halves.
+        u32 lo = 0, hi = 0;
+        const double2* tap = &s_ab[buf][off];
+        if (RT > 0) {
+#pragma unroll
+          for (int dc = 0; dc < 2 * RT + 1; ++dc) {
+            const double2 q = tap[dc];
+            const bool close = fabs(inv - q.x) < fmax(sd_self2, q.y);
+            if (dc < 32) lo |= close ? (1u << dc) : 0u; else hi |= close ? (1u << (dc - 32)) : 0u;
+          }
+        } else {
+          for (int dc = 0; dc < Wn; ++dc) {
+            const double2 q = tap[dc];
+            const bool close = fabs(inv - q.x) < fmax(sd_self2, q.y);
+            if (dc < 32) lo |= close ? (1u << dc) : 0u; else hi |= close ? (1u << (dc - 32)) : 0u;
+          }
         }
+        cm = ((u64)hi << 32) | lo;
       }
       nclose += (u32)__popcll(cm);
       while (cm) {
@@ -595,8 +610,10 @@ void launch_reg_apply(const MapCell* map_in, MapCell* map_out, const u32* owner_
   if (ty1 <= ty0) return;
   // grid = all tile rows (blockIdx -> tile); tiles outside the band find no element and leave at once
   const int tiles_y = (p.H + REG_TY - 1) / REG_TY;
-  hipLaunchKernelGGL(reg_apply_kernel, dim3(tiles_x * tiles_y), dim3(REG_TX * REG_TY), 0, s, map_in, map_out, owner_max,
-                     owner_min, ab, cd, p);
+  const dim3 grid(tiles_x * tiles_y), block(REG_TX * REG_TY);
+  if (p.reg_radius == 20) hipLaunchKernelGGL(reg_apply_kernel<20>, grid, block, 0, s, map_in, map_out, owner_max, owner_min, ab, cd, p);
+  else if (p.reg_radius == 5) hipLaunchKernelGGL(reg_apply_kernel<5>, grid, block, 0, s, map_in, map_out, owner_max, owner_min, ab, cd, p);
+  else hipLaunchKernelGGL(reg_apply_kernel<0>, grid, block, 0, s, map_in, map_out, owner_max, owner_min, ab, cd, p);
 }
 
 // ---- export: alive cells -> esvo_depth_point_t list (cell order; host orders by seq) --------------
