@@ -844,6 +844,124 @@ int esvo_map_get_pointcloud_xyz(esvo_handle h, float* out_xyz, size_t cap_points
   return ESVO_OK;
 }
 
+// pc_near_ of publishPointCloud (esvo_Mapping.cpp:925-932): what the global-cloud voxel filter is fed
+int esvo_map_get_pointcloud_near_xyz(esvo_handle h, double visualize_range, float* out_xyz, size_t cap_points, size_t* n) {
+  if (!h || !n) return ESVO_ERR_INVALID_ARG;
+  HIPCHK(hipSetDevice(h->device));
+  { int rcp = flush_pending_tick(h); if (rcp) return rcp; }
+  std::vector<esvo_depth_point_t> v;
+  int rc = export_map(h, v, nullptr);
+  if (rc) return rc;
+  const double* T = h->T_world_frame;
+  size_t k = 0;
+  for (size_t i = 0; i < v.size(); ++i) {
+    const double* q = v[i].p_cam;
+    if (!(std::sqrt((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]) < visualize_range)) continue;
+    if (out_xyz) {
+      if (k >= cap_points) FAIL(ESVO_ERR_CAPACITY, "output array too small for the point cloud");
+      for (int r = 0; r < 3; ++r)
+        out_xyz[3 * k + r] = (float)(((T[r * 4 + 0] * q[0] + T[r * 4 + 1] * q[1]) + T[r * 4 + 2] * q[2]) + T[r * 4 + 3]);
+    }
+    ++k;
+  }
+  *n = k;
+  return ESVO_OK;
+}
+
+// pcl::VoxelGrid<PointXYZ> with a cubic leaf (esvo_Mapping.cpp:960-964): host code, as in the reference -- it runs on a
+// few ten thousand points once per visualizeGPC_interval.  Float arithmetic throughout; one centroid per occupied voxel
+// in ascending voxel index (x fastest); the points of a voxel are summed in input order.
+int esvo_voxel_filter_xyz(const float* xyz, size_t n, float leaf, float* out_xyz, size_t cap_points, size_t* n_out) {
+  esvo_context* h = nullptr;
+  if ((n && !xyz) || !n_out || !(leaf > 0)) return ESVO_ERR_INVALID_ARG;
+  std::vector<size_t> fin;
+  float mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
+  for (size_t i = 0; i < n; ++i) {
+    const float* p = xyz + 3 * i;
+    if (!std::isfinite(p[0]) || !std::isfinite(p[1]) || !std::isfinite(p[2])) continue;
+    if (fin.empty()) for (int c = 0; c < 3; ++c) mn[c] = mx[c] = p[c];
+    for (int c = 0; c < 3; ++c) { mn[c] = std::min(mn[c], p[c]); mx[c] = std::max(mx[c], p[c]); }
+    fin.push_back(i);
+  }
+  *n_out = 0;
+  if (fin.empty()) return ESVO_OK;
+  const float inv = 1.0f / leaf;
+  long long minb[3], divb[3];
+  for (int c = 0; c < 3; ++c) {
+    minb[c] = (long long)std::floor(mn[c] * inv);
+    divb[c] = (long long)std::floor(mx[c] * inv) - minb[c] + 1;
+  }
+  if ((double)divb[0] * (double)divb[1] * (double)divb[2] > 2147483647.0)
+    FAIL(ESVO_ERR_CAPACITY, "leaf size too small for the extent of the cloud (voxel index overflows, as in pcl::VoxelGrid)");
+  std::vector<std::pair<long long, size_t>> idx;
+  idx.reserve(fin.size());
+  for (size_t i : fin) {
+    const float* p = xyz + 3 * i;
+    const long long a = (long long)std::floor(p[0] * inv) - minb[0], b = (long long)std::floor(p[1] * inv) - minb[1],
+                    c = (long long)std::floor(p[2] * inv) - minb[2];
+    idx.emplace_back(a + b * divb[0] + c * divb[0] * divb[1], i);
+  }
+  std::stable_sort(idx.begin(), idx.end(),
+                   [](const std::pair<long long, size_t>& x, const std::pair<long long, size_t>& y) { return x.first < y.first; });
+  size_t k = 0;
+  for (size_t a = 0; a < idx.size();) {
+    size_t b = a;
+    float c[3] = {0, 0, 0};
+    while (b < idx.size() && idx[b].first == idx[a].first) {
+      for (int d = 0; d < 3; ++d) c[d] += xyz[3 * idx[b].second + d];
+      ++b;
+    }
+    if (out_xyz) {
+      if (k >= cap_points) FAIL(ESVO_ERR_CAPACITY, "output array too small for the filtered cloud");
+      for (int d = 0; d < 3; ++d) out_xyz[3 * k + d] = c[d] / (float)(b - a);
+    }
+    ++k;
+    a = b;
+  }
+  *n_out = k;
+  return ESVO_OK;
+}
+
+// Visualization::plot_map x 4 with publishMappingResults' arguments (esvo_Mapping.cpp:868-884)
+int esvo_map_get_debug_images(esvo_handle h, double age_max_range, uint8_t* inv_depth_bgr, uint8_t* stdvar_bgr, uint8_t* age_bgr,
+                              uint8_t* cost_bgr) {
+  if (!h) return ESVO_ERR_INVALID_ARG;
+  HIPCHK(hipSetDevice(h->device));
+  { int rcp = flush_pending_tick(h); if (rcp) return rcp; }
+  const size_t npx = (size_t)h->W * h->H;
+  if (!h->d_viz_bgr) {
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&h->d_viz_bgr), npx * 3));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&h->d_viz_owner), npx * sizeof(u32)));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&h->d_viz_jet), 768));
+    // the reference's colour tables are jet on i / 255 (Visualization.cpp:128-226): 255 * channel =
+    // clamp(min(4 i + a, -4 i + b), 0, 255), stored in an 8-bit image by rounding half to even
+    uint8_t jet[768];
+    const double ab[3][2] = {{127.5, 637.5}, {-127.5, 892.5}, {-382.5, 1147.5}};  // B, G, R
+    for (int i = 0; i < 256; ++i)
+      for (int c = 0; c < 3; ++c) {
+        double v = std::min(4.0 * i + ab[c][0], -4.0 * i + ab[c][1]);
+        v = v < 0 ? 0 : (v > 255 ? 255 : v);
+        jet[3 * i + c] = (uint8_t)std::nearbyint(v);
+      }
+    HIPCHK(hipMemcpy(h->d_viz_jet, jet, 768, hipMemcpyHostToDevice));
+  }
+  const esvo_params_t& p = h->prm;
+  const double cost_thr = p.residual_vis_threshold * p.residual_vis_threshold * (p.patch_size_x * p.patch_size_y);  // esvo_Mapping.cpp:97
+  struct { uint8_t* out; int type; double mx, mn, t1, t2; } img[4] = {
+      {inv_depth_bgr, 0, p.invdepth_max, p.invdepth_min, p.stdvar_vis_threshold, p.age_vis_threshold},
+      {stdvar_bgr, 1, p.stdvar_vis_threshold, 0.0, p.stdvar_vis_threshold, 0.0},
+      {age_bgr, 3, age_max_range, 0.0, p.age_vis_threshold, 0.0},
+      {cost_bgr, 2, cost_thr, 0.0, cost_thr, 0.0}};
+  for (auto& im : img) {
+    if (!im.out) continue;
+    launch_debug_image(h->d_map_cur, h->d_viz_owner, h->d_viz_bgr, h->d_viz_jet, im.type, im.mx, im.mn, im.t1, im.t2, h->dp, h->stream_b);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(im.out, h->d_viz_bgr, npx * 3, hipMemcpyDeviceToHost, h->stream_b));
+    HIPCHK(hipStreamSynchronize(h->stream_b));
+  }
+  return ESVO_OK;
+}
+
 int esvo_map_get_last_frame(esvo_handle h, esvo_depth_point_t* out, size_t cap, size_t* n) {
   if (!h || !n) return ESVO_ERR_INVALID_ARG;
   HIPCHK(hipSetDevice(h->device));

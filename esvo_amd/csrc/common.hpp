@@ -255,6 +255,9 @@ void launch_reg_view(const MapCell* map_in, MapCell* map_out, u32* owner_max, u3
                      u32* n_elems, const DevParams& p, hipStream_t s);
 void launch_reg_apply(const MapCell* map_in, MapCell* map_out, const u32* owner_max, const u32* owner_min, const double2* ab,
                       const double2* cd, const DevParams& p, hipStream_t s);
+// kernels_viz.hip
+void launch_debug_image(const MapCell* map, u32* owner, uint8_t* bgr, const uint8_t* jet, int type, double max_range,
+                        double min_range, double thr1, double thr2, const DevParams& p, hipStream_t s);
 void launch_map_compact(const MapCell* map, u32* flags, u32* prefix, u32* d_total, u32* scan_tmp,
                         esvo_depth_point_t* out, u32* out_cell, const DevParams& p, hipStream_t s);
 

@@ -196,6 +196,11 @@ struct esvo_context {
   bool pool_ok = false;
   int pool_next = 0;
 
+  // debug images (kernels_viz.hip): allocated on first use
+  uint8_t* d_viz_bgr = nullptr;
+  uint8_t* d_viz_jet = nullptr;
+  u32* d_viz_owner = nullptr;
+
   struct esvo_comm* comm = nullptr;  // multi-GPU exchange (api_comm.hip), null on single-GPU handles
 
   hipEvent_t evt[EV_N];

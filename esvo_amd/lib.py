@@ -15,7 +15,7 @@ from .abi import (DEPTH_POINT_DTYPE, EVENT_DTYPE, MATCH_DTYPE, CalibStruct, Para
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 _LIB_PATH = os.path.join(_CSRC, "libesvo_hip.so")
-_SOURCES = ["api_core.hip", "api_ts.hip", "api_map.hip", "api_comm.hip", "api_track.hip", "scan.hip", "kernels_ts.hip", "kernels_bm.hip", "kernels_lm.hip", "kernels_fuse.hip", "kernels_shard.hip", "kernels_track.hip"]
+_SOURCES = ["api_core.hip", "api_ts.hip", "api_map.hip", "api_comm.hip", "api_bag.hip", "api_track.hip", "scan.hip", "kernels_ts.hip", "kernels_bm.hip", "kernels_lm.hip", "kernels_fuse.hip", "kernels_shard.hip", "kernels_track.hip", "kernels_viz.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
                "-Wno-unused-value", "-Wno-unused-result", "-ldl"]
 
@@ -27,6 +27,8 @@ SYMBOLS = [
     "esvo_get_stats", "esvo_shard_set_band", "esvo_shard_exchange", "esvo_shard_tick_phase", "esvo_abi_sizes",
     "esvo_map_front", "esvo_map_front_frame", "esvo_map_push_frame_device", "esvo_map_fuse_async",
     "esvo_track_set_current", "esvo_track_get_images", "esvo_track_set_reference", "esvo_track_residuals", "esvo_track_jacobian",
+    "esvo_bag_open", "esvo_bag_close", "esvo_bag_last_error", "esvo_bag_next_event_array", "esvo_ts_push_bag",
+    "esvo_map_get_debug_images", "esvo_map_get_pointcloud_near_xyz", "esvo_voxel_filter_xyz",
     "esvo_comm_unique_id", "esvo_comm_init", "esvo_comm_init_callbacks", "esvo_comm_destroy", "esvo_comm_owns_next_tick",
     "esvo_comm_tick", "esvo_comm_flush", "esvo_comm_newest_map", "esvo_comm_shard_tick", "esvo_comm_gather_map",
 ]
@@ -106,6 +108,14 @@ def load():
     lib.esvo_track_set_reference.argtypes = [vp, vp, sz, vp]
     lib.esvo_track_residuals.argtypes = [vp, vp, sz, sz, i32, C.c_double, vp, psz]
     lib.esvo_track_jacobian.argtypes = [vp, vp, vp, sz, sz, vp, psz]
+    lib.esvo_bag_open.argtypes = [C.c_char_p, C.POINTER(vp)]
+    lib.esvo_bag_close.argtypes = [vp]
+    lib.esvo_bag_last_error.argtypes = [vp]
+    lib.esvo_bag_next_event_array.argtypes = [vp, C.c_char_p, C.POINTER(vp), psz, C.POINTER(C.c_uint64), C.POINTER(C.c_char_p)]
+    lib.esvo_ts_push_bag.argtypes = [vp, i32, vp, C.c_char_p, u64, psz]
+    lib.esvo_map_get_debug_images.argtypes = [vp, C.c_double, vp, vp, vp, vp]
+    lib.esvo_map_get_pointcloud_near_xyz.argtypes = [vp, C.c_double, vp, sz, psz]
+    lib.esvo_voxel_filter_xyz.argtypes = [vp, sz, C.c_float, vp, sz, psz]
     lib.esvo_comm_unique_id.argtypes = [vp]
     lib.esvo_comm_init.argtypes = [vp, vp, i32, i32]
     lib.esvo_comm_init_callbacks.argtypes = [vp, i32, i32, ALL_GATHER_FN, ALL_REDUCE_FN, vp]
@@ -117,10 +127,11 @@ def load():
     lib.esvo_comm_shard_tick.argtypes = [vp, u64, vp, vp, sz]
     lib.esvo_comm_gather_map.argtypes = [vp, vp, sz, psz]
     for s in SYMBOLS:
-        if s not in ("esvo_default_params", "esvo_last_error", "esvo_abi_sizes"):
+        if s not in ("esvo_default_params", "esvo_last_error", "esvo_abi_sizes", "esvo_bag_last_error"):
             getattr(lib, s).restype = C.c_int
     lib.esvo_abi_sizes.argtypes = [vp]
     lib.esvo_abi_sizes.restype = None
+    lib.esvo_bag_last_error.restype = C.c_char_p
     _lib = lib
     return lib
 
@@ -136,6 +147,47 @@ def selftest_division(n=1 << 28, seed=1):
     if rc != 0:
         raise EsvoError(f"selftest failed ({rc}): {lib.esvo_last_error(None).decode()}")
     return bad.value
+
+
+class BagReader:
+    """rosbag format 2.0 reader of the C-ABI (esvo_bag_*): iterates (topic, bag stamp ns, serialised EventArray bytes)"""
+
+    def __init__(self, path):
+        self.lib = load()
+        b = C.c_void_p()
+        rc = self.lib.esvo_bag_open(path.encode(), C.byref(b))
+        if rc != 0:
+            raise EsvoError(f"esvo_bag_open failed ({rc}): {self.lib.esvo_last_error(None).decode()}")
+        self.b = b
+
+    def close(self):
+        if getattr(self, "b", None):
+            self.lib.esvo_bag_close(self.b)
+            self.b = None
+
+    def __del__(self):
+        self.close()
+
+    def messages(self, topic=None):
+        while True:
+            msg, nb, st, tp = C.c_void_p(), C.c_size_t(), C.c_uint64(), C.c_char_p()
+            rc = self.lib.esvo_bag_next_event_array(self.b, topic.encode() if topic else None, C.byref(msg), C.byref(nb), C.byref(st), C.byref(tp))
+            if rc == 1:
+                return
+            if rc != 0:
+                raise EsvoError(f"bag read failed ({rc}): {self.lib.esvo_bag_last_error(self.b).decode()}")
+            yield tp.value.decode(), int(st.value), C.string_at(msg.value, nb.value)
+
+
+def voxel_filter(xyz, leaf):
+    """pcl::VoxelGrid with a cubic leaf (host helper of the C-ABI)"""
+    xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+    out = np.empty((max(len(xyz), 1), 3), np.float32)
+    n = C.c_size_t()
+    rc = load().esvo_voxel_filter_xyz(xyz.ctypes.data, xyz.shape[0], float(leaf), out.ctypes.data, out.shape[0], C.byref(n))
+    if rc != 0:
+        raise EsvoError(f"esvo_voxel_filter_xyz failed ({rc})")
+    return out[: n.value].copy()
 
 
 def comm_unique_id():
@@ -210,6 +262,12 @@ class Esvo:
         self._ck(self.lib.esvo_ts_push_event_array(self.h, int(cam), buf.ctypes.data, buf.size, C.byref(n)))
         return int(n.value)
 
+    def ts_push_bag(self, cam, bag, topic, until_ns=0):
+        """stage the dvs_msgs/EventArray messages of `topic` (bag time < until_ns; 0: all) from a BagReader; returns the event count"""
+        n = C.c_size_t()
+        self._ck(self.lib.esvo_ts_push_bag(self.h, int(cam), bag.b, topic.encode() if topic else None, int(until_ns), C.byref(n)))
+        return int(n.value)
+
     def ts_render(self, cam, t_ns, download=True):
         out = np.empty((self.H, self.W), np.uint8) if download else None
         self._ck(self.lib.esvo_ts_render(self.h, int(cam), int(t_ns), _p(out)))
@@ -280,6 +338,18 @@ class Esvo:
         n = C.c_size_t(0)
         out = np.zeros((self.W * self.H, 3), np.float32)
         self._ck(self.lib.esvo_map_get_pointcloud_xyz(self.h, out.ctypes.data, out.shape[0], C.byref(n)))
+        return out[: n.value].copy()
+
+    def get_debug_images(self, age_max_range=10.0):
+        """(inverse depth, standard deviation, age, cost) images of publishMappingResults, BGR8"""
+        imgs = [np.empty((self.H, self.W, 3), np.uint8) for _ in range(4)]
+        self._ck(self.lib.esvo_map_get_debug_images(self.h, float(age_max_range), *[i.ctypes.data for i in imgs]))
+        return imgs
+
+    def get_pointcloud_near(self, visualize_range):
+        n = C.c_size_t(0)
+        out = np.zeros((self.W * self.H, 3), np.float32)
+        self._ck(self.lib.esvo_map_get_pointcloud_near_xyz(self.h, float(visualize_range), out.ctypes.data, out.shape[0], C.byref(n)))
         return out[: n.value].copy()
 
     def get_last_frame(self):

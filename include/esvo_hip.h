@@ -218,6 +218,20 @@ int esvo_ts_push_events(esvo_handle h, int cam, const esvo_event_t* ev, size_t n
  * std::vector<dvs_msgs::Event> is materialised (rosbag::MessageInstance::instantiate does that at
  * events_repacking_helper/src/EventMessageEditor.cpp:111).  *n_events (nullable) receives the message's event count. */
 int esvo_ts_push_event_array(esvo_handle h, int cam, const uint8_t* msg, size_t n_bytes, size_t* n_events);
+/* rosbag (format 2.0) ingest, SURVEY.md §8(f).2: the reading side of events_repacking_helper
+ * (events_repacking_helper/src/EventMessageEditor.cpp:66-119: rosbag::Bag::open, rosbag::View over an event topic,
+ * MessageInstance::instantiate<dvs_msgs::EventArray>).  Chunks (compression none / bz2 / lz4) are walked in file order;
+ * each serialised dvs_msgs/EventArray of the topic is returned as a byte range of the reader's buffer (valid until the next
+ * call) -- the input of esvo_ts_push_event_array.  Returns ESVO_OK, 1 at the end of the bag, or a negative status
+ * (esvo_bag_last_error).  topic == NULL: every topic of type dvs_msgs/EventArray.  Host code, no GPU needed. */
+typedef struct esvo_bag* esvo_bag_handle;
+int esvo_bag_open(const char* path, esvo_bag_handle* out);
+int esvo_bag_close(esvo_bag_handle b);
+const char* esvo_bag_last_error(esvo_bag_handle b);
+int esvo_bag_next_event_array(esvo_bag_handle b, const char* topic, const uint8_t** msg, size_t* n_bytes, uint64_t* stamp_ns,
+                              const char** topic_out);
+/* Stage the messages of `topic` with a bag time stamp below until_ns (0: all that are left) for camera `cam`. */
+int esvo_ts_push_bag(esvo_handle h, int cam, esvo_bag_handle b, const char* topic, uint64_t until_ns, size_t* n_events);
 /* Replaces TimeSurface::createTimeSurfaceAtTime (TimeSurface.cpp:52-152), BACKWARD mode.
  * Uses every staged event with ts < t_ns.  out_mono8 (W*H) may be NULL: the rectified TS
  * also stays device-resident as the camera's latest frame.
@@ -288,6 +302,18 @@ int esvo_map_get_committed(esvo_handle h, esvo_depth_point_t* out, size_t cap, s
 /* Replaces the loop of publishPointCloud (esvo_Mapping.cpp:925-932): p_world = R p_cam + t
  * as float32 xyz triples, the payload of /esvo_mapping/pointcloud_local. */
 int esvo_map_get_pointcloud_xyz(esvo_handle h, float* out_xyz, size_t cap_points, size_t* n);
+/* ---- Debug images and global-cloud helpers ----
+ * Replaces Visualization::plot_map / DrawPoint (Visualization.cpp:13-94) as esvo_Mapping::publishMappingResults calls
+ * them for the topics Inverse_Depth_Map, Standard_Variance_Map, Age_Map and cost_map (esvo_Mapping.cpp:868-884): BGR8
+ * images of H*W*3 bytes, each pointer may be NULL.  age_max_range is the yaml key of that name. */
+int esvo_map_get_debug_images(esvo_handle h, double age_max_range, uint8_t* inv_depth_bgr, uint8_t* stdvar_bgr,
+                              uint8_t* age_bgr, uint8_t* cost_bgr);
+/* pc_near_ of publishPointCloud (esvo_Mapping.cpp:925-932): world points of the elements with |p_cam| < visualize_range. */
+int esvo_map_get_pointcloud_near_xyz(esvo_handle h, double visualize_range, float* out_xyz, size_t cap_points, size_t* n);
+/* pcl::VoxelGrid<pcl::PointXYZ> with setLeafSize(leaf, leaf, leaf) (esvo_Mapping.cpp:960-964): host code, no handle.
+ * One centroid per occupied voxel, ascending voxel index; the node appends the last NumGPC_added_per_refresh - 1 of them
+ * to its global cloud (:966-969). */
+int esvo_voxel_filter_xyz(const float* xyz, size_t n, float leaf, float* out_xyz, size_t cap_points, size_t* n_out);
 /* The newest frame of the fusion window (culled DepthPoints of the last tick). */
 int esvo_map_get_last_frame(esvo_handle h, esvo_depth_point_t* out, size_t cap, size_t* n);
 int esvo_get_stats(esvo_handle h, esvo_stats_t* out);

@@ -1334,6 +1334,119 @@ extern "C" void orc_mapper_counters(orc_mapper_handle h, uint64_t out[8]) {
   out[4] = h->max_scale_iters; out[5] = h->n_evals; out[6] = out[7] = 0;
 }
 
+// =====================================================================================================
+// Debug image publishers and the global-cloud voxel filter
+// =====================================================================================================
+// The 256 colours of Visualization::DrawPoint (Visualization.cpp:74-94,128-226) as the BGR bytes an 8-bit image stores:
+// the reference's tables are jet on i / 255, i.e. 255 * channel = clamp(min(4 i + a, -4 i + b), 0, 255), rounded half
+// to even (tests/golden/jet256.npy holds the bytes computed from the reference's own tables).
+extern "C" void orc_jet_bgr(uint8_t out[768]) {
+  const double ab[3][2] = {{127.5, 637.5}, {-127.5, 892.5}, {-382.5, 1147.5}};  // B, G, R
+  for (int i = 0; i < 256; ++i)
+    for (int c = 0; c < 3; ++c) {
+      double v = std::min(4.0 * i + ab[c][0], -4.0 * i + ab[c][1]);
+      v = v < 0 ? 0 : (v > 255 ? 255 : v);
+      out[3 * i + c] = (uint8_t)std::nearbyint(v);
+    }
+}
+// Visualization::plot_map (Visualization.cpp:13-72) with the arguments of publishMappingResults (esvo_Mapping.cpp:868-884);
+// type: 0 InvDepthMap, 1 StdVarMap, 2 CostMap, 3 AgeMap.  bgr: H*W*3, zeroed here.
+extern "C" void orc_mapper_debug_image(orc_mapper_handle h, int type, double age_max_range, uint8_t* bgr) {
+  const int W = h->W(), H = h->H();
+  std::memset(bgr, 0, (size_t)W * H * 3);
+  uint8_t jet[768];
+  orc_jet_bgr(jet);
+  const esvo_params_t& p = h->prm;
+  const double cost_thr = sq(p.residual_vis_threshold) * (p.patch_size_x * p.patch_size_y);  // esvo_Mapping.cpp:97
+  double max_range = 0, min_range = 0, thr1 = 0, thr2 = 0;
+  switch (type) {
+    case 0: max_range = p.invdepth_max; min_range = p.invdepth_min; thr1 = p.stdvar_vis_threshold; thr2 = p.age_vis_threshold; break;
+    case 1: max_range = p.stdvar_vis_threshold; min_range = 0; thr1 = p.stdvar_vis_threshold; break;
+    case 2: max_range = cost_thr; min_range = 0; thr1 = cost_thr; break;
+    default: max_range = age_max_range; min_range = 0; thr1 = p.age_vis_threshold; break;
+  }
+  for (size_t e = 0; e < h->map.elems.size(); ++e) {
+    if (!h->map.alive[e]) continue;
+    const DP& d = h->map.elems[e];
+    if (!d.valid()) continue;
+    double val;
+    if (type == 0) { if (!(d.variance < sq(thr1) && (double)d.age >= (double)(int)thr2)) continue; val = d.invDepth; }
+    else if (type == 1) { if (!(d.variance < sq(thr1))) continue; val = std::sqrt(d.variance); }
+    else if (type == 2) { if (!(d.residual < thr1)) continue; val = d.residual; }
+    else { if (!((double)d.age >= (double)(int)thr1)) continue; val = (double)d.age; }
+    int index = (int)std::floor((val - min_range) / (max_range - min_range) * 255.0);  // DrawPoint, :82
+    if (index > 255) index = 255;
+    if (index < 0) index = 0;
+    const int cx = (int)d.x[0], cy = (int)d.x[1];  // cv::Point from doubles: truncation
+    // cv::circle(img, point, 1, color, cv::FILLED): the 5-pixel plus, clipped to the image
+    const int px[5] = {cx, cx - 1, cx + 1, cx, cx}, py[5] = {cy, cy, cy, cy - 1, cy + 1};
+    for (int k = 0; k < 5; ++k)
+      if (px[k] >= 0 && px[k] < W && py[k] >= 0 && py[k] < H)
+        for (int c = 0; c < 3; ++c) bgr[((size_t)py[k] * W + px[k]) * 3 + c] = jet[3 * index + c];
+  }
+}
+// pc_near_ of publishPointCloud (esvo_Mapping.cpp:925-932): world points of the elements with |p_cam| < visualize_range
+extern "C" size_t orc_mapper_get_pointcloud_near_xyz(orc_mapper_handle h, double visualize_range, float* out_xyz, size_t cap_points) {
+  const Mat4& T = h->T_world_frame;
+  size_t k = 0;
+  for (size_t i = 0; i < h->map.elems.size(); ++i) {
+    if (!h->map.alive[i]) continue;
+    const DP& d = h->map.elems[i];
+    const double nrm = std::sqrt((d.p_cam[0] * d.p_cam[0] + d.p_cam[1] * d.p_cam[1]) + d.p_cam[2] * d.p_cam[2]);
+    if (!(nrm < visualize_range)) continue;
+    if (k < cap_points)
+      for (int r = 0; r < 3; ++r)
+        out_xyz[3 * k + r] = (float)(((T.m[r * 4 + 0] * d.p_cam[0] + T.m[r * 4 + 1] * d.p_cam[1]) + T.m[r * 4 + 2] * d.p_cam[2]) + T.m[r * 4 + 3]);
+    ++k;
+  }
+  return k;
+}
+// pcl::VoxelGrid<PointXYZ> with setLeafSize(leaf, leaf, leaf) as used at esvo_Mapping.cpp:960-964 (PCL is a third-party
+// dependency absent from /root/reference and from this image: restated from its published algorithm -- bounding box of
+// the finite points, voxel index = floor(p / leaf) - floor(min / leaf) linearised x-fastest, one centroid per occupied
+// voxel in ascending index order, all in float; points of a voxel are summed in input order).  Returns the voxel count.
+extern "C" size_t orc_voxel_filter(const float* xyz, size_t n, float leaf, float* out) {
+  std::vector<size_t> fin;
+  float mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
+  for (size_t i = 0; i < n; ++i) {
+    const float* p = xyz + 3 * i;
+    if (!std::isfinite(p[0]) || !std::isfinite(p[1]) || !std::isfinite(p[2])) continue;
+    if (fin.empty()) for (int c = 0; c < 3; ++c) mn[c] = mx[c] = p[c];
+    for (int c = 0; c < 3; ++c) { mn[c] = std::min(mn[c], p[c]); mx[c] = std::max(mx[c], p[c]); }
+    fin.push_back(i);
+  }
+  if (fin.empty()) return 0;
+  const float inv = 1.0f / leaf;
+  int minb[3], divb[3];
+  for (int c = 0; c < 3; ++c) {
+    minb[c] = (int)std::floor(mn[c] * inv);
+    divb[c] = (int)std::floor(mx[c] * inv) - minb[c] + 1;
+  }
+  const long long mul[3] = {1, divb[0], (long long)divb[0] * divb[1]};
+  std::vector<std::pair<long long, size_t>> idx;
+  idx.reserve(fin.size());
+  for (size_t i : fin) {
+    const float* p = xyz + 3 * i;
+    long long v = 0;
+    for (int c = 0; c < 3; ++c) v += ((long long)((int)std::floor(p[c] * inv) - minb[c])) * mul[c];
+    idx.emplace_back(v, i);
+  }
+  std::stable_sort(idx.begin(), idx.end(), [](const std::pair<long long, size_t>& a, const std::pair<long long, size_t>& b) { return a.first < b.first; });
+  size_t k = 0;
+  for (size_t a = 0; a < idx.size();) {
+    size_t b = a;
+    float c[3] = {0, 0, 0};
+    while (b < idx.size() && idx[b].first == idx[a].first) {
+      for (int d = 0; d < 3; ++d) c[d] += xyz[3 * idx[b].second + d];
+      ++b;
+    }
+    for (int d = 0; d < 3; ++d) out[3 * k + d] = c[d] / (float)(b - a);
+    ++k;
+    a = b;
+  }
+  return k;
+}
+
 // residual vector of DepthProblem::operator() for one match at inverse depth rho (unit tests:
 // comparison of the restated LM against scipy's MINPACK wrapper)
 extern "C" int orc_mapper_eval_residual(orc_mapper_handle h, const double x_left[2], uint32_t pose_idx, double rho,

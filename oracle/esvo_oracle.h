@@ -103,6 +103,12 @@ size_t orc_mapper_get_pointcloud_xyz(orc_mapper_handle h, float* out_xyz, size_t
 /* counters: [0] window frames [1] window points [2] replace-branch hits [3] replace hits with
  * a displaced cell (row/col differ) [4] max t-scale loop iterations seen [5] LM evaluations */
 void orc_mapper_counters(orc_mapper_handle h, uint64_t out[8]);
+/* debug images + global-cloud helpers: Visualization::plot_map / DrawPoint (Visualization.cpp:13-94) with
+ * publishMappingResults' arguments (esvo_Mapping.cpp:868-884); type 0 InvDepth, 1 StdVar, 2 Cost, 3 Age; bgr = H*W*3 */
+void orc_jet_bgr(uint8_t out[768]);
+void orc_mapper_debug_image(orc_mapper_handle h, int type, double age_max_range, uint8_t* bgr);
+size_t orc_mapper_get_pointcloud_near_xyz(orc_mapper_handle h, double visualize_range, float* out_xyz, size_t cap_points);
+size_t orc_voxel_filter(const float* xyz, size_t n, float leaf, float* out); /* pcl::VoxelGrid, esvo_Mapping.cpp:960-964 */
 /* unit-test hooks */
 int orc_mapper_eval_residual(orc_mapper_handle h, const double x_left[2], uint32_t pose_idx, double rho, double* fvec);
 double orc_zncc_cost(const double* l, const double* r, int wx, int wy, int exact_int);

@@ -82,6 +82,12 @@ def load(fast=False):
     lib.orc_mapper_get_pointcloud_xyz.restype = sz
     lib.orc_mapper_get_pointcloud_xyz.argtypes = [vp, vp, sz]
     lib.orc_mapper_counters.argtypes = [vp, vp]
+    lib.orc_jet_bgr.argtypes = [vp]
+    lib.orc_mapper_debug_image.argtypes = [vp, i32, dbl, vp]
+    lib.orc_mapper_get_pointcloud_near_xyz.restype = sz
+    lib.orc_mapper_get_pointcloud_near_xyz.argtypes = [vp, dbl, vp, sz]
+    lib.orc_voxel_filter.restype = sz
+    lib.orc_voxel_filter.argtypes = [vp, sz, C.c_float, vp]
     lib.orc_mapper_eval_residual.restype = i32
     lib.orc_mapper_eval_residual.argtypes = [vp, vp, C.c_uint32, dbl, vp]
     lib.orc_zncc_cost.restype = dbl
@@ -326,6 +332,18 @@ class OracleMapper:
         n = self.lib.orc_mapper_get_pointcloud_xyz(self.h, out.ctypes.data, out.shape[0])
         return out[:n]
 
+    def debug_image(self, kind, age_max_range=10.0):
+        """Visualization::plot_map as publishMappingResults calls it; kind: 0 InvDepth, 1 StdVar, 2 Cost, 3 Age -> BGR image"""
+        out = np.empty((self.H, self.W, 3), np.uint8)
+        self.lib.orc_mapper_debug_image(self.h, int(kind), float(age_max_range), out.ctypes.data)
+        return out
+
+    def get_pointcloud_near(self, visualize_range):
+        n = self.lib.orc_mapper_map_size(self.h)
+        out = np.zeros((max(n, 1), 3), np.float32)
+        n = self.lib.orc_mapper_get_pointcloud_near_xyz(self.h, float(visualize_range), out.ctypes.data, out.shape[0])
+        return out[:n]
+
     def eval_residual(self, x_left, pose_idx, rho):
         x = np.ascontiguousarray(x_left, np.float64)
         f = np.empty(self.params.patch_size_x * self.params.patch_size_y, np.float64)
@@ -344,6 +362,19 @@ def zncc_cost(l, r, exact_int=False):
     l = np.ascontiguousarray(l, np.float64)
     r = np.ascontiguousarray(r, np.float64)
     return lib.orc_zncc_cost(l.ctypes.data, r.ctypes.data, l.shape[1], l.shape[0], int(exact_int))
+
+
+def jet_bgr():
+    out = np.empty((256, 3), np.uint8)
+    load().orc_jet_bgr(out.ctypes.data)
+    return out
+
+
+def voxel_filter(xyz, leaf):
+    xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+    out = np.empty_like(xyz) if len(xyz) else np.empty((1, 3), np.float32)
+    n = load().orc_voxel_filter(xyz.ctypes.data, xyz.shape[0], float(leaf), out.ctypes.data)
+    return out[:n].copy()
 
 
 def abi_sizes():
