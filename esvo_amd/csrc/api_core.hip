@@ -172,7 +172,8 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
   CK(dalloc(&h->d_pose_T2[0], (size_t)h->max_poses * 16));
   CK(dalloc(&h->d_pose_T2[1], (size_t)h->max_poses * 16));
   h->d_pose_T = h->d_pose_T2[0];
-  h->max_ev = (u32)std::max(params->max_events_per_tick, params->process_event_num);
+  // + 1: the SGM bootstrap selects up to PROCESS_EVENT_NUM + 1 events (esvo_Mapping.cpp:547: `size() <= PROCESS_EVENT_NUM_`)
+  h->max_ev = (u32)std::max(params->max_events_per_tick, params->process_event_num) + 1u;
   if (h->max_ev > 4000000u) { g_create_error = "max_events_per_tick too large (scan limit 4M)"; esvo_destroy(h); return ESVO_ERR_CAPACITY; }
   if (npx > 4000000u) { g_create_error = "image too large (scan limit 4M pixels)"; esvo_destroy(h); return ESVO_ERR_CAPACITY; }
   const size_t E = h->max_ev;
@@ -281,6 +282,10 @@ int esvo_destroy(esvo_handle h) {
   if (h->h_pose_pool) hipHostFree(h->h_pose_pool);
   if (h->d_wire) hipFree(h->d_wire);
   for (void* q : {(void*)h->d_viz_bgr, (void*)h->d_viz_jet, (void*)h->d_viz_owner}) if (q) hipFree(q);
+  for (void* q : {(void*)h->sgm.sobL, (void*)h->sgm.rawL, (void*)h->sgm.sobR, (void*)h->sgm.rawR, (void*)h->sgm.vol[0], (void*)h->sgm.vol[1],
+                  (void*)h->sgm.vol[2], (void*)h->sgm.vol[3], (void*)h->sgm.vol[4], (void*)h->sgm.vol[5], (void*)h->sgm.d1, (void*)h->sgm.d1b,
+                  (void*)h->sgm.d2key, (void*)h->d_sgm_img[0], (void*)h->d_sgm_img[1], (void*)h->d_sgm_disp, (void*)h->d_sgm_pair, (void*)h->d_sgm_T})
+    if (q) hipFree(q);
   if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
   if (h->stream_b) hipStreamDestroy(h->stream_b);
   if (h->stream_t) { hipStreamSynchronize(h->stream_t); hipStreamDestroy(h->stream_t); }

@@ -191,12 +191,12 @@ void apply_window_policy(esvo_context* h) {
 }
 
 // pose table of the frame: from the host (stage-wise API) or, in a tick, the front stage's device table
-int commit_frame(esvo_context* h, u32 off, u32 count, const double* pose_T_host, u32 m, int pose_buf) {
+int commit_frame(esvo_context* h, u32 off, u32 count, const double* pose_T_host, u32 m, int pose_buf, bool apply_policy) {
   if (count == 0) {  // an empty frame: no pose table, no ring space; consecutive ones share a record
     if (!h->frames.empty() && h->frames.back().count == 0) h->frames.back().run++;
     else h->frames.push_back(FrameRec{off, 0, NO_SLOT, 1});
     h->n_window_frames++;
-    apply_window_policy(h);
+    if (apply_policy) apply_window_policy(h);
     return ESVO_OK;
   }
   u32 slot;
@@ -219,7 +219,7 @@ int commit_frame(esvo_context* h, u32 off, u32 count, const double* pose_T_host,
   }
   h->frames.push_back(FrameRec{off, count, slot, 1});
   h->n_window_frames++;
-  apply_window_policy(h);
+  if (apply_policy) apply_window_policy(h);
   return ESVO_OK;
 }
 
@@ -696,6 +696,106 @@ extern "C" int esvo_map_tick(esvo_handle h, uint64_t t_ns, const uint64_t* pose_
     h->tick_pending = true;  // this tick (its front stage is enqueued whatever happened to the previous one)
     if (rc) return rc;
   }
+  return ESVO_OK;
+}
+
+// ---- SGM initialisation -----------------------------------------------------------------------
+// Replaces esvo_Mapping::InitializationAtTime (esvo_Mapping.cpp:433-492) with the SGM branch of dataTransferring (:537-552):
+// cv::StereoSGBM on the UN-smoothed Time-Surface pair, the rectified pixels of the newest <= PROCESS_EVENT_NUM + 1 left
+// events of the last 2 * BM_half_slice_thickness as edge mask, one Gaussian DepthPoint (variance 1e-6, age =
+// age_vis_threshold) per masked event with a disparity inside the inverse-depth range; if at least min_points
+// (INIT_SGM_DP_NUM_THRESHOLD) come out they open the fusion window and DepthFusion::naive_propagation fills the DepthFrame.
+extern "C" int esvo_map_init_sgm(esvo_handle h, const uint8_t* ts_left, const uint8_t* ts_right, size_t min_points, size_t* n_points,
+                                 int16_t* disp_out) {
+  if (!h || !n_points) return ESVO_ERR_INVALID_ARG;
+  if (!h->obs_set) FAIL(ESVO_ERR_STATE, "esvo_map_set_observation has not been called (time stamp and pose of the Time-Surface pair)");
+  if (h->sharded) FAIL(ESVO_ERR_STATE, "handle is sharded");
+  if (h->W <= 48 + 2) FAIL(ESVO_ERR_UNSUPPORTED, "image narrower than numDisparities");
+  HIPCHK(hipSetDevice(h->device));
+  int rc = flush_pending_tick(h);
+  if (rc) return rc;
+  const size_t npx = (size_t)h->W * h->H;
+  if (!h->sgm_ok) {
+    const size_t nvol = (size_t)h->H * (h->W - 48) * 48;
+    uint8_t** planes[4] = {&h->sgm.sobL, &h->sgm.rawL, &h->sgm.sobR, &h->sgm.rawR};
+    for (auto pp : planes) HIPCHK(hipMalloc(reinterpret_cast<void**>(pp), npx));
+    for (int i = 0; i < 6; ++i) HIPCHK(hipMalloc(reinterpret_cast<void**>(&h->sgm.vol[i]), nvol * sizeof(int16_t)));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&h->sgm.d1), npx * sizeof(int16_t)));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&h->sgm.d1b), npx * sizeof(int16_t)));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&h->sgm.d2key), npx * sizeof(u32)));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&h->d_sgm_img[0]), npx));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&h->d_sgm_img[1]), npx));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&h->d_sgm_disp), npx * sizeof(int16_t)));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&h->d_sgm_pair), sizeof(u32) * 8 * (size_t)h->max_ev));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&h->d_sgm_T), sizeof(double) * 16));
+    h->sgm_ok = true;
+  }
+  const uint8_t* src[2] = {ts_left, ts_right};
+  const uint8_t* img[2];
+  for (int cam = 0; cam < 2; ++cam) {
+    if (src[cam]) {
+      HIPCHK(hipMemcpyAsync(h->d_sgm_img[cam], src[cam], npx, hipMemcpyHostToDevice, h->stream));
+      img[cam] = h->d_sgm_img[cam];
+    } else {
+      if (!h->ts_valid[cam]) FAIL(ESVO_ERR_STATE, "no device-resident Time Surface: call esvo_ts_render first");
+      img[cam] = h->d_ts[cam];
+    }
+  }
+  HIPCHK(hipStreamSynchronize(h->stream_b));  // the DepthMap and the window are rebuilt below
+  launch_sgbm(img[0], img[1], h->sgm, h->d_sgm_disp, h->W, h->H, h->stream);
+  HIPCHK(hipGetLastError());
+  // the SGM event selection (esvo_Mapping.cpp:541-551): newest first from lower_bound(t), 2 * BM_half_slice_thickness back
+  const double t_end = ns_to_sec(h->obs_t_ns);
+  const double t_begin = ns_to_sec(ros_time_from_sec(std::max(0.0, t_end - 2 * h->prm.bm_half_slice_thickness)));
+  const u64 it_end = lower_bound_sec(h, 0, t_end), it_begin = lower_bound_sec(h, 0, t_begin);
+  const u64 staged_end = h->ring_base[0] + h->ts_host[0].size();
+  u64 avail = it_end - it_begin, first = it_end;
+  if (it_end == staged_end && avail > 0) { first = it_end - 1; avail -= 1; }  // end() is skipped (oracle definition)
+  const u32 n = (u32)std::min<u64>(avail, (u64)h->prm.process_event_num + 1);
+  if (n > h->max_ev) FAIL(ESVO_ERR_CAPACITY, "more events than max_events_per_tick");
+  if (n && first - (n - 1) < h->ring_next[0] - std::min<u64>(h->ring_next[0], h->ring_cap))
+    FAIL(ESVO_ERR_STATE, "selected events were already overwritten in the event ring");
+  HIPCHK(hipMemsetAsync(h->d_counters, 0, sizeof(u32) * 16, h->stream));
+  u32 count = 0;
+  if (n) {
+    HIPCHK(hipStreamWaitEvent(h->stream, h->evt[EV_RG1 + h->par * EV_BACK_STRIDE], 0));
+    launch_sgm_points(h->d_ring[0], first, h->ring_cap, n, h->d_lut, h->d_sgm_disp, h->d_pt_slots, h->d_pt_flags, h->dp, h->stream);
+    launch_exclusive_scan_u32(h->d_pt_flags, h->d_pt_prefix, h->d_counters + 1, h->d_scan_tmp, n, h->stream);
+    HIPCHK(hipMemcpyAsync(h->d_counters + 0, &n, sizeof(u32), hipMemcpyHostToDevice, h->stream));  // compaction bound (n_in of compact_points), behind the memset above
+    launch_compact_points(h->d_pt_slots, h->d_pt_flags, h->d_pt_prefix, h->d_counters + 0, n, h->d_pts_tmp, h->stream);
+    rc = read_counters(h);
+    if (rc) return rc;
+    count = h->h_counters[1];
+  }
+  if (disp_out) {
+    HIPCHK(hipMemcpyAsync(disp_out, h->d_sgm_disp, npx * sizeof(int16_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+  }
+  *n_points = 0;
+  if (count < min_points) return ESVO_OK;  // InitializationAtTime returns false: nothing is pushed (:482-483)
+  u32 off;
+  rc = window_reserve(h, count, &off);
+  if (rc) return rc;
+  rc = back_after_front(h);
+  if (rc) return rc;
+  if (count) HIPCHK(hipMemcpyAsync(h->d_win + off, h->d_pts_tmp, sizeof(DevPoint) * count, hipMemcpyDeviceToDevice, h->stream_b));
+  rc = commit_frame(h, off, count, h->T_world_obs, 1, 0, false);  // dqvDepthPoints_.push_back(vdp_sgm): no window policy (:485)
+  if (rc) return rc;
+  // DepthFusion::naive_propagation into a new DepthFrame at the observation's pose (:436-440, :486)
+  std::memcpy(h->T_world_frame, h->T_world_obs, sizeof(double) * 16);
+  double Tfw[16], Tfo[16];
+  rigid_inverse(h->T_world_frame, Tfw);
+  mat4_mul(Tfw, h->T_world_obs, Tfo);
+  HIPCHK(hipMemcpy(h->d_sgm_T, Tfo, sizeof(double) * 16, hipMemcpyHostToDevice));
+  launch_sgm_naive(h->d_win + off, count, h->d_sgm_T, h->d_owner_max, h->d_sgm_pair, h->d_sgm_pair + 4 * (size_t)h->max_ev, h->d_cnt_b + 4,
+                   h->d_scan_tmp_b, h->d_map, h->dp, h->stream_b);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(h->stream_b));
+  h->d_map_cur = h->d_map;
+  h->committed_t_ns = h->obs_t_ns;
+  h->stats.last_points = count;
+  h->stats.last_window_frames = (u32)h->n_window_frames;
+  *n_points = count;
   return ESVO_OK;
 }
 

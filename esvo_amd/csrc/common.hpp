@@ -255,6 +255,18 @@ void launch_reg_view(const MapCell* map_in, MapCell* map_out, u32* owner_max, u3
                      u32* n_elems, const DevParams& p, hipStream_t s);
 void launch_reg_apply(const MapCell* map_in, MapCell* map_out, const u32* owner_max, const u32* owner_min, const double2* ab,
                       const double2* cd, const DevParams& p, hipStream_t s);
+// kernels_sgm.hip: semi-global matching of the Time-Surface pair + the Gaussian DepthPoints of InitializationAtTime
+struct SgmScratch {
+  uint8_t *sobL, *rawL, *sobR, *rawR;  // pre-filtered planes, W*H each
+  int16_t* vol[6];                     // cost volumes [H][W - 48][48]: pixel cost / C, horizontal sums / L0, L1..L4
+  int16_t *d1, *d1b;                   // raw disparities before / after the left-right check
+  u32* d2key;                          // right-image candidates of the left-right check
+};
+void launch_sgbm(const uint8_t* left, const uint8_t* right, const SgmScratch& s, int16_t* disp, int W, int H, hipStream_t st);
+void launch_sgm_points(const esvo_event_t* ring, u64 first, u64 cap, u32 n, const float2* lut, const int16_t* disp, DevPoint* slots,
+                       u32* flags, const DevParams& p, hipStream_t st);
+void launch_sgm_naive(const DevPoint* pts, u32 n, const double* d_T_frame_obs, u32* owner, u32* pair_flags, u32* pair_rank, u32* d_total,
+                      u32* scan_tmp, MapCell* map, const DevParams& p, hipStream_t st);
 // kernels_viz.hip
 void launch_debug_image(const MapCell* map, u32* owner, uint8_t* bgr, const uint8_t* jet, int type, double max_range,
                         double min_range, double thr1, double thr2, const DevParams& p, hipStream_t s);

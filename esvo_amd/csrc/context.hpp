@@ -196,6 +196,14 @@ struct esvo_context {
   bool pool_ok = false;
   int pool_next = 0;
 
+  // SGM initialisation (kernels_sgm.hip): allocated on first use, released by esvo_destroy
+  SgmScratch sgm = {};
+  bool sgm_ok = false;
+  uint8_t* d_sgm_img[2] = {nullptr, nullptr};
+  int16_t* d_sgm_disp = nullptr;
+  u32* d_sgm_pair = nullptr;      // [2][4 * max_ev] winner flags / ranks of naive_propagation
+  double* d_sgm_T = nullptr;
+
   // debug images (kernels_viz.hip): allocated on first use
   uint8_t* d_viz_bgr = nullptr;
   uint8_t* d_viz_jet = nullptr;
@@ -224,7 +232,7 @@ int run_order_points(esvo_context* h, u32 max_matches, DevPoint* dst);
 int back_after_front(esvo_context* h);
 void collect_back(esvo_context* h, int par);
 int window_reserve(esvo_context* h, u32 n, u32* off_out);
-int commit_frame(esvo_context* h, u32 off, u32 count, const double* pose_T_host, u32 m, int pose_buf = 0);
+int commit_frame(esvo_context* h, u32 off, u32 count, const double* pose_T_host, u32 m, int pose_buf = 0, bool apply_policy = true);
 int run_fuse(esvo_context* h, int par, const double* T_world_obs);
 int export_map(esvo_context* h, std::vector<esvo_depth_point_t>& out, std::vector<u32>* cells);
 int tick_phase0(esvo_context* h, uint64_t t_ns, const uint64_t* pose_t_ns, const double* pose_T, size_t m);

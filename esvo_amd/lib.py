@@ -15,7 +15,7 @@ from .abi import (DEPTH_POINT_DTYPE, EVENT_DTYPE, MATCH_DTYPE, CalibStruct, Para
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 _LIB_PATH = os.path.join(_CSRC, "libesvo_hip.so")
-_SOURCES = ["api_core.hip", "api_ts.hip", "api_map.hip", "api_comm.hip", "api_bag.hip", "api_track.hip", "scan.hip", "kernels_ts.hip", "kernels_bm.hip", "kernels_lm.hip", "kernels_fuse.hip", "kernels_shard.hip", "kernels_track.hip", "kernels_viz.hip"]
+_SOURCES = ["api_core.hip", "api_ts.hip", "api_map.hip", "api_comm.hip", "api_bag.hip", "api_track.hip", "scan.hip", "kernels_ts.hip", "kernels_bm.hip", "kernels_lm.hip", "kernels_fuse.hip", "kernels_shard.hip", "kernels_track.hip", "kernels_viz.hip", "kernels_sgm.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
                "-Wno-unused-value", "-Wno-unused-result", "-ldl"]
 
@@ -27,6 +27,7 @@ SYMBOLS = [
     "esvo_get_stats", "esvo_shard_set_band", "esvo_shard_exchange", "esvo_shard_tick_phase", "esvo_abi_sizes",
     "esvo_map_front", "esvo_map_front_frame", "esvo_map_push_frame_device", "esvo_map_fuse_async",
     "esvo_track_set_current", "esvo_track_get_images", "esvo_track_set_reference", "esvo_track_residuals", "esvo_track_jacobian",
+    "esvo_map_init_sgm",
     "esvo_bag_open", "esvo_bag_close", "esvo_bag_last_error", "esvo_bag_next_event_array", "esvo_ts_push_bag",
     "esvo_map_get_debug_images", "esvo_map_get_pointcloud_near_xyz", "esvo_voxel_filter_xyz",
     "esvo_comm_unique_id", "esvo_comm_init", "esvo_comm_init_callbacks", "esvo_comm_destroy", "esvo_comm_owns_next_tick",
@@ -108,6 +109,7 @@ def load():
     lib.esvo_track_set_reference.argtypes = [vp, vp, sz, vp]
     lib.esvo_track_residuals.argtypes = [vp, vp, sz, sz, i32, C.c_double, vp, psz]
     lib.esvo_track_jacobian.argtypes = [vp, vp, vp, sz, sz, vp, psz]
+    lib.esvo_map_init_sgm.argtypes = [vp, vp, vp, sz, psz, vp]
     lib.esvo_bag_open.argtypes = [C.c_char_p, C.POINTER(vp)]
     lib.esvo_bag_close.argtypes = [vp]
     lib.esvo_bag_last_error.argtypes = [vp]
@@ -313,6 +315,15 @@ class Esvo:
         n = C.c_size_t(0)
         self._ck(self.lib.esvo_map_fuse(self.h, C.byref(n)))
         return n.value
+
+    def init_sgm(self, ts_left=None, ts_right=None, min_points=500, want_disp=True):
+        """InitializationAtTime (SGM bootstrap) on the observation set last; returns (#points, disparity*16 image or None)"""
+        l = None if ts_left is None else np.ascontiguousarray(ts_left, np.uint8)
+        r = None if ts_right is None else np.ascontiguousarray(ts_right, np.uint8)
+        disp = np.empty((self.H, self.W), np.int16) if want_disp else None
+        n = C.c_size_t()
+        self._ck(self.lib.esvo_map_init_sgm(self.h, _p(l), _p(r), int(min_points), C.byref(n), _p(disp)))
+        return int(n.value), disp
 
     # ---- mapper, fused tick (MappingAtTime on device-resident data)
     def tick(self, t_ns, stamps, poses):

@@ -269,6 +269,21 @@ int esvo_map_push_frame(esvo_handle h, const esvo_depth_point_t* pts, size_t n,
  * DepthFusion.cpp:71-192; SmartGrid.h:222-243; DepthRegularization.cpp:19-110). */
 int esvo_map_fuse(esvo_handle h, size_t* n_fusions);
 
+/* ---- Mapper: SGM bootstrap ---------------------------------------------- */
+
+/* Replaces esvo_Mapping::InitializationAtTime (esvo_Mapping.cpp:433-492) and the SGM branch of dataTransferring (:537-552):
+ * cv::StereoSGBM (0, 48, 11, P1 = 8*11*11, P2 = 32*11*11, -1, 0, 11; MODE_SGBM; :102-108) on the UN-smoothed Time-Surface
+ * pair -- ts_left / ts_right: host mono8 W*H, or NULL for the device-resident frames of esvo_ts_render -- masked by the
+ * rectified pixels of the newest <= PROCESS_EVENT_NUM + 1 staged left events of the last 2 * BM_half_slice_thickness
+ * (createEdgeMask, :1000-1044), one Gaussian DepthPoint (variance 1e-6, age = age_vis_threshold) per masked event whose
+ * disparity lies inside the inverse-depth range.  With at least min_points (INIT_SGM_DP_NUM_THRESHOLD, 500) of them the
+ * points open the fusion window and DepthFusion::naive_propagation (DepthFusion.cpp:234-288) fills the DepthFrame of the
+ * observation set last (esvo_map_set_observation gives its stamp and pose); otherwise *n_points is 0 and nothing
+ * changes.  disp_out (nullable): the W*H int16 disparity image (x16, -16 = none).  StereoSGBM is third-party code that
+ * is restated here from its published algorithm ("parity unpinned"). */
+int esvo_map_init_sgm(esvo_handle h, const uint8_t* ts_left, const uint8_t* ts_right, size_t min_points, size_t* n_points,
+                      int16_t* disp_out);
+
 /* ---- Mapper: fused tick (everything stays in HBM) ---------------------------------- */
 
 /* Replaces dataTransferring's event selection (esvo_Mapping.cpp:555-575) + MappingAtTime

@@ -1335,6 +1335,265 @@ extern "C" void orc_mapper_counters(orc_mapper_handle h, uint64_t out[8]) {
 }
 
 // =====================================================================================================
+// SGM initialisation: esvo_Mapping::InitializationAtTime, esvo_Mapping.cpp:433-492
+// =====================================================================================================
+// cv::StereoSGBM::compute as the reference configures it (esvo_Mapping.cpp:102-108: minDisparity 0, numDisparities 48,
+// blockSize 11, P1 = 8*11*11, P2 = 32*11*11, disp12MaxDiff -1, preFilterCap 0, uniquenessRatio 11, no speckle filter,
+// MODE_SGBM).  OpenCV is a third-party dependency absent from /root/reference and from this image: "parity unpinned".
+// Restated from the published algorithm of modules/calib3d/src/stereosgbm.cpp (OpenCV 4.x, scalar path):
+//   * pixel cost: Birchfield-Tomasi on the clipped x-Sobel image (ftzero = max(preFilterCap, 15) | 1 = 15) plus a
+//     quarter of the BT cost on the raw image; the first and last column of both planes are the constant tab[0] = 15;
+//     only x in [numDisparities, W) is matched
+//   * block cost C: blockSize x blockSize box sum of the pixel cost with replicated borders (inside the matched range)
+//   * single-pass mode = 5 paths: from the left, up-left, up, up-right, and from the right; along each
+//       L(p,d) = C(p,d) + min(L(q,d), L(q,d-1)+P1, L(q,d+1)+P1, min_k L(q,k)+P2) - (min_k L(q,k) + P2),  q = p - r,
+//     with L(q,.) = 0 outside the matched range (OpenCV's zeroed border cells); S = sat16(sat16(L0+L1+L2+L3) + L4)
+//   * winner = first minimum of S; rejected unless unique (S(d)*(100-u) >= minS*100 for all |d - best| > 1); parabola
+//     sub-pixel step in 1/16; left-right check with tolerance 1 (disp12MaxDiff <= 0 selects 1); 3x3 median of the result.
+// disp: W*H int16, disparity * 16, (minDisparity - 1) * 16 = -16 where no match.
+extern "C" void orc_sgbm_compute(const uint8_t* left, const uint8_t* right, int W, int H, int num_disp, int block, int P1, int P2,
+                                 int uniqueness, int16_t* disp) {
+  const int D = num_disp, minD = 0, DISP_SCALE = 16, INVALID = (minD - 1) * DISP_SCALE, MAX_COST = 32767;
+  const int ftzero = 15, SW2 = block / 2, SH2 = block / 2;
+  const int minX1 = D, width1 = W - minX1;
+  for (size_t i = 0; i < (size_t)W * H; ++i) disp[i] = (int16_t)INVALID;
+  if (width1 <= 0) return;
+  auto clip = [&](int v) { return std::min(std::max(v, -ftzero), ftzero) + ftzero; };
+  // pre-filtered planes: [0] clipped Sobel-x, [1] raw; border columns = tab[0]
+  std::vector<uint8_t> pl[2][2];
+  for (int im = 0; im < 2; ++im) {
+    const uint8_t* img = im ? right : left;
+    pl[im][0].assign((size_t)W * H, (uint8_t)clip(0));
+    pl[im][1].assign((size_t)W * H, (uint8_t)clip(0));
+    for (int y = 0; y < H; ++y) {
+      const uint8_t* r0 = img + (size_t)y * W;
+      const uint8_t* rn = img + (size_t)(y > 0 ? y - 1 : y) * W;
+      const uint8_t* rs = img + (size_t)(y < H - 1 ? y + 1 : y) * W;
+      for (int x = 1; x < W - 1; ++x) {
+        pl[im][0][(size_t)y * W + x] = (uint8_t)clip((r0[x + 1] - r0[x - 1]) * 2 + rn[x + 1] - rn[x - 1] + rs[x + 1] - rs[x - 1]);
+        pl[im][1][(size_t)y * W + x] = r0[x];
+      }
+    }
+  }
+  // pixel cost (Birchfield-Tomasi), x' = x - minX1
+  const size_t rowN = (size_t)width1 * D;
+  std::vector<int16_t> pix(rowN * H, 0), hs(rowN * H), C(rowN * H);
+  for (int y = 0; y < H; ++y)
+    for (int c = 0; c < 2; ++c) {
+      const uint8_t* p1 = pl[0][c].data() + (size_t)y * W;
+      const uint8_t* p2 = pl[1][c].data() + (size_t)y * W;
+      const int shift = c ? 2 : 0;
+      for (int x = minX1; x < W; ++x) {
+        const int u = p1[x];
+        const int ul = x > 0 ? (u + p1[x - 1]) / 2 : u, ur = x < W - 1 ? (u + p1[x + 1]) / 2 : u;
+        const int u0 = std::min(std::min(ul, ur), u), u1 = std::max(std::max(ul, ur), u);
+        for (int d = 0; d < D; ++d) {
+          const int xr = x - d - minD;
+          const int v = p2[xr];
+          const int vl = xr < W - 1 ? (v + p2[xr + 1]) / 2 : v;  // OpenCV walks the right row mirrored: its "x-1" is xr+1
+          const int vr = xr > 0 ? (v + p2[xr - 1]) / 2 : v;
+          const int v0 = std::min(std::min(vl, vr), v), v1 = std::max(std::max(vl, vr), v);
+          const int c0 = std::max(std::max(0, u - v1), v0 - u);
+          const int c1 = std::max(std::max(0, v - u1), u0 - v);
+          int16_t& o = pix[(size_t)y * rowN + (size_t)(x - minX1) * D + d];
+          o = (int16_t)(o + (std::min(c0, c1) >> shift));
+        }
+      }
+    }
+  // block cost: horizontal then vertical box sum, replicated borders
+  for (int y = 0; y < H; ++y)
+    for (int x = 0; x < width1; ++x)
+      for (int d = 0; d < D; ++d) {
+        int sum = 0;
+        for (int i = -SW2; i <= SW2; ++i) sum += pix[(size_t)y * rowN + (size_t)std::min(std::max(x + i, 0), width1 - 1) * D + d];
+        hs[(size_t)y * rowN + (size_t)x * D + d] = (int16_t)sum;
+      }
+  for (int y = 0; y < H; ++y)
+    for (size_t i = 0; i < rowN; ++i) {
+      int sum = 0;
+      for (int k = -SH2; k <= SH2; ++k) sum += hs[(size_t)std::min(std::max(y + k, 0), H - 1) * rowN + i];
+      C[(size_t)y * rowN + i] = (int16_t)sum;
+    }
+  // the five paths
+  const int dirs[5][2] = {{-1, 0}, {-1, -1}, {0, -1}, {1, -1}, {1, 0}};  // q = p + dir
+  std::vector<int16_t> L[5];
+  for (int r = 0; r < 5; ++r) {
+    L[r].assign(rowN * H, 0);
+    std::vector<int16_t>& Lr = L[r];
+    const int dx = dirs[r][0];
+    for (int y = 0; y < H; ++y)
+      for (int xi = 0; xi < width1; ++xi) {
+        const int x = dx > 0 ? width1 - 1 - xi : xi;  // the neighbour must have been computed already
+        const int qx = x + dx, qy = y + dirs[r][1];
+        const bool inside = qx >= 0 && qx < width1 && qy >= 0 && qy < H;
+        const int16_t* Lq = inside ? &Lr[(size_t)qy * rowN + (size_t)qx * D] : nullptr;
+        int minq = 0;
+        if (inside) { minq = MAX_COST; for (int d = 0; d < D; ++d) minq = std::min(minq, (int)Lq[d]); }
+        const int delta = minq + P2;
+        for (int d = 0; d < D; ++d) {
+          const int a = inside ? Lq[d] : 0;
+          const int bm = d > 0 ? (inside ? Lq[d - 1] : 0) : MAX_COST;
+          const int bp = d < D - 1 ? (inside ? Lq[d + 1] : 0) : MAX_COST;
+          const int v = C[(size_t)y * rowN + (size_t)x * D + d] + std::min(a, std::min(bm + P1, std::min(bp + P1, delta))) - delta;
+          Lr[(size_t)y * rowN + (size_t)x * D + d] = (int16_t)v;
+        }
+      }
+  }
+  auto sat16 = [](int v) { return v > 32767 ? 32767 : (v < -32768 ? -32768 : v); };
+  std::vector<int> Sp(D);
+  std::vector<int16_t> d1((size_t)W, 0), d2((size_t)W, 0);
+  std::vector<int> d2cost((size_t)W, 0);
+  std::vector<int16_t> raw((size_t)W * H, (int16_t)INVALID);
+  for (int y = 0; y < H; ++y) {
+    for (int x = 0; x < W; ++x) { d1[x] = d2[x] = (int16_t)INVALID; d2cost[x] = MAX_COST; }
+    for (int x = width1 - 1; x >= 0; --x) {
+      const size_t o = (size_t)y * rowN + (size_t)x * D;
+      int minS = MAX_COST, best = -1;
+      for (int d = 0; d < D; ++d) {
+        const int s4 = sat16(L[0][o + d] + L[1][o + d] + L[2][o + d] + L[3][o + d]);
+        Sp[d] = sat16(s4 + L[4][o + d]);
+        if (Sp[d] < minS) { minS = Sp[d]; best = d; }
+      }
+      int d;
+      for (d = 0; d < D; ++d)
+        if (Sp[d] * (100 - uniqueness) < minS * 100 && std::abs(best - d) > 1) break;
+      if (d < D) continue;
+      d = best;
+      const int x2 = x + minX1 - d - minD;
+      if (d2cost[x2] > minS) { d2cost[x2] = minS; d2[x2] = (int16_t)(d + minD); }
+      if (0 < d && d < D - 1) {
+        const int denom2 = std::max(Sp[d - 1] + Sp[d + 1] - 2 * Sp[d], 1);
+        d = d * DISP_SCALE + ((Sp[d - 1] - Sp[d + 1]) * DISP_SCALE + denom2) / (denom2 * 2);
+      } else {
+        d *= DISP_SCALE;
+      }
+      d1[x + minX1] = (int16_t)(d + minD * DISP_SCALE);
+    }
+    for (int x = minX1; x < W; ++x) {  // left-right consistency, tolerance 1
+      const int v = d1[x];
+      if (v == INVALID) continue;
+      const int lo = v >> 4, hi = (v + DISP_SCALE - 1) >> 4;
+      const int xa = x - lo, xb = x - hi;
+      if (0 <= xa && xa < W && d2[xa] >= minD && std::abs(d2[xa] - lo) > 1 && 0 <= xb && xb < W && d2[xb] >= minD &&
+          std::abs(d2[xb] - hi) > 1)
+        d1[x] = (int16_t)INVALID;
+    }
+    for (int x = 0; x < W; ++x) raw[(size_t)y * W + x] = d1[x];
+  }
+  // medianBlur(disp, disp, 3): 3x3 median, replicated border
+  for (int y = 0; y < H; ++y)
+    for (int x = 0; x < W; ++x) {
+      int16_t v[9];
+      int k = 0;
+      for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx)
+          v[k++] = raw[(size_t)std::min(std::max(y + dy, 0), H - 1) * W + std::min(std::max(x + dx, 0), W - 1)];
+      std::nth_element(v, v + 4, v + 9);
+      disp[(size_t)y * W + x] = v[4];
+    }
+}
+// the SGM branch of dataTransferring (esvo_Mapping.cpp:537-552): events of the last 2 * BM_half_slice_thickness walking
+// back from lower_bound(t), while size <= PROCESS_EVENT_NUM (i.e. up to PROCESS_EVENT_NUM + 1 events)
+extern "C" size_t orc_select_events_sgm(const esvo_event_t* ev, size_t n, uint64_t t_ns, double half_slice, size_t max_num,
+                                        uint32_t* out_idx, size_t cap) {
+  const double t_end = ns_to_sec(t_ns);
+  const double t_begin = ns_to_sec(ros_time_from_sec(std::max(0.0, t_end - 2 * half_slice)));
+  auto lb = [&](double t) {
+    size_t lo = 0, hi = n;
+    while (lo < hi) { size_t mid = (lo + hi) / 2; if (ev_sec(ev[mid]) < t) lo = mid + 1; else hi = mid; }
+    return lo;
+  };
+  size_t it_end = lb(t_end), it_begin = lb(t_begin), cnt = 0;
+  while (it_end != it_begin && cnt <= max_num) {
+    if (it_end < n) { if (cnt < cap) out_idx[cnt] = (uint32_t)it_end; cnt++; }  // end() is skipped, as in orc_select_events
+    it_end--;
+  }
+  return cnt;
+}
+// InitializationAtTime on the current observation (set_observation: the UN-smoothed pair is used, :444) and the SGM event
+// selection; returns the number of SGM depth points, or 0 when fewer than min_points (INIT_SGM_DP_NUM_THRESHOLD) were
+// found -- then nothing is pushed.  On success the points open the fusion window (:485) and naive_propagation fills the
+// DepthFrame (DepthFusion.cpp:234-288).  disp_out (nullable): the disparity image.
+extern "C" size_t orc_mapper_init_sgm(orc_mapper_handle h, const uint8_t* ts_left, const uint8_t* ts_right, const esvo_event_t* ev,
+                                      size_t n, size_t min_points, int16_t* disp_out) {
+  const int W = h->W(), H = h->H();
+  std::vector<int16_t> disp((size_t)W * H);
+  orc_sgbm_compute(ts_left, ts_right, W, H, 48, 11, 8 * 11 * 11, 32 * 11 * 11, 11, disp.data());
+  if (disp_out) std::memcpy(disp_out, disp.data(), sizeof(int16_t) * disp.size());
+  const esvo_params_t& p = h->prm;
+  Frame f;
+  f.poses.push_back(h->T_world_obs);
+  const double var_SGM = 0.001 * 0.001;
+  for (size_t i = 0; i < n; ++i) {  // createEdgeMask with radius 0 (:1000-1044) + the loop of :456-480
+    const esvo_event_t& e = ev[i];
+    if (e.x >= W || e.y >= H) continue;
+    const double cx = h->camL.lut[2 * ((size_t)e.y * W + e.x)], cy = h->camL.lut[2 * ((size_t)e.y * W + e.x) + 1];
+    const int xc = (int)std::floor(cx), yc = (int)std::floor(cy);
+    if (xc < 0 || xc >= W || yc < 0 || yc >= H) continue;
+    const double d = disp[(size_t)yc * W + xc] / 16.0;
+    if (d < 0) continue;
+    DP dp((size_t)xc, (size_t)yc);  // DepthPoint dp(x, y): the constructor takes (row, col) -- reproduced as written
+    dp.x[0] = xc * 1.0; dp.x[1] = yc * 1.0;
+    const double invDepth = d / (h->camL.P[0] * h->baseline);
+    if (invDepth < p.invdepth_min || invDepth > p.invdepth_max) continue;
+    h->camL.cam2World(dp.x, invDepth, dp.p_cam);
+    dp.invDepth = invDepth;  // DepthPoint::update on a new point (DepthPoint.cpp:146-164) + boundVariance
+    dp.variance = var_SGM < 1e-6 ? 1e-6 : var_SGM;
+    dp.residual = 0.0;
+    dp.age = (size_t)p.age_vis_threshold;
+    dp.pose_idx = 0;
+    f.pts.push_back(dp);
+  }
+  if (f.pts.size() < min_points) return 0;
+  const size_t n_pts = f.pts.size();
+  h->map.init(W, H);
+  h->T_world_frame = h->T_world_obs;
+  // DepthFusion::naive_propagation, DepthFusion.cpp:234-288
+  const Mat4 T_frame_world = rigid_inverse(h->T_world_frame);
+  for (const DP& prior : f.pts) {
+    const Mat4 T = mat4_mul(T_frame_world, f.poses[prior.pose_idx]);
+    double pp[3];
+    for (int r = 0; r < 3; ++r)
+      pp[r] = ((T.m[r * 4 + 0] * prior.p_cam[0] + T.m[r * 4 + 1] * prior.p_cam[1]) + T.m[r * 4 + 2] * prior.p_cam[2]) + T.m[r * 4 + 3];
+    double xp[2];
+    h->camL.world2Cam(pp, xp);
+    if (!boundaryCheck(xp[0], xp[1], W, H) || !(xp[0] == xp[0]) || !(xp[1] == xp[1])) continue;
+    DP prop((size_t)std::floor(xp[1]), (size_t)std::floor(xp[0]));
+    prop.x[0] = xp[0]; prop.x[1] = xp[1];
+    double denominator = (T.m[8] * prior.p_cam[0] + T.m[9] * prior.p_cam[1]) + T.m[11];
+    denominator /= prior.p_cam[2];
+    denominator += T.m[10];
+    const double J = T.m[10] / sq(denominator);
+    prop.invDepth = 1.0 / pp[2];
+    prop.variance = J * J * prior.variance;
+    if (prop.variance < 1e-6) prop.variance = 1e-6;  // boundVariance
+    prop.p_cam[0] = pp[0]; prop.p_cam[1] = pp[1]; prop.p_cam[2] = pp[2];
+    prop.residual = prior.residual;
+    prop.age = prior.age;
+    for (int dy = 0; dy <= 1; dy++)
+      for (int dx = 0; dx <= 1; dx++) {
+        const size_t row = prop.row + dy, col = prop.col + dx;
+        if (!boundaryCheck((double)col, (double)row, W, H)) continue;
+        if (!h->map.exists(row, col)) {
+          DP nw(row, col);
+          nw.invDepth = prop.invDepth;
+          nw.variance = prop.variance < 1e-6 ? 1e-6 : prop.variance;
+          nw.residual = prop.residual;
+          nw.age = prop.age;
+          h->camL.cam2World(nw.x, prop.invDepth, nw.p_cam);
+          h->map.set(row, col, nw);
+        } else {
+          DP& c = h->map.get(row, col);
+          if (c.invDepth > prop.invDepth) continue;
+          if (prop.residual < c.residual) c = prop;
+        }
+      }
+  }
+  h->window.push_back(std::move(f));  // dqvDepthPoints_.push_back(vdp_sgm): no window policy here (:485)
+  return n_pts;
+}
+
+// =====================================================================================================
 // Debug image publishers and the global-cloud voxel filter
 // =====================================================================================================
 // The 256 colours of Visualization::DrawPoint (Visualization.cpp:74-94,128-226) as the BGR bytes an 8-bit image stores:

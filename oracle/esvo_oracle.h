@@ -103,6 +103,14 @@ size_t orc_mapper_get_pointcloud_xyz(orc_mapper_handle h, float* out_xyz, size_t
 /* counters: [0] window frames [1] window points [2] replace-branch hits [3] replace hits with
  * a displaced cell (row/col differ) [4] max t-scale loop iterations seen [5] LM evaluations */
 void orc_mapper_counters(orc_mapper_handle h, uint64_t out[8]);
+/* SGM initialisation (esvo_Mapping.cpp:102-108,433-492,537-552): cv::StereoSGBM restated ("parity unpinned"),
+ * the SGM event selection, InitializationAtTime + DepthFusion::naive_propagation */
+void orc_sgbm_compute(const uint8_t* left, const uint8_t* right, int W, int H, int num_disp, int block, int P1, int P2,
+                      int uniqueness, int16_t* disp);
+size_t orc_select_events_sgm(const esvo_event_t* ev, size_t n, uint64_t t_ns, double half_slice, size_t max_num, uint32_t* out_idx,
+                             size_t cap);
+size_t orc_mapper_init_sgm(orc_mapper_handle h, const uint8_t* ts_left, const uint8_t* ts_right, const esvo_event_t* ev, size_t n,
+                           size_t min_points, int16_t* disp_out);
 /* debug images + global-cloud helpers: Visualization::plot_map / DrawPoint (Visualization.cpp:13-94) with
  * publishMappingResults' arguments (esvo_Mapping.cpp:868-884); type 0 InvDepth, 1 StdVar, 2 Cost, 3 Age; bgr = H*W*3 */
 void orc_jet_bgr(uint8_t out[768]);

@@ -82,6 +82,11 @@ def load(fast=False):
     lib.orc_mapper_get_pointcloud_xyz.restype = sz
     lib.orc_mapper_get_pointcloud_xyz.argtypes = [vp, vp, sz]
     lib.orc_mapper_counters.argtypes = [vp, vp]
+    lib.orc_sgbm_compute.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
+    lib.orc_select_events_sgm.restype = sz
+    lib.orc_select_events_sgm.argtypes = [vp, sz, u64, dbl, sz, vp, sz]
+    lib.orc_mapper_init_sgm.restype = sz
+    lib.orc_mapper_init_sgm.argtypes = [vp, vp, vp, vp, sz, sz, vp]
     lib.orc_jet_bgr.argtypes = [vp]
     lib.orc_mapper_debug_image.argtypes = [vp, i32, dbl, vp]
     lib.orc_mapper_get_pointcloud_near_xyz.restype = sz
@@ -332,6 +337,15 @@ class OracleMapper:
         n = self.lib.orc_mapper_get_pointcloud_xyz(self.h, out.ctypes.data, out.shape[0])
         return out[:n]
 
+    def init_sgm(self, ts_left, ts_right, ev, min_points=500):
+        """InitializationAtTime (esvo_Mapping.cpp:433-492) on the observation set last; returns (#points, disparity*16 image)"""
+        l = np.ascontiguousarray(ts_left, np.uint8)
+        r = np.ascontiguousarray(ts_right, np.uint8)
+        ev = np.ascontiguousarray(ev, dtype=EVENT_DTYPE)
+        disp = np.empty((self.H, self.W), np.int16)
+        n = self.lib.orc_mapper_init_sgm(self.h, l.ctypes.data, r.ctypes.data, ev.ctypes.data, ev.shape[0], int(min_points), disp.ctypes.data)
+        return int(n), disp
+
     def debug_image(self, kind, age_max_range=10.0):
         """Visualization::plot_map as publishMappingResults calls it; kind: 0 InvDepth, 1 StdVar, 2 Cost, 3 Age -> BGR image"""
         out = np.empty((self.H, self.W, 3), np.uint8)
@@ -362,6 +376,25 @@ def zncc_cost(l, r, exact_int=False):
     l = np.ascontiguousarray(l, np.float64)
     r = np.ascontiguousarray(r, np.float64)
     return lib.orc_zncc_cost(l.ctypes.data, r.ctypes.data, l.shape[1], l.shape[0], int(exact_int))
+
+
+def sgbm(left, right, num_disp=48, block=11, uniqueness=11):
+    """cv::StereoSGBM::compute restated (MODE_SGBM, P1 = 8 b^2, P2 = 32 b^2): int16 disparity * 16"""
+    l = np.ascontiguousarray(left, np.uint8)
+    r = np.ascontiguousarray(right, np.uint8)
+    out = np.empty(l.shape, np.int16)
+    load().orc_sgbm_compute(l.ctypes.data, r.ctypes.data, l.shape[1], l.shape[0], int(num_disp), int(block), 8 * block * block,
+                            32 * block * block, int(uniqueness), out.ctypes.data)
+    return out
+
+
+def select_events_sgm(ev, t_ns, half_slice, max_num):
+    lib = load()
+    ev = np.ascontiguousarray(ev, dtype=EVENT_DTYPE)
+    cap = min(max_num + 1, ev.shape[0]) + 1
+    idx = np.empty(cap, np.uint32)
+    n = lib.orc_select_events_sgm(ev.ctypes.data, ev.shape[0], int(t_ns), float(half_slice), int(max_num), idx.ctypes.data, cap)
+    return idx[:n]
 
 
 def jet_bgr():
