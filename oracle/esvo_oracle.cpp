@@ -2,9 +2,10 @@
 //
 // A dependency-free, double-precision restatement of the ESVO reference hot path.  Every
 // function cites the reference file:line it follows (paths relative to the ESVO repository).
-// PARITY UNPINNED: the reference has no tests or golden vectors and cannot be built here; the
-// third-party pieces (Eigen LM / NumericalDiff, OpenCV image ops) are restated from their
-// published algorithms.
+// PARITY: the mapper (block matching, residual functor, fusion, clean, regulariser) is pinned to the
+// reference's own sources through oracle/_ref (esvo_oracle.h).  UNPINNED: the
+// third-party pieces absent from /root/reference (OpenCV image ops and StereoSGBM, the Eigen LM
+// driver, PCL VoxelGrid), restated from their published algorithms.
 //
 // Build: g++ -O2 -std=c++17 -ffp-contract=off -fPIC -shared   (see oracle/Makefile)
 // -ffp-contract=off matters: the GPU kernels are built the same way so that identical

@@ -45,3 +45,25 @@ def test_gpu_chain_matches_reference_end_to_end(name):
         iou, rmse = map_stats(r["map"], g[f"map{k}"], sc.rig.width)
         assert iou >= 0.97 and rmse < 1e-4, (k, iou, rmse)
     dev.close()
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_gpu_chain_equals_canonical_oracle(name):
+    """The same four rigs, device chain vs the oracle in its GPU-comparable arithmetic: every match, point and DepthMap
+    element identical (hkust: Denoising + r = 5 + CONST_FRAMES; rpg: the 240x180 calibration)."""
+    from esvo_amd import lib
+    from oracle import oracle as O
+    g, sc, ticks = load_fixture(name)
+    dev = lib.Esvo(sc.params, sc.rig, device=0)
+    orc = O.OracleMapper(sc.params, sc.rig)
+    orc.set_mode(True, True)
+    a = S.run_stagewise(dev, ticks, pre_smoothed=False)
+    b = S.run_stagewise(orc, ticks, pre_smoothed=False)
+    for ra, rb in zip(a, b):
+        check_matches(ra["matches"], rb["matches"], cost_exact=True)
+        assert ra["nf"] == rb["nf"]
+        assert len(ra["points"]) == len(rb["points"])
+        for f in ("row", "col", "inv_depth", "variance", "residual", "scale2", "p_cam", "pose_idx"):
+            assert np.array_equal(ra["points"][f], rb["points"][f]), f
+        same_map(ra["map"], rb["map"], p_cam_rtol=0.0)
+    dev.close()
