@@ -168,9 +168,8 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
   for (int cam = 0; cam < 2; ++cam) CK(dalloc(&h->d_ring[cam], h->ring_cap));
   CK(dalloc(&h->d_T_world_obs, 16));
   h->max_poses = (u32)std::max(params->max_poses_per_tick, 2);
-  CK(dalloc(&h->d_pose_sec, h->max_poses));
-  CK(dalloc(&h->d_pose_T2[0], (size_t)h->max_poses * 16));
-  CK(dalloc(&h->d_pose_T2[1], (size_t)h->max_poses * 16));
+  CK(dalloc(&h->d_pose_T2[0], (size_t)h->max_poses * 17));  // [T | toSec]
+  CK(dalloc(&h->d_pose_T2[1], (size_t)h->max_poses * 17));
   h->d_pose_T = h->d_pose_T2[0];
   // + 1: the SGM bootstrap selects up to PROCESS_EVENT_NUM + 1 events (esvo_Mapping.cpp:547: `size() <= PROCESS_EVENT_NUM_`)
   h->max_ev = (u32)std::max(params->max_events_per_tick, params->process_event_num) + 1u;
@@ -266,7 +265,7 @@ int esvo_destroy(esvo_handle h) {
   comm_release(h);
   void* ptrs[] = {h->d_lut, h->d_mask, h->d_fixmap[0], h->d_fixmap[1], h->d_sae[0], h->d_sae[1], h->d_raw, h->d_ts[0],
                   h->d_ts[1], h->d_ring[0], h->d_ring[1], h->d_obs[0], h->d_obs[1], h->d_obs_tmp, h->d_T_world_obs,
-                  h->d_pose_sec, h->d_pose_T2[0], h->d_pose_T2[1], h->d_scan_tmp_b, h->d_cnt_b, h->d_tick_ev, h->d_match_slots, h->d_match_flags, h->d_match_prefix,
+                  h->d_pose_T2[0], h->d_pose_T2[1], h->d_scan_tmp_b, h->d_cnt_b, h->d_tick_ev, h->d_match_slots, h->d_match_flags, h->d_match_prefix,
                   h->d_matches, h->d_pt_slots, h->d_pt_flags, h->d_pt_prefix, h->d_pts_tmp, h->d_stage[0], h->d_stage[1], h->d_counters, h->d_scan_tmp,
                   h->d_win, h->d_frame_pose_T, h->d_fr_table, h->d_prop, h->d_cell_count, h->d_cell_offset,
                   h->d_cell_fill, h->d_rec_ids, h->d_map, h->d_map2, h->d_owner_max, h->d_owner_min, h->d_exp_flags,

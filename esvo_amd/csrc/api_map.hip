@@ -30,8 +30,8 @@ int upload_poses(esvo_context* h, const uint64_t* pose_t_ns, const double* pose_
   // staged through pinned memory (two alternating slots): no host synchronisation on the tick path
   h->pin_slot ^= 1;
   double* pin = h->h_pin + (size_t)h->pin_slot * ((size_t)h->max_poses * 17 + 16);
-  double* sec = pin;
-  double* T = pin + h->max_poses;
+  double* T = pin;            // [T (16 m) | toSec (m)]: one contiguous upload
+  double* sec = pin + 16 * m;
   for (size_t i = 0; i < m; ++i) sec[i] = ns_to_sec(pose_t_ns[i]);
   std::memcpy(T, pose_T, sizeof(double) * 16 * m);
   h->h_pose_T.assign(pose_T, pose_T + 16 * m);
@@ -40,10 +40,8 @@ int upload_poses(esvo_context* h, const uint64_t* pose_t_ns, const double* pose_
   h->pose_buf ^= 1;
   h->d_pose_T = h->d_pose_T2[h->pose_buf];
   HIPCHK(hipStreamWaitEvent(h->stream, h->evt[EV_POSE + h->pose_buf * EV_BACK_STRIDE], 0));
-  if (m) {
-    HIPCHK(hipMemcpyAsync(h->d_pose_sec, sec, sizeof(double) * m, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->d_pose_T, T, sizeof(double) * 16 * m, hipMemcpyHostToDevice, h->stream));
-  }
+  h->d_pose_sec = h->d_pose_T + 16 * m;
+  if (m) HIPCHK(hipMemcpyAsync(h->d_pose_T, T, sizeof(double) * 17 * m, hipMemcpyHostToDevice, h->stream));
   return ESVO_OK;
 }
 
@@ -84,7 +82,7 @@ int run_lm(esvo_context* h, u32 max_matches, int cull, bool dense) {
   LmArgs a;
   a.matches = h->d_matches; a.n_matches = h->d_counters + (dense ? 8 : 0); a.max_matches = max_matches;
   a.tsL = h->d_obs[0]; a.tsR = h->d_obs[1];
-  a.pose_T = h->d_pose_T; a.T_world_obs = h->d_T_world_obs;
+  a.pose_T = h->d_pose_T; std::memcpy(a.T_world_obs, h->T_world_obs, sizeof(double) * 16);
   a.out_slots = h->d_pt_slots; a.out_flags = flags; a.cull = cull; a.dense = dense ? 1 : 0;
   hipEventRecord(h->evt[EV_LM0 + h->fpar * EV_FRONT_STRIDE], h->stream);
   launch_lm_refine(a, h->dp, h->d_counters + 2, h->stream);
@@ -326,17 +324,13 @@ int esvo_map_set_observation(esvo_handle h, uint64_t t_ns, const uint8_t* ts_lef
       HIPCHK(hipStreamSynchronize(h->stream));
     } else {
       if (!h->ts_valid[cam]) FAIL(ESVO_ERR_STATE, "no device-resident Time Surface: call esvo_ts_render first");
-      HIPCHK(hipMemcpyAsync(dst, h->d_ts[cam], npx, hipMemcpyDeviceToDevice, h->stream));
+      if (h->prm.smooth_time_surface) dst = h->d_ts[cam];  // the blur reads the resident surface directly
+      else HIPCHK(hipMemcpyAsync(dst, h->d_ts[cam], npx, hipMemcpyDeviceToDevice, h->stream));
     }
     // createMatchProblem applies GaussianBlurTS(5) when SmoothTimeSurface (EventBM.cpp:68-72)
-    if (h->prm.smooth_time_surface) launch_gaussian5(h->d_obs_tmp, h->d_obs[cam], h->W, h->H, h->stream);
+    if (h->prm.smooth_time_surface) launch_gaussian5(dst, h->d_obs[cam], h->W, h->H, h->stream);
   }
-  std::memcpy(h->T_world_obs, T_world_cam, sizeof(double) * 16);
-  {
-    double* pinT = h->h_pin + (size_t)(h->pin_slot ^ 1) * ((size_t)h->max_poses * 17 + 16) + (size_t)h->max_poses * 17;
-    std::memcpy(pinT, T_world_cam, sizeof(double) * 16);
-    HIPCHK(hipMemcpyAsync(h->d_T_world_obs, pinT, sizeof(double) * 16, hipMemcpyHostToDevice, h->stream));
-  }
+  std::memcpy(h->T_world_obs, T_world_cam, sizeof(double) * 16);  // handed to the LM kernel by value
   h->obs_t_ns = t_ns;
   h->obs_set = true;
   return ESVO_OK;

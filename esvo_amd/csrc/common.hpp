@@ -209,7 +209,7 @@ struct LmArgs {
   const uint8_t* tsL;
   const uint8_t* tsR;
   const double* pose_T;         // [n_pose][16] T_world_virtual
-  const double* T_world_obs;    // [16]
+  double T_world_obs[16];       // by value: no upload per tick
   DevPoint* out_slots;          // [max_matches] slot s (thread-stride order of the solver)
   u32* out_flags;               // [max_matches] 1 = solved (and kept when cull)
   int cull;

@@ -84,7 +84,7 @@ struct esvo_context {
   bool obs_set = false;
 
   // pose table of the tick
-  double* d_pose_sec = nullptr;
+  double* d_pose_sec = nullptr;   // toSec() of the stamps: the tail of the tick's table (d_pose_T + 16 m)
   double* d_pose_T = nullptr;     // the tick's table (one of d_pose_T2, alternating)
   double* d_pose_T2[2] = {nullptr, nullptr};
   int pose_buf = 0;

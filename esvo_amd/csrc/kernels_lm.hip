@@ -302,6 +302,9 @@ __device__ inline double lm_lmpar2(double r, double diag, double qtf, double del
 #define LM_BLOCK 64   // threads per workgroup (no LDS, no barriers).  One wave per workgroup: a finished wave's slot is
                       // refilled at once instead of waiting for its three siblings -- 4 % per tick against 256
 #endif
+// Four matches per wave also for launches that cannot fill the chip: one match per wave (rows 1..3 idle, no lockstep
+// between matches) was measured on reference-faithful ticks and is not faster (upenn 1000 events: 277 vs 250-340 us,
+// DSEC 10 000 events: 447 vs 414 us) -- such a launch lasts as long as its slowest MATCH's own dependent chain.
 __global__ void __launch_bounds__(LM_BLOCK, LM_WAVES) lm_refine_kernel(LmArgs a, DevParams p, u32* n_solved) {
   const u32 s = (blockIdx.x * LM_BLOCK + threadIdx.x) >> 4;  // solver slot (thread-stride order)
   const int c = threadIdx.x & 15;

@@ -16,20 +16,12 @@ def main(path, which=12):
     rows.sort(key=lambda r: r[1])
     lm = [i for i, r in enumerate(rows) if "lm_refine" in r[0]]
     i0, i1 = lm[which - 1], lm[which]
-    # the tick = everything after the previous tick's last op; find the largest idle gap between the two lm launches
-    seg = rows[i0 + 1:i1 + 1]
-    gaps = [(seg[k + 1][1] - max(r[2] for r in seg[:k + 1]), k) for k in range(len(seg) - 1)]
-    g, k = max(gaps)
-    first = i0 + 1 + k + 1
-    nxt = rows[i1 + 1:]
-    # end of tick: ops until the next large gap
-    out = rows[first:i1 + 1]
+    # the tick = from the first Time-Surface scatter after the previous LM launch to the one after this LM launch
+    first = next(i for i in range(i0, i1) if "ts_scatter" in rows[i][0])
+    last = next((i for i in range(i1, len(rows)) if "ts_scatter" in rows[i][0]), len(rows))
+    out = rows[first:last]
     end = max(r[2] for r in out)
-    for r in nxt:
-        if r[1] - end > g * 0.5:
-            break
-        out.append(r)
-        end = max(end, r[2])
+    g = out[0][1] - max(r[2] for r in rows[:first]) if first else 0
     t0 = out[0][1]
     prev_end = t0
     busy = 0
