@@ -211,31 +211,37 @@ def main():
     duration = HIST_S + (n_ticks + 1) * TICK_S
     nd = p.bm_max_disparity - p.bm_min_disparity + 1
 
-    if world > 1:
+    native = (world > 1 and os.environ.get("ESVO_DIST_BACKEND", "nccl") == "nccl"
+              and os.environ.get("ESVO_NATIVE_COMM", "1") != "0")
+    comm_note = None
+
+    def make_runner(use_native):
+        if world == 1:
+            return lib.Esvo(p, rig, device=local_rank)
         from esvo_amd import dist as edist
         # "tick": ticks dealt round-robin to the GPUs, one all-gather of frames per round (throughput scaling);
-        # "band": every tick split over the GPUs by slot / image row band (latency of one tick)
-        # the exchange runs inside libesvo_hip.so (esvo_comm_*: RCCL called from C); the torch.distributed drivers remain
-        # for other backends (gloo on a shared GPU: tests) and with ESVO_NATIVE_COMM=0
-        native = os.environ.get("ESVO_DIST_BACKEND", "nccl") == "nccl" and os.environ.get("ESVO_NATIVE_COMM", "1") != "0"
-        if native:
+        # "band": every tick split over the GPUs by slot / image row band (latency of one tick).
+        # The exchange runs inside libesvo_hip.so (esvo_comm_*: RCCL called from C); the torch.distributed drivers remain
+        # for other backends (gloo on a shared GPU: tests), with ESVO_NATIVE_COMM=0, and as the fallback below.
+        if use_native:
             cls = edist.NativeTickSharded if shard_mode == "tick" else edist.NativeBandSharded
         else:
             cls = edist.TickShardedEsvo if shard_mode == "tick" else edist.ShardedEsvo
-        runner = cls(p, rig, rank, world, local_rank)
-    else:
-        runner = lib.Esvo(p, rig, device=local_rank)
+        return cls(p, rig, rank, world, local_rank)
 
-    # ---- stage the whole stream in HBM (untimed); with --timed-ingest only the history before the first tick ----
     if args.timed_ingest:
         t_first = stream.t0_ns + int(HIST_S * 1e9)
         bounds = [t_first] + [tk[0] for tk in ticks]
         chunks = [(stream.slice(0, a, b), stream.slice(1, a, b)) for a, b in zip(bounds[:-1], bounds[1:])]
-        runner.ts_push_events(0, stream.slice(0, stream.t0_ns, t_first))
-        runner.ts_push_events(1, stream.slice(1, stream.t0_ns, t_first))
-    else:
-        runner.ts_push_events(0, stream.ev_left)
-        runner.ts_push_events(1, stream.ev_right)
+
+    def stage(r):
+        # the whole stream goes to HBM before the timed region; with --timed-ingest only the history before the first tick
+        if args.timed_ingest:
+            r.ts_push_events(0, stream.slice(0, stream.t0_ns, t_first))
+            r.ts_push_events(1, stream.slice(1, stream.t0_ns, t_first))
+        else:
+            r.ts_push_events(0, stream.ev_left)
+            r.ts_push_events(1, stream.ev_right)
 
     def step(k):
         t, stamps, poses, T = ticks[k]
@@ -248,9 +254,30 @@ def main():
         runner.tick(t, stamps, poses)
 
     n_warm, n_all = Wm * per_gpu, (Wm + K) * per_gpu
-    for k in range(n_warm):
-        step(k)
-    runner.synchronize()
+    runner = None
+    for attempt_native in ([True, False] if native else [False]):
+        failed = None
+        try:
+            runner = make_runner(attempt_native)
+            stage(runner)
+            for k in range(n_warm):
+                step(k)
+            runner.synchronize()
+        except Exception as e:  # an error code from the C library (a hang or a fault inside RCCL cannot be caught here)
+            failed = f"{type(e).__name__}: {e}"
+        if dist:  # every rank takes the same path
+            flag = torch.tensor([1.0 if failed else 0.0], device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if flag.item() > 0 and not failed:
+                failed = "another rank failed"
+        if not failed:
+            native = attempt_native
+            break
+        if not attempt_native:
+            raise SystemExit(f"multi-GPU warm-up failed: {failed}")
+        comm_note = f"esvo_comm_* path failed in warm-up ({failed}); fell back to the torch.distributed driver"
+        print(f"[bench rank {rank}] {comm_note}", file=sys.stderr)
+        runner = None
     torch.cuda.synchronize()
     base = runner.stats()  # running totals so far (reading stats drains the handle: not done inside the timed loop)
     if dist:
@@ -322,7 +349,8 @@ def main():
             "disparity_range": [p.bm_min_disparity, p.bm_max_disparity],
             "parallelism": "1 GPU" if world == 1 else ((f"{world} GPUs, {K} ticks per GPU dealt round-robin, ncclAllGather of frames"
                                                         if shard_mode == "tick" else f"{world} GPUs, slots + image row bands")
-                                                       + (" (esvo_comm_*: RCCL inside the C library)" if native else " (torch.distributed)")),
+                                                       + (" (esvo_comm_*: RCCL inside the C library)" if native else " (torch.distributed)")
+                                                       + (f"; {comm_note}" if comm_note else "")),
         },
         "kernel_ms": {KERNEL_NAMES[i]: round(float(kavg[i]), 4) for i in range(7)},
         "roofline": {

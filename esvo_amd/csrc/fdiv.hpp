@@ -29,6 +29,13 @@ __device__ inline bool fdiv_ok(double v) {
   return ((hi >> 20) - 691u) <= 664u || (hi | (unsigned)__double2loint(v)) == 0u;
 }
 
+// the refined reciprocal alone, for a divisor the caller vouches for (inside the window above)
+__device__ inline double recip_refined(double b) {
+  double y = __builtin_amdgcn_rcp(b);
+  y = __builtin_fma(y, __builtin_fma(-b, y, 1.0), y);
+  return __builtin_fma(y, __builtin_fma(-b, y, 1.0), y);
+}
+
 __device__ inline Recip make_recip(double b) {
   Recip R;
   R.b = b;

@@ -95,6 +95,11 @@ __device__ inline double patch_dot(const double a[LM_ROWS], const double b[LM_RO
   return grp_sum(col_sum(t));
 }
 
+__device__ inline double in_vgpr(double x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+
 struct LmProblem {
   double cx, cy;           // rectified left coordinate of the event
   double T[12];            // T_left_virtual (3x4)
@@ -140,7 +145,7 @@ __device__ inline void interp_column(const uint8_t* __restrict__ img, int W, int
 
 // DepthProblem::operator(), Tdist norm.  fv[y] = residual of patch element (y, c); lane 15 -> 0.
 __device__ void lm_eval(const DevParams& p, const LmProblem& pr, double x, double fv[LM_ROWS]) {
-  const double nu = p.td_nu;
+  const double nu = in_vgpr(p.td_nu);  // VGPR: otherwise re-loaded from the kernel arguments in every t-scale iteration
   LM_COUNT(0, pr.c == 0);                                   // evaluations, per group
   LM_SLOT(0, pr.dbg_slot, pr.c == 0, 1u);
   LM_COUNT(1, __lane_id() == __ffsll(__ballot(1)) - 1);     // evaluations, per wave
@@ -177,23 +182,29 @@ __device__ void lm_eval(const DevParams& p, const LmProblem& pr, double x, doubl
   int knz = 0;
   double minabs = 1e300, r2max = 0;
   bool r2_ok = true;  // every r^2 is 0 or of moderate magnitude: shared-divisor quotients allowed
+  double r2n[LM_ROWS];  // r^2 (nu + 1): the numerators of the t-scale update
 #pragma unroll
   for (int y = 0; y < LM_ROWS; ++y) {
     r[y] = (pr.c < LM_COLS) ? (tau1[y] - tau2[y]) : 0.0;
     r2[y] = r[y] * r[y];
+    r2n[y] = r2[y] * (nu + 1);
     r2_ok = r2_ok && fdiv_ok(r2[y]);
     r2max = fmax(r2max, r2[y]);
     if (r[y] != 0) { knz++; minabs = fmin(minabs, fabs(r[y])); }
   }
+  const int knz_lane = knz;
   knz = grp_sum_int(knz);
 #ifdef LM_STATS
   if (pr.c == 0 && pr.dbg_slot < (1u << 18) && g_lm_slot[0][pr.dbg_slot] == 1u) g_lm_slot[2][pr.dbg_slot] = 1000u * (u32)knz;
 #endif
   minabs = grp_min(minabs);
-  const double scale2_0 = p.td_scale2;
+  const double scale2_0 = in_vgpr(p.td_scale2);
   double s2;
   const bool lane_ok = r2_ok && fdiv_ok(nu) && nu > 0 && fdiv_ok(r2max * (nu + 1));
   const int e_r2max = (__double2hiint(r2max) >> 20) & 0x7ff;
+  // all non-zero r^2 of the lane in [2^-100, 2^98]: minabs and r2max bound them (r^2 is monotone in |r|)
+  const bool r2_tight = knz_lane == 0 || (minabs * minabs >= 0x1p-100 && r2max < 0x1p98);
+  const bool nu_mid = nu >= 0x1p-100 && nu < 0x1p100;
   const int N = LM_ROWS * LM_COLS;
 #ifdef LM_EXPERIMENT_NOLOOP
   if (true) {
@@ -208,11 +219,45 @@ __device__ void lm_eval(const DevParams& p, const LmProblem& pr, double x, doubl
     // the weights' own divisors nu + r^2/s1 lie in [nu, 2^333) by the exponent test on the lane's largest r^2.
     double s1 = scale2_0;
     const Recip rN = make_recip((double)N);
-    while (true) {
-      LM_COUNT(2, pr.c == 0);                                 // t-scale iterations, per group
+    // "tight" evaluation (all but a handful): nu and every non-zero r^2 of the GROUP lie in [2^-100, 2^98].  Then, while
+    // s1 stays in [2^-100, 2^100], every operand of the iteration is inside fdiv.hpp's window by construction
+    // (r^2/s1 <= 2^198, t >= 2^-299, 2^-299 <= sum <= 2^110, |s2 - s1| is 0 or >= ulp(2^-100)), so the iteration runs
+    // without a single per-operand range test or branch: one exponent test on s1 decides, uniformly for the group.
+    const bool tight = grp_sum_int((r2_tight && nu_mid) ? 0 : 1) == 0;
+    bool done = false;
+#ifndef LM_PLAIN_DIV
+    if (tight) {
+      // sign bit included in the exponent field: a negative or NaN s1 fails the range test
+      while ((unsigned)(((__double2hiint(s1) >> 20) & 0xfff) - 923) <= 200u) {
+        LM_COUNT(2, pr.c == 0);                                 // t-scale iterations, per group
+        LM_SLOT(1, pr.dbg_slot, pr.c == 0, 1u);
+        LM_SLOT(2, pr.dbg_slot, pr.c == 0 && g_lm_slot[0][pr.dbg_slot < (1u << 18) ? pr.dbg_slot : 0] == 1u, 1u);
+        LM_COUNT(3, __lane_id() == __ffsll(__ballot(1)) - 1);   // t-scale iterations, per wave
+        Recip rs1;
+        rs1.b = s1;
+        rs1.y = recip_refined(s1);
+        double t[LM_ROWS];
+#pragma unroll
+        for (int y = 0; y < LM_ROWS; ++y) {  // r == 0 gives +0 / nu = +0 as the reference's skip does
+          Recip rd;
+          rd.b = nu + div_fast(r2[y], rs1);
+          rd.y = recip_refined(rd.b);
+          t[y] = div_fast(r2n[y], rd);
+        }
+        const double sum = grp_sum(col_sum(t));
+        if (sum == 0) { s2 = scale2_0; done = true; break; }
+        s2 = div_fast(sum, rN);
+        const double rel = div_fast(fabs(s2 - s1), rs1);
+        if (!(rel > 0.05)) { done = true; break; }
+        s1 = s2;
+      }
+    }
+#endif
+    while (!done) {
+      LM_COUNT(2, pr.c == 0);
       LM_SLOT(1, pr.dbg_slot, pr.c == 0, 1u);
       LM_SLOT(2, pr.dbg_slot, pr.c == 0 && g_lm_slot[0][pr.dbg_slot < (1u << 18) ? pr.dbg_slot : 0] == 1u, 1u);
-      LM_COUNT(3, __lane_id() == __ffsll(__ballot(1)) - 1);   // t-scale iterations, per wave
+      LM_COUNT(3, __lane_id() == __ffsll(__ballot(1)) - 1);
       double t[LM_ROWS];
       const Recip rs1 = make_recip(s1);
       const int e_s1 = (__double2hiint(s1) >> 20) & 0x7ff;
@@ -222,8 +267,8 @@ __device__ void lm_eval(const DevParams& p, const LmProblem& pr, double x, doubl
       if (lane_ok && rs1.fast && s1 > 0 && e_r2max - e_s1 < 300) {
 #endif
 #pragma unroll
-        for (int y = 0; y < LM_ROWS; ++y)  // r == 0 gives +0 / nu = +0 as the reference's skip does
-          t[y] = div_fast(r2[y] * (nu + 1), make_recip(nu + div_fast(r2[y], rs1)));
+        for (int y = 0; y < LM_ROWS; ++y)
+          t[y] = div_fast(r2n[y], make_recip(nu + div_fast(r2[y], rs1)));
       } else {
 #pragma unroll
         for (int y = 0; y < LM_ROWS; ++y) t[y] = (r[y] != 0) ? r2[y] * (nu + 1) / (nu + r2[y] / s1) : 0.0;
