@@ -181,14 +181,12 @@ __device__ void lm_eval(const DevParams& p, const LmProblem& pr, double x, doubl
   interp_column(pr.tsR, p.W, ulx2, uly2, pr.c, b1, b2, b3, b4, tau2);
   int knz = 0;
   double minabs = 1e300, r2max = 0;
-  bool r2_ok = true;  // every r^2 is 0 or of moderate magnitude: shared-divisor quotients allowed
   double r2n[LM_ROWS];  // r^2 (nu + 1): the numerators of the t-scale update
 #pragma unroll
   for (int y = 0; y < LM_ROWS; ++y) {
     r[y] = (pr.c < LM_COLS) ? (tau1[y] - tau2[y]) : 0.0;
     r2[y] = r[y] * r[y];
     r2n[y] = r2[y] * (nu + 1);
-    r2_ok = r2_ok && fdiv_ok(r2[y]);
     r2max = fmax(r2max, r2[y]);
     if (r[y] != 0) { knz++; minabs = fmin(minabs, fabs(r[y])); }
   }
@@ -200,11 +198,19 @@ __device__ void lm_eval(const DevParams& p, const LmProblem& pr, double x, doubl
   minabs = grp_min(minabs);
   const double scale2_0 = in_vgpr(p.td_scale2);
   double s2;
-  const bool lane_ok = r2_ok && fdiv_ok(nu) && nu > 0 && fdiv_ok(r2max * (nu + 1));
   const int e_r2max = (__double2hiint(r2max) >> 20) & 0x7ff;
   // all non-zero r^2 of the lane in [2^-100, 2^98]: minabs and r2max bound them (r^2 is monotone in |r|)
   const bool r2_tight = knz_lane == 0 || (minabs * minabs >= 0x1p-100 && r2max < 0x1p98);
   const bool nu_mid = nu >= 0x1p-100 && nu < 0x1p100;
+  // lane_ok: every r^2 is 0 or of moderate magnitude, so shared-divisor quotients are allowed.  The tight bounds imply
+  // it; the per-row exponent tests run only for the rare lane outside them.
+  bool lane_ok = r2_tight && nu_mid;
+  if (!lane_ok) {
+    bool r2_ok = true;
+#pragma unroll
+    for (int y = 0; y < LM_ROWS; ++y) r2_ok = r2_ok && fdiv_ok(r2[y]);
+    lane_ok = r2_ok && fdiv_ok(nu) && nu > 0 && fdiv_ok(r2max * (nu + 1));
+  }
   const int N = LM_ROWS * LM_COLS;
 #ifdef LM_EXPERIMENT_NOLOOP
   if (true) {
