@@ -23,6 +23,7 @@
 #include <algorithm>
 #include "common.hpp"
 #include "fdiv.hpp"
+#include "scan.hpp"
 
 namespace esvo {
 
@@ -146,55 +147,105 @@ __device__ inline u32 fuse_bucket(u32 n) {  // n >= 1: 1->0, 2->1, 3..4->2, 5..8
   const u32 b = (n <= 1u) ? 0u : 32u - (u32)__builtin_clz(n - 1u);
   return b < FUSE_NB - 1u ? b : FUSE_NB - 1u;
 }
-__global__ void __launch_bounds__(256) bucket_count_kernel(const u32* __restrict__ cell_count, u32* __restrict__ bucket_cnt,
-                                                           MapCell* __restrict__ map, int ncell, int band0, int band1, int W) {
+// The exclusive scan of the per-cell record counts (-> cell_offset) and the bucketing of the touched cells run in the
+// SAME three passes (reduce / block sums / down-sweep): both only read cell_count, so what used to be six dependent
+// launches (scan x3, bucket count / offsets / scatter) are three.
+__global__ void __launch_bounds__(SCAN_B) cell_scan_reduce_kernel(const u32* __restrict__ cell_count, u32* __restrict__ block_sums,
+                                                                 u32* __restrict__ bucket_cnt, MapCell* __restrict__ map, int ncell,
+                                                                 int band0, int band1, int W) {
+  __shared__ u32 lds[SCAN_B / ESVO_WAVE];
   __shared__ u32 h[FUSE_NB];
   if (threadIdx.x < FUSE_NB) h[threadIdx.x] = 0;
   __syncthreads();
-  const int cell = blockIdx.x * blockDim.x + threadIdx.x;
-  if (cell < ncell) {
+  const int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_V;
+  u32 s = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_V; ++k) {
+    const int cell = base + k;
+    if (cell >= ncell) break;
+    const u32 n = cell_count[cell];
+    s += n;
     const int row = cell / W;
     if (row >= band0 && row < band1) {
-      const u32 n = cell_count[cell];
       if (n == 0) map[cell].flags = 0;
       else atomicAdd(&h[fuse_bucket(n)], 1u);
     }
   }
-  __syncthreads();
+  u32 tot;
+  block_excl_scan(s, &tot, lds);  // (barriers inside: h is complete afterwards)
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
   if (threadIdx.x < FUSE_NB && h[threadIdx.x]) atomicAdd(&bucket_cnt[threadIdx.x], h[threadIdx.x]);
 }
-// bucket_off[b] = number of cells in buckets > b (descending order); single block
-__global__ void __launch_bounds__(FUSE_NB) bucket_offsets_kernel(const u32* __restrict__ bucket_cnt, u32* __restrict__ bucket_off,
-                                                                 u32* __restrict__ n_touched) {
+// single block: exclusive scan of the block sums; bucket_off[b] = number of cells in buckets > b (descending order)
+__global__ void __launch_bounds__(SCAN_B) cell_scan_sums_kernel(u32* __restrict__ block_sums, u32 nb, u32* __restrict__ total,
+                                                               const u32* __restrict__ bucket_cnt, u32* __restrict__ bucket_off,
+                                                               u32* __restrict__ n_touched) {
+  __shared__ u32 lds[SCAN_B / ESVO_WAVE];
   __shared__ u32 c[FUSE_NB];
-  c[threadIdx.x] = bucket_cnt[threadIdx.x];
-  __syncthreads();
-  u32 off = 0;
-  for (int b = FUSE_NB - 1; b > (int)threadIdx.x; --b) off += c[b];
-  bucket_off[threadIdx.x] = off;
-  if (threadIdx.x == 0) *n_touched = off + c[0];
+  if (threadIdx.x < FUSE_NB) c[threadIdx.x] = bucket_cnt[threadIdx.x];
+  u32 carry = 0;
+  for (u32 tile = 0; tile < nb; tile += SCAN_TILE) {  // nb <= SCAN_TILE for every supported image; the loop is for safety
+    u32 v[SCAN_V];
+    u32 s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_V; ++k) {
+      const u32 i = tile + threadIdx.x * SCAN_V + k;
+      v[k] = (i < nb) ? block_sums[i] : 0u;
+      s += v[k];
+    }
+    u32 tot;
+    u32 ex = block_excl_scan(s, &tot, lds) + carry;
+#pragma unroll
+    for (int k = 0; k < SCAN_V; ++k) {
+      const u32 i = tile + threadIdx.x * SCAN_V + k;
+      if (i < nb) block_sums[i] = ex;
+      ex += v[k];
+    }
+    carry += tot;
+  }
+  if (threadIdx.x == 0 && total) *total = carry;
+  if (threadIdx.x < FUSE_NB) {  // c[] was written before the first barrier of block_excl_scan
+    u32 off = 0;
+    for (int b = FUSE_NB - 1; b > (int)threadIdx.x; --b) off += c[b];
+    bucket_off[threadIdx.x] = off;
+    if (threadIdx.x == 0) *n_touched = off + c[0];
+  }
 }
-__global__ void __launch_bounds__(256) bucket_scatter_kernel(const u32* __restrict__ cell_count, const u32* __restrict__ bucket_off,
-                                                             u32* __restrict__ bucket_fill, u32* __restrict__ cell_list, int ncell,
-                                                             int band0, int band1, int W) {
+__global__ void __launch_bounds__(SCAN_B) cell_scan_down_kernel(const u32* __restrict__ cell_count, u32* __restrict__ cell_offset,
+                                                               const u32* __restrict__ block_sums, const u32* __restrict__ bucket_off,
+                                                               u32* __restrict__ bucket_fill, u32* __restrict__ cell_list, int ncell,
+                                                               int band0, int band1, int W) {
+  __shared__ u32 lds[SCAN_B / ESVO_WAVE];
   __shared__ u32 h[FUSE_NB];
-  __shared__ u32 base[FUSE_NB];
+  __shared__ u32 hbase[FUSE_NB];
   if (threadIdx.x < FUSE_NB) h[threadIdx.x] = 0;
   __syncthreads();
-  const int cell = blockIdx.x * blockDim.x + threadIdx.x;
-  u32 b = 0, rank = 0;
-  bool on = false;
-  if (cell < ncell) {
-    const int row = cell / W;
-    if (row >= band0 && row < band1) {
-      const u32 n = cell_count[cell];
-      if (n) { on = true; b = fuse_bucket(n); rank = atomicAdd(&h[b], 1u); }
+  const int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_V;
+  u32 v[SCAN_V], rank[SCAN_V];
+  u32 s = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_V; ++k) {
+    const int cell = base + k;
+    v[k] = 0;
+    rank[k] = 0xffffffffu;
+    if (cell < ncell) {
+      v[k] = cell_count[cell];
+      const int row = cell / W;
+      if (v[k] && row >= band0 && row < band1) rank[k] = atomicAdd(&h[fuse_bucket(v[k])], 1u);
     }
+    s += v[k];
   }
+  u32 tot;
+  u32 ex = block_excl_scan(s, &tot, lds) + block_sums[blockIdx.x];
+  if (threadIdx.x < FUSE_NB && h[threadIdx.x]) hbase[threadIdx.x] = bucket_off[threadIdx.x] + atomicAdd(&bucket_fill[threadIdx.x], h[threadIdx.x]);
   __syncthreads();
-  if (threadIdx.x < FUSE_NB && h[threadIdx.x]) base[threadIdx.x] = bucket_off[threadIdx.x] + atomicAdd(&bucket_fill[threadIdx.x], h[threadIdx.x]);
-  __syncthreads();
-  if (on) cell_list[base[b] + rank] = (u32)cell;
+#pragma unroll
+  for (int k = 0; k < SCAN_V; ++k) {
+    const int cell = base + k;
+    if (cell < ncell) cell_offset[cell] = ex;
+    ex += v[k];
+    if (rank[k] != 0xffffffffu) cell_list[hbase[fuse_bucket(v[k])] + rank[k]] = (u32)cell;
+  }
 }
 
 // Long record lists (n > 8: every bucket >= 4, i.e. the first bucket_off[3] entries of the cell
@@ -326,12 +377,14 @@ void launch_fuse(const FuseArgs& a, const DevParams& p, hipStream_t s) {
   const int nb = (ncell + 255) / 256;
   hipLaunchKernelGGL(fuse_reset_kernel, dim3(std::max(nb, 2)), dim3(256), 0, s, a, ncell);
   if (a.n_pts) hipLaunchKernelGGL(propagate_kernel, dim3((a.n_pts + 255) / 256), dim3(256), 0, s, a, p, K);
-  launch_exclusive_scan_u32(a.cell_count, a.cell_offset, a.d_total, a.scan_tmp, (size_t)ncell, s);
+  const u32 nsb = (u32)((ncell + SCAN_TILE - 1) / SCAN_TILE);
+  hipLaunchKernelGGL(cell_scan_reduce_kernel, dim3(nsb), dim3(SCAN_B), 0, s, a.cell_count, a.scan_tmp, a.bucket, a.map, ncell,
+                     p.cband_y0, p.cband_y1, p.W);
+  hipLaunchKernelGGL(cell_scan_sums_kernel, dim3(1), dim3(SCAN_B), 0, s, a.scan_tmp, nsb, a.d_total, a.bucket, a.bucket + FUSE_NB,
+                     a.n_touched);
+  hipLaunchKernelGGL(cell_scan_down_kernel, dim3(nsb), dim3(SCAN_B), 0, s, a.cell_count, a.cell_offset, a.scan_tmp,
+                     a.bucket + FUSE_NB, a.bucket + 2 * FUSE_NB, a.cell_list, ncell, p.cband_y0, p.cband_y1, p.W);
   if (a.n_pts) hipLaunchKernelGGL(scatter_records_kernel, dim3((a.n_pts + 255) / 256), dim3(256), 0, s, a, p, K);
-  hipLaunchKernelGGL(bucket_count_kernel, dim3(nb), dim3(256), 0, s, a.cell_count, a.bucket, a.map, ncell, p.cband_y0, p.cband_y1, p.W);
-  hipLaunchKernelGGL(bucket_offsets_kernel, dim3(1), dim3(FUSE_NB), 0, s, a.bucket, a.bucket + FUSE_NB, a.n_touched);
-  hipLaunchKernelGGL(bucket_scatter_kernel, dim3(nb), dim3(256), 0, s, a.cell_count, a.bucket + FUSE_NB, a.bucket + 2 * FUSE_NB,
-                     a.cell_list, ncell, p.cband_y0, p.cband_y1, p.W);
   hipLaunchKernelGGL(sort_long_lists_kernel, dim3(8192), dim3(64), 0, s, a.cell_list, a.bucket + FUSE_NB + 3, a.cell_count,
                      a.cell_offset, a.rec_ids);
   hipLaunchKernelGGL(fuse_cells_kernel, dim3((ncell + FUSE_BLOCK - 1) / FUSE_BLOCK), dim3(FUSE_BLOCK), 0, s, a, p, K);
@@ -360,25 +413,16 @@ void launch_clean(MapCell* map, const DevParams& p, hipStream_t s) {
 }
 
 // ---- DepthRegularization::apply -------------------------------------------------------------------
-__global__ void __launch_bounds__(256) reg_owner_kernel(const MapCell* __restrict__ map, u32* __restrict__ owner_max,
-                                                        u32* __restrict__ owner_min, DevParams p) {
-  const int cell = blockIdx.x * blockDim.x + threadIdx.x;
-  if (cell >= p.W * p.H) return;
-  { const int row = cell / p.W; if (row < p.cband_y0 || row >= p.cband_y1) return; }
-  const MapCell& c = map[cell];
-  if (!(c.flags & CELL_ALIVE)) return;
-  const u32 b = c.row * (u32)p.W + c.col;  // dmTmp.set(it->row(), it->col(), *it)
-  atomicMax(&owner_max[b], c.seq + 1u);
-  atomicMin(&owner_min[b], c.seq);
-}
-
 // "Regularisation view" of the map: what the (2r+1)^2 neighbourhood scan reads, 32 B per cell instead of a 104 B MapCell.
 //   ab[c] : (inv_depth, 2*sqrt(variance))  -- the closeness test operands; (NaN, NaN) where the tap is not a neighbour,
 //                                             i.e. !(exists(r,c) && at(r,c).valid()): every comparison with it is false
 //   cd[c] : (nu, scale2)                   -- read only for close neighbours
 // The neighbour's sqrt is computed once per cell instead of once per tap.
+// The same pass records, per believed cell, the last and the first element set there (dmTmp.set(it->row(), it->col(), *it)
+// in list order: the last one owns the cell, the first one fixes its position in dmTmp's list).
 __global__ void __launch_bounds__(256) reg_view_kernel(const MapCell* __restrict__ map, MapCell* __restrict__ out,
                                                        double2* __restrict__ ab, double2* __restrict__ cd,
+                                                       u32* __restrict__ owner_max, u32* __restrict__ owner_min,
                                                        u32* __restrict__ n_elems, int ncell, int W,
                                                        int band0, int band1, int view0, int view1) {
   const int cell = blockIdx.x * blockDim.x + threadIdx.x;
@@ -387,6 +431,11 @@ __global__ void __launch_bounds__(256) reg_view_kernel(const MapCell* __restrict
     const MapCell& n = map[cell];
     const int row = cell / W;
     if (row >= view0 && row < view1) {  // the view covers the band's halo as well (multi-GPU: computed, not exchanged)
+      if (n.flags & CELL_ALIVE) {
+        const u32 b = n.row * (u32)W + n.col;
+        atomicMax(&owner_max[b], n.seq + 1u);
+        atomicMin(&owner_min[b], n.seq);
+      }
       const bool v = (n.flags & CELL_ALIVE) && (n.flags & CELL_GRID) && n.inv_depth > -1e-6;
       const double nan = __longlong_as_double(0x7ff8000000000000ll);
       ab[cell] = v ? make_double2(n.inv_depth, 2.0 * sqrt(n.variance)) : make_double2(nan, nan);
@@ -599,8 +648,7 @@ void launch_reg_view(const MapCell* map_in, MapCell* map_out, u32* owner_max, u3
   const int ncell = p.W * p.H;
   // owner_max / owner_min / n_elems were reset by fuse_reset_kernel (launch_fuse of the same tick)
   const int nb = (ncell + 255) / 256;
-  hipLaunchKernelGGL(reg_owner_kernel, dim3(nb), dim3(256), 0, s, map_in, owner_max, owner_min, p);
-  hipLaunchKernelGGL(reg_view_kernel, dim3(nb), dim3(256), 0, s, map_in, map_out, ab, cd, n_elems, ncell, p.W,
+  hipLaunchKernelGGL(reg_view_kernel, dim3(nb), dim3(256), 0, s, map_in, map_out, ab, cd, owner_max, owner_min, n_elems, ncell, p.W,
                      p.band_y0, p.band_y1, p.cband_y0, p.cband_y1);
 }
 void launch_reg_apply(const MapCell* map_in, MapCell* map_out, const u32* owner_max, const u32* owner_min, const double2* ab,
