@@ -166,7 +166,6 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
   CK(dalloc(&h->d_obs_tmp, npx + 64));
   h->ring_cap = (u64)std::max<int64_t>(params->event_ring_capacity, 1024);
   for (int cam = 0; cam < 2; ++cam) CK(dalloc(&h->d_ring[cam], h->ring_cap));
-  CK(dalloc(&h->d_T_world_obs, 16));
   h->max_poses = (u32)std::max(params->max_poses_per_tick, 2);
   CK(dalloc(&h->d_pose_T2[0], (size_t)h->max_poses * 17));  // [T | toSec]
   CK(dalloc(&h->d_pose_T2[1], (size_t)h->max_poses * 17));
@@ -231,14 +230,7 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
   CK(dalloc(&h->d_codes, h->codes_bytes));
   CK(dalloc(&h->d_sel, E));
   CK(dalloc(&h->d_evmap, npx + 64));
-  CK(dalloc(&h->d_reg_valid, npx / 64 + 8));
-  CK(hipMemset(h->d_reg_valid, 0, sizeof(u64) * (npx / 64 + 8)));
   CK(dalloc(&h->d_cell_list, npx));
-  {
-    h->reg_words = (u32)(2 * std::max(params->reg_radius, 1) + 1);  // one mask per tap row and element
-    CK(dalloc(&h->d_reg_bits, npx * (size_t)h->reg_words));
-    CK(dalloc(&h->d_reg_counts, 2 * npx));
-  }
   CK(dalloc(&h->d_reg_ab, npx));
   CK(dalloc(&h->d_reg_cd, npx));
   CK(dalloc(&h->d_exp_flags, npx));
@@ -251,7 +243,6 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
   for (int i = 0; i < esvo_context::POSE_POOL; ++i) CK(hipEventCreate(&h->pool_evt[i]));
   h->pool_ok = true;
   for (int i = 0; i < 16; ++i) h->T_world_obs[i] = h->T_world_frame[i] = (i % 5 == 0) ? 1.0 : 0.0;
-  CK(hipMemcpy(h->d_T_world_obs, h->T_world_obs, sizeof(double) * 16, hipMemcpyHostToDevice));
 #undef CK
   *out = h;
   return ESVO_OK;
@@ -264,13 +255,13 @@ int esvo_destroy(esvo_handle h) {
   if (h->stream_b) hipStreamSynchronize(h->stream_b);
   comm_release(h);
   void* ptrs[] = {h->d_lut, h->d_mask, h->d_fixmap[0], h->d_fixmap[1], h->d_sae[0], h->d_sae[1], h->d_raw, h->d_ts[0],
-                  h->d_ts[1], h->d_ring[0], h->d_ring[1], h->d_obs[0], h->d_obs[1], h->d_obs_tmp, h->d_T_world_obs,
+                  h->d_ts[1], h->d_ring[0], h->d_ring[1], h->d_obs[0], h->d_obs[1], h->d_obs_tmp,
                   h->d_pose_T2[0], h->d_pose_T2[1], h->d_scan_tmp_b, h->d_cnt_b, h->d_tick_ev, h->d_match_slots, h->d_match_flags, h->d_match_prefix,
                   h->d_matches, h->d_pt_slots, h->d_pt_flags, h->d_pt_prefix, h->d_pts_tmp, h->d_stage[0], h->d_stage[1], h->d_counters, h->d_scan_tmp,
                   h->d_win, h->d_frame_pose_T, h->d_fr_table, h->d_prop, h->d_cell_count, h->d_cell_offset,
                   h->d_cell_fill, h->d_rec_ids, h->d_map, h->d_map2, h->d_owner_max, h->d_owner_min, h->d_exp_flags,
-                  h->d_exp_prefix, h->d_export, h->d_export_cell, h->d_reg_bits, h->d_reg_ab, h->d_reg_cd, h->d_bucket, h->d_cell_list, h->d_own_w, h->d_lkeep, h->d_codes,
-                  h->d_reg_valid, h->d_reg_counts, h->d_sel, h->d_evmap};
+                  h->d_exp_prefix, h->d_export, h->d_export_cell, h->d_reg_ab, h->d_reg_cd, h->d_bucket, h->d_cell_list, h->d_own_w, h->d_lkeep, h->d_codes,
+                  h->d_sel, h->d_evmap};
   for (void* p : ptrs) if (p) hipFree(p);
   if (h->h_counters) hipHostFree(h->h_counters);
   if (h->h_cnt_b) hipHostFree(h->h_cnt_b);
@@ -336,7 +327,6 @@ int esvo_set_params(esvo_handle h, const esvo_params_t* params) {
   if ((u32)std::max(params->max_events_per_tick, params->process_event_num) > h->max_ev)
     FAIL(ESVO_ERR_CAPACITY, "process_event_num exceeds the capacity fixed at esvo_create");
   {
-    if ((u32)(2 * std::max(params->reg_radius, 1) + 1) > h->reg_words) FAIL(ESVO_ERR_CAPACITY, "RegularizationRadius exceeds the capacity fixed at esvo_create");
     const u32 need = params->fusion_strategy == ESVO_FUSION_CONST_POINTS ? (u32)(1.5 * params->max_fusion_points) + 4u
                                                                          : (u32)params->max_fusion_frames + 2u;
     if (need > h->max_frames) FAIL(ESVO_ERR_CAPACITY, "fusion window (frames) exceeds the capacity fixed at esvo_create");

@@ -79,7 +79,6 @@ struct esvo_context {
   uint8_t* d_obs[2] = {nullptr, nullptr};
   uint8_t* d_obs_tmp = nullptr;
   double T_world_obs[16];
-  double* d_T_world_obs = nullptr;
   u64 obs_t_ns = 0;
   bool obs_set = false;
 
@@ -148,9 +147,7 @@ struct esvo_context {
   size_t codes_bytes = 0;
   void* xchg_ptr = nullptr;       // what the caller must sum across the ranks before the next phase
   size_t xchg_bytes = 0;
-  u64* d_reg_valid = nullptr;     // regulariser view: 1 bit per cell
   bool sharded = false;
-  u32 reg_words = 0;
   // A tick's state between its phases.  Unsharded ticks are finished lazily: esvo_map_tick(k) enqueues the front
   // stage of tick k and only then completes tick k-1 (point count -> window policy -> back stage), so the host
   // never waits on the front stream while it still has work to enqueue there.
@@ -165,8 +162,6 @@ struct esvo_context {
   u64 committed_t_ns = 0;         // stamp of the newest tick whose back stage is enqueued (0: none)
   u64 sh_first = 0;
   u32* d_cell_list = nullptr;
-  u64* d_reg_bits = nullptr;    // close-neighbour masks of the regulariser scan: [elements][words]
-  u32* d_reg_counts = nullptr;  // (n_neighbours, n_close) per element
   double2* d_reg_ab = nullptr;
   double2* d_reg_cd = nullptr;
   double T_world_frame[16];

@@ -146,11 +146,15 @@ class TickShardedEsvo:
         self.last_mine = -1        # index of the last tick this rank fused
         self.words = DEPTH_POINT_DTYPE.itemsize // 8
         self._cnt = torch.zeros(world, dtype=torch.int64, device=device)
-        # two alternating gather buffers (a fusion may still read the previous round's), sized for 64 k points per tick
-        # up front and grown on demand; one untimed round trip of both collectives sets up the communicator's channels
+        # Four alternating gather buffers, sized for 64 k points per tick up front and grown on demand.  The pushes of
+        # round R copy out of the buffer on the library's BACK stream; they are enqueued there before this rank's fusion
+        # of round R + 1, whose completion the front stage of round R + 3 waits for (two ticks in flight per handle) --
+        # so a buffer may be overwritten by the gather of round R + 3 at the earliest, and a reuse distance of 4 is safe.
+        # One untimed round trip of both collectives sets up the communicator's channels.
         prime = 65536 * self.words
-        self._gather = [torch.empty(world * prime, dtype=torch.int64, device=device) for _ in range(2)]
+        self._gather = [torch.empty(world * prime, dtype=torch.int64, device=device) for _ in range(4)]
         self._rounds = 0
+        self._retired = []
         import torch.distributed as dist
         dist.all_reduce(self._cnt, op=dist.ReduceOp.SUM, group=group)
         self._all_gather(self._gather[0][: world * 1024], torch.zeros(1024, dtype=torch.int64, device=device))
@@ -200,10 +204,11 @@ class TickShardedEsvo:
         dist.all_reduce(self._cnt, op=dist.ReduceOp.SUM, group=self.group)  # world counts (the host sizes the gather)
         counts = [int(c) for c in self._cnt.tolist()]
         stride = max(max(counts), 1) * self.words
-        buf = self._gather[self._rounds & 1]
+        buf = self._gather[self._rounds % 4]
         if buf is None or buf.numel() < self.world * stride:
+            self._retired.append(buf)  # copies on the back stream may still read it: never handed back to the allocator
             buf = torch.empty(self.world * stride, dtype=torch.int64, device=self.device)
-            self._gather[self._rounds & 1] = buf
+            self._gather[self._rounds % 4] = buf
         send = buf.new_zeros(stride) if not n_mine else torch.empty(stride, dtype=torch.int64, device=self.device)
         if n_mine:
             send[: n_mine * self.words] = device_tensor(self.mine[0], n_mine * self.words, "<i8", self.device)
