@@ -16,6 +16,7 @@
 // minima wins).  Results land in slot w of the reference's thread-stride order
 // (EventBM.cpp:289-308), so a stable compaction reproduces vEMP.
 #include "common.hpp"
+#include "fdiv.hpp"
 
 namespace esvo {
 
@@ -30,14 +31,33 @@ __device__ inline long long wave_sum_i64(long long v) {
   return v;
 }
 
-__device__ inline double zncc_from_moments(long long Sl, long long Sll, long long Sr, long long Srr, long long Slr,
-                                           int N) {
-  const double n = (double)N;
-  const double varl = (double)((long long)N * Sll - Sl * Sl) / (n * n);
-  const double varr = (double)((long long)N * Srr - Sr * Sr) / (n * n);
-  const double sigl = sqrt(varl) + 1e-6, sigr = sqrt(varr) + 1e-6;
-  const double cov = (double)((long long)N * Slr - Sl * Sr) / n;
-  return 0.5 * (1 - cov / (sigl * sigr) / n);
+// ZNCC cost from the exact integer moments of the two 105-pixel patches (tools::zncc_cost via normalizePatch,
+// utils.h:74-92 / EventBM.cpp:317-333, restated on moments -- see the oracle's integer mode).
+//   N*Sxx - Sx*Sx <= 105^2 * 255^2 < 2^31 and |N*Slr - Sl*Sr| < 2^31: 32-bit integer arithmetic is exact and the
+//   conversions to f64 are single instructions.
+// The quotients by the constants n and n^2 and by sigl*sigr are IEEE quotients through fdiv.hpp's refined reciprocal:
+// every operand is 0 or lies in [1e-12, 1e10] by the integer bounds, far inside its window; sqrt_moderate likewise
+// (a zero variance is selected around it).
+struct ZnccLeft {
+  double sigl;  // sqrt(var_l) + 1e-6
+  int Sl;
+};
+__device__ inline double sqrt_var(double v) { return v > 0 ? sqrt_moderate(v) : 0.0; }
+__device__ inline ZnccLeft zncc_left(int Sl, int Sll, int N, const Recip& rn2) {
+  ZnccLeft z;
+  z.Sl = Sl;
+  z.sigl = sqrt_var(div_fast((double)(N * Sll - Sl * Sl), rn2)) + 1e-6;
+  return z;
+}
+__device__ inline double zncc_from_moments(const ZnccLeft& zl, int Sr, int Srr, int Slr, int N, const Recip& rn,
+                                           const Recip& rn2) {
+  const double varr = div_fast((double)(N * Srr - Sr * Sr), rn2);
+  const double sigr = sqrt_var(varr) + 1e-6;
+  const double cov = div_fast((double)(N * Slr - zl.Sl * Sr), rn);
+  Recip rs;
+  rs.b = zl.sigl * sigr;
+  rs.y = recip_refined(rs.b);
+  return 0.5 * (1 - div_fast(div_fast(cov, rs), rn));
 }
 
 extern __shared__ __attribute__((aligned(16))) unsigned char bm_smem[];
@@ -101,7 +121,7 @@ __global__ void __launch_bounds__(BM_BLOCK) bm_match_kernel(BmArgs a, DevParams 
   if (ok) ok = !(x1 - hx < 1 || y1 - hy < 1 || x1 + hx >= W - 1 || y1 + hy >= H - 1);  // isValidPatch, :251-267
 
   // ---- stage the left patch (bytes -> LDS), left moments, low-texture test (:101-109) ----
-  long long Sl = 0, Sll = 0;
+  int Sl = 0, Sll = 0;
   if (ok) {
     for (int i = l; i < 28; i += G) ldsL[i] = 0u;  // zero incl. the pad bytes (same lane order as below: in-order LDS)
   }
@@ -145,6 +165,8 @@ __global__ void __launch_bounds__(BM_BLOCK) bm_match_kernel(BmArgs a, DevParams 
   double best = 1.0;  // ZNCC_MAX_
   int bestd = -1;
   if (ok) {
+    const Recip rn = make_recip((double)N), rn2 = make_recip((double)N * (double)N);
+    const ZnccLeft zl = zncc_left(Sl, Sll, N, rn2);
     u32 L[wy][4];
 #pragma unroll
     for (int py = 0; py < wy; ++py) {
@@ -179,7 +201,7 @@ __global__ void __launch_bounds__(BM_BLOCK) bm_match_kernel(BmArgs a, DevParams 
         srr = __builtin_amdgcn_udot4(w2, w2, srr, false);
         srr = __builtin_amdgcn_udot4(w3, w3, srr, false);
       }
-      const double cost = zncc_from_moments(Sl, Sll, (long long)sr, (long long)srr, (long long)slr, N);
+      const double cost = zncc_from_moments(zl, (int)sr, (int)srr, (int)slr, N, rn, rn2);
       if (cost <= best) { best = cost; bestd = d; }  // :198 (lane scans increasing d)
     }
     // group argmin; ties -> larger disparity

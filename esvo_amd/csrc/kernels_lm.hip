@@ -409,6 +409,9 @@ __global__ void __launch_bounds__(LM_BLOCK, LM_WAVES) lm_refine_kernel(LmArgs a,
   int phase = 0;
   bool need_step = false;
   double xe = x;
+#ifdef LM_STATS
+  double dbg_xjac = __longlong_as_double(0x7ff8000000000000ll);
+#endif
   while (true) {
     if (need_step) {  // determine the LM parameter and the trial point (minimizeOneStep, inner loop head)
       const double pstep = lm_lmpar2(r, diag, qtf, delta, par);
@@ -429,6 +432,11 @@ __global__ void __launch_bounds__(LM_BLOCK, LM_WAVES) lm_refine_kernel(LmArgs a,
       par = 0.;
       iter = 1;
     } else if (phase == 1) {
+#ifdef LM_STATS
+      LM_COUNT(5, pr.c == 0 && active);
+      LM_COUNT(6, pr.c == 0 && active && x == dbg_xjac);
+      dbg_xjac = x;
+#endif
       // NumericalDiff<Forward>::df: the reference evaluates F(x) again (val1) and F(x + h); F is a
       // pure function and fvec already holds F(x) at the current x, so val1 == fvec bit for bit and
       // only F(x + h) is computed.  nfev still advances by 2 (it drives the maxfev test).

@@ -18,3 +18,4 @@ L.esvo_debug_lm_counters(out)
 o = list(out)
 print("matches", tot_m, "evals/group", o[0], "evals/wave", o[1], "loop iters/group", o[2], "loop iters/wave", o[3], "shortcuts", o[4])
 print("evals per match %.1f; wave evals per (match/4) %.1f; loop iters per eval (group) %.2f; per wave-eval %.2f" % (o[0]/tot_m, o[1]/(tot_m/4), o[2]/o[0], o[3]/o[1]))
+print("Jacobian evaluations", o[5], "of which at the same x as the previous one (same x):", o[6], "= %.1f %% of all evaluations" % (100.0*o[6]/o[0]))
