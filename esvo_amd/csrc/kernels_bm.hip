@@ -38,6 +38,8 @@ __device__ inline long long wave_sum_i64(long long v) {
 // The quotients by the constants n and n^2 and by sigl*sigr are IEEE quotients through fdiv.hpp's refined reciprocal:
 // every operand is 0 or lies in [1e-12, 1e10] by the integer bounds, far inside its window; sqrt_moderate likewise
 // (a zero variance is selected around it).
+typedef u32 u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+
 struct ZnccLeft {
   double sigl;  // sqrt(var_l) + 1e-6
   int Sl;
@@ -120,29 +122,54 @@ __global__ void __launch_bounds__(BM_BLOCK) bm_match_kernel(BmArgs a, DevParams 
   }
   if (ok) ok = !(x1 - hx < 1 || y1 - hy < 1 || x1 + hx >= W - 1 || y1 + hy >= H - 1);  // isValidPatch, :251-267
 
-  // ---- stage the left patch (bytes -> LDS), left moments, low-texture test (:101-109) ----
+  // ---- stage the left patch, left moments, low-texture test (:101-109) ----
+  // Lane py < 7 owns patch row py: five aligned dwords straight from the image, re-aligned to the row's first byte with
+  // v_alignbyte (as the candidates do below), written as one 16-byte row (15 pixels + a zero pad byte).  Sum, sum of
+  // squares and the number of zero pixels come from the packed words (dot4, and the exact zero-byte mask).
   int Sl = 0, Sll = 0;
   if (ok) {
-    for (int i = l; i < 28; i += G) ldsL[i] = 0u;  // zero incl. the pad bytes (same lane order as below: in-order LDS)
-  }
-  __syncthreads();
-  if (ok) {
     int cnt = 0, sl = 0, sll = 0;
-    unsigned char* lb = reinterpret_cast<unsigned char*>(ldsL);
-    for (int i = l; i < N; i += G) {
-      const int py = i / wx, px = i - py * wx;
-      const int v = a.tsL[(y1 - hy + py) * W + (x1 - hx + px)];
-      lb[py * 16 + px] = (unsigned char)v;
-      cnt += (v < 1);
-      sl += v;
-      sll += v * v;
+    if (l < wy) {
+      const u32* ts32 = reinterpret_cast<const u32*>(a.tsL);
+      const int n_dw = (W * H + 3) >> 2;
+      const int A = (y1 - hy + l) * W + (x1 - hx);
+      const int a0 = A >> 2;
+      const u32 sh = (u32)(A & 3);
+      u32 d[5];
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        int idx = a0 + j;
+        idx = idx >= n_dw ? n_dw - 1 : idx;  // only the bytes behind the 15 pixels can be clamped (A >= 0: isValidPatch)
+        d[j] = ts32[idx];
+      }
+      uint4 wv;
+      wv.x = __builtin_amdgcn_alignbyte(d[1], d[0], sh);
+      wv.y = __builtin_amdgcn_alignbyte(d[2], d[1], sh);
+      wv.z = __builtin_amdgcn_alignbyte(d[3], d[2], sh);
+      wv.w = __builtin_amdgcn_alignbyte(d[4], d[3], sh) & 0x00ffffffu;
+      *reinterpret_cast<uint4*>(ldsL + l * 4) = wv;
+      u32 usl = 0, usll = 0;
+      usl = __builtin_amdgcn_udot4(wv.x, 0x01010101u, usl, false);
+      usl = __builtin_amdgcn_udot4(wv.y, 0x01010101u, usl, false);
+      usl = __builtin_amdgcn_udot4(wv.z, 0x01010101u, usl, false);
+      usl = __builtin_amdgcn_udot4(wv.w, 0x01010101u, usl, false);
+      usll = __builtin_amdgcn_udot4(wv.x, wv.x, usll, false);
+      usll = __builtin_amdgcn_udot4(wv.y, wv.y, usll, false);
+      usll = __builtin_amdgcn_udot4(wv.z, wv.z, usll, false);
+      usll = __builtin_amdgcn_udot4(wv.w, wv.w, usll, false);
+      auto zero_bytes = [](u32 x) {  // bit 7 of every byte that is 0, exactly
+        return __popc(~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu));
+      };
+      cnt = zero_bytes(wv.x) + zero_bytes(wv.y) + zero_bytes(wv.z) + zero_bytes(wv.w | 0xff000000u);
+      sl = (int)usl;
+      sll = (int)usll;
     }
     cnt = grp_sum_i32<G>(cnt);
     Sl = grp_sum_i32<G>(sl);
     Sll = grp_sum_i32<G>(sll);  // <= 105 * 255^2 < 2^31
     if ((double)cnt > 0.95 * (double)N) ok = false;
   }
-  // ---- stage the right strip: aligned dwords straight from the (dword-padded) image ----
+  // ---- stage the right strip: aligned 16-byte pieces straight from the (dword-padded) image; RD is a multiple of 4 ----
   const int xs0 = x1 - p.dmax - hx;
   int o_row[wy];  // byte offset of column xs0 inside the first staged dword of each row
   if (ok) {
@@ -153,10 +180,23 @@ __global__ void __launch_bounds__(BM_BLOCK) bm_match_kernel(BmArgs a, DevParams 
       const int A = (y1 - hy + py) * W + xs0;
       const int a0 = A >> 2;  // arithmetic shift = floor
       o_row[py] = A - (a0 << 2);
-      for (int j = l; j < RD; j += G) {
-        int idx = a0 + j;
-        idx = idx < 0 ? 0 : (idx >= n_dw ? n_dw - 1 : idx);  // only bytes of invalid candidates can be clamped
-        ldsR[py * RD + j] = ts32[idx];
+      for (int j4 = l; j4 < (RD >> 2); j4 += G) {
+        const int idx = a0 + 4 * j4;
+        uint4 v;
+        if (__builtin_expect(idx >= 0 && idx + 3 < n_dw, 1)) {
+          const u32x4_a4 q = *reinterpret_cast<const u32x4_a4*>(ts32 + idx);  // dword-aligned 16-byte load
+          v = make_uint4(q.x, q.y, q.z, q.w);
+        } else {  // only bytes of invalid candidates can be clamped
+          u32 t[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            int i = idx + q;
+            i = i < 0 ? 0 : (i >= n_dw ? n_dw - 1 : i);
+            t[q] = ts32[i];
+          }
+          v = make_uint4(t[0], t[1], t[2], t[3]);
+        }
+        *reinterpret_cast<uint4*>(ldsR + py * RD + 4 * j4) = v;
       }
     }
   }
@@ -255,7 +295,7 @@ static void launch_bm_g(const BmArgs& a, const DevParams& p, int RD, hipStream_t
 void launch_bm_match(const BmArgs& a, const DevParams& p, hipStream_t s) {
   if (a.n == 0) return;
   const int nd = p.dmax - p.dmin + 1;
-  const int RD = ((nd + 2) >> 2) + 5;  // dwords staged per strip row
+  const int RD = ((((nd + 2) >> 2) + 5) + 3) & ~3;  // dwords staged per strip row (16-byte pieces)
   // lanes per event: the group size that wastes the fewest candidate slots (ties -> wider)
   int bestG = 64, bestSlots = 1 << 30;
   for (int G = 64; G >= 8; G >>= 1) {
