@@ -462,7 +462,10 @@ __global__ void __launch_bounds__(256) reg_view_kernel(const MapCell* __restrict
 // row, and a view row is fetched once per tile instead of once per element.
 // The counts decide at the end (neighbours > minN, close > minClose), so the fusion runs speculatively.
 #define REG_TX 64
-#define REG_TY 4
+#ifndef REG_TY
+#define REG_TY 4   // 8 and 16 rows per tile (fuller waves, fewer tiles) were measured: the stage gets shorter (1.05 -> 0.93 ms
+                   // overlapped) but the tick longer (1.75 -> 1.87 ms): longer per-wave chains beside the LM kernel
+#endif
 #define REG_MARGIN 1   // an element's believed (row, col) is at most one cell away from its true cell (Appendix A-7)
 #define REG_MAXW (REG_TX + 2 * 31 + 2 * REG_MARGIN)
 template <int RT>  // RegularizationRadius when it is one of the shipped values (5, 20): the tap loop unrolls; 0: any radius
@@ -557,7 +560,7 @@ __global__ void __launch_bounds__(REG_TX * REG_TY) reg_apply_kernel(const MapCel
   // ---- stream the view rows through LDS ----
   const double nan = __longlong_as_double(0x7ff8000000000000ll);
   double2 ld = make_double2(nan, nan);  // threads [0, sw): ab of staged column t; threads [128, 128 + sw): cd
-  const int sj = (t < 128) ? t : t - 128;
+  const int sj = (t < 128) ? t : (t < 256 ? t - 128 : REG_MAXW);  // waves 0-1 stage ab, 2-3 cd; further waves only carry elements
   auto fetch_row = [&](int y) {
     const int gy = sr0 + y, gx = sc0 + sj;
     ld = make_double2(nan, nan);
