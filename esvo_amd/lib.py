@@ -147,7 +147,7 @@ def selftest_division(n=1 << 28, seed=1):
     lib.esvo_selftest_division.restype = C.c_int
     rc = lib.esvo_selftest_division(int(n), int(seed), C.byref(bad))
     if rc != 0:
-        raise EsvoError(f"selftest failed ({rc}): {lib.esvo_last_error(None).decode()}")
+        raise EsvoError(f"selftest failed ({rc}): {lib.esvo_last_error(None).decode(errors='replace')}")
     return bad.value
 
 
@@ -159,7 +159,7 @@ class BagReader:
         b = C.c_void_p()
         rc = self.lib.esvo_bag_open(path.encode(), C.byref(b))
         if rc != 0:
-            raise EsvoError(f"esvo_bag_open failed ({rc}): {self.lib.esvo_last_error(None).decode()}")
+            raise EsvoError(f"esvo_bag_open failed ({rc}): {self.lib.esvo_last_error(None).decode(errors='replace')}")
         self.b = b
 
     def close(self):
@@ -177,8 +177,8 @@ class BagReader:
             if rc == 1:
                 return
             if rc != 0:
-                raise EsvoError(f"bag read failed ({rc}): {self.lib.esvo_bag_last_error(self.b).decode()}")
-            yield tp.value.decode(), int(st.value), C.string_at(msg.value, nb.value)
+                raise EsvoError(f"bag read failed ({rc}): {self.lib.esvo_bag_last_error(self.b).decode(errors='replace')}")
+            yield tp.value.decode(errors='replace'), int(st.value), C.string_at(msg.value, nb.value)
 
 
 def voxel_filter(xyz, leaf):
@@ -197,7 +197,7 @@ def comm_unique_id():
     buf = (C.c_uint8 * 128)()
     rc = load().esvo_comm_unique_id(buf)
     if rc != 0:
-        raise EsvoError(f"esvo_comm_unique_id failed ({rc}): {load().esvo_last_error(None).decode()}")
+        raise EsvoError(f"esvo_comm_unique_id failed ({rc}): {load().esvo_last_error(None).decode(errors='replace')}")
     return bytes(buf)
 
 
@@ -222,7 +222,7 @@ class Esvo:
         h = C.c_void_p()
         rc = self.lib.esvo_create(C.addressof(params), C.addressof(self._cl), C.addressof(self._cr), int(device), C.byref(h))
         if rc != 0:
-            raise EsvoError(f"esvo_create failed ({rc}): {self.lib.esvo_last_error(None).decode()}")
+            raise EsvoError(f"esvo_create failed ({rc}): {self.lib.esvo_last_error(None).decode(errors='replace')}")
         self.h = h
         self._poses = None
 
@@ -236,7 +236,7 @@ class Esvo:
 
     def _ck(self, rc):
         if rc != 0:
-            raise EsvoError(f"esvo call failed ({rc}): {self.lib.esvo_last_error(self.h).decode()}")
+            raise EsvoError(f"esvo call failed ({rc}): {self.lib.esvo_last_error(self.h).decode(errors='replace')}")
 
     # ---- lifecycle
     def reset(self):
