@@ -56,14 +56,21 @@ KERNEL_SYMBOLS = {"lm_refine": "lm_refine_kernel", "bm_match": "bm_match_kernel"
                   "regularize": "reg_apply_kernel", "ts_render": "ts_decay_kernel", "ts_scatter": "ts_scatter_kernel"}
 
 
-def make_workload(name, n_ticks, events_cap=0):
-    """(rig, stream, params, ticks) of a bench workload: n_ticks ticks of 10 ms after 60 ms of history"""
+R01_POINTS = {"dsec640x480": 180000, "upenn346x260": 24000, "hd1280x720": 185000}
+
+
+def make_workload(name, n_ticks, events_cap=0, r01_scene=False):
+    """(rig, stream, params, ticks) of a bench workload: n_ticks ticks of 10 ms after 60 ms of history.
+    r01_scene: round 1's thinning, swaying scene (only for like-for-like comparisons with round-1 figures)"""
     wl = WORKLOADS[name]
     rig = calib.dataset_rig(wl["rig"])
     duration = HIST_S + (n_ticks + 1) * TICK_S
-    traj = synth.Trajectory(speed=wl["speed"], sway=0.002, yaw=0.0005, t0_s=10.0)
-    stream = synth.make_stream(rig, wl["points"], duration, wl["rho"][0], wl["rho"][1], seed=20250418 + 3, speed=wl["speed"],
-                               stationary=True, traj=traj)
+    if r01_scene:
+        stream = synth.make_stream(rig, R01_POINTS[name], duration, wl["rho"][0], wl["rho"][1], seed=20250418 + 3, speed=wl["speed"])
+    else:
+        traj = synth.Trajectory(speed=wl["speed"], sway=0.002, yaw=0.0005, t0_s=10.0)
+        stream = synth.make_stream(rig, wl["points"], duration, wl["rho"][0], wl["rho"][1], seed=20250418 + 3, speed=wl["speed"],
+                                   stationary=True, traj=traj)
     ev_per_tick = int(len(stream.ev_left) / duration * TICK_S)
     cap = events_cap or int(ev_per_tick * 1.25) + 1024
     p, _ = params.make_params(params.PRESETS[wl["preset"]], rig, throughput_events=cap,
@@ -176,6 +183,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary operating points (346x260, reference-faithful ticks)")
     ap.add_argument("--timed-ingest", action="store_true",
                     help="stage each tick's events inside the timed loop (PCIe-inclusive rate; the default stages the whole stream first)")
+    ap.add_argument("--r01-scene", action="store_true", help="round 1's thinning scene (like-for-like comparisons only)")
     ap.add_argument("--strong", action="store_true", help="N GPUs share K ticks in total instead of mapping K ticks each")
     ap.add_argument("--check", action="store_true",
                     help="replay up to the first timed tick on a fresh handle and compare its DepthMap with the CPU oracle's (SHA-1)")
@@ -207,7 +215,7 @@ def main():
     # weak scaling: K timed (and Wm warm-up) ticks PER GPU in the tick-interleaved mode; the band mode splits every tick
     per_gpu = world if (world > 1 and shard_mode == "tick" and not args.strong) else 1
     n_ticks = (K + Wm) * per_gpu
-    rig, stream, p, ticks = make_workload(args.workload, n_ticks, args.events_per_tick)
+    rig, stream, p, ticks = make_workload(args.workload, n_ticks, args.events_per_tick, r01_scene=args.r01_scene)
     duration = HIST_S + (n_ticks + 1) * TICK_S
     nd = p.bm_max_disparity - p.bm_min_disparity + 1
 
@@ -431,7 +439,8 @@ def check_against_oracle(rig, stream, p, ticks, n_first, device):
 def other_operating_points(device):
     """Secondary figures of the same JSON line: the 346x260 stream of north_star in throughput mode and the two
     reference-faithful tick sizes (the mode the ROS node runs: PROCESS_EVENT_NUM 10000 on DSEC, 1000 on upenn), each as
-    the time of one tick completed on its own (latency: nothing is in flight beside it)."""
+    the time of one tick completed on its own (latency: nothing is in flight beside it) and as the sustained time per tick
+    with two ticks in flight."""
     out = {}
 
     def throughput(name, n):
@@ -463,7 +472,19 @@ def other_operating_points(device):
         dt = time.perf_counter() - t0
         s = dev.stats()
         dev.close()
-        return {"ms_per_tick": dt / n * 1e3, "events_per_tick": int(s.last_events_in), "points_per_tick": int(s.last_points)}
+        # the same ticks with two in flight (no synchronisation inside the loop): the sustained rate of small ticks
+        dev = lib.Esvo(p, rig, device=device)
+        dev.ts_push_events(0, stream.ev_left)
+        dev.ts_push_events(1, stream.ev_right)
+        run_single(dev, stream, ticks, 0, 6)
+        dev.synchronize()
+        t0 = time.perf_counter()
+        run_single(dev, stream, ticks, 6, n + 6)
+        dev.synchronize()
+        dp = time.perf_counter() - t0
+        dev.close()
+        return {"ms_per_tick": dt / n * 1e3, "ms_per_tick_pipelined": dp / n * 1e3, "events_per_tick": int(s.last_events_in),
+                "points_per_tick": int(s.last_points)}
 
     out["upenn346x260_throughput"] = throughput("upenn346x260", 20)
     out["dsec640x480_reference_faithful_10000"] = latency("dsec640x480", 10000, 20)
