@@ -82,17 +82,75 @@ __device__ inline double grp_min(double v) {
   v = fmin(v, dpp_f64<DPP_MIRROR>(v));
   return v;
 }
-__device__ inline double col_sum(const double t[LM_ROWS]) {
-  double a = t[0];
-#pragma unroll
-  for (int y = 1; y < LM_ROWS; ++y) a = a + t[y];
-  return a;
+// ---- the two lane layouts ---------------------------------------------------------------------------
+// NARROW (throughput): a match is a 16-lane group, lane = patch column, 7 rows per lane, four matches per wave.
+// WIDE (latency): a match is a whole wave: lane = (row group, column); the four 16-lane DPP rows of the wave hold patch rows
+//   {0,1}, {2,3}, {4,5}, {6}.  One match per wave: no lockstep between matches, and 2 instead of 7 rows of dependent
+//   f64 work per lane -- for launches that cannot fill the chip anyway (a reference-faithful tick: a few hundred to a few
+//   thousand matches on 2048 wave slots) the launch lasts as long as its slowest match, and that match is ~2x shorter.
+// Both reduce in the SAME canonical order: per column the sequential sum over rows 0..6, then the xor butterfly over the
+// 16 columns.  In the wide layout the column sum travels through the row groups (rows {0,1} -> +{2,3} -> +{4,5} -> +{6}),
+// one v_permlane{16,32}_swap per hop: the groups sit in DPP rows 0, 1, 3, 2 of the wave so that every hop is one swap.
+template <bool WIDE>
+struct Lay {
+  static constexpr int RL = WIDE ? 2 : LM_ROWS;  // patch rows per lane
+};
+// value of the same column in the previous row group (wide layout); hop k leads into group k
+__device__ inline double hop_f64(double v, int k) {
+  const u32 lo = (u32)__double2loint(v), hi = (u32)__double2hiint(v);
+  u32 l2, h2;
+  if (k == 2) {        // DPP row 1 -> row 3
+    l2 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false)[0];
+    h2 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false)[0];
+  } else if (k == 1) {  // DPP row 0 -> row 1
+    l2 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false)[0];
+    h2 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false)[0];
+  } else {             // DPP row 3 -> row 2
+    l2 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false)[1];
+    h2 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false)[1];
+  }
+  return __hiloint2double((int)h2, (int)l2);
 }
-__device__ inline double patch_dot(const double a[LM_ROWS], const double b[LM_ROWS]) {
-  double t[LM_ROWS];
+#define LM_WIDE_LAST_ROW_LANE 32  // first lane of the DPP row that holds row group 3 (the end of the column-sum chain)
+__device__ inline double bcast_f64(double v, int lane) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+// canonical sum over the patch of the per-lane values t[]; the result is in every lane of the match
+template <bool WIDE>
+__device__ inline double patch_sum(const double* t, int rg) {
+  if constexpr (!WIDE) {
+    double a = t[0];
 #pragma unroll
-  for (int y = 0; y < LM_ROWS; ++y) t[y] = a[y] * b[y];
-  return grp_sum(col_sum(t));
+    for (int y = 1; y < LM_ROWS; ++y) a = a + t[y];
+    return grp_sum(a);
+  } else {
+    double a = t[0] + t[1];                    // rows 0, 1                      (meaningful in group 0)
+    a = (hop_f64(a, 1) + t[0]) + t[1];          // + rows 2, 3                    (group 1)
+    a = (hop_f64(a, 2) + t[0]) + t[1];          // + rows 4, 5                    (group 2)
+    a = hop_f64(a, 3) + t[0];                   // + row 6                        (group 3)
+    (void)rg;
+    return bcast_f64(grp_sum(a), LM_WIDE_LAST_ROW_LANE);
+  }
+}
+template <bool WIDE>
+__device__ inline int match_sum_int(int v) {
+  v = grp_sum_int(v);
+  if constexpr (WIDE)
+    v = (__builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16)) + (__builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48));
+  return v;
+}
+template <bool WIDE>
+__device__ inline double match_min(double v) {
+  v = grp_min(v);
+  if constexpr (WIDE) v = fmin(fmin(bcast_f64(v, 0), bcast_f64(v, 16)), fmin(bcast_f64(v, 32), bcast_f64(v, 48)));
+  return v;
+}
+template <bool WIDE>
+__device__ inline double patch_dot(const double* a, const double* b, int rg) {
+  double t[Lay<WIDE>::RL];
+#pragma unroll
+  for (int y = 0; y < Lay<WIDE>::RL; ++y) t[y] = a[y] * b[y];
+  return patch_sum<WIDE>(t, rg);
 }
 
 __device__ inline double in_vgpr(double x) {
@@ -105,7 +163,8 @@ struct LmProblem {
   double T[12];            // T_left_virtual (3x4)
   const uint8_t* tsL;
   const uint8_t* tsR;
-  int c;                   // lane within the group
+  int c;                   // patch column of the lane
+  int rg;                  // row group of the lane (wide layout; 0 in the narrow one)
 #ifdef LM_STATS
   u32 dbg_slot;
 #endif
@@ -130,21 +189,31 @@ __device__ inline bool interp_geom(const DevParams& p, double lx, double ly, int
   if (uly + LM_ROWS >= p.H || ulx + LM_COLS >= p.W) return false;
   return true;
 }
-__device__ inline void interp_column(const uint8_t* __restrict__ img, int W, int ulx, int uly, int c, double q1, double q2,
-                                     double q3, double q4, double tau[LM_ROWS]) {
-  double R[LM_ROWS + 1];
+template <bool WIDE>
+__device__ inline void interp_column(const uint8_t* __restrict__ img, int W, int ulx, int uly, int c, int rg, double q1, double q2,
+                                     double q3, double q4, double* tau) {
+  constexpr int RL = Lay<WIDE>::RL;
+  double R[RL + 1];
 #pragma unroll
-  for (int y = 0; y <= LM_ROWS; ++y) {
-    const int s0 = img[(uly + y) * W + ulx + c];
+  for (int y = 0; y <= RL; ++y) {
+    int row = (WIDE ? 2 * rg : 0) + y;
+    if (WIDE) row = row > LM_ROWS ? LM_ROWS : row;  // group 3 owns row 6 only: its third source row is not used
+    const int s0 = img[(uly + row) * W + ulx + c];
     const int s1 = dpp_i32<DPP_SHL1>(s0);  // column c+1 from the neighbour lane
     R[y] = q1 * (double)s0 + q2 * (double)s1;
   }
 #pragma unroll
-  for (int y = 0; y < LM_ROWS; ++y) tau[y] = q3 * R[y] + q4 * R[y + 1];
+  for (int y = 0; y < RL; ++y) tau[y] = q3 * R[y] + q4 * R[y + 1];
 }
 
 // DepthProblem::operator(), Tdist norm.  fv[y] = residual of patch element (y, c); lane 15 -> 0.
-__device__ void lm_eval(const DevParams& p, const LmProblem& pr, double x, double fv[LM_ROWS]) {
+template <bool WIDE>
+__device__ void lm_eval(const DevParams& p, const LmProblem& pr, double x, double* fv) {
+  constexpr int RL = Lay<WIDE>::RL;
+  // element (y, c) of the patch exists: column 15 only feeds its neighbour; row group 3 of the wide layout owns one row
+  bool el[RL];
+#pragma unroll
+  for (int y = 0; y < RL; ++y) el[y] = pr.c < LM_COLS && (!WIDE || 2 * pr.rg + y < LM_ROWS);
   const double nu = in_vgpr(p.td_nu);  // VGPR: otherwise re-loaded from the kernel arguments in every t-scale iteration
   LM_COUNT(0, pr.c == 0);                                   // evaluations, per group
   LM_SLOT(0, pr.dbg_slot, pr.c == 0, 1u);
@@ -173,29 +242,29 @@ __device__ void lm_eval(const DevParams& p, const LmProblem& pr, double x, doubl
     const double weight = (nu + 1) / (nu + q * q);
     const double f = sqrt(weight) * residual;
 #pragma unroll
-    for (int y = 0; y < LM_ROWS; ++y) fv[y] = (pr.c < LM_COLS) ? f : 0.0;
+    for (int y = 0; y < RL; ++y) fv[y] = el[y] ? f : 0.0;
     return;
   }
-  double tau1[LM_ROWS], tau2[LM_ROWS], r[LM_ROWS], r2[LM_ROWS];
-  interp_column(pr.tsL, p.W, ulx1, uly1, pr.c, a1, a2, a3, a4, tau1);
-  interp_column(pr.tsR, p.W, ulx2, uly2, pr.c, b1, b2, b3, b4, tau2);
+  double tau1[RL], tau2[RL], r[RL], r2[RL];
+  interp_column<WIDE>(pr.tsL, p.W, ulx1, uly1, pr.c, pr.rg, a1, a2, a3, a4, tau1);
+  interp_column<WIDE>(pr.tsR, p.W, ulx2, uly2, pr.c, pr.rg, b1, b2, b3, b4, tau2);
   int knz = 0;
   double minabs = 1e300, r2max = 0;
-  double r2n[LM_ROWS];  // r^2 (nu + 1): the numerators of the t-scale update
+  double r2n[RL];  // r^2 (nu + 1): the numerators of the t-scale update
 #pragma unroll
-  for (int y = 0; y < LM_ROWS; ++y) {
-    r[y] = (pr.c < LM_COLS) ? (tau1[y] - tau2[y]) : 0.0;
+  for (int y = 0; y < RL; ++y) {
+    r[y] = el[y] ? (tau1[y] - tau2[y]) : 0.0;
     r2[y] = r[y] * r[y];
     r2n[y] = r2[y] * (nu + 1);
     r2max = fmax(r2max, r2[y]);
     if (r[y] != 0) { knz++; minabs = fmin(minabs, fabs(r[y])); }
   }
   const int knz_lane = knz;
-  knz = grp_sum_int(knz);
+  knz = match_sum_int<WIDE>(knz);
 #ifdef LM_STATS
   if (pr.c == 0 && pr.dbg_slot < (1u << 18) && g_lm_slot[0][pr.dbg_slot] == 1u) g_lm_slot[2][pr.dbg_slot] = 1000u * (u32)knz;
 #endif
-  minabs = grp_min(minabs);
+  minabs = match_min<WIDE>(minabs);
   const double scale2_0 = in_vgpr(p.td_scale2);
   double s2;
   const int e_r2max = (__double2hiint(r2max) >> 20) & 0x7ff;
@@ -208,7 +277,7 @@ __device__ void lm_eval(const DevParams& p, const LmProblem& pr, double x, doubl
   if (!lane_ok) {
     bool r2_ok = true;
 #pragma unroll
-    for (int y = 0; y < LM_ROWS; ++y) r2_ok = r2_ok && fdiv_ok(r2[y]);
+    for (int y = 0; y < RL; ++y) r2_ok = r2_ok && fdiv_ok(r2[y]);
     lane_ok = r2_ok && fdiv_ok(nu) && nu > 0 && fdiv_ok(r2max * (nu + 1));
   }
   const int N = LM_ROWS * LM_COLS;
@@ -229,7 +298,7 @@ __device__ void lm_eval(const DevParams& p, const LmProblem& pr, double x, doubl
     // s1 stays in [2^-100, 2^100], every operand of the iteration is inside fdiv.hpp's window by construction
     // (r^2/s1 <= 2^198, t >= 2^-299, 2^-299 <= sum <= 2^110, |s2 - s1| is 0 or >= ulp(2^-100)), so the iteration runs
     // without a single per-operand range test or branch: one exponent test on s1 decides, uniformly for the group.
-    const bool tight = grp_sum_int((r2_tight && nu_mid) ? 0 : 1) == 0;
+    const bool tight = match_sum_int<WIDE>((r2_tight && nu_mid) ? 0 : 1) == 0;
     bool done = false;
 #ifndef LM_PLAIN_DIV
     if (tight) {
@@ -242,15 +311,15 @@ __device__ void lm_eval(const DevParams& p, const LmProblem& pr, double x, doubl
         Recip rs1;
         rs1.b = s1;
         rs1.y = recip_refined(s1);
-        double t[LM_ROWS];
+        double t[RL];
 #pragma unroll
-        for (int y = 0; y < LM_ROWS; ++y) {  // r == 0 gives +0 / nu = +0 as the reference's skip does
+        for (int y = 0; y < RL; ++y) {  // r == 0 gives +0 / nu = +0 as the reference's skip does
           Recip rd;
           rd.b = nu + div_fast(r2[y], rs1);
           rd.y = recip_refined(rd.b);
           t[y] = div_fast(r2n[y], rd);
         }
-        const double sum = grp_sum(col_sum(t));
+        const double sum = patch_sum<WIDE>(t, pr.rg);
         if (sum == 0) { s2 = scale2_0; done = true; break; }
         s2 = div_fast(sum, rN);
         const double rel = div_fast(fabs(s2 - s1), rs1);
@@ -264,7 +333,7 @@ __device__ void lm_eval(const DevParams& p, const LmProblem& pr, double x, doubl
       LM_SLOT(1, pr.dbg_slot, pr.c == 0, 1u);
       LM_SLOT(2, pr.dbg_slot, pr.c == 0 && g_lm_slot[0][pr.dbg_slot < (1u << 18) ? pr.dbg_slot : 0] == 1u, 1u);
       LM_COUNT(3, __lane_id() == __ffsll(__ballot(1)) - 1);
-      double t[LM_ROWS];
+      double t[RL];
       const Recip rs1 = make_recip(s1);
       const int e_s1 = (__double2hiint(s1) >> 20) & 0x7ff;
 #ifdef LM_PLAIN_DIV
@@ -273,13 +342,13 @@ __device__ void lm_eval(const DevParams& p, const LmProblem& pr, double x, doubl
       if (lane_ok && rs1.fast && s1 > 0 && e_r2max - e_s1 < 300) {
 #endif
 #pragma unroll
-        for (int y = 0; y < LM_ROWS; ++y)
+        for (int y = 0; y < RL; ++y)
           t[y] = div_fast(r2n[y], make_recip(nu + div_fast(r2[y], rs1)));
       } else {
 #pragma unroll
-        for (int y = 0; y < LM_ROWS; ++y) t[y] = (r[y] != 0) ? r2[y] * (nu + 1) / (nu + r2[y] / s1) : 0.0;
+        for (int y = 0; y < RL; ++y) t[y] = (r[y] != 0) ? r2[y] * (nu + 1) / (nu + r2[y] / s1) : 0.0;
       }
-      const double sum = grp_sum(col_sum(t));
+      const double sum = patch_sum<WIDE>(t, pr.rg);
       if (sum == 0) { s2 = scale2_0; break; }
       s2 = div_by(sum, rN);
       const double rel = div_by(fabs(s2 - s1), rs1);
@@ -294,7 +363,7 @@ __device__ void lm_eval(const DevParams& p, const LmProblem& pr, double x, doubl
   const bool fast2 = lane_ok && rs2.fast && s2 > 0 && e_r2max - ((__double2hiint(s2) >> 20) & 0x7ff) < 300;
 #endif
 #pragma unroll
-  for (int y = 0; y < LM_ROWS; ++y) {
+  for (int y = 0; y < RL; ++y) {
     // fast2 bounds r^2/s2 below 2^301, so the weight lies in (2^-300, (nu+1)/nu]: sqrt_moderate's range (fdiv.hpp)
     fv[y] = fast2 ? sqrt_moderate(div_fast(nu + 1, make_recip(nu + div_fast(r2[y], rs2)))) * r[y]
                   : sqrt((nu + 1) / (nu + r2[y] / s2)) * r[y];
@@ -353,19 +422,27 @@ __device__ inline double lm_lmpar2(double r, double diag, double qtf, double del
 #define LM_BLOCK 64   // threads per workgroup (no LDS, no barriers).  One wave per workgroup: a finished wave's slot is
                       // refilled at once instead of waiting for its three siblings -- 4 % per tick against 256
 #endif
-// Four matches per wave also for launches that cannot fill the chip: one match per wave (rows 1..3 idle, no lockstep
-// between matches) was measured on reference-faithful ticks and is not faster (upenn 1000 events: 277 vs 250-340 us,
-// DSEC 10 000 events: 447 vs 414 us) -- such a launch lasts as long as its slowest MATCH's own dependent chain.
+// (One match per wave in the NARROW layout -- rows 1..3 idle -- was measured on reference-faithful ticks and is not faster
+// than four: 277 vs 250-340 us, 447 vs 414 us.  A small launch lasts as long as its slowest MATCH's own dependent chain;
+// the wide layout shortens that chain.)
+#ifndef LM_WIDE_MAX
+#define LM_WIDE_MAX 12288u  // launches bounded by this many matches (= events handed to block matching) use the wide layout
+#endif
+template <bool WIDE>
 __global__ void __launch_bounds__(LM_BLOCK, LM_WAVES) lm_refine_kernel(LmArgs a, DevParams p, u32* n_solved) {
-  const u32 s = (blockIdx.x * LM_BLOCK + threadIdx.x) >> 4;  // solver slot (thread-stride order)
+  constexpr int RL = Lay<WIDE>::RL;
+  const u32 s = WIDE ? blockIdx.x : (blockIdx.x * LM_BLOCK + threadIdx.x) >> 4;  // solver slot (thread-stride order)
   const int c = threadIdx.x & 15;
+  const int drow = (threadIdx.x >> 4) & 3;
+  const int rg = WIDE ? (drow ^ (drow >> 1)) : 0;  // row groups 0,1,2,3 sit in DPP rows 0,1,3,2 (patch_sum)
+  const bool lead = WIDE ? threadIdx.x == 0 : c == 0;
   u32 M = *a.n_matches;
   if (M > a.max_matches) M = a.max_matches;
   bool active = s < M;
   // The grid is sized for the worst case (every event matched): waves without any match leave at once.
   // Inactive groups of a partially filled wave run the (cheap, failing) code path below with a dummy
   // problem so that the wave's control flow stays simple; they write nothing.
-  if (!active && c == 0 && s < a.max_matches) a.out_flags[s] = 0u;  // every slot of the launch gets its flag: no memset
+  if (!active && lead && s < a.max_matches) a.out_flags[s] = 0u;  // every slot of the launch gets its flag: no memset
   if (__ballot(active) == 0) return;
   u32 j = 0;
   esvo_match_t m;
@@ -380,6 +457,7 @@ __global__ void __launch_bounds__(LM_BLOCK, LM_WAVES) lm_refine_kernel(LmArgs a,
   pr.tsL = a.tsL;
   pr.tsR = a.tsR;
   pr.c = c;
+  pr.rg = rg;
 #ifdef LM_STATS
   pr.dbg_slot = active ? s : 0xffffffffu;
 #endif
@@ -402,7 +480,7 @@ __global__ void __launch_bounds__(LM_BLOCK, LM_WAVES) lm_refine_kernel(LmArgs a,
   // minimizeInit/minimizeOneStep driven by the loop of DepthProblemSolver.cpp:161-188; a single
   // inlined evaluator keeps the kernel ~3x smaller (I-cache, register pressure).
   double x = m.inv_depth;
-  double fvec[LM_ROWS], out[LM_ROWS];
+  double fvec[RL], out[RL];
   double fnorm = 0., par = 0., diag = 0., xnorm = 0., delta = 0., r = 0., qtf = 0., gnorm = 0.;
   double h = 0., xnew = 0., wa1 = 0., pnorm = 0.;
   int nfev = 1, iter = 1, iteration = 0, optState = 0;
@@ -422,13 +500,13 @@ __global__ void __launch_bounds__(LM_BLOCK, LM_WAVES) lm_refine_kernel(LmArgs a,
       xe = xnew;
       need_step = false;
     }
-    lm_eval(p, pr, xe, out);
+    lm_eval<WIDE>(p, pr, xe, out);
     int status = -1;
     bool outer_tail = false;
     if (phase == 0) {  // minimizeInit
 #pragma unroll
-      for (int y = 0; y < LM_ROWS; ++y) fvec[y] = out[y];
-      fnorm = sqrt(patch_dot(fvec, fvec));
+      for (int y = 0; y < RL; ++y) fvec[y] = out[y];
+      fnorm = sqrt(patch_dot<WIDE>(fvec, fvec, rg));
       par = 0.;
       iter = 1;
     } else if (phase == 1) {
@@ -440,14 +518,14 @@ __global__ void __launch_bounds__(LM_BLOCK, LM_WAVES) lm_refine_kernel(LmArgs a,
       // NumericalDiff<Forward>::df: the reference evaluates F(x) again (val1) and F(x + h); F is a
       // pure function and fvec already holds F(x) at the current x, so val1 == fvec bit for bit and
       // only F(x + h) is computed.  nfev still advances by 2 (it drives the maxfev test).
-      double fjac[LM_ROWS];
+      double fjac[RL];
 #pragma unroll
-      for (int y = 0; y < LM_ROWS; ++y) fjac[y] = (out[y] - fvec[y]) / h;
+      for (int y = 0; y < RL; ++y) fjac[y] = (out[y] - fvec[y]) / h;
       nfev += 2;
-      const double wa2n = sqrt(patch_dot(fjac, fjac));
-      const double jtf = patch_dot(fjac, fvec);
+      const double wa2n = sqrt(patch_dot<WIDE>(fjac, fjac, rg));
+      const double jtf = patch_dot<WIDE>(fjac, fvec, rg);
       r = wa2n;
-      const double fvec0 = __shfl(fvec[0], 0, 16);
+      const double fvec0 = WIDE ? bcast_f64(fvec[0], 0) : __shfl(fvec[0], 0, 16);  // element (0, 0) of the patch
       qtf = (r != 0.) ? jtf / r : fvec0;
       if (iter == 1) {
         diag = (wa2n == 0.) ? 1. : wa2n;
@@ -468,7 +546,7 @@ __global__ void __launch_bounds__(LM_BLOCK, LM_WAVES) lm_refine_kernel(LmArgs a,
       }
     } else {  // phase 2: trust-region trial at xnew
       ++nfev;
-      const double fnorm1 = sqrt(patch_dot(out, out));
+      const double fnorm1 = sqrt(patch_dot<WIDE>(out, out, rg));
       double actred = -1.;
       if (0.1 * fnorm1 < fnorm) actred = 1. - (fnorm1 / fnorm) * (fnorm1 / fnorm);
       const double wa3 = r * wa1;
@@ -493,7 +571,7 @@ __global__ void __launch_bounds__(LM_BLOCK, LM_WAVES) lm_refine_kernel(LmArgs a,
       if (ratio >= 1e-4) {
         x = xnew;
 #pragma unroll
-        for (int y = 0; y < LM_ROWS; ++y) fvec[y] = out[y];
+        for (int y = 0; y < RL; ++y) fvec[y] = out[y];
         xnorm = fabs(diag * x);
         fnorm = fnorm1;
         ++iter;
@@ -527,7 +605,7 @@ __global__ void __launch_bounds__(LM_BLOCK, LM_WAVES) lm_refine_kernel(LmArgs a,
     }
   }
 
-  if (!active || c != 0) return;
+  if (!active || !lead) return;
   const bool solved = !(x <= 0.001);  // DepthProblemSolver.cpp:192
   bool keep = solved;
   if (solved) {
@@ -566,9 +644,14 @@ extern "C" void esvo_debug_lm_slots(unsigned int* out, int clear) {  // out[3][1
 #endif
 void launch_lm_refine(const LmArgs& a, const DevParams& p, u32* n_solved, hipStream_t s) {
   if (a.max_matches == 0) return;
+  // the match count lives on the device; the layout is chosen by the launch's bound (the events handed to block matching)
+  if (a.max_matches <= LM_WIDE_MAX && LM_BLOCK == 64) {
+    hipLaunchKernelGGL(lm_refine_kernel<true>, dim3(a.max_matches), dim3(64), 0, s, a, p, n_solved);
+    return;
+  }
   const u32 groups_per_block = LM_BLOCK / 16;
   const u32 blocks = (a.max_matches + groups_per_block - 1) / groups_per_block;
-  hipLaunchKernelGGL(lm_refine_kernel, dim3(blocks), dim3(LM_BLOCK), 0, s, a, p, n_solved);
+  hipLaunchKernelGGL(lm_refine_kernel<false>, dim3(blocks), dim3(LM_BLOCK), 0, s, a, p, n_solved);
 }
 
 // stable compaction of the solver slots into a frame buffer
