@@ -425,11 +425,14 @@ __device__ inline double lm_lmpar2(double r, double diag, double qtf, double del
 // (One match per wave in the NARROW layout -- rows 1..3 idle -- was measured on reference-faithful ticks and is not faster
 // than four: 277 vs 250-340 us, 447 vs 414 us.  A small launch lasts as long as its slowest MATCH's own dependent chain;
 // the wide layout shortens that chain.)
+#ifndef LM_WIDE_WAVES
+#define LM_WIDE_WAVES 4  // the wide layout needs 127 VGPRs: four waves per SIMD, 4096 matches resident
+#endif
 #ifndef LM_WIDE_MAX
-#define LM_WIDE_MAX 12288u  // launches bounded by this many matches (= events handed to block matching) use the wide layout
+#define LM_WIDE_MAX 40000u  // launches bounded by this many matches (= events handed to block matching) use the wide layout
 #endif
 template <bool WIDE>
-__global__ void __launch_bounds__(LM_BLOCK, LM_WAVES) lm_refine_kernel(LmArgs a, DevParams p, u32* n_solved) {
+__global__ void __launch_bounds__(LM_BLOCK, WIDE ? LM_WIDE_WAVES : LM_WAVES) lm_refine_kernel(LmArgs a, DevParams p, u32* n_solved) {
   constexpr int RL = Lay<WIDE>::RL;
   const u32 s = WIDE ? blockIdx.x : (blockIdx.x * LM_BLOCK + threadIdx.x) >> 4;  // solver slot (thread-stride order)
   const int c = threadIdx.x & 15;
