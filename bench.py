@@ -164,10 +164,7 @@ def map_sha1(mp_):
 def run_single(dev, stream, ticks, first, last, sync_each=False):
     for k in range(first, last):
         t, stamps, poses, T = ticks[k]
-        dev.ts_render(0, t, download=False)
-        dev.ts_render(1, t, download=False)
-        dev.set_observation(t, None, None, T)
-        dev.tick(t, stamps, poses)
+        dev.tick_resident(t, T, stamps, poses)   # = ts_render x2 + set_observation + tick
         if sync_each:
             dev.synchronize()
 
@@ -256,10 +253,13 @@ def main():
         if args.timed_ingest:
             runner.ts_push_events(0, chunks[k][0])
             runner.ts_push_events(1, chunks[k][1])
-        runner.ts_render(0, t, download=False)
-        runner.ts_render(1, t, download=False)
-        runner.set_observation(t, None, None, T)
-        runner.tick(t, stamps, poses)
+        if hasattr(runner, "tick_resident"):
+            runner.tick_resident(t, T, stamps, poses)   # = ts_render x2 + set_observation + tick, one call
+        else:                                            # the multi-GPU drivers see the four calls
+            runner.ts_render(0, t, download=False)
+            runner.ts_render(1, t, download=False)
+            runner.set_observation(t, None, None, T)
+            runner.tick(t, stamps, poses)
 
     n_warm, n_all = Wm * per_gpu, (Wm + K) * per_gpu
     runner = None

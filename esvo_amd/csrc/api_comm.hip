@@ -389,21 +389,26 @@ int esvo_comm_newest_map(esvo_handle h, esvo_depth_point_t* out, size_t cap, siz
   const size_t count = (size_t)heads[2 * best];
   if (tick_index) *tick_index = (long long)heads[2 * best + 1] - 1;
   *n = count;
-  if (!out || !count) return ESVO_OK;
-  if (cap < count) FAIL(ESVO_ERR_CAPACITY, "output capacity too small");
+  if (!count) return ESVO_OK;  // the same on every rank
+  // the second all-gather runs on every rank whatever its `out` / `cap` (a rank that skipped it would hang the others)
   u64 *d_s = nullptr, *d_r = nullptr;
   const size_t bw = std::max<size_t>(max_n * W, 1);
-  HIPCHK(hipMalloc(reinterpret_cast<void**>(&d_s), bw * 8));
-  HIPCHK(hipMalloc(reinterpret_cast<void**>(&d_r), bw * 8 * c->world));
-  if (!mine.empty()) HIPCHK(hipMemcpyAsync(d_s, mine.data(), mine.size() * sizeof(esvo_depth_point_t), hipMemcpyHostToDevice, h->stream));
-  rc = comm_all_gather(h, d_s, d_r, bw * 8);
-  if (!rc) {
-    hipError_t e = hipMemcpyAsync(out, d_r + (size_t)best * bw, count * sizeof(esvo_depth_point_t), hipMemcpyDeviceToHost, h->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    if (e != hipSuccess) { h->err = "copy of the gathered map failed"; rc = ESVO_ERR_HIP; }
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_s), bw * 8);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_r), bw * 8 * c->world);
+  if (e == hipSuccess && !mine.empty())
+    e = hipMemcpyAsync(d_s, mine.data(), mine.size() * sizeof(esvo_depth_point_t), hipMemcpyHostToDevice, h->stream);
+  if (e != hipSuccess) { h->err = "staging of the map exchange failed"; rc = ESVO_ERR_HIP; }
+  if (!rc) rc = comm_all_gather(h, d_s, d_r, bw * 8);
+  if (!rc && out) {
+    if (cap < count) { h->err = "output capacity too small"; rc = ESVO_ERR_CAPACITY; }
+    else {
+      e = hipMemcpyAsync(out, d_r + (size_t)best * bw, count * sizeof(esvo_depth_point_t), hipMemcpyDeviceToHost, h->stream);
+      if (e != hipSuccess) { h->err = "copy of the gathered map failed"; rc = ESVO_ERR_HIP; }
+    }
   }
-  hipFree(d_s);
-  hipFree(d_r);
+  if (hipStreamSynchronize(h->stream) != hipSuccess && !rc) { h->err = "map exchange failed"; rc = ESVO_ERR_HIP; }
+  if (d_s) hipFree(d_s);
+  if (d_r) hipFree(d_r);
   return rc;
 }
 

@@ -665,6 +665,15 @@ int finalize_tick_stats(esvo_context* h) {
 }
 }  // namespace esvo_host
 
+extern "C" int esvo_map_tick_resident(esvo_handle h, uint64_t t_ns, const double T_world_cam[16], const uint64_t* pose_t_ns,
+                                      const double* pose_T, size_t m) {
+  int rc = esvo_ts_render(h, 0, t_ns, nullptr);
+  if (!rc) rc = esvo_ts_render(h, 1, t_ns, nullptr);
+  if (!rc) rc = esvo_map_set_observation(h, t_ns, nullptr, nullptr, T_world_cam);
+  if (!rc) rc = esvo_map_tick(h, t_ns, pose_t_ns, pose_T, m);
+  return rc;
+}
+
 extern "C" int esvo_map_tick(esvo_handle h, uint64_t t_ns, const uint64_t* pose_t_ns, const double* pose_T, size_t m) {
   if (!h || !pose_t_ns || !pose_T) return ESVO_ERR_INVALID_ARG;
   if (!h->obs_set) FAIL(ESVO_ERR_STATE, "esvo_map_set_observation has not been called");

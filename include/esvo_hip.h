@@ -290,6 +290,11 @@ int esvo_map_init_sgm(esvo_handle h, const uint8_t* ts_left, const uint8_t* ts_r
  * (esvo_Mapping.cpp:261-431) on the staged left events and the current observation. */
 int esvo_map_tick(esvo_handle h, uint64_t t_ns, const uint64_t* pose_t_ns, const double* pose_T,
                   size_t m);
+/* One call for a node that hosts the Time Surfaces and the mapper on the same handle: esvo_ts_render of both cameras at
+ * t_ns (device-resident, no download), esvo_map_set_observation on them with the pose T_world_cam, esvo_map_tick.  Same
+ * results as the four calls; a reference-faithful tick is short enough for their host overhead to show. */
+int esvo_map_tick_resident(esvo_handle h, uint64_t t_ns, const double T_world_cam[16], const uint64_t* pose_t_ns,
+                           const double* pose_T, size_t m);
 
 /* Device-resident variants of the stage-wise calls (no host copies of points): the front stage of a tick on the
  * events staged by esvo_ts_push_events (selection + match + refine + cull; the frame stays on the device,

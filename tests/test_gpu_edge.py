@@ -336,3 +336,26 @@ def test_sparse_stretch_under_const_points_does_not_exhaust_the_window(upenn_rig
     assert dev.fuse() == m.fuse()
     _same_map(dev.get_map(), m.get_map())
     assert dev.stats().last_window_frames == 1301 == m.counters()["window_frames"]
+
+
+def test_tick_resident_equals_the_four_calls(upenn_rig, upenn_stream):
+    """esvo_map_tick_resident = esvo_ts_render x2 + esvo_map_set_observation + esvo_map_tick"""
+    from esvo_amd import lib, params, rostime
+    p, _ = params.make_params(params.PRESETS["mapping_upenn"], upenn_rig)
+    a, b = lib.Esvo(p, upenn_rig), lib.Esvo(p, upenn_rig)
+    for d in (a, b):
+        d.ts_push_events(0, upenn_stream.ev_left)
+        d.ts_push_events(1, upenn_stream.ev_right)
+    for k in range(4):
+        t = upenn_stream.t0_ns + int((0.1 + 0.01 * k) * 1e9)
+        stamps, poses = rostime.pose_table(upenn_stream.pose, t, p.bm_half_slice_thickness)
+        T = upenn_stream.pose(t)
+        a.ts_render(0, t, download=False)
+        a.ts_render(1, t, download=False)
+        a.set_observation(t, None, None, T)
+        a.tick(t, stamps, poses)
+        b.tick_resident(t, T, stamps, poses)
+        ma, mb = a.get_map(), b.get_map()
+        assert len(ma) > 0 and ma.tobytes() == mb.tobytes()
+    a.close()
+    b.close()
