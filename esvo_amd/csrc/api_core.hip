@@ -139,6 +139,13 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
     h->own_stream = true;
     CK(hipStreamCreateWithPriority(&h->stream_b, hipStreamNonBlocking, mode == 1 ? prio_lo : (mode == 2 ? prio_hi : 0)));
   }
+  {
+    int lo = 0, hi = 0;
+    CK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    CK(hipStreamCreateWithPriority(&h->stream_l, hipStreamNonBlocking, hi));  // the LM stage is the critical path
+    const char* e = std::getenv("ESVO_LM_STREAM");
+    h->lm_split = !(e && std::atoi(e) == 0);
+  }
   CK(hipStreamCreateWithFlags(&h->stream_t, hipStreamNonBlocking));
   CK(hipStreamCreateWithFlags(&h->stream_i, hipStreamNonBlocking));
   // calibration -> device
@@ -160,7 +167,9 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
     CK(dalloc(&h->d_sae[cam], npx));
     CK(hipMemset(h->d_sae[cam], 0, sizeof(u64) * npx));
     CK(dalloc(&h->d_ts[cam], npx + 64));
-    CK(dalloc(&h->d_obs[cam], npx + 64));
+    CK(dalloc(&h->d_obs2[0][cam], npx + 64));
+    CK(dalloc(&h->d_obs2[1][cam], npx + 64));
+    h->d_obs[cam] = h->d_obs2[0][cam];
   }
   CK(dalloc(&h->d_raw, npx + 64));
   CK(dalloc(&h->d_obs_tmp, npx + 64));
@@ -179,20 +188,26 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
   CK(dalloc(&h->d_match_slots, E));
   CK(dalloc(&h->d_match_flags, E));
   CK(dalloc(&h->d_match_prefix, E));
-  CK(dalloc(&h->d_matches, E));
+  CK(dalloc(&h->d_matches2[0], E));
+  CK(dalloc(&h->d_matches2[1], E));
+  h->d_matches = h->d_matches2[0];
   CK(dalloc(&h->d_pt_slots, E));
   CK(dalloc(&h->d_pt_flags, E));
   CK(dalloc(&h->d_pt_prefix, E));
   CK(dalloc(&h->d_pts_tmp, E));
   CK(dalloc(&h->d_stage[0], E));
   CK(dalloc(&h->d_stage[1], E));
-  CK(dalloc(&h->d_counters, 16));
-  CK(hipMemset(h->d_counters, 0, sizeof(u32) * 16));
+  CK(dalloc(&h->d_counters2[0], 16));
+  CK(dalloc(&h->d_counters2[1], 16));
+  CK(hipMemset(h->d_counters2[0], 0, sizeof(u32) * 16));
+  CK(hipMemset(h->d_counters2[1], 0, sizeof(u32) * 16));
+  h->d_counters = h->d_counters2[0];
   CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_counters), sizeof(u32) * 16 * 2));
   std::memset(h->h_counters, 0, sizeof(u32) * 16 * 2);
   CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_pin), sizeof(double) * 2 * ((size_t)h->max_poses * 17 + 16)));
   CK(dalloc(&h->d_scan_tmp, scan_scratch_elems(std::max(E, npx)) + 8));
   CK(dalloc(&h->d_scan_tmp_b, scan_scratch_elems(std::max(E, npx)) + 8));
+  CK(dalloc(&h->d_scan_tmp_l, scan_scratch_elems(std::max(E, npx)) + 8));
   CK(dalloc(&h->d_cnt_b, 8));
   CK(hipMemset(h->d_cnt_b, 0, sizeof(u32) * 8));
   CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_cnt_b), sizeof(u32) * 8 * 3));
@@ -252,12 +267,13 @@ int esvo_destroy(esvo_handle h) {
   if (!h) return ESVO_OK;
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
+  if (h->stream_l) hipStreamSynchronize(h->stream_l);
   if (h->stream_b) hipStreamSynchronize(h->stream_b);
   comm_release(h);
   void* ptrs[] = {h->d_lut, h->d_mask, h->d_fixmap[0], h->d_fixmap[1], h->d_sae[0], h->d_sae[1], h->d_raw, h->d_ts[0],
-                  h->d_ts[1], h->d_ring[0], h->d_ring[1], h->d_obs[0], h->d_obs[1], h->d_obs_tmp,
+                  h->d_ts[1], h->d_ring[0], h->d_ring[1], h->d_obs2[0][0], h->d_obs2[0][1], h->d_obs2[1][0], h->d_obs2[1][1], h->d_obs_tmp,
                   h->d_pose_T2[0], h->d_pose_T2[1], h->d_scan_tmp_b, h->d_cnt_b, h->d_tick_ev, h->d_match_slots, h->d_match_flags, h->d_match_prefix,
-                  h->d_matches, h->d_pt_slots, h->d_pt_flags, h->d_pt_prefix, h->d_pts_tmp, h->d_stage[0], h->d_stage[1], h->d_counters, h->d_scan_tmp,
+                  h->d_matches2[0], h->d_matches2[1], h->d_scan_tmp_l, h->d_pt_slots, h->d_pt_flags, h->d_pt_prefix, h->d_pts_tmp, h->d_stage[0], h->d_stage[1], h->d_counters2[0], h->d_counters2[1], h->d_scan_tmp,
                   h->d_win, h->d_frame_pose_T, h->d_fr_table, h->d_prop, h->d_cell_count, h->d_cell_offset,
                   h->d_cell_fill, h->d_rec_ids, h->d_map, h->d_map2, h->d_owner_max, h->d_owner_min, h->d_exp_flags,
                   h->d_exp_prefix, h->d_export, h->d_export_cell, h->d_reg_ab, h->d_reg_cd, h->d_bucket, h->d_cell_list, h->d_own_w, h->d_lkeep, h->d_codes,
@@ -278,6 +294,7 @@ int esvo_destroy(esvo_handle h) {
     if (q) hipFree(q);
   if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
   if (h->stream_b) hipStreamDestroy(h->stream_b);
+  if (h->stream_l) { hipStreamSynchronize(h->stream_l); hipStreamDestroy(h->stream_l); }
   if (h->stream_t) { hipStreamSynchronize(h->stream_t); hipStreamDestroy(h->stream_t); }
   if (h->stream_i) { hipStreamSynchronize(h->stream_i); hipStreamDestroy(h->stream_i); }
   for (void* q : {(void*)h->d_trk_blur, (void*)h->d_trk_neg, (void*)h->d_trk_du, (void*)h->d_trk_dv, (void*)h->d_trk_xyz, (void*)h->d_trk_pts,
@@ -293,6 +310,7 @@ int esvo_reset(esvo_handle h) {
   { int rcp = flush_pending_tick(h); if (rcp) return rcp; }
   const size_t npx = (size_t)h->W * h->H;
   HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream_l));
   HIPCHK(hipStreamSynchronize(h->stream_b));
   for (int cam = 0; cam < 2; ++cam) {
     HIPCHK(hipMemsetAsync(h->d_sae[cam], 0, sizeof(u64) * npx, h->stream));
@@ -309,6 +327,7 @@ int esvo_reset(esvo_handle h) {
   h->obs_set = false;
   h->n_pose = 0;
   HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream_l));
   HIPCHK(hipStreamSynchronize(h->stream_b));
   h->back_pending[0] = h->back_pending[1] = false;
   h->committed_t_ns = 0;
@@ -346,6 +365,7 @@ int esvo_set_stream(esvo_handle h, void* hip_stream) {
   if (!h) return ESVO_ERR_INVALID_ARG;
   { int rcp = flush_pending_tick(h); if (rcp) return rcp; }
   HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream_l));
   HIPCHK(hipStreamSynchronize(h->stream_b));
   if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
   h->stream = reinterpret_cast<hipStream_t>(hip_stream);
@@ -357,6 +377,7 @@ int esvo_synchronize(esvo_handle h) {
   if (!h) return ESVO_ERR_INVALID_ARG;
   { int rcp = flush_pending_tick(h); if (rcp) return rcp; }
   HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream_l));
   HIPCHK(hipStreamSynchronize(h->stream_b));
   return ESVO_OK;
 }

@@ -77,24 +77,27 @@ int run_match(esvo_context* h, const esvo_event_t* d_ev, u64 first, u64 cap, int
 }
 
 // LM (+cull) over the compacted matches: point records + flags in solver-slot order (dense: in list order)
-int run_lm(esvo_context* h, u32 max_matches, int cull, bool dense) {
+int run_lm(esvo_context* h, u32 max_matches, int cull, bool dense, hipStream_t st = nullptr) {
+  if (!st) st = h->stream;
   u32* flags = dense ? h->d_lkeep : h->d_pt_flags;  // the kernel writes every flag of its launch range
   LmArgs a;
   a.matches = h->d_matches; a.n_matches = h->d_counters + (dense ? 8 : 0); a.max_matches = max_matches;
   a.tsL = h->d_obs[0]; a.tsR = h->d_obs[1];
   a.pose_T = h->d_pose_T; std::memcpy(a.T_world_obs, h->T_world_obs, sizeof(double) * 16);
   a.out_slots = h->d_pt_slots; a.out_flags = flags; a.cull = cull; a.dense = dense ? 1 : 0;
-  hipEventRecord(h->evt[EV_LM0 + h->fpar * EV_FRONT_STRIDE], h->stream);
-  launch_lm_refine(a, h->dp, h->d_counters + 2, h->stream);
-  hipEventRecord(h->evt[EV_LM1 + h->fpar * EV_FRONT_STRIDE], h->stream);
+  hipEventRecord(h->evt[EV_LM0 + h->fpar * EV_FRONT_STRIDE], st);
+  launch_lm_refine(a, h->dp, h->d_counters + 2, st);
+  hipEventRecord(h->evt[EV_LM1 + h->fpar * EV_FRONT_STRIDE], st);
   HIPCHK(hipGetLastError());
   return ESVO_OK;
 }
 // stable compaction of the solver slots: the culled points go to `dst` in the reference's order
-int run_order_points(esvo_context* h, u32 max_matches, DevPoint* dst) {
-  launch_exclusive_scan_u32(h->d_pt_flags, h->d_pt_prefix, h->d_counters + 1, h->d_scan_tmp, max_matches, h->stream);
-  launch_compact_points(h->d_pt_slots, h->d_pt_flags, h->d_pt_prefix, h->d_counters + 0, max_matches, dst, h->stream);
-  hipEventRecord(h->evt[EV_S2 + h->fpar * EV_FRONT_STRIDE], h->stream);
+int run_order_points(esvo_context* h, u32 max_matches, DevPoint* dst, hipStream_t st) {
+  u32* scratch = (st && st != h->stream) ? h->d_scan_tmp_l : h->d_scan_tmp;  // the LM stage scans beside the next tick's BM
+  if (!st) st = h->stream;
+  launch_exclusive_scan_u32(h->d_pt_flags, h->d_pt_prefix, h->d_counters + 1, scratch, max_matches, st);
+  launch_compact_points(h->d_pt_slots, h->d_pt_flags, h->d_pt_prefix, h->d_counters + 0, max_matches, dst, st);
+  hipEventRecord(h->evt[EV_S2 + h->fpar * EV_FRONT_STRIDE], st);
   HIPCHK(hipGetLastError());
   return ESVO_OK;
 }
@@ -317,6 +320,14 @@ int esvo_map_set_observation(esvo_handle h, uint64_t t_ns, const uint8_t* ts_lef
   HIPCHK(hipSetDevice(h->device));
   const size_t npx = (size_t)h->W * h->H;
   const uint8_t* src[2] = {ts_left, ts_right};
+  // a new observation goes into the OTHER pair of buffers: an LM stage still in flight keeps reading its own
+  // (the one before that has finished: the call that enqueued it completed its predecessor, context.hpp)
+  h->obs_par ^= 1;
+  h->d_obs[0] = h->d_obs2[h->obs_par][0];
+  h->d_obs[1] = h->d_obs2[h->obs_par][1];
+  // (observations set twice between two ticks: the pending tick's LM stage reads this very pair -- write behind it)
+  if (h->tick_pending && h->tk[h->fpar].obs_par == h->obs_par)
+    HIPCHK(hipStreamWaitEvent(h->stream, h->evt[EV_CNT + h->fpar * EV_FRONT_STRIDE], 0));
   for (int cam = 0; cam < 2; ++cam) {
     uint8_t* dst = h->prm.smooth_time_surface ? h->d_obs_tmp : h->d_obs[cam];
     if (src[cam]) {
@@ -408,12 +419,14 @@ int esvo_map_push_frame(esvo_handle h, const esvo_depth_point_t* pts, size_t n, 
   u32 off;
   int rc = window_reserve(h, (u32)n, &off);
   if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(h->stream_l));
   HIPCHK(hipStreamSynchronize(h->stream_b));  // the ring space may have been read by a fusion still in flight
   if (n) HIPCHK(hipMemcpyAsync(h->d_win + off, pts, sizeof(esvo_depth_point_t) * n, hipMemcpyHostToDevice, h->stream));
   static const double ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   rc = commit_frame(h, off, (u32)n, m ? pose_T : ident, (u32)m);
   if (rc) return rc;
   HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream_l));
   HIPCHK(hipStreamSynchronize(h->stream_b));
   return ESVO_OK;
 }
@@ -432,6 +445,7 @@ int esvo_map_fuse(esvo_handle h, size_t* n_fusions) {
   rc = run_fuse(h, par, h->T_world_obs);
   if (rc) return rc;
   h->committed_t_ns = h->obs_t_ns;
+  HIPCHK(hipStreamSynchronize(h->stream_l));
   HIPCHK(hipStreamSynchronize(h->stream_b));
   collect_back(h, par);
   h->stats.last_window_frames = (u32)h->n_window_frames;
@@ -475,8 +489,12 @@ int tick_phase0(esvo_context* h, uint64_t t_ns, const uint64_t* pose_t_ns, const
   rc = select_events(h, t_ns, &h->sh_first, &n);
   if (rc) return rc;
   h->fpar ^= 1;
+  h->d_matches = h->d_matches2[h->fpar];    // the tick's own match list and counters (the LM stage of the previous tick
+  h->d_counters = h->d_counters2[h->fpar];  // may still be running on its own)
   esvo_context::TickState& tk = h->tk[h->fpar];
   tk.n = n; tk.off = 0; tk.points = 0; tk.t_ns = t_ns;
+  tk.lm_stream = h->stream;
+  tk.obs_par = h->obs_par;
   tk.pose_buf = h->pose_buf; tk.n_pose = h->n_pose;
   std::memcpy(tk.T_world_obs, h->T_world_obs, sizeof(double) * 16);
   // two ticks in flight at most: what this tick's front stage overwrites (ring space of popped frames, the pose
@@ -503,7 +521,14 @@ int tick_phase0(esvo_context* h, uint64_t t_ns, const uint64_t* pose_t_ns, const
     if (rc) return rc;
     rc = run_order_matches(h, n, false);
     if (rc) return rc;
-    rc = run_lm(h, n, 1, false);
+    hipStream_t sl = h->stream;
+    if (h->split_now) {  // the LM stage on its own stream, behind this tick's matches
+      HIPCHK(hipEventRecord(h->evt[EV_A1 + h->fpar * EV_FRONT_STRIDE], h->stream));
+      HIPCHK(hipStreamWaitEvent(h->stream_l, h->evt[EV_A1 + h->fpar * EV_FRONT_STRIDE], 0));
+      sl = h->stream_l;
+    }
+    tk.lm_stream = sl;
+    rc = run_lm(h, n, 1, false, sl);
     if (rc) return rc;
   } else if (n) {
     // own slots only (w % n_shards == shard): BM, dense local list, LM + cull on it, then the (matched, kept)
@@ -544,8 +569,8 @@ int tick_phase1_enqueue(esvo_context* h) {
   if (n && !h->sharded) {
     // the frame waits in the staging buffer of its parity until the tick is committed and its size is known; the
     // buffer's previous frame (two ticks ago) has been copied into the ring by then
-    HIPCHK(hipStreamWaitEvent(h->stream, h->evt[EV_STG + h->fpar * EV_FRONT_STRIDE], 0));
-    rc = run_order_points(h, n, h->d_stage[h->fpar]);
+    HIPCHK(hipStreamWaitEvent(tk.lm_stream, h->evt[EV_STG + h->fpar * EV_FRONT_STRIDE], 0));
+    rc = run_order_points(h, n, h->d_stage[h->fpar], tk.lm_stream);
     if (rc) return rc;
   } else if (n) {
     const u32 N = (u32)h->dp.ev_nshards, r = (u32)h->dp.ev_shard, T = (u32)h->dp.num_threads;
@@ -560,8 +585,9 @@ int tick_phase1_enqueue(esvo_context* h) {
     hipEventRecord(h->evt[EV_S2 + h->fpar * EV_FRONT_STRIDE], h->stream);
     HIPCHK(hipGetLastError());
   }
-  HIPCHK(hipMemcpyAsync(h->h_counters + 16 * h->fpar, h->d_counters, sizeof(u32) * 16, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipEventRecord(h->evt[EV_CNT + h->fpar * EV_FRONT_STRIDE], h->stream));
+  hipStream_t sc = (n && !h->sharded) ? tk.lm_stream : h->stream;
+  HIPCHK(hipMemcpyAsync(h->h_counters + 16 * h->fpar, h->d_counters, sizeof(u32) * 16, hipMemcpyDeviceToHost, sc));
+  HIPCHK(hipEventRecord(h->evt[EV_CNT + h->fpar * EV_FRONT_STRIDE], sc));
   h->tick_pending = true;
   return ESVO_OK;
 }
@@ -656,6 +682,7 @@ int finalize_tick_stats(esvo_context* h) {
   const bool tick_done = h->stats_pending;
   h->stats_pending = false;
   HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream_l));
   HIPCHK(hipStreamSynchronize(h->stream_b));
   collect_ts_timing(h);
   collect_back(h, h->par);
@@ -687,8 +714,10 @@ extern "C" int esvo_map_tick(esvo_handle h, uint64_t t_ns, const uint64_t* pose_
   }
   const bool prev = h->tick_pending;
   const int prev_fp = h->fpar;
+  h->split_now = h->lm_split && !h->prm.denoising;
   int rc = tick_phase0(h, t_ns, pose_t_ns, pose_T, m);
   if (!rc) rc = tick_phase1_enqueue(h);
+  h->split_now = false;
   if (rc) {  // the failed tick leaves no trace: the previous one (if pending) stays pending on ITS parity and is
     h->fpar = prev_fp;  // completed -- with its own counters and staging buffer -- by the next call that needs it
     return rc;
@@ -744,6 +773,7 @@ extern "C" int esvo_map_init_sgm(esvo_handle h, const uint8_t* ts_left, const ui
       img[cam] = h->d_ts[cam];
     }
   }
+  HIPCHK(hipStreamSynchronize(h->stream_l));
   HIPCHK(hipStreamSynchronize(h->stream_b));  // the DepthMap and the window are rebuilt below
   launch_sgbm(img[0], img[1], h->sgm, h->d_sgm_disp, h->W, h->H, h->stream);
   HIPCHK(hipGetLastError());
@@ -793,6 +823,7 @@ extern "C" int esvo_map_init_sgm(esvo_handle h, const uint8_t* ts_left, const ui
   launch_sgm_naive(h->d_win + off, count, h->d_sgm_T, h->d_owner_max, h->d_sgm_pair, h->d_sgm_pair + 4 * (size_t)h->max_ev, h->d_cnt_b + 4,
                    h->d_scan_tmp_b, h->d_map, h->dp, h->stream_b);
   HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(h->stream_l));
   HIPCHK(hipStreamSynchronize(h->stream_b));
   h->d_map_cur = h->d_map;
   h->committed_t_ns = h->obs_t_ns;
@@ -1060,7 +1091,8 @@ int esvo_map_get_debug_images(esvo_handle h, double age_max_range, uint8_t* inv_
     launch_debug_image(h->d_map_cur, h->d_viz_owner, h->d_viz_bgr, h->d_viz_jet, im.type, im.mx, im.mn, im.t1, im.t2, h->dp, h->stream_b);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(im.out, h->d_viz_bgr, npx * 3, hipMemcpyDeviceToHost, h->stream_b));
-    HIPCHK(hipStreamSynchronize(h->stream_b));
+    HIPCHK(hipStreamSynchronize(h->stream_l));
+  HIPCHK(hipStreamSynchronize(h->stream_b));
   }
   return ESVO_OK;
 }

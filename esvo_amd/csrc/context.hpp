@@ -22,7 +22,7 @@ using namespace esvo;
 
 // front-stage events live on the front stream; the back-stage set exists once per tick parity (two ticks in flight)
 enum { EV_SC0 = 0, EV_SC1, EV_R1, EV_SC0b, EV_SC1b, EV_R1b, EV_FRAME,
-       EV_T0, EV_BM0, EV_BM1, EV_S1, EV_LM0, EV_LM1, EV_S2, EV_CNT, EV_STG, EV_T0b, EV_BM0b, EV_BM1b, EV_S1b, EV_LM0b, EV_LM1b, EV_S2b, EV_CNTb, EV_STGb,
+       EV_T0, EV_BM0, EV_BM1, EV_S1, EV_LM0, EV_LM1, EV_S2, EV_CNT, EV_STG, EV_A1, EV_T0b, EV_BM0b, EV_BM1b, EV_S1b, EV_LM0b, EV_LM1b, EV_S2b, EV_CNTb, EV_STGb, EV_A1b,
        EV_FU0, EV_FU1, EV_CL1, EV_RG1, EV_POSE, EV_FU0b, EV_FU1b, EV_CL1b, EV_RG1b, EV_POSEb, EV_N };
 constexpr int EV_BACK_STRIDE = EV_FU0b - EV_FU0;  // evt[EV_x + par * EV_BACK_STRIDE]
 constexpr int EV_FRONT_STRIDE = EV_T0b - EV_T0;   // evt[EV_x + fpar * EV_FRONT_STRIDE]
@@ -47,6 +47,17 @@ struct esvo_context {
   // stage only reads what the front stage finished (the frame in the window ring, the tick's pose table).
   hipStream_t stream = nullptr;
   hipStream_t stream_b = nullptr;
+  // LM stage of a lazy tick (refinement, frame assembly, counters): block matching and the Time Surfaces of the NEXT tick run
+  // beside it on `stream`.  What the two stages share is double-buffered by POINTER SWAP: d_obs / d_matches / d_counters
+  // below alias one of two buffers each (kernels capture the pointer at launch, so work in flight keeps its own).
+  hipStream_t stream_l = nullptr;
+  bool lm_split = true;           // ESVO_LM_STREAM=0: everything of the front stage on `stream`
+  bool split_now = false;         // set by esvo_map_tick around its front stage: only the lazy tick path splits
+  uint8_t* d_obs2[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+  int obs_par = 0;
+  esvo_match_t* d_matches2[2] = {nullptr, nullptr};
+  u32* d_counters2[2] = {nullptr, nullptr};
+  u32* d_scan_tmp_l = nullptr;    // scan scratch of the LM stage
   hipStream_t stream_i = nullptr;  // event ingest (H2D into the ring): staging new events never waits for a running tick
   bool own_stream = false;
   int par = 0;                    // parity of the tick being assembled
@@ -156,6 +167,8 @@ struct esvo_context {
     int pose_buf = 0;
     u64 t_ns = 0;
     double T_world_obs[16];
+    hipStream_t lm_stream = nullptr;  // where the tick's LM stage (refinement, frame, counters) was enqueued
+    int obs_par = 0;                  // which observation pair it reads
   } tk[2];
   int fpar = 0;                   // parity of the newest front stage
   bool tick_pending = false;      // tk[fpar] has its front stage enqueued but is not committed yet
@@ -223,7 +236,7 @@ void collect_ts_timing(esvo_context* h, int only = -1);
 int flush_pending_tick(esvo_context* h);  // completes a lazily finished tick (see esvo_context::TickState)
 int finalize_tick_stats(esvo_context* h);
 int run_bm(esvo_context* h, const esvo_event_t* d_ev, u64 first, u64 cap, int reverse, u32 n, const u32* sel = nullptr);
-int run_order_points(esvo_context* h, u32 max_matches, DevPoint* dst);
+int run_order_points(esvo_context* h, u32 max_matches, DevPoint* dst, hipStream_t st = nullptr);
 int back_after_front(esvo_context* h);
 void collect_back(esvo_context* h, int par);
 int window_reserve(esvo_context* h, u32 n, u32* off_out);

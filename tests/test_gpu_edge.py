@@ -359,3 +359,35 @@ def test_tick_resident_equals_the_four_calls(upenn_rig, upenn_stream):
         assert len(ma) > 0 and ma.tobytes() == mb.tobytes()
     a.close()
     b.close()
+
+
+def test_observation_set_twice_while_a_tick_is_in_flight(dsec_rig, dsec_stream):
+    """The LM stage of a lazy tick runs on its own stream and reads one of two observation pairs; setting the observation
+    twice before the next tick lands on the pair in use -- the write has to queue behind that stage.  Compared with a handle
+    that is synchronised after every call."""
+    from esvo_amd import lib, params, rostime
+    p, _ = params.make_params(params.PRESETS["mapping_dsec"], dsec_rig, throughput_events=30000)
+    a, b = lib.Esvo(p, dsec_rig), lib.Esvo(p, dsec_rig)
+    for d in (a, b):
+        d.ts_push_events(0, dsec_stream.ev_left)
+        d.ts_push_events(1, dsec_stream.ev_right)
+    for k in range(5):
+        t = dsec_stream.t0_ns + int((0.05 + 0.01 * k) * 1e9)
+        stamps, poses = rostime.pose_table(dsec_stream.pose, t, p.bm_half_slice_thickness)
+        T = dsec_stream.pose(t)
+        for d, sync in ((a, False), (b, True)):
+            d.ts_render(0, t, download=False)
+            d.ts_render(1, t, download=False)
+            d.set_observation(t, None, None, np.eye(4))      # a first observation that is replaced at once
+            if sync:
+                d.synchronize()
+            d.set_observation(t, None, None, T)
+            if sync:
+                d.synchronize()
+            d.tick(t, stamps, poses)
+            if sync:
+                d.synchronize()
+    ma, mb = a.get_map(), b.get_map()
+    assert len(ma) > 1000 and ma.tobytes() == mb.tobytes()
+    a.close()
+    b.close()
