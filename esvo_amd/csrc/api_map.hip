@@ -41,7 +41,7 @@ int upload_poses(esvo_context* h, const uint64_t* pose_t_ns, const double* pose_
   h->d_pose_T = h->d_pose_T2[h->pose_buf];
   HIPCHK(hipStreamWaitEvent(h->stream, h->evt[EV_POSE + h->pose_buf * EV_BACK_STRIDE], 0));
   h->d_pose_sec = h->d_pose_T + 16 * m;
-  if (m) HIPCHK(hipMemcpyAsync(h->d_pose_T, T, sizeof(double) * 17 * m, hipMemcpyHostToDevice, h->stream));
+  if (m) launch_upload_words(T, h->d_pose_T, sizeof(double) * 17 * m, h->stream);
   return ESVO_OK;
 }
 
@@ -244,7 +244,7 @@ int run_fuse(esvo_context* h, int par, const double* T_world_obs) {
   cum[nf] = total;
   hipStream_t sb = h->stream_b;
   u32* dtab = h->d_fr_table + (size_t)par * tab;
-  HIPCHK(hipMemcpyAsync(dtab, cum, sizeof(u32) * tab, hipMemcpyHostToDevice, sb));
+  launch_upload_words(cum, dtab, sizeof(u32) * tab, sb);
   std::memcpy(h->T_world_frame, T_world_obs, sizeof(double) * 16);  // new DepthFrame at the TS pose (:268-272)
   FuseArgs a;
   a.win = h->d_win;

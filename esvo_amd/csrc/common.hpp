@@ -141,6 +141,8 @@ typedef esvo_depth_point_t DevPoint;
 void launch_exclusive_scan_u32(const u32* d_in, u32* d_out, u32* d_total, u32* d_block_sums, size_t n,
                                hipStream_t s);
 size_t scan_scratch_elems(size_t n);
+// upload of a small pinned host buffer by a kernel (never blocks the host; scan.hip)
+void launch_upload_words(const void* pinned_src, void* d_dst, size_t bytes, hipStream_t s);
 
 // kernels_ts.hip
 void launch_ts_unpack_wire(const uint8_t* wire, size_t n, esvo_event_t* ring, u64 first_slot, u64 ring_cap, hipStream_t s);

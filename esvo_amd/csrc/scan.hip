@@ -89,6 +89,21 @@ __global__ void __launch_bounds__(SCAN_SB) scan_small_kernel(const u32* __restri
   if (threadIdx.x == 0 && total) *total = carry;
 }
 
+// Small host -> device uploads of the tick path (pose table, frame table) as a KERNEL that reads the pinned host buffer:
+// a kernel launch never blocks the host, whereas hipMemcpyAsync of a few KB was measured to stall its caller for 6-11 ms
+// once per process when a third stream of the handle is busy (the copy engine's queue is shared between the streams).
+__global__ void __launch_bounds__(256) upload_words_kernel(const u32* __restrict__ src, u32* __restrict__ dst, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+void launch_upload_words(const void* pinned_src, void* d_dst, size_t bytes, hipStream_t s) {
+  const size_t n = bytes / 4;  // callers pass multiples of 4 bytes
+  if (n == 0) return;
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 256) blocks = 256;
+  hipLaunchKernelGGL(upload_words_kernel, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const u32*>(pinned_src),
+                     reinterpret_cast<u32*>(d_dst), n);
+}
+
 size_t scan_scratch_elems(size_t n) { return (n + SCAN_TILE - 1) / SCAN_TILE + 1; }
 
 // d_out may alias d_in.  d_total (nullable) receives the sum.  d_block_sums: scan_scratch_elems(n).
