@@ -171,13 +171,14 @@ typedef struct esvo_stats_t {
   /* HIP-event time of single kernels / stages of the last tick (for roofline accounting):
    * [0] ts_scatter [1] ts_decay+median_remap [2] bm_match [3] lm_refine
    * [4] propagate+bucket+fuse_cells [5] clean [6] regularize [7] reserved.
-   * The front stage ([0]-[3]) and the back stage ([4]-[6]) of consecutive ticks run on two streams at the same
-   * time, so the values are not additive and each includes the slowdown from the other stream's kernels. */
+   * The matching stage ([0]-[2]), the LM stage ([3]) and the fusion stage ([4]-[6]) of consecutive ticks run on three
+   * streams at the same time, so the values are not additive and each includes the slowdown from the other streams'
+   * kernels. */
   float ms_kernel[8];
   float pad_;
   /* Running totals over all ticks since esvo_create / esvo_reset.  A throughput loop reads them once at its
-   * end: esvo_get_stats drains both streams, so calling it after every tick serialises the overlap of one
-   * tick's fusion stage with the next tick's matching stage. */
+   * end: esvo_get_stats drains the streams, so calling it after every tick serialises the overlap of one
+   * tick's LM and fusion stages with the next tick's matching stage. */
   uint64_t total_events_in;
   uint64_t total_matches;
   uint64_t total_points;
