@@ -142,7 +142,9 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
   {
     int lo = 0, hi = 0;
     CK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    CK(hipStreamCreateWithPriority(&h->stream_l, hipStreamNonBlocking, hi));  // the LM stage is the critical path
+    int pl = hi;
+    if (const char* e3 = std::getenv("ESVO_PRIO_LM")) pl = std::atoi(e3) == 0 ? hi : (std::atoi(e3) == 2 ? lo : 0);  // A/B only
+    CK(hipStreamCreateWithPriority(&h->stream_l, hipStreamNonBlocking, pl));  // the LM stage is the critical path
     const char* e = std::getenv("ESVO_LM_STREAM");
     h->lm_split = !(e && std::atoi(e) == 0);
   }

@@ -160,7 +160,11 @@ __device__ inline double in_vgpr(double x) {
 
 struct LmProblem {
   double cx, cy;           // rectified left coordinate of the event
+#ifdef LM_T_IN_LDS
+  const double* T;         // T_left_virtual (3x4) in LDS (A/B switch: 159 VGPRs -> 3 waves/SIMD; slower tick)
+#else
   double T[12];            // T_left_virtual (3x4)
+#endif
   const uint8_t* tsL;
   const uint8_t* tsR;
   int c;                   // patch column of the lane
@@ -434,6 +438,9 @@ __device__ inline double lm_lmpar2(double r, double diag, double qtf, double del
 template <bool WIDE>
 __global__ void __launch_bounds__(LM_BLOCK, WIDE ? LM_WIDE_WAVES : LM_WAVES) lm_refine_kernel(LmArgs a, DevParams p, u32* n_solved) {
   constexpr int RL = Lay<WIDE>::RL;
+#ifdef LM_T_IN_LDS
+  __shared__ double lds_T[LM_BLOCK / 16][12];
+#endif
   const u32 s = WIDE ? blockIdx.x : (blockIdx.x * LM_BLOCK + threadIdx.x) >> 4;  // solver slot (thread-stride order)
   const int c = threadIdx.x & 15;
   const int drow = (threadIdx.x >> 4) & 3;
@@ -468,8 +475,18 @@ __global__ void __launch_bounds__(LM_BLOCK, WIDE ? LM_WIDE_WAVES : LM_WAVES) lm_
     double Tlw[16], Tlv[16];
     rigid_inverse(a.T_world_obs, Tlw);
     mat4_mul(Tlw, a.pose_T + (size_t)m.pose_idx * 16, Tlv);
+#ifdef LM_T_IN_LDS
+    double* Tm = lds_T[WIDE ? 0 : (threadIdx.x >> 4)];
+    if (lead) {
+#pragma unroll
+      for (int i = 0; i < 12; ++i) Tm[i] = Tlv[i];
+    }
+    pr.T = Tm;
+    __syncthreads();  // one wave per workgroup: orders the LDS writes before the reads
+#else
 #pragma unroll
     for (int i = 0; i < 12; ++i) pr.T[i] = Tlv[i];
+#endif
   }
   const int N = LM_ROWS * LM_COLS;
   const double ftol = 1e-6, xtol = 1e-6, gtol = 0., factor = 100.;
