@@ -27,6 +27,17 @@
 
 namespace esvo {
 
+// Register budget of the back-stage kernels: they run beside the LM kernel of the next tick, whose two waves per SIMD
+// leave 144 of 512 VGPRs.  At <= 80 VGPRs a second back-stage wave fits where only one did (propagate 114 -> 72,
+// reg_apply 124 -> 78, no spills): +1.5 % per tick.  fuse_cells keeps its 112 (capping it spills; dropping its software
+// prefetch gives 80 and was measured neutral).
+#ifndef BACK_WAVES
+#define BACK_WAVES 6
+#endif
+#ifndef FUSE_WAVES
+#define FUSE_WAVES 1
+#endif
+
 __device__ inline bool boundaryCheck(double x, double y, int W, int H) {  // DepthFusion.cpp:194-205
   return !(x < 0 || x >= (double)W || y < 0 || y >= (double)H);
 }
@@ -42,7 +53,7 @@ __device__ inline bool fusion_cell(u32 prow, u32 pcol, int k, int radius, int W,
 }
 
 // ---- propagate (+ histogram) ------------------------------------------------------------------
-__global__ void __launch_bounds__(256) propagate_kernel(FuseArgs a, DevParams p, int K) {
+__global__ void __launch_bounds__(256, BACK_WAVES) propagate_kernel(FuseArgs a, DevParams p, int K) {
   const u32 q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= a.n_pts) return;
   u32 f = 0;  // frame of point q (binary search in the cumulative counts)
@@ -289,7 +300,7 @@ __global__ void __launch_bounds__(64) sort_long_lists_kernel(const u32* __restri
 #ifndef FUSE_BLOCK
 #define FUSE_BLOCK 256
 #endif
-__global__ void __launch_bounds__(FUSE_BLOCK) fuse_cells_kernel(FuseArgs a, DevParams p, int K) {
+__global__ void __launch_bounds__(FUSE_BLOCK, FUSE_WAVES) fuse_cells_kernel(FuseArgs a, DevParams p, int K) {
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= *a.n_touched) return;
   const int cell = (int)a.cell_list[t];
@@ -312,15 +323,25 @@ __global__ void __launch_bounds__(FUSE_BLOCK) fuse_cells_kernel(FuseArgs a, DevP
     }
     return id;
   };
+#ifndef FUSE_NO_PREFETCH
   u32 id_nxt = next_id(0, 0);
   DevPoint nxt = a.prop[id_nxt / (u32)K];
+#else
+  u32 id = 0;
+#endif
   for (u32 i = 0; i < n; ++i) {
+#ifndef FUSE_NO_PREFETCH
     const u32 id = id_nxt;
     const DevPoint prop = nxt;
     if (i + 1 < n) {  // software prefetch: the next record does not depend on the cell state
       id_nxt = next_id(i + 1, id);
       nxt = a.prop[id_nxt / (u32)K];
     }
+#else
+    // (A/B: without the software prefetch the kernel needs 80 instead of 112 VGPRs; measured neutral beside the LM kernel)
+    id = next_id(i, id);
+    const DevPoint prop = a.prop[id / (u32)K];
+#endif
     if (!exists) {  // case 1: DepthFusion.cpp:127-146
       c.row = (u32)crow; c.col = (u32)ccol;
       c.x[0] = (double)ccol + 0.5; c.x[1] = (double)crow + 0.5;
@@ -469,7 +490,7 @@ __global__ void __launch_bounds__(256) reg_view_kernel(const MapCell* __restrict
 #define REG_MARGIN 1   // an element's believed (row, col) is at most one cell away from its true cell (Appendix A-7)
 #define REG_MAXW (REG_TX + 2 * 31 + 2 * REG_MARGIN)
 template <int RT>  // RegularizationRadius when it is one of the shipped values (5, 20): the tap loop unrolls; 0: any radius
-__global__ void __launch_bounds__(REG_TX * REG_TY) reg_apply_kernel(const MapCell* __restrict__ map, MapCell* __restrict__ out,
+__global__ void __launch_bounds__(REG_TX * REG_TY, BACK_WAVES) reg_apply_kernel(const MapCell* __restrict__ map, MapCell* __restrict__ out,
                                                                     const u32* __restrict__ owner_max,
                                                                     const u32* __restrict__ owner_min,
                                                                     const double2* __restrict__ ab,
