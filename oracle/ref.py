@@ -1,8 +1,8 @@
 """ctypes bindings of oracle/_ref/libesvo_ref.so (TEST INFRASTRUCTURE ONLY).
 
 libesvo_ref.so is the REFERENCE's own mapper code -- esvo_core/src/{container/DepthPoint, container/CameraSystem,
-core/EventBM, core/DepthProblem, core/DepthProblemSolver, core/DepthFusion, core/DepthRegularization}.cpp and
-SmartGrid.h, compiled unmodified where they lie under /root/reference against the stand-in headers of
+core/EventBM, core/DepthProblem, core/DepthProblemSolver, core/DepthFusion, core/DepthRegularization,
+core/RegProblemLM, tools/cayley, container/ResidualItem}.cpp and SmartGrid.h, compiled unmodified where they lie under /root/reference against the stand-in headers of
 oracle/ref_shim/ (oracle/Makefile, target `ref`).  It exists only in the build container (no /root/reference on the
 GPU box): tests/golden/make_ref_fixtures.py records its outputs, tests/test_ref_pin.py compares the oracle with them.
 
@@ -43,6 +43,18 @@ def load():
         build()  # make tracks the dependencies
     lib = C.CDLL(_LIB)
     vp, u64, sz, dbl, i32, u32 = C.c_void_p, C.c_uint64, C.c_size_t, C.c_double, C.c_int, C.c_uint32
+    if hasattr(lib, "ref_tracker_create"):
+        lib.ref_tracker_create.restype = vp
+        lib.ref_tracker_create.argtypes = [C.c_char_p, vp, vp, i32, dbl, sz]
+        lib.ref_tracker_destroy.argtypes = [vp]
+        lib.ref_tracker_set_problem.argtypes = [vp, vp, vp, vp, vp, sz, vp, vp, C.c_uint, vp]
+        lib.ref_tracker_num_points.restype = sz
+        lib.ref_tracker_num_points.argtypes = [vp]
+        lib.ref_tracker_relative_pose.argtypes = [vp, vp, vp]
+        lib.ref_tracker_residuals.restype = sz
+        lib.ref_tracker_residuals.argtypes = [vp, sz, sz, vp, vp, vp]
+        lib.ref_tracker_jacobian.restype = sz
+        lib.ref_tracker_jacobian.argtypes = [vp, sz, sz, vp]
     lib.ref_mapper_create.restype = vp
     lib.ref_mapper_create.argtypes = [C.c_char_p, vp, vp, vp]
     lib.ref_mapper_destroy.argtypes = [vp]
@@ -240,3 +252,51 @@ def update_student_t(state, inv_depth, scale2, variance, nu):
     s = np.array(state, np.float64)
     lib.ref_update_student_t(s.ctypes.data, float(inv_depth), float(scale2), float(variance), float(nu))
     return s
+
+
+class RefTracker:
+    """The reference's RegProblemLM (esvo_core/src/core/RegProblemLM.cpp) on injected images: setProblem, operator(), df."""
+
+    def __init__(self, rig, huber=True, huber_threshold=50.0, max_points=2000):
+        self.lib = load()
+        self.rig = rig
+        self._cl, self._cr = rig.left.as_struct(), rig.right.as_struct()
+        with tempfile.TemporaryDirectory() as d:
+            write_calib_dir(rig, d)
+            self.h = self.lib.ref_tracker_create(d.encode(), C.addressof(self._cl), C.addressof(self._cr), int(bool(huber)),
+                                                 float(huber_threshold), int(max_points))
+        self.W, self.H = rig.width, rig.height
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.ref_tracker_destroy(self.h)
+            self.h = None
+
+    def set_problem(self, neg, du, dv, xyz_world, T_world_ref, T_world_left, seed=1):
+        """returns (order, R, t): order[i] = index of the input point the reference's shuffle put at position i (only
+        the first num_points positions are used), (R, t) = T_ref_left as setProblem derives it"""
+        neg = np.ascontiguousarray(neg, np.uint8)
+        du, dv = np.ascontiguousarray(du, np.int16), np.ascontiguousarray(dv, np.int16)
+        xyz = np.ascontiguousarray(xyz_world, np.float32).reshape(-1, 3)
+        Tr = np.ascontiguousarray(T_world_ref, np.float64).reshape(16)
+        Tl = np.ascontiguousarray(T_world_left, np.float64).reshape(16)
+        order = np.empty(len(xyz), np.uint32)
+        self._keep = (neg, du, dv, xyz)
+        self.lib.ref_tracker_set_problem(self.h, _p(neg), _p(du), _p(dv), _p(xyz), len(xyz), _p(Tr), _p(Tl), int(seed), _p(order))
+        self.n = int(self.lib.ref_tracker_num_points(self.h))
+        R, t = np.empty(9), np.empty(3)
+        self.lib.ref_tracker_relative_pose(self.h, _p(R), _p(t))
+        return order, R.reshape(3, 3), t
+
+    def residuals(self, offset, count, x=None):
+        """(fvec, T_warping) of operator()(x) on the batch [offset, offset + count)"""
+        x = np.zeros(6) if x is None else np.ascontiguousarray(x, np.float64)
+        out = np.empty(count, np.float64)
+        T = np.empty(16)
+        n = self.lib.ref_tracker_residuals(self.h, int(offset), int(count), _p(x), _p(out), _p(T))
+        return out[:n], T.reshape(4, 4)
+
+    def jacobian(self, offset, count):
+        out = np.empty(6 * count, np.float64)
+        n = self.lib.ref_tracker_jacobian(self.h, int(offset), int(count), _p(out))
+        return out[:6 * n].reshape(6, n).T

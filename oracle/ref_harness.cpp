@@ -121,6 +121,14 @@ ref_mapper* ref_mapper_create(const char* calib_dir, const esvo_params_t* p, con
   h->frame = std::make_shared<DepthFrame>(h->H, h->W);
   return h;
 }
+// the same CameraSystem factory for the tracker harness (ref_harness_track.cpp); the returned pointer owns a shared_ptr
+void* ref_make_camera_system(const char* calib_dir, const esvo_calib_t* left, const esvo_calib_t* right) {
+  esvo_ref_shim::Injected& g = esvo_ref_shim::inject();
+  g.W = left->width; g.H = left->height; g.cam = 0;
+  g.lut[0] = left->rect_lut; g.lut[1] = right->rect_lut;
+  g.mask[0] = left->rect_mask; g.mask[1] = right->rect_mask;
+  return new CameraSystem::Ptr(std::make_shared<CameraSystem>(std::string(calib_dir), false));
+}
 void ref_mapper_destroy(ref_mapper* h) { delete h; }
 void ref_mapper_reset(ref_mapper* h) { h->window.clear(); h->frame = std::make_shared<DepthFrame>(h->H, h->W); }
 void ref_mapper_set_params(ref_mapper* h, const esvo_params_t* p) { h->prm = *p; h->build(); }

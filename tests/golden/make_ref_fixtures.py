@@ -109,9 +109,53 @@ def make_units():
     print("units", os.path.getsize(path) // 1024, "KiB")
 
 
+def track_inputs():
+    """a 346x260 Time Surface, a cloud of 900 scene points seen from it, reference pose 20 ms earlier"""
+    from esvo_amd import calib, synth
+    from oracle import oracle as O
+    rig = calib.dataset_rig("upenn")
+    st = synth.make_stream(rig, 8000, 0.2, 0.16, 1.0, seed=7, speed=1.0)
+    t = st.t0_ns + int(0.1e9)
+    ts = O.OracleTS(rig.width, rig.height)
+    ts.push(st.ev_left[st.ns_left < t])
+    L = ts.render(t, map_x=rig.left.map_x, map_y=rig.left.map_y)
+    u, v, rho = st.true_inv_depth_image(t)
+    ok = (u >= 10) & (u < rig.width - 10) & (v >= 10) & (v < rig.height - 10)
+    Tw = st.pose(t)
+    K = np.array(rig.left.P).reshape(3, 4)[:, :3]
+    pc = (np.linalg.inv(K) @ np.stack([u[ok], v[ok], np.ones(ok.sum())])) / rho[ok]
+    pw = ((Tw[:3, :3] @ pc).T + Tw[:3, 3])[:900].astype(np.float32)
+    return rig, L, pw, st.pose(t - 20_000_000), st.pose(t)
+
+
+def make_track():
+    """RegProblemLM::setProblem / operator() / df (RegProblemLM.cpp:26-269) on the oracle's negated blurred Time Surface and
+    its Sobel derivatives (OpenCV products, injected: oracle/ref_harness_track.cpp)"""
+    from oracle import oracle as O
+    rig, L, pw, T_ref, T_left = track_inputs()
+    ot = O.OracleTracker(rig)
+    ot.set_current(L, 5)
+    neg, du, dv = ot.images()
+    out = dict(ts_left=L, xyz_world=pw, T_world_ref=T_ref, T_world_left=T_left)
+    for norm, huber in (("huber", True), ("l2", False)):
+        rt = R.RefTracker(rig, huber=huber, huber_threshold=50.0, max_points=700)
+        order, Rm, tv = rt.set_problem(neg, du, dv, pw, T_ref, T_left, seed=3)
+        out["order"], out["n"], out["R"], out["t"] = order, rt.n, Rm, tv
+        xs = [np.zeros(6), np.array([1e-3, -2e-3, 5e-4, 2e-3, -1e-3, 3e-3]), np.array([-4e-3, 1e-3, 2e-3, -5e-3, 4e-3, 1e-3])]
+        for i, x in enumerate(xs):
+            f, Tw = rt.residuals(100, 300, x)
+            out[f"{norm}_x{i}"], out[f"{norm}_f{i}"], out[f"{norm}_T{i}"] = x, f, Tw
+        out[f"{norm}_f_tail"], out[f"{norm}_T_tail"] = rt.residuals(600, 300, None)   # a batch cut short by the point count
+        out[f"{norm}_J"] = rt.jacobian(100, 300)
+    path = os.path.join(HERE, "ref_track.npz")
+    np.savez_compressed(path, **out)
+    print("track", os.path.getsize(path) // 1024, "KiB")
+
+
 if __name__ == "__main__":
     assert R.available(), "needs /root/reference (build container only)"
     names = [a for a in sys.argv[1:] if not a.startswith("-")] or list(S.SCENARIOS)
     for n in names:
         make(n)
     make_units()
+    make_track()

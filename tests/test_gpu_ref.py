@@ -67,3 +67,27 @@ def test_gpu_chain_equals_canonical_oracle(name):
             assert np.array_equal(ra["points"][f], rb["points"][f]), f
         same_map(ra["map"], rb["map"], p_cam_rtol=0.0)
     dev.close()
+
+
+def test_gpu_tracker_functor_equals_reference_source():
+    """esvo_track_residuals / esvo_track_jacobian against RegProblemLM::operator() / df compiled from the reference's own
+    source (tests/golden/ref_track.npz, oracle/ref_harness_track.cpp): bit for bit."""
+    from esvo_amd import calib, lib, params
+    from test_ref_pin import _tracker_on_fixture
+    rig = calib.dataset_rig("upenn")
+    p, _ = params.make_params(params.PRESETS["mapping_upenn"], rig)
+    dev = lib.Esvo(p, rig, device=0)
+
+    class Adapter:
+        def set_current(self, ts, k): dev.track_set_current(ts, k)
+        def set_reference(self, xyz, T): dev.track_set_reference(xyz, T)
+        def residuals(self, T, off, cnt, huber=True, huber_threshold=50.0): return dev.track_residuals(T, off, cnt, huber, huber_threshold)
+        def jacobian(self, R, t, off, cnt): return dev.track_jacobian(R, t, off, cnt)
+
+    n = 0
+    for key, got, want in _tracker_on_fixture(Adapter):
+        assert got.shape == want.shape, key
+        assert np.array_equal(got, want), key
+        n += 1
+    assert n == 10
+    dev.close()

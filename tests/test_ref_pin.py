@@ -171,3 +171,53 @@ def test_live_reference_reproduces_fixture(name):
         assert np.array_equal(x["points"]["inv_depth"], g[f"points{k}"]["inv_depth"])
         assert x["nf"] == int(g[f"nf{k}"])
         same_map(x["map"], g[f"map{k}"], p_cam_rtol=0.0)
+
+
+def _tracker_on_fixture(make_tracker):
+    """drive any tracker with the OracleTracker interface on the inputs of ref_track.npz; yields (key, value, reference)"""
+    g = np.load(os.path.join(GOLDEN, "ref_track.npz"))
+    n, order = int(g["n"]), g["order"]
+    tr = make_tracker()
+    tr.set_current(g["ts_left"], 5)
+    tr.set_reference(g["xyz_world"][order][:n], g["T_world_ref"])   # the order the reference's shuffle produced
+    for norm, huber in (("huber", True), ("l2", False)):
+        for i in range(3):
+            yield f"{norm}_f{i}", tr.residuals(g[f"{norm}_T{i}"], 100, 300, huber=huber, huber_threshold=50.0), g[f"{norm}_f{i}"]
+        yield f"{norm}_f_tail", tr.residuals(g[f"{norm}_T_tail"], 600, 300, huber=huber, huber_threshold=50.0), g[f"{norm}_f_tail"]
+        yield f"{norm}_J", tr.jacobian(g["R"], g["t"], 100, 300), g[f"{norm}_J"]
+
+
+def test_tracker_functor_equals_reference_source():
+    """RegProblemLM::operator() and df (RegProblemLM.cpp:91-269, compiled unmodified into oracle/_ref) against the oracle's
+    restatement: residuals (Huber and l2, at x = 0 and at two motions, a batch cut short by the point count) and the
+    Jacobian, bit for bit.  The negated blurred Time Surface and its Sobel derivatives are OpenCV products and are injected."""
+    from esvo_amd import calib
+    rig = calib.dataset_rig("upenn")
+    for key, got, want in _tracker_on_fixture(lambda: O.OracleTracker(rig)):
+        assert got.shape == want.shape, key
+        assert np.array_equal(got, want), key
+    g = np.load(os.path.join(GOLDEN, "ref_track.npz"))
+    assert len(g["huber_f_tail"]) == 100 and np.abs(g["huber_J"]).max() > 1e3   # the cases are not degenerate
+
+
+def test_live_reference_tracker_reproduces_fixture():
+    from oracle import ref as R
+    if not os.path.isdir(os.path.join(R.REFERENCE, "esvo_core", "src")):
+        pytest.skip("reference tree not present (GPU box): the fixtures are the pin")
+    sys_path = os.path.join(GOLDEN)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_ref_fixtures", os.path.join(sys_path, "make_ref_fixtures.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    g = np.load(os.path.join(GOLDEN, "ref_track.npz"))
+    rig, L, pw, T_ref, T_left = m.track_inputs()
+    assert np.array_equal(L, g["ts_left"]) and np.array_equal(pw, g["xyz_world"])
+    ot = O.OracleTracker(rig)
+    ot.set_current(L, 5)
+    neg, du, dv = ot.images()
+    rt = R.RefTracker(rig, huber=True, huber_threshold=50.0, max_points=700)
+    order, Rm, tv = rt.set_problem(neg, du, dv, pw, T_ref, T_left, seed=3)
+    assert np.array_equal(order, g["order"]) and np.array_equal(Rm, g["R"]) and np.array_equal(tv, g["t"])
+    f, Tw = rt.residuals(100, 300, g["huber_x1"])
+    assert np.array_equal(f, g["huber_f1"]) and np.array_equal(Tw, g["huber_T1"])
+    assert np.array_equal(rt.jacobian(100, 300), g["huber_J"])
