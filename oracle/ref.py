@@ -78,6 +78,8 @@ def load():
     lib.ref_zncc_cost.restype = dbl
     lib.ref_zncc_cost.argtypes = [vp, vp, i32, i32]
     lib.ref_mapper_push_frame.argtypes = [vp, vp, sz, vp, sz]
+    lib.ref_mapper_init_from_disparity.restype = sz
+    lib.ref_mapper_init_from_disparity.argtypes = [vp, vp, vp, sz, sz]
     lib.ref_mapper_fuse.restype = sz
     lib.ref_mapper_fuse.argtypes = [vp]
     lib.ref_mapper_tick.restype = sz
@@ -140,6 +142,12 @@ class RefMapper:
 
     def reset(self):
         self.lib.ref_mapper_reset(self.h)
+
+    def init_from_disparity(self, disp16, xy, min_points=500):
+        """InitializationAtTime behind the StereoSGBM call (esvo_Mapping.cpp:455-487) + naive_propagation"""
+        d = np.ascontiguousarray(disp16, np.int16)
+        q = np.ascontiguousarray(xy, np.uint32).reshape(-1, 2)
+        return int(self.lib.ref_mapper_init_from_disparity(self.h, _p(d), _p(q), len(q), int(min_points)))
 
     def set_params(self, params):
         self.params = params

@@ -333,6 +333,43 @@ size_t ref_mapper_fuse(ref_mapper* h) {
   return numFusionCount;
 }
 
+// InitializationAtTime after the StereoSGBM call (esvo_Mapping.cpp:433-492): the disparity image is an OpenCV product and
+// comes in (disp16: W*H int16, disparity * 16); xy: the (x, y) pairs createEdgeMask (:1000-1044, radius 0) derives from
+// the SGM events.  Glue for :455-480 (DepthPoint(x, y) with the arguments in the order the node passes them, update_x,
+// cam2World, the Gaussian update, residual, age, pose), then the reference's DepthFusion::naive_propagation
+// (DepthFusion.cpp:234-288).  Returns the number of SGM depth points; 0 (and no change) below min_points.
+size_t ref_mapper_init_from_disparity(ref_mapper* h, const int16_t* disp16, const uint32_t* xy, size_t n, size_t min_points) {
+  h->frame = std::make_shared<DepthFrame>(h->H, h->W);
+  h->frame->setTransformation(h->obs.second.tr_);
+  std::vector<DepthPoint> vdp_sgm;
+  vdp_sgm.reserve(n);
+  const double var_SGM = pow(0.001, 2);
+  for (size_t i = 0; i < n; i++) {
+    const size_t x = xy[2 * i], y = xy[2 * i + 1];
+    const double disp = disp16[y * (size_t)h->W + x] / 16.0;
+    if (disp < 0) continue;
+    DepthPoint dp(x, y);
+    Eigen::Vector2d p_img(x * 1.0, y * 1.0);
+    dp.update_x(p_img);
+    const double invDepth = disp / (h->camSys->cam_left_ptr_->P_(0, 0) * h->camSys->baseline_);
+    if (invDepth < h->prm.invdepth_min || invDepth > h->prm.invdepth_max) continue;
+    Eigen::Vector3d p_cam;
+    h->camSys->cam_left_ptr_->cam2World(p_img, invDepth, p_cam);
+    dp.update_p_cam(p_cam);
+    dp.update(invDepth, var_SGM);
+    dp.residual() = 0.0;
+    dp.age() = h->prm.age_vis_threshold;
+    Eigen::Matrix<double, 4, 4> T_world_cam = h->obs.second.tr_.getTransformationMatrix();
+    dp.updatePose(T_world_cam);
+    vdp_sgm.push_back(dp);
+  }
+  if (vdp_sgm.size() < min_points) return 0;
+  h->window.push_back(vdp_sgm);
+  h->last_vdp = vdp_sgm;
+  h->fusor->naive_propagation(vdp_sgm, h->frame);
+  return vdp_sgm.size();
+}
+
 // MappingAtTime on already selected (and denoised) events, esvo_Mapping.cpp:261-431
 size_t ref_mapper_tick(ref_mapper* h, const esvo_event_t* ev, size_t n) {
   std::vector<EventMatchPair> vEMP;

@@ -152,6 +152,45 @@ def make_track():
     print("track", os.path.getsize(path) // 1024, "KiB")
 
 
+def sgm_inputs():
+    """observation pair, SGM events and edgelet coordinates of the bootstrap case (tests/test_sgm.py uses the same stream)"""
+    from esvo_amd import calib, params, synth
+    from oracle import oracle as O
+    rig = calib.dataset_rig("upenn")
+    st = synth.make_stream(rig, 8000, 0.35, 0.16, 1.0, seed=20250419, speed=1.0)
+    p, _ = params.make_params(params.PRESETS["mapping_upenn"], rig)
+    t0 = st.t0_ns + int(0.08e9)
+    ts = [O.OracleTS(rig.width, rig.height), O.OracleTS(rig.width, rig.height)]
+    ts[0].push(st.ev_left[st.ns_left < t0])
+    ts[1].push(st.ev_right[st.ns_right < t0])
+    l0 = ts[0].render(t0, map_x=rig.left.map_x, map_y=rig.left.map_y)
+    r0 = ts[1].render(t0, map_x=rig.right.map_x, map_y=rig.right.map_y)
+    ev = st.ev_left[O.select_events_sgm(st.ev_left, t0, p.bm_half_slice_thickness, p.process_event_num)]
+    lut = np.array(rig.left.rect_lut).reshape(rig.height, rig.width, 2)
+    xy = []
+    for e in ev:                                       # createEdgeMask, radius 0 (esvo_Mapping.cpp:1000-1044)
+        xc, yc = int(np.floor(lut[e["y"], e["x"], 0])), int(np.floor(lut[e["y"], e["x"], 1]))
+        if 0 <= xc < rig.width and 0 <= yc < rig.height:
+            xy.append((xc, yc))
+    return rig, p, t0, l0, r0, ev, np.array(xy, np.uint32), st.pose(t0)
+
+
+def make_sgm():
+    """InitializationAtTime behind the StereoSGBM call (esvo_Mapping.cpp:455-487) + DepthFusion::naive_propagation
+    (DepthFusion.cpp:234-327) of the reference, fed with the ORACLE's disparity image (StereoSGBM is OpenCV: unpinned)"""
+    from oracle import oracle as O
+    rig, p, t0, l0, r0, ev, xy, T = sgm_inputs()
+    m = O.OracleMapper(p, rig)
+    m.set_observation(t0, l0, r0, T)
+    n, disp = m.init_sgm(l0, r0, ev, min_points=100)
+    rm = R.RefMapper(p, rig)
+    rm.set_observation(t0, l0, r0, T)
+    nr = rm.init_from_disparity(disp, xy, min_points=100)
+    path = os.path.join(HERE, "ref_sgm.npz")
+    np.savez_compressed(path, n_points=nr, ref_map=rm.get_map(), n_oracle=n)
+    print("sgm", os.path.getsize(path) // 1024, "KiB", n, nr)
+
+
 if __name__ == "__main__":
     assert R.available(), "needs /root/reference (build container only)"
     names = [a for a in sys.argv[1:] if not a.startswith("-")] or list(S.SCENARIOS)
@@ -159,3 +198,4 @@ if __name__ == "__main__":
         make(n)
     make_units()
     make_track()
+    make_sgm()

@@ -221,3 +221,36 @@ def test_live_reference_tracker_reproduces_fixture():
     f, Tw = rt.residuals(100, 300, g["huber_x1"])
     assert np.array_equal(f, g["huber_f1"]) and np.array_equal(Tw, g["huber_T1"])
     assert np.array_equal(rt.jacobian(100, 300), g["huber_J"])
+
+
+def test_sgm_bootstrap_behind_the_disparity_image_matches_reference_source():
+    """esvo_Mapping.cpp:455-487 (glue) + the reference's DepthPoint::update / DepthFusion::naive_propagation, fed with the
+    oracle's disparity image.  The node hands INTEGER pixel coordinates through cam2World -> T_frame_obs -> world2Cam and
+    floors the result: the cell a point lands in depends on the last bit of that round trip (the reference inverts a 4x4
+    matrix per cam2World call, CameraSystem.cpp:121-139; the oracle and the device use the closed form) -- upstream it
+    depends on the Eigen build.  What is pinned: the same SGM points are accepted, and the propagated elements agree up
+    to that one-cell ambiguity with inverse depths equal to 1e-12."""
+    import importlib.util
+    from collections import defaultdict
+    spec = importlib.util.spec_from_file_location("make_ref_fixtures", os.path.join(GOLDEN, "make_ref_fixtures.py"))
+    mk = importlib.util.module_from_spec(spec)
+    sys_argv = list(__import__("sys").argv)
+    spec.loader.exec_module(mk)
+    g = np.load(os.path.join(GOLDEN, "ref_sgm.npz"))
+    rig, p, t0, l0, r0, ev, xy, T = mk.sgm_inputs()
+    m = O.OracleMapper(p, rig)
+    m.set_observation(t0, l0, r0, T)
+    n, _ = m.init_sgm(l0, r0, ev, min_points=100)
+    assert n == int(g["n_points"]) > 500
+    om, rmap = m.get_map(), g["ref_map"]
+    assert abs(len(om) - len(rmap)) < 0.03 * len(rmap)
+    cells = defaultdict(list)
+    for e in om:
+        cells[(int(e["row"]), int(e["col"]))].append(float(e["inv_depth"]))
+    ok = 0
+    for e in rmap:
+        r, c, rho = int(e["row"]), int(e["col"]), float(e["inv_depth"])
+        near = [v for dr in (-1, 0, 1) for dc in (-1, 0, 1) for v in cells.get((r + dr, c + dc), [])]
+        ok += any(abs(v - rho) <= 1e-12 * rho for v in near)
+    assert ok >= 0.95 * len(rmap), (ok, len(rmap))      # the rest lose a cell to a displaced neighbour
+    assert np.allclose(rmap["variance"], 1e-6, rtol=1e-9) and np.allclose(om["variance"], 1e-6, rtol=1e-9)   # boundVariance
