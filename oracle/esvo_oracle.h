@@ -9,12 +9,13 @@
  * PARITY: pinned to REFERENCE SOURCE for the mapper.  oracle/_ref/libesvo_ref.so (make -C oracle ref) is the
  * reference's own EventBM / DepthProblem / DepthProblemSolver / DepthFusion / DepthRegularization / DepthPoint /
  * SmartGrid / CameraSystem sources and the tracker's RegProblemLM / cayley / ResidualItem sources compiled unmodified
- * against the stand-in headers of oracle/ref_shim/;
+ * against the stand-in headers of oracle/ref_shim/ (and libesvo_ref_ts.so: the Time-Surface node class TimeSurface.cpp);
  * tests/golden/ref_*.npz are its outputs and tests/test_ref_pin.py checks this oracle against them stage by stage
- * (block matching, fusion/clean/regularise and the tracker functor's residuals + Jacobian bit-identical, the mapper's
+ * (block matching, fusion/clean/regularise, the tracker functor's residuals + Jacobian and the Time-Surface raster before
+ * its OpenCV stages bit-identical, the mapper's
  * residual functor to 1e-9, the LM end result statistically: DESIGN.md section 2).
  * PARITY UNPINNED for the third-party pieces that are absent from /root/reference and from this image: OpenCV
- * (convertTo/medianBlur/remap/GaussianBlur of the Time-Surface raster, initUndistortRectifyMap, StereoSGBM), Eigen's
+ * (convertTo's rounding / medianBlur / remap / GaussianBlur of the Time-Surface raster, initUndistortRectifyMap, StereoSGBM), Eigen's
  * LevenbergMarquardt + NumericalDiff driver (restated twice, independently: here for n = 1 and in ref_shim for
  * general n), PCL VoxelGrid.  Those are
  * restated from the published algorithms and checked by known-answer and independent-

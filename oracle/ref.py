@@ -308,3 +308,47 @@ class RefTracker:
         out = np.empty(6 * count, np.float64)
         n = self.lib.ref_tracker_jacobian(self.h, int(offset), int(count), _p(out))
         return out[:6 * n].reshape(6, n).T
+
+
+_LIB_TS = os.path.join(_HERE, "_ref", "libesvo_ref_ts.so")
+_lib_ts = None
+
+
+def load_ts():
+    global _lib_ts
+    if _lib_ts is None:
+        if os.path.isdir(os.path.join(REFERENCE, "esvo_core", "src")):
+            build()
+        lib = C.CDLL(_LIB_TS)
+        lib.ref_ts_create.restype = C.c_void_p
+        lib.ref_ts_create.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int, C.c_int]
+        lib.ref_ts_destroy.argtypes = [C.c_void_p]
+        lib.ref_ts_push.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        lib.ref_ts_render.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
+        _lib_ts = lib
+    return _lib_ts
+
+
+class RefTS:
+    """The reference's Time-Surface node class (esvo_time_surface/src/TimeSurface.cpp): eventsCallback + createTimeSurfaceAtTime
+    (BACKWARD mode).  render() returns the f64 image the node hands to cv::Mat::convertTo(CV_8U); OpenCV's rounding, median
+    filter and remap are not part of the build."""
+
+    def __init__(self, width, height, decay_ms=30.0, ignore_polarity=True, queue_len=20):
+        self.lib = load_ts()
+        self.W, self.H = width, height
+        self.h = self.lib.ref_ts_create(width, height, float(decay_ms), int(bool(ignore_polarity)), int(queue_len))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.ref_ts_destroy(self.h)
+            self.h = None
+
+    def push(self, ev):
+        ev = np.ascontiguousarray(ev, dtype=EVENT_DTYPE)
+        self.lib.ref_ts_push(self.h, _p(ev), len(ev))
+
+    def render(self, t_ns):
+        out = np.empty((self.H, self.W), np.float64)
+        self.lib.ref_ts_render(self.h, int(t_ns), _p(out))
+        return out

@@ -191,6 +191,38 @@ def make_sgm():
     print("sgm", os.path.getsize(path) // 1024, "KiB", n, nr)
 
 
+def ts_inputs():
+    from esvo_amd import calib, synth
+    rig = calib.dataset_rig("upenn")
+    st = synth.make_stream(rig, 6000, 0.12, 0.16, 1.0, seed=11, speed=1.0)
+    return rig, st
+
+
+def make_ts():
+    """TimeSurface::eventsCallback + createTimeSurfaceAtTime (TimeSurface.cpp:52-152, 403-425; EventQueueMat of
+    TimeSurface.h:28-96) on 1 ms messages: per-pixel queues of 20 and of 3 events, renders at the newest stamp and at stamps
+    5 and 11 ms EARLIER than events already inserted (getMostRecentEventBeforeT walks the queue back).  Stored: the f64
+    images the node hands to convertTo(CV_8U), rounded as convertTo rounds, and their f64 sums."""
+    rig, st = ts_inputs()
+    out = {}
+    for ql in (20, 3):
+        ts = R.RefTS(rig.width, rig.height, 30.0, True, ql)
+        done = 0
+        for k in range(1, 9):
+            tk = st.t0_ns + k * 12_000_000
+            hi = int(np.searchsorted(st.ns_left, tk))
+            ts.push(st.ev_left[done:hi])
+            done = hi
+            for j, back in enumerate((0, 5_000_000, 11_000_000)):
+                img = ts.render(tk - back)
+                # cv::Mat::convertTo(CV_8U) = saturate_cast<uchar>(cvRound(v)), round half to even (OpenCV: not in the build)
+                out[f"q{ql}_k{k}_b{j}"] = np.clip(np.rint(img), 0, 255).astype(np.uint8)
+                out[f"q{ql}_k{k}_b{j}_sum"] = float(img.sum())
+    path = os.path.join(HERE, "ref_ts.npz")
+    np.savez_compressed(path, **out)
+    print("ts", os.path.getsize(path) // 1024, "KiB")
+
+
 if __name__ == "__main__":
     assert R.available(), "needs /root/reference (build container only)"
     names = [a for a in sys.argv[1:] if not a.startswith("-")] or list(S.SCENARIOS)
@@ -199,3 +231,4 @@ if __name__ == "__main__":
     make_units()
     make_track()
     make_sgm()
+    make_ts()

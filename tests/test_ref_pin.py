@@ -254,3 +254,54 @@ def test_sgm_bootstrap_behind_the_disparity_image_matches_reference_source():
         ok += any(abs(v - rho) <= 1e-12 * rho for v in near)
     assert ok >= 0.95 * len(rmap), (ok, len(rmap))      # the rest lose a cell to a displaced neighbour
     assert np.allclose(rmap["variance"], 1e-6, rtol=1e-9) and np.allclose(om["variance"], 1e-6, rtol=1e-9)   # boundVariance
+
+
+def _ts_cases():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_ref_fixtures", os.path.join(GOLDEN, "make_ref_fixtures.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    rig, st = mk.ts_inputs()
+    for ql in (20, 3):
+        done = 0
+        for k in range(1, 9):
+            tk = st.t0_ns + k * 12_000_000
+            hi = int(np.searchsorted(st.ns_left, tk))
+            yield ql, k, tk, st.ev_left[done:hi], rig
+            done = hi
+
+
+def test_time_surface_raster_equals_reference_source():
+    """TimeSurface::eventsCallback / createTimeSurfaceAtTime and EventQueueMat (esvo_time_surface, compiled unmodified into
+    oracle/_ref/libesvo_ref_ts.so) against the oracle's raster BEFORE the OpenCV stages (median filter, remap): the u8 image
+    after convertTo's rounding, per-pixel queues of 20 and of 3 events, render stamps at and before the newest events."""
+    g = np.load(os.path.join(GOLDEN, "ref_ts.npz"))
+    ts, cur = None, None
+    n = 0
+    for ql, k, tk, chunk, rig in _ts_cases():
+        if cur != ql:
+            ts, cur = O.OracleTS(rig.width, rig.height, queue_len=ql), ql
+        ts.push(chunk)
+        for j, back in enumerate((0, 5_000_000, 11_000_000)):
+            _, pre = ts.render(tk - back, decay_ms=30.0, ignore_polarity=True, median_k=0, want_prefilter=True)
+            assert np.array_equal(pre, g[f"q{ql}_k{k}_b{j}"]), (ql, k, j)
+            n += 1
+    assert n == 48
+    # the short queue really loses events that the long one still finds (the cases differ)
+    assert not np.array_equal(g["q20_k8_b2"], g["q3_k8_b2"])
+
+
+def test_live_reference_time_surface_reproduces_fixture():
+    from oracle import ref as R
+    if not os.path.isdir(os.path.join(R.REFERENCE, "esvo_core", "src")):
+        pytest.skip("reference tree not present (GPU box): the fixtures are the pin")
+    g = np.load(os.path.join(GOLDEN, "ref_ts.npz"))
+    ts, cur = None, None
+    for ql, k, tk, chunk, rig in _ts_cases():
+        if cur != ql:
+            ts, cur = R.RefTS(rig.width, rig.height, 30.0, True, ql), ql
+        ts.push(chunk)
+        if k in (3, 8):
+            img = ts.render(tk - 5_000_000)
+            assert np.array_equal(np.clip(np.rint(img), 0, 255).astype(np.uint8), g[f"q{ql}_k{k}_b1"])
+            assert float(img.sum()) == float(g[f"q{ql}_k{k}_b1_sum"])
