@@ -6,7 +6,9 @@ core/RegProblemLM, tools/cayley, container/ResidualItem}.cpp and SmartGrid.h, co
 oracle/ref_shim/ (oracle/Makefile, target `ref`).  It exists only in the build container (no /root/reference on the
 GPU box): tests/golden/make_ref_fixtures.py records its outputs, tests/test_ref_pin.py compares the oracle with them.
 
-RefMapper has the interface of oracle.OracleMapper, so one script drives both.
+RefMapper has the interface of oracle.OracleMapper, so one script drives both.  RefTracker (RegProblemLM), RefTS
+(libesvo_ref_ts.so: the Time-Surface node class) and RefNode (libesvo_ref_node.so: the esvo_Mapping node object, driven
+through its own callbacks) are built by the same make target.
 """
 import ctypes as C
 import os
@@ -352,3 +354,143 @@ class RefTS:
         out = np.empty((self.H, self.W), np.float64)
         self.lib.ref_ts_render(self.h, int(t_ns), _p(out))
         return out
+
+
+_lib_node = None
+_POSE_FN = C.CFUNCTYPE(C.c_int, C.c_ulonglong, C.POINTER(C.c_double))
+
+
+def load_node():
+    """oracle/_ref/libesvo_ref_node.so: esvo_core/src/esvo_Mapping.cpp (the mapper NODE) + the mapper sources, against the
+    inert ROS / tf / cv_bridge / pcl stand-ins of oracle/ref_shim_node/ (oracle/ref_harness_node.cpp)."""
+    global _lib_node
+    if _lib_node is None:
+        if os.path.isdir(os.path.join(REFERENCE, "esvo_core", "src")):
+            build()
+        lib = C.CDLL(os.path.join(_HERE, "_ref", "libesvo_ref_node.so"))
+        vp, u64, sz = C.c_void_p, C.c_uint64, C.c_size_t
+        lib.ref_node_create.restype = vp
+        lib.ref_node_create.argtypes = [C.c_char_p, vp, vp, vp]
+        lib.ref_node_destroy.argtypes = [vp]
+        lib.ref_node_set_pose_fn.argtypes = [_POSE_FN]
+        lib.ref_node_push_events.argtypes = [vp, vp, sz]
+        lib.ref_node_push_time_surfaces.argtypes = [vp, u64, vp, vp]
+        lib.ref_node_data_transferring.restype = C.c_int
+        lib.ref_node_data_transferring.argtypes = [vp]
+        lib.ref_node_obs_time.restype = u64
+        lib.ref_node_obs_time.argtypes = [vp]
+        for f in ("ref_node_selected_events", "ref_node_matched_events", "ref_node_sgm_events", "ref_node_window", "ref_node_get_map",
+                  "ref_node_newest_frame"):
+            getattr(lib, f).restype = sz
+            getattr(lib, f).argtypes = [vp, vp, sz]
+        lib.ref_node_pose_table.restype = sz
+        lib.ref_node_pose_table.argtypes = [vp, vp, vp, sz]
+        lib.ref_node_mapping_at_time.argtypes = [vp]
+        lib.ref_node_set_status.argtypes = [vp, C.c_char_p]
+        lib.ref_node_preset_param.argtypes = [C.c_char_p, C.c_char_p]
+        lib.ref_node_initialization_at_time.restype = C.c_int
+        lib.ref_node_initialization_at_time.argtypes = [vp, vp]
+        _lib_node = lib
+    return _lib_node
+
+
+class RefNode:
+    """The reference's mapper node object (esvo_Mapping): events enter through eventsCallback, Time-Surface pairs through
+    timeSurfaceCallback, poses through the tf stand-in (pose(t_ns) -> 4x4 T_world_cam or None); tick() = dataTransferring +
+    MappingAtTime as MappingLoop calls them (esvo_Mapping.cpp:146-259) without the threads, the rate and the publishers."""
+
+    def __init__(self, params, rig, pose, extra=None):
+        self.lib = load_node()
+        self.rig = rig
+        for k, v in (extra or {}).items():   # node parameters the POD has no field for, e.g. INIT_SGM_DP_NUM_THRESHOLD
+            self.lib.ref_node_preset_param(k.encode(), str(v).encode())
+
+        def cb(t_ns, out):
+            T = pose(int(t_ns))
+            if T is None:
+                return 0
+            T = np.asarray(T, np.float64).reshape(16)
+            for i in range(16):
+                out[i] = T[i]
+            return 1
+
+        self._cb = _POSE_FN(cb)  # kept alive with the object
+        self.lib.ref_node_set_pose_fn(self._cb)
+        cl, cr = rig.left.as_struct(), rig.right.as_struct()
+        with tempfile.TemporaryDirectory() as d:
+            write_calib_dir(rig, d)
+            self.h = self.lib.ref_node_create(d.encode(), C.addressof(params), C.addressof(cl), C.addressof(cr))
+        self._keep = (cl, cr)
+        self._last_ts = 0
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.ref_node_destroy(self.h)
+            self.h = None
+
+    def push_events(self, ev):
+        ev = np.ascontiguousarray(ev, dtype=EVENT_DTYPE)
+        self.lib.ref_node_push_events(self.h, _p(ev), len(ev))
+
+    def push_time_surfaces(self, t_ns, left, right):
+        left, right = np.ascontiguousarray(left, np.uint8), np.ascontiguousarray(right, np.uint8)
+        self.lib.ref_node_push_time_surfaces(self.h, int(t_ns), _p(left), _p(right))
+        self._last_ts = int(t_ns)
+
+    def push_observation(self, t_ns, left, right, step_ns=100_000):
+        """Time-Surface history so that the pair at t_ns is the SECOND newest (dataTransferring observes that one,
+        esvo_Mapping.cpp:503-506) behind ten older ones (the node waits for a history of > 10, :497)."""
+        for tt in [t_ns - (11 - i) * step_ns for i in range(1, 11)] + [t_ns, t_ns + step_ns]:
+            if tt > self._last_ts:
+                self.push_time_surfaces(tt, left, right)
+
+    def data_transferring(self):
+        return bool(self.lib.ref_node_data_transferring(self.h))
+
+    def obs_time(self):
+        return int(self.lib.ref_node_obs_time(self.h))
+
+    def _indices(self, fn, cap=1 << 20):
+        idx = np.empty(cap, np.uint32)
+        n = fn(self.h, _p(idx), cap)
+        return idx[:n].copy()
+
+    def selected_events(self):
+        return self._indices(self.lib.ref_node_selected_events)
+
+    def matched_events(self):
+        return self._indices(self.lib.ref_node_matched_events)
+
+    def pose_table(self, cap=4096):
+        stamps, poses = np.empty(cap, np.uint64), np.empty((cap, 4, 4), np.float64)
+        n = self.lib.ref_node_pose_table(self.h, _p(stamps), _p(poses), cap)
+        return stamps[:n].copy(), poses[:n].copy()
+
+    def mapping_at_time(self):
+        self.lib.ref_node_mapping_at_time(self.h)
+
+    def set_status(self, status):
+        """ESVO_System_Status_ and the /ESVO_SYSTEM_STATUS parameter: "INITIALIZATION" or "WORKING" """
+        self.lib.ref_node_set_status(self.h, status.encode())
+
+    def sgm_events(self):
+        return self._indices(self.lib.ref_node_sgm_events)
+
+    def initialization_at_time(self, disp16):
+        """InitializationAtTime (esvo_Mapping.cpp:433-492) with disp16 standing in for StereoSGBM::compute's output"""
+        d = np.ascontiguousarray(disp16, np.int16)
+        return bool(self.lib.ref_node_initialization_at_time(self.h, _p(d)))
+
+    def window(self):
+        return self._indices(self.lib.ref_node_window, 256).tolist()
+
+    def _points(self, fn):
+        out = np.zeros(self.rig.width * self.rig.height, DEPTH_POINT_DTYPE)
+        n = fn(self.h, _p(out), len(out))
+        return out[:n].copy()
+
+    def newest_frame(self):
+        return self._points(self.lib.ref_node_newest_frame)
+
+    def get_map(self):
+        return self._points(self.lib.ref_node_get_map)

@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
+#include <memory>
 #include <vector>
 
 #define CV_MAJOR_VERSION 4
@@ -23,6 +24,8 @@
 
 namespace esvo_ref_shim {
 struct Injected {
+  const short* disparity = nullptr;  // what the stand-in StereoSGBM::compute returns (node build: InitializationAtTime)
+
   const float* lut[2] = {nullptr, nullptr};     // per camera: 2*W*H, what undistortPoints returns for every raw pixel
   const uint8_t* mask[2] = {nullptr, nullptr};  // per camera: W*H 0/255, the thresholded remap of the all-ones image
                                                 // (NULL: all valid)
@@ -33,6 +36,7 @@ struct Injected {
 inline Injected& inject() { static Injected g; return g; }
 }  // namespace esvo_ref_shim
 
+typedef unsigned char uchar;
 namespace cv {
 enum { INTER_LINEAR = 1, THRESH_BINARY = 0 };
 
@@ -47,6 +51,7 @@ struct Point2f {
   Point2f(float x_, float y_) : x(x_), y(y_) {}
 };
 
+struct Scalar { double v0 = 0; Scalar() {} Scalar(double a) : v0(a) {} Scalar(double a, double, double) : v0(a) {} };
 // dense 2-D image, one channel, stored as doubles whatever the nominal type
 class Mat {
  public:
@@ -54,14 +59,19 @@ class Mat {
   std::vector<double> v;
   Mat() {}
   Mat(int r, int c, int t) : rows(r), cols(c), type_(t), v((size_t)r * c, 0.0) {}
+  Mat(Size s, int t, Scalar sc = Scalar()) : rows(s.height), cols(s.width), type_(t), v((size_t)s.height * s.width, sc.v0) {}
+  template <class T> double& at(int r, int c) { return v[(size_t)r * cols + c]; }
+  template <class T> double at(int r, int c) const { return v[(size_t)r * cols + c]; }
+  Mat clone() const { return *this; }
+  bool empty() const { return v.empty(); }
   static Mat ones(int r, int c, int t) { Mat m(r, c, t); m.v.assign(m.v.size(), 1.0); return m; }
   static Mat zeros(int r, int c, int t) { return Mat(r, c, t); }
   double& at(int r, int c) { return v[(size_t)r * cols + c]; }
   double at(int r, int c) const { return v[(size_t)r * cols + c]; }
-  void convertTo(Mat& dst, int t) const {
+  void convertTo(Mat& dst, int t, double alpha = 1.0) const {
     Mat o(rows, cols, t);
     for (size_t i = 0; i < v.size(); ++i) {
-      double x = v[i];
+      double x = v[i] * alpha;
       if (t == CV_8U) { x = std::nearbyint(x); x = x < 0 ? 0 : (x > 255 ? 255 : x); }
       o.v[i] = x;
     }
@@ -119,6 +129,46 @@ inline double threshold(const Mat& src, Mat& dst, double thresh, double maxval, 
 }
 inline void GaussianBlur(const Mat&, Mat&, Size, double) { std::abort(); }
 inline void Sobel(const Mat&, Mat&, int, int, int) { std::abort(); }
+
+// ---- node build (esvo_Mapping.cpp): stand-ins, NOT restatements of OpenCV ----------------------------------------
+// medianBlur(3) on a 0/255 event mask (createDenoisingMask): 3x3 median, borders replicated
+inline void medianBlur(const Mat& src, Mat& dst, int k) {
+  if (k != 3) std::abort();
+  Mat o(src.rows, src.cols, src.type_);
+  for (int y = 0; y < src.rows; ++y)
+    for (int x = 0; x < src.cols; ++x) {
+      double w[9];
+      int n = 0;
+      for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+          const int yy = y + dy < 0 ? 0 : (y + dy >= src.rows ? src.rows - 1 : y + dy);
+          const int xx = x + dx < 0 ? 0 : (x + dx >= src.cols ? src.cols - 1 : x + dx);
+          w[n++] = src.v[(size_t)yy * src.cols + xx];
+        }
+      for (int i = 1; i < 9; ++i) { const double t = w[i]; int j = i - 1; while (j >= 0 && w[j] > t) { w[j + 1] = w[j]; --j; } w[j + 1] = t; }
+      o.v[(size_t)y * src.cols + x] = w[4];
+    }
+  dst = o;
+}
+template <class T> struct Ptr {
+  std::shared_ptr<T> p;
+  Ptr() {}
+  Ptr(std::shared_ptr<T> q) : p(q) {}
+  T* operator->() const { return p.get(); }
+  explicit operator bool() const { return (bool)p; }
+};
+// the disparity image comes from the harness (esvo_ref_shim::inject().disparity: W*H int16, disparity * 16)
+struct StereoSGBM {
+  static Ptr<StereoSGBM> create(int, int, int, int = 0, int = 0, int = 0, int = 0, int = 0, int = 0, int = 0, int = 0) {
+    return Ptr<StereoSGBM>(std::make_shared<StereoSGBM>());
+  }
+  void compute(const Mat& left, const Mat&, Mat& disp) const {
+    disp = Mat(left.rows, left.cols, CV_64F);
+    const short* d = esvo_ref_shim::inject().disparity;
+    if (!d) std::abort();
+    for (size_t i = 0; i < disp.v.size(); ++i) disp.v[i] = (double)d[i];
+  }
+};
 
 namespace fisheye {
 inline void undistortPoints(const Mat_<Point2f>& src, Mat_<Point2f>& dst, const Mat&, const Mat&, const Mat&, const Mat&) {

@@ -1,0 +1,1 @@
+#include <message_filters/subscriber.h>

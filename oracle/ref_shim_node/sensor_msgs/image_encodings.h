@@ -1,0 +1,1 @@
+#include <sensor_msgs/Image.h>

@@ -13,6 +13,9 @@ What the fixtures pin, and what they cannot:
     stand-in is a second, independent MINPACK restatement), Eigen's 4x4 inverse (cofactor form in the stand-in),
     OpenCV's calibration maps / remap / median / Gaussian (inputs here, computed by esvo_amd/calib.py and the oracle).
 
+ref_node.npz comes from the mapper NODE object (esvo_Mapping.cpp compiled unmodified, oracle/ref_harness_node.cpp) fed
+through its callbacks: what dataTransferring / MappingAtTime / InitializationAtTime do around the classes above.
+
     python tests/golden/make_ref_fixtures.py
 """
 import os
@@ -223,6 +226,107 @@ def make_ts():
     print("ts", os.path.getsize(path) // 1024, "KiB")
 
 
+NODE_SCENARIOS = ("dsec", "hkust")   # the two whose preset is the Mapping node's (upenn / rpg follow esvo_MVStereo)
+NODE_MAP_FIELDS = ("row", "col", "age", "inv_depth", "scale2", "nu", "variance", "residual", "x")
+
+
+def map_digest(mp):
+    """sha256 over the list order and every field of a DepthMap dump that the mapper node defines"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in NODE_MAP_FIELDS:
+        h.update(np.ascontiguousarray(mp[f]).tobytes())
+    return np.frombuffer(h.digest(), np.uint8).copy()
+
+
+def run_node(sc, ticks, st, regularization):
+    """the reference's esvo_Mapping node object on a scenario: the whole left stream through eventsCallback, the tick's
+    Time-Surface pair through timeSurfaceCallback, poses through the tf stand-in, then dataTransferring + MappingAtTime"""
+    import copy
+    p = copy.copy(sc.params)
+    p.regularization = int(regularization)
+    node = R.RefNode(p, sc.rig, st.pose)
+    node.push_events(st.ev_left)
+    out = []
+    for tk in ticks:
+        node.push_observation(tk["t"], tk["tsL"], tk["tsR"])
+        assert node.data_transferring()
+        sel = node.selected_events()
+        stamps, poses = node.pose_table()
+        node.mapping_at_time()
+        out.append(dict(obs_t=node.obs_time(), sel=sel, matched=node.matched_events(), stamps=stamps, poses=poses,
+                        window=np.array(node.window(), np.uint32), frame=node.newest_frame(), map=node.get_map()))
+    return out
+
+
+def node_init():
+    """the node while ESVO_System_Status_ is INITIALIZATION: dataTransferring (identity pose :508-513, the SGM events
+    :538-552) and InitializationAtTime (:433-492) with the ORACLE's disparity image standing in for StereoSGBM::compute"""
+    from esvo_amd import synth
+    from oracle import oracle as O
+    rig, p, t0, l0, r0, ev, xy, _ = sgm_inputs()
+    st = synth.make_stream(rig, 8000, 0.35, 0.16, 1.0, seed=20250419, speed=1.0)   # the stream of sgm_inputs()
+    m = O.OracleMapper(p, rig)
+    m.set_observation(t0, l0, r0, np.eye(4))
+    _, disp = m.init_sgm(l0, r0, ev, min_points=100)
+    node = R.RefNode(p, rig, st.pose, extra={"INIT_SGM_DP_NUM_THRESHOLD": 100})
+    node.set_status("INITIALIZATION")
+    node.push_events(st.ev_left)
+    node.push_observation(t0, l0, r0)
+    assert node.data_transferring() and node.obs_time() == t0
+    sel = node.sgm_events()
+    assert st.ev_left[sel].tobytes() == np.ascontiguousarray(ev).tobytes()
+    assert node.initialization_at_time(disp)
+    mp = node.get_map()
+    # oracle/ref_harness.cpp's restatement of the node's glue (:455-480), same disparity, identity pose: identical
+    rm = R.RefMapper(p, rig)
+    rm.set_observation(t0, l0, r0, np.eye(4))
+    rm.init_from_disparity(disp, xy, min_points=100)
+    ref = rm.get_map()
+    assert len(mp) == len(ref) and all(np.array_equal(mp[f], ref[f]) for f in NODE_MAP_FIELDS + ("p_cam",))
+    print("node init", len(sel), len(mp))
+    return dict(init_sel=sel, init_row=mp["row"].astype(np.uint16), init_col=mp["col"].astype(np.uint16),
+                init_inv_depth=mp["inv_depth"], init_variance=mp["variance"])
+
+
+def make_node():
+    """esvo_Mapping.cpp itself (eventsCallback :669-703, timeSurfaceCallback :718-760, dataTransferring :494-600, getPoseAt
+    :602-667, MappingAtTime :261-431, createDenoisingMask / extractDenoisedEvents :975-998, 1046-1062) compiled unmodified
+    (oracle/ref_harness_node.cpp, oracle/ref_shim_node/).  Recorded without the regulariser: with it the node reads erased
+    list elements through the grid, which no restatement can reproduce; the regulariser is pinned on
+    defined input by ref_<scenario>.npz."""
+    out = {}
+    for name in NODE_SCENARIOS:
+        sc = S.Scenario(name)
+        ticks, st = sc.inputs(), sc.stream()
+        g = np.load(os.path.join(HERE, f"ref_{name}.npz"))
+        res = run_node(sc, ticks, st, regularization=False)
+        res_reg = run_node(sc, ticks, st, regularization=True)
+        out[f"{name}_n_ticks"] = len(ticks)
+        for k, (tk, r, rr) in enumerate(zip(ticks, res, res_reg)):
+            # the node's virtual-view poses are the callback's answers at the stamps it chose: only the stamps are the node's
+            assert np.array_equal(r["poses"], np.asarray(tk["poses"]).reshape(-1, 4, 4))
+            # the frame the node's own BM + LM + culling kept == the frame ref_<name>.npz records from oracle/ref_harness.cpp
+            fr, ref = r["frame"], g[f"points{k}"]
+            assert len(fr) == len(ref) and all(np.array_equal(fr[f], ref[f]) for f in NODE_MAP_FIELDS + ("pose_idx", "p_cam"))
+            # with the regulariser the node differs from the defined-input run only in inverse depths (Appendix A-7)
+            assert all(np.array_equal(rr["map"][f], g[f"map{k}"][f]) for f in NODE_MAP_FIELDS if f != "inv_depth")
+            pre = f"{name}_"
+            out.update({pre + f"obs_t{k}": r["obs_t"], pre + f"sel{k}": r["sel"], pre + f"matched{k}": r["matched"],
+                        pre + f"stamps{k}": r["stamps"], pre + f"window{k}": r["window"], pre + f"map_n{k}": len(r["map"]),
+                        pre + f"map_sha{k}": map_digest(r["map"]),
+                        pre + f"reg_same_inv_depth{k}": int(np.sum(rr["map"]["inv_depth"] == g[f"map{k}"]["inv_depth"]))})
+        last = res[-1]["map"]
+        for f in NODE_MAP_FIELDS:
+            out[f"{name}_last_{f}"] = last[f] if last[f].dtype.kind == "f" else last[f].astype(np.uint16)
+        print("node", name, [(len(r["sel"]), len(r["matched"]), len(r["stamps"]), r["window"].tolist(), len(r["map"]))
+                             for r in res])
+    out.update(node_init())
+    path = os.path.join(HERE, "ref_node.npz")
+    np.savez_compressed(path, **out)
+    print("ref_node.npz", os.path.getsize(path) // 1024, "KiB")
+
+
 if __name__ == "__main__":
     assert R.available(), "needs /root/reference (build container only)"
     names = [a for a in sys.argv[1:] if not a.startswith("-")] or list(S.SCENARIOS)
@@ -232,3 +336,4 @@ if __name__ == "__main__":
     make_track()
     make_sgm()
     make_ts()
+    make_node()

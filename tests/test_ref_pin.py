@@ -231,7 +231,6 @@ def test_sgm_bootstrap_behind_the_disparity_image_matches_reference_source():
     depends on the Eigen build.  What is pinned: the same SGM points are accepted, and the propagated elements agree up
     to that one-cell ambiguity with inverse depths equal to 1e-12."""
     import importlib.util
-    from collections import defaultdict
     spec = importlib.util.spec_from_file_location("make_ref_fixtures", os.path.join(GOLDEN, "make_ref_fixtures.py"))
     mk = importlib.util.module_from_spec(spec)
     sys_argv = list(__import__("sys").argv)
@@ -243,17 +242,43 @@ def test_sgm_bootstrap_behind_the_disparity_image_matches_reference_source():
     n, _ = m.init_sgm(l0, r0, ev, min_points=100)
     assert n == int(g["n_points"]) > 500
     om, rmap = m.get_map(), g["ref_map"]
-    assert abs(len(om) - len(rmap)) < 0.03 * len(rmap)
+    _sgm_maps_agree(om["row"], om["col"], om["inv_depth"], rmap["row"], rmap["col"], rmap["inv_depth"])
+    assert np.allclose(rmap["variance"], 1e-6, rtol=1e-9) and np.allclose(om["variance"], 1e-6, rtol=1e-9)   # boundVariance
+
+
+def _sgm_maps_agree(o_row, o_col, o_rho, r_row, r_col, r_rho):
+    """same propagated elements up to the one-cell ambiguity of the floor, inverse depths equal to 1e-12"""
+    from collections import defaultdict
+    assert abs(len(o_rho) - len(r_rho)) < 0.03 * len(r_rho)
     cells = defaultdict(list)
-    for e in om:
-        cells[(int(e["row"]), int(e["col"]))].append(float(e["inv_depth"]))
+    for r, c, rho in zip(o_row.tolist(), o_col.tolist(), o_rho.tolist()):
+        cells[(r, c)].append(rho)
     ok = 0
-    for e in rmap:
-        r, c, rho = int(e["row"]), int(e["col"]), float(e["inv_depth"])
+    for r, c, rho in zip(r_row.tolist(), r_col.tolist(), r_rho.tolist()):
         near = [v for dr in (-1, 0, 1) for dc in (-1, 0, 1) for v in cells.get((r + dr, c + dc), [])]
         ok += any(abs(v - rho) <= 1e-12 * rho for v in near)
-    assert ok >= 0.95 * len(rmap), (ok, len(rmap))      # the rest lose a cell to a displaced neighbour
-    assert np.allclose(rmap["variance"], 1e-6, rtol=1e-9) and np.allclose(om["variance"], 1e-6, rtol=1e-9)   # boundVariance
+    assert ok >= 0.95 * len(r_rho), (ok, len(r_rho))      # the rest lose a cell to a displaced neighbour
+
+
+def test_initialization_glue_equals_the_reference_node():
+    """The node object while its status is INITIALIZATION (ref_node.npz, init_*): dataTransferring's SGM event list is the
+    oracle's, exactly; InitializationAtTime's map (identity pose, the oracle's disparity image in place of StereoSGBM)
+    equals oracle/ref_harness.cpp's restatement of that glue exactly (asserted at generation) and the oracle's up to the
+    floor's one-cell ambiguity."""
+    import sys
+    sys.path.insert(0, GOLDEN)
+    import make_ref_fixtures as mk
+    from esvo_amd import synth
+    n = np.load(os.path.join(GOLDEN, "ref_node.npz"))
+    rig, p, t0, l0, r0, ev, xy, T = mk.sgm_inputs()
+    st = synth.make_stream(rig, 8000, 0.35, 0.16, 1.0, seed=20250419, speed=1.0)
+    assert np.array_equal(O.select_events_sgm(st.ev_left, t0, p.bm_half_slice_thickness, p.process_event_num), n["init_sel"])
+    m = O.OracleMapper(p, rig)
+    m.set_observation(t0, l0, r0, np.eye(4))
+    m.init_sgm(l0, r0, ev, min_points=100)
+    om = m.get_map()
+    _sgm_maps_agree(om["row"], om["col"], om["inv_depth"], n["init_row"], n["init_col"], n["init_inv_depth"])
+    assert np.allclose(n["init_variance"], 1e-6, rtol=1e-9)
 
 
 def _ts_cases():
@@ -305,3 +330,83 @@ def test_live_reference_time_surface_reproduces_fixture():
             img = ts.render(tk - 5_000_000)
             assert np.array_equal(np.clip(np.rint(img), 0, 255).astype(np.uint8), g[f"q{ql}_k{k}_b1"])
             assert float(img.sum()) == float(g[f"q{ql}_k{k}_b1_sum"])
+
+
+# ---- the mapper NODE (esvo_core/src/esvo_Mapping.cpp compiled unmodified: oracle/ref_harness_node.cpp) ----
+NODE_NAMES = ["dsec", "hkust"]   # the scenarios whose preset is the Mapping node's
+NODE_MAP_FIELDS = ("row", "col", "age", "inv_depth", "scale2", "nu", "variance", "residual", "x")
+
+
+def _map_digest(mp):
+    import hashlib
+    h = hashlib.sha256()
+    for f in NODE_MAP_FIELDS:
+        h.update(np.ascontiguousarray(mp[f]).tobytes())
+    return np.frombuffer(h.digest(), np.uint8)
+
+
+@pytest.mark.parametrize("name", NODE_NAMES)
+def test_data_transfer_and_tick_glue_equal_the_reference_node(name):
+    """ref_node.npz = the reference's esvo_Mapping object fed through its own callbacks.  Pinned exactly:
+      dataTransferring   the observation it picks, the events it selects (indices into the left queue, order), the stamps
+                         of the virtual-view table (getPoseAt at 50 us steps over the slice)
+      MappingAtTime      the events handed to the block matcher (denoising mask + extraction on hkust), the window
+                         policy (frames kept, their sizes), and -- fed the frame the node's own BM + LM kept, which equals
+                         ref_<name>.npz's frame (asserted when the fixture was made) -- every element of the fused and
+                         cleaned DepthMap.
+    Recorded with the regulariser off (the node regularises over erased elements; with it on, the
+    node's map differs from ref_<name>.npz in inverse depths only -- also asserted at generation)."""
+    import copy
+    from esvo_amd import rostime
+    n = np.load(os.path.join(GOLDEN, "ref_node.npz"))
+    g, sc, ticks = load_fixture(name)
+    st = sc.stream()
+    p = copy.copy(sc.params)
+    p.regularization = 0
+    m = O.OracleMapper(p, sc.rig)
+    assert int(n[f"{name}_n_ticks"]) == len(ticks)
+    for k, tk in enumerate(ticks):
+        pre = f"{name}_"
+        assert int(n[pre + f"obs_t{k}"]) == tk["t"]
+        sel = O.select_events(st.ev_left, tk["t"], p.bm_half_slice_thickness, p.process_event_num)
+        assert np.array_equal(sel, n[pre + f"sel{k}"])
+        fed = O.denoise_events(st.ev_left, sel, sc.rig.width, sc.rig.height, p.process_event_num) if sc.denoise else sel
+        assert np.array_equal(fed, n[pre + f"matched{k}"])
+        assert st.ev_left[fed].tobytes() == np.ascontiguousarray(tk["ev"]).tobytes()
+        stamps, _ = rostime.pose_table(st.pose, tk["t"], p.bm_half_slice_thickness)
+        assert np.array_equal(np.asarray(stamps, np.uint64), n[pre + f"stamps{k}"])
+        m.set_observation(tk["t"], tk["raw"][0], tk["raw"][1], tk["T"])
+        m.set_poses(tk["stamps"], tk["poses"])
+        m.push_frame(g[f"points{k}"], tk["poses"])
+        m.fuse()
+        c = m.counters()
+        win = n[pre + f"window{k}"]
+        assert c["window_frames"] == len(win) and c["window_points"] == int(win.sum())
+        mp = m.get_map()
+        assert len(mp) == int(n[pre + f"map_n{k}"])
+        if k == len(ticks) - 1:  # the last map is stored in full, so that a mismatch names the field
+            for f in NODE_MAP_FIELDS:
+                assert np.array_equal(mp[f], n[pre + f"last_{f}"]), f
+        assert np.array_equal(_map_digest(mp), n[pre + f"map_sha{k}"]), k
+        # with the regulariser on, the node agreed with ref_<name>.npz on most inverse depths and on everything else
+        assert int(n[pre + f"reg_same_inv_depth{k}"]) >= 0.9 * len(g[f"map{k}"])
+
+
+@pytest.mark.parametrize("name", NODE_NAMES)
+def test_live_reference_node_reproduces_fixture(name):
+    from oracle import ref as R
+    if not os.path.isdir(os.path.join(R.REFERENCE, "esvo_core", "src")):
+        pytest.skip("reference tree not present (GPU box): the fixtures are the pin")
+    import sys
+    sys.path.insert(0, GOLDEN)
+    import make_ref_fixtures as M
+    n = np.load(os.path.join(GOLDEN, "ref_node.npz"))
+    g, sc, ticks = load_fixture(name)
+    res = M.run_node(sc, ticks, sc.stream(), regularization=False)
+    for k, r in enumerate(res):
+        pre = f"{name}_"
+        assert r["obs_t"] == int(n[pre + f"obs_t{k}"])
+        for f in ("sel", "matched", "stamps", "window"):
+            assert np.array_equal(r[f], n[pre + f"{f}{k}"]), f
+        assert np.array_equal(M.map_digest(r["map"]), n[pre + f"map_sha{k}"])
+        assert all(np.array_equal(r["frame"][f], g[f"points{k}"][f]) for f in NODE_MAP_FIELDS + ("pose_idx", "p_cam"))
