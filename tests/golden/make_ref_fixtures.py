@@ -239,12 +239,19 @@ def map_digest(mp):
     return np.frombuffer(h.digest(), np.uint8).copy()
 
 
-def run_node(sc, ticks, st, regularization):
+# the same node with FUSION_STRATEGY = CONST_POINTS (esvo_Mapping.cpp:341-353): 1.5 x 1000 points keep two or three ~600-point
+# frames, and "window full" (the clean rule, :385) is two frames
+NODE_CONST_POINTS = dict(fusion_strategy=1, max_fusion_points=1000, max_fusion_frames=2)
+
+
+def run_node(sc, ticks, st, regularization, **override):
     """the reference's esvo_Mapping node object on a scenario: the whole left stream through eventsCallback, the tick's
     Time-Surface pair through timeSurfaceCallback, poses through the tf stand-in, then dataTransferring + MappingAtTime"""
     import copy
     p = copy.copy(sc.params)
     p.regularization = int(regularization)
+    for k, v in override.items():
+        setattr(p, k, v)
     node = R.RefNode(p, sc.rig, st.pose)
     node.push_events(st.ev_left)
     out = []
@@ -316,6 +323,15 @@ def make_node():
                         pre + f"stamps{k}": r["stamps"], pre + f"window{k}": r["window"], pre + f"map_n{k}": len(r["map"]),
                         pre + f"map_sha{k}": map_digest(r["map"]),
                         pre + f"reg_same_inv_depth{k}": int(np.sum(rr["map"]["inv_depth"] == g[f"map{k}"]["inv_depth"]))})
+        if name == "dsec":
+            from esvo_amd.abi import FUSION_CONST_POINTS
+            assert NODE_CONST_POINTS["fusion_strategy"] == FUSION_CONST_POINTS
+            res_cp = run_node(sc, ticks, st, regularization=False, **NODE_CONST_POINTS)
+            for k, r in enumerate(res_cp):
+                assert all(np.array_equal(r["frame"][f], g[f"points{k}"][f]) for f in NODE_MAP_FIELDS)
+                out.update({f"dsec_cp_window{k}": r["window"], f"dsec_cp_map_n{k}": len(r["map"]),
+                            f"dsec_cp_map_sha{k}": map_digest(r["map"])})
+            print("node dsec CONST_POINTS", [(r["window"].tolist(), len(r["map"])) for r in res_cp])
         last = res[-1]["map"]
         for f in NODE_MAP_FIELDS:
             out[f"{name}_last_{f}"] = last[f] if last[f].dtype.kind == "f" else last[f].astype(np.uint16)

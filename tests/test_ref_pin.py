@@ -392,6 +392,35 @@ def test_data_transfer_and_tick_glue_equal_the_reference_node(name):
         assert int(n[pre + f"reg_same_inv_depth{k}"]) >= 0.9 * len(g[f"map{k}"])
 
 
+def test_const_points_window_policy_equals_the_reference_node():
+    """the node's FUSION_STRATEGY = CONST_POINTS branch (esvo_Mapping.cpp:341-353) on the dsec frames: frames kept, their
+    sizes, and every element of the fused + cleaned map"""
+    import copy
+    import sys
+    sys.path.insert(0, GOLDEN)
+    import make_ref_fixtures as mk
+    n = np.load(os.path.join(GOLDEN, "ref_node.npz"))
+    g, sc, ticks = load_fixture("dsec")
+    p = copy.copy(sc.params)
+    p.regularization = 0
+    for k, v in mk.NODE_CONST_POINTS.items():
+        setattr(p, k, v)
+    m = O.OracleMapper(p, sc.rig)
+    popped = False
+    for k, tk in enumerate(ticks):
+        m.set_observation(tk["t"], tk["raw"][0], tk["raw"][1], tk["T"])
+        m.set_poses(tk["stamps"], tk["poses"])
+        m.push_frame(g[f"points{k}"], tk["poses"])
+        m.fuse()
+        c, win = m.counters(), n[f"dsec_cp_window{k}"]
+        assert c["window_frames"] == len(win) and c["window_points"] == int(win.sum())
+        popped |= len(win) < k + 1
+        mp = m.get_map()
+        assert len(mp) == int(n[f"dsec_cp_map_n{k}"])
+        assert np.array_equal(_map_digest(mp), n[f"dsec_cp_map_sha{k}"]), k
+    assert popped
+
+
 @pytest.mark.parametrize("name", NODE_NAMES)
 def test_live_reference_node_reproduces_fixture(name):
     from oracle import ref as R
