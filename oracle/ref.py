@@ -356,18 +356,18 @@ class RefTS:
         return out
 
 
-_lib_node = None
+_lib_node = {}
 _POSE_FN = C.CFUNCTYPE(C.c_int, C.c_ulonglong, C.POINTER(C.c_double))
 
 
-def load_node():
+def load_node(mvstereo=False):
     """oracle/_ref/libesvo_ref_node.so: esvo_core/src/esvo_Mapping.cpp (the mapper NODE) + the mapper sources, against the
-    inert ROS / tf / cv_bridge / pcl stand-ins of oracle/ref_shim_node/ (oracle/ref_harness_node.cpp)."""
-    global _lib_node
-    if _lib_node is None:
+    inert ROS / tf / cv_bridge / pcl stand-ins of oracle/ref_shim_node/ (oracle/ref_harness_node.cpp);
+    libesvo_ref_mvstereo.so: the same entry points around esvo_core/src/esvo_MVStereo.cpp."""
+    if _lib_node.get(mvstereo) is None:
         if os.path.isdir(os.path.join(REFERENCE, "esvo_core", "src")):
             build()
-        lib = C.CDLL(os.path.join(_HERE, "_ref", "libesvo_ref_node.so"))
+        lib = C.CDLL(os.path.join(_HERE, "_ref", "libesvo_ref_mvstereo.so" if mvstereo else "libesvo_ref_node.so"))
         vp, u64, sz = C.c_void_p, C.c_uint64, C.c_size_t
         lib.ref_node_create.restype = vp
         lib.ref_node_create.argtypes = [C.c_char_p, vp, vp, vp]
@@ -390,8 +390,8 @@ def load_node():
         lib.ref_node_preset_param.argtypes = [C.c_char_p, C.c_char_p]
         lib.ref_node_initialization_at_time.restype = C.c_int
         lib.ref_node_initialization_at_time.argtypes = [vp, vp]
-        _lib_node = lib
-    return _lib_node
+        _lib_node[mvstereo] = lib
+    return _lib_node[mvstereo]
 
 
 class RefNode:
@@ -399,8 +399,8 @@ class RefNode:
     timeSurfaceCallback, poses through the tf stand-in (pose(t_ns) -> 4x4 T_world_cam or None); tick() = dataTransferring +
     MappingAtTime as MappingLoop calls them (esvo_Mapping.cpp:146-259) without the threads, the rate and the publishers."""
 
-    def __init__(self, params, rig, pose, extra=None):
-        self.lib = load_node()
+    def __init__(self, params, rig, pose, extra=None, mvstereo=False):
+        self.lib = load_node(mvstereo)   # mvstereo: the esvo_MVStereo node object (BM_PLUS_ESTIMATION) instead of esvo_Mapping
         self.rig = rig
         for k, v in (extra or {}).items():   # node parameters the POD has no field for, e.g. INIT_SGM_DP_NUM_THRESHOLD
             self.lib.ref_node_preset_param(k.encode(), str(v).encode())

@@ -10,6 +10,8 @@
 // lookup is answered by the harness's pose function: tf's interpolation is third-party), OpenCV (the calibration
 // products and the StereoSGBM disparity are injected, medianBlur(3) on the denoising mask is a 3x3 median), the
 // publishers (nobody subscribes), Visualization::plot_eventMap (restated below: Visualization.cpp draws with OpenCV).
+// With -DREF_NODE_MVSTEREO the same entry points wrap esvo_core/src/esvo_MVStereo.cpp (+ core/EventMatcher.cpp, linked but
+// unused) in BM_PLUS_ESTIMATION mode -> oracle/_ref/libesvo_ref_mvstereo.so: dataTransferring :567-668, MappingAtTime :244-565.
 // The node's MappingLoop thread leaves at once (ros::ok() is false); the harness calls the stages itself.
 //
 // One known difference from ref_harness.cpp: between SmartGrid::clean and the regulariser the node dereferences grid cells
@@ -30,7 +32,11 @@
 #include <Eigen/Eigen>
 #define private public
 #define protected public
+#ifdef REF_NODE_MVSTEREO   // -DREF_NODE_MVSTEREO: the same entry points around esvo_MVStereo (BM_PLUS_ESTIMATION mode)
+#include <esvo_core/esvo_MVStereo.h>
+#else
 #include <esvo_core/esvo_Mapping.h>
+#endif
 #undef private
 #undef protected
 
@@ -41,6 +47,11 @@
 #include "../include/esvo_hip.h"
 
 using namespace esvo_core;
+#ifdef REF_NODE_MVSTEREO
+typedef esvo_MVStereo NodeClass;
+#else
+typedef esvo_Mapping NodeClass;
+#endif
 
 // ---- Visualization (tools/Visualization.cpp is OpenCV drawing code): only plot_eventMap matters to the mapper ----
 namespace esvo_core {
@@ -61,7 +72,7 @@ void Visualization::plot_eventMap(std::vector<dvs_msgs::Event*>& vEventPtr, cv::
 
 struct ref_node {
   ros::NodeHandle nh, pnh;
-  std::unique_ptr<esvo_Mapping> node;
+  std::unique_ptr<NodeClass> node;
   std::vector<short> disparity;
   int W = 0, H = 0;
 };
@@ -110,15 +121,22 @@ ref_node* ref_node_create(const char* calib_dir, const esvo_params_t* p, const e
   setp("BM_bUpDownConfiguration", p->bm_updown ? 1 : 0);
   for (auto& kv : overrides()) esvo_node_shim::params()[kv.first] = kv.second;
   overrides().clear();
-  h->node.reset(new esvo_Mapping(h->nh, h->pnh));
+#ifdef REF_NODE_MVSTEREO
+  setp("MVStereoMode", 3);  // BM_PLUS_ESTIMATION (esvo_MVStereo.h:43-50), the mode of cfg/mvstereo/*.yaml
+#endif
+  h->node.reset(new NodeClass(h->nh, h->pnh));
+#ifndef REF_NODE_MVSTEREO
   h->node->ESVO_System_Status_ = "WORKING";
   h->nh.setParam("/ESVO_SYSTEM_STATUS", std::string("WORKING"));
+#endif
   return h;
 }
 void ref_node_destroy(ref_node* h) { delete h; }
 void ref_node_set_pose_fn(esvo_node_shim::pose_fn f) { esvo_node_shim::pose_cb() = f; }
 void ref_node_set_status(ref_node* h, const char* s) {
+#ifndef REF_NODE_MVSTEREO
   h->node->ESVO_System_Status_ = s;
+#endif
   h->nh.setParam("/ESVO_SYSTEM_STATUS", std::string(s));
 }
 // esvo_Mapping::eventsCallback (:669-703) on the left queue
@@ -192,7 +210,11 @@ void ref_node_mapping_at_time(ref_node* h) { h->node->MappingAtTime(h->node->TS_
 int ref_node_initialization_at_time(ref_node* h, const int16_t* disp16) {
   h->disparity.assign(disp16, disp16 + (size_t)h->W * h->H);
   esvo_ref_shim::inject().disparity = h->disparity.data();
+#ifndef REF_NODE_MVSTEREO
   return h->node->InitializationAtTime(h->node->TS_obs_.first) ? 1 : 0;
+#else
+  return 0;  // esvo_MVStereo has no bootstrap
+#endif
 }
 size_t ref_node_window(ref_node* h, uint32_t* sizes, size_t cap) {
   size_t k = 0;

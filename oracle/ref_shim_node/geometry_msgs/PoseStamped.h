@@ -10,6 +10,7 @@ struct Quaternion { double x = 0, y = 0, z = 0, w = 1; };
 struct Pose { Point position; Quaternion orientation; };
 struct PoseStamped { std_msgs::Header header; Pose pose; };
 typedef std::shared_ptr<const PoseStamped> PoseStampedConstPtr;
+typedef std::shared_ptr<PoseStamped> PoseStampedPtr;
 struct TransformStamped {};
 }
 #endif

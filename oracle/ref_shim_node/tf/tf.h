@@ -25,6 +25,7 @@ struct Transformer {
   Transformer(bool = true, ros::Duration = ros::Duration()) {}
   bool setTransform(const StampedTransform&) { return true; }
   void clear() {}
+  int getLatestCommonTime(const std::string&, const std::string&, ros::Time& t, std::string*) const { t = ros::Time(); return 0; }
   bool canTransform(const std::string&, const std::string&, const ros::Time& t, std::string* = nullptr) const {
     double T[16];
     return esvo_node_shim::pose_cb() && esvo_node_shim::pose_cb()(t.toNSec(), T) != 0;

@@ -227,6 +227,7 @@ def make_ts():
 
 
 NODE_SCENARIOS = ("dsec", "hkust")   # the two whose preset is the Mapping node's (upenn / rpg follow esvo_MVStereo)
+MVSTEREO_SCENARIOS = ("upenn", "rpg")  # ... and the two that follow esvo_MVStereo
 NODE_MAP_FIELDS = ("row", "col", "age", "inv_depth", "scale2", "nu", "variance", "residual", "x")
 
 
@@ -244,7 +245,7 @@ def map_digest(mp):
 NODE_CONST_POINTS = dict(fusion_strategy=1, max_fusion_points=1000, max_fusion_frames=2)
 
 
-def run_node(sc, ticks, st, regularization, **override):
+def run_node(sc, ticks, st, regularization, mvstereo=False, **override):
     """the reference's esvo_Mapping node object on a scenario: the whole left stream through eventsCallback, the tick's
     Time-Surface pair through timeSurfaceCallback, poses through the tf stand-in, then dataTransferring + MappingAtTime"""
     import copy
@@ -252,7 +253,7 @@ def run_node(sc, ticks, st, regularization, **override):
     p.regularization = int(regularization)
     for k, v in override.items():
         setattr(p, k, v)
-    node = R.RefNode(p, sc.rig, st.pose)
+    node = R.RefNode(p, sc.rig, st.pose, mvstereo=mvstereo)
     node.push_events(st.ev_left)
     out = []
     for tk in ticks:
@@ -337,6 +338,27 @@ def make_node():
             out[f"{name}_last_{f}"] = last[f] if last[f].dtype.kind == "f" else last[f].astype(np.uint16)
         print("node", name, [(len(r["sel"]), len(r["matched"]), len(r["stamps"]), r["window"].tolist(), len(r["map"]))
                              for r in res])
+    # the other node, esvo_MVStereo.cpp (BM_PLUS_ESTIMATION; cleans every tick, selects up to 10 000 events and cuts to
+    # PROCESS_EVENT_NUM in MappingAtTime: :383-405, 496-497, 627-647), on the two scenarios with its presets
+    for name in MVSTEREO_SCENARIOS:
+        sc = S.Scenario(name)
+        ticks, st = sc.inputs(), sc.stream()
+        g = np.load(os.path.join(HERE, f"ref_{name}.npz"))
+        res = run_node(sc, ticks, st, regularization=False, mvstereo=True)
+        res_reg = run_node(sc, ticks, st, regularization=bool(sc.params.regularization), mvstereo=True)
+        out[f"mvs_{name}_n_ticks"] = len(ticks)
+        for k, (tk, r, rr) in enumerate(zip(ticks, res, res_reg)):
+            assert np.array_equal(r["poses"], np.asarray(tk["poses"]).reshape(-1, 4, 4))
+            fr, ref = r["frame"], g[f"points{k}"]
+            assert len(fr) == len(ref) and all(np.array_equal(fr[f], ref[f]) for f in NODE_MAP_FIELDS + ("pose_idx", "p_cam"))
+            assert all(np.array_equal(rr["map"][f], g[f"map{k}"][f]) for f in NODE_MAP_FIELDS if f != "inv_depth")
+            pre = f"mvs_{name}_"
+            out.update({pre + f"obs_t{k}": r["obs_t"], pre + f"sel{k}": r["sel"], pre + f"matched{k}": r["matched"],
+                        pre + f"stamps{k}": r["stamps"], pre + f"window{k}": r["window"], pre + f"map_n{k}": len(r["map"]),
+                        pre + f"map_sha{k}": map_digest(r["map"]),
+                        pre + f"reg_same_inv_depth{k}": int(np.sum(rr["map"]["inv_depth"] == g[f"map{k}"]["inv_depth"]))})
+        print("mvstereo node", name, [(len(r["sel"]), len(r["matched"]), len(r["stamps"]), r["window"].tolist(), len(r["map"]))
+                                      for r in res])
     out.update(node_init())
     path = os.path.join(HERE, "ref_node.npz")
     np.savez_compressed(path, **out)

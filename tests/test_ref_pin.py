@@ -392,6 +392,42 @@ def test_data_transfer_and_tick_glue_equal_the_reference_node(name):
         assert int(n[pre + f"reg_same_inv_depth{k}"]) >= 0.9 * len(g[f"map{k}"])
 
 
+@pytest.mark.parametrize("name", ["upenn", "rpg"])
+def test_data_transfer_and_tick_glue_equal_the_reference_mvstereo_node(name):
+    """the same for esvo_MVStereo.cpp (BM_PLUS_ESTIMATION), whose presets upenn and rpg follow: it selects up to 10 000 events
+    of the slice and cuts to PROCESS_EVENT_NUM in MappingAtTime (:627-647, 383-405), and cleans every tick (:496-497)"""
+    import copy
+    from esvo_amd import rostime
+    n = np.load(os.path.join(GOLDEN, "ref_node.npz"))
+    g, sc, ticks = load_fixture(name)
+    st = sc.stream()
+    p = copy.copy(sc.params)
+    p.regularization = 0
+    assert not p.clean_requires_full_window
+    m = O.OracleMapper(p, sc.rig)
+    pre = f"mvs_{name}_"
+    assert int(n[pre + "n_ticks"]) == len(ticks)
+    for k, tk in enumerate(ticks):
+        assert int(n[pre + f"obs_t{k}"]) == tk["t"]
+        sel = O.select_events(st.ev_left, tk["t"], p.bm_half_slice_thickness, 10000)
+        assert np.array_equal(sel, n[pre + f"sel{k}"])
+        fed = (O.denoise_events(st.ev_left, sel, sc.rig.width, sc.rig.height, p.process_event_num) if sc.denoise
+               else sel[:p.process_event_num])
+        assert np.array_equal(fed, n[pre + f"matched{k}"])
+        assert st.ev_left[fed].tobytes() == np.ascontiguousarray(tk["ev"]).tobytes()
+        stamps, _ = rostime.pose_table(st.pose, tk["t"], p.bm_half_slice_thickness)
+        assert np.array_equal(np.asarray(stamps, np.uint64), n[pre + f"stamps{k}"])
+        m.set_observation(tk["t"], tk["raw"][0], tk["raw"][1], tk["T"])
+        m.set_poses(tk["stamps"], tk["poses"])
+        m.push_frame(g[f"points{k}"], tk["poses"])
+        m.fuse()
+        c, win = m.counters(), n[pre + f"window{k}"]
+        assert c["window_frames"] == len(win) and c["window_points"] == int(win.sum())
+        mp = m.get_map()
+        assert len(mp) == int(n[pre + f"map_n{k}"])
+        assert np.array_equal(_map_digest(mp), n[pre + f"map_sha{k}"]), k
+
+
 def test_const_points_window_policy_equals_the_reference_node():
     """the node's FUSION_STRATEGY = CONST_POINTS branch (esvo_Mapping.cpp:341-353) on the dsec frames: frames kept, their
     sizes, and every element of the fused + cleaned map"""
@@ -421,8 +457,8 @@ def test_const_points_window_policy_equals_the_reference_node():
     assert popped
 
 
-@pytest.mark.parametrize("name", NODE_NAMES)
-def test_live_reference_node_reproduces_fixture(name):
+@pytest.mark.parametrize("name,mvstereo", [("dsec", False), ("hkust", False), ("upenn", True), ("rpg", True)])
+def test_live_reference_node_reproduces_fixture(name, mvstereo):
     from oracle import ref as R
     if not os.path.isdir(os.path.join(R.REFERENCE, "esvo_core", "src")):
         pytest.skip("reference tree not present (GPU box): the fixtures are the pin")
@@ -431,9 +467,9 @@ def test_live_reference_node_reproduces_fixture(name):
     import make_ref_fixtures as M
     n = np.load(os.path.join(GOLDEN, "ref_node.npz"))
     g, sc, ticks = load_fixture(name)
-    res = M.run_node(sc, ticks, sc.stream(), regularization=False)
+    res = M.run_node(sc, ticks, sc.stream(), regularization=False, mvstereo=mvstereo)
     for k, r in enumerate(res):
-        pre = f"{name}_"
+        pre = f"mvs_{name}_" if mvstereo else f"{name}_"
         assert r["obs_t"] == int(n[pre + f"obs_t{k}"])
         for f in ("sel", "matched", "stamps", "window"):
             assert np.array_equal(r[f], n[pre + f"{f}{k}"]), f
