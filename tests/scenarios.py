@@ -32,8 +32,10 @@ SCENARIOS = {
 
 
 class Scenario:
-    def __init__(self, name):
-        s = SCENARIOS[name]
+    def __init__(self, name, n_ticks=None):
+        s = dict(SCENARIOS[name])
+        if n_ticks is not None:   # a longer run of the same scene (the stream's first n_ticks are the fixture's)
+            s["n_ticks"] = n_ticks
         self.name, self.spec = name, s
         self.rig = calib.dataset_rig(s["rig"])
         self.params, self.denoise = params.make_params(params.PRESETS[s["preset"]], self.rig,

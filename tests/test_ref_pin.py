@@ -475,3 +475,51 @@ def test_live_reference_node_reproduces_fixture(name, mvstereo):
             assert np.array_equal(r[f], n[pre + f"{f}{k}"]), f
         assert np.array_equal(M.map_digest(r["map"]), n[pre + f"map_sha{k}"])
         assert all(np.array_equal(r["frame"][f], g[f"points{k}"][f]) for f in NODE_MAP_FIELDS + ("pose_idx", "p_cam"))
+
+
+@pytest.mark.parametrize("name,mvstereo,n_ticks,override", [("hkust", False, 16, {}), ("dsec", False, 12, {}),
+                                                             ("upenn", True, 14, dict(max_fusion_points=800))])
+def test_live_reference_node_long_run_window_churn(name, mvstereo, n_ticks, override):
+    """Build container only: the reference node objects over a longer run than the fixtures hold -- the window fills and
+    rolls several times, ages grow, every tick cleans.  The oracle's fusion is fed the node's own newest frame each tick
+    (so the LM's statistical tolerance stays out) and must reproduce every element of the node's map, tick after tick;
+    its selection / denoising / pose stamps must equal the node's."""
+    from oracle import ref as R
+    if not os.path.isdir(os.path.join(R.REFERENCE, "esvo_core", "src")):
+        pytest.skip("reference tree not present (GPU box): the fixtures are the pin")
+    import copy
+    from esvo_amd import rostime
+    sc = S.Scenario(name, n_ticks=n_ticks)
+    ticks, st = sc.inputs(), sc.stream()
+    p = copy.copy(sc.params)
+    p.regularization = 0
+    for k, v in override.items():   # upenn: CONST_POINTS with a point budget that makes the window roll in 14 ticks
+        setattr(p, k, v)
+    node = R.RefNode(p, sc.rig, st.pose, mvstereo=mvstereo)
+    node.push_events(st.ev_left)
+    m = O.OracleMapper(p, sc.rig)
+    sizes = []
+    for tk in ticks:
+        node.push_observation(tk["t"], tk["tsL"], tk["tsR"])
+        assert node.data_transferring() and node.obs_time() == tk["t"]
+        sel = O.select_events(st.ev_left, tk["t"], p.bm_half_slice_thickness, 10000 if mvstereo else p.process_event_num)
+        assert np.array_equal(node.selected_events(), sel)
+        stamps, poses = node.pose_table()
+        assert np.array_equal(stamps, np.asarray(rostime.pose_table(st.pose, tk["t"], p.bm_half_slice_thickness)[0], np.uint64))
+        node.mapping_at_time()
+        fed = (O.denoise_events(st.ev_left, sel, sc.rig.width, sc.rig.height, p.process_event_num) if sc.denoise
+               else sel[:p.process_event_num])
+        assert np.array_equal(node.matched_events(), fed)
+        m.set_observation(tk["t"], tk["raw"][0], tk["raw"][1], tk["T"])
+        m.set_poses(stamps, poses)
+        m.push_frame(node.newest_frame(), poses)
+        m.fuse()
+        win = node.window()
+        c = m.counters()
+        assert c["window_frames"] == len(win) and c["window_points"] == sum(win)
+        a, b = m.get_map(), node.get_map()
+        assert len(a) == len(b)
+        for f in NODE_MAP_FIELDS:
+            assert np.array_equal(a[f], b[f]), (f, len(sizes))
+        sizes.append(len(win))
+    assert max(sizes) > 1 and any(b <= a for a, b in zip(sizes[2:], sizes[3:]))   # the window rolled
