@@ -25,7 +25,7 @@ u64 ros_time_from_sec(double t) {
   return (u64)sec * 1000000000ull + nsec;
 }
 
-int upload_poses(esvo_context* h, const uint64_t* pose_t_ns, const double* pose_T, size_t m) {
+int upload_poses(esvo_context* h, const uint64_t* pose_t_ns, const double* pose_T, size_t m, u32* d_zero16 = nullptr) {
   if (m > h->max_poses) FAIL(ESVO_ERR_CAPACITY, "pose table larger than max_poses_per_tick");
   // staged through pinned memory (two alternating slots): no host synchronisation on the tick path
   h->pin_slot ^= 1;
@@ -41,7 +41,8 @@ int upload_poses(esvo_context* h, const uint64_t* pose_t_ns, const double* pose_
   h->d_pose_T = h->d_pose_T2[h->pose_buf];
   HIPCHK(hipStreamWaitEvent(h->stream, h->evt[EV_POSE + h->pose_buf * EV_BACK_STRIDE], 0));
   h->d_pose_sec = h->d_pose_T + 16 * m;
-  if (m) launch_upload_words(T, h->d_pose_T, sizeof(double) * 17 * m, h->stream);
+  // d_zero16: the 16 counters of the tick that follows, cleared by the same launch
+  launch_upload_words(T, h->d_pose_T, sizeof(double) * 17 * m, h->stream, d_zero16, 16);
   return ESVO_OK;
 }
 
@@ -311,6 +312,19 @@ int export_map(esvo_context* h, std::vector<esvo_depth_point_t>& out, std::vecto
 }  // namespace esvo_host
 
 // =================================================================================================
+namespace {
+// a new observation goes into the OTHER pair of buffers: an LM stage still in flight keeps reading its own
+// (the one before that has finished: the call that enqueued it completed its predecessor, context.hpp)
+void begin_observation(esvo_context* h) {
+  h->obs_par ^= 1;
+  h->d_obs[0] = h->d_obs2[h->obs_par][0];
+  h->d_obs[1] = h->d_obs2[h->obs_par][1];
+  // (observations set twice between two ticks: the pending tick's LM stage reads this very pair -- write behind it)
+  if (h->tick_pending && h->tk[h->fpar].obs_par == h->obs_par)
+    hipStreamWaitEvent(h->stream, h->evt[EV_CNT + h->fpar * EV_FRONT_STRIDE], 0);
+}
+}  // namespace
+
 extern "C" {
 
 // ---- Mapper: stage-wise ---------------------------------------------------------------------------
@@ -320,14 +334,7 @@ int esvo_map_set_observation(esvo_handle h, uint64_t t_ns, const uint8_t* ts_lef
   HIPCHK(hipSetDevice(h->device));
   const size_t npx = (size_t)h->W * h->H;
   const uint8_t* src[2] = {ts_left, ts_right};
-  // a new observation goes into the OTHER pair of buffers: an LM stage still in flight keeps reading its own
-  // (the one before that has finished: the call that enqueued it completed its predecessor, context.hpp)
-  h->obs_par ^= 1;
-  h->d_obs[0] = h->d_obs2[h->obs_par][0];
-  h->d_obs[1] = h->d_obs2[h->obs_par][1];
-  // (observations set twice between two ticks: the pending tick's LM stage reads this very pair -- write behind it)
-  if (h->tick_pending && h->tk[h->fpar].obs_par == h->obs_par)
-    HIPCHK(hipStreamWaitEvent(h->stream, h->evt[EV_CNT + h->fpar * EV_FRONT_STRIDE], 0));
+  begin_observation(h);
   for (int cam = 0; cam < 2; ++cam) {
     uint8_t* dst = h->prm.smooth_time_surface ? h->d_obs_tmp : h->d_obs[cam];
     if (src[cam]) {
@@ -483,7 +490,8 @@ int select_events(esvo_context* h, uint64_t t_ns, u64* first_out, u32* n_out) {
 
 // phase 0 (front stage): poses, event selection, block matching + LM of the events of this handle's shard
 int tick_phase0(esvo_context* h, uint64_t t_ns, const uint64_t* pose_t_ns, const double* pose_T, size_t m) {
-  int rc = upload_poses(h, pose_t_ns, pose_T, m);
+  // (the counter row of this tick's parity -- last used two ticks ago, collected since -- is cleared with the pose upload)
+  int rc = upload_poses(h, pose_t_ns, pose_T, m, h->d_counters2[h->fpar ^ 1]);
   if (rc) return rc;
   u32 n = 0;
   rc = select_events(h, t_ns, &h->sh_first, &n);
@@ -501,7 +509,6 @@ int tick_phase0(esvo_context* h, uint64_t t_ns, const uint64_t* pose_t_ns, const
   // table buffer) was last read by the back stage two ticks ago
   HIPCHK(hipStreamWaitEvent(h->stream, h->evt[EV_RG1 + h->par * EV_BACK_STRIDE], 0));
   hipEventRecord(h->evt[EV_T0 + h->fpar * EV_FRONT_STRIDE], h->stream);
-  HIPCHK(hipMemsetAsync(h->d_counters, 0, sizeof(u32) * 16, h->stream));
   const u32* sel = nullptr;
   if (h->prm.denoising && n) {
     // Denoising (esvo_Mapping.cpp:282-296): mask from the selected events, keep those on it, in order.
@@ -694,11 +701,26 @@ int finalize_tick_stats(esvo_context* h) {
 
 extern "C" int esvo_map_tick_resident(esvo_handle h, uint64_t t_ns, const double T_world_cam[16], const uint64_t* pose_t_ns,
                                       const double* pose_T, size_t m) {
-  int rc = esvo_ts_render(h, 0, t_ns, nullptr);
-  if (!rc) rc = esvo_ts_render(h, 1, t_ns, nullptr);
-  if (!rc) rc = esvo_map_set_observation(h, t_ns, nullptr, nullptr, T_world_cam);
-  if (!rc) rc = esvo_map_tick(h, t_ns, pose_t_ns, pose_T, m);
-  return rc;
+  if (!h || !T_world_cam || !pose_t_ns || !pose_T) return ESVO_ERR_INVALID_ARG;
+  HIPCHK(hipSetDevice(h->device));
+  // = esvo_ts_render x2 + esvo_map_set_observation + esvo_map_tick with both cameras in one launch per kernel; an
+  // un-smoothed observation is written by the remap itself (no device-to-device copies)
+  begin_observation(h);
+  uint8_t* obs[2] = {h->d_obs[0], h->d_obs[1]};
+  int rc = ts_render_pair(h, t_ns, h->prm.smooth_time_surface ? nullptr : obs);
+  if (rc) {  // nothing was rendered: the previous observation stays current
+    h->obs_par ^= 1;
+    h->d_obs[0] = h->d_obs2[h->obs_par][0];
+    h->d_obs[1] = h->d_obs2[h->obs_par][1];
+    return rc;
+  }
+  if (h->prm.smooth_time_surface)  // createMatchProblem applies GaussianBlurTS(5) when SmoothTimeSurface (EventBM.cpp:68-72)
+    launch_gaussian5_pair(h->d_ts[0], h->d_ts[1], h->d_obs[0], h->d_obs[1], h->W, h->H, h->stream);
+  HIPCHK(hipGetLastError());
+  std::memcpy(h->T_world_obs, T_world_cam, sizeof(double) * 16);
+  h->obs_t_ns = t_ns;
+  h->obs_set = true;
+  return esvo_map_tick(h, t_ns, pose_t_ns, pose_T, m);
 }
 
 extern "C" int esvo_map_tick(esvo_handle h, uint64_t t_ns, const uint64_t* pose_t_ns, const double* pose_T, size_t m) {

@@ -16,9 +16,64 @@ void collect_ts_timing(esvo_context* h, int only) {
       h->stats.ms_ts_render = h->stats.ms_kernel[1] = rd;
       h->stats.sum_ms_kernel[0] += sc;
       h->stats.sum_ms_kernel[1] += rd;
-      h->stats.sum_ms_kernel[7] += 1;
+      h->stats.sum_ms_kernel[7] += (cam == 0 && h->ts_pair_sample) ? 2 : 1;
     }
+    if (cam == 0) h->ts_pair_sample = false;
   }
+}
+
+// Both cameras' surfaces at t_ns with one launch per kernel (scatter segments, decay, median + remap): what two
+// esvo_ts_render calls do, in four launches less.  obs_out[cam] (may be null) receives a second copy of the surface.
+int ts_render_pair(esvo_context* h, uint64_t t_ns, uint8_t* const obs_out[2]) {
+  u64 upto[2];
+  for (int cam = 0; cam < 2; ++cam) {
+    const auto& tsq = h->ts_host[cam];
+    const size_t k = std::lower_bound(tsq.begin(), tsq.end(), (u64)t_ns) - tsq.begin();
+    upto[cam] = h->ring_base[cam] + k;
+    if (upto[cam] < h->scattered[cam])
+      FAIL(ESVO_ERR_STATE, "esvo_ts_render: t_ns precedes events of an earlier render (render times must not decrease; esvo_reset to replay)");
+  }
+  for (int cam = 0; cam < 2; ++cam)
+    if (h->ts_timing_pending[cam] && hipEventQuery(h->evt[EV_R1 + cam * EV_TS_STRIDE]) == hipSuccess) collect_ts_timing(h, cam);
+  hipEventRecord(h->evt[EV_SC0], h->stream);
+  TsScatterSegs g;
+  int n_seg = 0;
+  for (int cam = 0; cam < 2; ++cam) {
+    u64 a = h->scattered[cam];
+    if (upto[cam] <= a) continue;
+    h->scatter_pending_lo[cam] = std::min(h->scatter_pending_lo[cam], a);
+    h->stats.events_scattered[cam] += upto[cam] - a;
+    while (a < upto[cam]) {
+      const u64 slot = a % h->ring_cap;
+      const u64 cnt = std::min<u64>(upto[cam] - a, h->ring_cap - slot);
+      if (n_seg == 4) {  // a range longer than the ring (cannot happen: staging refuses it) -- flush and go on
+        launch_ts_scatter_segs(g, n_seg, h->W, h->H, h->stream);
+        n_seg = 0;
+      }
+      g.ev[n_seg] = h->d_ring[cam] + slot; g.n[n_seg] = (size_t)cnt; g.sae[n_seg] = h->d_sae[cam];
+      ++n_seg;
+      a += cnt;
+    }
+    h->scattered[cam] = upto[cam];
+  }
+  launch_ts_scatter_segs(g, n_seg, h->W, h->H, h->stream);
+  hipEventRecord(h->evt[EV_SC1], h->stream);
+  TsPair c;
+  for (int cam = 0; cam < 2; ++cam) {
+    c.sae[cam] = h->d_sae[cam]; c.fixmap[cam] = h->d_fixmap[cam]; c.out[cam] = h->d_ts[cam];
+    c.out2[cam] = obs_out ? obs_out[cam] : nullptr;
+  }
+  c.raw[0] = h->d_raw; c.raw[1] = h->d_raw1;
+  launch_ts_render_pair(c, h->W, h->H, (u64)t_ns, h->prm.decay_ms / 1000.0, h->prm.ignore_polarity, h->prm.median_blur_kernel_size,
+                        h->stream);
+  hipEventRecord(h->evt[EV_R1], h->stream);
+  HIPCHK(hipGetLastError());
+  h->ts_valid[0] = h->ts_valid[1] = true;
+  h->ts_timing_pending[0] = true;
+  h->ts_pair_sample = true;
+  h->stats.ts_frames[0]++;
+  h->stats.ts_frames[1]++;
+  return ESVO_OK;
 }
 
 }  // namespace esvo_host

@@ -142,7 +142,7 @@ void launch_exclusive_scan_u32(const u32* d_in, u32* d_out, u32* d_total, u32* d
                                hipStream_t s);
 size_t scan_scratch_elems(size_t n);
 // upload of a small pinned host buffer by a kernel (never blocks the host; scan.hip)
-void launch_upload_words(const void* pinned_src, void* d_dst, size_t bytes, hipStream_t s);
+void launch_upload_words(const void* pinned_src, void* d_dst, size_t bytes, hipStream_t s, u32* d_zero = nullptr, u32 n_zero = 0);
 
 // kernels_ts.hip
 void launch_ts_unpack_wire(const uint8_t* wire, size_t n, esvo_event_t* ring, u64 first_slot, u64 ring_cap, hipStream_t s);
@@ -150,6 +150,13 @@ void launch_ts_scatter(const esvo_event_t* d_ev, size_t n, u64* d_sae, int W, in
 void launch_ts_render(const u64* d_sae, const int2* d_fixmap, uint8_t* d_raw, uint8_t* d_out, int W, int H,
                       u64 t_ns, double decay_sec, int ignore_polarity, int median_k, hipStream_t s);
 void launch_gaussian5(const uint8_t* d_in, uint8_t* d_out, int W, int H, hipStream_t s);
+// both cameras per launch (esvo_map_tick_resident): scatter segments, decay + median/remap, blur
+struct TsScatterSegs { const esvo_event_t* ev[4]; size_t n[4]; u64* sae[4]; };
+struct TsPair { const u64* sae[2]; uint8_t* raw[2]; const int2* fixmap[2]; uint8_t* out[2]; uint8_t* out2[2]; };
+void launch_ts_scatter_segs(const TsScatterSegs& g, int n_seg, int W, int H, hipStream_t s);
+void launch_ts_render_pair(const TsPair& c, int W, int H, u64 t_ns, double decay_sec, int ignore_polarity, int median_k,
+                           hipStream_t s);
+void launch_gaussian5_pair(const uint8_t* in0, const uint8_t* in1, uint8_t* out0, uint8_t* out1, int W, int H, hipStream_t s);
 // createDenoisingMask + extractDenoisedEvents (esvo_Mapping.cpp:1046-1072) on the n selected events
 void launch_denoise_flags(const esvo_event_t* ring, u64 first, u64 cap, u32 n, uint8_t* evmap, u32* flags, int W, int H,
                           hipStream_t s);

@@ -74,6 +74,7 @@ struct esvo_context {
   // Time Surface
   u64* d_sae[2] = {nullptr, nullptr};
   uint8_t* d_raw = nullptr;
+  uint8_t* d_raw1 = nullptr;  // the right camera's raw surface when both cameras render in one launch (esvo_map_tick_resident)
   uint8_t* d_ts[2] = {nullptr, nullptr};
   bool ts_valid[2] = {false, false};
   esvo_event_t* d_ring[2] = {nullptr, nullptr};
@@ -223,6 +224,7 @@ struct esvo_context {
   bool evt_ok = false;
   esvo_stats_t stats;
   bool ts_timing_pending[2] = {false, false};
+  bool ts_pair_sample = false;  // the pending sample of camera 0 covers both cameras (pair render)
 };
 
 namespace esvo_host {
@@ -232,6 +234,7 @@ void fill_dev_params(esvo_context* h);
 void set_compute_band(esvo_context* h);
 // api_ts.hip
 void collect_ts_timing(esvo_context* h, int only = -1);
+int ts_render_pair(esvo_context* h, uint64_t t_ns, uint8_t* const obs_out[2]);
 // api_map.hip
 int flush_pending_tick(esvo_context* h);  // completes a lazily finished tick (see esvo_context::TickState)
 int finalize_tick_stats(esvo_context* h);

@@ -17,8 +17,7 @@ namespace esvo {
 // ---- K1 -----------------------------------------------------------------------------------------
 // One thread per event, 16-byte coalesced loads (the reference's in-memory dvs_msgs::Event),
 // 8-byte atomicMax into the SAE.  HBM-bound: 16 B read + 8 B atomic per event.
-__global__ void __launch_bounds__(256) ts_scatter_kernel(const uint4* __restrict__ ev, size_t n, u64* __restrict__ sae,
-                                                         int W, int H) {
+__device__ inline void ts_scatter_range(const uint4* __restrict__ ev, size_t n, u64* __restrict__ sae, int W, int H) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (; i < n; i += stride) {
@@ -30,6 +29,15 @@ __global__ void __launch_bounds__(256) ts_scatter_kernel(const uint4* __restrict
     atomicMax(&sae[(size_t)y * W + x], key);
   }
 }
+__global__ void __launch_bounds__(256) ts_scatter_kernel(const uint4* __restrict__ ev, size_t n, u64* __restrict__ sae,
+                                                         int W, int H) {
+  ts_scatter_range(ev, n, sae, W, H);
+}
+// up to four ring segments (two cameras, each range may wrap the ring once) in one launch: blockIdx.y = segment
+__global__ void __launch_bounds__(256) ts_scatter_segs_kernel(TsScatterSegs g, int W, int H) {
+  const int k = blockIdx.y;
+  ts_scatter_range(reinterpret_cast<const uint4*>(g.ev[k]), g.n[k], g.sae[k], W, H);
+}
 
 void launch_ts_scatter(const esvo_event_t* d_ev, size_t n, u64* d_sae, int W, int H, hipStream_t s) {
   if (n == 0) return;
@@ -38,12 +46,20 @@ void launch_ts_scatter(const esvo_event_t* d_ev, size_t n, u64* d_sae, int W, in
   hipLaunchKernelGGL(ts_scatter_kernel, dim3((u32)blocks), dim3(256), 0, s, reinterpret_cast<const uint4*>(d_ev), n,
                      d_sae, W, H);
 }
+void launch_ts_scatter_segs(const TsScatterSegs& g, int n_seg, int W, int H, hipStream_t s) {
+  size_t n_max = 0;
+  for (int k = 0; k < n_seg; ++k) n_max = n_max > g.n[k] ? n_max : g.n[k];
+  if (n_seg == 0 || n_max == 0) return;
+  size_t blocks = (n_max + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(ts_scatter_segs_kernel, dim3((u32)blocks, (u32)n_seg), dim3(256), 0, s, g, W, H);
+}
 
 // ---- K2a: decay + quantise ------------------------------------------------------------------------
 // TimeSurface.cpp:65-127.  dt is formed like ros::Duration::toSec() (Appendix A-17); the u8
 // conversion is cv::Mat::convertTo = saturate_cast<uchar>(cvRound(v)) = round-half-even.
-__global__ void __launch_bounds__(256) ts_decay_kernel(const u64* __restrict__ sae, uint8_t* __restrict__ raw, int n_px,
-                                                       u64 t_ns, double decay_sec, int ignore_polarity) {
+__device__ inline void ts_decay_px(const u64* __restrict__ sae, uint8_t* __restrict__ raw, int n_px, u64 t_ns,
+                                   double decay_sec, int ignore_polarity) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_px) return;
   const u64 key = sae[i];
@@ -59,6 +75,13 @@ __global__ void __launch_bounds__(256) ts_decay_kernel(const u64* __restrict__ s
   int q = (int)rint(g);
   q = q < 0 ? 0 : (q > 255 ? 255 : q);
   raw[i] = (uint8_t)q;
+}
+__global__ void __launch_bounds__(256) ts_decay_kernel(const u64* __restrict__ sae, uint8_t* __restrict__ raw, int n_px,
+                                                       u64 t_ns, double decay_sec, int ignore_polarity) {
+  ts_decay_px(sae, raw, n_px, t_ns, decay_sec, ignore_polarity);
+}
+__global__ void __launch_bounds__(256) ts_decay_pair_kernel(TsPair c, int n_px, u64 t_ns, double decay_sec, int ignore_polarity) {
+  ts_decay_px(c.sae[blockIdx.y], c.raw[blockIdx.y], n_px, t_ns, decay_sec, ignore_polarity);
 }
 
 // ---- K2b: 3x3 median (BORDER_REPLICATE) fused with the fixed-point bilinear remap --------------------
@@ -84,11 +107,8 @@ __device__ inline int median_tap(const uint8_t* __restrict__ raw, int W, int H, 
 // fixmap[i] = (cvRound(map_x*32), cvRound(map_y*32)): OpenCV's INTER_BITS=5 coordinate
 // quantisation, precomputed once on the host (Appendix B.2).  Weights are the exact 15-bit
 // integers (32-fx)(32-fy)*32 ...; dst = (sum + 16384) >> 15.
-__global__ void __launch_bounds__(256) ts_median_remap_kernel(const uint8_t* __restrict__ raw, const int2* __restrict__ fixmap,
-                                                              uint8_t* __restrict__ out, int W, int H, int median_k) {
-  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (x >= W || y >= H) return;
+__device__ inline int ts_median_remap_px(const uint8_t* __restrict__ raw, const int2* __restrict__ fixmap, int W, int H,
+                                         int median_k, int x, int y) {
   const int i = y * W + x;
   int v;
   if (fixmap) {
@@ -104,7 +124,24 @@ __global__ void __launch_bounds__(256) ts_median_remap_kernel(const uint8_t* __r
   } else {
     v = median_tap(raw, W, H, x, y, median_k);
   }
-  out[i] = (uint8_t)v;
+  return v;
+}
+__global__ void __launch_bounds__(256) ts_median_remap_kernel(const uint8_t* __restrict__ raw, const int2* __restrict__ fixmap,
+                                                              uint8_t* __restrict__ out, int W, int H, int median_k) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= W || y >= H) return;
+  out[y * W + x] = (uint8_t)ts_median_remap_px(raw, fixmap, W, H, median_k, x, y);
+}
+// both cameras (blockIdx.z); out2 (may be null): a second copy of the surface, the mapper's observation when it is not smoothed
+__global__ void __launch_bounds__(256) ts_median_remap_pair_kernel(TsPair c, int W, int H, int median_k) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= W || y >= H) return;
+  const int cam = blockIdx.z;
+  const uint8_t v = (uint8_t)ts_median_remap_px(c.raw[cam], c.fixmap[cam], W, H, median_k, x, y);
+  c.out[cam][y * W + x] = v;
+  if (c.out2[cam]) c.out2[cam][y * W + x] = v;
 }
 
 void launch_ts_render(const u64* d_sae, const int2* d_fixmap, uint8_t* d_raw, uint8_t* d_out, int W, int H, u64 t_ns,
@@ -116,6 +153,13 @@ void launch_ts_render(const u64* d_sae, const int2* d_fixmap, uint8_t* d_raw, ui
                      H, median_k);
 }
 
+void launch_ts_render_pair(const TsPair& c, int W, int H, u64 t_ns, double decay_sec, int ignore_polarity, int median_k,
+                           hipStream_t s) {
+  const int n = W * H;
+  hipLaunchKernelGGL(ts_decay_pair_kernel, dim3((n + 255) / 256, 2), dim3(256), 0, s, c, n, t_ns, decay_sec, ignore_polarity);
+  hipLaunchKernelGGL(ts_median_remap_pair_kernel, dim3((W + 63) / 64, (H + 3) / 4, 2), dim3(256), 0, s, c, W, H, median_k);
+}
+
 // ---- 5x5 Gaussian, [1 4 6 4 1]^2 / 256, BORDER_REFLECT_101, round-to-nearest once ------------------
 __device__ inline int reflect101(int p, int n) {
   if (n == 1) return 0;
@@ -125,7 +169,7 @@ __device__ inline int reflect101(int p, int n) {
   }
   return p;
 }
-__global__ void __launch_bounds__(256) gaussian5_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int W, int H) {
+__device__ inline void gaussian5_px(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int W, int H) {
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
   const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (x >= W || y >= H) return;
@@ -142,8 +186,18 @@ __global__ void __launch_bounds__(256) gaussian5_kernel(const uint8_t* __restric
   int v = (acc + 128) >> 8;
   out[y * W + x] = (uint8_t)(v > 255 ? 255 : v);
 }
+__global__ void __launch_bounds__(256) gaussian5_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int W, int H) {
+  gaussian5_px(in, out, W, H);
+}
+__global__ void __launch_bounds__(256) gaussian5_pair_kernel(const uint8_t* __restrict__ in0, const uint8_t* __restrict__ in1,
+                                                             uint8_t* __restrict__ out0, uint8_t* __restrict__ out1, int W, int H) {
+  gaussian5_px(blockIdx.z ? in1 : in0, blockIdx.z ? out1 : out0, W, H);
+}
 void launch_gaussian5(const uint8_t* d_in, uint8_t* d_out, int W, int H, hipStream_t s) {
   hipLaunchKernelGGL(gaussian5_kernel, dim3((W + 63) / 64, (H + 3) / 4), dim3(256), 0, s, d_in, d_out, W, H);
+}
+void launch_gaussian5_pair(const uint8_t* in0, const uint8_t* in1, uint8_t* out0, uint8_t* out1, int W, int H, hipStream_t s) {
+  hipLaunchKernelGGL(gaussian5_pair_kernel, dim3((W + 63) / 64, (H + 3) / 4, 2), dim3(256), 0, s, in0, in1, out0, out1, W, H);
 }
 
 

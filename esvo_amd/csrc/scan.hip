@@ -92,16 +92,22 @@ __global__ void __launch_bounds__(SCAN_SB) scan_small_kernel(const u32* __restri
 // Small host -> device uploads of the tick path (pose table, frame table) as a KERNEL that reads the pinned host buffer:
 // a kernel launch never blocks the host, whereas hipMemcpyAsync of a few KB was measured to stall its caller for 6-11 ms
 // once per process when a third stream of the handle is busy (the copy engine's queue is shared between the streams).
-__global__ void __launch_bounds__(256) upload_words_kernel(const u32* __restrict__ src, u32* __restrict__ dst, size_t n) {
+// zero (nullable, n_zero <= 256 words): a few counters cleared by the same launch (the tick's counter row)
+__global__ void __launch_bounds__(256) upload_words_kernel(const u32* __restrict__ src, u32* __restrict__ dst, size_t n,
+                                                           u32* __restrict__ zero, u32 n_zero) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+  if (blockIdx.x == 0 && threadIdx.x < n_zero) zero[threadIdx.x] = 0u;
 }
-void launch_upload_words(const void* pinned_src, void* d_dst, size_t bytes, hipStream_t s) {
+void launch_upload_words(const void* pinned_src, void* d_dst, size_t bytes, hipStream_t s, u32* d_zero, u32 n_zero) {
   const size_t n = bytes / 4;  // callers pass multiples of 4 bytes
-  if (n == 0) return;
+  if (n == 0) {
+    if (d_zero && n_zero) hipMemsetAsync(d_zero, 0, sizeof(u32) * n_zero, s);
+    return;
+  }
   size_t blocks = (n + 255) / 256;
   if (blocks > 256) blocks = 256;
   hipLaunchKernelGGL(upload_words_kernel, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const u32*>(pinned_src),
-                     reinterpret_cast<u32*>(d_dst), n);
+                     reinterpret_cast<u32*>(d_dst), n, d_zero, d_zero ? n_zero : 0u);
 }
 
 size_t scan_scratch_elems(size_t n) { return (n + SCAN_TILE - 1) / SCAN_TILE + 1; }
