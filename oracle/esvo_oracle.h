@@ -9,7 +9,9 @@
  * PARITY: pinned to REFERENCE SOURCE for the mapper.  oracle/_ref/libesvo_ref.so (make -C oracle ref) is the
  * reference's own EventBM / DepthProblem / DepthProblemSolver / DepthFusion / DepthRegularization / DepthPoint /
  * SmartGrid / CameraSystem sources and the tracker's RegProblemLM / cayley / ResidualItem sources compiled unmodified
- * against the stand-in headers of oracle/ref_shim/ (and libesvo_ref_ts.so: the Time-Surface node class TimeSurface.cpp);
+ * against the stand-in headers of oracle/ref_shim/ (libesvo_ref_ts.so: the Time-Surface node class TimeSurface.cpp;
+ * libesvo_ref_node.so / libesvo_ref_mvstereo.so: the mapper NODE objects esvo_Mapping.cpp / esvo_MVStereo.cpp driven through
+ * their own callbacks -- event selection, denoising, pose-table stamps, window policy, tick glue, SGM bootstrap glue);
  * tests/golden/ref_*.npz are its outputs and tests/test_ref_pin.py checks this oracle against them stage by stage
  * (block matching, fusion/clean/regularise, the tracker functor's residuals + Jacobian and the Time-Surface raster before
  * its OpenCV stages bit-identical, the mapper's
