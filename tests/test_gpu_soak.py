@@ -11,7 +11,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("args", [["upenn346x260", "3000", "40", "262144"], ["dsec640x480", "5000", "12", "2097152"]])
+@pytest.mark.parametrize("args", [["upenn346x260", "3000", "40", "262144"], ["dsec640x480", "5000", "12", "2097152"],
+                                  ["upenn346x260", "2000", "30", "262144", "resident"], ["dsec640x480", "4000", "8", "2097152", "resident"]])
 def test_every_tick_of_a_long_run_equals_the_oracle(args):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak.py")] + args, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

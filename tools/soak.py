@@ -1,5 +1,5 @@
 """Long run against the oracle: every tick's DepthMap of the device (lazy two-stream pipeline, small event ring that wraps)
-is compared with the canonical CPU oracle's.  usage: python tools/soak.py [workload] [events per tick] [ticks] [ring capacity]"""
+is compared with the canonical CPU oracle's.  usage: python tools/soak.py [workload] [events per tick] [ticks] [ring capacity] [resident: esvo_map_tick_resident instead of the four calls]"""
 import os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
@@ -11,6 +11,7 @@ name = sys.argv[1] if len(sys.argv) > 1 else "upenn346x260"
 n_ev = int(sys.argv[2]) if len(sys.argv) > 2 else 4000
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 100
 ring = int(sys.argv[4]) if len(sys.argv) > 4 else 1 << 17
+resident = len(sys.argv) > 5 and sys.argv[5] == "resident"
 rig, stream, p, ticks = bench.make_workload(name, n, events_cap=n_ev)
 p.event_ring_capacity = ring
 dev = lib.Esvo(p, rig)
@@ -27,9 +28,12 @@ for k, (t, stamps, poses, T) in enumerate(ticks):
         dev.ts_push_events(cam, ev[done[cam]:hi])      # staged tick by tick: the ring wraps
         ts[cam].push(ev[done[cam]:hi])
         done[cam] = hi
-    dev.ts_render(0, t, download=False); dev.ts_render(1, t, download=False)
-    dev.set_observation(t, None, None, T)
-    dev.tick(t, stamps, poses)
+    if resident:   # both cameras per launch; the scatter ranges wrap the ring
+        dev.tick_resident(t, T, stamps, poses)
+    else:
+        dev.ts_render(0, t, download=False); dev.ts_render(1, t, download=False)
+        dev.set_observation(t, None, None, T)
+        dev.tick(t, stamps, poses)
     l = ts[0].render(t, map_x=rig.left.map_x, map_y=rig.left.map_y)
     r = ts[1].render(t, map_x=rig.right.map_x, map_y=rig.right.map_y)
     m.set_observation(t, l, r, T); m.set_poses(stamps, poses)
