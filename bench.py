@@ -186,6 +186,12 @@ def main():
                     help="replay up to the first timed tick on a fresh handle and compare its DepthMap with the CPU oracle's (SHA-1)")
     args = ap.parse_args()
 
+    # stdout carries the ONE JSON line and nothing else: whatever libraries write to fd 1 on the way (RCCL prints a version
+    # banner at communicator creation) is routed to stderr; the line itself goes to the saved descriptor.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -400,7 +406,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(rig, stream, p, ticks)
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), file=json_out, flush=True)
     if dist:
         dist.destroy_process_group()
 
