@@ -31,6 +31,9 @@ def available():
 
 def build():
     subprocess.check_call(["make", "-C", _HERE, "ref", "REF=" + REFERENCE], stdout=subprocess.DEVNULL)
+    # the node objects with the product's binding attached link against the HIP library: only once that is built
+    if os.path.exists(os.path.join(_HERE, "..", "esvo_amd", "csrc", "libesvo_hip.so")):
+        subprocess.check_call(["make", "-C", _HERE, "ref_hip", "REF=" + REFERENCE], stdout=subprocess.DEVNULL)
     return _LIB
 
 
@@ -360,14 +363,17 @@ _lib_node = {}
 _POSE_FN = C.CFUNCTYPE(C.c_int, C.c_ulonglong, C.POINTER(C.c_double))
 
 
-def load_node(mvstereo=False):
+def load_node(mvstereo=False, hip=False):
     """oracle/_ref/libesvo_ref_node.so: esvo_core/src/esvo_Mapping.cpp (the mapper NODE) + the mapper sources, against the
     inert ROS / tf / cv_bridge / pcl stand-ins of oracle/ref_shim_node/ (oracle/ref_harness_node.cpp);
     libesvo_ref_mvstereo.so: the same entry points around esvo_core/src/esvo_MVStereo.cpp."""
-    if _lib_node.get(mvstereo) is None:
+    key = (mvstereo, hip)
+    if _lib_node.get(key) is None:
         if os.path.isdir(os.path.join(REFERENCE, "esvo_core", "src")):
             build()
-        lib = C.CDLL(os.path.join(_HERE, "_ref", "libesvo_ref_mvstereo.so" if mvstereo else "libesvo_ref_node.so"))
+        # hip: the same objects + include/esvo_hip_mapping_node.hpp, linked with esvo_amd/csrc/libesvo_hip.so
+        name = ("libesvo_ref_mvstereo" if mvstereo else "libesvo_ref_node") + ("_hip.so" if hip else ".so")
+        lib = C.CDLL(os.path.join(_HERE, "_ref", name))
         vp, u64, sz = C.c_void_p, C.c_uint64, C.c_size_t
         lib.ref_node_create.restype = vp
         lib.ref_node_create.argtypes = [C.c_char_p, vp, vp, vp]
@@ -390,8 +396,17 @@ def load_node(mvstereo=False):
         lib.ref_node_preset_param.argtypes = [C.c_char_p, C.c_char_p]
         lib.ref_node_initialization_at_time.restype = C.c_int
         lib.ref_node_initialization_at_time.argtypes = [vp, vp]
-        _lib_node[mvstereo] = lib
-    return _lib_node[mvstereo]
+        if hip:
+            lib.ref_node_hip_error.restype = C.c_char_p
+            lib.ref_node_hip_attach.restype = C.c_int
+            lib.ref_node_hip_attach.argtypes = [vp, vp, vp, vp, C.c_int]
+            lib.ref_node_hip_mapping_at_time.restype = C.c_int
+            lib.ref_node_hip_mapping_at_time.argtypes = [vp]
+            for f in ("ref_node_hip_matched_events", "ref_node_hip_newest_frame", "ref_node_hip_get_map"):
+                getattr(lib, f).restype = sz
+                getattr(lib, f).argtypes = [vp, vp, sz]
+        _lib_node[key] = lib
+    return _lib_node[key]
 
 
 class RefNode:
@@ -399,8 +414,8 @@ class RefNode:
     timeSurfaceCallback, poses through the tf stand-in (pose(t_ns) -> 4x4 T_world_cam or None); tick() = dataTransferring +
     MappingAtTime as MappingLoop calls them (esvo_Mapping.cpp:146-259) without the threads, the rate and the publishers."""
 
-    def __init__(self, params, rig, pose, extra=None, mvstereo=False):
-        self.lib = load_node(mvstereo)   # mvstereo: the esvo_MVStereo node object (BM_PLUS_ESTIMATION) instead of esvo_Mapping
+    def __init__(self, params, rig, pose, extra=None, mvstereo=False, hip=False):
+        self.lib = load_node(mvstereo, hip)   # mvstereo: the esvo_MVStereo node object (BM_PLUS_ESTIMATION) instead of esvo_Mapping
         self.rig = rig
         for k, v in (extra or {}).items():   # node parameters the POD has no field for, e.g. INIT_SGM_DP_NUM_THRESHOLD
             self.lib.ref_node_preset_param(k.encode(), str(v).encode())
@@ -422,6 +437,15 @@ class RefNode:
             self.h = self.lib.ref_node_create(d.encode(), C.addressof(params), C.addressof(cl), C.addressof(cr))
         self._keep = (cl, cr)
         self._last_ts = 0
+        if hip:
+            # the product's binding takes over MappingAtTime of THIS node object; the observations the tests hand to the node
+            # are smoothed already (the stand-in OpenCV has no GaussianBlur), so the device must not smooth again
+            import copy
+            ph = copy.copy(params)
+            ph.smooth_time_surface = 0
+            rc = self.lib.ref_node_hip_attach(self.h, C.addressof(ph), C.addressof(cl), C.addressof(cr), 0)
+            if rc:
+                raise RuntimeError(f"esvo_hip binding: {rc}: {self.lib.ref_node_hip_error().decode(errors='replace')}")
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -480,6 +504,21 @@ class RefNode:
         """InitializationAtTime (esvo_Mapping.cpp:433-492) with disp16 standing in for StereoSGBM::compute's output"""
         d = np.ascontiguousarray(disp16, np.int16)
         return bool(self.lib.ref_node_initialization_at_time(self.h, _p(d)))
+
+    def hip_mapping_at_time(self):
+        """MappingAtTime through include/esvo_hip_mapping_node.hpp (device) on what dataTransferring loaded"""
+        rc = self.lib.ref_node_hip_mapping_at_time(self.h)
+        if rc:
+            raise RuntimeError(f"esvo_hip binding: {rc}: {self.lib.ref_node_hip_error().decode(errors='replace')}")
+
+    def hip_matched_events(self):
+        return self._indices(self.lib.ref_node_hip_matched_events)
+
+    def hip_newest_frame(self):
+        return self._points(self.lib.ref_node_hip_newest_frame)
+
+    def hip_get_map(self):
+        return self._points(self.lib.ref_node_hip_get_map)
 
     def window(self):
         return self._indices(self.lib.ref_node_window, 256).tolist()

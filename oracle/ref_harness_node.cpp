@@ -45,6 +45,9 @@
 #include <sstream>
 
 #include "../include/esvo_hip.h"
+#ifdef REF_NODE_WITH_HIP  // + the product's reference-side binding (include/esvo_hip_mapping_node.hpp), linked with libesvo_hip.so
+#include "../include/esvo_hip_mapping_node.hpp"
+#endif
 
 using namespace esvo_core;
 #ifdef REF_NODE_MVSTEREO
@@ -75,6 +78,9 @@ struct ref_node {
   std::unique_ptr<NodeClass> node;
   std::vector<short> disparity;
   int W = 0, H = 0;
+#ifdef REF_NODE_WITH_HIP
+  std::unique_ptr<esvo_hip::MappingNodeHip<NodeClass, cv::Mat>> hip;
+#endif
 };
 
 namespace {
@@ -263,4 +269,39 @@ size_t ref_node_get_map(ref_node* h, esvo_depth_point_t* out, size_t cap) {
     }
   return k;
 }
+
+#ifdef REF_NODE_WITH_HIP
+// ---- the same node object with MappingAtTime replaced by the device path (include/esvo_hip_mapping_node.hpp) ----
+static std::string& hip_error() { static std::string e; return e; }
+const char* ref_node_hip_error() { return hip_error().c_str(); }
+int ref_node_hip_attach(ref_node* h, const esvo_params_t* p, const esvo_calib_t* left, const esvo_calib_t* right, int device) {
+  try {
+    h->hip.reset(new esvo_hip::MappingNodeHip<NodeClass, cv::Mat>(*h->node, *p, *left, *right, device));
+  } catch (const esvo_hip::Error& e) { hip_error() = e.what(); return e.code; }
+  return 0;
+}
+// what MappingLoop would call in place of MappingAtTime(TS_obs_.first)
+int ref_node_hip_mapping_at_time(ref_node* h) {
+  try {
+    h->hip->MappingAtTime();
+  } catch (const esvo_hip::Error& e) { hip_error() = e.what(); return e.code; }
+  return 0;
+}
+size_t ref_node_hip_matched_events(ref_node* h, uint32_t* idx_out, size_t cap) {
+  return index_events(h, h->node->vDenoisedEventsPtr_left_, idx_out, cap);
+}
+size_t ref_node_hip_newest_frame(ref_node* h, esvo_depth_point_t* out, size_t cap) {
+  const auto& f = h->hip->newestFrame();
+  for (size_t i = 0; i < f.size() && i < cap; ++i) out[i] = f[i];
+  return f.size();
+}
+size_t ref_node_hip_get_map(ref_node* h, esvo_depth_point_t* out, size_t cap) {
+  std::vector<esvo_depth_point_t> m;
+  try {
+    h->hip->getDepthMap(m);
+  } catch (const esvo_hip::Error& e) { hip_error() = e.what(); return 0; }
+  for (size_t i = 0; i < m.size() && i < cap; ++i) out[i] = m[i];
+  return m.size();
+}
+#endif
 }  // extern "C"

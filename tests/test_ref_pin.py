@@ -523,3 +523,20 @@ def test_live_reference_node_long_run_window_churn(name, mvstereo, n_ticks, over
             assert np.array_equal(a[f], b[f]), (f, len(sizes))
         sizes.append(len(win))
     assert max(sizes) > 1 and any(b <= a for a, b in zip(sizes[2:], sizes[3:]))   # the window rolled
+
+
+def test_hip_binding_compiles_against_the_reference_node_classes():
+    """Build container only: include/esvo_hip_mapping_node.hpp (the reference-side binding of INTEGRATION.md) instantiated
+    with the reference's real esvo_Mapping and esvo_MVStereo classes and linked with libesvo_hip.so; the GPU side of it is
+    tests/test_gpu_node_dropin.py."""
+    import ctypes
+    from oracle import ref as R
+    if not os.path.isdir(os.path.join(R.REFERENCE, "esvo_core", "src")):
+        pytest.skip("reference tree not present (GPU box)")
+    from esvo_amd import lib
+    lib.build()
+    R.build()
+    for name in ("libesvo_ref_node_hip.so", "libesvo_ref_mvstereo_hip.so"):
+        so = ctypes.CDLL(os.path.join(os.path.dirname(R._LIB), name))
+        for sym in ("ref_node_hip_attach", "ref_node_hip_mapping_at_time", "ref_node_hip_newest_frame", "ref_node_hip_get_map"):
+            getattr(so, sym)
