@@ -392,6 +392,9 @@ def load_node(mvstereo=False, hip=False):
         lib.ref_node_pose_table.restype = sz
         lib.ref_node_pose_table.argtypes = [vp, vp, vp, sz]
         lib.ref_node_mapping_at_time.argtypes = [vp]
+        if not mvstereo:
+            lib.ref_node_pointcloud.restype = sz
+            lib.ref_node_pointcloud.argtypes = [vp, C.c_int, vp, sz]
         lib.ref_node_set_status.argtypes = [vp, C.c_char_p]
         lib.ref_node_preset_param.argtypes = [C.c_char_p, C.c_char_p]
         lib.ref_node_initialization_at_time.restype = C.c_int
@@ -526,6 +529,13 @@ class RefNode:
     def _points(self, fn):
         out = np.zeros(self.rig.width * self.rig.height, DEPTH_POINT_DTYPE)
         n = fn(self.h, _p(out), len(out))
+        return out[:n].copy()
+
+    def pointcloud(self, near=False):
+        """publishPointCloud (esvo_Mapping.cpp:909-978) on the current DepthFrame: pc_ (the tracker's reference cloud) or
+        pc_near_ (|p_cam| < visualize_range), float32 xyz, world frame"""
+        out = np.zeros((self.rig.width * self.rig.height, 3), np.float32)
+        n = self.lib.ref_node_pointcloud(self.h, int(bool(near)), _p(out), len(out))
         return out[:n].copy()
 
     def newest_frame(self):

@@ -18,6 +18,7 @@
 // that point at erased elements (undefined behaviour upstream); ref_harness.cpp nulls them, the node
 // cannot.  The fixture (tests/golden/ref_node.npz) is therefore recorded with Regularization off; with it on the node's
 // maps equal ref_harness.cpp's in everything but the inverse depths around those cells (asserted when the fixture is made).
+#include <chrono>
 #include <cstring>
 #include <deque>
 #include <future>
@@ -211,7 +212,28 @@ size_t ref_node_pose_table(ref_node* h, uint64_t* stamps, double* poses, size_t 
   return k;
 }
 // MappingAtTime (:261-431) on what dataTransferring loaded
-void ref_node_mapping_at_time(ref_node* h) { h->node->MappingAtTime(h->node->TS_obs_.first); }
+void ref_node_mapping_at_time(ref_node* h) {
+  h->node->MappingAtTime(h->node->TS_obs_.first);
+  // MappingAtTime hands the DepthMap (a shared_ptr, by value) to a detached publisher thread (:400-403): wait until that
+  // thread has let go of it, so that what the harness reads next -- the map, the clouds -- is not being written
+  for (int spin = 0; spin < 20000 && h->node->depthFramePtr_->dMap_.use_count() > 1; ++spin)
+    std::this_thread::sleep_for(std::chrono::microseconds(100));
+}
+#ifndef REF_NODE_MVSTEREO
+// publishPointCloud (:909-978) on the current DepthFrame: the cloud handed to the tracker (which = 0) or the points
+// closer than visualize_range (which = 1), float32 xyz in the world frame
+size_t ref_node_pointcloud(ref_node* h, int which, float* out_xyz, size_t cap_points) {
+  ros::Time t = h->node->TS_obs_.first;
+  h->node->publishPointCloud(h->node->depthFramePtr_->dMap_, h->node->depthFramePtr_->T_world_frame_, t);
+  auto& pc = which ? *h->node->pc_near_ : *h->node->pc_;
+  size_t k = 0;
+  for (auto& p : pc.points) {
+    if (k < cap_points) { out_xyz[3 * k] = p.x; out_xyz[3 * k + 1] = p.y; out_xyz[3 * k + 2] = p.z; }
+    ++k;
+  }
+  return k;
+}
+#endif
 // InitializationAtTime (:433-492) with the given disparity image standing in for StereoSGBM::compute
 int ref_node_initialization_at_time(ref_node* h, const int16_t* disp16) {
   h->disparity.assign(disp16, disp16 + (size_t)h->W * h->H);

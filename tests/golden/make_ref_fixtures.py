@@ -245,6 +245,14 @@ def map_digest(mp):
 NODE_CONST_POINTS = dict(fusion_strategy=1, max_fusion_points=1000, max_fusion_frames=2)
 
 
+NODE_VISUALIZE_RANGE = dict(dsec=12.0, hkust=1.5)   # visualize_range of the node (pc_near_), chosen to cut each scene's cloud
+
+
+def cloud_digest(xyz):
+    import hashlib
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(xyz, np.float32).tobytes()).digest(), np.uint8).copy()
+
+
 def run_node(sc, ticks, st, regularization, mvstereo=False, **override):
     """the reference's esvo_Mapping node object on a scenario: the whole left stream through eventsCallback, the tick's
     Time-Surface pair through timeSurfaceCallback, poses through the tf stand-in, then dataTransferring + MappingAtTime"""
@@ -253,7 +261,8 @@ def run_node(sc, ticks, st, regularization, mvstereo=False, **override):
     p.regularization = int(regularization)
     for k, v in override.items():
         setattr(p, k, v)
-    node = R.RefNode(p, sc.rig, st.pose, mvstereo=mvstereo)
+    vr = NODE_VISUALIZE_RANGE.get(sc.name)
+    node = R.RefNode(p, sc.rig, st.pose, mvstereo=mvstereo, extra={"visualize_range": vr} if vr and not mvstereo else None)
     node.push_events(st.ev_left)
     out = []
     for tk in ticks:
@@ -264,6 +273,8 @@ def run_node(sc, ticks, st, regularization, mvstereo=False, **override):
         node.mapping_at_time()
         out.append(dict(obs_t=node.obs_time(), sel=sel, matched=node.matched_events(), stamps=stamps, poses=poses,
                         window=np.array(node.window(), np.uint32), frame=node.newest_frame(), map=node.get_map()))
+        if not mvstereo:   # publishPointCloud's two clouds (esvo_Mapping.cpp:909-934)
+            out[-1].update(pc=node.pointcloud(), pc_near=node.pointcloud(near=True))
     return out
 
 
@@ -323,7 +334,10 @@ def make_node():
             out.update({pre + f"obs_t{k}": r["obs_t"], pre + f"sel{k}": r["sel"], pre + f"matched{k}": r["matched"],
                         pre + f"stamps{k}": r["stamps"], pre + f"window{k}": r["window"], pre + f"map_n{k}": len(r["map"]),
                         pre + f"map_sha{k}": map_digest(r["map"]),
-                        pre + f"reg_same_inv_depth{k}": int(np.sum(rr["map"]["inv_depth"] == g[f"map{k}"]["inv_depth"]))})
+                        pre + f"reg_same_inv_depth{k}": int(np.sum(rr["map"]["inv_depth"] == g[f"map{k}"]["inv_depth"])),
+                        pre + f"pc_n{k}": len(r["pc"]), pre + f"pc_sha{k}": cloud_digest(r["pc"]),
+                        pre + f"pc_near_n{k}": len(r["pc_near"]), pre + f"pc_near_sha{k}": cloud_digest(r["pc_near"])})
+            assert 0 < len(r["pc_near"]) < len(r["pc"]) == len(r["map"])
         if name == "dsec":
             from esvo_amd.abi import FUSION_CONST_POINTS
             assert NODE_CONST_POINTS["fusion_strategy"] == FUSION_CONST_POINTS

@@ -351,7 +351,8 @@ def test_data_transfer_and_tick_glue_equal_the_reference_node(name):
       dataTransferring   the observation it picks, the events it selects (indices into the left queue, order), the stamps
                          of the virtual-view table (getPoseAt at 50 us steps over the slice)
       MappingAtTime      the events handed to the block matcher (denoising mask + extraction on hkust), the window
-                         policy (frames kept, their sizes), and -- fed the frame the node's own BM + LM kept, which equals
+                         policy (frames kept, their sizes), publishPointCloud's clouds, and -- fed the frame the node's own
+                         BM + LM kept, which equals
                          ref_<name>.npz's frame (asserted when the fixture was made) -- every element of the fused and
                          cleaned DepthMap.
     Recorded with the regulariser off (the node regularises over erased elements; with it on, the
@@ -390,6 +391,16 @@ def test_data_transfer_and_tick_glue_equal_the_reference_node(name):
         assert np.array_equal(_map_digest(mp), n[pre + f"map_sha{k}"]), k
         # with the regulariser on, the node agreed with ref_<name>.npz on most inverse depths and on everything else
         assert int(n[pre + f"reg_same_inv_depth{k}"]) >= 0.9 * len(g[f"map{k}"])
+        # publishPointCloud (:909-934): the tracker's cloud and the near cloud, float32 world coordinates, list order
+        import hashlib
+        import sys
+        sys.path.insert(0, GOLDEN)
+        from make_ref_fixtures import NODE_VISUALIZE_RANGE
+        pc, near = m.get_pointcloud(), m.get_pointcloud_near(NODE_VISUALIZE_RANGE[name])
+        assert len(pc) == int(n[pre + f"pc_n{k}"]) and len(near) == int(n[pre + f"pc_near_n{k}"])
+        for cloud, key in ((pc, "pc_sha"), (near, "pc_near_sha")):
+            sha = np.frombuffer(hashlib.sha256(np.ascontiguousarray(cloud, np.float32).tobytes()).digest(), np.uint8)
+            assert np.array_equal(sha, n[pre + f"{key}{k}"]), key
 
 
 @pytest.mark.parametrize("name", ["upenn", "rpg"])
