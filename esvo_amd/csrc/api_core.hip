@@ -175,6 +175,8 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
   }
   CK(dalloc(&h->d_raw, npx + 64));
   CK(dalloc(&h->d_raw1, npx + 64));
+  h->h_rect_lut[0].assign(left->rect_lut, left->rect_lut + 2 * npx);
+  if (right->rect_lut) h->h_rect_lut[1].assign(right->rect_lut, right->rect_lut + 2 * npx);
   CK(dalloc(&h->d_obs_tmp, npx + 64));
   h->ring_cap = (u64)std::max<int64_t>(params->event_ring_capacity, 1024);
   for (int cam = 0; cam < 2; ++cam) CK(dalloc(&h->d_ring[cam], h->ring_cap));
@@ -273,7 +275,8 @@ int esvo_destroy(esvo_handle h) {
   if (h->stream_l) hipStreamSynchronize(h->stream_l);
   if (h->stream_b) hipStreamSynchronize(h->stream_b);
   comm_release(h);
-  void* ptrs[] = {h->d_lut, h->d_mask, h->d_fixmap[0], h->d_fixmap[1], h->d_sae[0], h->d_sae[1], h->d_raw, h->d_raw1, h->d_ts[0],
+  void* ptrs[] = {h->d_lut, h->d_mask, h->d_fixmap[0], h->d_fixmap[1], h->d_sae[0], h->d_sae[1], h->d_raw, h->d_raw1, h->d_fwd_lut[0], h->d_fwd_lut[1], h->d_fwd_off[0], h->d_fwd_off[1],
+                  h->d_fwd_src[0], h->d_fwd_src[1], h->d_fwd_val, h->d_ts[0],
                   h->d_ts[1], h->d_ring[0], h->d_ring[1], h->d_obs2[0][0], h->d_obs2[0][1], h->d_obs2[1][0], h->d_obs2[1][1], h->d_obs_tmp,
                   h->d_pose_T2[0], h->d_pose_T2[1], h->d_scan_tmp_b, h->d_cnt_b, h->d_tick_ev, h->d_match_slots, h->d_match_flags, h->d_match_prefix,
                   h->d_matches2[0], h->d_matches2[1], h->d_scan_tmp_l, h->d_pt_slots, h->d_pt_flags, h->d_pt_prefix, h->d_pts_tmp, h->d_stage[0], h->d_stage[1], h->d_counters2[0], h->d_counters2[1], h->d_scan_tmp,

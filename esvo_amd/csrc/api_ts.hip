@@ -177,6 +177,82 @@ int esvo_ts_push_event_array(esvo_handle h, int cam, const uint8_t* msg, size_t 
   return ESVO_OK;
 }
 
+namespace {
+// FORWARD mode, first use for a camera: the contribution lists of TimeSurface.cpp:85-116.  A source pixel s with rectified
+// position (u, v), u, v >= 0, u_i + 1 < W, v_i + 1 < H adds to the four pixels around (u, v); every destination pixel gets the
+// list of (source, corner) pairs that reach it, in raster order of the sources (a stable counting sort).
+int build_forward_lists(esvo_context* h, int cam) {
+  if (h->d_fwd_off[cam]) return ESVO_OK;
+  const std::vector<float>& lut = h->h_rect_lut[cam];
+  const size_t npx = (size_t)h->W * h->H;
+  if (lut.size() != 2 * npx) FAIL(ESVO_ERR_STATE, "esvo_ts_render_forward: this camera's rect_lut was not given to esvo_create");
+  if (npx >= (1u << 30)) FAIL(ESVO_ERR_UNSUPPORTED, "image too large for the packed contribution records");
+  const size_t W = (size_t)h->W, H = (size_t)h->H;
+  std::vector<u32> off(npx + 1, 0);
+  auto corners = [&](size_t s, size_t dst[4]) -> bool {
+    const double u = (double)lut[2 * s], v = (double)lut[2 * s + 1];
+    if (!(u >= 0 && v >= 0)) return false;
+    const double fu = std::floor(u), fv = std::floor(v);
+    if (!(fu < 4e9 && fv < 4e9)) return false;
+    const size_t u_i = (size_t)fu, v_i = (size_t)fv;
+    if (!(u_i + 1 < W && v_i + 1 < H)) return false;
+    dst[0] = v_i * W + u_i; dst[1] = v_i * W + u_i + 1; dst[2] = (v_i + 1) * W + u_i; dst[3] = (v_i + 1) * W + u_i + 1;
+    return true;
+  };
+  size_t dst[4];
+  for (size_t s = 0; s < npx; ++s)
+    if (corners(s, dst))
+      for (int c = 0; c < 4; ++c) off[dst[c] + 1]++;
+  for (size_t i = 0; i < npx; ++i) off[i + 1] += off[i];
+  std::vector<u32> src(std::max<size_t>(off[npx], 1)), fill(off.begin(), off.end() - 1);
+  for (size_t s = 0; s < npx; ++s)
+    if (corners(s, dst))
+      for (int c = 0; c < 4; ++c) src[fill[dst[c]]++] = (u32)s | ((u32)c << 30);
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(&h->d_fwd_off[cam]), sizeof(u32) * (npx + 1)));
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(&h->d_fwd_src[cam]), sizeof(u32) * src.size()));
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(&h->d_fwd_lut[cam]), sizeof(float2) * npx));
+  if (!h->d_fwd_val) HIPCHK(hipMalloc(reinterpret_cast<void**>(&h->d_fwd_val), sizeof(double) * npx));
+  HIPCHK(hipMemcpy(h->d_fwd_off[cam], off.data(), sizeof(u32) * (npx + 1), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->d_fwd_src[cam], src.data(), sizeof(u32) * src.size(), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->d_fwd_lut[cam], lut.data(), sizeof(float2) * npx, hipMemcpyHostToDevice));
+  return ESVO_OK;
+}
+}  // namespace
+
+int esvo_ts_render_forward(esvo_handle h, int cam, uint64_t t_ns, uint8_t* out_mono8) {
+  if (!h || cam < 0 || cam > 1) return ESVO_ERR_INVALID_ARG;
+  HIPCHK(hipSetDevice(h->device));
+  { int rc = build_forward_lists(h, cam); if (rc) return rc; }
+  const auto& tsq = h->ts_host[cam];
+  const size_t k = std::lower_bound(tsq.begin(), tsq.end(), (u64)t_ns) - tsq.begin();
+  const u64 upto = h->ring_base[cam] + k;
+  if (upto < h->scattered[cam])
+    FAIL(ESVO_ERR_STATE, "esvo_ts_render_forward: t_ns precedes events of an earlier render (render times must not decrease; esvo_reset to replay)");
+  if (upto > h->scattered[cam]) {  // events with ts < T that are not in the SAE yet (as esvo_ts_render)
+    u64 a = h->scattered[cam];
+    h->scatter_pending_lo[cam] = std::min(h->scatter_pending_lo[cam], a);
+    h->stats.events_scattered[cam] += upto - a;
+    while (a < upto) {
+      const u64 slot = a % h->ring_cap;
+      const u64 cnt = std::min<u64>(upto - a, h->ring_cap - slot);
+      launch_ts_scatter(h->d_ring[cam] + slot, (size_t)cnt, h->d_sae[cam], h->W, h->H, h->stream);
+      a += cnt;
+    }
+    h->scattered[cam] = upto;
+  }
+  launch_ts_render_forward(h->d_sae[cam], h->d_fwd_off[cam], h->d_fwd_src[cam], h->d_fwd_lut[cam], h->d_fwd_val, cam ? h->d_raw1 : h->d_raw,
+                           h->d_ts[cam], h->W, h->H, (u64)t_ns, h->prm.decay_ms / 1000.0, h->prm.ignore_polarity,
+                           h->prm.median_blur_kernel_size, h->stream);
+  HIPCHK(hipGetLastError());
+  h->ts_valid[cam] = true;
+  h->stats.ts_frames[cam]++;
+  if (out_mono8) {
+    HIPCHK(hipMemcpyAsync(out_mono8, h->d_ts[cam], (size_t)h->W * h->H, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+  }
+  return ESVO_OK;
+}
+
 int esvo_ts_render(esvo_handle h, int cam, uint64_t t_ns, uint8_t* out_mono8) {
   if (!h || cam < 0 || cam > 1) return ESVO_ERR_INVALID_ARG;
   HIPCHK(hipSetDevice(h->device));

@@ -156,6 +156,9 @@ struct TsPair { const u64* sae[2]; uint8_t* raw[2]; const int2* fixmap[2]; uint8
 void launch_ts_scatter_segs(const TsScatterSegs& g, int n_seg, int W, int H, hipStream_t s);
 void launch_ts_render_pair(const TsPair& c, int W, int H, u64 t_ns, double decay_sec, int ignore_polarity, int median_k,
                            hipStream_t s);
+void launch_ts_render_forward(const u64* d_sae, const u32* d_off, const u32* d_src, const float2* d_lut, double* d_val,
+                              uint8_t* d_raw, uint8_t* d_out, int W, int H, u64 t_ns, double decay_sec, int ignore_polarity,
+                              int median_k, hipStream_t s);
 void launch_gaussian5_pair(const uint8_t* in0, const uint8_t* in1, uint8_t* out0, uint8_t* out1, int W, int H, hipStream_t s);
 // createDenoisingMask + extractDenoisedEvents (esvo_Mapping.cpp:1046-1072) on the n selected events
 void launch_denoise_flags(const esvo_event_t* ring, u64 first, u64 cap, u32 n, uint8_t* evmap, u32* flags, int W, int H,

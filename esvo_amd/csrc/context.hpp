@@ -74,7 +74,14 @@ struct esvo_context {
   // Time Surface
   u64* d_sae[2] = {nullptr, nullptr};
   uint8_t* d_raw = nullptr;
-  uint8_t* d_raw1 = nullptr;  // the right camera's raw surface when both cameras render in one launch (esvo_map_tick_resident)
+  uint8_t* d_raw1 = nullptr;
+  // FORWARD-mode Time Surface (esvo_ts_render_forward): host copy of each camera's rect_lut, and -- built on first use --
+  // its device copy, the per-destination contribution lists (CSR: offsets, source index | corner << 30) and a f64 scratch
+  std::vector<float> h_rect_lut[2];
+  float2* d_fwd_lut[2] = {nullptr, nullptr};
+  uint32_t* d_fwd_off[2] = {nullptr, nullptr};
+  uint32_t* d_fwd_src[2] = {nullptr, nullptr};
+  double* d_fwd_val = nullptr;  // the right camera's raw surface when both cameras render in one launch (esvo_map_tick_resident)
   uint8_t* d_ts[2] = {nullptr, nullptr};
   bool ts_valid[2] = {false, false};
   esvo_event_t* d_ring[2] = {nullptr, nullptr};

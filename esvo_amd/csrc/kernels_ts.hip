@@ -4,6 +4,7 @@
 //                   (esvo_time_surface/src/TimeSurface.cpp:403-425, TimeSurface.h:39-50)
 //   K2 ts_decay + ts_median_remap : TimeSurface::createTimeSurfaceAtTime, BACKWARD mode
 //                   (TimeSurface.cpp:52-152): exp decay -> x255 -> u8 -> 3x3 median -> rectifying remap
+//   ts_decay_f64 + ts_forward_gather : the same function in FORWARD mode (TimeSurface.cpp:85-116)
 //   gaussian5     : TimeSurfaceObservation::GaussianBlurTS(5) (TimeSurfaceObservation.h:107-116)
 //
 // Data layout: the per-pixel event queues of the reference (std::deque, length 20) collapse to a
@@ -158,6 +159,60 @@ void launch_ts_render_pair(const TsPair& c, int W, int H, u64 t_ns, double decay
   const int n = W * H;
   hipLaunchKernelGGL(ts_decay_pair_kernel, dim3((n + 255) / 256, 2), dim3(256), 0, s, c, n, t_ns, decay_sec, ignore_polarity);
   hipLaunchKernelGGL(ts_median_remap_pair_kernel, dim3((W + 63) / 64, (H + 3) / 4, 2), dim3(256), 0, s, c, W, H, median_k);
+}
+
+// ---- FORWARD mode (TimeSurface.cpp:85-116) ------------------------------------------------------------------------------
+// Pass 1: the decayed value of every raw pixel as f64 (NaN: no event before T, :71-73).  Pass 2, one thread per DESTINATION
+// pixel: the contributions the reference's raster-order splat would add to it, in that order (the list is sorted by source
+// index on the host), each `+= w * expVal` followed by the clamp to 1 (:101-113); x255, round-half-even, u8 (:123-127).
+__global__ void __launch_bounds__(256) ts_decay_f64_kernel(const u64* __restrict__ sae, double* __restrict__ val, int n_px, u64 t_ns,
+                                                           double decay_sec, int ignore_polarity) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_px) return;
+  const u64 key = sae[i];
+  const u64 te = key >> 1;
+  double v = __longlong_as_double(0x7ff8000000000000ll);
+  if (key != 0 && te < t_ns && ns_to_sec(te) > 0) {
+    const double dt = duration_to_sec(t_ns, te);
+    double e = exp(-dt / decay_sec);
+    if (!ignore_polarity) e *= (key & 1ull) ? 1.0 : -1.0;
+    v = e;
+  }
+  val[i] = v;
+}
+__global__ void __launch_bounds__(256) ts_forward_gather_kernel(const u32* __restrict__ off, const u32* __restrict__ src,
+                                                                const float2* __restrict__ lut, const double* __restrict__ val,
+                                                                uint8_t* __restrict__ raw, int n_px, int ignore_polarity) {
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= n_px) return;
+  double acc = 0.0;
+  for (u32 k = off[d]; k < off[d + 1]; ++k) {
+    const u32 rec = src[k];
+    const u32 s = rec & 0x3fffffffu, corner = rec >> 30;
+    const double e = val[s];
+    if (!(e == e)) continue;  // the source pixel has no event before T
+    const float2 uv = lut[s];
+    const double u = (double)uv.x, v = (double)uv.y;
+    const double fu = u - floor(u), fv = v - floor(v), fu1 = 1.0 - fu, fv1 = 1.0 - fv;
+    const double w = corner == 0 ? fu1 * fv1 : (corner == 1 ? fu * fv1 : (corner == 2 ? fu1 * fv : fu * fv));
+    acc += w * e;
+    if (acc > 1) acc = 1;
+  }
+  const double g = ignore_polarity ? 255.0 * acc : 255.0 * (acc + 1.0) / 2.0;
+  int q = (int)rint(g);
+  q = q < 0 ? 0 : (q > 255 ? 255 : q);
+  raw[d] = (uint8_t)q;
+}
+void launch_ts_render_forward(const u64* d_sae, const u32* d_off, const u32* d_src, const float2* d_lut, double* d_val,
+                              uint8_t* d_raw, uint8_t* d_out, int W, int H, u64 t_ns, double decay_sec, int ignore_polarity,
+                              int median_k, hipStream_t s) {
+  const int n = W * H;
+  hipLaunchKernelGGL(ts_decay_f64_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_sae, d_val, n, t_ns, decay_sec, ignore_polarity);
+  hipLaunchKernelGGL(ts_forward_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_off, d_src, d_lut, d_val, d_raw, n,
+                     ignore_polarity);
+  // the 3x3 median of the BACKWARD path without its remap (fixmap == null)
+  hipLaunchKernelGGL(ts_median_remap_kernel, dim3((W + 63) / 64, (H + 3) / 4), dim3(256), 0, s, d_raw, (const int2*)nullptr, d_out, W,
+                     H, median_k);
 }
 
 // ---- 5x5 Gaussian, [1 4 6 4 1]^2 / 256, BORDER_REFLECT_101, round-to-nearest once ------------------

@@ -21,7 +21,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
 
 SYMBOLS = [
     "esvo_default_params", "esvo_create", "esvo_destroy", "esvo_reset", "esvo_set_params", "esvo_last_error",
-    "esvo_set_stream", "esvo_synchronize", "esvo_ts_push_events", "esvo_ts_push_event_array", "esvo_ts_render", "esvo_map_set_observation",
+    "esvo_set_stream", "esvo_synchronize", "esvo_ts_push_events", "esvo_ts_push_event_array", "esvo_ts_render", "esvo_ts_render_forward", "esvo_map_set_observation",
     "esvo_map_match", "esvo_map_set_poses", "esvo_map_refine", "esvo_map_push_frame", "esvo_map_fuse",
     "esvo_map_tick", "esvo_map_tick_resident", "esvo_map_get_depth_points", "esvo_map_get_committed", "esvo_map_get_pointcloud_xyz", "esvo_map_get_last_frame",
     "esvo_get_stats", "esvo_shard_set_band", "esvo_shard_exchange", "esvo_shard_tick_phase", "esvo_abi_sizes",
@@ -85,6 +85,7 @@ def load():
     lib.esvo_ts_push_events.argtypes = [vp, i32, vp, sz]
     lib.esvo_ts_push_event_array.argtypes = [vp, i32, vp, sz, psz]
     lib.esvo_ts_render.argtypes = [vp, i32, u64, vp]
+    lib.esvo_ts_render_forward.argtypes = [vp, i32, u64, vp]
     lib.esvo_map_set_observation.argtypes = [vp, u64, vp, vp, vp]
     lib.esvo_map_match.argtypes = [vp, vp, sz, vp, vp, sz, vp, sz, psz]
     lib.esvo_map_set_poses.argtypes = [vp, vp, vp, sz]
@@ -277,6 +278,12 @@ class Esvo:
         return out
 
     # ---- mapper, stage-wise (EventBM / DepthProblemSolver / DepthFusion seams)
+    def ts_render_forward(self, cam, t_ns, download=True):
+        """esvo_ts_render_forward: the camera's Time Surface in the reference's FORWARD mode"""
+        out = np.empty((self.H, self.W), np.uint8) if download else None
+        self._ck(self.lib.esvo_ts_render_forward(self.h, int(cam), int(t_ns), _p(out)))
+        return out
+
     def set_observation(self, t_ns, ts_left, ts_right, T_world_cam):
         l = None if ts_left is None else np.ascontiguousarray(ts_left, np.uint8)
         r = None if ts_right is None else np.ascontiguousarray(ts_right, np.uint8)

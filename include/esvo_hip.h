@@ -245,6 +245,13 @@ int esvo_ts_push_bag(esvo_handle h, int cam, esvo_bag_handle b, const char* topi
  * pixel, so it reads as empty" (TimeSurface.h:52-75) cannot occur here: events with ts >= t_ns are never scattered
  * before the render at t_ns. */
 int esvo_ts_render(esvo_handle h, int cam, uint64_t t_ns, uint8_t* out_mono8);
+/* The same in FORWARD mode (time_surface_mode: 1, TimeSurface.cpp:85-116): every raw pixel's decayed value is splatted
+ * bilinearly at the pixel's rectified position (the camera's rect_lut, which must have been given to esvo_create) with a
+ * clamp to 1 after every add, in raster order of the source pixels -- reproduced by a gather over per-pixel contribution
+ * lists sorted by source index (built on first use).  x255, round to u8, 3x3 median; the image is rectified by
+ * construction (no remap).  Same staging / monotonic-time rules as esvo_ts_render; the result is the camera's resident
+ * frame as well.  No shipped configuration selects this mode. */
+int esvo_ts_render_forward(esvo_handle h, int cam, uint64_t t_ns, uint8_t* out_mono8);
 
 /* ---- Mapper: stage-wise seams ------------------------------------------------------ */
 

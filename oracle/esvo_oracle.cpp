@@ -201,6 +201,57 @@ extern "C" void orc_ts_render(orc_ts_handle h, uint64_t t_ns, double decay_ms, i
     std::memcpy(out, cur, (size_t)W * H);
 }
 
+extern "C" void orc_ts_render_forward(orc_ts_handle h, uint64_t t_ns, double decay_ms, int ignore_polarity,
+                                      int median_blur_kernel_size, const float* rect_lut, uint8_t* out, double* out_f64) {
+  // TimeSurface::createTimeSurfaceAtTime, TimeSurface.cpp:52-135, FORWARD mode (:85-116): every pixel's decayed value is
+  // splatted bilinearly at the pixel's rectified position (precomputed_rectified_points_, :363-399: the float output of
+  // cv::undistortPoints, here rect_lut = (u, v) per raw pixel), in raster order of the SOURCE pixels, with a clamp to 1
+  // after every add.  The image is rectified by construction: no remap follows (:137-141).
+  const int W = h->W, H = h->H;
+  const double decay_sec = decay_ms / 1000.0;
+  std::vector<double> ts((size_t)W * H, 0.0);
+  for (int y = 0; y < H; ++y)
+    for (int x = 0; x < W; ++x) {
+      const auto& eq = h->q[(size_t)x + (size_t)W * y];
+      const esvo_event_t* found = nullptr;
+      for (auto it = eq.rbegin(); it != eq.rend(); ++it)
+        if (ev_ns(*it) < t_ns) { found = &*it; break; }
+      if (!found) continue;
+      if (!(ev_sec(*found) > 0)) continue;
+      const double dt = duration_to_sec(t_ns, ev_ns(*found));
+      double polarity = found->polarity ? 1.0 : -1.0;
+      double expVal = std::exp(-dt / decay_sec);
+      if (!ignore_polarity) expVal *= polarity;
+      const double u = (double)rect_lut[2 * ((size_t)y * W + x)], v = (double)rect_lut[2 * ((size_t)y * W + x) + 1];  // :88
+      if (u >= 0 && v >= 0) {
+        const size_t u_i = (size_t)std::floor(u), v_i = (size_t)std::floor(v);  // :92-93
+        if (u_i + 1 < (size_t)W && v_i + 1 < (size_t)H) {
+          const double fu = u - u_i, fv = v - v_i, fu1 = 1.0 - fu, fv1 = 1.0 - fv;
+          double* p00 = &ts[v_i * W + u_i];
+          double* p01 = &ts[v_i * W + u_i + 1];
+          double* p10 = &ts[(v_i + 1) * W + u_i];
+          double* p11 = &ts[(v_i + 1) * W + u_i + 1];
+          *p00 += fu1 * fv1 * expVal;  // :101-104
+          *p01 += fu * fv1 * expVal;
+          *p10 += fu1 * fv * expVal;
+          *p11 += fu * fv * expVal;
+          if (*p00 > 1) *p00 = 1;      // :106-113
+          if (*p01 > 1) *p01 = 1;
+          if (*p10 > 1) *p10 = 1;
+          if (*p11 > 1) *p11 = 1;
+        }
+      }
+    }
+  std::vector<uint8_t> img((size_t)W * H);
+  for (size_t i = 0; i < ts.size(); ++i) {
+    const double v = ignore_polarity ? 255.0 * ts[i] : 255.0 * (ts[i] + 1.0) / 2.0;  // :123-126
+    if (out_f64) out_f64[i] = v;
+    img[i] = sat_u8(cv_round(v));
+  }
+  if (median_blur_kernel_size > 0) median3_u8(img.data(), out, W, H);
+  else std::memcpy(out, img.data(), img.size());
+}
+
 extern "C" void orc_median3_u8(const uint8_t* s, uint8_t* d, int w, int h) { median3_u8(s, d, w, h); }
 extern "C" void orc_remap_bilinear_u8(const uint8_t* s, uint8_t* d, int w, int h, const float* mx,
                                       const float* my) { remap_bilinear_u8(s, d, w, h, mx, my); }

@@ -48,6 +48,10 @@ void orc_ts_push(orc_ts_handle h, const esvo_event_t* ev, size_t n);
 void orc_ts_render(orc_ts_handle h, uint64_t t_ns, double decay_ms, int ignore_polarity,
                    int median_blur_kernel_size, const float* map_x, const float* map_y,
                    uint8_t* out, uint8_t* out_prefilter);
+/* FORWARD mode of the same function (TimeSurface.cpp:85-116): rect_lut = (u, v) of every raw pixel; out_f64 (nullable) =
+ * the image handed to convertTo(CV_8U) */
+void orc_ts_render_forward(orc_ts_handle h, uint64_t t_ns, double decay_ms, int ignore_polarity, int median_blur_kernel_size,
+                           const float* rect_lut, uint8_t* out, double* out_f64);
 
 /* OpenCV-style image primitives restated in Appendix B.2 (exposed for unit tests) */
 void orc_median3_u8(const uint8_t* src, uint8_t* dst, int w, int h);

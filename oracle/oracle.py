@@ -42,6 +42,7 @@ def load(fast=False):
     lib.orc_ts_clear.argtypes = [vp]
     lib.orc_ts_push.argtypes = [vp, vp, sz]
     lib.orc_ts_render.argtypes = [vp, u64, dbl, i32, i32, vp, vp, vp, vp]
+    lib.orc_ts_render_forward.argtypes = [vp, u64, dbl, i32, i32, vp, vp, vp]
     lib.orc_median3_u8.argtypes = [vp, vp, i32, i32]
     lib.orc_remap_bilinear_u8.argtypes = [vp, vp, i32, i32, vp, vp]
     lib.orc_gaussian5_u8.argtypes = [vp, vp, i32, i32]
@@ -133,6 +134,15 @@ class OracleTS:
     def push(self, ev):
         ev = np.ascontiguousarray(ev, dtype=EVENT_DTYPE)
         self.lib.orc_ts_push(self.h, ev.ctypes.data, ev.shape[0])
+
+    def render_forward(self, t_ns, rect_lut, decay_ms=30.0, ignore_polarity=True, median_k=1, want_f64=False):
+        """createTimeSurfaceAtTime in FORWARD mode (TimeSurface.cpp:85-116): bilinear splat at the rectified positions"""
+        lut = np.ascontiguousarray(rect_lut, np.float32).reshape(self.H * self.W, 2)
+        out = np.empty((self.H, self.W), np.uint8)
+        f64 = np.empty((self.H, self.W), np.float64) if want_f64 else None
+        self.lib.orc_ts_render_forward(self.h, int(t_ns), float(decay_ms), int(bool(ignore_polarity)), int(median_k),
+                                       lut.ctypes.data, out.ctypes.data, f64.ctypes.data if want_f64 else None)
+        return (out, f64) if want_f64 else out
 
     def render(self, t_ns, decay_ms=30.0, ignore_polarity=True, median_k=1, map_x=None, map_y=None,
                want_prefilter=False):

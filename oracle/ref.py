@@ -330,6 +330,7 @@ def load_ts():
         lib.ref_ts_destroy.argtypes = [C.c_void_p]
         lib.ref_ts_push.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         lib.ref_ts_render.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
+        lib.ref_ts_set_forward.argtypes = [C.c_void_p, C.c_void_p]
         _lib_ts = lib
     return _lib_ts
 
@@ -352,6 +353,12 @@ class RefTS:
     def push(self, ev):
         ev = np.ascontiguousarray(ev, dtype=EVENT_DTYPE)
         self.lib.ref_ts_push(self.h, _p(ev), len(ev))
+
+    def set_forward(self, rect_lut):
+        """FORWARD mode (TimeSurface.cpp:85-116) with the given rectified pixel positions (cv::undistortPoints' output)"""
+        lut = np.ascontiguousarray(rect_lut, np.float32).reshape(self.H * self.W, 2)
+        self._lut = lut
+        self.lib.ref_ts_set_forward(self.h, _p(lut))
 
     def render(self, t_ns):
         out = np.empty((self.H, self.W), np.float64)

@@ -39,6 +39,15 @@ ref_ts* ref_ts_create(int width, int height, double decay_ms, int ignore_polarit
   return h;
 }
 void ref_ts_destroy(ref_ts* h) { delete h; }
+// FORWARD mode (TimeSurface.cpp:85-116): rect_lut = what cameraInfoCallback's cv::undistortPoints would have produced
+// (:374-399, an OpenCV product: injected), 2 floats per raw pixel
+void ref_ts_set_forward(ref_ts* h, const float* rect_lut) {
+  const size_t n = (size_t)h->W * h->H;
+  h->node->precomputed_rectified_points_ = Eigen::Matrix2Xd(2, n);
+  for (size_t i = 0; i < n; ++i)
+    h->node->precomputed_rectified_points_.col(i) = Eigen::Matrix<double, 2, 1>(rect_lut[2 * i], rect_lut[2 * i + 1]);
+  h->node->time_surface_mode_ = TimeSurface::FORWARD;
+}
 // eventsCallback with one EventArray message
 void ref_ts_push(ref_ts* h, const esvo_event_t* ev, size_t n) {
   auto msg = std::make_shared<dvs_msgs::EventArray>();

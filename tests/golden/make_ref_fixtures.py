@@ -226,6 +226,33 @@ def make_ts():
     print("ts", os.path.getsize(path) // 1024, "KiB")
 
 
+def make_ts_forward():
+    """The same node class in FORWARD mode (TimeSurface.cpp:85-116: bilinear splat at the rectified pixel positions with a
+    clamp after every add), the rectified positions = the upenn rig's left rect_lut (cv::undistortPoints' output, an OpenCV
+    product: injected).  Stored: the image handed to convertTo(CV_8U), rounded as convertTo rounds, and the sha-256 of its
+    f64 bytes; queue of 20, with and without polarity, stamps at and 5 ms before the newest events."""
+    import hashlib
+    rig, st = ts_inputs()
+    lut = np.array(rig.left.rect_lut, np.float32).reshape(-1, 2)
+    out = {}
+    for pol in (0, 1):
+        ts = R.RefTS(rig.width, rig.height, 30.0, not pol, 20)
+        ts.set_forward(lut)
+        done = 0
+        for k in range(1, 5):
+            tk = st.t0_ns + k * 12_000_000
+            hi = int(np.searchsorted(st.ns_left, tk))
+            ts.push(st.ev_left[done:hi])
+            done = hi
+            for j, back in enumerate((0, 5_000_000)):
+                img = ts.render(tk - back)
+                out[f"p{pol}_k{k}_b{j}"] = np.clip(np.rint(img), 0, 255).astype(np.uint8)
+                out[f"p{pol}_k{k}_b{j}_sha"] = np.frombuffer(hashlib.sha256(np.ascontiguousarray(img).tobytes()).digest(), np.uint8).copy()
+    path = os.path.join(HERE, "ref_ts_forward.npz")
+    np.savez_compressed(path, **out)
+    print("ts forward", os.path.getsize(path) // 1024, "KiB")
+
+
 NODE_SCENARIOS = ("dsec", "hkust")   # the two whose preset is the Mapping node's (upenn / rpg follow esvo_MVStereo)
 MVSTEREO_SCENARIOS = ("upenn", "rpg")  # ... and the two that follow esvo_MVStereo
 NODE_MAP_FIELDS = ("row", "col", "age", "inv_depth", "scale2", "nu", "variance", "residual", "x")
@@ -388,4 +415,5 @@ if __name__ == "__main__":
     make_track()
     make_sgm()
     make_ts()
+    make_ts_forward()
     make_node()

@@ -81,6 +81,37 @@ def test_time_surface_bit_exact(rig_name):
     assert n_cmp > 0
 
 
+@pytest.mark.parametrize("rig_name,polarity,median", [("upenn", False, 1), ("dsec", False, 1), ("upenn", True, 0)])
+def test_time_surface_forward_mode_bit_exact(rig_name, polarity, median):
+    """esvo_ts_render_forward vs createTimeSurfaceAtTime in FORWARD mode (TimeSurface.cpp:85-116; the oracle's splat is pinned to
+    the reference's source by tests/test_ref_pin.py): the order-dependent clamped splat, reproduced as a gather over
+    contribution lists sorted by source index, must give identical mono8 images on both cameras."""
+    O = _oracle()
+    rig = calib.dataset_rig(rig_name)
+    st = synth.make_stream(rig, 8000, 0.08, 0.05, 0.5, seed=11 + len(rig_name))
+    p, _ = params.make_params(params.PRESETS["mapping_dsec" if rig_name == "dsec" else "mvstereo_upenn"], rig)
+    p.ignore_polarity = 0 if polarity else 1
+    p.median_blur_kernel_size = median
+    dev = _dev(p, rig)
+    ots = [O.OracleTS(rig.width, rig.height), O.OracleTS(rig.width, rig.height)]
+    t = st.t0_ns
+    lit = 0
+    for k in range(1, 7):
+        t_next = st.t0_ns + k * 10_000_000
+        for cam, ots_c in enumerate(ots):
+            ev = st.slice(cam, t, t_next)
+            dev.ts_push_events(cam, ev)
+            ots_c.push(ev)
+        T = t_next - 123_456
+        for cam, c in enumerate((rig.left, rig.right)):
+            g = dev.ts_render_forward(cam, T)
+            o = ots[cam].render_forward(T, c.rect_lut, ignore_polarity=not polarity, median_k=median)
+            assert np.array_equal(g, o), f"{rig_name} cam{cam} tick{k}: {np.count_nonzero(g != o)} px differ"
+            lit += int(np.count_nonzero(o != (128 if polarity else 0)))   # untouched pixels: 0, or 127.5 -> 128 (round half even) with polarity
+        t = t_next
+    assert lit > 10000
+
+
 def test_time_surface_polarity_and_no_median():
     O = _oracle()
     rig = calib.dataset_rig("upenn")

@@ -316,6 +316,35 @@ def test_time_surface_raster_equals_reference_source():
     assert not np.array_equal(g["q20_k8_b2"], g["q3_k8_b2"])
 
 
+def test_forward_time_surface_equals_reference_source():
+    """createTimeSurfaceAtTime in FORWARD mode (TimeSurface.cpp:85-116, the node class compiled unmodified): the oracle's
+    splat -- raster order of the sources, clamp after every add -- gives the same f64 image bit for bit (sha-256) and the
+    same u8 image, with and without polarity, at and before the newest stamps."""
+    import hashlib
+    import sys
+    sys.path.insert(0, GOLDEN)
+    import make_ref_fixtures as mk
+    g = np.load(os.path.join(GOLDEN, "ref_ts_forward.npz"))
+    rig, st = mk.ts_inputs()
+    lut = np.array(rig.left.rect_lut, np.float32).reshape(-1, 2)
+    n = 0
+    for pol in (0, 1):
+        ts = O.OracleTS(rig.width, rig.height, queue_len=20)
+        done = 0
+        for k in range(1, 5):
+            tk = st.t0_ns + k * 12_000_000
+            hi = int(np.searchsorted(st.ns_left, tk))
+            ts.push(st.ev_left[done:hi])
+            done = hi
+            for j, back in enumerate((0, 5_000_000)):
+                u8, f64 = ts.render_forward(tk - back, lut, ignore_polarity=not pol, median_k=0, want_f64=True)
+                assert np.array_equal(u8, g[f"p{pol}_k{k}_b{j}"]), (pol, k, j)
+                sha = np.frombuffer(hashlib.sha256(np.ascontiguousarray(f64).tobytes()).digest(), np.uint8)
+                assert np.array_equal(sha, g[f"p{pol}_k{k}_b{j}_sha"]), (pol, k, j)
+                n += 1
+    assert n == 16 and int(g["p0_k4_b0"].max()) == 255 and not np.array_equal(g["p0_k4_b0"], g["p1_k4_b0"])
+
+
 def test_live_reference_time_surface_reproduces_fixture():
     from oracle import ref as R
     if not os.path.isdir(os.path.join(R.REFERENCE, "esvo_core", "src")):
