@@ -539,7 +539,9 @@ struct BM {
     std::vector<double> patch_dst((size_t)wx * wy), t1((size_t)wx * wy), t2((size_t)wx * wy);
     const double ZNCC_MAX = 1.0, thr = M->prm.bm_zncc_threshold;
     for (size_t disp = start; disp <= end; disp += step) {
-      int x2x = (int)((size_t)x1x - disp), x2y = x1y;  // bUpDownConfiguration == false
+      int x2x, x2y;  // :180-183
+      if (!M->prm.bm_updown) { x2x = (int)((size_t)x1x - disp); x2y = x1y; }
+      else { x2x = x1x; x2y = (int)((size_t)x1y - disp); }
       int ltx, lty;
       if (!isValidPatch(x2x, x2y, ltx, lty)) {
         mDispCost.emplace(disp, ZNCC_MAX);
@@ -613,7 +615,7 @@ struct BM {
                            patch_src.data(), nullptr, exact_int))
       return false;
     if (min_cost <= M->prm.bm_zncc_threshold) {  // :141
-      const double disparity = (double)(x1x - bx);            // :151
+      const double disparity = M->prm.bm_updown ? (double)(x1y - by) : (double)(x1x - bx);  // :146-151
       const double depth = M->baseline * cam.P[0] / disparity;  // :152
       // StampTransformationMap_lower_bound (utils.h:66-71): first stamp with toSec >= event toSec
       const double te = ev_sec(e);

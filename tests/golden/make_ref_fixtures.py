@@ -226,6 +226,31 @@ def make_ts():
     print("ts", os.path.getsize(path) // 1024, "KiB")
 
 
+def make_bm_step():
+    """EventBM with BM_step = 2 and 3 (EventBM.cpp:113-138,169-225: coarse pass on the stride grid, the rule that both
+    stride neighbours of the coarse minimum must have been evaluated on a valid patch, fine pass around it with the minimum
+    carried over, size_t arithmetic at the lower end) on tick 1 of two scenarios.  No shipped configuration sets it; the
+    device rejects it (ESVO_ERR_UNSUPPORTED), the oracle carries it for the day the kernel does."""
+    import copy
+    out = {}
+    for name in ("upenn", "dsec"):
+        sc = S.Scenario(name)
+        tk = sc.inputs()[1]
+        for step, updown in ((2, 0), (3, 0), (1, 1), (2, 1)):   # + BM_bUpDownConfiguration (:180-183,146-151): the search runs along y
+            p = copy.copy(sc.params)
+            p.bm_step = step
+            p.bm_updown = updown
+            r = R.RefMapper(p, sc.rig)
+            r.set_observation(tk["t"], tk["tsL"], tk["tsR"], tk["T"])
+            r.set_poses(tk["stamps"], tk["poses"])
+            mt = r.match(tk["ev"])
+            out[f"{name}_s{step}" + ("_ud" if updown else "")] = mt
+            print("bm_step", name, step, updown, len(mt))
+    path = os.path.join(HERE, "ref_bm_step.npz")
+    np.savez_compressed(path, **out)
+    print("ref_bm_step.npz", os.path.getsize(path) // 1024, "KiB")
+
+
 def make_ts_forward():
     """The same node class in FORWARD mode (TimeSurface.cpp:85-116: bilinear splat at the rectified pixel positions with a
     clamp after every add), the rectified positions = the upenn rig's left rect_lut (cv::undistortPoints' output, an OpenCV
@@ -416,4 +441,5 @@ if __name__ == "__main__":
     make_sgm()
     make_ts()
     make_ts_forward()
+    make_bm_step()
     make_node()

@@ -316,6 +316,31 @@ def test_time_surface_raster_equals_reference_source():
     assert not np.array_equal(g["q20_k8_b2"], g["q3_k8_b2"])
 
 
+@pytest.mark.parametrize("name", ["upenn", "dsec"])
+@pytest.mark.parametrize("step,updown", [(2, 0), (3, 0), (1, 1), (2, 1)])
+def test_coarse_to_fine_block_matching_equals_reference_source(name, step, updown):
+    """BM_step > 1 (EventBM.cpp:113-138,169-225) and BM_bUpDownConfiguration (:180-183,146-151: the search along y) in the
+    oracle against the reference's EventBM: same matched events, order, disparities, virtual views and costs.  (The device
+    rejects both: no shipped configuration sets them.)"""
+    import copy
+    g = np.load(os.path.join(GOLDEN, "ref_bm_step.npz"))
+    _, sc, ticks = load_fixture(name)
+    tk = ticks[1]
+    p = copy.copy(sc.params)
+    p.bm_step = step
+    p.bm_updown = updown
+    m = O.OracleMapper(p, sc.rig)
+    m.set_observation(tk["t"], tk["raw"][0], tk["raw"][1], tk["T"])
+    m.set_poses(tk["stamps"], tk["poses"])
+    ref = g[f"{name}_s{step}" + ("_ud" if updown else "")]
+    check_matches(m.match(tk["ev"]), ref)
+    p1 = copy.copy(sc.params)
+    m1 = O.OracleMapper(p1, sc.rig)
+    m1.set_observation(tk["t"], tk["raw"][0], tk["raw"][1], tk["T"])
+    m1.set_poses(tk["stamps"], tk["poses"])
+    assert 0 < len(ref) < len(m1.match(tk["ev"]))   # the coarse pass and its neighbour rule reject matches the dense search keeps
+
+
 def test_forward_time_surface_equals_reference_source():
     """createTimeSurfaceAtTime in FORWARD mode (TimeSurface.cpp:85-116, the node class compiled unmodified): the oracle's
     splat -- raster order of the sources, clamp after every add -- gives the same f64 image bit for bit (sha-256) and the
