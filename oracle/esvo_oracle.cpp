@@ -351,6 +351,19 @@ struct DP {
       invDepth = invD; scale2 = s2; variance = var; nu = nu_in;
     }
   }
+  // DepthPoint::update (Gaussian, LSnorm == "l2"), DepthPoint.cpp:146-164 + boundVariance :140-144
+  void update(double invD, double var) {
+    if (invDepth > -1e-6) {
+      double temp = invDepth;
+      invDepth = (variance * invD + var * temp) / (variance + var);
+      temp = variance;
+      variance = (temp * var) / (temp + var);
+    } else {
+      invDepth = invD;
+      variance = var;
+    }
+    if (variance < 1e-6) variance = 1e-6;
+  }
   bool valid() const { return invDepth > -1e-6; }  // DepthPoint.cpp:215-218
   bool valid(double var_thr, double age_thr, double dmax, double dmin) const {  // :221-230
     return invDepth > -1e-6 && (double)age >= age_thr && variance <= var_thr && invDepth <= dmax &&
@@ -710,6 +723,15 @@ struct DepthProblem {
       }
     };
     double x1[2], x2[2];
+    if (M->prm.ls_norm == ESVO_LSNORM_L2) {  // :43-45, 67-75, 143-147: the plain temporal residual, 255 on failure
+      std::vector<double> a1(N), a2(N);
+      if (warping(x, x1, x2) && patchInterpolation(M->tsL, x1, a1.data()) && patchInterpolation(M->tsR, x2, a2.data())) {
+        for (int i = 0; i < N; ++i) fvec[i] = a1[i] - a2[i];
+        return 1;
+      }
+      for (int i = 0; i < N; ++i) fvec[i] = 255;
+      return 0;
+    }
     if (!warping(x, x1, x2)) { fail_fill(); return 0; }
     std::vector<double> tau1(N), tau2(N);
     if (patchInterpolation(M->tsL, x1, tau1.data()) && patchInterpolation(M->tsR, x2, tau2.data())) {
@@ -929,7 +951,13 @@ bool solve_single(orc_mapper* M, const DepthProblem& prob, double d_init, double
   const double nu = M->prm.td_nu;
   const double td_stdvar = std::sqrt(nu / (nu - 2) * sq(M->prm.td_scale));  // DepthProblem.h:34
   const double invJtJ = (lm.r != 0.) ? (1. / lm.r) * (1. / lm.r) : 0.;
-  result[1] = sq(td_stdvar) * invJtJ;  // :210
+  if (M->prm.ls_norm == ESVO_LSNORM_L2) {  // :200-206: cov = |f|^2 / (values - inputs) * (J^T J)^-1
+    const double fnorm = lm.fnorm;       // lm.fvec.blueNorm(): the norm of the final residual vector
+    const double covfac = fnorm * fnorm / (double)(lm.m - 1);
+    result[1] = covfac * invJtJ;
+  } else {
+    result[1] = sq(td_stdvar) * invJtJ;  // :210
+  }
   result[2] = lm.fnorm * lm.fnorm;              // :212
   if (info) info[3] = 1;
   return true;
@@ -954,7 +982,12 @@ inline bool studentTCompatibleTest(double d1, double d2, double v1, double v2) {
   return diff < 2 * s1 || diff < 2 * s2;
 }
 
-// DepthFusion::propagate_one_point, DepthFusion.cpp:18-68 (Tdist)
+inline bool chiSquareTest(double d1, double d2, double v1, double v2) {  // :207-218
+  const double dd = sq(d1 - d2);
+  return dd / v1 + dd / v2 < 5.99;
+}
+
+// DepthFusion::propagate_one_point, DepthFusion.cpp:18-68
 bool propagate_one_point(const orc_mapper* M, const DP& prior, DP& prop, const Mat4& T) {
   double pp[3];
   for (int r = 0; r < 3; ++r)
@@ -970,10 +1003,14 @@ bool propagate_one_point(const orc_mapper* M, const DP& prior, DP& prop, const M
   denominator /= prior.p_cam[2];
   denominator += T.m[10];
   const double J = T.m[10] / sq(denominator);
-  const double scale2 = J * J * prior.scale2;
-  const double nu = prior.nu;
-  const double variance = nu / (nu - 2) * scale2;
-  prop.update_studentT(invDepth, scale2, variance, nu);
+  if (M->prm.ls_norm == ESVO_LSNORM_L2) {  // :49-53
+    prop.update(invDepth, J * J * prior.variance);
+  } else {
+    const double scale2 = J * J * prior.scale2;
+    const double nu = prior.nu;
+    const double variance = nu / (nu - 2) * scale2;
+    prop.update_studentT(invDepth, scale2, variance, nu);
+  }
   prop.p_cam[0] = pp[0]; prop.p_cam[1] = pp[1]; prop.p_cam[2] = pp[2];
   prop.residual = prior.residual;
   prop.age = prior.age;
@@ -984,6 +1021,7 @@ bool propagate_one_point(const orc_mapper* M, const DP& prior, DP& prop, const M
 int fusion(orc_mapper* M, const DP& prop, int fusion_radius) {
   int numFusion = 0;
   Grid& dm = M->map;
+  const bool l2 = M->prm.ls_norm == ESVO_LSNORM_L2;
   std::vector<std::pair<size_t, size_t>> coords;
   if (fusion_radius == 0) {
     for (int dy = 0; dy <= 1; dy++) for (int dx = 0; dx <= 1; dx++) coords.emplace_back(prop.row + dy, prop.col + dx);
@@ -995,15 +1033,19 @@ int fusion(orc_mapper* M, const DP& prop, int fusion_radius) {
     if (!boundaryCheck((double)col, (double)row, M->W(), M->H())) continue;
     if (!dm.exists(row, col)) {  // case 1
       DP dp_new(row, col);
-      dp_new.update_studentT(prop.invDepth, prop.scale2, prop.variance, prop.nu);
+      if (l2) dp_new.update(prop.invDepth, prop.variance);  // :130-131
+      else dp_new.update_studentT(prop.invDepth, prop.scale2, prop.variance, prop.nu);
       dp_new.residual = prop.residual;
       dp_new.age = prop.age;
       M->camL.cam2World(dp_new.x, prop.invDepth, dp_new.p_cam);
       dm.set(row, col, dp_new);
     } else {
       DP& c = dm.get(row, col);
-      if (studentTCompatibleTest(prop.invDepth, c.invDepth, prop.variance, c.variance)) {  // 2.1
-        c.update_studentT(prop.invDepth, prop.scale2, prop.variance, prop.nu);
+      const bool compatible = l2 ? chiSquareTest(prop.invDepth, c.invDepth, prop.variance, c.variance)   // :150-152
+                                 : studentTCompatibleTest(prop.invDepth, c.invDepth, prop.variance, c.variance);
+      if (compatible) {  // 2.1
+        if (l2) c.update(prop.invDepth, prop.variance);  // :164-165
+        else c.update_studentT(prop.invDepth, prop.scale2, prop.variance, prop.nu);
         c.age++;
         c.residual = std::min(c.residual, prop.residual);
         M->camL.cam2World(c.x, prop.invDepth, c.p_cam);
@@ -1057,7 +1099,14 @@ void regularize(orc_mapper* M) {
             double diff = std::fabs(it.invDepth - n->invDepth);
             if (diff < 2.0 * std::sqrt(it.variance) || diff < 2.0 * std::sqrt(n->variance)) close.push_back(n);
           }
-        if (close.size() > minClose) {
+        if (close.size() > minClose && M->prm.ls_norm == ESVO_LSNORM_L2) {  // :56-65: inverse-variance weighted mean
+          double totalInvVariances = 0.0, statisticalMean = 0.0;
+          for (size_t i = 0; i < close.size(); ++i) totalInvVariances += 1.0 / close[i]->variance;
+          for (size_t i = 0; i < close.size(); ++i)
+            statisticalMean += close[i]->invDepth * (1.0 / close[i]->variance) / totalInvVariances;
+          newDp.invDepth = statisticalMean;
+          isSet = true;
+        } else if (close.size() > minClose) {
           double nu_post = close[0]->nu, invDepth_post = close[0]->invDepth, scale2_post = close[0]->scale2;
           for (size_t i = 1; i < close.size(); ++i) {
             double nu_prior = nu_post, invDepth_prior = invDepth_post, scale2_prior = scale2_post;
@@ -1257,8 +1306,12 @@ extern "C" size_t orc_mapper_refine(orc_mapper_handle h, const esvo_match_t* mat
       DP dp((size_t)std::floor(m.x_left[1]), (size_t)std::floor(m.x_left[0]));  // :116
       dp.x[0] = m.x_left[0]; dp.x[1] = m.x_left[1];
       h->camL.cam2World(m.x_left, result[0], dp.p_cam);  // :119
-      const double scale2_rho = result[1] * (nu - 2) / nu;  // :125
-      dp.update_studentT(result[0], scale2_rho, result[1], nu);
+      if (h->prm.ls_norm == ESVO_LSNORM_L2) {
+        dp.update(result[0], result[1]);  // :121-122
+      } else {
+        const double scale2_rho = result[1] * (nu - 2) / nu;  // :125
+        dp.update_studentT(result[0], scale2_rho, result[1], nu);
+      }
       dp.residual = result[2];
       dp.pose_idx = m.pose_idx;
       res[i] = dp;

@@ -251,6 +251,55 @@ def make_bm_step():
     print("ref_bm_step.npz", os.path.getsize(path) // 1024, "KiB")
 
 
+L2_SCENARIOS = ("upenn", "hkust")
+L2_MAP_FIELDS = ("row", "col", "age", "inv_depth", "variance", "residual", "x")   # nu / scale are never set on this path (A-8)
+
+
+def l2_digest(mp):
+    import hashlib
+    h = hashlib.sha256()
+    for f in L2_MAP_FIELDS:
+        h.update(np.ascontiguousarray(mp[f]).tobytes())
+    return np.frombuffer(h.digest(), np.uint8).copy()
+
+
+def make_l2():
+    """LSnorm: l2 -- the Gaussian model beside the Student-t one: the plain temporal residual (DepthProblem.cpp:43-45,67-75),
+    the covariance from |f|^2 / (m - n) (DepthProblemSolver.cpp:200-206), DepthPoint::update (DepthPoint.cpp:146-164),
+    variance propagation, chiSquareTest and Gaussian fusion (DepthFusion.cpp:49-53,130-131,150-152,164-165) and the
+    inverse-variance mean of the regulariser (DepthRegularization.cpp:56-65), on two scenarios (hkust regularises).  The
+    matches are those of ref_<name>.npz (block matching does not depend on the norm).  No shipped configuration sets it; the
+    device rejects it, the oracle carries it."""
+    import copy
+    from esvo_amd.abi import LSNORM_L2
+    out = {}
+    for name in L2_SCENARIOS:
+        sc = S.Scenario(name)
+        ticks = sc.inputs()
+        g = np.load(os.path.join(HERE, f"ref_{name}.npz"))
+        p = copy.copy(sc.params)
+        p.ls_norm = LSNORM_L2
+        r = R.RefMapper(p, sc.rig)
+        sizes = []
+        for k, tk in enumerate(ticks):
+            r.set_observation(tk["t"], tk["tsL"], tk["tsR"], tk["T"])
+            r.set_poses(tk["stamps"], tk["poses"])
+            mt = r.match(tk["ev"])
+            assert mt.tobytes() == np.ascontiguousarray(g[f"matches{k}"]).tobytes()
+            pts = r.refine(mt, cull=True)
+            r.push_frame(pts, tk["poses"])
+            nf = r.fuse()
+            mp = r.get_map()
+            out.update({f"{name}_points{k}": pts, f"{name}_nf{k}": nf, f"{name}_map_n{k}": len(mp), f"{name}_map_sha{k}": l2_digest(mp)})
+            sizes.append((len(pts), nf, len(mp)))
+        for f in L2_MAP_FIELDS:
+            out[f"{name}_last_{f}"] = mp[f] if mp[f].dtype.kind == "f" else mp[f].astype(np.uint16)
+        print("l2", name, sizes)
+    path = os.path.join(HERE, "ref_l2.npz")
+    np.savez_compressed(path, **out)
+    print("ref_l2.npz", os.path.getsize(path) // 1024, "KiB")
+
+
 def make_ts_forward():
     """The same node class in FORWARD mode (TimeSurface.cpp:85-116: bilinear splat at the rectified pixel positions with a
     clamp after every add), the rectified positions = the upenn rig's left rect_lut (cv::undistortPoints' output, an OpenCV
@@ -442,4 +491,5 @@ if __name__ == "__main__":
     make_ts()
     make_ts_forward()
     make_bm_step()
+    make_l2()
     make_node()

@@ -341,6 +341,42 @@ def test_coarse_to_fine_block_matching_equals_reference_source(name, step, updow
     assert 0 < len(ref) < len(m1.match(tk["ev"]))   # the coarse pass and its neighbour rule reject matches the dense search keeps
 
 
+@pytest.mark.parametrize("name", ["upenn", "hkust"])
+def test_gaussian_model_l2_equals_reference_source(name):
+    """LSnorm: l2 in the oracle against the reference's classes configured with it (tests/golden/ref_l2.npz), stage by stage
+    like the Student-t pin: LM result (plain residual, covariance from |f|^2 / (m - n)) to the LM tolerance; Gaussian
+    DepthPoint::update, variance propagation, chiSquareTest fusion, clean and the inverse-variance regulariser: every map
+    element bit-identical.  (The device rejects LSnorm != Tdist: no shipped configuration sets it.)"""
+    import copy
+    import sys
+    sys.path.insert(0, GOLDEN)
+    import make_ref_fixtures as mk
+    from esvo_amd.abi import LSNORM_L2
+    n = np.load(os.path.join(GOLDEN, "ref_l2.npz"))
+    g, sc, ticks = load_fixture(name)
+    p = copy.copy(sc.params)
+    p.ls_norm = LSNORM_L2
+    m = O.OracleMapper(p, sc.rig)
+    for k, tk in enumerate(ticks):
+        m.set_observation(tk["t"], tk["raw"][0], tk["raw"][1], tk["T"])
+        m.set_poses(tk["stamps"], tk["poses"])
+        ref_pts = n[f"{name}_points{k}"].copy()
+        pts = m.refine(g[f"matches{k}"], cull=True)
+        for f in ("nu", "scale2"):   # never set on the Gaussian path: the reference's DepthPoint() leaves them uninitialised (A-8)
+            ref_pts[f] = pts[f] if len(pts) == len(ref_pts) else 0
+        check_points(pts, ref_pts, rho_rtol=1e-5)
+        m.push_frame(ref_pts, tk["poses"])
+        assert m.fuse() == int(n[f"{name}_nf{k}"])
+        mp = m.get_map()
+        assert len(mp) == int(n[f"{name}_map_n{k}"])
+        if k == len(ticks) - 1:
+            for f in mk.L2_MAP_FIELDS:
+                assert np.array_equal(mp[f], n[f"{name}_last_{f}"]), f
+        assert np.array_equal(mk.l2_digest(mp), n[f"{name}_map_sha{k}"]), k
+    # the Gaussian model really is another one: its maps differ from the Student-t fixture's
+    assert int(n[f"{name}_map_n{len(ticks) - 1}"]) != len(g[f"map{len(ticks) - 1}"])
+
+
 def test_forward_time_surface_equals_reference_source():
     """createTimeSurfaceAtTime in FORWARD mode (TimeSurface.cpp:85-116, the node class compiled unmodified): the oracle's
     splat -- raster order of the sources, clamp after every add -- gives the same f64 image bit for bit (sha-256) and the
