@@ -1617,45 +1617,11 @@ extern "C" size_t orc_select_events_sgm(const esvo_event_t* ev, size_t n, uint64
   }
   return cnt;
 }
-// InitializationAtTime on the current observation (set_observation: the UN-smoothed pair is used, :444) and the SGM event
-// selection; returns the number of SGM depth points, or 0 when fewer than min_points (INIT_SGM_DP_NUM_THRESHOLD) were
-// found -- then nothing is pushed.  On success the points open the fusion window (:485) and naive_propagation fills the
-// DepthFrame (DepthFusion.cpp:234-288).  disp_out (nullable): the disparity image.
-extern "C" size_t orc_mapper_init_sgm(orc_mapper_handle h, const uint8_t* ts_left, const uint8_t* ts_right, const esvo_event_t* ev,
-                                      size_t n, size_t min_points, int16_t* disp_out) {
-  const int W = h->W(), H = h->H();
-  std::vector<int16_t> disp((size_t)W * H);
-  orc_sgbm_compute(ts_left, ts_right, W, H, 48, 11, 8 * 11 * 11, 32 * 11 * 11, 11, disp.data());
-  if (disp_out) std::memcpy(disp_out, disp.data(), sizeof(int16_t) * disp.size());
-  const esvo_params_t& p = h->prm;
-  Frame f;
-  f.poses.push_back(h->T_world_obs);
-  const double var_SGM = 0.001 * 0.001;
-  for (size_t i = 0; i < n; ++i) {  // createEdgeMask with radius 0 (:1000-1044) + the loop of :456-480
-    const esvo_event_t& e = ev[i];
-    if (e.x >= W || e.y >= H) continue;
-    const double cx = h->camL.lut[2 * ((size_t)e.y * W + e.x)], cy = h->camL.lut[2 * ((size_t)e.y * W + e.x) + 1];
-    const int xc = (int)std::floor(cx), yc = (int)std::floor(cy);
-    if (xc < 0 || xc >= W || yc < 0 || yc >= H) continue;
-    const double d = disp[(size_t)yc * W + xc] / 16.0;
-    if (d < 0) continue;
-    DP dp((size_t)xc, (size_t)yc);  // DepthPoint dp(x, y): the constructor takes (row, col) -- reproduced as written
-    dp.x[0] = xc * 1.0; dp.x[1] = yc * 1.0;
-    const double invDepth = d / (h->camL.P[0] * h->baseline);
-    if (invDepth < p.invdepth_min || invDepth > p.invdepth_max) continue;
-    h->camL.cam2World(dp.x, invDepth, dp.p_cam);
-    dp.invDepth = invDepth;  // DepthPoint::update on a new point (DepthPoint.cpp:146-164) + boundVariance
-    dp.variance = var_SGM < 1e-6 ? 1e-6 : var_SGM;
-    dp.residual = 0.0;
-    dp.age = (size_t)p.age_vis_threshold;
-    dp.pose_idx = 0;
-    f.pts.push_back(dp);
-  }
-  if (f.pts.size() < min_points) return 0;
-  const size_t n_pts = f.pts.size();
-  h->map.init(W, H);
-  h->T_world_frame = h->T_world_obs;
-  // DepthFusion::naive_propagation, DepthFusion.cpp:234-288
+// DepthFusion::naive_propagation, DepthFusion.cpp:234-288: every point of the frame into the current DepthFrame (Gaussian
+// variance propagation, 2 x 2 cells, new / closer-and-better-residual replace); used by InitializationAtTime and by
+// esvo_MVStereo's PURE_BLOCK_MATCHING mode
+static void naive_propagation(orc_mapper* h, const Frame& f) {
+  const size_t W = h->W(), H = h->H();
   const Mat4 T_frame_world = rigid_inverse(h->T_world_frame);
   for (const DP& prior : f.pts) {
     const Mat4 T = mat4_mul(T_frame_world, f.poses[prior.pose_idx]);
@@ -1696,6 +1662,75 @@ extern "C" size_t orc_mapper_init_sgm(orc_mapper_handle h, const uint8_t* ts_lef
         }
       }
   }
+}
+
+// InitializationAtTime on the current observation (set_observation: the UN-smoothed pair is used, :444) and the SGM event
+// selection; returns the number of SGM depth points, or 0 when fewer than min_points (INIT_SGM_DP_NUM_THRESHOLD) were
+// found -- then nothing is pushed.  On success the points open the fusion window (:485) and naive_propagation fills the
+// DepthFrame (DepthFusion.cpp:234-288).  disp_out (nullable): the disparity image.
+// esvo_MVStereo::MappingAtTime in PURE_BLOCK_MATCHING mode (esvo_MVStereo.cpp:383-432): block matching, vEMP2vDP
+// (:1072-1094: a Gaussian DepthPoint per match with pseudo-variance 0 -> the 1e-6 bound, residual = ZNCC cost, age =
+// age_vis_threshold), a window of maxNumFusionFrames frames, naive_propagation of every frame (newest first) into a new
+// DepthFrame.  Returns the number of matches.
+extern "C" size_t orc_mapper_tick_bm_only(orc_mapper_handle h, const esvo_event_t* ev, size_t n) {
+  std::vector<esvo_match_t> vEMP(n ? n : 1);
+  const size_t nm = orc_mapper_match(h, ev, n, vEMP.data(), n);
+  Frame f;
+  f.poses = h->pose_T;
+  for (size_t i = 0; i < nm; ++i) {
+    const esvo_match_t& m = vEMP[i];
+    DP dp((size_t)std::floor(m.x_left[1]), (size_t)std::floor(m.x_left[0]));
+    dp.x[0] = m.x_left[0]; dp.x[1] = m.x_left[1];
+    h->camL.cam2World(m.x_left, m.inv_depth, dp.p_cam);
+    dp.update(m.inv_depth, 0.0);
+    dp.residual = m.cost;
+    dp.age = (size_t)h->prm.age_vis_threshold;
+    dp.pose_idx = m.pose_idx;
+    f.pts.push_back(dp);
+  }
+  h->window.push_back(std::move(f));
+  while (h->window.size() > (size_t)h->prm.max_fusion_frames) h->window.pop_front();
+  h->map.init(h->W(), h->H());
+  h->T_world_frame = h->T_world_obs;
+  for (auto it = h->window.rbegin(); it != h->window.rend(); ++it) naive_propagation(h, *it);
+  return nm;
+}
+
+extern "C" size_t orc_mapper_init_sgm(orc_mapper_handle h, const uint8_t* ts_left, const uint8_t* ts_right, const esvo_event_t* ev,
+                                      size_t n, size_t min_points, int16_t* disp_out) {
+  const int W = h->W(), H = h->H();
+  std::vector<int16_t> disp((size_t)W * H);
+  orc_sgbm_compute(ts_left, ts_right, W, H, 48, 11, 8 * 11 * 11, 32 * 11 * 11, 11, disp.data());
+  if (disp_out) std::memcpy(disp_out, disp.data(), sizeof(int16_t) * disp.size());
+  const esvo_params_t& p = h->prm;
+  Frame f;
+  f.poses.push_back(h->T_world_obs);
+  const double var_SGM = 0.001 * 0.001;
+  for (size_t i = 0; i < n; ++i) {  // createEdgeMask with radius 0 (:1000-1044) + the loop of :456-480
+    const esvo_event_t& e = ev[i];
+    if (e.x >= W || e.y >= H) continue;
+    const double cx = h->camL.lut[2 * ((size_t)e.y * W + e.x)], cy = h->camL.lut[2 * ((size_t)e.y * W + e.x) + 1];
+    const int xc = (int)std::floor(cx), yc = (int)std::floor(cy);
+    if (xc < 0 || xc >= W || yc < 0 || yc >= H) continue;
+    const double d = disp[(size_t)yc * W + xc] / 16.0;
+    if (d < 0) continue;
+    DP dp((size_t)xc, (size_t)yc);  // DepthPoint dp(x, y): the constructor takes (row, col) -- reproduced as written
+    dp.x[0] = xc * 1.0; dp.x[1] = yc * 1.0;
+    const double invDepth = d / (h->camL.P[0] * h->baseline);
+    if (invDepth < p.invdepth_min || invDepth > p.invdepth_max) continue;
+    h->camL.cam2World(dp.x, invDepth, dp.p_cam);
+    dp.invDepth = invDepth;  // DepthPoint::update on a new point (DepthPoint.cpp:146-164) + boundVariance
+    dp.variance = var_SGM < 1e-6 ? 1e-6 : var_SGM;
+    dp.residual = 0.0;
+    dp.age = (size_t)p.age_vis_threshold;
+    dp.pose_idx = 0;
+    f.pts.push_back(dp);
+  }
+  if (f.pts.size() < min_points) return 0;
+  const size_t n_pts = f.pts.size();
+  h->map.init(W, H);
+  h->T_world_frame = h->T_world_obs;
+  naive_propagation(h, f);
   h->window.push_back(std::move(f));  // dqvDepthPoints_.push_back(vdp_sgm): no window policy here (:485)
   return n_pts;
 }

@@ -106,6 +106,8 @@ void orc_mapper_push_frame(orc_mapper_handle h, const esvo_depth_point_t* pts, s
 size_t orc_mapper_fuse(orc_mapper_handle h);
 /* whole MappingAtTime on already-selected events (esvo_Mapping.cpp:261-431) */
 size_t orc_mapper_tick(orc_mapper_handle h, const esvo_event_t* ev, size_t n);
+/* esvo_MVStereo's PURE_BLOCK_MATCHING mode (esvo_MVStereo.cpp:383-432): BM, vEMP2vDP, CONST_FRAMES window, naive_propagation */
+size_t orc_mapper_tick_bm_only(orc_mapper_handle h, const esvo_event_t* ev, size_t n);
 
 size_t orc_mapper_map_size(orc_mapper_handle h);
 size_t orc_mapper_get_map(orc_mapper_handle h, esvo_depth_point_t* out, size_t cap);

@@ -72,6 +72,8 @@ def load(fast=False):
     lib.orc_mapper_fuse.argtypes = [vp]
     lib.orc_mapper_tick.restype = sz
     lib.orc_mapper_tick.argtypes = [vp, vp, sz]
+    lib.orc_mapper_tick_bm_only.restype = sz
+    lib.orc_mapper_tick_bm_only.argtypes = [vp, vp, sz]
     lib.orc_mapper_map_size.restype = sz
     lib.orc_mapper_map_size.argtypes = [vp]
     lib.orc_mapper_get_map.restype = sz
@@ -322,6 +324,11 @@ class OracleMapper:
     def tick(self, ev):
         ev = np.ascontiguousarray(ev, dtype=EVENT_DTYPE)
         return self.lib.orc_mapper_tick(self.h, ev.ctypes.data, ev.shape[0])
+
+    def tick_bm_only(self, ev):
+        """esvo_MVStereo::MappingAtTime in PURE_BLOCK_MATCHING mode (esvo_MVStereo.cpp:383-432); returns the match count"""
+        ev = np.ascontiguousarray(ev, dtype=EVENT_DTYPE)
+        return self.lib.orc_mapper_tick_bm_only(self.h, ev.ctypes.data, ev.shape[0])
 
     def get_map(self):
         n = self.lib.orc_mapper_map_size(self.h)

@@ -126,11 +126,11 @@ ref_node* ref_node_create(const char* calib_dir, const esvo_params_t* p, const e
   setp("BM_min_disparity", p->bm_min_disparity); setp("BM_max_disparity", p->bm_max_disparity);
   setp("BM_step", p->bm_step); setp("BM_ZNCC_Threshold", p->bm_zncc_threshold);
   setp("BM_bUpDownConfiguration", p->bm_updown ? 1 : 0);
+#ifdef REF_NODE_MVSTEREO
+  setp("MVStereoMode", 3);  // BM_PLUS_ESTIMATION (esvo_MVStereo.h:43-50), the mode of cfg/mvstereo/*.yaml (1: PURE_BLOCK_MATCHING)
+#endif
   for (auto& kv : overrides()) esvo_node_shim::params()[kv.first] = kv.second;
   overrides().clear();
-#ifdef REF_NODE_MVSTEREO
-  setp("MVStereoMode", 3);  // BM_PLUS_ESTIMATION (esvo_MVStereo.h:43-50), the mode of cfg/mvstereo/*.yaml
-#endif
   h->node.reset(new NodeClass(h->nh, h->pnh));
 #ifndef REF_NODE_MVSTEREO
   h->node->ESVO_System_Status_ = "WORKING";

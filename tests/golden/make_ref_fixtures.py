@@ -332,6 +332,17 @@ MVSTEREO_SCENARIOS = ("upenn", "rpg")  # ... and the two that follow esvo_MVSter
 NODE_MAP_FIELDS = ("row", "col", "age", "inv_depth", "scale2", "nu", "variance", "residual", "x")
 
 
+BM_ONLY_FIELDS = ("row", "col", "age", "residual")   # exact; inverse depth, variance, x: to 1e-12 (propagated p_cam)
+
+
+def fields_digest(mp, fields):
+    import hashlib
+    h = hashlib.sha256()
+    for f in fields:
+        h.update(np.ascontiguousarray(mp[f]).tobytes())
+    return np.frombuffer(h.digest(), np.uint8).copy()
+
+
 def map_digest(mp):
     """sha256 over the list order and every field of a DepthMap dump that the mapper node defines"""
     import hashlib
@@ -474,6 +485,27 @@ def make_node():
                         pre + f"reg_same_inv_depth{k}": int(np.sum(rr["map"]["inv_depth"] == g[f"map{k}"]["inv_depth"]))})
         print("mvstereo node", name, [(len(r["sel"]), len(r["matched"]), len(r["stamps"]), r["window"].tolist(), len(r["map"]))
                                       for r in res])
+    # esvo_MVStereo in PURE_BLOCK_MATCHING mode (MVStereoMode 1, esvo_MVStereo.cpp:383-432): BM, vEMP2vDP, naive_propagation of
+    # the window.  Propagated points carry p_cam through T_frame_obs (the reference's cam2World inverts a 4x4, the oracle uses
+    # the closed form: last-bit differences), so inverse depth, variance and x of older frames' points agree to 1e-12 only:
+    # row / col / age / residual are digested, the inverse depths stored per tick, variance and x for the last map
+    for name in MVSTEREO_SCENARIOS:
+        sc = S.Scenario(name)
+        ticks, st = sc.inputs(), sc.stream()
+        node = R.RefNode(sc.params, sc.rig, st.pose, mvstereo=True, extra={"MVStereoMode": 1})
+        node.push_events(st.ev_left)
+        sizes = []
+        for k, tk in enumerate(ticks):
+            node.push_observation(tk["t"], tk["tsL"], tk["tsR"])
+            assert node.data_transferring()
+            node.mapping_at_time()
+            mp = node.get_map()
+            out.update({f"mvs1_{name}_window{k}": np.array(node.window(), np.uint32), f"mvs1_{name}_map_n{k}": len(mp),
+                        f"mvs1_{name}_map_sha{k}": fields_digest(mp, BM_ONLY_FIELDS), f"mvs1_{name}_inv_depth{k}": mp["inv_depth"]})
+            sizes.append((node.window(), len(mp)))
+        out[f"mvs1_{name}_last_x"] = mp["x"]
+        out[f"mvs1_{name}_last_variance"] = mp["variance"]
+        print("mvstereo mode 1", name, sizes)
     out.update(node_init())
     path = os.path.join(HERE, "ref_node.npz")
     np.savez_compressed(path, **out)

@@ -529,6 +529,30 @@ def test_data_transfer_and_tick_glue_equal_the_reference_mvstereo_node(name):
         assert np.array_equal(_map_digest(mp), n[pre + f"map_sha{k}"]), k
 
 
+@pytest.mark.parametrize("name", ["upenn", "rpg"])
+def test_block_matching_only_mode_equals_the_reference_mvstereo_node(name):
+    """esvo_MVStereo's PURE_BLOCK_MATCHING mode (MVStereoMode 1, esvo_MVStereo.cpp:383-432, vEMP2vDP :1072-1094) in the oracle
+    against the node object: window, and every element of the naively propagated map (row / col / age / residual exact;
+    inverse depth, variance, x to 1e-12: propagated points carry p_cam, where the reference inverts a 4x4 per cam2World call)."""
+    import sys
+    sys.path.insert(0, GOLDEN)
+    import make_ref_fixtures as mk
+    n = np.load(os.path.join(GOLDEN, "ref_node.npz"))
+    g, sc, ticks = load_fixture(name)
+    m = O.OracleMapper(sc.params, sc.rig)
+    for k, tk in enumerate(ticks):
+        m.set_observation(tk["t"], tk["raw"][0], tk["raw"][1], tk["T"])
+        m.set_poses(tk["stamps"], tk["poses"])
+        assert m.tick_bm_only(tk["ev"]) == len(g[f"matches{k}"]) == int(n[f"mvs1_{name}_window{k}"][-1])
+        assert m.counters()["window_frames"] == len(n[f"mvs1_{name}_window{k}"])
+        mp = m.get_map()
+        assert len(mp) == int(n[f"mvs1_{name}_map_n{k}"])
+        assert np.array_equal(mk.fields_digest(mp, mk.BM_ONLY_FIELDS), n[f"mvs1_{name}_map_sha{k}"]), k
+        assert np.allclose(mp["inv_depth"], n[f"mvs1_{name}_inv_depth{k}"], rtol=1e-12, atol=0)
+    assert np.allclose(mp["x"], n[f"mvs1_{name}_last_x"], rtol=1e-12, atol=1e-12)
+    assert np.allclose(mp["variance"], n[f"mvs1_{name}_last_variance"], rtol=1e-12, atol=0)
+
+
 def test_const_points_window_policy_equals_the_reference_node():
     """the node's FUSION_STRATEGY = CONST_POINTS branch (esvo_Mapping.cpp:341-353) on the dsec frames: frames kept, their
     sizes, and every element of the fused + cleaned map"""
