@@ -169,6 +169,34 @@ def run_single(dev, stream, ticks, first, last, sync_each=False):
             dev.synchronize()
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-execute this command as N ranks under torch.distributed.run (one
+    process per GPU, rendezvous on 127.0.0.1, a free port).  Fails loudly when the node has fewer than N devices -- a
+    single-rank number must never be reported as an N-GPU point.  (ESVO_SHARED_GPU=1: N ranks share device 0, functional
+    tests only.)"""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < 1:
+        print("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback", file=sys.stderr)
+        return 2
+    if have < n and not os.environ.get("ESVO_SHARED_GPU"):
+        print(f"bench.py --gpus {n}: only {have} GPU(s) visible on this node (hipGetDeviceCount); refusing to run fewer ranks "
+              f"than asked for", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max((os.cpu_count() or n) // n, 1)))
+    env["ESVO_BENCH_SELF_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -185,6 +213,9 @@ def main():
     ap.add_argument("--check", action="store_true",
                     help="replay up to the first timed tick on a fresh handle and compare its DepthMap with the CPU oracle's (SHA-1)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
 
     # stdout carries the ONE JSON line and nothing else: whatever libraries write to fd 1 on the way (RCCL prints a version
     # banner at communicator creation) is routed to stderr; the line itself goes to the saved descriptor.
@@ -214,115 +245,141 @@ def main():
 
     wl = WORKLOADS[args.workload]
     K, Wm = args.steps, args.warmup
-    shard_mode = os.environ.get("ESVO_SHARD_MODE", "tick")
-    # weak scaling: K timed (and Wm warm-up) ticks PER GPU in the tick-interleaved mode; the band mode splits every tick
-    per_gpu = world if (world > 1 and shard_mode == "tick" and not args.strong) else 1
-    n_ticks = (K + Wm) * per_gpu
-    rig, stream, p, ticks = make_workload(args.workload, n_ticks, args.events_per_tick, r01_scene=args.r01_scene)
-    duration = HIST_S + (n_ticks + 1) * TICK_S
-    nd = p.bm_max_disparity - p.bm_min_disparity + 1
+    ranks_seen = None
+    rccl = None
+    if dist:  # who is really there: one line per rank (device ordinal, bus id) gathered onto rank 0's JSON line
+        props = torch.cuda.get_device_properties(local_rank)
+        mine = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.current_device(), "name": props.name,
+                "pci_bus_id": getattr(props, "pci_bus_id", None), "pid": os.getpid()}
+        ranks_seen = [None] * world
+        dist.all_gather_object(ranks_seen, mine)
+        if os.environ.get("ESVO_DIST_BACKEND", "nccl") == "nccl":
+            try:
+                ver, path = lib.comm_rccl_info()   # the RCCL the C library resolved (dlopen), not torch's notion of it
+                rccl = {"version_code": ver, "library": path}
+            except Exception as e:  # noqa: BLE001
+                rccl = {"error": str(e)}
 
-    native = (world > 1 and os.environ.get("ESVO_DIST_BACKEND", "nccl") == "nccl"
-              and os.environ.get("ESVO_NATIVE_COMM", "1") != "0")
-    comm_note = None
+    def measure(shard_mode, strong):
+        """warm-up + the timed region for one way of putting the ranks on the stream; returns the raw figures"""
+        # weak scaling: K timed (and Wm warm-up) ticks PER GPU in the tick-interleaved mode; the band mode splits every tick
+        per_gpu = world if (world > 1 and shard_mode == "tick" and not strong) else 1
+        n_ticks = (K + Wm) * per_gpu
+        rig, stream, p, ticks = make_workload(args.workload, n_ticks, args.events_per_tick, r01_scene=args.r01_scene)
+        duration = HIST_S + (n_ticks + 1) * TICK_S
 
-    def make_runner(use_native):
-        if world == 1:
-            return lib.Esvo(p, rig, device=local_rank)
-        from esvo_amd import dist as edist
-        # "tick": ticks dealt round-robin to the GPUs, one all-gather of frames per round (throughput scaling);
-        # "band": every tick split over the GPUs by slot / image row band (latency of one tick).
-        # The exchange runs inside libesvo_hip.so (esvo_comm_*: RCCL called from C); the torch.distributed drivers remain
-        # for other backends (gloo on a shared GPU: tests), with ESVO_NATIVE_COMM=0, and as the fallback below.
-        if use_native:
-            cls = edist.NativeTickSharded if shard_mode == "tick" else edist.NativeBandSharded
-        else:
-            cls = edist.TickShardedEsvo if shard_mode == "tick" else edist.ShardedEsvo
-        return cls(p, rig, rank, world, local_rank)
+        native = (world > 1 and os.environ.get("ESVO_DIST_BACKEND", "nccl") == "nccl"
+                  and os.environ.get("ESVO_NATIVE_COMM", "1") != "0")
+        comm_note = None
 
-    if args.timed_ingest:
-        t_first = stream.t0_ns + int(HIST_S * 1e9)
-        bounds = [t_first] + [tk[0] for tk in ticks]
-        chunks = [(stream.slice(0, a, b), stream.slice(1, a, b)) for a, b in zip(bounds[:-1], bounds[1:])]
+        def make_runner(use_native):
+            if world == 1:
+                return lib.Esvo(p, rig, device=local_rank)
+            from esvo_amd import dist as edist
+            # "tick": ticks dealt round-robin to the GPUs, one all-gather of frames per round (throughput scaling);
+            # "band": every tick split over the GPUs by slot / image row band (latency of one tick).
+            # The exchange runs inside libesvo_hip.so (esvo_comm_*: RCCL called from C); the torch.distributed drivers remain
+            # for other backends (gloo on a shared GPU: tests), with ESVO_NATIVE_COMM=0, and as the fallback below.
+            if use_native:
+                cls = edist.NativeTickSharded if shard_mode == "tick" else edist.NativeBandSharded
+            else:
+                cls = edist.TickShardedEsvo if shard_mode == "tick" else edist.ShardedEsvo
+            return cls(p, rig, rank, world, local_rank)
 
-    def stage(r):
-        # the whole stream goes to HBM before the timed region; with --timed-ingest only the history before the first tick
         if args.timed_ingest:
-            r.ts_push_events(0, stream.slice(0, stream.t0_ns, t_first))
-            r.ts_push_events(1, stream.slice(1, stream.t0_ns, t_first))
-        else:
-            r.ts_push_events(0, stream.ev_left)
-            r.ts_push_events(1, stream.ev_right)
+            t_first = stream.t0_ns + int(HIST_S * 1e9)
+            bounds = [t_first] + [tk[0] for tk in ticks]
+            chunks = [(stream.slice(0, a, b), stream.slice(1, a, b)) for a, b in zip(bounds[:-1], bounds[1:])]
 
-    def step(k):
-        t, stamps, poses, T = ticks[k]
-        if args.timed_ingest:
-            runner.ts_push_events(0, chunks[k][0])
-            runner.ts_push_events(1, chunks[k][1])
-        if hasattr(runner, "tick_resident"):
-            runner.tick_resident(t, T, stamps, poses)   # = ts_render x2 + set_observation + tick, one call
-        else:                                            # the multi-GPU drivers see the four calls
-            runner.ts_render(0, t, download=False)
-            runner.ts_render(1, t, download=False)
-            runner.set_observation(t, None, None, T)
-            runner.tick(t, stamps, poses)
+        def stage(r):
+            # the whole stream goes to HBM before the timed region; with --timed-ingest only the history before the first tick
+            if args.timed_ingest:
+                r.ts_push_events(0, stream.slice(0, stream.t0_ns, t_first))
+                r.ts_push_events(1, stream.slice(1, stream.t0_ns, t_first))
+            else:
+                r.ts_push_events(0, stream.ev_left)
+                r.ts_push_events(1, stream.ev_right)
 
-    n_warm, n_all = Wm * per_gpu, (Wm + K) * per_gpu
-    runner = None
-    for attempt_native in ([True, False] if native else [False]):
-        failed = None
-        try:
-            runner = make_runner(attempt_native)
-            stage(runner)
-            for k in range(n_warm):
-                step(k)
-            runner.synchronize()
-        except Exception as e:  # an error code from the C library (a hang or a fault inside RCCL cannot be caught here)
-            failed = f"{type(e).__name__}: {e}"
-        if dist:  # every rank takes the same path
-            flag = torch.tensor([1.0 if failed else 0.0], device="cuda")
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-            if flag.item() > 0 and not failed:
-                failed = "another rank failed"
-        if not failed:
-            native = attempt_native
-            break
-        if not attempt_native:
-            raise SystemExit(f"multi-GPU warm-up failed: {failed}")
-        comm_note = f"esvo_comm_* path failed in warm-up ({failed}); fell back to the torch.distributed driver"
-        print(f"[bench rank {rank}] {comm_note}", file=sys.stderr)
+        def step(k):
+            t, stamps, poses, T = ticks[k]
+            if args.timed_ingest:
+                runner.ts_push_events(0, chunks[k][0])
+                runner.ts_push_events(1, chunks[k][1])
+            if hasattr(runner, "tick_resident"):
+                runner.tick_resident(t, T, stamps, poses)   # = ts_render x2 + set_observation + tick, one call
+            else:                                            # the multi-GPU drivers see the four calls
+                runner.ts_render(0, t, download=False)
+                runner.ts_render(1, t, download=False)
+                runner.set_observation(t, None, None, T)
+                runner.tick(t, stamps, poses)
+
+        n_warm, n_all = Wm * per_gpu, (Wm + K) * per_gpu
         runner = None
-    torch.cuda.synchronize()
-    base = runner.stats()  # running totals so far (reading stats drains the handle: not done inside the timed loop)
-    if dist:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for k in range(n_warm, n_all):
-        step(k)
-    runner.synchronize()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    st = runner.stats()
-    n_events = int(st.total_events_in - base.total_events_in)
-    n_points = int(st.total_points - base.total_points)
-    n_matches = int(st.total_matches - base.total_matches)
-    ksum = np.array(list(st.sum_ms_kernel)) - np.array(list(base.sum_ms_kernel))
-    launches = max(int(st.ticks - base.ticks), 1)   # ticks THIS rank mapped (all of them unless ticks are interleaved)
-    if dist:
-        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-        if getattr(runner, "counts_are_local", False):  # tick-interleaved: every rank counted its own ticks
-            cnt = torch.tensor([n_events, n_points], device="cuda", dtype=torch.float64)
-            dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-            ev_rank, mt_rank = n_events, n_matches
-            n_events, n_points = int(cnt[0].item()), int(cnt[1].item())
+        for attempt_native in ([True, False] if native else [False]):
+            failed = None
+            try:
+                runner = make_runner(attempt_native)
+                stage(runner)
+                for k in range(n_warm):
+                    step(k)
+                runner.synchronize()
+            except Exception as e:  # an error code from the C library (a hang or a fault inside RCCL cannot be caught here)
+                failed = f"{type(e).__name__}: {e}"
+            if dist:  # every rank takes the same path
+                flag = torch.tensor([1.0 if failed else 0.0], device="cuda")
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                if flag.item() > 0 and not failed:
+                    failed = "another rank failed"
+            if not failed:
+                native = attempt_native
+                break
+            if not attempt_native:
+                raise SystemExit(f"multi-GPU warm-up failed: {failed}")
+            comm_note = f"esvo_comm_* path failed in warm-up ({failed}); fell back to the torch.distributed driver"
+            print(f"[bench rank {rank}] {comm_note}", file=sys.stderr)
+            runner = None
+        torch.cuda.synchronize()
+        base = runner.stats()  # running totals so far (reading stats drains the handle: not done inside the timed loop)
+        if dist:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for k in range(n_warm, n_all):
+            step(k)
+        runner.synchronize()
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        st = runner.stats()
+        n_events = int(st.total_events_in - base.total_events_in)
+        n_points = int(st.total_points - base.total_points)
+        n_matches = int(st.total_matches - base.total_matches)
+        ksum = np.array(list(st.sum_ms_kernel)) - np.array(list(base.sum_ms_kernel))
+        launches = max(int(st.ticks - base.ticks), 1)   # ticks THIS rank mapped (all of them unless ticks are interleaved)
+        if dist:
+            tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+            if getattr(runner, "counts_are_local", False):  # tick-interleaved: every rank counted its own ticks
+                cnt = torch.tensor([n_events, n_points], device="cuda", dtype=torch.float64)
+                dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+                ev_rank, mt_rank = n_events, n_matches
+                n_events, n_points = int(cnt[0].item()), int(cnt[1].item())
+            else:
+                ev_rank, mt_rank = n_events / world, n_matches / world
         else:
-            ev_rank, mt_rank = n_events / world, n_matches / world
-    else:
-        ev_rank, mt_rank = n_events, n_matches
+            ev_rank, mt_rank = n_events, n_matches
+        return dict(per_gpu=per_gpu, rig=rig, stream=stream, p=p, ticks=ticks, duration=duration, native=native, comm_note=comm_note,
+                    runner=runner, dt=dt, st=st, n_events=n_events, n_points=n_points, n_matches=n_matches, ksum=ksum,
+                    launches=launches, ev_rank=ev_rank, mt_rank=mt_rank, shard_mode=shard_mode)
+
+    shard_mode = os.environ.get("ESVO_SHARD_MODE", "tick")
+    M = measure(shard_mode, args.strong)
+    per_gpu, rig, stream, p, ticks, duration = M["per_gpu"], M["rig"], M["stream"], M["p"], M["ticks"], M["duration"]
+    native, comm_note, runner, dt, st = M["native"], M["comm_note"], M["runner"], M["dt"], M["st"]
+    n_events, n_points, n_matches, ksum, launches = M["n_events"], M["n_points"], M["n_matches"], M["ksum"], M["launches"]
+    ev_rank, mt_rank = M["ev_rank"], M["mt_rank"]
+    nd = p.bm_max_disparity - p.bm_min_disparity + 1
 
     kavg = ksum / launches
     if ksum[7] > 0:  # TS kernels: per-render samples (some are skipped while their events are in flight), two renders per tick
@@ -395,6 +452,10 @@ def main():
         out["roofline_kernels"].append({"kernel": name, "avg_launch_ms": float(kavg[slot]), "algorithmic_bytes_per_launch": nbytes,
                                         "achieved": gbs, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": tr,
                                         "valu_frac": None if vl is None else vl["frac"]})
+    if world > 1:
+        out["ranks_seen"] = ranks_seen
+        out["rccl"] = rccl
+        out["launcher"] = "self (python bench.py --gpus N)" if os.environ.get("ESVO_BENCH_SELF_LAUNCHED") else "external (torch.distributed.run)"
     if args.check:
         mp_ = runner.get_map()  # collective at N > 1
         if rank == 0:
@@ -405,6 +466,23 @@ def main():
         out["other_operating_points"] = other_operating_points(local_rank)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(rig, stream, p, ticks)
+    if world > 1 and "ESVO_SHARD_MODE" not in os.environ and not args.strong and not args.check and not args.no_extras:
+        # the OTHER way of using N GPUs, on the same line: every tick of ONE stream split over the ranks -- per-event work
+        # by slot, per-cell work by image row band (north_star's image-tile partition), two ncclAllReduce per tick and the
+        # all-gather of the DepthMap bands at read-out.  Strong scaling: K ticks in total, shorter ticks.
+        if hasattr(runner, "dev"):
+            runner.dev.close()
+        B = measure("band", True)
+        gm = B["runner"].get_map()   # collective: ncclAllGather of the bands
+        if rank == 0:
+            out["band_mode"] = {
+                "value": B["n_events"] / B["dt"], "unit": "events/s", "ms_per_step": B["dt"] / K * 1e3, "scaling": "strong",
+                "depth_points_per_s": B["n_points"] / B["dt"], "events_per_tick": B["n_events"] // max(K, 1),
+                "map_size_after_gather": int(len(gm)),
+                "parallelism": f"{world} GPUs: slots w % {world} for block matching + LM, {world} image row bands for fusion / clean / "
+                               f"regularisation; 2 ncclAllReduce(u64 sum) per tick + ncclAllGather of the map bands"
+                               + (" (esvo_comm_*: RCCL inside the C library)" if B["native"] else " (torch.distributed)"),
+            }
     if rank == 0:
         print(json.dumps(out), file=json_out, flush=True)
     if dist:

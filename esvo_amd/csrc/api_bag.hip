@@ -126,6 +126,7 @@ bool bz2_decode(const uint8_t* src, size_t n, std::vector<uint8_t>& dst, size_t 
 
 struct esvo_bag {
   FILE* f = nullptr;
+  uint64_t file_size = 0;         // every length read from the file is bounded by what the file can still hold
   std::string err;
   std::map<uint32_t, std::pair<std::string, std::string>> conns;  // conn id -> (topic, type)
   std::vector<uint8_t> rec_header, rec_data, chunk;  // current record / decompressed chunk
@@ -145,6 +146,10 @@ struct esvo_bag {
     if (hl && fread(rec_header.data(), 1, hl, f) != hl) { err = "truncated bag record header"; return -1; }
     if (fread(len4, 1, 4, f) != 4) { err = "truncated bag record"; return -1; }
     const uint32_t dl = rd32(len4);
+    {
+      const long at = ftell(f);
+      if (at < 0 || (uint64_t)at + dl > file_size) { err = "bag record data longer than the file (truncated or corrupt)"; return -1; }
+    }
     rec_data.resize(dl);
     if (dl && fread(rec_data.data(), 1, dl, f) != dl) { err = "truncated bag record data"; return -1; }
     if (!parse_fields(rec_header.data(), hl, fields)) { err = "malformed bag record header"; return -1; }
@@ -173,6 +178,13 @@ int esvo_bag_open(const char* path, esvo_bag_handle* out) {
   }
   esvo_bag* b = new esvo_bag();
   b->f = f;
+  {
+    const long at = ftell(f);
+    fseek(f, 0, SEEK_END);
+    const long end = ftell(f);
+    fseek(f, at, SEEK_SET);
+    b->file_size = end > 0 ? (uint64_t)end : 0;
+  }
   Fields fields;
   uint8_t op = 0;
   if (b->read_record(fields) != 0 || !field_u8(fields, "op", op) || op != 0x03) {  // bag header record (padded to 4096 B)
@@ -196,9 +208,21 @@ int esvo_bag_close(esvo_bag_handle b) {
 
 const char* esvo_bag_last_error(esvo_bag_handle b) { return b ? b->err.c_str() : ""; }
 
+static int bag_next_event_array(esvo_bag_handle b, const char* topic, const uint8_t** msg, size_t* n_bytes, uint64_t* stamp_ns,
+                                const char** topic_out);
+// no exception crosses the C boundary: an allocation a corrupt length field asked for becomes an error code
 int esvo_bag_next_event_array(esvo_bag_handle b, const char* topic, const uint8_t** msg, size_t* n_bytes, uint64_t* stamp_ns,
                               const char** topic_out) {
   if (!b || !msg || !n_bytes) return ESVO_ERR_INVALID_ARG;
+  try {
+    return bag_next_event_array(b, topic, msg, n_bytes, stamp_ns, topic_out);
+  } catch (const std::exception& e) {
+    b->err = std::string("bag read failed: ") + e.what();
+    return ESVO_ERR_UNSUPPORTED;
+  }
+}
+static int bag_next_event_array(esvo_bag_handle b, const char* topic, const uint8_t** msg, size_t* n_bytes, uint64_t* stamp_ns,
+                                const char** topic_out) {
   Fields fields;
   while (true) {
     // ---- records inside the current chunk ----
@@ -242,6 +266,7 @@ int esvo_bag_next_event_array(esvo_bag_handle b, const char* topic, const uint8_
     const std::string comp = field_str(fields, "compression");
     uint32_t size = 0;
     field_u32(fields, "size", size);
+    if (size > (1u << 30)) { b->err = "chunk claims more than 1 GiB of uncompressed data (corrupt file?)"; return ESVO_ERR_UNSUPPORTED; }
     if (comp == "none") {
       b->chunk.swap(b->rec_data);
     } else if (comp == "bz2") {
@@ -263,6 +288,7 @@ int esvo_bag_next_event_array(esvo_bag_handle b, const char* topic, const uint8_
 int esvo_ts_push_bag(esvo_handle h, int cam, esvo_bag_handle b, const char* topic, uint64_t until_ns, size_t* n_events) {
   if (!h || !b) return ESVO_ERR_INVALID_ARG;
   size_t total = 0;
+  int status = ESVO_OK;
   while (true) {
     const uint8_t* msg = nullptr;
     size_t nb = 0;
@@ -272,19 +298,24 @@ int esvo_ts_push_bag(esvo_handle h, int cam, esvo_bag_handle b, const char* topi
     const size_t left0 = b->cur_left;
     int rc = esvo_bag_next_event_array(b, topic, &msg, &nb, &stamp, nullptr);
     if (rc == 1) break;
-    if (rc) { h->err = "bag: " + b->err; return rc; }
-    if (until_ns && stamp >= until_ns) {  // not yet: step back so that the next call finds this message again
+    if (rc) { g_create_error = "bag: " + b->err; status = rc; break; }
+    bool step_back = until_ns && stamp >= until_ns;  // not yet: the next call must find this message again
+    if (!step_back) {
+      size_t n = 0;
+      rc = esvo_ts_push_event_array(h, cam, msg, nb, &n);
+      // a refused message ("event ring full: render before staging more" is ordinary flow control) is not consumed either:
+      // the caller renders and calls again, and no EventArray is lost
+      if (rc) { status = rc; step_back = true; }
+      else total += n;
+    }
+    if (step_back) {
       if (b->chunk_serial == serial0) { b->cur = cur0; b->cur_left = left0; }     // same chunk: rewind the walk
       else { b->cur = b->chunk.data(); b->cur_left = b->chunk.size(); }           // it is the first match of a new chunk
       break;
     }
-    size_t n = 0;
-    rc = esvo_ts_push_event_array(h, cam, msg, nb, &n);
-    if (rc) return rc;
-    total += n;
   }
-  if (n_events) *n_events = total;
-  return ESVO_OK;
+  if (n_events) *n_events = total;  // also on failure: what was staged before it
+  return status;
 }
 
 }  // extern "C"

@@ -44,13 +44,23 @@ struct RcclApi {
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*GetVersion)(int*) = nullptr;
+  std::string path;  // the shared object the symbols resolved into (dladdr)
 };
 static RcclApi g_rccl;
 static const char* load_rccl() {
   if (g_rccl.lib) return nullptr;
   void* lib = nullptr;
-  for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"})
-    if ((lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
+  // ESVO_RCCL_PATH pins the library; otherwise the soname already mapped into the process wins (a process that imported
+  // torch has torch's bundled RCCL, and two RCCL copies in one process must not be mixed), then the loader path, then ROCm's.
+  const char* pinned = getenv("ESVO_RCCL_PATH");
+  if (pinned && *pinned) {
+    lib = dlopen(pinned, RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) return "ESVO_RCCL_PATH could not be loaded (dlopen)";
+  }
+  if (!lib)
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"})
+      if ((lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
   if (!lib) return "librccl.so not found (dlopen)";
   RcclApi a;
   a.lib = lib;
@@ -60,6 +70,9 @@ static const char* load_rccl() {
   a.AllGather = reinterpret_cast<decltype(a.AllGather)>(dlsym(lib, "ncclAllGather"));
   a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(dlsym(lib, "ncclAllReduce"));
   a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+  a.GetVersion = reinterpret_cast<decltype(a.GetVersion)>(dlsym(lib, "ncclGetVersion"));
+  Dl_info info;
+  if (a.GetUniqueId && dladdr(reinterpret_cast<void*>(a.GetUniqueId), &info) && info.dli_fname) a.path = info.dli_fname;
   if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllGather || !a.AllReduce || !a.GetErrorString)
     return "librccl.so lacks an expected symbol";
   g_rccl = a;
@@ -88,6 +101,8 @@ struct esvo_comm {
   u64* d_send = nullptr;
   u64* d_recv[2] = {nullptr, nullptr};
   u64* d_heads = nullptr;          // [world] point counts of the gathered blocks
+  u64* d_map_heads = nullptr;      // esvo_comm_newest_map: [2] send + [2 * world] gathered (size, tick index + 1) -- a buffer of
+                                   // its own: the back stream may still copy frames out of d_recv[] while the maps are exchanged
   u64* h_heads = nullptr;          // pinned
   hipEvent_t pushed[2];            // the back stream has copied every frame out of d_recv[i]
   bool pushed_ok = false;
@@ -103,7 +118,7 @@ namespace esvo_host {
 void comm_release(esvo_context* h) {
   esvo_comm* c = h->comm;
   if (!c) return;
-  for (void* p : {(void*)c->d_send, (void*)c->d_recv[0], (void*)c->d_recv[1], (void*)c->d_heads, (void*)c->d_band_send, (void*)c->d_band_recv})
+  for (void* p : {(void*)c->d_send, (void*)c->d_recv[0], (void*)c->d_recv[1], (void*)c->d_heads, (void*)c->d_map_heads, (void*)c->d_band_send, (void*)c->d_band_recv})
     if (p) hipFree(p);
   if (c->h_heads) hipHostFree(c->h_heads);
   if (c->pushed_ok) { hipEventDestroy(c->pushed[0]); hipEventDestroy(c->pushed[1]); }
@@ -118,7 +133,7 @@ namespace {
   do {                                                                                                        \
     ncclResult_t _r = (call);                                                                                 \
     if (_r != ncclSuccess) {                                                                                  \
-      h->err = std::string(#call) + " failed: " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(_r) : "?");  \
+      g_create_error = std::string(#call) + " failed: " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(_r) : "?");  \
       return ESVO_ERR_HIP;                                                                                    \
     }                                                                                                         \
   } while (0)
@@ -163,6 +178,7 @@ int comm_setup(esvo_context* h, int rank, int world) {
   int rc = comm_alloc(h);
   if (rc) return rc;
   HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->d_heads), sizeof(u64) * world));
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->d_map_heads), sizeof(u64) * (2 + 2 * (size_t)world)));
   HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&c->h_heads), sizeof(u64) * world));
   HIPCHK(hipEventCreateWithFlags(&c->pushed[0], hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&c->pushed[1], hipEventDisableTiming));
@@ -271,8 +287,22 @@ int esvo_comm_unique_id(uint8_t id[ESVO_COMM_ID_BYTES]) {
   return ESVO_OK;
 }
 
+int esvo_comm_rccl_info(int* version, char* path, size_t path_cap) {
+  if (const char* e = load_rccl()) { g_create_error = e; return ESVO_ERR_UNSUPPORTED; }
+  if (version) {
+    *version = 0;
+    if (g_rccl.GetVersion) g_rccl.GetVersion(version);
+  }
+  if (path && path_cap) {
+    std::strncpy(path, g_rccl.path.c_str(), path_cap - 1);
+    path[path_cap - 1] = 0;
+  }
+  return ESVO_OK;
+}
+
 int esvo_comm_init(esvo_handle h, const uint8_t id[ESVO_COMM_ID_BYTES], int rank, int world) {
   if (!h || !id || world < 1 || rank < 0 || rank >= world) return ESVO_ERR_INVALID_ARG;
+  API_LOCK(h);
   if (h->comm) FAIL(ESVO_ERR_STATE, "the handle already has a communicator");
   if (const char* e = load_rccl()) FAIL(ESVO_ERR_UNSUPPORTED, e);
   HIPCHK(hipSetDevice(h->device));
@@ -282,7 +312,7 @@ int esvo_comm_init(esvo_handle h, const uint8_t id[ESVO_COMM_ID_BYTES], int rank
   std::memcpy(&u, id, sizeof(u));
   ncclResult_t r = g_rccl.CommInitRank(&h->comm->nccl, world, u, rank);
   if (r != ncclSuccess) {
-    h->err = std::string("ncclCommInitRank failed: ") + g_rccl.GetErrorString(r);
+    g_create_error = std::string("ncclCommInitRank failed: ") + g_rccl.GetErrorString(r);
     delete h->comm;
     h->comm = nullptr;
     return ESVO_ERR_HIP;
@@ -295,6 +325,7 @@ int esvo_comm_init(esvo_handle h, const uint8_t id[ESVO_COMM_ID_BYTES], int rank
 int esvo_comm_init_callbacks(esvo_handle h, int rank, int world, esvo_all_gather_fn all_gather, esvo_all_reduce_u64_fn all_reduce,
                              void* user) {
   if (!h || !all_gather || !all_reduce || world < 1 || rank < 0 || rank >= world) return ESVO_ERR_INVALID_ARG;
+  API_LOCK(h);
   if (h->comm) FAIL(ESVO_ERR_STATE, "the handle already has a communicator");
   HIPCHK(hipSetDevice(h->device));
   { int rcp = flush_pending_tick(h); if (rcp) return rcp; }
@@ -309,6 +340,7 @@ int esvo_comm_init_callbacks(esvo_handle h, int rank, int world, esvo_all_gather
 
 int esvo_comm_destroy(esvo_handle h) {
   if (!h) return ESVO_ERR_INVALID_ARG;
+  API_LOCK(h);
   if (!h->comm) return ESVO_OK;
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -326,6 +358,7 @@ int esvo_comm_owns_next_tick(esvo_handle h) {
 int esvo_comm_tick(esvo_handle h, uint64_t t_ns, const double T_world_cam[16], const uint64_t* pose_t_ns, const double* pose_T,
                    size_t m) {
   if (!h || !T_world_cam || !pose_t_ns || !pose_T) return ESVO_ERR_INVALID_ARG;
+  API_LOCK(h);
   if (!h->comm) FAIL(ESVO_ERR_STATE, "esvo_comm_init has not been called");
   if (h->sharded) FAIL(ESVO_ERR_STATE, "handle is sharded by slot/band: use esvo_comm_shard_tick");
   if (m > h->max_poses) FAIL(ESVO_ERR_CAPACITY, "pose table larger than max_poses_per_tick");
@@ -358,6 +391,7 @@ int esvo_comm_tick(esvo_handle h, uint64_t t_ns, const double T_world_cam[16], c
 
 int esvo_comm_flush(esvo_handle h) {
   if (!h) return ESVO_ERR_INVALID_ARG;
+  API_LOCK(h);
   if (!h->comm) return ESVO_OK;
   HIPCHK(hipSetDevice(h->device));
   return finish_round(h);
@@ -365,6 +399,7 @@ int esvo_comm_flush(esvo_handle h) {
 
 int esvo_comm_newest_map(esvo_handle h, esvo_depth_point_t* out, size_t cap, size_t* n, long long* tick_index) {
   if (!h || !n) return ESVO_ERR_INVALID_ARG;
+  API_LOCK(h);
   if (!h->comm) FAIL(ESVO_ERR_STATE, "esvo_comm_init has not been called");
   HIPCHK(hipSetDevice(h->device));
   esvo_comm* c = h->comm;
@@ -376,11 +411,13 @@ int esvo_comm_newest_map(esvo_handle h, esvo_depth_point_t* out, size_t cap, siz
   const size_t W = 13;
   // sizes first (8 B per rank), then the data with the largest size as block length
   u64 head[2] = {(u64)mine.size(), (u64)(c->last_own + 1)};
-  HIPCHK(hipMemcpyAsync(c->d_send, head, 16, hipMemcpyHostToDevice, h->stream));
-  rc = comm_all_gather(h, c->d_send, c->d_recv[0], 16);
+  u64* d_hs = c->d_map_heads;
+  u64* d_hr = c->d_map_heads + 2;
+  HIPCHK(hipMemcpyAsync(d_hs, head, 16, hipMemcpyHostToDevice, h->stream));
+  rc = comm_all_gather(h, d_hs, d_hr, 16);
   if (rc) return rc;
   std::vector<u64> heads(2 * (size_t)c->world);
-  HIPCHK(hipMemcpyAsync(heads.data(), c->d_recv[0], 16 * (size_t)c->world, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(heads.data(), d_hr, 16 * (size_t)c->world, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   int best = 0;
   u64 max_n = 0;
@@ -392,23 +429,37 @@ int esvo_comm_newest_map(esvo_handle h, esvo_depth_point_t* out, size_t cap, siz
   if (tick_index) *tick_index = (long long)heads[2 * best + 1] - 1;
   *n = count;
   if (!count) return ESVO_OK;  // the same on every rank
-  // the second all-gather runs on every rank whatever its `out` / `cap` (a rank that skipped it would hang the others)
+  // Every rank takes the same path from here on, whatever its `out` / `cap` and whatever its local allocations did: the
+  // ranks first agree (one more 16-byte gather) that all of them could stage the exchange, and only then gather the maps --
+  // a rank that skipped a collective the others make would hang them.
   u64 *d_s = nullptr, *d_r = nullptr;
   const size_t bw = std::max<size_t>(max_n * W, 1);
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_s), bw * 8);
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_r), bw * 8 * c->world);
   if (e == hipSuccess && !mine.empty())
     e = hipMemcpyAsync(d_s, mine.data(), mine.size() * sizeof(esvo_depth_point_t), hipMemcpyHostToDevice, h->stream);
-  if (e != hipSuccess) { h->err = "staging of the map exchange failed"; rc = ESVO_ERR_HIP; }
-  if (!rc) rc = comm_all_gather(h, d_s, d_r, bw * 8);
+  u64 ok[2] = {e == hipSuccess ? 0u : 1u, 0u};
+  bool all_ok = false;
+  if (hipMemcpyAsync(d_hs, ok, 16, hipMemcpyHostToDevice, h->stream) != hipSuccess) rc = ESVO_ERR_HIP;
+  if (!rc) rc = comm_all_gather(h, d_hs, d_hr, 16);
+  if (!rc && hipMemcpyAsync(heads.data(), d_hr, 16 * (size_t)c->world, hipMemcpyDeviceToHost, h->stream) != hipSuccess) rc = ESVO_ERR_HIP;
+  if (!rc && hipStreamSynchronize(h->stream) != hipSuccess) rc = ESVO_ERR_HIP;
+  if (!rc) {
+    all_ok = true;
+    for (int r = 0; r < c->world; ++r) all_ok = all_ok && heads[2 * r] == 0;
+    if (!all_ok) { g_create_error = "staging of the map exchange failed on a rank"; rc = ESVO_ERR_HIP; }
+  } else {
+    g_create_error = "map exchange failed";
+  }
+  if (all_ok) rc = comm_all_gather(h, d_s, d_r, bw * 8);
   if (!rc && out) {
-    if (cap < count) { h->err = "output capacity too small"; rc = ESVO_ERR_CAPACITY; }
+    if (cap < count) { g_create_error = "output capacity too small"; rc = ESVO_ERR_CAPACITY; }
     else {
       e = hipMemcpyAsync(out, d_r + (size_t)best * bw, count * sizeof(esvo_depth_point_t), hipMemcpyDeviceToHost, h->stream);
-      if (e != hipSuccess) { h->err = "copy of the gathered map failed"; rc = ESVO_ERR_HIP; }
+      if (e != hipSuccess) { g_create_error = "copy of the gathered map failed"; rc = ESVO_ERR_HIP; }
     }
   }
-  if (hipStreamSynchronize(h->stream) != hipSuccess && !rc) { h->err = "map exchange failed"; rc = ESVO_ERR_HIP; }
+  if (hipStreamSynchronize(h->stream) != hipSuccess && !rc) { g_create_error = "map exchange failed"; rc = ESVO_ERR_HIP; }
   if (d_s) hipFree(d_s);
   if (d_r) hipFree(d_r);
   return rc;
@@ -417,6 +468,7 @@ int esvo_comm_newest_map(esvo_handle h, esvo_depth_point_t* out, size_t cap, siz
 // ---- one tick split over the ranks: the three phases of esvo_shard_tick_phase with their two sums -------------------
 int esvo_comm_shard_tick(esvo_handle h, uint64_t t_ns, const uint64_t* pose_t_ns, const double* pose_T, size_t m) {
   if (!h || !pose_t_ns || !pose_T) return ESVO_ERR_INVALID_ARG;
+  API_LOCK(h);
   if (!h->comm) FAIL(ESVO_ERR_STATE, "esvo_comm_init has not been called");
   for (int phase = 0; phase < 3; ++phase) {
     int rc = esvo_shard_tick_phase(h, phase, t_ns, pose_t_ns, pose_T, m);
@@ -436,6 +488,7 @@ int esvo_comm_shard_tick(esvo_handle h, uint64_t t_ns, const uint64_t* pose_t_ns
 // order so that the result is the unsharded map's element list
 int esvo_comm_gather_map(esvo_handle h, esvo_depth_point_t* out, size_t cap, size_t* n) {
   if (!h || !n) return ESVO_ERR_INVALID_ARG;
+  API_LOCK(h);
   if (!h->comm) FAIL(ESVO_ERR_STATE, "esvo_comm_init has not been called");
   HIPCHK(hipSetDevice(h->device));
   esvo_comm* c = h->comm;

@@ -87,7 +87,7 @@ void esvo_default_params(esvo_params_t* p) {
   p->event_ring_capacity = 1 << 24;
 }
 
-const char* esvo_last_error(esvo_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+const char* esvo_last_error(esvo_handle h) { (void)h; return g_create_error.c_str(); }  // the calling thread's last error
 
 int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esvo_calib_t* right, int device,
                 esvo_handle* out) {
@@ -259,6 +259,7 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
   CK(dalloc(&h->d_export_cell, npx));
   for (int i = 0; i < EV_N; ++i) CK(hipEventCreate(&h->evt[i]));
   h->evt_ok = true;
+  CK(hipEventCreateWithFlags(&h->evt_trk_read, hipEventDisableTiming));
   CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_pose_pool), sizeof(double) * 16 * (size_t)h->max_poses * esvo_context::POSE_POOL));
   for (int i = 0; i < esvo_context::POSE_POOL; ++i) CK(hipEventCreate(&h->pool_evt[i]));
   h->pool_ok = true;
@@ -292,7 +293,8 @@ int esvo_destroy(esvo_handle h) {
   if (h->evt_ok) for (int i = 0; i < EV_N; ++i) hipEventDestroy(h->evt[i]);
   if (h->pool_ok) for (int i = 0; i < esvo_context::POSE_POOL; ++i) hipEventDestroy(h->pool_evt[i]);
   if (h->h_pose_pool) hipHostFree(h->h_pose_pool);
-  if (h->d_wire) hipFree(h->d_wire);
+  for (int cam = 0; cam < 2; ++cam) if (h->d_wire[cam]) hipFree(h->d_wire[cam]);
+  if (h->evt_trk_read) hipEventDestroy(h->evt_trk_read);
   for (void* q : {(void*)h->d_viz_bgr, (void*)h->d_viz_jet, (void*)h->d_viz_owner}) if (q) hipFree(q);
   for (void* q : {(void*)h->sgm.sobL, (void*)h->sgm.rawL, (void*)h->sgm.sobR, (void*)h->sgm.rawR, (void*)h->sgm.vol[0], (void*)h->sgm.vol[1],
                   (void*)h->sgm.vol[2], (void*)h->sgm.vol[3], (void*)h->sgm.vol[4], (void*)h->sgm.vol[5], (void*)h->sgm.d1, (void*)h->sgm.d1b,
@@ -312,18 +314,25 @@ int esvo_destroy(esvo_handle h) {
 
 int esvo_reset(esvo_handle h) {
   if (!h) return ESVO_ERR_INVALID_ARG;
+  API_LOCK(h);
+  // a reset excludes the other two groups as well: pushers in flight finish first, the tracker's images go
+  std::lock_guard<std::mutex> lp0(h->mu_push[0]), lp1(h->mu_push[1]), ltk(h->mu_track), lts(h->mu_ts), lr(h->mu_ring);
   HIPCHK(hipSetDevice(h->device));
   { int rcp = flush_pending_tick(h); if (rcp) return rcp; }
   const size_t npx = (size_t)h->W * h->H;
   HIPCHK(hipStreamSynchronize(h->stream));
   HIPCHK(hipStreamSynchronize(h->stream_l));
   HIPCHK(hipStreamSynchronize(h->stream_b));
+  HIPCHK(hipStreamSynchronize(h->stream_t));
   for (int cam = 0; cam < 2; ++cam) {
     HIPCHK(hipMemsetAsync(h->d_sae[cam], 0, sizeof(u64) * npx, h->stream));
     h->ts_host[cam].clear();
-    h->ring_base[cam] = h->ring_next[cam] = h->scattered[cam] = 0;
+    h->ring_base[cam] = h->ring_next[cam] = h->ring_reserved[cam] = h->scattered[cam] = 0;
+    h->scatter_pending_lo[cam] = ~0ull;
     h->ts_valid[cam] = false;
   }
+  h->sh_first = 0;
+  h->trk_read_pending = false;
   h->frames.clear();
   h->n_window_frames = 0;
   std::fill(h->slot_used.begin(), h->slot_used.end(), 0);
@@ -346,6 +355,7 @@ int esvo_reset(esvo_handle h) {
 
 int esvo_set_params(esvo_handle h, const esvo_params_t* params) {
   if (!h || !params) return ESVO_ERR_INVALID_ARG;
+  API_LOCK(h);
   { int rcp = flush_pending_tick(h); if (rcp) return rcp; }
   std::string why;
   int rc = validate_params(params, why);
@@ -370,6 +380,8 @@ int esvo_set_params(esvo_handle h, const esvo_params_t* params) {
 
 int esvo_set_stream(esvo_handle h, void* hip_stream) {
   if (!h) return ESVO_ERR_INVALID_ARG;
+  API_LOCK(h);
+  std::lock_guard<std::mutex> lp0(h->mu_push[0]), lp1(h->mu_push[1]);  // a pusher may be draining the front stream
   { int rcp = flush_pending_tick(h); if (rcp) return rcp; }
   HIPCHK(hipStreamSynchronize(h->stream));
   HIPCHK(hipStreamSynchronize(h->stream_l));
@@ -382,6 +394,7 @@ int esvo_set_stream(esvo_handle h, void* hip_stream) {
 
 int esvo_synchronize(esvo_handle h) {
   if (!h) return ESVO_ERR_INVALID_ARG;
+  API_LOCK(h);
   { int rcp = flush_pending_tick(h); if (rcp) return rcp; }
   HIPCHK(hipStreamSynchronize(h->stream));
   HIPCHK(hipStreamSynchronize(h->stream_l));

@@ -331,6 +331,7 @@ extern "C" {
 int esvo_map_set_observation(esvo_handle h, uint64_t t_ns, const uint8_t* ts_left, const uint8_t* ts_right,
                              const double T_world_cam[16]) {
   if (!h || !T_world_cam) return ESVO_ERR_INVALID_ARG;
+  API_LOCK(h);
   HIPCHK(hipSetDevice(h->device));
   const size_t npx = (size_t)h->W * h->H;
   const uint8_t* src[2] = {ts_left, ts_right};
@@ -356,6 +357,7 @@ int esvo_map_set_observation(esvo_handle h, uint64_t t_ns, const uint8_t* ts_lef
 
 int esvo_map_set_poses(esvo_handle h, const uint64_t* pose_t_ns, const double* pose_T, size_t m) {
   if (!h || (m && (!pose_t_ns || !pose_T))) return ESVO_ERR_INVALID_ARG;
+  API_LOCK(h);
   HIPCHK(hipSetDevice(h->device));
   return upload_poses(h, pose_t_ns, pose_T, m);
 }
@@ -363,6 +365,7 @@ int esvo_map_set_poses(esvo_handle h, const uint64_t* pose_t_ns, const double* p
 int esvo_map_match(esvo_handle h, const esvo_event_t* ev, size_t n, const uint64_t* pose_t_ns, const double* pose_T,
                    size_t m, esvo_match_t* out, size_t cap, size_t* n_out) {
   if (!h || (n && !ev) || !n_out) return ESVO_ERR_INVALID_ARG;
+  API_LOCK(h);
   if (!h->obs_set) FAIL(ESVO_ERR_STATE, "esvo_map_set_observation has not been called");
   if (n > h->max_ev) FAIL(ESVO_ERR_CAPACITY, "more events than max_events_per_tick");
   HIPCHK(hipSetDevice(h->device));
@@ -389,6 +392,7 @@ int esvo_map_match(esvo_handle h, const esvo_event_t* ev, size_t n, const uint64
 int esvo_map_refine(esvo_handle h, const esvo_match_t* matches, size_t n, int cull, esvo_depth_point_t* out, size_t cap,
                     size_t* n_out) {
   if (!h || (n && !matches) || !n_out) return ESVO_ERR_INVALID_ARG;
+  API_LOCK(h);
   if (!h->obs_set) FAIL(ESVO_ERR_STATE, "esvo_map_set_observation has not been called");
   if (n > h->max_ev) FAIL(ESVO_ERR_CAPACITY, "more matches than max_events_per_tick");
   for (size_t i = 0; i < n; ++i)
@@ -418,6 +422,7 @@ int esvo_map_refine(esvo_handle h, const esvo_match_t* matches, size_t n, int cu
 
 int esvo_map_push_frame(esvo_handle h, const esvo_depth_point_t* pts, size_t n, const double* pose_T, size_t m) {
   if (!h || (n && !pts) || (m && !pose_T)) return ESVO_ERR_INVALID_ARG;
+  API_LOCK(h);
   if (m > h->max_poses) FAIL(ESVO_ERR_CAPACITY, "pose table larger than max_poses_per_tick");
   for (size_t i = 0; i < n; ++i)
     if (pts[i].pose_idx >= m) FAIL(ESVO_ERR_INVALID_ARG, "depth point refers to a pose outside the frame's pose table");
@@ -440,6 +445,7 @@ int esvo_map_push_frame(esvo_handle h, const esvo_depth_point_t* pts, size_t n, 
 
 int esvo_map_fuse(esvo_handle h, size_t* n_fusions) {
   if (!h) return ESVO_ERR_INVALID_ARG;
+  API_LOCK(h);
   if (!h->obs_set) FAIL(ESVO_ERR_STATE, "esvo_map_set_observation has not been called");
   HIPCHK(hipSetDevice(h->device));
   { int rcp = flush_pending_tick(h); if (rcp) return rcp; }
@@ -470,6 +476,7 @@ namespace esvo_host {
 // event selection, esvo_Mapping.cpp:562-574 (Appendix A-3): walk back from lower_bound(t_end) to
 // lower_bound(t_begin), newest first, at most PROCESS_EVENT_NUM
 int select_events(esvo_context* h, uint64_t t_ns, u64* first_out, u32* n_out) {
+  std::lock_guard<std::mutex> lr(h->mu_ring);  // the ingest thread appends to ts_host / advances the ring meanwhile
   const double t_end = ns_to_sec(t_ns);
   const u64 t_begin_ns = ros_time_from_sec(std::max(0.0, t_end - 10 * h->prm.bm_half_slice_thickness));
   const double t_begin = ns_to_sec(t_begin_ns);
@@ -481,20 +488,28 @@ int select_events(esvo_context* h, uint64_t t_ns, u64* first_out, u32* n_out) {
   if (it_end == staged_end && avail > 0) { first = it_end - 1; avail -= 1; }  // end() is skipped (oracle definition)
   const u32 n = (u32)std::min<u64>(avail, (u64)h->prm.process_event_num);
   if (n > h->max_ev) FAIL(ESVO_ERR_CAPACITY, "more events than max_events_per_tick");
-  if (n && first - (n - 1) < h->ring_next[0] - std::min<u64>(h->ring_next[0], h->ring_cap))
+  // (against ring_reserved: a pusher on another thread may be overwriting the slots of its block right now)
+  if (n && first - (n - 1) < h->ring_reserved[0] - std::min<u64>(h->ring_reserved[0], h->ring_cap))
     FAIL(ESVO_ERR_STATE, "selected events were already overwritten in the event ring");
   *first_out = first;
   *n_out = n;
+  h->sh_first = first;  // under mu_ring: what the ingest thread's overwrite guard reads
   return ESVO_OK;
 }
 
 // phase 0 (front stage): poses, event selection, block matching + LM of the events of this handle's shard
 int tick_phase0(esvo_context* h, uint64_t t_ns, const uint64_t* pose_t_ns, const double* pose_T, size_t m) {
-  // (the counter row of this tick's parity -- last used two ticks ago, collected since -- is cleared with the pose upload)
-  int rc = upload_poses(h, pose_t_ns, pose_T, m, h->d_counters2[h->fpar ^ 1]);
-  if (rc) return rc;
+  // Everything that can refuse the tick (pose table too large, events beyond the capacity or already overwritten in
+  // the ring) is checked BEFORE any per-tick state is switched: a refused tick must leave no trace, in particular not in
+  // the pose-table double buffer, which the LM stage of a still pending tick reads and whose content the back stage
+  // copies into that tick's frame slot.
+  if (m > h->max_poses) FAIL(ESVO_ERR_CAPACITY, "pose table larger than max_poses_per_tick");
   u32 n = 0;
-  rc = select_events(h, t_ns, &h->sh_first, &n);
+  u64 first = 0;
+  int rc = select_events(h, t_ns, &first, &n);
+  if (rc) return rc;
+  // (the counter row of this tick's parity -- last used two ticks ago, collected since -- is cleared with the pose upload)
+  rc = upload_poses(h, pose_t_ns, pose_T, m, h->d_counters2[h->fpar ^ 1]);
   if (rc) return rc;
   h->fpar ^= 1;
   h->d_matches = h->d_matches2[h->fpar];    // the tick's own match list and counters (the LM stage of the previous tick
@@ -702,6 +717,7 @@ int finalize_tick_stats(esvo_context* h) {
 extern "C" int esvo_map_tick_resident(esvo_handle h, uint64_t t_ns, const double T_world_cam[16], const uint64_t* pose_t_ns,
                                       const double* pose_T, size_t m) {
   if (!h || !T_world_cam || !pose_t_ns || !pose_T) return ESVO_ERR_INVALID_ARG;
+  API_LOCK(h);
   HIPCHK(hipSetDevice(h->device));
   // = esvo_ts_render x2 + esvo_map_set_observation + esvo_map_tick with both cameras in one launch per kernel; an
   // un-smoothed observation is written by the remap itself (no device-to-device copies)
@@ -725,6 +741,7 @@ extern "C" int esvo_map_tick_resident(esvo_handle h, uint64_t t_ns, const double
 
 extern "C" int esvo_map_tick(esvo_handle h, uint64_t t_ns, const uint64_t* pose_t_ns, const double* pose_T, size_t m) {
   if (!h || !pose_t_ns || !pose_T) return ESVO_ERR_INVALID_ARG;
+  API_LOCK(h);
   if (!h->obs_set) FAIL(ESVO_ERR_STATE, "esvo_map_set_observation has not been called");
   if (h->sharded) FAIL(ESVO_ERR_STATE, "handle is sharded: drive it with esvo_shard_tick_phase");
   HIPCHK(hipSetDevice(h->device));
@@ -762,6 +779,7 @@ extern "C" int esvo_map_tick(esvo_handle h, uint64_t t_ns, const uint64_t* pose_
 extern "C" int esvo_map_init_sgm(esvo_handle h, const uint8_t* ts_left, const uint8_t* ts_right, size_t min_points, size_t* n_points,
                                  int16_t* disp_out) {
   if (!h || !n_points) return ESVO_ERR_INVALID_ARG;
+  API_LOCK(h);
   if (!h->obs_set) FAIL(ESVO_ERR_STATE, "esvo_map_set_observation has not been called (time stamp and pose of the Time-Surface pair)");
   if (h->sharded) FAIL(ESVO_ERR_STATE, "handle is sharded");
   if (h->W <= 48 + 2) FAIL(ESVO_ERR_UNSUPPORTED, "image narrower than numDisparities");
@@ -800,16 +818,23 @@ extern "C" int esvo_map_init_sgm(esvo_handle h, const uint8_t* ts_left, const ui
   launch_sgbm(img[0], img[1], h->sgm, h->d_sgm_disp, h->W, h->H, h->stream);
   HIPCHK(hipGetLastError());
   // the SGM event selection (esvo_Mapping.cpp:541-551): newest first from lower_bound(t), 2 * BM_half_slice_thickness back
-  const double t_end = ns_to_sec(h->obs_t_ns);
-  const double t_begin = ns_to_sec(ros_time_from_sec(std::max(0.0, t_end - 2 * h->prm.bm_half_slice_thickness)));
-  const u64 it_end = lower_bound_sec(h, 0, t_end), it_begin = lower_bound_sec(h, 0, t_begin);
-  const u64 staged_end = h->ring_base[0] + h->ts_host[0].size();
-  u64 avail = it_end - it_begin, first = it_end;
-  if (it_end == staged_end && avail > 0) { first = it_end - 1; avail -= 1; }  // end() is skipped (oracle definition)
-  const u32 n = (u32)std::min<u64>(avail, (u64)h->prm.process_event_num + 1);
-  if (n > h->max_ev) FAIL(ESVO_ERR_CAPACITY, "more events than max_events_per_tick");
-  if (n && first - (n - 1) < h->ring_next[0] - std::min<u64>(h->ring_next[0], h->ring_cap))
-    FAIL(ESVO_ERR_STATE, "selected events were already overwritten in the event ring");
+  u64 first = 0;
+  u32 n = 0;
+  {
+    std::lock_guard<std::mutex> lr(h->mu_ring);
+    const double t_end = ns_to_sec(h->obs_t_ns);
+    const double t_begin = ns_to_sec(ros_time_from_sec(std::max(0.0, t_end - 2 * h->prm.bm_half_slice_thickness)));
+    const u64 it_end = lower_bound_sec(h, 0, t_end), it_begin = lower_bound_sec(h, 0, t_begin);
+    const u64 staged_end = h->ring_base[0] + h->ts_host[0].size();
+    u64 avail = it_end - it_begin;
+    first = it_end;
+    if (it_end == staged_end && avail > 0) { first = it_end - 1; avail -= 1; }  // end() is skipped (oracle definition)
+    n = (u32)std::min<u64>(avail, (u64)h->prm.process_event_num + 1);
+    if (n > h->max_ev) FAIL(ESVO_ERR_CAPACITY, "more events than max_events_per_tick");
+    if (n && first - (n - 1) < h->ring_reserved[0] - std::min<u64>(h->ring_reserved[0], h->ring_cap))
+      FAIL(ESVO_ERR_STATE, "selected events were already overwritten in the event ring");
+    if (n) h->sh_first = first;  // the overwrite guard of the ingest thread protects this selection like a tick's
+  }
   HIPCHK(hipMemsetAsync(h->d_counters, 0, sizeof(u32) * 16, h->stream));
   u32 count = 0;
   if (n) {
@@ -862,6 +887,7 @@ extern "C" int esvo_map_init_sgm(esvo_handle h, const uint8_t* ts_left, const ui
 extern "C" int esvo_map_front(esvo_handle h, uint64_t t_ns, const uint64_t* pose_t_ns, const double* pose_T, size_t m,
                               size_t* n_points) {
   if (!h || !pose_t_ns || !pose_T || !n_points) return ESVO_ERR_INVALID_ARG;
+  API_LOCK(h);
   if (!h->obs_set) FAIL(ESVO_ERR_STATE, "esvo_map_set_observation has not been called");
   if (h->sharded) FAIL(ESVO_ERR_STATE, "handle is sharded by slot/band: esvo_map_front maps whole ticks");
   HIPCHK(hipSetDevice(h->device));
@@ -881,6 +907,7 @@ extern "C" int esvo_map_front(esvo_handle h, uint64_t t_ns, const uint64_t* pose
 
 extern "C" int esvo_map_front_frame(esvo_handle h, const esvo_depth_point_t** d_frame) {
   if (!h || !d_frame) return ESVO_ERR_INVALID_ARG;
+  API_LOCK(h);
   *d_frame = h->d_pts_tmp;
   return ESVO_OK;
 }
@@ -888,6 +915,7 @@ extern "C" int esvo_map_front_frame(esvo_handle h, const esvo_depth_point_t** d_
 extern "C" int esvo_map_push_frame_device(esvo_handle h, const esvo_depth_point_t* d_pts, size_t n, const double* pose_T,
                                           size_t m) {
   if (!h || (n && !d_pts) || (m && !pose_T)) return ESVO_ERR_INVALID_ARG;
+  API_LOCK(h);
   if (m > h->max_poses) FAIL(ESVO_ERR_CAPACITY, "pose table larger than max_poses_per_tick");
   HIPCHK(hipSetDevice(h->device));
   int rc = flush_pending_tick(h);
@@ -906,6 +934,7 @@ extern "C" int esvo_map_push_frame_device(esvo_handle h, const esvo_depth_point_
 
 extern "C" int esvo_map_fuse_async(esvo_handle h) {
   if (!h) return ESVO_ERR_INVALID_ARG;
+  API_LOCK(h);
   if (!h->obs_set) FAIL(ESVO_ERR_STATE, "esvo_map_set_observation has not been called");
   HIPCHK(hipSetDevice(h->device));
   int rc = flush_pending_tick(h);
@@ -931,6 +960,7 @@ extern "C" int esvo_map_fuse_async(esvo_handle h) {
 extern "C" int esvo_shard_tick_phase(esvo_handle h, int phase, uint64_t t_ns, const uint64_t* pose_t_ns, const double* pose_T,
                                      size_t m) {
   if (!h) return ESVO_ERR_INVALID_ARG;
+  API_LOCK(h);
   if (!h->obs_set) FAIL(ESVO_ERR_STATE, "esvo_map_set_observation has not been called");
   if (!h->sharded) FAIL(ESVO_ERR_STATE, "call esvo_shard_set_band first");
   HIPCHK(hipSetDevice(h->device));
@@ -952,6 +982,7 @@ extern "C" {
 // ---- Outputs -----------------------------------------------------------------------------------------
 int esvo_map_get_depth_points(esvo_handle h, esvo_depth_point_t* out, size_t cap, size_t* n) {
   if (!h || !n) return ESVO_ERR_INVALID_ARG;
+  API_LOCK(h);
   HIPCHK(hipSetDevice(h->device));
   { int rcp = flush_pending_tick(h); if (rcp) return rcp; }
   std::vector<esvo_depth_point_t> v;
@@ -967,6 +998,7 @@ int esvo_map_get_depth_points(esvo_handle h, esvo_depth_point_t* out, size_t cap
 
 int esvo_map_get_committed(esvo_handle h, esvo_depth_point_t* out, size_t cap, size_t* n, uint64_t* t_ns) {
   if (!h || !n) return ESVO_ERR_INVALID_ARG;
+  API_LOCK(h);
   HIPCHK(hipSetDevice(h->device));
   if (t_ns) *t_ns = h->committed_t_ns;
   *n = 0;
@@ -984,6 +1016,7 @@ int esvo_map_get_committed(esvo_handle h, esvo_depth_point_t* out, size_t cap, s
 
 int esvo_map_get_pointcloud_xyz(esvo_handle h, float* out_xyz, size_t cap_points, size_t* n) {
   if (!h || !n) return ESVO_ERR_INVALID_ARG;
+  API_LOCK(h);
   HIPCHK(hipSetDevice(h->device));
   { int rcp = flush_pending_tick(h); if (rcp) return rcp; }
   std::vector<esvo_depth_point_t> v;
@@ -1003,6 +1036,7 @@ int esvo_map_get_pointcloud_xyz(esvo_handle h, float* out_xyz, size_t cap_points
 // pc_near_ of publishPointCloud (esvo_Mapping.cpp:925-932): what the global-cloud voxel filter is fed
 int esvo_map_get_pointcloud_near_xyz(esvo_handle h, double visualize_range, float* out_xyz, size_t cap_points, size_t* n) {
   if (!h || !n) return ESVO_ERR_INVALID_ARG;
+  API_LOCK(h);
   HIPCHK(hipSetDevice(h->device));
   { int rcp = flush_pending_tick(h); if (rcp) return rcp; }
   std::vector<esvo_depth_point_t> v;
@@ -1082,6 +1116,7 @@ int esvo_voxel_filter_xyz(const float* xyz, size_t n, float leaf, float* out_xyz
 int esvo_map_get_debug_images(esvo_handle h, double age_max_range, uint8_t* inv_depth_bgr, uint8_t* stdvar_bgr, uint8_t* age_bgr,
                               uint8_t* cost_bgr) {
   if (!h) return ESVO_ERR_INVALID_ARG;
+  API_LOCK(h);
   HIPCHK(hipSetDevice(h->device));
   { int rcp = flush_pending_tick(h); if (rcp) return rcp; }
   const size_t npx = (size_t)h->W * h->H;
@@ -1121,6 +1156,7 @@ int esvo_map_get_debug_images(esvo_handle h, double age_max_range, uint8_t* inv_
 
 int esvo_map_get_last_frame(esvo_handle h, esvo_depth_point_t* out, size_t cap, size_t* n) {
   if (!h || !n) return ESVO_ERR_INVALID_ARG;
+  API_LOCK(h);
   HIPCHK(hipSetDevice(h->device));
   { int rcp = flush_pending_tick(h); if (rcp) return rcp; }
   *n = 0;
@@ -1137,9 +1173,11 @@ int esvo_map_get_last_frame(esvo_handle h, esvo_depth_point_t* out, size_t cap, 
 
 int esvo_get_stats(esvo_handle h, esvo_stats_t* out) {
   if (!h || !out) return ESVO_ERR_INVALID_ARG;
+  API_LOCK(h);
   HIPCHK(hipSetDevice(h->device));
   int rc = finalize_tick_stats(h);
   if (rc) return rc;
+  std::lock_guard<std::mutex> lr(h->mu_ring);  // events_staged is written by the ingest thread
   *out = h->stats;
   return ESVO_OK;
 }
@@ -1148,6 +1186,7 @@ int esvo_get_stats(esvo_handle h, esvo_stats_t* out) {
 int esvo_shard_set_band(esvo_handle h, int row_begin, int row_end, int shard, int n_shards) {
   if (!h || row_begin < 0 || row_end > h->H || row_begin >= row_end || n_shards < 1 || shard < 0 || shard >= n_shards)
     return ESVO_ERR_INVALID_ARG;
+  API_LOCK(h);
   { int rcp = flush_pending_tick(h); if (rcp) return rcp; }
   h->dp.ev_shard = shard;
   h->dp.ev_nshards = n_shards;
@@ -1160,6 +1199,7 @@ int esvo_shard_set_band(esvo_handle h, int row_begin, int row_end, int shard, in
 
 int esvo_shard_exchange(esvo_handle h, void** d_ptr, size_t* n_bytes) {
   if (!h || !d_ptr || !n_bytes) return ESVO_ERR_INVALID_ARG;
+  API_LOCK(h);
   *d_ptr = h->xchg_ptr;
   *n_bytes = h->xchg_bytes;
   return ESVO_OK;

@@ -5,6 +5,7 @@
 extern "C" {
 int esvo_track_set_current(esvo_handle h, const uint8_t* ts_left, int kernel_size) {
   if (!h) return ESVO_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> _trk_lock(h->mu_track);
   if (kernel_size != 0 && kernel_size != 5)
     FAIL(ESVO_ERR_UNSUPPORTED, "tracker kernelSize must be 0 or 5 (the shipped configs); other sizes take OpenCV's float kernel path");
   HIPCHK(hipSetDevice(h->device));
@@ -19,21 +20,29 @@ int esvo_track_set_current(esvo_handle h, const uint8_t* ts_left, int kernel_siz
   if (ts_left) {  // host image (TS node in another process)
     HIPCHK(hipMemcpyAsync(h->d_trk_neg, ts_left, npx, hipMemcpyHostToDevice, h->stream_t));
     src = h->d_trk_neg;  // staged here, consumed by the blur / copy below before track_images writes it
+    if (kernel_size == 5) launch_gaussian5(src, h->d_trk_blur, h->W, h->H, h->stream_t);
+    else HIPCHK(hipMemcpyAsync(h->d_trk_blur, src, npx, hipMemcpyDeviceToDevice, h->stream_t));
   } else {
+    // The resident left surface belongs to the mapper group, whose thread may render the next one at any moment: the read
+    // is enqueued behind the newest render (EV_R1) and marked, under mu_ts, so that the next render queues behind it.
+    std::lock_guard<std::mutex> lt(h->mu_ts);
     if (!h->ts_valid[0]) FAIL(ESVO_ERR_STATE, "no device-resident left Time Surface: call esvo_ts_render(h, 0, ...) first");
     HIPCHK(hipStreamWaitEvent(h->stream_t, h->evt[EV_R1], 0));  // the render of camera 0 on the front stream
+    if (kernel_size == 5) launch_gaussian5(src, h->d_trk_blur, h->W, h->H, h->stream_t);
+    else HIPCHK(hipMemcpyAsync(h->d_trk_blur, src, npx, hipMemcpyDeviceToDevice, h->stream_t));
+    HIPCHK(hipEventRecord(h->evt_trk_read, h->stream_t));
+    h->trk_read_pending = true;
   }
-  if (kernel_size == 5) launch_gaussian5(src, h->d_trk_blur, h->W, h->H, h->stream_t);
-  else HIPCHK(hipMemcpyAsync(h->d_trk_blur, src, npx, hipMemcpyDeviceToDevice, h->stream_t));
   launch_track_images(h->d_trk_blur, h->d_trk_neg, h->d_trk_du, h->d_trk_dv, h->W, h->H, h->stream_t);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(h->stream_t));  // the left TS may be re-rendered right after this call
+  HIPCHK(hipStreamSynchronize(h->stream_t));
   h->trk_cur = true;
   return ESVO_OK;
 }
 
 int esvo_track_get_images(esvo_handle h, uint8_t* neg, int16_t* du, int16_t* dv) {
   if (!h) return ESVO_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> _trk_lock(h->mu_track);
   if (!h->trk_cur) FAIL(ESVO_ERR_STATE, "esvo_track_set_current has not been called");
   HIPCHK(hipSetDevice(h->device));
   const size_t npx = (size_t)h->W * h->H;
@@ -46,6 +55,7 @@ int esvo_track_get_images(esvo_handle h, uint8_t* neg, int16_t* du, int16_t* dv)
 
 int esvo_track_set_reference(esvo_handle h, const float* xyz_world, size_t n, const double T_world_ref[16]) {
   if (!h || (n && !xyz_world) || !T_world_ref) return ESVO_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> _trk_lock(h->mu_track);
   HIPCHK(hipSetDevice(h->device));
   if (n > h->trk_cap) {
     HIPCHK(hipStreamSynchronize(h->stream_t));
@@ -82,6 +92,7 @@ extern "C" {
 int esvo_track_residuals(esvo_handle h, const double T_left_ref[16], size_t offset, size_t count, int ls_norm,
                          double huber_threshold, double* fvec, size_t* n_out) {
   if (!h || !T_left_ref || !n_out || (ls_norm != ESVO_TRACK_L2 && ls_norm != ESVO_TRACK_HUBER)) return ESVO_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> _trk_lock(h->mu_track);
   if (!h->trk_cur) FAIL(ESVO_ERR_STATE, "esvo_track_set_current has not been called");
   HIPCHK(hipSetDevice(h->device));
   const size_t m = offset >= h->trk_n ? 0 : std::min(count, h->trk_n - offset);  // setStochasticSampling, :71-88
@@ -103,6 +114,7 @@ int esvo_track_residuals(esvo_handle h, const double T_left_ref[16], size_t offs
 int esvo_track_jacobian(esvo_handle h, const double R[9], const double t[3], size_t offset, size_t count, double* fjac,
                         size_t* n_out) {
   if (!h || !R || !t || !n_out) return ESVO_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> _trk_lock(h->mu_track);
   if (!h->trk_cur) FAIL(ESVO_ERR_STATE, "esvo_track_set_current has not been called");
   HIPCHK(hipSetDevice(h->device));
   const size_t m = offset >= h->trk_n ? 0 : std::min(count, h->trk_n - offset);

@@ -22,53 +22,70 @@ void collect_ts_timing(esvo_context* h, int only) {
   }
 }
 
+// The resident surface of `cam` is about to be overwritten on the front stream (caller holds mu_ts): a tracker thread's
+// esvo_track_set_current may still be reading the left one on the tracker stream.
+void resident_write_begin(esvo_context* h, int cam) {
+  if (cam == 0 && h->trk_read_pending) {
+    hipStreamWaitEvent(h->stream, h->evt_trk_read, 0);
+    h->trk_read_pending = false;
+  }
+}
+
 // Both cameras' surfaces at t_ns with one launch per kernel (scatter segments, decay, median + remap): what two
 // esvo_ts_render calls do, in four launches less.  obs_out[cam] (may be null) receives a second copy of the surface.
 int ts_render_pair(esvo_context* h, uint64_t t_ns, uint8_t* const obs_out[2]) {
-  u64 upto[2];
-  for (int cam = 0; cam < 2; ++cam) {
-    const auto& tsq = h->ts_host[cam];
-    const size_t k = std::lower_bound(tsq.begin(), tsq.end(), (u64)t_ns) - tsq.begin();
-    upto[cam] = h->ring_base[cam] + k;
-    if (upto[cam] < h->scattered[cam])
-      FAIL(ESVO_ERR_STATE, "esvo_ts_render: t_ns precedes events of an earlier render (render times must not decrease; esvo_reset to replay)");
-  }
-  for (int cam = 0; cam < 2; ++cam)
-    if (h->ts_timing_pending[cam] && hipEventQuery(h->evt[EV_R1 + cam * EV_TS_STRIDE]) == hipSuccess) collect_ts_timing(h, cam);
-  hipEventRecord(h->evt[EV_SC0], h->stream);
-  TsScatterSegs g;
-  int n_seg = 0;
-  for (int cam = 0; cam < 2; ++cam) {
-    u64 a = h->scattered[cam];
-    if (upto[cam] <= a) continue;
-    h->scatter_pending_lo[cam] = std::min(h->scatter_pending_lo[cam], a);
-    h->stats.events_scattered[cam] += upto[cam] - a;
-    while (a < upto[cam]) {
-      const u64 slot = a % h->ring_cap;
-      const u64 cnt = std::min<u64>(upto[cam] - a, h->ring_cap - slot);
-      if (n_seg == 4) {  // a range longer than the ring (cannot happen: staging refuses it) -- flush and go on
-        launch_ts_scatter_segs(g, n_seg, h->W, h->H, h->stream);
-        n_seg = 0;
-      }
-      g.ev[n_seg] = h->d_ring[cam] + slot; g.n[n_seg] = (size_t)cnt; g.sae[n_seg] = h->d_sae[cam];
-      ++n_seg;
-      a += cnt;
+  {
+    std::lock_guard<std::mutex> lr(h->mu_ring);  // what a pusher on another thread reads and writes (context.hpp)
+    u64 upto[2];
+    for (int cam = 0; cam < 2; ++cam) {
+      const auto& tsq = h->ts_host[cam];
+      const size_t k = std::lower_bound(tsq.begin(), tsq.end(), (u64)t_ns) - tsq.begin();
+      upto[cam] = h->ring_base[cam] + k;
+      if (upto[cam] < h->scattered[cam])
+        FAIL(ESVO_ERR_STATE, "esvo_ts_render: t_ns precedes events of an earlier render (render times must not decrease; esvo_reset to replay)");
     }
-    h->scattered[cam] = upto[cam];
+    for (int cam = 0; cam < 2; ++cam)
+      if (h->ts_timing_pending[cam] && hipEventQuery(h->evt[EV_R1 + cam * EV_TS_STRIDE]) == hipSuccess) collect_ts_timing(h, cam);
+    hipEventRecord(h->evt[EV_SC0], h->stream);
+    TsScatterSegs g;
+    int n_seg = 0;
+    for (int cam = 0; cam < 2; ++cam) {
+      u64 a = h->scattered[cam];
+      if (upto[cam] <= a) continue;
+      h->scatter_pending_lo[cam] = std::min(h->scatter_pending_lo[cam], a);
+      h->scatter_seq++;
+      h->stats.events_scattered[cam] += upto[cam] - a;
+      while (a < upto[cam]) {
+        const u64 slot = a % h->ring_cap;
+        const u64 cnt = std::min<u64>(upto[cam] - a, h->ring_cap - slot);
+        if (n_seg == 4) {  // a range longer than the ring (cannot happen: staging refuses it) -- flush and go on
+          launch_ts_scatter_segs(g, n_seg, h->W, h->H, h->stream);
+          n_seg = 0;
+        }
+        g.ev[n_seg] = h->d_ring[cam] + slot; g.n[n_seg] = (size_t)cnt; g.sae[n_seg] = h->d_sae[cam];
+        ++n_seg;
+        a += cnt;
+      }
+      h->scattered[cam] = upto[cam];
+    }
+    launch_ts_scatter_segs(g, n_seg, h->W, h->H, h->stream);
+    hipEventRecord(h->evt[EV_SC1], h->stream);
   }
-  launch_ts_scatter_segs(g, n_seg, h->W, h->H, h->stream);
-  hipEventRecord(h->evt[EV_SC1], h->stream);
   TsPair c;
   for (int cam = 0; cam < 2; ++cam) {
     c.sae[cam] = h->d_sae[cam]; c.fixmap[cam] = h->d_fixmap[cam]; c.out[cam] = h->d_ts[cam];
     c.out2[cam] = obs_out ? obs_out[cam] : nullptr;
   }
   c.raw[0] = h->d_raw; c.raw[1] = h->d_raw1;
-  launch_ts_render_pair(c, h->W, h->H, (u64)t_ns, h->prm.decay_ms / 1000.0, h->prm.ignore_polarity, h->prm.median_blur_kernel_size,
-                        h->stream);
-  hipEventRecord(h->evt[EV_R1], h->stream);
-  HIPCHK(hipGetLastError());
-  h->ts_valid[0] = h->ts_valid[1] = true;
+  {
+    std::lock_guard<std::mutex> lt(h->mu_ts);
+    resident_write_begin(h, 0);
+    launch_ts_render_pair(c, h->W, h->H, (u64)t_ns, h->prm.decay_ms / 1000.0, h->prm.ignore_polarity, h->prm.median_blur_kernel_size,
+                          h->stream);
+    hipEventRecord(h->evt[EV_R1], h->stream);
+    HIPCHK(hipGetLastError());
+    h->ts_valid[0] = h->ts_valid[1] = true;
+  }
   h->ts_timing_pending[0] = true;
   h->ts_pair_sample = true;
   h->stats.ts_frames[0]++;
@@ -78,51 +95,94 @@ int ts_render_pair(esvo_context* h, uint64_t t_ns, uint8_t* const obs_out[2]) {
 
 }  // namespace esvo_host
 
-extern "C" {
-
 // ---- Time Surface ---------------------------------------------------------------------------------
 namespace {
-// Staging runs on its own stream.  The slots it overwrites hold events older than ring_cap; a front stage still in flight
-// reads at most the max_ev events before its selection point, so only a (nearly) full ring needs the front stream drained.
-int ring_overwrite_guard(esvo_context* h, int cam, size_t n) {
-  if (h->ring_next[cam] + n <= h->ring_cap) return ESVO_OK;
-  const u64 evict_end = h->ring_next[cam] + n - h->ring_cap;  // first absolute index that survives
-  u64 oldest_read = h->scatter_pending_lo[cam];              // scatter kernels enqueued since the last drain
-  if (cam == 0) oldest_read = std::min(oldest_read, h->sh_first > (u64)h->max_ev ? h->sh_first - (u64)h->max_ev : 0);
-  if (evict_end > oldest_read) {
-    HIPCHK(hipStreamSynchronize(h->stream));
-    h->scatter_pending_lo[0] = h->scatter_pending_lo[1] = ~0ull;
+// ---- ingest protocol (INGEST group: may run on another thread than the renders and ticks of the same handle) ----------
+// Staging runs on its own stream.  A pusher (one per camera at a time, mu_push) works in three steps:
+//   begin   (mu_ring) order + capacity checks, then it RESERVES [ring_next, ring_next + n): from here on selections are
+//           validated against ring_reserved, so no new kernel can be pointed at the slots about to be overwritten;
+//   drain   the slots hold events older than ring_cap; kernels already enqueued read at most the max_ev events before the
+//           last selection point and the not yet completed scatter ranges, so only a (nearly) full ring needs the front
+//           stream drained -- done WITHOUT holding mu_ring;
+//   copy + commit  host-to-device on the ingest stream (no lock), then (mu_ring) the stamps and ring_next are published.
+struct PushTicket {
+  u64 slot = 0;
+  bool drain = false;
+  u64 seq = 0;
+};
+int push_begin(esvo_context* h, int cam, size_t n, u64 t_first, PushTicket& tk) {
+  std::lock_guard<std::mutex> lr(h->mu_ring);
+  const auto& tsq = h->ts_host[cam];
+  if (!tsq.empty() && t_first < tsq.back()) FAIL(ESVO_ERR_INVALID_ARG, "events must be sorted by time stamp (SURVEY Appendix A-1)");
+  // the ring must not overwrite events that are not yet scattered into the SAE
+  if (h->ring_next[cam] + n - h->scattered[cam] > h->ring_cap)
+    FAIL(ESVO_ERR_CAPACITY, "event ring full: render (scatter) before staging more events");
+  tk.slot = h->ring_next[cam] % h->ring_cap;
+  h->ring_reserved[cam] = h->ring_next[cam] + n;
+  if (h->ring_reserved[cam] > h->ring_cap) {
+    const u64 evict_end = h->ring_reserved[cam] - h->ring_cap;  // first absolute index that survives
+    u64 oldest_read = h->scatter_pending_lo[cam];               // scatter kernels enqueued since the last drain
+    if (cam == 0) oldest_read = std::min(oldest_read, h->sh_first > (u64)h->max_ev ? h->sh_first - (u64)h->max_ev : 0);
+    tk.drain = evict_end > oldest_read;
+    tk.seq = h->scatter_seq;
   }
   return ESVO_OK;
 }
+void push_abort(esvo_context* h, int cam) {
+  std::lock_guard<std::mutex> lr(h->mu_ring);
+  h->ring_reserved[cam] = h->ring_next[cam];
+}
+int push_drain(esvo_context* h, int cam, const PushTicket& tk) {
+  if (!tk.drain) return ESVO_OK;
+  if (hipStreamSynchronize(h->stream) != hipSuccess) { push_abort(h, cam); FAIL(ESVO_ERR_HIP, "draining the front stream failed"); }
+  std::lock_guard<std::mutex> lr(h->mu_ring);
+  if (h->scatter_seq == tk.seq) h->scatter_pending_lo[0] = h->scatter_pending_lo[1] = ~0ull;  // nothing enqueued meanwhile
+  return ESVO_OK;
+}
+template <typename StampFn>
+void push_commit(esvo_context* h, int cam, size_t n, StampFn stamp) {
+  std::lock_guard<std::mutex> lr(h->mu_ring);
+  auto& tsq = h->ts_host[cam];
+  for (size_t i = 0; i < n; ++i) tsq.push_back(stamp(i));
+  h->ring_next[cam] += n;
+  h->ring_reserved[cam] = h->ring_next[cam];
+  while (tsq.size() > h->ring_cap) { tsq.pop_front(); h->ring_base[cam]++; }
+  h->stats.events_staged[cam] += n;
+}
+#define PUSH_HIPCHK(call)                                     \
+  do {                                                        \
+    hipError_t _pe = (call);                                  \
+    if (_pe != hipSuccess) {                                  \
+      push_abort(h, cam);                                     \
+      FAIL(ESVO_ERR_HIP, std::string(#call) + " failed: " + hipGetErrorString(_pe)); \
+    }                                                         \
+  } while (0)
 }  // namespace
+
+extern "C" {
 
 int esvo_ts_push_events(esvo_handle h, int cam, const esvo_event_t* ev, size_t n) {
   if (!h || cam < 0 || cam > 1 || (n && !ev)) return ESVO_ERR_INVALID_ARG;
   if (n == 0) return ESVO_OK;
   if (n > h->ring_cap) FAIL(ESVO_ERR_CAPACITY, "event block larger than the event ring");
+  std::lock_guard<std::mutex> lp(h->mu_push[cam]);
   HIPCHK(hipSetDevice(h->device));
-  auto& tsq = h->ts_host[cam];
-  u64 last = tsq.empty() ? 0 : tsq.back();
-  for (size_t i = 0; i < n; ++i) {
-    const u64 t = (u64)ev[i].sec * 1000000000ull + ev[i].nsec;
+  auto stamp = [&](size_t i) { return (u64)ev[i].sec * 1000000000ull + ev[i].nsec; };
+  u64 last = stamp(0);
+  for (size_t i = 1; i < n; ++i) {
+    const u64 t = stamp(i);
     if (t < last) FAIL(ESVO_ERR_INVALID_ARG, "events must be sorted by time stamp (SURVEY Appendix A-1)");
     last = t;
   }
-  // the ring must not overwrite events that are not yet scattered into the SAE
-  if (h->ring_next[cam] + n - h->scattered[cam] > h->ring_cap)
-    FAIL(ESVO_ERR_CAPACITY, "event ring full: render (scatter) before staging more events");
-  { int rcg = ring_overwrite_guard(h, cam, n); if (rcg) return rcg; }
-  const u64 slot = h->ring_next[cam] % h->ring_cap;
-  const size_t first = (size_t)std::min<u64>(n, h->ring_cap - slot);
-  HIPCHK(hipMemcpyAsync(h->d_ring[cam] + slot, ev, sizeof(esvo_event_t) * first, hipMemcpyHostToDevice, h->stream_i));
+  PushTicket tk;
+  { int rc = push_begin(h, cam, n, stamp(0), tk); if (rc) return rc; }
+  { int rc = push_drain(h, cam, tk); if (rc) return rc; }
+  const size_t first = (size_t)std::min<u64>(n, h->ring_cap - tk.slot);
+  PUSH_HIPCHK(hipMemcpyAsync(h->d_ring[cam] + tk.slot, ev, sizeof(esvo_event_t) * first, hipMemcpyHostToDevice, h->stream_i));
   if (first < n)
-    HIPCHK(hipMemcpyAsync(h->d_ring[cam], ev + first, sizeof(esvo_event_t) * (n - first), hipMemcpyHostToDevice, h->stream_i));
-  HIPCHK(hipStreamSynchronize(h->stream_i));  // `ev` is borrowed for the duration of the call only; later work sees the copy
-  for (size_t i = 0; i < n; ++i) tsq.push_back((u64)ev[i].sec * 1000000000ull + ev[i].nsec);
-  h->ring_next[cam] += n;
-  while (tsq.size() > h->ring_cap) { tsq.pop_front(); h->ring_base[cam]++; }
-  h->stats.events_staged[cam] += n;
+    PUSH_HIPCHK(hipMemcpyAsync(h->d_ring[cam], ev + first, sizeof(esvo_event_t) * (n - first), hipMemcpyHostToDevice, h->stream_i));
+  PUSH_HIPCHK(hipStreamSynchronize(h->stream_i));  // `ev` is borrowed for the duration of the call only; later work sees the copy
+  push_commit(h, cam, n, stamp);
   return ESVO_OK;
 }
 
@@ -143,6 +203,7 @@ int esvo_ts_push_event_array(esvo_handle h, int cam, const uint8_t* msg, size_t 
   if ((height && (int)height != h->H) || (width && (int)width != h->W)) FAIL(ESVO_ERR_INVALID_ARG, "EventArray sensor size differs from the handle's");
   if (n == 0) return ESVO_OK;
   if (n > h->ring_cap) FAIL(ESVO_ERR_CAPACITY, "event block larger than the event ring");
+  std::lock_guard<std::mutex> lp(h->mu_push[cam]);
   HIPCHK(hipSetDevice(h->device));
   const uint8_t* rec = msg + off;
   auto stamp = [&](size_t i) {
@@ -151,29 +212,25 @@ int esvo_ts_push_event_array(esvo_handle h, int cam, const uint8_t* msg, size_t 
     const u32 nsec = (u32)r[4] | ((u32)r[5] << 8) | ((u32)r[6] << 16) | ((u32)r[7] << 24);
     return (u64)sec * 1000000000ull + nsec;
   };
-  auto& tsq = h->ts_host[cam];
-  u64 last = tsq.empty() ? 0 : tsq.back();
-  for (size_t i = 0; i < n; ++i) {
+  u64 last = stamp(0);
+  for (size_t i = 1; i < n; ++i) {
     const u64 t = stamp(i);
     if (t < last) FAIL(ESVO_ERR_INVALID_ARG, "events must be sorted by time stamp (SURVEY Appendix A-1)");
     last = t;
   }
-  if (h->ring_next[cam] + n - h->scattered[cam] > h->ring_cap)
-    FAIL(ESVO_ERR_CAPACITY, "event ring full: render (scatter) before staging more events");
-  if ((size_t)n * 13 > h->wire_cap) {
-    if (h->d_wire) { hipFree(h->d_wire); h->d_wire = nullptr; }  // the ingest stream is idle between calls
-    h->wire_cap = std::max<size_t>((size_t)n * 13, (size_t)1 << 20);
-    HIPCHK(hipMalloc(reinterpret_cast<void**>(&h->d_wire), h->wire_cap));
+  if ((size_t)n * 13 > h->wire_cap[cam]) {  // this camera's staging buffer: its pusher is the only user (mu_push)
+    if (h->d_wire[cam]) { hipFree(h->d_wire[cam]); h->d_wire[cam] = nullptr; }
+    h->wire_cap[cam] = std::max<size_t>((size_t)n * 13, (size_t)1 << 20);
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&h->d_wire[cam]), h->wire_cap[cam]));
   }
-  { int rcg = ring_overwrite_guard(h, cam, n); if (rcg) return rcg; }
-  HIPCHK(hipMemcpyAsync(h->d_wire, rec, (size_t)n * 13, hipMemcpyHostToDevice, h->stream_i));
-  launch_ts_unpack_wire(h->d_wire, n, h->d_ring[cam], h->ring_next[cam] % h->ring_cap, h->ring_cap, h->stream_i);
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(h->stream_i));  // `msg` is borrowed for the duration of the call only
-  for (size_t i = 0; i < n; ++i) tsq.push_back(stamp(i));
-  h->ring_next[cam] += n;
-  while (tsq.size() > h->ring_cap) { tsq.pop_front(); h->ring_base[cam]++; }
-  h->stats.events_staged[cam] += n;
+  PushTicket tk;
+  { int rc = push_begin(h, cam, n, stamp(0), tk); if (rc) return rc; }
+  { int rc = push_drain(h, cam, tk); if (rc) return rc; }
+  PUSH_HIPCHK(hipMemcpyAsync(h->d_wire[cam], rec, (size_t)n * 13, hipMemcpyHostToDevice, h->stream_i));
+  launch_ts_unpack_wire(h->d_wire[cam], n, h->d_ring[cam], tk.slot, h->ring_cap, h->stream_i);
+  PUSH_HIPCHK(hipGetLastError());
+  PUSH_HIPCHK(hipStreamSynchronize(h->stream_i));  // `msg` is borrowed for the duration of the call only
+  push_commit(h, cam, n, stamp);
   return ESVO_OK;
 }
 
@@ -221,30 +278,41 @@ int build_forward_lists(esvo_context* h, int cam) {
 
 int esvo_ts_render_forward(esvo_handle h, int cam, uint64_t t_ns, uint8_t* out_mono8) {
   if (!h || cam < 0 || cam > 1) return ESVO_ERR_INVALID_ARG;
+  API_LOCK(h);
   HIPCHK(hipSetDevice(h->device));
   { int rc = build_forward_lists(h, cam); if (rc) return rc; }
-  const auto& tsq = h->ts_host[cam];
-  const size_t k = std::lower_bound(tsq.begin(), tsq.end(), (u64)t_ns) - tsq.begin();
-  const u64 upto = h->ring_base[cam] + k;
-  if (upto < h->scattered[cam])
-    FAIL(ESVO_ERR_STATE, "esvo_ts_render_forward: t_ns precedes events of an earlier render (render times must not decrease; esvo_reset to replay)");
-  if (upto > h->scattered[cam]) {  // events with ts < T that are not in the SAE yet (as esvo_ts_render)
-    u64 a = h->scattered[cam];
-    h->scatter_pending_lo[cam] = std::min(h->scatter_pending_lo[cam], a);
-    h->stats.events_scattered[cam] += upto - a;
-    while (a < upto) {
-      const u64 slot = a % h->ring_cap;
-      const u64 cnt = std::min<u64>(upto - a, h->ring_cap - slot);
-      launch_ts_scatter(h->d_ring[cam] + slot, (size_t)cnt, h->d_sae[cam], h->W, h->H, h->stream);
-      a += cnt;
+  {
+    std::lock_guard<std::mutex> lr(h->mu_ring);
+    const auto& tsq = h->ts_host[cam];
+    const size_t k = std::lower_bound(tsq.begin(), tsq.end(), (u64)t_ns) - tsq.begin();
+    const u64 upto = h->ring_base[cam] + k;
+    if (upto < h->scattered[cam])
+      FAIL(ESVO_ERR_STATE, "esvo_ts_render_forward: t_ns precedes events of an earlier render (render times must not decrease; esvo_reset to replay)");
+    if (upto > h->scattered[cam]) {  // events with ts < T that are not in the SAE yet (as esvo_ts_render)
+      u64 a = h->scattered[cam];
+      h->scatter_pending_lo[cam] = std::min(h->scatter_pending_lo[cam], a);
+      h->scatter_seq++;
+      h->stats.events_scattered[cam] += upto - a;
+      while (a < upto) {
+        const u64 slot = a % h->ring_cap;
+        const u64 cnt = std::min<u64>(upto - a, h->ring_cap - slot);
+        launch_ts_scatter(h->d_ring[cam] + slot, (size_t)cnt, h->d_sae[cam], h->W, h->H, h->stream);
+        a += cnt;
+      }
+      h->scattered[cam] = upto;
     }
-    h->scattered[cam] = upto;
   }
-  launch_ts_render_forward(h->d_sae[cam], h->d_fwd_off[cam], h->d_fwd_src[cam], h->d_fwd_lut[cam], h->d_fwd_val, cam ? h->d_raw1 : h->d_raw,
-                           h->d_ts[cam], h->W, h->H, (u64)t_ns, h->prm.decay_ms / 1000.0, h->prm.ignore_polarity,
-                           h->prm.median_blur_kernel_size, h->stream);
-  HIPCHK(hipGetLastError());
-  h->ts_valid[cam] = true;
+  {
+    std::lock_guard<std::mutex> lt(h->mu_ts);
+    resident_write_begin(h, cam);
+    launch_ts_render_forward(h->d_sae[cam], h->d_fwd_off[cam], h->d_fwd_src[cam], h->d_fwd_lut[cam], h->d_fwd_val, cam ? h->d_raw1 : h->d_raw,
+                             h->d_ts[cam], h->W, h->H, (u64)t_ns, h->prm.decay_ms / 1000.0, h->prm.ignore_polarity,
+                             h->prm.median_blur_kernel_size, h->stream);
+    if (cam == 0) hipEventRecord(h->evt[EV_R1], h->stream);  // what esvo_track_set_current waits for
+    HIPCHK(hipGetLastError());
+    h->ts_valid[cam] = true;
+  }
+  if (cam == 0) h->ts_timing_pending[0] = false;  // EV_R1 no longer belongs to a timed scatter / render pair
   h->stats.ts_frames[cam]++;
   if (out_mono8) {
     HIPCHK(hipMemcpyAsync(out_mono8, h->d_ts[cam], (size_t)h->W * h->H, hipMemcpyDeviceToHost, h->stream));
@@ -255,37 +323,46 @@ int esvo_ts_render_forward(esvo_handle h, int cam, uint64_t t_ns, uint8_t* out_m
 
 int esvo_ts_render(esvo_handle h, int cam, uint64_t t_ns, uint8_t* out_mono8) {
   if (!h || cam < 0 || cam > 1) return ESVO_ERR_INVALID_ARG;
+  API_LOCK(h);
   HIPCHK(hipSetDevice(h->device));
-  // events with ts < T (strict, TimeSurface.h:68) that are not in the SAE yet
-  const auto& tsq = h->ts_host[cam];
-  const size_t k = std::lower_bound(tsq.begin(), tsq.end(), (u64)t_ns) - tsq.begin();
-  const u64 upto = h->ring_base[cam] + k;
-  // The SAE keeps ONE stamp per pixel, the reference a queue of 20 (TimeSurface.h:28-96): rendering at a T that precedes
-  // events already scattered would read pixels as empty where getMostRecentEventBeforeT finds the older event.
-  if (upto < h->scattered[cam])
-    FAIL(ESVO_ERR_STATE, "esvo_ts_render: t_ns precedes events of an earlier render (render times must not decrease; esvo_reset to replay)");
   const int evo = cam * EV_TS_STRIDE;
-  if (h->ts_timing_pending[cam] && hipEventQuery(h->evt[EV_R1 + evo]) == hipSuccess) collect_ts_timing(h, cam);
-  hipEventRecord(h->evt[EV_SC0 + evo], h->stream);
-  if (upto > h->scattered[cam]) {
-    u64 a = h->scattered[cam];
-    h->scatter_pending_lo[cam] = std::min(h->scatter_pending_lo[cam], a);
-    const u64 total = upto - a;
-    while (a < upto) {
-      const u64 slot = a % h->ring_cap;
-      const u64 cnt = std::min<u64>(upto - a, h->ring_cap - slot);
-      launch_ts_scatter(h->d_ring[cam] + slot, (size_t)cnt, h->d_sae[cam], h->W, h->H, h->stream);
-      a += cnt;
+  {
+    std::lock_guard<std::mutex> lr(h->mu_ring);
+    // events with ts < T (strict, TimeSurface.h:68) that are not in the SAE yet
+    const auto& tsq = h->ts_host[cam];
+    const size_t k = std::lower_bound(tsq.begin(), tsq.end(), (u64)t_ns) - tsq.begin();
+    const u64 upto = h->ring_base[cam] + k;
+    // The SAE keeps ONE stamp per pixel, the reference a queue of 20 (TimeSurface.h:28-96): rendering at a T that precedes
+    // events already scattered would read pixels as empty where getMostRecentEventBeforeT finds the older event.
+    if (upto < h->scattered[cam])
+      FAIL(ESVO_ERR_STATE, "esvo_ts_render: t_ns precedes events of an earlier render (render times must not decrease; esvo_reset to replay)");
+    if (h->ts_timing_pending[cam] && hipEventQuery(h->evt[EV_R1 + evo]) == hipSuccess) collect_ts_timing(h, cam);
+    hipEventRecord(h->evt[EV_SC0 + evo], h->stream);
+    if (upto > h->scattered[cam]) {
+      u64 a = h->scattered[cam];
+      h->scatter_pending_lo[cam] = std::min(h->scatter_pending_lo[cam], a);
+      h->scatter_seq++;
+      const u64 total = upto - a;
+      while (a < upto) {
+        const u64 slot = a % h->ring_cap;
+        const u64 cnt = std::min<u64>(upto - a, h->ring_cap - slot);
+        launch_ts_scatter(h->d_ring[cam] + slot, (size_t)cnt, h->d_sae[cam], h->W, h->H, h->stream);
+        a += cnt;
+      }
+      h->scattered[cam] = upto;
+      h->stats.events_scattered[cam] += total;
     }
-    h->scattered[cam] = upto;
-    h->stats.events_scattered[cam] += total;
+    hipEventRecord(h->evt[EV_SC1 + evo], h->stream);
   }
-  hipEventRecord(h->evt[EV_SC1 + evo], h->stream);
-  launch_ts_render(h->d_sae[cam], h->d_fixmap[cam], h->d_raw, h->d_ts[cam], h->W, h->H, (u64)t_ns, h->prm.decay_ms / 1000.0,
-                   h->prm.ignore_polarity, h->prm.median_blur_kernel_size, h->stream);
-  hipEventRecord(h->evt[EV_R1 + evo], h->stream);
-  HIPCHK(hipGetLastError());
-  h->ts_valid[cam] = true;
+  {
+    std::lock_guard<std::mutex> lt(h->mu_ts);
+    resident_write_begin(h, cam);
+    launch_ts_render(h->d_sae[cam], h->d_fixmap[cam], h->d_raw, h->d_ts[cam], h->W, h->H, (u64)t_ns, h->prm.decay_ms / 1000.0,
+                     h->prm.ignore_polarity, h->prm.median_blur_kernel_size, h->stream);
+    hipEventRecord(h->evt[EV_R1 + evo], h->stream);
+    HIPCHK(hipGetLastError());
+    h->ts_valid[cam] = true;
+  }
   h->ts_timing_pending[cam] = true;
   h->stats.ts_frames[cam]++;
   if (out_mono8) {

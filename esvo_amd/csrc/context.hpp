@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -63,8 +64,18 @@ struct esvo_context {
   int par = 0;                    // parity of the tick being assembled
   bool back_pending[2] = {false, false};  // back-stage timings / counters of that parity not collected yet
   u32 back_frames[2] = {0, 0};
-  std::string err;
   double baseline = 0;
+
+  // ---- threading contract (include/esvo_hip.h, "Threads"): three groups of calls may run concurrently on one handle --
+  // INGEST (esvo_ts_push_events / _event_array / _bag: the ROS spinner's eventsCallback), TRACKER (esvo_track_*) and
+  // everything else (the MAPPER group: renders, ticks, outputs, parameters).
+  std::recursive_mutex mu_api;  // held by every mapper-group call for its duration (they call each other: recursive)
+  std::mutex mu_ring;           // event-ring bookkeeping: ts_host, ring_base / _next / _reserved, scattered, scatter_pending_lo,
+                                // scatter_seq, sh_first, stats.events_staged / _scattered.  Never held across a host wait.
+  std::mutex mu_push[2];        // one pusher per camera at a time (held across its host-to-device copy)
+  std::mutex mu_track;          // tracker-group calls
+  std::mutex mu_ts;             // the resident left Time Surface (d_ts[0], ts_valid[0], EV_R1) between a render and a
+                                // tracker read (esvo_track_set_current without a host image)
 
   // calibration
   float2* d_lut = nullptr;
@@ -85,12 +96,16 @@ struct esvo_context {
   uint8_t* d_ts[2] = {nullptr, nullptr};
   bool ts_valid[2] = {false, false};
   esvo_event_t* d_ring[2] = {nullptr, nullptr};
-  uint8_t* d_wire = nullptr;    // staging of serialised 13-byte event records (esvo_ts_push_event_array)
-  size_t wire_cap = 0;
+  uint8_t* d_wire[2] = {nullptr, nullptr};  // staging of serialised 13-byte event records (esvo_ts_push_event_array), per camera
+  size_t wire_cap[2] = {0, 0};
   u64 ring_cap = 0;
   std::deque<u64> ts_host[2];   // time stamps of staged events [ring_base, ring_base + size)
   u64 ring_base[2] = {0, 0};    // absolute index of ts_host[cam].front()
   u64 ring_next[2] = {0, 0};    // absolute index of the next event to stage
+  u64 ring_reserved[2] = {0, 0};  // >= ring_next: end of the block a pusher is copying right now (its slots are being
+                                  // overwritten: selections are validated against THIS, not against ring_next)
+  u64 scatter_seq = 0;          // scatter launches so far (a pusher that drained the front stream resets scatter_pending_lo
+                                // only if no scatter was enqueued meanwhile)
   u64 scattered[2] = {0, 0};    // absolute index of the first event not yet in the SAE
   u64 scatter_pending_lo[2] = {~0ull, ~0ull};  // oldest event a possibly still running scatter kernel reads
 
@@ -203,6 +218,8 @@ struct esvo_context {
   double* d_trk_out = nullptr;
   size_t trk_cap = 0, trk_n = 0;
   bool trk_cur = false;
+  hipEvent_t evt_trk_read = nullptr;  // the tracker stream has read the resident left Time Surface (mu_ts)
+  bool trk_read_pending = false;
 
   // pinned staging slots for frame pose tables that arrive from the host (push_frame variants): a slot is reused only
   // after the back stream has consumed it
@@ -235,12 +252,15 @@ struct esvo_context {
 };
 
 namespace esvo_host {
-extern thread_local std::string g_create_error;  // esvo_last_error(nullptr): why the last esvo_create failed
+// esvo_last_error: the message of the calling THREAD's last failed call (with or without a handle) -- three threads may
+// use one handle at the same time, a string inside the handle could be rewritten while another thread reads it
+extern thread_local std::string g_create_error;
 // api_core.hip
 void fill_dev_params(esvo_context* h);
 void set_compute_band(esvo_context* h);
 // api_ts.hip
 void collect_ts_timing(esvo_context* h, int only = -1);
+void resident_write_begin(esvo_context* h, int cam);
 int ts_render_pair(esvo_context* h, uint64_t t_ns, uint8_t* const obs_out[2]);
 // api_map.hip
 int flush_pending_tick(esvo_context* h);  // completes a lazily finished tick (see esvo_context::TickState)
@@ -268,13 +288,16 @@ using namespace esvo_host;
     if (_e != hipSuccess) {                                                                       \
       char _b[512];                                                                               \
       snprintf(_b, sizeof(_b), "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
-      if (h) h->err = _b; else g_create_error = _b;                                               \
+      (void)h; g_create_error = _b;                                                               \
       return ESVO_ERR_HIP;                                                                        \
     }                                                                                             \
   } while (0)
 
+#define ESVO_SET_ERR(msg) (esvo_host::g_create_error = (msg))
+#define API_LOCK(h) std::lock_guard<std::recursive_mutex> _api_lock((h)->mu_api)
+
 #define FAIL(code, msg)                      \
   do {                                       \
-    if (h) h->err = (msg); else g_create_error = (msg); \
+    (void)h; g_create_error = (msg);                    \
     return (code);                           \
   } while (0)

@@ -30,7 +30,7 @@ SYMBOLS = [
     "esvo_map_init_sgm",
     "esvo_bag_open", "esvo_bag_close", "esvo_bag_last_error", "esvo_bag_next_event_array", "esvo_ts_push_bag",
     "esvo_map_get_debug_images", "esvo_map_get_pointcloud_near_xyz", "esvo_voxel_filter_xyz",
-    "esvo_comm_unique_id", "esvo_comm_init", "esvo_comm_init_callbacks", "esvo_comm_destroy", "esvo_comm_owns_next_tick",
+    "esvo_comm_unique_id", "esvo_comm_rccl_info", "esvo_comm_init", "esvo_comm_init_callbacks", "esvo_comm_destroy", "esvo_comm_owns_next_tick",
     "esvo_comm_tick", "esvo_comm_flush", "esvo_comm_newest_map", "esvo_comm_shard_tick", "esvo_comm_gather_map",
 ]
 
@@ -122,6 +122,7 @@ def load():
     lib.esvo_voxel_filter_xyz.argtypes = [vp, sz, C.c_float, vp, sz, psz]
     lib.esvo_comm_unique_id.argtypes = [vp]
     lib.esvo_comm_init.argtypes = [vp, vp, i32, i32]
+    lib.esvo_comm_rccl_info.argtypes = [C.POINTER(C.c_int), C.c_char_p, sz]
     lib.esvo_comm_init_callbacks.argtypes = [vp, i32, i32, ALL_GATHER_FN, ALL_REDUCE_FN, vp]
     lib.esvo_comm_destroy.argtypes = [vp]
     lib.esvo_comm_owns_next_tick.argtypes = [vp]
@@ -201,6 +202,15 @@ def comm_unique_id():
     if rc != 0:
         raise EsvoError(f"esvo_comm_unique_id failed ({rc}): {load().esvo_last_error(None).decode(errors='replace')}")
     return bytes(buf)
+
+
+def comm_rccl_info():
+    """(ncclGetVersion code, path of the RCCL shared object the C library resolved)"""
+    v, buf = C.c_int(), C.create_string_buffer(512)
+    rc = load().esvo_comm_rccl_info(C.byref(v), buf, 512)
+    if rc != 0:
+        raise EsvoError(f"esvo_comm_rccl_info failed ({rc}): {load().esvo_last_error(None).decode(errors='replace')}")
+    return int(v.value), buf.value.decode(errors="replace")
 
 
 def abi_sizes():

@@ -14,7 +14,21 @@
  *     ESVO_OK (0) or a negative esvo_status_t; esvo_last_error() gives text.
  *   - all input buffers are borrowed for the duration of the call only.
  *   - outputs go to caller-allocated arrays (capacity + returned count).
- *   - one handle is not thread-safe; distinct handles are independent.
+ *   - Threads.  Distinct handles are independent.  On ONE handle the calls form three groups that may run
+ *     concurrently, one thread per group -- the threading of the reference's nodes (esvo_Mapping.cpp:160,179-247: the
+ *     MappingLoop worker thread; :669-703 and TimeSurface.cpp:403-425: eventsCallback on the ROS spinner under
+ *     data_mutex_; esvo_Tracking's own loop):
+ *       INGEST   esvo_ts_push_events, esvo_ts_push_event_array, esvo_ts_push_bag (one thread per camera is fine)
+ *       TRACKER  esvo_track_*
+ *       MAPPER   every other call that takes the handle (renders, observation, ticks, stage-wise calls, outputs,
+ *                parameters, esvo_comm_*, esvo_reset -- which excludes the other two groups while it runs)
+ *     Calls of the same group are serialised by the library (safe from several threads, never concurrent).  The node's
+ *     data_mutex_ is therefore NOT needed around these calls.  What the caller still owns is causality: a render or
+ *     tick at time t sees the events staged when it is called, exactly like the reference's TS_history_/events_left_
+ *     snapshot (dataTransferring) -- stage the events up to t before asking for t.  An ingest call never waits for a
+ *     running tick (own HIP stream; the ring bookkeeping is locked for microseconds); the tracker calls run on a HIP
+ *     stream of their own and wait only for the render that produced the Time Surface they read.
+ *     esvo_last_error returns the message of the calling thread's last failed call.
  *   - every call is synchronous w.r.t. its host-visible outputs; calls without
  *     host outputs only enqueue work on the handle's HIP stream.
  *   - pointers named d_* are DEVICE pointers (HBM), everything else is host.
@@ -231,7 +245,9 @@ int esvo_bag_close(esvo_bag_handle b);
 const char* esvo_bag_last_error(esvo_bag_handle b);
 int esvo_bag_next_event_array(esvo_bag_handle b, const char* topic, const uint8_t** msg, size_t* n_bytes, uint64_t* stamp_ns,
                               const char** topic_out);
-/* Stage the messages of `topic` with a bag time stamp below until_ns (0: all that are left) for camera `cam`. */
+/* Stage the messages of `topic` with a bag time stamp below until_ns (0: all that are left) for camera `cam`.  *n_events
+ * (nullable) receives the events staged by this call, also when it fails.  A message the handle refuses (typically
+ * ESVO_ERR_CAPACITY "event ring full: render before staging more") is NOT consumed: render and call again. */
 int esvo_ts_push_bag(esvo_handle h, int cam, esvo_bag_handle b, const char* topic, uint64_t until_ns, size_t* n_events);
 /* Replaces TimeSurface::createTimeSurfaceAtTime (TimeSurface.cpp:52-152), BACKWARD mode.
  * Uses every staged event with ts < t_ns.  out_mono8 (W*H) may be NULL: the rectified TS
@@ -385,6 +401,10 @@ int esvo_shard_exchange(esvo_handle h, void** d_ptr, size_t* n_bytes);
 #define ESVO_COMM_ID_BYTES 128
 /* ncclGetUniqueId on one rank; hand the bytes to the others by any means (ROS parameter server, MPI, a file). */
 int esvo_comm_unique_id(uint8_t id[ESVO_COMM_ID_BYTES]);
+/* Which RCCL the calls above resolved: ncclGetVersion's code and the path of the shared object (dladdr).  The library is
+ * loaded with dlopen on first use: ESVO_RCCL_PATH if set, else the librccl.so.1 already mapped into the process (a
+ * process that imported torch carries torch's copy), else the loader path, else /opt/rocm/lib. */
+int esvo_comm_rccl_info(int* version, char* path, size_t path_cap);
 /* ncclCommInitRank on the handle's device. */
 int esvo_comm_init(esvo_handle h, const uint8_t id[ESVO_COMM_ID_BYTES], int rank, int world);
 /* The same with the two collectives supplied by the caller (another transport; tests that run several ranks on one GPU):

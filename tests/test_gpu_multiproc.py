@@ -12,10 +12,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _bench(extra_env, launcher, n, strong=True):
+def _bench(extra_env, launcher, n, strong=True, check=True, extras=False):
     env = dict(os.environ, **extra_env)
     cmd = launcher + [os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--workload", "upenn346x260", "--steps", "5", "--warmup", "2",
-                      "--no-cpu-baseline", "--no-extras", "--check"] + (["--strong"] if strong else [])
+                      "--no-cpu-baseline"] + ([] if extras else ["--no-extras"]) + (["--check"] if check else []) + (["--strong"] if strong else [])
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
@@ -36,3 +36,42 @@ def test_two_ranks_give_the_single_process_map():
     weak = _bench({"ESVO_SHARED_GPU": "1", "ESVO_DIST_BACKEND": "gloo"}, torchrun, 2, strong=False)
     assert weak["scaling"] == "weak" and weak["config"]["ticks_timed"] == 10 and weak["steps"] == 5
     assert abs(weak["config"]["events_per_tick"] - single["config"]["events_per_tick"]) < 0.05 * single["config"]["events_per_tick"]
+
+
+def _device_count():
+    import torch
+    return torch.cuda.device_count() if torch.cuda.is_available() else 0
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it spawns the two ranks itself (here: both on the one GPU, gloo);
+    without enough devices -- and without the shared-GPU test switch -- it refuses instead of reporting a one-rank number."""
+    two = _bench({"ESVO_SHARED_GPU": "1", "ESVO_DIST_BACKEND": "gloo"}, [sys.executable], 2, strong=False)
+    assert two["n_gpus"] == 2 and two["scaling"] == "weak" and two["config"]["ticks_timed"] == 10
+    assert two["launcher"].startswith("self") and len(two["ranks_seen"]) == 2 and {r["rank"] for r in two["ranks_seen"]} == {0, 1}
+    # the line of a multi-GPU run carries BOTH modes: tick-interleaved (weak, `value`) and one tick split by slot / row band
+    both = _bench({"ESVO_SHARED_GPU": "1", "ESVO_DIST_BACKEND": "gloo"}, [sys.executable], 2, strong=False, check=False, extras=True)
+    assert both["band_mode"]["scaling"] == "strong" and both["band_mode"]["value"] > 0 and both["band_mode"]["map_size_after_gather"] > 100
+    if _device_count() < 2:
+        env = {k: v for k, v in os.environ.items() if k not in ("ESVO_SHARED_GPU", "WORLD_SIZE", "RANK", "LOCAL_RANK")}
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"], env=env, cwd=ROOT,
+                             capture_output=True, text=True, timeout=300)
+        assert out.returncode != 0 and "GPU(s) visible" in out.stderr and not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+@pytest.mark.skipif(_device_count() < 2, reason="needs two MI355X on the node (real RCCL between two processes)")
+def test_two_gpus_over_real_rccl():
+    """Self-enabling on a multi-GPU node: one process per GPU, esvo_comm_init at world 2 over real RCCL (ncclCommInitRank,
+    ncclAllGather of frames / ncclAllReduce of the slot codes inside libesvo_hip.so), no launcher.  Both ways of using the
+    GPUs must reproduce the single-GPU DepthMap."""
+    single = _bench({}, [sys.executable], 1)
+    for mode in ("tick", "band"):
+        two = _bench({"ESVO_SHARD_MODE": mode}, [sys.executable], 2)
+        assert two["n_gpus"] == 2 and "esvo_comm_*" in two["config"]["parallelism"], two["config"]["parallelism"]
+        assert "failed" not in two["config"]["parallelism"]                       # no fallback to the torch.distributed driver
+        assert two["rccl"]["version_code"] > 0 and two["rccl"]["library"]
+        assert len({r["device"] for r in two["ranks_seen"]}) == 2                 # really two devices
+        assert two["check"]["final"] == single["check"]["final"], (mode, two["check"], single["check"])
+    both = _bench({}, [sys.executable], 2, strong=False, check=False, extras=True)  # the default line: weak + the band-mode block
+    assert both["scaling"] == "weak" and both["n_gpus"] == 2
+    assert both["band_mode"]["scaling"] == "strong" and both["band_mode"]["value"] > 0 and both["band_mode"]["map_size_after_gather"] > 100
