@@ -465,7 +465,13 @@ def main():
     if rank == 0 and world == 1 and not args.no_extras:
         out["other_operating_points"] = other_operating_points(local_rank)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(rig, stream, p, ticks)
+        port = cpu_baseline(rig, stream, p, ticks)
+        try:
+            out["cpu_baseline"] = cpu_baseline_reference(args.workload, rig, stream, ticks)
+            out["cpu_baseline"]["port"] = port     # the CPU oracle on every host thread, for the record
+        except Exception as e:  # noqa: BLE001  (oracle/_ref is built in the build container and travels with the snapshot)
+            port["reference_unavailable"] = f"{type(e).__name__}: {e}"
+            out["cpu_baseline"] = port
     if world > 1 and "ESVO_SHARD_MODE" not in os.environ and not args.strong and not args.check and not args.no_extras:
         # the OTHER way of using N GPUs, on the same line: every tick of ONE stream split over the ranks -- per-event work
         # by slot, per-cell work by image row band (north_star's image-tile partition), two ncclAllReduce per tick and the
@@ -636,6 +642,79 @@ def cpu_baseline(rig, stream, p, ticks):
                                 "sample": f"block matching + LM only ({len(small)} events, {len(pts)} points) on the reference's "
                                           f"NUM_THREAD_MAPPING = 4 threads"},
     }
+
+
+def cpu_baseline_reference(workload, rig, stream, ticks):
+    """The REFERENCE's own CPU path timed beside the GPU number (`kind: "reference"`): oracle/_ref = ESVO's sources compiled
+    unmodified in the build container (oracle/Makefile; they cannot travel, so the library is -O2 for generic x86-64) --
+    the Time-Surface node class (TimeSurface.cpp: eventsCallback + createTimeSurfaceAtTime, one thread per camera as in the
+    ROS graph's two node processes) and the mapper NODE object (esvo_Mapping.cpp: dataTransferring + MappingAtTime with its
+    own NUM_THREAD_MAPPING = 4 std::threads, esvo_core/include/esvo_core/tools/utils.h:36), driven through their own
+    callbacks.  OpenCV is absent from the image: its three calls on the path (convertTo + medianBlur + remap of the raster,
+    GaussianBlur of the observation) are done by the CPU oracle's restatement and timed with the stage they belong to.
+    Steady state: the fusion window is filled first.  Two sizes: the tick the reference really runs (PROCESS_EVENT_NUM of
+    the yaml) and a capped throughput tick (every event of the slice up to a bound, so that the default run stays short)."""
+    from oracle import oracle, ref
+    wl = WORKLOADS[workload]
+    W, H = rig.width, rig.height
+
+    def run(process_event_num, n_fill, n_meas):
+        over = {} if process_event_num is None else dict(process_event_num=process_event_num)
+        pf, _ = params.make_params(params.PRESETS[wl["preset"]], rig, **over)
+        node = ref.RefNode(pf, rig, stream.pose)
+        node.push_events(stream.ev_left)          # the whole stream staged first, as for `value`
+        ts = [ref.RefTS(W, H, pf.decay_ms, bool(pf.ignore_polarity)), ref.RefTS(W, H, pf.decay_ms, bool(pf.ignore_polarity))]
+        done = [0, 0]
+        rows = []
+        for k, (t, stamps, poses, T) in enumerate(ticks[: n_fill + n_meas]):
+            t_ts = []
+            imgs = []
+            for cam, (ev, ns, c) in enumerate(((stream.ev_left, stream.ns_left, rig.left), (stream.ev_right, stream.ns_right, rig.right))):
+                hi = int(np.searchsorted(ns, t, side="left"))
+                t0 = time.perf_counter()
+                ts[cam].push(ev[done[cam]:hi])                       # TimeSurface::eventsCallback
+                f64 = ts[cam].render(t)                              # createTimeSurfaceAtTime up to convertTo
+                u8 = np.rint(f64).astype(np.uint8)                   # cv::Mat::convertTo(CV_8U): round half to even, values in [0, 255]
+                if pf.median_blur_kernel_size:
+                    u8 = oracle.median3(u8)                          # cv::medianBlur
+                u8 = oracle.remap_bilinear(u8, c.map_x, c.map_y)     # cv::remap
+                t_ts.append(time.perf_counter() - t0)
+                done[cam] = hi
+                imgs.append(u8)
+            t0 = time.perf_counter()
+            obs = [oracle.gaussian5(i) for i in imgs] if pf.smooth_time_surface else imgs   # GaussianBlurTS(5), EventBM.cpp:68-72
+            node.push_observation(t, obs[0], obs[1])                 # timeSurfaceCallback
+            ok = node.data_transferring()                            # dataTransferring (event selection, 201 tf lookups)
+            if ok:
+                node.mapping_at_time()                               # MappingAtTime: BM + LM on 4 threads, fusion, clean, regularisation
+            t_map = time.perf_counter() - t0
+            if k >= n_fill and ok:
+                rows.append((len(node.selected_events()), max(t_ts) + t_map, max(t_ts), t_map, len(node.newest_frame())))
+        return pf, rows
+
+    p0 = params.make_params(params.PRESETS[wl["preset"]], rig)[0]
+    n_fill = int(p0.max_fusion_frames) if p0.fusion_strategy == 0 else 5   # CONST_FRAMES: the window; CONST_POINTS: a few ticks
+    pf, rows = run(None, max(min(n_fill, len(ticks) - 3), 0), 3)
+    if not rows:
+        raise RuntimeError("the reference node mapped no tick (dataTransferring refused every observation)")
+    rates = sorted(n / s for n, s, _, _, _ in rows)
+    med = rows[len(rows) // 2]
+    out = {
+        "value": rates[len(rates) // 2], "unit": "events/s", "cores": 4, "kind": "reference",
+        "sample": f"ESVO's own TimeSurface + esvo_Mapping node objects (oracle/_ref, -O2, stand-in Eigen / ROS headers): median of "
+                  f"{len(rows)} steady-state ticks of the reference's own size (PROCESS_EVENT_NUM = {pf.process_event_num}: "
+                  f"{med[0]} events selected, {med[4]} depth points), same stages as `value`; mapper on NUM_THREAD_MAPPING = 4 "
+                  f"threads, one Time-Surface thread per camera (the slower camera counts); {med[1]:.2f} s per tick "
+                  f"(Time Surface {med[2]:.3f} s, mapper {med[3]:.2f} s)",
+    }
+    cap = 30000
+    _, rows2 = run(cap, 2, 1)
+    if rows2:
+        n, sec, tts, tmap, pts = rows2[0]
+        out["throughput_tick_capped"] = {"value": n / sec, "unit": "events/s", "cores": 4,
+                                         "sample": f"one tick with PROCESS_EVENT_NUM = {cap} ({n} events selected, {pts} depth points) "
+                                                   f"after 2 ticks of window fill: {sec:.2f} s (Time Surface {tts:.3f} s, mapper {tmap:.2f} s)"}
+    return out
 
 
 if __name__ == "__main__":
