@@ -102,6 +102,8 @@ class StatsStruct(C.Structure):
         ("pad_", C.c_float),
         ("total_events_in", C.c_uint64), ("total_matches", C.c_uint64), ("total_points", C.c_uint64),
         ("sum_ms_kernel", C.c_double * 8),
+        ("last_bm_info_noise_low", C.c_uint32), ("last_bm_coarse_fail", C.c_uint32), ("last_bm_fine_fail", C.c_uint32), ("pad2_", C.c_uint32),
+        ("total_bm_info_noise_low", C.c_uint64), ("total_bm_coarse_fail", C.c_uint64), ("total_bm_fine_fail", C.c_uint64),
     ]
 
 

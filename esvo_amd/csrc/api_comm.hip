@@ -373,7 +373,7 @@ int esvo_comm_tick(esvo_handle h, uint64_t t_ns, const double T_world_cam[16], c
     if (rc) return rc;
     const u32 n = h->tk[h->fpar].n;
     if (n) { rc = run_order_points(h, n, h->d_pts_tmp); if (rc) return rc; }
-    HIPCHK(hipMemcpyAsync(h->h_counters + 16 * h->fpar, h->d_counters, sizeof(u32) * 16, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(h->h_counters + CNT_ROW * h->fpar, h->d_counters, sizeof(u32) * CNT_ROW, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipEventRecord(h->evt[EV_CNT + h->fpar * EV_FRONT_STRIDE], h->stream));
     c->have_own = true;
     c->own_fp = h->fpar;

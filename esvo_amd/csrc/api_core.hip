@@ -19,8 +19,7 @@ void invert3x3(const double* P, double* Kinv, double* Kinv_t) {
 
 int validate_params(const esvo_params_t* p, std::string& why) {
   if (p->ls_norm != ESVO_LSNORM_TDIST) { why = "only LSnorm == Tdist is supported (every shipped config uses it)"; return ESVO_ERR_UNSUPPORTED; }
-  if (p->bm_updown) { why = "BM_bUpDownConfiguration is not supported"; return ESVO_ERR_UNSUPPORTED; }
-  if (p->bm_step != 1) { why = "BM_step != 1 is not supported (every shipped config uses 1)"; return ESVO_ERR_UNSUPPORTED; }
+  if (p->bm_step < 1) { why = "BM_step must be >= 1"; return ESVO_ERR_INVALID_ARG; }
   if (p->patch_size_x != 15 || p->patch_size_y != 7) { why = "patch size must be 15x7 (every shipped config)"; return ESVO_ERR_UNSUPPORTED; }
   if (p->median_blur_kernel_size < 0 || p->median_blur_kernel_size > 1) { why = "median_blur_kernel_size must be 0 or 1"; return ESVO_ERR_UNSUPPORTED; }
   if (p->bm_max_disparity < p->bm_min_disparity || p->bm_min_disparity < 0) { why = "bad disparity range"; return ESVO_ERR_INVALID_ARG; }
@@ -40,7 +39,7 @@ void fill_dev_params(esvo_context* h) {
   DevParams& d = h->dp;
   d.W = h->W; d.H = h->H;
   d.wx = p.patch_size_x; d.wy = p.patch_size_y;
-  d.dmin = p.bm_min_disparity; d.dmax = p.bm_max_disparity; d.step = p.bm_step;
+  d.dmin = p.bm_min_disparity; d.dmax = p.bm_max_disparity; d.step = p.bm_step; d.updown = p.bm_updown ? 1 : 0;
   d.zncc_thr = p.bm_zncc_threshold;
   d.baseline_f = h->baseline * d.camL.P[0];
   d.td_nu = p.td_nu; d.td_scale = p.td_scale; d.td_scale2 = p.td_scale * p.td_scale;
@@ -202,13 +201,13 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
   CK(dalloc(&h->d_pts_tmp, E));
   CK(dalloc(&h->d_stage[0], E));
   CK(dalloc(&h->d_stage[1], E));
-  CK(dalloc(&h->d_counters2[0], 16));
-  CK(dalloc(&h->d_counters2[1], 16));
-  CK(hipMemset(h->d_counters2[0], 0, sizeof(u32) * 16));
-  CK(hipMemset(h->d_counters2[1], 0, sizeof(u32) * 16));
+  CK(dalloc(&h->d_counters2[0], CNT_ROW));
+  CK(dalloc(&h->d_counters2[1], CNT_ROW));
+  CK(hipMemset(h->d_counters2[0], 0, sizeof(u32) * CNT_ROW));
+  CK(hipMemset(h->d_counters2[1], 0, sizeof(u32) * CNT_ROW));
   h->d_counters = h->d_counters2[0];
-  CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_counters), sizeof(u32) * 16 * 2));
-  std::memset(h->h_counters, 0, sizeof(u32) * 16 * 2);
+  CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_counters), sizeof(u32) * CNT_ROW * 2));
+  std::memset(h->h_counters, 0, sizeof(u32) * CNT_ROW * 2);
   CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_pin), sizeof(double) * 2 * ((size_t)h->max_poses * 17 + 16)));
   CK(dalloc(&h->d_scan_tmp, scan_scratch_elems(std::max(E, npx)) + 8));
   CK(dalloc(&h->d_scan_tmp_b, scan_scratch_elems(std::max(E, npx)) + 8));

@@ -25,7 +25,7 @@ u64 ros_time_from_sec(double t) {
   return (u64)sec * 1000000000ull + nsec;
 }
 
-int upload_poses(esvo_context* h, const uint64_t* pose_t_ns, const double* pose_T, size_t m, u32* d_zero16 = nullptr) {
+int upload_poses(esvo_context* h, const uint64_t* pose_t_ns, const double* pose_T, size_t m, u32* d_zero_row = nullptr) {
   if (m > h->max_poses) FAIL(ESVO_ERR_CAPACITY, "pose table larger than max_poses_per_tick");
   // staged through pinned memory (two alternating slots): no host synchronisation on the tick path
   h->pin_slot ^= 1;
@@ -41,8 +41,8 @@ int upload_poses(esvo_context* h, const uint64_t* pose_t_ns, const double* pose_
   h->d_pose_T = h->d_pose_T2[h->pose_buf];
   HIPCHK(hipStreamWaitEvent(h->stream, h->evt[EV_POSE + h->pose_buf * EV_BACK_STRIDE], 0));
   h->d_pose_sec = h->d_pose_T + 16 * m;
-  // d_zero16: the 16 counters of the tick that follows, cleared by the same launch
-  launch_upload_words(T, h->d_pose_T, sizeof(double) * 17 * m, h->stream, d_zero16, 16);
+  // d_zero_row: the counter row of the tick that follows, cleared by the same launch
+  launch_upload_words(T, h->d_pose_T, sizeof(double) * 17 * m, h->stream, d_zero_row, CNT_ROW);
   return ESVO_OK;
 }
 
@@ -55,6 +55,7 @@ int run_bm(esvo_context* h, const esvo_event_t* d_ev, u64 first, u64 cap, int re
   a.lut = h->d_lut; a.mask = h->d_mask;
   a.pose_sec = h->d_pose_sec; a.n_pose = h->n_pose;
   a.out_slots = h->d_match_slots; a.out_flags = h->d_match_flags;
+  a.fail_counters = h->d_counters;
   hipEventRecord(h->evt[EV_BM0 + h->fpar * EV_FRONT_STRIDE], h->stream);
   launch_bm_match(a, h->dp, h->stream);
   hipEventRecord(h->evt[EV_BM1 + h->fpar * EV_FRONT_STRIDE], h->stream);
@@ -109,8 +110,17 @@ int run_refine(esvo_context* h, u32 max_matches, int cull, DevPoint* dst) {
   return run_order_points(h, max_matches, dst);
 }
 
+// EventBM's per-reason failure counters (EventBM.h:89) from a counter row read back from the device
+void collect_bm_failures(esvo_context* h, const u32* row, bool accumulate) {
+  u32 r[3] = {0, 0, 0};
+  for (int k = 0; k < 3; ++k)
+    for (int i = 0; i < CNT_STRIPES; ++i) r[k] += row[CNT_BM_FAIL + k * CNT_STRIPES + i];
+  esvo_stats_t& s = h->stats;
+  s.last_bm_info_noise_low = r[0]; s.last_bm_coarse_fail = r[1]; s.last_bm_fine_fail = r[2];
+  if (accumulate) { s.total_bm_info_noise_low += r[0]; s.total_bm_coarse_fail += r[1]; s.total_bm_fine_fail += r[2]; }
+}
 int read_counters(esvo_context* h) {
-  HIPCHK(hipMemcpyAsync(h->h_counters, h->d_counters, sizeof(u32) * 16, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(h->h_counters, h->d_counters, sizeof(u32) * CNT_ROW, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   return ESVO_OK;
 }
@@ -374,6 +384,7 @@ int esvo_map_match(esvo_handle h, const esvo_event_t* ev, size_t n, const uint64
   *n_out = 0;
   if (n == 0) { HIPCHK(hipMemsetAsync(h->d_counters, 0, sizeof(u32), h->stream)); return ESVO_OK; }
   HIPCHK(hipMemcpyAsync(h->d_tick_ev, ev, sizeof(esvo_event_t) * n, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemsetAsync(h->d_counters + CNT_BM_FAIL, 0, sizeof(u32) * 3 * CNT_STRIPES, h->stream));
   int rc = run_match(h, h->d_tick_ev, 0, (u64)h->max_ev, 0, (u32)n);
   if (rc) return rc;
   rc = read_counters(h);
@@ -382,6 +393,7 @@ int esvo_map_match(esvo_handle h, const esvo_event_t* ev, size_t n, const uint64
   *n_out = nm;
   h->stats.last_events_in = (u32)n;
   h->stats.last_matches = nm;
+  collect_bm_failures(h, h->h_counters, false);
   if (out && nm) {
     if (nm > cap) FAIL(ESVO_ERR_CAPACITY, "output array too small for the matches");
     HIPCHK(hipMemcpy(out, h->d_matches, sizeof(esvo_match_t) * nm, hipMemcpyDeviceToHost));
@@ -608,7 +620,7 @@ int tick_phase1_enqueue(esvo_context* h) {
     HIPCHK(hipGetLastError());
   }
   hipStream_t sc = (n && !h->sharded) ? tk.lm_stream : h->stream;
-  HIPCHK(hipMemcpyAsync(h->h_counters + 16 * h->fpar, h->d_counters, sizeof(u32) * 16, hipMemcpyDeviceToHost, sc));
+  HIPCHK(hipMemcpyAsync(h->h_counters + CNT_ROW * h->fpar, h->d_counters, sizeof(u32) * CNT_ROW, hipMemcpyDeviceToHost, sc));
   HIPCHK(hipEventRecord(h->evt[EV_CNT + h->fpar * EV_FRONT_STRIDE], sc));
   h->tick_pending = true;
   return ESVO_OK;
@@ -618,7 +630,7 @@ int tick_phase1_enqueue(esvo_context* h) {
 int tick_phase1_collect(esvo_context* h, int fp) {
   esvo_context::TickState& tk = h->tk[fp];
   HIPCHK(hipEventSynchronize(h->evt[EV_CNT + fp * EV_FRONT_STRIDE]));
-  const u32* cnt = h->h_counters + 16 * fp;
+  const u32* cnt = h->h_counters + CNT_ROW * fp;
   const u32 n = tk.n;
   const u32 n_points = n ? cnt[1] : 0;
   esvo_stats_t& s = h->stats;
@@ -629,6 +641,7 @@ int tick_phase1_collect(esvo_context* h, int fp) {
   s.total_events_in += n;
   s.total_matches += cnt[0];
   s.total_points += n_points;
+  collect_bm_failures(h, cnt, true);
   tk.points = n_points;
   const int o = fp * EV_FRONT_STRIDE;
   s.ms_bm = s.ms_refine = 0;
@@ -835,7 +848,7 @@ extern "C" int esvo_map_init_sgm(esvo_handle h, const uint8_t* ts_left, const ui
       FAIL(ESVO_ERR_STATE, "selected events were already overwritten in the event ring");
     if (n) h->sh_first = first;  // the overwrite guard of the ingest thread protects this selection like a tick's
   }
-  HIPCHK(hipMemsetAsync(h->d_counters, 0, sizeof(u32) * 16, h->stream));
+  HIPCHK(hipMemsetAsync(h->d_counters, 0, sizeof(u32) * CNT_ROW, h->stream));
   u32 count = 0;
   if (n) {
     HIPCHK(hipStreamWaitEvent(h->stream, h->evt[EV_RG1 + h->par * EV_BACK_STRIDE], 0));
@@ -897,7 +910,7 @@ extern "C" int esvo_map_front(esvo_handle h, uint64_t t_ns, const uint64_t* pose
   if (rc) return rc;
   const u32 n = h->tk[h->fpar].n;
   if (n) { rc = run_order_points(h, n, h->d_pts_tmp); if (rc) return rc; }
-  HIPCHK(hipMemcpyAsync(h->h_counters + 16 * h->fpar, h->d_counters, sizeof(u32) * 16, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(h->h_counters + CNT_ROW * h->fpar, h->d_counters, sizeof(u32) * CNT_ROW, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipEventRecord(h->evt[EV_CNT + h->fpar * EV_FRONT_STRIDE], h->stream));
   rc = tick_phase1_collect(h, h->fpar);
   if (rc) return rc;

@@ -26,10 +26,18 @@ struct CamConst {
 };
 
 // Parameters the kernels read (a by-value kernel argument: lives in SGPRs / kernarg segment).
+// One row of per-tick device counters (esvo_context::d_counters): [0] n_matches [1] n_points [2] n_solved [3] n_fusion
+// [4] n_records [5] n_map [6] touched cells [7] regulariser elements [8] own matches (sharded); from CNT_BM_FAIL on, three
+// blocks of CNT_STRIPES partial sums: block matching failures by reason (info-noise ratio, coarse search, fine search).
+constexpr int CNT_STRIPES = 16;
+constexpr int CNT_BM_FAIL = 16;
+constexpr int CNT_ROW = CNT_BM_FAIL + 3 * CNT_STRIPES;  // 64 words
+
 struct DevParams {
   int W, H;
   int wx, wy;                    // patch size
-  int dmin, dmax, step;          // effective disparity range
+  int dmin, dmax, step;          // effective disparity range; BM_step (1: dense; > 1: coarse-to-fine, EventBM.cpp:118-138)
+  int updown;                    // BM_bUpDownConfiguration: the epipolar search runs along y (EventBM.cpp:178-186)
   double zncc_thr;               // BM_ZNCC_Threshold
   double baseline_f;             // baseline * P_left(0,0)
   double td_nu, td_scale, td_scale2, td_stdvar2;
@@ -181,6 +189,7 @@ struct BmArgs {
   u32 n_pose;
   esvo_match_t* out_slots;  // [n] slot w (thread-stride order)
   u32* out_flags;           // [n]
+  u32* fail_counters;       // nullable: the tick's counter row (CNT_BM_FAIL: per-reason failures, EventBM.h:89)
 };
 void launch_bm_match(const BmArgs& a, const DevParams& p, hipStream_t s);
 void launch_compact_matches(const esvo_match_t* slots, const u32* flags, const u32* prefix, u32 n,

@@ -80,18 +80,60 @@ __device__ inline int grp_sum_i32(int v) {
 // each lane reads 5 dwords per row, re-aligns them with v_alignbyte_b32 and accumulates
 // S_r, S_rr and S_lr with v_dot4_u32_u8 (the pad byte of the left patch is zero and the 16th
 // byte of the window is masked out).
+//
+// Template switches for the two EventBM options no shipped configuration sets:
+//   COARSE (BM_step > 1, EventBM.cpp:118-138): the dense cost row [dmin, dmax] is formed as for step 1 -- a superset of
+//     what the reference evaluates -- and kept in LDS (cost 1.0 = ZNCC_MAX_ for invalid candidates, as mDispCost holds
+//     them); the coarse pass is the argmin over d = dmin + j step with the neighbour rule of :207-219 (both coarse
+//     neighbours in the map and < ZNCC_MAX_), the fine pass the argmin over [best - (step-1), best + (step-1)] with the
+//     carried minimum (:127-133).  Both use the reference's `cost <= min_cost` tie rule (largest disparity among equal
+//     minima).  The neighbour rule implies dmin + step <= best <= dmax - step, so the fine window lies inside the row.
+//   UPDOWN (BM_bUpDownConfiguration, :178-186, :148-151): candidates are x2 = (x1.x, x1.y - d); the strip is vertical,
+//     7 + Nd - 1 rows of 15 pixels staged like the left patch (16-byte rows), candidate d reads rows dmax - d .. + 6.
 #ifndef BM_BLOCK
 #define BM_BLOCK 64   // threads per workgroup (a multiple of 64; the two barriers are per workgroup).  64 beats 256 by 20 %:
                       // barriers span one wave and a finished wave frees its slot and LDS at once
 #endif
+
+// one 15-pixel row starting at byte address A of a dword-padded image -> 4 dwords (15 pixels + a zero pad byte)
+__device__ inline uint4 load_row15(const u32* ts32, int n_dw, int A) {
+  const int a0 = A >> 2;  // arithmetic shift = floor
+  const u32 sh = (u32)(A & 3);
+  u32 d[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    int idx = a0 + j;
+    idx = idx < 0 ? 0 : (idx >= n_dw ? n_dw - 1 : idx);  // only bytes that no valid patch reads can be clamped
+    d[j] = ts32[idx];
+  }
+  uint4 wv;
+  wv.x = __builtin_amdgcn_alignbyte(d[1], d[0], sh);
+  wv.y = __builtin_amdgcn_alignbyte(d[2], d[1], sh);
+  wv.z = __builtin_amdgcn_alignbyte(d[3], d[2], sh);
+  wv.w = __builtin_amdgcn_alignbyte(d[4], d[3], sh) & 0x00ffffffu;
+  return wv;
+}
+
 template <int G>
+__device__ inline void grp_argmin(double& best, int& bestd) {  // ties -> larger disparity (`<=` while scanning upwards)
+#pragma unroll
+  for (int s = G / 2; s >= 1; s >>= 1) {
+    const double oc = __shfl_xor(best, s, G);
+    const int od = __shfl_xor(bestd, s, G);
+    if (od >= 0 && (bestd < 0 || oc < best || (oc == best && od > bestd))) { best = oc; bestd = od; }
+  }
+}
+
+template <int G, bool COARSE, bool UPDOWN>
 __global__ void __launch_bounds__(BM_BLOCK) bm_match_kernel(BmArgs a, DevParams p, int RD, int lds_per_event) {
   constexpr int EPB = BM_BLOCK / G;  // events per block
   const int grp = threadIdx.x / G, l = threadIdx.x % G;
   // slot in thread-stride order; multi-GPU: slots are dealt round-robin and a rank's launch covers its own ones densely
   const u32 w = (blockIdx.x * EPB + grp) * (u32)p.ev_nshards + (u32)p.ev_shard;
   u32* ldsL = reinterpret_cast<u32*>(bm_smem + grp * lds_per_event);  // [7][4] dwords
-  u32* ldsR = ldsL + 28;                                              // [7][RD] dwords
+  u32* ldsR = ldsL + 28;                                              // [7][RD] dwords / UPDOWN: [Nd + 6][4] dwords
+  const int nd = p.dmax - p.dmin + 1;
+  double* cost_row = reinterpret_cast<double*>(ldsR + (UPDOWN ? (nd + 6) * 4 : 7 * RD));  // COARSE only: [Nd]
 
   const int W = p.W, H = p.H;
   constexpr int wx = 15, wy = 7, N = wx * wy, hx = 7, hy = 3;
@@ -121,6 +163,7 @@ __global__ void __launch_bounds__(BM_BLOCK) bm_match_kernel(BmArgs a, DevParams 
     y1 = (int)floor(yr);
   }
   if (ok) ok = !(x1 - hx < 1 || y1 - hy < 1 || x1 + hx >= W - 1 || y1 + hy >= H - 1);  // isValidPatch, :251-267
+  int reason = 0;  // why the event failed, as the reference counts it (EventBM.h:89): 1 info-noise ratio, 2 coarse, 3 fine
 
   // ---- stage the left patch, left moments, low-texture test (:101-109) ----
   // Lane py < 7 owns patch row py: five aligned dwords straight from the image, re-aligned to the row's first byte with
@@ -132,21 +175,7 @@ __global__ void __launch_bounds__(BM_BLOCK) bm_match_kernel(BmArgs a, DevParams 
     if (l < wy) {
       const u32* ts32 = reinterpret_cast<const u32*>(a.tsL);
       const int n_dw = (W * H + 3) >> 2;
-      const int A = (y1 - hy + l) * W + (x1 - hx);
-      const int a0 = A >> 2;
-      const u32 sh = (u32)(A & 3);
-      u32 d[5];
-#pragma unroll
-      for (int j = 0; j < 5; ++j) {
-        int idx = a0 + j;
-        idx = idx >= n_dw ? n_dw - 1 : idx;  // only the bytes behind the 15 pixels can be clamped (A >= 0: isValidPatch)
-        d[j] = ts32[idx];
-      }
-      uint4 wv;
-      wv.x = __builtin_amdgcn_alignbyte(d[1], d[0], sh);
-      wv.y = __builtin_amdgcn_alignbyte(d[2], d[1], sh);
-      wv.z = __builtin_amdgcn_alignbyte(d[3], d[2], sh);
-      wv.w = __builtin_amdgcn_alignbyte(d[4], d[3], sh) & 0x00ffffffu;
+      const uint4 wv = load_row15(ts32, n_dw, (y1 - hy + l) * W + (x1 - hx));
       *reinterpret_cast<uint4*>(ldsL + l * 4) = wv;
       u32 usl = 0, usll = 0;
       usl = __builtin_amdgcn_udot4(wv.x, 0x01010101u, usl, false);
@@ -167,41 +196,51 @@ __global__ void __launch_bounds__(BM_BLOCK) bm_match_kernel(BmArgs a, DevParams 
     cnt = grp_sum_i32<G>(cnt);
     Sl = grp_sum_i32<G>(sl);
     Sll = grp_sum_i32<G>(sll);  // <= 105 * 255^2 < 2^31
-    if ((double)cnt > 0.95 * (double)N) ok = false;
+    if ((double)cnt > 0.95 * (double)N) { ok = false; reason = 1; }  // infoNoiseRatioLowNum_++, :105-109
   }
-  // ---- stage the right strip: aligned 16-byte pieces straight from the (dword-padded) image; RD is a multiple of 4 ----
+  // ---- stage the right strip ----
   const int xs0 = x1 - p.dmax - hx;
   int o_row[wy];  // byte offset of column xs0 inside the first staged dword of each row
   if (ok) {
     const u32* ts32 = reinterpret_cast<const u32*>(a.tsR);
     const int n_dw = (W * H + 3) >> 2;
+    if constexpr (UPDOWN) {  // rows y1 - dmax - hy ... y1 - dmin + hy, 15 pixels each, one 16-byte row per lane and trip
+      for (int r = l; r < nd + 6; r += G)
+        *reinterpret_cast<uint4*>(ldsR + r * 4) = load_row15(ts32, n_dw, (y1 - p.dmax - hy + r) * W + (x1 - hx));
+    } else {  // aligned 16-byte pieces straight from the (dword-padded) image; RD is a multiple of 4
 #pragma unroll
-    for (int py = 0; py < wy; ++py) {
-      const int A = (y1 - hy + py) * W + xs0;
-      const int a0 = A >> 2;  // arithmetic shift = floor
-      o_row[py] = A - (a0 << 2);
-      for (int j4 = l; j4 < (RD >> 2); j4 += G) {
-        const int idx = a0 + 4 * j4;
-        uint4 v;
-        if (__builtin_expect(idx >= 0 && idx + 3 < n_dw, 1)) {
-          const u32x4_a4 q = *reinterpret_cast<const u32x4_a4*>(ts32 + idx);  // dword-aligned 16-byte load
-          v = make_uint4(q.x, q.y, q.z, q.w);
-        } else {  // only bytes of invalid candidates can be clamped
-          u32 t[4];
+      for (int py = 0; py < wy; ++py) {
+        const int A = (y1 - hy + py) * W + xs0;
+        const int a0 = A >> 2;  // arithmetic shift = floor
+        o_row[py] = A - (a0 << 2);
+        for (int j4 = l; j4 < (RD >> 2); j4 += G) {
+          const int idx = a0 + 4 * j4;
+          uint4 v;
+          if (__builtin_expect(idx >= 0 && idx + 3 < n_dw, 1)) {
+            const u32x4_a4 q = *reinterpret_cast<const u32x4_a4*>(ts32 + idx);  // dword-aligned 16-byte load
+            v = make_uint4(q.x, q.y, q.z, q.w);
+          } else {  // only bytes of invalid candidates can be clamped
+            u32 t[4];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            int i = idx + q;
-            i = i < 0 ? 0 : (i >= n_dw ? n_dw - 1 : i);
-            t[q] = ts32[i];
+            for (int q = 0; q < 4; ++q) {
+              int i = idx + q;
+              i = i < 0 ? 0 : (i >= n_dw ? n_dw - 1 : i);
+              t[q] = ts32[i];
+            }
+            v = make_uint4(t[0], t[1], t[2], t[3]);
           }
-          v = make_uint4(t[0], t[1], t[2], t[3]);
+          *reinterpret_cast<uint4*>(ldsR + py * RD + 4 * j4) = v;
         }
-        *reinterpret_cast<uint4*>(ldsR + py * RD + 4 * j4) = v;
       }
     }
   }
   __syncthreads();
 
+  // isValidPatch of candidate d (:184-190): only the coordinate that moves can leave the image
+  auto cand_valid = [&](int d) {
+    if constexpr (UPDOWN) { const int y2 = y1 - d; return !(y2 - hy < 1 || y2 + hy >= H - 1); }
+    else { const int x2 = x1 - d; return !(x2 - hx < 1 || x2 + hx >= W - 1); }
+  };
   double best = 1.0;  // ZNCC_MAX_
   int bestd = -1;
   if (ok) {
@@ -214,20 +253,28 @@ __global__ void __launch_bounds__(BM_BLOCK) bm_match_kernel(BmArgs a, DevParams 
       L[py][0] = v.x; L[py][1] = v.y; L[py][2] = v.z; L[py][3] = v.w;
     }
     for (int d = p.dmin + l; d <= p.dmax; d += G) {
-      const int x2 = x1 - d;
-      if (x2 - hx < 1 || x2 + hx >= W - 1) continue;  // invalid candidates never update (:186-190)
+      if (!cand_valid(d)) {  // invalid candidates never update (:186-190); the map holds ZNCC_MAX_ for them
+        if constexpr (COARSE) cost_row[d - p.dmin] = 1.0;
+        continue;
+      }
       const int col0 = p.dmax - d;
       u32 sr = 0, srr = 0, slr = 0;
 #pragma unroll
       for (int py = 0; py < wy; ++py) {
-        const int b = o_row[py] + col0;
-        const u32* row = ldsR + py * RD + (b >> 2);
-        const u32 sh = (u32)(b & 3);
-        const u32 d0 = row[0], d1 = row[1], d2 = row[2], d3 = row[3], d4 = row[4];
-        const u32 w0 = __builtin_amdgcn_alignbyte(d1, d0, sh);
-        const u32 w1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
-        const u32 w2 = __builtin_amdgcn_alignbyte(d3, d2, sh);
-        const u32 w3 = __builtin_amdgcn_alignbyte(d4, d3, sh) & 0x00ffffffu;
+        u32 w0, w1, w2, w3;
+        if constexpr (UPDOWN) {
+          const uint4 v = *reinterpret_cast<const uint4*>(ldsR + (col0 + py) * 4);
+          w0 = v.x; w1 = v.y; w2 = v.z; w3 = v.w;
+        } else {
+          const int b = o_row[py] + col0;
+          const u32* row = ldsR + py * RD + (b >> 2);
+          const u32 sh = (u32)(b & 3);
+          const u32 d0 = row[0], d1 = row[1], d2 = row[2], d3 = row[3], d4 = row[4];
+          w0 = __builtin_amdgcn_alignbyte(d1, d0, sh);
+          w1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+          w2 = __builtin_amdgcn_alignbyte(d3, d2, sh);
+          w3 = __builtin_amdgcn_alignbyte(d4, d3, sh) & 0x00ffffffu;
+        }
         slr = __builtin_amdgcn_udot4(L[py][0], w0, slr, false);
         slr = __builtin_amdgcn_udot4(L[py][1], w1, slr, false);
         slr = __builtin_amdgcn_udot4(L[py][2], w2, slr, false);
@@ -242,16 +289,46 @@ __global__ void __launch_bounds__(BM_BLOCK) bm_match_kernel(BmArgs a, DevParams 
         srr = __builtin_amdgcn_udot4(w3, w3, srr, false);
       }
       const double cost = zncc_from_moments(zl, (int)sr, (int)srr, (int)slr, N, rn, rn2);
-      if (cost <= best) { best = cost; bestd = d; }  // :198 (lane scans increasing d)
+      if constexpr (COARSE) cost_row[d - p.dmin] = cost;
+      else if (cost <= best) { best = cost; bestd = d; }  // :198 (lane scans increasing d)
     }
-    // group argmin; ties -> larger disparity
-#pragma unroll
-    for (int s = G / 2; s >= 1; s >>= 1) {
-      const double oc = __shfl_xor(best, s, G);
-      const int od = __shfl_xor(bestd, s, G);
-      if (od >= 0 && (bestd < 0 || oc < best || (oc == best && od > bestd))) { best = oc; bestd = od; }
+  }
+  if constexpr (COARSE) {
+    __syncthreads();  // the cost row is complete
+    if (ok) {
+      const int step = p.step;
+      const int nc = (p.dmax - p.dmin) / step + 1;  // coarse candidates dmin + j step (:119-121)
+      for (int j = l; j < nc; j += G) {
+        const int d = p.dmin + j * step;
+        if (!cand_valid(d)) continue;
+        const double c = cost_row[d - p.dmin];
+        if (c <= best) { best = c; bestd = d; }
+      }
+      grp_argmin<G>(best, bestd);
+      // :207-219: both coarse neighbours are in the map (size_t arithmetic: best - step must not wrap) and below ZNCC_MAX_
+      bool found = bestd >= 0 && bestd - step >= p.dmin && bestd + step <= p.dmin + (nc - 1) * step;
+      if (found) found = cost_row[bestd - step - p.dmin] < 1.0 && cost_row[bestd + step - p.dmin] < 1.0 && best < p.zncc_thr;
+      if (!found) { ok = false; reason = 2; }  // coarseSearchingFailNum_++, :122-126
+      else {  // fine pass over [best - (step - 1), best + (step - 1)] with the carried minimum (:127-133)
+        const int cd = bestd;
+        double fb = 2.0;
+        int fd = -1;
+        for (int d = cd - (step - 1) + l; d <= cd + (step - 1); d += G) {
+          if (!cand_valid(d)) continue;
+          const double c = cost_row[d - p.dmin];
+          if (c <= fb) { fb = c; fd = d; }
+        }
+        grp_argmin<G>(fb, fd);
+        // the window contains cd itself (valid, cost == best), so its minimum is <= best and the scan's last `<=` hit wins
+        best = fb;
+        bestd = fd;
+        if (!(best < p.zncc_thr)) { ok = false; reason = 3; }  // fineSearchingFailNum_++ (cannot happen: the minimum only falls)
+      }
     }
-    ok = bestd >= 0 && best < p.zncc_thr;  // :222 (fine search re-evaluates the same candidate)
+  } else if (ok) {
+    grp_argmin<G>(best, bestd);  // group argmin; ties -> larger disparity
+    // :222 (the fine search re-evaluates the same candidate); a failure here is the COARSE search's in the reference's count
+    if (!(bestd >= 0 && best < p.zncc_thr)) { ok = false; reason = 2; }
   }
   u32 pose_idx = 0;
   if (ok) {  // StampTransformationMap_lower_bound, utils.h:66-71
@@ -268,7 +345,7 @@ __global__ void __launch_bounds__(BM_BLOCK) bm_match_kernel(BmArgs a, DevParams 
     a.out_flags[w] = ok ? 1u : 0u;
     if (ok) {
       esvo_match_t m;
-      const double disparity = (double)bestd;         // x1(0) - bestMatch(0), :151
+      const double disparity = (double)bestd;         // x1(0) - bestMatch(0) / x1(1) - bestMatch(1), :146-151
       const double depth = p.baseline_f / disparity;  // :152
       m.x_left[0] = xr;
       m.x_left[1] = yr;
@@ -280,16 +357,37 @@ __global__ void __launch_bounds__(BM_BLOCK) bm_match_kernel(BmArgs a, DevParams 
       a.out_slots[w] = m;
     }
   }
+  // the reference's per-reason failure counters (EventBM.h:89, EventBM.cpp:107,124,135): one atomic per wave and reason,
+  // striped over CNT_STRIPES addresses so that a launch of 10^5 waves does not queue on one L2 line
+  if (a.fail_counters) {
+    const bool lead = w < a.n && l == 0;
+#pragma unroll
+    for (int r = 1; r <= 3; ++r) {
+      const int n = __popcll(__ballot(lead && reason == r));
+      if (n && (threadIdx.x & 63) == 0)
+        atomicAdd(a.fail_counters + CNT_BM_FAIL + (r - 1) * CNT_STRIPES + (blockIdx.x % CNT_STRIPES), (u32)n);
+    }
+  }
 }
 
-template <int G>
+template <int G, bool COARSE, bool UPDOWN>
 static void launch_bm_g(const BmArgs& a, const DevParams& p, int RD, hipStream_t s) {
-  const int per_event = (28 + 7 * RD) * 4;
+  const int nd = p.dmax - p.dmin + 1;
+  const int per_event = (28 + (UPDOWN ? (nd + 6) * 4 : 7 * RD)) * 4 + (COARSE ? ((nd + 1) & ~1) * 8 : 0);
   const int epb = BM_BLOCK / G;
   const u32 own = (a.n > (u32)p.ev_shard) ? (a.n - (u32)p.ev_shard + (u32)p.ev_nshards - 1) / (u32)p.ev_nshards : 0;
   if (own == 0) return;
   const u32 blocks = (own + epb - 1) / epb;
-  hipLaunchKernelGGL(bm_match_kernel<G>, dim3(blocks), dim3(BM_BLOCK), (size_t)per_event * epb, s, a, p, RD, per_event);
+  hipLaunchKernelGGL((bm_match_kernel<G, COARSE, UPDOWN>), dim3(blocks), dim3(BM_BLOCK), (size_t)per_event * epb, s, a, p, RD, per_event);
+}
+template <bool COARSE, bool UPDOWN>
+static void launch_bm_mode(int G, const BmArgs& a, const DevParams& p, int RD, hipStream_t s) {
+  switch (G) {
+    case 64: launch_bm_g<64, COARSE, UPDOWN>(a, p, RD, s); break;
+    case 32: launch_bm_g<32, COARSE, UPDOWN>(a, p, RD, s); break;
+    case 16: launch_bm_g<16, COARSE, UPDOWN>(a, p, RD, s); break;
+    default: launch_bm_g<8, COARSE, UPDOWN>(a, p, RD, s); break;
+  }
 }
 
 void launch_bm_match(const BmArgs& a, const DevParams& p, hipStream_t s) {
@@ -302,11 +400,13 @@ void launch_bm_match(const BmArgs& a, const DevParams& p, hipStream_t s) {
     const int slots = ((nd + G - 1) / G) * G;
     if (slots < bestSlots) { bestSlots = slots; bestG = G; }
   }
-  switch (bestG) {
-    case 64: launch_bm_g<64>(a, p, RD, s); break;
-    case 32: launch_bm_g<32>(a, p, RD, s); break;
-    case 16: launch_bm_g<16>(a, p, RD, s); break;
-    default: launch_bm_g<8>(a, p, RD, s); break;
+  const bool coarse = p.step > 1;
+  if (p.updown) {
+    if (coarse) launch_bm_mode<true, true>(bestG, a, p, RD, s);
+    else launch_bm_mode<false, true>(bestG, a, p, RD, s);
+  } else {
+    if (coarse) launch_bm_mode<true, false>(bestG, a, p, RD, s);
+    else launch_bm_mode<false, false>(bestG, a, p, RD, s);
   }
 }
 

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define ESVO_HIP_ABI_VERSION 1
+#define ESVO_HIP_ABI_VERSION 2
 
 typedef enum esvo_status_t {
   ESVO_OK = 0,
@@ -109,9 +109,9 @@ typedef struct esvo_params_t {
    * depth-range clamp of esvo_Mapping.cpp:110-116 (esvo_amd/params.py does it). */
   int32_t bm_min_disparity;
   int32_t bm_max_disparity;
-  int32_t bm_step;                 /* 1 in every shipped config */
+  int32_t bm_step;                 /* 1 in every shipped config; > 1: coarse-to-fine search (EventBM.cpp:118-138) */
   double bm_zncc_threshold;        /* 0.1 */
-  int32_t bm_updown;               /* BM_bUpDownConfiguration; only 0 supported */
+  int32_t bm_updown;               /* BM_bUpDownConfiguration: vertical epipolar search (EventBM.cpp:178-186) */
   int32_t smooth_time_surface;     /* SmoothTimeSurface: 5x5 Gaussian before BM (DSEC) */
   /* mapping node (esvo_Mapping.cpp:63-99) */
   double invdepth_min, invdepth_max;
@@ -197,6 +197,11 @@ typedef struct esvo_stats_t {
   uint64_t total_matches;
   uint64_t total_points;
   double sum_ms_kernel[8];      /* same slots as ms_kernel; [7] = launches of ts kernels summed in [0],[1] */
+  /* EventBM's failure counters by reason (EventBM.h:89; incremented at EventBM.cpp:107, :124, :135), of the last block
+   * matching and summed over the ticks: left patch with > 95 % of its pixels below 1, coarse search without a match
+   * (with BM_step 1: no candidate below the ZNCC threshold), fine search without a match. */
+  uint32_t last_bm_info_noise_low, last_bm_coarse_fail, last_bm_fine_fail, pad2_;
+  uint64_t total_bm_info_noise_low, total_bm_coarse_fail, total_bm_fine_fail;
 } esvo_stats_t;
 
 /* ---- lifecycle -------------------------------------------------------------------- */

@@ -122,3 +122,81 @@ def test_gpu_tracker_functor_equals_reference_source():
         n += 1
     assert n == 10
     dev.close()
+
+
+@pytest.mark.parametrize("name", ["upenn", "dsec"])
+@pytest.mark.parametrize("step,updown", [(2, 0), (3, 0), (1, 1), (2, 1)])
+def test_gpu_coarse_to_fine_and_updown_block_matching(name, step, updown):
+    """BM_step > 1 (coarse pass on the stride grid, neighbour rule, fine pass with the carried minimum: EventBM.cpp:118-138,
+    :207-219) and BM_bUpDownConfiguration (vertical search, :178-186, :146-151) on the device: the same matched events, order,
+    disparities, virtual views and inverse depths as the reference's EventBM (tests/golden/ref_bm_step.npz), the cost to
+    1e-12, and everything bit for bit against the CPU oracle's integer mode.  Also through the fused tick path: the
+    failure counters add up to the events that did not match."""
+    import copy
+    import os
+    from esvo_amd import lib
+    from oracle import oracle as O
+    from test_ref_pin import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "ref_bm_step.npz"))
+    _, sc, ticks = load_fixture(name)
+    tk = ticks[1]
+    p = copy.copy(sc.params)
+    p.bm_step = step
+    p.bm_updown = updown
+    dev = lib.Esvo(p, sc.rig, device=0)
+    dev.set_observation(tk["t"], tk["raw"][0], tk["raw"][1], tk["T"])
+    dev.set_poses(tk["stamps"], tk["poses"])
+    mt = dev.match(tk["ev"])
+    ref = g[f"{name}_s{step}" + ("_ud" if updown else "")]
+    assert len(ref) > 0
+    check_matches(mt, ref, cost_exact=False, cost_atol=1e-12)
+    m = O.OracleMapper(p, sc.rig)
+    m.set_mode(True, True)   # costs from exact integer moments, as the device forms them
+    m.set_observation(tk["t"], tk["raw"][0], tk["raw"][1], tk["T"])
+    m.set_poses(tk["stamps"], tk["poses"])
+    check_matches(mt, m.match(tk["ev"]))
+    s = dev.stats()
+    assert s.last_matches == len(mt)
+    assert s.last_bm_info_noise_low + s.last_bm_coarse_fail + s.last_bm_fine_fail <= len(tk["ev"]) - len(mt)
+    assert s.last_bm_coarse_fail > 0 and s.last_bm_fine_fail == 0
+    dev.close()
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_gpu_bm_failure_counters(name):
+    """EventBM's per-reason failure counters (EventBM.h:89) in esvo_stats_t against a count made from the inputs: the
+    info-noise-ratio rejections are the events whose left patch has > 95 % of its pixels below 1 (EventBM.cpp:104-109),
+    among those that pass the checks before it; with BM_step 1 every other search failure is the coarse search's."""
+    from esvo_amd import lib
+    g, sc, ticks = load_fixture(name)
+    p, rig = sc.params, sc.rig
+    dev = lib.Esvo(p, rig, device=0)
+    W, H = rig.width, rig.height
+    for k, tk in enumerate(ticks[:3]):
+        dev.set_observation(tk["t"], tk["raw"][0], tk["raw"][1], tk["T"])
+        dev.set_poses(tk["stamps"], tk["poses"])
+        mt = dev.match(tk["ev"])
+        tsL = tk["tsL"].astype(np.int32)
+        low = searched = 0
+        lut = rig.left.rect_lut
+        for e in tk["ev"]:
+            xr, yr = float(lut[e["y"], e["x"], 0]), float(lut[e["y"], e["x"], 1])
+            if xr < 0 or xr > W - 1 or yr < 0 or yr > H - 1:
+                continue
+            if rig.left.rect_mask is not None and rig.left.rect_mask[int(yr), int(xr)] <= 125:
+                continue
+            x1, y1 = int(np.floor(xr)), int(np.floor(yr))
+            if x1 - 7 < 1 or y1 - 3 < 1 or x1 + 7 >= W - 1 or y1 + 3 >= H - 1:
+                continue
+            patch = tsL[y1 - 3:y1 + 4, x1 - 7:x1 + 8]
+            if (patch < 1).sum() > 0.95 * patch.size:
+                low += 1
+            else:
+                searched += 1
+        s = dev.stats()
+        assert s.last_bm_info_noise_low == low, (k, s.last_bm_info_noise_low, low)
+        # an event that reaches the search either fails it or matches -- except the one event with a stamp >= t that the
+        # selection includes (Appendix A-3): it can pass the search and then finds no virtual view at or after its stamp
+        # (EventBM.cpp:154-156), which no counter records
+        assert 0 <= searched - len(mt) - s.last_bm_coarse_fail <= 1 and s.last_bm_fine_fail == 0, (k, s.last_bm_coarse_fail, searched, len(mt))
+    dev.close()

@@ -26,7 +26,7 @@ def test_abi_struct_sizes_match_bindings():
     assert s[1] == ctypes.sizeof(abi.CalibStruct) and s[2] == ctypes.sizeof(abi.ParamsStruct)
     assert s[3] == abi.MATCH_DTYPE.itemsize == 48 and s[4] == abi.DEPTH_POINT_DTYPE.itemsize == 104
     assert s[5] == ctypes.sizeof(abi.StatsStruct) and s[6] == 0
-    assert s[7] == 1
+    assert s[7] == 2
 
 
 def test_create_fails_loudly_without_gpu():
@@ -44,7 +44,7 @@ def test_unsupported_params_are_rejected_not_approximated():
     from esvo_amd import lib
     so = lib.load()
     rig = calib.ideal_rig(64, 48, 100.0, 0.1)
-    for kw in (dict(bm_step=2), dict(patch_size_x=25), dict(ls_norm=abi.LSNORM_L2), dict(bm_updown=1)):
+    for kw in (dict(patch_size_x=25), dict(ls_norm=abi.LSNORM_L2), dict(median_blur_kernel_size=2)):
         p, _ = params.make_params(params.PRESETS["mvstereo_upenn"], rig, **kw)
         h = ctypes.c_void_p()
         cl, cr = rig.left.as_struct(), rig.right.as_struct()

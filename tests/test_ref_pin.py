@@ -321,7 +321,7 @@ def test_time_surface_raster_equals_reference_source():
 def test_coarse_to_fine_block_matching_equals_reference_source(name, step, updown):
     """BM_step > 1 (EventBM.cpp:113-138,169-225) and BM_bUpDownConfiguration (:180-183,146-151: the search along y) in the
     oracle against the reference's EventBM: same matched events, order, disparities, virtual views and costs.  (The device
-    rejects both: no shipped configuration sets them.)"""
+    side of both: tests/test_gpu_ref.py::test_gpu_coarse_to_fine_and_updown_block_matching.)"""
     import copy
     g = np.load(os.path.join(GOLDEN, "ref_bm_step.npz"))
     _, sc, ticks = load_fixture(name)
