@@ -18,7 +18,7 @@ void invert3x3(const double* P, double* Kinv, double* Kinv_t) {
 }
 
 int validate_params(const esvo_params_t* p, std::string& why) {
-  if (p->ls_norm != ESVO_LSNORM_TDIST) { why = "only LSnorm == Tdist is supported (every shipped config uses it)"; return ESVO_ERR_UNSUPPORTED; }
+  if (p->ls_norm != ESVO_LSNORM_TDIST && p->ls_norm != ESVO_LSNORM_L2) { why = "LSnorm must be Tdist or l2 (DepthProblemSolver.cpp:121-131 exits on anything else)"; return ESVO_ERR_UNSUPPORTED; }
   if (p->bm_step < 1) { why = "BM_step must be >= 1"; return ESVO_ERR_INVALID_ARG; }
   if (p->patch_size_x != 15 || p->patch_size_y != 7) { why = "patch size must be 15x7 (every shipped config)"; return ESVO_ERR_UNSUPPORTED; }
   if (p->median_blur_kernel_size < 0 || p->median_blur_kernel_size > 1) { why = "median_blur_kernel_size must be 0 or 1"; return ESVO_ERR_UNSUPPORTED; }
@@ -53,6 +53,7 @@ void fill_dev_params(esvo_context* h) {
   d.fusion_radius = p.fusion_radius;
   d.reg_radius = p.reg_radius; d.reg_min_nb = p.reg_min_neighbours; d.reg_min_close = p.reg_min_close_neighbours;
   d.num_threads = p.num_threads;
+  d.ls_norm = p.ls_norm;
 }
 
 template <typename T>

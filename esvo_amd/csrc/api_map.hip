@@ -237,7 +237,7 @@ int commit_frame(esvo_context* h, u32 off, u32 count, const double* pose_T_host,
 
 // fusion loop + clean + regularisation on the current window, on the back stream; `par` selects the
 // pinned frame table and the event set (two ticks may be in flight)
-int run_fuse(esvo_context* h, int par, const double* T_world_obs) {
+int run_fuse(esvo_context* h, int par, const double* T_world_obs, bool naive) {
   // frames newest -> oldest (esvo_Mapping.cpp:372-377)
   const size_t tab = 3 * (size_t)h->max_frames + 1;
   u32* cum = h->h_fr_table + (size_t)par * tab;
@@ -255,7 +255,13 @@ int run_fuse(esvo_context* h, int par, const double* T_world_obs) {
   cum[nf] = total;
   hipStream_t sb = h->stream_b;
   u32* dtab = h->d_fr_table + (size_t)par * tab;
-  launch_upload_words(cum, dtab, sizeof(u32) * tab, sb);
+  // only the used prefixes of the three sub-tables (cum[0..nf], off[0..nf), slot[0..nf)): max_frames is sized for the
+  // worst case of CONST_POINTS (one point per frame), a tick uses a handful of entries
+  launch_upload_words(cum, dtab, sizeof(u32) * (nf + 1), sb);
+  if (nf) {
+    launch_upload_words(off, dtab + (h->max_frames + 1), sizeof(u32) * nf, sb);
+    launch_upload_words(slot, dtab + (h->max_frames + 1) + h->max_frames, sizeof(u32) * nf, sb);
+  }
   std::memcpy(h->T_world_frame, T_world_obs, sizeof(double) * 16);  // new DepthFrame at the TS pose (:268-272)
   FuseArgs a;
   a.win = h->d_win;
@@ -268,6 +274,7 @@ int run_fuse(esvo_context* h, int par, const double* T_world_obs) {
   a.rec_ids = h->d_rec_ids; a.scan_tmp = h->d_scan_tmp_b; a.d_total = h->d_cnt_b + 4;
   a.map = h->d_map; a.d_num_fusion = h->d_cnt_b + 3;
   a.bucket = h->d_bucket; a.cell_list = h->d_cell_list; a.n_touched = h->d_cnt_b + 6;
+  a.naive = naive ? 1 : 0;
   a.owner_max = h->prm.regularization ? h->d_owner_max : nullptr;
   a.owner_min = h->d_owner_min; a.n_reg_elems = h->prm.regularization ? h->d_cnt_b + 7 : nullptr;
   if (total > h->win_cap) FAIL(ESVO_ERR_CAPACITY, "window points exceed capacity");
@@ -276,10 +283,11 @@ int run_fuse(esvo_context* h, int par, const double* T_world_obs) {
   launch_fuse(a, h->dp, sb);
   hipEventRecord(h->evt[EV_FU1 + o], sb);
   h->d_map_cur = h->d_map;
-  const bool do_clean = h->prm.clean_requires_full_window ? (h->n_window_frames >= (size_t)h->prm.max_fusion_frames) : true;
+  // (naive propagation, esvo_MVStereo.cpp:416-428: the map is published as it is, neither cleaned nor regularised)
+  const bool do_clean = naive ? false : (h->prm.clean_requires_full_window ? (h->n_window_frames >= (size_t)h->prm.max_fusion_frames) : true);
   if (do_clean) launch_clean(h->d_map, h->dp, sb);
   hipEventRecord(h->evt[EV_CL1 + o], sb);
-  if (h->prm.regularization) {
+  if (h->prm.regularization && !naive) {
     launch_reg_view(h->d_map, h->d_map2, h->d_owner_max, h->d_owner_min, h->d_reg_ab, h->d_reg_cd, h->d_cnt_b + 7, h->dp, sb);
     launch_reg_apply(h->d_map, h->d_map2, h->d_owner_max, h->d_owner_min, h->d_reg_ab, h->d_reg_cd, h->dp, sb);
     h->d_map_cur = h->d_map2;
@@ -780,6 +788,86 @@ extern "C" int esvo_map_tick(esvo_handle h, uint64_t t_ns, const uint64_t* pose_
     h->tick_pending = true;  // this tick (its front stage is enqueued whatever happened to the previous one)
     if (rc) return rc;
   }
+  return ESVO_OK;
+}
+
+// ---- esvo_MVStereo's PURE_BLOCK_MATCHING mode (MVStereoMode 1, esvo_MVStereo.cpp:383-432) -------------------------------------
+// Event selection + (denoising) + block matching as in every tick; then vEMP2vDP (:1072-1094) instead of the nonlinear
+// refinement, a window of maxNumFusionFrames frames whatever the fusion strategy (:419-421), and
+// DepthFusion::naive_propagation of every frame, newest first, into a new DepthFrame (:422-423) -- no culling, no clean, no
+// regularisation.  Synchronous (a visualisation baseline: nothing is pipelined).
+extern "C" int esvo_map_tick_bm_only(esvo_handle h, uint64_t t_ns, const uint64_t* pose_t_ns, const double* pose_T, size_t m) {
+  if (!h || !pose_t_ns || !pose_T) return ESVO_ERR_INVALID_ARG;
+  API_LOCK(h);
+  if (!h->obs_set) FAIL(ESVO_ERR_STATE, "esvo_map_set_observation has not been called");
+  if (h->sharded) FAIL(ESVO_ERR_STATE, "handle is sharded");
+  HIPCHK(hipSetDevice(h->device));
+  int rc = flush_pending_tick(h);
+  if (rc) return rc;
+  // phase 0 up to the match list (tick_phase0 also enqueues the LM kernel, which this mode does not run), on the front stream
+  if (m > h->max_poses) FAIL(ESVO_ERR_CAPACITY, "pose table larger than max_poses_per_tick");
+  u32 n = 0;
+  u64 first = 0;
+  rc = select_events(h, t_ns, &first, &n);
+  if (!rc) rc = upload_poses(h, pose_t_ns, pose_T, m, h->d_counters2[h->fpar ^ 1]);
+  if (rc) return rc;
+  h->fpar ^= 1;
+  h->d_matches = h->d_matches2[h->fpar];
+  h->d_counters = h->d_counters2[h->fpar];
+  HIPCHK(hipStreamWaitEvent(h->stream, h->evt[EV_RG1 + h->par * EV_BACK_STRIDE], 0));
+  hipEventRecord(h->evt[EV_T0 + h->fpar * EV_FRONT_STRIDE], h->stream);
+  const u32* sel = nullptr;
+  if (h->prm.denoising && n) {
+    launch_denoise_flags(h->d_ring[0], h->sh_first, h->ring_cap, n, h->d_evmap, h->d_match_flags, h->W, h->H, h->stream);
+    launch_exclusive_scan_u32(h->d_match_flags, h->d_match_prefix, h->d_counters + 5, h->d_scan_tmp, n, h->stream);
+    launch_denoise_select(h->d_match_flags, h->d_match_prefix, n, h->d_sel, h->stream);
+    rc = read_counters(h);
+    if (rc) return rc;
+    n = h->h_counters[5];
+    sel = h->d_sel;
+  }
+  u32 n_matches = 0;
+  if (n) {
+    rc = run_bm(h, h->d_ring[0], h->sh_first, h->ring_cap, 1, n, sel);
+    if (rc) return rc;
+    rc = run_order_matches(h, n, false);
+    if (rc) return rc;
+    launch_matches_to_points(h->d_matches, h->d_counters + 0, n, h->d_pts_tmp, h->dp, h->stream);
+    HIPCHK(hipGetLastError());
+    rc = read_counters(h);
+    if (rc) return rc;
+    n_matches = h->h_counters[0];
+    collect_bm_failures(h, h->h_counters, true);
+  }
+  esvo_stats_t& s = h->stats;
+  s.last_events_in = n; s.last_matches = n_matches; s.last_solved = 0; s.last_points = n_matches;
+  s.total_events_in += n; s.total_matches += n_matches; s.total_points += n_matches;
+  // dqvDepthPoints_.push_back(vdp_em); while (size > maxNumFusionFrames_) pop_front()
+  u32 off;
+  rc = window_reserve(h, n_matches, &off);
+  if (rc) return rc;
+  rc = back_after_front(h);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(h->stream_b));  // the ring space may still be read by a fusion in flight
+  if (n_matches)
+    HIPCHK(hipMemcpyAsync(h->d_win + off, h->d_pts_tmp, sizeof(DevPoint) * n_matches, hipMemcpyDeviceToDevice, h->stream_b));
+  rc = commit_frame(h, off, n_matches, nullptr, h->n_pose, h->pose_buf, false);
+  if (rc) return rc;
+  while (h->n_window_frames > (size_t)h->prm.max_fusion_frames) pop_front_frame(h);
+  const int par = h->par;
+  h->par ^= 1;
+  HIPCHK(hipEventSynchronize(h->evt[EV_RG1 + par * EV_BACK_STRIDE]));
+  collect_back(h, par);
+  rc = run_fuse(h, par, h->T_world_obs, true);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(h->stream_b));
+  collect_back(h, par);
+  h->committed_t_ns = t_ns;
+  s.ticks++;
+  s.last_window_frames = (u32)h->n_window_frames;
+  u32 np = 0;
+  for (auto& f : h->frames) np += f.count;
+  s.last_window_points = np;
   return ESVO_OK;
 }
 

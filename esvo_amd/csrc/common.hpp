@@ -49,6 +49,7 @@ struct DevParams {
   int fusion_radius;
   int reg_radius, reg_min_nb, reg_min_close;
   int num_threads;               // stride-N output permutation
+  int ls_norm;                   // ESVO_LSNORM_TDIST / ESVO_LSNORM_L2 (DepthProblemConfig::LSnorm_)
   int band_y0, band_y1;          // row band owned by this handle (0,H when unsharded)
   int ev_shard, ev_nshards;      // per-event work (BM, LM) of slot w belongs to shard w % ev_nshards (balanced
                                  // whatever the scene; every rank holds the full Time Surfaces)
@@ -194,6 +195,8 @@ struct BmArgs {
 void launch_bm_match(const BmArgs& a, const DevParams& p, hipStream_t s);
 void launch_compact_matches(const esvo_match_t* slots, const u32* flags, const u32* prefix, u32 n,
                             esvo_match_t* out, u32* slot_of, hipStream_t s);
+void launch_matches_to_points(const esvo_match_t* m, const u32* n_ptr, u32 max_n, esvo_depth_point_t* out, const DevParams& p,
+                              hipStream_t s);
 
 // kernels_track.hip: tracker residual / Jacobian evaluation (RegProblemLM.cpp), SURVEY.md section 8(f).1
 struct TrackRef { double T[16]; };            // T_world_ref
@@ -266,6 +269,7 @@ struct FuseArgs {
   u32* bucket;                  // [3*128] load-balancing buckets: count | offset | fill
   u32* cell_list;               // [W*H] touched cells, longest record lists first
   u32* n_touched;               // number of touched cells
+  int naive;                    // 1: DepthFusion::naive_propagation instead of update (esvo_MVStereo's PURE_BLOCK_MATCHING mode)
   u32* owner_max;               // regulariser scratch reset together with the per-cell counters (or nullptr)
   u32* owner_min;
   u32* n_reg_elems;

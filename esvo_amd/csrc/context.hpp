@@ -271,7 +271,7 @@ int back_after_front(esvo_context* h);
 void collect_back(esvo_context* h, int par);
 int window_reserve(esvo_context* h, u32 n, u32* off_out);
 int commit_frame(esvo_context* h, u32 off, u32 count, const double* pose_T_host, u32 m, int pose_buf = 0, bool apply_policy = true);
-int run_fuse(esvo_context* h, int par, const double* T_world_obs);
+int run_fuse(esvo_context* h, int par, const double* T_world_obs, bool naive = false);
 int export_map(esvo_context* h, std::vector<esvo_depth_point_t>& out, std::vector<u32>* cells);
 int tick_phase0(esvo_context* h, uint64_t t_ns, const uint64_t* pose_t_ns, const double* pose_T, size_t m);
 int tick_phase1_enqueue(esvo_context* h);

@@ -425,4 +425,34 @@ void launch_compact_matches(const esvo_match_t* slots, const u32* flags, const u
   hipLaunchKernelGGL(compact_matches_kernel, dim3((n + 255) / 256), dim3(256), 0, s, slots, flags, prefix, n, out, slot_of);
 }
 
+// esvo_MVStereo::vEMP2vDP (esvo_MVStereo.cpp:1072-1094): one Gaussian DepthPoint per match for the PURE_BLOCK_MATCHING mode --
+// pseudo-variance 0, i.e. the 1e-6 bound of DepthPoint::boundVariance; residual = ZNCC cost; age = age_vis_threshold.
+__global__ void __launch_bounds__(256) matches_to_points_kernel(const esvo_match_t* __restrict__ m, const u32* __restrict__ n_ptr,
+                                                                u32 max_n, DevPoint* __restrict__ out, DevParams p) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  u32 n = *n_ptr;
+  if (n > max_n) n = max_n;
+  if (i >= n) return;
+  const esvo_match_t e = m[i];
+  DevPoint o;
+  o.row = (u32)(size_t)floor(e.x_left[1]);
+  o.col = (u32)(size_t)floor(e.x_left[0]);
+  o.x[0] = e.x_left[0];
+  o.x[1] = e.x_left[1];
+  cam2World(p.camL, e.x_left[0], e.x_left[1], e.inv_depth, o.p_cam);
+  o.inv_depth = e.inv_depth;  // DepthPoint::update on a new point
+  o.variance = 1e-6;
+  o.scale2 = 0;
+  o.nu = 0;
+  o.residual = e.cost;
+  o.age = (u64)p.age_thr;
+  o.pose_idx = e.pose_idx;
+  o.seq = i;
+  out[i] = o;
+}
+void launch_matches_to_points(const esvo_match_t* m, const u32* n_ptr, u32 max_n, DevPoint* out, const DevParams& p, hipStream_t s) {
+  if (max_n == 0) return;
+  hipLaunchKernelGGL(matches_to_points_kernel, dim3((max_n + 255) / 256), dim3(256), 0, s, m, n_ptr, max_n, out, p);
+}
+
 }  // namespace esvo

@@ -52,7 +52,17 @@ __device__ inline bool fusion_cell(u32 prow, u32 pcol, int k, int radius, int W,
   return row >= 0 && row < H && col >= 0 && col < W;
 }
 
+// ---- the three observation models of DepthFusion -------------------------------------------------------------------
+//   FUSE_TDIST  DepthFusion::update with LSnorm "Tdist" (every shipped configuration): Student-t propagation and fusion
+//   FUSE_L2     the same with LSnorm "l2": Gaussian propagation (DepthFusion.cpp:49-53), chiSquareTest (:207-218) and
+//               DepthPoint::update (DepthPoint.cpp:146-164) in the compatible branch
+//   FUSE_NAIVE  DepthFusion::naive_propagation (:234-288): Gaussian propagation, always 2 x 2 cells, an occupied cell is
+//               replaced by a propagated point that is not farther and has the smaller residual -- esvo_MVStereo's
+//               PURE_BLOCK_MATCHING mode (esvo_MVStereo.cpp:416-428)
+enum { FUSE_TDIST = 0, FUSE_L2 = 1, FUSE_NAIVE = 2 };
+
 // ---- propagate (+ histogram) ------------------------------------------------------------------
+template <int MODEL>
 __global__ void __launch_bounds__(256, BACK_WAVES) propagate_kernel(FuseArgs a, DevParams p, int K) {
   const u32 q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= a.n_pts) return;
@@ -90,22 +100,30 @@ __global__ void __launch_bounds__(256, BACK_WAVES) propagate_kernel(FuseArgs a, 
   denominator /= prior.p_cam[2];
   denominator += T[10];
   const double J = T[10] / (denominator * denominator);
-  const double scale2 = J * J * prior.scale2;
-  const double nu = prior.nu;
-  const double variance = nu / (nu - 2) * scale2;
-  prop.inv_depth = invDepth;  // update_studentT on a fresh DepthPoint: plain assignment
-  prop.scale2 = scale2;
-  prop.variance = variance;
-  prop.nu = nu;
+  prop.inv_depth = invDepth;  // update_studentT / update on a fresh DepthPoint: plain assignment
+  if constexpr (MODEL == FUSE_TDIST) {
+    const double scale2 = J * J * prior.scale2;
+    const double nu = prior.nu;
+    prop.scale2 = scale2;
+    prop.variance = nu / (nu - 2) * scale2;
+    prop.nu = nu;
+  } else {  // DepthPoint::update(invDepth, J^2 variance) on a new point + boundVariance (DepthPoint.cpp:140-164)
+    double variance = J * J * prior.variance;
+    if (variance < 1e-6) variance = 1e-6;
+    prop.variance = variance;
+    prop.scale2 = 0;  // the Gaussian update leaves scaleSquared_ / nu_ as constructed (zero here and in the oracle, Appendix A-8)
+    prop.nu = 0;
+  }
   prop.p_cam[0] = pp[0]; prop.p_cam[1] = pp[1]; prop.p_cam[2] = pp[2];
   prop.residual = prior.residual;
   prop.age = prior.age;
   prop.pose_idx = 0;
   prop.seq = q;
   a.prop[q] = prop;
+  const int radius = MODEL == FUSE_NAIVE ? 0 : p.fusion_radius;
   for (int k = 0; k < K; ++k) {
     int row, col;
-    if (!fusion_cell(prop.row, prop.col, k, p.fusion_radius, p.W, p.H, row, col)) continue;
+    if (!fusion_cell(prop.row, prop.col, k, radius, p.W, p.H, row, col)) continue;
     if (row < p.cband_y0 || row >= p.cband_y1) continue;
     atomicAdd(&a.cell_count[row * p.W + col], 1u);
   }
@@ -116,9 +134,10 @@ __global__ void __launch_bounds__(256) scatter_records_kernel(FuseArgs a, DevPar
   if (q >= a.n_pts) return;
   const u32 prow = a.prop[q].row, pcol = a.prop[q].col;
   if (prow == 0xffffffffu) return;
+  const int radius = K == 4 ? 0 : p.fusion_radius;  // (naive propagation: always 2 x 2)
   for (int k = 0; k < K; ++k) {
     int row, col;
-    if (!fusion_cell(prow, pcol, k, p.fusion_radius, p.W, p.H, row, col)) continue;
+    if (!fusion_cell(prow, pcol, k, radius, p.W, p.H, row, col)) continue;
     if (row < p.cband_y0 || row >= p.cband_y1) continue;
     const int cell = row * p.W + col;
     const u32 pos = a.cell_offset[cell] + atomicAdd(&a.cell_fill[cell], 1u);
@@ -300,6 +319,7 @@ __global__ void __launch_bounds__(64) sort_long_lists_kernel(const u32* __restri
 #ifndef FUSE_BLOCK
 #define FUSE_BLOCK 256
 #endif
+template <int MODEL>
 __global__ void __launch_bounds__(FUSE_BLOCK, FUSE_WAVES) fuse_cells_kernel(FuseArgs a, DevParams p, int K) {
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= *a.n_touched) return;
@@ -342,19 +362,48 @@ __global__ void __launch_bounds__(FUSE_BLOCK, FUSE_WAVES) fuse_cells_kernel(Fuse
     id = next_id(i, id);
     const DevPoint prop = a.prop[id / (u32)K];
 #endif
-    if (!exists) {  // case 1: DepthFusion.cpp:127-146
+    if (!exists) {  // case 1: DepthFusion.cpp:127-146 (naive_propagation: :262-272)
       c.row = (u32)crow; c.col = (u32)ccol;
       c.x[0] = (double)ccol + 0.5; c.x[1] = (double)crow + 0.5;
       c.inv_depth = prop.inv_depth; c.scale2 = prop.scale2; c.variance = prop.variance; c.nu = prop.nu;
+      if (MODEL != FUSE_TDIST && c.variance < 1e-6) c.variance = 1e-6;  // DepthPoint::update -> boundVariance
       c.residual = prop.residual;
       c.age = prop.age;
       cam2World(p.camL, c.x[0], c.x[1], prop.inv_depth, c.p_cam);
       c.seq = id;
       exists = true;
+    } else if constexpr (MODEL == FUSE_NAIVE) {  // case 2 of naive_propagation, :273-282
+      if (c.inv_depth > prop.inv_depth) continue;  // the propagated point is farther
+      if (prop.residual < c.residual) {
+        c.row = prop.row; c.col = prop.col;        // `get(row, col) = dp_prop`: its row / col / x travel with it (Appendix A-7)
+        c.x[0] = prop.x[0]; c.x[1] = prop.x[1];
+        c.inv_depth = prop.inv_depth; c.scale2 = prop.scale2; c.nu = prop.nu; c.variance = prop.variance;
+        c.residual = prop.residual; c.age = prop.age;
+        c.p_cam[0] = prop.p_cam[0]; c.p_cam[1] = prop.p_cam[1]; c.p_cam[2] = prop.p_cam[2];
+      }
     } else {
-      const double s1 = sqrt(prop.variance), s2 = sqrt(c.variance), diff = fabs(prop.inv_depth - c.inv_depth);
-      if (diff < 2 * s1 || diff < 2 * s2) {  // studentTCompatibleTest, :220-231 -> case 2.1
-        update_studentT(c, prop.inv_depth, prop.scale2, prop.variance, prop.nu);
+      bool compatible;
+      if constexpr (MODEL == FUSE_L2) {  // chiSquareTest, :207-218
+        const double d = prop.inv_depth - c.inv_depth, dd = d * d;
+        compatible = dd / prop.variance + dd / c.variance < 5.99;
+      } else {  // studentTCompatibleTest, :220-231
+        const double s1 = sqrt(prop.variance), s2 = sqrt(c.variance), diff = fabs(prop.inv_depth - c.inv_depth);
+        compatible = diff < 2 * s1 || diff < 2 * s2;
+      }
+      if (compatible) {  // case 2.1
+        if constexpr (MODEL == FUSE_L2) {  // DepthPoint::update, DepthPoint.cpp:146-164
+          if (c.inv_depth > -1e-6) {
+            const double temp = c.inv_depth, tv = c.variance;
+            c.inv_depth = (tv * prop.inv_depth + prop.variance * temp) / (tv + prop.variance);
+            c.variance = (tv * prop.variance) / (tv + prop.variance);
+          } else {
+            c.inv_depth = prop.inv_depth;
+            c.variance = prop.variance;
+          }
+          if (c.variance < 1e-6) c.variance = 1e-6;
+        } else {
+          update_studentT(c, prop.inv_depth, prop.scale2, prop.variance, prop.nu);
+        }
         c.age++;                                                        // :171
         c.residual = (prop.residual < c.residual) ? prop.residual : c.residual;  // std::min
         cam2World(p.camL, c.x[0], c.x[1], prop.inv_depth, c.p_cam);     // :173-175
@@ -394,10 +443,16 @@ __global__ void __launch_bounds__(256) fuse_reset_kernel(FuseArgs a, int ncell) 
 
 void launch_fuse(const FuseArgs& a, const DevParams& p, hipStream_t s) {
   const int ncell = p.W * p.H;
-  const int K = (p.fusion_radius == 0) ? 4 : 9;
+  const int model = a.naive ? FUSE_NAIVE : (p.ls_norm == ESVO_LSNORM_L2 ? FUSE_L2 : FUSE_TDIST);
+  const int K = (model == FUSE_NAIVE || p.fusion_radius == 0) ? 4 : 9;
   const int nb = (ncell + 255) / 256;
   hipLaunchKernelGGL(fuse_reset_kernel, dim3(std::max(nb, 2)), dim3(256), 0, s, a, ncell);
-  if (a.n_pts) hipLaunchKernelGGL(propagate_kernel, dim3((a.n_pts + 255) / 256), dim3(256), 0, s, a, p, K);
+  if (a.n_pts) {
+    const dim3 g((a.n_pts + 255) / 256), b(256);
+    if (model == FUSE_TDIST) hipLaunchKernelGGL(propagate_kernel<FUSE_TDIST>, g, b, 0, s, a, p, K);
+    else if (model == FUSE_L2) hipLaunchKernelGGL(propagate_kernel<FUSE_L2>, g, b, 0, s, a, p, K);
+    else hipLaunchKernelGGL(propagate_kernel<FUSE_NAIVE>, g, b, 0, s, a, p, K);
+  }
   const u32 nsb = (u32)((ncell + SCAN_TILE - 1) / SCAN_TILE);
   hipLaunchKernelGGL(cell_scan_reduce_kernel, dim3(nsb), dim3(SCAN_B), 0, s, a.cell_count, a.scan_tmp, a.bucket, a.map, ncell,
                      p.cband_y0, p.cband_y1, p.W);
@@ -408,7 +463,12 @@ void launch_fuse(const FuseArgs& a, const DevParams& p, hipStream_t s) {
   if (a.n_pts) hipLaunchKernelGGL(scatter_records_kernel, dim3((a.n_pts + 255) / 256), dim3(256), 0, s, a, p, K);
   hipLaunchKernelGGL(sort_long_lists_kernel, dim3(8192), dim3(64), 0, s, a.cell_list, a.bucket + FUSE_NB + 3, a.cell_count,
                      a.cell_offset, a.rec_ids);
-  hipLaunchKernelGGL(fuse_cells_kernel, dim3((ncell + FUSE_BLOCK - 1) / FUSE_BLOCK), dim3(FUSE_BLOCK), 0, s, a, p, K);
+  {
+    const dim3 g((ncell + FUSE_BLOCK - 1) / FUSE_BLOCK), b(FUSE_BLOCK);
+    if (model == FUSE_TDIST) hipLaunchKernelGGL(fuse_cells_kernel<FUSE_TDIST>, g, b, 0, s, a, p, K);
+    else if (model == FUSE_L2) hipLaunchKernelGGL(fuse_cells_kernel<FUSE_L2>, g, b, 0, s, a, p, K);
+    else hipLaunchKernelGGL(fuse_cells_kernel<FUSE_NAIVE>, g, b, 0, s, a, p, K);
+  }
 }
 
 // ---- SmartGrid::clean ---------------------------------------------------------------------------
@@ -445,7 +505,7 @@ __global__ void __launch_bounds__(256) reg_view_kernel(const MapCell* __restrict
                                                        double2* __restrict__ ab, double2* __restrict__ cd,
                                                        u32* __restrict__ owner_max, u32* __restrict__ owner_min,
                                                        u32* __restrict__ n_elems, int ncell, int W,
-                                                       int band0, int band1, int view0, int view1) {
+                                                       int band0, int band1, int view0, int view1, int l2) {
   const int cell = blockIdx.x * blockDim.x + threadIdx.x;
   bool alive = false;
   if (cell < ncell) {
@@ -460,7 +520,7 @@ __global__ void __launch_bounds__(256) reg_view_kernel(const MapCell* __restrict
       const bool v = (n.flags & CELL_ALIVE) && (n.flags & CELL_GRID) && n.inv_depth > -1e-6;
       const double nan = __longlong_as_double(0x7ff8000000000000ll);
       ab[cell] = v ? make_double2(n.inv_depth, 2.0 * sqrt(n.variance)) : make_double2(nan, nan);
-      if (v) cd[cell] = make_double2(n.nu, n.scale2);
+      if (v) cd[cell] = l2 ? make_double2(n.variance, 0.0) : make_double2(n.nu, n.scale2);
     }
     if (row >= band0 && row < band1) {
       alive = (n.flags & CELL_ALIVE) != 0;
@@ -667,16 +727,67 @@ __global__ void __launch_bounds__(REG_TX * REG_TY, BACK_WAVES) reg_apply_kernel(
   out[cell] = c;
 }
 
+// LSnorm "l2" (DepthRegularization.cpp:56-65): the new inverse depth is the inverse-variance weighted mean of the close
+// neighbours -- two passes over them (the total first), so one thread per element walks its window in the view twice.  No
+// shipped configuration selects it: the plain formulation, not the tile kernel.  cd holds (variance, 0) in this mode.
+__global__ void __launch_bounds__(256) reg_apply_l2_kernel(const MapCell* __restrict__ map, MapCell* __restrict__ out,
+                                                           const u32* __restrict__ owner_max, const u32* __restrict__ owner_min,
+                                                           const double2* __restrict__ ab, const double2* __restrict__ cd, DevParams p) {
+  const int cell = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cell >= p.W * p.H) return;
+  { const int r0 = cell / p.W; if (r0 < p.band_y0 || r0 >= p.band_y1) return; }
+  MapCell c = map[cell];
+  if (!(c.flags & CELL_ALIVE)) return;
+  const int row = (int)c.row, col = (int)c.col, R = p.reg_radius;
+  const u32 b = (u32)row * (u32)p.W + (u32)col;  // dmTmp.set(it->row(), it->col(), *it)
+  if (owner_max[b] != c.seq + 1u) { out[cell].flags = 0; return; }  // overwritten by a later element
+  if (c.inv_depth > -1e-6) {  // it->valid()
+    u32 nb = 0, nclose = 0;
+    double total = 0.0;
+    const double sd_self2 = 2.0 * sqrt(c.variance);
+    // SmartGrid::getNeighbourhood's loop bounds mix int and size_t (SmartGrid.h:373-375): row < radius or col < radius -> no neighbours
+    const bool scan = row >= R && col >= R;
+    if (scan)
+      for (int r = row - R; r <= row + R && r < p.H; ++r)
+        for (int c2 = col - R; c2 <= col + R && c2 < p.W; ++c2) {
+          const double2 q = ab[r * p.W + c2];
+          if (!(q.x == q.x)) continue;
+          nb++;
+          const double diff = fabs(c.inv_depth - q.x);
+          if (diff < sd_self2 || diff < q.y) { nclose++; total += 1.0 / cd[r * p.W + c2].x; }
+        }
+    double mean = 0.0;
+    const bool set = nb > (u32)p.reg_min_nb && nclose > (u32)p.reg_min_close;
+    if (set)
+      for (int r = row - R; r <= row + R && r < p.H; ++r)
+        for (int c2 = col - R; c2 <= col + R && c2 < p.W; ++c2) {
+          const double2 q = ab[r * p.W + c2];
+          if (!(q.x == q.x)) continue;
+          const double diff = fabs(c.inv_depth - q.x);
+          if (diff < sd_self2 || diff < q.y) mean += q.x * (1.0 / cd[r * p.W + c2].x) / total;
+        }
+    c.inv_depth = set ? mean : -1.0;
+  }
+  c.seq = owner_min[b];
+  c.flags = CELL_ALIVE | CELL_GRID;
+  out[cell] = c;
+}
+
 void launch_reg_view(const MapCell* map_in, MapCell* map_out, u32* owner_max, u32* owner_min, double2* ab, double2* cd,
                      u32* n_elems, const DevParams& p, hipStream_t s) {
   const int ncell = p.W * p.H;
   // owner_max / owner_min / n_elems were reset by fuse_reset_kernel (launch_fuse of the same tick)
   const int nb = (ncell + 255) / 256;
   hipLaunchKernelGGL(reg_view_kernel, dim3(nb), dim3(256), 0, s, map_in, map_out, ab, cd, owner_max, owner_min, n_elems, ncell, p.W,
-                     p.band_y0, p.band_y1, p.cband_y0, p.cband_y1);
+                     p.band_y0, p.band_y1, p.cband_y0, p.cband_y1, p.ls_norm == ESVO_LSNORM_L2 ? 1 : 0);
 }
 void launch_reg_apply(const MapCell* map_in, MapCell* map_out, const u32* owner_max, const u32* owner_min, const double2* ab,
                       const double2* cd, const DevParams& p, hipStream_t s) {
+  if (p.ls_norm == ESVO_LSNORM_L2) {
+    const int ncell = p.W * p.H;
+    hipLaunchKernelGGL(reg_apply_l2_kernel, dim3((ncell + 255) / 256), dim3(256), 0, s, map_in, map_out, owner_max, owner_min, ab, cd, p);
+    return;
+  }
   const int tiles_x = (p.W + REG_TX - 1) / REG_TX;
   const int ty0 = p.band_y0 / REG_TY, ty1 = (p.band_y1 + REG_TY - 1) / REG_TY;  // tile rows that intersect the band
   if (ty1 <= ty0) return;

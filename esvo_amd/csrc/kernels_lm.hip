@@ -210,8 +210,10 @@ __device__ inline void interp_column(const uint8_t* __restrict__ img, int W, int
   for (int y = 0; y < RL; ++y) tau[y] = q3 * R[y] + q4 * R[y + 1];
 }
 
-// DepthProblem::operator(), Tdist norm.  fv[y] = residual of patch element (y, c); lane 15 -> 0.
-template <bool WIDE>
+// DepthProblem::operator().  fv[y] = residual of patch element (y, c); lane 15 -> 0.
+// L2 (LSnorm "l2", DepthProblem.cpp:43-45,67-75,143-147; no shipped configuration sets it): the plain temporal residual
+// tau_L - tau_R, 255 where warping or interpolation fails; no weights, no scale iteration.
+template <bool WIDE, bool L2>
 __device__ void lm_eval(const DevParams& p, const LmProblem& pr, double x, double* fv) {
   constexpr int RL = Lay<WIDE>::RL;
   // element (y, c) of the patch exists: column 15 only feeds its neighbour; row group 3 of the wide layout owns one row
@@ -240,6 +242,11 @@ __device__ void lm_eval(const DevParams& p, const LmProblem& pr, double x, doubl
   double a1 = 0, a2 = 0, a3 = 0, a4 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0;
   if (okw) okw = interp_geom(p, x1u, x1v, ulx1, uly1, a1, a2, a3, a4);
   if (okw) okw = interp_geom(p, x2u, x2v, ulx2, uly2, b1, b2, b3, b4);
+  if (L2 && !okw) {
+#pragma unroll
+    for (int y = 0; y < RL; ++y) fv[y] = el[y] ? 255.0 : 0.0;
+    return;
+  }
   if (!okw) {  // failure fill, DepthProblem.cpp:49-56 / :149-155
     const double residual = 255;
     const double q = residual / p.td_scale;
@@ -252,6 +259,11 @@ __device__ void lm_eval(const DevParams& p, const LmProblem& pr, double x, doubl
   double tau1[RL], tau2[RL], r[RL], r2[RL];
   interp_column<WIDE>(pr.tsL, p.W, ulx1, uly1, pr.c, pr.rg, a1, a2, a3, a4, tau1);
   interp_column<WIDE>(pr.tsR, p.W, ulx2, uly2, pr.c, pr.rg, b1, b2, b3, b4, tau2);
+  if constexpr (L2) {
+#pragma unroll
+    for (int y = 0; y < RL; ++y) fv[y] = el[y] ? (tau1[y] - tau2[y]) : 0.0;
+    return;
+  }
   int knz = 0;
   double minabs = 1e300, r2max = 0;
   double r2n[RL];  // r^2 (nu + 1): the numerators of the t-scale update
@@ -435,7 +447,7 @@ __device__ inline double lm_lmpar2(double r, double diag, double qtf, double del
 #ifndef LM_WIDE_MAX
 #define LM_WIDE_MAX 40000u  // launches bounded by this many matches (= events handed to block matching) use the wide layout
 #endif
-template <bool WIDE>
+template <bool WIDE, bool L2 = false>
 __global__ void __launch_bounds__(LM_BLOCK, WIDE ? LM_WIDE_WAVES : LM_WAVES) lm_refine_kernel(LmArgs a, DevParams p, u32* n_solved) {
   constexpr int RL = Lay<WIDE>::RL;
 #ifdef LM_T_IN_LDS
@@ -520,7 +532,7 @@ __global__ void __launch_bounds__(LM_BLOCK, WIDE ? LM_WIDE_WAVES : LM_WAVES) lm_
       xe = xnew;
       need_step = false;
     }
-    lm_eval<WIDE>(p, pr, xe, out);
+    lm_eval<WIDE, L2>(p, pr, xe, out);
     int status = -1;
     bool outer_tail = false;
     if (phase == 0) {  // minimizeInit
@@ -631,7 +643,13 @@ __global__ void __launch_bounds__(LM_BLOCK, WIDE ? LM_WIDE_WAVES : LM_WAVES) lm_
   if (solved) {
     atomicAdd(n_solved, 1u);
     const double invJtJ = (r != 0.) ? (1. / r) * (1. / r) : 0.;  // internal::covar, n == 1
-    const double variance = p.td_stdvar2 * invJtJ;               // :210
+    double variance;
+    if constexpr (L2) {  // :200-206: cov = |f|^2 / (values - inputs) * (J^T J)^-1; DepthPoint::update on a new point bounds it
+      variance = fnorm * fnorm / (double)(N - 1) * invJtJ;
+      if (variance < 1e-6) variance = 1e-6;
+    } else {
+      variance = p.td_stdvar2 * invJtJ;                          // :210
+    }
     const double residual = fnorm * fnorm;                       // :212
     DevPoint o;
     o.row = (u32)(size_t)floor(pr.cy);  // :116
@@ -640,8 +658,8 @@ __global__ void __launch_bounds__(LM_BLOCK, WIDE ? LM_WIDE_WAVES : LM_WAVES) lm_
     o.x[1] = pr.cy;
     cam2World(p.camL, pr.cx, pr.cy, x, o.p_cam);                 // :119
     o.inv_depth = x;                                             // update_studentT, new-point branch
-    o.scale2 = variance * (p.td_nu - 2) / p.td_nu;               // :125
-    o.nu = p.td_nu;
+    o.scale2 = L2 ? 0.0 : variance * (p.td_nu - 2) / p.td_nu;    // :125 (l2: the Gaussian update leaves scaleSquared_ / nu_
+    o.nu = L2 ? 0.0 : p.td_nu;                                   //  as constructed -- zero here and in the oracle, Appendix A-8)
     o.variance = variance;
     o.residual = residual;
     o.age = 0;
@@ -664,14 +682,18 @@ extern "C" void esvo_debug_lm_slots(unsigned int* out, int clear) {  // out[3][1
 #endif
 void launch_lm_refine(const LmArgs& a, const DevParams& p, u32* n_solved, hipStream_t s) {
   if (a.max_matches == 0) return;
-  // the match count lives on the device; the layout is chosen by the launch's bound (the events handed to block matching)
-  if (a.max_matches <= LM_WIDE_MAX && LM_BLOCK == 64) {
-    hipLaunchKernelGGL(lm_refine_kernel<true>, dim3(a.max_matches), dim3(64), 0, s, a, p, n_solved);
-    return;
-  }
   const u32 groups_per_block = LM_BLOCK / 16;
   const u32 blocks = (a.max_matches + groups_per_block - 1) / groups_per_block;
-  hipLaunchKernelGGL(lm_refine_kernel<false>, dim3(blocks), dim3(LM_BLOCK), 0, s, a, p, n_solved);
+  if (p.ls_norm == ESVO_LSNORM_L2) {  // no shipped configuration: the narrow layout only
+    hipLaunchKernelGGL((lm_refine_kernel<false, true>), dim3(blocks), dim3(LM_BLOCK), 0, s, a, p, n_solved);
+    return;
+  }
+  // the match count lives on the device; the layout is chosen by the launch's bound (the events handed to block matching)
+  if (a.max_matches <= LM_WIDE_MAX && LM_BLOCK == 64) {
+    hipLaunchKernelGGL((lm_refine_kernel<true, false>), dim3(a.max_matches), dim3(64), 0, s, a, p, n_solved);
+    return;
+  }
+  hipLaunchKernelGGL((lm_refine_kernel<false, false>), dim3(blocks), dim3(LM_BLOCK), 0, s, a, p, n_solved);
 }
 
 // stable compaction of the solver slots into a frame buffer

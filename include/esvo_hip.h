@@ -61,7 +61,7 @@ typedef struct esvo_context* esvo_handle;
 
 enum { ESVO_CAM_LEFT = 0, ESVO_CAM_RIGHT = 1 };
 enum { ESVO_FUSION_CONST_FRAMES = 0, ESVO_FUSION_CONST_POINTS = 1 };
-enum { ESVO_LSNORM_TDIST = 0, ESVO_LSNORM_L2 = 1 /* unsupported: no shipped config uses it */ };
+enum { ESVO_LSNORM_TDIST = 0, ESVO_LSNORM_L2 = 1 /* Gaussian model; no shipped config uses it */ };
 
 /* Layout-identical to the in-memory dvs_msgs::Event (uint16 x, uint16 y,
  * ros::Time{uint32 sec, uint32 nsec}, bool polarity; sizeof == 16), so ROS glue
@@ -319,6 +319,12 @@ int esvo_map_init_sgm(esvo_handle h, const uint8_t* ts_left, const uint8_t* ts_r
  * (esvo_Mapping.cpp:261-431) on the staged left events and the current observation. */
 int esvo_map_tick(esvo_handle h, uint64_t t_ns, const uint64_t* pose_t_ns, const double* pose_T,
                   size_t m);
+/* Replaces esvo_MVStereo::MappingAtTime in MVStereoMode 1, PURE_BLOCK_MATCHING (esvo_MVStereo.cpp:383-432): the same event
+ * selection (+ Denoising) and block matching, then vEMP2vDP (:1072-1094: one Gaussian DepthPoint per match, variance at the
+ * 1e-6 bound, residual = ZNCC cost, age = age_vis_threshold), a window of max_fusion_frames frames and
+ * DepthFusion::naive_propagation (DepthFusion.cpp:234-288) of every frame, newest first, into a new DepthFrame.  The map is
+ * read with the usual output calls; nothing is culled, cleaned or regularised.  Synchronous. */
+int esvo_map_tick_bm_only(esvo_handle h, uint64_t t_ns, const uint64_t* pose_t_ns, const double* pose_T, size_t m);
 /* One call for a node that hosts the Time Surfaces and the mapper on the same handle: esvo_ts_render of both cameras at
  * t_ns (device-resident, no download), esvo_map_set_observation on them with the pose T_world_cam, esvo_map_tick.  Same
  * results as the four calls; a reference-faithful tick is short enough for their host overhead to show. */

@@ -200,3 +200,123 @@ def test_gpu_bm_failure_counters(name):
         # (EventBM.cpp:154-156), which no counter records
         assert 0 <= searched - len(mt) - s.last_bm_coarse_fail <= 1 and s.last_bm_fine_fail == 0, (k, s.last_bm_coarse_fail, searched, len(mt))
     dev.close()
+
+
+@pytest.mark.parametrize("name", ["upenn", "hkust"])
+def test_gpu_gaussian_model_l2(name):
+    """LSnorm: l2 on the device, stage by stage: the refinement (plain residual, covariance |f|^2 / (m - n) (J^T J)^-1,
+    Gaussian DepthPoint) bit for bit against the CPU oracle and to the LM tolerance against the reference's classes
+    (tests/golden/ref_l2.npz); variance propagation, chiSquareTest fusion, Gaussian update, clean and the inverse-variance
+    regulariser: every map element identical to the REFERENCE's (the digest of the fixture) when fed its points."""
+    import copy
+    import os
+    import sys
+    from esvo_amd import lib
+    from esvo_amd.abi import LSNORM_L2
+    from oracle import oracle as O
+    from test_ref_pin import GOLDEN
+    sys.path.insert(0, GOLDEN)
+    import make_ref_fixtures as mk
+    n = np.load(os.path.join(GOLDEN, "ref_l2.npz"))
+    g, sc, ticks = load_fixture(name)
+    p = copy.copy(sc.params)
+    p.ls_norm = LSNORM_L2
+    dev = lib.Esvo(p, sc.rig, device=0)
+    m = O.OracleMapper(p, sc.rig)
+    m.set_mode(True, True)
+    for k, tk in enumerate(ticks):
+        dev.set_observation(tk["t"], tk["raw"][0], tk["raw"][1], tk["T"])
+        dev.set_poses(tk["stamps"], tk["poses"])
+        m.set_observation(tk["t"], tk["raw"][0], tk["raw"][1], tk["T"])
+        m.set_poses(tk["stamps"], tk["poses"])
+        pts = dev.refine(g[f"matches{k}"], cull=True)
+        opts = m.refine(g[f"matches{k}"], cull=True)
+        assert len(pts) == len(opts) and len(pts) > 0
+        for f in ("row", "col", "pose_idx", "age", "x", "inv_depth", "variance", "residual", "scale2", "nu", "p_cam"):
+            assert np.array_equal(pts[f], opts[f]), (k, f)
+        ref_pts = n[f"{name}_points{k}"].copy()
+        for f in ("nu", "scale2"):   # never set on the Gaussian path (uninitialised in the reference, zero here: Appendix A-8)
+            ref_pts[f] = 0
+        check_points(pts, ref_pts, rho_rtol=1e-5)
+        dev.push_frame(ref_pts, tk["poses"])
+        assert dev.fuse() == int(n[f"{name}_nf{k}"])
+        mp = dev.get_map()
+        assert len(mp) == int(n[f"{name}_map_n{k}"])
+        assert np.array_equal(mk.l2_digest(mp), n[f"{name}_map_sha{k}"]), k
+    for f in mk.L2_MAP_FIELDS:
+        assert np.array_equal(mp[f], n[f"{name}_last_{f}"]), f
+    dev.close()
+
+
+@pytest.mark.parametrize("name", ["upenn", "hkust"])
+def test_gpu_l2_fused_tick_equals_oracle(name):
+    """the same model through the fused tick (lazy pipeline, device-resident frames) against the oracle's ticks"""
+    import copy
+    from esvo_amd import lib
+    from esvo_amd.abi import LSNORM_L2
+    from oracle import oracle as O
+    g, sc, ticks = load_fixture(name)
+    p = copy.copy(sc.params)
+    p.ls_norm = LSNORM_L2
+    st = sc.stream()
+    dev = lib.Esvo(p, sc.rig, device=0)
+    dev.ts_push_events(0, st.ev_left)
+    m = O.OracleMapper(p, sc.rig)
+    m.set_mode(True, True)
+    for k, tk in enumerate(ticks):
+        dev.set_observation(tk["t"], tk["raw"][0], tk["raw"][1], tk["T"])
+        dev.tick(tk["t"], tk["stamps"], tk["poses"])
+        m.set_observation(tk["t"], tk["raw"][0], tk["raw"][1], tk["T"])
+        m.set_poses(tk["stamps"], tk["poses"])
+        m.tick(tk["ev"])
+        a, b = dev.get_map(), m.get_map()
+        assert len(a) == len(b) and len(a) > 0, (k, len(a), len(b))
+        for f in ("row", "col", "age", "inv_depth", "variance", "residual", "x", "p_cam", "scale2", "nu"):
+            assert np.array_equal(a[f], b[f]), (k, f)
+    dev.close()
+
+
+@pytest.mark.parametrize("name", ["upenn", "rpg"])
+def test_gpu_block_matching_only_mode(name):
+    """esvo_MVStereo's PURE_BLOCK_MATCHING mode (esvo_map_tick_bm_only: block matching, vEMP2vDP, naive propagation of a
+    window of maxNumFusionFrames frames) against the reference's esvo_MVStereo NODE object in that mode (tests/golden/
+    ref_node.npz: window, map size, exact fields by digest, inverse depth / x / variance to 1e-12 -- the reference inverts a
+    4x4 per cam2World call) and bit for bit against the CPU oracle."""
+    import os
+    import sys
+    from esvo_amd import lib
+    from oracle import oracle as O
+    from test_ref_pin import GOLDEN
+    sys.path.insert(0, GOLDEN)
+    import make_ref_fixtures as mk
+    n = np.load(os.path.join(GOLDEN, "ref_node.npz"))
+    g, sc, ticks = load_fixture(name)
+    st = sc.stream()
+    dev = lib.Esvo(sc.params, sc.rig, device=0)
+    dev.ts_push_events(0, st.ev_left)
+    m = O.OracleMapper(sc.params, sc.rig)
+    m.set_mode(True, True)                    # ZNCC cost from exact integer moments, as the device forms it
+    lit = O.OracleMapper(sc.params, sc.rig)   # literal mode (normalised f64 patches): the one the node fixture pins bit for bit
+    for k, tk in enumerate(ticks):
+        dev.set_observation(tk["t"], tk["raw"][0], tk["raw"][1], tk["T"])
+        dev.tick_bm_only(tk["t"], tk["stamps"], tk["poses"])
+        for o in (m, lit):
+            o.set_observation(tk["t"], tk["raw"][0], tk["raw"][1], tk["T"])
+            o.set_poses(tk["stamps"], tk["poses"])
+            o.tick_bm_only(tk["ev"])
+        s = dev.stats()
+        assert s.last_matches == len(g[f"matches{k}"]) == int(n[f"mvs1_{name}_window{k}"][-1])
+        assert s.last_window_frames == len(n[f"mvs1_{name}_window{k}"])
+        mp, om = dev.get_map(), m.get_map()
+        assert len(mp) == int(n[f"mvs1_{name}_map_n{k}"]) == len(om)
+        for f in ("row", "col", "age", "inv_depth", "variance", "residual", "x", "p_cam"):
+            assert np.array_equal(mp[f], om[f]), (k, f)
+        lm_ = lit.get_map()
+        assert np.array_equal(mk.fields_digest(lm_, mk.BM_ONLY_FIELDS), n[f"mvs1_{name}_map_sha{k}"]), k   # the node's map
+        for f in ("row", "col", "age"):
+            assert np.array_equal(mp[f], lm_[f]), (k, f)
+        assert np.abs(mp["residual"] - lm_["residual"]).max() <= 1e-12     # the two ways of forming the ZNCC cost
+        assert np.allclose(mp["inv_depth"], n[f"mvs1_{name}_inv_depth{k}"], rtol=1e-12, atol=0)
+    assert np.allclose(mp["x"], n[f"mvs1_{name}_last_x"], rtol=1e-12, atol=1e-12)
+    assert np.allclose(mp["variance"], n[f"mvs1_{name}_last_variance"], rtol=1e-12, atol=0)
+    dev.close()
