@@ -130,21 +130,40 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
   {
     int prio_lo = 0, prio_hi = 0;  // numerically lower = higher priority
     CK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-    // The front stage is the critical path of the two-stream pipeline: its stream gets the high priority, the
-    // (latency-bound, gap-filling) back stage the low one: -2 % per tick; the reverse costs +6 %.  ESVO_STREAM_PRIO
-    // = 0 (no priorities) / 2 (reversed) exist for that A/B.
+    // Three stages on three streams share the chip.  The LM kernel is the bulk of the vector-ALU work and tolerates waiting
+    // (two dense waves per SIMD); the matching stage and the fusion stage are short, latency-bound kernels that run one wave
+    // per SIMD beside it.  They get the HIGH priority and the LM stream the LOWEST: whenever one of their waves is ready it
+    // issues, the LM waves fill every other slot.  Measured on the bench workload with the round-3 LM kernel (fewer stalls,
+    // so it no longer leaves slots by itself): 1.40 ms per tick against 1.70 ms with the LM stream high and the fusion
+    // stream low (round 2's setting, then worth -2 %).  ESVO_STREAM_PRIO = 0 / 2 and ESVO_PRIOS exist for that A/B.
     const char* pe = std::getenv("ESVO_STREAM_PRIO");
     const int mode = pe ? std::atoi(pe) : 1;
-    CK(hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, mode == 1 ? prio_hi : (mode == 2 ? prio_lo : 0)));
+    int pf = mode == 1 ? prio_hi : (mode == 2 ? prio_lo : 0), pb = mode == 1 ? prio_hi : (mode == 2 ? prio_lo : 0);
+    // ESVO_PRIOS="front,lm,back" (A/B only): explicit priorities, 0 = the device's highest, larger = lower
+    int pl_explicit = 0;
+    bool have_explicit = false;
+    if (const char* e4 = std::getenv("ESVO_PRIOS")) {
+      int f = 0, l = 0, b = 0;
+      if (std::sscanf(e4, "%d,%d,%d", &f, &l, &b) == 3) {
+        auto clampp = [&](int v) { v = prio_hi + v; return v > prio_lo ? prio_lo : v; };
+        pf = clampp(f); pb = clampp(b); pl_explicit = clampp(l);
+        have_explicit = true;
+      }
+    }
+    h->prio_note[0] = prio_lo; h->prio_note[1] = prio_hi;
+    CK(hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, pf));
     h->own_stream = true;
-    CK(hipStreamCreateWithPriority(&h->stream_b, hipStreamNonBlocking, mode == 1 ? prio_lo : (mode == 2 ? prio_hi : 0)));
+    CK(hipStreamCreateWithPriority(&h->stream_b, hipStreamNonBlocking, pb));
+    if (have_explicit) h->prio_note[2] = pl_explicit; else h->prio_note[2] = 12345;
   }
   {
     int lo = 0, hi = 0;
     CK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    int pl = hi;
+    int pl = lo;  // see above: the LM stream yields to the two latency-bound stages
     if (const char* e3 = std::getenv("ESVO_PRIO_LM")) pl = std::atoi(e3) == 0 ? hi : (std::atoi(e3) == 2 ? lo : 0);  // A/B only
-    CK(hipStreamCreateWithPriority(&h->stream_l, hipStreamNonBlocking, pl));  // the LM stage is the critical path
+    if (h->prio_note[2] != 12345) pl = h->prio_note[2];
+    if (std::getenv("ESVO_PRIO_PRINT")) fprintf(stderr, "[esvo] stream priority range: lowest %d .. highest %d; LM %d\n", lo, hi, pl);
+    CK(hipStreamCreateWithPriority(&h->stream_l, hipStreamNonBlocking, pl));
     const char* e = std::getenv("ESVO_LM_STREAM");
     h->lm_split = !(e && std::atoi(e) == 0);
   }

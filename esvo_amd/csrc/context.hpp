@@ -61,6 +61,7 @@ struct esvo_context {
   u32* d_scan_tmp_l = nullptr;    // scan scratch of the LM stage
   hipStream_t stream_i = nullptr;  // event ingest (H2D into the ring): staging new events never waits for a running tick
   bool own_stream = false;
+  int prio_note[3] = {0, 0, 12345};  // stream priority range of the device / explicit LM priority (ESVO_PRIOS, A/B only)
   int par = 0;                    // parity of the tick being assembled
   bool back_pending[2] = {false, false};  // back-stage timings / counters of that parity not collected yet
   u32 back_frames[2] = {0, 0};

@@ -160,13 +160,24 @@ __device__ inline double in_vgpr(double x) {
 
 struct LmProblem {
   double cx, cy;           // rectified left coordinate of the event
+  double ray[3];           // Kinv [cx cy 1]^T: the part of cam2World that does not depend on the inverse depth
 #ifdef LM_T_IN_LDS
   const double* T;         // T_left_virtual (3x4) in LDS (A/B switch: 159 VGPRs -> 3 waves/SIMD; slower tick)
 #else
   double T[12];            // T_left_virtual (3x4)
 #endif
-  const uint8_t* tsL;
-  const uint8_t* tsR;
+  // The two Time Surfaces as buffer resources: a patch byte is  buffer_load_ubyte v, v_off, s[rsrc], s_row offen  with the
+  // per-lane offset of the block's first row in v_off and the row stride in a scalar -- no per-row 64-bit address
+  // arithmetic on the vector ALU, and an offset outside the image reads 0 instead of faulting, so the loads can be issued
+  // before the bounds predicate is resolved (no branch ladder around them).
+  __amdgpu_buffer_rsrc_t tsL;
+  __amdgpu_buffer_rsrc_t tsR;
+  // The 27 camera constants an evaluation reads (P_left, P_right, Kinv_t of the left camera) from LDS instead of the
+  // kernel-argument SGPRs: with the two projection matrices, the image descriptors and the driver's state the scalar
+  // register file overflowed and every evaluation re-fetched ~60 spilled values with v_readlane (vector-ALU issue slots).
+  // An LDS read costs none; the narrow layout may keep the values in VGPRs across the loop (it has the room), the wide one
+  // re-reads them per evaluation (128-VGPR budget).
+  const double* cam;       // [0..11] P_left, [12..23] P_right, [24..26] Kinv_t (left)
   int c;                   // patch column of the lane
   int rg;                  // row group of the lane (wide layout; 0 in the narrow one)
 #ifdef LM_STATS
@@ -174,47 +185,50 @@ struct LmProblem {
 #endif
 };
 
-// bilinear 15x7 patch column for this lane; returns false like patchInterpolation
-__device__ inline bool interp_geom(const DevParams& p, double lx, double ly, int& ulx, int& uly, double& q1, double& q2,
-                                   double& q3, double& q4) {
+// patchInterpolation's geometry (DepthProblem.cpp:193-230) as straight-line code: the block's upper-left corner, the four
+// bilinear weights and the predicate "the patch lies inside the image".  Nothing here is guarded: for a location that fails
+// the predicate (or is not finite) the integers are garbage, which only ever feeds bounds-checked buffer loads.
+struct PatchGeom { int ulx, uly; double q1, q2, q3, q4; bool ok; };
+__device__ inline PatchGeom interp_geom(const DevParams& p, double lx, double ly) {
+  PatchGeom g;
   const int hx = (LM_COLS - 1) / 2, hy = (LM_ROWS - 1) / 2;
   const double fx = floor(lx), fy = floor(ly);
-  ulx = (int)fx - hx;
-  uly = (int)fy - hy;
-  const int drx = (int)fx + hx, dry = (int)fy + hy;
-  if (ulx < 0 || uly < 0) return false;
-  if (drx >= p.W || dry >= p.H) return false;
-  const int l0 = (int)fy, l1 = (int)fx;
-  const int u0 = l0 + 1, u1 = l1 + 1;
-  q1 = (double)u1 - lx;
-  q2 = lx - (double)l1;
-  q3 = (double)u0 - ly;
-  q4 = ly - (double)l0;
-  if (uly + LM_ROWS >= p.H || ulx + LM_COLS >= p.W) return false;
-  return true;
+  const int l1 = (int)fx, l0 = (int)fy;
+  g.ulx = l1 - hx;
+  g.uly = l0 - hy;
+  const int drx = l1 + hx, dry = l0 + hy;
+  g.ok = (int)(g.ulx >= 0) & (int)(g.uly >= 0) & (int)(drx < p.W) & (int)(dry < p.H) & (int)(g.uly + LM_ROWS < p.H) & (int)(g.ulx + LM_COLS < p.W);
+  g.q1 = (double)(l1 + 1) - lx;
+  g.q2 = lx - (double)l1;
+  g.q3 = (double)(l0 + 1) - ly;
+  g.q4 = ly - (double)l0;
+  return g;
 }
 template <bool WIDE>
-__device__ inline void interp_column(const uint8_t* __restrict__ img, int W, int ulx, int uly, int c, int rg, double q1, double q2,
-                                     double q3, double q4, double* tau) {
+__device__ inline void interp_column(__amdgpu_buffer_rsrc_t img, int W, const PatchGeom& g, int c, int rg, double* tau) {
   constexpr int RL = Lay<WIDE>::RL;
+  // first source row of the lane (the wide layout's row group rg owns rows 2 rg, 2 rg + 1 and reads one more; group 3 owns
+  // row 6 only: its third source row lies below the block and is not used -- wherever it falls, the load is bounds-checked)
+  const int voff = (g.uly + (WIDE ? 2 * rg : 0)) * W + g.ulx + c;
   double R[RL + 1];
 #pragma unroll
   for (int y = 0; y <= RL; ++y) {
-    int row = (WIDE ? 2 * rg : 0) + y;
-    if (WIDE) row = row > LM_ROWS ? LM_ROWS : row;  // group 3 owns row 6 only: its third source row is not used
-    const int s0 = img[(uly + row) * W + ulx + c];
+    const int s0 = (int)__builtin_amdgcn_raw_buffer_load_b8(img, voff, y * W, 0);
     const int s1 = dpp_i32<DPP_SHL1>(s0);  // column c+1 from the neighbour lane
-    R[y] = q1 * (double)s0 + q2 * (double)s1;
+    R[y] = g.q1 * (double)s0 + g.q2 * (double)s1;
   }
 #pragma unroll
-  for (int y = 0; y < RL; ++y) tau[y] = q3 * R[y] + q4 * R[y + 1];
+  for (int y = 0; y < RL; ++y) tau[y] = g.q3 * R[y] + g.q4 * R[y + 1];
 }
 
 // DepthProblem::operator().  fv[y] = residual of patch element (y, c); lane 15 -> 0.
 // L2 (LSnorm "l2", DepthProblem.cpp:43-45,67-75,143-147; no shipped configuration sets it): the plain temporal residual
 // tau_L - tau_R, 255 where warping or interpolation fails; no weights, no scale iteration.
+// Returns whether the evaluation was "tight" (group-uniform): every non-zero residual of the match has 2^-50 <= |r| and the
+// final scale lies in [2^-100, 2^100], so every non-zero f = sqrt(w) r has 2^-150 <= |f| < 2^11 -- what lets the caller
+// divide differences of two such evaluations through a shared reciprocal (fdiv.hpp's window) without testing them.
 template <bool WIDE, bool L2>
-__device__ void lm_eval(const DevParams& p, const LmProblem& pr, double x, double* fv) {
+__device__ bool lm_eval(const DevParams& p, const LmProblem& pr, double x, double* fv) {
   constexpr int RL = Lay<WIDE>::RL;
   // element (y, c) of the patch exists: column 15 only feeds its neighbour; row group 3 of the wide layout owns one row
   bool el[RL];
@@ -224,45 +238,57 @@ __device__ void lm_eval(const DevParams& p, const LmProblem& pr, double x, doubl
   LM_COUNT(0, pr.c == 0);                                   // evaluations, per group
   LM_SLOT(0, pr.dbg_slot, pr.c == 0, 1u);
   LM_COUNT(1, __lane_id() == __ffsll(__ballot(1)) - 1);     // evaluations, per wave
+  if constexpr (WIDE) asm volatile("" ::: "memory");  // the LDS reads below stay inside the loop (see LmProblem::cam)
   double prv[3], pl[3];
-  cam2World(p.camL, pr.cx, pr.cy, x, prv);
+  {  // cam2World(p.camL, cx, cy, x): z * (Kinv [cx cy 1]^T) - Kinv_t with the ray computed once per match
+    const double z = 1.0 / x;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) prv[r] = z * pr.ray[r] - pr.cam[24 + r];
+  }
 #pragma unroll
   for (int r = 0; r < 3; ++r)
     pl[r] = ((pr.T[r * 4 + 0] * prv[0] + pr.T[r * 4 + 1] * prv[1]) + pr.T[r * 4 + 2] * prv[2]) + pr.T[r * 4 + 3];
   double x1u, x1v, x2u, x2v;
-  world2Cam(p.camL, pl, x1u, x1v);
-  world2Cam(p.camR, pl, x2u, x2v);
-  const int hx = (LM_COLS - 1) / 2, hy = (LM_ROWS - 1) / 2;
-  bool okw = isfinite(x1u) && isfinite(x1v) && isfinite(x2u) && isfinite(x2v);
-  if (okw) {  // warping bounds, DepthProblem.cpp:186-189
-    if (x1u < hx || x1u > p.W - hx || x1v < hy || x1v > p.H - hy) okw = false;
-    if (x2u < hx || x2u > p.W - hx || x2v < hy || x2v > p.H - hy) okw = false;
-  }
-  int ulx1 = 0, uly1 = 0, ulx2 = 0, uly2 = 0;
-  double a1 = 0, a2 = 0, a3 = 0, a4 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0;
-  if (okw) okw = interp_geom(p, x1u, x1v, ulx1, uly1, a1, a2, a3, a4);
-  if (okw) okw = interp_geom(p, x2u, x2v, ulx2, uly2, b1, b2, b3, b4);
-  if (L2 && !okw) {
+  {  // world2Cam for both cameras (common.hpp), the matrices from LDS
+    double hL[3], hR[3];
 #pragma unroll
-    for (int y = 0; y < RL; ++y) fv[y] = el[y] ? 255.0 : 0.0;
-    return;
+    for (int r = 0; r < 3; ++r) {
+      const double* PL = pr.cam + r * 4;
+      const double* PR = pr.cam + 12 + r * 4;
+      hL[r] = ((PL[0] * pl[0] + PL[1] * pl[1]) + PL[2] * pl[2]) + PL[3];
+      hR[r] = ((PR[0] * pl[0] + PR[1] * pl[1]) + PR[2] * pl[2]) + PR[3];
+    }
+    x1u = hL[0] / hL[2];
+    x1v = hL[1] / hL[2];
+    x2u = hR[0] / hR[2];
+    x2v = hR[1] / hR[2];
   }
-  if (!okw) {  // failure fill, DepthProblem.cpp:49-56 / :149-155
-    const double residual = 255;
-    const double q = residual / p.td_scale;
-    const double weight = (nu + 1) / (nu + q * q);
-    const double f = sqrt(weight) * residual;
+  const int hx = (LM_COLS - 1) / 2, hy = (LM_ROWS - 1) / 2;
+  // warping bounds (DepthProblem.cpp:186-189) and patchInterpolation's (:205-230), as ONE predicate in straight-line code:
+  // every comparison is evaluated, nothing is short-circuited into a branch ladder (a NaN coordinate fails `inside`)
+  const double wlo = (double)hx, whi = (double)(p.W - hx), vlo = (double)hy, vhi = (double)(p.H - hy);
+  const bool inside = (int)(x1u >= wlo) & (int)(x1u <= whi) & (int)(x1v >= vlo) & (int)(x1v <= vhi) &
+                      (int)(x2u >= wlo) & (int)(x2u <= whi) & (int)(x2v >= vlo) & (int)(x2v <= vhi);
+  const PatchGeom g1 = interp_geom(p, x1u, x1v), g2 = interp_geom(p, x2u, x2v);
+  const bool okw = inside & g1.ok & g2.ok;
+  double tau1[RL], tau2[RL], r[RL], r2[RL];
+  interp_column<WIDE>(pr.tsL, p.W, g1, pr.c, pr.rg, tau1);
+  interp_column<WIDE>(pr.tsR, p.W, g2, pr.c, pr.rg, tau2);
+  if (!okw) {  // failure fill, DepthProblem.cpp:49-56 / :149-155 (l2: :67-75, :143-147)
+    double f = 255;
+    if constexpr (!L2) {
+      const double q = f / p.td_scale;
+      const double weight = (nu + 1) / (nu + q * q);
+      f = sqrt(weight) * f;
+    }
 #pragma unroll
     for (int y = 0; y < RL; ++y) fv[y] = el[y] ? f : 0.0;
-    return;
+    return false;
   }
-  double tau1[RL], tau2[RL], r[RL], r2[RL];
-  interp_column<WIDE>(pr.tsL, p.W, ulx1, uly1, pr.c, pr.rg, a1, a2, a3, a4, tau1);
-  interp_column<WIDE>(pr.tsR, p.W, ulx2, uly2, pr.c, pr.rg, b1, b2, b3, b4, tau2);
   if constexpr (L2) {
 #pragma unroll
     for (int y = 0; y < RL; ++y) fv[y] = el[y] ? (tau1[y] - tau2[y]) : 0.0;
-    return;
+    return false;
   }
   int knz = 0;
   double minabs = 1e300, r2max = 0;
@@ -297,6 +323,8 @@ __device__ void lm_eval(const DevParams& p, const LmProblem& pr, double x, doubl
     lane_ok = r2_ok && fdiv_ok(nu) && nu > 0 && fdiv_ok(r2max * (nu + 1));
   }
   const int N = LM_ROWS * LM_COLS;
+  // "tight" evaluation (all but a handful): nu and every non-zero r^2 of the GROUP lie in [2^-100, 2^98].
+  const bool tight = match_sum_int<WIDE>((r2_tight && nu_mid) ? 0 : 1) == 0;
 #ifdef LM_EXPERIMENT_NOLOOP
   if (true) {
 #else
@@ -310,11 +338,10 @@ __device__ void lm_eval(const DevParams& p, const LmProblem& pr, double x, doubl
     // the weights' own divisors nu + r^2/s1 lie in [nu, 2^333) by the exponent test on the lane's largest r^2.
     double s1 = scale2_0;
     const Recip rN = make_recip((double)N);
-    // "tight" evaluation (all but a handful): nu and every non-zero r^2 of the GROUP lie in [2^-100, 2^98].  Then, while
-    // s1 stays in [2^-100, 2^100], every operand of the iteration is inside fdiv.hpp's window by construction
-    // (r^2/s1 <= 2^198, t >= 2^-299, 2^-299 <= sum <= 2^110, |s2 - s1| is 0 or >= ulp(2^-100)), so the iteration runs
-    // without a single per-operand range test or branch: one exponent test on s1 decides, uniformly for the group.
-    const bool tight = match_sum_int<WIDE>((r2_tight && nu_mid) ? 0 : 1) == 0;
+    // In a tight evaluation, while s1 stays in [2^-100, 2^100], every operand of the iteration is inside fdiv.hpp's
+    // window by construction (r^2/s1 <= 2^198, t >= 2^-299, 2^-299 <= sum <= 2^110, |s2 - s1| is 0 or >= ulp(2^-100)), so
+    // the iteration runs without a single per-operand range test or branch: one exponent test on s1 decides, uniformly
+    // for the group.
     bool done = false;
 #ifndef LM_PLAIN_DIV
     if (tight) {
@@ -372,6 +399,26 @@ __device__ void lm_eval(const DevParams& p, const LmProblem& pr, double x, doubl
       s1 = s2;
     }
   }
+  // The weights sqrt((nu + 1) / (nu + r^2 / s2)) (DepthProblem.cpp:127-135).  Tight evaluation with s2 in [2^-100, 2^100]
+  // (a group-uniform test; s2 is the group's): r^2/s2 <= 2^198, so every divisor nu + r^2/s2 lies in [2^-100, 2^199] and
+  // every weight in [2^-200, (nu+1)/nu] -- fdiv.hpp's window and sqrt_moderate's range -- and the seven rows run as a
+  // straight line of shared-reciprocal quotients without a per-row test or select.
+#ifndef LM_PLAIN_DIV
+  if (tight && (unsigned)(((__double2hiint(s2) >> 20) & 0xfff) - 923) <= 200u) {
+    Recip rs2;
+    rs2.b = s2;
+    rs2.y = recip_refined(s2);
+    const double nu1 = nu + 1;
+#pragma unroll
+    for (int y = 0; y < RL; ++y) {
+      Recip rd;
+      rd.b = nu + div_fast(r2[y], rs2);
+      rd.y = recip_refined(rd.b);
+      fv[y] = sqrt_moderate(div_fast(nu1, rd)) * r[y];
+    }
+    return true;
+  }
+#endif
   const Recip rs2 = make_recip(s2);
 #ifdef LM_PLAIN_DIV
   const bool fast2 = false;
@@ -384,6 +431,7 @@ __device__ void lm_eval(const DevParams& p, const LmProblem& pr, double x, doubl
     fv[y] = fast2 ? sqrt_moderate(div_fast(nu + 1, make_recip(nu + div_fast(r2[y], rs2)))) * r[y]
                   : sqrt((nu + 1) / (nu + r2[y] / s2)) * r[y];
   }
+  return false;
 }
 
 // internal::lmpar2 for n == 1 (Appendix B.1)
@@ -453,6 +501,12 @@ __global__ void __launch_bounds__(LM_BLOCK, WIDE ? LM_WIDE_WAVES : LM_WAVES) lm_
 #ifdef LM_T_IN_LDS
   __shared__ double lds_T[LM_BLOCK / 16][12];
 #endif
+  __shared__ double lds_cam[28];
+  if (threadIdx.x < 27) {
+    const int i = threadIdx.x;
+    lds_cam[i] = i < 12 ? p.camL.P[i] : (i < 24 ? p.camR.P[i - 12] : p.camL.Kinv_t[i - 24]);
+  }
+  __syncthreads();
   const u32 s = WIDE ? blockIdx.x : (blockIdx.x * LM_BLOCK + threadIdx.x) >> 4;  // solver slot (thread-stride order)
   const int c = threadIdx.x & 15;
   const int drow = (threadIdx.x >> 4) & 3;
@@ -476,8 +530,15 @@ __global__ void __launch_bounds__(LM_BLOCK, WIDE ? LM_WIDE_WAVES : LM_WAVES) lm_
   LmProblem pr;
   pr.cx = m.x_left[0];
   pr.cy = m.x_left[1];
-  pr.tsL = a.tsL;
-  pr.tsR = a.tsR;
+  {  // one bounds-checked window over each image (0x00020000: untyped 32-bit data format, the gfx9 raw-buffer descriptor)
+    const int n_bytes = p.W * p.H;
+    pr.tsL = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.tsL), 0, n_bytes, 0x00020000);
+    pr.tsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.tsR), 0, n_bytes, 0x00020000);
+  }
+#pragma unroll
+  for (int r3 = 0; r3 < 3; ++r3)
+    pr.ray[r3] = (p.camL.Kinv[r3 * 3 + 0] * pr.cx + p.camL.Kinv[r3 * 3 + 1] * pr.cy) + p.camL.Kinv[r3 * 3 + 2];
+  pr.cam = lds_cam;
   pr.c = c;
   pr.rg = rg;
 #ifdef LM_STATS
@@ -518,6 +579,7 @@ __global__ void __launch_bounds__(LM_BLOCK, WIDE ? LM_WIDE_WAVES : LM_WAVES) lm_
   int nfev = 1, iter = 1, iteration = 0, optState = 0;
   int phase = 0;
   bool need_step = false;
+  bool fvec_tight = false;  // fvec comes from a tight evaluation (lm_eval's return value)
   double xe = x;
 #ifdef LM_STATS
   double dbg_xjac = __longlong_as_double(0x7ff8000000000000ll);
@@ -532,10 +594,11 @@ __global__ void __launch_bounds__(LM_BLOCK, WIDE ? LM_WIDE_WAVES : LM_WAVES) lm_
       xe = xnew;
       need_step = false;
     }
-    lm_eval<WIDE, L2>(p, pr, xe, out);
+    const bool out_tight = lm_eval<WIDE, L2>(p, pr, xe, out);
     int status = -1;
     bool outer_tail = false;
     if (phase == 0) {  // minimizeInit
+      fvec_tight = out_tight;
 #pragma unroll
       for (int y = 0; y < RL; ++y) fvec[y] = out[y];
       fnorm = sqrt(patch_dot<WIDE>(fvec, fvec, rg));
@@ -551,8 +614,19 @@ __global__ void __launch_bounds__(LM_BLOCK, WIDE ? LM_WIDE_WAVES : LM_WAVES) lm_
       // pure function and fvec already holds F(x) at the current x, so val1 == fvec bit for bit and
       // only F(x + h) is computed.  nfev still advances by 2 (it drives the maxfev test).
       double fjac[RL];
+      {
+        // Both evaluations tight: every entry is 0 or has 2^-150 <= |f| < 2^11, so a non-zero difference has
+        // 2^-202 <= |d| < 2^12; with h inside the window too the seven quotients share one refined reciprocal (fdiv.hpp:
+        // bit for bit the IEEE quotient), 3 instead of 13 instructions each.
+        const Recip rh = make_recip(h);
+        if (out_tight && fvec_tight && rh.fast) {
 #pragma unroll
-      for (int y = 0; y < RL; ++y) fjac[y] = (out[y] - fvec[y]) / h;
+          for (int y = 0; y < RL; ++y) fjac[y] = div_fast(out[y] - fvec[y], rh);
+        } else {
+#pragma unroll
+          for (int y = 0; y < RL; ++y) fjac[y] = (out[y] - fvec[y]) / h;
+        }
+      }
       nfev += 2;
       const double wa2n = sqrt(patch_dot<WIDE>(fjac, fjac, rg));
       const double jtf = patch_dot<WIDE>(fjac, fvec, rg);
@@ -602,6 +676,7 @@ __global__ void __launch_bounds__(LM_BLOCK, WIDE ? LM_WIDE_WAVES : LM_WAVES) lm_
       }
       if (ratio >= 1e-4) {
         x = xnew;
+        fvec_tight = out_tight;
 #pragma unroll
         for (int y = 0; y < RL; ++y) fvec[y] = out[y];
         xnorm = fabs(diag * x);

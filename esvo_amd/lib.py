@@ -14,7 +14,8 @@ from .abi import (DEPTH_POINT_DTYPE, EVENT_DTYPE, MATCH_DTYPE, CalibStruct, Para
                   StatsStruct)
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-_LIB_PATH = os.path.join(_CSRC, "libesvo_hip.so")
+# ESVO_HIP_LIB: another build of the same library (A/B measurements of kernel variants, tools/ab_build.py); never a fallback
+_LIB_PATH = os.environ.get("ESVO_HIP_LIB") or os.path.join(_CSRC, "libesvo_hip.so")
 _SOURCES = ["api_core.hip", "api_ts.hip", "api_map.hip", "api_comm.hip", "api_bag.hip", "api_track.hip", "scan.hip", "kernels_ts.hip", "kernels_bm.hip", "kernels_lm.hip", "kernels_fuse.hip", "kernels_shard.hip", "kernels_track.hip", "kernels_viz.hip", "kernels_sgm.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
                "-Wno-unused-value", "-Wno-unused-result", "-ldl"]
@@ -70,6 +71,15 @@ def load():
         raise EsvoError(f"{_LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                         "(the ESVO hot path has no CPU fallback)")
     lib = C.CDLL(_LIB_PATH)
+    if os.environ.get("ESVO_HIP_LIB"):  # an A/B build of an older revision may lack the newest entry points: stub them
+        class _Missing:
+            argtypes = restype = None
+
+            def __call__(self, *a):
+                raise EsvoError("entry point missing in the ESVO_HIP_LIB build")
+        for s in SYMBOLS:
+            if not hasattr(lib, s):
+                setattr(lib, s, _Missing())
     vp, u64, sz, i32 = C.c_void_p, C.c_uint64, C.c_size_t, C.c_int
     psz = C.POINTER(C.c_size_t)
     lib.esvo_default_params.argtypes = [vp]
