@@ -215,6 +215,20 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
   CK(dalloc(&h->d_matches2[0], E));
   CK(dalloc(&h->d_matches2[1], E));
   h->d_matches = h->d_matches2[0];
+  if (E > LM_SPLIT_MIN_EVENTS) {
+    // The split LM launch (kernels_lm.hip, LmSplit) executes 10 % fewer vector instructions (3.47e8 against 3.85e8 per launch
+    // of the bench workload) but does not shorten the tick (1.40 against 1.38 ms): what it removes are the partially masked
+    // instructions of lockstep execution, and the tick is bound by the chip's throughput at its sustained f64 clock.  It is
+    // therefore OFF unless ESVO_LM_SPLIT=1; its scratch is allocated either way so that the switch works per handle.
+    const char* es = std::getenv("ESVO_LM_SPLIT");
+    h->lm_use_split = es && std::atoi(es) == 1;
+    CK(dalloc(&h->d_lm_fvec0, E * 7 * 16));
+    CK(dalloc(&h->d_lm_fnorm0, E));
+    CK(dalloc(&h->d_lm_meta, E));
+    CK(dalloc(&h->d_lm_order, E));
+    CK(dalloc(&h->d_lm_hist, 2 * 32 * 64));  // kernels_lm.hip: 2 x LM_SPLIT_STRIPES x LM_SPLIT_BINS
+    CK(hipMemset(h->d_lm_hist, 0, sizeof(u32) * 2 * 32 * 64));
+  }
   CK(dalloc(&h->d_pt_slots, E));
   CK(dalloc(&h->d_pt_flags, E));
   CK(dalloc(&h->d_pt_prefix, E));
@@ -303,7 +317,7 @@ int esvo_destroy(esvo_handle h) {
                   h->d_win, h->d_frame_pose_T, h->d_fr_table, h->d_prop, h->d_cell_count, h->d_cell_offset,
                   h->d_cell_fill, h->d_rec_ids, h->d_map, h->d_map2, h->d_owner_max, h->d_owner_min, h->d_exp_flags,
                   h->d_exp_prefix, h->d_export, h->d_export_cell, h->d_reg_ab, h->d_reg_cd, h->d_bucket, h->d_cell_list, h->d_own_w, h->d_lkeep, h->d_codes,
-                  h->d_sel, h->d_evmap};
+                  h->d_sel, h->d_evmap, h->d_lm_fvec0, h->d_lm_fnorm0, h->d_lm_meta, h->d_lm_order, h->d_lm_hist};
   for (void* p : ptrs) if (p) hipFree(p);
   if (h->h_counters) hipHostFree(h->h_counters);
   if (h->h_cnt_b) hipHostFree(h->h_cnt_b);

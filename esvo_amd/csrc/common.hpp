@@ -238,7 +238,14 @@ struct LmArgs {
   u32* out_flags;               // [max_matches] 1 = solved (and kept when cull)
   int cull;
   int dense;                    // sharded mode: `matches` is this rank's own dense list; slot s solves match s
+  // scratch of the split launch (kernels_lm.hip, LmSplit); split_fvec0 == nullptr: single launch
+  double* split_fvec0;
+  double* split_fnorm0;
+  u32* split_meta;
+  u32* split_order;
+  u32* split_hist;
 };
+constexpr u32 LM_SPLIT_MIN_EVENTS = 40000u;  // launches bounded by fewer events use the wide layout (LM_WIDE_MAX), never the split
 void launch_lm_refine(const LmArgs& a, const DevParams& p, u32* n_solved, hipStream_t s);
 void launch_compact_points(const DevPoint* slots, const u32* flags, const u32* prefix, const u32* n_in,
                            u32 max_n, DevPoint* out, hipStream_t s);

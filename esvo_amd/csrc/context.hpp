@@ -135,6 +135,14 @@ struct esvo_context {
   u32* d_match_flags = nullptr;
   u32* d_match_prefix = nullptr;
   esvo_match_t* d_matches = nullptr;
+  // split LM launch (kernels_lm.hip): F(x0) of every match, its cost, the processing order; allocated when the handle can see
+  // launches above the wide layout's bound
+  double* d_lm_fvec0 = nullptr;
+  double* d_lm_fnorm0 = nullptr;
+  u32* d_lm_meta = nullptr;
+  u32* d_lm_order = nullptr;
+  u32* d_lm_hist = nullptr;
+  bool lm_use_split = false;      // ESVO_LM_SPLIT=1: the split launch
   DevPoint* d_pt_slots = nullptr;
   u32* d_pt_flags = nullptr;
   u32* d_pt_prefix = nullptr;

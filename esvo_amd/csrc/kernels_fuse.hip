@@ -358,7 +358,8 @@ __global__ void __launch_bounds__(FUSE_BLOCK, FUSE_WAVES) fuse_cells_kernel(Fuse
       nxt = a.prop[id_nxt / (u32)K];
     }
 #else
-    // (A/B: without the software prefetch the kernel needs 80 instead of 112 VGPRs; measured neutral beside the LM kernel)
+    // (A/B: without the software prefetch the kernel needs 80 instead of 112 VGPRs; measured slower beside the LM kernel in
+    //  round 3 as well -- 1.43 against 1.39 ms per tick -- see the register footprint note in kernels_lm.hip)
     id = next_id(i, id);
     const DevPoint prop = a.prop[id / (u32)K];
 #endif

@@ -24,6 +24,7 @@
 #include "common.hpp"
 #include "fdiv.hpp"
 
+
 namespace esvo {
 
 #ifdef LM_STATS
@@ -162,7 +163,7 @@ struct LmProblem {
   double cx, cy;           // rectified left coordinate of the event
   double ray[3];           // Kinv [cx cy 1]^T: the part of cam2World that does not depend on the inverse depth
 #ifdef LM_T_IN_LDS
-  const double* T;         // T_left_virtual (3x4) in LDS (A/B switch: 159 VGPRs -> 3 waves/SIMD; slower tick)
+  const double* T;         // T_left_virtual (3x4) in LDS: 24 VGPRs less (see the register footprint note at lm_refine_kernel)
 #else
   double T[12];            // T_left_virtual (3x4)
 #endif
@@ -198,10 +199,12 @@ __device__ inline PatchGeom interp_geom(const DevParams& p, double lx, double ly
   g.uly = l0 - hy;
   const int drx = l1 + hx, dry = l0 + hy;
   g.ok = (int)(g.ulx >= 0) & (int)(g.uly >= 0) & (int)(drx < p.W) & (int)(dry < p.H) & (int)(g.uly + LM_ROWS < p.H) & (int)(g.ulx + LM_COLS < p.W);
-  g.q1 = (double)(l1 + 1) - lx;
-  g.q2 = lx - (double)l1;
-  g.q3 = (double)(l0 + 1) - ly;
-  g.q4 = ly - (double)l0;
+  // (double)(l1 + 1) - lx etc. (:215-222): floor(lx) already IS (double)l1, and adding 1.0 to an integer-valued double
+  // below 2^31 is exact, so the int -> double conversions are not needed (a location outside that range fails g.ok)
+  g.q1 = (fx + 1.0) - lx;
+  g.q2 = lx - fx;
+  g.q3 = (fy + 1.0) - ly;
+  g.q4 = ly - fy;
   return g;
 }
 template <bool WIDE>
@@ -227,8 +230,9 @@ __device__ inline void interp_column(__amdgpu_buffer_rsrc_t img, int W, const Pa
 // Returns whether the evaluation was "tight" (group-uniform): every non-zero residual of the match has 2^-50 <= |r| and the
 // final scale lies in [2^-100, 2^100], so every non-zero f = sqrt(w) r has 2^-150 <= |f| < 2^11 -- what lets the caller
 // divide differences of two such evaluations through a shared reciprocal (fdiv.hpp's window) without testing them.
-template <bool WIDE, bool L2>
-__device__ bool lm_eval(const DevParams& p, const LmProblem& pr, double x, double* fv) {
+template <bool WIDE, bool L2, bool COUNT = false>
+__device__ bool lm_eval(const DevParams& p, const LmProblem& pr, double x, double* fv, int* n_iter = nullptr) {
+  int iters = 0;  // t-scale iterations of this evaluation (COUNT only: the split launch orders the matches by it)
   constexpr int RL = Lay<WIDE>::RL;
   // element (y, c) of the patch exists: column 15 only feeds its neighbour; row group 3 of the wide layout owns one row
   bool el[RL];
@@ -258,10 +262,26 @@ __device__ bool lm_eval(const DevParams& p, const LmProblem& pr, double x, doubl
       hL[r] = ((PL[0] * pl[0] + PL[1] * pl[1]) + PL[2] * pl[2]) + PL[3];
       hR[r] = ((PR[0] * pl[0] + PR[1] * pl[1]) + PR[2] * pl[2]) + PR[3];
     }
-    x1u = hL[0] / hL[2];
-    x1v = hL[1] / hL[2];
-    x2u = hR[0] / hR[2];
-    x2v = hR[1] / hR[2];
+    // Rectified cameras share the third row of P, so the four quotients have ONE divisor.  With |h2| in [2^-100, 2^100]
+    // (one exponent test) they go through a shared refined reciprocal: a coordinate that passes the bounds test below lies
+    // in [3, W], i.e. its numerator lies in fdiv.hpp's window and the quotient is the IEEE one; a numerator outside the
+    // window gives a quotient outside [3, W] (or NaN) on either path, and such an evaluation takes the failure fill
+    // whatever the coordinate's bits are.
+    if (__double_as_longlong(hL[2]) == __double_as_longlong(hR[2]) &&
+        (unsigned)(((__double2hiint(hL[2]) >> 20) & 0x7ff) - 923) <= 200u) {
+      Recip rz;
+      rz.b = hL[2];
+      rz.y = recip_refined(hL[2]);
+      x1u = div_fast(hL[0], rz);
+      x1v = div_fast(hL[1], rz);
+      x2u = div_fast(hR[0], rz);
+      x2v = div_fast(hR[1], rz);
+    } else {
+      x1u = hL[0] / hL[2];
+      x1v = hL[1] / hL[2];
+      x2u = hR[0] / hR[2];
+      x2v = hR[1] / hR[2];
+    }
   }
   const int hx = (LM_COLS - 1) / 2, hy = (LM_ROWS - 1) / 2;
   // warping bounds (DepthProblem.cpp:186-189) and patchInterpolation's (:205-230), as ONE predicate in straight-line code:
@@ -283,6 +303,7 @@ __device__ bool lm_eval(const DevParams& p, const LmProblem& pr, double x, doubl
     }
 #pragma unroll
     for (int y = 0; y < RL; ++y) fv[y] = el[y] ? f : 0.0;
+    if constexpr (COUNT) *n_iter = 0;
     return false;
   }
   if constexpr (L2) {
@@ -347,6 +368,7 @@ __device__ bool lm_eval(const DevParams& p, const LmProblem& pr, double x, doubl
     if (tight) {
       // sign bit included in the exponent field: a negative or NaN s1 fails the range test
       while ((unsigned)(((__double2hiint(s1) >> 20) & 0xfff) - 923) <= 200u) {
+        if constexpr (COUNT) ++iters;
         LM_COUNT(2, pr.c == 0);                                 // t-scale iterations, per group
         LM_SLOT(1, pr.dbg_slot, pr.c == 0, 1u);
         LM_SLOT(2, pr.dbg_slot, pr.c == 0 && g_lm_slot[0][pr.dbg_slot < (1u << 18) ? pr.dbg_slot : 0] == 1u, 1u);
@@ -372,6 +394,7 @@ __device__ bool lm_eval(const DevParams& p, const LmProblem& pr, double x, doubl
     }
 #endif
     while (!done) {
+      if constexpr (COUNT) ++iters;
       LM_COUNT(2, pr.c == 0);
       LM_SLOT(1, pr.dbg_slot, pr.c == 0, 1u);
       LM_SLOT(2, pr.dbg_slot, pr.c == 0 && g_lm_slot[0][pr.dbg_slot < (1u << 18) ? pr.dbg_slot : 0] == 1u, 1u);
@@ -416,6 +439,7 @@ __device__ bool lm_eval(const DevParams& p, const LmProblem& pr, double x, doubl
       rd.y = recip_refined(rd.b);
       fv[y] = sqrt_moderate(div_fast(nu1, rd)) * r[y];
     }
+    if constexpr (COUNT) *n_iter = iters;
     return true;
   }
 #endif
@@ -431,6 +455,7 @@ __device__ bool lm_eval(const DevParams& p, const LmProblem& pr, double x, doubl
     fv[y] = fast2 ? sqrt_moderate(div_fast(nu + 1, make_recip(nu + div_fast(r2[y], rs2)))) * r[y]
                   : sqrt((nu + 1) / (nu + r2[y] / s2)) * r[y];
   }
+  if constexpr (COUNT) *n_iter = iters;
   return false;
 }
 
@@ -495,9 +520,53 @@ __device__ inline double lm_lmpar2(double r, double diag, double qtf, double del
 #ifndef LM_WIDE_MAX
 #define LM_WIDE_MAX 40000u  // launches bounded by this many matches (= events handed to block matching) use the wide layout
 #endif
-template <bool WIDE, bool L2 = false>
-__global__ void __launch_bounds__(LM_BLOCK, WIDE ? LM_WIDE_WAVES : LM_WAVES) lm_refine_kernel(LmArgs a, DevParams p, u32* n_solved) {
+// ---- the split launch (narrow layout, large launches) ---------------------------------------------------------------
+// Four matches share a wave in lockstep: the wave executes the LONGEST of their t-scale loops in every evaluation, and a
+// launch ends with its slowest waves running alone.  A match's cost is set by its patch (how many iterations the scale
+// needs), which its first evaluation F(x0) already shows.  So the launch is split:
+//   STAGE 1  F(x0) of every match (minimizeInit) in slot order: residuals, |f|, the iteration count -> a histogram
+//   order    matches sorted by that count, longest first (counting sort over 64 bins)
+//   STAGE 2  the remaining ~19 evaluations, four NEIGHBOURS of the sorted list per wave
+// Waves then hold matches of equal cost (the lockstep loss of the t-scale loop shrinks) and the expensive waves start
+// first (the tail of the launch is filled with cheap ones).  Every match is solved by the same instructions on the same
+// operands as in the single launch -- only its position in the grid changes -- and results are written by slot, so the
+// output is bit-identical.  F(x0) travels through a scratch buffer (LmArgs::split_*: 7 x 16 doubles per match).
+struct LmSplit {
+  double* fvec0;   // [max_matches][7][16]
+  double* fnorm0;  // [max_matches]
+  u32* meta;       // [max_matches] iteration count of F(x0) (clamped to 63) | tight << 8
+  u32* order;      // [max_matches] slot of the k-th match in processing order
+  u32* hist;       // [STRIPES][64] matches per iteration count, then [STRIPES][64] fill counters of the scatter.  Striped by
+                   // the first stage's block index: 4 x 10^4 atomics on the five or six bins that occur in practice
+                   // serialise on their L2 lines otherwise (measured: 0.18 ms for the sort alone)
+};
+#define LM_SPLIT_BINS 64
+#define LM_SPLIT_STRIPES 32
+__device__ inline u32 lm_split_stripe(u32 slot) { return (slot >> 2) & (LM_SPLIT_STRIPES - 1); }  // 4 slots per first-stage wave
+
+// Register footprint of the narrow layout (A/B switches, measured in round 3 and left OFF).  The LM kernel shares every SIMD
+// with the latency-bound kernels of the matching and fusion stages, and a kernel trace shows the LM stream and the fusion
+// stream both busy for the whole tick (fuse_cells 0.57 ms beside the LM kernel against 0.33 ms alone).  The experiment: the
+// match's pose matrix in LDS (-DLM_T_IN_LDS, ~160 VGPRs) and the kernel PADDED back to 169..176 VGPRs (-DLM_PAD0 / -DLM_PAD2)
+// so that exactly two LM waves fit per SIMD and 160 VGPRs stay free -- two waves of every fusion-stage kernel (<= 80 VGPRs
+// without fuse_cells' software prefetch) instead of one.  Result: the tick gets LONGER (1.50 ms against 1.39 ms; 1.77 ms
+// in the single launch): more resident waves of the other stages take issue slots from the LM kernel without finishing
+// sooner themselves.  The chip runs this f64 load at ~1.75 GHz; the tick is bound by vector-ALU throughput at that clock.
+#ifndef LM_PAD0
+#define LM_PAD0 0
+#endif
+#ifndef LM_PAD2
+#define LM_PAD2 0
+#endif
+template <bool WIDE, bool L2 = false, int STAGE = 0>
+__global__ void __launch_bounds__(LM_BLOCK, WIDE ? LM_WIDE_WAVES : LM_WAVES) lm_refine_kernel(LmArgs a, DevParams p, u32* n_solved, LmSplit sp) {
   constexpr int RL = Lay<WIDE>::RL;
+  constexpr int PAD = (WIDE || L2) ? 0 : (STAGE == 2 ? LM_PAD2 : (STAGE == 0 ? LM_PAD0 : 0));
+  int pad[PAD > 0 ? PAD : 1];
+  if constexpr (PAD > 0) {
+#pragma unroll
+    for (int i = 0; i < PAD; ++i) asm volatile("v_mov_b32 %0, 0" : "=v"(pad[i]));
+  }
 #ifdef LM_T_IN_LDS
   __shared__ double lds_T[LM_BLOCK / 16][12];
 #endif
@@ -507,18 +576,25 @@ __global__ void __launch_bounds__(LM_BLOCK, WIDE ? LM_WIDE_WAVES : LM_WAVES) lm_
     lds_cam[i] = i < 12 ? p.camL.P[i] : (i < 24 ? p.camR.P[i - 12] : p.camL.Kinv_t[i - 24]);
   }
   __syncthreads();
-  const u32 s = WIDE ? blockIdx.x : (blockIdx.x * LM_BLOCK + threadIdx.x) >> 4;  // solver slot (thread-stride order)
+  const u32 pos = WIDE ? blockIdx.x : (blockIdx.x * LM_BLOCK + threadIdx.x) >> 4;  // position in the grid
   const int c = threadIdx.x & 15;
   const int drow = (threadIdx.x >> 4) & 3;
   const int rg = WIDE ? (drow ^ (drow >> 1)) : 0;  // row groups 0,1,2,3 sit in DPP rows 0,1,3,2 (patch_sum)
   const bool lead = WIDE ? threadIdx.x == 0 : c == 0;
   u32 M = *a.n_matches;
   if (M > a.max_matches) M = a.max_matches;
-  bool active = s < M;
+  bool active = pos < M;
+  // solver slot (thread-stride order): the grid position, or -- second stage of a split launch -- what the sort put there
+  u32 s = pos;
+  if constexpr (STAGE == 2) {
+    // the sort's counters, for the next launch (its kernels are done): 2 x STRIPES x BINS words, 64 per block
+    if (blockIdx.x < 2 * LM_SPLIT_STRIPES * LM_SPLIT_BINS / LM_BLOCK) sp.hist[blockIdx.x * LM_BLOCK + threadIdx.x] = 0u;
+    s = active ? sp.order[pos] : 0xffffffffu;
+  }
   // The grid is sized for the worst case (every event matched): waves without any match leave at once.
   // Inactive groups of a partially filled wave run the (cheap, failing) code path below with a dummy
   // problem so that the wave's control flow stays simple; they write nothing.
-  if (!active && lead && s < a.max_matches) a.out_flags[s] = 0u;  // every slot of the launch gets its flag: no memset
+  if (STAGE != 2 && !active && lead && s < a.max_matches) a.out_flags[s] = 0u;  // every slot of the launch gets its flag: no memset
   if (__ballot(active) == 0) return;
   u32 j = 0;
   esvo_match_t m;
@@ -581,6 +657,41 @@ __global__ void __launch_bounds__(LM_BLOCK, WIDE ? LM_WIDE_WAVES : LM_WAVES) lm_
   bool need_step = false;
   bool fvec_tight = false;  // fvec comes from a tight evaluation (lm_eval's return value)
   double xe = x;
+  if constexpr (STAGE == 1) {  // minimizeInit only: F(x0), |F(x0)|, what the evaluation cost
+    int n_it = 0;
+    const bool tgt = lm_eval<WIDE, L2, true>(p, pr, x, out, &n_it);
+    const double f0 = sqrt(patch_dot<WIDE>(out, out, rg));
+    if (active) {
+      double* dst = sp.fvec0 + (size_t)s * (LM_ROWS * 16) + c;
+#pragma unroll
+      for (int y = 0; y < RL; ++y) dst[y * 16] = out[y];
+      if (lead) {
+        const u32 key = n_it < LM_SPLIT_BINS - 1 ? (u32)n_it : (u32)(LM_SPLIT_BINS - 1);
+        sp.fnorm0[s] = f0;
+        sp.meta[s] = key | (tgt ? 0x100u : 0u);
+        atomicAdd(&sp.hist[lm_split_stripe(s) * LM_SPLIT_BINS + key], 1u);
+      }
+    }
+    return;
+  }
+  if constexpr (STAGE == 2) {  // resume behind minimizeInit (the `phase == 0` branch and the step to phase 1 below)
+    if (active) {
+      const double* src = sp.fvec0 + (size_t)s * (LM_ROWS * 16) + c;
+#pragma unroll
+      for (int y = 0; y < RL; ++y) fvec[y] = src[y * 16];
+      fnorm = sp.fnorm0[s];
+      fvec_tight = (sp.meta[s] & 0x100u) != 0;
+    } else {
+#pragma unroll
+      for (int y = 0; y < RL; ++y) fvec[y] = 0.0;
+    }
+    par = 0.;
+    iter = 1;
+    phase = 1;
+    h = sqrt_eps * fabs(x);
+    if (h == 0.) h = sqrt_eps;
+    xe = x + h;
+  }
 #ifdef LM_STATS
   double dbg_xjac = __longlong_as_double(0x7ff8000000000000ll);
 #endif
@@ -712,6 +823,10 @@ __global__ void __launch_bounds__(LM_BLOCK, WIDE ? LM_WIDE_WAVES : LM_WAVES) lm_
     }
   }
 
+  if constexpr (PAD > 0) {  // (the padding registers are live up to here)
+#pragma unroll
+    for (int i = 0; i < PAD; ++i) asm volatile("" ::"v"(pad[i]));
+  }
   if (!active || !lead) return;
   const bool solved = !(x <= 0.001);  // DepthProblemSolver.cpp:192
   bool keep = solved;
@@ -755,20 +870,61 @@ extern "C" void esvo_debug_lm_slots(unsigned int* out, int clear) {  // out[3][1
   if (clear) { void* p = nullptr; hipGetSymbolAddress(&p, HIP_SYMBOL(esvo::g_lm_slot)); hipMemset(p, 0, sizeof(unsigned int) * 3 * (1 << 18)); }
 }
 #endif
+// counting sort of the slots by the cost of F(x0), most expensive first: offsets from the (complete) histogram, computed
+// per block in LDS; the order inside a bin is whatever the atomics make it (it does not matter: see above)
+__global__ void __launch_bounds__(256) lm_order_kernel(const u32* __restrict__ n_matches, u32 max_matches, LmSplit sp) {
+  // base[stripe][key]: first position of the (stripe, key) sub-list -- bins in descending key order, stripes ascending
+  // inside a bin.  Every block derives the table from the (complete) histogram: 2048 cached words.
+  __shared__ u32 base[LM_SPLIT_STRIPES][LM_SPLIT_BINS];
+  __shared__ u32 tot[LM_SPLIT_BINS];
+  if (threadIdx.x < LM_SPLIT_BINS) {
+    const int k = threadIdx.x;
+    u32 run = 0;
+    for (int st = 0; st < LM_SPLIT_STRIPES; ++st) {
+      base[st][k] = run;
+      run += sp.hist[st * LM_SPLIT_BINS + k];
+    }
+    tot[k] = run;
+  }
+  __syncthreads();
+  u32 off = 0;  // matches in bins above the thread's own (threads >= BINS only help with the adds below)
+  if (threadIdx.x < LM_SPLIT_BINS)
+    for (int k = LM_SPLIT_BINS - 1; k > (int)threadIdx.x; --k) off += tot[k];
+  __syncthreads();
+  if (threadIdx.x < LM_SPLIT_BINS)
+    for (int st = 0; st < LM_SPLIT_STRIPES; ++st) base[st][threadIdx.x] += off;
+  __syncthreads();
+  u32 M = *n_matches;
+  if (M > max_matches) M = max_matches;
+  const u32 s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= M) return;
+  const u32 key = sp.meta[s] & 0xffu, st = lm_split_stripe(s);
+  u32* fill = sp.hist + LM_SPLIT_STRIPES * LM_SPLIT_BINS;
+  sp.order[base[st][key] + atomicAdd(&fill[st * LM_SPLIT_BINS + key], 1u)] = s;
+}
+
 void launch_lm_refine(const LmArgs& a, const DevParams& p, u32* n_solved, hipStream_t s) {
   if (a.max_matches == 0) return;
+  LmSplit sp;
+  sp.fvec0 = a.split_fvec0; sp.fnorm0 = a.split_fnorm0; sp.meta = a.split_meta; sp.order = a.split_order; sp.hist = a.split_hist;
   const u32 groups_per_block = LM_BLOCK / 16;
   const u32 blocks = (a.max_matches + groups_per_block - 1) / groups_per_block;
   if (p.ls_norm == ESVO_LSNORM_L2) {  // no shipped configuration: the narrow layout only
-    hipLaunchKernelGGL((lm_refine_kernel<false, true>), dim3(blocks), dim3(LM_BLOCK), 0, s, a, p, n_solved);
+    hipLaunchKernelGGL((lm_refine_kernel<false, true, 0>), dim3(blocks), dim3(LM_BLOCK), 0, s, a, p, n_solved, sp);
     return;
   }
   // the match count lives on the device; the layout is chosen by the launch's bound (the events handed to block matching)
   if (a.max_matches <= LM_WIDE_MAX && LM_BLOCK == 64) {
-    hipLaunchKernelGGL((lm_refine_kernel<true, false>), dim3(a.max_matches), dim3(64), 0, s, a, p, n_solved);
+    hipLaunchKernelGGL((lm_refine_kernel<true, false, 0>), dim3(a.max_matches), dim3(64), 0, s, a, p, n_solved, sp);
     return;
   }
-  hipLaunchKernelGGL((lm_refine_kernel<false, false>), dim3(blocks), dim3(LM_BLOCK), 0, s, a, p, n_solved);
+  if (a.split_fvec0 && !a.dense) {  // the split launch (see LmSplit)
+    hipLaunchKernelGGL((lm_refine_kernel<false, false, 1>), dim3(blocks), dim3(LM_BLOCK), 0, s, a, p, n_solved, sp);
+    hipLaunchKernelGGL(lm_order_kernel, dim3((a.max_matches + 255) / 256), dim3(256), 0, s, a.n_matches, a.max_matches, sp);
+    hipLaunchKernelGGL((lm_refine_kernel<false, false, 2>), dim3(blocks), dim3(LM_BLOCK), 0, s, a, p, n_solved, sp);
+    return;
+  }
+  hipLaunchKernelGGL((lm_refine_kernel<false, false, 0>), dim3(blocks), dim3(LM_BLOCK), 0, s, a, p, n_solved, sp);
 }
 
 // stable compaction of the solver slots into a frame buffer
