@@ -101,6 +101,30 @@ def algorithmic_bytes(kernel, st, W, H, nd, fusion_radius=1, events=None, matche
     return 0
 
 
+TRAFFIC_NOTE = ("traffic = 2 x FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes (committed CSV named in traffic_source). The x2 on "
+                "FETCH_SIZE is MI355X_MICROARCH.md's gfx950 correction, calibrated for streaming 16-byte-per-lane loads only; for byte "
+                "gathers and atomics (ts_scatter, scatter_records, reg_apply's LDS staging) it is an uncalibrated upper bound")
+
+
+def roofline_rows(st, kavg, rig, nd, p, prof, events, matches, scattered):
+    """per-kernel roofline entries: Time-Surface scatter and render (the HBM-bound stage), block matching, LM"""
+    rows = []
+    ts_bytes = {"ts_scatter": scattered * 24.0,                    # 16 B event read + 8 B SAE atomic (SURVEY 8d)
+                "ts_render": 2.0 * rig.width * rig.height * 9.0}   # both cameras: 8 B SAE read + 1 B mono8 write per pixel
+    for slot in (0, 1, 2, 3):
+        name = KERNEL_NAMES[slot]
+        if slot < 2:
+            nbytes = ts_bytes[name]
+        else:
+            nbytes = algorithmic_bytes(name, st, rig.width, rig.height, nd, p.fusion_radius, events=events, matches=matches)
+        gbs = (nbytes / (kavg[slot] * 1e-3)) / 1e9 if kavg[slot] > 0 else 0.0
+        tr, vl = profile_figures(prof, name, float(kavg[slot]))
+        rows.append({"kernel": name, "avg_launch_ms": float(kavg[slot]), "algorithmic_bytes_per_launch": nbytes,
+                     "achieved": gbs, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": tr,
+                     "valu_frac": None if vl is None else vl["frac"]})
+    return rows
+
+
 def committed_profile(workload):
     """The newest committed rocprofv3 round (profiles/<tag>_meta.json names the command and workload it ran): per-kernel
     HBM bytes (separate FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction) and
@@ -370,7 +394,7 @@ def main():
         else:
             ev_rank, mt_rank = n_events, n_matches
         return dict(per_gpu=per_gpu, rig=rig, stream=stream, p=p, ticks=ticks, duration=duration, native=native, comm_note=comm_note,
-                    runner=runner, dt=dt, st=st, n_events=n_events, n_points=n_points, n_matches=n_matches, ksum=ksum,
+                    runner=runner, dt=dt, st=st, base=base, n_events=n_events, n_points=n_points, n_matches=n_matches, ksum=ksum,
                     launches=launches, ev_rank=ev_rank, mt_rank=mt_rank, shard_mode=shard_mode)
 
     shard_mode = os.environ.get("ESVO_SHARD_MODE", "tick")
@@ -397,7 +421,10 @@ def main():
     traffic, valu = profile_figures(prof, dom_name, float(kavg[dom]))
     total_ticks = K * per_gpu
     out = {
-        "metric": "mapped events/sec (stereo TS raster + block matching + LM depth refinement + fusion)",
+        "metric": "mapped events/sec (stereo TS raster + block matching + LM depth refinement + fusion), events resident in HBM "
+                  "before the timed region" if not args.timed_ingest else
+                  "mapped events/sec (stereo TS raster + block matching + LM depth refinement + fusion), host-to-device staging of every "
+                  "tick's events inside the timed region",
         "value": n_events / dt,
         "unit": "events/s",
         "n_gpus": world,
@@ -442,16 +469,10 @@ def main():
         },
     }
 
-    # the same figures for both single-kernel slots (block matching is the one with a meaningful HBM fraction)
-    out["roofline_kernels"] = []
-    for slot in (2, 3):
-        name = KERNEL_NAMES[slot]
-        nbytes = algorithmic_bytes(name, st, rig.width, rig.height, nd, p.fusion_radius, events=ev_rank / launches, matches=mt_rank / launches)
-        gbs = (nbytes / (kavg[slot] * 1e-3)) / 1e9 if kavg[slot] > 0 else 0.0
-        tr, vl = profile_figures(prof, name, float(kavg[slot]))
-        out["roofline_kernels"].append({"kernel": name, "avg_launch_ms": float(kavg[slot]), "algorithmic_bytes_per_launch": nbytes,
-                                        "achieved": gbs, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": tr,
-                                        "valu_frac": None if vl is None else vl["frac"]})
+    out["roofline"]["traffic_note"] = TRAFFIC_NOTE
+    # the same figures for the Time-Surface stage (the HBM-bound one: 24 B/event, 9 B/pixel) and both single-kernel slots
+    n_scat = (int(st.events_scattered[0]) + int(st.events_scattered[1])) - (int(M["base"].events_scattered[0]) + int(M["base"].events_scattered[1]))
+    out["roofline_kernels"] = roofline_rows(st, kavg, rig, nd, p, prof, ev_rank / launches, mt_rank / launches, n_scat / launches)
     if world > 1:
         out["ranks_seen"] = ranks_seen
         out["rccl"] = rccl
@@ -533,23 +554,52 @@ def other_operating_points(device):
     with two ticks in flight."""
     out = {}
 
-    def throughput(name, n):
+    def throughput(name, n, check=False, timed_ingest=False):
         rig, stream, p, ticks = make_workload(name, n + 3)
         dev = lib.Esvo(p, rig, device=device)
-        dev.ts_push_events(0, stream.ev_left)
-        dev.ts_push_events(1, stream.ev_right)
-        run_single(dev, stream, ticks, 0, 3)
+        if timed_ingest:   # PCIe-inclusive: only the history is resident, every tick's events are staged inside the loop
+            t_first = stream.t0_ns + int(HIST_S * 1e9)
+            bounds = [t_first] + [tk[0] for tk in ticks]
+            chunks = [(stream.slice(0, a, b), stream.slice(1, a, b)) for a, b in zip(bounds[:-1], bounds[1:])]
+            dev.ts_push_events(0, stream.slice(0, stream.t0_ns, t_first))
+            dev.ts_push_events(1, stream.slice(1, stream.t0_ns, t_first))
+        else:
+            dev.ts_push_events(0, stream.ev_left)
+            dev.ts_push_events(1, stream.ev_right)
+
+        def run(a, b):
+            for k in range(a, b):
+                if timed_ingest:
+                    dev.ts_push_events(0, chunks[k][0])
+                    dev.ts_push_events(1, chunks[k][1])
+                t, stamps, poses, T = ticks[k]
+                dev.tick_resident(t, T, stamps, poses)
+        run(0, 3)
         dev.synchronize()
         b = dev.stats()
         t0 = time.perf_counter()
-        run_single(dev, stream, ticks, 3, n + 3)
+        run(3, n + 3)
         dev.synchronize()
         dt = time.perf_counter() - t0
         s = dev.stats()
         dev.close()
         ev = int(s.total_events_in - b.total_events_in)
-        return {"events_per_s": ev / dt, "ms_per_tick": dt / n * 1e3, "events_per_tick": ev // n,
-                "depth_points_per_s": int(s.total_points - b.total_points) / dt}
+        res = {"events_per_s": ev / dt, "ms_per_tick": dt / n * 1e3, "events_per_tick": ev // n,
+               "depth_points_per_s": int(s.total_points - b.total_points) / dt}
+        if timed_ingest:
+            res["note"] = "host-to-device staging of each tick's events (2 x 16 B/event from pageable memory) inside the timed loop"
+            return res
+        ks = np.array(list(s.sum_ms_kernel)) - np.array(list(b.sum_ms_kernel))
+        ka = ks / n
+        if ks[7] > 0:
+            ka[0], ka[1] = 2 * ks[0] / ks[7], 2 * ks[1] / ks[7]
+        scat = (int(s.events_scattered[0]) + int(s.events_scattered[1])) - (int(b.events_scattered[0]) + int(b.events_scattered[1]))
+        res["kernel_ms"] = {KERNEL_NAMES[i]: round(float(ka[i]), 4) for i in range(7)}
+        res["roofline_kernels"] = roofline_rows(s, ka, rig, p.bm_max_disparity - p.bm_min_disparity + 1, p, committed_profile(name),
+                                                ev / n, int(s.total_matches - b.total_matches) / n, scat / n)
+        if check:   # the first timed tick replayed on a fresh handle against the CPU oracle (as bench.py --check does)
+            res["check_oracle_equal"] = bool(check_against_oracle(rig, stream, p, ticks, 3, device)["equal"])
+        return res
 
     def latency(name, n_events, n):
         rig, stream, p, ticks = make_workload(name, n + 6, events_cap=n_events)
@@ -579,6 +629,10 @@ def other_operating_points(device):
     out["upenn346x260_throughput"] = throughput("upenn346x260", 20)
     out["dsec640x480_reference_faithful_10000"] = latency("dsec640x480", 10000, 20)
     out["upenn346x260_reference_faithful_1000"] = latency("upenn346x260", 1000, 20)
+    # SURVEY.md section 8 stress row: 1280x720, 145 disparity candidates, 100 Mev/s over both cameras, with the oracle equality flag
+    out["hd1280x720_throughput"] = throughput("hd1280x720", 6, check=True)
+    # the headline workload with the PCIe transfer of every tick's events inside the timed loop (never `value`)
+    out["dsec640x480_with_timed_ingest"] = throughput("dsec640x480", 20, timed_ingest=True)
     return out
 
 

@@ -129,15 +129,29 @@ __global__ void __launch_bounds__(256, BACK_WAVES) propagate_kernel(FuseArgs a, 
   }
 }
 
+// XCD-aware scatter.  The record ids of a cell are contiguous, cells in row-major order, and the points arrive in event
+// order, i.e. spatially at random: one launch over the points writes 4-byte ids all over the 6 MB id array from all eight
+// XCDs, every XCD's L2 ends up with its own partially dirty copy of every 128-byte line, and the write-back is ~12x the
+// array (profiles/r02_v8_hbm_traffic.csv: 70 MB for 5.8 MB of ids).  Workgroups are dealt to the XCDs round-robin by their
+// index, so the launch is replicated SCATTER_PARTS = 8 times and replica x -- the workgroups with blockIdx % 8 == x, all on
+// one XCD -- emits only the records of image row band x: every line of the id array (and of the per-cell fill counters) is
+// written from ONE L2 and leaves it once, full.  Each replica reads every point's (row, col) again: 8 B x 8 per point from
+// L2 / Infinity Cache, and a few integer instructions.
+#define SCATTER_PARTS 8
 __global__ void __launch_bounds__(256) scatter_records_kernel(FuseArgs a, DevParams p, int K) {
-  const u32 q = blockIdx.x * blockDim.x + threadIdx.x;
+  const u32 part = blockIdx.x % SCATTER_PARTS;
+  const u32 q = (blockIdx.x / SCATTER_PARTS) * blockDim.x + threadIdx.x;
   if (q >= a.n_pts) return;
   const u32 prow = a.prop[q].row, pcol = a.prop[q].col;
   if (prow == 0xffffffffu) return;
+  const int rows_per = (p.H + SCATTER_PARTS - 1) / SCATTER_PARTS;
+  const int r0 = (int)part * rows_per, r1 = r0 + rows_per;
   const int radius = K == 4 ? 0 : p.fusion_radius;  // (naive propagation: always 2 x 2)
+  if ((int)prow + 1 < r0 || (int)prow - 1 >= r1) return;  // none of the point's cells lies in the band
   for (int k = 0; k < K; ++k) {
     int row, col;
     if (!fusion_cell(prow, pcol, k, radius, p.W, p.H, row, col)) continue;
+    if (row < r0 || row >= r1) continue;
     if (row < p.cband_y0 || row >= p.cband_y1) continue;
     const int cell = row * p.W + col;
     const u32 pos = a.cell_offset[cell] + atomicAdd(&a.cell_fill[cell], 1u);
@@ -461,7 +475,7 @@ void launch_fuse(const FuseArgs& a, const DevParams& p, hipStream_t s) {
                      a.n_touched);
   hipLaunchKernelGGL(cell_scan_down_kernel, dim3(nsb), dim3(SCAN_B), 0, s, a.cell_count, a.cell_offset, a.scan_tmp,
                      a.bucket + FUSE_NB, a.bucket + 2 * FUSE_NB, a.cell_list, ncell, p.cband_y0, p.cband_y1, p.W);
-  if (a.n_pts) hipLaunchKernelGGL(scatter_records_kernel, dim3((a.n_pts + 255) / 256), dim3(256), 0, s, a, p, K);
+  if (a.n_pts) hipLaunchKernelGGL(scatter_records_kernel, dim3(((a.n_pts + 255) / 256) * SCATTER_PARTS), dim3(256), 0, s, a, p, K);
   hipLaunchKernelGGL(sort_long_lists_kernel, dim3(8192), dim3(64), 0, s, a.cell_list, a.bucket + FUSE_NB + 3, a.cell_count,
                      a.cell_offset, a.rec_ids);
   {

@@ -1599,6 +1599,43 @@ extern "C" void orc_sgbm_compute(const uint8_t* left, const uint8_t* right, int 
       disp[(size_t)y * W + x] = v[4];
     }
 }
+// ---- wire format ---------------------------------------------------------------------------------
+// What rosbag::MessageInstance::instantiate<dvs_msgs::EventArray>() does to a message's bytes at
+// events_repacking_helper/src/EventMessageEditor.cpp:104-119 (ros::serialization of the generated message class; rpg_dvs_ros
+// dvs_msgs/EventArray.msg: Header header; uint32 height; uint32 width; Event[] events -- dvs_msgs/Event.msg: uint16 x; uint16 y;
+// time ts; bool polarity -- std_msgs/Header: uint32 seq; time stamp; string frame_id; all little-endian, arrays and strings
+// with a uint32 length prefix): the events in memory, one esvo_event_t (= in-memory dvs_msgs::Event) each.
+// Returns the event count, or -1 when the buffer is not a complete EventArray.  out may be null (count only).
+extern "C" long orc_decode_event_array(const uint8_t* msg, size_t n_bytes, esvo_event_t* out, size_t cap, uint32_t* height,
+                                       uint32_t* width) {
+  auto u32 = [&](size_t o) { return (uint32_t)msg[o] | ((uint32_t)msg[o + 1] << 8) | ((uint32_t)msg[o + 2] << 16) | ((uint32_t)msg[o + 3] << 24); };
+  size_t o = 0;
+  if (n_bytes < 16) return -1;
+  o += 4;                      // header.seq
+  o += 8;                      // header.stamp (secs, nsecs)
+  const uint32_t id_len = u32(o);
+  o += 4;
+  if ((size_t)id_len > n_bytes - o) return -1;
+  o += id_len;                 // header.frame_id
+  if (n_bytes - o < 12) return -1;
+  const uint32_t h = u32(o), w = u32(o + 4), count = u32(o + 8);
+  o += 12;
+  if ((n_bytes - o) / 13 < count || (size_t)count * 13 != n_bytes - o) return -1;
+  if (height) *height = h;
+  if (width) *width = w;
+  for (uint32_t i = 0; i < count && out && i < cap; ++i, o += 13) {
+    esvo_event_t e;
+    std::memset(&e, 0, sizeof(e));
+    e.x = (uint16_t)(msg[o] | (msg[o + 1] << 8));
+    e.y = (uint16_t)(msg[o + 2] | (msg[o + 3] << 8));
+    e.sec = u32(o + 4);
+    e.nsec = u32(o + 8);
+    e.polarity = msg[o + 12] ? 1 : 0;   // bool: any non-zero byte deserialises to true
+    out[i] = e;
+  }
+  return (long)count;
+}
+
 // the SGM branch of dataTransferring (esvo_Mapping.cpp:537-552): events of the last 2 * BM_half_slice_thickness walking
 // back from lower_bound(t), while size <= PROCESS_EVENT_NUM (i.e. up to PROCESS_EVENT_NUM + 1 events)
 extern "C" size_t orc_select_events_sgm(const esvo_event_t* ev, size_t n, uint64_t t_ns, double half_slice, size_t max_num,

@@ -123,6 +123,7 @@ void orc_mapper_counters(orc_mapper_handle h, uint64_t out[8]);
  * the SGM event selection, InitializationAtTime + DepthFusion::naive_propagation */
 void orc_sgbm_compute(const uint8_t* left, const uint8_t* right, int W, int H, int num_disp, int block, int P1, int P2,
                       int uniqueness, int16_t* disp);
+long orc_decode_event_array(const uint8_t* msg, size_t n_bytes, esvo_event_t* out, size_t cap, uint32_t* height, uint32_t* width);
 size_t orc_select_events_sgm(const esvo_event_t* ev, size_t n, uint64_t t_ns, double half_slice, size_t max_num, uint32_t* out_idx,
                              size_t cap);
 size_t orc_mapper_init_sgm(orc_mapper_handle h, const uint8_t* ts_left, const uint8_t* ts_right, const esvo_event_t* ev, size_t n,

@@ -32,7 +32,11 @@ def load(fast=False):
         return _libs[key]
     target = "libesvo_oracle_fast.so" if fast else "libesvo_oracle.so"
     path = os.path.join(_HERE, target)
-    if not os.path.exists(path):
+    if os.environ.get("ESVO_ORACLE_ASAN"):  # the AddressSanitizer / UBSan build (make asan), for tests/test_oracle_asan.py
+        path = os.path.join(_HERE, "libesvo_oracle_asan.so")
+        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(os.path.join(_HERE, "esvo_oracle.cpp")):
+            subprocess.check_call(["make", "-C", _HERE, "asan"], stdout=subprocess.DEVNULL)
+    elif not os.path.exists(path):
         path = build(fast=fast)
     lib = C.CDLL(path)
     vp, u64, sz, dbl, i32 = C.c_void_p, C.c_uint64, C.c_size_t, C.c_double, C.c_int
@@ -86,6 +90,8 @@ def load(fast=False):
     lib.orc_mapper_get_pointcloud_xyz.argtypes = [vp, vp, sz]
     lib.orc_mapper_counters.argtypes = [vp, vp]
     lib.orc_sgbm_compute.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
+    lib.orc_decode_event_array.restype = C.c_long
+    lib.orc_decode_event_array.argtypes = [vp, sz, vp, sz, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     lib.orc_select_events_sgm.restype = sz
     lib.orc_select_events_sgm.argtypes = [vp, sz, u64, dbl, sz, vp, sz]
     lib.orc_mapper_init_sgm.restype = sz
@@ -188,6 +194,20 @@ def select_events(ev, t_ns, half_slice, max_num, fast=False):
     n = lib.orc_select_events(ev.ctypes.data, ev.shape[0], int(t_ns), float(half_slice), int(max_num),
                               idx.ctypes.data, cap)
     return idx[:n]
+
+
+def decode_event_array(msg):
+    """ros::serialization of one dvs_msgs/EventArray (what rosbag's instantiate<> does, EventMessageEditor.cpp:111): returns
+    (events as esvo_event_t array, height, width); raises ValueError on a malformed buffer"""
+    lib = load()
+    buf = np.frombuffer(bytes(msg), np.uint8)
+    h, w = C.c_uint32(), C.c_uint32()
+    n = lib.orc_decode_event_array(buf.ctypes.data, buf.size, None, 0, C.byref(h), C.byref(w))
+    if n < 0:
+        raise ValueError("not a complete dvs_msgs/EventArray")
+    out = np.zeros(max(n, 1), EVENT_DTYPE)
+    lib.orc_decode_event_array(buf.ctypes.data, buf.size, out.ctypes.data, n, C.byref(h), C.byref(w))
+    return out[:n], int(h.value), int(w.value)
 
 
 def denoise_events(ev, idx, width, height, max_num):
