@@ -716,7 +716,9 @@ def cpu_baseline_reference(workload, rig, stream, ticks):
         over = {} if process_event_num is None else dict(process_event_num=process_event_num)
         pf, _ = params.make_params(params.PRESETS[wl["preset"]], rig, **over)
         node = ref.RefNode(pf, rig, stream.pose)
-        node.push_events(stream.ev_left)          # the whole stream staged first, as for `value`
+        # (the node keeps the newest MAX_EVENT_QUEUE_LENGTH = 3 000 000 left events, esvo_Mapping.cpp:706-713: the stream is fed
+        #  tick by tick as the events topic would, one 1 ms message ahead of the tick time)
+        fed = 0
         ts = [ref.RefTS(W, H, pf.decay_ms, bool(pf.ignore_polarity)), ref.RefTS(W, H, pf.decay_ms, bool(pf.ignore_polarity))]
         done = [0, 0]
         rows = []
@@ -736,6 +738,9 @@ def cpu_baseline_reference(workload, rig, stream, ticks):
                 done[cam] = hi
                 imgs.append(u8)
             t0 = time.perf_counter()
+            hi = int(np.searchsorted(stream.ns_left, t + 1_000_000, side="left"))
+            node.push_events(stream.ev_left[fed:hi])                 # esvo_Mapping::eventsCallback (left camera)
+            fed = hi
             obs = [oracle.gaussian5(i) for i in imgs] if pf.smooth_time_surface else imgs   # GaussianBlurTS(5), EventBM.cpp:68-72
             node.push_observation(t, obs[0], obs[1])                 # timeSurfaceCallback
             ok = node.data_transferring()                            # dataTransferring (event selection, 201 tf lookups)

@@ -242,33 +242,33 @@ int commit_frame(esvo_context* h, u32 off, u32 count, const double* pose_T_host,
 // pinned frame table and the event set (two ticks may be in flight)
 int run_fuse(esvo_context* h, int par, const double* T_world_obs, bool naive) {
   // frames newest -> oldest (esvo_Mapping.cpp:372-377)
+  // The table is laid out COMPACTLY for the frames in use -- [cum (nf + 1) | off (nf) | slot (nf)] -- so that one small
+  // upload carries it (max_frames is sized for the worst case of CONST_POINTS, one point per frame; a tick uses a handful).
   const size_t tab = 3 * (size_t)h->max_frames + 1;
-  u32* cum = h->h_fr_table + (size_t)par * tab;
-  u32* off = cum + (h->max_frames + 1);
-  u32* slot = off + h->max_frames;
-  u32 total = 0, nf = 0;
+  u32* host = h->h_fr_table + (size_t)par * tab;
+  u32 nf = 0;
+  for (size_t q = h->frames.size(); q-- > 0;)
+    if (h->frames[q].count) ++nf;  // empty frames contribute no point (DepthFusion::update loops over none)
+  if (nf > h->max_frames) FAIL(ESVO_ERR_CAPACITY, "too many non-empty frames in the fusion window");
+  u32* cum = host;
+  u32* off = host + (nf + 1);
+  u32* slot = off + nf;
+  u32 total = 0, i = 0;
   for (size_t q = h->frames.size(); q-- > 0;) {
     const FrameRec& f = h->frames[q];
-    if (f.count == 0) continue;  // empty frames contribute no point (DepthFusion::update loops over none)
-    if (nf >= h->max_frames) FAIL(ESVO_ERR_CAPACITY, "too many non-empty frames in the fusion window");
-    const u32 i = nf++;
+    if (f.count == 0) continue;
     cum[i] = total; off[i] = f.off; slot[i] = f.slot;
     total += f.count;
+    ++i;
   }
   cum[nf] = total;
   hipStream_t sb = h->stream_b;
   u32* dtab = h->d_fr_table + (size_t)par * tab;
-  // only the used prefixes of the three sub-tables (cum[0..nf], off[0..nf), slot[0..nf)): max_frames is sized for the
-  // worst case of CONST_POINTS (one point per frame), a tick uses a handful of entries
-  launch_upload_words(cum, dtab, sizeof(u32) * (nf + 1), sb);
-  if (nf) {
-    launch_upload_words(off, dtab + (h->max_frames + 1), sizeof(u32) * nf, sb);
-    launch_upload_words(slot, dtab + (h->max_frames + 1) + h->max_frames, sizeof(u32) * nf, sb);
-  }
+  launch_upload_words(host, dtab, sizeof(u32) * (3 * (size_t)nf + 1), sb);
   std::memcpy(h->T_world_frame, T_world_obs, sizeof(double) * 16);  // new DepthFrame at the TS pose (:268-272)
   FuseArgs a;
   a.win = h->d_win;
-  a.fr_cum = dtab; a.fr_off = dtab + (h->max_frames + 1); a.fr_slot = a.fr_off + h->max_frames;
+  a.fr_cum = dtab; a.fr_off = dtab + (nf + 1); a.fr_slot = a.fr_off + nf;
   a.n_frames = nf; a.n_pts = total;
   a.frame_pose_T = h->d_frame_pose_T; a.max_poses = h->max_poses;
   rigid_inverse(h->T_world_frame, a.T_frame_world);
