@@ -647,7 +647,9 @@ def cpu_baseline(rig, stream, p, ticks):
     except Exception:
         fast = False
     cores = os.cpu_count() or 1
-    n_fill, n_meas = int(p.max_fusion_frames), 5
+    n_meas = 5
+    n_fill = int(p.max_fusion_frames) if p.fusion_strategy == 0 else 5   # CONST_FRAMES: the window; CONST_POINTS: a few ticks
+    n_fill = max(min(n_fill, len(ticks) - n_meas), 0)
     use = ticks[: n_fill + n_meas]
     cap = None if cores >= 32 else 60000  # a small host maps a bounded sample of every tick's events
     ts = [oracle.OracleTS(rig.width, rig.height, fast=fast), oracle.OracleTS(rig.width, rig.height, fast=fast)]

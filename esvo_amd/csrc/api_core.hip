@@ -219,9 +219,11 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
     // The split LM launch (kernels_lm.hip, LmSplit) executes 10 % fewer vector instructions (3.47e8 against 3.85e8 per launch
     // of the bench workload) but does not shorten the tick (1.40 against 1.38 ms): what it removes are the partially masked
     // instructions of lockstep execution, and the tick is bound by the chip's throughput at its sustained f64 clock.  It is
-    // therefore OFF unless ESVO_LM_SPLIT=1; its scratch is allocated either way so that the switch works per handle.
+    // On the 1280x720 stress stream (4.9e5 events, 2.3e5 matches per tick: five times the waves) it does pay: 7.7 against
+    // 8.4 ms per tick (profiles/r03_split_launch_other_workloads.txt).  So: used for launches bounded by >= 400 000 events,
+    // ESVO_LM_SPLIT=0 / 1 forces it off / on.
     const char* es = std::getenv("ESVO_LM_SPLIT");
-    h->lm_use_split = es && std::atoi(es) == 1;
+    h->lm_split_mode = es ? (std::atoi(es) == 1 ? 1 : 0) : -1;
     CK(dalloc(&h->d_lm_fvec0, E * 7 * 16));
     CK(dalloc(&h->d_lm_fnorm0, E));
     CK(dalloc(&h->d_lm_meta, E));

@@ -87,7 +87,7 @@ int run_lm(esvo_context* h, u32 max_matches, int cull, bool dense, hipStream_t s
   a.tsL = h->d_obs[0]; a.tsR = h->d_obs[1];
   a.pose_T = h->d_pose_T; std::memcpy(a.T_world_obs, h->T_world_obs, sizeof(double) * 16);
   a.out_slots = h->d_pt_slots; a.out_flags = flags; a.cull = cull; a.dense = dense ? 1 : 0;
-  const bool split = h->lm_use_split && h->d_lm_fvec0 != nullptr;
+  const bool split = h->d_lm_fvec0 != nullptr && (h->lm_split_mode == 1 || (h->lm_split_mode < 0 && max_matches >= 400000u));
   a.split_fvec0 = split ? h->d_lm_fvec0 : nullptr; a.split_fnorm0 = h->d_lm_fnorm0; a.split_meta = h->d_lm_meta;
   a.split_order = h->d_lm_order; a.split_hist = h->d_lm_hist;
   hipEventRecord(h->evt[EV_LM0 + h->fpar * EV_FRONT_STRIDE], st);

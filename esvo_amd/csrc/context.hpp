@@ -142,7 +142,7 @@ struct esvo_context {
   u32* d_lm_meta = nullptr;
   u32* d_lm_order = nullptr;
   u32* d_lm_hist = nullptr;
-  bool lm_use_split = false;      // ESVO_LM_SPLIT=1: the split launch
+  int lm_split_mode = -1;         // the split launch: -1 by launch size (>= 400 000 events), 0 never, 1 always (ESVO_LM_SPLIT)
   DevPoint* d_pt_slots = nullptr;
   u32* d_pt_flags = nullptr;
   u32* d_pt_prefix = nullptr;
