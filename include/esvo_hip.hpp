@@ -235,6 +235,15 @@ inline void MappingAtTime(Context& ctx, const StampedTimeSurfaceObs& obs, const 
             "esvo_map_tick");
 }
 
+// esvo_MVStereo::MappingAtTime in MVStereoMode 1, PURE_BLOCK_MATCHING (esvo_MVStereo.cpp:383-432): block matching, vEMP2vDP and
+// naive_propagation of the window instead of refinement and fusion
+inline void MappingAtTimePureBlockMatching(Context& ctx, const StampedTimeSurfaceObs& obs, const StampTransformationMap& st_map) {
+  ctx.check(esvo_map_set_observation(ctx.handle(), obs.t_ns, obs.TS_left, obs.TS_right, obs.T_world_cam),
+            "esvo_map_set_observation");
+  ctx.check(esvo_map_tick_bm_only(ctx.handle(), obs.t_ns, st_map.stamps_ns.data(), st_map.T_world_virtual.data(), st_map.size()),
+            "esvo_map_tick_bm_only");
+}
+
 // esvo_core::core::RegProblemLM's evaluation side (esvo_core/src/core/RegProblemLM.cpp): the per-point loops of
 // setProblem (:44-56), operator() (:91-136) and df (:178-269) on the device.  The 6-DoF LM driver, the Cayley update and
 // the SVD re-orthonormalisation (getWarpingTransformation / addMotionUpdate, :328-364) stay with the caller, who passes
