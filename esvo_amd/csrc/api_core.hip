@@ -215,7 +215,12 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
   CK(dalloc(&h->d_matches2[0], E));
   CK(dalloc(&h->d_matches2[1], E));
   h->d_matches = h->d_matches2[0];
-  if (E > LM_SPLIT_MIN_EVENTS) {
+  {
+    const char* es0 = std::getenv("ESVO_LM_SPLIT");
+    h->lm_split_mode = es0 ? (std::atoi(es0) == 1 ? 1 : 0) : -1;
+  }
+  // (scratch of the split launch: 7 x 16 doubles per match -- only where the launch can be used)
+  if (E > LM_SPLIT_MIN_EVENTS && (h->lm_split_mode == 1 || (h->lm_split_mode < 0 && E >= 400000u))) {
     // The split LM launch (kernels_lm.hip, LmSplit) executes 10 % fewer vector instructions (3.47e8 against 3.85e8 per launch
     // of the bench workload) but does not shorten the tick (1.40 against 1.38 ms): what it removes are the partially masked
     // instructions of lockstep execution, and the tick is bound by the chip's throughput at its sustained f64 clock.  It is
