@@ -110,7 +110,8 @@ def test_device_ingest_of_the_hand_laid_bytes_equals_the_oracle(upenn_rig):
     path = os.path.join(GOLDEN, "wire_mini.bag")
     rig = upenn_rig
     for ignore_polarity in (1, 0):
-        p, _ = params.make_params(params.PRESETS["mvstereo_upenn"], rig, ignore_polarity=ignore_polarity)
+        # (no median filter: the fixture's handful of isolated events would not survive a 3x3 median -- every image would be 0)
+        p, _ = params.make_params(params.PRESETS["mvstereo_upenn"], rig, ignore_polarity=ignore_polarity, median_blur_kernel_size=0)
         # (1) the EventArray bytes through esvo_ts_push_event_array
         dev = lib.Esvo(p, rig)
         ots = O.OracleTS(rig.width, rig.height)
@@ -119,8 +120,9 @@ def test_device_ingest_of_the_hand_laid_bytes_equals_the_oracle(upenn_rig):
         ots.push(ev)
         for t in (1_600_000_000 * 10**9 + 3_000, 1_600_000_001 * 10**9 + 10, 1_600_000_001 * 10**9 + 5_000_000):
             g = dev.ts_render(0, t)
-            o = ots.render(t, ignore_polarity=bool(ignore_polarity), map_x=rig.left.map_x, map_y=rig.left.map_y)
-            assert np.array_equal(g, o) and (t < 1_600_000_000 * 10**9 + 5_000 or o.any())
+            o = ots.render(t, ignore_polarity=bool(ignore_polarity), median_k=0, map_x=rig.left.map_x, map_y=rig.left.map_y)
+            assert np.array_equal(g, o)
+            assert o.any() or t < 1_600_000_001 * 10**9   # (the three early events fall outside the rectified image)
         dev.close()
         # (2) the bag through esvo_ts_push_bag, message by message (until_ns)
         dev = lib.Esvo(p, rig)
@@ -131,11 +133,11 @@ def test_device_ingest_of_the_hand_laid_bytes_equals_the_oracle(upenn_rig):
         assert n1 == len(W.EVENTS_A)
         ots.push(O.decode_event_array(payloads[0])[0])
         t1 = 1_600_000_001 * 10**9 + 1_900_000
-        assert np.array_equal(dev.ts_render(0, t1), ots.render(t1, ignore_polarity=bool(ignore_polarity), map_x=rig.left.map_x, map_y=rig.left.map_y))
+        assert np.array_equal(dev.ts_render(0, t1), ots.render(t1, ignore_polarity=bool(ignore_polarity), median_k=0, map_x=rig.left.map_x, map_y=rig.left.map_y))
         n2 = dev.ts_push_bag(0, bag, "/davis/left/events")
         assert n2 == len(W.EVENTS_B)
         ots.push(O.decode_event_array(payloads[1])[0])
         t2 = 1_600_000_001 * 10**9 + 4_200_000
-        g, o = dev.ts_render(0, t2), ots.render(t2, ignore_polarity=bool(ignore_polarity), map_x=rig.left.map_x, map_y=rig.left.map_y)
+        g, o = dev.ts_render(0, t2), ots.render(t2, ignore_polarity=bool(ignore_polarity), median_k=0, map_x=rig.left.map_x, map_y=rig.left.map_y)
         assert np.array_equal(g, o) and o.any()
         dev.close()
