@@ -59,18 +59,42 @@ KERNEL_SYMBOLS = {"lm_refine": "lm_refine_kernel", "bm_match": "bm_match_kernel"
 R01_POINTS = {"dsec640x480": 180000, "upenn346x260": 24000, "hd1280x720": 185000}
 
 
-def make_workload(name, n_ticks, events_cap=0, r01_scene=False):
+def make_workload(name, n_ticks, events_cap=0, r01_scene=False, share=None):
     """(rig, stream, params, ticks) of a bench workload: n_ticks ticks of 10 ms after 60 ms of history.
-    r01_scene: round 1's thinning, swaying scene (only for like-for-like comparisons with round-1 figures)"""
+    r01_scene: round 1's thinning, swaying scene (only for like-for-like comparisons with round-1 figures).
+    share = (rank, barrier): an N-rank job generates the (identical, seeded) stream ONCE -- rank 0 writes the two event
+    arrays to a scratch file, the others read them after the barrier -- instead of N times in parallel on one host
+    (an 8-GPU weak-scaling run maps 200 ticks = 2 s of stream = 40 M events per camera: ~100 s of numpy per rank)."""
     wl = WORKLOADS[name]
     rig = calib.dataset_rig(wl["rig"])
     duration = HIST_S + (n_ticks + 1) * TICK_S
-    if r01_scene:
-        stream = synth.make_stream(rig, R01_POINTS[name], duration, wl["rho"][0], wl["rho"][1], seed=20250418 + 3, speed=wl["speed"])
-    else:
+    traj = None
+    if not r01_scene:
         traj = synth.Trajectory(speed=wl["speed"], sway=0.002, yaw=0.0005, t0_s=10.0)
-        stream = synth.make_stream(rig, wl["points"], duration, wl["rho"][0], wl["rho"][1], seed=20250418 + 3, speed=wl["speed"],
-                                   stationary=True, traj=traj)
+
+    def generate():
+        if r01_scene:
+            return synth.make_stream(rig, R01_POINTS[name], duration, wl["rho"][0], wl["rho"][1], seed=20250418 + 3, speed=wl["speed"])
+        return synth.make_stream(rig, wl["points"], duration, wl["rho"][0], wl["rho"][1], seed=20250418 + 3, speed=wl["speed"],
+                                 stationary=True, traj=traj)
+    if share is None:
+        stream = generate()
+    else:
+        import tempfile
+        rank, barrier = share
+        path = os.path.join(tempfile.gettempdir(), f"esvo_bench_stream_{name}_{n_ticks}_{int(r01_scene)}_{os.environ.get('MASTER_PORT', '0')}.npz")
+        if rank == 0:
+            stream = generate()
+            with open(path + ".tmp", "wb") as f:
+                np.savez(f, l=stream.ev_left, r=stream.ev_right, t=np.array([stream.t0_ns, stream.t1_ns], np.int64))
+            os.replace(path + ".tmp", path)
+        barrier()
+        if rank != 0:
+            z = np.load(path)
+            stream = synth.SynthStream(rig, z["l"], z["r"], traj or synth.Trajectory(speed=wl["speed"], t0_s=10.0), int(z["t"][0]), int(z["t"][1]), None)
+        barrier()
+        if rank == 0:
+            os.remove(path)
     ev_per_tick = int(len(stream.ev_left) / duration * TICK_S)
     cap = events_cap or int(ev_per_tick * 1.25) + 1024
     p, _ = params.make_params(params.PRESETS[wl["preset"]], rig, throughput_events=cap,
@@ -289,7 +313,8 @@ def main():
         # weak scaling: K timed (and Wm warm-up) ticks PER GPU in the tick-interleaved mode; the band mode splits every tick
         per_gpu = world if (world > 1 and shard_mode == "tick" and not strong) else 1
         n_ticks = (K + Wm) * per_gpu
-        rig, stream, p, ticks = make_workload(args.workload, n_ticks, args.events_per_tick, r01_scene=args.r01_scene)
+        rig, stream, p, ticks = make_workload(args.workload, n_ticks, args.events_per_tick, r01_scene=args.r01_scene,
+                                              share=(rank, dist.barrier) if dist else None)
         duration = HIST_S + (n_ticks + 1) * TICK_S
 
         native = (world > 1 and os.environ.get("ESVO_DIST_BACKEND", "nccl") == "nccl"
