@@ -874,6 +874,58 @@ extern "C" int esvo_map_tick_bm_only(esvo_handle h, uint64_t t_ns, const uint64_
   return ESVO_OK;
 }
 
+// The stage-wise seam of the same mode: what follows match_all_HyperThread in PURE_BLOCK_MATCHING (esvo_MVStereo.cpp:411-423)
+// on matches the caller holds (esvo_map_match gave them): vEMP2vDP, dqvDepthPoints_.push_back + pop to maxNumFusionFrames_,
+// naive_propagation of the window (newest first) into a new DepthFrame at the observation's pose.  Synchronous.
+extern "C" int esvo_map_fuse_matches_naive(esvo_handle h, const esvo_match_t* matches, size_t n, const double* pose_T, size_t m) {
+  if (!h || (n && !matches) || (m && !pose_T)) return ESVO_ERR_INVALID_ARG;
+  API_LOCK(h);
+  if (!h->obs_set) FAIL(ESVO_ERR_STATE, "esvo_map_set_observation has not been called");
+  if (h->sharded) FAIL(ESVO_ERR_STATE, "handle is sharded");
+  if (n > h->max_ev) FAIL(ESVO_ERR_CAPACITY, "more matches than max_events_per_tick");
+  if (m > h->max_poses) FAIL(ESVO_ERR_CAPACITY, "pose table larger than max_poses_per_tick");
+  for (size_t i = 0; i < n; ++i)
+    if (matches[i].pose_idx >= m) FAIL(ESVO_ERR_INVALID_ARG, "match refers to a pose outside the pose table");
+  HIPCHK(hipSetDevice(h->device));
+  int rc = flush_pending_tick(h);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(h->stream_l));
+  HIPCHK(hipStreamSynchronize(h->stream_b));  // the staging buffers and the ring may still be read by work in flight
+  const u32 n32 = (u32)n;
+  if (n) {
+    HIPCHK(hipMemcpyAsync(h->d_matches, matches, sizeof(esvo_match_t) * n, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_counters, &n32, sizeof(u32), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));  // n32 / matches are borrowed
+    launch_matches_to_points(h->d_matches, h->d_counters + 0, n32, h->d_pts_tmp, h->dp, h->stream);
+    HIPCHK(hipGetLastError());
+  }
+  u32 off;
+  rc = window_reserve(h, n32, &off);
+  if (rc) return rc;
+  rc = back_after_front(h);
+  if (rc) return rc;
+  if (n) HIPCHK(hipMemcpyAsync(h->d_win + off, h->d_pts_tmp, sizeof(DevPoint) * n, hipMemcpyDeviceToDevice, h->stream_b));
+  static const double ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  rc = commit_frame(h, off, n32, m ? pose_T : ident, (u32)m, 0, false);
+  if (rc) return rc;
+  while (h->n_window_frames > (size_t)h->prm.max_fusion_frames) pop_front_frame(h);
+  const int par = h->par;
+  h->par ^= 1;
+  HIPCHK(hipEventSynchronize(h->evt[EV_RG1 + par * EV_BACK_STRIDE]));
+  collect_back(h, par);
+  rc = run_fuse(h, par, h->T_world_obs, true);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(h->stream_b));
+  collect_back(h, par);
+  h->committed_t_ns = h->obs_t_ns;
+  h->stats.last_points = n32;
+  h->stats.last_window_frames = (u32)h->n_window_frames;
+  u32 np = 0;
+  for (auto& f : h->frames) np += f.count;
+  h->stats.last_window_points = np;
+  return ESVO_OK;
+}
+
 // ---- SGM initialisation -----------------------------------------------------------------------
 // Replaces esvo_Mapping::InitializationAtTime (esvo_Mapping.cpp:433-492) with the SGM branch of dataTransferring (:537-552):
 // cv::StereoSGBM on the UN-smoothed Time-Surface pair, the rectified pixels of the newest <= PROCESS_EVENT_NUM + 1 left

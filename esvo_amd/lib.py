@@ -24,7 +24,7 @@ SYMBOLS = [
     "esvo_default_params", "esvo_create", "esvo_destroy", "esvo_reset", "esvo_set_params", "esvo_last_error",
     "esvo_set_stream", "esvo_synchronize", "esvo_ts_push_events", "esvo_ts_push_event_array", "esvo_ts_render", "esvo_ts_render_forward", "esvo_map_set_observation",
     "esvo_map_match", "esvo_map_set_poses", "esvo_map_refine", "esvo_map_push_frame", "esvo_map_fuse",
-    "esvo_map_tick", "esvo_map_tick_bm_only", "esvo_map_tick_resident", "esvo_map_get_depth_points", "esvo_map_get_committed", "esvo_map_get_pointcloud_xyz", "esvo_map_get_last_frame",
+    "esvo_map_tick", "esvo_map_tick_bm_only", "esvo_map_fuse_matches_naive", "esvo_map_tick_resident", "esvo_map_get_depth_points", "esvo_map_get_committed", "esvo_map_get_pointcloud_xyz", "esvo_map_get_last_frame",
     "esvo_get_stats", "esvo_shard_set_band", "esvo_shard_exchange", "esvo_shard_tick_phase", "esvo_abi_sizes",
     "esvo_map_front", "esvo_map_front_frame", "esvo_map_push_frame_device", "esvo_map_fuse_async",
     "esvo_track_set_current", "esvo_track_get_images", "esvo_track_set_reference", "esvo_track_residuals", "esvo_track_jacobian",
@@ -105,6 +105,7 @@ def load():
     lib.esvo_map_tick.argtypes = [vp, u64, vp, vp, sz]
     lib.esvo_map_tick_resident.argtypes = [vp, u64, vp, vp, vp, sz]
     lib.esvo_map_tick_bm_only.argtypes = [vp, u64, vp, vp, sz]
+    lib.esvo_map_fuse_matches_naive.argtypes = [vp, vp, sz, vp, sz]
     lib.esvo_map_get_depth_points.argtypes = [vp, vp, sz, psz]
     lib.esvo_map_get_committed.argtypes = [vp, vp, sz, psz, C.POINTER(C.c_uint64)]
     lib.esvo_map_get_pointcloud_xyz.argtypes = [vp, vp, sz, psz]
@@ -365,6 +366,12 @@ class Esvo:
         st = np.ascontiguousarray(stamps, np.uint64)
         T = np.ascontiguousarray(poses, np.float64).reshape(-1, 16)
         self._ck(self.lib.esvo_map_tick_bm_only(self.h, int(t_ns), st.ctypes.data, T.ctypes.data, st.shape[0]))
+
+    def fuse_matches_naive(self, matches, poses=None):
+        """vEMP2vDP + window of maxNumFusionFrames + naive propagation on the given matches (stage-wise PURE_BLOCK_MATCHING)"""
+        mt = np.ascontiguousarray(matches, dtype=MATCH_DTYPE)
+        T = self._poses if poses is None else np.ascontiguousarray(poses, np.float64).reshape(-1, 16)
+        self._ck(self.lib.esvo_map_fuse_matches_naive(self.h, mt.ctypes.data, mt.shape[0], T.ctypes.data, T.shape[0]))
 
     def tick_resident(self, t_ns, T_world_cam, stamps, poses):
         """render both Time Surfaces at t_ns, take them as the observation, tick: one call"""

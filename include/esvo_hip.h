@@ -325,6 +325,10 @@ int esvo_map_tick(esvo_handle h, uint64_t t_ns, const uint64_t* pose_t_ns, const
  * DepthFusion::naive_propagation (DepthFusion.cpp:234-288) of every frame, newest first, into a new DepthFrame.  The map is
  * read with the usual output calls; nothing is culled, cleaned or regularised.  Synchronous. */
 int esvo_map_tick_bm_only(esvo_handle h, uint64_t t_ns, const uint64_t* pose_t_ns, const double* pose_T, size_t m);
+/* The stage-wise seam of that mode: what follows match_all_HyperThread (esvo_MVStereo.cpp:411-423) on the matches of
+ * esvo_map_match -- vEMP2vDP, dqvDepthPoints_.push_back(vdp_em) + pop to maxNumFusionFrames_, naive_propagation of the window.
+ * pose_T: the m virtual views the matches' pose_idx refer to (the st_map_ handed to esvo_map_match). */
+int esvo_map_fuse_matches_naive(esvo_handle h, const esvo_match_t* matches, size_t n, const double* pose_T, size_t m);
 /* One call for a node that hosts the Time Surfaces and the mapper on the same handle: esvo_ts_render of both cameras at
  * t_ns (device-resident, no download), esvo_map_set_observation on them with the pose T_world_cam, esvo_map_tick.  Same
  * results as the four calls; a reference-faithful tick is short enough for their host overhead to show. */

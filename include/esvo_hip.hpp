@@ -180,6 +180,12 @@ class DepthFusion {
     ctx_->check(esvo_map_push_frame(ctx_->handle(), vdp.data(), vdp.size(), st_map.T_world_virtual.data(), st_map.size()),
                 "esvo_map_push_frame");
   }
+  // esvo_MVStereo's PURE_BLOCK_MATCHING branch (esvo_MVStereo.cpp:411-423): vEMP2vDP, the window of maxNumFusionFrames_ frames
+  // and DepthFusion::naive_propagation of every frame -- on the matches of EventBM::match_all_HyperThread
+  void naivePropagation(const std::vector<EventMatchPair>& vEMP, const StampTransformationMap& st_map) {
+    ctx_->check(esvo_map_fuse_matches_naive(ctx_->handle(), vEMP.data(), vEMP.size(), st_map.T_world_virtual.data(), st_map.size()),
+                "esvo_map_fuse_matches_naive");
+  }
   // returns numFusionCount
   size_t update() {
     size_t n = 0;

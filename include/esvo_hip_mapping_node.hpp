@@ -77,6 +77,12 @@ class MappingNodeHip {
     // :307-339 -- block matching, refinement, culling
     ebm_.createMatchProblem(&obs_, &st_map_, &events_);
     ebm_.match_all_HyperThread(vEMP_);
+    if (pureBlockMatching(node_, 0)) {  // esvo_MVStereo in MVStereoMode 1 (esvo_MVStereo.cpp:411-432): no refinement, no fusion
+      vdp_.clear();
+      fusion_.naivePropagation(vEMP_, st_map_);
+      numFusionCount_ = 0;
+      return;
+    }
     solver_.solve(&vEMP_, &obs_, vdp_);
     solver_.pointCulling(vdp_, node_.stdVar_vis_threshold_, node_.cost_vis_threshold_, node_.invDepth_min_range_,
                          node_.invDepth_max_range_);
@@ -93,6 +99,9 @@ class MappingNodeHip {
   Context& context() { return *ctx_; }
 
  private:
+  // msm_ == PURE_BLOCK_MATCHING where the node class has that member (esvo_MVStereo.h:43-50,155); esvo_Mapping has none
+  template <class N> static auto pureBlockMatching(const N& n, int) -> decltype((void)n.msm_, bool()) { return (int)n.msm_ == 1; }
+  template <class N> static bool pureBlockMatching(const N&, long) { return false; }
   template <class M> static void row_major(const M& T, double out[16]) {
     for (int i = 0; i < 4; ++i)
       for (int j = 0; j < 4; ++j) out[i * 4 + j] = T(i, j);

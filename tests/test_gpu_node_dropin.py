@@ -69,3 +69,37 @@ def test_reference_node_with_the_hip_binding_equals_the_reference_node(name, mvs
             assert iou >= 0.97 and _agreement(a, b, sc.rig.width) >= 0.97, (k, iou, _agreement(a, b, sc.rig.width))
         else:
             assert iou >= 0.97 and rmse < 1e-4, (k, iou, rmse)
+
+
+@pytest.mark.parametrize("name", ["upenn", "rpg"])
+def test_mvstereo_node_in_block_matching_only_mode_with_the_hip_binding(name):
+    """esvo_MVStereo in MVStereoMode 1, PURE_BLOCK_MATCHING (esvo_MVStereo.cpp:383-432): the same node object once with its own
+    MappingAtTime (block matching, vEMP2vDP, naive_propagation of the window on the host) and once with the binding, whose
+    branch for that mode calls esvo_map_match + esvo_map_fuse_matches_naive.  Matched events identical; maps element by
+    element -- row / col / age exact and the ZNCC residual to 1e-12 on all but the handful of cells where that difference
+    flips naive_propagation's `residual <` between two near-equal costs (see tests/test_gpu_ref.py), inverse depth to 1e-12."""
+    lib = os.path.join(_REF, "libesvo_ref_mvstereo_hip.so")
+    if not os.path.exists(lib):
+        pytest.skip("oracle/_ref/*_hip.so not built (needs the reference tree: build container only)")
+    from oracle import ref as R
+    sc = S.Scenario(name)
+    ticks, st = sc.inputs(), sc.stream()
+    p = sc.params
+    cpu = R.RefNode(p, sc.rig, st.pose, mvstereo=True, extra={"MVStereoMode": 1})
+    dev = R.RefNode(p, sc.rig, st.pose, mvstereo=True, hip=True, extra={"MVStereoMode": 1})
+    for node in (cpu, dev):
+        node.push_events(st.ev_left)
+    for k, tk in enumerate(ticks):
+        for node in (cpu, dev):
+            node.push_observation(tk["t"], tk["tsL"], tk["tsR"])
+            assert node.data_transferring() and node.obs_time() == tk["t"]
+        cpu.mapping_at_time()
+        dev.hip_mapping_at_time()
+        assert np.array_equal(cpu.matched_events(), dev.hip_matched_events())
+        assert len(dev.hip_newest_frame()) == 0          # no refinement in this mode: the frame is the match list
+        a, b = dev.hip_get_map(), cpu.get_map()
+        assert len(a) == len(b) and len(a) > 0, (k, len(a), len(b))
+        same = (a["row"] == b["row"]) & (a["col"] == b["col"]) & (a["age"] == b["age"]) & (np.abs(a["residual"] - b["residual"]) <= 1e-12)
+        assert same.mean() >= 0.995, (k, same.mean())
+        assert np.allclose(a["inv_depth"][same], b["inv_depth"][same], rtol=1e-12, atol=0)
+        assert np.allclose(a["variance"][same], b["variance"][same], rtol=1e-12, atol=0)
