@@ -53,7 +53,7 @@ WORKLOADS = {
 
 KERNEL_NAMES = ["ts_scatter", "ts_render", "bm_match", "lm_refine", "fuse", "clean", "regularize"]
 KERNEL_SYMBOLS = {"lm_refine": "lm_refine_kernel", "bm_match": "bm_match_kernel", "fuse": "fuse_cells_kernel",
-                  "regularize": "reg_apply_kernel", "ts_render": "ts_decay_kernel", "ts_scatter": "ts_scatter_kernel"}
+                  "regularize": "reg_apply_kernel", "ts_render": "ts_render_fused_kernel", "ts_scatter": "ts_scatter_kernel"}
 
 
 R01_POINTS = {"dsec640x480": 180000, "upenn346x260": 24000, "hd1280x720": 185000}

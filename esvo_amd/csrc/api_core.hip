@@ -167,6 +167,14 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
     const char* e = std::getenv("ESVO_LM_STREAM");
     h->lm_split = !(e && std::atoi(e) == 0);
   }
+  if (const char* e1 = std::getenv("ESVO_ONE_STREAM")) {  // A/B only: the three stages in one queue (no cross-queue hand-offs)
+    if (std::atoi(e1) == 1) {
+      hipStreamDestroy(h->stream_b);
+      h->stream_b = h->stream;
+      h->one_stream = true;
+      h->lm_split = false;
+    }
+  }
   CK(hipStreamCreateWithFlags(&h->stream_t, hipStreamNonBlocking));
   CK(hipStreamCreateWithFlags(&h->stream_i, hipStreamNonBlocking));
   // calibration -> device
@@ -341,7 +349,7 @@ int esvo_destroy(esvo_handle h) {
                   (void*)h->sgm.d2key, (void*)h->d_sgm_img[0], (void*)h->d_sgm_img[1], (void*)h->d_sgm_disp, (void*)h->d_sgm_pair, (void*)h->d_sgm_T})
     if (q) hipFree(q);
   if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
-  if (h->stream_b) hipStreamDestroy(h->stream_b);
+  if (h->stream_b && !h->one_stream) hipStreamDestroy(h->stream_b);
   if (h->stream_l) { hipStreamSynchronize(h->stream_l); hipStreamDestroy(h->stream_l); }
   if (h->stream_t) { hipStreamSynchronize(h->stream_t); hipStreamDestroy(h->stream_t); }
   if (h->stream_i) { hipStreamSynchronize(h->stream_i); hipStreamDestroy(h->stream_i); }
@@ -428,6 +436,7 @@ int esvo_set_stream(esvo_handle h, void* hip_stream) {
   HIPCHK(hipStreamSynchronize(h->stream_b));
   if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
   h->stream = reinterpret_cast<hipStream_t>(hip_stream);
+  if (h->one_stream) h->stream_b = h->stream;
   h->own_stream = false;
   return ESVO_OK;
 }

@@ -53,6 +53,7 @@ struct esvo_context {
   // below alias one of two buffers each (kernels capture the pointer at launch, so work in flight keeps its own).
   hipStream_t stream_l = nullptr;
   bool lm_split = true;           // ESVO_LM_STREAM=0: everything of the front stage on `stream`
+  bool one_stream = false;       // ESVO_ONE_STREAM=1 (A/B): stream_b aliases stream
   bool split_now = false;         // set by esvo_map_tick around its front stage: only the lazy tick path splits
   uint8_t* d_obs2[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
   int obs_par = 0;

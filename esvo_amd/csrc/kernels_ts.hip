@@ -2,8 +2,8 @@
 //
 //   K1 ts_scatter : esvo_time_surface eventsCallback / EventQueueMat::insertEvent
 //                   (esvo_time_surface/src/TimeSurface.cpp:403-425, TimeSurface.h:39-50)
-//   K2 ts_decay + ts_median_remap : TimeSurface::createTimeSurfaceAtTime, BACKWARD mode
-//                   (TimeSurface.cpp:52-152): exp decay -> x255 -> u8 -> 3x3 median -> rectifying remap
+//   K2 ts_render_fused : TimeSurface::createTimeSurfaceAtTime, BACKWARD mode
+//                   (TimeSurface.cpp:52-152): exp decay -> x255 -> u8 -> 3x3 median -> rectifying remap, one LDS-staged pass
 //   ts_decay_f64 + ts_forward_gather : the same function in FORWARD mode (TimeSurface.cpp:85-116)
 //   gaussian5     : TimeSurfaceObservation::GaussianBlurTS(5) (TimeSurfaceObservation.h:107-116)
 //
@@ -11,6 +11,7 @@
 // Surface of Active Events: one u64 per pixel holding (t_ns << 1 | polarity) of the newest
 // event, updated with atomicMax.  The host only scatters events with ts < T before rendering at
 // T, which is exactly what getMostRecentEventBeforeT (TimeSurface.h:52-75) returns.
+#include <cstdlib>
 #include "common.hpp"
 
 namespace esvo {
@@ -56,36 +57,34 @@ void launch_ts_scatter_segs(const TsScatterSegs& g, int n_seg, int W, int H, hip
   hipLaunchKernelGGL(ts_scatter_segs_kernel, dim3((u32)blocks, (u32)n_seg), dim3(256), 0, s, g, W, H);
 }
 
-// ---- K2a: decay + quantise ------------------------------------------------------------------------
+// ---- K2: decay + quantise ------------------------------------------------------------------------
 // TimeSurface.cpp:65-127.  dt is formed like ros::Duration::toSec() (Appendix A-17); the u8
 // conversion is cv::Mat::convertTo = saturate_cast<uchar>(cvRound(v)) = round-half-even.
-__device__ inline void ts_decay_px(const u64* __restrict__ sae, uint8_t* __restrict__ raw, int n_px, u64 t_ns,
-                                   double decay_sec, int ignore_polarity) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_px) return;
-  const u64 key = sae[i];
+// The quantised value only depends on which side of a half-integer 255 * exp(-dt / tau) falls, so an f32 evaluation
+// (v_exp_f32) decides it whenever its result is further from the half-integer than its error bound allows; the f64
+// evaluation -- the reference's arithmetic, ~150 instructions -- runs for the lanes that are not.  Error of the short
+// form: the exponent x = dt * kf carries <= 1.8e-7 |x| relative (u64 -> f32, kf in f32, the product, the * log2 e inside
+// __expf), v_exp_f32 and the final product 2 ulp, so |g32 - g| <= 255 e^x (1.8e-7 |x| + 1.2e-7) <= 4.8e-5 for every
+// x <= 0; the guard band is 5e-4, ten times that.  About 0.1 % of the pixels (6 % of the waves) take both paths.
+struct TsDecay { u64 t_ns; double decay_sec; float kf; int ignore_polarity; };  // kf = -1e-9 / decay_sec
+__device__ inline int ts_decay_u8(u64 key, const TsDecay& d) {
   const u64 te = key >> 1;
-  double v = 0.0;
-  if (key != 0 && te < t_ns && ns_to_sec(te) > 0) {
-    const double dt = duration_to_sec(t_ns, te);
-    double e = exp(-dt / decay_sec);
-    if (!ignore_polarity) e *= (key & 1ull) ? 1.0 : -1.0;
-    v = e;
-  }
-  const double g = ignore_polarity ? 255.0 * v : 255.0 * (v + 1.0) / 2.0;
-  int q = (int)rint(g);
-  q = q < 0 ? 0 : (q > 255 ? 255 : q);
-  raw[i] = (uint8_t)q;
-}
-__global__ void __launch_bounds__(256) ts_decay_kernel(const u64* __restrict__ sae, uint8_t* __restrict__ raw, int n_px,
-                                                       u64 t_ns, double decay_sec, int ignore_polarity) {
-  ts_decay_px(sae, raw, n_px, t_ns, decay_sec, ignore_polarity);
-}
-__global__ void __launch_bounds__(256) ts_decay_pair_kernel(TsPair c, int n_px, u64 t_ns, double decay_sec, int ignore_polarity) {
-  ts_decay_px(c.sae[blockIdx.y], c.raw[blockIdx.y], n_px, t_ns, decay_sec, ignore_polarity);
+  // no event before T (TimeSurface.cpp:71-73); ns_to_sec(te) > 0 <=> te != 0.  The empty value is 0, or 127.5 -> 128.
+  if (!(key > 1ull && te < d.t_ns)) return d.ignore_polarity ? 0 : 128;
+  const float e32 = __expf((float)(d.t_ns - te) * d.kf);
+  const float g32 = d.ignore_polarity ? 255.0f * e32 : 127.5f * ((key & 1ull) ? 1.0f + e32 : 1.0f - e32);
+  const float q32 = rintf(g32);
+  if (fabsf(g32 - q32) < 0.5f - 5e-4f) return (int)q32;  // in [0, 255]: e32 in [0, 1]
+  const double dt = duration_to_sec(d.t_ns, te);
+  double e = exp(-dt / d.decay_sec);
+  if (!d.ignore_polarity) e *= (key & 1ull) ? 1.0 : -1.0;
+  const double g = d.ignore_polarity ? 255.0 * e : 255.0 * (e + 1.0) / 2.0;
+  const int q = (int)rint(g);
+  return q < 0 ? 0 : (q > 255 ? 255 : q);
 }
 
-// ---- K2b: 3x3 median (BORDER_REPLICATE) fused with the fixed-point bilinear remap --------------------
+// ---- 3x3 median (BORDER_REPLICATE) and the fixed-point bilinear remap, tap by tap from a raw image in memory: the last
+// step of FORWARD mode, whose raw image is the output of the splat ---------------------------------------------------------
 __device__ inline void cswap(int& a, int& b) { int lo = min(a, b), hi = max(a, b); a = lo; b = hi; }
 __device__ inline int median9(int p0, int p1, int p2, int p3, int p4, int p5, int p6, int p7, int p8) {
   // 19-exchange median network
@@ -134,31 +133,149 @@ __global__ void __launch_bounds__(256) ts_median_remap_kernel(const uint8_t* __r
   if (x >= W || y >= H) return;
   out[y * W + x] = (uint8_t)ts_median_remap_px(raw, fixmap, W, H, median_k, x, y);
 }
-// both cameras (blockIdx.z); out2 (may be null): a second copy of the surface, the mapper's observation when it is not smoothed
-__global__ void __launch_bounds__(256) ts_median_remap_pair_kernel(TsPair c, int W, int H, int median_k) {
-  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (x >= W || y >= H) return;
+// ---- K2, fused: decay -> u8 -> 3x3 median -> rectifying remap in ONE pass, staged through LDS ----------------------------
+// A workgroup renders a TSF_TX x TSF_TY tile of the RECTIFIED surface (threads 32 x 8, two rows each).  It first reads its
+// pixels' fixed-point source coordinates and reduces the bounding box of the bilinear taps that carry weight; then
+//   1. the decayed, quantised raw surface over that box (+ the median's one-pixel ring, coordinates clamped to the image =
+//      BORDER_REPLICATE) goes from the SAE into LDS -- one 8-byte stamp and one exp per staged raw pixel, once;
+//   2. the 3x3 median of the box goes LDS -> LDS, once per source pixel instead of once per bilinear tap (the two-kernel
+//      version above evaluates four medians = 36 global byte loads per output pixel and writes / re-reads the raw image);
+//   3. every thread blends its four taps from LDS with the exact 15-bit weights.
+// The intermediate raw image never exists in memory: 8 B (stamp) + 8 B (map entry) read and 1-2 B written per output pixel.
+// A tile whose box does not fit the staging buffers (it cannot for the lens models of the shipped rigs; a wildly distorted
+// map could) takes the direct path: the same arithmetic, taps evaluated from the SAE one by one.
+#define TSF_TX 32
+#define TSF_TY 16
+#define TSF_CAP 2560   // staged raw pixels (e.g. 64 x 40: the 32 x 16 tile sheared by the rectification, + taps, + the ring)
+__device__ inline int ts_raw_at(const u64* __restrict__ sae, int W, int H, int x, int y, const TsDecay& d) {
+  x = min(max(x, 0), W - 1); y = min(max(y, 0), H - 1);
+  return ts_decay_u8(sae[(size_t)y * W + x], d);
+}
+__device__ inline int ts_median_tap_direct(const u64* __restrict__ sae, int W, int H, int x, int y, int median_k, const TsDecay& d) {
+  if (x < 0 || x >= W || y < 0 || y >= H) return 0;
+  if (median_k <= 0) return ts_raw_at(sae, W, H, x, y, d);
+  int v[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) v[k] = ts_raw_at(sae, W, H, x + k % 3 - 1, y + k / 3 - 1, d);
+  return median9(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8]);
+}
+__global__ void __launch_bounds__(256) ts_render_fused_kernel(TsPair c, int W, int H, TsDecay d, int median_k, int stage_cap) {
+  __shared__ uint8_t s_raw[TSF_CAP];
+  __shared__ uint8_t s_med[TSF_CAP];
+  __shared__ int s_bb[4];
   const int cam = blockIdx.z;
-  const uint8_t v = (uint8_t)ts_median_remap_px(c.raw[cam], c.fixmap[cam], W, H, median_k, x, y);
-  c.out[cam][y * W + x] = v;
-  if (c.out2[cam]) c.out2[cam][y * W + x] = v;
+  const u64* __restrict__ sae = c.sae[cam];
+  const int2* __restrict__ fixmap = c.fixmap[cam];
+  const int t = threadIdx.x, tx = t & 31, ty = t >> 5;
+  const int x = blockIdx.x * TSF_TX + tx;
+  if (t < 4) s_bb[t] = (t < 2) ? 0x7fffffff : (int)0x80000000;
+  __syncthreads();
+  int ix[2], iy[2], fx[2], fy[2];
+  bool in[2];
+  int bx0 = 0x7fffffff, by0 = 0x7fffffff, bx1 = (int)0x80000000, by1 = (int)0x80000000;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int y = blockIdx.y * TSF_TY + ty + 8 * k;
+    in[k] = x < W && y < H;
+    ix[k] = iy[k] = fx[k] = fy[k] = 0;
+    if (in[k]) {
+      const int2 m = fixmap ? fixmap[(size_t)y * W + x] : make_int2(x << 5, y << 5);
+      ix[k] = m.x >> 5; iy[k] = m.y >> 5; fx[k] = m.x & 31; fy[k] = m.y & 31;
+      // the taps that carry weight (the others are never read: ts_median_remap_px), clipped to the image (outside: constant 0)
+      const int lx = max(ix[k], 0), hx = min(ix[k] + (fx[k] ? 1 : 0), W - 1);
+      const int ly = max(iy[k], 0), hy = min(iy[k] + (fy[k] ? 1 : 0), H - 1);
+      if (lx <= hx && ly <= hy) { bx0 = min(bx0, lx); bx1 = max(bx1, hx); by0 = min(by0, ly); by1 = max(by1, hy); }
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    bx0 = min(bx0, __shfl_xor(bx0, d)); by0 = min(by0, __shfl_xor(by0, d));
+    bx1 = max(bx1, __shfl_xor(bx1, d)); by1 = max(by1, __shfl_xor(by1, d));
+  }
+  if ((t & 63) == 0) { atomicMin(&s_bb[0], bx0); atomicMin(&s_bb[1], by0); atomicMax(&s_bb[2], bx1); atomicMax(&s_bb[3], by1); }
+  __syncthreads();
+  // the box is workgroup-uniform: kept in scalar registers, and so is everything derived from it
+  const int mx0 = __builtin_amdgcn_readfirstlane(s_bb[0]), my0 = __builtin_amdgcn_readfirstlane(s_bb[1]);
+  const int mx1 = __builtin_amdgcn_readfirstlane(s_bb[2]), my1 = __builtin_amdgcn_readfirstlane(s_bb[3]);
+  const bool any = mx0 <= mx1;
+  const int hal = median_k > 0 ? 1 : 0;
+  const int mw = any ? mx1 - mx0 + 1 : 0, mh = any ? my1 - my0 + 1 : 0;
+  const int rw = mw + 2 * hal, rh = mh + 2 * hal;
+  const bool staged = any && (long long)rw * rh <= stage_cap;
+  const uint8_t* med = s_raw;
+  if (staged) {
+    {  // element i = t, t + 256, ... of the rw x rh box: (rx, ry) advance by (256 % rw, 256 / rw), one division per thread
+      const int sx = 256 % rw, sy = 256 / rw;
+      int ry = t / rw, rx = t - ry * rw;
+      for (int i = t; i < rw * rh; i += 256) {
+        s_raw[i] = (uint8_t)ts_raw_at(sae, W, H, mx0 - hal + rx, my0 - hal + ry, d);
+        rx += sx; ry += sy;
+        if (rx >= rw) { rx -= rw; ++ry; }
+      }
+    }
+    __syncthreads();
+    if (hal) {
+      const int sx = 256 % mw, sy = 256 / mw;
+      int my = t / mw, mx = t - my * mw;
+      for (int i = t; i < mw * mh; i += 256) {
+        const uint8_t* r0 = s_raw + my * rw + mx;
+        const uint8_t* r1 = r0 + rw;
+        const uint8_t* r2 = r1 + rw;
+        s_med[i] = (uint8_t)median9(r0[0], r0[1], r0[2], r1[0], r1[1], r1[2], r2[0], r2[1], r2[2]);
+        mx += sx; my += sy;
+        if (mx >= mw) { mx -= mw; ++my; }
+      }
+      __syncthreads();
+      med = s_med;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    if (!in[k]) continue;
+    const int y = blockIdx.y * TSF_TY + ty + 8 * k;
+    auto tap = [&](int sx, int sy) -> int {
+      if (sx < 0 || sx >= W || sy < 0 || sy >= H) return 0;  // BORDER_CONSTANT 0 of cv::remap
+      if (staged) return med[(sy - my0) * mw + (sx - mx0)];
+      return ts_median_tap_direct(sae, W, H, sx, sy, median_k, d);
+    };
+    const int w00 = (32 - fx[k]) * (32 - fy[k]) * 32, w01 = fx[k] * (32 - fy[k]) * 32, w10 = (32 - fx[k]) * fy[k] * 32,
+              w11 = fx[k] * fy[k] * 32;
+    int acc = 0;
+    if (w00) acc += w00 * tap(ix[k], iy[k]);
+    if (w01) acc += w01 * tap(ix[k] + 1, iy[k]);
+    if (w10) acc += w10 * tap(ix[k], iy[k] + 1);
+    if (w11) acc += w11 * tap(ix[k] + 1, iy[k] + 1);
+    const uint8_t v = (uint8_t)((acc + 16384) >> 15);
+    c.out[cam][(size_t)y * W + x] = v;
+    if (c.out2[cam]) c.out2[cam][(size_t)y * W + x] = v;
+  }
 }
 
+// ESVO_TS_STAGE_CAP (tests only): a smaller staging capacity, down to 0 = every tile on the direct path
+static int ts_stage_cap() {
+  static const int cap = [] {
+    const char* e = std::getenv("ESVO_TS_STAGE_CAP");
+    const int v = e ? std::atoi(e) : TSF_CAP;
+    return v < 0 ? 0 : (v > TSF_CAP ? TSF_CAP : v);
+  }();
+  return cap;
+}
+static TsDecay ts_decay_args(u64 t_ns, double decay_sec, int ignore_polarity) {
+  return TsDecay{t_ns, decay_sec, (float)(-1e-9 / decay_sec), ignore_polarity};
+}
 void launch_ts_render(const u64* d_sae, const int2* d_fixmap, uint8_t* d_raw, uint8_t* d_out, int W, int H, u64 t_ns,
                       double decay_sec, int ignore_polarity, int median_k, hipStream_t s) {
-  const int n = W * H;
-  hipLaunchKernelGGL(ts_decay_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_sae, d_raw, n, t_ns, decay_sec,
-                     ignore_polarity);
-  hipLaunchKernelGGL(ts_median_remap_kernel, dim3((W + 63) / 64, (H + 3) / 4), dim3(256), 0, s, d_raw, d_fixmap, d_out, W,
-                     H, median_k);
+  (void)d_raw;  // the raw image is an intermediate of FORWARD mode only
+  TsPair c{};
+  c.sae[0] = d_sae; c.fixmap[0] = d_fixmap; c.out[0] = d_out;
+  hipLaunchKernelGGL(ts_render_fused_kernel, dim3((W + TSF_TX - 1) / TSF_TX, (H + TSF_TY - 1) / TSF_TY, 1), dim3(256), 0, s, c, W, H,
+                     ts_decay_args(t_ns, decay_sec, ignore_polarity), median_k, ts_stage_cap());
 }
 
 void launch_ts_render_pair(const TsPair& c, int W, int H, u64 t_ns, double decay_sec, int ignore_polarity, int median_k,
                            hipStream_t s) {
-  const int n = W * H;
-  hipLaunchKernelGGL(ts_decay_pair_kernel, dim3((n + 255) / 256, 2), dim3(256), 0, s, c, n, t_ns, decay_sec, ignore_polarity);
-  hipLaunchKernelGGL(ts_median_remap_pair_kernel, dim3((W + 63) / 64, (H + 3) / 4, 2), dim3(256), 0, s, c, W, H, median_k);
+  hipLaunchKernelGGL(ts_render_fused_kernel, dim3((W + TSF_TX - 1) / TSF_TX, (H + TSF_TY - 1) / TSF_TY, 2), dim3(256), 0, s, c, W, H,
+                     ts_decay_args(t_ns, decay_sec, ignore_polarity), median_k, ts_stage_cap());
 }
 
 // ---- FORWARD mode (TimeSurface.cpp:85-116) ------------------------------------------------------------------------------

@@ -8,6 +8,8 @@ Bars (stated per test):
     mode (the reference's own summation order is unspecified: Eigen reductions).
   * north_star tolerance: inverse-depth RMSE < 1e-4 against the literal oracle.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -126,6 +128,22 @@ def test_time_surface_polarity_and_no_median():
         g = dev.ts_render(0, T)
         o = ots.render(T, ignore_polarity=bool(ignore_pol), median_k=med, map_x=rig.left.map_x, map_y=rig.left.map_y)
         assert np.array_equal(g, o), (ignore_pol, med, np.count_nonzero(g != o))
+
+
+@pytest.mark.parametrize("cap", [0, 900])
+def test_time_surface_direct_path_of_the_fused_render(cap):
+    """ts_render_fused_kernel stages a tile's source box in LDS; a box that does not fit takes the direct path (taps evaluated
+    from the SAE one by one).  No shipped lens model produces such a box, so the staging capacity is lowered instead
+    (ESVO_TS_STAGE_CAP, read once per process: 0 = every tile direct, 900 = a mix on the distorted rigs) and the Time-Surface
+    parity tests are run again in a process of their own."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ESVO_TS_STAGE_CAP=str(cap))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-m", "gpu", "-q", "-x",
+                        "-k", "time_surface_bit_exact or polarity_and_no_median or epoch_timestamps"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-2000:]
 
 
 def test_time_surface_epoch_timestamps():
