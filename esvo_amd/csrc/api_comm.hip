@@ -222,7 +222,7 @@ int finish_round(esvo_context* h) {
     // a frame did not fit its block: every rank sees the same counts, grows its blocks alike and gathers again
     // (the owners' frames are still in place: nothing was enqueued behind the wait above)
     c->stride_pts = (u32)std::min<u64>((u64)h->max_ev, max_n + max_n / 4);
-    HIPCHK(hipStreamSynchronize(h->stream_l));
+    HIPCHK(hipStreamSynchronize(h->stream_l)); HIPCHK(hipStreamSynchronize(h->stream_l1));
   HIPCHK(hipStreamSynchronize(h->stream_b));
     rc = comm_alloc(h);
     if (rc) return rc;
@@ -344,7 +344,7 @@ int esvo_comm_destroy(esvo_handle h) {
   if (!h->comm) return ESVO_OK;
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipStreamSynchronize(h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream_l));
+  HIPCHK(hipStreamSynchronize(h->stream_l)); HIPCHK(hipStreamSynchronize(h->stream_l1));
   HIPCHK(hipStreamSynchronize(h->stream_b));
   comm_release(h);
   return ESVO_OK;

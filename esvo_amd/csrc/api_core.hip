@@ -164,6 +164,9 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
     if (h->prio_note[2] != 12345) pl = h->prio_note[2];
     if (std::getenv("ESVO_PRIO_PRINT")) fprintf(stderr, "[esvo] stream priority range: lowest %d .. highest %d; LM %d\n", lo, hi, pl);
     CK(hipStreamCreateWithPriority(&h->stream_l, hipStreamNonBlocking, pl));
+    CK(hipStreamCreateWithPriority(&h->stream_l1, hipStreamNonBlocking, pl));
+    if (const char* eq = std::getenv("ESVO_LM_QUEUES")) h->lm_queues = std::atoi(eq) == 1 ? 1 : 2;
+    if (const char* em = std::getenv("ESVO_LM_QUEUES_MAX_EVENTS")) h->lm_two_max = (u32)std::strtoul(em, nullptr, 10);  // A/B only
     const char* e = std::getenv("ESVO_LM_STREAM");
     h->lm_split = !(e && std::atoi(e) == 0);
   }
@@ -244,9 +247,14 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
     CK(dalloc(&h->d_lm_hist, 2 * 32 * 64));  // kernels_lm.hip: 2 x LM_SPLIT_STRIPES x LM_SPLIT_BINS
     CK(hipMemset(h->d_lm_hist, 0, sizeof(u32) * 2 * 32 * 64));
   }
-  CK(dalloc(&h->d_pt_slots, E));
-  CK(dalloc(&h->d_pt_flags, E));
-  CK(dalloc(&h->d_pt_prefix, E));
+  for (int k = 0; k < 2; ++k) {
+    CK(dalloc(&h->d_pt_slots2[k], E));
+    CK(dalloc(&h->d_pt_flags2[k], E));
+    CK(dalloc(&h->d_pt_prefix2[k], E));
+    CK(dalloc(&h->d_scan_tmp_l2[k], scan_scratch_elems(std::max(E, npx)) + 8));
+  }
+  h->d_pt_slots = h->d_pt_slots2[0]; h->d_pt_flags = h->d_pt_flags2[0]; h->d_pt_prefix = h->d_pt_prefix2[0];
+  h->d_scan_tmp_l = h->d_scan_tmp_l2[0];
   CK(dalloc(&h->d_pts_tmp, E));
   CK(dalloc(&h->d_stage[0], E));
   CK(dalloc(&h->d_stage[1], E));
@@ -260,7 +268,6 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
   CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_pin), sizeof(double) * 2 * ((size_t)h->max_poses * 17 + 16)));
   CK(dalloc(&h->d_scan_tmp, scan_scratch_elems(std::max(E, npx)) + 8));
   CK(dalloc(&h->d_scan_tmp_b, scan_scratch_elems(std::max(E, npx)) + 8));
-  CK(dalloc(&h->d_scan_tmp_l, scan_scratch_elems(std::max(E, npx)) + 8));
   CK(dalloc(&h->d_cnt_b, 8));
   CK(hipMemset(h->d_cnt_b, 0, sizeof(u32) * 8));
   CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_cnt_b), sizeof(u32) * 8 * 3));
@@ -322,13 +329,14 @@ int esvo_destroy(esvo_handle h) {
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
   if (h->stream_l) hipStreamSynchronize(h->stream_l);
+  if (h->stream_l1) hipStreamSynchronize(h->stream_l1);
   if (h->stream_b) hipStreamSynchronize(h->stream_b);
   comm_release(h);
   void* ptrs[] = {h->d_lut, h->d_mask, h->d_fixmap[0], h->d_fixmap[1], h->d_sae[0], h->d_sae[1], h->d_raw, h->d_raw1, h->d_fwd_lut[0], h->d_fwd_lut[1], h->d_fwd_off[0], h->d_fwd_off[1],
                   h->d_fwd_src[0], h->d_fwd_src[1], h->d_fwd_val, h->d_ts[0],
                   h->d_ts[1], h->d_ring[0], h->d_ring[1], h->d_obs2[0][0], h->d_obs2[0][1], h->d_obs2[1][0], h->d_obs2[1][1], h->d_obs_tmp,
                   h->d_pose_T2[0], h->d_pose_T2[1], h->d_scan_tmp_b, h->d_cnt_b, h->d_tick_ev, h->d_match_slots, h->d_match_flags, h->d_match_prefix,
-                  h->d_matches2[0], h->d_matches2[1], h->d_scan_tmp_l, h->d_pt_slots, h->d_pt_flags, h->d_pt_prefix, h->d_pts_tmp, h->d_stage[0], h->d_stage[1], h->d_counters2[0], h->d_counters2[1], h->d_scan_tmp,
+                  h->d_matches2[0], h->d_matches2[1], h->d_scan_tmp_l2[0], h->d_scan_tmp_l2[1], h->d_pt_slots2[0], h->d_pt_slots2[1], h->d_pt_flags2[0], h->d_pt_flags2[1], h->d_pt_prefix2[0], h->d_pt_prefix2[1], h->d_pts_tmp, h->d_stage[0], h->d_stage[1], h->d_counters2[0], h->d_counters2[1], h->d_scan_tmp,
                   h->d_win, h->d_frame_pose_T, h->d_fr_table, h->d_prop, h->d_cell_count, h->d_cell_offset,
                   h->d_cell_fill, h->d_rec_ids, h->d_map, h->d_map2, h->d_owner_max, h->d_owner_min, h->d_exp_flags,
                   h->d_exp_prefix, h->d_export, h->d_export_cell, h->d_reg_ab, h->d_reg_cd, h->d_bucket, h->d_cell_list, h->d_own_w, h->d_lkeep, h->d_codes,
@@ -351,6 +359,7 @@ int esvo_destroy(esvo_handle h) {
   if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
   if (h->stream_b && !h->one_stream) hipStreamDestroy(h->stream_b);
   if (h->stream_l) { hipStreamSynchronize(h->stream_l); hipStreamDestroy(h->stream_l); }
+  if (h->stream_l1) { hipStreamSynchronize(h->stream_l1); hipStreamDestroy(h->stream_l1); }
   if (h->stream_t) { hipStreamSynchronize(h->stream_t); hipStreamDestroy(h->stream_t); }
   if (h->stream_i) { hipStreamSynchronize(h->stream_i); hipStreamDestroy(h->stream_i); }
   for (void* q : {(void*)h->d_trk_blur, (void*)h->d_trk_neg, (void*)h->d_trk_du, (void*)h->d_trk_dv, (void*)h->d_trk_xyz, (void*)h->d_trk_pts,
@@ -369,7 +378,7 @@ int esvo_reset(esvo_handle h) {
   { int rcp = flush_pending_tick(h); if (rcp) return rcp; }
   const size_t npx = (size_t)h->W * h->H;
   HIPCHK(hipStreamSynchronize(h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream_l));
+  HIPCHK(hipStreamSynchronize(h->stream_l)); HIPCHK(hipStreamSynchronize(h->stream_l1));
   HIPCHK(hipStreamSynchronize(h->stream_b));
   HIPCHK(hipStreamSynchronize(h->stream_t));
   for (int cam = 0; cam < 2; ++cam) {
@@ -390,7 +399,7 @@ int esvo_reset(esvo_handle h) {
   h->obs_set = false;
   h->n_pose = 0;
   HIPCHK(hipStreamSynchronize(h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream_l));
+  HIPCHK(hipStreamSynchronize(h->stream_l)); HIPCHK(hipStreamSynchronize(h->stream_l1));
   HIPCHK(hipStreamSynchronize(h->stream_b));
   h->back_pending[0] = h->back_pending[1] = false;
   h->committed_t_ns = 0;
@@ -432,7 +441,7 @@ int esvo_set_stream(esvo_handle h, void* hip_stream) {
   std::lock_guard<std::mutex> lp0(h->mu_push[0]), lp1(h->mu_push[1]);  // a pusher may be draining the front stream
   { int rcp = flush_pending_tick(h); if (rcp) return rcp; }
   HIPCHK(hipStreamSynchronize(h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream_l));
+  HIPCHK(hipStreamSynchronize(h->stream_l)); HIPCHK(hipStreamSynchronize(h->stream_l1));
   HIPCHK(hipStreamSynchronize(h->stream_b));
   if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
   h->stream = reinterpret_cast<hipStream_t>(hip_stream);
@@ -446,7 +455,7 @@ int esvo_synchronize(esvo_handle h) {
   API_LOCK(h);
   { int rcp = flush_pending_tick(h); if (rcp) return rcp; }
   HIPCHK(hipStreamSynchronize(h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream_l));
+  HIPCHK(hipStreamSynchronize(h->stream_l)); HIPCHK(hipStreamSynchronize(h->stream_l1));
   HIPCHK(hipStreamSynchronize(h->stream_b));
   return ESVO_OK;
 }

@@ -79,6 +79,11 @@ int run_match(esvo_context* h, const esvo_event_t* d_ev, u64 first, u64 cap, int
 }
 
 // LM (+cull) over the compacted matches: point records + flags in solver-slot order (dense: in list order)
+// the LM stage's own buffers follow the front parity (context.hpp: two LM queues)
+static void set_lm_parity(esvo_context* h) {
+  h->d_pt_slots = h->d_pt_slots2[h->fpar]; h->d_pt_flags = h->d_pt_flags2[h->fpar]; h->d_pt_prefix = h->d_pt_prefix2[h->fpar];
+  h->d_scan_tmp_l = h->d_scan_tmp_l2[h->fpar];
+}
 int run_lm(esvo_context* h, u32 max_matches, int cull, bool dense, hipStream_t st = nullptr) {
   if (!st) st = h->stream;
   u32* flags = dense ? h->d_lkeep : h->d_pt_flags;  // the kernel writes every flag of its launch range
@@ -454,14 +459,14 @@ int esvo_map_push_frame(esvo_handle h, const esvo_depth_point_t* pts, size_t n, 
   u32 off;
   int rc = window_reserve(h, (u32)n, &off);
   if (rc) return rc;
-  HIPCHK(hipStreamSynchronize(h->stream_l));
+  HIPCHK(hipStreamSynchronize(h->stream_l)); HIPCHK(hipStreamSynchronize(h->stream_l1));
   HIPCHK(hipStreamSynchronize(h->stream_b));  // the ring space may have been read by a fusion still in flight
   if (n) HIPCHK(hipMemcpyAsync(h->d_win + off, pts, sizeof(esvo_depth_point_t) * n, hipMemcpyHostToDevice, h->stream));
   static const double ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   rc = commit_frame(h, off, (u32)n, m ? pose_T : ident, (u32)m);
   if (rc) return rc;
   HIPCHK(hipStreamSynchronize(h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream_l));
+  HIPCHK(hipStreamSynchronize(h->stream_l)); HIPCHK(hipStreamSynchronize(h->stream_l1));
   HIPCHK(hipStreamSynchronize(h->stream_b));
   return ESVO_OK;
 }
@@ -481,7 +486,7 @@ int esvo_map_fuse(esvo_handle h, size_t* n_fusions) {
   rc = run_fuse(h, par, h->T_world_obs);
   if (rc) return rc;
   h->committed_t_ns = h->obs_t_ns;
-  HIPCHK(hipStreamSynchronize(h->stream_l));
+  HIPCHK(hipStreamSynchronize(h->stream_l)); HIPCHK(hipStreamSynchronize(h->stream_l1));
   HIPCHK(hipStreamSynchronize(h->stream_b));
   collect_back(h, par);
   h->stats.last_window_frames = (u32)h->n_window_frames;
@@ -537,6 +542,7 @@ int tick_phase0(esvo_context* h, uint64_t t_ns, const uint64_t* pose_t_ns, const
   h->fpar ^= 1;
   h->d_matches = h->d_matches2[h->fpar];    // the tick's own match list and counters (the LM stage of the previous tick
   h->d_counters = h->d_counters2[h->fpar];  // may still be running on its own)
+  set_lm_parity(h);
   esvo_context::TickState& tk = h->tk[h->fpar];
   tk.n = n; tk.off = 0; tk.points = 0; tk.t_ns = t_ns;
   tk.lm_stream = h->stream;
@@ -569,8 +575,12 @@ int tick_phase0(esvo_context* h, uint64_t t_ns, const uint64_t* pose_t_ns, const
     hipStream_t sl = h->stream;
     if (h->split_now) {  // the LM stage on its own stream, behind this tick's matches
       HIPCHK(hipEventRecord(h->evt[EV_A1 + h->fpar * EV_FRONT_STRIDE], h->stream));
-      HIPCHK(hipStreamWaitEvent(h->stream_l, h->evt[EV_A1 + h->fpar * EV_FRONT_STRIDE], 0));
-      sl = h->stream_l;
+      // launches in the latency-bound (wide) layout alternate between the two LM queues; the split launch's scratch and
+      // the throughput layout (which fills the chip by itself) stay on one
+      const bool split_scratch = h->d_lm_fvec0 != nullptr && (h->lm_split_mode == 1 || (h->lm_split_mode < 0 && n >= 400000u));
+      const bool two = h->lm_queues == 2 && n <= h->lm_two_max && !split_scratch;
+      sl = (two && h->fpar) ? h->stream_l1 : h->stream_l;
+      HIPCHK(hipStreamWaitEvent(sl, h->evt[EV_A1 + h->fpar * EV_FRONT_STRIDE], 0));
     }
     tk.lm_stream = sl;
     rc = run_lm(h, n, 1, false, sl);
@@ -728,7 +738,7 @@ int finalize_tick_stats(esvo_context* h) {
   const bool tick_done = h->stats_pending;
   h->stats_pending = false;
   HIPCHK(hipStreamSynchronize(h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream_l));
+  HIPCHK(hipStreamSynchronize(h->stream_l)); HIPCHK(hipStreamSynchronize(h->stream_l1));
   HIPCHK(hipStreamSynchronize(h->stream_b));
   collect_ts_timing(h);
   collect_back(h, h->par);
@@ -817,6 +827,7 @@ extern "C" int esvo_map_tick_bm_only(esvo_handle h, uint64_t t_ns, const uint64_
   h->fpar ^= 1;
   h->d_matches = h->d_matches2[h->fpar];
   h->d_counters = h->d_counters2[h->fpar];
+  set_lm_parity(h);
   HIPCHK(hipStreamWaitEvent(h->stream, h->evt[EV_RG1 + h->par * EV_BACK_STRIDE], 0));
   hipEventRecord(h->evt[EV_T0 + h->fpar * EV_FRONT_STRIDE], h->stream);
   const u32* sel = nullptr;
@@ -889,7 +900,7 @@ extern "C" int esvo_map_fuse_matches_naive(esvo_handle h, const esvo_match_t* ma
   HIPCHK(hipSetDevice(h->device));
   int rc = flush_pending_tick(h);
   if (rc) return rc;
-  HIPCHK(hipStreamSynchronize(h->stream_l));
+  HIPCHK(hipStreamSynchronize(h->stream_l)); HIPCHK(hipStreamSynchronize(h->stream_l1));
   HIPCHK(hipStreamSynchronize(h->stream_b));  // the staging buffers and the ring may still be read by work in flight
   const u32 n32 = (u32)n;
   if (n) {
@@ -969,7 +980,7 @@ extern "C" int esvo_map_init_sgm(esvo_handle h, const uint8_t* ts_left, const ui
       img[cam] = h->d_ts[cam];
     }
   }
-  HIPCHK(hipStreamSynchronize(h->stream_l));
+  HIPCHK(hipStreamSynchronize(h->stream_l)); HIPCHK(hipStreamSynchronize(h->stream_l1));
   HIPCHK(hipStreamSynchronize(h->stream_b));  // the DepthMap and the window are rebuilt below
   launch_sgbm(img[0], img[1], h->sgm, h->d_sgm_disp, h->W, h->H, h->stream);
   HIPCHK(hipGetLastError());
@@ -1026,7 +1037,7 @@ extern "C" int esvo_map_init_sgm(esvo_handle h, const uint8_t* ts_left, const ui
   launch_sgm_naive(h->d_win + off, count, h->d_sgm_T, h->d_owner_max, h->d_sgm_pair, h->d_sgm_pair + 4 * (size_t)h->max_ev, h->d_cnt_b + 4,
                    h->d_scan_tmp_b, h->d_map, h->dp, h->stream_b);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(h->stream_l));
+  HIPCHK(hipStreamSynchronize(h->stream_l)); HIPCHK(hipStreamSynchronize(h->stream_l1));
   HIPCHK(hipStreamSynchronize(h->stream_b));
   h->d_map_cur = h->d_map;
   h->committed_t_ns = h->obs_t_ns;
@@ -1304,7 +1315,7 @@ int esvo_map_get_debug_images(esvo_handle h, double age_max_range, uint8_t* inv_
     launch_debug_image(h->d_map_cur, h->d_viz_owner, h->d_viz_bgr, h->d_viz_jet, im.type, im.mx, im.mn, im.t1, im.t2, h->dp, h->stream_b);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(im.out, h->d_viz_bgr, npx * 3, hipMemcpyDeviceToHost, h->stream_b));
-    HIPCHK(hipStreamSynchronize(h->stream_l));
+    HIPCHK(hipStreamSynchronize(h->stream_l)); HIPCHK(hipStreamSynchronize(h->stream_l1));
   HIPCHK(hipStreamSynchronize(h->stream_b));
   }
   return ESVO_OK;

@@ -245,6 +245,7 @@ struct LmArgs {
   u32* split_order;
   u32* split_hist;
 };
+constexpr u32 LM_TWO_QUEUES_MAX_EVENTS = 40000u;  // = LM_WIDE_MAX (kernels_lm.hip): launches that use the wide layout
 constexpr u32 LM_SPLIT_MIN_EVENTS = 40000u;  // launches bounded by fewer events use the wide layout (LM_WIDE_MAX), never the split
 void launch_lm_refine(const LmArgs& a, const DevParams& p, u32* n_solved, hipStream_t s);
 void launch_compact_points(const DevPoint* slots, const u32* flags, const u32* prefix, const u32* n_in,

@@ -52,6 +52,13 @@ struct esvo_context {
   // beside it on `stream`.  What the two stages share is double-buffered by POINTER SWAP: d_obs / d_matches / d_counters
   // below alias one of two buffers each (kernels capture the pointer at launch, so work in flight keeps its own).
   hipStream_t stream_l = nullptr;
+  // A SECOND queue for the LM stage (round 3): the LM stages of consecutive lazy ticks alternate between stream_l and
+  // stream_l1 by the tick's parity, so the head of tick k+1's launch fills the chip while the tail of tick k's -- a few
+  // long dependent chains -- drains.  Used for launches in the latency-bound (wide) layout; everything the stage writes
+  // (d_pt_slots / d_pt_flags / d_pt_prefix / the scan scratch, besides the buffers listed above) exists once per parity.
+  hipStream_t stream_l1 = nullptr;
+  int lm_queues = 2;              // ESVO_LM_QUEUES=1: one LM queue (A/B)
+  u32 lm_two_max = esvo::LM_TWO_QUEUES_MAX_EVENTS;  // launches bounded by more events stay on one queue
   bool lm_split = true;           // ESVO_LM_STREAM=0: everything of the front stage on `stream`
   bool one_stream = false;       // ESVO_ONE_STREAM=1 (A/B): stream_b aliases stream
   bool split_now = false;         // set by esvo_map_tick around its front stage: only the lazy tick path splits
@@ -59,7 +66,8 @@ struct esvo_context {
   int obs_par = 0;
   esvo_match_t* d_matches2[2] = {nullptr, nullptr};
   u32* d_counters2[2] = {nullptr, nullptr};
-  u32* d_scan_tmp_l = nullptr;    // scan scratch of the LM stage
+  u32* d_scan_tmp_l = nullptr;    // scan scratch of the LM stage (of the current parity)
+  u32* d_scan_tmp_l2[2] = {nullptr, nullptr};
   hipStream_t stream_i = nullptr;  // event ingest (H2D into the ring): staging new events never waits for a running tick
   bool own_stream = false;
   int prio_note[3] = {0, 0, 12345};  // stream priority range of the device / explicit LM priority (ESVO_PRIOS, A/B only)
@@ -144,9 +152,12 @@ struct esvo_context {
   u32* d_lm_order = nullptr;
   u32* d_lm_hist = nullptr;
   int lm_split_mode = -1;         // the split launch: -1 by launch size (>= 400 000 events), 0 never, 1 always (ESVO_LM_SPLIT)
-  DevPoint* d_pt_slots = nullptr;
+  DevPoint* d_pt_slots = nullptr;   // LM output by slot + keep flags + their scan: alias one of two sets (front parity)
   u32* d_pt_flags = nullptr;
   u32* d_pt_prefix = nullptr;
+  DevPoint* d_pt_slots2[2] = {nullptr, nullptr};
+  u32* d_pt_flags2[2] = {nullptr, nullptr};
+  u32* d_pt_prefix2[2] = {nullptr, nullptr};
   DevPoint* d_pts_tmp = nullptr;  // stage-wise refine output
   DevPoint* d_stage[2] = {nullptr, nullptr};  // a lazily completed tick's frame (by parity) until its count is known
   u32* d_counters = nullptr;      // [0] n_matches [1] n_points [2] n_solved [3] n_fusion [4] n_records [5] n_map
