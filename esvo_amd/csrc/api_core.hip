@@ -165,7 +165,7 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
     if (std::getenv("ESVO_PRIO_PRINT")) fprintf(stderr, "[esvo] stream priority range: lowest %d .. highest %d; LM %d\n", lo, hi, pl);
     CK(hipStreamCreateWithPriority(&h->stream_l, hipStreamNonBlocking, pl));
     CK(hipStreamCreateWithPriority(&h->stream_l1, hipStreamNonBlocking, pl));
-    if (const char* eq = std::getenv("ESVO_LM_QUEUES")) h->lm_queues = std::atoi(eq) == 1 ? 1 : 2;
+    if (const char* eq = std::getenv("ESVO_LM_QUEUES")) h->lm_queues = std::atoi(eq) == 1 ? 1 : (std::atoi(eq) == 2 ? 2 : 0);
     if (const char* em = std::getenv("ESVO_LM_QUEUES_MAX_EVENTS")) h->lm_two_max = (u32)std::strtoul(em, nullptr, 10);  // A/B only
     const char* e = std::getenv("ESVO_LM_STREAM");
     h->lm_split = !(e && std::atoi(e) == 0);
@@ -390,6 +390,8 @@ int esvo_reset(esvo_handle h) {
   }
   h->sh_first = 0;
   h->trk_read_pending = false;
+  h->ema_lm_ms = h->ema_back_ms = 0.f;
+  h->lm_two_on = false;
   h->frames.clear();
   h->n_window_frames = 0;
   std::fill(h->slot_used.begin(), h->slot_used.end(), 0);

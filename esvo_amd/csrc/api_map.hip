@@ -160,6 +160,7 @@ void collect_back(esvo_context* h, int par) {
   s.ms_regularization = rg;
   s.ms_kernel[4] = fu; s.ms_kernel[5] = cl; s.ms_kernel[6] = rg;
   s.sum_ms_kernel[4] += fu; s.sum_ms_kernel[5] += cl; s.sum_ms_kernel[6] += rg;
+  h->ema_back_ms = h->ema_back_ms > 0.f ? 0.75f * h->ema_back_ms + 0.25f * (fu + cl + rg) : fu + cl + rg;
 }
 
 // place a frame of n points in the window ring (frames stay contiguous: [oldest frame, newest frame) modulo the wrap)
@@ -578,7 +579,9 @@ int tick_phase0(esvo_context* h, uint64_t t_ns, const uint64_t* pose_t_ns, const
       // launches in the latency-bound (wide) layout alternate between the two LM queues; the split launch's scratch and
       // the throughput layout (which fills the chip by itself) stay on one
       const bool split_scratch = h->d_lm_fvec0 != nullptr && (h->lm_split_mode == 1 || (h->lm_split_mode < 0 && n >= 400000u));
-      const bool two = h->lm_queues == 2 && n <= h->lm_two_max && !split_scratch;
+      if (h->ema_lm_ms > 0.f && h->ema_back_ms > 0.f)
+        h->lm_two_on = h->ema_lm_ms > (h->lm_two_on ? 1.2f : 1.5f) * h->ema_back_ms;
+      const bool two = (h->lm_queues == 2 || (h->lm_queues == 0 && h->lm_two_on)) && n <= h->lm_two_max && !split_scratch;
       sl = (two && h->fpar) ? h->stream_l1 : h->stream_l;
       HIPCHK(hipStreamWaitEvent(sl, h->evt[EV_A1 + h->fpar * EV_FRONT_STRIDE], 0));
     }
@@ -674,6 +677,7 @@ int tick_phase1_collect(esvo_context* h, int fp) {
     hipEventElapsedTime(&s.ms_kernel[3], h->evt[EV_LM0 + o], h->evt[EV_LM1 + o]);
     s.sum_ms_kernel[2] += s.ms_kernel[2];
     s.sum_ms_kernel[3] += s.ms_kernel[3];
+    h->ema_lm_ms = h->ema_lm_ms > 0.f ? 0.75f * h->ema_lm_ms + 0.25f * s.ms_kernel[3] : s.ms_kernel[3];
   }
   if (h->sharded && n_points) {
     h->xchg_ptr = h->d_win + tk.off;

@@ -57,7 +57,15 @@ struct esvo_context {
   // long dependent chains -- drains.  Used for launches in the latency-bound (wide) layout; everything the stage writes
   // (d_pt_slots / d_pt_flags / d_pt_prefix / the scan scratch, besides the buffers listed above) exists once per parity.
   hipStream_t stream_l1 = nullptr;
-  int lm_queues = 2;              // ESVO_LM_QUEUES=1: one LM queue (A/B)
+  // Whether the second queue pays depends on what else the tick holds: where the LM launch is much longer than the fusion
+  // stage (346x260, no regulariser: 0.37 ms against 0.12) two launches in flight raise the rate by 18 %; where the two are
+  // of similar length (DSEC's reference-faithful tick: 0.25 against 0.30 ms) the fusion stage is the bottleneck either way
+  // and a second resident LM launch only takes its registers (0.33 -> 0.375 ms).  So the handle decides from its own stage
+  // timings (HIP events of the completed ticks, smoothed): on above 1.5 x, off below 1.2 x.  Scheduling only -- results do
+  // not depend on it.  ESVO_LM_QUEUES = 1 / 2 forces never / always.
+  int lm_queues = 0;              // 0 auto, 1 never, 2 always
+  float ema_lm_ms = 0.f, ema_back_ms = 0.f;
+  bool lm_two_on = false;
   u32 lm_two_max = esvo::LM_TWO_QUEUES_MAX_EVENTS;  // launches bounded by more events stay on one queue
   bool lm_split = true;           // ESVO_LM_STREAM=0: everything of the front stage on `stream`
   bool one_stream = false;       // ESVO_ONE_STREAM=1 (A/B): stream_b aliases stream
