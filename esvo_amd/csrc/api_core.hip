@@ -280,8 +280,12 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
   h->max_frames = (u32)std::max(params->max_fusion_frames + 2, 512);
   if (params->fusion_strategy == ESVO_FUSION_CONST_POINTS)
     h->max_frames = std::max(h->max_frames, (u32)(1.5 * params->max_fusion_points) + 4u);
-  h->n_pose_slots = h->max_frames + 1;
-  h->slot_used.assign(h->n_pose_slots, 0);
+  // pose-table slots of the window's non-empty frames: max_frames + 1 in the worst case (CONST_POINTS with one point per
+  // frame: 1 GB of tables at 20 000 points x 256 poses), a handful in practice -- allocated for 1024 frames and doubled on
+  // demand (alloc_pose_slot, api_map.hip).  ESVO_POSE_SLOTS0 (tests): a smaller first allocation.
+  h->slot_used.assign(h->max_frames + 1, 0);
+  h->n_pose_slots = std::min<u32>(h->max_frames + 1, 1024u);
+  if (const char* e0 = std::getenv("ESVO_POSE_SLOTS0")) h->n_pose_slots = std::min<u32>(h->max_frames + 1, (u32)std::max(1, std::atoi(e0)));
   CK(dalloc(&h->d_frame_pose_T, (size_t)h->n_pose_slots * h->max_poses * 16));
   CK(dalloc(&h->d_fr_table, 2 * (3 * (size_t)h->max_frames + 1)));
   CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_fr_table), sizeof(u32) * 2 * (3 * (size_t)h->max_frames + 1)));

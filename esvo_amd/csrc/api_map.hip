@@ -191,7 +191,27 @@ int window_reserve(esvo_context* h, u32 n, u32* off_out) {
 int alloc_pose_slot(esvo_context* h, u32* slot) {
   for (u32 i = 0; i < h->n_pose_slots; ++i)
     if (!h->slot_used[i]) { h->slot_used[i] = 1; *slot = i; return ESVO_OK; }
-  FAIL(ESVO_ERR_CAPACITY, "no free pose-table slot (too many frames in the fusion window)");
+  // every allocated slot holds a frame of the window: double the table (a rare, synchronising step; kernels take the pointer
+  // at launch, so nothing in flight may still read the old one)
+  const u32 cap = h->max_frames + 1;
+  if (h->n_pose_slots >= cap) FAIL(ESVO_ERR_CAPACITY, "no free pose-table slot (too many frames in the fusion window)");
+  const u32 n_new = (u32)std::min<u64>(cap, 2ull * h->n_pose_slots);
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream_l)); HIPCHK(hipStreamSynchronize(h->stream_l1));
+  HIPCHK(hipStreamSynchronize(h->stream_b));
+  double* d_new = nullptr;
+  const size_t per = (size_t)h->max_poses * 16 * sizeof(double);
+  if (hipMalloc(reinterpret_cast<void**>(&d_new), per * n_new) != hipSuccess) {
+    (void)hipGetLastError();
+    FAIL(ESVO_ERR_CAPACITY, "out of device memory growing the pose-table slots");
+  }
+  HIPCHK(hipMemcpy(d_new, h->d_frame_pose_T, per * h->n_pose_slots, hipMemcpyDeviceToDevice));
+  HIPCHK(hipFree(h->d_frame_pose_T));
+  h->d_frame_pose_T = d_new;
+  *slot = h->n_pose_slots;
+  h->slot_used[*slot] = 1;
+  h->n_pose_slots = n_new;
+  return ESVO_OK;
 }
 void pop_front_frame(esvo_context* h) {
   FrameRec& f = h->frames.front();

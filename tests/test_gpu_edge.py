@@ -435,3 +435,16 @@ def test_refused_tick_leaves_no_trace(dsec_rig, dsec_stream):
     og = m.get_map()
     assert len(og) > 50
     _same_map(dev.get_map(), og)
+
+
+def test_pose_table_slots_grow_on_demand():
+    """The pose tables of the window's frames live in slots allocated for 1024 frames and doubled when the window holds more
+    (CONST_POINTS may hold one frame per point).  ESVO_POSE_SLOTS0=2 makes the first allocation two slots, so the
+    back-to-back tests above (up to 17 small frames in the window, compared with the oracle) grow it three times."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ESVO_POSE_SLOTS0="2")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_edge.py"), "-m", "gpu", "-q", "-x",
+                        "-k", "back_to_back or sparse_stretch"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-2000:]
