@@ -176,6 +176,7 @@ def committed_profile(workload):
                         out["hbm"].setdefault(k, {})[row["counter"]] = float(row["avg_value_per_dispatch_KB"]) * 1024.0
                     else:
                         out["sq"].setdefault(k, {})[row["counter"]] = float(row["avg_value_per_dispatch"])
+                        out.setdefault("sq_dispatches", {})[k] = int(row.get("dispatches") or 0)
         return out
     return None
 
@@ -201,6 +202,21 @@ def profile_figures(prof, kernel, launch_ms):
             if "SQ_ACTIVE_INST_VALU" in v and "SQ_BUSY_CYCLES" in v:
                 valu["busy_frac_profiled"] = (v["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0) / (v["SQ_BUSY_CYCLES"] / 32.0)
     return traffic, valu
+
+
+def whole_tick_valu(prof, tick_ms):
+    """VALU wave-instructions of EVERY kernel of a tick (committed SQ_INSTS_VALU pass: per-launch average x launches per tick,
+    the LM kernel's dispatch count = the ticks of that pass) against what the chip can issue in this run's tick time.  The
+    three stages overlap on three queues, so this -- not one kernel's rate -- is the figure that bounds the tick."""
+    if prof is None or not prof.get("sq_dispatches"):
+        return None
+    ticks = max([n for k, n in prof["sq_dispatches"].items() if "lm_refine_kernel" in k] or [0])
+    if ticks <= 0 or tick_ms <= 0:
+        return None
+    total = sum(v["SQ_INSTS_VALU"] * prof["sq_dispatches"].get(k, 0) for k, v in prof["sq"].items() if "SQ_INSTS_VALU" in v) / ticks
+    rate = total / (tick_ms * 1e-3)
+    return {"wave_insts_per_tick": total, "achieved": rate, "peak": VALU_PEAK_INST_S, "frac": rate / VALU_PEAK_INST_S,
+            "note": "all kernels of a tick; peak as above (2.4 GHz; the chip sustains ~1.75 GHz under this f64 load, DESIGN.md section 5)"}
 
 
 def map_sha1(mp_):
@@ -494,6 +510,9 @@ def main():
         },
     }
 
+    whole = whole_tick_valu(prof, dt / K * 1e3 / per_gpu)
+    if valu is not None and whole is not None:
+        valu["whole_tick"] = whole
     out["roofline"]["traffic_note"] = TRAFFIC_NOTE
     # the same figures for the Time-Surface stage (the HBM-bound one: 24 B/event, 9 B/pixel) and both single-kernel slots
     n_scat = (int(st.events_scattered[0]) + int(st.events_scattered[1])) - (int(M["base"].events_scattered[0]) + int(M["base"].events_scattered[1]))
