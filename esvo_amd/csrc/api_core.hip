@@ -295,10 +295,10 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
   CK(dalloc(&h->d_cell_offset, npx));
   CK(dalloc(&h->d_cell_fill, npx));
   CK(dalloc(&h->d_rec_ids, (size_t)h->win_cap * 9));
-  CK(dalloc(&h->d_map, npx));
-  CK(dalloc(&h->d_map2, npx));
-  CK(hipMemset(h->d_map, 0, sizeof(MapCell) * npx));
-  CK(hipMemset(h->d_map2, 0, sizeof(MapCell) * npx));
+  CK(hipMalloc(reinterpret_cast<void**>(&h->d_map), map_buffer_bytes(npx)));  // cells + their dense flags (common.hpp: map_flags)
+  CK(hipMalloc(reinterpret_cast<void**>(&h->d_map2), map_buffer_bytes(npx)));  // cells + their dense flags (common.hpp: map_flags)
+  CK(hipMemset(h->d_map, 0, map_buffer_bytes(npx)));
+  CK(hipMemset(h->d_map2, 0, map_buffer_bytes(npx)));
   h->d_map_cur = h->d_map;
   CK(dalloc(&h->d_owner_max, npx));
   CK(dalloc(&h->d_owner_min, npx));
@@ -399,8 +399,8 @@ int esvo_reset(esvo_handle h) {
   h->frames.clear();
   h->n_window_frames = 0;
   std::fill(h->slot_used.begin(), h->slot_used.end(), 0);
-  HIPCHK(hipMemsetAsync(h->d_map, 0, sizeof(MapCell) * npx, h->stream));
-  HIPCHK(hipMemsetAsync(h->d_map2, 0, sizeof(MapCell) * npx, h->stream));
+  HIPCHK(hipMemsetAsync(h->d_map, 0, map_buffer_bytes(npx), h->stream));
+  HIPCHK(hipMemsetAsync(h->d_map2, 0, map_buffer_bytes(npx), h->stream));
   h->d_map_cur = h->d_map;
   h->obs_set = false;
   h->n_pose = 0;

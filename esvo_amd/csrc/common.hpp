@@ -137,10 +137,17 @@ struct MapCell {
   u64 age;
   u32 row, col;
   u32 seq;     // creation order (id of the record that created the element)
-  u32 flags;
+  u32 unused_; // (the flags lived here until round 3)
 };
 static_assert(sizeof(MapCell) == 104, "MapCell layout");
 enum { CELL_ALIVE = 1u, CELL_GRID = 2u };
+// The cells' flags are a dense u32 array BEHIND the cell array, in the same allocation (a DepthMap buffer is ncell cells +
+// ncell words): the passes that visit every cell -- the untouched-cell reset, clean, the regulariser's view and tile set-up,
+// the export -- read 4 contiguous bytes per cell instead of one word of every 104-byte record (32 MB of lines for a 640x480
+// map that holds 12 k elements on a reference-faithful tick).
+__host__ __device__ inline u32* map_flags(MapCell* map, int ncell) { return reinterpret_cast<u32*>(map + ncell); }
+__host__ __device__ inline const u32* map_flags(const MapCell* map, int ncell) { return reinterpret_cast<const u32*>(map + ncell); }
+constexpr size_t map_buffer_bytes(size_t ncell) { return ncell * (sizeof(MapCell) + sizeof(u32)); }
 
 // Window point (what DepthFusion::update reads from a stored DepthPoint)
 typedef esvo_depth_point_t DevPoint;

@@ -211,7 +211,7 @@ __global__ void __launch_bounds__(SCAN_B) cell_scan_reduce_kernel(const u32* __r
     s += n;
     const int row = cell / W;
     if (row >= band0 && row < band1) {
-      if (n == 0) map[cell].flags = 0;
+      if (n == 0) map_flags(map, ncell)[cell] = 0;
       else atomicAdd(&h[fuse_bucket(n)], 1u);
     }
   }
@@ -436,8 +436,8 @@ __global__ void __launch_bounds__(FUSE_BLOCK, FUSE_WAVES) fuse_cells_kernel(Fuse
       }
     }
   }
-  c.flags = CELL_ALIVE | CELL_GRID;
   a.map[cell] = c;
+  map_flags(a.map, p.W * p.H)[cell] = CELL_ALIVE | CELL_GRID;
   if (numFusion) atomicAdd(a.d_num_fusion, numFusion);
 }
 
@@ -491,17 +491,18 @@ __global__ void __launch_bounds__(256) clean_kernel(MapCell* __restrict__ map, D
   const int cell = blockIdx.x * blockDim.x + threadIdx.x;
   if (cell >= p.W * p.H) return;
   { const int row = cell / p.W; if (row < p.cband_y0 || row >= p.cband_y1) return; }
-  MapCell& c = map[cell];
-  if (!(c.flags & CELL_ALIVE)) return;
+  u32* mf = map_flags(map, p.W * p.H);
+  if (!(mf[cell] & CELL_ALIVE)) return;  // (dense flags: a dead cell costs 4 contiguous bytes)
+  const MapCell& c = map[cell];
   // DepthPoint::valid(var, age, max, min), DepthPoint.cpp:221-230
   const bool valid = c.inv_depth > -1e-6 && (double)c.age >= p.age_thr && c.variance <= p.var_thr &&
                      c.inv_depth <= p.invdepth_max && c.inv_depth >= p.invdepth_min;
   if (valid) return;
   // erase the element: its true cell reads empty; the reference also NULLs the grid entry of the
   // cell the element believes it occupies (SmartGrid.h:239), orphaning that cell's element.
-  atomicAnd(&c.flags, ~(CELL_ALIVE | CELL_GRID));
+  atomicAnd(&mf[cell], ~(CELL_ALIVE | CELL_GRID));
   const u32 b = c.row * (u32)p.W + c.col;
-  if (b != (u32)cell && c.row < (u32)p.H && c.col < (u32)p.W) atomicAnd(&map[b].flags, ~CELL_GRID);
+  if (b != (u32)cell && c.row < (u32)p.H && c.col < (u32)p.W) atomicAnd(&mf[b], ~CELL_GRID);
 }
 void launch_clean(MapCell* map, const DevParams& p, hipStream_t s) {
   const int ncell = p.W * p.H;
@@ -524,22 +525,26 @@ __global__ void __launch_bounds__(256) reg_view_kernel(const MapCell* __restrict
   const int cell = blockIdx.x * blockDim.x + threadIdx.x;
   bool alive = false;
   if (cell < ncell) {
-    const MapCell& n = map[cell];
+    const u32 fl = map_flags(map, ncell)[cell];  // dense: the record itself is only read where an element lives
     const int row = cell / W;
     if (row >= view0 && row < view1) {  // the view covers the band's halo as well (multi-GPU: computed, not exchanged)
-      if (n.flags & CELL_ALIVE) {
+      const double nan = __longlong_as_double(0x7ff8000000000000ll);
+      double2 vab = make_double2(nan, nan);
+      if (fl & CELL_ALIVE) {
+        const MapCell& n = map[cell];
         const u32 b = n.row * (u32)W + n.col;
         atomicMax(&owner_max[b], n.seq + 1u);
         atomicMin(&owner_min[b], n.seq);
+        if ((fl & CELL_GRID) && n.inv_depth > -1e-6) {
+          vab = make_double2(n.inv_depth, 2.0 * sqrt(n.variance));
+          cd[cell] = l2 ? make_double2(n.variance, 0.0) : make_double2(n.nu, n.scale2);
+        }
       }
-      const bool v = (n.flags & CELL_ALIVE) && (n.flags & CELL_GRID) && n.inv_depth > -1e-6;
-      const double nan = __longlong_as_double(0x7ff8000000000000ll);
-      ab[cell] = v ? make_double2(n.inv_depth, 2.0 * sqrt(n.variance)) : make_double2(nan, nan);
-      if (v) cd[cell] = l2 ? make_double2(n.variance, 0.0) : make_double2(n.nu, n.scale2);
+      ab[cell] = vab;
     }
     if (row >= band0 && row < band1) {
-      alive = (n.flags & CELL_ALIVE) != 0;
-      if (!alive) out[cell].flags = 0;
+      alive = (fl & CELL_ALIVE) != 0;
+      if (!alive) map_flags(out, ncell)[cell] = 0;
     }
   }
   const u64 am = __ballot(alive);  // number of elements of the band (a statistic)
@@ -582,7 +587,7 @@ __global__ void __launch_bounds__(REG_TX * REG_TY, BACK_WAVES) reg_apply_kernel(
   // ---- the tile's elements, compacted in row-major order ----
   const int cr = tile_r0 + wv, cc = tile_c0 + lane;
   bool alive = false;
-  if (cr < p.H && cc < p.W && cr >= p.band_y0 && cr < p.band_y1) alive = (map[cr * p.W + cc].flags & CELL_ALIVE) != 0;
+  if (cr < p.H && cc < p.W && cr >= p.band_y0 && cr < p.band_y1) alive = (map_flags(map, p.W * p.H)[cr * p.W + cc] & CELL_ALIVE) != 0;
   const u64 am = __ballot(alive);
   if (lane == 0) s_wcount[wv] = (u32)__popcll(am);
   __syncthreads();
@@ -739,13 +744,14 @@ __global__ void __launch_bounds__(REG_TX * REG_TY, BACK_WAVES) reg_apply_kernel(
       }
   }
   if (!has) return;
-  if (!owner) { out[cell].flags = 0; return; }
+  u32* of = map_flags(out, p.W * p.H);
+  if (!owner) { of[cell] = 0; return; }
   MapCell c = map[cell];
   if (c.inv_depth > -1e-6)  // it->valid()
     c.inv_depth = (nb > (u32)p.reg_min_nb && nclose > (u32)p.reg_min_close) ? inv_post : -1.0;
   c.seq = owner_min[b];  // position of the first element set at that cell in dmTmp's list
-  c.flags = CELL_ALIVE | CELL_GRID;
   out[cell] = c;
+  of[cell] = CELL_ALIVE | CELL_GRID;
 }
 
 // LSnorm "l2" (DepthRegularization.cpp:56-65): the new inverse depth is the inverse-variance weighted mean of the close
@@ -757,11 +763,12 @@ __global__ void __launch_bounds__(256) reg_apply_l2_kernel(const MapCell* __rest
   const int cell = blockIdx.x * blockDim.x + threadIdx.x;
   if (cell >= p.W * p.H) return;
   { const int r0 = cell / p.W; if (r0 < p.band_y0 || r0 >= p.band_y1) return; }
+  if (!(map_flags(map, p.W * p.H)[cell] & CELL_ALIVE)) return;
   MapCell c = map[cell];
-  if (!(c.flags & CELL_ALIVE)) return;
+  u32* of = map_flags(out, p.W * p.H);
   const int row = (int)c.row, col = (int)c.col, R = p.reg_radius;
   const u32 b = (u32)row * (u32)p.W + (u32)col;  // dmTmp.set(it->row(), it->col(), *it)
-  if (owner_max[b] != c.seq + 1u) { out[cell].flags = 0; return; }  // overwritten by a later element
+  if (owner_max[b] != c.seq + 1u) { of[cell] = 0; return; }  // overwritten by a later element
   if (c.inv_depth > -1e-6) {  // it->valid()
     u32 nb = 0, nclose = 0;
     double total = 0.0;
@@ -790,8 +797,8 @@ __global__ void __launch_bounds__(256) reg_apply_l2_kernel(const MapCell* __rest
     c.inv_depth = set ? mean : -1.0;
   }
   c.seq = owner_min[b];
-  c.flags = CELL_ALIVE | CELL_GRID;
   out[cell] = c;
+  of[cell] = CELL_ALIVE | CELL_GRID;
 }
 
 void launch_reg_view(const MapCell* map_in, MapCell* map_out, u32* owner_max, u32* owner_min, double2* ab, double2* cd,
@@ -826,7 +833,7 @@ __global__ void __launch_bounds__(256) map_flags_kernel(const MapCell* __restric
   const int cell = blockIdx.x * blockDim.x + threadIdx.x;
   if (cell >= ncell) return;
   const int row = cell / W;
-  flags[cell] = (row >= band0 && row < band1 && (map[cell].flags & CELL_ALIVE)) ? 1u : 0u;
+  flags[cell] = (row >= band0 && row < band1 && (map_flags(map, ncell)[cell] & CELL_ALIVE)) ? 1u : 0u;
 }
 __global__ void __launch_bounds__(256) map_export_kernel(const MapCell* __restrict__ map, const u32* __restrict__ flags,
                                                          const u32* __restrict__ prefix, esvo_depth_point_t* __restrict__ out,
@@ -843,7 +850,7 @@ __global__ void __launch_bounds__(256) map_export_kernel(const MapCell* __restri
   o.pose_idx = 0;
   o.seq = c.seq;
   out[prefix[cell]] = o;
-  if (out_cell) out_cell[prefix[cell]] = (c.flags & CELL_GRID) ? (u32)cell : 0xffffffffu;
+  if (out_cell) out_cell[prefix[cell]] = (map_flags(map, ncell)[cell] & CELL_GRID) ? (u32)cell : 0xffffffffu;
 }
 void launch_map_compact(const MapCell* map, u32* flags, u32* prefix, u32* d_total, u32* scan_tmp,
                         esvo_depth_point_t* out, u32* out_cell, const DevParams& p, hipStream_t s) {

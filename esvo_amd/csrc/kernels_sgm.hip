@@ -345,8 +345,9 @@ __global__ void __launch_bounds__(256) sgm_naive_create_kernel(const DevPoint* _
   c.row = (u32)row;
   c.col = (u32)col;
   c.seq = pair_rank[o];
-  c.flags = CELL_ALIVE | CELL_GRID;
+  c.unused_ = 0;
   map[cell] = c;
+  map_flags(map, p.W * p.H)[cell] = CELL_ALIVE | CELL_GRID;
 }
 
 void launch_sgm_points(const esvo_event_t* ring, u64 first, u64 cap, u32 n, const float2* lut, const int16_t* disp, DevPoint* slots,
@@ -358,7 +359,7 @@ void launch_sgm_naive(const DevPoint* pts, u32 n, const double* d_T_frame_obs, u
                       u32* scan_tmp, MapCell* map, const DevParams& p, hipStream_t st) {
   const int ncell = p.W * p.H;
   hipMemsetAsync(owner, 0xFF, sizeof(u32) * ncell, st);
-  hipMemsetAsync(map, 0, sizeof(MapCell) * ncell, st);
+  hipMemsetAsync(map, 0, map_buffer_bytes((size_t)ncell), st);  // cells + flags
   if (!n) return;
   hipMemsetAsync(pair_flags, 0, sizeof(u32) * 4 * (size_t)n, st);
   hipLaunchKernelGGL(sgm_naive_owner_kernel, dim3((n + 255) / 256), dim3(256), 0, st, pts, n, d_T_frame_obs, owner, p);

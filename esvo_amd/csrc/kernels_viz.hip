@@ -17,7 +17,7 @@ struct VizSel {
 
 // value of the element for the image, or false if the image's filter drops it (Visualization.cpp:28-64)
 __device__ inline bool viz_value(const MapCell& c, const VizSel& s, double& val) {
-  if (!(c.flags & CELL_ALIVE) || !(c.inv_depth > -1e-6)) return false;  // it->valid()
+  if (!(c.inv_depth > -1e-6)) return false;  // it->valid() (the caller has checked that the cell holds an element)
   switch (s.type) {
     case 0: val = c.inv_depth; return c.variance < s.thr1 * s.thr1 && (double)c.age >= (double)(int)s.thr2;
     case 1: val = sqrt(c.variance); return c.variance < s.thr1 * s.thr1;
@@ -32,6 +32,7 @@ __global__ void __launch_bounds__(256) viz_kernel(const MapCell* __restrict__ ma
   const int cell = blockIdx.x * blockDim.x + threadIdx.x;
   if (cell >= W * H) return;
   { const int row = cell / W; if (row < band0 || row >= band1) return; }
+  if (!(map_flags(map, W * H)[cell] & CELL_ALIVE)) return;
   const MapCell c = map[cell];
   double val;
   if (!viz_value(c, s, val)) return;
