@@ -165,6 +165,7 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
     if (std::getenv("ESVO_PRIO_PRINT")) fprintf(stderr, "[esvo] stream priority range: lowest %d .. highest %d; LM %d\n", lo, hi, pl);
     CK(hipStreamCreateWithPriority(&h->stream_l, hipStreamNonBlocking, pl));
     CK(hipStreamCreateWithPriority(&h->stream_l1, hipStreamNonBlocking, pl));
+    if (const char* ep = std::getenv("ESVO_LM_PAIR")) h->lm_pair_forced = std::atoi(ep) == 1 ? 1 : (std::atoi(ep) == 0 ? 0 : -1);
     if (const char* eq = std::getenv("ESVO_LM_QUEUES")) h->lm_queues = std::atoi(eq) == 1 ? 1 : (std::atoi(eq) == 2 ? 2 : 0);
     if (const char* em = std::getenv("ESVO_LM_QUEUES_MAX_EVENTS")) h->lm_two_max = (u32)std::strtoul(em, nullptr, 10);  // A/B only
     const char* e = std::getenv("ESVO_LM_STREAM");
@@ -331,6 +332,9 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
 int esvo_destroy(esvo_handle h) {
   if (!h) return ESVO_OK;
   hipSetDevice(h->device);
+  if (std::getenv("ESVO_POLICY_PRINT"))
+    fprintf(stderr, "[esvo] LM layout policy: wide %.4f ms (%u ticks), pair %.4f ms (%u ticks); LM queues: lm %.4f ms, back %.4f ms, two %d\n",
+            h->lm_pair_ms[0][0], h->lm_pair_n[0], h->lm_pair_ms[1][0], h->lm_pair_n[1], h->ema_lm_ms, h->ema_back_ms, (int)h->lm_two_on);
   if (h->stream) hipStreamSynchronize(h->stream);
   if (h->stream_l) hipStreamSynchronize(h->stream_l);
   if (h->stream_l1) hipStreamSynchronize(h->stream_l1);
@@ -396,6 +400,9 @@ int esvo_reset(esvo_handle h) {
   h->trk_read_pending = false;
   h->ema_lm_ms = h->ema_back_ms = 0.f;
   h->lm_two_on = false;
+  std::memset(h->lm_pair_ms, 0, sizeof(h->lm_pair_ms));
+  h->lm_pair_n[0] = h->lm_pair_n[1] = 0u;
+  h->lm_pair_decisions = 0;
   h->frames.clear();
   h->n_window_frames = 0;
   std::fill(h->slot_used.begin(), h->slot_used.end(), 0);

@@ -84,7 +84,21 @@ static void set_lm_parity(esvo_context* h) {
   h->d_pt_slots = h->d_pt_slots2[h->fpar]; h->d_pt_flags = h->d_pt_flags2[h->fpar]; h->d_pt_prefix = h->d_pt_prefix2[h->fpar];
   h->d_scan_tmp_l = h->d_scan_tmp_l2[h->fpar];
 }
-int run_lm(esvo_context* h, u32 max_matches, int cull, bool dense, hipStream_t st = nullptr) {
+// which LM layout the next lazy tick uses (context.hpp: lm_pair_*): -1 not a candidate, else 0 wide / 1 pair
+static int lm_pair_policy(esvo_context* h, u32 n_events) {
+  if (n_events == 0 || n_events > esvo::LM_PAIR_MAX_EVENTS || h->prm.ls_norm == ESVO_LSNORM_L2) return -1;
+  if (h->lm_pair_forced >= 0) return h->lm_pair_forced;
+  const u32 k = h->lm_pair_decisions++;
+  if (k < 8u || h->lm_pair_n[0] == 0u || h->lm_pair_n[1] == 0u) return (int)(k & 1u);
+  auto recent_min = [&](int mode) {
+    float m = 1e30f;
+    for (u32 i = 0; i < 4u && i < h->lm_pair_n[mode]; ++i) m = std::min(m, h->lm_pair_ms[mode][i]);
+    return m;
+  };
+  const int best = recent_min(1) < recent_min(0) ? 1 : 0;
+  return (k % 64u == 63u) ? best ^ 1 : best;
+}
+int run_lm(esvo_context* h, u32 max_matches, int cull, bool dense, hipStream_t st = nullptr, int pair = -1) {
   if (!st) st = h->stream;
   u32* flags = dense ? h->d_lkeep : h->d_pt_flags;  // the kernel writes every flag of its launch range
   LmArgs a;
@@ -95,6 +109,7 @@ int run_lm(esvo_context* h, u32 max_matches, int cull, bool dense, hipStream_t s
   const bool split = h->d_lm_fvec0 != nullptr && (h->lm_split_mode == 1 || (h->lm_split_mode < 0 && max_matches >= 400000u));
   a.split_fvec0 = split ? h->d_lm_fvec0 : nullptr; a.split_fnorm0 = h->d_lm_fnorm0; a.split_meta = h->d_lm_meta;
   a.split_order = h->d_lm_order; a.split_hist = h->d_lm_hist;
+  a.pair = pair >= 0 ? pair : (h->lm_pair_forced == 1 && max_matches <= esvo::LM_PAIR_MAX_EVENTS ? 1 : 0);
   hipEventRecord(h->evt[EV_LM0 + h->fpar * EV_FRONT_STRIDE], st);
   launch_lm_refine(a, h->dp, h->d_counters + 2, st);
   hipEventRecord(h->evt[EV_LM1 + h->fpar * EV_FRONT_STRIDE], st);
@@ -567,6 +582,7 @@ int tick_phase0(esvo_context* h, uint64_t t_ns, const uint64_t* pose_t_ns, const
   esvo_context::TickState& tk = h->tk[h->fpar];
   tk.n = n; tk.off = 0; tk.points = 0; tk.t_ns = t_ns;
   tk.lm_stream = h->stream;
+  tk.lm_pair = -1;
   tk.obs_par = h->obs_par;
   tk.pose_buf = h->pose_buf; tk.n_pose = h->n_pose;
   std::memcpy(tk.T_world_obs, h->T_world_obs, sizeof(double) * 16);
@@ -606,7 +622,8 @@ int tick_phase0(esvo_context* h, uint64_t t_ns, const uint64_t* pose_t_ns, const
       HIPCHK(hipStreamWaitEvent(sl, h->evt[EV_A1 + h->fpar * EV_FRONT_STRIDE], 0));
     }
     tk.lm_stream = sl;
-    rc = run_lm(h, n, 1, false, sl);
+    tk.lm_pair = lm_pair_policy(h, n);
+    rc = run_lm(h, n, 1, false, sl, tk.lm_pair);
     if (rc) return rc;
   } else if (n) {
     // own slots only (w % n_shards == shard): BM, dense local list, LM + cull on it, then the (matched, kept)
@@ -698,6 +715,10 @@ int tick_phase1_collect(esvo_context* h, int fp) {
     s.sum_ms_kernel[2] += s.ms_kernel[2];
     s.sum_ms_kernel[3] += s.ms_kernel[3];
     h->ema_lm_ms = h->ema_lm_ms > 0.f ? 0.75f * h->ema_lm_ms + 0.25f * s.ms_kernel[3] : s.ms_kernel[3];
+    if (tk.lm_pair >= 0 && s.ms_kernel[3] > 0.f) {  // feedback for lm_pair_policy
+      h->lm_pair_ms[tk.lm_pair][h->lm_pair_n[tk.lm_pair] & 3u] = s.ms_kernel[3];  // ring of the last four
+      h->lm_pair_n[tk.lm_pair]++;
+    }
   }
   if (h->sharded && n_points) {
     h->xchg_ptr = h->d_win + tk.off;

@@ -251,7 +251,9 @@ struct LmArgs {
   u32* split_meta;
   u32* split_order;
   u32* split_hist;
+  int pair;                     // wide layout only: two waves per match (kernels_lm.hip "pair layout"); the caller's choice
 };
+constexpr u32 LM_PAIR_MAX_EVENTS = 10000u;       // launches bounded by more events never use the pair layout (2 waves per match)
 constexpr u32 LM_TWO_QUEUES_MAX_EVENTS = 40000u;  // = LM_WIDE_MAX (kernels_lm.hip): launches that use the wide layout
 constexpr u32 LM_SPLIT_MIN_EVENTS = 40000u;  // launches bounded by fewer events use the wide layout (LM_WIDE_MAX), never the split
 void launch_lm_refine(const LmArgs& a, const DevParams& p, u32* n_solved, hipStream_t s);

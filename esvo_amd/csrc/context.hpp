@@ -221,7 +221,17 @@ struct esvo_context {
     double T_world_obs[16];
     hipStream_t lm_stream = nullptr;  // where the tick's LM stage (refinement, frame, counters) was enqueued
     int obs_par = 0;                  // which observation pair it reads
+    int lm_pair = -1;                 // LM layout of the tick: 1 pair, 0 wide, -1 not a candidate (policy feedback)
   } tk[2];
+  // pair layout of the LM kernel (kernels_lm.hip): chosen per tick from the LM launch times the handle measures anyway
+  // (HIP events).  The first eight candidate ticks alternate between the layouts, then the faster one is used, with one tick
+  // of the other every 64 so that a change of scene is noticed; a layout's figure is the MINIMUM of its last four launches
+  // (the first ticks of a handle are slow whatever the layout).  ESVO_LM_PAIR = 0 / 1 forces never / always.  Scheduling
+  // only: same bits either way.
+  int lm_pair_forced = -1;
+  float lm_pair_ms[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  u32 lm_pair_n[2] = {0u, 0u};
+  u32 lm_pair_decisions = 0;
   int fpar = 0;                   // parity of the newest front stage
   bool tick_pending = false;      // tk[fpar] has its front stage enqueued but is not committed yet
   u64 committed_t_ns = 0;         // stamp of the newest tick whose back stage is enqueued (0: none)

@@ -558,9 +558,30 @@ __device__ inline u32 lm_split_stripe(u32 slot) { return (slot >> 2) & (LM_SPLIT
 #ifndef LM_PAD2
 #define LM_PAD2 0
 #endif
-template <bool WIDE, bool L2 = false, int STAGE = 0>
-__global__ void __launch_bounds__(LM_BLOCK, WIDE ? LM_WIDE_WAVES : LM_WAVES) lm_refine_kernel(LmArgs a, DevParams p, u32* n_solved, LmSplit sp) {
+// ---- the pair layout (wide layout, the smallest launches) ----------------------------------------------------------------
+// A small launch lasts as long as its slowest match's DEPENDENT CHAIN of evaluations, and lmdif's chain alternates two kinds:
+// the trial point F(x + p) and, once the step is accepted, the forward-difference point F(x' + h(x')) at the new x' = x + p.
+// The second is known as soon as the first is -- h(x') = sqrt(eps) |x'| -- so TWO waves work on one match: both run the same
+// driver on the same state (they stay in lockstep by construction), wave 0 evaluates the point the driver asks for, wave 1
+// the difference point that follows if the step is accepted, and they swap residuals through LDS (one barrier).  When the
+// driver then asks for exactly the point wave 1 evaluated (compared bit for bit) the residuals are there; otherwise -- a
+// rejected step, a restart of the outer loop at an unchanged x -- both waves evaluate as before.  F is a pure function, so
+// the result is the same bits; an accepted LM iteration costs one evaluation's latency instead of two (F(x0) and
+// F(x0 + h) of minimizeInit likewise).  Twice the waves per match: used while the launch's matches fit the chip twice.
+// Whether it pays depends on the data: on the un-smoothed 346x260 surfaces (long chains of accepted steps) a synchronised
+// 1000-event tick drops from 0.50 to 0.41 ms and ticks of 2500-7500 events by 14 %; on DSEC's smoothed surfaces the same
+// sizes get 2-8 % SLOWER (short chains: the second wave, the exchange and the extra SGPR spills cost more than the few
+// reused evaluations save), and above ~2000 matches the doubled waves crowd the SIMDs.  The handle therefore measures
+// (api_map.hip, lm_pair_policy): both layouts give the same bits, so it may switch between ticks.
+template <bool WIDE, bool L2 = false, int STAGE = 0, bool PAIR = false>
+__global__ void __launch_bounds__(PAIR ? 128 : LM_BLOCK, WIDE ? LM_WIDE_WAVES : LM_WAVES) lm_refine_kernel(LmArgs a, DevParams p, u32* n_solved, LmSplit sp) {
+  static_assert(!PAIR || (WIDE && !L2 && STAGE == 0), "the pair layout is a variant of the wide one");
   constexpr int RL = Lay<WIDE>::RL;
+  // [exchange parity][wave][row][lane]: residuals of the two points evaluated side by side, + whether each was tight
+  __shared__ double lds_pair[PAIR ? 2 : 1][2][RL][64];
+  __shared__ int lds_pair_tight[PAIR ? 2 : 1][2];
+  const int wv = PAIR ? (int)(threadIdx.x >> 6) : 0;
+  const int ln = threadIdx.x & 63;
   constexpr int PAD = (WIDE || L2) ? 0 : (STAGE == 2 ? LM_PAD2 : (STAGE == 0 ? LM_PAD0 : 0));
   int pad[PAD > 0 ? PAD : 1];
   if constexpr (PAD > 0) {
@@ -657,6 +678,10 @@ __global__ void __launch_bounds__(LM_BLOCK, WIDE ? LM_WIDE_WAVES : LM_WAVES) lm_
   bool need_step = false;
   bool fvec_tight = false;  // fvec comes from a tight evaluation (lm_eval's return value)
   double xe = x;
+  // pair layout: the point wave 1 evaluated in the last exchange, which LDS buffer holds it, whether it is still there
+  double xs = 0.;
+  int xpar = 0;
+  bool have_spec = false;
   if constexpr (STAGE == 1) {  // minimizeInit only: F(x0), |F(x0)|, what the evaluation cost
     int n_it = 0;
     const bool tgt = lm_eval<WIDE, L2, true>(p, pr, x, out, &n_it);
@@ -705,7 +730,38 @@ __global__ void __launch_bounds__(LM_BLOCK, WIDE ? LM_WIDE_WAVES : LM_WAVES) lm_
       xe = xnew;
       need_step = false;
     }
-    const bool out_tight = lm_eval<WIDE, L2>(p, pr, xe, out);
+    bool out_tight;
+    if constexpr (PAIR) {
+      const bool reuse = phase == 1 && have_spec && __double_as_longlong(xe) == __double_as_longlong(xs);
+      if (reuse) {  // F(x + h): wave 1 evaluated it beside the trial point
+#pragma unroll
+        for (int y = 0; y < RL; ++y) out[y] = lds_pair[xpar][1][y][ln];
+        out_tight = lds_pair_tight[xpar][1] != 0;
+        have_spec = false;
+      } else {
+        const bool side = phase != 1;  // beside F(xe): the difference point that follows if the driver moves to xe
+        if (side) {
+          double hs = sqrt_eps * fabs(xe);
+          if (hs == 0.) hs = sqrt_eps;
+          xs = xe + hs;
+        }
+        const bool t_mine = lm_eval<WIDE, L2>(p, pr, (side && wv) ? xs : xe, out);
+        out_tight = t_mine;
+        if (side) {
+          xpar ^= 1;
+#pragma unroll
+          for (int y = 0; y < RL; ++y) lds_pair[xpar][wv][y][ln] = out[y];
+          if (ln == 0) lds_pair_tight[xpar][wv] = t_mine ? 1 : 0;
+          __syncthreads();  // both waves run the same driver on the same state: they arrive here together
+#pragma unroll
+          for (int y = 0; y < RL; ++y) out[y] = lds_pair[xpar][0][y][ln];
+          out_tight = lds_pair_tight[xpar][0] != 0;
+          have_spec = true;
+        }
+      }
+    } else {
+      out_tight = lm_eval<WIDE, L2>(p, pr, xe, out);
+    }
     int status = -1;
     bool outer_tail = false;
     if (phase == 0) {  // minimizeInit
@@ -915,7 +971,10 @@ void launch_lm_refine(const LmArgs& a, const DevParams& p, u32* n_solved, hipStr
   }
   // the match count lives on the device; the layout is chosen by the launch's bound (the events handed to block matching)
   if (a.max_matches <= LM_WIDE_MAX && LM_BLOCK == 64) {
-    hipLaunchKernelGGL((lm_refine_kernel<true, false, 0>), dim3(a.max_matches), dim3(64), 0, s, a, p, n_solved, sp);
+    if (a.pair)
+      hipLaunchKernelGGL((lm_refine_kernel<true, false, 0, true>), dim3(a.max_matches), dim3(128), 0, s, a, p, n_solved, sp);
+    else
+      hipLaunchKernelGGL((lm_refine_kernel<true, false, 0>), dim3(a.max_matches), dim3(64), 0, s, a, p, n_solved, sp);
     return;
   }
   if (a.split_fvec0 && !a.dense) {  // the split launch (see LmSplit)
