@@ -146,6 +146,23 @@ def test_time_surface_direct_path_of_the_fused_render(cap):
     assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-2000:]
 
 
+@pytest.mark.parametrize("pair", [1, 0])
+def test_lm_layouts_forced(pair):
+    """lm_refine_kernel's pair layout (two waves per match: the requested point beside the forward-difference point that follows
+    an accepted step, residuals swapped through LDS) and the plain wide layout must give the same bits: the handle switches
+    between them from tick to tick by measurement.  Both are forced here (ESVO_LM_PAIR, read at esvo_create) over the LM parity
+    tests, the chain against the canonical oracle and the reference fixtures, in a process of their own."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ESVO_LM_PAIR=str(pair))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"),
+                        os.path.join(root, "tests", "test_gpu_ref.py"), "-m", "gpu", "-q", "-x",
+                        "-k", "lm_parity or end_to_end_tick or chain_equals_canonical_oracle or stages_match_reference"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-2000:]
+
+
 def test_time_surface_epoch_timestamps():
     """Full (sec,nsec) stamps near the Unix epoch of real bags: dt must be formed like ros::Duration."""
     O = _oracle()
