@@ -34,6 +34,10 @@
  *   - pointers named d_* are DEVICE pointers (HBM), everything else is host.
  *   - there is no CPU fallback: esvo_create() fails with ESVO_ERR_NO_DEVICE
  *     when no gfx950 device is visible.
+ *   - Scheduling is the library's business and never changes a result: how many HIP queues a tick's stages use, which
+ *     layout the refinement kernel runs in, whether two refinement launches are in flight -- the handle decides from the
+ *     sizes of the launches and from its own stage timings (HIP events).  The ESVO_* environment variables read at
+ *     esvo_create (tools/README.md lists them) pin those choices for measurements; none of them alters an output bit.
  */
 #ifndef ESVO_HIP_H
 #define ESVO_HIP_H
