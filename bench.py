@@ -674,9 +674,26 @@ def other_operating_points(device):
         return {"ms_per_tick": dt / n * 1e3, "ms_per_tick_pipelined": dp / n * 1e3, "events_per_tick": int(s.last_events_in),
                 "points_per_tick": int(s.last_points)}
 
+    def closed_loop():
+        # BASELINE.json configs[2]: 346x260, the full mapping + tracking loop on one GPU -- SGM bootstrap, then per cycle both
+        # Time Surfaces, the tracker's registration (residuals / Jacobian on the device, the Gauss-Newton update on the host in
+        # Python: the reference keeps its optimiser on the host too) and the mapper tick fed with the TRACKED poses
+        from esvo_amd import closed_loop as cl
+        r = cl.run(n_ticks=15)
+        med = lambda v: float(np.median(np.asarray(v[3:])))  # steady state: past the first cycles
+        return {"ms_per_cycle": med(r["cycle_ms"]), "ms_tracking": med(r["track_ms"]), "ms_mapping": med(r["map_ms"]),
+                "cycles": len(r["cycle_ms"]), "path_mm": r["gt_len"][-1] * 1e3, "final_position_error_mm": r["pos_err"][-1] * 1e3,
+                "depth_points_per_cycle": int(np.median(r["points"])), "map_median_abs_inv_depth_error": r["map_median_abs_err"],
+                "note": "synthetic 346x260 scene, poses from the tracker only (bootstrap pose given); tracker optimiser in host "
+                        "Python over esvo_track_residuals / esvo_track_jacobian (12 Gauss-Newton iterations at most)"}
+
     out["upenn346x260_throughput"] = throughput("upenn346x260", 20)
     out["dsec640x480_reference_faithful_10000"] = latency("dsec640x480", 10000, 20)
     out["upenn346x260_reference_faithful_1000"] = latency("upenn346x260", 1000, 20)
+    try:
+        out["upenn346x260_closed_loop"] = closed_loop()
+    except Exception as e:  # an extra: never takes the headline down with it
+        out["upenn346x260_closed_loop"] = {"error": f"{type(e).__name__}: {e}"}
     # SURVEY.md section 8 stress row: 1280x720, 145 disparity candidates, 100 Mev/s over both cameras, with the oracle equality flag
     out["hd1280x720_throughput"] = throughput("hd1280x720", 6, check=True)
     # the headline workload with the PCIe transfer of every tick's events inside the timed loop (never `value`)
