@@ -1,6 +1,6 @@
 """Closed loop on the device: SGM bootstrap (f3) -> tracker evaluation (f1) -> mapper (a*) with the tracked
 poses (esvo_core/src/esvo_Mapping.cpp:309-353 InitializationAtTime, esvo_Tracking.cpp:150-260).
-Bars are measured on MI355X (see tests/closed_loop.py for the lag the formulation carries by design)."""
+Bars are measured on MI355X (see esvo_amd/closed_loop.py for the lag the formulation carries by design)."""
 import numpy as np
 import pytest
 
