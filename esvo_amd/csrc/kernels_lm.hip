@@ -515,7 +515,9 @@ __device__ inline double lm_lmpar2(double r, double diag, double qtf, double del
 // than four: 277 vs 250-340 us, 447 vs 414 us.  A small launch lasts as long as its slowest MATCH's own dependent chain;
 // the wide layout shortens that chain.)
 #ifndef LM_WIDE_WAVES
-#define LM_WIDE_WAVES 4  // the wide layout needs 127 VGPRs: four waves per SIMD, 4096 matches resident
+#define LM_WIDE_WAVES 3  // three waves per SIMD (146 VGPRs; 152 in the pair layout), 3072 waves resident.  Round 2 ran four: the
+                         // kernel has grown since and at the 128-register bound it spilled 16-18 VGPRs into the solver loop --
+                         // measured against it: 346x260 throughput 55.4 -> 58.1 M events/s, synchronised small ticks -2 %
 #endif
 #ifndef LM_WIDE_MAX
 #define LM_WIDE_MAX 40000u  // launches bounded by this many matches (= events handed to block matching) use the wide layout
