@@ -65,9 +65,14 @@ int run_bm(esvo_context* h, const esvo_event_t* d_ev, u64 first, u64 cap, int re
 // stable compaction of the match slots into vEMP order.  Sharded mode: the flags are this rank's own
 // ones, the list is its dense local list (count -> counters[8]) and slot_of remembers each entry's slot.
 int run_order_matches(esvo_context* h, u32 n, bool local) {
-  launch_exclusive_scan_u32(h->d_match_flags, h->d_match_prefix, h->d_counters + (local ? 8 : 0), h->d_scan_tmp, n, h->stream);
-  launch_compact_matches(h->d_match_slots, h->d_match_flags, h->d_match_prefix, n, h->d_matches, local ? h->d_own_w : nullptr,
-                         h->stream);
+  if (scan_compact_is_small(n)) {  // a small tick: one launch (scan.hip)
+    launch_scan_compact_matches_small(h->d_match_flags, h->d_match_prefix, h->d_counters + (local ? 8 : 0), n, h->d_match_slots,
+                                      h->d_matches, local ? h->d_own_w : nullptr, h->stream);
+  } else {
+    launch_exclusive_scan_u32(h->d_match_flags, h->d_match_prefix, h->d_counters + (local ? 8 : 0), h->d_scan_tmp, n, h->stream);
+    launch_compact_matches(h->d_match_slots, h->d_match_flags, h->d_match_prefix, n, h->d_matches, local ? h->d_own_w : nullptr,
+                           h->stream);
+  }
   hipEventRecord(h->evt[EV_S1 + h->fpar * EV_FRONT_STRIDE], h->stream);
   HIPCHK(hipGetLastError());
   return ESVO_OK;
@@ -120,8 +125,13 @@ int run_lm(esvo_context* h, u32 max_matches, int cull, bool dense, hipStream_t s
 int run_order_points(esvo_context* h, u32 max_matches, DevPoint* dst, hipStream_t st) {
   u32* scratch = (st && st != h->stream) ? h->d_scan_tmp_l : h->d_scan_tmp;  // the LM stage scans beside the next tick's BM
   if (!st) st = h->stream;
-  launch_exclusive_scan_u32(h->d_pt_flags, h->d_pt_prefix, h->d_counters + 1, scratch, max_matches, st);
-  launch_compact_points(h->d_pt_slots, h->d_pt_flags, h->d_pt_prefix, h->d_counters + 0, max_matches, dst, st);
+  if (scan_compact_is_small(max_matches)) {
+    // (the refinement kernel writes a flag for every slot of its launch, 0 beyond the match count: no count to clip to)
+    launch_scan_compact_points_small(h->d_pt_flags, h->d_pt_prefix, h->d_counters + 1, max_matches, h->d_pt_slots, dst, st);
+  } else {
+    launch_exclusive_scan_u32(h->d_pt_flags, h->d_pt_prefix, h->d_counters + 1, scratch, max_matches, st);
+    launch_compact_points(h->d_pt_slots, h->d_pt_flags, h->d_pt_prefix, h->d_counters + 0, max_matches, dst, st);
+  }
   hipEventRecord(h->evt[EV_S2 + h->fpar * EV_FRONT_STRIDE], st);
   HIPCHK(hipGetLastError());
   return ESVO_OK;

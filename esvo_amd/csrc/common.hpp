@@ -157,6 +157,12 @@ typedef esvo_depth_point_t DevPoint;
 void launch_exclusive_scan_u32(const u32* d_in, u32* d_out, u32* d_total, u32* d_block_sums, size_t n,
                                hipStream_t s);
 size_t scan_scratch_elems(size_t n);
+// scan + stable compaction in ONE single-workgroup launch, for inputs of at most 32 768 flags (scan.hip)
+bool scan_compact_is_small(size_t n);
+void launch_scan_compact_matches_small(const u32* flags, u32* prefix, u32* d_total, size_t n, const esvo_match_t* slots,
+                                       esvo_match_t* out, u32* slot_of, hipStream_t s);
+void launch_scan_compact_points_small(const u32* flags, u32* prefix, u32* d_total, size_t n, const esvo_depth_point_t* slots,
+                                      esvo_depth_point_t* out, hipStream_t s);
 // upload of a small pinned host buffer by a kernel (never blocks the host; scan.hip)
 void launch_upload_words(const void* pinned_src, void* d_dst, size_t bytes, hipStream_t s, u32* d_zero = nullptr, u32 n_zero = 0);
 

@@ -89,6 +89,57 @@ __global__ void __launch_bounds__(SCAN_SB) scan_small_kernel(const u32* __restri
   if (threadIdx.x == 0 && total) *total = carry;
 }
 
+// The same walk with the COMPACTION folded in (round 3): a small tick's "flags -> exclusive scan -> stable compaction of the
+// records" pairs (matches after block matching, depth points after the refinement) were two dependent launches each, 4 us of
+// kernel + 6 us of queue latency per launch on the critical path of a reference-faithful tick.  The workgroup that scans
+// the flags writes the records it keeps straight away.  SEQ: the record's `seq` field takes its position (DevPoint);
+// slot_of (nullable): the source slot of every kept record.  The prefix array is still written: other kernels read it.
+template <class Rec, bool SEQ>
+__global__ void __launch_bounds__(SCAN_SB) scan_compact_small_kernel(const u32* __restrict__ flags, u32* __restrict__ prefix,
+                                                                     u32* __restrict__ total, size_t n, const Rec* __restrict__ slots,
+                                                                     Rec* __restrict__ out, u32* __restrict__ slot_of) {
+  __shared__ u32 lds[SCAN_SB / ESVO_WAVE];
+  u32 carry = 0;
+  for (size_t tile = 0; tile < n; tile += (size_t)SCAN_SB * SCAN_V) {
+    const size_t base = tile + (size_t)threadIdx.x * SCAN_V;
+    u32 v[SCAN_V];
+    u32 s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_V; ++k) {
+      v[k] = (base + k < n) ? flags[base + k] : 0u;
+      s += v[k];
+    }
+    u32 tot;
+    u32 ex = block_excl_scan<SCAN_SB / ESVO_WAVE>(s, &tot, lds) + carry;
+#pragma unroll
+    for (int k = 0; k < SCAN_V; ++k) {
+      if (base + k < n) {
+        prefix[base + k] = ex;
+        if (v[k]) {
+          Rec o = slots[base + k];
+          if constexpr (SEQ) o.seq = ex;
+          out[ex] = o;
+          if (slot_of) slot_of[ex] = (u32)(base + k);
+        }
+      }
+      ex += v[k];
+    }
+    carry += tot;
+  }
+  if (threadIdx.x == 0 && total) *total = carry;
+}
+bool scan_compact_is_small(size_t n) { return n > 0 && n <= SCAN_SMALL_MAX; }
+void launch_scan_compact_matches_small(const u32* flags, u32* prefix, u32* d_total, size_t n, const esvo_match_t* slots,
+                                       esvo_match_t* out, u32* slot_of, hipStream_t s) {
+  hipLaunchKernelGGL((scan_compact_small_kernel<esvo_match_t, false>), dim3(1), dim3(SCAN_SB), 0, s, flags, prefix, d_total, n, slots,
+                     out, slot_of);
+}
+void launch_scan_compact_points_small(const u32* flags, u32* prefix, u32* d_total, size_t n, const DevPoint* slots, DevPoint* out,
+                                      hipStream_t s) {
+  hipLaunchKernelGGL((scan_compact_small_kernel<DevPoint, true>), dim3(1), dim3(SCAN_SB), 0, s, flags, prefix, d_total, n, slots, out,
+                     (u32*)nullptr);
+}
+
 // Small host -> device uploads of the tick path (pose table, frame table) as a KERNEL that reads the pinned host buffer:
 // a kernel launch never blocks the host, whereas hipMemcpyAsync of a few KB was measured to stall its caller for 6-11 ms
 // once per process when a third stream of the handle is busy (the copy engine's queue is shared between the streams).
