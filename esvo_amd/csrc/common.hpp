@@ -157,7 +157,7 @@ typedef esvo_depth_point_t DevPoint;
 void launch_exclusive_scan_u32(const u32* d_in, u32* d_out, u32* d_total, u32* d_block_sums, size_t n,
                                hipStream_t s);
 size_t scan_scratch_elems(size_t n);
-// scan + stable compaction in ONE single-workgroup launch, for inputs of at most 32 768 flags (scan.hip)
+// scan + stable compaction in ONE single-workgroup launch, for inputs of at most 10 240 flags (scan.hip)
 bool scan_compact_is_small(size_t n);
 void launch_scan_compact_matches_small(const u32* flags, u32* prefix, u32* d_total, size_t n, const esvo_match_t* slots,
                                        esvo_match_t* out, u32* slot_of, hipStream_t s);
