@@ -104,7 +104,20 @@ class StatsStruct(C.Structure):
         ("sum_ms_kernel", C.c_double * 8),
         ("last_bm_info_noise_low", C.c_uint32), ("last_bm_coarse_fail", C.c_uint32), ("last_bm_fine_fail", C.c_uint32), ("pad2_", C.c_uint32),
         ("total_bm_info_noise_low", C.c_uint64), ("total_bm_coarse_fail", C.c_uint64), ("total_bm_fine_fail", C.c_uint64),
+        # ABI 3: in-run shader-clock probe of the refinement kernel (include/esvo_hip.h)
+        ("clk_cycles", C.c_uint64 * 8), ("clk_ref_ticks", C.c_uint64 * 8), ("clk_samples", C.c_uint64),
+        ("clk_ref_khz", C.c_uint32), ("pad3_", C.c_uint32),
     ]
+
+    def sclk_mhz(self, base=None):
+        """(all XCDs, [per XCD]) shader clock in MHz the LM kernel ran at since `base` (an earlier StatsStruct) or since
+        esvo_create: sum of s_memtime differences / sum of s_memrealtime differences x the reference rate; None without samples"""
+        cyc = [int(self.clk_cycles[i]) - (int(base.clk_cycles[i]) if base is not None else 0) for i in range(8)]
+        ref = [int(self.clk_ref_ticks[i]) - (int(base.clk_ref_ticks[i]) if base is not None else 0) for i in range(8)]
+        khz = float(self.clk_ref_khz)
+        per = [c / r * khz / 1e3 if r > 0 else None for c, r in zip(cyc, ref)]
+        tot = sum(cyc) / sum(ref) * khz / 1e3 if sum(ref) > 0 else None
+        return tot, per
 
 
 def make_events(x, y, t_ns, polarity=None):

@@ -248,6 +248,14 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
     CK(dalloc(&h->d_lm_hist, 2 * 32 * 64));  // kernels_lm.hip: 2 x LM_SPLIT_STRIPES x LM_SPLIT_BINS
     CK(hipMemset(h->d_lm_hist, 0, sizeof(u32) * 2 * 32 * 64));
   }
+  CK(dalloc(&h->d_clk, clk_words(h->max_ev)));
+  CK(hipMemset(h->d_clk, 0, sizeof(u64) * clk_words(h->max_ev)));
+  if (const char* ec = std::getenv("ESVO_CLK_PROBE")) h->clk_probe = std::atoi(ec) != 0;
+  {
+    int khz = 0;  // rate of s_memrealtime (wall_clock64): the constant reference clock the probe divides by
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) != hipSuccess || khz <= 0) khz = 100000;
+    h->stats.clk_ref_khz = (uint32_t)khz;
+  }
   for (int k = 0; k < 2; ++k) {
     CK(dalloc(&h->d_pt_slots2[k], E));
     CK(dalloc(&h->d_pt_flags2[k], E));
@@ -348,7 +356,7 @@ int esvo_destroy(esvo_handle h) {
                   h->d_win, h->d_frame_pose_T, h->d_fr_table, h->d_prop, h->d_cell_count, h->d_cell_offset,
                   h->d_cell_fill, h->d_rec_ids, h->d_map, h->d_map2, h->d_owner_max, h->d_owner_min, h->d_exp_flags,
                   h->d_exp_prefix, h->d_export, h->d_export_cell, h->d_reg_ab, h->d_reg_cd, h->d_bucket, h->d_cell_list, h->d_own_w, h->d_lkeep, h->d_codes,
-                  h->d_sel, h->d_evmap, h->d_lm_fvec0, h->d_lm_fnorm0, h->d_lm_meta, h->d_lm_order, h->d_lm_hist};
+                  h->d_sel, h->d_evmap, h->d_lm_fvec0, h->d_lm_fnorm0, h->d_lm_meta, h->d_lm_order, h->d_lm_hist, h->d_clk};
   for (void* p : ptrs) if (p) hipFree(p);
   if (h->h_counters) hipHostFree(h->h_counters);
   if (h->h_cnt_b) hipHostFree(h->h_cnt_b);
@@ -419,7 +427,12 @@ int esvo_reset(esvo_handle h) {
   h->ts_timing_pending[0] = h->ts_timing_pending[1] = false;
   h->ts_pair_sample = false;
   h->stats_pending = false;
-  std::memset(&h->stats, 0, sizeof(h->stats));
+  {
+    const uint32_t khz = h->stats.clk_ref_khz;
+    std::memset(&h->stats, 0, sizeof(h->stats));
+    h->stats.clk_ref_khz = khz;
+  }
+  HIPCHK(hipMemset(h->d_clk, 0, sizeof(u64) * CLK_SCRATCH));
   return ESVO_OK;
 }
 

@@ -115,6 +115,7 @@ int run_lm(esvo_context* h, u32 max_matches, int cull, bool dense, hipStream_t s
   a.split_fvec0 = split ? h->d_lm_fvec0 : nullptr; a.split_fnorm0 = h->d_lm_fnorm0; a.split_meta = h->d_lm_meta;
   a.split_order = h->d_lm_order; a.split_hist = h->d_lm_hist;
   a.pair = pair >= 0 ? pair : (h->lm_pair_forced == 1 && max_matches <= esvo::LM_PAIR_MAX_EVENTS ? 1 : 0);
+  a.clk = h->clk_probe ? h->d_clk : nullptr;
   hipEventRecord(h->evt[EV_LM0 + h->fpar * EV_FRONT_STRIDE], st);
   launch_lm_refine(a, h->dp, h->d_counters + 2, st);
   hipEventRecord(h->evt[EV_LM1 + h->fpar * EV_FRONT_STRIDE], st);
@@ -1399,6 +1400,12 @@ int esvo_get_stats(esvo_handle h, esvo_stats_t* out) {
   HIPCHK(hipSetDevice(h->device));
   int rc = finalize_tick_stats(h);
   if (rc) return rc;
+  {  // the LM kernel's clock probe (every stream is drained here): running sums since esvo_create / esvo_reset
+    u64 acc[CLK_SCRATCH];
+    HIPCHK(hipMemcpy(acc, h->d_clk, sizeof(acc), hipMemcpyDeviceToHost));
+    for (u32 x = 0; x < CLK_XCDS; ++x) { h->stats.clk_cycles[x] = acc[2 * x]; h->stats.clk_ref_ticks[x] = acc[2 * x + 1]; }
+    h->stats.clk_samples = acc[CLK_SAMPLES];
+  }
   std::lock_guard<std::mutex> lr(h->mu_ring);  // events_staged is written by the ingest thread
   *out = h->stats;
   return ESVO_OK;

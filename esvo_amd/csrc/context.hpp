@@ -159,6 +159,8 @@ struct esvo_context {
   u32* d_lm_meta = nullptr;
   u32* d_lm_order = nullptr;
   u32* d_lm_hist = nullptr;
+  u64* d_clk = nullptr;           // in-run shader-clock probe of the LM kernel (LmArgs::clk, common.hpp); read by esvo_get_stats
+  bool clk_probe = true;          // ESVO_CLK_PROBE=0 (A/B only) launches the LM kernel without it
   int lm_split_mode = -1;         // the split launch: -1 by launch size (>= 400 000 events), 0 never, 1 always (ESVO_LM_SPLIT)
   DevPoint* d_pt_slots = nullptr;   // LM output by slot + keep flags + their scan: alias one of two sets (front parity)
   u32* d_pt_flags = nullptr;

@@ -619,6 +619,13 @@ __global__ void __launch_bounds__(PAIR ? 128 : LM_BLOCK, WIDE ? LM_WIDE_WAVES : 
   // problem so that the wave's control flow stays simple; they write nothing.
   if (STAGE != 2 && !active && lead && s < a.max_matches) a.out_flags[s] = 0u;  // every slot of the launch gets its flag: no memset
   if (__ballot(active) == 0) return;
+  // shader-clock probe (LmArgs::clk): the start values go to memory, not into registers that would stay live across the solver
+  const bool probe = STAGE != 1 && a.clk != nullptr && threadIdx.x == 0 && (blockIdx.x & 63u) == 0u;
+  if (probe) {
+    u64* sc = a.clk + CLK_SCRATCH + 2 * (size_t)(blockIdx.x >> 6);
+    sc[0] = __builtin_readcyclecounter();
+    sc[1] = __builtin_amdgcn_s_memrealtime();
+  }
   u32 j = 0;
   esvo_match_t m;
   m.x_left[0] = m.x_left[1] = -1e9; m.inv_depth = 1.0; m.pose_idx = 0; m.cost = 0; m.disp = 0; m.event_idx = 0;
@@ -885,6 +892,16 @@ __global__ void __launch_bounds__(PAIR ? 128 : LM_BLOCK, WIDE ? LM_WIDE_WAVES : 
 #pragma unroll
     for (int i = 0; i < PAD; ++i) asm volatile("" ::"v"(pad[i]));
   }
+  if (probe) {
+    const u64* sc = a.clk + CLK_SCRATCH + 2 * (size_t)(blockIdx.x >> 6);
+    const u64 c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+    u32 xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+    xcc &= CLK_XCDS - 1;
+    atomicAdd(&a.clk[2 * xcc], c1 - sc[0]);
+    atomicAdd(&a.clk[2 * xcc + 1], r1 - sc[1]);
+    atomicAdd(&a.clk[CLK_SAMPLES], 1ull);
+  }
   if (!active || !lead) return;
   const bool solved = !(x <= 0.001);  // DepthProblemSolver.cpp:192
   bool keep = solved;
@@ -906,6 +923,11 @@ __global__ void __launch_bounds__(PAIR ? 128 : LM_BLOCK, WIDE ? LM_WIDE_WAVES : 
     o.x[1] = pr.cy;
     cam2World(p.camL, pr.cx, pr.cy, x, o.p_cam);                 // :119
     o.inv_depth = x;                                             // update_studentT, new-point branch
+#ifdef ESVO_PERTURB_ONE_ULP
+    // libesvo_hip_perturbed.so only (esvo_amd/lib.py build(perturbed=True)): one inverse depth per tick, one ulp off -- the
+    // deliberate defect tests/test_gpu_bench_parity.py uses to show that bench.py's parity.oracle_equal has teeth
+    if (s == 7u) o.inv_depth = __longlong_as_double(__double_as_longlong(x) ^ 1ll);
+#endif
     o.scale2 = L2 ? 0.0 : variance * (p.td_nu - 2) / p.td_nu;    // :125 (l2: the Gaussian update leaves scaleSquared_ / nu_
     o.nu = L2 ? 0.0 : p.td_nu;                                   //  as constructed -- zero here and in the oracle, Appendix A-8)
     o.variance = variance;

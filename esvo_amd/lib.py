@@ -43,21 +43,57 @@ class EsvoError(RuntimeError):
     pass
 
 
-def build(force=False, verbose=False):
-    """hipcc cross-compiles the extension for gfx950 in-tree (works without a GPU)."""
-    srcs = [os.path.join(_CSRC, s) for s in _SOURCES]
+_PERTURBED_PATH = os.path.join(_CSRC, "libesvo_hip_perturbed.so")
+
+
+def build(force=False, verbose=False, perturbed=False):
+    """hipcc cross-compiles the extension for gfx950 in-tree (works without a GPU): one object per source file (in parallel,
+    only the files that changed), then one link.
+    perturbed=True additionally links libesvo_hip_perturbed.so: the same library with -DESVO_PERTURB_ONE_ULP, i.e. ONE inverse
+    depth per tick off by one unit in the last place (kernels_lm.hip) -- never loaded by the product; tests/test_gpu_bench_parity.py
+    points ESVO_HIP_LIB at it to show that bench.py's `parity.oracle_equal` notices a single flipped bit."""
+    from concurrent.futures import ThreadPoolExecutor
     inc = os.path.join(_CSRC, "..", "..", "include")
-    deps = srcs + [os.path.join(_CSRC, f) for f in sorted(os.listdir(_CSRC)) if f.endswith(".hpp")] + [
+    headers = [os.path.join(_CSRC, f) for f in sorted(os.listdir(_CSRC)) if f.endswith(".hpp")] + [
         os.path.join(inc, "esvo_hip.h"), os.path.join(inc, "esvo_hip.hpp")]
-    if not force and os.path.exists(_LIB_PATH) and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(d) for d in deps):
-        return _LIB_PATH
+    hdr_time = max(os.path.getmtime(h) for h in headers)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     extra = os.environ.get("ESVO_EXTRA_HIPCC_FLAGS", "").split()  # A/B experiments only
-    cmd = [hipcc] + HIPCC_FLAGS + extra + ["-I", os.path.join(_CSRC, "..", "..", "include"), "-o", _LIB_PATH] + srcs
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    return _LIB_PATH
+    lib_path = os.path.join(_CSRC, "libesvo_hip.so") if not os.environ.get("ESVO_HIP_LIB") else _LIB_PATH
+    objdir = os.path.join(_CSRC, "build" + ("_" + str(abs(hash(" ".join(extra))) % 100000) if extra else ""))
+    os.makedirs(objdir, exist_ok=True)
+    cflags = [f for f in HIPCC_FLAGS if f not in ("-shared", "-ldl")] + extra + ["-I", inc, "-c"]
+
+    def compile_one(job):
+        src, obj, defs = job
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), hdr_time):
+            return False
+        cmd = [hipcc] + cflags + defs + ["-o", obj, src]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        return True
+
+    jobs = [(os.path.join(_CSRC, s), os.path.join(objdir, s[:-4] + ".o"), []) for s in _SOURCES]
+    if perturbed:
+        jobs.append((os.path.join(_CSRC, "kernels_lm.hip"), os.path.join(objdir, "kernels_lm_perturbed.o"), ["-DESVO_PERTURB_ONE_ULP"]))
+    with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
+        rebuilt = list(ex.map(compile_one, jobs))
+    objs = [j[1] for j in jobs[:len(_SOURCES)]]
+
+    def link(out, obj_list, changed):
+        if not changed and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(o) for o in obj_list):
+            return
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + obj_list + ["-ldl"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+
+    link(lib_path, objs, any(rebuilt[:len(_SOURCES)]))
+    if perturbed:
+        pobjs = [jobs[-1][1] if o.endswith(os.sep + "kernels_lm.o") else o for o in objs]
+        link(_PERTURBED_PATH, pobjs, any(rebuilt))
+    return lib_path
 
 
 _lib = None

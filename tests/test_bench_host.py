@@ -45,3 +45,13 @@ def test_workloads_have_the_stated_shape():
     # the reference-faithful variant cuts the per-tick selection to the yaml's PROCESS_EVENT_NUM
     _, _, p_small, _ = bench.make_workload("upenn346x260", 3, events_cap=1000)
     assert p_small.process_event_num == 1000 < p.process_event_num
+
+
+def test_looped_stream_of_the_sustained_point_is_sorted_and_continuous():
+    from esvo_amd.abi import event_ns
+    rig, stream, p, ticks = bench.make_workload("upenn346x260", 3)
+    a = stream.slice(0, stream.t0_ns, stream.t0_ns + 20_000_000)
+    b = bench.shift_events(a, 3_000_000_123)
+    assert np.array_equal(event_ns(b), event_ns(a) + np.uint64(3_000_000_123))
+    assert np.array_equal(b["x"], a["x"]) and np.array_equal(b["y"], a["y"]) and np.array_equal(b["polarity"], a["polarity"])
+    assert np.all(b["nsec"] < 1_000_000_000)

@@ -9,12 +9,15 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-cmd="python $root/bench.py --steps 20 --warmup 3 --workload $wl"
+export ESVO_BENCH_STREAM_CACHE=/tmp/esvo_streams   # the seeded stream is generated once for the five runs below
+cmd="python $root/bench.py --steps 20 --warmup 3 --workload $wl --sustained-ticks 0 --no-parity"
 $cmd --no-extras > $out/${tag}_bench.json 2> $out/${tag}_bench.err
 echo "{\"workload\": \"$wl\", \"bench_cmd\": \"bench.py --steps 20 --warmup 3 (kernel stats), --steps 5 --warmup 2 (counter passes)\"}" > $out/${tag}_meta.json
 rocprofv3 --kernel-trace --stats -d $out/prof_$tag -o ks -- $cmd --no-cpu-baseline --no-extras > /dev/null 2>&1
 python $root/tools/prof_summary.py $out/prof_$tag/ks_results.db $out/${tag}_kernel_stats.csv
-short="python $root/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --workload $wl"
+python $root/tools/stream_trace.py $out/prof_$tag/ks_results.db > $out/${tag}_stream_trace.txt 2>&1
+python $root/tools/timeline.py $out/prof_$tag/ks_results.db > $out/${tag}_timeline.txt 2>&1
+short="python $root/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --no-parity --workload $wl"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/prof_$tag -o fetch -- $short > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/prof_$tag -o write -- $short > /dev/null 2>&1
 python $root/tools/pmc_summary.py $out/${tag}_hbm_traffic.csv hbm $out/prof_$tag/fetch_results.db $out/prof_$tag/write_results.db
