@@ -726,43 +726,64 @@ def sustained_point(name, n_ticks, device, prof, events_cap=0, base_ticks=40):
     return res
 
 
+def _map_compare(gm, ref_map, W):
+    """valid-set IoU over the believed cells and inverse-depth statistics on the intersection"""
+    ka = gm["row"].astype(np.int64) * W + gm["col"]
+    kb = ref_map["row"].astype(np.int64) * W + ref_map["col"]
+    da = dict(zip(ka.tolist(), gm["inv_depth"].tolist()))
+    db = dict(zip(kb.tolist(), ref_map["inv_depth"].tolist()))
+    both = [k for k in da if k in db and da[k] > -1e-6 and db[k] > -1e-6]
+    union = len(set(da) | set(db))
+    d = np.array([da[k] - db[k] for k in both]) if both else np.zeros(0)
+    return {"map_size": int(len(gm)), "reference_map_size": int(len(ref_map)),
+            "iou": (len(set(da) & set(db)) / union) if union else 1.0,
+            "rmse": float(np.sqrt(np.mean(d * d))) if len(d) else 0.0,
+            "max_abs_diff": float(np.abs(d).max()) if len(d) else 0.0,
+            "frac_within_1e-6": float((np.abs(d) <= 1e-6).mean()) if len(d) else 1.0,
+            "frac_within_1e-4": float((np.abs(d) <= 1e-4).mean()) if len(d) else 1.0}
+
+
+def _frame_compare(fr, ref_frame):
+    out = {"frame_points": int(len(fr)), "reference_frame_points": int(len(ref_frame))}
+    if len(fr) == len(ref_frame) and len(fr):
+        rel = np.abs(fr["inv_depth"] - ref_frame["inv_depth"]) / np.maximum(np.abs(ref_frame["inv_depth"]), 1e-300)
+        out["frame_same_points"] = bool(np.array_equal(fr["row"], ref_frame["row"]) and np.array_equal(fr["col"], ref_frame["col"]))
+        out["frame_inv_depth_max_rel"] = float(rel.max())
+        out["frame_inv_depth_median_rel"] = float(np.median(rel))
+    return out
+
+
 def parity_vs_reference_node(workload, rig, stream, ticks, ref_maps, device):
-    """The device on exactly the ticks the reference's own node object (esvo_Mapping.cpp compiled unmodified, oracle/_ref) just
-    mapped for `cpu_baseline`: raw events of both cameras in, esvo_map_tick_resident per tick, PROCESS_EVENT_NUM of the shipped
-    yaml (10 000 on DSEC).  Compared after the last of those ticks: the newest frame (same points; inverse depth to the LM
-    tolerance -- the reference's Eigen driver is third-party) and the DepthMap (valid-set IoU, inverse-depth
-    RMSE on the intersection: north_star's bar is RMSE < 1e-4)."""
-    wl = WORKLOADS[workload]
-    pf, n_used, node_map, node_frame = ref_maps
+    """The device on exactly the ticks the reference's own code just mapped for `cpu_baseline`: raw events of both cameras in,
+    esvo_map_tick_resident per tick, PROCESS_EVENT_NUM of the shipped yaml (10 000 on DSEC).  Compared after the last of those
+    ticks -- the newest frame (same points; inverse depth to the LM tolerance: the reference's Eigen driver is third-party,
+    DESIGN.md section 2) and the DepthMap (valid-set IoU, inverse-depth RMSE on the intersection; north_star: RMSE < 1e-4) --
+    against TWO runs of the reference's sources (oracle/_ref, compiled unmodified):
+      reference_classes  EventBM / DepthProblemSolver / DepthFusion / DepthRegularization driven in MappingAtTime's order on the
+                         events the node selected (oracle/ref_harness.cpp), with the one behaviour the reference leaves undefined
+                         DEFINED: a grid cell whose list element SmartGrid::clean erased reads empty (SURVEY Appendix A-7)
+      reference_node     the esvo_Mapping node object itself, as is: its regulariser reads erased list elements through dangling
+                         grid pointers (freed memory); with RegularizationRadius 20 every such cell is a stale neighbour of up to
+                         41 x 41 cells, so inverse depths differ wherever the heap still holds the erased values -- reported, not
+                         a parity target (no implementation can reproduce freed memory)."""
+    pf, n_used, node_map, node_frame, cls_map, cls_frame, dangling = ref_maps
     dev = lib.Esvo(pf, rig, device=device)
     dev.ts_push_events(0, stream.ev_left)
     dev.ts_push_events(1, stream.ev_right)
     run_single(dev, stream, ticks, 0, n_used)
     gm, fr = dev.get_map(), dev.get_last_frame()
     dev.close()
-    W = rig.width
-    ka = gm["row"].astype(np.int64) * W + gm["col"]
-    kb = node_map["row"].astype(np.int64) * W + node_map["col"]
-    da = dict(zip(ka.tolist(), gm["inv_depth"].tolist()))
-    db = dict(zip(kb.tolist(), node_map["inv_depth"].tolist()))
-    both = [k for k in da if k in db and da[k] > -1e-6 and db[k] > -1e-6]
-    union = len(set(da) | set(db))
-    d = np.array([da[k] - db[k] for k in both]) if both else np.zeros(0)
-    out = {"events": int(pf.process_event_num), "ticks": int(n_used), "map_size": int(len(gm)), "reference_map_size": int(len(node_map)),
-           "iou": (len(set(da) & set(db)) / union) if union else 1.0,
-           "rmse": float(np.sqrt(np.mean(d * d))) if len(d) else 0.0,
-           "max_abs_diff": float(np.abs(d).max()) if len(d) else 0.0,
-           "frac_within_1e-6": float((np.abs(d) <= 1e-6).mean()) if len(d) else 1.0,
-           "frame_points": int(len(fr)), "reference_frame_points": int(len(node_frame))}
-    if len(fr) == len(node_frame) and len(fr):
-        same = bool(np.array_equal(fr["row"], node_frame["row"]) and np.array_equal(fr["col"], node_frame["col"]))
-        rel = np.abs(fr["inv_depth"] - node_frame["inv_depth"]) / np.maximum(np.abs(node_frame["inv_depth"]), 1e-300)
-        out["frame_same_points"] = same
-        out["frame_inv_depth_max_rel"] = float(rel.max())
-        out["frame_inv_depth_median_rel"] = float(np.median(rel))
-    out["note"] = ("device (esvo_map_tick_resident, raw events in) vs the reference's esvo_Mapping node object driven through its "
-                   "callbacks on the same events; with Regularization on the node regularises through erased list elements "
-                   "(SURVEY Appendix A-7: undefined behaviour upstream), which moves single cells")
+    out = {"events": int(pf.process_event_num), "ticks": int(n_used)}
+    out.update(_map_compare(gm, cls_map, rig.width))
+    out.update(_frame_compare(fr, cls_frame))
+    out["what"] = ("device (esvo_map_tick_resident, raw events in) vs the reference's mapper classes compiled from source and driven in "
+                   "MappingAtTime's order on the same events (erased grid cells read empty)")
+    node = {"erased_cells_still_referenced": int(dangling)}
+    node.update(_map_compare(gm, node_map, rig.width))
+    node.update(_frame_compare(fr, node_frame))
+    node["what"] = ("the same device map vs the esvo_Mapping node object as is: its regulariser (radius 20) reads erased list elements "
+                    "through dangling grid pointers -- undefined behaviour upstream (SURVEY Appendix A-7), reported for completeness")
+    out["node_object_as_is"] = node
     return out
 
 
@@ -989,6 +1010,7 @@ def cpu_baseline_reference(workload, rig, stream, ticks):
         over = {} if process_event_num is None else dict(process_event_num=process_event_num)
         pf, _ = params.make_params(params.PRESETS[wl["preset"]], rig, **over)
         node = ref.RefNode(pf, rig, stream.pose)
+        classes = ref.RefMapper(pf, rig) if process_event_num is None else None   # for bench.py's parity block (not timed)
         # (the node keeps the newest MAX_EVENT_QUEUE_LENGTH = 3 000 000 left events, esvo_Mapping.cpp:706-713: the stream is fed
         #  tick by tick as the events topic would, one 1 ms message ahead of the tick time)
         fed = 0
@@ -1022,7 +1044,15 @@ def cpu_baseline_reference(workload, rig, stream, ticks):
             t_map = time.perf_counter() - t0
             if k >= n_fill and ok:
                 rows.append((len(node.selected_events()), max(t_ts) + t_map, max(t_ts), t_map, len(node.newest_frame())))
-        return pf, rows, (pf, min(n_fill + n_meas, len(ticks)), node.get_map(), node.newest_frame())
+            if classes is not None and ok:   # the reference's classes on what the node just handed to its matcher
+                st_n, T_n = node.pose_table()
+                classes.set_observation(t, obs[0], obs[1], T)
+                classes.set_poses(st_n, T_n)
+                classes.tick(stream.ev_left[node.matched_events()])
+        if classes is None:
+            return pf, rows, None
+        return pf, rows, (pf, min(n_fill + n_meas, len(ticks)), node.get_map(), node.newest_frame(), classes.get_map(),
+                          classes.get_last_frame(), classes.counters()["dangling_cells"])
 
     p0 = params.make_params(params.PRESETS[wl["preset"]], rig)[0]
     n_fill = int(p0.max_fusion_frames) if p0.fusion_strategy == 0 else 5   # CONST_FRAMES: the window; CONST_POINTS: a few ticks

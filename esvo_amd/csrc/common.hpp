@@ -258,14 +258,14 @@ struct LmArgs {
   u32* split_order;
   u32* split_hist;
   int pair;                     // wide layout only: two waves per match (kernels_lm.hip "pair layout"); the caller's choice
-  // In-run shader-clock probe (nullable): lane 0 of every 64th workgroup reads s_memtime (shader cycles) and s_memrealtime
+  // In-run shader-clock probe (nullable): lane 0 of every 65th workgroup reads s_memtime (shader cycles) and s_memrealtime
   // (the constant reference clock) when it starts and when it ends and adds the two differences to clk[2 xcc], clk[2 xcc + 1]
-  // (xcc = the XCD the wave ran on), one sample to clk[16]; the start values wait in clk[CLK_SCRATCH + 2 * (block >> 6) ...].
+  // (xcc = the XCD the wave ran on), one sample to clk[16]; the start values wait in clk[CLK_SCRATCH + 2 * (block / 65) ...].
   // Sum of cycle differences / sum of reference differences x the reference rate = the clock the LM waves really ran at,
   // averaged over their lifetimes -- under the load of the whole tick, without a profiler attached.
   u64* clk;
 };
-constexpr u32 CLK_XCDS = 8, CLK_SAMPLES = 16, CLK_SCRATCH = 32;
+constexpr u32 CLK_XCDS = 8, CLK_SAMPLES = 16, CLK_SCRATCH = 32, CLK_STRIDE = 65;
 inline size_t clk_words(u32 max_ev) { return CLK_SCRATCH + 2 * ((size_t)max_ev / 64 + 2); }
 constexpr u32 LM_PAIR_MAX_EVENTS = 10000u;       // launches bounded by more events never use the pair layout (2 waves per match)
 constexpr u32 LM_TWO_QUEUES_MAX_EVENTS = 40000u;  // = LM_WIDE_MAX (kernels_lm.hip): launches that use the wide layout

@@ -49,8 +49,8 @@ _PERTURBED_PATH = os.path.join(_CSRC, "libesvo_hip_perturbed.so")
 def build(force=False, verbose=False, perturbed=False):
     """hipcc cross-compiles the extension for gfx950 in-tree (works without a GPU): one object per source file (in parallel,
     only the files that changed), then one link.
-    perturbed=True additionally links libesvo_hip_perturbed.so: the same library with -DESVO_PERTURB_ONE_ULP, i.e. ONE inverse
-    depth per tick off by one unit in the last place (kernels_lm.hip) -- never loaded by the product; tests/test_gpu_bench_parity.py
+    perturbed=True additionally links libesvo_hip_perturbed.so: the same library with -DESVO_PERTURB_ONE_ULP, i.e. the inverse
+    depth of every eighth solver slot off by one unit in the last place (kernels_lm.hip) -- never loaded by the product; tests/test_gpu_bench_parity.py
     points ESVO_HIP_LIB at it to show that bench.py's `parity.oracle_equal` notices a single flipped bit."""
     from concurrent.futures import ThreadPoolExecutor
     inc = os.path.join(_CSRC, "..", "..", "include")

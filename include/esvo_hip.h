@@ -207,7 +207,7 @@ typedef struct esvo_stats_t {
   uint32_t last_bm_info_noise_low, last_bm_coarse_fail, last_bm_fine_fail, pad2_;
   uint64_t total_bm_info_noise_low, total_bm_coarse_fail, total_bm_fine_fail;
   /* ABI 3 -- the shader clock the refinement kernel really ran at, measured inside the run (no profiler): lane 0 of every
-   * 64th workgroup of the kernel reads s_memtime (shader cycles) and s_memrealtime (constant reference clock, clk_ref_khz)
+   * 65th workgroup of the kernel reads s_memtime (shader cycles) and s_memrealtime (constant reference clock, clk_ref_khz)
    * when it starts and when it ends; the differences are summed per XCD since esvo_create / esvo_reset.
    * clock [MHz] of XCD x = clk_cycles[x] / clk_ref_ticks[x] * clk_ref_khz / 1000; all XCDs: the ratio of the sums. */
   uint64_t clk_cycles[8];

@@ -66,17 +66,36 @@ def run_reference(sc, ticks):
     return out, unit
 
 
+MAP_SHA_FIELDS = ("row", "col", "age", "inv_depth", "scale2", "nu", "variance", "residual", "x")   # every field but p_cam (1e-12)
+
+
+def ref_map_digest(mp, cells=None):
+    """sha256 over the list order and every exactly reproducible field of a DepthMap dump (+ the elements' true cells)"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in MAP_SHA_FIELDS:
+        h.update(np.ascontiguousarray(mp[f]).tobytes())
+    if cells is not None:
+        h.update(np.ascontiguousarray(cells, np.uint32).tobytes())
+    return np.frombuffer(h.digest(), np.uint8).copy()
+
+
 def make(name):
     sc = S.Scenario(name)
     ticks = sc.inputs()
     res, unit = run_reference(sc, ticks)
     out = dict(scenario=name, n_ticks=len(ticks), smooth=int(sc.params.smooth_time_surface))
+    big = name in S.BIG   # shipped tick sizes: digests of the maps, the last one in full
     for k, (tk, r) in enumerate(zip(ticks, res)):
         # the un-smoothed pair is stored; consumers re-apply GaussianBlurTS(5) where the preset asks for it
         out.update({f"t{k}": tk["t"], f"tsL{k}": tk["raw"][0], f"tsR{k}": tk["raw"][1], f"T{k}": tk["T"],
                     f"stamps{k}": tk["stamps"], f"poses{k}": tk["poses"], f"ev{k}": tk["ev"],
-                    f"matches{k}": r["matches"], f"points{k}": r["points"], f"nf{k}": r["nf"], f"map{k}": r["map"],
-                    f"cells{k}": r["cells"]})
+                    f"matches{k}": r["matches"], f"points{k}": r["points"], f"nf{k}": r["nf"]})
+        if not big or k == len(ticks) - 1:
+            out.update({f"map{k}": r["map"], f"cells{k}": r["cells"]})
+        if big:
+            out.update({f"map_n{k}": len(r["map"]), f"map_sha{k}": ref_map_digest(r["map"]),
+                        f"map_cells_sha{k}": ref_map_digest(r["map"], r["cells"])})
     out.update({"u_" + k: v for k, v in unit.items()})
     path = os.path.join(HERE, f"ref_{name}.npz")
     np.savez_compressed(path, **out)
@@ -512,11 +531,40 @@ def make_node():
     print("ref_node.npz", os.path.getsize(path) // 1024, "KiB")
 
 
+def make_node_big():
+    """the node objects on the shipped-size scenarios (esvo_Mapping on dsec10k, esvo_MVStereo on upenn1k), regulariser off as in
+    make_node: selection, window and a digest of every tick's fused + cleaned DepthMap -> ref_node_big.npz"""
+    out = {}
+    for name, mvs in (("dsec10k", False), ("upenn1k", True)):
+        sc = S.Scenario(name)
+        ticks, st = sc.inputs(), sc.stream()
+        g = np.load(os.path.join(HERE, f"ref_{name}.npz"))
+        res = run_node(sc, ticks, st, regularization=False, mvstereo=mvs)
+        pre = ("mvs_" if mvs else "") + f"{name}_"
+        out[pre + "n_ticks"] = len(ticks)
+        for k, (tk, r) in enumerate(zip(ticks, res)):
+            fr, ref = r["frame"], g[f"points{k}"]
+            assert len(fr) == len(ref) and all(np.array_equal(fr[f], ref[f]) for f in NODE_MAP_FIELDS + ("pose_idx", "p_cam"))
+            assert st.ev_left[r["matched"]].tobytes() == np.ascontiguousarray(tk["ev"]).tobytes()
+            out.update({pre + f"obs_t{k}": r["obs_t"], pre + f"window{k}": r["window"], pre + f"map_n{k}": len(r["map"]),
+                        pre + f"map_sha{k}": map_digest(r["map"])})
+        print("node (big)", name, [(len(r["sel"]), len(r["matched"]), r["window"].tolist(), len(r["map"])) for r in res])
+    path = os.path.join(HERE, "ref_node_big.npz")
+    np.savez_compressed(path, **out)
+    print("ref_node_big.npz", os.path.getsize(path) // 1024, "KiB")
+
+
 if __name__ == "__main__":
     assert R.available(), "needs /root/reference (build container only)"
+    if "--big" in sys.argv:   # only the shipped-size fixtures (round 4): ref_upenn1k.npz, ref_dsec10k.npz, ref_node_big.npz
+        for n in S.BIG:
+            make(n)
+        make_node_big()
+        sys.exit(0)
     names = [a for a in sys.argv[1:] if not a.startswith("-")] or list(S.SCENARIOS)
     for n in names:
         make(n)
+    make_node_big()
     make_units()
     make_track()
     make_sgm()

@@ -28,7 +28,16 @@ SCENARIOS = {
     # shortened to 4 frames so that the Mapping node's "clean only when the window is full" rule fires in a short run
     "hkust": dict(rig="hkust", preset="mapping_hkust", n_points=5000, rho=(0.35, 1.8), seed=20250504, n_ticks=6,
                   n_events=8000, speed=1.5, t_first=0.05, dt=0.01, overrides=dict(max_fusion_frames=4)),
+    # ---- the same rigs at the SHIPPED tick sizes (PROCESS_EVENT_NUM of cfg/mvstereo/mvstereo_upenn.yaml:18 and
+    # cfg/mapping/mapping_dsec.yaml:18).  Their fixtures keep every tick's matches and points but only digests of the
+    # DepthMaps (the last map in full): BIG below.
+    "upenn1k": dict(rig="upenn", preset="mvstereo_upenn", n_points=5000, rho=(0.16, 1.0), seed=20250501, n_ticks=4,
+                    n_events=1000, speed=1.0, t_first=0.06, dt=0.01),
+    # 15 000 scene points at 2 m/s fire ~1.2 M events/s per camera: the 10 ms slice holds > 10 000, the selection is cut
+    "dsec10k": dict(rig="dsec", preset="mapping_dsec", n_points=15000, rho=(0.02, 0.25), seed=20250512, n_ticks=6,
+                    n_events=10000, speed=2.0, t_first=0.05, dt=0.01),
 }
+BIG = ("upenn1k", "dsec10k")
 
 
 class Scenario:

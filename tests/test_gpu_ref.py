@@ -6,20 +6,23 @@
   esvo_map_refine    same solved + culled set; inverse depth rel <= 1e-4, <= 1e-6 for >= 99 % per tick; variance rel
                      <= 1e-3 for >= 98 %
   esvo_map_fuse      (propagate, fuse, clean, regularise) every DepthMap element bit-identical (p_cam rel <= 1e-12)
-and the chained device run end to end: valid-set IoU >= 0.97, inverse-depth RMSE < 1e-4 vs the reference's map
+and the chained device run end to end: valid-set IoU >= 0.999, inverse-depth RMSE < 1e-6 vs the reference's map
 (BASELINE.json north_star: "inverse-depth RMSE vs reference < 1e-4").  All four shipped rigs: upenn 346x260 (2x2 fusion,
 CONST_POINTS), DSEC 640x480 (smoothed TS, 3x3 fusion, r = 20), rpg 240x180 and hkust 346x260 (Denoising, r = 5).
 """
+import os
+
 import numpy as np
 import pytest
 
 import scenarios as S
-from test_ref_pin import NAMES, check_matches, check_points, load_fixture, map_stats, same_map
+from test_ref_pin import (ALL_NAMES, BIG_NAMES, BIG_POINT_BARS, IOU_BAR, NAMES, RMSE_NORTH_STAR, check_map, check_matches, check_points,
+                          load_fixture, map_stats, rmse_bar, same_map)
 
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name", NAMES)
+@pytest.mark.parametrize("name", ALL_NAMES)
 def test_gpu_stages_match_reference(name):
     from esvo_amd import lib
     g, sc, ticks = load_fixture(name)
@@ -28,26 +31,29 @@ def test_gpu_stages_match_reference(name):
         dev.set_observation(tk["t"], tk["raw"][0], tk["raw"][1], tk["T"])
         dev.set_poses(tk["stamps"], tk["poses"])
         check_matches(dev.match(tk["ev"]), g[f"matches{k}"], cost_exact=False, cost_atol=1e-12)
-        check_points(dev.refine(g[f"matches{k}"], cull=True), g[f"points{k}"])
+        check_points(dev.refine(g[f"matches{k}"], cull=True), g[f"points{k}"], **(BIG_POINT_BARS if name in BIG_NAMES else {}))
         dev.push_frame(g[f"points{k}"], tk["poses"])
         assert dev.fuse() == int(g[f"nf{k}"])
-        same_map(dev.get_map(), g[f"map{k}"])
+        check_map(dev.get_map(), g, k)
     dev.close()
 
 
-@pytest.mark.parametrize("name", NAMES)
+@pytest.mark.parametrize("name", ALL_NAMES)
 def test_gpu_chain_matches_reference_end_to_end(name):
+    """bars: what the chain achieves (IoU 1.0, RMSE <= 1.7e-7 measured), two orders inside north_star's RMSE < 1e-4"""
     from esvo_amd import lib
     g, sc, ticks = load_fixture(name)
     dev = lib.Esvo(sc.params, sc.rig, device=0)
     res = S.run_stagewise(dev, ticks, pre_smoothed=False)
     for k, r in enumerate(res):
+        if f"map{k}" not in g.files:   # shipped-size fixtures keep the last map in full
+            continue
         iou, rmse = map_stats(r["map"], g[f"map{k}"], sc.rig.width)
-        assert iou >= 0.97 and rmse < 1e-4, (k, iou, rmse)
+        assert iou >= IOU_BAR and rmse < rmse_bar(name) < RMSE_NORTH_STAR, (k, iou, rmse)
     dev.close()
 
 
-@pytest.mark.parametrize("name", NAMES)
+@pytest.mark.parametrize("name", ALL_NAMES)
 def test_gpu_chain_equals_canonical_oracle(name):
     """The same four rigs, device chain vs the oracle in its GPU-comparable arithmetic: every match, point and DepthMap
     element identical (hkust: Denoising + r = 5 + CONST_FRAMES; rpg: the 240x180 calibration)."""
@@ -57,6 +63,8 @@ def test_gpu_chain_equals_canonical_oracle(name):
     dev = lib.Esvo(sc.params, sc.rig, device=0)
     orc = O.OracleMapper(sc.params, sc.rig)
     orc.set_mode(True, True)
+    if name in BIG_NAMES:
+        orc.set_threads(os.cpu_count() or 1)
     a = S.run_stagewise(dev, ticks, pre_smoothed=False)
     b = S.run_stagewise(orc, ticks, pre_smoothed=False)
     for ra, rb in zip(a, b):
@@ -69,18 +77,18 @@ def test_gpu_chain_equals_canonical_oracle(name):
     dev.close()
 
 
-@pytest.mark.parametrize("name", NAMES)
+@pytest.mark.parametrize("name", ALL_NAMES)
 def test_gpu_resident_tick_from_raw_events_matches_the_reference_node(name):
     """The drop-in seam itself: raw events of both cameras in, esvo_map_tick_resident per tick (Time-Surface raster,
     rectification, smoothing, event selection, denoising, BM, LM, culling, window, fusion, clean, regulariser all on the
     device), against what the reference's NODE objects produced from the same events through their own callbacks
     (tests/golden/ref_node.npz: esvo_Mapping on dsec / hkust, esvo_MVStereo on upenn / rpg; their frames equal
     ref_<name>.npz's, asserted when the fixtures were made).  Frame: same points, inverse depth to the LM tolerance;
-    window: same frames; map: IoU >= 0.97, inverse-depth RMSE < 1e-4 (north_star's bar)."""
-    import os
+    window: same frames; map: IoU >= 0.999, inverse-depth RMSE < 1e-6 (north_star's bar is 1e-4).  Also at the shipped tick sizes
+    (upenn1k: 1000 events, dsec10k: 10 000 events; ref_node_big.npz)."""
     from esvo_amd import lib
     from test_ref_pin import GOLDEN
-    n = np.load(os.path.join(GOLDEN, "ref_node.npz"))
+    n = np.load(os.path.join(GOLDEN, "ref_node_big.npz" if name in BIG_NAMES else "ref_node.npz"))
     pre = f"{name}_" if f"{name}_n_ticks" in n else f"mvs_{name}_"
     g, sc, ticks = load_fixture(name)
     st = sc.stream()
@@ -93,10 +101,11 @@ def test_gpu_resident_tick_from_raw_events_matches_the_reference_node(name):
         win = n[pre + f"window{k}"]
         assert len(fr) == int(win[-1])
         fr["pose_idx"] = g[f"points{k}"]["pose_idx"]   # the window keeps its own pose slots; the virtual view is checked per stage above
-        check_points(fr, g[f"points{k}"])
+        check_points(fr, g[f"points{k}"], **(BIG_POINT_BARS if name in BIG_NAMES else {}))
         assert dev.stats().last_window_frames == len(win)
-        iou, rmse = map_stats(dev.get_map(), g[f"map{k}"], sc.rig.width)
-        assert iou >= 0.97 and rmse < 1e-4, (k, iou, rmse)
+        if f"map{k}" in g.files:
+            iou, rmse = map_stats(dev.get_map(), g[f"map{k}"], sc.rig.width)
+            assert iou >= IOU_BAR and rmse < rmse_bar(name) < RMSE_NORTH_STAR, (k, iou, rmse)
     dev.close()
 
 

@@ -15,7 +15,8 @@ stage by stage -- each stage is fed the REFERENCE's output of the previous one, 
                         form in oracle/ref_shim)
   fusion/clean/regularise  every element of the DepthMap, list order, believed row/col, true cell, age, nu, inverse
                         depth, scale, variance, residual: bit-identical; p_cam rel <= 1e-12; fusion count identical
-and end to end (the oracle's own chain): valid-set IoU >= 0.97, inverse-depth RMSE < 1e-4 on the intersection.
+and end to end (the oracle's own chain): valid-set IoU >= 0.999, inverse-depth RMSE < 1e-6 on the intersection (measured: 1.0,
+<= 1.7e-7; north_star asks for RMSE < 1e-4), also at the shipped tick sizes (ref_upenn1k.npz: 1000 events, ref_dsec10k.npz: 10 000).
 Where the reference tree is present (build container) the library is also run live against the fixtures.
 """
 import os
@@ -28,7 +29,44 @@ from oracle import oracle as O
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 NAMES = ["upenn", "dsec", "rpg", "hkust"]
+# the same rigs at the SHIPPED tick sizes (PROCESS_EVENT_NUM 1000 / 10 000: mvstereo_upenn.yaml:18, mapping_dsec.yaml:18); their
+# fixtures hold every tick's matches and points, digests of every DepthMap and the last map in full (tests/scenarios.py: BIG)
+BIG_NAMES = list(S.BIG)
+ALL_NAMES = NAMES + BIG_NAMES
 EXACT = ["inv_depth", "scale2", "nu", "variance", "residual", "x"]
+# End-to-end bars.  Measured: IoU 1.0 on every tick of every fixture, RMSE 0 ... 1.7e-7 on the small ones (the reference's Eigen
+# LM driver is third-party; two restatements of it stop at xtol = 1e-6 a few 1e-7 apart), 2.1e-8 on upenn1k and 1.7e-6 on
+# dsec10k (31 455 cells; the five LM outliers explained at BIG_POINT_BARS).  north_star's line is RMSE < 1e-4; the tests hold the
+# chain to what it achieves, so that losing 0.1 % of the cells fails.
+IOU_BAR, RMSE_BAR, RMSE_NORTH_STAR = 0.999, 1e-6, 1e-4
+RMSE_BAR_BIG = 1e-5
+
+
+def rmse_bar(name):
+    return RMSE_BAR_BIG if name in S.BIG else RMSE_BAR
+MAP_SHA_FIELDS = ("row", "col", "age", "inv_depth", "scale2", "nu", "variance", "residual", "x")
+
+
+def map_sha(mp, cells=None):
+    """the digest tests/golden/make_ref_fixtures.py stores for the maps of the shipped-size fixtures"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in MAP_SHA_FIELDS:
+        h.update(np.ascontiguousarray(mp[f]).tobytes())
+    if cells is not None:
+        h.update(np.ascontiguousarray(cells, np.uint32).tobytes())
+    return np.frombuffer(h.digest(), np.uint8)
+
+
+def check_map(mp, g, k, cells=None, p_cam_rtol=1e-12):
+    """every element of tick k's DepthMap equals the fixture's: field by field where the map is stored, else by digest"""
+    if f"map{k}" in g.files:
+        same_map(mp, g[f"map{k}"], cells, g[f"cells{k}"] if cells is not None else None, p_cam_rtol=p_cam_rtol)
+        return
+    assert len(mp) == int(g[f"map_n{k}"]), (k, len(mp), int(g[f"map_n{k}"]))
+    assert np.array_equal(map_sha(mp), g[f"map_sha{k}"]), k
+    if cells is not None:
+        assert np.array_equal(map_sha(mp, cells), g[f"map_cells_sha{k}"]), k
 
 
 def load_fixture(name):
@@ -64,7 +102,16 @@ def check_matches(mt, ref, cost_exact=True, cost_atol=0.0):
         assert np.abs(mt["cost"] - ref["cost"]).max() <= cost_atol
 
 
-def check_points(pts, ref, rho_rtol=1e-4, rho_tight=1e-6, rho_frac=0.99, var_rtol=1e-3, var_frac=0.98):
+# LM bars at the shipped tick sizes (5 800 solved points per tick on dsec10k).  The solved / culled SET is still identical and
+# 99.85 % of 34 841 points agree to 1e-6, 99.986 % to 1e-4 -- but five points differ by 1e-4 ... 1.5e-2: the two functors agree to
+# 1e-12 grey levels there, the OBJECTIVE is discontinuous (the uncapped Student-t scale loop of DepthProblem.cpp:96-124 jumps
+# between its converged and its collapsed outcome: |F|^2 688 -> 5e-4 between two neighbouring inverse depths), and a last-bit
+# difference in a forward-difference Jacobian decides on which side a trial step lands.  The reference's own result depends on
+# its Eigen build in the same way; the bars are statistical by nature, not by sloppiness.
+BIG_POINT_BARS = dict(rho_rtol=5e-2, rho_frac=0.995, mid_frac=0.999)
+
+
+def check_points(pts, ref, rho_rtol=1e-4, rho_tight=1e-6, rho_frac=0.99, var_rtol=1e-3, var_frac=0.98, mid_frac=None):
     assert len(pts) == len(ref)
     if not len(ref):
         return
@@ -72,6 +119,14 @@ def check_points(pts, ref, rho_rtol=1e-4, rho_tight=1e-6, rho_frac=0.99, var_rto
         assert np.array_equal(pts[f], ref[f]), f
     rel = np.abs(pts["inv_depth"] - ref["inv_depth"]) / ref["inv_depth"]
     assert rel.max() <= rho_rtol and (rel <= rho_tight).mean() >= rho_frac, (rel.max(), (rel <= rho_tight).mean())
+    if mid_frac is not None:
+        assert (rel <= 1e-4).mean() >= mid_frac, (rel <= 1e-4).mean()
+        # outliers sit at jumps of the objective: compare the costs only where the solutions agree
+        ok = rel <= 1e-4
+        assert np.allclose(pts["residual"][ok], ref["residual"][ok], rtol=1e-3)
+        rv = np.abs(pts["variance"] - ref["variance"]) / np.maximum(ref["variance"], 1e-300)
+        assert (rv <= var_rtol).mean() >= var_frac, (rv <= var_rtol).mean()
+        return
     rel = np.abs(pts["variance"] - ref["variance"]) / np.maximum(ref["variance"], 1e-300)
     assert (rel <= var_rtol).mean() >= var_frac, (rel <= var_rtol).mean()
     assert np.allclose(pts["residual"], ref["residual"], rtol=1e-3)
@@ -89,29 +144,35 @@ def map_stats(mp, ref, W):
     return (len(set(da) & set(db)) / union if union else 1.0), rmse
 
 
-@pytest.mark.parametrize("name", NAMES)
+@pytest.mark.parametrize("name", ALL_NAMES)
 def test_oracle_stages_match_reference(name):
     g, sc, ticks = load_fixture(name)
     m = O.OracleMapper(sc.params, sc.rig)  # literal mode
+    if name in BIG_NAMES:
+        m.set_threads(os.cpu_count() or 1)
     for k, tk in enumerate(ticks):
         m.set_observation(tk["t"], tk["raw"][0], tk["raw"][1], tk["T"])
         m.set_poses(tk["stamps"], tk["poses"])
         check_matches(m.match(tk["ev"]), g[f"matches{k}"])
-        check_points(m.refine(g[f"matches{k}"], cull=True), g[f"points{k}"])
+        check_points(m.refine(g[f"matches{k}"], cull=True), g[f"points{k}"], **(BIG_POINT_BARS if name in BIG_NAMES else {}))
         m.push_frame(g[f"points{k}"], tk["poses"])
         assert m.fuse() == int(g[f"nf{k}"])
-        same_map(m.get_map(), g[f"map{k}"], m.get_map_cells(), g[f"cells{k}"])
+        check_map(m.get_map(), g, k, m.get_map_cells())
     assert int(g["u_dangling"]) > 0 and m.counters()["replace_displaced"] > 0  # Appendix A-7 is exercised
 
 
-@pytest.mark.parametrize("name", NAMES)
+@pytest.mark.parametrize("name", ALL_NAMES)
 def test_oracle_chain_matches_reference_end_to_end(name):
     g, sc, ticks = load_fixture(name)
     m = O.OracleMapper(sc.params, sc.rig)
+    if name in BIG_NAMES:
+        m.set_threads(os.cpu_count() or 1)
     res = S.run_stagewise(m, ticks, pre_smoothed=False)
     for k, r in enumerate(res):
+        if f"map{k}" not in g.files:   # shipped-size fixtures keep the last map in full
+            continue
         iou, rmse = map_stats(r["map"], g[f"map{k}"], sc.rig.width)
-        assert iou >= 0.97 and rmse < 1e-4, (k, iou, rmse)
+        assert iou >= IOU_BAR and rmse < rmse_bar(name) < RMSE_NORTH_STAR, (k, iou, rmse)
 
 
 @pytest.mark.parametrize("name", NAMES)
@@ -158,7 +219,7 @@ def test_student_t_and_zncc_units():
         assert abs(O.zncc_cost(l.astype(np.float64), r.astype(np.float64), exact_int=True) - c) <= 1e-12
 
 
-@pytest.mark.parametrize("name", NAMES)
+@pytest.mark.parametrize("name", ALL_NAMES)
 def test_live_reference_reproduces_fixture(name):
     from oracle import ref as R
     if not os.path.isdir(os.path.join(R.REFERENCE, "esvo_core", "src")):
@@ -170,7 +231,7 @@ def test_live_reference_reproduces_fixture(name):
         check_matches(x["matches"], g[f"matches{k}"])
         assert np.array_equal(x["points"]["inv_depth"], g[f"points{k}"]["inv_depth"])
         assert x["nf"] == int(g[f"nf{k}"])
-        same_map(x["map"], g[f"map{k}"], p_cam_rtol=0.0)
+        check_map(x["map"], g, k, p_cam_rtol=0.0)
 
 
 def _tracker_on_fixture(make_tracker):
