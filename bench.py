@@ -355,8 +355,9 @@ def main():
         # weak scaling: K timed (and Wm warm-up) ticks PER GPU in the tick-interleaved mode; the band mode splits every tick
         per_gpu = world if (world > 1 and shard_mode == "tick" and not strong) else 1
         n_ticks = (K + Wm) * per_gpu
-        # (one GPU: the stream is generated once for every operating point of the run, the sustained point's 40-tick segment included)
-        rig, stream, p, ticks = make_workload(args.workload, max(n_ticks, 40) if not dist else n_ticks, args.events_per_tick,
+        # (at least 40 ticks whatever N is: the seeded stream -- its noise events are drawn over the whole duration -- is then the
+        #  same for an N-rank run and the one-rank run it is compared with, and serves the sustained point's 40-tick segment too)
+        rig, stream, p, ticks = make_workload(args.workload, max(n_ticks, 40), args.events_per_tick,
                                               r01_scene=args.r01_scene, share=(rank, dist.barrier) if dist else None)
         duration = (stream.t1_ns - stream.t0_ns) * 1e-9
 
@@ -903,16 +904,18 @@ def other_operating_points(device):
 
     def closed_loop():
         # BASELINE.json configs[2]: 346x260, the full mapping + tracking loop on one GPU -- SGM bootstrap, then per cycle both
-        # Time Surfaces, the tracker's registration (residuals / Jacobian on the device, the Gauss-Newton update on the host in
-        # Python: the reference keeps its optimiser on the host too) and the mapper tick fed with the TRACKED poses
+        # Time Surfaces, the tracker's registration (residuals, Jacobian and their products J^T J / J^T f on the device in one
+        # launch per iteration; the 6 x 6 Gauss-Newton update on the host in C++ inside the library -- the reference keeps its
+        # optimiser on the host too) and the mapper tick fed with the TRACKED poses
         from esvo_amd import closed_loop as cl
         r = cl.run(n_ticks=15)
         med = lambda v: float(np.median(np.asarray(v[3:])))  # steady state: past the first cycles
         return {"ms_per_cycle": med(r["cycle_ms"]), "ms_tracking": med(r["track_ms"]), "ms_mapping": med(r["map_ms"]),
                 "cycles": len(r["cycle_ms"]), "path_mm": r["gt_len"][-1] * 1e3, "final_position_error_mm": r["pos_err"][-1] * 1e3,
                 "depth_points_per_cycle": int(np.median(r["points"])), "map_median_abs_inv_depth_error": r["map_median_abs_err"],
-                "note": "synthetic 346x260 scene, poses from the tracker only (bootstrap pose given); tracker optimiser in host "
-                        "Python over esvo_track_residuals / esvo_track_jacobian (12 Gauss-Newton iterations at most)"}
+                "note": "synthetic 346x260 scene, poses from the tracker only (bootstrap pose given); tracker optimiser = "
+                        "esvo_track_register (host C++ over esvo_track_normal_equations: one launch and 224 B back per iteration, "
+                        "12 Gauss-Newton iterations at most)"}
 
     out["upenn346x260_throughput"] = throughput("upenn346x260", 20)
     out["dsec640x480_reference_faithful_10000"] = latency("dsec640x480", 10000, 20)

@@ -1,7 +1,8 @@
 """Closed-loop harness: SGM bootstrap -> tracker -> mapper, all three on the device.
 
-The tracker's optimiser is host-side Python (a damped Gauss-Newton over esvo_track_residuals / esvo_track_jacobian,
-the same residual and Jacobian RegProblemLM hands to Eigen's LM, esvo_core/src/core/RegProblemLM.cpp:93-236);
+The tracker's optimiser is host-side C++ inside the library (esvo_track_register: a damped Gauss-Newton over
+esvo_track_normal_equations -- the same residual and Jacobian RegProblemLM hands to Eigen's LM,
+esvo_core/src/core/RegProblemLM.cpp:93-236, reduced to J^T J / J^T f on the device);
 the poses the mapper fuses with are the tracker's estimates, never ground truth after the bootstrap pose.
 
 Property of the formulation worth knowing when reading the bars: the map sits on the LEADING edge of the
@@ -33,7 +34,15 @@ def orth(R):
 
 
 def register(dev, n_points, R_, t_, iters=12):
-    """Damped Gauss-Newton on (cayley, translation); (R_, t_) is the current camera in the reference frame."""
+    """The registration of one frame: the library's driver (esvo_track_register: host C++ over esvo_track_normal_equations,
+    one launch and 224 bytes back per iteration)."""
+    R, t, rms, _ = dev.track_register(n_points, R_, t_, huber=True, huber_threshold=50.0, max_iterations=iters, damping=1e-3)
+    return R, t, rms
+
+
+def register_python(dev, n_points, R_, t_, iters=12):
+    """The same damped Gauss-Newton on (cayley, translation) in Python over esvo_track_residuals / esvo_track_jacobian (two
+    synchronous calls and a count x 7 download per iteration): round 3's driver, kept as the cross-check of the C++ one."""
     r = None
     for _ in range(iters):
         Tlr = np.eye(4)

@@ -151,9 +151,30 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
       }
     }
     h->prio_note[0] = prio_lo; h->prio_note[1] = prio_hi;
-    CK(hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, pf));
+    // ESVO_CU_SPLIT="b[,f]" (A/B only): SPATIAL partition instead of priorities -- the fusion stage's stream is confined to b
+    // compute units, the matching stage's to the next f (0: it shares the LM stage's), the LM queues get the rest.
+    if (const char* ec = std::getenv("ESVO_CU_SPLIT")) {
+      int nb = 0, nf = 0;
+      std::sscanf(ec, "%d,%d", &nb, &nf);
+      hipDeviceProp_t prop;
+      CK(hipGetDeviceProperties(&prop, device));
+      const int ncu = prop.multiProcessorCount;
+      if (nb > 0 && nb + nf < ncu) { h->cu_split[0] = nb; h->cu_split[1] = nf; h->cu_split[2] = ncu; }
+    }
+    auto make_masked = [&](hipStream_t* st, int lo, int hi) {  // CUs [lo, hi) in HSA order
+      uint32_t mask[16] = {0};
+      for (int i = lo; i < hi; ++i) mask[i >> 5] |= 1u << (i & 31);
+      return hipExtStreamCreateWithCUMask(st, (uint32_t)((h->cu_split[2] + 31) / 32), mask);
+    };
+    if (h->cu_split[0]) {
+      const int nb = h->cu_split[0], nf = h->cu_split[1], ncu = h->cu_split[2];
+      CK(make_masked(&h->stream_b, 0, nb));
+      CK(nf ? make_masked(&h->stream, nb, nb + nf) : make_masked(&h->stream, nb, ncu));
+    } else {
+      CK(hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, pf));
+      CK(hipStreamCreateWithPriority(&h->stream_b, hipStreamNonBlocking, pb));
+    }
     h->own_stream = true;
-    CK(hipStreamCreateWithPriority(&h->stream_b, hipStreamNonBlocking, pb));
     if (have_explicit) h->prio_note[2] = pl_explicit; else h->prio_note[2] = 12345;
   }
   {
@@ -163,8 +184,15 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
     if (const char* e3 = std::getenv("ESVO_PRIO_LM")) pl = std::atoi(e3) == 0 ? hi : (std::atoi(e3) == 2 ? lo : 0);  // A/B only
     if (h->prio_note[2] != 12345) pl = h->prio_note[2];
     if (std::getenv("ESVO_PRIO_PRINT")) fprintf(stderr, "[esvo] stream priority range: lowest %d .. highest %d; LM %d\n", lo, hi, pl);
-    CK(hipStreamCreateWithPriority(&h->stream_l, hipStreamNonBlocking, pl));
-    CK(hipStreamCreateWithPriority(&h->stream_l1, hipStreamNonBlocking, pl));
+    if (h->cu_split[0]) {
+      uint32_t mask[16] = {0};
+      for (int i = h->cu_split[0] + h->cu_split[1]; i < h->cu_split[2]; ++i) mask[i >> 5] |= 1u << (i & 31);
+      CK(hipExtStreamCreateWithCUMask(&h->stream_l, (uint32_t)((h->cu_split[2] + 31) / 32), mask));
+      CK(hipExtStreamCreateWithCUMask(&h->stream_l1, (uint32_t)((h->cu_split[2] + 31) / 32), mask));
+    } else {
+      CK(hipStreamCreateWithPriority(&h->stream_l, hipStreamNonBlocking, pl));
+      CK(hipStreamCreateWithPriority(&h->stream_l1, hipStreamNonBlocking, pl));
+    }
     if (const char* ep = std::getenv("ESVO_LM_PAIR")) h->lm_pair_forced = std::atoi(ep) == 1 ? 1 : (std::atoi(ep) == 0 ? 0 : -1);
     if (const char* eq = std::getenv("ESVO_LM_QUEUES")) h->lm_queues = std::atoi(eq) == 1 ? 1 : (std::atoi(eq) == 2 ? 2 : 0);
     if (const char* em = std::getenv("ESVO_LM_QUEUES_MAX_EVENTS")) h->lm_two_max = (u32)std::strtoul(em, nullptr, 10);  // A/B only
@@ -365,6 +393,7 @@ int esvo_destroy(esvo_handle h) {
   if (h->evt_ok) for (int i = 0; i < EV_N; ++i) hipEventDestroy(h->evt[i]);
   if (h->pool_ok) for (int i = 0; i < esvo_context::POSE_POOL; ++i) hipEventDestroy(h->pool_evt[i]);
   if (h->h_pose_pool) hipHostFree(h->h_pose_pool);
+  if (h->h_trk_ne) hipHostFree(h->h_trk_ne);
   for (int cam = 0; cam < 2; ++cam) if (h->d_wire[cam]) hipFree(h->d_wire[cam]);
   if (h->evt_trk_read) hipEventDestroy(h->evt_trk_read);
   for (void* q : {(void*)h->d_viz_bgr, (void*)h->d_viz_jet, (void*)h->d_viz_owner}) if (q) hipFree(q);

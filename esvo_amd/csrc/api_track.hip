@@ -1,5 +1,6 @@
 // api_track.hip — tracker residual / Jacobian evaluation on the device-resident Time Surface (see context.hpp).
 #include "context.hpp"
+#include "../../include/esvo_hip.hpp"  // esvo_hip::gauss_newton_register: the host-side driver esvo_track_register runs
 
 // ---- Tracker residual / Jacobian evaluation ---------------------------------------
 extern "C" {
@@ -136,6 +137,62 @@ int esvo_track_jacobian(esvo_handle h, const double R[9], const double t[3], siz
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(fjac, h->d_trk_out, m * 6 * sizeof(double), hipMemcpyDeviceToHost, h->stream_t));
   HIPCHK(hipStreamSynchronize(h->stream_t));
+  return ESVO_OK;
+}
+
+// f = operator()(0), J = df(0) and their products in one launch: H = J^T J (6 x 6, row-major, symmetric), b = J^T f, cost = |f|^2
+int esvo_track_normal_equations(esvo_handle h, const double R[9], const double t[3], size_t offset, size_t count, int ls_norm,
+                                double huber_threshold, double H[36], double b[6], double* cost, size_t* n_out) {
+  if (!h || !R || !t || !H || !b || !n_out || (ls_norm != ESVO_TRACK_L2 && ls_norm != ESVO_TRACK_HUBER)) return ESVO_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> _trk_lock(h->mu_track);
+  if (!h->trk_cur) FAIL(ESVO_ERR_STATE, "esvo_track_set_current has not been called");
+  HIPCHK(hipSetDevice(h->device));
+  const size_t m = offset >= h->trk_n ? 0 : std::min(count, h->trk_n - offset);
+  *n_out = m;
+  std::memset(H, 0, sizeof(double) * 36);
+  std::memset(b, 0, sizeof(double) * 6);
+  if (cost) *cost = 0.0;
+  if (m == 0) return ESVO_OK;
+  if (!h->h_trk_ne) HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h->h_trk_ne), sizeof(double) * TRK_NE_TERMS));
+  TrackArgs a;
+  fill_track_args(h, a);
+  TrackPose pose;  // as esvo_track_jacobian: T_left_ref = [R^T | -R^T t] (RegProblemLM.cpp:203-205), J_constPart (:189-194)
+  std::memset(pose.T, 0, sizeof(pose.T));
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) pose.T[r * 4 + c] = R[c * 3 + r];
+    pose.T[r * 4 + 3] = (-R[0 * 3 + r] * t[0] + -R[1 * 3 + r] * t[1]) + -R[2 * 3 + r] * t[2];
+  }
+  pose.T[15] = 1.0;
+  const double iP11 = 1.0 / a.P[0], iP22 = 1.0 / a.P[5];
+  for (int r = 0; r < 3; ++r) { pose.Jc[r * 2 + 0] = R[0 * 3 + r] * iP11; pose.Jc[r * 2 + 1] = R[1 * 3 + r] * iP22; }
+  launch_track_normal(a, pose, (u32)offset, (u32)m, ls_norm == ESVO_TRACK_HUBER, huber_threshold, h->d_trk_out, h->stream_t);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(h->h_trk_ne, h->d_trk_out, sizeof(double) * TRK_NE_TERMS, hipMemcpyDeviceToHost, h->stream_t));
+  HIPCHK(hipStreamSynchronize(h->stream_t));
+  int n = 0;
+  for (int i = 0; i < 6; ++i)
+    for (int j = i; j < 6; ++j) { H[i * 6 + j] = H[j * 6 + i] = h->h_trk_ne[n]; ++n; }
+  for (int i = 0; i < 6; ++i) b[i] = h->h_trk_ne[21 + i];
+  if (cost) *cost = h->h_trk_ne[27];
+  return ESVO_OK;
+}
+
+// The registration of one frame: esvo_hip::gauss_newton_register (include/esvo_hip.hpp, host C++) over
+// esvo_track_normal_equations -- one launch and 224 bytes back per iteration.
+int esvo_track_register(esvo_handle h, size_t n_points, double R[9], double t[3], int ls_norm, double huber_threshold,
+                        int max_iterations, double damping, double* rms, int* iterations) {
+  if (!h || !R || !t || max_iterations < 1) return ESVO_ERR_INVALID_ARG;
+  int rc = ESVO_OK;
+  auto ne = [&](const double* Rc, const double* tc, double* H, double* b, double* cost, size_t* n) {
+    rc = esvo_track_normal_equations(h, Rc, tc, 0, n_points, ls_norm, huber_threshold, H, b, cost, n);
+    return rc == ESVO_OK;
+  };
+  const esvo_hip::Registration res = esvo_hip::gauss_newton_register(ne, R, t, max_iterations, damping);
+  if (rc) return rc;
+  std::memcpy(R, res.R, sizeof(res.R));
+  std::memcpy(t, res.t, sizeof(res.t));
+  if (rms) *rms = res.rms;
+  if (iterations) *iterations = res.iterations;
   return ESVO_OK;
 }
 }  // extern "C"

@@ -228,6 +228,10 @@ void launch_track_reference(const float* xyz, u32 n, const TrackRef& r, double* 
 void launch_track_residuals(const TrackArgs& a, const TrackPose& pose, u32 offset, u32 count, int huber, double thr, double* fvec,
                             hipStream_t s);
 void launch_track_jacobian(const TrackArgs& a, const TrackPose& pose, u32 offset, u32 count, double* fjac, hipStream_t s);
+#define TRK_NE_THREADS 256
+#define TRK_NE_TERMS 28   // 21 upper-triangle entries of J^T J, 6 of J^T f, |f|^2
+void launch_track_normal(const TrackArgs& a, const TrackPose& pose, u32 offset, u32 count, int huber, double thr, double* out28,
+                         hipStream_t s);
 
 // kernels_shard.hip: ordering of a tick's frame from the ranks' (matched, kept) bits
 void launch_shard_codes(const u32* own_w, const u32* keep, const u32* n_local, u32 max_local, uint8_t* codes, hipStream_t s);

@@ -69,6 +69,7 @@ struct esvo_context {
   u32 lm_two_max = esvo::LM_TWO_QUEUES_MAX_EVENTS;  // launches bounded by more events stay on one queue
   bool lm_split = true;           // ESVO_LM_STREAM=0: everything of the front stage on `stream`
   bool one_stream = false;       // ESVO_ONE_STREAM=1 (A/B): stream_b aliases stream
+  int cu_split[3] = {0, 0, 0};    // ESVO_CU_SPLIT (A/B): CUs of the fusion / matching streams, CUs of the device
   bool split_now = false;         // set by esvo_map_tick around its front stage: only the lazy tick path splits
   uint8_t* d_obs2[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
   int obs_par = 0;
@@ -257,6 +258,7 @@ struct esvo_context {
   float* d_trk_xyz = nullptr;
   double* d_trk_pts = nullptr;
   double* d_trk_out = nullptr;
+  double* h_trk_ne = nullptr;     // pinned: the 28 sums of esvo_track_normal_equations
   size_t trk_cap = 0, trk_n = 0;
   bool trk_cur = false;
   hipEvent_t evt_trk_read = nullptr;  // the tracker stream has read the resident left Time Surface (mu_ts)

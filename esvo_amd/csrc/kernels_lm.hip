@@ -923,13 +923,14 @@ __global__ void __launch_bounds__(PAIR ? 128 : LM_BLOCK, WIDE ? LM_WIDE_WAVES : 
     o.x[0] = pr.cx;
     o.x[1] = pr.cy;
     cam2World(p.camL, pr.cx, pr.cy, x, o.p_cam);                 // :119
-    o.inv_depth = x;                                             // update_studentT, new-point branch
 #ifdef ESVO_PERTURB_ONE_ULP
-    // libesvo_hip_perturbed.so only (esvo_amd/lib.py build(perturbed=True)): the inverse depth of every eighth solver slot one
-    // unit in the last place off -- the deliberate defect tests/test_gpu_bench_parity.py uses to show that bench.py's
-    // parity.oracle_equal has teeth
-    if ((s & 7u) == 7u) o.inv_depth = __longlong_as_double(__double_as_longlong(x) ^ 1ll);
+    // libesvo_hip_perturbed.so only (esvo_amd/lib.py build(perturbed=True)): the depth of every eighth solver slot's point one
+    // unit in the last place off (p_cam is what the fusion propagates) -- the deliberate defect tests/test_gpu_bench_parity.py
+    // uses to show that bench.py's parity.oracle_equal has teeth
+    if ((s & 7u) == 7u) o.p_cam[2] = __longlong_as_double(__double_as_longlong(o.p_cam[2]) ^ 1ll);
 #endif
+    o.inv_depth = x;                                             // update_studentT, new-point branch
+
     o.scale2 = L2 ? 0.0 : variance * (p.td_nu - 2) / p.td_nu;    // :125 (l2: the Gaussian update leaves scaleSquared_ / nu_
     o.nu = L2 ? 0.0 : p.td_nu;                                   //  as constructed -- zero here and in the oracle, Appendix A-8)
     o.variance = variance;

@@ -81,21 +81,24 @@ __device__ inline bool trk_interp(const TrackArgs& a, const Px* __restrict__ img
   return true;
 }
 
-// RegProblemLM::operator() (:91-136) + thread() (:138-176)
+// one value of RegProblemLM::operator() (:91-136) + thread() (:138-176)
+__device__ inline double trk_residual(const TrackArgs& a, const double* T_left_ref, const double pp[3], int huber, double huber_threshold) {
+  double x[2], r = 255.0, tau;
+  if (trk_reproject(a, pp, T_left_ref, x) && trk_interp(a, a.neg, x, tau)) r = tau;
+  if (huber) {
+    double w = 1.0;
+    if (r > huber_threshold) w = huber_threshold / r;
+    r = sqrt(w) * r;
+  }
+  return r;
+}
 __global__ void __launch_bounds__(256) track_residual_kernel(TrackArgs a, TrackPose pose, u32 offset, u32 count, int huber,
                                                              double huber_threshold, double* __restrict__ fvec) {
   const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= count) return;
   const double* p = a.pts + 3 * (size_t)(offset + k);
   const double pp[3] = {p[0], p[1], p[2]};
-  double x[2], r = 255.0, tau;
-  if (trk_reproject(a, pp, pose.T, x) && trk_interp(a, a.neg, x, tau)) r = tau;
-  if (huber) {
-    double w = 1.0;
-    if (r > huber_threshold) w = huber_threshold / r;
-    r = sqrt(w) * r;
-  }
-  fvec[k] = r;
+  fvec[k] = trk_residual(a, pose.T, pp, huber, huber_threshold);
 }
 void launch_track_residuals(const TrackArgs& a, const TrackPose& pose, u32 offset, u32 count, int huber, double thr, double* fvec,
                             hipStream_t s) {
@@ -103,13 +106,8 @@ void launch_track_residuals(const TrackArgs& a, const TrackPose& pose, u32 offse
   hipLaunchKernelGGL(track_residual_kernel, dim3((count + 255) / 256), dim3(256), 0, s, a, pose, offset, count, huber, thr, fvec);
 }
 
-// RegProblemLM::df at x = 0 (:178-269); pose.T = T_left_ref, pose.Jc = J_constPart (3x2); fjac is count x 6 column-major
-__global__ void __launch_bounds__(256) track_jacobian_kernel(TrackArgs a, TrackPose pose, u32 offset, u32 count,
-                                                             double* __restrict__ fjac) {
-  const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= count) return;
-  const double* pq = a.pts + 3 * (size_t)(offset + k);
-  const double p[3] = {pq[0], pq[1], pq[2]};
+// one row of RegProblemLM::df at x = 0 (:178-269); pose.T = T_left_ref, pose.Jc = J_constPart (3x2)
+__device__ inline void trk_jacobian_row(const TrackArgs& a, const TrackPose& pose, const double p[3], double row[6]) {
   double e[12];
   double x[2];
   if (!trk_reproject(a, p, pose.T, x)) {
@@ -137,17 +135,73 @@ __global__ void __launch_bounds__(256) track_jacobian_kernel(TrackArgs a, TrackP
       e[j] = (c[j] * p[0]) * z; e[3 + j] = (c[j] * p[1]) * z; e[6 + j] = (c[j] * p[2]) * z; e[9 + j] = c[j] * z;
     }
   }
+  row[0] = -(2.0 * e[5] - 2.0 * e[7]);
+  row[1] = -(2.0 * e[6] - 2.0 * e[2]);
+  row[2] = -(2.0 * e[1] - 2.0 * e[3]);
+  row[3] = -e[9];
+  row[4] = -e[10];
+  row[5] = -e[11];
+}
+// fjac is count x 6 column-major
+__global__ void __launch_bounds__(256) track_jacobian_kernel(TrackArgs a, TrackPose pose, u32 offset, u32 count,
+                                                             double* __restrict__ fjac) {
+  const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= count) return;
+  const double* pq = a.pts + 3 * (size_t)(offset + k);
+  const double p[3] = {pq[0], pq[1], pq[2]};
+  double row[6];
+  trk_jacobian_row(a, pose, p, row);
   const size_t m = count;
-  fjac[0 * m + k] = -(2.0 * e[5] - 2.0 * e[7]);
-  fjac[1 * m + k] = -(2.0 * e[6] - 2.0 * e[2]);
-  fjac[2 * m + k] = -(2.0 * e[1] - 2.0 * e[3]);
-  fjac[3 * m + k] = -e[9];
-  fjac[4 * m + k] = -e[10];
-  fjac[5 * m + k] = -e[11];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) fjac[(size_t)j * m + k] = row[j];
 }
 void launch_track_jacobian(const TrackArgs& a, const TrackPose& pose, u32 offset, u32 count, double* fjac, hipStream_t s) {
   if (count == 0) return;
   hipLaunchKernelGGL(track_jacobian_kernel, dim3((count + 255) / 256), dim3(256), 0, s, a, pose, offset, count, fjac);
+}
+
+// ---- normal equations of one Gauss-Newton / LM iteration in ONE launch --------------------------------------------------
+// What RegProblemSolverLM::solve_analytical's iteration consumes (esvo_core/src/core/RegProblemSolverLM.cpp:148-215:
+// minimizeInit -> F(0), minimizeOneStep -> df at 0, then the 6 x 6 system): f = operator()(0) with the Huber weights
+// (:121-131), J = df(0) (the reference's Jacobian carries no weight), and their products J^T J (21 upper-triangle entries,
+// row-major i <= j), J^T f (6) and |f|^2 -- 28 doubles instead of count x 7 over PCIe and two synchronous calls.
+// Summation order (the oracle restates it: orc_tracker_normal_equations): thread t of the single 256-thread workgroup adds
+// the terms of points t, t + 256, t + 512, ... in that order; the 256 partial sums are then folded by the tree
+// s[t] += s[t + 128], s[t] += s[t + 64], ..., s[0] += s[1].
+__global__ void __launch_bounds__(TRK_NE_THREADS) track_normal_kernel(TrackArgs a, TrackPose pose, u32 offset, u32 count, int huber,
+                                                                    double huber_threshold, double* __restrict__ out) {
+  __shared__ double red[TRK_NE_TERMS][TRK_NE_THREADS];
+  double acc[TRK_NE_TERMS];
+#pragma unroll
+  for (int n = 0; n < TRK_NE_TERMS; ++n) acc[n] = 0.0;
+  for (u32 k = threadIdx.x; k < count; k += TRK_NE_THREADS) {
+    const double* pq = a.pts + 3 * (size_t)(offset + k);
+    const double p[3] = {pq[0], pq[1], pq[2]};
+    const double f = trk_residual(a, pose.T, p, huber, huber_threshold);
+    double row[6];
+    trk_jacobian_row(a, pose, p, row);
+    int n = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = i; j < 6; ++j) { acc[n] = acc[n] + row[i] * row[j]; ++n; }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) acc[21 + i] = acc[21 + i] + row[i] * f;
+    acc[27] = acc[27] + f * f;
+  }
+#pragma unroll
+  for (int n = 0; n < TRK_NE_TERMS; ++n) red[n][threadIdx.x] = acc[n];
+  for (u32 s = TRK_NE_THREADS / 2; s > 0; s >>= 1) {
+    __syncthreads();
+    if (threadIdx.x < s)
+      for (int n = 0; n < TRK_NE_TERMS; ++n) red[n][threadIdx.x] = red[n][threadIdx.x] + red[n][threadIdx.x + s];
+  }
+  __syncthreads();
+  if (threadIdx.x < TRK_NE_TERMS) out[threadIdx.x] = red[threadIdx.x][0];
+}
+void launch_track_normal(const TrackArgs& a, const TrackPose& pose, u32 offset, u32 count, int huber, double thr, double* out,
+                         hipStream_t s) {
+  hipLaunchKernelGGL(track_normal_kernel, dim3(1), dim3(TRK_NE_THREADS), 0, s, a, pose, offset, count, huber, thr, out);
 }
 
 }  // namespace esvo

@@ -28,6 +28,7 @@ SYMBOLS = [
     "esvo_get_stats", "esvo_shard_set_band", "esvo_shard_exchange", "esvo_shard_tick_phase", "esvo_abi_sizes",
     "esvo_map_front", "esvo_map_front_frame", "esvo_map_push_frame_device", "esvo_map_fuse_async",
     "esvo_track_set_current", "esvo_track_get_images", "esvo_track_set_reference", "esvo_track_residuals", "esvo_track_jacobian",
+    "esvo_track_normal_equations", "esvo_track_register",
     "esvo_map_init_sgm",
     "esvo_bag_open", "esvo_bag_close", "esvo_bag_last_error", "esvo_bag_next_event_array", "esvo_ts_push_bag",
     "esvo_map_get_debug_images", "esvo_map_get_pointcloud_near_xyz", "esvo_voxel_filter_xyz",
@@ -49,8 +50,8 @@ _PERTURBED_PATH = os.path.join(_CSRC, "libesvo_hip_perturbed.so")
 def build(force=False, verbose=False, perturbed=False):
     """hipcc cross-compiles the extension for gfx950 in-tree (works without a GPU): one object per source file (in parallel,
     only the files that changed), then one link.
-    perturbed=True additionally links libesvo_hip_perturbed.so: the same library with -DESVO_PERTURB_ONE_ULP, i.e. the inverse
-    depth of every eighth solver slot off by one unit in the last place (kernels_lm.hip) -- never loaded by the product; tests/test_gpu_bench_parity.py
+    perturbed=True additionally links libesvo_hip_perturbed.so: the same library with -DESVO_PERTURB_ONE_ULP, i.e. the depth
+    of every eighth solver slot's point off by one unit in the last place (kernels_lm.hip) -- never loaded by the product; tests/test_gpu_bench_parity.py
     points ESVO_HIP_LIB at it to show that bench.py's `parity.oracle_equal` notices a single flipped bit."""
     from concurrent.futures import ThreadPoolExecutor
     inc = os.path.join(_CSRC, "..", "..", "include")
@@ -159,6 +160,8 @@ def load():
     lib.esvo_track_set_reference.argtypes = [vp, vp, sz, vp]
     lib.esvo_track_residuals.argtypes = [vp, vp, sz, sz, i32, C.c_double, vp, psz]
     lib.esvo_track_jacobian.argtypes = [vp, vp, vp, sz, sz, vp, psz]
+    lib.esvo_track_normal_equations.argtypes = [vp, vp, vp, sz, sz, i32, C.c_double, vp, vp, C.POINTER(C.c_double), psz]
+    lib.esvo_track_register.argtypes = [vp, sz, vp, vp, i32, C.c_double, i32, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_int)]
     lib.esvo_map_init_sgm.argtypes = [vp, vp, vp, sz, psz, vp]
     lib.esvo_bag_open.argtypes = [C.c_char_p, C.POINTER(vp)]
     lib.esvo_bag_close.argtypes = [vp]
@@ -510,6 +513,26 @@ class Esvo:
         n = C.c_size_t()
         self._ck(self.lib.esvo_track_jacobian(self.h, R.ctypes.data, t.ctypes.data, int(offset), int(count), out.ctypes.data, C.byref(n)))
         return out[:6 * n.value].reshape(6, n.value).T  # (n, 6); column-major like Eigen's fjac
+
+    def track_normal_equations(self, R, t, offset, count, huber=True, huber_threshold=50.0):
+        """(H = J^T J 6x6, b = J^T f, |f|^2, n) at (R, t): residuals, Jacobian and their products in one device call"""
+        R = np.ascontiguousarray(R, np.float64).reshape(9)
+        t = np.ascontiguousarray(t, np.float64).reshape(3)
+        H, b = np.zeros((6, 6), np.float64), np.zeros(6, np.float64)
+        cost, n = C.c_double(), C.c_size_t()
+        self._ck(self.lib.esvo_track_normal_equations(self.h, R.ctypes.data, t.ctypes.data, int(offset), int(count), 1 if huber else 0,
+                                                      float(huber_threshold), H.ctypes.data, b.ctypes.data, C.byref(cost), C.byref(n)))
+        return H, b, cost.value, n.value
+
+    def track_register(self, n_points, R, t, huber=True, huber_threshold=50.0, max_iterations=12, damping=1e-3):
+        """the registration loop inside the library (esvo_hip::gauss_newton_register over the normal equations):
+        -> (R 3x3, t, rms, iterations)"""
+        R = np.ascontiguousarray(R, np.float64).reshape(9).copy()
+        t = np.ascontiguousarray(t, np.float64).reshape(3).copy()
+        rms, it = C.c_double(), C.c_int()
+        self._ck(self.lib.esvo_track_register(self.h, int(n_points), R.ctypes.data, t.ctypes.data, 1 if huber else 0, float(huber_threshold),
+                                              int(max_iterations), float(damping), C.byref(rms), C.byref(it)))
+        return R.reshape(3, 3), t, rms.value, it.value
 
     # ---- multi-GPU exchange behind the C-ABI (api_comm.hip): RCCL, or the two collectives as callbacks ----
     def comm_init(self, unique_id, rank, world):

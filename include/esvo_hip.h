@@ -488,6 +488,21 @@ int esvo_track_residuals(esvo_handle h, const double T_left_ref[16], size_t offs
 /* RegProblemLM::df at x = 0 (:178-269) for the problem's current R_, t_: fjac is n_out x 6, column-major. */
 int esvo_track_jacobian(esvo_handle h, const double R[9], const double t[3], size_t offset, size_t count,
                         double* fjac, size_t* n_out);
+/* What one iteration of RegProblemSolverLM::solve_analytical consumes (RegProblemSolverLM.cpp:148-215: minimizeInit -> F(0),
+ * minimizeOneStep -> df at 0, then a 6 x 6 system), in ONE launch and 43 doubles back: f = operator()(0) on the batch with its
+ * Huber weights (RegProblemLM.cpp:121-131), J = df(0) (:178-269; the reference's Jacobian carries no weight), H = J^T J (6 x 6,
+ * row-major, symmetric), b = J^T f, *cost = |f|^2.  R, t: the problem's R_, t_ as for esvo_track_jacobian (the warp of
+ * operator()(0) is [R^T | -R^T t]).  The sums are taken in a fixed order (kernels_track.hip), reproduced by the CPU oracle. */
+int esvo_track_normal_equations(esvo_handle h, const double R[9], const double t[3], size_t offset, size_t count, int ls_norm,
+                                double huber_threshold, double H[36], double b[6], double* cost, size_t* n_out);
+/* The registration loop on top of it, host C++ inside the library (esvo_hip::gauss_newton_register of esvo_hip.hpp -- the same
+ * code a C++ node calls directly): damped Gauss-Newton on (Cayley, translation) with the reference's motion update
+ * (RegProblemLM::addMotionUpdate, :347-360: R <- orth(dR R), t <- dt + dR t), over the first n_points of the reference cloud.
+ * R, t: in = the start (R_, t_ of setProblem: identity / zero, or the previous frame's), out = the registered motion.
+ * The reference's own driver is Eigen's LevenbergMarquardt (third-party, absent here); this one is what the closed-loop test
+ * and bench.py use in its place. */
+int esvo_track_register(esvo_handle h, size_t n_points, double R[9], double t[3], int ls_norm, double huber_threshold,
+                        int max_iterations, double damping, double* rms, int* iterations);
 
 #ifdef __cplusplus
 }

@@ -250,6 +250,89 @@ inline void MappingAtTimePureBlockMatching(Context& ctx, const StampedTimeSurfac
             "esvo_map_tick_bm_only");
 }
 
+// ---- the tracker's optimiser: host C++ over the device's normal equations ----------------------------------------------------
+// tools::cayley2rot (esvo_core/src/tools/cayley.cpp), row-major
+inline void cayley2rot(const double c[3], double R[9]) {
+  const double c0 = c[0], c1 = c[1], c2 = c[2];
+  const double s = 1.0 + ((c0 * c0 + c1 * c1) + c2 * c2);
+  const double M[9] = {1 + c0 * c0 - c1 * c1 - c2 * c2, 2 * (c0 * c1 - c2), 2 * (c0 * c2 + c1),
+                       2 * (c0 * c1 + c2), 1 - c0 * c0 + c1 * c1 - c2 * c2, 2 * (c1 * c2 - c0),
+                       2 * (c0 * c2 - c1), 2 * (c1 * c2 + c0), 1 - c0 * c0 - c1 * c1 + c2 * c2};
+  for (int i = 0; i < 9; ++i) R[i] = M[i] / s;
+}
+// U V^T of the SVD of a (nearly orthonormal) 3x3 matrix = its orthogonal polar factor -- what addMotionUpdate's JacobiSVD
+// re-orthonormalisation (RegProblemLM.cpp:355-357) returns; Newton's iteration X <- (X + X^-T) / 2 converges quadratically
+inline void orthonormalize3(double X[9]) {
+  for (int it = 0; it < 20; ++it) {
+    const double* a = X;
+    const double c00 = a[4] * a[8] - a[5] * a[7], c01 = a[5] * a[6] - a[3] * a[8], c02 = a[3] * a[7] - a[4] * a[6];
+    const double c10 = a[2] * a[7] - a[1] * a[8], c11 = a[0] * a[8] - a[2] * a[6], c12 = a[1] * a[6] - a[0] * a[7];
+    const double c20 = a[1] * a[5] - a[2] * a[4], c21 = a[2] * a[3] - a[0] * a[5], c22 = a[0] * a[4] - a[1] * a[3];
+    const double det = (a[0] * c00 + a[1] * c01) + a[2] * c02;
+    const double invT[9] = {c00 / det, c01 / det, c02 / det, c10 / det, c11 / det, c12 / det, c20 / det, c21 / det, c22 / det};  // X^-T
+    double d = 0;
+    for (int i = 0; i < 9; ++i) { const double n = 0.5 * (X[i] + invT[i]); d = std::max(d, std::fabs(n - X[i])); X[i] = n; }
+    if (d < 1e-16) break;
+  }
+}
+// solves A x = rhs (6 x 6, row-major) by Gaussian elimination with partial pivoting; false if singular
+inline bool solve6(const double A_in[36], const double rhs[6], double x[6]) {
+  double A[6][7];
+  for (int i = 0; i < 6; ++i) { for (int j = 0; j < 6; ++j) A[i][j] = A_in[i * 6 + j]; A[i][6] = rhs[i]; }
+  for (int c = 0; c < 6; ++c) {
+    int piv = c;
+    for (int r = c + 1; r < 6; ++r) if (std::fabs(A[r][c]) > std::fabs(A[piv][c])) piv = r;
+    if (A[piv][c] == 0.0 || !std::isfinite(A[piv][c])) return false;
+    if (piv != c) for (int j = 0; j < 7; ++j) std::swap(A[piv][j], A[c][j]);
+    for (int r = c + 1; r < 6; ++r) {
+      const double f = A[r][c] / A[c][c];
+      for (int j = c; j < 7; ++j) A[r][j] -= f * A[c][j];
+    }
+  }
+  for (int i = 5; i >= 0; --i) {
+    double s = A[i][6];
+    for (int j = i + 1; j < 6; ++j) s -= A[i][j] * x[j];
+    x[i] = s / A[i][i];
+  }
+  return true;
+}
+struct Registration { double R[9]; double t[3]; double rms = 0; int iterations = 0; bool ok = true; };
+// Damped Gauss-Newton on x = (Cayley parameters, translation), linearised at x = 0 in every iteration exactly as
+// RegProblemSolverLM::solve_analytical does (RegProblemSolverLM.cpp:160-183: x.fill(0), one step, addMotionUpdate):
+//   (H + damping diag(H) + 1e-9 I) dx = -b,   R <- orth(cayley2rot(dx_c) R),   t <- dx_t + cayley2rot(dx_c) t
+// until |dx| < 1e-6 or max_iterations.  `normal_eq(R, t, H[36], b[6], &cost, &n)` evaluates H = J^T J, b = J^T f, cost = |f|^2 at
+// the current (R, t): esvo_track_normal_equations on the device, or the CPU oracle's restatement in the tests.
+template <class NormalEq>
+Registration gauss_newton_register(NormalEq&& normal_eq, const double R0[9], const double t0[3], int max_iterations = 12,
+                                   double damping = 1e-3) {
+  Registration g;
+  for (int i = 0; i < 9; ++i) g.R[i] = R0[i];
+  for (int i = 0; i < 3; ++i) g.t[i] = t0[i];
+  for (int it = 0; it < max_iterations; ++it) {
+    double H[36], b[6], cost = 0;
+    size_t n = 0;
+    if (!normal_eq(g.R, g.t, H, b, &cost, &n)) { g.ok = false; return g; }
+    g.iterations = it + 1;
+    g.rms = n ? std::sqrt(cost / (double)n) : 0.0;
+    double A[36], rhs[6], dx[6];
+    for (int i = 0; i < 36; ++i) A[i] = H[i];
+    for (int i = 0; i < 6; ++i) { A[i * 6 + i] = (H[i * 6 + i] + damping * H[i * 6 + i]) + 1e-9; rhs[i] = -b[i]; }
+    if (!solve6(A, rhs, dx)) { g.ok = false; return g; }
+    double dR[9], Rn[9], tn[3];
+    cayley2rot(dx, dR);
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) Rn[r * 3 + c] = (dR[r * 3 + 0] * g.R[0 * 3 + c] + dR[r * 3 + 1] * g.R[1 * 3 + c]) + dR[r * 3 + 2] * g.R[2 * 3 + c];
+    orthonormalize3(Rn);
+    for (int r = 0; r < 3; ++r) tn[r] = dx[3 + r] + ((dR[r * 3 + 0] * g.t[0] + dR[r * 3 + 1] * g.t[1]) + dR[r * 3 + 2] * g.t[2]);
+    for (int i = 0; i < 9; ++i) g.R[i] = Rn[i];
+    for (int i = 0; i < 3; ++i) g.t[i] = tn[i];
+    double nrm = 0;
+    for (int i = 0; i < 6; ++i) nrm += dx[i] * dx[i];
+    if (std::sqrt(nrm) < 1e-6) break;
+  }
+  return g;
+}
+
 // esvo_core::core::RegProblemLM's evaluation side (esvo_core/src/core/RegProblemLM.cpp): the per-point loops of
 // setProblem (:44-56), operator() (:91-136) and df (:178-269) on the device.  The 6-DoF LM driver, the Cayley update and
 // the SVD re-orthonormalisation (getWarpingTransformation / addMotionUpdate, :328-364) stay with the caller, who passes
@@ -290,6 +373,25 @@ class RegProblemLM {
     ctx_->check(esvo_track_jacobian(ctx_->handle(), R, t, offset_, count_, fjac.data(), &n), "esvo_track_jacobian");
     fjac.resize(6 * n);
     return n;
+  }
+  // F(0), df(0) and their products J^T J, J^T F, |F|^2 on the current batch in one device call
+  size_t normalEquations(const double R[9], const double t[3], double H[36], double b[6], double* cost) const {
+    size_t n = 0;
+    ctx_->check(esvo_track_normal_equations(ctx_->handle(), R, t, offset_, count_, cfg_.huber ? ESVO_TRACK_HUBER : ESVO_TRACK_L2,
+                                            cfg_.huber_threshold, H, b, cost, &n), "esvo_track_normal_equations");
+    return n;
+  }
+  // RegProblemSolverLM::solve_analytical's loop (RegProblemSolverLM.cpp:148-215) with gauss_newton_register as the step:
+  // the batch advances with the iteration as setStochasticSampling does there (:167-168)
+  Registration solve(const double R0[9], const double t0[3], int MAX_ITERATION = 12, double damping = 1e-3) {
+    size_t it = 0;
+    auto ne = [&](const double* R, const double* t, double* H, double* b, double* cost, size_t* n) {
+      if (cfg_.BATCH_SIZE < numPoints_) setStochasticSampling((it % numBatches_) * cfg_.BATCH_SIZE, cfg_.BATCH_SIZE);
+      ++it;
+      *n = normalEquations(R, t, H, b, cost);
+      return true;
+    };
+    return gauss_newton_register(ne, R0, t0, MAX_ITERATION, damping);
   }
   size_t numBatches_ = 1, numPoints_ = 0;
 

@@ -2048,6 +2048,47 @@ extern "C" size_t orc_tracker_jacobian(orc_tracker_handle T, const double R[9], 
   return m;
 }
 
+// The normal equations of one tracker iteration (RegProblemSolverLM::solve_analytical, RegProblemSolverLM.cpp:148-215, consumes
+// F(0) and df(0); the device hands back their products): out[0..20] = upper triangle of J^T J (row-major, i <= j),
+// out[21..26] = J^T f, out[27] = |f|^2, summed in the device's order (kernels_track.hip, track_normal_kernel): partial sum t of
+// 256 takes the points t, t + 256, ... in turn, then the tree s[t] += s[t + 128], ..., s[0] += s[1].
+extern "C" size_t orc_tracker_normal_equations(orc_tracker_handle T, const double R[9], const double t[3], size_t offset, size_t count,
+                                               int huber, double huber_threshold, double out[28]) {
+  size_t m = 0;
+  for (size_t i = offset; i < offset + count && 3 * i < T->pts.size(); ++i) ++m;
+  for (int n = 0; n < 28; ++n) out[n] = 0.0;
+  if (m == 0) return 0;
+  std::vector<double> fjac(6 * m), fvec(m);
+  double Tlr[16] = {0};  // T_left_ref = [R^T | -R^T t], as orc_tracker_jacobian forms it
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) Tlr[r * 4 + c] = R[c * 3 + r];
+    Tlr[r * 4 + 3] = (-R[0 * 3 + r] * t[0] + -R[1 * 3 + r] * t[1]) + -R[2 * 3 + r] * t[2];
+  }
+  Tlr[15] = 1.0;
+  orc_tracker_residuals(T, Tlr, offset, m, huber, huber_threshold, fvec.data());
+  orc_tracker_jacobian(T, R, t, offset, m, fjac.data());
+  const int NT = 256;
+  std::vector<double> part((size_t)28 * NT, 0.0);
+  for (int th = 0; th < NT; ++th) {
+    double* acc = &part[(size_t)th * 28];
+    for (size_t k = (size_t)th; k < m; k += NT) {
+      double row[6];
+      for (int j = 0; j < 6; ++j) row[j] = fjac[(size_t)j * m + k];
+      const double f = fvec[k];
+      int n = 0;
+      for (int i = 0; i < 6; ++i)
+        for (int j = i; j < 6; ++j) { acc[n] = acc[n] + row[i] * row[j]; ++n; }
+      for (int i = 0; i < 6; ++i) acc[21 + i] = acc[21 + i] + row[i] * f;
+      acc[27] = acc[27] + f * f;
+    }
+  }
+  for (int s = NT / 2; s > 0; s >>= 1)
+    for (int th = 0; th < s; ++th)
+      for (int n = 0; n < 28; ++n) part[(size_t)th * 28 + n] = part[(size_t)th * 28 + n] + part[(size_t)(th + s) * 28 + n];
+  for (int n = 0; n < 28; ++n) out[n] = part[n];
+  return m;
+}
+
 extern "C" double orc_zncc_cost(const double* l, const double* r, int wx, int wy, int exact_int) {
   if (!exact_int) {
     std::vector<double> t1((size_t)wx * wy), t2((size_t)wx * wy);

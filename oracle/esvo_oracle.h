@@ -151,6 +151,9 @@ size_t orc_tracker_residuals(orc_tracker_handle h, const double T_left_ref[16], 
                              double huber_threshold, double* fvec);
 size_t orc_tracker_jacobian(orc_tracker_handle h, const double R[9], const double t[3], size_t offset, size_t count,
                             double* fjac);
+/* H = J^T J (upper triangle, 21), b = J^T f (6), |f|^2 of one tracker iteration in the device's summation order */
+size_t orc_tracker_normal_equations(orc_tracker_handle h, const double R[9], const double t[3], size_t offset, size_t count,
+                                    int huber, double huber_threshold, double out[28]);
 
 #ifdef __cplusplus
 }

@@ -117,6 +117,8 @@ def load(fast=False):
     lib.orc_tracker_residuals.argtypes = [vp, vp, sz, sz, i32, dbl, vp]
     lib.orc_tracker_jacobian.restype = sz
     lib.orc_tracker_jacobian.argtypes = [vp, vp, vp, sz, sz, vp]
+    lib.orc_tracker_normal_equations.restype = sz
+    lib.orc_tracker_normal_equations.argtypes = [vp, vp, vp, sz, sz, i32, dbl, vp]
     lib.orc_abi_sizes.argtypes = [vp]
     _libs[key] = lib
     return lib
@@ -220,6 +222,17 @@ def denoise_events(ev, idx, width, height, max_num):
     return out[:n]
 
 
+def unpack_normal_equations(v):
+    """28 sums (upper triangle of J^T J row-major, J^T f, |f|^2) -> (H 6x6 symmetric, b, cost)"""
+    H = np.zeros((6, 6))
+    n = 0
+    for i in range(6):
+        for j in range(i, 6):
+            H[i, j] = H[j, i] = v[n]
+            n += 1
+    return H, np.array(v[21:27]), float(v[27])
+
+
 class OracleTracker:
     """RegProblemLM residual / Jacobian evaluation (esvo_core/src/core/RegProblemLM.cpp), SURVEY.md section 8(f).1."""
 
@@ -265,6 +278,15 @@ class OracleTracker:
         out = np.empty(6 * count, np.float64)
         n = self.lib.orc_tracker_jacobian(self.h, R.ctypes.data, t.ctypes.data, int(offset), int(count), out.ctypes.data)
         return out[:6 * n].reshape(6, n).T  # (n, 6); the C layout is column-major like Eigen's
+
+    def normal_equations(self, R, t, offset, count, huber=True, huber_threshold=50.0):
+        """(H 6x6, b 6, |f|^2, n) of one tracker iteration at (R, t), summed in the device's order"""
+        R = np.ascontiguousarray(R, np.float64).reshape(9)
+        t = np.ascontiguousarray(t, np.float64).reshape(3)
+        out = np.zeros(28, np.float64)
+        n = self.lib.orc_tracker_normal_equations(self.h, R.ctypes.data, t.ctypes.data, int(offset), int(count), int(bool(huber)),
+                                                  float(huber_threshold), out.ctypes.data)
+        return unpack_normal_equations(out) + (int(n),)
 
 
 class OracleMapper:

@@ -1,5 +1,5 @@
 """bench.py's `parity` block has teeth: the same command run on libesvo_hip_perturbed.so -- the product library built with
--DESVO_PERTURB_ONE_ULP, i.e. the inverse depth of every eighth solver slot off by one unit in the last place (kernels_lm.hip) --
+-DESVO_PERTURB_ONE_ULP, i.e. the depth of every eighth solver slot's point off by one unit in the last place (kernels_lm.hip) --
 must report
 `oracle_equal: false`, while the shipped library reports true.  (The twin is linked by __graft_entry__.build() and is never
 loaded by the product: ESVO_HIP_LIB, the A/B switch of esvo_amd/lib.py, points this test's subprocess at it.)"""
