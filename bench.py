@@ -298,6 +298,9 @@ def main():
     ap.add_argument("--strong", action="store_true", help="N GPUs share K ticks in total instead of mapping K ticks each")
     ap.add_argument("--check", action="store_true",
                     help="replay up to the first timed tick on a fresh handle and compare its DepthMap with the CPU oracle's (SHA-1)")
+    ap.add_argument("--selftest", action="store_true",
+                    help="N-GPU plumbing check in < 30 s instead of the benchmark: who is there (rank, device, bus id), the RCCL the library "
+                         "resolved, one all-gather round trip, and the DepthMap SHA-1 of both N-GPU modes against the one-GPU run")
     ap.add_argument("--no-parity", action="store_true",
                     help="skip the `parity` block of the line (oracle equality of the first timed tick; IoU / RMSE against the reference node)")
     ap.add_argument("--sustained-ticks", type=int, default=1600,
@@ -466,6 +469,14 @@ def main():
                     runner=runner, dt=dt, st=st, base=base, n_events=n_events, n_points=n_points, n_matches=n_matches, ksum=ksum,
                     launches=launches, ev_rank=ev_rank, mt_rank=mt_rank, shard_mode=shard_mode)
 
+    if args.selftest:
+        res = selftest(rank, world, local_rank, dist, ranks_seen, rccl)
+        if rank == 0:
+            print(json.dumps(res), file=json_out, flush=True)
+        if dist:
+            dist.destroy_process_group()
+        raise SystemExit(0 if res.get("ok", True) else 1)
+
     shard_mode = os.environ.get("ESVO_SHARD_MODE", "tick")
     M = measure(shard_mode, args.strong)
     per_gpu, rig, stream, p, ticks, duration = M["per_gpu"], M["rig"], M["stream"], M["p"], M["ticks"], M["duration"]
@@ -549,6 +560,10 @@ def main():
         out["ranks_seen"] = ranks_seen
         out["rccl"] = rccl
         out["launcher"] = "self (python bench.py --gpus N)" if os.environ.get("ESVO_BENCH_SELF_LAUNCHED") else "external (torch.distributed.run)"
+        out["multi_gpu_note"] = ("`value` = tick-interleaved mode: rank r maps ticks k = r (mod N) whole, so the poses of N consecutive ticks "
+                                 "must be known before the first of their maps exists -- true for esvo_MVStereo with given poses "
+                                 "(BASELINE configs[1], [3]), NOT for the closed loop (configs[2]: tick k+1's poses come from tracking on "
+                                 "tick k's map), where only `band_mode` (one tick split over the GPUs) applies")
     if args.check:
         mp_ = runner.get_map()  # collective at N > 1
         if rank == 0:
@@ -629,6 +644,84 @@ def main():
         print(json.dumps(out), file=json_out, flush=True)
     if dist:
         dist.destroy_process_group()
+
+
+def selftest(rank, world, local_rank, dist, ranks_seen, rccl, n_ticks=6):
+    """`python bench.py --gpus N --selftest`: everything a failed scaling run would want to know, in well under 30 s.
+    ranks_seen / rccl as on the benchmark line; one all-gather of 1 MiB per rank, verified and timed (10 repeats); then six
+    ticks of the 346x260 workload through BOTH N-GPU modes (tick-interleaved: esvo_comm_tick; band: esvo_comm_shard_tick -- the
+    native RCCL path unless ESVO_DIST_BACKEND / ESVO_NATIVE_COMM say otherwise) and, on rank 0, through one plain handle: the
+    three DepthMap SHA-1 must be equal.  Prints ONE JSON line; the exit code is 0 only if every check passed."""
+    import torch
+    t_begin = time.perf_counter()
+    backend = os.environ.get("ESVO_DIST_BACKEND", "nccl")
+    res = {"selftest": True, "n_gpus": world, "backend": backend if dist else None, "ranks_seen": ranks_seen, "rccl": rccl, "ok": True}
+    if dist:
+        dev = "cuda" if backend == "nccl" else "cpu"
+        n = 1 << 18   # 1 MiB of f32 per rank
+        send = torch.full((n,), float(rank + 1), device=dev)
+        recv = [torch.empty(n, device=dev) for _ in range(world)]
+        times = []
+        for i in range(13):
+            if dev == "cuda":
+                torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            dist.all_gather(recv, send)
+            if dev == "cuda":
+                torch.cuda.synchronize()
+            if i >= 3:
+                times.append((time.perf_counter() - t0) * 1e6)
+        good = all(bool((recv[r] == float(r + 1)).all().item()) for r in range(world))
+        res["all_gather"] = {"bytes_per_rank": 4 * n, "us_min": min(times), "us_median": sorted(times)[len(times) // 2], "verified": good}
+        res["ok"] = res["ok"] and good
+    rig, stream, p, ticks = make_workload("upenn346x260", n_ticks, share=(rank, dist.barrier) if dist else None)
+
+    def drive(runner):
+        runner.ts_push_events(0, stream.ev_left)
+        runner.ts_push_events(1, stream.ev_right)
+        for t, stamps, poses, T in ticks:
+            if hasattr(runner, "tick_resident"):
+                runner.tick_resident(t, T, stamps, poses)
+            else:
+                runner.ts_render(0, t, download=False)
+                runner.ts_render(1, t, download=False)
+                runner.set_observation(t, None, None, T)
+                runner.tick(t, stamps, poses)
+        runner.synchronize()
+        return runner.get_map()   # collective at N > 1
+
+    shas = {}
+    if dist:
+        from esvo_amd import dist as edist
+        native = backend == "nccl" and os.environ.get("ESVO_NATIVE_COMM", "1") != "0"
+        res["exchange"] = "esvo_comm_* (RCCL inside libesvo_hip.so)" if native else f"torch.distributed ({backend})"
+        for mode in ("tick", "band"):
+            cls = ((edist.NativeTickSharded if mode == "tick" else edist.NativeBandSharded) if native
+                   else (edist.TickShardedEsvo if mode == "tick" else edist.ShardedEsvo))
+            t0 = time.perf_counter()
+            try:
+                runner = cls(p, rig, rank, world, local_rank)
+                gm = drive(runner)
+                shas[mode] = {"sha1": map_sha1(gm), "map_size": int(len(gm)), "seconds": round(time.perf_counter() - t0, 2)}
+                runner.dev.close()
+            except Exception as e:  # noqa: BLE001  (a hang inside RCCL cannot be caught: the 30 s budget is the caller's timeout)
+                shas[mode] = {"error": f"{type(e).__name__}: {e}"}
+                res["ok"] = False
+    if rank == 0:
+        single = lib.Esvo(p, rig, device=local_rank)
+        gm = drive(single)
+        single.close()
+        shas["one_gpu"] = {"sha1": map_sha1(gm), "map_size": int(len(gm))}
+        res["depth_map"] = shas
+        same = all(v.get("sha1") == shas["one_gpu"]["sha1"] for v in shas.values())
+        res["depth_map_equal_to_one_gpu"] = same
+        res["ok"] = res["ok"] and same and shas["one_gpu"]["map_size"] > 100
+    if dist:
+        flag = torch.tensor([0.0 if res["ok"] else 1.0], device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        res["ok"] = flag.item() == 0.0
+    res["seconds"] = round(time.perf_counter() - t_begin, 2)
+    return res
 
 
 def attach_measured_clock(v, sclk_mhz):
@@ -826,13 +919,24 @@ def other_operating_points(device):
     with two ticks in flight."""
     out = {}
 
-    def throughput(name, n, check=False, timed_ingest=False):
+    def throughput(name, n, check=False, timed_ingest=False, pinned=False):
         rig, stream, p, ticks = make_workload(name, n + 3)
+        ticks = ticks[: n + 3]
         dev = lib.Esvo(p, rig, device=device)
+        pins = []
         if timed_ingest:   # PCIe-inclusive: only the history is resident, every tick's events are staged inside the loop
             t_first = stream.t0_ns + int(HIST_S * 1e9)
             bounds = [t_first] + [tk[0] for tk in ticks]
             chunks = [(stream.slice(0, a, b), stream.slice(1, a, b)) for a, b in zip(bounds[:-1], bounds[1:])]
+            if pinned:   # the node's message pool in pinned memory (esvo_host_alloc): filled before the timed region
+                for k, pair in enumerate(chunks):
+                    held = []
+                    for ev in pair:
+                        pe = lib.PinnedEvents(len(ev))
+                        pe.array[:] = ev
+                        pins.append(pe)
+                        held.append(pe.array)
+                    chunks[k] = tuple(held)
             dev.ts_push_events(0, stream.slice(0, stream.t0_ns, t_first))
             dev.ts_push_events(1, stream.slice(1, stream.t0_ns, t_first))
         else:
@@ -841,7 +945,10 @@ def other_operating_points(device):
 
         def run(a, b):
             for k in range(a, b):
-                if timed_ingest:
+                if timed_ingest and pinned:   # enqueue the DMA and go on: the tick queues behind it on the device
+                    dev.ts_push_events_async(0, chunks[k][0])
+                    dev.ts_push_events_async(1, chunks[k][1])
+                elif timed_ingest:
                     dev.ts_push_events(0, chunks[k][0])
                     dev.ts_push_events(1, chunks[k][1])
                 t, stamps, poses, T = ticks[k]
@@ -854,12 +961,19 @@ def other_operating_points(device):
         dev.synchronize()
         dt = time.perf_counter() - t0
         s = dev.stats()
+        if pinned:
+            dev.ts_push_wait(0)
+            dev.ts_push_wait(1)
         dev.close()
+        for pe in pins:
+            pe.free()
         ev = int(s.total_events_in - b.total_events_in)
         res = {"events_per_s": ev / dt, "ms_per_tick": dt / n * 1e3, "events_per_tick": ev // n,
                "depth_points_per_s": int(s.total_points - b.total_points) / dt}
         if timed_ingest:
-            res["note"] = "host-to-device staging of each tick's events (2 x 16 B/event from pageable memory) inside the timed loop"
+            res["note"] = ("host-to-device staging of each tick's events (2 x 16 B/event) inside the timed loop, " +
+                           ("from pinned buffers through esvo_ts_push_events_async: the DMA overlaps the running tick" if pinned
+                            else "from pageable memory through the synchronous esvo_ts_push_events"))
             return res
         ks = np.array(list(s.sum_ms_kernel)) - np.array(list(b.sum_ms_kernel))
         ka = ks / n
@@ -928,6 +1042,7 @@ def other_operating_points(device):
     out["hd1280x720_throughput"] = throughput("hd1280x720", 6, check=True)
     # the headline workload with the PCIe transfer of every tick's events inside the timed loop (never `value`)
     out["dsec640x480_with_timed_ingest"] = throughput("dsec640x480", 20, timed_ingest=True)
+    out["dsec640x480_with_timed_ingest_pinned"] = throughput("dsec640x480", 20, timed_ingest=True, pinned=True)
     return out
 
 

@@ -356,6 +356,7 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
   for (int i = 0; i < EV_N; ++i) CK(hipEventCreate(&h->evt[i]));
   h->evt_ok = true;
   CK(hipEventCreateWithFlags(&h->evt_trk_read, hipEventDisableTiming));
+  for (int cam = 0; cam < 2; ++cam) CK(hipEventCreateWithFlags(&h->evt_ingest[cam], hipEventDisableTiming));
   CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_pose_pool), sizeof(double) * 16 * (size_t)h->max_poses * esvo_context::POSE_POOL));
   for (int i = 0; i < esvo_context::POSE_POOL; ++i) CK(hipEventCreate(&h->pool_evt[i]));
   h->pool_ok = true;
@@ -394,8 +395,10 @@ int esvo_destroy(esvo_handle h) {
   if (h->pool_ok) for (int i = 0; i < esvo_context::POSE_POOL; ++i) hipEventDestroy(h->pool_evt[i]);
   if (h->h_pose_pool) hipHostFree(h->h_pose_pool);
   if (h->h_trk_ne) hipHostFree(h->h_trk_ne);
+  if (h->h_trk_xyz) hipHostFree(h->h_trk_xyz);
   for (int cam = 0; cam < 2; ++cam) if (h->d_wire[cam]) hipFree(h->d_wire[cam]);
   if (h->evt_trk_read) hipEventDestroy(h->evt_trk_read);
+  for (int cam = 0; cam < 2; ++cam) if (h->evt_ingest[cam]) hipEventDestroy(h->evt_ingest[cam]);
   for (void* q : {(void*)h->d_viz_bgr, (void*)h->d_viz_jet, (void*)h->d_viz_owner}) if (q) hipFree(q);
   for (void* q : {(void*)h->sgm.sobL, (void*)h->sgm.rawL, (void*)h->sgm.sobR, (void*)h->sgm.rawR, (void*)h->sgm.vol[0], (void*)h->sgm.vol[1],
                   (void*)h->sgm.vol[2], (void*)h->sgm.vol[3], (void*)h->sgm.vol[4], (void*)h->sgm.vol[5], (void*)h->sgm.d1, (void*)h->sgm.d1b,
@@ -426,11 +429,13 @@ int esvo_reset(esvo_handle h) {
   HIPCHK(hipStreamSynchronize(h->stream_l)); HIPCHK(hipStreamSynchronize(h->stream_l1));
   HIPCHK(hipStreamSynchronize(h->stream_b));
   HIPCHK(hipStreamSynchronize(h->stream_t));
+  HIPCHK(hipStreamSynchronize(h->stream_i));
   for (int cam = 0; cam < 2; ++cam) {
     HIPCHK(hipMemsetAsync(h->d_sae[cam], 0, sizeof(u64) * npx, h->stream));
     h->ts_host[cam].clear();
     h->ring_base[cam] = h->ring_next[cam] = h->ring_reserved[cam] = h->scattered[cam] = 0;
     h->scatter_pending_lo[cam] = ~0ull;
+    h->ingest_pending[cam] = false;
     h->ts_valid[cam] = false;
   }
   h->sh_first = 0;

@@ -552,6 +552,7 @@ namespace esvo_host {
 // lower_bound(t_begin), newest first, at most PROCESS_EVENT_NUM
 int select_events(esvo_context* h, uint64_t t_ns, u64* first_out, u32* n_out) {
   std::lock_guard<std::mutex> lr(h->mu_ring);  // the ingest thread appends to ts_host / advances the ring meanwhile
+  ingest_fence(h, 0);  // block matching reads the left camera's ring on the front stream
   const double t_end = ns_to_sec(t_ns);
   const u64 t_begin_ns = ros_time_from_sec(std::max(0.0, t_end - 10 * h->prm.bm_half_slice_thickness));
   const double t_begin = ns_to_sec(t_begin_ns);
@@ -1045,6 +1046,7 @@ extern "C" int esvo_map_init_sgm(esvo_handle h, const uint8_t* ts_left, const ui
   u32 n = 0;
   {
     std::lock_guard<std::mutex> lr(h->mu_ring);
+    ingest_fence(h, 0);
     const double t_end = ns_to_sec(h->obs_t_ns);
     const double t_begin = ns_to_sec(ros_time_from_sec(std::max(0.0, t_end - 2 * h->prm.bm_half_slice_thickness)));
     const u64 it_end = lower_bound_sec(h, 0, t_end), it_begin = lower_bound_sec(h, 0, t_begin);

@@ -36,7 +36,8 @@ int esvo_track_set_current(esvo_handle h, const uint8_t* ts_left, int kernel_siz
   }
   launch_track_images(h->d_trk_blur, h->d_trk_neg, h->d_trk_du, h->d_trk_dv, h->W, h->H, h->stream_t);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(h->stream_t));
+  // a host image is borrowed for the call; the resident surface needs no host wait (the evaluation calls run on this stream)
+  if (ts_left) HIPCHK(hipStreamSynchronize(h->stream_t));
   h->trk_cur = true;
   return ESVO_OK;
 }
@@ -61,8 +62,10 @@ int esvo_track_set_reference(esvo_handle h, const float* xyz_world, size_t n, co
   if (n > h->trk_cap) {
     HIPCHK(hipStreamSynchronize(h->stream_t));
     for (void* q : {(void*)h->d_trk_xyz, (void*)h->d_trk_pts, (void*)h->d_trk_out}) if (q) hipFree(q);
-    h->d_trk_xyz = nullptr; h->d_trk_pts = nullptr; h->d_trk_out = nullptr;
+    if (h->h_trk_xyz) hipHostFree(h->h_trk_xyz);
+    h->d_trk_xyz = nullptr; h->d_trk_pts = nullptr; h->d_trk_out = nullptr; h->h_trk_xyz = nullptr;
     const size_t cap = std::max<size_t>(n, 4096);
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h->h_trk_xyz), cap * 3 * sizeof(float)));
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&h->d_trk_xyz), cap * 3 * sizeof(float)));
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&h->d_trk_pts), cap * 3 * sizeof(double)));
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&h->d_trk_out), cap * 6 * sizeof(double)));
@@ -72,10 +75,15 @@ int esvo_track_set_reference(esvo_handle h, const float* xyz_world, size_t n, co
   if (n) {
     TrackRef r;
     std::memcpy(r.T, T_world_ref, sizeof(r.T));
-    HIPCHK(hipMemcpyAsync(h->d_trk_xyz, xyz_world, n * 3 * sizeof(float), hipMemcpyHostToDevice, h->stream_t));
+    // xyz_world is borrowed for the call: it is copied into a pinned staging buffer (24 KB for 2000 points) instead of waiting
+    // for the device -- the previous upload out of that buffer finished long ago (every evaluation call ends with a wait on
+    // this stream), the stream wait below only covers a caller that sets two references in a row
+    if (h->trk_xyz_inflight) HIPCHK(hipStreamSynchronize(h->stream_t));
+    std::memcpy(h->h_trk_xyz, xyz_world, n * 3 * sizeof(float));
+    h->trk_xyz_inflight = true;
+    HIPCHK(hipMemcpyAsync(h->d_trk_xyz, h->h_trk_xyz, n * 3 * sizeof(float), hipMemcpyHostToDevice, h->stream_t));
     launch_track_reference(h->d_trk_xyz, (u32)n, r, h->d_trk_pts, h->stream_t);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(h->stream_t));  // xyz_world is borrowed for the call
   }
   return ESVO_OK;
 }
@@ -109,6 +117,7 @@ int esvo_track_residuals(esvo_handle h, const double T_left_ref[16], size_t offs
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(fvec, h->d_trk_out, m * sizeof(double), hipMemcpyDeviceToHost, h->stream_t));
   HIPCHK(hipStreamSynchronize(h->stream_t));
+  h->trk_xyz_inflight = false;
   return ESVO_OK;
 }
 
@@ -137,6 +146,7 @@ int esvo_track_jacobian(esvo_handle h, const double R[9], const double t[3], siz
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(fjac, h->d_trk_out, m * 6 * sizeof(double), hipMemcpyDeviceToHost, h->stream_t));
   HIPCHK(hipStreamSynchronize(h->stream_t));
+  h->trk_xyz_inflight = false;
   return ESVO_OK;
 }
 
@@ -169,6 +179,7 @@ int esvo_track_normal_equations(esvo_handle h, const double R[9], const double t
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(h->h_trk_ne, h->d_trk_out, sizeof(double) * TRK_NE_TERMS, hipMemcpyDeviceToHost, h->stream_t));
   HIPCHK(hipStreamSynchronize(h->stream_t));
+  h->trk_xyz_inflight = false;
   int n = 0;
   for (int i = 0; i < 6; ++i)
     for (int j = i; j < 6; ++j) { H[i * 6 + j] = H[j * 6 + i] = h->h_trk_ne[n]; ++n; }

@@ -22,6 +22,14 @@ void collect_ts_timing(esvo_context* h, int only) {
   }
 }
 
+// A copy enqueued by esvo_ts_push_events_async may still be in flight on the ingest stream: whatever the front stream launches
+// next that reads the camera's ring (scatter, block matching, the SGM points) waits for it on the DEVICE.  Caller holds mu_ring.
+void ingest_fence(esvo_context* h, int cam) {
+  if (!h->ingest_pending[cam]) return;
+  hipStreamWaitEvent(h->stream, h->evt_ingest[cam], 0);
+  h->ingest_pending[cam] = false;
+}
+
 // The resident surface of `cam` is about to be overwritten on the front stream (caller holds mu_ts): a tracker thread's
 // esvo_track_set_current may still be reading the left one on the tracker stream.
 void resident_write_begin(esvo_context* h, int cam) {
@@ -36,6 +44,8 @@ void resident_write_begin(esvo_context* h, int cam) {
 int ts_render_pair(esvo_context* h, uint64_t t_ns, uint8_t* const obs_out[2]) {
   {
     std::lock_guard<std::mutex> lr(h->mu_ring);  // what a pusher on another thread reads and writes (context.hpp)
+    ingest_fence(h, 0);
+    ingest_fence(h, 1);
     u64 upto[2];
     for (int cam = 0; cam < 2; ++cam) {
       const auto& tsq = h->ts_host[cam];
@@ -140,8 +150,9 @@ int push_drain(esvo_context* h, int cam, const PushTicket& tk) {
   return ESVO_OK;
 }
 template <typename StampFn>
-void push_commit(esvo_context* h, int cam, size_t n, StampFn stamp) {
+void push_commit(esvo_context* h, int cam, size_t n, StampFn stamp, bool copy_in_flight = false) {
   std::lock_guard<std::mutex> lr(h->mu_ring);
+  if (copy_in_flight) h->ingest_pending[cam] = true;
   auto& tsq = h->ts_host[cam];
   for (size_t i = 0; i < n; ++i) tsq.push_back(stamp(i));
   h->ring_next[cam] += n;
@@ -161,7 +172,28 @@ void push_commit(esvo_context* h, int cam, size_t n, StampFn stamp) {
 
 extern "C" {
 
-int esvo_ts_push_events(esvo_handle h, int cam, const esvo_event_t* ev, size_t n) {
+static int push_events_impl(esvo_handle h, int cam, const esvo_event_t* ev, size_t n, bool wait);
+int esvo_ts_push_events(esvo_handle h, int cam, const esvo_event_t* ev, size_t n) { return push_events_impl(h, cam, ev, n, true); }
+int esvo_ts_push_events_async(esvo_handle h, int cam, const esvo_event_t* ev, size_t n) { return push_events_impl(h, cam, ev, n, false); }
+int esvo_ts_push_wait(esvo_handle h, int cam) {
+  if (!h || cam < 0 || cam > 1) return ESVO_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lp(h->mu_push[cam]);
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize(h->stream_i));
+  return ESVO_OK;
+}
+int esvo_host_alloc(size_t bytes, void** out) {
+  esvo_context* h = nullptr;
+  if (!out || !bytes) return ESVO_ERR_INVALID_ARG;
+  HIPCHK(hipHostMalloc(out, bytes, hipHostMallocDefault));
+  return ESVO_OK;
+}
+int esvo_host_free(void* p) {
+  esvo_context* h = nullptr;
+  if (p) HIPCHK(hipHostFree(p));
+  return ESVO_OK;
+}
+static int push_events_impl(esvo_handle h, int cam, const esvo_event_t* ev, size_t n, bool wait) {
   if (!h || cam < 0 || cam > 1 || (n && !ev)) return ESVO_ERR_INVALID_ARG;
   if (n == 0) return ESVO_OK;
   if (n > h->ring_cap) FAIL(ESVO_ERR_CAPACITY, "event block larger than the event ring");
@@ -181,8 +213,15 @@ int esvo_ts_push_events(esvo_handle h, int cam, const esvo_event_t* ev, size_t n
   PUSH_HIPCHK(hipMemcpyAsync(h->d_ring[cam] + tk.slot, ev, sizeof(esvo_event_t) * first, hipMemcpyHostToDevice, h->stream_i));
   if (first < n)
     PUSH_HIPCHK(hipMemcpyAsync(h->d_ring[cam], ev + first, sizeof(esvo_event_t) * (n - first), hipMemcpyHostToDevice, h->stream_i));
-  PUSH_HIPCHK(hipStreamSynchronize(h->stream_i));  // `ev` is borrowed for the duration of the call only; later work sees the copy
-  push_commit(h, cam, n, stamp);
+  if (wait) {
+    PUSH_HIPCHK(hipStreamSynchronize(h->stream_i));  // `ev` is borrowed for the duration of the call only; later work sees the copy
+    push_commit(h, cam, n, stamp);
+  } else {
+    // esvo_ts_push_events_async: the caller keeps `ev` alive until esvo_ts_push_wait; whoever reads these ring slots on the
+    // front stream queues behind the copy (ingest_fence)
+    PUSH_HIPCHK(hipEventRecord(h->evt_ingest[cam], h->stream_i));
+    push_commit(h, cam, n, stamp, true);
+  }
   return ESVO_OK;
 }
 
@@ -283,6 +322,7 @@ int esvo_ts_render_forward(esvo_handle h, int cam, uint64_t t_ns, uint8_t* out_m
   { int rc = build_forward_lists(h, cam); if (rc) return rc; }
   {
     std::lock_guard<std::mutex> lr(h->mu_ring);
+    ingest_fence(h, cam);
     const auto& tsq = h->ts_host[cam];
     const size_t k = std::lower_bound(tsq.begin(), tsq.end(), (u64)t_ns) - tsq.begin();
     const u64 upto = h->ring_base[cam] + k;
@@ -328,6 +368,7 @@ int esvo_ts_render(esvo_handle h, int cam, uint64_t t_ns, uint8_t* out_mono8) {
   const int evo = cam * EV_TS_STRIDE;
   {
     std::lock_guard<std::mutex> lr(h->mu_ring);
+    ingest_fence(h, cam);
     // events with ts < T (strict, TimeSurface.h:68) that are not in the SAE yet
     const auto& tsq = h->ts_host[cam];
     const size_t k = std::lower_bound(tsq.begin(), tsq.end(), (u64)t_ns) - tsq.begin();

@@ -127,6 +127,10 @@ struct esvo_context {
                                 // only if no scatter was enqueued meanwhile)
   u64 scattered[2] = {0, 0};    // absolute index of the first event not yet in the SAE
   u64 scatter_pending_lo[2] = {~0ull, ~0ull};  // oldest event a possibly still running scatter kernel reads
+  // esvo_ts_push_events_async: the newest enqueued (not awaited) copy of a camera; consumers of the ring on the front stream
+  // queue behind it (ingest_fence, api_ts.hip) -- under mu_ring
+  hipEvent_t evt_ingest[2] = {nullptr, nullptr};
+  bool ingest_pending[2] = {false, false};
 
   // observation
   uint8_t* d_obs[2] = {nullptr, nullptr};
@@ -259,6 +263,8 @@ struct esvo_context {
   double* d_trk_pts = nullptr;
   double* d_trk_out = nullptr;
   double* h_trk_ne = nullptr;     // pinned: the 28 sums of esvo_track_normal_equations
+  float* h_trk_xyz = nullptr;     // pinned staging of esvo_track_set_reference's point cloud
+  bool trk_xyz_inflight = false;  // an upload out of it has been enqueued and no call has waited for the tracker stream since
   size_t trk_cap = 0, trk_n = 0;
   bool trk_cur = false;
   hipEvent_t evt_trk_read = nullptr;  // the tracker stream has read the resident left Time Surface (mu_ts)
@@ -303,6 +309,7 @@ void fill_dev_params(esvo_context* h);
 void set_compute_band(esvo_context* h);
 // api_ts.hip
 void collect_ts_timing(esvo_context* h, int only = -1);
+void ingest_fence(esvo_context* h, int cam);  // caller holds mu_ring
 void resident_write_begin(esvo_context* h, int cam);
 int ts_render_pair(esvo_context* h, uint64_t t_ns, uint8_t* const obs_out[2]);
 // api_map.hip

@@ -22,7 +22,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
 
 SYMBOLS = [
     "esvo_default_params", "esvo_create", "esvo_destroy", "esvo_reset", "esvo_set_params", "esvo_last_error",
-    "esvo_set_stream", "esvo_synchronize", "esvo_ts_push_events", "esvo_ts_push_event_array", "esvo_ts_render", "esvo_ts_render_forward", "esvo_map_set_observation",
+    "esvo_set_stream", "esvo_synchronize", "esvo_ts_push_events", "esvo_ts_push_events_async", "esvo_ts_push_wait", "esvo_host_alloc", "esvo_host_free", "esvo_ts_push_event_array", "esvo_ts_render", "esvo_ts_render_forward", "esvo_map_set_observation",
     "esvo_map_match", "esvo_map_set_poses", "esvo_map_refine", "esvo_map_push_frame", "esvo_map_fuse",
     "esvo_map_tick", "esvo_map_tick_bm_only", "esvo_map_fuse_matches_naive", "esvo_map_tick_resident", "esvo_map_get_depth_points", "esvo_map_get_committed", "esvo_map_get_pointcloud_xyz", "esvo_map_get_last_frame",
     "esvo_get_stats", "esvo_shard_set_band", "esvo_shard_exchange", "esvo_shard_tick_phase", "esvo_abi_sizes",
@@ -130,6 +130,10 @@ def load():
     lib.esvo_set_stream.argtypes = [vp, vp]
     lib.esvo_synchronize.argtypes = [vp]
     lib.esvo_ts_push_events.argtypes = [vp, i32, vp, sz]
+    lib.esvo_ts_push_events_async.argtypes = [vp, i32, vp, sz]
+    lib.esvo_ts_push_wait.argtypes = [vp, i32]
+    lib.esvo_host_alloc.argtypes = [sz, C.POINTER(vp)]
+    lib.esvo_host_free.argtypes = [vp]
     lib.esvo_ts_push_event_array.argtypes = [vp, i32, vp, sz, psz]
     lib.esvo_ts_render.argtypes = [vp, i32, u64, vp]
     lib.esvo_ts_render_forward.argtypes = [vp, i32, u64, vp]
@@ -264,6 +268,25 @@ def comm_rccl_info():
     return int(v.value), buf.value.decode(errors="replace")
 
 
+class PinnedEvents:
+    """an esvo_event_t array in pinned host memory (esvo_host_alloc): what a node's message pool would be"""
+
+    def __init__(self, n):
+        self.lib = load()
+        self.ptr = C.c_void_p()
+        rc = self.lib.esvo_host_alloc(max(int(n), 1) * EVENT_DTYPE.itemsize, C.byref(self.ptr))
+        if rc:
+            raise EsvoError(f"esvo_host_alloc: {rc}")
+        buf = (C.c_char * (max(int(n), 1) * EVENT_DTYPE.itemsize)).from_address(self.ptr.value)
+        self.array = np.frombuffer(buf, dtype=EVENT_DTYPE, count=int(n))
+
+    def free(self):
+        if self.ptr:
+            self.array = None
+            self.lib.esvo_host_free(self.ptr)
+            self.ptr = None
+
+
 def abi_sizes():
     out = (C.c_size_t * 8)()
     load().esvo_abi_sizes(out)
@@ -319,6 +342,18 @@ class Esvo:
     def ts_push_events(self, cam, ev):
         ev = np.ascontiguousarray(ev, dtype=EVENT_DTYPE)
         self._ck(self.lib.esvo_ts_push_events(self.h, int(cam), ev.ctypes.data, ev.shape[0]))
+
+    def ts_push_events_async(self, cam, ev):
+        """enqueue the copy and return; `ev` (ideally pinned: pinned_events) is kept alive here until ts_push_wait(cam)"""
+        assert ev.dtype == EVENT_DTYPE and ev.flags["C_CONTIGUOUS"]
+        self._async_keep = getattr(self, "_async_keep", {0: [], 1: []})
+        self._async_keep[int(cam)].append(ev)
+        self._ck(self.lib.esvo_ts_push_events_async(self.h, int(cam), ev.ctypes.data, ev.shape[0]))
+
+    def ts_push_wait(self, cam):
+        self._ck(self.lib.esvo_ts_push_wait(self.h, int(cam)))
+        if hasattr(self, "_async_keep"):
+            self._async_keep[int(cam)].clear()
 
     def ts_push_event_array(self, cam, msg):
         """stage one serialised dvs_msgs/EventArray (bytes / uint8 array, ROS1 wire format); returns its event count"""

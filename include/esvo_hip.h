@@ -18,7 +18,7 @@
  *     concurrently, one thread per group -- the threading of the reference's nodes (esvo_Mapping.cpp:160,179-247: the
  *     MappingLoop worker thread; :669-703 and TimeSurface.cpp:403-425: eventsCallback on the ROS spinner under
  *     data_mutex_; esvo_Tracking's own loop):
- *       INGEST   esvo_ts_push_events, esvo_ts_push_event_array, esvo_ts_push_bag (one thread per camera is fine)
+ *       INGEST   esvo_ts_push_events(_async), esvo_ts_push_wait, esvo_ts_push_event_array, esvo_ts_push_bag (one thread per camera is fine)
  *       TRACKER  esvo_track_*
  *       MAPPER   every other call that takes the handle (renders, observation, ticks, stage-wise calls, outputs,
  *                parameters, esvo_comm_*, esvo_reset -- which excludes the other two groups while it runs)
@@ -243,6 +243,18 @@ int esvo_synchronize(esvo_handle h);
  * TimeSurface.h:39-50) and, for the left camera, esvo_Mapping::eventsCallback
  * (esvo_Mapping.cpp:669-703).  Events must be time-sorted (Appendix A-1). */
 int esvo_ts_push_events(esvo_handle h, int cam, const esvo_event_t* ev, size_t n);
+/* The same without waiting for the copy: the call returns once the host-to-device copy of `ev` is ENQUEUED on the ingest stream
+ * (time stamps and order are checked during the call).  `ev` must stay valid and unchanged until esvo_ts_push_wait(h, cam) has
+ * returned.  Meant for PINNED buffers (esvo_host_alloc below, or the node's own hipHostRegister'ed message pool): from pinned
+ * memory the copy is a DMA that overlaps the running tick, so a node that stages every tick's events pays no PCIe time on
+ * its mapping thread; from pageable memory the runtime stages the copy itself and the call is as synchronous as
+ * esvo_ts_push_events.  Renders and ticks that read the events are ordered behind the copy on the device (an event wait on the
+ * handle's front stream), never by a host wait. */
+int esvo_ts_push_events_async(esvo_handle h, int cam, const esvo_event_t* ev, size_t n);
+int esvo_ts_push_wait(esvo_handle h, int cam);
+/* Pinned host memory for such buffers (hipHostMalloc / hipHostFree behind the C-ABI; no handle needed). */
+int esvo_host_alloc(size_t bytes, void** out);
+int esvo_host_free(void* p);
 /* The same, straight from the ROS1 wire format: `msg` is one serialised
  * dvs_msgs/EventArray (Header, u32 height, u32 width, u32 count, count x 13-byte dvs_msgs/Event: u16 x, u16 y,
  * u32 sec, u32 nsec, u8 polarity) as a rosbag chunk or a TCPROS connection delivers it.  The packed records are copied to

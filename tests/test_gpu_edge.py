@@ -448,3 +448,44 @@ def test_pose_table_slots_grow_on_demand():
                         "-k", "back_to_back or sparse_stretch"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-2000:]
+
+
+def test_async_pinned_ingest_gives_the_same_maps(upenn_rig, upenn_stream):
+    """esvo_ts_push_events_async from pinned buffers (esvo_host_alloc): the copy is only ENQUEUED when the call returns and the
+    tick that follows is launched at once -- the device orders it behind the copy.  Tick by tick (each tick's events staged
+    one tick ahead, in a ring that wraps) the maps must equal those of the synchronous push of the same blocks."""
+    from esvo_amd import lib
+    p, _ = params.make_params(params.PRESETS["mapping_upenn"], upenn_rig, event_ring_capacity=32768)
+    st = upenn_stream
+    t0 = st.t0_ns + 60_000_000
+    ticks = [t0 + k * 10_000_000 for k in range(8)]
+    bounds = [st.t0_ns] + [t + 10_000_000 for t in ticks]     # block k holds the events up to one tick AFTER tick k
+    runs = []
+    for use_async in (False, True):
+        dev = lib.Esvo(p, upenn_rig)
+        pins, maps = [], []
+        for k, t in enumerate(ticks):
+            for cam in (0, 1):
+                ev = st.slice(cam, bounds[k], bounds[k + 1])
+                if use_async:
+                    pe = lib.PinnedEvents(len(ev))
+                    pe.array[:] = ev
+                    pins.append(pe)
+                    dev.ts_push_events_async(cam, pe.array)
+                else:
+                    dev.ts_push_events(cam, ev)
+            stamps, poses = rostime.pose_table(st.pose, t, p.bm_half_slice_thickness)
+            dev.tick_resident(t, st.pose(t), stamps, poses)   # launched while the copies may still be in flight
+            if k % 3 == 2:
+                maps.append(dev.get_map())
+        maps.append(dev.get_map())
+        assert dev.stats().last_points > 0
+        if use_async:
+            dev.ts_push_wait(0)
+            dev.ts_push_wait(1)
+        dev.close()
+        for pe in pins:
+            pe.free()
+        runs.append(maps)
+    for a, b in zip(*runs):
+        _same_map(a, b)

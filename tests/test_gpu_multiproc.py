@@ -59,6 +59,27 @@ def test_bench_launches_its_own_ranks():
         assert out.returncode != 0 and "GPU(s) visible" in out.stderr and not [l for l in out.stdout.splitlines() if l.startswith("{")]
 
 
+def _selftest(extra_env, n):
+    env = dict(os.environ, **extra_env)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--selftest"], env=env, cwd=ROOT,
+                         capture_output=True, text=True, timeout=300)
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    return out.returncode, (json.loads(line[-1]) if line else None), out.stderr[-1500:]
+
+
+def test_selftest_reports_ranks_exchange_and_map_equality():
+    """`python bench.py --gpus N --selftest`: the plumbing check a scaling run starts with.  Here two ranks on the one GPU over
+    gloo (the torch.distributed drivers; on a multi-GPU node the same command runs esvo_comm_* over RCCL), and one rank alone."""
+    rc, one, err = _selftest({}, 1)
+    assert rc == 0 and one["ok"] and one["n_gpus"] == 1 and one["depth_map"]["one_gpu"]["map_size"] > 100, (rc, one, err)
+    rc, two, err = _selftest({"ESVO_SHARED_GPU": "1", "ESVO_DIST_BACKEND": "gloo"}, 2)
+    assert rc == 0 and two["ok"], (rc, two, err)
+    assert {r["rank"] for r in two["ranks_seen"]} == {0, 1} and two["all_gather"]["verified"] and two["all_gather"]["us_min"] > 0
+    assert two["depth_map_equal_to_one_gpu"] and set(two["depth_map"]) == {"tick", "band", "one_gpu"}
+    assert two["depth_map"]["one_gpu"]["sha1"] == one["depth_map"]["one_gpu"]["sha1"]
+    assert two["seconds"] < 60
+
+
 @pytest.mark.skipif(_device_count() < 2, reason="needs two MI355X on the node (real RCCL between two processes)")
 def test_two_gpus_over_real_rccl():
     """Self-enabling on a multi-GPU node: one process per GPU, esvo_comm_init at world 2 over real RCCL (ncclCommInitRank,
