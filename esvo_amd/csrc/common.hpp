@@ -291,19 +291,20 @@ struct FuseArgs {
   const double* frame_pose_T;   // [n_pose_slots][max_poses][16]
   u32 max_poses;
   double T_frame_world[16];     // inverse of the depth frame's pose
-  // scratch
+  // scratch (kernels_fuse.hip, "the fusion front: tiles")
   DevPoint* prop;               // [n_pts] propagated points (row == 0xffffffff: rejected)
-  u32* cell_count;              // [W*H]
-  u32* cell_offset;             // [W*H]
-  u32* cell_fill;               // [W*H]
-  u32* rec_ids;                 // [n_pts * K]
-  u32* scan_tmp;                // scan scratch
-  u32* d_total;                 // total records
+  u32* pt_tile;                 // [n_pts] tile of the point's centre cell (0xffffffff: rejected)
+  u32* tile_count;              // [n_tiles] points per tile; zero between ticks (tile_scan_kernel clears it after reading)
+  u32* tile_fill;               // [n_tiles]
+  u32* tile_offset;             // [n_tiles + 1]
+  u32* tile_pts;                // [n_pts] point ids grouped by tile
+  u32* rec_ids;                 // [n_pts * K] record ids of cells too long for LDS (degenerate scenes only)
+  u32* overflow_cursor;         // next free entry of rec_ids
+  u32 lds_cap;                  // record ids a tile may hold in LDS (0: the maximum; smaller values: tests)
+  u32* d_total;                 // total records (a statistic)
   MapCell* map;                 // [W*H]
   u32* d_num_fusion;            // fusion counter
-  u32* bucket;                  // [3*128] load-balancing buckets: count | offset | fill
-  u32* cell_list;               // [W*H] touched cells, longest record lists first
-  u32* n_touched;               // number of touched cells
+  u32* n_touched;               // number of touched cells (a statistic)
   int naive;                    // 1: DepthFusion::naive_propagation instead of update (esvo_MVStereo's PURE_BLOCK_MATCHING mode)
   u32* owner_max;               // regulariser scratch reset together with the per-cell counters (or nullptr)
   u32* owner_min;

@@ -179,7 +179,7 @@ struct esvo_context {
                                   // [6] touched cells [7] regulariser elements [8] own matches (sharded)
   u32* h_counters = nullptr;      // pinned
   u32* d_scan_tmp = nullptr;
-  u32* d_cnt_b = nullptr;         // back stage: [3] n_fusion [4] n_records [5] n_map [6] touched cells [7] regulariser elements
+  u32* d_cnt_b = nullptr;         // back stage: [2] overflow cursor of the fusion front [3] n_fusion [4] n_records [5] n_map [6] touched cells [7] regulariser elements
   u32* h_cnt_b = nullptr;         // pinned, one row of 8 per parity + one for exports
   u32* d_scan_tmp_b = nullptr;
 
@@ -198,16 +198,18 @@ struct esvo_context {
 
   // DepthMap
   DevPoint* d_prop = nullptr;
-  u32* d_cell_count = nullptr;
-  u32* d_cell_offset = nullptr;
-  u32* d_cell_fill = nullptr;
-  u32* d_rec_ids = nullptr;
+  u32* d_pt_tile = nullptr;       // fusion front (kernels_fuse.hip): per point, its tile; per tile, count / fill / offset; the
+  u32* d_tile_count = nullptr;    // point ids grouped by tile
+  u32* d_tile_fill = nullptr;
+  u32* d_tile_offset = nullptr;
+  u32* d_tile_pts = nullptr;
+  u32* d_rec_ids = nullptr;       // record ids of cells whose list does not fit LDS (degenerate scenes)
+  u32 fuse_lds_cap = 0;           // ESVO_FUSE_LDS_CAP (tests): record ids per tile kept in LDS; 0 = the maximum
   MapCell* d_map = nullptr;
   MapCell* d_map2 = nullptr;
   MapCell* d_map_cur = nullptr;
   u32* d_owner_max = nullptr;
   u32* d_owner_min = nullptr;
-  u32* d_bucket = nullptr;
   u32* d_sel = nullptr;           // denoising: walk positions of the kept events
   uint8_t* d_evmap = nullptr;     // denoising: binary event map
   // sharded mode (kernels_shard.hip): dense local lists + the (matched, kept) byte per slot that is exchanged
@@ -243,7 +245,6 @@ struct esvo_context {
   bool tick_pending = false;      // tk[fpar] has its front stage enqueued but is not committed yet
   u64 committed_t_ns = 0;         // stamp of the newest tick whose back stage is enqueued (0: none)
   u64 sh_first = 0;
-  u32* d_cell_list = nullptr;
   double2* d_reg_ab = nullptr;
   double2* d_reg_cd = nullptr;
   double T_world_frame[16];

@@ -61,7 +61,34 @@ __device__ inline bool fusion_cell(u32 prow, u32 pcol, int k, int radius, int W,
 //               PURE_BLOCK_MATCHING mode (esvo_MVStereo.cpp:416-428)
 enum { FUSE_TDIST = 0, FUSE_L2 = 1, FUSE_NAIVE = 2 };
 
-// ---- propagate (+ histogram) ------------------------------------------------------------------
+// ---- the fusion front: tiles (round 4) ------------------------------------------------------------------------------------
+// Until round 3 every (point, cell) record went through a per-CELL counting sort in global memory: 9 device-scope atomics per
+// point on a 300 k-entry histogram, a 3-pass scan of it, 9 more atomics + a scattered 4-byte store per point, a sort kernel for
+// the long lists, then the walk -- 2 x 1.44 M atomics per tick, each a 32-byte memory-side write on this eight-XCD part
+// (profiles/r03_v3_hbm_traffic.csv: 40 MB written for 5.8 MB of ids).  Now the global sort is two-level and only the coarse
+// level touches memory:
+//   A  propagate       one thread per window point: the propagated point (as before) + ONE atomic on the counter of the
+//                      16 x 16-cell TILE its centre cell lies in, and the tile index of the point
+//   S  tile_scan       one workgroup: exclusive scan of the <= 4096 tile counters -> tile offsets; resets the counters and
+//                      the back stage's statistics (what fuse_reset did)
+//   B  tile_scatter    one thread per point: its id into its tile's list (one atomic on the tile's fill counter)
+//   T  fuse_tiles      one workgroup per tile, one thread per cell: the points of the tile and of its eight neighbours
+//                      (a 3 x 3 footprint reaches at most one tile further) are expanded to records IN LDS -- per-cell
+//                      histogram, scan and fill with LDS atomics -- each cell's list is put in id order in LDS, and the
+//                      cell's thread walks it with the reference's state machine.  No record id ever reaches memory.
+// Order: a cell's records are applied in increasing id q K + k exactly as before (the lists are sorted, whatever order the
+// atomics produced), so every map element keeps its bits.
+// Capacity: the tile's records stay in LDS up to `cap` ids; a denser tile is processed in runs of consecutive cells that fit,
+// and a single cell with more records than `cap` (a degenerate scene) takes a slow serial path from global memory
+// (FuseArgs::rec_ids).  ESVO_FUSE_LDS_CAP (read at esvo_create) forces small capacities in the tests.
+#define FT 16                      // tile edge in cells
+#define FT_CELLS (FT * FT)
+#define FUSE_LDS_CAP_MAX 8192      // record ids per tile in LDS (32 KB)
+#define FUSE_SORT_TMP 1024         // per-wave scratch of the cooperative sort of long lists
+
+__host__ __device__ inline int fuse_tiles_x(int W) { return (W + FT - 1) / FT; }
+__host__ __device__ inline int fuse_tiles_y(int H) { return (H + FT - 1) / FT; }
+
 template <int MODEL>
 __global__ void __launch_bounds__(256, BACK_WAVES) propagate_kernel(FuseArgs a, DevParams p, int K) {
   const u32 q = blockIdx.x * blockDim.x + threadIdx.x;
@@ -83,14 +110,15 @@ __global__ void __launch_bounds__(256, BACK_WAVES) propagate_kernel(FuseArgs a, 
     pp[r] = ((T[r * 4 + 0] * prior.p_cam[0] + T[r * 4 + 1] * prior.p_cam[1]) + T[r * 4 + 2] * prior.p_cam[2]) + T[r * 4 + 3];
   double u, v;
   world2Cam(p.camL, pp, u, v);
-  if (!boundaryCheck(u, v, p.W, p.H)) {  // also rejects NaN coordinates?  NaN passes the reference's
-    // test (all comparisons false) and then floor(NaN) -> size_t is undefined; treat as rejected.
+  // boundaryCheck; NaN coordinates pass the reference's test (all comparisons false) and then floor(NaN) -> size_t is
+  // undefined: treated as rejected
+  if (!boundaryCheck(u, v, p.W, p.H) || !(u == u) || !(v == v)) {
     prop.row = 0xffffffffu;
     prop.col = 0;
     a.prop[q] = prop;
+    a.pt_tile[q] = 0xffffffffu;
     return;
   }
-  if (!(u == u) || !(v == v)) { prop.row = 0xffffffffu; prop.col = 0; a.prop[q] = prop; return; }
   prop.row = (u32)(size_t)floor(v);
   prop.col = (u32)(size_t)floor(u);
   prop.x[0] = u;
@@ -120,43 +148,52 @@ __global__ void __launch_bounds__(256, BACK_WAVES) propagate_kernel(FuseArgs a, 
   prop.pose_idx = 0;
   prop.seq = q;
   a.prop[q] = prop;
-  const int radius = MODEL == FUSE_NAIVE ? 0 : p.fusion_radius;
-  for (int k = 0; k < K; ++k) {
-    int row, col;
-    if (!fusion_cell(prop.row, prop.col, k, radius, p.W, p.H, row, col)) continue;
-    if (row < p.cband_y0 || row >= p.cband_y1) continue;
-    atomicAdd(&a.cell_count[row * p.W + col], 1u);
+  (void)K;
+  const u32 tile = (prop.row / FT) * (u32)fuse_tiles_x(p.W) + prop.col / FT;
+  a.pt_tile[q] = tile;
+  atomicAdd(&a.tile_count[tile], 1u);
+}
+
+// S: exclusive scan of the tile counters (one workgroup; n_tiles <= 16 k for a 4 M-pixel image), counters cleared for the
+// next tick, the back stage's statistics cleared for this one
+__global__ void __launch_bounds__(1024) tile_scan_kernel(FuseArgs a, int n_tiles) {
+  __shared__ u32 lds[1024 / ESVO_WAVE];
+  u32 carry = 0;
+  for (int base = 0; base < n_tiles; base += 1024 * 4) {
+    u32 v[4], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = base + (int)threadIdx.x * 4 + k;
+      v[k] = i < n_tiles ? a.tile_count[i] : 0u;
+      sum += v[k];
+    }
+    u32 tot;
+    u32 ex = block_excl_scan<1024 / ESVO_WAVE>(sum, &tot, lds) + carry;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = base + (int)threadIdx.x * 4 + k;
+      if (i < n_tiles) { a.tile_offset[i] = ex; a.tile_count[i] = 0u; a.tile_fill[i] = 0u; }
+      ex += v[k];
+    }
+    carry += tot;
+  }
+  if (threadIdx.x == 0) {
+    a.tile_offset[n_tiles] = carry;
+    *a.d_num_fusion = 0;
+    *a.d_total = 0;
+    *a.n_touched = 0;
+    *a.overflow_cursor = 0;
+    if (a.n_reg_elems) *a.n_reg_elems = 0;
   }
 }
 
-// XCD-aware scatter.  The record ids of a cell are contiguous, cells in row-major order, and the points arrive in event
-// order, i.e. spatially at random: one launch over the points writes 4-byte ids all over the 6 MB id array from all eight
-// XCDs, every XCD's L2 ends up with its own partially dirty copy of every 128-byte line, and the write-back is ~12x the
-// array (profiles/r02_v8_hbm_traffic.csv: 70 MB for 5.8 MB of ids).  Workgroups are dealt to the XCDs round-robin by their
-// index, so the launch is replicated SCATTER_PARTS = 8 times and replica x -- the workgroups with blockIdx % 8 == x, all on
-// one XCD -- emits only the records of image row band x: every line of the id array (and of the per-cell fill counters) is
-// written from ONE L2 and leaves it once, full.  Each replica reads every point's (row, col) again: 8 B x 8 per point from
-// L2 / Infinity Cache, and a few integer instructions.
-#define SCATTER_PARTS 8
-__global__ void __launch_bounds__(256) scatter_records_kernel(FuseArgs a, DevParams p, int K) {
-  const u32 part = blockIdx.x % SCATTER_PARTS;
-  const u32 q = (blockIdx.x / SCATTER_PARTS) * blockDim.x + threadIdx.x;
+// B: the point ids, grouped by tile
+__global__ void __launch_bounds__(256) tile_scatter_kernel(FuseArgs a) {
+  const u32 q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= a.n_pts) return;
-  const u32 prow = a.prop[q].row, pcol = a.prop[q].col;
-  if (prow == 0xffffffffu) return;
-  const int rows_per = (p.H + SCATTER_PARTS - 1) / SCATTER_PARTS;
-  const int r0 = (int)part * rows_per, r1 = r0 + rows_per;
-  const int radius = K == 4 ? 0 : p.fusion_radius;  // (naive propagation: always 2 x 2)
-  if ((int)prow + 1 < r0 || (int)prow - 1 >= r1) return;  // none of the point's cells lies in the band
-  for (int k = 0; k < K; ++k) {
-    int row, col;
-    if (!fusion_cell(prow, pcol, k, radius, p.W, p.H, row, col)) continue;
-    if (row < r0 || row >= r1) continue;
-    if (row < p.cband_y0 || row >= p.cband_y1) continue;
-    const int cell = row * p.W + col;
-    const u32 pos = a.cell_offset[cell] + atomicAdd(&a.cell_fill[cell], 1u);
-    a.rec_ids[pos] = q * (u32)K + (u32)k;
-  }
+  const u32 tile = a.pt_tile[q];
+  if (tile == 0xffffffffu) return;
+  a.tile_pts[a.tile_offset[tile] + atomicAdd(&a.tile_fill[tile], 1u)] = q;
 }
 
 // DepthPoint::update_studentT, DepthPoint.cpp:167-188
@@ -179,310 +216,275 @@ __device__ inline void update_studentT(MapCell& c, double invD, double s2, doubl
   }
 }
 
-// ---- load balancing: touched cells ordered by record count (longest lists first) ----------------
-// The per-cell walk is sequential, so a wave lasts as long as its longest list.  Bucketing the
-// touched cells by min(n, NB-1) (block-local LDS histogram -> one global reservation per bucket
-// and block -> LDS-ranked scatter) gives waves of near-uniform length; cells are independent, so
-// their processing order is free.
-#define FUSE_NB 16
-// bucket = ceil(log2(n)): lists in a wave differ by at most 2x while cells stay in (block-)spatial
-// order inside a bucket, which keeps the propagated points they share in L1/L2.
-__device__ inline u32 fuse_bucket(u32 n) {  // n >= 1: 1->0, 2->1, 3..4->2, 5..8->3, ...
-  const u32 b = (n <= 1u) ? 0u : 32u - (u32)__builtin_clz(n - 1u);
-  return b < FUSE_NB - 1u ? b : FUSE_NB - 1u;
-}
-// The exclusive scan of the per-cell record counts (-> cell_offset) and the bucketing of the touched cells run in the
-// SAME three passes (reduce / block sums / down-sweep): both only read cell_count, so what used to be six dependent
-// launches (scan x3, bucket count / offsets / scatter) are three.
-__global__ void __launch_bounds__(SCAN_B) cell_scan_reduce_kernel(const u32* __restrict__ cell_count, u32* __restrict__ block_sums,
-                                                                 u32* __restrict__ bucket_cnt, MapCell* __restrict__ map, int ncell,
-                                                                 int band0, int band1, int W) {
-  __shared__ u32 lds[SCAN_B / ESVO_WAVE];
-  __shared__ u32 h[FUSE_NB];
-  if (threadIdx.x < FUSE_NB) h[threadIdx.x] = 0;
-  __syncthreads();
-  const int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_V;
-  u32 s = 0;
-#pragma unroll
-  for (int k = 0; k < SCAN_V; ++k) {
-    const int cell = base + k;
-    if (cell >= ncell) break;
-    const u32 n = cell_count[cell];
-    s += n;
-    const int row = cell / W;
-    if (row >= band0 && row < band1) {
-      if (n == 0) map_flags(map, ncell)[cell] = 0;
-      else atomicAdd(&h[fuse_bucket(n)], 1u);
-    }
+// one record applied to a cell: DepthFusion::fusion's body (DepthFusion.cpp:119-190; naive_propagation: :262-282)
+template <int MODEL>
+__device__ inline void fuse_record(const DevParams& p, MapCell& c, bool& exists, u32& numFusion, const DevPoint& prop, u32 id, int crow,
+                                   int ccol) {
+  if (!exists) {  // case 1: DepthFusion.cpp:127-146 (naive_propagation: :262-272)
+    c.row = (u32)crow; c.col = (u32)ccol;
+    c.x[0] = (double)ccol + 0.5; c.x[1] = (double)crow + 0.5;
+    c.inv_depth = prop.inv_depth; c.scale2 = prop.scale2; c.variance = prop.variance; c.nu = prop.nu;
+    if (MODEL != FUSE_TDIST && c.variance < 1e-6) c.variance = 1e-6;  // DepthPoint::update -> boundVariance
+    c.residual = prop.residual;
+    c.age = prop.age;
+    cam2World(p.camL, c.x[0], c.x[1], prop.inv_depth, c.p_cam);
+    c.seq = id;
+    exists = true;
+    return;
   }
-  u32 tot;
-  block_excl_scan(s, &tot, lds);  // (barriers inside: h is complete afterwards)
-  if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
-  if (threadIdx.x < FUSE_NB && h[threadIdx.x]) atomicAdd(&bucket_cnt[threadIdx.x], h[threadIdx.x]);
-}
-// single block: exclusive scan of the block sums; bucket_off[b] = number of cells in buckets > b (descending order)
-__global__ void __launch_bounds__(SCAN_B) cell_scan_sums_kernel(u32* __restrict__ block_sums, u32 nb, u32* __restrict__ total,
-                                                               const u32* __restrict__ bucket_cnt, u32* __restrict__ bucket_off,
-                                                               u32* __restrict__ n_touched) {
-  __shared__ u32 lds[SCAN_B / ESVO_WAVE];
-  __shared__ u32 c[FUSE_NB];
-  if (threadIdx.x < FUSE_NB) c[threadIdx.x] = bucket_cnt[threadIdx.x];
-  u32 carry = 0;
-  for (u32 tile = 0; tile < nb; tile += SCAN_TILE) {  // nb <= SCAN_TILE for every supported image; the loop is for safety
-    u32 v[SCAN_V];
-    u32 s = 0;
-#pragma unroll
-    for (int k = 0; k < SCAN_V; ++k) {
-      const u32 i = tile + threadIdx.x * SCAN_V + k;
-      v[k] = (i < nb) ? block_sums[i] : 0u;
-      s += v[k];
+  if constexpr (MODEL == FUSE_NAIVE) {  // case 2 of naive_propagation, :273-282
+    if (c.inv_depth > prop.inv_depth) return;  // the propagated point is farther
+    if (prop.residual < c.residual) {
+      c.row = prop.row; c.col = prop.col;        // `get(row, col) = dp_prop`: its row / col / x travel with it (Appendix A-7)
+      c.x[0] = prop.x[0]; c.x[1] = prop.x[1];
+      c.inv_depth = prop.inv_depth; c.scale2 = prop.scale2; c.nu = prop.nu; c.variance = prop.variance;
+      c.residual = prop.residual; c.age = prop.age;
+      c.p_cam[0] = prop.p_cam[0]; c.p_cam[1] = prop.p_cam[1]; c.p_cam[2] = prop.p_cam[2];
     }
-    u32 tot;
-    u32 ex = block_excl_scan(s, &tot, lds) + carry;
-#pragma unroll
-    for (int k = 0; k < SCAN_V; ++k) {
-      const u32 i = tile + threadIdx.x * SCAN_V + k;
-      if (i < nb) block_sums[i] = ex;
-      ex += v[k];
+    return;
+  } else {
+    bool compatible;
+    if constexpr (MODEL == FUSE_L2) {  // chiSquareTest, :207-218
+      const double d = prop.inv_depth - c.inv_depth, dd = d * d;
+      compatible = dd / prop.variance + dd / c.variance < 5.99;
+    } else {  // studentTCompatibleTest, :220-231
+      const double s1 = sqrt(prop.variance), s2 = sqrt(c.variance), diff = fabs(prop.inv_depth - c.inv_depth);
+      compatible = diff < 2 * s1 || diff < 2 * s2;
     }
-    carry += tot;
-  }
-  if (threadIdx.x == 0 && total) *total = carry;
-  if (threadIdx.x < FUSE_NB) {  // c[] was written before the first barrier of block_excl_scan
-    u32 off = 0;
-    for (int b = FUSE_NB - 1; b > (int)threadIdx.x; --b) off += c[b];
-    bucket_off[threadIdx.x] = off;
-    if (threadIdx.x == 0) *n_touched = off + c[0];
-  }
-}
-__global__ void __launch_bounds__(SCAN_B) cell_scan_down_kernel(const u32* __restrict__ cell_count, u32* __restrict__ cell_offset,
-                                                               const u32* __restrict__ block_sums, const u32* __restrict__ bucket_off,
-                                                               u32* __restrict__ bucket_fill, u32* __restrict__ cell_list, int ncell,
-                                                               int band0, int band1, int W) {
-  __shared__ u32 lds[SCAN_B / ESVO_WAVE];
-  __shared__ u32 h[FUSE_NB];
-  __shared__ u32 hbase[FUSE_NB];
-  if (threadIdx.x < FUSE_NB) h[threadIdx.x] = 0;
-  __syncthreads();
-  const int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_V;
-  u32 v[SCAN_V], rank[SCAN_V];
-  u32 s = 0;
-#pragma unroll
-  for (int k = 0; k < SCAN_V; ++k) {
-    const int cell = base + k;
-    v[k] = 0;
-    rank[k] = 0xffffffffu;
-    if (cell < ncell) {
-      v[k] = cell_count[cell];
-      const int row = cell / W;
-      if (v[k] && row >= band0 && row < band1) rank[k] = atomicAdd(&h[fuse_bucket(v[k])], 1u);
+    if (compatible) {  // case 2.1
+      if constexpr (MODEL == FUSE_L2) {  // DepthPoint::update, DepthPoint.cpp:146-164
+        if (c.inv_depth > -1e-6) {
+          const double temp = c.inv_depth, tv = c.variance;
+          c.inv_depth = (tv * prop.inv_depth + prop.variance * temp) / (tv + prop.variance);
+          c.variance = (tv * prop.variance) / (tv + prop.variance);
+        } else {
+          c.inv_depth = prop.inv_depth;
+          c.variance = prop.variance;
+        }
+        if (c.variance < 1e-6) c.variance = 1e-6;
+      } else {
+        update_studentT(c, prop.inv_depth, prop.scale2, prop.variance, prop.nu);
+      }
+      c.age++;                                                        // :171
+      c.residual = (prop.residual < c.residual) ? prop.residual : c.residual;  // std::min
+      cam2World(p.camL, c.x[0], c.x[1], prop.inv_depth, c.p_cam);     // :173-175
+      numFusion++;
+    } else {  // case 2.2
+      if (c.inv_depth - 2 * sqrt(c.variance) > prop.inv_depth) return;  // occluded
+      if (prop.variance < c.variance && prop.residual < c.residual) {
+        // operator=: the propagated point's row/col/x travel with it (Appendix A-7)
+        c.row = prop.row; c.col = prop.col;
+        c.x[0] = prop.x[0]; c.x[1] = prop.x[1];
+        c.inv_depth = prop.inv_depth; c.scale2 = prop.scale2; c.nu = prop.nu; c.variance = prop.variance;
+        c.residual = prop.residual; c.age = prop.age;
+        c.p_cam[0] = prop.p_cam[0]; c.p_cam[1] = prop.p_cam[1]; c.p_cam[2] = prop.p_cam[2];
+      }
     }
-    s += v[k];
-  }
-  u32 tot;
-  u32 ex = block_excl_scan(s, &tot, lds) + block_sums[blockIdx.x];
-  if (threadIdx.x < FUSE_NB && h[threadIdx.x]) hbase[threadIdx.x] = bucket_off[threadIdx.x] + atomicAdd(&bucket_fill[threadIdx.x], h[threadIdx.x]);
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < SCAN_V; ++k) {
-    const int cell = base + k;
-    if (cell < ncell) cell_offset[cell] = ex;
-    ex += v[k];
-    if (rank[k] != 0xffffffffu) cell_list[hbase[fuse_bucket(v[k])] + rank[k]] = (u32)cell;
   }
 }
 
-// Long record lists (n > 8: every bucket >= 4, i.e. the first bucket_off[3] entries of the cell
-// list) are ordered by a wave-cooperative rank sort: the wave copies the ids to LDS, lane j counts
-// how many ids are smaller than its own (ids are unique) and writes it to that slot.  The atomic
-// scatter leaves the lists in essentially random order, and an in-place insertion sort by a single
-// thread (O(n^2) dependent global round trips) was the tail of the whole tick.
-#define SORT_CAP 2048
-__global__ void __launch_bounds__(64) sort_long_lists_kernel(const u32* __restrict__ cell_list, const u32* __restrict__ n_long_ptr,
-                                                             const u32* __restrict__ cell_count, const u32* __restrict__ cell_offset,
-                                                             u32* __restrict__ rec_ids) {
-  __shared__ u32 l[SORT_CAP];
-  const u32 n_long = *n_long_ptr;
-  for (u32 w = blockIdx.x; w < n_long; w += gridDim.x) {
-    const u32 cell = cell_list[w];
-    const u32 n = cell_count[cell];
-    u32* ids = rec_ids + cell_offset[cell];
-    if (n > SORT_CAP) {  // absurdly long list: serial fallback
-      if (threadIdx.x == 0)
+// T: one workgroup per tile, one thread per cell
+template <int MODEL>
+__global__ void __launch_bounds__(FT_CELLS, 2) fuse_tiles_kernel(FuseArgs a, DevParams p, int K, u32 cap) {
+  __shared__ u32 s_cnt[FT_CELLS];        // records per cell of the tile (whole tile, set once)
+  __shared__ u32 s_off[FT_CELLS + 1];    // their exclusive scan
+  __shared__ u32 s_fill[FT_CELLS];
+  __shared__ u32 s_ids[FUSE_LDS_CAP_MAX];
+  __shared__ u32 s_tmp[FT_CELLS / ESVO_WAVE][FUSE_SORT_TMP];
+  __shared__ u32 s_scan[FT_CELLS / ESVO_WAVE];
+  __shared__ u32 s_red[2];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tiles_x = fuse_tiles_x(p.W), tiles_y = fuse_tiles_y(p.H);
+  const int tx = (int)(blockIdx.x % tiles_x), ty = (int)(blockIdx.x / tiles_x);
+  const int r0 = ty * FT, c0 = tx * FT;
+  const int crow = r0 + tid / FT, ccol = c0 + tid % FT;
+  const int ncell = p.W * p.H;
+  const bool in_img = crow < p.H && ccol < p.W;
+  const bool in_band = in_img && crow >= p.cband_y0 && crow < p.cband_y1;
+  const int cell = crow * p.W + ccol;
+  const int radius = MODEL == FUSE_NAIVE ? 0 : p.fusion_radius;
+  s_cnt[tid] = 0;
+  s_fill[tid] = 0;
+  if (tid < 2) s_red[tid] = 0;
+  // what fuse_reset cleared per cell: the regulariser's owner marks (reg_view re-creates them by atomics)
+  if (in_img && a.owner_max) { a.owner_max[cell] = 0; a.owner_min[cell] = 0xffffffffu; }
+  __syncthreads();
+  // the candidate points: this tile's and its neighbours' lists; expand(fn) calls fn(local cell, record id) for every record
+  // of a cell of this tile (inside the compute band)
+  auto expand = [&](auto&& fn) {
+    for (int dy = -1; dy <= 1; ++dy) {
+      const int ny = ty + dy;
+      if (ny < 0 || ny >= tiles_y) continue;
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int nx = tx + dx;
+        if (nx < 0 || nx >= tiles_x) continue;
+        const int nt = ny * tiles_x + nx;
+        const u32 b0 = a.tile_offset[nt], b1 = a.tile_offset[nt + 1];
+        for (u32 i = b0 + (u32)tid; i < b1; i += FT_CELLS) {
+          const u32 q = a.tile_pts[i];
+          const u32 prow = a.prop[q].row, pcol = a.prop[q].col;
+          for (int k = 0; k < K; ++k) {
+            int row, col;
+            if (!fusion_cell(prow, pcol, k, radius, p.W, p.H, row, col)) continue;
+            if (row < r0 || row >= r0 + FT || col < c0 || col >= c0 + FT) continue;
+            if (row < p.cband_y0 || row >= p.cband_y1) continue;
+            fn((row - r0) * FT + (col - c0), q * (u32)K + (u32)k);
+          }
+        }
+      }
+    }
+  };
+  expand([&](int lc, u32) { atomicAdd(&s_cnt[lc], 1u); });
+  __syncthreads();
+  const u32 n = s_cnt[tid];
+  {
+    u32 tot;
+    const u32 ex = block_excl_scan<FT_CELLS / ESVO_WAVE>(n, &tot, s_scan);
+    s_off[tid] = ex;
+    if (tid == 0) s_off[FT_CELLS] = tot;
+  }
+  __syncthreads();
+  const u32 total = s_off[FT_CELLS];
+  if (total == 0) {  // nothing lands here: the band's cells read empty
+    if (in_band) map_flags(a.map, ncell)[cell] = 0;
+    return;
+  }
+  MapCell c;
+  bool exists = false;
+  u32 numFusion = 0;
+  // runs of consecutive cells whose records fit the LDS buffer together
+  u32 run0 = 0;
+  while (run0 < FT_CELLS) {
+    // (every thread derives the same run: s_off is complete)
+    u32 run1 = run0 + 1;
+    while (run1 < FT_CELLS && s_off[run1 + 1] - s_off[run0] <= cap) ++run1;
+    const u32 base = s_off[run0];
+    const u32 run_n = s_off[run1] - base;
+    const bool mine = (u32)tid >= run0 && (u32)tid < run1 && n > 0;
+    if (run_n == 0) { run0 = run1; continue; }
+    if (run_n <= cap) {
+      // ---- fill: the run's records into LDS, each cell's contiguous ----
+      expand([&](int lc, u32 id) {
+        if ((u32)lc >= run0 && (u32)lc < run1) s_ids[s_off[lc] - base + atomicAdd(&s_fill[lc], 1u)] = id;
+      });
+      __syncthreads();
+      u32* ids = s_ids + (s_off[tid] - base);
+      // ---- order: short lists by insertion in place; long ones by the wave, rank-sorted through its scratch ----
+      if (mine && n > 1 && n <= 24) {
         for (u32 i = 1; i < n; ++i) {
           const u32 key = ids[i];
           int j = (int)i - 1;
           while (j >= 0 && ids[j] > key) { ids[j + 1] = ids[j]; --j; }
           ids[j + 1] = key;
         }
-      continue;
-    }
-    __syncthreads();  // previous iteration's readers are done
-    for (u32 i = threadIdx.x; i < n; i += 64) l[i] = ids[i];
-    __syncthreads();
-    for (u32 i = threadIdx.x; i < n; i += 64) {
-      const u32 v = l[i];
-      u32 rank = 0;
-      for (u32 j = 0; j < n; ++j) rank += (l[j] < v);
-      ids[rank] = v;
-    }
-  }
-}
-
-// One thread per touched cell: order the cell's record ids, then walk them (DepthFusion::fusion).
-#ifndef FUSE_BLOCK
-#define FUSE_BLOCK 256
-#endif
-template <int MODEL>
-__global__ void __launch_bounds__(FUSE_BLOCK, FUSE_WAVES) fuse_cells_kernel(FuseArgs a, DevParams p, int K) {
-  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= *a.n_touched) return;
-  const int cell = (int)a.cell_list[t];
-  const int crow = cell / p.W, ccol = cell - crow * p.W;
-  const u32 n = a.cell_count[cell];
-  u32* ids = a.rec_ids + a.cell_offset[cell];
-  // Records must be applied in increasing id order.  Short lists (the common case) are walked by
-  // repeated minimum selection straight from the (cached) id list; long ones were ordered by
-  // sort_long_lists_kernel.
-  const bool presorted = n > 8;  // ordered by sort_long_lists_kernel
-  MapCell c;
-  bool exists = false;
-  u32 numFusion = 0;
-  auto next_id = [&](u32 i, u32 last) -> u32 {
-    if (presorted) return ids[i];
-    u32 id = 0xffffffffu;
-    for (u32 j = 0; j < n; ++j) {
-      const u32 v = ids[j];
-      if ((i == 0 || v > last) && v < id) id = v;
-    }
-    return id;
-  };
-#ifndef FUSE_NO_PREFETCH
-  u32 id_nxt = next_id(0, 0);
-  DevPoint nxt = a.prop[id_nxt / (u32)K];
-#else
-  u32 id = 0;
-#endif
-  for (u32 i = 0; i < n; ++i) {
-#ifndef FUSE_NO_PREFETCH
-    const u32 id = id_nxt;
-    const DevPoint prop = nxt;
-    if (i + 1 < n) {  // software prefetch: the next record does not depend on the cell state
-      id_nxt = next_id(i + 1, id);
-      nxt = a.prop[id_nxt / (u32)K];
-    }
-#else
-    // (A/B: without the software prefetch the kernel needs 80 instead of 112 VGPRs; measured slower beside the LM kernel in
-    //  round 3 as well -- 1.43 against 1.39 ms per tick -- see the register footprint note in kernels_lm.hip)
-    id = next_id(i, id);
-    const DevPoint prop = a.prop[id / (u32)K];
-#endif
-    if (!exists) {  // case 1: DepthFusion.cpp:127-146 (naive_propagation: :262-272)
-      c.row = (u32)crow; c.col = (u32)ccol;
-      c.x[0] = (double)ccol + 0.5; c.x[1] = (double)crow + 0.5;
-      c.inv_depth = prop.inv_depth; c.scale2 = prop.scale2; c.variance = prop.variance; c.nu = prop.nu;
-      if (MODEL != FUSE_TDIST && c.variance < 1e-6) c.variance = 1e-6;  // DepthPoint::update -> boundVariance
-      c.residual = prop.residual;
-      c.age = prop.age;
-      cam2World(p.camL, c.x[0], c.x[1], prop.inv_depth, c.p_cam);
-      c.seq = id;
-      exists = true;
-    } else if constexpr (MODEL == FUSE_NAIVE) {  // case 2 of naive_propagation, :273-282
-      if (c.inv_depth > prop.inv_depth) continue;  // the propagated point is farther
-      if (prop.residual < c.residual) {
-        c.row = prop.row; c.col = prop.col;        // `get(row, col) = dp_prop`: its row / col / x travel with it (Appendix A-7)
-        c.x[0] = prop.x[0]; c.x[1] = prop.x[1];
-        c.inv_depth = prop.inv_depth; c.scale2 = prop.scale2; c.nu = prop.nu; c.variance = prop.variance;
-        c.residual = prop.residual; c.age = prop.age;
-        c.p_cam[0] = prop.p_cam[0]; c.p_cam[1] = prop.p_cam[1]; c.p_cam[2] = prop.p_cam[2];
       }
-    } else {
-      bool compatible;
-      if constexpr (MODEL == FUSE_L2) {  // chiSquareTest, :207-218
-        const double d = prop.inv_depth - c.inv_depth, dd = d * d;
-        compatible = dd / prop.variance + dd / c.variance < 5.99;
-      } else {  // studentTCompatibleTest, :220-231
-        const double s1 = sqrt(prop.variance), s2 = sqrt(c.variance), diff = fabs(prop.inv_depth - c.inv_depth);
-        compatible = diff < 2 * s1 || diff < 2 * s2;
-      }
-      if (compatible) {  // case 2.1
-        if constexpr (MODEL == FUSE_L2) {  // DepthPoint::update, DepthPoint.cpp:146-164
-          if (c.inv_depth > -1e-6) {
-            const double temp = c.inv_depth, tv = c.variance;
-            c.inv_depth = (tv * prop.inv_depth + prop.variance * temp) / (tv + prop.variance);
-            c.variance = (tv * prop.variance) / (tv + prop.variance);
-          } else {
-            c.inv_depth = prop.inv_depth;
-            c.variance = prop.variance;
+      u64 longm = __ballot(mine && n > 24);
+      while (longm) {
+        const int src = __ffsll((long long)longm) - 1;
+        longm &= longm - 1;
+        const u32 ln = (u32)__shfl((int)n, src), lo = (u32)__shfl((int)(s_off[tid] - base), src);
+        u32* lid = s_ids + lo;
+        if (ln <= FUSE_SORT_TMP) {
+          for (u32 i = (u32)lane; i < ln; i += ESVO_WAVE) {
+            const u32 vkey = lid[i];
+            u32 rank = 0;
+            for (u32 j = 0; j < ln; ++j) rank += (lid[j] < vkey);
+            s_tmp[wv][rank] = vkey;
           }
-          if (c.variance < 1e-6) c.variance = 1e-6;
-        } else {
-          update_studentT(c, prop.inv_depth, prop.scale2, prop.variance, prop.nu);
-        }
-        c.age++;                                                        // :171
-        c.residual = (prop.residual < c.residual) ? prop.residual : c.residual;  // std::min
-        cam2World(p.camL, c.x[0], c.x[1], prop.inv_depth, c.p_cam);     // :173-175
-        numFusion++;
-      } else {  // case 2.2
-        if (c.inv_depth - 2 * sqrt(c.variance) > prop.inv_depth) continue;  // occluded
-        if (prop.variance < c.variance && prop.residual < c.residual) {
-          // operator=: the propagated point's row/col/x travel with it (Appendix A-7)
-          c.row = prop.row; c.col = prop.col;
-          c.x[0] = prop.x[0]; c.x[1] = prop.x[1];
-          c.inv_depth = prop.inv_depth; c.scale2 = prop.scale2; c.nu = prop.nu; c.variance = prop.variance;
-          c.residual = prop.residual; c.age = prop.age;
-          c.p_cam[0] = prop.p_cam[0]; c.p_cam[1] = prop.p_cam[1]; c.p_cam[2] = prop.p_cam[2];
+          // (one wave: its LDS operations execute in program order; the barrier only keeps the compiler from moving them)
+          __builtin_amdgcn_wave_barrier();
+          for (u32 i = (u32)lane; i < ln; i += ESVO_WAVE) lid[i] = s_tmp[wv][i];
+          __builtin_amdgcn_wave_barrier();
+        } else if (lane == src) {  // longer than the scratch: one lane, insertion sort
+          for (u32 i = 1; i < ln; ++i) {
+            const u32 key = lid[i];
+            int j = (int)i - 1;
+            while (j >= 0 && lid[j] > key) { lid[j + 1] = lid[j]; --j; }
+            lid[j + 1] = key;
+          }
         }
       }
+      // ---- walk ----
+      if (mine) {
+        u32 id_nxt = ids[0];
+        DevPoint nxt = a.prop[id_nxt / (u32)K];
+        for (u32 i = 0; i < n; ++i) {
+          const u32 id = id_nxt;
+          const DevPoint prop = nxt;
+          if (i + 1 < n) {  // software prefetch: the next record does not depend on the cell state
+            id_nxt = ids[i + 1];
+            nxt = a.prop[id_nxt / (u32)K];
+          }
+          fuse_record<MODEL>(p, c, exists, numFusion, prop, id, crow, ccol);
+        }
+      }
+      __syncthreads();  // the buffer is reused by the next run
+    } else {
+      // ---- a single cell with more records than the LDS buffer holds: through global memory, by its own thread ----
+      // (run1 == run0 + 1 here.)  The whole workgroup fills the cell's segment of rec_ids, then its thread orders and walks it.
+      __shared__ u32 s_gbase;
+      if (tid == 0) s_gbase = atomicAdd(a.overflow_cursor, run_n);
+      __syncthreads();
+      u32* gids = a.rec_ids + s_gbase;
+      expand([&](int lc, u32 id) {
+        if ((u32)lc == run0) gids[atomicAdd(&s_fill[lc], 1u)] = id;
+      });
+      __threadfence_block();
+      __syncthreads();
+      if (mine) {
+        for (u32 i = 1; i < n; ++i) {
+          const u32 key = gids[i];
+          long long j = (long long)i - 1;
+          while (j >= 0 && gids[j] > key) { gids[j + 1] = gids[j]; --j; }
+          gids[j + 1] = key;
+        }
+        for (u32 i = 0; i < n; ++i) {
+          const u32 id = gids[i];
+          const DevPoint prop = a.prop[id / (u32)K];
+          fuse_record<MODEL>(p, c, exists, numFusion, prop, id, crow, ccol);
+        }
+      }
+      __syncthreads();
+    }
+    run0 = run1;
+  }
+  if (in_band) {
+    if (n > 0) {
+      a.map[cell] = c;
+      map_flags(a.map, ncell)[cell] = CELL_ALIVE | CELL_GRID;
+    } else {
+      map_flags(a.map, ncell)[cell] = 0;
     }
   }
-  a.map[cell] = c;
-  map_flags(a.map, p.W * p.H)[cell] = CELL_ALIVE | CELL_GRID;
-  if (numFusion) atomicAdd(a.d_num_fusion, numFusion);
-}
-
-// one launch instead of seven fills: per-cell counters, load-balancing buckets, counters of the back stage
-__global__ void __launch_bounds__(256) fuse_reset_kernel(FuseArgs a, int ncell) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < ncell) {
-    a.cell_count[i] = 0;
-    a.cell_fill[i] = 0;
-    if (a.owner_max) { a.owner_max[i] = 0; a.owner_min[i] = 0xffffffffu; }
-  }
-  if (i < 3 * 128) a.bucket[i] = 0;  // cnt | off | fill
-  if (i == 0) {
-    *a.d_num_fusion = 0;
-    if (a.n_reg_elems) *a.n_reg_elems = 0;
+  // statistics: fusions, touched cells (one atomic per workgroup each), records
+  if (numFusion) atomicAdd(&s_red[0], numFusion);
+  if (n > 0) atomicAdd(&s_red[1], 1u);
+  __syncthreads();
+  if (tid == 0) {
+    if (s_red[0]) atomicAdd(a.d_num_fusion, s_red[0]);
+    atomicAdd(a.n_touched, s_red[1]);
+    atomicAdd(a.d_total, total);
   }
 }
 
 void launch_fuse(const FuseArgs& a, const DevParams& p, hipStream_t s) {
-  const int ncell = p.W * p.H;
   const int model = a.naive ? FUSE_NAIVE : (p.ls_norm == ESVO_LSNORM_L2 ? FUSE_L2 : FUSE_TDIST);
   const int K = (model == FUSE_NAIVE || p.fusion_radius == 0) ? 4 : 9;
-  const int nb = (ncell + 255) / 256;
-  hipLaunchKernelGGL(fuse_reset_kernel, dim3(std::max(nb, 2)), dim3(256), 0, s, a, ncell);
+  const int n_tiles = fuse_tiles_x(p.W) * fuse_tiles_y(p.H);
   if (a.n_pts) {
     const dim3 g((a.n_pts + 255) / 256), b(256);
     if (model == FUSE_TDIST) hipLaunchKernelGGL(propagate_kernel<FUSE_TDIST>, g, b, 0, s, a, p, K);
     else if (model == FUSE_L2) hipLaunchKernelGGL(propagate_kernel<FUSE_L2>, g, b, 0, s, a, p, K);
     else hipLaunchKernelGGL(propagate_kernel<FUSE_NAIVE>, g, b, 0, s, a, p, K);
   }
-  const u32 nsb = (u32)((ncell + SCAN_TILE - 1) / SCAN_TILE);
-  hipLaunchKernelGGL(cell_scan_reduce_kernel, dim3(nsb), dim3(SCAN_B), 0, s, a.cell_count, a.scan_tmp, a.bucket, a.map, ncell,
-                     p.cband_y0, p.cband_y1, p.W);
-  hipLaunchKernelGGL(cell_scan_sums_kernel, dim3(1), dim3(SCAN_B), 0, s, a.scan_tmp, nsb, a.d_total, a.bucket, a.bucket + FUSE_NB,
-                     a.n_touched);
-  hipLaunchKernelGGL(cell_scan_down_kernel, dim3(nsb), dim3(SCAN_B), 0, s, a.cell_count, a.cell_offset, a.scan_tmp,
-                     a.bucket + FUSE_NB, a.bucket + 2 * FUSE_NB, a.cell_list, ncell, p.cband_y0, p.cband_y1, p.W);
-  if (a.n_pts) hipLaunchKernelGGL(scatter_records_kernel, dim3(((a.n_pts + 255) / 256) * SCATTER_PARTS), dim3(256), 0, s, a, p, K);
-  hipLaunchKernelGGL(sort_long_lists_kernel, dim3(8192), dim3(64), 0, s, a.cell_list, a.bucket + FUSE_NB + 3, a.cell_count,
-                     a.cell_offset, a.rec_ids);
+  hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, a, n_tiles);
+  if (a.n_pts) hipLaunchKernelGGL(tile_scatter_kernel, dim3((a.n_pts + 255) / 256), dim3(256), 0, s, a);
   {
-    const dim3 g((ncell + FUSE_BLOCK - 1) / FUSE_BLOCK), b(FUSE_BLOCK);
-    if (model == FUSE_TDIST) hipLaunchKernelGGL(fuse_cells_kernel<FUSE_TDIST>, g, b, 0, s, a, p, K);
-    else if (model == FUSE_L2) hipLaunchKernelGGL(fuse_cells_kernel<FUSE_L2>, g, b, 0, s, a, p, K);
-    else hipLaunchKernelGGL(fuse_cells_kernel<FUSE_NAIVE>, g, b, 0, s, a, p, K);
+    const dim3 g(n_tiles), b(FT_CELLS);
+    const u32 cap = (a.lds_cap >= 1 && a.lds_cap <= FUSE_LDS_CAP_MAX) ? a.lds_cap : FUSE_LDS_CAP_MAX;
+    if (model == FUSE_TDIST) hipLaunchKernelGGL(fuse_tiles_kernel<FUSE_TDIST>, g, b, 0, s, a, p, K, cap);
+    else if (model == FUSE_L2) hipLaunchKernelGGL(fuse_tiles_kernel<FUSE_L2>, g, b, 0, s, a, p, K, cap);
+    else hipLaunchKernelGGL(fuse_tiles_kernel<FUSE_NAIVE>, g, b, 0, s, a, p, K, cap);
   }
 }
 

@@ -489,3 +489,38 @@ def test_async_pinned_ingest_gives_the_same_maps(upenn_rig, upenn_stream):
         runs.append(maps)
     for a, b in zip(*runs):
         _same_map(a, b)
+
+
+@pytest.mark.parametrize("cap", [1, 7, 200])
+def test_fusion_front_with_tiny_lds_capacity_gives_the_same_maps(dsec_rig, dsec_stream, cap):
+    """The fusion front keeps a tile's record ids in LDS (kernels_fuse.hip).  A tile that holds more than the buffer is walked
+    in runs of cells that fit, and a single cell with more records than the buffer goes through global memory.  With
+    ESVO_FUSE_LDS_CAP = 1 / 7 / 200 (8192 in production) those two paths carry a whole DSEC run (3 x 3 fusion, r = 20
+    regulariser): every map must equal the one the full-size buffer gives."""
+    import os
+    from esvo_amd import lib
+    p, _ = params.make_params(params.PRESETS["mapping_dsec"], dsec_rig, process_event_num=4000)
+    st = dsec_stream
+
+    def run():
+        dev = lib.Esvo(p, dsec_rig)
+        dev.ts_push_events(0, st.ev_left)
+        dev.ts_push_events(1, st.ev_right)
+        maps = []
+        for k in range(7):
+            t = st.t0_ns + 50_000_000 + k * 10_000_000
+            stamps, poses = rostime.pose_table(st.pose, t, p.bm_half_slice_thickness)
+            dev.tick_resident(t, st.pose(t), stamps, poses)
+            maps.append(dev.get_map())
+        dev.close()
+        return maps
+
+    ref = run()
+    os.environ["ESVO_FUSE_LDS_CAP"] = str(cap)
+    try:
+        got = run()
+    finally:
+        del os.environ["ESVO_FUSE_LDS_CAP"]
+    assert len(ref[-1]) > 1000
+    for a, b in zip(ref, got):
+        _same_map(a, b)
