@@ -328,15 +328,18 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
   CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_fr_table), sizeof(u32) * 2 * (3 * (size_t)h->max_frames + 1)));
   // map
   CK(dalloc(&h->d_prop, h->win_cap));
-  {  // the fusion front's tile lists (kernels_fuse.hip): 16 x 16-cell tiles
+  {  // the fusion front (kernels_fuse.hip): 16 x 16-cell tiles
     const size_t n_tiles = (size_t)((h->W + 15) / 16) * ((h->H + 15) / 16);
-    CK(dalloc(&h->d_pt_tile, h->win_cap));
-    CK(dalloc(&h->d_tile_pts, h->win_cap));
+    if (const char* et = std::getenv("ESVO_FUSE_TILE_CAP")) h->fuse_tile_cap = (u32)std::max(1L, std::atol(et));
+    CK(dalloc(&h->d_tile_pts, n_tiles * h->fuse_tile_cap));
+    CK(dalloc(&h->d_over_pts, h->win_cap));
     CK(dalloc(&h->d_tile_count, n_tiles));
-    CK(dalloc(&h->d_tile_fill, n_tiles));
-    CK(dalloc(&h->d_tile_offset, n_tiles + 1));
-    CK(hipMemset(h->d_tile_count, 0, sizeof(u32) * n_tiles));  // zero between ticks: the scan clears what it has read
-    CK(hipMemset(h->d_tile_fill, 0, sizeof(u32) * n_tiles));
+    CK(dalloc(&h->d_cell_count, npx));
+    CK(dalloc(&h->d_cell_offset, npx));
+    CK(dalloc(&h->d_cell_list, (size_t)16 * npx));
+    CK(dalloc(&h->d_fuse_ctr, 64));
+    CK(hipMemset(h->d_tile_count, 0, sizeof(u32) * n_tiles));  // zero between ticks: fuse_turn_kernel clears what was read
+    CK(hipMemset(h->d_fuse_ctr, 0, sizeof(u32) * 64));
   }
   CK(dalloc(&h->d_rec_ids, (size_t)h->win_cap * 9));
   if (const char* ef = std::getenv("ESVO_FUSE_LDS_CAP")) h->fuse_lds_cap = (u32)std::max(0L, std::atol(ef));
@@ -388,8 +391,8 @@ int esvo_destroy(esvo_handle h) {
                   h->d_ts[1], h->d_ring[0], h->d_ring[1], h->d_obs2[0][0], h->d_obs2[0][1], h->d_obs2[1][0], h->d_obs2[1][1], h->d_obs_tmp,
                   h->d_pose_T2[0], h->d_pose_T2[1], h->d_scan_tmp_b, h->d_cnt_b, h->d_tick_ev, h->d_match_slots, h->d_match_flags, h->d_match_prefix,
                   h->d_matches2[0], h->d_matches2[1], h->d_scan_tmp_l2[0], h->d_scan_tmp_l2[1], h->d_pt_slots2[0], h->d_pt_slots2[1], h->d_pt_flags2[0], h->d_pt_flags2[1], h->d_pt_prefix2[0], h->d_pt_prefix2[1], h->d_pts_tmp, h->d_stage[0], h->d_stage[1], h->d_counters2[0], h->d_counters2[1], h->d_scan_tmp,
-                  h->d_win, h->d_frame_pose_T, h->d_fr_table, h->d_prop, h->d_pt_tile, h->d_tile_pts, h->d_tile_count,
-                  h->d_tile_fill, h->d_tile_offset, h->d_rec_ids, h->d_map, h->d_map2, h->d_owner_max, h->d_owner_min, h->d_exp_flags,
+                  h->d_win, h->d_frame_pose_T, h->d_fr_table, h->d_prop, h->d_tile_pts, h->d_tile_count, h->d_over_pts,
+                  h->d_cell_count, h->d_cell_offset, h->d_cell_list, h->d_fuse_ctr, h->d_rec_ids, h->d_map, h->d_map2, h->d_owner_max, h->d_owner_min, h->d_exp_flags,
                   h->d_exp_prefix, h->d_export, h->d_export_cell, h->d_reg_ab, h->d_reg_cd, h->d_own_w, h->d_lkeep, h->d_codes,
                   h->d_sel, h->d_evmap, h->d_lm_fvec0, h->d_lm_fnorm0, h->d_lm_meta, h->d_lm_order, h->d_lm_hist, h->d_clk};
   for (void* p : ptrs) if (p) hipFree(p);
@@ -457,6 +460,7 @@ int esvo_reset(esvo_handle h) {
   HIPCHK(hipMemsetAsync(h->d_map, 0, map_buffer_bytes(npx), h->stream));
   HIPCHK(hipMemsetAsync(h->d_map2, 0, map_buffer_bytes(npx), h->stream));
   HIPCHK(hipMemsetAsync(h->d_tile_count, 0, sizeof(u32) * (size_t)((h->W + 15) / 16) * ((h->H + 15) / 16), h->stream));
+  HIPCHK(hipMemsetAsync(h->d_fuse_ctr, 0, sizeof(u32) * 64, h->stream));
   h->d_map_cur = h->d_map;
   h->obs_set = false;
   h->n_pose = 0;

@@ -325,8 +325,12 @@ int run_fuse(esvo_context* h, int par, const double* T_world_obs, bool naive) {
   a.frame_pose_T = h->d_frame_pose_T; a.max_poses = h->max_poses;
   rigid_inverse(h->T_world_frame, a.T_frame_world);
   a.prop = h->d_prop;
-  a.pt_tile = h->d_pt_tile; a.tile_count = h->d_tile_count; a.tile_fill = h->d_tile_fill; a.tile_offset = h->d_tile_offset;
-  a.tile_pts = h->d_tile_pts; a.rec_ids = h->d_rec_ids; a.overflow_cursor = h->d_cnt_b + 2; a.lds_cap = h->fuse_lds_cap; a.d_total = h->d_cnt_b + 4;
+  a.tile_count = h->d_tile_count; a.tile_pts = h->d_tile_pts; a.tile_cap = h->fuse_tile_cap;
+  a.over_pts = h->d_over_pts; a.over_count = h->d_fuse_ctr + 33;
+  a.rec_ids = h->d_rec_ids; a.rec_cursor = h->d_fuse_ctr + 32;
+  a.cell_count = h->d_cell_count; a.cell_offset = h->d_cell_offset; a.cell_list = h->d_cell_list;
+  a.class_count = h->d_fuse_ctr; a.class_total = h->d_fuse_ctr + 16;
+  a.lds_cap = h->fuse_lds_cap; a.d_total = h->d_cnt_b + 4;
   a.map = h->d_map; a.d_num_fusion = h->d_cnt_b + 3;
   a.n_touched = h->d_cnt_b + 6;
   a.naive = naive ? 1 : 0;

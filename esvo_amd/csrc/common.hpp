@@ -293,14 +293,19 @@ struct FuseArgs {
   double T_frame_world[16];     // inverse of the depth frame's pose
   // scratch (kernels_fuse.hip, "the fusion front: tiles")
   DevPoint* prop;               // [n_pts] propagated points (row == 0xffffffff: rejected)
-  u32* pt_tile;                 // [n_pts] tile of the point's centre cell (0xffffffff: rejected)
-  u32* tile_count;              // [n_tiles] points per tile; zero between ticks (tile_scan_kernel clears it after reading)
-  u32* tile_fill;               // [n_tiles]
-  u32* tile_offset;             // [n_tiles + 1]
-  u32* tile_pts;                // [n_pts] point ids grouped by tile
-  u32* rec_ids;                 // [n_pts * K] record ids of cells too long for LDS (degenerate scenes only)
-  u32* overflow_cursor;         // next free entry of rec_ids
-  u32 lds_cap;                  // record ids a tile may hold in LDS (0: the maximum; smaller values: tests)
+  u32* tile_count;              // [n_tiles] points appended per tile (may exceed tile_cap: readers clamp); zero between ticks
+  u32* tile_pts;                // [n_tiles][tile_cap] point ids of each tile
+  u32 tile_cap;
+  u32* over_pts;                // [n_pts] points whose tile list was full
+  u32* over_count;
+  u32* rec_ids;                 // [n_pts * K] record ids grouped by cell, each cell's in increasing order
+  u32* rec_cursor;              // next free entry of rec_ids (one reservation per tile)
+  u32* cell_count;              // [W*H] records of the cell
+  u32* cell_offset;             // [W*H] its first entry in rec_ids
+  u32* cell_list;               // [16][W*H] touched cells by length class
+  u32* class_count;             // [16] cells per class (being filled) / class_total: the finished figures of this tick
+  u32* class_total;
+  u32 lds_cap;                  // record ids a tile may order in LDS at a time (0: the maximum; smaller values: tests)
   u32* d_total;                 // total records (a statistic)
   MapCell* map;                 // [W*H]
   u32* d_num_fusion;            // fusion counter

@@ -65,29 +65,36 @@ enum { FUSE_TDIST = 0, FUSE_L2 = 1, FUSE_NAIVE = 2 };
 // Until round 3 every (point, cell) record went through a per-CELL counting sort in global memory: 9 device-scope atomics per
 // point on a 300 k-entry histogram, a 3-pass scan of it, 9 more atomics + a scattered 4-byte store per point, a sort kernel for
 // the long lists, then the walk -- 2 x 1.44 M atomics per tick, each a 32-byte memory-side write on this eight-XCD part
-// (profiles/r03_v3_hbm_traffic.csv: 40 MB written for 5.8 MB of ids).  Now the global sort is two-level and only the coarse
-// level touches memory:
-//   A  propagate       one thread per window point: the propagated point (as before) + ONE atomic on the counter of the
-//                      16 x 16-cell TILE its centre cell lies in, and the tile index of the point
-//   S  tile_scan       one workgroup: exclusive scan of the <= 4096 tile counters -> tile offsets; resets the counters and
-//                      the back stage's statistics (what fuse_reset did)
-//   B  tile_scatter    one thread per point: its id into its tile's list (one atomic on the tile's fill counter)
-//   T  fuse_tiles      one workgroup per tile, one thread per cell: the points of the tile and of its eight neighbours
-//                      (a 3 x 3 footprint reaches at most one tile further) are expanded to records IN LDS -- per-cell
-//                      histogram, scan and fill with LDS atomics -- each cell's list is put in id order in LDS, and the
-//                      cell's thread walks it with the reference's state machine.  No record id ever reaches memory.
+// (profiles/r03_v3_hbm_traffic.csv: 40 MB written for 5.8 MB of ids), in 8 launches.  Now the sort is two-level and only the
+// coarse level uses global atomics, ONE per point:
+//   A  propagate    one thread per window point: the propagated point (as before) and its id appended to the list of the
+//                   16 x 16-cell TILE its centre cell lies in (fixed-capacity lists; a point that finds its list full goes
+//                   to one shared overflow list -- dense scenes only, every tile then looks through it)
+//   T  tile_lists   one workgroup per tile, one thread per cell: the points of the tile and of its eight neighbours (a
+//                   3 x 3 footprint reaches at most one tile further) are expanded to records IN LDS -- per-cell histogram,
+//                   scan and fill with LDS atomics -- and each cell's list is put in id order there; the lists leave the chip
+//                   once, as full lines (one reservation per tile), with each cell's (offset, count), and the touched cells are
+//                   appended to sixteen length classes (one reservation per tile and class)
+//   W  fuse_cells   one thread per touched cell, longest lists first (waves of uniform length): the reference's state machine
 // Order: a cell's records are applied in increasing id q K + k exactly as before (the lists are sorted, whatever order the
 // atomics produced), so every map element keeps its bits.
-// Capacity: the tile's records stay in LDS up to `cap` ids; a denser tile is processed in runs of consecutive cells that fit,
-// and a single cell with more records than `cap` (a degenerate scene) takes a slow serial path from global memory
-// (FuseArgs::rec_ids).  ESVO_FUSE_LDS_CAP (read at esvo_create) forces small capacities in the tests.
+// Capacity: a tile's records are ordered in LDS up to `cap` ids at a time; a denser tile is handled in runs of consecutive
+// cells that fit, and a single cell with more records than `cap` (a degenerate scene) is ordered in global memory by one
+// thread.  ESVO_FUSE_LDS_CAP / ESVO_FUSE_TILE_CAP (read at esvo_create) force small capacities in the tests.
 #define FT 16                      // tile edge in cells
 #define FT_CELLS (FT * FT)
-#define FUSE_LDS_CAP_MAX 8192      // record ids per tile in LDS (32 KB)
-#define FUSE_SORT_TMP 1024         // per-wave scratch of the cooperative sort of long lists
+#define FUSE_LDS_CAP_MAX 6144      // record ids per run in LDS (24 KB)
+#define FUSE_SORT_TMP 512          // per-wave scratch of the cooperative sort of long lists
+#define FUSE_NB 16                 // length classes of the touched cells
 
 __host__ __device__ inline int fuse_tiles_x(int W) { return (W + FT - 1) / FT; }
 __host__ __device__ inline int fuse_tiles_y(int H) { return (H + FT - 1) / FT; }
+// class = ceil(log2(n)): lists in a wave differ by at most 2x while cells stay in tile order inside a class, which keeps the
+// propagated points they share in L1 / L2
+__device__ inline u32 fuse_bucket(u32 n) {  // n >= 1: 1->0, 2->1, 3..4->2, 5..8->3, ...
+  const u32 b = (n <= 1u) ? 0u : 32u - (u32)__builtin_clz(n - 1u);
+  return b < FUSE_NB - 1u ? b : FUSE_NB - 1u;
+}
 
 template <int MODEL>
 __global__ void __launch_bounds__(256, BACK_WAVES) propagate_kernel(FuseArgs a, DevParams p, int K) {
@@ -116,7 +123,6 @@ __global__ void __launch_bounds__(256, BACK_WAVES) propagate_kernel(FuseArgs a, 
     prop.row = 0xffffffffu;
     prop.col = 0;
     a.prop[q] = prop;
-    a.pt_tile[q] = 0xffffffffu;
     return;
   }
   prop.row = (u32)(size_t)floor(v);
@@ -150,50 +156,9 @@ __global__ void __launch_bounds__(256, BACK_WAVES) propagate_kernel(FuseArgs a, 
   a.prop[q] = prop;
   (void)K;
   const u32 tile = (prop.row / FT) * (u32)fuse_tiles_x(p.W) + prop.col / FT;
-  a.pt_tile[q] = tile;
-  atomicAdd(&a.tile_count[tile], 1u);
-}
-
-// S: exclusive scan of the tile counters (one workgroup; n_tiles <= 16 k for a 4 M-pixel image), counters cleared for the
-// next tick, the back stage's statistics cleared for this one
-__global__ void __launch_bounds__(1024) tile_scan_kernel(FuseArgs a, int n_tiles) {
-  __shared__ u32 lds[1024 / ESVO_WAVE];
-  u32 carry = 0;
-  for (int base = 0; base < n_tiles; base += 1024 * 4) {
-    u32 v[4], sum = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int i = base + (int)threadIdx.x * 4 + k;
-      v[k] = i < n_tiles ? a.tile_count[i] : 0u;
-      sum += v[k];
-    }
-    u32 tot;
-    u32 ex = block_excl_scan<1024 / ESVO_WAVE>(sum, &tot, lds) + carry;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int i = base + (int)threadIdx.x * 4 + k;
-      if (i < n_tiles) { a.tile_offset[i] = ex; a.tile_count[i] = 0u; a.tile_fill[i] = 0u; }
-      ex += v[k];
-    }
-    carry += tot;
-  }
-  if (threadIdx.x == 0) {
-    a.tile_offset[n_tiles] = carry;
-    *a.d_num_fusion = 0;
-    *a.d_total = 0;
-    *a.n_touched = 0;
-    *a.overflow_cursor = 0;
-    if (a.n_reg_elems) *a.n_reg_elems = 0;
-  }
-}
-
-// B: the point ids, grouped by tile
-__global__ void __launch_bounds__(256) tile_scatter_kernel(FuseArgs a) {
-  const u32 q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= a.n_pts) return;
-  const u32 tile = a.pt_tile[q];
-  if (tile == 0xffffffffu) return;
-  a.tile_pts[a.tile_offset[tile] + atomicAdd(&a.tile_fill[tile], 1u)] = q;
+  const u32 pos = atomicAdd(&a.tile_count[tile], 1u);
+  if (pos < a.tile_cap) a.tile_pts[(size_t)tile * a.tile_cap + pos] = q;
+  else a.over_pts[atomicAdd(a.over_count, 1u)] = q;  // the tile's list is full (tile_count keeps counting: the reader clamps)
 }
 
 // DepthPoint::update_studentT, DepthPoint.cpp:167-188
@@ -283,16 +248,16 @@ __device__ inline void fuse_record(const DevParams& p, MapCell& c, bool& exists,
   }
 }
 
-// T: one workgroup per tile, one thread per cell
-template <int MODEL>
-__global__ void __launch_bounds__(FT_CELLS, 2) fuse_tiles_kernel(FuseArgs a, DevParams p, int K, u32 cap) {
-  __shared__ u32 s_cnt[FT_CELLS];        // records per cell of the tile (whole tile, set once)
+// T: one workgroup per tile, one thread per cell -- the cells' sorted record lists
+__global__ void __launch_bounds__(FT_CELLS, 4) tile_lists_kernel(FuseArgs a, DevParams p, int K, int radius, u32 cap) {
+  __shared__ u32 s_cnt[FT_CELLS];        // records per cell of the tile
   __shared__ u32 s_off[FT_CELLS + 1];    // their exclusive scan
   __shared__ u32 s_fill[FT_CELLS];
   __shared__ u32 s_ids[FUSE_LDS_CAP_MAX];
   __shared__ u32 s_tmp[FT_CELLS / ESVO_WAVE][FUSE_SORT_TMP];
   __shared__ u32 s_scan[FT_CELLS / ESVO_WAVE];
-  __shared__ u32 s_red[2];
+  __shared__ u32 s_hist[FUSE_NB], s_hbase[FUSE_NB];
+  __shared__ u32 s_gbase;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int tiles_x = fuse_tiles_x(p.W), tiles_y = fuse_tiles_y(p.H);
   const int tx = (int)(blockIdx.x % tiles_x), ty = (int)(blockIdx.x / tiles_x);
@@ -302,15 +267,26 @@ __global__ void __launch_bounds__(FT_CELLS, 2) fuse_tiles_kernel(FuseArgs a, Dev
   const bool in_img = crow < p.H && ccol < p.W;
   const bool in_band = in_img && crow >= p.cband_y0 && crow < p.cband_y1;
   const int cell = crow * p.W + ccol;
-  const int radius = MODEL == FUSE_NAIVE ? 0 : p.fusion_radius;
   s_cnt[tid] = 0;
   s_fill[tid] = 0;
-  if (tid < 2) s_red[tid] = 0;
+  if (tid < FUSE_NB) s_hist[tid] = 0;
   // what fuse_reset cleared per cell: the regulariser's owner marks (reg_view re-creates them by atomics)
   if (in_img && a.owner_max) { a.owner_max[cell] = 0; a.owner_min[cell] = 0xffffffffu; }
   __syncthreads();
-  // the candidate points: this tile's and its neighbours' lists; expand(fn) calls fn(local cell, record id) for every record
-  // of a cell of this tile (inside the compute band)
+  // one candidate point: fn(local cell, record id) for each of its records that lies in a cell of this tile (inside the
+  // compute band)
+  auto records_of = [&](u32 q, auto&& fn) {
+    const u32 prow = a.prop[q].row, pcol = a.prop[q].col;
+    for (int k = 0; k < K; ++k) {
+      int row, col;
+      if (!fusion_cell(prow, pcol, k, radius, p.W, p.H, row, col)) continue;
+      if (row < r0 || row >= r0 + FT || col < c0 || col >= c0 + FT) continue;
+      if (row < p.cband_y0 || row >= p.cband_y1) continue;
+      fn((row - r0) * FT + (col - c0), q * (u32)K + (u32)k);
+    }
+  };
+  // the candidate points: this tile's and its neighbours' lists, and whatever overflowed its list anywhere
+  const u32 n_over = *a.over_count;
   auto expand = [&](auto&& fn) {
     for (int dy = -1; dy <= 1; ++dy) {
       const int ny = ty + dy;
@@ -319,20 +295,13 @@ __global__ void __launch_bounds__(FT_CELLS, 2) fuse_tiles_kernel(FuseArgs a, Dev
         const int nx = tx + dx;
         if (nx < 0 || nx >= tiles_x) continue;
         const int nt = ny * tiles_x + nx;
-        const u32 b0 = a.tile_offset[nt], b1 = a.tile_offset[nt + 1];
-        for (u32 i = b0 + (u32)tid; i < b1; i += FT_CELLS) {
-          const u32 q = a.tile_pts[i];
-          const u32 prow = a.prop[q].row, pcol = a.prop[q].col;
-          for (int k = 0; k < K; ++k) {
-            int row, col;
-            if (!fusion_cell(prow, pcol, k, radius, p.W, p.H, row, col)) continue;
-            if (row < r0 || row >= r0 + FT || col < c0 || col >= c0 + FT) continue;
-            if (row < p.cband_y0 || row >= p.cband_y1) continue;
-            fn((row - r0) * FT + (col - c0), q * (u32)K + (u32)k);
-          }
-        }
+        u32 cnt = a.tile_count[nt];
+        if (cnt > a.tile_cap) cnt = a.tile_cap;
+        const u32* list = a.tile_pts + (size_t)nt * a.tile_cap;
+        for (u32 i = (u32)tid; i < cnt; i += FT_CELLS) records_of(list[i], fn);
       }
     }
+    for (u32 i = (u32)tid; i < n_over; i += FT_CELLS) records_of(a.over_pts[i], fn);
   };
   expand([&](int lc, u32) { atomicAdd(&s_cnt[lc], 1u); });
   __syncthreads();
@@ -341,22 +310,31 @@ __global__ void __launch_bounds__(FT_CELLS, 2) fuse_tiles_kernel(FuseArgs a, Dev
     u32 tot;
     const u32 ex = block_excl_scan<FT_CELLS / ESVO_WAVE>(n, &tot, s_scan);
     s_off[tid] = ex;
-    if (tid == 0) s_off[FT_CELLS] = tot;
+    if (tid == 0) {
+      s_off[FT_CELLS] = tot;
+      s_gbase = tot ? atomicAdd(a.rec_cursor, tot) : 0u;   // the tile's lists, contiguous in rec_ids
+    }
   }
+  // the touched cells by length class: rank inside the tile, one reservation per class
+  u32 rank = 0, bk = 0;
+  if (n > 0) { bk = fuse_bucket(n); rank = atomicAdd(&s_hist[bk], 1u); }
   __syncthreads();
   const u32 total = s_off[FT_CELLS];
-  if (total == 0) {  // nothing lands here: the band's cells read empty
-    if (in_band) map_flags(a.map, ncell)[cell] = 0;
-    return;
+  if (tid < FUSE_NB && s_hist[tid]) s_hbase[tid] = atomicAdd(&a.class_count[tid], s_hist[tid]);
+  if (in_band) {
+    a.cell_count[cell] = n;
+    if (n == 0) map_flags(a.map, ncell)[cell] = 0;  // nothing lands here: the cell reads empty
   }
-  MapCell c;
-  bool exists = false;
-  u32 numFusion = 0;
+  if (total == 0) return;  // (block-uniform)
+  const u32 gbase = s_gbase;
+  if (n > 0) a.cell_offset[cell] = gbase + s_off[tid];
+  __syncthreads();
+  if (n > 0) a.cell_list[(size_t)bk * ncell + s_hbase[bk] + rank] = (u32)cell;
+  u32* gout = a.rec_ids + gbase;
   // runs of consecutive cells whose records fit the LDS buffer together
   u32 run0 = 0;
   while (run0 < FT_CELLS) {
-    // (every thread derives the same run: s_off is complete)
-    u32 run1 = run0 + 1;
+    u32 run1 = run0 + 1;  // (every thread derives the same run: s_off is complete)
     while (run1 < FT_CELLS && s_off[run1 + 1] - s_off[run0] <= cap) ++run1;
     const u32 base = s_off[run0];
     const u32 run_n = s_off[run1] - base;
@@ -387,9 +365,9 @@ __global__ void __launch_bounds__(FT_CELLS, 2) fuse_tiles_kernel(FuseArgs a, Dev
         if (ln <= FUSE_SORT_TMP) {
           for (u32 i = (u32)lane; i < ln; i += ESVO_WAVE) {
             const u32 vkey = lid[i];
-            u32 rank = 0;
-            for (u32 j = 0; j < ln; ++j) rank += (lid[j] < vkey);
-            s_tmp[wv][rank] = vkey;
+            u32 rk = 0;
+            for (u32 j = 0; j < ln; ++j) rk += (lid[j] < vkey);
+            s_tmp[wv][rk] = vkey;
           }
           // (one wave: its LDS operations execute in program order; the barrier only keeps the compiler from moving them)
           __builtin_amdgcn_wave_barrier();
@@ -404,28 +382,14 @@ __global__ void __launch_bounds__(FT_CELLS, 2) fuse_tiles_kernel(FuseArgs a, Dev
           }
         }
       }
-      // ---- walk ----
-      if (mine) {
-        u32 id_nxt = ids[0];
-        DevPoint nxt = a.prop[id_nxt / (u32)K];
-        for (u32 i = 0; i < n; ++i) {
-          const u32 id = id_nxt;
-          const DevPoint prop = nxt;
-          if (i + 1 < n) {  // software prefetch: the next record does not depend on the cell state
-            id_nxt = ids[i + 1];
-            nxt = a.prop[id_nxt / (u32)K];
-          }
-          fuse_record<MODEL>(p, c, exists, numFusion, prop, id, crow, ccol);
-        }
-      }
+      __syncthreads();
+      // ---- out: the run's lists as they lie in LDS (full lines) ----
+      for (u32 i = (u32)tid; i < run_n; i += FT_CELLS) gout[base + i] = s_ids[i];
       __syncthreads();  // the buffer is reused by the next run
     } else {
-      // ---- a single cell with more records than the LDS buffer holds: through global memory, by its own thread ----
-      // (run1 == run0 + 1 here.)  The whole workgroup fills the cell's segment of rec_ids, then its thread orders and walks it.
-      __shared__ u32 s_gbase;
-      if (tid == 0) s_gbase = atomicAdd(a.overflow_cursor, run_n);
-      __syncthreads();
-      u32* gids = a.rec_ids + s_gbase;
+      // ---- a single cell with more records than the LDS buffer holds (run1 == run0 + 1): filled straight into its segment
+      // of rec_ids by the whole workgroup, ordered there by its own thread ----
+      u32* gids = gout + base;
       expand([&](int lc, u32 id) {
         if ((u32)lc == run0) gids[atomicAdd(&s_fill[lc], 1u)] = id;
       });
@@ -438,38 +402,90 @@ __global__ void __launch_bounds__(FT_CELLS, 2) fuse_tiles_kernel(FuseArgs a, Dev
           while (j >= 0 && gids[j] > key) { gids[j + 1] = gids[j]; --j; }
           gids[j + 1] = key;
         }
-        for (u32 i = 0; i < n; ++i) {
-          const u32 id = gids[i];
-          const DevPoint prop = a.prop[id / (u32)K];
-          fuse_record<MODEL>(p, c, exists, numFusion, prop, id, crow, ccol);
-        }
       }
       __syncthreads();
     }
     run0 = run1;
   }
-  if (in_band) {
-    if (n > 0) {
-      a.map[cell] = c;
-      map_flags(a.map, ncell)[cell] = CELL_ALIVE | CELL_GRID;
-    } else {
-      map_flags(a.map, ncell)[cell] = 0;
-    }
+}
+
+// W: one thread per touched cell, the longest lists first: walk the cell's (sorted) records (DepthFusion::fusion).  The first
+// threads also clear the fusion front's counters for the next tick (the tile kernel has read them).
+#ifndef FUSE_BLOCK
+#define FUSE_BLOCK 256
+#endif
+template <int MODEL>
+__global__ void __launch_bounds__(FUSE_BLOCK, FUSE_WAVES) fuse_cells_kernel(FuseArgs a, DevParams p, int K, int n_tiles) {
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int ncell = p.W * p.H;
+  // thread t -> the t-th touched cell in the order "longest class first" (class_total: fuse_turn_kernel)
+  u32 cum = 0, bsel = FUSE_NB;
+  u32 idx = 0;
+#pragma unroll
+  for (int b = FUSE_NB - 1; b >= 0; --b) {
+    const u32 c = a.class_total[b];
+    if (bsel == FUSE_NB && t < cum + c) { bsel = (u32)b; idx = t - cum; }
+    cum += c;
   }
-  // statistics: fusions, touched cells (one atomic per workgroup each), records
-  if (numFusion) atomicAdd(&s_red[0], numFusion);
-  if (n > 0) atomicAdd(&s_red[1], 1u);
-  __syncthreads();
-  if (tid == 0) {
-    if (s_red[0]) atomicAdd(a.d_num_fusion, s_red[0]);
-    atomicAdd(a.n_touched, s_red[1]);
-    atomicAdd(a.d_total, total);
+  if (bsel == FUSE_NB) return;
+  const int cell = (int)a.cell_list[(size_t)bsel * ncell + idx];
+  const int crow = cell / p.W, ccol = cell - crow * p.W;
+  const u32 n = a.cell_count[cell];
+  const u32* ids = a.rec_ids + a.cell_offset[cell];
+  MapCell c;
+  bool exists = false;
+  u32 numFusion = 0;
+#ifndef FUSE_NO_PREFETCH
+  u32 id_nxt = ids[0];
+  DevPoint nxt = a.prop[id_nxt / (u32)K];
+#endif
+  for (u32 i = 0; i < n; ++i) {
+#ifndef FUSE_NO_PREFETCH
+    const u32 id = id_nxt;
+    const DevPoint prop = nxt;
+    if (i + 1 < n) {  // software prefetch: the next record does not depend on the cell state
+      id_nxt = ids[i + 1];
+      nxt = a.prop[id_nxt / (u32)K];
+    }
+#else
+    const u32 id = ids[i];
+    const DevPoint prop = a.prop[id / (u32)K];
+#endif
+    fuse_record<MODEL>(p, c, exists, numFusion, prop, id, crow, ccol);
+  }
+  a.map[cell] = c;
+  map_flags(a.map, ncell)[cell] = CELL_ALIVE | CELL_GRID;
+  if (numFusion) atomicAdd(a.d_num_fusion, numFusion);
+  (void)n_tiles;
+}
+
+// between T and W (one thread): the class sizes become read-only totals, every counter of the front is cleared for the next
+// tick, the statistics of this one are cleared / set
+__global__ void __launch_bounds__(256) fuse_turn_kernel(FuseArgs a, int n_tiles) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_tiles) a.tile_count[i] = 0;
+  if (i == 0) {
+    u32 tot = 0;
+    for (int b = 0; b < FUSE_NB; ++b) {
+      const u32 c = a.class_count[b];
+      a.class_total[b] = c;
+      a.class_count[b] = 0;
+      tot += c;
+    }
+    *a.n_touched = tot;
+    *a.d_total = *a.rec_cursor;
+    *a.rec_cursor = 0;
+    *a.over_count = 0;
+    *a.d_num_fusion = 0;
+    if (a.n_reg_elems) *a.n_reg_elems = 0;
   }
 }
 
 void launch_fuse(const FuseArgs& a, const DevParams& p, hipStream_t s) {
+  const int ncell = p.W * p.H;
   const int model = a.naive ? FUSE_NAIVE : (p.ls_norm == ESVO_LSNORM_L2 ? FUSE_L2 : FUSE_TDIST);
   const int K = (model == FUSE_NAIVE || p.fusion_radius == 0) ? 4 : 9;
+  const int radius = model == FUSE_NAIVE ? 0 : p.fusion_radius;
   const int n_tiles = fuse_tiles_x(p.W) * fuse_tiles_y(p.H);
   if (a.n_pts) {
     const dim3 g((a.n_pts + 255) / 256), b(256);
@@ -477,14 +493,14 @@ void launch_fuse(const FuseArgs& a, const DevParams& p, hipStream_t s) {
     else if (model == FUSE_L2) hipLaunchKernelGGL(propagate_kernel<FUSE_L2>, g, b, 0, s, a, p, K);
     else hipLaunchKernelGGL(propagate_kernel<FUSE_NAIVE>, g, b, 0, s, a, p, K);
   }
-  hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, a, n_tiles);
-  if (a.n_pts) hipLaunchKernelGGL(tile_scatter_kernel, dim3((a.n_pts + 255) / 256), dim3(256), 0, s, a);
+  const u32 cap = (a.lds_cap >= 1 && a.lds_cap <= FUSE_LDS_CAP_MAX) ? a.lds_cap : FUSE_LDS_CAP_MAX;
+  hipLaunchKernelGGL(tile_lists_kernel, dim3(n_tiles), dim3(FT_CELLS), 0, s, a, p, K, radius, cap);
+  hipLaunchKernelGGL(fuse_turn_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, s, a, n_tiles);
   {
-    const dim3 g(n_tiles), b(FT_CELLS);
-    const u32 cap = (a.lds_cap >= 1 && a.lds_cap <= FUSE_LDS_CAP_MAX) ? a.lds_cap : FUSE_LDS_CAP_MAX;
-    if (model == FUSE_TDIST) hipLaunchKernelGGL(fuse_tiles_kernel<FUSE_TDIST>, g, b, 0, s, a, p, K, cap);
-    else if (model == FUSE_L2) hipLaunchKernelGGL(fuse_tiles_kernel<FUSE_L2>, g, b, 0, s, a, p, K, cap);
-    else hipLaunchKernelGGL(fuse_tiles_kernel<FUSE_NAIVE>, g, b, 0, s, a, p, K, cap);
+    const dim3 g((ncell + FUSE_BLOCK - 1) / FUSE_BLOCK), b(FUSE_BLOCK);
+    if (model == FUSE_TDIST) hipLaunchKernelGGL(fuse_cells_kernel<FUSE_TDIST>, g, b, 0, s, a, p, K, n_tiles);
+    else if (model == FUSE_L2) hipLaunchKernelGGL(fuse_cells_kernel<FUSE_L2>, g, b, 0, s, a, p, K, n_tiles);
+    else hipLaunchKernelGGL(fuse_cells_kernel<FUSE_NAIVE>, g, b, 0, s, a, p, K, n_tiles);
   }
 }
 

@@ -455,7 +455,7 @@ def test_async_pinned_ingest_gives_the_same_maps(upenn_rig, upenn_stream):
     tick that follows is launched at once -- the device orders it behind the copy.  Tick by tick (each tick's events staged
     one tick ahead, in a ring that wraps) the maps must equal those of the synchronous push of the same blocks."""
     from esvo_amd import lib
-    p, _ = params.make_params(params.PRESETS["mapping_upenn"], upenn_rig, event_ring_capacity=32768)
+    p, _ = params.make_params(params.PRESETS["mapping_upenn"], upenn_rig, event_ring_capacity=1 << 17)
     st = upenn_stream
     t0 = st.t0_ns + 60_000_000
     ticks = [t0 + k * 10_000_000 for k in range(8)]
@@ -491,12 +491,13 @@ def test_async_pinned_ingest_gives_the_same_maps(upenn_rig, upenn_stream):
         _same_map(a, b)
 
 
-@pytest.mark.parametrize("cap", [1, 7, 200])
-def test_fusion_front_with_tiny_lds_capacity_gives_the_same_maps(dsec_rig, dsec_stream, cap):
-    """The fusion front keeps a tile's record ids in LDS (kernels_fuse.hip).  A tile that holds more than the buffer is walked
-    in runs of cells that fit, and a single cell with more records than the buffer goes through global memory.  With
-    ESVO_FUSE_LDS_CAP = 1 / 7 / 200 (8192 in production) those two paths carry a whole DSEC run (3 x 3 fusion, r = 20
-    regulariser): every map must equal the one the full-size buffer gives."""
+@pytest.mark.parametrize("cap,tile_cap", [(1, 0), (7, 0), (200, 0), (0, 5), (3, 1)])
+def test_fusion_front_with_tiny_capacities_gives_the_same_maps(dsec_rig, dsec_stream, cap, tile_cap):
+    """The fusion front orders a tile's record ids in LDS (kernels_fuse.hip).  A tile that holds more than the buffer is
+    handled in runs of cells that fit, and a single cell with more records than the buffer is ordered in global memory; a
+    point that finds its tile's (fixed-capacity) list full goes to the shared overflow list every tile looks through.  With
+    ESVO_FUSE_LDS_CAP = 1 / 7 / 200 (6144 in production) and ESVO_FUSE_TILE_CAP = 5 / 1 (4096) those paths carry a whole DSEC
+    run (3 x 3 fusion, r = 20 regulariser): every map must equal the one the full-size buffers give."""
     import os
     from esvo_amd import lib
     p, _ = params.make_params(params.PRESETS["mapping_dsec"], dsec_rig, process_event_num=4000)
@@ -516,11 +517,13 @@ def test_fusion_front_with_tiny_lds_capacity_gives_the_same_maps(dsec_rig, dsec_
         return maps
 
     ref = run()
-    os.environ["ESVO_FUSE_LDS_CAP"] = str(cap)
+    env = {k: str(v) for k, v in (("ESVO_FUSE_LDS_CAP", cap), ("ESVO_FUSE_TILE_CAP", tile_cap)) if v}
+    os.environ.update(env)
     try:
         got = run()
     finally:
-        del os.environ["ESVO_FUSE_LDS_CAP"]
+        for k in env:
+            del os.environ[k]
     assert len(ref[-1]) > 1000
     for a, b in zip(ref, got):
         _same_map(a, b)
