@@ -328,20 +328,23 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
   CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_fr_table), sizeof(u32) * 2 * (3 * (size_t)h->max_frames + 1)));
   // map
   CK(dalloc(&h->d_prop, h->win_cap));
-  {  // the fusion front (kernels_fuse.hip): 16 x 16-cell tiles
-    const size_t n_tiles = (size_t)((h->W + 15) / 16) * ((h->H + 15) / 16);
+  {  // the fusion front (kernels_fuse.hip): FUSE_TILE x FUSE_TILE-cell tiles
+    const size_t n_tiles = (size_t)((h->W + FUSE_TILE - 1) / FUSE_TILE) * ((h->H + FUSE_TILE - 1) / FUSE_TILE);
     if (const char* et = std::getenv("ESVO_FUSE_TILE_CAP")) h->fuse_tile_cap = (u32)std::max(1L, std::atol(et));
+    if (const char* ep = std::getenv("ESVO_FUSE_PMAX")) h->fuse_pmax_plus1 = (u32)std::max(0L, std::atol(ep)) + 1u;
     CK(dalloc(&h->d_tile_pts, n_tiles * h->fuse_tile_cap));
     CK(dalloc(&h->d_over_pts, h->win_cap));
     CK(dalloc(&h->d_tile_count, n_tiles));
     CK(dalloc(&h->d_cell_count, npx));
     CK(dalloc(&h->d_cell_offset, npx));
-    CK(dalloc(&h->d_cell_list, (size_t)16 * npx));
-    CK(dalloc(&h->d_fuse_ctr, 64));
+    h->fuse_slice_cap = (u32)((n_tiles + 63) / 64) * FUSE_TILE * FUSE_TILE;   // the cells of the tiles t with t % 64 == slice
+    CK(dalloc(&h->d_cell_list, (size_t)16 * 64 * h->fuse_slice_cap));
+    CK(dalloc(&h->d_fuse_ctr, 2112 + 64));
     CK(hipMemset(h->d_tile_count, 0, sizeof(u32) * n_tiles));  // zero between ticks: fuse_turn_kernel clears what was read
-    CK(hipMemset(h->d_fuse_ctr, 0, sizeof(u32) * 64));
+    CK(hipMemset(h->d_fuse_ctr, 0, sizeof(u32) * (2112 + 64)));
+    if (const char* er = std::getenv("ESVO_FUSE_TILE_REC")) h->fuse_tile_rec = (u32)std::max(1L, std::atol(er));
+    CK(dalloc(&h->d_rec_ids, n_tiles * h->fuse_tile_rec + (size_t)h->win_cap * 9));
   }
-  CK(dalloc(&h->d_rec_ids, (size_t)h->win_cap * 9));
   if (const char* ef = std::getenv("ESVO_FUSE_LDS_CAP")) h->fuse_lds_cap = (u32)std::max(0L, std::atol(ef));
   CK(hipMalloc(reinterpret_cast<void**>(&h->d_map), map_buffer_bytes(npx)));  // cells + their dense flags (common.hpp: map_flags)
   CK(hipMalloc(reinterpret_cast<void**>(&h->d_map2), map_buffer_bytes(npx)));  // cells + their dense flags (common.hpp: map_flags)
@@ -381,6 +384,34 @@ int esvo_destroy(esvo_handle h) {
   if (std::getenv("ESVO_POLICY_PRINT"))
     fprintf(stderr, "[esvo] LM layout policy: wide %.4f ms (%u ticks), pair %.4f ms (%u ticks); LM queues: lm %.4f ms, back %.4f ms, two %d\n",
             h->lm_pair_ms[0][0], h->lm_pair_n[0], h->lm_pair_ms[1][0], h->lm_pair_n[1], h->ema_lm_ms, h->ema_back_ms, (int)h->lm_two_on);
+  if (std::getenv("ESVO_FUSE_STATS") && h->d_over_pts) {  // -DFUSE_STATS builds only: per-tile phase cycles of the last tile_lists launch
+    hipDeviceSynchronize();
+    const size_t nt = (size_t)((h->W + FUSE_TILE - 1) / FUSE_TILE) * ((h->H + FUSE_TILE - 1) / FUSE_TILE);
+    std::vector<unsigned long long> st(nt * 8);
+    hipMemcpy(st.data(), h->d_over_pts, st.size() * 8, hipMemcpyDeviceToHost);
+    double sum[5] = {0, 0, 0, 0, 0};
+    unsigned long long tmin = ~0ull, tmax = 0;
+    std::vector<std::pair<unsigned long long, size_t>> tot;
+    for (size_t t = 0; t < nt; ++t) {
+      unsigned long long s5 = 0;
+      for (int i = 0; i < 5; ++i) { sum[i] += (double)st[t * 8 + i]; s5 += st[t * 8 + i]; }
+      tot.emplace_back(s5, t);
+      tmin = std::min(tmin, st[t * 8 + 7]);
+      tmax = std::max(tmax, st[t * 8 + 7] + s5);
+    }
+    std::sort(tot.begin(), tot.end());
+    fprintf(stderr, "[esvo] tile kernel: %zu tiles, span %llu cycles; mean cycles gather %.0f sort %.0f mark %.0f meta %.0f emit %.0f; wave life median %llu p99 %llu max %llu\n",
+            nt, tmax - tmin, sum[0] / nt, sum[1] / nt, sum[2] / nt, sum[3] / nt, sum[4] / nt, tot[nt / 2].first, tot[nt * 99 / 100].first, tot[nt - 1].first);
+    for (int k = 1; k <= 4; ++k) {
+      const size_t t = tot[nt - k].second;
+      fprintf(stderr, "[esvo]   slow tile %zu: P %llu C %llu start +%llu phases %llu %llu %llu %llu %llu\n", t, st[t * 8 + 5], st[t * 8 + 6], st[t * 8 + 7] - tmin,
+              st[t * 8], st[t * 8 + 1], st[t * 8 + 2], st[t * 8 + 3], st[t * 8 + 4]);
+    }
+    // start-time histogram: how many waves started in each tenth of the span
+    unsigned hist[10] = {0};
+    for (size_t t = 0; t < nt; ++t) hist[std::min<size_t>(9, (size_t)((st[t * 8 + 7] - tmin) * 10 / std::max<unsigned long long>(tmax - tmin, 1)))]++;
+    fprintf(stderr, "[esvo]   wave starts per tenth of the span: %u %u %u %u %u %u %u %u %u %u\n", hist[0], hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7], hist[8], hist[9]);
+  }
   if (h->stream) hipStreamSynchronize(h->stream);
   if (h->stream_l) hipStreamSynchronize(h->stream_l);
   if (h->stream_l1) hipStreamSynchronize(h->stream_l1);
@@ -459,8 +490,8 @@ int esvo_reset(esvo_handle h) {
   std::fill(h->slot_used.begin(), h->slot_used.end(), 0);
   HIPCHK(hipMemsetAsync(h->d_map, 0, map_buffer_bytes(npx), h->stream));
   HIPCHK(hipMemsetAsync(h->d_map2, 0, map_buffer_bytes(npx), h->stream));
-  HIPCHK(hipMemsetAsync(h->d_tile_count, 0, sizeof(u32) * (size_t)((h->W + 15) / 16) * ((h->H + 15) / 16), h->stream));
-  HIPCHK(hipMemsetAsync(h->d_fuse_ctr, 0, sizeof(u32) * 64, h->stream));
+  HIPCHK(hipMemsetAsync(h->d_tile_count, 0, sizeof(u32) * (size_t)((h->W + FUSE_TILE - 1) / FUSE_TILE) * ((h->H + FUSE_TILE - 1) / FUSE_TILE), h->stream));
+  HIPCHK(hipMemsetAsync(h->d_fuse_ctr, 0, sizeof(u32) * 2112, h->stream));
   h->d_map_cur = h->d_map;
   h->obs_set = false;
   h->n_pose = 0;

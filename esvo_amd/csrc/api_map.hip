@@ -326,11 +326,11 @@ int run_fuse(esvo_context* h, int par, const double* T_world_obs, bool naive) {
   rigid_inverse(h->T_world_frame, a.T_frame_world);
   a.prop = h->d_prop;
   a.tile_count = h->d_tile_count; a.tile_pts = h->d_tile_pts; a.tile_cap = h->fuse_tile_cap;
-  a.over_pts = h->d_over_pts; a.over_count = h->d_fuse_ctr + 33;
-  a.rec_ids = h->d_rec_ids; a.rec_cursor = h->d_fuse_ctr + 32;
-  a.cell_count = h->d_cell_count; a.cell_offset = h->d_cell_offset; a.cell_list = h->d_cell_list;
-  a.class_count = h->d_fuse_ctr; a.class_total = h->d_fuse_ctr + 16;
-  a.lds_cap = h->fuse_lds_cap; a.d_total = h->d_cnt_b + 4;
+  a.over_pts = h->d_over_pts; a.over_count = h->d_fuse_ctr + 2081;
+  a.rec_ids = h->d_rec_ids; a.tile_rec = h->fuse_tile_rec; a.rec_cursor = h->d_fuse_ctr + 2080;
+  a.cell_count = h->d_cell_count; a.cell_offset = h->d_cell_offset; a.cell_list = h->d_cell_list; a.slice_cap = h->fuse_slice_cap;
+  a.class_count = h->d_fuse_ctr; a.class_total = h->d_fuse_ctr + 1024;
+  a.lds_cap = h->fuse_lds_cap; a.pmax_plus1 = h->fuse_pmax_plus1; a.d_total = h->d_cnt_b + 4;
   a.map = h->d_map; a.d_num_fusion = h->d_cnt_b + 3;
   a.n_touched = h->d_cnt_b + 6;
   a.naive = naive ? 1 : 0;

@@ -279,6 +279,7 @@ void launch_compact_points(const DevPoint* slots, const u32* flags, const u32* p
                            u32 max_n, DevPoint* out, hipStream_t s);
 
 // kernels_fuse.hip
+#define FUSE_TILE 8   // the fusion front sorts per FUSE_TILE x FUSE_TILE-cell tile
 struct FuseArgs {
   const DevPoint* win;          // window point ring
   // frames in FUSION order (newest -> oldest): point q belongs to frame f with
@@ -294,18 +295,21 @@ struct FuseArgs {
   // scratch (kernels_fuse.hip, "the fusion front: tiles")
   DevPoint* prop;               // [n_pts] propagated points (row == 0xffffffff: rejected)
   u32* tile_count;              // [n_tiles] points appended per tile (may exceed tile_cap: readers clamp); zero between ticks
-  u32* tile_pts;                // [n_tiles][tile_cap] point ids of each tile
+  uint2* tile_pts;              // [n_tiles][tile_cap] the points of each tile: (id, row << 16 | col)
   u32 tile_cap;
-  u32* over_pts;                // [n_pts] points whose tile list was full
+  uint2* over_pts;              // [n_pts] points whose tile list was full
   u32* over_count;
-  u32* rec_ids;                 // [n_pts * K] record ids grouped by cell, each cell's in increasing order
-  u32* rec_cursor;              // next free entry of rec_ids (one reservation per tile)
+  u32* rec_ids;                 // record ids grouped by cell, each cell's in increasing order: [n_tiles][tile_rec] the tiles' own
+  u32 tile_rec;                 //   regions, then [n_pts * K] for the tiles that outgrow theirs (rec_cursor)
+  u32* rec_cursor;
   u32* cell_count;              // [W*H] records of the cell
   u32* cell_offset;             // [W*H] its first entry in rec_ids
-  u32* cell_list;               // [16][W*H] touched cells by length class
-  u32* class_count;             // [16] cells per class (being filled) / class_total: the finished figures of this tick
-  u32* class_total;
+  u32* cell_list;               // [16 classes][64 slices][slice_cap] touched cells by length class and tile slice
+  u32 slice_cap;                //   = cells of the tiles of one slice
+  u32* class_count;             // [16 * 64] cells per (class, slice), being filled
+  u32* class_total;             // [16 * 64 + 1] their exclusive scan in walk order (fuse_turn_kernel)
   u32 lds_cap;                  // record ids a tile may order in LDS at a time (0: the maximum; smaller values: tests)
+  u32 pmax_plus1;               // 0: default; else 1 + the largest candidate count that takes the tile kernel's fast path (tests)
   u32* d_total;                 // total records (a statistic)
   MapCell* map;                 // [W*H]
   u32* d_num_fusion;            // fusion counter

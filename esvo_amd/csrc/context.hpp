@@ -201,13 +201,16 @@ struct esvo_context {
   // fusion front (kernels_fuse.hip): per tile a fixed-capacity list of point ids + one shared overflow list; per cell the
   // (offset, count) of its sorted record list; the touched cells by length class; counters (class sizes, cursors)
   u32* d_tile_count = nullptr;
-  u32* d_tile_pts = nullptr;
-  u32* d_over_pts = nullptr;
+  uint2* d_tile_pts = nullptr;
+  uint2* d_over_pts = nullptr;
   u32* d_cell_count = nullptr;
   u32* d_cell_offset = nullptr;
   u32* d_cell_list = nullptr;
-  u32* d_fuse_ctr = nullptr;      // [0..15] class_count [16..31] class_total [32] rec_cursor [33] over_count
-  u32 fuse_tile_cap = 4096;       // ESVO_FUSE_TILE_CAP (tests): entries per tile list
+  u32* d_fuse_ctr = nullptr;      // [0..1023] class_count [1024..2048] class_total [2080] rec_cursor [2081] over_count
+  u32 fuse_tile_rec = 4096;       // entries of a tile's own region of d_rec_ids (ESVO_FUSE_TILE_REC: tests)
+  u32 fuse_slice_cap = 0;         // entries of one (class, slice) segment of d_cell_list
+  u32 fuse_tile_cap = 1024;       // ESVO_FUSE_TILE_CAP (tests): entries per tile list
+  u32 fuse_pmax_plus1 = 0;        // ESVO_FUSE_PMAX (tests) + 1: candidates up to which a tile takes the bit-row path
   u32* d_rec_ids = nullptr;       // record ids of cells whose list does not fit LDS (degenerate scenes)
   u32 fuse_lds_cap = 0;           // ESVO_FUSE_LDS_CAP (tests): record ids per tile kept in LDS; 0 = the maximum
   MapCell* d_map = nullptr;

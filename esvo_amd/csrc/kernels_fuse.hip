@@ -21,6 +21,7 @@
 // replace branch (DepthFusion.cpp:186), whose side effects on
 // clean/regularisation are reproduced through the ALIVE/GRID flag pair.
 #include <algorithm>
+#include <type_traits>
 #include "common.hpp"
 #include "fdiv.hpp"
 #include "scan.hpp"
@@ -68,24 +69,24 @@ enum { FUSE_TDIST = 0, FUSE_L2 = 1, FUSE_NAIVE = 2 };
 // (profiles/r03_v3_hbm_traffic.csv: 40 MB written for 5.8 MB of ids), in 8 launches.  Now the sort is two-level and only the
 // coarse level uses global atomics, ONE per point:
 //   A  propagate    one thread per window point: the propagated point (as before) and its id appended to the list of the
-//                   16 x 16-cell TILE its centre cell lies in (fixed-capacity lists; a point that finds its list full goes
+//                   8 x 8-cell TILE its centre cell lies in (fixed-capacity lists; a point that finds its list full goes
 //                   to one shared overflow list -- dense scenes only, every tile then looks through it)
-//   T  tile_lists   one workgroup per tile, one thread per cell: the points of the tile and of its eight neighbours (a
-//                   3 x 3 footprint reaches at most one tile further) are expanded to records IN LDS -- per-cell histogram,
-//                   scan and fill with LDS atomics -- and each cell's list is put in id order there; the lists leave the chip
-//                   once, as full lines (one reservation per tile), with each cell's (offset, count), and the touched cells are
-//                   appended to sixteen length classes (one reservation per tile and class)
+//   T  tile_lists   one wave per tile, one lane per cell: the points of the tile and of its eight neighbours (a 3 x 3
+//                   footprint reaches at most one tile further) become each cell's record list, in id order, IN LDS (see the
+//                   kernel); the lists leave the chip once (one reservation per tile), with each cell's (offset, count), and
+//                   the touched cells are appended to sixteen length classes (one reservation per tile and class)
 //   W  fuse_cells   one thread per touched cell, longest lists first (waves of uniform length): the reference's state machine
 // Order: a cell's records are applied in increasing id q K + k exactly as before (the lists are sorted, whatever order the
 // atomics produced), so every map element keeps its bits.
 // Capacity: a tile's records are ordered in LDS up to `cap` ids at a time; a denser tile is handled in runs of consecutive
 // cells that fit, and a single cell with more records than `cap` (a degenerate scene) is ordered in global memory by one
-// thread.  ESVO_FUSE_LDS_CAP / ESVO_FUSE_TILE_CAP (read at esvo_create) force small capacities in the tests.
-#define FT 16                      // tile edge in cells
+// thread.  ESVO_FUSE_LDS_CAP / ESVO_FUSE_TILE_CAP / ESVO_FUSE_PMAX (read at esvo_create) force small capacities in the tests.
+#define FT FUSE_TILE               // tile edge in cells (common.hpp)
 #define FT_CELLS (FT * FT)
-#define FUSE_LDS_CAP_MAX 6144      // record ids per run in LDS (24 KB)
+#define FUSE_LDS_CAP_MAX 3072      // record ids per run in LDS (dense path)
 #define FUSE_SORT_TMP 512          // per-wave scratch of the cooperative sort of long lists
 #define FUSE_NB 16                 // length classes of the touched cells
+#define FUSE_SLICES 64              // each class's list is kept per slice of the tiles (tile % 64): 64x fewer hits per counter
 
 __host__ __device__ inline int fuse_tiles_x(int W) { return (W + FT - 1) / FT; }
 __host__ __device__ inline int fuse_tiles_y(int H) { return (H + FT - 1) / FT; }
@@ -156,9 +157,12 @@ __global__ void __launch_bounds__(256, BACK_WAVES) propagate_kernel(FuseArgs a, 
   a.prop[q] = prop;
   (void)K;
   const u32 tile = (prop.row / FT) * (u32)fuse_tiles_x(p.W) + prop.col / FT;
+  // the list entry carries the point's cell with its id: the tile kernel decides what reaches it from the lists alone (reading
+  // row / col out of the 104-byte records cost a cache line per candidate, 9 x 160 k lines per tick)
+  const uint2 entry = make_uint2(q, (prop.row << 16) | prop.col);
   const u32 pos = atomicAdd(&a.tile_count[tile], 1u);
-  if (pos < a.tile_cap) a.tile_pts[(size_t)tile * a.tile_cap + pos] = q;
-  else a.over_pts[atomicAdd(a.over_count, 1u)] = q;  // the tile's list is full (tile_count keeps counting: the reader clamps)
+  if (pos < a.tile_cap) a.tile_pts[(size_t)tile * a.tile_cap + pos] = entry;
+  else a.over_pts[atomicAdd(a.over_count, 1u)] = entry;  // the tile's list is full (tile_count keeps counting: the reader clamps)
 }
 
 // DepthPoint::update_studentT, DepthPoint.cpp:167-188
@@ -248,46 +252,56 @@ __device__ inline void fuse_record(const DevParams& p, MapCell& c, bool& exists,
   }
 }
 
-// T: one workgroup per tile, one thread per cell -- the cells' sorted record lists
-__global__ void __launch_bounds__(FT_CELLS, 4) tile_lists_kernel(FuseArgs a, DevParams p, int K, int radius, u32 cap) {
-  __shared__ u32 s_cnt[FT_CELLS];        // records per cell of the tile
-  __shared__ u32 s_off[FT_CELLS + 1];    // their exclusive scan
+// T: one wave per 8 x 8-cell tile, one lane per cell -- the cells' sorted record lists.
+// Candidates: the points of the tile's own list and of its eight neighbours' (+ the shared overflow list) whose footprint
+// reaches the tile -- its own points and a one-cell rim of the neighbours'.
+//   fast path (at most FUSE_PMAX candidates, i.e. every tile of an ordinary scene): the candidates are RANKED by id in LDS
+//     (id_j < id_i counted over all j: the ids are unique), every (candidate, cell) record sets bit `rank` of the cell's bit
+//     row, and a cell's list is its row read lowest bit first -- born sorted, no per-cell sort, no fill pass
+//   dense path: per-cell histogram / scan / fill with LDS atomics in runs of cells that fit `cap` ids, each list ordered in
+//     LDS (insertion for short ones, the wave's rank sort for long ones); a single cell beyond `cap` is ordered in global
+//     memory by its lane
+#define FUSE_PMAX 1024
+#define FUSE_BITW (FUSE_PMAX / 32 + 1)   // words per cell row (+1: no bank conflicts between the lanes' rows)
+#define FUSE_BUF (FUSE_LDS_CAP_MAX > 2 * FUSE_PMAX + FT_CELLS * FUSE_BITW ? FUSE_LDS_CAP_MAX : 2 * FUSE_PMAX + FT_CELLS * FUSE_BITW)
+__global__ void __launch_bounds__(FT_CELLS, 8) tile_lists_kernel(FuseArgs a, DevParams p, int K, int radius, u32 cap, u32 pmax) {
+  __shared__ u32 s_buf[FUSE_BUF];        // fast path: ids | (row, col) | bit rows; dense path: record ids
+  __shared__ u32 s_cnt[FT_CELLS];        // dense path: records per cell of the tile
+  __shared__ u32 s_off[FT_CELLS + 1];    //             their exclusive scan
   __shared__ u32 s_fill[FT_CELLS];
-  __shared__ u32 s_ids[FUSE_LDS_CAP_MAX];
-  __shared__ u32 s_tmp[FT_CELLS / ESVO_WAVE][FUSE_SORT_TMP];
-  __shared__ u32 s_scan[FT_CELLS / ESVO_WAVE];
+  __shared__ u32 s_tmp[FUSE_SORT_TMP];
+  __shared__ u32 s_scan[1];
   __shared__ u32 s_hist[FUSE_NB], s_hbase[FUSE_NB];
-  __shared__ u32 s_gbase;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int lane = threadIdx.x;
   const int tiles_x = fuse_tiles_x(p.W), tiles_y = fuse_tiles_y(p.H);
   const int tx = (int)(blockIdx.x % tiles_x), ty = (int)(blockIdx.x / tiles_x);
   const int r0 = ty * FT, c0 = tx * FT;
-  const int crow = r0 + tid / FT, ccol = c0 + tid % FT;
+  const int crow = r0 + lane / FT, ccol = c0 + lane % FT;
   const int ncell = p.W * p.H;
   const bool in_img = crow < p.H && ccol < p.W;
   const bool in_band = in_img && crow >= p.cband_y0 && crow < p.cband_y1;
   const int cell = crow * p.W + ccol;
-  s_cnt[tid] = 0;
-  s_fill[tid] = 0;
-  if (tid < FUSE_NB) s_hist[tid] = 0;
+  const u64 lt_mask = (1ull << lane) - 1ull;
+#ifdef FUSE_STATS
+  u64 tph[6];
+  tph[0] = __builtin_readcyclecounter();
+#define FUSE_PH(i) tph[i] = __builtin_readcyclecounter()
+#define FUSE_PH_END() do { if (lane == 0) { u64* st = (u64*)a.over_pts + (size_t)blockIdx.x * 8; for (int i = 0; i < 5; ++i) st[i] = tph[i + 1] - tph[i]; st[5] = P; st[6] = C; st[7] = tph[0]; } } while (0)
+#else
+#define FUSE_PH(i) do {} while (0)
+#define FUSE_PH_END() do {} while (0)
+#endif
+  if (lane < FUSE_NB) s_hist[lane] = 0;
   // what fuse_reset cleared per cell: the regulariser's owner marks (reg_view re-creates them by atomics)
   if (in_img && a.owner_max) { a.owner_max[cell] = 0; a.owner_min[cell] = 0xffffffffu; }
-  __syncthreads();
-  // one candidate point: fn(local cell, record id) for each of its records that lies in a cell of this tile (inside the
-  // compute band)
-  auto records_of = [&](u32 q, auto&& fn) {
-    const u32 prow = a.prop[q].row, pcol = a.prop[q].col;
-    for (int k = 0; k < K; ++k) {
-      int row, col;
-      if (!fusion_cell(prow, pcol, k, radius, p.W, p.H, row, col)) continue;
-      if (row < r0 || row >= r0 + FT || col < c0 || col >= c0 + FT) continue;
-      if (row < p.cband_y0 || row >= p.cband_y1) continue;
-      fn((row - r0) * FT + (col - c0), q * (u32)K + (u32)k);
-    }
+  // footprint of a point (DepthFusion.cpp:98-117): rows prow + [lo, hi], the same for the columns
+  const int f_lo = radius == 0 ? 0 : -1, f_hi = 1;
+  auto reaches = [&](u32 prow, u32 pcol) {
+    return (int)prow + f_hi >= r0 && (int)prow + f_lo < r0 + FT && (int)pcol + f_hi >= c0 && (int)pcol + f_lo < c0 + FT;
   };
-  // the candidate points: this tile's and its neighbours' lists, and whatever overflowed its list anywhere
+  // every candidate list in turn: fn(q) for the points this lane is dealt (call sites are wave-uniform)
   const u32 n_over = *a.over_count;
-  auto expand = [&](auto&& fn) {
+  auto for_lists = [&](auto&& fn) {
     for (int dy = -1; dy <= 1; ++dy) {
       const int ny = ty + dy;
       if (ny < 0 || ny >= tiles_y) continue;
@@ -297,48 +311,235 @@ __global__ void __launch_bounds__(FT_CELLS, 4) tile_lists_kernel(FuseArgs a, Dev
         const int nt = ny * tiles_x + nx;
         u32 cnt = a.tile_count[nt];
         if (cnt > a.tile_cap) cnt = a.tile_cap;
-        const u32* list = a.tile_pts + (size_t)nt * a.tile_cap;
-        for (u32 i = (u32)tid; i < cnt; i += FT_CELLS) records_of(list[i], fn);
+        fn(a.tile_pts + (size_t)nt * a.tile_cap, cnt);
       }
     }
-    for (u32 i = (u32)tid; i < n_over; i += FT_CELLS) records_of(a.over_pts[i], fn);
+    fn(a.over_pts, n_over);
   };
-  expand([&](int lc, u32) { atomicAdd(&s_cnt[lc], 1u); });
+  // ---- gather the candidates that reach the tile, compacted: ids and packed (row, col) ----
+  u32* s_q = s_buf;
+  u32* s_rc = s_buf + FUSE_PMAX;
+  u32 P = 0;
+  // the ten lists as one flat index range (wave-uniform): list l covers [lpref[l], lpref[l + 1])
+  const uint2* lptr[10];
+  u32 lpref[11];
+  {
+    int l = 0;
+    lpref[0] = 0;
+    for (int dy = -1; dy <= 1; ++dy)
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int ny = ty + dy, nx = tx + dx;
+        u32 cnt = 0;
+        const uint2* ptr = a.tile_pts;
+        if (ny >= 0 && ny < tiles_y && nx >= 0 && nx < tiles_x) {
+          const int nt = ny * tiles_x + nx;
+          cnt = a.tile_count[nt];
+          if (cnt > a.tile_cap) cnt = a.tile_cap;
+          ptr = a.tile_pts + (size_t)nt * a.tile_cap;
+        }
+        lptr[l] = ptr;
+        lpref[l + 1] = lpref[l] + cnt;
+        ++l;
+      }
+    lptr[9] = a.over_pts;
+    lpref[10] = lpref[9] + n_over;
+  }
+  const u32 C = lpref[10];
+  constexpr int GQ = 16;  // candidates per lane held in registers: all loads of a phase are issued back to back
+  for (u32 cbase = 0; cbase < C; cbase += (u32)GQ * ESVO_WAVE) {  // (one trip for all but the densest neighbourhoods)
+    u32 qv[GQ], rcv[GQ];
+#pragma unroll
+    for (int j = 0; j < GQ; ++j) {
+      const u32 i = cbase + (u32)j * ESVO_WAVE + (u32)lane;
+      qv[j] = 0;
+      rcv[j] = 0xffffffffu;
+      if (i < C) {
+        int l = 0;
+#pragma unroll
+        for (int t = 1; t < 10; ++t) l += (i >= lpref[t]) ? 1 : 0;
+        const uint2 e = lptr[l][i - lpref[l]];
+        qv[j] = e.x;
+        rcv[j] = e.y;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < GQ; ++j) {
+      const u32 i = cbase + (u32)j * ESVO_WAVE + (u32)lane;
+      const bool keep = i < C && reaches(rcv[j] >> 16, rcv[j] & 0xffffu);
+      const u64 km = __ballot(keep);
+      if (keep) {
+        const u32 pos = P + (u32)__popcll(km & lt_mask);
+        if (pos < FUSE_PMAX) { s_q[pos] = qv[j]; s_rc[pos] = rcv[j]; }  // (beyond: the dense path re-reads the lists)
+      }
+      P += (u32)__popcll(km);
+    }
+  }
   __syncthreads();
-  const u32 n = s_cnt[tid];
+  FUSE_PH(1);
+  u32 n = 0, ex = 0, total = 0;
+  u32* s_bits = s_buf + 2 * FUSE_PMAX;
+  const bool fast = P <= pmax;   // pmax <= FUSE_PMAX (smaller: tests)
+  if (fast) {
+    u32* s_q2 = s_q;     // ranked IN PLACE: every lane reads its candidates and counts before anyone writes
+    u32* s_rc2 = s_rc;
+    for (u32 w = (u32)lane; w < FT_CELLS * FUSE_BITW; w += ESVO_WAVE) s_bits[w] = 0;
+    // (as many candidates per lane as P needs: 1, 4 or 16 -- the counting loop costs P x that many compares)
+    auto rank_in_place = [&](auto rq_tag) {
+      constexpr int RQ = decltype(rq_tag)::value;
+      u32 myq[RQ], myrc[RQ], myr[RQ];
+#pragma unroll
+      for (int j = 0; j < RQ; ++j) {
+        const u32 i = (u32)j * ESVO_WAVE + (u32)lane;
+        myq[j] = i < P ? s_q[i] : 0u;
+        myrc[j] = i < P ? s_rc[i] : 0u;
+        myr[j] = 0;
+      }
+      for (u32 jj = 0; jj < P; ++jj) {  // the ids below the lane's own, counted over all candidates (LDS broadcast)
+        const u32 qj = s_q[jj];
+#pragma unroll
+        for (int j = 0; j < RQ; ++j) myr[j] += (qj < myq[j]) ? 1u : 0u;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < RQ; ++j) {
+        const u32 i = (u32)j * ESVO_WAVE + (u32)lane;
+        if (i < P) { s_q2[myr[j]] = myq[j]; s_rc2[myr[j]] = myrc[j]; }
+      }
+      __syncthreads();
+    };
+    if (P <= ESVO_WAVE) {
+      rank_in_place(std::integral_constant<int, 1>{});
+    } else if (P <= 2 * ESVO_WAVE) {
+      rank_in_place(std::integral_constant<int, 2>{});
+    } else if (P <= 4 * ESVO_WAVE) {
+      rank_in_place(std::integral_constant<int, 4>{});
+    } else if (P <= 8 * ESVO_WAVE) {
+      rank_in_place(std::integral_constant<int, 8>{});   // (measured at P = 425: 29 k cycles; the network below: 62 k)
+    } else {
+      // still more candidates: a bitonic network over the (id, cell) pairs in LDS, O(P log^2 P) -- counting ranks costs
+      // P^2 / 64 compares per lane
+      u32 N2 = 1024;
+      while (N2 < P) N2 <<= 1;
+      for (u32 i = P + (u32)lane; i < N2; i += ESVO_WAVE) s_q[i] = 0xffffffffu;  // padding sorts to the end
+      __syncthreads();
+      for (u32 k = 2; k <= N2; k <<= 1)
+        for (u32 j = k >> 1; j > 0; j >>= 1) {
+          for (u32 t = (u32)lane; t < N2 / 2; t += ESVO_WAVE) {
+            const u32 i = ((t & ~(j - 1u)) << 1) | (t & (j - 1u)), l = i | j;
+            const u32 qa = s_q[i], qb = s_q[l];
+            const bool up = (i & k) == 0;
+            if ((qa > qb) == up) {
+              s_q[i] = qb; s_q[l] = qa;
+              const u32 ra = s_rc[i], rb = s_rc[l];
+              s_rc[i] = rb; s_rc[l] = ra;
+            }
+          }
+          __syncthreads();
+        }
+    }
+    FUSE_PH(2);
+    for (u32 r = (u32)lane; r < P; r += ESVO_WAVE) {  // one bit per record
+      const u32 rc = s_rc2[r];
+      const u32 prow = rc >> 16, pcol = rc & 0xffffu;
+      for (int k = 0; k < K; ++k) {
+        int row, col;
+        if (!fusion_cell(prow, pcol, k, radius, p.W, p.H, row, col)) continue;
+        if (row < r0 || row >= r0 + FT || col < c0 || col >= c0 + FT) continue;
+        if (row < p.cband_y0 || row >= p.cband_y1) continue;
+        atomicOr(&s_bits[((row - r0) * FT + (col - c0)) * FUSE_BITW + (r >> 5)], 1u << (r & 31u));
+      }
+    }
+    __syncthreads();
+    const u32 nw = (P + 31u) >> 5;
+    for (u32 w = 0; w < nw; ++w) n += (u32)__popc(s_bits[lane * FUSE_BITW + w]);
+  } else {
+    s_cnt[lane] = 0;
+    s_fill[lane] = 0;
+    __syncthreads();
+  }
+  // one candidate point of the dense path: fn(local cell, record id) for each of its records in a cell of this tile
+  auto records_of = [&](uint2 e, auto&& fn) {
+    const u32 q = e.x, prow = e.y >> 16, pcol = e.y & 0xffffu;
+    for (int k = 0; k < K; ++k) {
+      int row, col;
+      if (!fusion_cell(prow, pcol, k, radius, p.W, p.H, row, col)) continue;
+      if (row < r0 || row >= r0 + FT || col < c0 || col >= c0 + FT) continue;
+      if (row < p.cband_y0 || row >= p.cband_y1) continue;
+      fn((row - r0) * FT + (col - c0), q * (u32)K + (u32)k);
+    }
+  };
+  auto expand = [&](auto&& fn) {
+    for_lists([&](const uint2* list, u32 cnt) {
+      for (u32 i = (u32)lane; i < cnt; i += ESVO_WAVE) records_of(list[i], fn);
+    });
+  };
+  if (!fast) {
+    expand([&](int lc, u32) { atomicAdd(&s_cnt[lc], 1u); });
+    __syncthreads();
+    n = s_cnt[lane];
+  }
+  FUSE_PH(3);
   {
     u32 tot;
-    const u32 ex = block_excl_scan<FT_CELLS / ESVO_WAVE>(n, &tot, s_scan);
-    s_off[tid] = ex;
-    if (tid == 0) {
-      s_off[FT_CELLS] = tot;
-      s_gbase = tot ? atomicAdd(a.rec_cursor, tot) : 0u;   // the tile's lists, contiguous in rec_ids
-    }
+    ex = block_excl_scan<1>(n, &tot, s_scan);
+    total = tot;
+    s_off[lane] = ex;
+    if (lane == 0) s_off[FT_CELLS] = tot;
+  }
+  // the tile's lists, contiguous in rec_ids: its own fixed region; a tile with more records reserves behind the regions (a
+  // counter every tile of the launch would hit costs ~20 ns per tile at the memory side: 4800 tiles, 0.1 ms)
+  u32 gbase = blockIdx.x * a.tile_rec;
+  if (total > a.tile_rec) {
+    if (lane == 0) gbase = (u32)(gridDim.x * a.tile_rec) + atomicAdd(a.rec_cursor, total);
+    gbase = (u32)__shfl((int)gbase, 0);
   }
   // the touched cells by length class: rank inside the tile, one reservation per class
   u32 rank = 0, bk = 0;
   if (n > 0) { bk = fuse_bucket(n); rank = atomicAdd(&s_hist[bk], 1u); }
   __syncthreads();
-  const u32 total = s_off[FT_CELLS];
-  if (tid < FUSE_NB && s_hist[tid]) s_hbase[tid] = atomicAdd(&a.class_count[tid], s_hist[tid]);
+  // (one counter per class AND slice of the tiles -- tile % FUSE_SLICES -- for the same reason; the slices' lists are disjoint
+  //  regions of the class's list, fuse_turn_kernel lays them end to end)
+  const u32 slice = blockIdx.x % FUSE_SLICES;
+  if (lane < FUSE_NB && s_hist[lane]) s_hbase[lane] = atomicAdd(&a.class_count[lane * FUSE_SLICES + slice], s_hist[lane]);
   if (in_band) {
     a.cell_count[cell] = n;
     if (n == 0) map_flags(a.map, ncell)[cell] = 0;  // nothing lands here: the cell reads empty
   }
-  if (total == 0) return;  // (block-uniform)
-  const u32 gbase = s_gbase;
-  if (n > 0) a.cell_offset[cell] = gbase + s_off[tid];
+  if (total == 0) return;  // (wave-uniform)
+  if (n > 0) a.cell_offset[cell] = gbase + ex;
   __syncthreads();
-  if (n > 0) a.cell_list[(size_t)bk * ncell + s_hbase[bk] + rank] = (u32)cell;
+  if (n > 0) a.cell_list[((size_t)bk * FUSE_SLICES + slice) * a.slice_cap + s_hbase[bk] + rank] = (u32)cell;
   u32* gout = a.rec_ids + gbase;
-  // runs of consecutive cells whose records fit the LDS buffer together
+  FUSE_PH(4);
+  if (fast) {  // ---- the cell's bit row, lowest rank first ----
+    const u32* s_q2 = s_q;
+    const u32* s_rc2 = s_rc;
+    const u32 nw = (P + 31u) >> 5;
+    u32 o = ex;
+    for (u32 w = 0; w < nw; ++w) {
+      u32 m = s_bits[lane * FUSE_BITW + w];
+      while (m) {
+        const u32 r = (w << 5) + (u32)__builtin_ctz(m);
+        m &= m - 1u;
+        const u32 rc = s_rc2[r];
+        const int dyc = crow - (int)(rc >> 16), dxc = ccol - (int)(rc & 0xffffu);
+        const u32 k = radius == 0 ? (u32)(dyc * 2 + dxc) : (u32)((dyc + 1) * 3 + (dxc + 1));  // fusion_cell's k of this cell
+        gout[o++] = s_q2[r] * (u32)K + k;
+      }
+    }
+    FUSE_PH(5);
+    FUSE_PH_END();
+    return;
+  }
+  // ---- dense path: runs of consecutive cells whose records fit the LDS buffer together ----
+  u32* s_ids = s_buf;
   u32 run0 = 0;
   while (run0 < FT_CELLS) {
-    u32 run1 = run0 + 1;  // (every thread derives the same run: s_off is complete)
+    u32 run1 = run0 + 1;  // (every lane derives the same run: s_off is complete)
     while (run1 < FT_CELLS && s_off[run1 + 1] - s_off[run0] <= cap) ++run1;
     const u32 base = s_off[run0];
     const u32 run_n = s_off[run1] - base;
-    const bool mine = (u32)tid >= run0 && (u32)tid < run1 && n > 0;
+    const bool mine = (u32)lane >= run0 && (u32)lane < run1 && n > 0;
     if (run_n == 0) { run0 = run1; continue; }
     if (run_n <= cap) {
       // ---- fill: the run's records into LDS, each cell's contiguous ----
@@ -346,7 +547,7 @@ __global__ void __launch_bounds__(FT_CELLS, 4) tile_lists_kernel(FuseArgs a, Dev
         if ((u32)lc >= run0 && (u32)lc < run1) s_ids[s_off[lc] - base + atomicAdd(&s_fill[lc], 1u)] = id;
       });
       __syncthreads();
-      u32* ids = s_ids + (s_off[tid] - base);
+      u32* ids = s_ids + (s_off[lane] - base);
       // ---- order: short lists by insertion in place; long ones by the wave, rank-sorted through its scratch ----
       if (mine && n > 1 && n <= 24) {
         for (u32 i = 1; i < n; ++i) {
@@ -360,18 +561,18 @@ __global__ void __launch_bounds__(FT_CELLS, 4) tile_lists_kernel(FuseArgs a, Dev
       while (longm) {
         const int src = __ffsll((long long)longm) - 1;
         longm &= longm - 1;
-        const u32 ln = (u32)__shfl((int)n, src), lo = (u32)__shfl((int)(s_off[tid] - base), src);
+        const u32 ln = (u32)__shfl((int)n, src), lo = (u32)__shfl((int)(s_off[lane] - base), src);
         u32* lid = s_ids + lo;
         if (ln <= FUSE_SORT_TMP) {
           for (u32 i = (u32)lane; i < ln; i += ESVO_WAVE) {
             const u32 vkey = lid[i];
             u32 rk = 0;
             for (u32 j = 0; j < ln; ++j) rk += (lid[j] < vkey);
-            s_tmp[wv][rk] = vkey;
+            s_tmp[rk] = vkey;
           }
           // (one wave: its LDS operations execute in program order; the barrier only keeps the compiler from moving them)
           __builtin_amdgcn_wave_barrier();
-          for (u32 i = (u32)lane; i < ln; i += ESVO_WAVE) lid[i] = s_tmp[wv][i];
+          for (u32 i = (u32)lane; i < ln; i += ESVO_WAVE) lid[i] = s_tmp[i];
           __builtin_amdgcn_wave_barrier();
         } else if (lane == src) {  // longer than the scratch: one lane, insertion sort
           for (u32 i = 1; i < ln; ++i) {
@@ -384,11 +585,11 @@ __global__ void __launch_bounds__(FT_CELLS, 4) tile_lists_kernel(FuseArgs a, Dev
       }
       __syncthreads();
       // ---- out: the run's lists as they lie in LDS (full lines) ----
-      for (u32 i = (u32)tid; i < run_n; i += FT_CELLS) gout[base + i] = s_ids[i];
+      for (u32 i = (u32)lane; i < run_n; i += ESVO_WAVE) gout[base + i] = s_ids[i];
       __syncthreads();  // the buffer is reused by the next run
     } else {
       // ---- a single cell with more records than the LDS buffer holds (run1 == run0 + 1): filled straight into its segment
-      // of rec_ids by the whole workgroup, ordered there by its own thread ----
+      // of rec_ids by the whole wave, ordered there by its own lane ----
       u32* gids = gout + base;
       expand([&](int lc, u32 id) {
         if ((u32)lc == run0) gids[atomicAdd(&s_fill[lc], 1u)] = id;
@@ -418,17 +619,17 @@ template <int MODEL>
 __global__ void __launch_bounds__(FUSE_BLOCK, FUSE_WAVES) fuse_cells_kernel(FuseArgs a, DevParams p, int K, int n_tiles) {
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   const int ncell = p.W * p.H;
-  // thread t -> the t-th touched cell in the order "longest class first" (class_total: fuse_turn_kernel)
-  u32 cum = 0, bsel = FUSE_NB;
-  u32 idx = 0;
-#pragma unroll
-  for (int b = FUSE_NB - 1; b >= 0; --b) {
-    const u32 c = a.class_total[b];
-    if (bsel == FUSE_NB && t < cum + c) { bsel = (u32)b; idx = t - cum; }
-    cum += c;
-  }
-  if (bsel == FUSE_NB) return;
-  const int cell = (int)a.cell_list[(size_t)bsel * ncell + idx];
+  // thread t -> the t-th touched cell in the order "longest class first": class_total[s] = cells before segment s, segments
+  // ordered (class descending, slice ascending) by fuse_turn_kernel; [FUSE_NB * FUSE_SLICES] = all touched cells
+  constexpr u32 NSEG = FUSE_NB * FUSE_SLICES;
+  __shared__ u32 s_seg[NSEG + 1];  // (staged: ten dependent look-ups per thread cost one global latency instead of ten)
+  for (u32 i = threadIdx.x; i <= NSEG; i += FUSE_BLOCK) s_seg[i] = a.class_total[i];
+  __syncthreads();
+  if (t >= s_seg[NSEG]) return;
+  u32 lo = 0, hi = NSEG;  // the segment with s_seg[seg] <= t < s_seg[seg + 1]
+  while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (s_seg[mid] <= t) lo = mid; else hi = mid; }
+  const u32 cls = FUSE_NB - 1u - lo / FUSE_SLICES, slc = lo % FUSE_SLICES;
+  const int cell = (int)a.cell_list[((size_t)cls * FUSE_SLICES + slc) * a.slice_cap + (t - s_seg[lo])];
   const int crow = cell / p.W, ccol = cell - crow * p.W;
   const u32 n = a.cell_count[cell];
   const u32* ids = a.rec_ids + a.cell_offset[cell];
@@ -459,21 +660,34 @@ __global__ void __launch_bounds__(FUSE_BLOCK, FUSE_WAVES) fuse_cells_kernel(Fuse
   (void)n_tiles;
 }
 
-// between T and W (one thread): the class sizes become read-only totals, every counter of the front is cleared for the next
-// tick, the statistics of this one are cleared / set
-__global__ void __launch_bounds__(256) fuse_turn_kernel(FuseArgs a, int n_tiles) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n_tiles) a.tile_count[i] = 0;
-  if (i == 0) {
-    u32 tot = 0;
-    for (int b = 0; b < FUSE_NB; ++b) {
-      const u32 c = a.class_count[b];
-      a.class_total[b] = c;
-      a.class_count[b] = 0;
-      tot += c;
-    }
+// between T and W (one small workgroup: 4 waves -- a 1024-thread workgroup needs 16 free wave slots on ONE compute unit and,
+// beside the LM kernel's long-lived waves, waited ~0.3 ms for them): the (class, slice) sizes become the exclusive scan the walk
+// indexes by -- classes in DESCENDING order, slices ascending --, every counter of the front is cleared for the next tick, this
+// tick's statistics are cleared / set
+#define FUSE_TURN_B 256
+__global__ void __launch_bounds__(FUSE_TURN_B) fuse_turn_kernel(FuseArgs a, int n_tiles) {
+  __shared__ u32 lds[FUSE_TURN_B / ESVO_WAVE];
+  constexpr u32 NSEG = FUSE_NB * FUSE_SLICES;
+  constexpr u32 PER = NSEG / FUSE_TURN_B;
+  static_assert(NSEG % FUSE_TURN_B == 0, "segments per thread");
+  u32 c[PER], sum = 0;
+#pragma unroll
+  for (u32 k = 0; k < PER; ++k) {
+    const u32 seg = threadIdx.x * PER + k;
+    const u32 cls = FUSE_NB - 1u - seg / FUSE_SLICES, slc = seg % FUSE_SLICES;
+    c[k] = a.class_count[cls * FUSE_SLICES + slc];
+    a.class_count[cls * FUSE_SLICES + slc] = 0;
+    sum += c[k];
+  }
+  u32 tot;
+  u32 ex = block_excl_scan<FUSE_TURN_B / ESVO_WAVE>(sum, &tot, lds);
+#pragma unroll
+  for (u32 k = 0; k < PER; ++k) { a.class_total[threadIdx.x * PER + k] = ex; ex += c[k]; }
+  for (int i = (int)threadIdx.x; i < n_tiles; i += FUSE_TURN_B) a.tile_count[i] = 0;
+  if (threadIdx.x == 0) {
+    a.class_total[NSEG] = tot;
     *a.n_touched = tot;
-    *a.d_total = *a.rec_cursor;
+    *a.d_total = *a.rec_cursor;   // (records beyond the tiles' own regions: a density statistic)
     *a.rec_cursor = 0;
     *a.over_count = 0;
     *a.d_num_fusion = 0;
@@ -494,8 +708,9 @@ void launch_fuse(const FuseArgs& a, const DevParams& p, hipStream_t s) {
     else hipLaunchKernelGGL(propagate_kernel<FUSE_NAIVE>, g, b, 0, s, a, p, K);
   }
   const u32 cap = (a.lds_cap >= 1 && a.lds_cap <= FUSE_LDS_CAP_MAX) ? a.lds_cap : FUSE_LDS_CAP_MAX;
-  hipLaunchKernelGGL(tile_lists_kernel, dim3(n_tiles), dim3(FT_CELLS), 0, s, a, p, K, radius, cap);
-  hipLaunchKernelGGL(fuse_turn_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, s, a, n_tiles);
+  const u32 pmax = a.pmax_plus1 ? std::min<u32>(a.pmax_plus1 - 1u, FUSE_PMAX) : FUSE_PMAX;
+  hipLaunchKernelGGL(tile_lists_kernel, dim3(n_tiles), dim3(FT_CELLS), 0, s, a, p, K, radius, cap, pmax);
+  hipLaunchKernelGGL(fuse_turn_kernel, dim3(1), dim3(FUSE_TURN_B), 0, s, a, n_tiles);
   {
     const dim3 g((ncell + FUSE_BLOCK - 1) / FUSE_BLOCK), b(FUSE_BLOCK);
     if (model == FUSE_TDIST) hipLaunchKernelGGL(fuse_cells_kernel<FUSE_TDIST>, g, b, 0, s, a, p, K, n_tiles);

@@ -491,13 +491,16 @@ def test_async_pinned_ingest_gives_the_same_maps(upenn_rig, upenn_stream):
         _same_map(a, b)
 
 
-@pytest.mark.parametrize("cap,tile_cap", [(1, 0), (7, 0), (200, 0), (0, 5), (3, 1)])
-def test_fusion_front_with_tiny_capacities_gives_the_same_maps(dsec_rig, dsec_stream, cap, tile_cap):
-    """The fusion front orders a tile's record ids in LDS (kernels_fuse.hip).  A tile that holds more than the buffer is
-    handled in runs of cells that fit, and a single cell with more records than the buffer is ordered in global memory; a
-    point that finds its tile's (fixed-capacity) list full goes to the shared overflow list every tile looks through.  With
-    ESVO_FUSE_LDS_CAP = 1 / 7 / 200 (6144 in production) and ESVO_FUSE_TILE_CAP = 5 / 1 (4096) those paths carry a whole DSEC
-    run (3 x 3 fusion, r = 20 regulariser): every map must equal the one the full-size buffers give."""
+@pytest.mark.parametrize("cap,tile_cap,pmax,tile_rec", [(1, 0, 0, 0), (7, 0, 0, 5), (200, 0, 0, 0), (0, 5, 0, 0), (3, 1, 0, 0), (0, 0, 40, 0),
+                                                         (0, 2, None, 0), (0, 0, None, 1), (0, 0, None, 40)])
+def test_fusion_front_with_tiny_capacities_gives_the_same_maps(dsec_rig, dsec_stream, cap, tile_cap, pmax, tile_rec):
+    """The fusion front builds each cell's sorted record list per 8 x 8 tile in LDS (kernels_fuse.hip): tiles with up to 512
+    candidate points through ranked bit rows, denser ones through per-cell lists ordered in runs that fit the LDS buffer, a
+    single cell beyond the buffer in global memory; a point that finds its tile's (fixed-capacity) list full goes to the shared
+    overflow list every tile looks through.  ESVO_FUSE_PMAX = 0 / 40 sends every / the busier tiles down the dense path,
+    ESVO_FUSE_LDS_CAP = 1 / 7 / 200 (3072 in production), ESVO_FUSE_TILE_CAP = 5 / 2 / 1 (1024) and ESVO_FUSE_TILE_REC = 1 / 5 / 40
+    (4096: a tile's own region of the record array; beyond it a tile reserves behind the regions) shrink the buffers: each
+    combination carries a whole DSEC run (3 x 3 fusion, r = 20 regulariser) and every map must equal the production one."""
     import os
     from esvo_amd import lib
     p, _ = params.make_params(params.PRESETS["mapping_dsec"], dsec_rig, process_event_num=4000)
@@ -517,7 +520,9 @@ def test_fusion_front_with_tiny_capacities_gives_the_same_maps(dsec_rig, dsec_st
         return maps
 
     ref = run()
-    env = {k: str(v) for k, v in (("ESVO_FUSE_LDS_CAP", cap), ("ESVO_FUSE_TILE_CAP", tile_cap)) if v}
+    env = {k: str(v) for k, v in (("ESVO_FUSE_LDS_CAP", cap), ("ESVO_FUSE_TILE_CAP", tile_cap), ("ESVO_FUSE_TILE_REC", tile_rec)) if v}
+    if pmax is not None:
+        env["ESVO_FUSE_PMAX"] = str(pmax)
     os.environ.update(env)
     try:
         got = run()

@@ -25,7 +25,7 @@ else:
     cur = sqlite3.connect(dbs[0]).cursor()
     q = ("select kernel_name, counter_name, avg(value), count(*) from counters_collection group by kernel_name, counter_name")
     for k, c, v, n in cur.execute(q):
-        if any(s in k for s in ("lm_refine", "bm_match", "fuse_cells", "reg_apply", "scatter_records", "propagate_kernel", "ts_scatter")):
+        if any(s in k for s in ("lm_refine", "bm_match", "fuse_cells", "reg_apply", "scatter_records", "propagate_kernel", "ts_scatter", "tile_lists", "fuse_turn")):
             print(f"{k.split('(')[0].replace('void ', '')[:60]:60s} {c:28s} {v:14.5g} n={n}")
     try:
         for r in cur.execute("select name, average from top_kernels where name like '%lm_refine%' or name like '%fuse_cells%' or name like '%bm_match%'"):
