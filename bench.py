@@ -625,7 +625,7 @@ def main():
         out["parity"] = par
     if world > 1 and "ESVO_SHARD_MODE" not in os.environ and not args.strong and not args.check and not args.no_extras:
         # the OTHER way of using N GPUs, on the same line: every tick of ONE stream split over the ranks -- per-event work
-        # by slot, per-cell work by image row band (north_star's image-tile partition), two ncclAllReduce per tick and the
+        # by slot, per-cell work by image row band (north_star's image-tile partition), two ncclAllGather per tick (own-slot bytes; [count | kept points]) and the
         # all-gather of the DepthMap bands at read-out.  Strong scaling: K ticks in total, shorter ticks.
         if hasattr(runner, "dev"):
             runner.dev.close()
@@ -637,7 +637,7 @@ def main():
                 "depth_points_per_s": B["n_points"] / B["dt"], "events_per_tick": B["n_events"] // max(K, 1),
                 "map_size_after_gather": int(len(gm)),
                 "parallelism": f"{world} GPUs: slots w % {world} for block matching + LM, {world} image row bands for fusion / clean / "
-                               f"regularisation; 2 ncclAllReduce(u64 sum) per tick + ncclAllGather of the map bands"
+                               f"regularisation; 2 ncclAllGather per tick (one byte per own slot; [count | kept points] with the block sized by the largest kept count) + ncclAllGather of the map bands"
                                + (" (esvo_comm_*: RCCL inside the C library)" if B["native"] else " (torch.distributed)"),
             }
     if rank == 0:

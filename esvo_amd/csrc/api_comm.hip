@@ -465,7 +465,7 @@ int esvo_comm_newest_map(esvo_handle h, esvo_depth_point_t* out, size_t cap, siz
   return rc;
 }
 
-// ---- one tick split over the ranks: the three phases of esvo_shard_tick_phase with their two sums -------------------
+// ---- one tick split over the ranks: the three phases of esvo_shard_tick_phase with their two all-gathers -------------------
 int esvo_comm_shard_tick(esvo_handle h, uint64_t t_ns, const uint64_t* pose_t_ns, const double* pose_T, size_t m) {
   if (!h || !pose_t_ns || !pose_T) return ESVO_ERR_INVALID_ARG;
   API_LOCK(h);
@@ -474,11 +474,12 @@ int esvo_comm_shard_tick(esvo_handle h, uint64_t t_ns, const uint64_t* pose_t_ns
     int rc = esvo_shard_tick_phase(h, phase, t_ns, pose_t_ns, pose_T, m);
     if (rc) return rc;
     if (phase < 2 && h->comm->world > 1) {
-      void* ptr = nullptr;
+      void *snd = nullptr, *rcv = nullptr;
       size_t nb = 0;
-      esvo_shard_exchange(h, &ptr, &nb);
-      // the sizes are identical on every rank (slots of the tick; kept points after the first sum)
-      if (nb) { rc = comm_all_reduce_u64(h, ptr, nb / 8); if (rc) return rc; }
+      esvo_shard_exchange(h, &snd, &rcv, &nb);
+      // the block lengths are identical on every rank (slots of the tick / ranks; the largest kept count, which every rank
+      // derives from the first exchange)
+      if (nb) { rc = comm_all_gather(h, snd, rcv, nb); if (rc) return rc; }
     }
   }
   return ESVO_OK;

@@ -424,7 +424,7 @@ int esvo_destroy(esvo_handle h) {
                   h->d_matches2[0], h->d_matches2[1], h->d_scan_tmp_l2[0], h->d_scan_tmp_l2[1], h->d_pt_slots2[0], h->d_pt_slots2[1], h->d_pt_flags2[0], h->d_pt_flags2[1], h->d_pt_prefix2[0], h->d_pt_prefix2[1], h->d_pts_tmp, h->d_stage[0], h->d_stage[1], h->d_counters2[0], h->d_counters2[1], h->d_scan_tmp,
                   h->d_win, h->d_frame_pose_T, h->d_fr_table, h->d_prop, h->d_tile_pts, h->d_tile_count, h->d_over_pts,
                   h->d_cell_count, h->d_cell_offset, h->d_cell_list, h->d_fuse_ctr, h->d_rec_ids, h->d_map, h->d_map2, h->d_owner_max, h->d_owner_min, h->d_exp_flags,
-                  h->d_exp_prefix, h->d_export, h->d_export_cell, h->d_reg_ab, h->d_reg_cd, h->d_own_w, h->d_lkeep, h->d_codes,
+                  h->d_exp_prefix, h->d_export, h->d_export_cell, h->d_reg_ab, h->d_reg_cd, h->d_own_w, h->d_lkeep, h->d_codes, h->d_codes_send, h->d_codes_all, h->d_pts_send, h->d_pts_all, h->d_rank_kept,
                   h->d_sel, h->d_evmap, h->d_lm_fvec0, h->d_lm_fnorm0, h->d_lm_meta, h->d_lm_order, h->d_lm_hist, h->d_clk};
   for (void* p : ptrs) if (p) hipFree(p);
   if (h->h_counters) hipHostFree(h->h_counters);
@@ -479,12 +479,14 @@ int esvo_reset(esvo_handle h) {
     h->ts_valid[cam] = false;
   }
   h->sh_first = 0;
+  h->sh_first_prev = 0;
   h->trk_read_pending = false;
   h->ema_lm_ms = h->ema_back_ms = 0.f;
   h->lm_two_on = false;
   std::memset(h->lm_pair_ms, 0, sizeof(h->lm_pair_ms));
   h->lm_pair_n[0] = h->lm_pair_n[1] = 0u;
   h->lm_pair_decisions = 0;
+  h->lm_pair_current = -1;
   h->frames.clear();
   h->n_window_frames = 0;
   std::fill(h->slot_used.begin(), h->slot_used.end(), 0);
@@ -492,6 +494,7 @@ int esvo_reset(esvo_handle h) {
   HIPCHK(hipMemsetAsync(h->d_map2, 0, map_buffer_bytes(npx), h->stream));
   HIPCHK(hipMemsetAsync(h->d_tile_count, 0, sizeof(u32) * (size_t)((h->W + FUSE_TILE - 1) / FUSE_TILE) * ((h->H + FUSE_TILE - 1) / FUSE_TILE), h->stream));
   HIPCHK(hipMemsetAsync(h->d_fuse_ctr, 0, sizeof(u32) * 2112, h->stream));
+  if (h->d_rank_kept) HIPCHK(hipMemsetAsync(h->d_rank_kept, 0, sizeof(u32) * esvo_context::SHARD_MAX_RANKS, h->stream));
   h->d_map_cur = h->d_map;
   h->obs_set = false;
   h->n_pose = 0;

@@ -100,8 +100,12 @@ static int lm_pair_policy(esvo_context* h, u32 n_events) {
     for (u32 i = 0; i < 4u && i < h->lm_pair_n[mode]; ++i) m = std::min(m, h->lm_pair_ms[mode][i]);
     return m;
   };
-  const int best = recent_min(1) < recent_min(0) ? 1 : 0;
-  return (k % 64u == 63u) ? best ^ 1 : best;
+  // The samples are EV_LM0..EV_LM1 intervals on the lowest-priority stream: contention with the other stages only ever ADDS
+  // time, so the minimum of the recent four is the estimate least touched by it; and the layout in use is left only for one
+  // that is 5 % faster by that estimate (hysteresis: two layouts within noise of each other do not alternate run to run).
+  if (h->lm_pair_current < 0) h->lm_pair_current = recent_min(1) < recent_min(0) ? 1 : 0;
+  else if (recent_min(h->lm_pair_current ^ 1) < 0.95f * recent_min(h->lm_pair_current)) h->lm_pair_current ^= 1;
+  return (k % 64u == 63u) ? h->lm_pair_current ^ 1 : h->lm_pair_current;  // (a periodic sample of the other one keeps its estimate fresh)
 }
 int run_lm(esvo_context* h, u32 max_matches, int cull, bool dense, hipStream_t st = nullptr, int pair = -1) {
   if (!st) st = h->stream;
@@ -231,9 +235,14 @@ int alloc_pose_slot(esvo_context* h, u32* slot) {
     (void)hipGetLastError();
     FAIL(ESVO_ERR_CAPACITY, "out of device memory growing the pose-table slots");
   }
-  HIPCHK(hipMemcpy(d_new, h->d_frame_pose_T, per * h->n_pose_slots, hipMemcpyDeviceToDevice));
-  HIPCHK(hipFree(h->d_frame_pose_T));
-  h->d_frame_pose_T = d_new;
+  if (hipMemcpy(d_new, h->d_frame_pose_T, per * h->n_pose_slots, hipMemcpyDeviceToDevice) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipFree(d_new);  // the old table stays in place and in use
+    FAIL(ESVO_ERR_HIP, "copying the pose-table slots into the grown table failed");
+  }
+  double* d_old = h->d_frame_pose_T;
+  h->d_frame_pose_T = d_new;  // the copy succeeded: from here on the handle owns the new table whatever the free says
+  HIPCHK(hipFree(d_old));
   *slot = h->n_pose_slots;
   h->slot_used[*slot] = 1;
   h->n_pose_slots = n_new;
@@ -573,9 +582,13 @@ int select_events(esvo_context* h, uint64_t t_ns, u64* first_out, u32* n_out) {
     FAIL(ESVO_ERR_STATE, "selected events were already overwritten in the event ring");
   *first_out = first;
   *n_out = n;
-  h->sh_first = first;  // under mu_ring: what the ingest thread's overwrite guard reads
+  h->sh_first_prev = h->sh_first;  // the previous tick's front stage may still be in flight on the front stream (lazy ticks)
+  h->sh_first = first;             // under mu_ring: what the ingest thread's overwrite guard reads
   return ESVO_OK;
 }
+
+// block length of exchange 1 (kernels_shard.hip): the bytes of a rank's own slots, whole 64-bit words
+static inline size_t shard_codes_block(u32 n, u32 N) { return (((size_t)n + N - 1) / N + 7) / 8 * 8; }
 
 // phase 0 (front stage): poses, event selection, block matching + LM of the events of this handle's shard
 int tick_phase0(esvo_context* h, uint64_t t_ns, const uint64_t* pose_t_ns, const double* pose_T, size_t m) {
@@ -618,8 +631,8 @@ int tick_phase0(esvo_context* h, uint64_t t_ns, const uint64_t* pose_t_ns, const
     n = tk.n = h->h_counters[5];
     sel = h->d_sel;
   }
-  h->xchg_ptr = nullptr;
-  h->xchg_bytes = 0;
+  h->xchg_send = h->xchg_recv = nullptr;
+  h->xchg_block = 0;
   if (n && !h->sharded) {
     rc = run_bm(h, h->d_ring[0], h->sh_first, h->ring_cap, 1, n, sel);
     if (rc) return rc;
@@ -643,7 +656,7 @@ int tick_phase0(esvo_context* h, uint64_t t_ns, const uint64_t* pose_t_ns, const
     if (rc) return rc;
   } else if (n) {
     // own slots only (w % n_shards == shard): BM, dense local list, LM + cull on it, then the (matched, kept)
-    // byte of every own slot; the other ranks' bytes stay zero and arrive with the caller's sum
+    // byte of every own slot, back to back: this rank's block of the caller's all-gather
     const u32 N = (u32)h->dp.ev_nshards, r = (u32)h->dp.ev_shard;
     const u32 own = n > r ? (n - r + N - 1) / N : 0;
     HIPCHK(hipMemsetAsync(h->d_match_flags, 0, sizeof(u32) * n, h->stream));
@@ -653,12 +666,13 @@ int tick_phase0(esvo_context* h, uint64_t t_ns, const uint64_t* pose_t_ns, const
     if (rc) return rc;
     rc = run_lm(h, own, 1, true);
     if (rc) return rc;
-    const size_t nb = ((size_t)n + 7) / 8 * 8;
-    HIPCHK(hipMemsetAsync(h->d_codes, 0, nb, h->stream));
-    launch_shard_codes(h->d_own_w, h->d_lkeep, h->d_counters + 8, own, h->d_codes, h->stream);
+    const size_t nb = shard_codes_block(n, N);
+    HIPCHK(hipMemsetAsync(h->d_codes_send, 0, nb, h->stream));
+    launch_shard_codes(h->d_own_w, h->d_lkeep, h->d_counters + 8, own, N, h->d_codes_send, h->stream);
     HIPCHK(hipGetLastError());
-    h->xchg_ptr = h->d_codes;
-    h->xchg_bytes = nb;
+    h->xchg_send = h->d_codes_send;
+    h->xchg_recv = N > 1 ? h->d_codes_all : h->d_codes_send;
+    h->xchg_block = nb;
   }
   return ESVO_OK;
 }
@@ -675,8 +689,8 @@ int tick_phase1_enqueue(esvo_context* h) {
     if (rc) return rc;
     frame = h->d_win + tk.off;
   }
-  h->xchg_ptr = nullptr;
-  h->xchg_bytes = 0;
+  h->xchg_send = h->xchg_recv = nullptr;
+  h->xchg_block = 0;
   if (n && !h->sharded) {
     // the frame waits in the staging buffer of its parity until the tick is committed and its size is known; the
     // buffer's previous frame (two ticks ago) has been copied into the ring by then
@@ -686,13 +700,17 @@ int tick_phase1_enqueue(esvo_context* h) {
   } else if (n) {
     const u32 N = (u32)h->dp.ev_nshards, r = (u32)h->dp.ev_shard, T = (u32)h->dp.num_threads;
     const u32 own = n > r ? (n - r + N - 1) / N : 0;
+    launch_shard_unpack_codes(N > 1 ? h->d_codes_all : h->d_codes_send, (u32)shard_codes_block(n, N), N, n, h->d_codes, h->d_rank_kept,
+                              h->stream);
     launch_shard_match_flags(h->d_codes, n, h->d_match_flags, h->stream);
     launch_exclusive_scan_u32(h->d_match_flags, h->d_match_prefix, h->d_counters + 0, h->d_scan_tmp, n, h->stream);
     HIPCHK(hipMemsetAsync(h->d_pt_flags, 0, sizeof(u32) * n, h->stream));
     launch_shard_keep_flags(h->d_codes, h->d_match_prefix, h->d_counters + 0, n, T, h->d_pt_flags, h->stream);
     launch_exclusive_scan_u32(h->d_pt_flags, h->d_pt_prefix, h->d_counters + 1, h->d_scan_tmp, n, h->stream);
-    launch_shard_place(h->d_own_w, h->d_lkeep, h->d_pt_slots, h->d_counters + 8, own, h->d_match_prefix, h->d_counters + 0,
-                       h->d_pt_prefix, h->d_counters + 1, T, frame, n, h->stream);
+    (void)frame;  // filled after exchange 2 (tick_phase2)
+    HIPCHK(hipMemsetAsync(h->d_pts_send, 0, 8, h->stream));  // the block's count word = the append cursor
+    launch_shard_pack(h->d_own_w, h->d_lkeep, h->d_pt_slots, h->d_counters + 8, own, h->d_match_prefix, h->d_counters + 0,
+                      h->d_pt_prefix, T, h->d_pts_send, own, n, h->d_rank_kept, N, h->d_counters + 9, h->stream);
     hipEventRecord(h->evt[EV_S2 + h->fpar * EV_FRONT_STRIDE], h->stream);
     HIPCHK(hipGetLastError());
   }
@@ -736,9 +754,11 @@ int tick_phase1_collect(esvo_context* h, int fp) {
       h->lm_pair_n[tk.lm_pair]++;
     }
   }
-  if (h->sharded && n_points) {
-    h->xchg_ptr = h->d_win + tk.off;
-    h->xchg_bytes = (size_t)n_points * sizeof(DevPoint);
+  tk.max_kept = (h->sharded && n) ? cnt[9] : 0;
+  if (h->sharded && n_points) {  // exchange 2: [count | kept points], block length from the largest kept count among the ranks
+    h->xchg_send = h->d_pts_send;
+    h->xchg_recv = h->dp.ev_nshards > 1 ? h->d_pts_all : h->d_pts_send;
+    h->xchg_block = 8 + (size_t)tk.max_kept * sizeof(DevPoint);
   }
   return ESVO_OK;
 }
@@ -748,9 +768,13 @@ int tick_phase1_collect(esvo_context* h, int fp) {
 // collected then.
 int tick_phase2(esvo_context* h, int fp) {
   esvo_context::TickState& tk = h->tk[fp];
-  h->xchg_ptr = nullptr;
-  h->xchg_bytes = 0;
-  if (h->sharded) {  // the caller's frame sum was issued on the front stream after EV_CNT
+  h->xchg_send = h->xchg_recv = nullptr;
+  h->xchg_block = 0;
+  if (h->sharded) {  // the caller's all-gather was issued on the front stream after EV_CNT: every block's points to frame[seq]
+    const u32 N = (u32)h->dp.ev_nshards;
+    launch_shard_scatter(N > 1 ? h->d_pts_all : h->d_pts_send, 1 + (size_t)tk.max_kept * (sizeof(DevPoint) / 8), N, tk.max_kept,
+                         h->d_win + tk.off, tk.n, h->stream);
+    HIPCHK(hipGetLastError());
     int rc = back_after_front(h);
     if (rc) return rc;
   } else {
@@ -885,6 +909,18 @@ extern "C" int esvo_map_tick_bm_only(esvo_handle h, uint64_t t_ns, const uint64_
   rc = select_events(h, t_ns, &first, &n);
   if (!rc) rc = upload_poses(h, pose_t_ns, pose_T, m, h->d_counters2[h->fpar ^ 1]);
   if (rc) return rc;
+  // This mode keeps maxNumFusionFrames frames of up to PROCESS_EVENT_NUM un-culled matches whatever the fusion strategy, while
+  // the window ring is sized for the normal policy (max_window_points): a CONST_POINTS preset with a small point budget and
+  // many frames can run out of ring.  Find that out HERE, before any tick state flips: the frame that leaves at this tick
+  // leaves first (push_back + pop_front while size > max == pop while size >= max, then push), and the ring must take a
+  // frame of n points (n = the selected events bounds the matches).
+  while (h->n_window_frames && h->n_window_frames >= (size_t)std::max(1, h->prm.max_fusion_frames)) pop_front_frame(h);
+  {
+    u32 probe_off;
+    if (window_reserve(h, n, &probe_off) != ESVO_OK)
+      FAIL(ESVO_ERR_CAPACITY, "PURE_BLOCK_MATCHING window (maxNumFusionFrames frames of up to PROCESS_EVENT_NUM matches) "
+                              "does not fit the fusion window ring: raise max_window_points");
+  }
   h->fpar ^= 1;
   h->d_matches = h->d_matches2[h->fpar];
   h->d_counters = h->d_counters2[h->fpar];
@@ -972,6 +1008,8 @@ extern "C" int esvo_map_fuse_matches_naive(esvo_handle h, const esvo_match_t* ma
     HIPCHK(hipGetLastError());
   }
   u32 off;
+  // the frame that leaves at this call leaves first (its ring space is free: stream_b was drained above)
+  while (h->n_window_frames && h->n_window_frames >= (size_t)std::max(1, h->prm.max_fusion_frames)) pop_front_frame(h);
   rc = window_reserve(h, n32, &off);
   if (rc) return rc;
   rc = back_after_front(h);
@@ -1062,7 +1100,7 @@ extern "C" int esvo_map_init_sgm(esvo_handle h, const uint8_t* ts_left, const ui
     if (n > h->max_ev) FAIL(ESVO_ERR_CAPACITY, "more events than max_events_per_tick");
     if (n && first - (n - 1) < h->ring_reserved[0] - std::min<u64>(h->ring_reserved[0], h->ring_cap))
       FAIL(ESVO_ERR_STATE, "selected events were already overwritten in the event ring");
-    if (n) h->sh_first = first;  // the overwrite guard of the ingest thread protects this selection like a tick's
+    if (n) { h->sh_first_prev = h->sh_first; h->sh_first = first; }  // the ingest thread's overwrite guard protects this selection like a tick's
   }
   HIPCHK(hipMemsetAsync(h->d_counters, 0, sizeof(u32) * CNT_ROW, h->stream));
   u32 count = 0;
@@ -1419,7 +1457,8 @@ int esvo_get_stats(esvo_handle h, esvo_stats_t* out) {
 
 // ---- Multi-GPU row-band sharding ------------------------------------------------------------------
 int esvo_shard_set_band(esvo_handle h, int row_begin, int row_end, int shard, int n_shards) {
-  if (!h || row_begin < 0 || row_end > h->H || row_begin >= row_end || n_shards < 1 || shard < 0 || shard >= n_shards)
+  if (!h || row_begin < 0 || row_end > h->H || row_begin >= row_end || n_shards < 1 || shard < 0 || shard >= n_shards ||
+      n_shards > (int)esvo_context::SHARD_MAX_RANKS)
     return ESVO_ERR_INVALID_ARG;
   API_LOCK(h);
   { int rcp = flush_pending_tick(h); if (rcp) return rcp; }
@@ -1429,14 +1468,27 @@ int esvo_shard_set_band(esvo_handle h, int row_begin, int row_end, int shard, in
   h->dp.band_y1 = row_end;
   set_compute_band(h);
   h->sharded = !(row_begin == 0 && row_end == h->H) || n_shards > 1;
+  if (h->sharded && !h->d_codes_send) {  // exchange blocks, sized for any rank count up to SHARD_MAX_RANKS (lazily: unsharded handles never pay)
+    const size_t E = h->max_ev, R = esvo_context::SHARD_MAX_RANKS, WP = sizeof(DevPoint) / 8;
+    HIPCHK(hipSetDevice(h->device));
+    auto alloc = [&](auto** p, size_t bytes) { return hipMalloc(reinterpret_cast<void**>(p), bytes) == hipSuccess; };
+    if (!alloc(&h->d_codes_send, (E + 7) / 8 * 8) || !alloc(&h->d_codes_all, E + 8 * R) || !alloc(&h->d_pts_send, 8 * (1 + E * WP)) ||
+        !alloc(&h->d_pts_all, 8 * (R + (E + R) * WP)) || !alloc(&h->d_rank_kept, sizeof(u32) * R)) {
+      (void)hipGetLastError();
+      h->sharded = false;
+      FAIL(ESVO_ERR_CAPACITY, "out of device memory for the shard exchange blocks");
+    }
+    HIPCHK(hipMemset(h->d_rank_kept, 0, sizeof(u32) * R));
+  }
   return ESVO_OK;
 }
 
-int esvo_shard_exchange(esvo_handle h, void** d_ptr, size_t* n_bytes) {
-  if (!h || !d_ptr || !n_bytes) return ESVO_ERR_INVALID_ARG;
+int esvo_shard_exchange(esvo_handle h, void** d_send, void** d_recv, size_t* block_bytes) {
+  if (!h || !d_send || !d_recv || !block_bytes) return ESVO_ERR_INVALID_ARG;
   API_LOCK(h);
-  *d_ptr = h->xchg_ptr;
-  *n_bytes = h->xchg_bytes;
+  *d_send = h->xchg_send;
+  *d_recv = h->xchg_recv;
+  *block_bytes = h->xchg_block;
   return ESVO_OK;
 }
 

@@ -132,7 +132,11 @@ int push_begin(esvo_context* h, int cam, size_t n, u64 t_first, PushTicket& tk) 
   if (h->ring_reserved[cam] > h->ring_cap) {
     const u64 evict_end = h->ring_reserved[cam] - h->ring_cap;  // first absolute index that survives
     u64 oldest_read = h->scatter_pending_lo[cam];               // scatter kernels enqueued since the last drain
-    if (cam == 0) oldest_read = std::min(oldest_read, h->sh_first > (u64)h->max_ev ? h->sh_first - (u64)h->max_ev : 0);
+    if (cam == 0) {  // the selections of the (up to) two ticks whose front stages may not have completed: each reads at most
+                     // max_ev events up to its selection point
+      const u64 sel_lo = std::min(h->sh_first, h->sh_first_prev);
+      oldest_read = std::min(oldest_read, sel_lo > (u64)h->max_ev ? sel_lo - (u64)h->max_ev : 0);
+    }
     tk.drain = evict_end > oldest_read;
     tk.seq = h->scatter_seq;
   }

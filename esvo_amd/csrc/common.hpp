@@ -234,13 +234,16 @@ void launch_track_normal(const TrackArgs& a, const TrackPose& pose, u32 offset, 
                          hipStream_t s);
 
 // kernels_shard.hip: ordering of a tick's frame from the ranks' (matched, kept) bits
-void launch_shard_codes(const u32* own_w, const u32* keep, const u32* n_local, u32 max_local, uint8_t* codes, hipStream_t s);
+void launch_shard_codes(const u32* own_w, const u32* keep, const u32* n_local, u32 max_local, u32 N, uint8_t* block, hipStream_t s);
+void launch_shard_unpack_codes(const uint8_t* blocks, u32 block_bytes, u32 N, u32 n, uint8_t* codes, u32* rank_kept, hipStream_t s);
 void launch_shard_match_flags(const uint8_t* codes, u32 n, u32* flags, hipStream_t s);
 void launch_shard_keep_flags(const uint8_t* codes, const u32* prefix_f, const u32* n_matches, u32 n, u32 T, u32* keep_by_slot,
                              hipStream_t s);
-void launch_shard_place(const u32* own_w, const u32* keep, const DevPoint* local_pts, const u32* n_local, u32 max_local,
-                        const u32* prefix_f, const u32* n_matches, const u32* prefix_g, const u32* n_points, u32 T,
-                        DevPoint* frame, u32 frame_cap, hipStream_t s);
+void launch_shard_pack(const u32* own_w, const u32* keep, const DevPoint* local_pts, const u32* n_local, u32 max_local,
+                       const u32* prefix_f, const u32* n_matches, const u32* prefix_g, u32 T, unsigned long long* block, u32 block_cap,
+                       u32 frame_cap, u32* rank_kept, u32 N, u32* max_kept_out, hipStream_t s);
+void launch_shard_scatter(const unsigned long long* blocks, size_t block_words, u32 N, u32 max_kept, DevPoint* frame, u32 frame_cap,
+                          hipStream_t s);
 
 // kernels_lm.hip
 struct LmArgs {

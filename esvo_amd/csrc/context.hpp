@@ -223,16 +223,26 @@ struct esvo_context {
   // sharded mode (kernels_shard.hip): dense local lists + the (matched, kept) byte per slot that is exchanged
   u32* d_own_w = nullptr;         // slot w of the k-th own match
   u32* d_lkeep = nullptr;         // keep flag of the k-th own match after LM + culling
-  uint8_t* d_codes = nullptr;     // [codes_bytes] one byte per slot, zero for other ranks' slots
+  uint8_t* d_codes = nullptr;     // [codes_bytes] one byte per slot (all ranks' slots, after exchange 1)
   size_t codes_bytes = 0;
-  void* xchg_ptr = nullptr;       // what the caller must sum across the ranks before the next phase
-  size_t xchg_bytes = 0;
+  // what the caller must all-gather across the ranks before the next phase (esvo_shard_exchange): xchg_block bytes from
+  // xchg_send of every rank into xchg_recv, rank-major.  One rank (n_shards == 1): recv aliases send, nothing to exchange.
+  void* xchg_send = nullptr;
+  void* xchg_recv = nullptr;
+  size_t xchg_block = 0;
+  uint8_t* d_codes_send = nullptr;             // exchange 1: [roundup8(ceil(n / N))] the bytes of the own slots r, r + N ...
+  uint8_t* d_codes_all = nullptr;              //             [N][that]
+  unsigned long long* d_pts_send = nullptr;    // exchange 2: [1 + own * 13] count | kept points (final index in seq)
+  unsigned long long* d_pts_all = nullptr;     //             [N][1 + max_kept * 13]
+  u32* d_rank_kept = nullptr;                  // [SHARD_MAX_RANKS] kept count of every rank (from exchange 1)
+  static constexpr u32 SHARD_MAX_RANKS = 1024;
   bool sharded = false;
   // A tick's state between its phases.  Unsharded ticks are finished lazily: esvo_map_tick(k) enqueues the front
   // stage of tick k and only then completes tick k-1 (point count -> window policy -> back stage), so the host
   // never waits on the front stream while it still has work to enqueue there.
   struct TickState {
     u32 n = 0, off = 0, points = 0, n_pose = 0;
+    u32 max_kept = 0;                 // sharded: largest kept count among the ranks (block length of exchange 2)
     int pose_buf = 0;
     u64 t_ns = 0;
     double T_world_obs[16];
@@ -249,10 +259,12 @@ struct esvo_context {
   float lm_pair_ms[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
   u32 lm_pair_n[2] = {0u, 0u};
   u32 lm_pair_decisions = 0;
+  int lm_pair_current = -1;       // the layout the policy settled on (-1: still exploring)
   int fpar = 0;                   // parity of the newest front stage
   bool tick_pending = false;      // tk[fpar] has its front stage enqueued but is not committed yet
   u64 committed_t_ns = 0;         // stamp of the newest tick whose back stage is enqueued (0: none)
   u64 sh_first = 0;
+  u64 sh_first_prev = 0;  // the selection before it (two ticks may be in flight)
   double2* d_reg_ab = nullptr;
   double2* d_reg_cd = nullptr;
   double T_world_frame[16];

@@ -911,6 +911,9 @@ __global__ void __launch_bounds__(PAIR ? 128 : LM_BLOCK, WIDE ? LM_WIDE_WAVES : 
     const double invJtJ = (r != 0.) ? (1. / r) * (1. / r) : 0.;  // internal::covar, n == 1
     double variance;
     if constexpr (L2) {  // :200-206: cov = |f|^2 / (values - inputs) * (J^T J)^-1; DepthPoint::update on a new point bounds it
+      // (upstream takes lm.fvec.blueNorm() here and lm.fnorm -- stableNorm -- for the residual below: two Eigen algorithms for
+      // the same |f| that may round differently in the last place.  Both are third-party code absent from the reference tree;
+      // this path and the oracle use the solver's one canonical |f| for both.  Stated deviation, DESIGN.md "Deviations".)
       variance = fnorm * fnorm / (double)(N - 1) * invJtJ;
       if (variance < 1e-6) variance = 1e-6;
     } else {

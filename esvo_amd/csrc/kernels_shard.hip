@@ -6,25 +6,58 @@
 //   bit 0  the event was matched             -> position j of the match in vEMP (prefix over w)
 //   bit 1  its point survived LM + culling   -> solver slot s = stride_slot(j, M, T)
 //                                               (DepthProblemSolver.cpp:75-90), final index = prefix over s
-// so the ranks exchange these bits (one byte per slot, summed: foreign bytes are zero), every rank
-// derives the same order, writes its own points at their final indices into a zeroed frame, and a second
-// sum over the frame completes it everywhere.  Nothing here touches a point's payload.
+// Both exchanges of a tick are ALL-GATHERS of fixed-size blocks:
+//   1. the (matched, kept) byte of every own slot -- block r holds rank r's slots r, r + N, r + 2N ... back to back (ceil(n / N)
+//      bytes rounded up to 8); every rank then derives the same order AND every rank's kept count;
+//   2. the kept points, each already carrying its final index (seq) -- block r = [count (8 B) | points], the block length sized
+//      by the largest kept count among the ranks (known to every rank from exchange 1), so no zero padding travels beyond
+//      the imbalance between ranks.  Every rank copies the points of all blocks to frame[seq].
+// Nothing here touches a point's payload.
 #include "common.hpp"
 
 namespace esvo {
 
+// own block of exchange 1 (zeroed by the caller): byte k = slot r + k N
 __global__ void __launch_bounds__(256) shard_codes_kernel(const u32* __restrict__ own_w, const u32* __restrict__ keep,
-                                                          const u32* __restrict__ n_local, u32 max_local,
-                                                          uint8_t* __restrict__ codes) {
+                                                          const u32* __restrict__ n_local, u32 max_local, u32 N,
+                                                          uint8_t* __restrict__ block) {
   const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
   u32 n = *n_local;
   if (n > max_local) n = max_local;
   if (k >= n) return;
-  codes[own_w[k]] = (uint8_t)(1u | (keep[k] ? 2u : 0u));
+  block[own_w[k] / N] = (uint8_t)(1u | (keep[k] ? 2u : 0u));
 }
-void launch_shard_codes(const u32* own_w, const u32* keep, const u32* n_local, u32 max_local, uint8_t* codes, hipStream_t s) {
+void launch_shard_codes(const u32* own_w, const u32* keep, const u32* n_local, u32 max_local, u32 N, uint8_t* block, hipStream_t s) {
   if (max_local == 0) return;
-  hipLaunchKernelGGL(shard_codes_kernel, dim3((max_local + 255) / 256), dim3(256), 0, s, own_w, keep, n_local, max_local, codes);
+  hipLaunchKernelGGL(shard_codes_kernel, dim3((max_local + 255) / 256), dim3(256), 0, s, own_w, keep, n_local, max_local, N, block);
+}
+
+// after exchange 1: the gathered blocks [N][block_bytes] back into one byte per slot, and every rank's kept count
+// (rank_kept[r], zero on entry: one atomic per workgroup)
+__global__ void __launch_bounds__(256) shard_unpack_codes_kernel(const uint8_t* __restrict__ blocks, u32 block_bytes, u32 N, u32 n,
+                                                                 uint8_t* __restrict__ codes, u32* __restrict__ rank_kept) {
+  __shared__ u32 part[4];
+  const u32 k = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+  const u64 w = (u64)r + (u64)k * N;
+  u32 kept = 0;
+  if (w < n) {
+    const u32 c = blocks[(size_t)r * block_bytes + k];
+    codes[w] = (uint8_t)c;
+    kept = (c >> 1) & 1u;
+  }
+  const u32 cnt = (u32)__popcll(__ballot(kept));
+  if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const u32 t = part[0] + part[1] + part[2] + part[3];
+    if (t) atomicAdd(&rank_kept[r], t);
+  }
+}
+void launch_shard_unpack_codes(const uint8_t* blocks, u32 block_bytes, u32 N, u32 n, uint8_t* codes, u32* rank_kept, hipStream_t s) {
+  if (n == 0) return;
+  const u32 per = (n + N - 1) / N;
+  hipLaunchKernelGGL(shard_unpack_codes_kernel, dim3((per + 255) / 256, N), dim3(256), 0, s, blocks, block_bytes, N, n, codes,
+                     rank_kept);
 }
 
 __global__ void __launch_bounds__(256) shard_match_flags_kernel(const uint8_t* __restrict__ codes, u32 n, u32* __restrict__ flags) {
@@ -54,40 +87,73 @@ void launch_shard_keep_flags(const uint8_t* codes, const u32* prefix_f, const u3
                      keep_by_slot);
 }
 
-// frame[0, K) <- 0, then the own points at their final indices: two kernels, because the zeroing must be complete
-// before any point is placed (K is only known on the device, so a hipMemsetAsync cannot be sized by the host)
-__global__ void __launch_bounds__(256) shard_zero_frame_kernel(unsigned long long* __restrict__ words, const u32* __restrict__ n_points,
-                                                               u32 frame_cap) {
-  u32 K = *n_points;
-  if (K > frame_cap) K = frame_cap;
-  const size_t total = (size_t)K * (sizeof(DevPoint) / 8);
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) words[i] = 0ull;
-}
-__global__ void __launch_bounds__(256) shard_place_kernel(const u32* __restrict__ own_w, const u32* __restrict__ keep,
-                                                          const DevPoint* __restrict__ local_pts, const u32* __restrict__ n_local,
-                                                          u32 max_local, const u32* __restrict__ prefix_f,
-                                                          const u32* __restrict__ n_matches, const u32* __restrict__ prefix_g, u32 T,
-                                                          DevPoint* __restrict__ frame, u32 frame_cap) {
+// own block of exchange 2: [count (u64) | kept points in any order], each point with its final index in seq (as
+// compact_points_kernel numbers them).  The count word is the append cursor (zero on entry; one atomic per wave).  Thread 0 also
+// publishes the block length of the exchange -- the largest kept count among the ranks -- and clears the per-rank counts for
+// the next tick (every workgroup of shard_unpack_codes_kernel finished long ago: same stream).
+__global__ void __launch_bounds__(256) shard_pack_kernel(const u32* __restrict__ own_w, const u32* __restrict__ keep,
+                                                         const DevPoint* __restrict__ local_pts, const u32* __restrict__ n_local,
+                                                         u32 max_local, const u32* __restrict__ prefix_f,
+                                                         const u32* __restrict__ n_matches, const u32* __restrict__ prefix_g, u32 T,
+                                                         unsigned long long* __restrict__ block, u32 block_cap, u32 frame_cap,
+                                                         u32* __restrict__ rank_kept, u32 N, u32* __restrict__ max_kept_out) {
   const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k == 0) {
+    u32 mx = 0;
+    for (u32 r = 0; r < N; ++r) { mx = max(mx, rank_kept[r]); rank_kept[r] = 0u; }
+    *max_kept_out = mx;
+  }
   u32 n = *n_local;
   if (n > max_local) n = max_local;
-  if (k >= n || !keep[k]) return;
-  const u32 s = stride_slot(prefix_f[own_w[k]], *n_matches, T);
-  const u32 idx = prefix_g[s];
-  if (idx >= frame_cap) return;
+  const bool mine = k < n && keep[k];
+  u32 idx = 0;
+  if (mine) {
+    const u32 s = stride_slot(prefix_f[own_w[k]], *n_matches, T);
+    idx = prefix_g[s];
+  }
+  const bool put = mine && idx < frame_cap;
+  const u64 m = __ballot(put);
+  if (m == 0) return;
+  const u32 lane = threadIdx.x & 63u;
+  u32 base = 0;
+  if (lane == (u32)__ffsll((long long)m) - 1u) base = (u32)atomicAdd(block, (unsigned long long)__popcll(m));
+  base = __shfl(base, __ffsll((long long)m) - 1);
+  if (!put) return;
+  const u32 pos = base + (u32)__popcll(m & ((1ull << lane) - 1ull));
+  if (pos >= block_cap) return;
   DevPoint o = local_pts[k];
-  o.seq = idx;  // as compact_points_kernel
-  frame[idx] = o;
+  o.seq = idx;
+  reinterpret_cast<DevPoint*>(block + 1)[pos] = o;
 }
-void launch_shard_place(const u32* own_w, const u32* keep, const DevPoint* local_pts, const u32* n_local, u32 max_local,
-                        const u32* prefix_f, const u32* n_matches, const u32* prefix_g, const u32* n_points, u32 T, DevPoint* frame,
-                        u32 frame_cap, hipStream_t s) {
-  static_assert(sizeof(DevPoint) % 8 == 0, "frame is exchanged as 64-bit words");
-  if (max_local == 0 || frame_cap == 0) return;
-  hipLaunchKernelGGL(shard_zero_frame_kernel, dim3(512), dim3(256), 0, s, reinterpret_cast<unsigned long long*>(frame), n_points,
+void launch_shard_pack(const u32* own_w, const u32* keep, const DevPoint* local_pts, const u32* n_local, u32 max_local,
+                       const u32* prefix_f, const u32* n_matches, const u32* prefix_g, u32 T, unsigned long long* block, u32 block_cap,
+                       u32 frame_cap, u32* rank_kept, u32 N, u32* max_kept_out, hipStream_t s) {
+  static_assert(sizeof(DevPoint) % 8 == 0, "blocks are exchanged as 64-bit words");
+  hipLaunchKernelGGL(shard_pack_kernel, dim3(max_local ? (max_local + 255) / 256 : 1), dim3(256), 0, s, own_w, keep, local_pts, n_local,
+                     max_local, prefix_f, n_matches, prefix_g, T, block, block_cap, frame_cap, rank_kept, N, max_kept_out);
+}
+
+// after exchange 2: every block's points to frame[seq]; one thread per 64-bit word (13 per point)
+__global__ void __launch_bounds__(256) shard_scatter_kernel(const unsigned long long* __restrict__ blocks, size_t block_words, u32 max_kept,
+                                                            DevPoint* __restrict__ frame, u32 frame_cap) {
+  constexpr u32 WP = sizeof(DevPoint) / 8;
+  const unsigned long long* blk = blocks + (size_t)blockIdx.y * block_words;
+  u32 cnt = (u32)blk[0];
+  if (cnt > max_kept) cnt = max_kept;
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  const u32 kk = t / WP, wd = t % WP;
+  if (kk >= cnt) return;
+  const DevPoint* p = reinterpret_cast<const DevPoint*>(blk + 1) + kk;
+  const u32 idx = p->seq;
+  if (idx >= frame_cap) return;
+  reinterpret_cast<unsigned long long*>(frame + idx)[wd] = reinterpret_cast<const unsigned long long*>(p)[wd];
+}
+void launch_shard_scatter(const unsigned long long* blocks, size_t block_words, u32 N, u32 max_kept, DevPoint* frame, u32 frame_cap,
+                          hipStream_t s) {
+  if (max_kept == 0 || frame_cap == 0) return;
+  constexpr u32 WP = sizeof(DevPoint) / 8;
+  hipLaunchKernelGGL(shard_scatter_kernel, dim3((max_kept * WP + 255) / 256, N), dim3(256), 0, s, blocks, block_words, max_kept, frame,
                      frame_cap);
-  hipLaunchKernelGGL(shard_place_kernel, dim3((max_local + 255) / 256), dim3(256), 0, s, own_w, keep, local_pts, n_local, max_local,
-                     prefix_f, n_matches, prefix_g, T, frame, frame_cap);
 }
 
 }  // namespace esvo

@@ -3,16 +3,17 @@
 
   TickShardedEsvo  ticks dealt round-robin to the ranks, one all-gather of the round's frames (throughput scaling)
   ShardedEsvo      ONE tick split over the ranks -- per-event work by slot, per-cell work by image row band -- with
-                   the two integer sums of esvo_shard_exchange (latency scaling of a single tick; see below)
+                   the two all-gathers of esvo_shard_exchange (latency scaling of a single tick; see below)
 
 ShardedEsvo:  PyTorch is plumbing here: device-pointer views + collectives; every
 kernel is in libesvo_hip.so.
 
 Per tick (see esvo_shard_tick_phase in include/esvo_hip.h):
-    phase 0  BM + LM + culling of every world-th slot      -> sum of one byte per slot (matched, kept)
-    phase 1  frame order from the bytes, own points placed  -> sum of the frame (104 B per kept point)
-    phase 2  window policy, fusion + clean + regularisation of the row band (halo rows recomputed locally)
-Entries of other ranks are zero in both buffers, so SUM over 64-bit integer words is an exact union.
+    phase 0  BM + LM + culling of every world-th slot        -> all-gather: one byte per own slot (matched, kept)
+    phase 1  frame order from all bytes, own kept points packed -> all-gather: [count | points], block = largest kept count
+    phase 2  points to their frame positions, window policy, fusion + clean + regularisation of the row band (halo rows
+             recomputed locally)
+No zero padding travels except the imbalance between the ranks' kept counts.
 """
 import numpy as np
 
@@ -43,12 +44,16 @@ def band_of(rank, world, height):
     return min(rank * rows, height), min((rank + 1) * rows, height)
 
 
-# ---- the exchange primitives (backend agnostic: exercised with gloo on CPU in tests/test_dist.py) ----
-def merge_disjoint_(t, group=None):
-    """all-reduce(SUM) of an integer tensor whose non-owned entries are zero == union of the owners' entries"""
+# ---- the exchange primitive (backend agnostic: exercised with gloo on CPU in tests/test_dist.py) ----
+def gather_blocks_(recv, send, world, group=None):
+    """all-gather of one fixed-size block per rank into `recv` (rank-major): ncclAllGather under the nccl backend, a list
+    gather under gloo (which has no all_gather_into_tensor on CPU tensors)"""
     import torch.distributed as dist
-    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-    return t
+    if recv.device.type == "cpu":
+        dist.all_gather(list(recv.view(world, -1).unbind(0)), send, group=group)
+    else:
+        dist.all_gather_into_tensor(recv, send, group=group)
+    return recv
 
 
 class ShardedEsvo:
@@ -72,7 +77,8 @@ class ShardedEsvo:
         if self.y1 <= self.y0:
             raise lib.EsvoError(f"rank {rank} of {world} would own no image rows (H={self.H})")
         self.dev.set_band(self.y0, self.y1, rank, world)
-        merge_disjoint_(torch.zeros(1024, dtype=torch.int64, device=device), group)  # communicator set-up, untimed
+        gather_blocks_(torch.zeros(1024 * world, dtype=torch.int64, device=device), torch.zeros(1024, dtype=torch.int64, device=device),
+                       world, group)  # communicator set-up, untimed
         if device == "cuda":
             torch.cuda.synchronize()
     # replicated stages: every rank ingests all events and renders the full Time Surfaces
@@ -92,9 +98,10 @@ class ShardedEsvo:
         return self.dev.stats()
 
     def _exchange(self):
-        ptr, nbytes = self.dev.shard_exchange()
-        if nbytes:
-            merge_disjoint_(device_tensor(ptr, nbytes // 8, "<i8", self.device), self.group)
+        snd, rcv, nbytes = self.dev.shard_exchange()
+        if nbytes and self.world > 1:
+            gather_blocks_(device_tensor(rcv, self.world * nbytes // 8, "<i8", self.device),
+                           device_tensor(snd, nbytes // 8, "<i8", self.device), self.world, self.group)
 
     def tick(self, t_ns, stamps, poses):
         d = self.dev
@@ -297,7 +304,7 @@ class NativeTickSharded:
 
 
 class NativeBandSharded:
-    """ShardedEsvo with the two sums (ncclAllReduce) and the all-gather of the DepthMap bands in C."""
+    """ShardedEsvo with the two all-gathers of a tick and the all-gather of the DepthMap bands in C (ncclAllGather)."""
 
     counts_are_local = False
 

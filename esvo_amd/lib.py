@@ -153,7 +153,7 @@ def load():
     lib.esvo_map_get_last_frame.argtypes = [vp, vp, sz, psz]
     lib.esvo_get_stats.argtypes = [vp, vp]
     lib.esvo_shard_set_band.argtypes = [vp, i32, i32, i32, i32]
-    lib.esvo_shard_exchange.argtypes = [vp, vp, vp]
+    lib.esvo_shard_exchange.argtypes = [vp, vp, vp, vp]
     lib.esvo_shard_tick_phase.argtypes = [vp, i32, u64, vp, vp, sz]
     lib.esvo_map_front.argtypes = [vp, u64, vp, vp, sz, psz]
     lib.esvo_map_front_frame.argtypes = [vp, vp]
@@ -616,10 +616,11 @@ class Esvo:
         self._ck(self.lib.esvo_shard_set_band(self.h, int(y0), int(y1), int(shard), int(n_shards)))
 
     def shard_exchange(self):
-        """(device pointer, bytes) of the buffer to sum over the ranks before the next phase; bytes == 0: nothing"""
-        ptr, nb = C.c_void_p(), C.c_size_t()
-        self._ck(self.lib.esvo_shard_exchange(self.h, C.byref(ptr), C.byref(nb)))
-        return (ptr.value or 0), int(nb.value)
+        """(send pointer, receive pointer, block bytes) of the all-gather due before the next phase (device pointers; block
+        bytes == 0: nothing to do; one shard: receive aliases send)"""
+        snd, rcv, nb = C.c_void_p(), C.c_void_p(), C.c_size_t()
+        self._ck(self.lib.esvo_shard_exchange(self.h, C.byref(snd), C.byref(rcv), C.byref(nb)))
+        return (snd.value or 0), (rcv.value or 0), int(nb.value)
 
     def shard_phase(self, phase, t_ns=0, stamps=None, poses=None):
         if phase == 0:

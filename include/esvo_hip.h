@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define ESVO_HIP_ABI_VERSION 3
+#define ESVO_HIP_ABI_VERSION 4
 
 typedef enum esvo_status_t {
   ESVO_OK = 0,
@@ -413,23 +413,27 @@ void esvo_abi_sizes(size_t out[8]);
 int esvo_shard_set_band(esvo_handle h, int row_begin, int row_end, int shard, int n_shards);
 /* Three-phase tick for sharded operation.  Every rank stages ALL events, renders the full Time
  * Surfaces and keeps the full fusion window (replicated, a few % of a tick); the per-event work is dealt by
- * slot, the per-cell work by row band.  After phase 0 and after phase 1 the caller sums ONE device buffer
- * over the ranks (esvo_shard_exchange: 64-bit integer words, entries of other ranks are zero, so SUM is an
- * exact union; torch.distributed / RCCL all-reduce issued on the handle's stream, see esvo_amd/dist.py):
+ * slot, the per-cell work by row band.  After phase 0 and after phase 1 the caller ALL-GATHERS one fixed-size
+ * block per rank (esvo_shard_exchange; ncclAllGather / torch.distributed all_gather_into_tensor issued on the
+ * handle's stream, see esvo_amd/dist.py):
  *   phase 0: poses + event selection + block matching + LM refinement + culling of the shard's slots
- *            -> exchange: one byte per slot (bit 0 matched, bit 1 point kept), n rounded up to 8 bytes
- *   phase 1: the tick's frame in the reference's order (EventBM.cpp:289-308 and
- *            DepthProblemSolver.cpp:75-90 permutations, derived from the bytes), own points placed
- *            -> exchange: the frame, last_points x sizeof(esvo_depth_point_t) bytes
- *   phase 2: window policy (identical on every rank), fusion + clean + regularisation of the band; the
- *            halo rows the band's neighbourhoods read (2 + RegularizationRadius) are recomputed locally,
- *            which is exact because the DepthFrame is rebuilt from the window at every tick.
+ *            -> exchange 1: one byte per OWN slot (bit 0 matched, bit 1 point kept), slots shard, shard + n_shards ...
+ *               back to back: ceil(n / n_shards) bytes rounded up to 8
+ *   phase 1: the tick's frame order (EventBM.cpp:289-308 and DepthProblemSolver.cpp:75-90 permutations, derived
+ *            from all ranks' bytes), own kept points packed with their final index
+ *            -> exchange 2: [count (8 B) | points], 8 + K x sizeof(esvo_depth_point_t) bytes with K = the largest
+ *               kept count among the ranks (every rank derives it from exchange 1)
+ *   phase 2: every block's points to their place in the frame; window policy (identical on every rank), fusion +
+ *            clean + regularisation of the band; the halo rows the band's neighbourhoods read
+ *            (2 + RegularizationRadius) are recomputed locally, which is exact because the DepthFrame is rebuilt
+ *            from the window at every tick.
  * The DepthMap stays sharded; esvo_map_get_depth_points returns the band's elements (seq = global
  * creation order, so bands merge by sorting on it).  stats.last_solved counts the shard's own problems. */
 int esvo_shard_tick_phase(esvo_handle h, int phase, uint64_t t_ns, const uint64_t* pose_t_ns,
                           const double* pose_T, size_t m);
-/* The buffer to sum over the ranks before the next phase (n_bytes is a multiple of 8; 0 = nothing). */
-int esvo_shard_exchange(esvo_handle h, void** d_ptr, size_t* n_bytes);
+/* The exchange due before the next phase: all-gather block_bytes (a multiple of 8; 0 = nothing to do) from d_send of
+ * every rank into d_recv, rank-major.  With n_shards == 1 d_recv aliases d_send and the call may be skipped. */
+int esvo_shard_exchange(esvo_handle h, void** d_send, void** d_recv, size_t* block_bytes);
 
 /* ---- Multi-GPU exchange behind the C-ABI: one process per GPU, RCCL over xGMI ------------------
 

@@ -1,4 +1,4 @@
-"""world_size-2 tests of the multi-GPU exchange steps on CPU (gloo): the two sums ShardedEsvo runs between
+"""world_size-2 tests of the multi-GPU exchange steps on CPU (gloo): the two all-gathers ShardedEsvo runs between
 the phases of a sharded tick (on host tensors here), and the band bookkeeping."""
 import os
 
@@ -18,23 +18,37 @@ def _worker(rank, world, port, height, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         rng = np.random.default_rng(5)
-        n = 1000 + height  # not a multiple of 8: the byte buffer is padded to whole 64-bit words
+        n = 1000 + height  # not a multiple of 8 * world: blocks are padded to whole 64-bit words
         words = DEPTH_POINT_DTYPE.itemsize // 8
-        # exchange 1: one byte per slot (bit 0 matched, bit 1 kept); slot w belongs to rank w % world
+        # exchange 1: one byte per OWN slot (bit 0 matched, bit 1 kept), slots rank, rank + world ... back to back
         codes_ref = rng.choice(np.array([0, 1, 3], np.uint8), n)
-        mine = np.zeros((n + 7) // 8 * 8, np.uint8)
-        own = np.arange(n) % world == rank
-        mine[:n][own] = codes_ref[own]
-        t = torch.from_numpy(mine.view(np.int64))
-        edist.merge_disjoint_(t)
-        ok1 = np.array_equal(mine[:n], codes_ref) and not mine[n:].any()
-        # exchange 2: the frame, 13 words per kept point (any bit pattern, negative words included), zero elsewhere
+        blk = (-(-n // world) + 7) // 8 * 8
+        mine = np.zeros(blk, np.uint8)
+        own = codes_ref[rank::world]
+        mine[: len(own)] = own
+        recv = np.zeros(world * blk, np.uint8)
+        edist.gather_blocks_(torch.from_numpy(recv.view(np.int64)), torch.from_numpy(mine.view(np.int64)), world)
+        back = np.zeros(n, np.uint8)
+        for r in range(world):
+            back[r::world] = recv[r * blk: r * blk + len(range(r, n, world))]
+        ok1 = np.array_equal(back, codes_ref)
+        # exchange 2: [count | kept points] per rank, block length = the largest kept count (13 words per point, any bit
+        # pattern, negative words included); the receiver places every point by the index it carries
         kept = np.flatnonzero(codes_ref == 3)
         frame_ref = rng.integers(-2**63, 2**63 - 1, (len(kept), words), dtype=np.int64)
-        frame = np.where((kept % world == rank)[:, None], frame_ref, 0).astype(np.int64).reshape(-1)
-        t = torch.from_numpy(frame)
-        edist.merge_disjoint_(t)
-        ok2 = np.array_equal(frame.reshape(-1, words), frame_ref)
+        counts = [int((kept % world == r).sum()) for r in range(world)]
+        bw = 1 + words * max(counts)
+        send = np.zeros(bw, np.int64)
+        idx_mine = np.flatnonzero(kept % world == rank)
+        send[0] = len(idx_mine)
+        send[1: 1 + words * len(idx_mine)] = frame_ref[idx_mine].reshape(-1)
+        recv2 = np.zeros(world * bw, np.int64)
+        edist.gather_blocks_(torch.from_numpy(recv2), torch.from_numpy(send), world)
+        frame = np.zeros_like(frame_ref)
+        for r in range(world):
+            c = int(recv2[r * bw])
+            frame[np.flatnonzero(kept % world == r)] = recv2[r * bw + 1: r * bw + 1 + words * c].reshape(c, words)
+        ok2 = [int(recv2[r * bw]) for r in range(world)] == counts and np.array_equal(frame, frame_ref)
         q.put((rank, ok1, ok2))
     finally:
         dist.destroy_process_group()
@@ -152,29 +166,36 @@ def test_tick_interleaved_driver_gloo_world2(n_ticks):
 
 # ---- band driver (dist.ShardedEsvo) on CPU: the phase / exchange protocol with a host-memory stand-in ---------------
 class _FakeBand:
+    """host-memory stand-in for lib.Esvo's three-phase tick: hands out (send, receive, block bytes) as esvo_shard_exchange does"""
+
     def __init__(self, rank, world):
-        self.rank, self.world, self.phase_log, self.buf = rank, world, [], None
+        self.rank, self.world, self.phase_log = rank, world, []
+        self.send = self.recv = None
 
     def set_band(self, y0, y1, shard, n_shards):
         self.band = (y0, y1, shard, n_shards)
 
     def shard_phase(self, phase, t_ns=0, stamps=None, poses=None):
         self.phase_log.append(phase)
-        if phase == 0:      # one byte per slot, own slots only (w % world == rank), padded to 8
+        if phase == 0:      # one byte per own slot (w = rank + k world), padded to whole words
             n = 21
-            b = np.zeros(24, np.uint8)
-            own = np.arange(n) % self.world == self.rank
-            b[:n][own] = 1 + 2 * (np.arange(n)[own] % 2)
-            self.buf = b.view(np.int64)
-        elif phase == 1:    # the frame: own points at their final indices, zero elsewhere
-            f = np.zeros((5, 13), np.int64)
-            f[self.rank::self.world] = (np.arange(5)[self.rank::self.world, None] + 1) * 100 + np.arange(13)
-            self.buf = f.reshape(-1)
+            own = np.arange(n)[self.rank::self.world]
+            b = np.zeros((-(-n // self.world) + 7) // 8 * 8, np.uint8)
+            b[: len(own)] = 1 + 2 * (own % 2)
+            self.send = b.view(np.int64)
+        elif phase == 1:    # [count | own points], block length = the largest count among the ranks
+            mine = np.arange(5)[self.rank::self.world]
+            most = len(np.arange(5)[0::self.world])
+            f = np.zeros(1 + 13 * most, np.int64)
+            f[0] = len(mine)
+            f[1: 1 + 13 * len(mine)] = ((mine[:, None] + 1) * 100 + np.arange(13)).reshape(-1)
+            self.send = f
         else:
-            self.buf = None
+            self.send = None
+        self.recv = None if self.send is None else np.zeros(self.world * len(self.send), np.int64)
 
     def shard_exchange(self):
-        return (self.buf.ctypes.data, self.buf.nbytes) if self.buf is not None else (0, 0)
+        return (self.send.ctypes.data, self.recv.ctypes.data, self.send.nbytes) if self.send is not None else (0, 0, 0)
 
 
 class _Rig:
@@ -193,15 +214,23 @@ def _band_worker(rank, world, port, q):
         orig = fake.shard_phase
 
         def spy(phase, *a, **k):
-            if fake.buf is not None:
-                snap[phase - 1] = fake.buf.copy()      # what the previous phase's buffer looked like after the exchange
+            if fake.recv is not None:
+                snap[phase - 1] = fake.recv.copy()     # what the previous phase's receive buffer held after the exchange
             orig(phase, *a, **k)
         fake.shard_phase = spy
         drv.tick(1, np.zeros(1, np.uint64), np.zeros((1, 16)))
         ok &= fake.phase_log == [0, 1, 2]
-        codes = snap[0].view(np.uint8)[:21]
-        ok &= bool((codes == 1 + 2 * (np.arange(21) % 2)).all())                       # union of both ranks' bytes
-        ok &= bool((snap[1].reshape(5, 13) == (np.arange(5)[:, None] + 1) * 100 + np.arange(13)).all())
+        blk = len(snap[0]) // world
+        codes = np.zeros(21, np.uint8)
+        for r in range(world):
+            codes[r::world] = snap[0][r * blk: (r + 1) * blk].view(np.uint8)[: len(range(r, 21, world))]
+        ok &= bool((codes == 1 + 2 * (np.arange(21) % 2)).all())                       # every rank's bytes, in place
+        bw = len(snap[1]) // world
+        frame = np.zeros((5, 13), np.int64)
+        for r in range(world):
+            c = int(snap[1][r * bw])
+            frame[r::world] = snap[1][r * bw + 1: r * bw + 1 + 13 * c].reshape(c, 13)
+        ok &= bool((frame == (np.arange(5)[:, None] + 1) * 100 + np.arange(13)).all())
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()

@@ -3,7 +3,7 @@
 * real RCCL with a one-rank communicator: ncclGetUniqueId / ncclCommInitRank / ncclAllGather run from libesvo_hip.so;
 * several ranks = several handles driven from threads, their collectives supplied as callbacks that rendezvous in-process
   (esvo_comm_init_callbacks): the round logic, the in-band counts, block growth, partial rounds, buffer reuse, the band
-  mode's two sums and the all-gather of the DepthMap bands are the code a node with one process per GPU runs.
+  mode's two all-gathers per tick and the all-gather of the DepthMap bands are the code a node with one process per GPU runs.
 Every tick's DepthMap must equal the single-handle one bit for bit."""
 import threading
 

@@ -532,3 +532,50 @@ def test_fusion_front_with_tiny_capacities_gives_the_same_maps(dsec_rig, dsec_st
     assert len(ref[-1]) > 1000
     for a, b in zip(ref, got):
         _same_map(a, b)
+
+
+def test_block_matching_only_mode_refuses_before_any_state_flips(upenn_rig, upenn_stream):
+    """esvo_map_tick_bm_only keeps maxNumFusionFrames un-culled frames whatever the fusion strategy; the window ring is sized
+    by max_window_points.  A ring too small for that window is reported at ENTRY (ESVO_ERR_CAPACITY, 'max_window_points') --
+    before the tick's parities flip -- and the handle goes on working: after a reset a normal tick gives the oracle's map."""
+    from esvo_amd import lib
+    from oracle import oracle as O
+    p, _ = params.make_params(params.PRESETS["mvstereo_upenn"], upenn_rig, process_event_num=600)
+    p.max_fusion_frames = 50
+    p.max_window_points = 800      # ring = max(800, E) + 2 E with E = max_events_per_tick: two or three 600-match frames
+    dev = lib.Esvo(p, upenn_rig)
+    dev.ts_push_events(0, upenn_stream.ev_left)
+    dev.ts_push_events(1, upenn_stream.ev_right)
+    refused = None
+    for k in range(12):
+        t = upenn_stream.t0_ns + (60 + 10 * k) * 1_000_000
+        dev.ts_render(0, t, download=False)
+        dev.ts_render(1, t, download=False)
+        stamps, poses = rostime.pose_table(upenn_stream.pose, t, p.bm_half_slice_thickness)
+        dev.set_observation(t, None, None, upenn_stream.pose(t))
+        try:
+            dev.tick_bm_only(t, stamps, poses)
+        except lib.EsvoError as e:
+            assert "max_window_points" in str(e), str(e)
+            refused = k
+            break
+    assert refused is not None and refused >= 1, "the ring was expected to run out within 12 frames of 50"
+    assert dev.stats().last_window_frames >= 1      # the accepted frames are still the window
+    dev.reset()                     # and after a reset the handle maps as a fresh one does
+    dev.ts_push_events(0, upenn_stream.ev_left)
+    dev.ts_push_events(1, upenn_stream.ev_right)
+    t = upenn_stream.t0_ns + 60_000_000
+    dev.ts_render(0, t, download=False)
+    dev.ts_render(1, t, download=False)
+    stamps, poses = rostime.pose_table(upenn_stream.pose, t, p.bm_half_slice_thickness)
+    dev.set_observation(t, None, None, upenn_stream.pose(t))
+    dev.tick(t, stamps, poses)
+    fresh = O.OracleMapper(p, upenn_rig)
+    fresh.set_mode(True, True)
+    ots2 = [O.OracleTS(upenn_rig.width, upenn_rig.height), O.OracleTS(upenn_rig.width, upenn_rig.height)]
+    ots2[0].push(upenn_stream.ev_left)
+    ots2[1].push(upenn_stream.ev_right)
+    _oracle_tick(O, fresh, ots2, upenn_rig, upenn_stream, p, t)
+    idx = O.select_events(upenn_stream.ev_left, t, p.bm_half_slice_thickness, p.process_event_num)
+    fresh.tick(upenn_stream.ev_left[idx])
+    _same_map(dev.get_map(), fresh.get_map())

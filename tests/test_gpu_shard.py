@@ -1,5 +1,5 @@
 """Sharded == unsharded on ONE GPU: G handles with disjoint event shards / row bands run the three-phase
-tick, the two sums between the phases are emulated with torch ops on the same device buffers the real
+tick, the two all-gathers between the phases are emulated with torch copies on the same device buffers the real
 run hands to RCCL (esvo_shard_exchange).  The merged DepthMap must equal the unsharded one bit for bit (gpurun exposes a
 single GPU; the multi-process path itself is covered by tests/test_dist.py with gloo)."""
 import numpy as np
@@ -12,31 +12,26 @@ pytestmark = pytest.mark.gpu
 F64 = ["inv_depth", "scale2", "nu", "variance", "residual", "x", "p_cam"]
 
 
-def _emulated_sum(shards, whole_words=False):
-    """what dist.ShardedEsvo._exchange does with an all-reduce: 64-bit integer SUM of the ranks' buffers"""
+def _emulated_gather(shards):
+    """what dist.ShardedEsvo._exchange does with an all-gather: every rank's block into every rank's receive buffer,
+    rank-major.  Returns the list of blocks (int64 tensors), or None when nothing is due."""
     import torch
     from esvo_amd import dist as edist
     for d in shards:
         d.synchronize()
-    bufs = []
-    for d in shards:
-        ptr, nbytes = d.shard_exchange()
-        bufs.append(edist.device_tensor(ptr, nbytes // 8, "<i8") if nbytes else None)
-    sizes = {0 if b is None else b.numel() for b in bufs}
-    assert len(sizes) == 1, sizes  # every rank derives the same size
-    if bufs[0] is None:
+    ex = [d.shard_exchange() for d in shards]
+    sizes = {e[2] for e in ex}
+    assert len(sizes) == 1, sizes  # every rank derives the same block length
+    nb = ex[0][2]
+    if nb == 0:
         return None
-    stack = torch.stack(bufs)
-    by = stack.view(torch.uint8).view(len(bufs), -1)
-    if not whole_words:
-        assert int(((by != 0).sum(0) > 1).sum()) == 0  # byte-wise disjoint: the word sums cannot carry
-    else:
-        assert int(((stack.view(len(bufs), -1, 13) != 0).any(2).sum(0) > 1).sum()) == 0  # every point from ONE shard
-    tot = stack.sum(0)
-    for b in bufs:
-        b.copy_(tot)
+    assert nb % 8 == 0
+    blocks = [edist.device_tensor(snd, nb // 8, "<i8").clone() for snd, _, _ in ex]
+    for _, rcv, _ in ex:
+        for r, blk in enumerate(blocks):
+            edist.device_tensor(rcv + r * nb, nb // 8, "<i8").copy_(blk)
     torch.cuda.synchronize()
-    return tot
+    return blocks
 
 
 @pytest.mark.parametrize("preset,rig_fix,stream_fix,n_ev,G", [
@@ -67,16 +62,25 @@ def test_logical_shards_equal_unsharded(request, preset, rig_fix, stream_fix, n_
             d.set_observation(t, None, None, stream.pose(t))
         t_prev = t + 5_000_000
         ref.tick(t, stamps, poses)
-        for d in shards:  # BM + LM of the own slots -> sum of the (matched, kept) bytes
+        for d in shards:  # BM + LM of the own slots -> all-gather of the (matched, kept) bytes of the own slots
             d.shard_phase(0, t, stamps, poses)
-        codes = _emulated_sum(shards)
-        for d in shards:  # frame order, own points placed -> sum of the frame
+        codes = _emulated_gather(shards)
+        for d in shards:  # frame order from all bytes, own kept points packed -> all-gather of [count | points]
             d.shard_phase(1)
-        assert shards[0].stats().last_events_in == ref.stats().last_events_in
-        assert codes.numel() * 8 == (ref.stats().last_events_in + 7) // 8 * 8
+        n_in = ref.stats().last_events_in
+        assert shards[0].stats().last_events_in == n_in
+        assert codes[0].numel() * 8 == (-(-n_in // G) + 7) // 8 * 8      # ceil(n / G) bytes, whole words
+        by = [c.view(torch.uint8).cpu().numpy() for c in codes]
+        n_matched = sum(int((b[: len(range(g, n_in, G))] & 1).sum()) for g, b in enumerate(by))
+        kept = [int(((b[: len(range(g, n_in, G))] >> 1) & 1).sum()) for g, b in enumerate(by)]
+        assert n_matched == ref.stats().last_matches
         assert shards[0].stats().last_matches == ref.stats().last_matches
         assert sum(d.stats().last_solved for d in shards) == ref.stats().last_solved
-        _emulated_sum(shards, whole_words=True)
+        pts = _emulated_gather(shards)
+        if ref.stats().last_points:
+            assert pts[0].numel() == 1 + 13 * max(kept), (pts[0].numel(), kept)   # block = the largest kept count, no more
+            assert [int(b[0]) for b in pts] == kept                              # in-band counts
+            assert sum(kept) == ref.stats().last_points
         for d in shards:
             d.shard_phase(2)
         assert shards[0].stats().last_points == ref.stats().last_points
