@@ -20,8 +20,10 @@ void invert3x3(const double* P, double* Kinv, double* Kinv_t) {
 int validate_params(const esvo_params_t* p, std::string& why) {
   if (p->ls_norm != ESVO_LSNORM_TDIST && p->ls_norm != ESVO_LSNORM_L2) { why = "LSnorm must be Tdist or l2 (DepthProblemSolver.cpp:121-131 exits on anything else)"; return ESVO_ERR_UNSUPPORTED; }
   if (p->bm_step < 1) { why = "BM_step must be >= 1"; return ESVO_ERR_INVALID_ARG; }
-  if (p->patch_size_x != 15 || p->patch_size_y != 7) { why = "patch size must be 15x7 (every shipped config)"; return ESVO_ERR_UNSUPPORTED; }
-  if (p->median_blur_kernel_size < 0 || p->median_blur_kernel_size > 1) { why = "median_blur_kernel_size must be 0 or 1"; return ESVO_ERR_UNSUPPORTED; }
+  // 15 x 7 (every shipped configuration) runs the register-layout kernels; any other size the general ones (kernels_lm_any.hip:
+  // lane = column, three [rows][64] f64 arrays in LDS)
+  if (p->patch_size_x < 1 || p->patch_size_x > 64 || p->patch_size_y < 1 || p->patch_size_y > 40) { why = "patch size must be within 1..64 x 1..40"; return ESVO_ERR_UNSUPPORTED; }
+  if (p->median_blur_kernel_size < 0 || p->median_blur_kernel_size > 3) { why = "median_blur_kernel_size must be 0..3 (kernel 2k + 1)"; return ESVO_ERR_UNSUPPORTED; }
   if (p->bm_max_disparity < p->bm_min_disparity || p->bm_min_disparity < 0) { why = "bad disparity range"; return ESVO_ERR_INVALID_ARG; }
   if (p->td_nu <= 2.0 || p->td_scale <= 0) { why = "Tdist_nu must be > 2 and Tdist_scale > 0"; return ESVO_ERR_INVALID_ARG; }
   if (p->num_threads < 1 || p->num_threads > 64) { why = "num_threads out of range"; return ESVO_ERR_INVALID_ARG; }

@@ -372,6 +372,196 @@ __global__ void __launch_bounds__(BM_BLOCK) bm_match_kernel(BmArgs a, DevParams 
 #endif
 }
 
+// ---- any patch size (patch_size_X x patch_size_Y: a run-time parameter upstream, code default 25 x 25, esvo_Mapping.cpp:38-39) ----
+// The same decisions in the same order as bm_match_kernel, written for generality: one wave per event, the left patch and the
+// right strip as plain bytes in LDS, every candidate's moments by byte loops, 64-bit integer moments (N Sxx reaches 2^31 from
+// 183 pixels on) and plain IEEE division / square root in the oracle's expression order (zncc_cost_int).
+__device__ inline double zncc_any(long long Sl, long long Sll, long long Sr, long long Srr, long long Slr, int N) {
+  const double n = (double)N;
+  const double varl = (double)(N * Sll - Sl * Sl) / (n * n);
+  const double varr = (double)(N * Srr - Sr * Sr) / (n * n);
+  const double sigl = sqrt(varl) + 1e-6, sigr = sqrt(varr) + 1e-6;
+  const double cov = (double)(N * Slr - Sl * Sr) / n;
+  return 0.5 * (1 - cov / (sigl * sigr) / n);
+}
+__device__ inline uint8_t ts_byte_clamped(const uint8_t* ts, int n_px, int idx) {  // only bytes no valid patch reads can be clamped
+  return ts[idx < 0 ? 0 : (idx >= n_px ? n_px - 1 : idx)];
+}
+
+template <bool COARSE, bool UPDOWN>
+__global__ void __launch_bounds__(64) bm_match_any_kernel(BmArgs a, DevParams p, int lds_strip_bytes) {
+  const int l = threadIdx.x;
+  const u32 w = blockIdx.x * (u32)p.ev_nshards + (u32)p.ev_shard;
+  const int W = p.W, H = p.H, wx = p.wx, wy = p.wy, N = wx * wy, hx = (wx - 1) / 2, hy = (wy - 1) / 2;
+  const int nd = p.dmax - p.dmin + 1;
+  uint8_t* ldsL = bm_smem;                                          // [wy][wx]
+  uint8_t* ldsR = bm_smem + ((N + 7) & ~7);                         // [wy][wx + nd - 1] / UPDOWN: [wy + nd - 1][wx]
+  double* cost_row = reinterpret_cast<double*>(ldsR + lds_strip_bytes);  // COARSE only: [nd]
+  const int SW = wx + nd - 1;  // strip row length (horizontal search)
+
+  bool ok = w < a.n;
+  u32 k = 0;
+  uint4 e = make_uint4(0, 0, 0, 0);
+  if (ok) {
+    k = stride_item(w, a.n, (u32)p.num_threads);
+    const u32 kk = a.sel ? a.sel[k] : k;
+    const u64 ei = (a.ev_reverse ? (a.ev_first - kk) : (a.ev_first + kk)) % a.ev_cap;
+    e = reinterpret_cast<const uint4*>(a.ev)[ei];
+  }
+  const int ex = e.x & 0xffffu, ey = e.x >> 16;
+  double xr = 0, yr = 0;
+  int x1 = 0, y1 = 0;
+  if (ok) ok = ex < W && ey < H;
+  if (ok) {
+    const float2 q = a.lut[ey * W + ex];  // EventBM.cpp:88
+    xr = (double)q.x;
+    yr = (double)q.y;
+    ok = !(xr < 0 || xr > (double)(W - 1) || yr < 0 || yr > (double)(H - 1));  // :90-92
+  }
+  if (ok && a.mask) ok = a.mask[(int)yr * W + (int)xr] > 125;  // :94
+  if (ok) {
+    x1 = (int)floor(xr);
+    y1 = (int)floor(yr);
+  }
+  if (ok) ok = !(x1 - hx < 1 || y1 - hy < 1 || x1 + hx >= W - 1 || y1 + hy >= H - 1);  // isValidPatch, :251-267
+  int reason = 0;
+  long long Sl = 0, Sll = 0;
+  if (ok) {  // left patch (block of wx x wy from the left-top corner, :101), its moments, the low-texture test (:104-109)
+    int cnt = 0, sl = 0, sll = 0;
+    for (int i = l; i < N; i += 64) {
+      const int py = i / wx, px = i - py * wx;
+      const int v = a.tsL[(y1 - hy + py) * W + (x1 - hx + px)];
+      ldsL[i] = (uint8_t)v;
+      cnt += v < 1;
+      sl += v;
+      sll += v * v;
+    }
+    cnt = wave_sum_i32(cnt);
+    Sl = wave_sum_i32(sl);
+    Sll = wave_sum_i64((long long)sll);
+    if ((double)cnt > 0.95 * (double)N) { ok = false; reason = 1; }
+  }
+  if (ok) {  // right strip
+    const int n_px = W * H;
+    if constexpr (UPDOWN) {  // rows y1 - dmax - hy ... , wx pixels each
+      const int rows = wy + nd - 1;
+      for (int i = l; i < rows * wx; i += 64) {
+        const int r = i / wx, px = i - r * wx;
+        ldsR[i] = ts_byte_clamped(a.tsR, n_px, (y1 - p.dmax - hy + r) * W + (x1 - hx + px));
+      }
+    } else {
+      const int xs0 = x1 - p.dmax - hx;
+      for (int i = l; i < wy * SW; i += 64) {
+        const int py = i / SW, q = i - py * SW;
+        ldsR[i] = ts_byte_clamped(a.tsR, n_px, (y1 - hy + py) * W + xs0 + q);
+      }
+    }
+  }
+  __syncthreads();
+  auto cand_valid = [&](int d) {  // isValidPatch of candidate d (:184-190)
+    if constexpr (UPDOWN) { const int y2 = y1 - d; return !(y2 - hy < 1 || y2 + hy >= H - 1); }
+    else { const int x2 = x1 - d; return !(x2 - hx < 1 || x2 + hx >= W - 1); }
+  };
+  double best = 1.0;  // ZNCC_MAX_
+  int bestd = -1;
+  if (ok) {
+    for (int d = p.dmin + l; d <= p.dmax; d += 64) {
+      if (!cand_valid(d)) {
+        if constexpr (COARSE) cost_row[d - p.dmin] = 1.0;
+        continue;
+      }
+      const int col0 = p.dmax - d;
+      u32 sr = 0, slr = 0;
+      unsigned long long srr = 0;
+      for (int py = 0; py < wy; ++py) {
+        const uint8_t* lrow = ldsL + py * wx;
+        const uint8_t* rrow = UPDOWN ? ldsR + (col0 + py) * wx : ldsR + py * SW + col0;
+        for (int px = 0; px < wx; ++px) {
+          const u32 lv = lrow[px], rv = rrow[px];
+          sr += rv;
+          srr += rv * rv;
+          slr += lv * rv;
+        }
+      }
+      const double cost = zncc_any(Sl, Sll, (long long)sr, (long long)srr, (long long)slr, N);
+      if constexpr (COARSE) cost_row[d - p.dmin] = cost;
+      else if (cost <= best) { best = cost; bestd = d; }  // :198
+    }
+  }
+  if constexpr (COARSE) {
+    __syncthreads();
+    if (ok) {
+      const int step = p.step;
+      const int nc = (p.dmax - p.dmin) / step + 1;
+      for (int j = l; j < nc; j += 64) {
+        const int d = p.dmin + j * step;
+        if (!cand_valid(d)) continue;
+        const double c = cost_row[d - p.dmin];
+        if (c <= best) { best = c; bestd = d; }
+      }
+      grp_argmin<64>(best, bestd);
+      bool found = bestd >= 0 && bestd - step >= p.dmin && bestd + step <= p.dmin + (nc - 1) * step;  // :207-219
+      if (found) found = cost_row[bestd - step - p.dmin] < 1.0 && cost_row[bestd + step - p.dmin] < 1.0 && best < p.zncc_thr;
+      if (!found) { ok = false; reason = 2; }
+      else {  // fine pass (:127-133)
+        const int cd = bestd;
+        double fb = 2.0;
+        int fd = -1;
+        for (int d = cd - (step - 1) + l; d <= cd + (step - 1); d += 64) {
+          if (!cand_valid(d)) continue;
+          const double c = cost_row[d - p.dmin];
+          if (c <= fb) { fb = c; fd = d; }
+        }
+        grp_argmin<64>(fb, fd);
+        best = fb;
+        bestd = fd;
+        if (!(best < p.zncc_thr)) { ok = false; reason = 3; }
+      }
+    }
+  } else if (ok) {
+    grp_argmin<64>(best, bestd);
+    if (!(bestd >= 0 && best < p.zncc_thr)) { ok = false; reason = 2; }
+  }
+  u32 pose_idx = 0;
+  if (ok) {  // StampTransformationMap_lower_bound, utils.h:66-71
+    const double te = time_to_sec(e.y, e.z);
+    u32 lo = 0, hi = a.n_pose;
+    while (lo < hi) {
+      const u32 mid = (lo + hi) >> 1;
+      if (a.pose_sec[mid] < te) lo = mid + 1; else hi = mid;
+    }
+    pose_idx = lo;
+    ok = lo < a.n_pose;  // :155-156
+  }
+  if (w < a.n && l == 0) {
+    a.out_flags[w] = ok ? 1u : 0u;
+    if (ok) {
+      esvo_match_t m;
+      const double disparity = (double)bestd;
+      const double depth = p.baseline_f / disparity;  // :152
+      m.x_left[0] = xr;
+      m.x_left[1] = yr;
+      m.inv_depth = 1.0 / depth;  // :158
+      m.cost = best;
+      m.disp = disparity;
+      m.event_idx = k;
+      m.pose_idx = pose_idx;
+      a.out_slots[w] = m;
+    }
+    if (a.fail_counters && reason)
+      atomicAdd(a.fail_counters + CNT_BM_FAIL + (reason - 1) * CNT_STRIPES + (blockIdx.x % CNT_STRIPES), 1u);
+  }
+}
+template <bool COARSE, bool UPDOWN>
+static void launch_bm_any(const BmArgs& a, const DevParams& p, hipStream_t s) {
+  const int nd = p.dmax - p.dmin + 1, N = p.wx * p.wy;
+  const int strip = ((UPDOWN ? (p.wy + nd - 1) * p.wx : p.wy * (p.wx + nd - 1)) + 7) & ~7;
+  const size_t lds = (size_t)((N + 7) & ~7) + strip + (COARSE ? (size_t)nd * 8 : 0);
+  const u32 own = (a.n > (u32)p.ev_shard) ? (a.n - (u32)p.ev_shard + (u32)p.ev_nshards - 1) / (u32)p.ev_nshards : 0;
+  if (own == 0) return;
+  hipLaunchKernelGGL((bm_match_any_kernel<COARSE, UPDOWN>), dim3(own), dim3(64), lds, s, a, p, strip);
+}
+
 template <int G, bool COARSE, bool UPDOWN>
 static void launch_bm_g(const BmArgs& a, const DevParams& p, int RD, hipStream_t s) {
   const int nd = p.dmax - p.dmin + 1;
@@ -403,6 +593,11 @@ void launch_bm_match(const BmArgs& a, const DevParams& p, hipStream_t s) {
     if (slots < bestSlots) { bestSlots = slots; bestG = G; }
   }
   const bool coarse = p.step > 1;
+  if (p.wx != 15 || p.wy != 7) {  // any other patch size: the general kernel
+    if (p.updown) { if (coarse) launch_bm_any<true, true>(a, p, s); else launch_bm_any<false, true>(a, p, s); }
+    else { if (coarse) launch_bm_any<true, false>(a, p, s); else launch_bm_any<false, false>(a, p, s); }
+    return;
+  }
   if (p.updown) {
     if (coarse) launch_bm_mode<true, true>(bestG, a, p, RD, s);
     else launch_bm_mode<false, true>(bestG, a, p, RD, s);

@@ -23,6 +23,7 @@
 // other case runs the literal loop.
 #include "common.hpp"
 #include "fdiv.hpp"
+#include "lm_common.hpp"
 
 
 namespace esvo {
@@ -457,50 +458,6 @@ __device__ bool lm_eval(const DevParams& p, const LmProblem& pr, double x, doubl
   }
   if constexpr (COUNT) *n_iter = iters;
   return false;
-}
-
-// internal::lmpar2 for n == 1 (Appendix B.1)
-__device__ inline double lm_lmpar2(double r, double diag, double qtf, double delta, double& par) {
-  const double dwarf = 2.2250738585072014e-308;
-  double x = qtf / r;
-  double wa2 = diag * x;
-  double dxnorm = fabs(wa2);
-  double fp = dxnorm - delta;
-  if (fp <= 0.1 * delta) { par = 0; return x; }
-  double wa1 = diag * wa2 / dxnorm;
-  wa1 = wa1 / r;
-  double temp = fabs(wa1);
-  double parl = fp / delta / temp / temp;
-  wa1 = r * qtf / diag;
-  const double gn = fabs(wa1);
-  double paru = gn / delta;
-  if (paru == 0.) paru = dwarf / ((delta < 0.1) ? delta : 0.1);
-  par = (par < parl) ? parl : par;   // std::max(par, parl)
-  par = (paru < par) ? paru : par;   // std::min(par, paru)
-  if (par == 0.) par = gn / dxnorm;
-  int it = 0;
-  while (true) {
-    ++it;
-    if (par == 0.) { const double c = 0.001 * paru; par = (dwarf < c) ? c : dwarf; }
-    const double ds = sqrt(par) * diag;
-    const double sdiag2 = r * r + ds * ds;
-    const double sdiag = sqrt(sdiag2);
-    x = r * qtf / sdiag2;
-    wa2 = diag * x;
-    dxnorm = fabs(wa2);
-    temp = fp;
-    fp = dxnorm - delta;
-    if (fabs(fp) <= 0.1 * delta || (parl == 0. && fp <= temp && temp < 0.) || it == 10) break;
-    wa1 = diag * (wa2 / dxnorm);
-    wa1 = wa1 / sdiag;
-    temp = fabs(wa1);
-    const double parc = fp / delta / temp / temp;
-    if (fp > 0.) parl = (parl < par) ? par : parl;
-    if (fp < 0.) paru = (par < paru) ? par : paru;
-    const double pc = par + parc;
-    par = (parl < pc) ? pc : parl;
-  }
-  return x;
 }
 
 #ifndef LM_WAVES
@@ -989,8 +946,10 @@ __global__ void __launch_bounds__(256) lm_order_kernel(const u32* __restrict__ n
   sp.order[base[st][key] + atomicAdd(&fill[st * LM_SPLIT_BINS + key], 1u)] = s;
 }
 
+void launch_lm_refine_any(const LmArgs& a, const DevParams& p, u32* n_solved, hipStream_t s);  // kernels_lm_any.hip
 void launch_lm_refine(const LmArgs& a, const DevParams& p, u32* n_solved, hipStream_t s) {
   if (a.max_matches == 0) return;
+  if (p.wx != LM_COLS || p.wy != LM_ROWS) { launch_lm_refine_any(a, p, n_solved, s); return; }  // (no clock probe, no layouts)
   LmSplit sp;
   sp.fvec0 = a.split_fvec0; sp.fnorm0 = a.split_fnorm0; sp.meta = a.split_meta; sp.order = a.split_order; sp.hist = a.split_hist;
   const u32 groups_per_block = LM_BLOCK / 16;

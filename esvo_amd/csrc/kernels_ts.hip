@@ -94,9 +94,29 @@ __device__ inline int median9(int p0, int p1, int p2, int p3, int p4, int p5, in
   cswap(p4, p2);
   return p4;
 }
+// median of n <= 49 values by rank (kernels 5x5 and 7x7: medianBlur(2k + 1), TimeSurface.cpp:130-131; no shipped configuration
+// sets k > 1): the element with at most n/2 values below it and more than n/2 values not above it
+#define TS_MEDIAN_K_MAX 3
+__device__ inline int median_by_rank(const int* v, int n) {
+  for (int i = 0; i < n; ++i) {
+    int lt = 0, le = 0;
+    for (int j = 0; j < n; ++j) { lt += v[j] < v[i]; le += v[j] <= v[i]; }
+    if (lt <= n / 2 && le > n / 2) return v[i];
+  }
+  return v[0];  // (not reached)
+}
+template <bool BIGMED>
 __device__ inline int median_tap(const uint8_t* __restrict__ raw, int W, int H, int x, int y, int median_k) {
   if (x < 0 || x >= W || y < 0 || y >= H) return 0;  // BORDER_CONSTANT 0 of cv::remap
   if (median_k <= 0) return raw[y * W + x];
+  if constexpr (BIGMED) {
+    int v[(2 * TS_MEDIAN_K_MAX + 1) * (2 * TS_MEDIAN_K_MAX + 1)];
+    int n = 0;
+    for (int dy = -median_k; dy <= median_k; ++dy)
+      for (int dx = -median_k; dx <= median_k; ++dx)
+        v[n++] = raw[min(max(y + dy, 0), H - 1) * W + min(max(x + dx, 0), W - 1)];
+    return median_by_rank(v, n);
+  }
   const int xm = max(x - 1, 0), xp = min(x + 1, W - 1), ym = max(y - 1, 0), yp = min(y + 1, H - 1);
   const uint8_t* r0 = raw + ym * W;
   const uint8_t* r1 = raw + y * W;
@@ -107,6 +127,7 @@ __device__ inline int median_tap(const uint8_t* __restrict__ raw, int W, int H, 
 // fixmap[i] = (cvRound(map_x*32), cvRound(map_y*32)): OpenCV's INTER_BITS=5 coordinate
 // quantisation, precomputed once on the host (Appendix B.2).  Weights are the exact 15-bit
 // integers (32-fx)(32-fy)*32 ...; dst = (sum + 16384) >> 15.
+template <bool BIGMED>
 __device__ inline int ts_median_remap_px(const uint8_t* __restrict__ raw, const int2* __restrict__ fixmap, int W, int H,
                                          int median_k, int x, int y) {
   const int i = y * W + x;
@@ -116,22 +137,23 @@ __device__ inline int ts_median_remap_px(const uint8_t* __restrict__ raw, const 
     const int ix = m.x >> 5, iy = m.y >> 5, fx = m.x & 31, fy = m.y & 31;
     const int w00 = (32 - fx) * (32 - fy) * 32, w01 = fx * (32 - fy) * 32, w10 = (32 - fx) * fy * 32, w11 = fx * fy * 32;
     int acc = 0;
-    if (w00) acc += w00 * median_tap(raw, W, H, ix, iy, median_k);
-    if (w01) acc += w01 * median_tap(raw, W, H, ix + 1, iy, median_k);
-    if (w10) acc += w10 * median_tap(raw, W, H, ix, iy + 1, median_k);
-    if (w11) acc += w11 * median_tap(raw, W, H, ix + 1, iy + 1, median_k);
+    if (w00) acc += w00 * median_tap<BIGMED>(raw, W, H, ix, iy, median_k);
+    if (w01) acc += w01 * median_tap<BIGMED>(raw, W, H, ix + 1, iy, median_k);
+    if (w10) acc += w10 * median_tap<BIGMED>(raw, W, H, ix, iy + 1, median_k);
+    if (w11) acc += w11 * median_tap<BIGMED>(raw, W, H, ix + 1, iy + 1, median_k);
     v = (acc + 16384) >> 15;
   } else {
-    v = median_tap(raw, W, H, x, y, median_k);
+    v = median_tap<BIGMED>(raw, W, H, x, y, median_k);
   }
   return v;
 }
+template <bool BIGMED>
 __global__ void __launch_bounds__(256) ts_median_remap_kernel(const uint8_t* __restrict__ raw, const int2* __restrict__ fixmap,
                                                               uint8_t* __restrict__ out, int W, int H, int median_k) {
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
   const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (x >= W || y >= H) return;
-  out[y * W + x] = (uint8_t)ts_median_remap_px(raw, fixmap, W, H, median_k, x, y);
+  out[y * W + x] = (uint8_t)ts_median_remap_px<BIGMED>(raw, fixmap, W, H, median_k, x, y);
 }
 // ---- K2, fused: decay -> u8 -> 3x3 median -> rectifying remap in ONE pass, staged through LDS ----------------------------
 // A workgroup renders a TSF_TX x TSF_TY tile of the RECTIFIED surface (threads 32 x 8, two rows each).  It first reads its
@@ -151,14 +173,23 @@ __device__ inline int ts_raw_at(const u64* __restrict__ sae, int W, int H, int x
   x = min(max(x, 0), W - 1); y = min(max(y, 0), H - 1);
   return ts_decay_u8(sae[(size_t)y * W + x], d);
 }
+template <bool BIGMED>
 __device__ inline int ts_median_tap_direct(const u64* __restrict__ sae, int W, int H, int x, int y, int median_k, const TsDecay& d) {
   if (x < 0 || x >= W || y < 0 || y >= H) return 0;
   if (median_k <= 0) return ts_raw_at(sae, W, H, x, y, d);
+  if constexpr (BIGMED) {
+    int w[(2 * TS_MEDIAN_K_MAX + 1) * (2 * TS_MEDIAN_K_MAX + 1)];
+    int n = 0;
+    for (int dy = -median_k; dy <= median_k; ++dy)
+      for (int dx = -median_k; dx <= median_k; ++dx) w[n++] = ts_raw_at(sae, W, H, x + dx, y + dy, d);
+    return median_by_rank(w, n);
+  }
   int v[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) v[k] = ts_raw_at(sae, W, H, x + k % 3 - 1, y + k / 3 - 1, d);
   return median9(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8]);
 }
+template <bool BIGMED>
 __global__ void __launch_bounds__(256) ts_render_fused_kernel(TsPair c, int W, int H, TsDecay d, int median_k, int stage_cap) {
   __shared__ uint8_t s_raw[TSF_CAP];
   __shared__ uint8_t s_med[TSF_CAP];
@@ -198,7 +229,7 @@ __global__ void __launch_bounds__(256) ts_render_fused_kernel(TsPair c, int W, i
   const int mx0 = __builtin_amdgcn_readfirstlane(s_bb[0]), my0 = __builtin_amdgcn_readfirstlane(s_bb[1]);
   const int mx1 = __builtin_amdgcn_readfirstlane(s_bb[2]), my1 = __builtin_amdgcn_readfirstlane(s_bb[3]);
   const bool any = mx0 <= mx1;
-  const int hal = median_k > 0 ? 1 : 0;
+  const int hal = median_k > 0 ? median_k : 0;
   const int mw = any ? mx1 - mx0 + 1 : 0, mh = any ? my1 - my0 + 1 : 0;
   const int rw = mw + 2 * hal, rh = mh + 2 * hal;
   const bool staged = any && (long long)rw * rh <= stage_cap;
@@ -219,9 +250,17 @@ __global__ void __launch_bounds__(256) ts_render_fused_kernel(TsPair c, int W, i
       int my = t / mw, mx = t - my * mw;
       for (int i = t; i < mw * mh; i += 256) {
         const uint8_t* r0 = s_raw + my * rw + mx;
-        const uint8_t* r1 = r0 + rw;
-        const uint8_t* r2 = r1 + rw;
-        s_med[i] = (uint8_t)median9(r0[0], r0[1], r0[2], r1[0], r1[1], r1[2], r2[0], r2[1], r2[2]);
+        if constexpr (!BIGMED) {
+          const uint8_t* r1 = r0 + rw;
+          const uint8_t* r2 = r1 + rw;
+          s_med[i] = (uint8_t)median9(r0[0], r0[1], r0[2], r1[0], r1[1], r1[2], r2[0], r2[1], r2[2]);
+        } else {  // (2 hal + 1)^2 window, LDS -> LDS
+          int v[(2 * TS_MEDIAN_K_MAX + 1) * (2 * TS_MEDIAN_K_MAX + 1)];
+          int n = 0;
+          for (int dy = 0; dy <= 2 * hal; ++dy)
+            for (int dx = 0; dx <= 2 * hal; ++dx) v[n++] = r0[dy * rw + dx];
+          s_med[i] = (uint8_t)median_by_rank(v, n);
+        }
         mx += sx; my += sy;
         if (mx >= mw) { mx -= mw; ++my; }
       }
@@ -236,7 +275,7 @@ __global__ void __launch_bounds__(256) ts_render_fused_kernel(TsPair c, int W, i
     auto tap = [&](int sx, int sy) -> int {
       if (sx < 0 || sx >= W || sy < 0 || sy >= H) return 0;  // BORDER_CONSTANT 0 of cv::remap
       if (staged) return med[(sy - my0) * mw + (sx - mx0)];
-      return ts_median_tap_direct(sae, W, H, sx, sy, median_k, d);
+      return ts_median_tap_direct<BIGMED>(sae, W, H, sx, sy, median_k, d);
     };
     const int w00 = (32 - fx[k]) * (32 - fy[k]) * 32, w01 = fx[k] * (32 - fy[k]) * 32, w10 = (32 - fx[k]) * fy[k] * 32,
               w11 = fx[k] * fy[k] * 32;
@@ -268,14 +307,22 @@ void launch_ts_render(const u64* d_sae, const int2* d_fixmap, uint8_t* d_raw, ui
   (void)d_raw;  // the raw image is an intermediate of FORWARD mode only
   TsPair c{};
   c.sae[0] = d_sae; c.fixmap[0] = d_fixmap; c.out[0] = d_out;
-  hipLaunchKernelGGL(ts_render_fused_kernel, dim3((W + TSF_TX - 1) / TSF_TX, (H + TSF_TY - 1) / TSF_TY, 1), dim3(256), 0, s, c, W, H,
-                     ts_decay_args(t_ns, decay_sec, ignore_polarity), median_k, ts_stage_cap());
+  if (median_k > 1)
+    hipLaunchKernelGGL(ts_render_fused_kernel<true>, dim3((W + TSF_TX - 1) / TSF_TX, (H + TSF_TY - 1) / TSF_TY, 1), dim3(256), 0, s, c, W,
+                       H, ts_decay_args(t_ns, decay_sec, ignore_polarity), median_k, ts_stage_cap());
+  else
+    hipLaunchKernelGGL(ts_render_fused_kernel<false>, dim3((W + TSF_TX - 1) / TSF_TX, (H + TSF_TY - 1) / TSF_TY, 1), dim3(256), 0, s, c, W,
+                       H, ts_decay_args(t_ns, decay_sec, ignore_polarity), median_k, ts_stage_cap());
 }
 
 void launch_ts_render_pair(const TsPair& c, int W, int H, u64 t_ns, double decay_sec, int ignore_polarity, int median_k,
                            hipStream_t s) {
-  hipLaunchKernelGGL(ts_render_fused_kernel, dim3((W + TSF_TX - 1) / TSF_TX, (H + TSF_TY - 1) / TSF_TY, 2), dim3(256), 0, s, c, W, H,
-                     ts_decay_args(t_ns, decay_sec, ignore_polarity), median_k, ts_stage_cap());
+  if (median_k > 1)
+    hipLaunchKernelGGL(ts_render_fused_kernel<true>, dim3((W + TSF_TX - 1) / TSF_TX, (H + TSF_TY - 1) / TSF_TY, 2), dim3(256), 0, s, c, W,
+                       H, ts_decay_args(t_ns, decay_sec, ignore_polarity), median_k, ts_stage_cap());
+  else
+    hipLaunchKernelGGL(ts_render_fused_kernel<false>, dim3((W + TSF_TX - 1) / TSF_TX, (H + TSF_TY - 1) / TSF_TY, 2), dim3(256), 0, s, c, W,
+                       H, ts_decay_args(t_ns, decay_sec, ignore_polarity), median_k, ts_stage_cap());
 }
 
 // ---- FORWARD mode (TimeSurface.cpp:85-116) ------------------------------------------------------------------------------
@@ -328,8 +375,12 @@ void launch_ts_render_forward(const u64* d_sae, const u32* d_off, const u32* d_s
   hipLaunchKernelGGL(ts_forward_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_off, d_src, d_lut, d_val, d_raw, n,
                      ignore_polarity);
   // the 3x3 median of the BACKWARD path without its remap (fixmap == null)
-  hipLaunchKernelGGL(ts_median_remap_kernel, dim3((W + 63) / 64, (H + 3) / 4), dim3(256), 0, s, d_raw, (const int2*)nullptr, d_out, W,
-                     H, median_k);
+  if (median_k > 1)
+    hipLaunchKernelGGL(ts_median_remap_kernel<true>, dim3((W + 63) / 64, (H + 3) / 4), dim3(256), 0, s, d_raw, (const int2*)nullptr, d_out,
+                       W, H, median_k);
+  else
+    hipLaunchKernelGGL(ts_median_remap_kernel<false>, dim3((W + 63) / 64, (H + 3) / 4), dim3(256), 0, s, d_raw, (const int2*)nullptr, d_out,
+                       W, H, median_k);
 }
 
 // ---- 5x5 Gaussian, [1 4 6 4 1]^2 / 256, BORDER_REFLECT_101, round-to-nearest once ------------------

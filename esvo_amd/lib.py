@@ -16,7 +16,7 @@ from .abi import (DEPTH_POINT_DTYPE, EVENT_DTYPE, MATCH_DTYPE, CalibStruct, Para
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 # ESVO_HIP_LIB: another build of the same library (A/B measurements of kernel variants, tools/ab_build.py); never a fallback
 _LIB_PATH = os.environ.get("ESVO_HIP_LIB") or os.path.join(_CSRC, "libesvo_hip.so")
-_SOURCES = ["api_core.hip", "api_ts.hip", "api_map.hip", "api_comm.hip", "api_bag.hip", "api_track.hip", "scan.hip", "kernels_ts.hip", "kernels_bm.hip", "kernels_lm.hip", "kernels_fuse.hip", "kernels_shard.hip", "kernels_track.hip", "kernels_viz.hip", "kernels_sgm.hip"]
+_SOURCES = ["api_core.hip", "api_ts.hip", "api_map.hip", "api_comm.hip", "api_bag.hip", "api_track.hip", "scan.hip", "kernels_ts.hip", "kernels_bm.hip", "kernels_lm.hip", "kernels_lm_any.hip", "kernels_fuse.hip", "kernels_shard.hip", "kernels_track.hip", "kernels_viz.hip", "kernels_sgm.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
                "-Wno-unused-value", "-Wno-unused-result", "-ldl"]
 

@@ -97,11 +97,11 @@ typedef struct esvo_calib_t {
 typedef struct esvo_params_t {
   /* esvo_time_surface (cfg/time_surface/ts_parameters.yaml; TimeSurface.cpp:23-30) */
   double decay_ms;                 /* 30 */
-  int32_t median_blur_kernel_size; /* 1 -> 3x3; 0 disables; >1 unsupported */
+  int32_t median_blur_kernel_size; /* k: medianBlur(2k + 1); 1 -> 3x3 (every shipped config); 0 disables; 0..3 */
   int32_t ignore_polarity;         /* 1 */
   /* DepthProblemConfig (DepthProblem.h:15-51) */
-  int32_t patch_size_x;            /* 15 */
-  int32_t patch_size_y;            /* 7 */
+  int32_t patch_size_x;            /* 15 in every shipped config (register-layout kernels); any 1..64 otherwise */
+  int32_t patch_size_y;            /* 7 in every shipped config; any 1..40 otherwise */
   int32_t ls_norm;                 /* ESVO_LSNORM_TDIST */
   double td_nu;                    /* Tdist_nu */
   double td_scale;                 /* Tdist_scale */

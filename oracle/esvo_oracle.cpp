@@ -62,22 +62,24 @@ inline uint8_t sat_u8(int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v))
 // ---------------------------------------------------------------------------------------------
 // OpenCV image primitives
 // ---------------------------------------------------------------------------------------------
-void median3_u8(const uint8_t* src, uint8_t* dst, int w, int h) {
-  // cv::medianBlur(ksize=3): exact 3x3 median, BORDER_REPLICATE
+void median_u8(const uint8_t* src, uint8_t* dst, int w, int h, int k) {
+  // cv::medianBlur(ksize = 2k + 1) on CV_8U (TimeSurface.cpp:130-131): the exact (2k+1)^2 median, BORDER_REPLICATE
+  const int n = (2 * k + 1) * (2 * k + 1);
+  std::vector<uint8_t> v((size_t)n);
   for (int y = 0; y < h; ++y)
     for (int x = 0; x < w; ++x) {
-      uint8_t v[9];
-      int k = 0;
-      for (int dy = -1; dy <= 1; ++dy)
-        for (int dx = -1; dx <= 1; ++dx) {
+      int q = 0;
+      for (int dy = -k; dy <= k; ++dy)
+        for (int dx = -k; dx <= k; ++dx) {
           int yy = std::min(std::max(y + dy, 0), h - 1);
           int xx = std::min(std::max(x + dx, 0), w - 1);
-          v[k++] = src[yy * w + xx];
+          v[q++] = src[yy * w + xx];
         }
-      std::nth_element(v, v + 4, v + 9);
-      dst[y * w + x] = v[4];
+      std::nth_element(v.begin(), v.begin() + n / 2, v.end());
+      dst[y * w + x] = v[n / 2];
     }
 }
+void median3_u8(const uint8_t* src, uint8_t* dst, int w, int h) { median_u8(src, dst, w, h, 1); }
 
 void remap_bilinear_u8(const uint8_t* src, uint8_t* dst, int w, int h, const float* map_x,
                        const float* map_y) {
@@ -192,7 +194,7 @@ extern "C" void orc_ts_render(orc_ts_handle h, uint64_t t_ns, double decay_ms, i
   if (out_prefilter) std::memcpy(out_prefilter, img.data(), img.size());
   const uint8_t* cur = img.data();
   if (median_blur_kernel_size > 0) {  // :130-131 (kernel 2k+1; only k=1 shipped)
-    median3_u8(img.data(), med.data(), W, H);
+    median_u8(img.data(), med.data(), W, H, median_blur_kernel_size);
     cur = med.data();
   }
   if (map_x && map_y)
@@ -248,7 +250,7 @@ extern "C" void orc_ts_render_forward(orc_ts_handle h, uint64_t t_ns, double dec
     if (out_f64) out_f64[i] = v;
     img[i] = sat_u8(cv_round(v));
   }
-  if (median_blur_kernel_size > 0) median3_u8(img.data(), out, W, H);
+  if (median_blur_kernel_size > 0) median_u8(img.data(), out, W, H, median_blur_kernel_size);
   else std::memcpy(out, img.data(), img.size());
 }
 

@@ -564,6 +564,8 @@ if __name__ == "__main__":
     names = [a for a in sys.argv[1:] if not a.startswith("-")] or list(S.SCENARIOS)
     for n in names:
         make(n)
+    if "--only" in sys.argv:   # just the named scenarios (e.g. `--only upenn25 dsec10x4`)
+        sys.exit(0)
     make_node_big()
     make_units()
     make_track()

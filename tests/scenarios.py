@@ -36,8 +36,17 @@ SCENARIOS = {
     # 15 000 scene points at 2 m/s fire ~1.2 M events/s per camera: the 10 ms slice holds > 10 000, the selection is cut
     "dsec10k": dict(rig="dsec", preset="mapping_dsec", n_points=15000, rho=(0.02, 0.25), seed=20250512, n_ticks=6,
                     n_events=10000, speed=2.0, t_first=0.05, dt=0.01),
+    # ---- the reference's CODE-DEFAULT patch (patch_size_X = patch_size_Y = 25, esvo_Mapping.cpp:38-39 / esvo_MVStereo.cpp:39-40; every
+    # shipped yaml sets 15 x 7): the general block-matching and refinement kernels
+    "upenn25": dict(rig="upenn", preset="mvstereo_upenn", n_points=5000, rho=(0.16, 1.0), seed=20250521, n_ticks=3,
+                    n_events=600, speed=1.0, t_first=0.06, dt=0.01, overrides=dict(patch_size_x=25, patch_size_y=25)),
+    # an even, non-square patch on the smoothed DSEC surfaces with the regulariser on (left-top = centre - (w - 1) / 2: the
+    # block is not centred, EventBM.cpp:255-258)
+    "dsec10x4": dict(rig="dsec", preset="mapping_dsec", n_points=9000, rho=(0.02, 0.25), seed=20250522, n_ticks=3,
+                     n_events=900, speed=2.0, t_first=0.05, dt=0.01, overrides=dict(patch_size_x=10, patch_size_y=4)),
 }
 BIG = ("upenn1k", "dsec10k")
+PATCH = ("upenn25", "dsec10x4")   # other patch sizes than the shipped 15 x 7
 
 
 class Scenario:

@@ -173,6 +173,8 @@ def test_denoising_in_the_fused_tick():
     ("mapping_dsec", "dsec_rig", "dsec_stream", dict(process_event_num=4000), 8),      # CONST_FRAMES, radius 1, regularised
     # many small frames: the window ring must be packed by the frames' real sizes, not by their worst case
     ("mapping_upenn", "upenn_rig", "upenn_stream", dict(max_fusion_points=1500, process_event_num=300), 17),
+    # the reference's code-default patch 25 x 25 (general BM / LM kernels) through the pipelined tick, smoothed surfaces + regulariser
+    ("mapping_dsec", "dsec_rig", "dsec_stream", dict(process_event_num=1500, patch_size_x=25, patch_size_y=25), 6),
 ])
 def test_back_to_back_ticks_without_reads(request, preset, rig_fix, stream_fix, over, n_first):
     """esvo_map_tick completes lazily (tick k is committed while tick k+1's front stage is already enqueued).  Ticks

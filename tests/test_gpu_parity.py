@@ -83,7 +83,7 @@ def test_time_surface_bit_exact(rig_name):
     assert n_cmp > 0
 
 
-@pytest.mark.parametrize("rig_name,polarity,median", [("upenn", False, 1), ("dsec", False, 1), ("upenn", True, 0)])
+@pytest.mark.parametrize("rig_name,polarity,median", [("upenn", False, 1), ("dsec", False, 1), ("upenn", True, 0), ("upenn", False, 2)])
 def test_time_surface_forward_mode_bit_exact(rig_name, polarity, median):
     """esvo_ts_render_forward vs createTimeSurfaceAtTime in FORWARD mode (TimeSurface.cpp:85-116; the oracle's splat is pinned to
     the reference's source by tests/test_ref_pin.py): the order-dependent clamped splat, reproduced as a gather over
@@ -115,10 +115,12 @@ def test_time_surface_forward_mode_bit_exact(rig_name, polarity, median):
 
 
 def test_time_surface_polarity_and_no_median():
+    """polarity on/off; median_blur_kernel_size 0 (off), 1 (3x3, every shipped config), 2 and 3 (medianBlur(2k + 1),
+    TimeSurface.cpp:130-131: 5x5 and 7x7 by rank selection, LDS-staged and -- under ESVO_TS_STAGE_CAP -- direct)"""
     O = _oracle()
     rig = calib.dataset_rig("upenn")
     ev = synth.random_events(rig.width, rig.height, 40000, 5_000_000_000, 5_050_000_000, seed=3)
-    for ignore_pol, med in ((0, 1), (1, 0), (0, 0)):
+    for ignore_pol, med in ((0, 1), (1, 0), (0, 0), (1, 2), (0, 2), (1, 3)):
         p, _ = params.make_params(params.PRESETS["mvstereo_upenn"], rig, ignore_polarity=ignore_pol, median_blur_kernel_size=med)
         dev = _dev(p, rig)
         ots = O.OracleTS(rig.width, rig.height)

@@ -16,13 +16,13 @@ import numpy as np
 import pytest
 
 import scenarios as S
-from test_ref_pin import (ALL_NAMES, BIG_NAMES, BIG_POINT_BARS, IOU_BAR, NAMES, RMSE_NORTH_STAR, check_map, check_matches, check_points,
+from test_ref_pin import (ALL_NAMES, STAGE_NAMES, BIG_NAMES, BIG_POINT_BARS, IOU_BAR, NAMES, RMSE_NORTH_STAR, check_map, check_matches, check_points,
                           load_fixture, map_stats, rmse_bar, same_map)
 
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name", ALL_NAMES)
+@pytest.mark.parametrize("name", STAGE_NAMES)
 def test_gpu_stages_match_reference(name):
     from esvo_amd import lib
     g, sc, ticks = load_fixture(name)
@@ -38,7 +38,7 @@ def test_gpu_stages_match_reference(name):
     dev.close()
 
 
-@pytest.mark.parametrize("name", ALL_NAMES)
+@pytest.mark.parametrize("name", STAGE_NAMES)
 def test_gpu_chain_matches_reference_end_to_end(name):
     """bars: what the chain achieves (IoU 1.0, RMSE <= 1.7e-7 measured), two orders inside north_star's RMSE < 1e-4"""
     from esvo_amd import lib
@@ -53,7 +53,7 @@ def test_gpu_chain_matches_reference_end_to_end(name):
     dev.close()
 
 
-@pytest.mark.parametrize("name", ALL_NAMES)
+@pytest.mark.parametrize("name", STAGE_NAMES)
 def test_gpu_chain_equals_canonical_oracle(name):
     """The same four rigs, device chain vs the oracle in its GPU-comparable arithmetic: every match, point and DepthMap
     element identical (hkust: Denoising + r = 5 + CONST_FRAMES; rpg: the 240x180 calibration)."""

@@ -44,7 +44,8 @@ def test_unsupported_params_are_rejected_not_approximated():
     from esvo_amd import lib
     so = lib.load()
     rig = calib.ideal_rig(64, 48, 100.0, 0.1)
-    for kw in (dict(patch_size_x=25), dict(ls_norm=7), dict(median_blur_kernel_size=2)):
+    # (patch 25 x 25 and median_blur_kernel_size 2 are supported since round 4: general kernels)
+    for kw in (dict(patch_size_x=65), dict(patch_size_y=41), dict(patch_size_x=0), dict(ls_norm=7), dict(median_blur_kernel_size=4)):
         p, _ = params.make_params(params.PRESETS["mvstereo_upenn"], rig, **kw)
         h = ctypes.c_void_p()
         cl, cr = rig.left.as_struct(), rig.right.as_struct()

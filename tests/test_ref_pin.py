@@ -33,6 +33,9 @@ NAMES = ["upenn", "dsec", "rpg", "hkust"]
 # fixtures hold every tick's matches and points, digests of every DepthMap and the last map in full (tests/scenarios.py: BIG)
 BIG_NAMES = list(S.BIG)
 ALL_NAMES = NAMES + BIG_NAMES
+# other patch sizes than the shipped 15 x 7 (the reference's code default 25 x 25; an even, non-square one): the general kernels
+PATCH_NAMES = list(S.PATCH)
+STAGE_NAMES = ALL_NAMES + PATCH_NAMES
 EXACT = ["inv_depth", "scale2", "nu", "variance", "residual", "x"]
 # End-to-end bars.  Measured: IoU 1.0 on every tick of every fixture, RMSE 0 ... 1.7e-7 on the small ones (the reference's Eigen
 # LM driver is third-party; two restatements of it stop at xtol = 1e-6 a few 1e-7 apart), 2.1e-8 on upenn1k and 1.7e-6 on
@@ -144,7 +147,7 @@ def map_stats(mp, ref, W):
     return (len(set(da) & set(db)) / union if union else 1.0), rmse
 
 
-@pytest.mark.parametrize("name", ALL_NAMES)
+@pytest.mark.parametrize("name", STAGE_NAMES)
 def test_oracle_stages_match_reference(name):
     g, sc, ticks = load_fixture(name)
     m = O.OracleMapper(sc.params, sc.rig)  # literal mode
@@ -158,10 +161,11 @@ def test_oracle_stages_match_reference(name):
         m.push_frame(g[f"points{k}"], tk["poses"])
         assert m.fuse() == int(g[f"nf{k}"])
         check_map(m.get_map(), g, k, m.get_map_cells())
-    assert int(g["u_dangling"]) > 0 and m.counters()["replace_displaced"] > 0  # Appendix A-7 is exercised
+    if name not in PATCH_NAMES:
+        assert int(g["u_dangling"]) > 0 and m.counters()["replace_displaced"] > 0  # Appendix A-7 is exercised
 
 
-@pytest.mark.parametrize("name", ALL_NAMES)
+@pytest.mark.parametrize("name", STAGE_NAMES)
 def test_oracle_chain_matches_reference_end_to_end(name):
     g, sc, ticks = load_fixture(name)
     m = O.OracleMapper(sc.params, sc.rig)
@@ -219,7 +223,7 @@ def test_student_t_and_zncc_units():
         assert abs(O.zncc_cost(l.astype(np.float64), r.astype(np.float64), exact_int=True) - c) <= 1e-12
 
 
-@pytest.mark.parametrize("name", ALL_NAMES)
+@pytest.mark.parametrize("name", STAGE_NAMES)
 def test_live_reference_reproduces_fixture(name):
     from oracle import ref as R
     if not os.path.isdir(os.path.join(R.REFERENCE, "esvo_core", "src")):
