@@ -208,17 +208,44 @@ __device__ inline PatchGeom interp_geom(const DevParams& p, double lx, double ly
   g.q4 = ly - fy;
   return g;
 }
+// The source bytes of the lane's block column, kept across the evaluations of a match as floats (exact: 0..255).  lmdif's
+// evaluations come in pairs at x and x + sqrt(eps) |x| -- the same pixel block, other bilinear weights -- and a converging
+// trial step rarely leaves the block either, so most evaluations find both images' columns here and issue no load at all
+// (measured: a second, dependent batch of these loads costs the tick 8.5 %).  voff = the block column's first byte, the key;
+// a wave reloads when ANY of its matches moved (the branch is wave-uniform), and a failed warp's garbage offset is as good
+// a key as any: the loads are bounds-checked, the same offset gives the same bytes.
 template <bool WIDE>
-__device__ inline void interp_column(__amdgpu_buffer_rsrc_t img, int W, const PatchGeom& g, int c, int rg, double* tau) {
+struct LmCache {
+  float l[Lay<WIDE>::RL + 1], r[Lay<WIDE>::RL + 1];
+  int vl, vr;
+  __device__ inline void clear() {
+#pragma unroll
+    for (int y = 0; y <= Lay<WIDE>::RL; ++y) l[y] = r[y] = 0.f;  // what an out-of-range offset reads
+    vl = vr = 0x7fffffff;
+  }
+};
+__device__ inline float dpp_shl1_f32(float v) { return __int_as_float(dpp_i32<DPP_SHL1>(__float_as_int(v))); }
+template <bool WIDE>
+__device__ inline void interp_column(__amdgpu_buffer_rsrc_t img, int W, const PatchGeom& g, int c, int rg, double* tau, float* cs,
+                                     int& cvoff) {
   constexpr int RL = Lay<WIDE>::RL;
   // first source row of the lane (the wide layout's row group rg owns rows 2 rg, 2 rg + 1 and reads one more; group 3 owns
   // row 6 only: its third source row lies below the block and is not used -- wherever it falls, the load is bounds-checked)
   const int voff = (g.uly + (WIDE ? 2 * rg : 0)) * W + g.ulx + c;
+#ifndef LM_NO_BLOCK_CACHE
+  if (__ballot(voff != cvoff) != 0ull) {
+#endif
+#pragma unroll
+    for (int y = 0; y <= RL; ++y) cs[y] = (float)(int)__builtin_amdgcn_raw_buffer_load_b8(img, voff, y * W, 0);
+    cvoff = voff;
+#ifndef LM_NO_BLOCK_CACHE
+  }
+#endif
   double R[RL + 1];
 #pragma unroll
   for (int y = 0; y <= RL; ++y) {
-    const int s0 = (int)__builtin_amdgcn_raw_buffer_load_b8(img, voff, y * W, 0);
-    const int s1 = dpp_i32<DPP_SHL1>(s0);  // column c+1 from the neighbour lane
+    const float s0 = cs[y];
+    const float s1 = dpp_shl1_f32(s0);  // column c+1 from the neighbour lane
     R[y] = g.q1 * (double)s0 + g.q2 * (double)s1;
   }
 #pragma unroll
@@ -232,7 +259,7 @@ __device__ inline void interp_column(__amdgpu_buffer_rsrc_t img, int W, const Pa
 // final scale lies in [2^-100, 2^100], so every non-zero f = sqrt(w) r has 2^-150 <= |f| < 2^11 -- what lets the caller
 // divide differences of two such evaluations through a shared reciprocal (fdiv.hpp's window) without testing them.
 template <bool WIDE, bool L2, bool COUNT = false>
-__device__ bool lm_eval(const DevParams& p, const LmProblem& pr, double x, double* fv, int* n_iter = nullptr) {
+__device__ bool lm_eval(const DevParams& p, const LmProblem& pr, LmCache<WIDE>& cc, double x, double* fv, int* n_iter = nullptr) {
   int iters = 0;  // t-scale iterations of this evaluation (COUNT only: the split launch orders the matches by it)
   constexpr int RL = Lay<WIDE>::RL;
   // element (y, c) of the patch exists: column 15 only feeds its neighbour; row group 3 of the wide layout owns one row
@@ -293,8 +320,8 @@ __device__ bool lm_eval(const DevParams& p, const LmProblem& pr, double x, doubl
   const PatchGeom g1 = interp_geom(p, x1u, x1v), g2 = interp_geom(p, x2u, x2v);
   const bool okw = inside & g1.ok & g2.ok;
   double tau1[RL], tau2[RL], r[RL], r2[RL];
-  interp_column<WIDE>(pr.tsL, p.W, g1, pr.c, pr.rg, tau1);
-  interp_column<WIDE>(pr.tsR, p.W, g2, pr.c, pr.rg, tau2);
+  interp_column<WIDE>(pr.tsL, p.W, g1, pr.c, pr.rg, tau1, cc.l, cc.vl);
+  interp_column<WIDE>(pr.tsR, p.W, g2, pr.c, pr.rg, tau2, cc.r, cc.vr);
   if (!okw) {  // failure fill, DepthProblem.cpp:49-56 / :149-155 (l2: :67-75, :143-147)
     double f = 255;
     if constexpr (!L2) {
@@ -638,6 +665,8 @@ __global__ void __launch_bounds__(PAIR ? 128 : LM_BLOCK, WIDE ? LM_WIDE_WAVES : 
   // inlined evaluator keeps the kernel ~3x smaller (I-cache, register pressure).
   double x = m.inv_depth;
   double fvec[RL], out[RL];
+  LmCache<WIDE> cc;
+  cc.clear();
   double fnorm = 0., par = 0., diag = 0., xnorm = 0., delta = 0., r = 0., qtf = 0., gnorm = 0.;
   double h = 0., xnew = 0., wa1 = 0., pnorm = 0.;
   int nfev = 1, iter = 1, iteration = 0, optState = 0;
@@ -651,7 +680,7 @@ __global__ void __launch_bounds__(PAIR ? 128 : LM_BLOCK, WIDE ? LM_WIDE_WAVES : 
   bool have_spec = false;
   if constexpr (STAGE == 1) {  // minimizeInit only: F(x0), |F(x0)|, what the evaluation cost
     int n_it = 0;
-    const bool tgt = lm_eval<WIDE, L2, true>(p, pr, x, out, &n_it);
+    const bool tgt = lm_eval<WIDE, L2, true>(p, pr, cc, x, out, &n_it);
     const double f0 = sqrt(patch_dot<WIDE>(out, out, rg));
     if (active) {
       double* dst = sp.fvec0 + (size_t)s * (LM_ROWS * 16) + c;
@@ -712,7 +741,7 @@ __global__ void __launch_bounds__(PAIR ? 128 : LM_BLOCK, WIDE ? LM_WIDE_WAVES : 
           if (hs == 0.) hs = sqrt_eps;
           xs = xe + hs;
         }
-        const bool t_mine = lm_eval<WIDE, L2>(p, pr, (side && wv) ? xs : xe, out);
+        const bool t_mine = lm_eval<WIDE, L2>(p, pr, cc, (side && wv) ? xs : xe, out);
         out_tight = t_mine;
         if (side) {
           xpar ^= 1;
@@ -727,7 +756,7 @@ __global__ void __launch_bounds__(PAIR ? 128 : LM_BLOCK, WIDE ? LM_WIDE_WAVES : 
         }
       }
     } else {
-      out_tight = lm_eval<WIDE, L2>(p, pr, xe, out);
+      out_tight = lm_eval<WIDE, L2>(p, pr, cc, xe, out);
     }
     int status = -1;
     bool outer_tail = false;
