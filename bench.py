@@ -238,7 +238,8 @@ def whole_tick_valu(prof, tick_ms):
     total = sum(v["SQ_INSTS_VALU"] * prof["sq_dispatches"].get(k, 0) for k, v in prof["sq"].items() if "SQ_INSTS_VALU" in v) / ticks
     rate = total / (tick_ms * 1e-3)
     return {"wave_insts_per_tick": total, "achieved": rate, "peak": VALU_PEAK_INST_S, "frac": rate / VALU_PEAK_INST_S,
-            "note": "all kernels of a tick; peak as above (2.4 GHz; the chip sustains ~1.75 GHz under this f64 load, DESIGN.md section 5)"}
+            "note": "all kernels of a tick; peak as above (nominal 2.4 GHz); `frac_at_measured_clock` re-prices it at the shader clock "
+                    "measured inside this run (DESIGN.md section 5: 2.3 GHz -- round 3's 1.75 GHz estimate was wrong)"}
 
 
 def map_sha1(mp_):
