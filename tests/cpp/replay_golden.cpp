@@ -106,8 +106,8 @@ int main(int argc, char** argv) {
     }
     // error behaviour: unsupported configuration is rejected, not approximated
     try {
-      ebm.resetParameters(25, 25, 1, 40, 1, 0.1, false);
-      std::fprintf(stderr, "expected ESVO_ERR_UNSUPPORTED for a 25x25 patch\n");
+      ebm.resetParameters(65, 25, 1, 40, 1, 0.1, false);  // (25 x 25 -- the reference's code default -- is supported since round 4)
+      std::fprintf(stderr, "expected ESVO_ERR_UNSUPPORTED for a 65x25 patch\n");
       return 1;
     } catch (const Error& e) {
       if (e.code != ESVO_ERR_UNSUPPORTED) { std::fprintf(stderr, "unexpected error code %d\n", e.code); return 1; }

@@ -17,7 +17,7 @@ rocprofv3 --kernel-trace --stats -d $out/prof_$tag -o ks -- $cmd --no-cpu-baseli
 python $root/tools/prof_summary.py $out/prof_$tag/ks_results.db $out/${tag}_kernel_stats.csv
 python $root/tools/stream_trace.py $out/prof_$tag/ks_results.db > $out/${tag}_stream_trace.txt 2>&1
 python $root/tools/timeline.py $out/prof_$tag/ks_results.db > $out/${tag}_timeline.txt 2>&1
-short="python $root/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --no-parity --workload $wl"
+short="python $root/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --no-parity --sustained-ticks 0 --workload $wl"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/prof_$tag -o fetch -- $short > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/prof_$tag -o write -- $short > /dev/null 2>&1
 python $root/tools/pmc_summary.py $out/${tag}_hbm_traffic.csv hbm $out/prof_$tag/fetch_results.db $out/prof_$tag/write_results.db
