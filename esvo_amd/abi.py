@@ -78,6 +78,8 @@ class ParamsStruct(C.Structure):
         ("max_window_points", C.c_int32),
         ("max_poses_per_tick", C.c_int32),
         ("event_ring_capacity", C.c_int64),
+        ("max_event_queue_len", C.c_int32),   # ABI 5: 0 = one stamp per pixel (fast path), 1..32 = EventQueueMat semantics
+        ("pad_params_", C.c_int32),
     ]
 
 

@@ -24,6 +24,7 @@ int validate_params(const esvo_params_t* p, std::string& why) {
   // lane = column, three [rows][64] f64 arrays in LDS)
   if (p->patch_size_x < 1 || p->patch_size_x > 64 || p->patch_size_y < 1 || p->patch_size_y > 40) { why = "patch size must be within 1..64 x 1..40"; return ESVO_ERR_UNSUPPORTED; }
   if (p->median_blur_kernel_size < 0 || p->median_blur_kernel_size > 3) { why = "median_blur_kernel_size must be 0..3 (kernel 2k + 1)"; return ESVO_ERR_UNSUPPORTED; }
+  if (p->max_event_queue_len < 0 || p->max_event_queue_len > TSQ_LMAX) { why = "max_event_queue_len must be 0 (one stamp per pixel) or 1..32"; return ESVO_ERR_UNSUPPORTED; }
   if (p->bm_max_disparity < p->bm_min_disparity || p->bm_min_disparity < 0) { why = "bad disparity range"; return ESVO_ERR_INVALID_ARG; }
   if (p->td_nu <= 2.0 || p->td_scale <= 0) { why = "Tdist_nu must be > 2 and Tdist_scale > 0"; return ESVO_ERR_INVALID_ARG; }
   if (p->num_threads < 1 || p->num_threads > 64) { why = "num_threads out of range"; return ESVO_ERR_INVALID_ARG; }
@@ -229,10 +230,25 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
     CK(hipMemcpy(h->d_fixmap[cam], fm.data(), sizeof(int2) * npx, hipMemcpyHostToDevice));
     CK(dalloc(&h->d_sae[cam], npx));
     CK(hipMemset(h->d_sae[cam], 0, sizeof(u64) * npx));
+    if (params->max_event_queue_len > 0) {  // EventQueueMat semantics: a set of <= L keys per pixel, slot-major
+      CK(dalloc(&h->d_tsq[cam], npx * (size_t)params->max_event_queue_len));
+      CK(hipMemset(h->d_tsq[cam], 0, sizeof(u64) * npx * (size_t)params->max_event_queue_len));
+    }
     CK(dalloc(&h->d_ts[cam], npx + 64));
     CK(dalloc(&h->d_obs2[0][cam], npx + 64));
     CK(dalloc(&h->d_obs2[1][cam], npx + 64));
     h->d_obs[cam] = h->d_obs2[0][cam];
+  }
+  if (params->max_event_queue_len > 0) {
+    h->tsq_len = params->max_event_queue_len;
+    const size_t tiles = (size_t)((h->W + 7) / 8) * ((h->H + 7) / 8);
+    h->tsq_tcap = 1024;
+    if (const char* e = std::getenv("ESVO_TSQ_TILE_CAP")) h->tsq_tcap = (u32)std::max(1, std::atoi(e));  // tests: force the overflow list
+    CK(dalloc(&h->d_tsq_tcount, tiles));
+    CK(hipMemset(h->d_tsq_tcount, 0, sizeof(u32) * tiles));
+    CK(dalloc(&h->d_tsq_tlist, tiles * h->tsq_tcap));
+    CK(dalloc(&h->d_tsq_over, (size_t)esvo_context::TSQ_ROUND));
+    CK(dalloc(&h->d_tsq_over_count, 1));
   }
   CK(dalloc(&h->d_raw, npx + 64));
   CK(dalloc(&h->d_raw1, npx + 64));
@@ -426,7 +442,7 @@ int esvo_destroy(esvo_handle h) {
                   h->d_matches2[0], h->d_matches2[1], h->d_scan_tmp_l2[0], h->d_scan_tmp_l2[1], h->d_pt_slots2[0], h->d_pt_slots2[1], h->d_pt_flags2[0], h->d_pt_flags2[1], h->d_pt_prefix2[0], h->d_pt_prefix2[1], h->d_pts_tmp, h->d_stage[0], h->d_stage[1], h->d_counters2[0], h->d_counters2[1], h->d_scan_tmp,
                   h->d_win, h->d_frame_pose_T, h->d_fr_table, h->d_prop, h->d_tile_pts, h->d_tile_count, h->d_over_pts,
                   h->d_cell_count, h->d_cell_offset, h->d_cell_list, h->d_fuse_ctr, h->d_rec_ids, h->d_map, h->d_map2, h->d_owner_max, h->d_owner_min, h->d_exp_flags,
-                  h->d_exp_prefix, h->d_export, h->d_export_cell, h->d_reg_ab, h->d_reg_cd, h->d_own_w, h->d_lkeep, h->d_codes, h->d_codes_send, h->d_codes_all, h->d_pts_send, h->d_pts_all, h->d_rank_kept,
+                  h->d_exp_prefix, h->d_export, h->d_export_cell, h->d_reg_ab, h->d_reg_cd, h->d_tsq[0], h->d_tsq[1], h->d_tsq_tcount, h->d_tsq_tlist, h->d_tsq_over, h->d_tsq_over_count, h->d_own_w, h->d_lkeep, h->d_codes, h->d_codes_send, h->d_codes_all, h->d_pts_send, h->d_pts_all, h->d_rank_kept,
                   h->d_sel, h->d_evmap, h->d_lm_fvec0, h->d_lm_fnorm0, h->d_lm_meta, h->d_lm_order, h->d_lm_hist, h->d_clk};
   for (void* p : ptrs) if (p) hipFree(p);
   if (h->h_counters) hipHostFree(h->h_counters);
@@ -474,6 +490,7 @@ int esvo_reset(esvo_handle h) {
   HIPCHK(hipStreamSynchronize(h->stream_i));
   for (int cam = 0; cam < 2; ++cam) {
     HIPCHK(hipMemsetAsync(h->d_sae[cam], 0, sizeof(u64) * npx, h->stream));
+    if (h->d_tsq[cam]) HIPCHK(hipMemsetAsync(h->d_tsq[cam], 0, sizeof(u64) * npx * (size_t)h->tsq_len, h->stream));
     h->ts_host[cam].clear();
     h->ring_base[cam] = h->ring_next[cam] = h->ring_reserved[cam] = h->scattered[cam] = 0;
     h->scatter_pending_lo[cam] = ~0ull;
@@ -536,6 +553,7 @@ int esvo_set_params(esvo_handle h, const esvo_params_t* params) {
   np.max_window_points = h->prm.max_window_points;
   np.max_poses_per_tick = h->prm.max_poses_per_tick;
   np.event_ring_capacity = h->prm.event_ring_capacity;
+  if (np.max_event_queue_len != h->prm.max_event_queue_len) FAIL(ESVO_ERR_CAPACITY, "max_event_queue_len is fixed at esvo_create (the per-pixel queues are allocated there)");
   h->prm = np;
   fill_dev_params(h);
   set_compute_band(h);

@@ -39,6 +39,35 @@ void resident_write_begin(esvo_context* h, int cam) {
   }
 }
 
+// Queue mode (max_event_queue_len > 0; caller holds mu_ring): every staged event of `cam` that is not in its pixel's queue yet
+// goes in -- future ones included, as eventsCallback inserts them on arrival (TimeSurface.cpp:403-425) -- and the SAE word
+// of every pixel is derived for THIS render time (getMostRecentEventBeforeT); the render kernels read the SAE as ever.
+void queue_prepare(esvo_context* h, int cam, u64 t_ns) {
+  u64 a = h->scattered[cam];
+  const u64 upto = h->ring_next[cam];
+  if (upto > a) {
+    h->scatter_pending_lo[cam] = std::min(h->scatter_pending_lo[cam], a);
+    h->scatter_seq++;
+    h->stats.events_scattered[cam] += upto - a;
+    while (a < upto) {  // rounds of at most TSQ_ROUND events: the overflow list can hold a whole round
+      TsQueueArgs g{};
+      g.q = h->d_tsq[cam]; g.L = h->tsq_len;
+      g.tcount = h->d_tsq_tcount; g.tlist = h->d_tsq_tlist; g.tcap = h->tsq_tcap;
+      g.over = h->d_tsq_over; g.over_count = h->d_tsq_over_count; g.over_cap = (u32)esvo_context::TSQ_ROUND;
+      u64 left = std::min<u64>(upto - a, esvo_context::TSQ_ROUND);
+      for (int k = 0; k < 2 && left; ++k) {
+        const u64 slot = a % h->ring_cap;
+        const u64 cnt = std::min<u64>(left, h->ring_cap - slot);
+        g.ev[k] = h->d_ring[cam] + slot; g.n[k] = (size_t)cnt;
+        a += cnt; left -= cnt;
+      }
+      launch_tsq_insert(g, h->W, h->H, h->stream);
+    }
+    h->scattered[cam] = upto;
+  }
+  launch_tsq_view(h->d_tsq[cam], h->tsq_len, h->W, h->H, t_ns, h->d_sae[cam], h->stream);
+}
+
 // Both cameras' surfaces at t_ns with one launch per kernel (scatter segments, decay, median + remap): what two
 // esvo_ts_render calls do, in four launches less.  obs_out[cam] (may be null) receives a second copy of the surface.
 int ts_render_pair(esvo_context* h, uint64_t t_ns, uint8_t* const obs_out[2]) {
@@ -47,7 +76,7 @@ int ts_render_pair(esvo_context* h, uint64_t t_ns, uint8_t* const obs_out[2]) {
     ingest_fence(h, 0);
     ingest_fence(h, 1);
     u64 upto[2];
-    for (int cam = 0; cam < 2; ++cam) {
+    for (int cam = 0; cam < 2 && !h->tsq_len; ++cam) {
       const auto& tsq = h->ts_host[cam];
       const size_t k = std::lower_bound(tsq.begin(), tsq.end(), (u64)t_ns) - tsq.begin();
       upto[cam] = h->ring_base[cam] + k;
@@ -59,7 +88,8 @@ int ts_render_pair(esvo_context* h, uint64_t t_ns, uint8_t* const obs_out[2]) {
     hipEventRecord(h->evt[EV_SC0], h->stream);
     TsScatterSegs g;
     int n_seg = 0;
-    for (int cam = 0; cam < 2; ++cam) {
+    if (h->tsq_len) { queue_prepare(h, 0, (u64)t_ns); queue_prepare(h, 1, (u64)t_ns); }
+    for (int cam = 0; cam < 2 && !h->tsq_len; ++cam) {
       u64 a = h->scattered[cam];
       if (upto[cam] <= a) continue;
       h->scatter_pending_lo[cam] = std::min(h->scatter_pending_lo[cam], a);
@@ -330,9 +360,10 @@ int esvo_ts_render_forward(esvo_handle h, int cam, uint64_t t_ns, uint8_t* out_m
     const auto& tsq = h->ts_host[cam];
     const size_t k = std::lower_bound(tsq.begin(), tsq.end(), (u64)t_ns) - tsq.begin();
     const u64 upto = h->ring_base[cam] + k;
-    if (upto < h->scattered[cam])
+    if (h->tsq_len) queue_prepare(h, cam, (u64)t_ns);
+    else if (upto < h->scattered[cam])
       FAIL(ESVO_ERR_STATE, "esvo_ts_render_forward: t_ns precedes events of an earlier render (render times must not decrease; esvo_reset to replay)");
-    if (upto > h->scattered[cam]) {  // events with ts < T that are not in the SAE yet (as esvo_ts_render)
+    if (!h->tsq_len && upto > h->scattered[cam]) {  // events with ts < T that are not in the SAE yet (as esvo_ts_render)
       u64 a = h->scattered[cam];
       h->scatter_pending_lo[cam] = std::min(h->scatter_pending_lo[cam], a);
       h->scatter_seq++;
@@ -379,11 +410,12 @@ int esvo_ts_render(esvo_handle h, int cam, uint64_t t_ns, uint8_t* out_mono8) {
     const u64 upto = h->ring_base[cam] + k;
     // The SAE keeps ONE stamp per pixel, the reference a queue of 20 (TimeSurface.h:28-96): rendering at a T that precedes
     // events already scattered would read pixels as empty where getMostRecentEventBeforeT finds the older event.
-    if (upto < h->scattered[cam])
+    if (!h->tsq_len && upto < h->scattered[cam])
       FAIL(ESVO_ERR_STATE, "esvo_ts_render: t_ns precedes events of an earlier render (render times must not decrease; esvo_reset to replay)");
     if (h->ts_timing_pending[cam] && hipEventQuery(h->evt[EV_R1 + evo]) == hipSuccess) collect_ts_timing(h, cam);
     hipEventRecord(h->evt[EV_SC0 + evo], h->stream);
-    if (upto > h->scattered[cam]) {
+    if (h->tsq_len) queue_prepare(h, cam, (u64)t_ns);
+    else if (upto > h->scattered[cam]) {
       u64 a = h->scattered[cam];
       h->scatter_pending_lo[cam] = std::min(h->scatter_pending_lo[cam], a);
       h->scatter_seq++;

@@ -174,6 +174,17 @@ void launch_ts_render(const u64* d_sae, const int2* d_fixmap, uint8_t* d_raw, ui
 void launch_gaussian5(const uint8_t* d_in, uint8_t* d_out, int W, int H, hipStream_t s);
 // both cameras per launch (esvo_map_tick_resident): scatter segments, decay + median/remap, blur
 struct TsScatterSegs { const esvo_event_t* ev[4]; size_t n[4]; u64* sae[4]; };
+// per-pixel event queues (kernels_ts.hip): up to two ring segments of ONE camera per insertion
+#define TSQ_LMAX 32
+struct TsQueueArgs {
+  const esvo_event_t* ev[2]; size_t n[2];
+  u64* q;                       // [L][W * H] the camera's key sets, slot-major; 0 = empty slot
+  int L;
+  u32* tcount; uint4* tlist; u32 tcap;  // [tiles], [tiles][tcap] (key lo, key hi, pixel in tile, -)
+  uint4* over; u32* over_count; u32 over_cap;  // (key lo, key hi, pixel in tile, tile)
+};
+void launch_tsq_insert(const TsQueueArgs& a, int W, int H, hipStream_t s);
+void launch_tsq_view(const u64* q, int L, int W, int H, u64 t_ns, u64* sae, hipStream_t s);
 struct TsPair { const u64* sae[2]; uint8_t* raw[2]; const int2* fixmap[2]; uint8_t* out[2]; uint8_t* out2[2]; };
 void launch_ts_scatter_segs(const TsScatterSegs& g, int n_seg, int W, int H, hipStream_t s);
 void launch_ts_render_pair(const TsPair& c, int W, int H, u64 t_ns, double decay_sec, int ignore_polarity, int median_k,

@@ -263,6 +263,15 @@ struct esvo_context {
   int fpar = 0;                   // parity of the newest front stage
   bool tick_pending = false;      // tk[fpar] has its front stage enqueued but is not committed yet
   u64 committed_t_ns = 0;         // stamp of the newest tick whose back stage is enqueued (0: none)
+  // per-pixel event queues (max_event_queue_len > 0; kernels_ts.hip): key sets of both cameras + the batch's tile lists
+  int tsq_len = 0;
+  u64* d_tsq[2] = {nullptr, nullptr};
+  u32* d_tsq_tcount = nullptr;
+  uint4* d_tsq_tlist = nullptr;
+  uint4* d_tsq_over = nullptr;
+  u32* d_tsq_over_count = nullptr;
+  u32 tsq_tcap = 0;
+  static constexpr u64 TSQ_ROUND = 1ull << 20;  // events per insertion round = capacity of the overflow list
   u64 sh_first = 0;
   u64 sh_first_prev = 0;  // the selection before it (two ticks may be in flight)
   double2* d_reg_ab = nullptr;

@@ -57,6 +57,122 @@ void launch_ts_scatter_segs(const TsScatterSegs& g, int n_seg, int W, int H, hip
   hipLaunchKernelGGL(ts_scatter_segs_kernel, dim3((u32)blocks, (u32)n_seg), dim3(256), 0, s, g, W, H);
 }
 
+// ---- per-pixel event queues (max_event_queue_len > 0) --------------------------------------------------------------------
+// EventQueueMat (TimeSurface.h:28-97): every received event is appended to its pixel's deque, the deque is trimmed to the
+// newest L, and a render at T walks it back to the first event with ts < T.  Events arrive sorted by time (the ingest calls
+// refuse anything else), so "the newest L by arrival" is "the L largest stamps", a SET: the queue is kept as an unordered
+// set of <= L keys (t_ns << 1 | polarity; 0 = empty slot) in slot-major layout q[slot][pixel], an insertion replaces the
+// smallest key once the set is full, and the render takes the largest key below T.  Insertion order inside a batch is
+// therefore free, which is what lets a batch be inserted in parallel:
+//   tsq_bin    thread / event: the event goes to the list of its 8x8-pixel tile (one atomic per event; lists of fixed
+//              capacity, the rare rest to one overflow list every tile scans);
+//   tsq_merge  one wave / tile, lane = pixel: the tile's queues in LDS, the tile's list broadcast entry by entry, the
+//              owning lane inserts;
+//   tsq_view   thread / pixel: the largest key with stamp < T -> the SAE word the render kernels read (they are unchanged).
+// (Two events of one pixel with the same nanosecond stamp: the reference keeps arrival order, this keeps key order -- as the
+// one-stamp path, visible only with ignore_polarity = false.)
+#define TSQ_TILE 8
+__global__ void __launch_bounds__(256) tsq_bin_kernel(TsQueueArgs a, int W, int H) {
+  const int tiles_x = (W + TSQ_TILE - 1) / TSQ_TILE;
+  for (int k = 0; k < 2; ++k) {
+    const uint4* __restrict__ ev = reinterpret_cast<const uint4*>(a.ev[k]);
+    const size_t n = a.n[k];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+      const uint4 e = ev[i];
+      const u32 x = e.x & 0xffffu, y = e.x >> 16;
+      if (x >= (u32)W || y >= (u32)H) continue;  // EventQueueMat::insideImage
+      const u64 t_ns = (u64)e.y * 1000000000ull + (u64)e.z;
+      const u64 key = (t_ns << 1) | (u64)((e.w & 0xffu) ? 1u : 0u);
+      if (key <= 1ull) continue;  // a zero stamp never renders (TimeSurface.cpp:73) and would read as an empty slot
+      const u32 tile = (y / TSQ_TILE) * (u32)tiles_x + x / TSQ_TILE;
+      const u32 pix = (y % TSQ_TILE) * TSQ_TILE + x % TSQ_TILE;
+      const u32 pos = atomicAdd(&a.tcount[tile], 1u);
+      if (pos < a.tcap) {
+        a.tlist[(size_t)tile * a.tcap + pos] = make_uint4((u32)key, (u32)(key >> 32), pix, 0u);
+      } else {
+        const u32 o = atomicAdd(a.over_count, 1u);
+        if (o < a.over_cap) a.over[o] = make_uint4((u32)key, (u32)(key >> 32), pix, tile);
+      }
+    }
+  }
+}
+__global__ void __launch_bounds__(64) tsq_merge_kernel(TsQueueArgs a, int W, int H) {
+  __shared__ u64 s_q[TSQ_LMAX][64];
+  __shared__ uint4 s_e[64];
+  const int lane = threadIdx.x;
+  const u32 tile = blockIdx.x;
+  const u32 cnt = a.tcount[tile];
+  const u32 n_over = min(*a.over_count, a.over_cap);
+  if (cnt == 0 && n_over == 0) return;
+  const u32 P = min(cnt, a.tcap);
+  const int tiles_x = (W + TSQ_TILE - 1) / TSQ_TILE;
+  const int x = (int)(tile % tiles_x) * TSQ_TILE + lane % TSQ_TILE, y = (int)(tile / tiles_x) * TSQ_TILE + lane / TSQ_TILE;
+  const bool in_img = x < W && y < H;
+  const size_t npx = (size_t)W * H, px = (size_t)y * W + x;
+  const int L = a.L;
+  int n = 0;  // keys in the set (the non-empty slots, compacted to the front)
+  if (in_img)
+    for (int sl = 0; sl < L; ++sl) {
+      const u64 k = a.q[(size_t)sl * npx + px];
+      if (k) s_q[n++][lane] = k;
+    }
+  bool changed = false;
+  auto insert = [&](u64 key) {
+    if (n < L) { s_q[n++][lane] = key; changed = true; return; }
+    int m = 0;
+    u64 mv = s_q[0][lane];
+    for (int sl = 1; sl < L; ++sl) { const u64 v = s_q[sl][lane]; if (v < mv) { mv = v; m = sl; } }
+    if (key >= mv) { s_q[m][lane] = key; changed = true; }  // (an equal stamp: the later arrival displaces the earlier one)
+  };
+  for (u32 base = 0; base < P; base += 64) {
+    __syncthreads();
+    if (base + lane < P) s_e[lane] = a.tlist[(size_t)tile * a.tcap + base + lane];
+    __syncthreads();
+    const u32 m = min(64u, P - base);
+    for (u32 j = 0; j < m; ++j) {
+      const uint4 e = s_e[j];
+      if ((int)e.z == lane && in_img) insert(((u64)e.y << 32) | e.x);
+    }
+  }
+  for (u32 base = 0; base < n_over; base += 64) {  // (rare: a tile that received more than its list holds)
+    __syncthreads();
+    if (base + lane < n_over) s_e[lane] = a.over[base + lane];
+    __syncthreads();
+    const u32 m = min(64u, n_over - base);
+    for (u32 j = 0; j < m; ++j) {
+      const uint4 e = s_e[j];
+      if (e.w == tile && (int)e.z == lane && in_img) insert(((u64)e.y << 32) | e.x);
+    }
+  }
+  if (changed)
+    for (int sl = 0; sl < n; ++sl) a.q[(size_t)sl * npx + px] = s_q[sl][lane];
+  if (lane == 0) a.tcount[tile] = 0;  // (only this workgroup reads it: the list is free for the next batch)
+}
+__global__ void __launch_bounds__(256) tsq_view_kernel(const u64* __restrict__ q, int L, size_t npx, u64 t_ns, u64* __restrict__ sae) {
+  const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= npx) return;
+  u64 best = 0;
+  for (int sl = 0; sl < L; ++sl) {  // EventQueueMat::getMostRecentEventBeforeT, TimeSurface.h:52-75 (strict <)
+    const u64 k = q[(size_t)sl * npx + p];
+    if ((k >> 1) < t_ns && k > best) best = k;
+  }
+  sae[p] = best;
+}
+void launch_tsq_insert(const TsQueueArgs& a, int W, int H, hipStream_t s) {
+  const size_t n = a.n[0] + a.n[1];
+  if (n == 0) return;
+  hipMemsetAsync(a.over_count, 0, sizeof(u32), s);
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(tsq_bin_kernel, dim3((u32)blocks), dim3(256), 0, s, a, W, H);
+  const int n_tiles = ((W + TSQ_TILE - 1) / TSQ_TILE) * ((H + TSQ_TILE - 1) / TSQ_TILE);
+  hipLaunchKernelGGL(tsq_merge_kernel, dim3(n_tiles), dim3(64), 0, s, a, W, H);
+}
+void launch_tsq_view(const u64* q, int L, int W, int H, u64 t_ns, u64* sae, hipStream_t s) {
+  const size_t npx = (size_t)W * H;
+  hipLaunchKernelGGL(tsq_view_kernel, dim3((u32)((npx + 255) / 256)), dim3(256), 0, s, q, L, npx, t_ns, sae);
+}
+
 // ---- K2: decay + quantise ------------------------------------------------------------------------
 // TimeSurface.cpp:65-127.  dt is formed like ros::Duration::toSec() (Appendix A-17); the u8
 // conversion is cv::Mat::convertTo = saturate_cast<uchar>(cvRound(v)) = round-half-even.

@@ -142,6 +142,9 @@ def make_params(cfg, rig, node=None, throughput_events=None, **overrides):
         p.max_window_points = p.max_fusion_frames * p.max_events_per_tick
     p.max_poses_per_tick = 256
     p.event_ring_capacity = 1 << 24
+    # The reference's max_event_queue_len (20) is NOT taken over by default: 0 selects the one-stamp-per-pixel fast path
+    # (include/esvo_hip.h); pass max_event_queue_len=20 as an override for EventQueueMat's exact semantics.
+    p.max_event_queue_len = 0
     for k, v in overrides.items():
         if not hasattr(p, k):
             raise KeyError(k)

@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define ESVO_HIP_ABI_VERSION 4
+#define ESVO_HIP_ABI_VERSION 5
 
 typedef enum esvo_status_t {
   ESVO_OK = 0,
@@ -140,6 +140,12 @@ typedef struct esvo_params_t {
   int32_t max_window_points;       /* total DepthPoints the fusion window may hold */
   int32_t max_poses_per_tick;      /* >= 201 */
   int64_t event_ring_capacity;     /* staged events per camera */
+  /* esvo_time_surface: max_event_queue_len (TimeSurface.cpp:30, default 20).  0 (default here): ONE stamp per pixel -- the
+   * fast path; render times must not decrease and the queue's eviction artefact (a render older than max_event_queue_len
+   * newer events of a pixel reads that pixel empty, TimeSurface.h:39-75) is not reproduced.  1..32: EventQueueMat semantics
+   * exactly -- every staged event enters its pixel's queue at the next render, renders at any time in any order. */
+  int32_t max_event_queue_len;
+  int32_t pad_params_;
 } esvo_params_t;
 
 /* What flows EventBM -> DepthProblemSolver.  The reference's EventMatchPair

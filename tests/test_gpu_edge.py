@@ -581,3 +581,37 @@ def test_block_matching_only_mode_refuses_before_any_state_flips(upenn_rig, upen
     idx = O.select_events(upenn_stream.ev_left, t, p.bm_half_slice_thickness, p.process_event_num)
     fresh.tick(upenn_stream.ev_left[idx])
     _same_map(dev.get_map(), fresh.get_map())
+
+
+def test_event_queue_mode_maps_like_the_one_stamp_path(upenn_rig, upenn_stream):
+    """max_event_queue_len = 20 (EventQueueMat semantics, tests/test_gpu_parity.py::test_time_surface_event_queues_...) through the
+    resident tick: on a stream that never fires one pixel more than 20 times between a render time and the newest staged
+    event, the queues and the one-stamp path see the same newest-event-before-T, so Time Surfaces and DepthMaps are identical
+    -- with ALL events staged up front (the queues hold the future ones too), ticks in order, then one tick in the PAST,
+    which only the queue mode accepts."""
+    from esvo_amd import lib, params, rostime
+    p0, _ = params.make_params(params.PRESETS["mapping_upenn"], upenn_rig)
+    p1, _ = params.make_params(params.PRESETS["mapping_upenn"], upenn_rig, max_event_queue_len=20)
+    a, b = lib.Esvo(p0, upenn_rig), lib.Esvo(p1, upenn_rig)
+    for d in (a, b):
+        d.ts_push_events(0, upenn_stream.ev_left)
+        d.ts_push_events(1, upenn_stream.ev_right)
+    for k in range(4):
+        t = upenn_stream.t0_ns + int((0.1 + 0.01 * k) * 1e9)
+        stamps, poses = rostime.pose_table(upenn_stream.pose, t, p0.bm_half_slice_thickness)
+        T = upenn_stream.pose(t)
+        a.tick_resident(t, T, stamps, poses)
+        b.tick_resident(t, T, stamps, poses)
+        ma, mb = a.get_map(), b.get_map()
+        assert len(ma) > 0 and ma.tobytes() == mb.tobytes(), k
+    t_past = upenn_stream.t0_ns + int(0.105 * 1e9)
+    img_b = b.ts_render(0, t_past)                      # a render in the past: the queues walk back
+    with pytest.raises(lib.EsvoError, match="render times must not decrease"):
+        a.ts_render(0, t_past)
+    fresh = lib.Esvo(p0, upenn_rig)                     # what the one-stamp path renders at that time when it gets there in order
+    fresh.ts_push_events(0, upenn_stream.ev_left)
+    img_f = fresh.ts_render(0, t_past)
+    # identical wherever no pixel fired more than 20 times between t_past and the end of the stream
+    assert np.mean(img_b == img_f) > 0.97 and img_b.any()
+    for d in (a, b, fresh):
+        d.close()

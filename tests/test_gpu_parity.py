@@ -427,3 +427,40 @@ def test_shared_divisor_division_is_ieee_identical():
     """fdiv.hpp: div_by(a, make_recip(b)) must equal a / b bit for bit (2^28 random + edge-case pairs)."""
     from esvo_amd import lib
     assert lib.selftest_division(1 << 28, seed=7) == 0
+
+
+@pytest.mark.parametrize("tile_cap", [None, 4])
+def test_time_surface_event_queues_equal_the_reference_source(tile_cap):
+    """max_event_queue_len > 0: EventQueueMat semantics on the device (kernels_ts.hip: a set of <= L keys per pixel, batches
+    inserted through 8x8-pixel tile lists, the SAE word of every pixel derived per render) against the reference's own
+    TimeSurface class compiled from source (tests/golden/ref_ts.npz: queues of 20 and of 3 events, renders at the newest stamp
+    and 5 / 11 ms BEFORE events already inserted -- the short queue loses events the long one still finds).  tile_cap = 4 forces
+    every tile's list to overflow into the shared list (ESVO_TSQ_TILE_CAP, read at esvo_create)."""
+    import subprocess, sys
+    if tile_cap is not None and os.environ.get("ESVO_TSQ_TILE_CAP") != str(tile_cap):
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        env = dict(os.environ, ESVO_TSQ_TILE_CAP=str(tile_cap))
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-m", "gpu", "-q", "-x",
+                            "-k", "event_queues_equal_the_reference_source and None"], cwd=root, env=env, capture_output=True, text=True,
+                           timeout=600)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+        assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-2000:]
+        return
+    from test_ref_pin import GOLDEN, _ts_cases
+    g = np.load(os.path.join(GOLDEN, "ref_ts.npz"))
+    dev, cur, n = None, None, 0
+    for ql, k, tk, chunk, rig_ in _ts_cases():
+        if cur != ql:
+            if dev is not None:
+                dev.close()
+            rig = calib.ideal_rig(rig_.width, rig_.height, 200.0, 0.1)    # identity remap: the raster itself is compared
+            p, _ = params.make_params(params.PRESETS["mvstereo_upenn"], rig, median_blur_kernel_size=0, max_event_queue_len=ql)
+            dev, cur = _dev(p, rig), ql
+        dev.ts_push_events(0, chunk)
+        for j, back in enumerate((0, 5_000_000, 11_000_000)):      # render times go BACK: allowed in queue mode
+            img = dev.ts_render(0, tk - back)
+            want = g[f"q{ql}_k{k}_b{j}"]
+            assert np.array_equal(img, want), (ql, k, j, int(np.count_nonzero(img != want)))
+            n += 1
+    dev.close()
+    assert n == 48
