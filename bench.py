@@ -743,7 +743,7 @@ def shift_events(ev, dt_ns):
     return out
 
 
-def sustained_point(name, n_ticks, device, prof, events_cap=0, base_ticks=40):
+def sustained_point(name, n_ticks, device, prof, events_cap=0, base_ticks=40, hook=None):
     """The headline workload for >= 2 s of wall time instead of 20 ticks (28 ms): long enough for the chip's power management
     to settle, with the shader clock measured inside the run.  Generating 16 s of synthetic stream would take minutes of
     numpy, so the stationary stream is LOOPED: 60 ms of history, then a segment of `base_ticks` ticks played again and again
@@ -791,6 +791,8 @@ def sustained_point(name, n_ticks, device, prof, events_cap=0, base_ticks=40):
     for k in range(n_warm, n_warm + n_ticks):
         t, stamps, poses, T = ticks[k]
         dev.tick_resident(t, T, stamps, poses)
+        if hook is not None:   # tools/regime_probe.py: a disturbance in the middle of the run
+            hook(k - n_warm)
         if (k - n_warm) % 100 == 99:   # host time stamps without a synchronisation: the lazy tick paces the host to the device
             marks.append(time.perf_counter())
     dev.synchronize()
@@ -801,7 +803,7 @@ def sustained_point(name, n_ticks, device, prof, events_cap=0, base_ticks=40):
     sclk, per_xcd = s.sclk_mhz(b)
     ks = (np.array(list(s.sum_ms_kernel)) - np.array(list(b.sum_ms_kernel))) / n_ticks
     win = np.diff(np.array([t0] + marks)) / 100.0 * 1e3    # ms per tick over windows of 100 ticks
-    res = {"events_per_s": ev / dt, "ms_per_tick": dt / n_ticks * 1e3, "ticks": n_ticks, "wall_s": dt,
+    res = {"windows_ms": [round(float(w), 4) for w in win], "events_per_s": ev / dt, "ms_per_tick": dt / n_ticks * 1e3, "ticks": n_ticks, "wall_s": dt,
            "events_per_tick": ev // n_ticks, "depth_points_per_s": int(s.total_points - b.total_points) / dt,
            "matches_per_tick": int(s.total_matches - b.total_matches) // n_ticks,
            "sclk_mhz": sclk, "sclk_mhz_per_xcd": per_xcd, "sclk_samples": int(s.clk_samples - b.clk_samples),
@@ -969,7 +971,7 @@ def other_operating_points(device):
         for pe in pins:
             pe.free()
         ev = int(s.total_events_in - b.total_events_in)
-        res = {"events_per_s": ev / dt, "ms_per_tick": dt / n * 1e3, "events_per_tick": ev // n,
+        res = {"windows_ms": [round(float(w), 4) for w in win], "events_per_s": ev / dt, "ms_per_tick": dt / n * 1e3, "events_per_tick": ev // n,
                "depth_points_per_s": int(s.total_points - b.total_points) / dt}
         if timed_ingest:
             res["note"] = ("host-to-device staging of each tick's events (2 x 16 B/event) inside the timed loop, " +

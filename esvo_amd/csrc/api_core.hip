@@ -202,6 +202,7 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
     const char* e = std::getenv("ESVO_LM_STREAM");
     h->lm_split = !(e && std::atoi(e) == 0);
   }
+  if (const char* ef = std::getenv("ESVO_FRONT_THROTTLE")) h->front_throttle = std::atoi(ef) != 0;
   if (const char* e1 = std::getenv("ESVO_ONE_STREAM")) {  // A/B only: the three stages in one queue (no cross-queue hand-offs)
     if (std::atoi(e1) == 1) {
       hipStreamDestroy(h->stream_b);

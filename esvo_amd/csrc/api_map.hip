@@ -616,8 +616,16 @@ int tick_phase0(esvo_context* h, uint64_t t_ns, const uint64_t* pose_t_ns, const
   tk.pose_buf = h->pose_buf; tk.n_pose = h->n_pose;
   std::memcpy(tk.T_world_obs, h->T_world_obs, sizeof(double) * 16);
   // two ticks in flight at most: what this tick's front stage overwrites (ring space of popped frames, the pose
-  // table buffer) was last read by the back stage two ticks ago
-  HIPCHK(hipStreamWaitEvent(h->stream, h->evt[EV_RG1 + h->par * EV_BACK_STRIDE], 0));
+  // table buffer) was last read by the back stage two ticks ago.
+  // (For the ordinary tick this device-side wait is, by inspection, only a throttle: it writes parity buffers that are
+  // released by events of their own -- EV_STG, EV_POSE, the collected EV_CNT -- and the host never runs more than two back
+  // stages ahead.  It is also the coupling behind the pipeline's second, slower operating point -- back chain behind -> the
+  // front stage and the next LM launch start only when a back stage ends -> the LM kernel runs beside the regulariser's whole
+  // launch -> regulariser 0.9 instead of 0.65 ms -> back chain stays behind: 1.5 instead of 1.3 ms per tick, seen in 2 of ~25
+  // sustained runs.  ESVO_FRONT_THROTTLE=0 drops the wait for unsharded ticks: neutral in the usual operating point, GPU suite
+  // green; whether it removes the slow one could not be shown in the GPU time of round 4 (profiles/r04_front_throttle.txt),
+  // so the wait stays.)
+  if (h->sharded || h->front_throttle) HIPCHK(hipStreamWaitEvent(h->stream, h->evt[EV_RG1 + h->par * EV_BACK_STRIDE], 0));
   hipEventRecord(h->evt[EV_T0 + h->fpar * EV_FRONT_STRIDE], h->stream);
   const u32* sel = nullptr;
   if (h->prm.denoising && n) {

@@ -69,6 +69,7 @@ struct esvo_context {
   u32 lm_two_max = esvo::LM_TWO_QUEUES_MAX_EVENTS;  // launches bounded by more events stay on one queue
   bool lm_split = true;           // ESVO_LM_STREAM=0: everything of the front stage on `stream`
   bool one_stream = false;       // ESVO_ONE_STREAM=1 (A/B): stream_b aliases stream
+  bool front_throttle = true;    // ESVO_FRONT_THROTTLE=0 (A/B): an unsharded tick's front stage does not wait for the back stage two ticks ago (api_map.hip)
   int cu_split[3] = {0, 0, 0};    // ESVO_CU_SPLIT (A/B): CUs of the fusion / matching streams, CUs of the device
   bool split_now = false;         // set by esvo_map_tick around its front stage: only the lazy tick path splits
   uint8_t* d_obs2[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
