@@ -32,6 +32,12 @@ namespace esvo {
 // leave 144 of 512 VGPRs.  At <= 80 VGPRs a second back-stage wave fits where only one did (propagate 114 -> 72,
 // reg_apply 124 -> 78, no spills): +1.5 % per tick.  fuse_cells keeps its 112 (capping it spills; dropping its software
 // prefetch gives 80 and was measured neutral).
+// A/B only (-DBACK_SETPRIO=n): the issue priority of the back stage's waves inside their SIMD (s_setprio 0..3; default 0)
+#ifdef BACK_SETPRIO
+#define BACK_PRIO() __builtin_amdgcn_s_setprio(BACK_SETPRIO)
+#else
+#define BACK_PRIO() do {} while (0)
+#endif
 #ifndef BACK_WAVES
 #define BACK_WAVES 6
 #endif
@@ -99,6 +105,7 @@ __device__ inline u32 fuse_bucket(u32 n) {  // n >= 1: 1->0, 2->1, 3..4->2, 5..8
 
 template <int MODEL>
 __global__ void __launch_bounds__(256, BACK_WAVES) propagate_kernel(FuseArgs a, DevParams p, int K) {
+  BACK_PRIO();
   const u32 q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= a.n_pts) return;
   u32 f = 0;  // frame of point q (binary search in the cumulative counts)
@@ -265,6 +272,7 @@ __device__ inline void fuse_record(const DevParams& p, MapCell& c, bool& exists,
 #define FUSE_BITW (FUSE_PMAX / 32 + 1)   // words per cell row (+1: no bank conflicts between the lanes' rows)
 #define FUSE_BUF (FUSE_LDS_CAP_MAX > 2 * FUSE_PMAX + FT_CELLS * FUSE_BITW ? FUSE_LDS_CAP_MAX : 2 * FUSE_PMAX + FT_CELLS * FUSE_BITW)
 __global__ void __launch_bounds__(FT_CELLS, 8) tile_lists_kernel(FuseArgs a, DevParams p, int K, int radius, u32 cap, u32 pmax) {
+  BACK_PRIO();
   __shared__ u32 s_buf[FUSE_BUF];        // fast path: ids | (row, col) | bit rows; dense path: record ids
   __shared__ u32 s_cnt[FT_CELLS];        // dense path: records per cell of the tile
   __shared__ u32 s_off[FT_CELLS + 1];    //             their exclusive scan
@@ -617,6 +625,7 @@ __global__ void __launch_bounds__(FT_CELLS, 8) tile_lists_kernel(FuseArgs a, Dev
 #endif
 template <int MODEL>
 __global__ void __launch_bounds__(FUSE_BLOCK, FUSE_WAVES) fuse_cells_kernel(FuseArgs a, DevParams p, int K, int n_tiles) {
+  BACK_PRIO();
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   const int ncell = p.W * p.H;
   // thread t -> the t-th touched cell in the order "longest class first": class_total[s] = cells before segment s, segments
@@ -666,6 +675,7 @@ __global__ void __launch_bounds__(FUSE_BLOCK, FUSE_WAVES) fuse_cells_kernel(Fuse
 // tick's statistics are cleared / set
 #define FUSE_TURN_B 256
 __global__ void __launch_bounds__(FUSE_TURN_B) fuse_turn_kernel(FuseArgs a, int n_tiles) {
+  BACK_PRIO();
   __shared__ u32 lds[FUSE_TURN_B / ESVO_WAVE];
   constexpr u32 NSEG = FUSE_NB * FUSE_SLICES;
   constexpr u32 PER = NSEG / FUSE_TURN_B;
@@ -755,6 +765,7 @@ __global__ void __launch_bounds__(256) reg_view_kernel(const MapCell* __restrict
                                                        u32* __restrict__ owner_max, u32* __restrict__ owner_min,
                                                        u32* __restrict__ n_elems, int ncell, int W,
                                                        int band0, int band1, int view0, int view1, int l2) {
+  BACK_PRIO();
   const int cell = blockIdx.x * blockDim.x + threadIdx.x;
   bool alive = false;
   if (cell < ncell) {
@@ -808,6 +819,7 @@ __global__ void __launch_bounds__(REG_TX * REG_TY, BACK_WAVES) reg_apply_kernel(
                                                                     const u32* __restrict__ owner_min,
                                                                     const double2* __restrict__ ab,
                                                                     const double2* __restrict__ cd, DevParams p) {
+  BACK_PRIO();
   __shared__ double2 s_ab[2][REG_MAXW];
   __shared__ double2 s_cd[2][REG_MAXW];
   __shared__ u64 s_vb[2][3];

@@ -563,6 +563,9 @@ template <bool WIDE, bool L2 = false, int STAGE = 0, bool PAIR = false>
 __global__ void __launch_bounds__(PAIR ? 128 : LM_BLOCK, WIDE ? LM_WIDE_WAVES : LM_WAVES) lm_refine_kernel(LmArgs a, DevParams p, u32* n_solved, LmSplit sp) {
   static_assert(!PAIR || (WIDE && !L2 && STAGE == 0), "the pair layout is a variant of the wide one");
   constexpr int RL = Lay<WIDE>::RL;
+#ifdef LM_SETPRIO  // A/B only: the wave's issue priority inside its SIMD (0..3; default 0 like every other kernel)
+  __builtin_amdgcn_s_setprio(LM_SETPRIO);
+#endif
   // [exchange parity][wave][row][lane]: residuals of the two points evaluated side by side, + whether each was tight
   __shared__ double lds_pair[PAIR ? 2 : 1][2][RL][64];
   __shared__ int lds_pair_tight[PAIR ? 2 : 1][2];
