@@ -589,10 +589,16 @@ def main():
         except Exception as e:  # noqa: BLE001  (an extra: never takes the headline down with it)
             out["sustained"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not args.no_extras:
-        out["other_operating_points"] = other_operating_points(local_rank)
+        try:
+            out["other_operating_points"] = other_operating_points(local_rank)
+        except Exception as e:  # noqa: BLE001  (extras: the headline line is printed whatever happens here)
+            out["other_operating_points"] = {"error": f"{type(e).__name__}: {e}"}
     ref_maps = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        port = cpu_baseline(rig, stream, p, ticks)
+        try:
+            port = cpu_baseline(rig, stream, p, ticks)
+        except Exception as e:  # noqa: BLE001  (the line is printed whatever happens to a baseline leg)
+            port = {"error": f"{type(e).__name__}: {e}", "kind": "port"}
         try:
             out["cpu_baseline"], ref_maps = cpu_baseline_reference(args.workload, rig, stream, ticks)
             out["cpu_baseline"]["port"] = port     # the CPU oracle on every host thread, for the record
@@ -1034,18 +1040,21 @@ def other_operating_points(device):
                         "esvo_track_register (host C++ over esvo_track_normal_equations: one launch and 224 B back per iteration, "
                         "12 Gauss-Newton iterations at most)"}
 
-    out["upenn346x260_throughput"] = throughput("upenn346x260", 20)
-    out["dsec640x480_reference_faithful_10000"] = latency("dsec640x480", 10000, 20)
-    out["upenn346x260_reference_faithful_1000"] = latency("upenn346x260", 1000, 20)
-    try:
-        out["upenn346x260_closed_loop"] = closed_loop()
-    except Exception as e:  # an extra: never takes the headline down with it
-        out["upenn346x260_closed_loop"] = {"error": f"{type(e).__name__}: {e}"}
+    def point(key, fn, *a, **kw):   # an extra never takes the headline down with it: its failure is reported in its place
+        try:
+            out[key] = fn(*a, **kw)
+        except Exception as e:  # noqa: BLE001
+            out[key] = {"error": f"{type(e).__name__}: {e}"}
+
+    point("upenn346x260_throughput", throughput, "upenn346x260", 20)
+    point("dsec640x480_reference_faithful_10000", latency, "dsec640x480", 10000, 20)
+    point("upenn346x260_reference_faithful_1000", latency, "upenn346x260", 1000, 20)
+    point("upenn346x260_closed_loop", closed_loop)
     # SURVEY.md section 8 stress row: 1280x720, 145 disparity candidates, 100 Mev/s over both cameras, with the oracle equality flag
-    out["hd1280x720_throughput"] = throughput("hd1280x720", 6, check=True)
+    point("hd1280x720_throughput", throughput, "hd1280x720", 6, check=True)
     # the headline workload with the PCIe transfer of every tick's events inside the timed loop (never `value`)
-    out["dsec640x480_with_timed_ingest"] = throughput("dsec640x480", 20, timed_ingest=True)
-    out["dsec640x480_with_timed_ingest_pinned"] = throughput("dsec640x480", 20, timed_ingest=True, pinned=True)
+    point("dsec640x480_with_timed_ingest", throughput, "dsec640x480", 20, timed_ingest=True)
+    point("dsec640x480_with_timed_ingest_pinned", throughput, "dsec640x480", 20, timed_ingest=True, pinned=True)
     return out
 
 
