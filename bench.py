@@ -702,14 +702,23 @@ def selftest(rank, world, local_rank, dist, ranks_seen, rccl, n_ticks=6):
         from esvo_amd import dist as edist
         native = backend == "nccl" and os.environ.get("ESVO_NATIVE_COMM", "1") != "0"
         res["exchange"] = "esvo_comm_* (RCCL inside libesvo_hip.so)" if native else f"torch.distributed ({backend})"
-        for mode in ("tick", "band"):
+        # "band": events routed by image row, banded Time Surfaces; "band_broadcast": the A/B switch (every rank
+        # stages everything, per-event work dealt by slot)
+        for mode in ("tick", "band", "band_broadcast"):
             cls = ((edist.NativeTickSharded if mode == "tick" else edist.NativeBandSharded) if native
                    else (edist.TickShardedEsvo if mode == "tick" else edist.ShardedEsvo))
+            kw = {} if mode == "tick" else {"routing": "y_rect" if mode == "band" else "broadcast"}
             t0 = time.perf_counter()
             try:
-                runner = cls(p, rig, rank, world, local_rank)
+                runner = cls(p, rig, rank, world, local_rank, **kw)
                 gm = drive(runner)
                 shas[mode] = {"sha1": map_sha1(gm), "map_size": int(len(gm)), "seconds": round(time.perf_counter() - t0, 2)}
+                if mode == "band":
+                    st_ = runner.stats()
+                    shas[mode]["rows"] = runner.dev.shard_rows()
+                    shas[mode]["events_staged_rank0"] = [int(st_.events_staged[0]), int(st_.events_staged[1])]
+                    shas[mode]["events_in_stream"] = [int(len(stream.ev_left)), int(len(stream.ev_right))]
+                    shas[mode]["halo_violations"] = int(st_.halo_violations)
                 runner.dev.close()
             except Exception as e:  # noqa: BLE001  (a hang inside RCCL cannot be caught: the 30 s budget is the caller's timeout)
                 shas[mode] = {"error": f"{type(e).__name__}: {e}"}

@@ -109,6 +109,8 @@ class StatsStruct(C.Structure):
         # ABI 3: in-run shader-clock probe of the refinement kernel (include/esvo_hip.h)
         ("clk_cycles", C.c_uint64 * 8), ("clk_ref_ticks", C.c_uint64 * 8), ("clk_samples", C.c_uint64),
         ("clk_ref_khz", C.c_uint32), ("pad3_", C.c_uint32),
+        # ABI 6: routed band mode
+        ("halo_violations", C.c_uint64),
     ]
 
     def sclk_mhz(self, base=None):

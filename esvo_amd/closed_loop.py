@@ -40,24 +40,44 @@ def register(dev, n_points, R_, t_, iters=12):
     return R, t, rms
 
 
-def register_python(dev, n_points, R_, t_, iters=12):
-    """The same damped Gauss-Newton on (cayley, translation) in Python over esvo_track_residuals / esvo_track_jacobian (two
-    synchronous calls and a count x 7 download per iteration): round 3's driver, kept as the cross-check of the C++ one."""
-    r = None
-    for _ in range(iters):
-        Tlr = np.eye(4)
-        Tlr[:3, :3] = R_.T
-        Tlr[:3, 3] = -R_.T @ t_
-        r = dev.track_residuals(Tlr, 0, n_points, huber=True, huber_threshold=50.0)
-        J = dev.track_jacobian(R_, t_, 0, n_points)
-        H = J.T @ J
-        dx = -np.linalg.solve(H + 1e-3 * np.diag(np.diag(H)) + 1e-9 * np.eye(6), J.T @ r)
-        dR = cayley2rot(dx[:3])
-        R_ = orth(dR @ R_)
-        t_ = dx[3:] + dR @ t_
+def lm_gn_loop(evaluate, R_, t_, iters=12, damping=1e-3):
+    """include/esvo_hip.hpp's gauss_newton_register in numpy (same batch every iteration): Levenberg-damped Gauss-Newton steps
+    linearised at x = 0, each accepted only if actual / predicted reduction >= 1e-4 (cost evaluated at the trial pose), the
+    damping raised tenfold otherwise.  evaluate(R, t) -> (H, b, cost, n).  Returns (R, t, rms, iterations)."""
+    H, b, cost, n = evaluate(R_, t_)
+    it = 0
+    for it in range(iters):
+        lam, accepted = damping, False
+        for _ in range(6):
+            dx = np.linalg.solve(H + lam * np.diag(np.diag(H)) + 1e-9 * np.eye(6), -b)
+            dR = cayley2rot(dx[:3])
+            Rn, tn = orth(dR @ R_), dx[3:] + dR @ t_
+            Ht, bt, cost_t, nt = evaluate(Rn, tn)
+            pred = -(2.0 * b @ dx + dx @ H @ dx)
+            if pred > 0 and (cost - cost_t) >= 1e-4 * pred:
+                accepted = True
+                break
+            lam *= 10.0
+        if not accepted:
+            break
+        R_, t_, H, b, cost, n = Rn, tn, Ht, bt, cost_t, nt
         if np.linalg.norm(dx) < 1e-6:
             break
-    return R_, t_, float(np.sqrt(np.mean(r * r)))
+    return R_, t_, float(np.sqrt(cost / n)) if n else 0.0, it + 1
+
+
+def register_python(dev, n_points, R_, t_, iters=12):
+    """The library's driver (esvo_track_register) restated in Python over esvo_track_residuals / esvo_track_jacobian (two
+    synchronous calls and a count x 7 download per evaluation): the cross-check of the C++ one."""
+    def evaluate(R, t):
+        Tlr = np.eye(4)
+        Tlr[:3, :3] = R.T
+        Tlr[:3, 3] = -R.T @ t
+        r = dev.track_residuals(Tlr, 0, n_points, huber=True, huber_threshold=50.0)
+        J = dev.track_jacobian(R, t, 0, n_points)
+        return J.T @ J, J.T @ r, float(r @ r), len(r)
+    R, t, rms, _ = lm_gn_loop(evaluate, R_, t_, iters)
+    return R, t, rms
 
 
 def run(n_ticks=15, reref=10**9, speed=1.0, seed=20250419, verbose=False):

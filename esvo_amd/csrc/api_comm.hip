@@ -6,12 +6,14 @@
 //     only through the DepthPoint frames of its fusion window (MappingAtTime builds a new DepthFrame every tick,
 //     esvo_Mapping.cpp:266-272, :341-377), so the ONE exchange per round of N ticks is an ncclAllGather of the round's
 //     frames.  Each block carries its own point count in-band: one collective and one host wait per round.
-//   * one tick split by slot / image row band (esvo_comm_shard_tick): the two integer sums of esvo_shard_tick_phase as
-//     ncclAllReduce(ncclUint64, ncclSum), and the DepthMap bands as ncclAllGather (esvo_comm_gather_map) -- north_star's
-//     "all-gather of per-tile depth estimates".
-// RCCL is loaded with dlopen at esvo_comm_init, so single-GPU users of libesvo_hip.so neither link nor initialise it.
-// esvo_comm_init_callbacks takes the two collectives as function pointers instead: tests drive several ranks on ONE GPU
-// through exactly this code with an in-process transport, and another transport can be plugged in without touching it.
+//   * one tick split over the ranks (esvo_comm_shard_tick): per-event work by image row of the rectified event (or, as
+//     an A/B switch, dealt by slot), per-cell work by image row band; the two exchanges of esvo_shard_tick_phase -- the
+//     (matched, kept) bits of the tick's slots, then [count | kept points] -- and the DepthMap bands
+//     (esvo_comm_gather_map: north_star's "all-gather of per-tile depth estimates") are all ncclAllGather.
+// ncclAllGather is the ONLY collective this library issues.  RCCL is loaded with dlopen at esvo_comm_init, so single-GPU
+// users of libesvo_hip.so neither link nor initialise it.  esvo_comm_init_callbacks takes the collective as a function
+// pointer instead: tests drive several ranks on ONE GPU through exactly this code with an in-process transport, and
+// another transport can be plugged in without touching it.
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
@@ -42,7 +44,6 @@ struct RcclApi {
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
-  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   ncclResult_t (*GetVersion)(int*) = nullptr;
   std::string path;  // the shared object the symbols resolved into (dladdr)
@@ -68,12 +69,11 @@ static const char* load_rccl() {
   a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(lib, "ncclCommInitRank"));
   a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
   a.AllGather = reinterpret_cast<decltype(a.AllGather)>(dlsym(lib, "ncclAllGather"));
-  a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(dlsym(lib, "ncclAllReduce"));
   a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
   a.GetVersion = reinterpret_cast<decltype(a.GetVersion)>(dlsym(lib, "ncclGetVersion"));
   Dl_info info;
   if (a.GetUniqueId && dladdr(reinterpret_cast<void*>(a.GetUniqueId), &info) && info.dli_fname) a.path = info.dli_fname;
-  if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllGather || !a.AllReduce || !a.GetErrorString)
+  if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllGather || !a.GetErrorString)
     return "librccl.so lacks an expected symbol";
   g_rccl = a;
   return nullptr;
@@ -88,7 +88,6 @@ struct esvo_comm {
   int rank = 0, world = 1;
   ncclComm_t nccl = nullptr;
   esvo_all_gather_fn cb_gather = nullptr;
-  esvo_all_reduce_u64_fn cb_reduce = nullptr;
   void* cb_user = nullptr;
   // tick-interleaved mode
   u64 k = 0;                       // index of the next tick
@@ -145,15 +144,6 @@ int comm_all_gather(esvo_context* h, const void* d_send, void* d_recv, size_t by
     return ESVO_OK;
   }
   NCCLCHK(g_rccl.AllGather(d_send, d_recv, bytes, ncclUint8, c->nccl, h->stream));
-  return ESVO_OK;
-}
-int comm_all_reduce_u64(esvo_context* h, void* d_buf, size_t n_words) {
-  esvo_comm* c = h->comm;
-  if (c->cb_reduce) {
-    if (c->cb_reduce(c->cb_user, d_buf, n_words, h->stream)) FAIL(ESVO_ERR_HIP, "all-reduce callback failed");
-    return ESVO_OK;
-  }
-  NCCLCHK(g_rccl.AllReduce(d_buf, d_buf, n_words, ncclUint64, ncclSum, c->nccl, h->stream));
   return ESVO_OK;
 }
 
@@ -322,16 +312,14 @@ int esvo_comm_init(esvo_handle h, const uint8_t id[ESVO_COMM_ID_BYTES], int rank
   return rc;
 }
 
-int esvo_comm_init_callbacks(esvo_handle h, int rank, int world, esvo_all_gather_fn all_gather, esvo_all_reduce_u64_fn all_reduce,
-                             void* user) {
-  if (!h || !all_gather || !all_reduce || world < 1 || rank < 0 || rank >= world) return ESVO_ERR_INVALID_ARG;
+int esvo_comm_init_callbacks(esvo_handle h, int rank, int world, esvo_all_gather_fn all_gather, void* user) {
+  if (!h || !all_gather || world < 1 || rank < 0 || rank >= world) return ESVO_ERR_INVALID_ARG;
   API_LOCK(h);
   if (h->comm) FAIL(ESVO_ERR_STATE, "the handle already has a communicator");
   HIPCHK(hipSetDevice(h->device));
   { int rcp = flush_pending_tick(h); if (rcp) return rcp; }
   h->comm = new esvo_comm();
   h->comm->cb_gather = all_gather;
-  h->comm->cb_reduce = all_reduce;
   h->comm->cb_user = user;
   int rc = comm_setup(h, rank, world);
   if (rc) comm_release(h);

@@ -70,6 +70,17 @@ void set_compute_band(esvo_context* h) {
   h->dp.cband_y1 = std::min(h->H, h->dp.band_y1 + halo);
 }
 
+// pinned staging + the global-index ring of the routed band mode
+void release_routing(esvo_context* h) {
+  for (int cam = 0; cam < 2; ++cam) {
+    if (h->h_route_ev[cam]) hipHostFree(h->h_route_ev[cam]);
+    h->h_route_ev[cam] = nullptr;
+    h->route_cap[cam] = 0;
+  }
+  if (h->h_route_gidx) hipHostFree(h->h_route_gidx);
+  h->h_route_gidx = nullptr;
+}
+
 }  // namespace esvo_host
 
 // =================================================================================================
@@ -229,6 +240,20 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
     }
     CK(dalloc(&h->d_fixmap[cam], npx));
     CK(hipMemcpy(h->d_fixmap[cam], fm.data(), sizeof(int2) * npx, hipMemcpyHostToDevice));
+    // per rectified row: the raw rows its bilinear taps reach (what a row band of the Time Surface needs of the SAE;
+    // esvo_shard_set_routing).  A tap outside the image reads the constant 0 and needs nothing.
+    h->fix_row_lo[cam].assign(h->H, h->H);
+    h->fix_row_hi[cam].assign(h->H, -1);
+    for (int y = 0; y < h->H; ++y)
+      for (int x = 0; x < h->W; ++x) {
+        const int2 m = fm[(size_t)y * h->W + x];
+        const int ix = m.x >> 5, iy = m.y >> 5, fx = m.x & 31, fy = m.y & 31;
+        if (ix + (fx ? 1 : 0) < 0 || ix >= h->W) continue;
+        const int lo = std::max(iy, 0), hi = std::min(iy + (fy ? 1 : 0), h->H - 1);
+        if (lo > hi) continue;
+        h->fix_row_lo[cam][y] = std::min(h->fix_row_lo[cam][y], lo);
+        h->fix_row_hi[cam][y] = std::max(h->fix_row_hi[cam][y], hi);
+      }
     CK(dalloc(&h->d_sae[cam], npx));
     CK(hipMemset(h->d_sae[cam], 0, sizeof(u64) * npx));
     if (params->max_event_queue_len > 0) {  // EventQueueMat semantics: a set of <= L keys per pixel, slot-major
@@ -326,8 +351,10 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
   CK(dalloc(&h->d_scan_tmp_b, scan_scratch_elems(std::max(E, npx)) + 8));
   CK(dalloc(&h->d_cnt_b, 8));
   CK(hipMemset(h->d_cnt_b, 0, sizeof(u32) * 8));
-  CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_cnt_b), sizeof(u32) * 8 * 3));
-  std::memset(h->h_cnt_b, 0, sizeof(u32) * 8 * 3);
+  CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_cnt_b), sizeof(u32) * 8 * 4));  // rows 0, 1: tick parities; 2: exports; 3: [par] halo violations
+  std::memset(h->h_cnt_b, 0, sizeof(u32) * 8 * 4);
+  CK(dalloc(&h->d_halo_viol, 2));
+  CK(hipMemset(h->d_halo_viol, 0, sizeof(u32) * 2));
   // fusion window
   h->win_cap = (u32)std::max<int64_t>((int64_t)params->max_window_points, (int64_t)E) + 2 * (u32)E;
   CK(dalloc(&h->d_win, h->win_cap));
@@ -363,6 +390,9 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
     CK(hipMemset(h->d_fuse_ctr, 0, sizeof(u32) * (2112 + 64)));
     if (const char* er = std::getenv("ESVO_FUSE_TILE_REC")) h->fuse_tile_rec = (u32)std::max(1L, std::atol(er));
     CK(dalloc(&h->d_rec_ids, n_tiles * h->fuse_tile_rec + (size_t)h->win_cap * 9));
+#ifdef FUSE_STATS
+    if (std::getenv("ESVO_FUSE_STATS")) { CK(dalloc(&h->d_fuse_stats, n_tiles * 8)); CK(hipMemset(h->d_fuse_stats, 0, sizeof(u64) * n_tiles * 8)); }
+#endif
   }
   if (const char* ef = std::getenv("ESVO_FUSE_LDS_CAP")) h->fuse_lds_cap = (u32)std::max(0L, std::atol(ef));
   CK(hipMalloc(reinterpret_cast<void**>(&h->d_map), map_buffer_bytes(npx)));  // cells + their dense flags (common.hpp: map_flags)
@@ -403,11 +433,12 @@ int esvo_destroy(esvo_handle h) {
   if (std::getenv("ESVO_POLICY_PRINT"))
     fprintf(stderr, "[esvo] LM layout policy: wide %.4f ms (%u ticks), pair %.4f ms (%u ticks); LM queues: lm %.4f ms, back %.4f ms, two %d\n",
             h->lm_pair_ms[0][0], h->lm_pair_n[0], h->lm_pair_ms[1][0], h->lm_pair_n[1], h->ema_lm_ms, h->ema_back_ms, (int)h->lm_two_on);
-  if (std::getenv("ESVO_FUSE_STATS") && h->d_over_pts) {  // -DFUSE_STATS builds only: per-tile phase cycles of the last tile_lists launch
+#ifdef FUSE_STATS  // tools-only builds: per-tile phase cycles of the last tile_lists launch (a buffer of their own, allocated at esvo_create)
+  if (h->d_fuse_stats) {
     hipDeviceSynchronize();
     const size_t nt = (size_t)((h->W + FUSE_TILE - 1) / FUSE_TILE) * ((h->H + FUSE_TILE - 1) / FUSE_TILE);
     std::vector<unsigned long long> st(nt * 8);
-    hipMemcpy(st.data(), h->d_over_pts, st.size() * 8, hipMemcpyDeviceToHost);
+    hipMemcpy(st.data(), h->d_fuse_stats, st.size() * 8, hipMemcpyDeviceToHost);
     double sum[5] = {0, 0, 0, 0, 0};
     unsigned long long tmin = ~0ull, tmax = 0;
     std::vector<std::pair<unsigned long long, size_t>> tot;
@@ -431,6 +462,7 @@ int esvo_destroy(esvo_handle h) {
     for (size_t t = 0; t < nt; ++t) hist[std::min<size_t>(9, (size_t)((st[t * 8 + 7] - tmin) * 10 / std::max<unsigned long long>(tmax - tmin, 1)))]++;
     fprintf(stderr, "[esvo]   wave starts per tenth of the span: %u %u %u %u %u %u %u %u %u %u\n", hist[0], hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7], hist[8], hist[9]);
   }
+#endif
   if (h->stream) hipStreamSynchronize(h->stream);
   if (h->stream_l) hipStreamSynchronize(h->stream_l);
   if (h->stream_l1) hipStreamSynchronize(h->stream_l1);
@@ -444,7 +476,7 @@ int esvo_destroy(esvo_handle h) {
                   h->d_win, h->d_frame_pose_T, h->d_fr_table, h->d_prop, h->d_tile_pts, h->d_tile_count, h->d_over_pts,
                   h->d_cell_count, h->d_cell_offset, h->d_cell_list, h->d_fuse_ctr, h->d_rec_ids, h->d_map, h->d_map2, h->d_owner_max, h->d_owner_min, h->d_exp_flags,
                   h->d_exp_prefix, h->d_export, h->d_export_cell, h->d_reg_ab, h->d_reg_cd, h->d_tsq[0], h->d_tsq[1], h->d_tsq_tcount, h->d_tsq_tlist, h->d_tsq_over, h->d_tsq_over_count, h->d_own_w, h->d_lkeep, h->d_codes, h->d_codes_send, h->d_codes_all, h->d_pts_send, h->d_pts_all, h->d_rank_kept,
-                  h->d_sel, h->d_evmap, h->d_lm_fvec0, h->d_lm_fnorm0, h->d_lm_meta, h->d_lm_order, h->d_lm_hist, h->d_clk};
+                  h->d_sel, h->d_evmap, h->d_lm_fvec0, h->d_lm_fnorm0, h->d_lm_meta, h->d_lm_order, h->d_lm_hist, h->d_clk, h->d_fuse_stats, h->d_ring_gidx, h->d_halo_viol};
   for (void* p : ptrs) if (p) hipFree(p);
   if (h->h_counters) hipHostFree(h->h_counters);
   if (h->h_cnt_b) hipHostFree(h->h_cnt_b);
@@ -455,6 +487,7 @@ int esvo_destroy(esvo_handle h) {
   if (h->h_pose_pool) hipHostFree(h->h_pose_pool);
   if (h->h_trk_ne) hipHostFree(h->h_trk_ne);
   if (h->h_trk_xyz) hipHostFree(h->h_trk_xyz);
+  release_routing(h);
   for (int cam = 0; cam < 2; ++cam) if (h->d_wire[cam]) hipFree(h->d_wire[cam]);
   if (h->evt_trk_read) hipEventDestroy(h->evt_trk_read);
   for (int cam = 0; cam < 2; ++cam) if (h->evt_ingest[cam]) hipEventDestroy(h->evt_ingest[cam]);
@@ -497,7 +530,14 @@ int esvo_reset(esvo_handle h) {
     h->scatter_pending_lo[cam] = ~0ull;
     h->ingest_pending[cam] = false;
     h->ts_valid[cam] = false;
+    h->last_stamp[cam] = 0;
   }
+  h->glob_ts.clear();
+  h->kept_g.clear();
+  h->glob_base = 0;
+  h->halo_error = false;
+  HIPCHK(hipMemsetAsync(h->d_halo_viol, 0, sizeof(u32) * 2, h->stream));
+  std::memset(h->h_cnt_b + 8 * 3, 0, sizeof(u32) * 8);
   h->sh_first = 0;
   h->sh_first_prev = 0;
   h->trk_read_pending = false;
@@ -549,6 +589,10 @@ int esvo_set_params(esvo_handle h, const esvo_params_t* params) {
                                                                          : (u32)params->max_fusion_frames + 2u;
     if (need > h->max_frames) FAIL(ESVO_ERR_CAPACITY, "fusion window (frames) exceeds the capacity fixed at esvo_create");
   }
+  if (h->routed && (params->smooth_time_surface != h->prm.smooth_time_surface || params->median_blur_kernel_size != h->prm.median_blur_kernel_size ||
+                    params->patch_size_y != h->prm.patch_size_y || params->denoising || params->bm_updown))
+    FAIL(ESVO_ERR_STATE, "the handle routes events by row (esvo_shard_set_routing): SmoothTimeSurface, median_blur_kernel_size and patch_size_Y "
+                         "fix the rows it renders and the events it keeps; esvo_reset + esvo_shard_set_routing to change them");
   esvo_params_t np = *params;
   np.max_events_per_tick = h->prm.max_events_per_tick;
   np.max_window_points = h->prm.max_window_points;

@@ -120,6 +120,7 @@ int run_lm(esvo_context* h, u32 max_matches, int cull, bool dense, hipStream_t s
   a.split_order = h->d_lm_order; a.split_hist = h->d_lm_hist;
   a.pair = pair >= 0 ? pair : (h->lm_pair_forced == 1 && max_matches <= esvo::LM_PAIR_MAX_EVENTS ? 1 : 0);
   a.clk = h->clk_probe ? h->d_clk : nullptr;
+  if (h->routed && dense) { a.halo_viol = h->d_counters + 10; a.vy0 = h->oband_y0; a.vy1 = h->oband_y1; }
   hipEventRecord(h->evt[EV_LM0 + h->fpar * EV_FRONT_STRIDE], st);
   launch_lm_refine(a, h->dp, h->d_counters + 2, st);
   hipEventRecord(h->evt[EV_LM1 + h->fpar * EV_FRONT_STRIDE], st);
@@ -181,6 +182,10 @@ void collect_back(esvo_context* h, int par) {
   const int o = par * EV_BACK_STRIDE;
   esvo_stats_t& s = h->stats;
   s.last_fusions = h->h_cnt_b[8 * par + 3];
+  if (h->routed && h->h_cnt_b[8 * 3 + par]) {  // (the running total over all ranks: identical on every rank at this point of the call sequence)
+    s.halo_violations = h->h_cnt_b[8 * 3 + par];
+    h->halo_error = true;
+  }
   if (h->prm.regularization) s.last_map_size = h->h_cnt_b[8 * par + 7];  // alive cells of the band (exports refresh it)
   float fu = 0, cl = 0, rg = 0;
   hipEventElapsedTime(&fu, h->evt[EV_FU0 + o], h->evt[EV_FU1 + o]);
@@ -194,11 +199,13 @@ void collect_back(esvo_context* h, int par) {
 }
 
 // place a frame of n points in the window ring (frames stay contiguous: [oldest frame, newest frame) modulo the wrap)
-int window_reserve(esvo_context* h, u32 n, u32* off_out) {
+// (`frames`: the window to place it behind -- the handle's own, or a copy on which a caller has already dropped the frames that
+// will leave, to learn whether a frame fits BEFORE it changes anything)
+static int window_reserve_in(esvo_context* h, const std::deque<FrameRec>& frames, u32 n, u32* off_out) {
   u32 off = 0;
   const FrameRec* first = nullptr;  // oldest and newest frames that occupy ring space (empty frames hold none)
   const FrameRec* last = nullptr;
-  for (const FrameRec& f : h->frames)
+  for (const FrameRec& f : frames)
     if (f.count) { if (!first) first = &f; last = &f; }
   if (first) {
     const FrameRec& back = *last;
@@ -217,6 +224,19 @@ int window_reserve(esvo_context* h, u32 n, u32* off_out) {
   }
   *off_out = off;
   return ESVO_OK;
+}
+int window_reserve(esvo_context* h, u32 n, u32* off_out) { return window_reserve_in(h, h->frames, n, off_out); }
+// would a frame of n points fit once the window has been cut down to fewer than `keep_below` frames (the pops themselves are
+// left to the caller, after its last fallible step)?
+static int window_probe_after_pops(esvo_context* h, size_t keep_below, u32 n) {
+  std::deque<FrameRec> fr = h->frames;
+  size_t nwf = h->n_window_frames;
+  while (nwf && nwf >= keep_below) {
+    nwf--;
+    if (fr.front().run > 1) fr.front().run--; else fr.pop_front();
+  }
+  u32 off;
+  return window_reserve_in(h, fr, n, &off);
 }
 int alloc_pose_slot(esvo_context* h, u32* slot) {
   for (u32 i = 0; i < h->n_pose_slots; ++i)
@@ -343,6 +363,7 @@ int run_fuse(esvo_context* h, int par, const double* T_world_obs, bool naive) {
   a.map = h->d_map; a.d_num_fusion = h->d_cnt_b + 3;
   a.n_touched = h->d_cnt_b + 6;
   a.naive = naive ? 1 : 0;
+  a.fuse_stats = h->d_fuse_stats;
   a.owner_max = h->prm.regularization ? h->d_owner_max : nullptr;
   a.owner_min = h->d_owner_min; a.n_reg_elems = h->prm.regularization ? h->d_cnt_b + 7 : nullptr;
   if (total > h->win_cap) FAIL(ESVO_ERR_CAPACITY, "window points exceed capacity");
@@ -361,6 +382,7 @@ int run_fuse(esvo_context* h, int par, const double* T_world_obs, bool naive) {
     h->d_map_cur = h->d_map2;
   }
   HIPCHK(hipMemcpyAsync(h->h_cnt_b + 8 * par, h->d_cnt_b, sizeof(u32) * 8, hipMemcpyDeviceToHost, sb));
+  if (h->routed) HIPCHK(hipMemcpyAsync(h->h_cnt_b + 8 * 3 + par, h->d_halo_viol, sizeof(u32), hipMemcpyDeviceToHost, sb));
   hipEventRecord(h->evt[EV_RG1 + o], sb);  // also "back stage of this parity done"
   HIPCHK(hipGetLastError());
   h->back_pending[par] = true;
@@ -433,7 +455,8 @@ int esvo_map_set_observation(esvo_handle h, uint64_t t_ns, const uint8_t* ts_lef
       else HIPCHK(hipMemcpyAsync(dst, h->d_ts[cam], npx, hipMemcpyDeviceToDevice, h->stream));
     }
     // createMatchProblem applies GaussianBlurTS(5) when SmoothTimeSurface (EventBM.cpp:68-72)
-    if (h->prm.smooth_time_surface) launch_gaussian5(dst, h->d_obs[cam], h->W, h->H, h->stream);
+    if (h->prm.smooth_time_surface)
+      launch_gaussian5(dst, h->d_obs[cam], h->W, h->H, h->stream, h->routed ? h->oband_y0 : 0, h->routed ? h->oband_y1 : -1);
   }
   std::memcpy(h->T_world_obs, T_world_cam, sizeof(double) * 16);  // handed to the LM kernel by value
   h->obs_t_ns = t_ns;
@@ -586,9 +609,56 @@ int select_events(esvo_context* h, uint64_t t_ns, u64* first_out, u32* n_out) {
   h->sh_first = first;             // under mu_ring: what the ingest thread's overwrite guard reads
   return ESVO_OK;
 }
+// The same selection on a routed band handle: the walk is defined on the WHOLE left stream (glob_ts: every stamp, kept on the
+// host), the rank's ring holds the events of its rows.  n / g_first: size of the global selection and the global index of its
+// newest event; loc_first / n_loc: the newest of them in this rank's ring (absolute local index) and how many the ring holds.
+int select_events_routed(esvo_context* h, uint64_t t_ns, u32* n_out, u32* g_first_out, u64* loc_first_out, u32* n_loc_out) {
+  std::lock_guard<std::mutex> lr(h->mu_ring);
+  ingest_fence(h, 0);
+  const double t_end = ns_to_sec(t_ns);
+  const u64 t_begin_ns = ros_time_from_sec(std::max(0.0, t_end - 10 * h->prm.bm_half_slice_thickness));
+  const double t_begin = ns_to_sec(t_begin_ns);
+  auto lower = [&](double t) {
+    const auto& v = h->glob_ts;
+    size_t lo = 0, hi = v.size();
+    while (lo < hi) {
+      const size_t mid = (lo + hi) / 2;
+      if (ns_to_sec(v[mid]) < t) lo = mid + 1; else hi = mid;
+    }
+    return h->glob_base + lo;
+  };
+  const u64 it_end = lower(t_end), it_begin = lower(t_begin);
+  const u64 staged_end = h->glob_base + h->glob_ts.size();
+  u64 avail = it_end - it_begin;
+  u64 first = it_end;
+  if (it_end == staged_end && avail > 0) { first = it_end - 1; avail -= 1; }  // end() is skipped (oracle definition)
+  const u32 n = (u32)std::min<u64>(avail, (u64)h->prm.process_event_num);
+  if (n > h->max_ev) FAIL(ESVO_ERR_CAPACITY, "more events than max_events_per_tick");
+  *n_out = n;
+  *g_first_out = (u32)first;
+  *loc_first_out = 0;
+  *n_loc_out = 0;
+  if (n == 0) return ESVO_OK;
+  // the kept events with a global index in [first - n + 1, first]
+  const auto& kg = h->kept_g;
+  const size_t lo = std::lower_bound(kg.begin(), kg.end(), first - (n - 1)) - kg.begin();
+  const size_t hi = std::upper_bound(kg.begin(), kg.end(), first) - kg.begin();
+  if (hi <= lo) return ESVO_OK;
+  const u64 loc_first = h->ring_base[0] + hi - 1;
+  const u32 n_loc = (u32)(hi - lo);
+  if (loc_first - (n_loc - 1) < h->ring_reserved[0] - std::min<u64>(h->ring_reserved[0], h->ring_cap))
+    FAIL(ESVO_ERR_STATE, "selected events were already overwritten in the event ring");
+  *loc_first_out = loc_first;
+  *n_loc_out = n_loc;
+  h->sh_first_prev = h->sh_first;
+  h->sh_first = loc_first;
+  return ESVO_OK;
+}
 
 // block length of exchange 1 (kernels_shard.hip): the bytes of a rank's own slots, whole 64-bit words
 static inline size_t shard_codes_block(u32 n, u32 N) { return (((size_t)n + N - 1) / N + 7) / 8 * 8; }
+// the same in routed band mode: two bits per slot of the whole tick, whole 64-bit words
+static inline size_t shard_codes_block_routed(u32 n) { return (((size_t)n + 15) / 16 * 4 + 7) / 8 * 8; }
 
 // phase 0 (front stage): poses, event selection, block matching + LM of the events of this handle's shard
 int tick_phase0(esvo_context* h, uint64_t t_ns, const uint64_t* pose_t_ns, const double* pose_T, size_t m) {
@@ -597,9 +667,12 @@ int tick_phase0(esvo_context* h, uint64_t t_ns, const uint64_t* pose_t_ns, const
   // the pose-table double buffer, which the LM stage of a still pending tick reads and whose content the back stage
   // copies into that tick's frame slot.
   if (m > h->max_poses) FAIL(ESVO_ERR_CAPACITY, "pose table larger than max_poses_per_tick");
-  u32 n = 0;
+  if (h->routed && h->halo_error)
+    FAIL(ESVO_ERR_HALO, "a refinement of an earlier tick read outside the Time-Surface rows some rank renders (stats.halo_violations): "
+                        "raise ts_halo_rows or use ESVO_ROUTE_BROADCAST");
+  u32 n = 0, n_loc = 0, g_first = 0;
   u64 first = 0;
-  int rc = select_events(h, t_ns, &first, &n);
+  int rc = h->routed ? select_events_routed(h, t_ns, &n, &g_first, &first, &n_loc) : select_events(h, t_ns, &first, &n);
   if (rc) return rc;
   // (the counter row of this tick's parity -- last used two ticks ago, collected since -- is cleared with the pose upload)
   rc = upload_poses(h, pose_t_ns, pose_T, m, h->d_counters2[h->fpar ^ 1]);
@@ -610,6 +683,7 @@ int tick_phase0(esvo_context* h, uint64_t t_ns, const uint64_t* pose_t_ns, const
   set_lm_parity(h);
   esvo_context::TickState& tk = h->tk[h->fpar];
   tk.n = n; tk.off = 0; tk.points = 0; tk.t_ns = t_ns;
+  tk.n_loc = n_loc; tk.g_first = g_first;
   tk.lm_stream = h->stream;
   tk.lm_pair = -1;
   tk.obs_par = h->obs_par;
@@ -662,6 +736,46 @@ int tick_phase0(esvo_context* h, uint64_t t_ns, const uint64_t* pose_t_ns, const
     tk.lm_pair = lm_pair_policy(h, n);
     rc = run_lm(h, n, 1, false, sl, tk.lm_pair);
     if (rc) return rc;
+  } else if (n && h->routed) {
+    // the events of the band's rows (the rank's own ring): BM over them, dense local list of the own matches, LM + cull on it,
+    // then the (matched, kept) bits of the own slots in a block that spans the whole tick
+    const u32 N = (u32)h->dp.ev_nshards;
+    if (n_loc) {
+      BmArgs a;
+      a.ev = h->d_ring[0]; a.n = n; a.ev_first = h->sh_first; a.ev_cap = h->ring_cap; a.ev_reverse = 1; a.sel = nullptr;
+      a.gidx = h->d_ring_gidx; a.g_first = g_first; a.n_loc = n_loc;
+      a.tsL = h->d_obs[0]; a.tsR = h->d_obs[1];
+      a.lut = h->d_lut; a.mask = h->d_mask;
+      a.pose_sec = h->d_pose_sec; a.n_pose = h->n_pose;
+      a.out_slots = h->d_match_slots; a.out_flags = h->d_match_flags;
+      a.fail_counters = h->d_counters;
+      hipEventRecord(h->evt[EV_BM0 + h->fpar * EV_FRONT_STRIDE], h->stream);
+      launch_bm_match(a, h->dp, h->stream);
+      hipEventRecord(h->evt[EV_BM1 + h->fpar * EV_FRONT_STRIDE], h->stream);
+      HIPCHK(hipGetLastError());
+      // dense list of the own matches (count -> counters[8]); the slot of each follows from its walk position (shard_codes_routed)
+      if (scan_compact_is_small(n_loc)) {
+        launch_scan_compact_matches_small(h->d_match_flags, h->d_match_prefix, h->d_counters + 8, n_loc, h->d_match_slots, h->d_matches, nullptr,
+                                          h->stream);
+      } else {
+        launch_exclusive_scan_u32(h->d_match_flags, h->d_match_prefix, h->d_counters + 8, h->d_scan_tmp, n_loc, h->stream);
+        launch_compact_matches(h->d_match_slots, h->d_match_flags, h->d_match_prefix, n_loc, h->d_matches, nullptr, h->stream);
+      }
+      hipEventRecord(h->evt[EV_S1 + h->fpar * EV_FRONT_STRIDE], h->stream);
+      HIPCHK(hipGetLastError());
+      rc = run_lm(h, n_loc, 1, true);
+      if (rc) return rc;
+    } else {  // no event of this tick in the band: the stage events the statistics read are still recorded
+      for (int e : {EV_BM0, EV_BM1, EV_S1, EV_LM0, EV_LM1}) hipEventRecord(h->evt[e + h->fpar * EV_FRONT_STRIDE], h->stream);
+    }
+    const size_t nb = shard_codes_block_routed(n);
+    HIPCHK(hipMemsetAsync(h->d_codes_send, 0, nb, h->stream));
+    launch_shard_codes_routed(h->d_matches, h->d_lkeep, h->d_counters + 8, n_loc, n, (u32)h->dp.num_threads, h->d_own_w,
+                              reinterpret_cast<u32*>(h->d_codes_send), h->stream);
+    HIPCHK(hipGetLastError());
+    h->xchg_send = h->d_codes_send;
+    h->xchg_recv = N > 1 ? h->d_codes_all : h->d_codes_send;
+    h->xchg_block = nb;
   } else if (n) {
     // own slots only (w % n_shards == shard): BM, dense local list, LM + cull on it, then the (matched, kept)
     // byte of every own slot, back to back: this rank's block of the caller's all-gather
@@ -707,7 +821,12 @@ int tick_phase1_enqueue(esvo_context* h) {
     if (rc) return rc;
   } else if (n) {
     const u32 N = (u32)h->dp.ev_nshards, r = (u32)h->dp.ev_shard, T = (u32)h->dp.num_threads;
-    const u32 own = n > r ? (n - r + N - 1) / N : 0;
+    const u32 own = h->routed ? tk.n_loc : (n > r ? (n - r + N - 1) / N : 0);
+    if (h->routed) {
+      HIPCHK(hipMemsetAsync(h->d_codes, 0, n, h->stream));
+      launch_shard_unpack_routed(reinterpret_cast<const u32*>(N > 1 ? h->d_codes_all : h->d_codes_send), (u32)(shard_codes_block_routed(n) / 4), N,
+                                 n, h->d_codes, h->d_rank_kept, h->stream);
+    } else
     launch_shard_unpack_codes(N > 1 ? h->d_codes_all : h->d_codes_send, (u32)shard_codes_block(n, N), N, n, h->d_codes, h->d_rank_kept,
                               h->stream);
     launch_shard_match_flags(h->d_codes, n, h->d_match_flags, h->stream);
@@ -718,7 +837,8 @@ int tick_phase1_enqueue(esvo_context* h) {
     (void)frame;  // filled after exchange 2 (tick_phase2)
     HIPCHK(hipMemsetAsync(h->d_pts_send, 0, 8, h->stream));  // the block's count word = the append cursor
     launch_shard_pack(h->d_own_w, h->d_lkeep, h->d_pt_slots, h->d_counters + 8, own, h->d_match_prefix, h->d_counters + 0,
-                      h->d_pt_prefix, T, h->d_pts_send, own, n, h->d_rank_kept, N, h->d_counters + 9, h->stream);
+                      h->d_pt_prefix, T, h->d_pts_send, own, n, h->d_rank_kept, N, h->d_counters + 9, h->stream,
+                      h->routed ? h->d_counters + 10 : nullptr);
     hipEventRecord(h->evt[EV_S2 + h->fpar * EV_FRONT_STRIDE], h->stream);
     HIPCHK(hipGetLastError());
   }
@@ -781,7 +901,7 @@ int tick_phase2(esvo_context* h, int fp) {
   if (h->sharded) {  // the caller's all-gather was issued on the front stream after EV_CNT: every block's points to frame[seq]
     const u32 N = (u32)h->dp.ev_nshards;
     launch_shard_scatter(N > 1 ? h->d_pts_all : h->d_pts_send, 1 + (size_t)tk.max_kept * (sizeof(DevPoint) / 8), N, tk.max_kept,
-                         h->d_win + tk.off, tk.n, h->stream);
+                         h->d_win + tk.off, tk.n, h->stream, h->routed ? h->d_halo_viol : nullptr);
     HIPCHK(hipGetLastError());
     int rc = back_after_front(h);
     if (rc) return rc;
@@ -858,7 +978,8 @@ extern "C" int esvo_map_tick_resident(esvo_handle h, uint64_t t_ns, const double
     return rc;
   }
   if (h->prm.smooth_time_surface)  // createMatchProblem applies GaussianBlurTS(5) when SmoothTimeSurface (EventBM.cpp:68-72)
-    launch_gaussian5_pair(h->d_ts[0], h->d_ts[1], h->d_obs[0], h->d_obs[1], h->W, h->H, h->stream);
+    launch_gaussian5_pair(h->d_ts[0], h->d_ts[1], h->d_obs[0], h->d_obs[1], h->W, h->H, h->stream, h->routed ? h->oband_y0 : 0,
+                          h->routed ? h->oband_y1 : -1);
   HIPCHK(hipGetLastError());
   std::memcpy(h->T_world_obs, T_world_cam, sizeof(double) * 16);
   h->obs_t_ns = t_ns;
@@ -922,13 +1043,11 @@ extern "C" int esvo_map_tick_bm_only(esvo_handle h, uint64_t t_ns, const uint64_
   // many frames can run out of ring.  Find that out HERE, before any tick state flips: the frame that leaves at this tick
   // leaves first (push_back + pop_front while size > max == pop while size >= max, then push), and the ring must take a
   // frame of n points (n = the selected events bounds the matches).
-  while (h->n_window_frames && h->n_window_frames >= (size_t)std::max(1, h->prm.max_fusion_frames)) pop_front_frame(h);
-  {
-    u32 probe_off;
-    if (window_reserve(h, n, &probe_off) != ESVO_OK)
-      FAIL(ESVO_ERR_CAPACITY, "PURE_BLOCK_MATCHING window (maxNumFusionFrames frames of up to PROCESS_EVENT_NUM matches) "
-                              "does not fit the fusion window ring: raise max_window_points");
-  }
+  // (probed on a COPY of the window: a refused tick, or one that fails further down, has dropped no frame)
+  const size_t keep_below = (size_t)std::max(1, h->prm.max_fusion_frames);
+  if (window_probe_after_pops(h, keep_below, n) != ESVO_OK)
+    FAIL(ESVO_ERR_CAPACITY, "PURE_BLOCK_MATCHING window (maxNumFusionFrames frames of up to PROCESS_EVENT_NUM matches) "
+                            "does not fit the fusion window ring: raise max_window_points");
   h->fpar ^= 1;
   h->d_matches = h->d_matches2[h->fpar];
   h->d_counters = h->d_counters2[h->fpar];
@@ -962,12 +1081,15 @@ extern "C" int esvo_map_tick_bm_only(esvo_handle h, uint64_t t_ns, const uint64_
   s.last_events_in = n; s.last_matches = n_matches; s.last_solved = 0; s.last_points = n_matches;
   s.total_events_in += n; s.total_matches += n_matches; s.total_points += n_matches;
   // dqvDepthPoints_.push_back(vdp_em); while (size > maxNumFusionFrames_) pop_front()
-  u32 off;
-  rc = window_reserve(h, n_matches, &off);
-  if (rc) return rc;
   rc = back_after_front(h);
   if (rc) return rc;
   HIPCHK(hipStreamSynchronize(h->stream_b));  // the ring space may still be read by a fusion in flight
+  // the frame that leaves at this tick leaves first (push_back + pop_front while size > max == pop while size >= max, then
+  // push) -- now that every fallible step of the front stage is behind us; the probe above guarantees the space
+  while (h->n_window_frames && h->n_window_frames >= keep_below) pop_front_frame(h);
+  u32 off;
+  rc = window_reserve(h, n_matches, &off);
+  if (rc) return rc;
   if (n_matches)
     HIPCHK(hipMemcpyAsync(h->d_win + off, h->d_pts_tmp, sizeof(DevPoint) * n_matches, hipMemcpyDeviceToDevice, h->stream_b));
   rc = commit_frame(h, off, n_matches, nullptr, h->n_pose, h->pose_buf, false);
@@ -1016,11 +1138,15 @@ extern "C" int esvo_map_fuse_matches_naive(esvo_handle h, const esvo_match_t* ma
     HIPCHK(hipGetLastError());
   }
   u32 off;
-  // the frame that leaves at this call leaves first (its ring space is free: stream_b was drained above)
-  while (h->n_window_frames && h->n_window_frames >= (size_t)std::max(1, h->prm.max_fusion_frames)) pop_front_frame(h);
-  rc = window_reserve(h, n32, &off);
+  // the frame that leaves at this call leaves first (its ring space is free: stream_b was drained above) -- probed on a copy
+  // of the window, popped for real only when nothing can fail any more before the frame is committed
+  const size_t keep_below = (size_t)std::max(1, h->prm.max_fusion_frames);
+  rc = window_probe_after_pops(h, keep_below, n32);
   if (rc) return rc;
   rc = back_after_front(h);
+  if (rc) return rc;
+  while (h->n_window_frames && h->n_window_frames >= keep_below) pop_front_frame(h);
+  rc = window_reserve(h, n32, &off);
   if (rc) return rc;
   if (n) HIPCHK(hipMemcpyAsync(h->d_win + off, h->d_pts_tmp, sizeof(DevPoint) * n, hipMemcpyDeviceToDevice, h->stream_b));
   static const double ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
@@ -1464,30 +1590,117 @@ int esvo_get_stats(esvo_handle h, esvo_stats_t* out) {
 }
 
 // ---- Multi-GPU row-band sharding ------------------------------------------------------------------
+namespace {
+bool rings_empty(esvo_context* h) {
+  std::lock_guard<std::mutex> lr(h->mu_ring);
+  return h->ring_next[0] == 0 && h->ring_next[1] == 0 && h->glob_ts.empty();
+}
+void free_shard_blocks(esvo_context* h) {
+  for (void** p : {(void**)&h->d_codes_send, (void**)&h->d_codes_all, (void**)&h->d_pts_send, (void**)&h->d_pts_all, (void**)&h->d_rank_kept, (void**)&h->d_ring_gidx})
+    if (*p) { (void)hipFree(*p); *p = nullptr; }
+}
+}  // namespace
+
 int esvo_shard_set_band(esvo_handle h, int row_begin, int row_end, int shard, int n_shards) {
   if (!h || row_begin < 0 || row_end > h->H || row_begin >= row_end || n_shards < 1 || shard < 0 || shard >= n_shards ||
       n_shards > (int)esvo_context::SHARD_MAX_RANKS)
     return ESVO_ERR_INVALID_ARG;
   API_LOCK(h);
   { int rcp = flush_pending_tick(h); if (rcp) return rcp; }
+  if (h->routed && !rings_empty(h))
+    FAIL(ESVO_ERR_STATE, "the handle routes events by row and holds staged events: esvo_reset before changing its band");
+  h->routed = false;  // (esvo_shard_set_routing follows)
   h->dp.ev_shard = shard;
   h->dp.ev_nshards = n_shards;
   h->dp.band_y0 = row_begin;
   h->dp.band_y1 = row_end;
   set_compute_band(h);
   h->sharded = !(row_begin == 0 && row_end == h->H) || n_shards > 1;
-  if (h->sharded && !h->d_codes_send) {  // exchange blocks, sized for any rank count up to SHARD_MAX_RANKS (lazily: unsharded handles never pay)
+  if (h->sharded && !h->d_rank_kept) {  // exchange blocks, sized for any rank count up to SHARD_MAX_RANKS (lazily: unsharded handles never pay)
     const size_t E = h->max_ev, R = esvo_context::SHARD_MAX_RANKS, WP = sizeof(DevPoint) / 8;
     HIPCHK(hipSetDevice(h->device));
     auto alloc = [&](auto** p, size_t bytes) { return hipMalloc(reinterpret_cast<void**>(p), bytes) == hipSuccess; };
+    // (d_rank_kept, the guard above, is allocated LAST: a failure in the chain frees what came before and leaves the guard null)
     if (!alloc(&h->d_codes_send, (E + 7) / 8 * 8) || !alloc(&h->d_codes_all, E + 8 * R) || !alloc(&h->d_pts_send, 8 * (1 + E * WP)) ||
         !alloc(&h->d_pts_all, 8 * (R + (E + R) * WP)) || !alloc(&h->d_rank_kept, sizeof(u32) * R)) {
       (void)hipGetLastError();
+      free_shard_blocks(h);
       h->sharded = false;
+      h->dp.ev_shard = 0; h->dp.ev_nshards = 1; h->dp.band_y0 = 0; h->dp.band_y1 = h->H;
+      set_compute_band(h);
       FAIL(ESVO_ERR_CAPACITY, "out of device memory for the shard exchange blocks");
     }
     HIPCHK(hipMemset(h->d_rank_kept, 0, sizeof(u32) * R));
   }
+  return ESVO_OK;
+}
+
+int esvo_shard_set_routing(esvo_handle h, int mode, int ts_halo_rows) {
+  if (!h || (mode != ESVO_ROUTE_BROADCAST && mode != ESVO_ROUTE_Y_RECT)) return ESVO_ERR_INVALID_ARG;
+  API_LOCK(h);
+  { int rcp = flush_pending_tick(h); if (rcp) return rcp; }
+  if (!h->sharded) FAIL(ESVO_ERR_STATE, "call esvo_shard_set_band first");
+  if (!rings_empty(h)) FAIL(ESVO_ERR_STATE, "events are already staged: choose the routing before the first esvo_ts_push_events (or esvo_reset)");
+  if (mode == ESVO_ROUTE_BROADCAST) { h->routed = false; return ESVO_OK; }
+  const esvo_params_t& p = h->prm;
+  if (p.denoising) FAIL(ESVO_ERR_UNSUPPORTED, "Denoising builds its mask from the whole event slice: use ESVO_ROUTE_BROADCAST");
+  if (h->tsq_len) FAIL(ESVO_ERR_UNSUPPORTED, "per-pixel event queues (max_event_queue_len) are not routed: use ESVO_ROUTE_BROADCAST");
+  if (p.bm_updown) FAIL(ESVO_ERR_UNSUPPORTED, "up-down stereo searches along y, across the bands: use ESVO_ROUTE_BROADCAST");
+  const int H = h->H, W = h->W;
+  const int hy = (p.patch_size_y - 1) / 2;
+  int halo = ts_halo_rows < 0 ? 24 : ts_halo_rows;
+  // block matching reads the band + hy rows; the refinement's blocks reach one row further before any motion
+  if (halo < hy + 2) FAIL(ESVO_ERR_INVALID_ARG, "ts_halo_rows must be at least patch_size_Y / 2 + 2");
+  // rows of the observation pair that must hold data, in whole 4-row tiles of the blur; the Time-Surface rows they are made
+  // from (+ 2 under SmoothTimeSurface: GaussianBlurTS(5)), in whole tiles of the render kernel
+  const int o0 = std::max(0, h->dp.band_y0 - halo) / 4 * 4;
+  const int o1 = std::min(H, (std::min(H, h->dp.band_y1 + halo) + 3) / 4 * 4);
+  const int pad = p.smooth_time_surface ? 2 : 0;
+  const int r0 = std::max(0, o0 - pad) / TS_TILE_ROWS * TS_TILE_ROWS;
+  const int r1 = std::min(H, (std::min(H, o1 + pad) + TS_TILE_ROWS - 1) / TS_TILE_ROWS * TS_TILE_ROWS);
+  const int k = std::max(0, p.median_blur_kernel_size);
+  for (int cam = 0; cam < 2; ++cam) {  // raw rows the remap taps of [r0, r1) reach, + the median's ring
+    int lo = H, hi = -1;
+    for (int y = r0; y < r1; ++y) { lo = std::min(lo, h->fix_row_lo[cam][y]); hi = std::max(hi, h->fix_row_hi[cam][y]); }
+    h->sband_y0[cam] = hi < lo ? 0 : std::max(0, lo - k);
+    h->sband_y1[cam] = hi < lo ? 0 : std::min(H, hi + k + 1);
+  }
+  h->keep_px.assign((size_t)W * H, 0);
+  const float* lut = h->h_rect_lut[0].data();
+  for (int y = 0; y < H; ++y)
+    for (int x = 0; x < W; ++x) {
+      uint8_t f = (y >= h->sband_y0[0] && y < h->sband_y1[0]) ? 1 : 0;
+      const int yb = (int)std::floor((double)lut[2 * ((size_t)y * W + x) + 1]);  // kernels_bm.hip: the rank that owns floor(y_rect)
+      if (yb >= h->dp.band_y0 && yb < h->dp.band_y1) f |= 2;
+      h->keep_px[(size_t)y * W + x] = f;
+    }
+  HIPCHK(hipSetDevice(h->device));
+  if (!h->d_ring_gidx) HIPCHK(hipMalloc(reinterpret_cast<void**>(&h->d_ring_gidx), sizeof(u32) * h->ring_cap));
+  {  // exchange 1 spans the whole tick in this mode: n_shards blocks of two bits per slot
+    const size_t need = (size_t)h->dp.ev_nshards * shard_codes_block_routed(h->max_ev);
+    if (need > (size_t)h->max_ev + 8 * esvo_context::SHARD_MAX_RANKS) {
+      HIPCHK(hipStreamSynchronize(h->stream));
+      uint8_t* d_new = nullptr;
+      if (hipMalloc(reinterpret_cast<void**>(&d_new), need) != hipSuccess) { (void)hipGetLastError(); FAIL(ESVO_ERR_CAPACITY, "out of device memory for the routed exchange blocks"); }
+      (void)hipFree(h->d_codes_all);
+      h->d_codes_all = d_new;
+    }
+  }
+  h->ts_halo = halo;
+  h->oband_y0 = o0; h->oband_y1 = o1;
+  h->rband_y0 = r0; h->rband_y1 = r1;
+  h->routed = true;
+  return ESVO_OK;
+}
+
+int esvo_shard_get_rows(esvo_handle h, int render_rows[2], int observation_rows[2], int source_rows_left[2], int source_rows_right[2]) {
+  if (!h) return ESVO_ERR_INVALID_ARG;
+  API_LOCK(h);
+  const bool r = h->routed;
+  if (render_rows) { render_rows[0] = r ? h->rband_y0 : 0; render_rows[1] = r ? h->rband_y1 : h->H; }
+  if (observation_rows) { observation_rows[0] = r ? h->oband_y0 : 0; observation_rows[1] = r ? h->oband_y1 : h->H; }
+  if (source_rows_left) { source_rows_left[0] = r ? h->sband_y0[0] : 0; source_rows_left[1] = r ? h->sband_y1[0] : h->H; }
+  if (source_rows_right) { source_rows_right[0] = r ? h->sband_y0[1] : 0; source_rows_right[1] = r ? h->sband_y1[1] : h->H; }
   return ESVO_OK;
 }
 

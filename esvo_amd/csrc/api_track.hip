@@ -194,7 +194,7 @@ int esvo_track_register(esvo_handle h, size_t n_points, double R[9], double t[3]
                         int max_iterations, double damping, double* rms, int* iterations) {
   if (!h || !R || !t || max_iterations < 1) return ESVO_ERR_INVALID_ARG;
   int rc = ESVO_OK;
-  auto ne = [&](const double* Rc, const double* tc, double* H, double* b, double* cost, size_t* n) {
+  auto ne = [&](int, const double* Rc, const double* tc, double* H, double* b, double* cost, size_t* n) {
     rc = esvo_track_normal_equations(h, Rc, tc, 0, n_points, ls_norm, huber_threshold, H, b, cost, n);
     return rc == ESVO_OK;
   };

@@ -120,8 +120,9 @@ int ts_render_pair(esvo_context* h, uint64_t t_ns, uint8_t* const obs_out[2]) {
   {
     std::lock_guard<std::mutex> lt(h->mu_ts);
     resident_write_begin(h, 0);
+    // (a routed band handle renders the rows of its band + halo only: h->rband_*, whole tiles)
     launch_ts_render_pair(c, h->W, h->H, (u64)t_ns, h->prm.decay_ms / 1000.0, h->prm.ignore_polarity, h->prm.median_blur_kernel_size,
-                          h->stream);
+                          h->stream, h->routed ? h->rband_y0 : 0, h->routed ? h->rband_y1 : -1);
     hipEventRecord(h->evt[EV_R1], h->stream);
     HIPCHK(hipGetLastError());
     h->ts_valid[0] = h->ts_valid[1] = true;
@@ -194,6 +195,88 @@ void push_commit(esvo_context* h, int cam, size_t n, StampFn stamp, bool copy_in
   while (tsq.size() > h->ring_cap) { tsq.pop_front(); h->ring_base[cam]++; }
   h->stats.events_staged[cam] += n;
 }
+// ---- routed band mode (esvo_shard_set_routing): the packet is filtered on the host -----------------------------------------------
+// Of the n events of a packet the rank keeps those its Time Surfaces need (raw row inside the camera's source rows) and, for the
+// left camera, those it block-matches (floor(y_rect) inside the band): keep_px / sband_*.  Only they are copied to the device
+// ring; each kept left event carries its index in the GLOBAL left sequence (d_ring_gidx), because the reference's event selection
+// (esvo_Mapping.cpp:562-574) and its thread-stride order are defined on the whole stream -- whose stamps stay on the host
+// (glob_ts).  Synchronous (the staging buffer is the library's): esvo_ts_push_events_async behaves like esvo_ts_push_events.
+// Caller holds mu_push[cam]; the packet is sorted.
+template <typename GetEv>
+int push_routed(esvo_context* h, int cam, size_t n, GetEv get) {
+  auto stamp_of = [](const esvo_event_t& e) { return (u64)e.sec * 1000000000ull + e.nsec; };
+  u64 g0 = 0;
+  {
+    std::lock_guard<std::mutex> lr(h->mu_ring);
+    if (h->last_stamp[cam] && stamp_of(get(0)) < h->last_stamp[cam])
+      FAIL(ESVO_ERR_INVALID_ARG, "events must be sorted by time stamp (SURVEY Appendix A-1)");
+    g0 = h->glob_base + h->glob_ts.size();
+  }
+  if (n > h->route_cap[cam]) {  // (idle: every routed push ends with a wait for its copies)
+    const size_t cap = std::max<size_t>(n, (size_t)1 << 16);
+    if (h->h_route_ev[cam]) { hipHostFree(h->h_route_ev[cam]); h->h_route_ev[cam] = nullptr; h->route_cap[cam] = 0; }
+    if (cam == 0 && h->h_route_gidx) { hipHostFree(h->h_route_gidx); h->h_route_gidx = nullptr; }
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h->h_route_ev[cam]), sizeof(esvo_event_t) * cap, hipHostMallocDefault));
+    if (cam == 0) HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h->h_route_gidx), sizeof(u32) * cap, hipHostMallocDefault));
+    h->route_cap[cam] = cap;
+  }
+  esvo_event_t* kept = h->h_route_ev[cam];
+  std::vector<u64> kept_ts, kept_gl, all_ts;
+  kept_ts.reserve(n / 2 + 16);
+  if (cam == 0) { kept_gl.reserve(n / 2 + 16); all_ts.resize(n); }
+  size_t m = 0;
+  const int W = h->W, H = h->H, sy0 = h->sband_y0[cam], sy1 = h->sband_y1[cam];
+  const uint8_t* keep_px = h->keep_px.data();
+  u64 last = 0;
+  for (size_t i = 0; i < n; ++i) {
+    const esvo_event_t e = get(i);
+    const u64 t = stamp_of(e);
+    last = t;
+    if (cam == 0) all_ts[i] = t;
+    bool keep = false;
+    if ((int)e.x < W && (int)e.y < H) keep = cam == 0 ? keep_px[(size_t)e.y * W + e.x] != 0 : ((int)e.y >= sy0 && (int)e.y < sy1);
+    if (!keep) continue;
+    kept[m] = e;
+    if (cam == 0) { h->h_route_gidx[m] = (u32)(g0 + i); kept_gl.push_back(g0 + i); }
+    kept_ts.push_back(t);
+    ++m;
+  }
+  if (m) {
+    PushTicket tk;
+    { int rc = push_begin(h, cam, m, kept_ts[0], tk); if (rc) return rc; }
+    { int rc = push_drain(h, cam, tk); if (rc) return rc; }
+    const size_t first = (size_t)std::min<u64>(m, h->ring_cap - tk.slot);
+    hipError_t e = hipMemcpyAsync(h->d_ring[cam] + tk.slot, kept, sizeof(esvo_event_t) * first, hipMemcpyHostToDevice, h->stream_i);
+    if (e == hipSuccess && first < m)
+      e = hipMemcpyAsync(h->d_ring[cam], kept + first, sizeof(esvo_event_t) * (m - first), hipMemcpyHostToDevice, h->stream_i);
+    if (e == hipSuccess && cam == 0) {
+      e = hipMemcpyAsync(h->d_ring_gidx + tk.slot, h->h_route_gidx, sizeof(u32) * first, hipMemcpyHostToDevice, h->stream_i);
+      if (e == hipSuccess && first < m)
+        e = hipMemcpyAsync(h->d_ring_gidx, h->h_route_gidx + first, sizeof(u32) * (m - first), hipMemcpyHostToDevice, h->stream_i);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream_i);
+    if (e != hipSuccess) { push_abort(h, cam); FAIL(ESVO_ERR_HIP, std::string("staging the routed events failed: ") + hipGetErrorString(e)); }
+  }
+  std::lock_guard<std::mutex> lr(h->mu_ring);
+  auto& tsq = h->ts_host[cam];
+  for (size_t i = 0; i < m; ++i) tsq.push_back(kept_ts[i]);
+  h->ring_next[cam] += m;
+  h->ring_reserved[cam] = h->ring_next[cam];
+  if (cam == 0) {
+    for (size_t i = 0; i < m; ++i) h->kept_g.push_back(kept_gl[i]);
+    for (size_t i = 0; i < n; ++i) h->glob_ts.push_back(all_ts[i]);
+    while (h->glob_ts.size() > h->ring_cap) { h->glob_ts.pop_front(); h->glob_base++; }
+  }
+  while (tsq.size() > h->ring_cap) {
+    tsq.pop_front();
+    h->ring_base[cam]++;
+    if (cam == 0) h->kept_g.pop_front();
+  }
+  h->last_stamp[cam] = last;
+  h->stats.events_staged[cam] += m;
+  return ESVO_OK;
+}
+
 #define PUSH_HIPCHK(call)                                     \
   do {                                                        \
     hipError_t _pe = (call);                                  \
@@ -240,6 +323,7 @@ static int push_events_impl(esvo_handle h, int cam, const esvo_event_t* ev, size
     if (t < last) FAIL(ESVO_ERR_INVALID_ARG, "events must be sorted by time stamp (SURVEY Appendix A-1)");
     last = t;
   }
+  if (h->routed) return push_routed(h, cam, n, [&](size_t i) { return ev[i]; });
   PushTicket tk;
   { int rc = push_begin(h, cam, n, stamp(0), tk); if (rc) return rc; }
   { int rc = push_drain(h, cam, tk); if (rc) return rc; }
@@ -291,6 +375,18 @@ int esvo_ts_push_event_array(esvo_handle h, int cam, const uint8_t* msg, size_t 
     if (t < last) FAIL(ESVO_ERR_INVALID_ARG, "events must be sorted by time stamp (SURVEY Appendix A-1)");
     last = t;
   }
+  if (h->routed)  // the records are widened on the host, where they are filtered
+    return push_routed(h, cam, n, [&](size_t i) {
+      const uint8_t* r = rec + i * 13;
+      esvo_event_t e;
+      std::memset(&e, 0, sizeof(e));
+      e.x = (uint16_t)(r[0] | (r[1] << 8));
+      e.y = (uint16_t)(r[2] | (r[3] << 8));
+      e.sec = (u32)r[4] | ((u32)r[5] << 8) | ((u32)r[6] << 16) | ((u32)r[7] << 24);
+      e.nsec = (u32)r[8] | ((u32)r[9] << 8) | ((u32)r[10] << 16) | ((u32)r[11] << 24);
+      e.polarity = r[12];
+      return e;
+    });
   if ((size_t)n * 13 > h->wire_cap[cam]) {  // this camera's staging buffer: its pusher is the only user (mu_push)
     if (h->d_wire[cam]) { hipFree(h->d_wire[cam]); h->d_wire[cam] = nullptr; }
     h->wire_cap[cam] = std::max<size_t>((size_t)n * 13, (size_t)1 << 20);
@@ -353,6 +449,7 @@ int esvo_ts_render_forward(esvo_handle h, int cam, uint64_t t_ns, uint8_t* out_m
   if (!h || cam < 0 || cam > 1) return ESVO_ERR_INVALID_ARG;
   API_LOCK(h);
   HIPCHK(hipSetDevice(h->device));
+  if (h->routed) FAIL(ESVO_ERR_UNSUPPORTED, "FORWARD mode on a routed band handle (the splat needs every raw row): use ESVO_ROUTE_BROADCAST");
   { int rc = build_forward_lists(h, cam); if (rc) return rc; }
   {
     std::lock_guard<std::mutex> lr(h->mu_ring);
@@ -435,7 +532,8 @@ int esvo_ts_render(esvo_handle h, int cam, uint64_t t_ns, uint8_t* out_mono8) {
     std::lock_guard<std::mutex> lt(h->mu_ts);
     resident_write_begin(h, cam);
     launch_ts_render(h->d_sae[cam], h->d_fixmap[cam], h->d_raw, h->d_ts[cam], h->W, h->H, (u64)t_ns, h->prm.decay_ms / 1000.0,
-                     h->prm.ignore_polarity, h->prm.median_blur_kernel_size, h->stream);
+                     h->prm.ignore_polarity, h->prm.median_blur_kernel_size, h->stream, h->routed ? h->rband_y0 : 0,
+                     h->routed ? h->rband_y1 : -1);
     hipEventRecord(h->evt[EV_R1 + evo], h->stream);
     HIPCHK(hipGetLastError());
     h->ts_valid[cam] = true;

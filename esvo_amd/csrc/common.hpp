@@ -169,9 +169,11 @@ void launch_upload_words(const void* pinned_src, void* d_dst, size_t bytes, hipS
 // kernels_ts.hip
 void launch_ts_unpack_wire(const uint8_t* wire, size_t n, esvo_event_t* ring, u64 first_slot, u64 ring_cap, hipStream_t s);
 void launch_ts_scatter(const esvo_event_t* d_ev, size_t n, u64* d_sae, int W, int H, hipStream_t s);
+// (row0, row1: the rectified rows to render -- whole tiles of TS_TILE_ROWS; a routed band handle renders its band + halo only)
+#define TS_TILE_ROWS 16
 void launch_ts_render(const u64* d_sae, const int2* d_fixmap, uint8_t* d_raw, uint8_t* d_out, int W, int H,
-                      u64 t_ns, double decay_sec, int ignore_polarity, int median_k, hipStream_t s);
-void launch_gaussian5(const uint8_t* d_in, uint8_t* d_out, int W, int H, hipStream_t s);
+                      u64 t_ns, double decay_sec, int ignore_polarity, int median_k, hipStream_t s, int row0 = 0, int row1 = -1);
+void launch_gaussian5(const uint8_t* d_in, uint8_t* d_out, int W, int H, hipStream_t s, int row0 = 0, int row1 = -1);
 // both cameras per launch (esvo_map_tick_resident): scatter segments, decay + median/remap, blur
 struct TsScatterSegs { const esvo_event_t* ev[4]; size_t n[4]; u64* sae[4]; };
 // per-pixel event queues (kernels_ts.hip): up to two ring segments of ONE camera per insertion
@@ -188,11 +190,12 @@ void launch_tsq_view(const u64* q, int L, int W, int H, u64 t_ns, u64* sae, hipS
 struct TsPair { const u64* sae[2]; uint8_t* raw[2]; const int2* fixmap[2]; uint8_t* out[2]; uint8_t* out2[2]; };
 void launch_ts_scatter_segs(const TsScatterSegs& g, int n_seg, int W, int H, hipStream_t s);
 void launch_ts_render_pair(const TsPair& c, int W, int H, u64 t_ns, double decay_sec, int ignore_polarity, int median_k,
-                           hipStream_t s);
+                           hipStream_t s, int row0 = 0, int row1 = -1);
 void launch_ts_render_forward(const u64* d_sae, const u32* d_off, const u32* d_src, const float2* d_lut, double* d_val,
                               uint8_t* d_raw, uint8_t* d_out, int W, int H, u64 t_ns, double decay_sec, int ignore_polarity,
                               int median_k, hipStream_t s);
-void launch_gaussian5_pair(const uint8_t* in0, const uint8_t* in1, uint8_t* out0, uint8_t* out1, int W, int H, hipStream_t s);
+void launch_gaussian5_pair(const uint8_t* in0, const uint8_t* in1, uint8_t* out0, uint8_t* out1, int W, int H, hipStream_t s,
+                           int row0 = 0, int row1 = -1);
 // createDenoisingMask + extractDenoisedEvents (esvo_Mapping.cpp:1046-1072) on the n selected events
 void launch_denoise_flags(const esvo_event_t* ring, u64 first, u64 cap, u32 n, uint8_t* evmap, u32* flags, int W, int H,
                           hipStream_t s);
@@ -215,6 +218,12 @@ struct BmArgs {
   esvo_match_t* out_slots;  // [n] slot w (thread-stride order)
   u32* out_flags;           // [n]
   u32* fail_counters;       // nullable: the tick's counter row (CNT_BM_FAIL: per-reason failures, EventBM.h:89)
+  // routed band mode (kernels_bm.hip, bm_item): `ev` is the rank's OWN ring (the events of its image rows); the launch walks
+  // its n_loc newest-first events from ev_first, gidx[slot] is each event's index in the global sequence (low 32 bits) and
+  // g_first that of the tick's newest selected event; n stays the GLOBAL selection size; results are indexed by walk position
+  const u32* gidx = nullptr;
+  u32 g_first = 0;
+  u32 n_loc = 0;
 };
 void launch_bm_match(const BmArgs& a, const DevParams& p, hipStream_t s);
 void launch_compact_matches(const esvo_match_t* slots, const u32* flags, const u32* prefix, u32 n,
@@ -252,9 +261,13 @@ void launch_shard_keep_flags(const uint8_t* codes, const u32* prefix_f, const u3
                              hipStream_t s);
 void launch_shard_pack(const u32* own_w, const u32* keep, const DevPoint* local_pts, const u32* n_local, u32 max_local,
                        const u32* prefix_f, const u32* n_matches, const u32* prefix_g, u32 T, unsigned long long* block, u32 block_cap,
-                       u32 frame_cap, u32* rank_kept, u32 N, u32* max_kept_out, hipStream_t s);
+                       u32 frame_cap, u32* rank_kept, u32 N, u32* max_kept_out, hipStream_t s, const u32* halo_viol = nullptr);
 void launch_shard_scatter(const unsigned long long* blocks, size_t block_words, u32 N, u32 max_kept, DevPoint* frame, u32 frame_cap,
-                          hipStream_t s);
+                          hipStream_t s, u32* viol_total = nullptr);
+// routed band mode (two bits per slot of the whole tick)
+void launch_shard_codes_routed(const esvo_match_t* own_matches, const u32* keep, const u32* n_local, u32 max_local, u32 n, u32 T, u32* own_w,
+                               u32* block, hipStream_t s);
+void launch_shard_unpack_routed(const u32* blocks, u32 block_words, u32 N, u32 n, uint8_t* codes, u32* rank_kept, hipStream_t s);
 
 // kernels_lm.hip
 struct LmArgs {
@@ -282,6 +295,10 @@ struct LmArgs {
   // Sum of cycle differences / sum of reference differences x the reference rate = the clock the LM waves really ran at,
   // averaged over their lifetimes -- under the load of the whole tick, without a profiler attached.
   u64* clk;
+  // routed band mode: the rows [vy0, vy1) of tsL / tsR hold data; matches whose evaluations read outside are counted here
+  // (non-null selects the guarded kernels)
+  u32* halo_viol = nullptr;
+  int vy0 = 0, vy1 = 0;
 };
 constexpr u32 CLK_XCDS = 8, CLK_SAMPLES = 16, CLK_SCRATCH = 32, CLK_STRIDE = 65;
 inline size_t clk_words(u32 max_ev) { return CLK_SCRATCH + 2 * ((size_t)max_ev / 64 + 2); }
@@ -332,6 +349,7 @@ struct FuseArgs {
   u32* owner_max;               // regulariser scratch reset together with the per-cell counters (or nullptr)
   u32* owner_min;
   u32* n_reg_elems;
+  u64* fuse_stats = nullptr;    // -DFUSE_STATS builds with ESVO_FUSE_STATS set: [n_tiles][8] phase cycles of tile_lists (tools only)
 };
 void launch_fuse(const FuseArgs& a, const DevParams& p, hipStream_t s);
 void launch_clean(MapCell* map, const DevParams& p, hipStream_t s);

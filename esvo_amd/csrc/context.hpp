@@ -213,6 +213,7 @@ struct esvo_context {
   u32 fuse_tile_cap = 1024;       // ESVO_FUSE_TILE_CAP (tests): entries per tile list
   u32 fuse_pmax_plus1 = 0;        // ESVO_FUSE_PMAX (tests) + 1: candidates up to which a tile takes the bit-row path
   u32* d_rec_ids = nullptr;       // record ids of cells whose list does not fit LDS (degenerate scenes)
+  u64* d_fuse_stats = nullptr;    // ESVO_FUSE_STATS (with a -DFUSE_STATS build; tools only): per-tile phase cycles, a buffer of their own
   u32 fuse_lds_cap = 0;           // ESVO_FUSE_LDS_CAP (tests): record ids per tile kept in LDS; 0 = the maximum
   MapCell* d_map = nullptr;
   MapCell* d_map2 = nullptr;
@@ -238,11 +239,34 @@ struct esvo_context {
   u32* d_rank_kept = nullptr;                  // [SHARD_MAX_RANKS] kept count of every rank (from exchange 1)
   static constexpr u32 SHARD_MAX_RANKS = 1024;
   bool sharded = false;
+  // ---- routed band mode (esvo_shard_set_routing): events are routed by image row at ingest, the Time Surfaces are
+  // rendered for the band + halo only, block matching and refinement belong to the rank that owns floor(y_rect) of the event.
+  bool routed = false;
+  int ts_halo = 0;                       // rows beyond the band for which the observation pair is valid
+  int rband_y0 = 0, rband_y1 = 0;        // rectified rows the Time Surfaces are rendered for (whole tiles of TS_TILE_ROWS)
+  int oband_y0 = 0, oband_y1 = 0;        // rows of the observation pair that hold data: what block matching and LM may read
+  int sband_y0[2] = {0, 0}, sband_y1[2] = {0, 0};  // RAW rows whose events a camera's SAE needs for rband (remap + median taps)
+  std::vector<int> fix_row_lo[2], fix_row_hi[2];   // per rectified row: the raw rows its remap taps reach (from the fixed-point maps)
+  std::vector<uint8_t> keep_px;          // left camera, [W * H]: bit 0 the SAE needs the pixel's events, bit 1 floor(y_rect) is in the band
+  // event selection stays GLOBAL (dataTransferring walks the whole left stream): every left stamp is kept on the host, each
+  // kept event remembers its index in that sequence -- under mu_ring like ts_host
+  std::deque<u64> glob_ts;               // stamps of ALL left events [glob_base, glob_base + size)
+  u64 glob_base = 0;
+  std::deque<u64> kept_g;                // global index of each kept left event, aligned with ts_host[0]
+  u64 last_stamp[2] = {0, 0};            // newest stamp seen per camera (kept or not): the order check of the push calls
+  u32* d_ring_gidx = nullptr;            // [ring_cap] low 32 bits of the global index of the left ring's events
+  esvo_event_t* h_route_ev[2] = {nullptr, nullptr};  // pinned staging of the kept events of one push, per camera
+  u32* h_route_gidx = nullptr;
+  size_t route_cap[2] = {0, 0};
+  u32* d_halo_viol = nullptr;            // [2] matches whose refinement read outside oband, all ranks, summed over the ticks | scratch
+  bool halo_error = false;               // sticky (esvo_reset clears it): ticks are refused with ESVO_ERR_HALO
   // A tick's state between its phases.  Unsharded ticks are finished lazily: esvo_map_tick(k) enqueues the front
   // stage of tick k and only then completes tick k-1 (point count -> window policy -> back stage), so the host
   // never waits on the front stream while it still has work to enqueue there.
   struct TickState {
     u32 n = 0, off = 0, points = 0, n_pose = 0;
+    u32 n_loc = 0;                    // routed band mode: events of the selection in this rank's ring (n stays the global count)
+    u32 g_first = 0;                  //   global index (low 32 bits) of the selection's newest event
     u32 max_kept = 0;                 // sharded: largest kept count among the ranks (block length of exchange 2)
     int pose_buf = 0;
     u64 t_ns = 0;
@@ -338,6 +362,7 @@ extern thread_local std::string g_create_error;
 // api_core.hip
 void fill_dev_params(esvo_context* h);
 void set_compute_band(esvo_context* h);
+void release_routing(esvo_context* h);
 // api_ts.hip
 void collect_ts_timing(esvo_context* h, int only = -1);
 void ingest_fence(esvo_context* h, int cam);  // caller holds mu_ring

@@ -114,6 +114,24 @@ __device__ inline uint4 load_row15(const u32* ts32, int n_dw, int A) {
   return wv;
 }
 
+// Which event a group handles (k = its position in the newest-first walk of the tick's selection) and its record.
+//   thread-stride slots (default; multi-GPU: dealt by slot): k = stride_item(w)
+//   routed band mode (a.gidx): the rank's ring holds only the events of its image rows, each with its index in the GLOBAL event
+//     sequence (low 32 bits); w is the position in the newest-first walk of the LOCAL ring and k = g_first - gidx
+__device__ inline void bm_item(const BmArgs& a, const DevParams& p, u32 w, u32& k, uint4& e, bool& ok) {
+  if (a.gidx) {
+    const u64 ei = (a.ev_first - w) % a.ev_cap;
+    e = reinterpret_cast<const uint4*>(a.ev)[ei];
+    k = a.g_first - a.gidx[ei];
+    ok = k < a.n;
+    return;
+  }
+  k = stride_item(w, a.n, (u32)p.num_threads);
+  const u32 kk = a.sel ? a.sel[k] : k;
+  const u64 ei = (a.ev_reverse ? (a.ev_first - kk) : (a.ev_first + kk)) % a.ev_cap;
+  e = reinterpret_cast<const uint4*>(a.ev)[ei];
+}
+
 template <int G>
 __device__ inline void grp_argmin(double& best, int& bestd) {  // ties -> larger disparity (`<=` while scanning upwards)
 #pragma unroll
@@ -128,8 +146,11 @@ template <int G, bool COARSE, bool UPDOWN>
 __global__ void __launch_bounds__(BM_BLOCK) bm_match_kernel(BmArgs a, DevParams p, int RD, int lds_per_event) {
   constexpr int EPB = BM_BLOCK / G;  // events per block
   const int grp = threadIdx.x / G, l = threadIdx.x % G;
-  // slot in thread-stride order; multi-GPU: slots are dealt round-robin and a rank's launch covers its own ones densely
-  const u32 w = (blockIdx.x * EPB + grp) * (u32)p.ev_nshards + (u32)p.ev_shard;
+  // slot in thread-stride order; multi-GPU: slots are dealt round-robin and a rank's launch covers its own ones densely --
+  // or (routed band mode, bm_item) position w of the walk over the rank's own ring, results indexed by that position
+  const u32 pos = blockIdx.x * EPB + grp;
+  const u32 w = a.gidx ? pos : pos * (u32)p.ev_nshards + (u32)p.ev_shard;
+  const u32 n_out = a.gidx ? a.n_loc : a.n;
   u32* ldsL = reinterpret_cast<u32*>(bm_smem + grp * lds_per_event);  // [7][4] dwords
   u32* ldsR = ldsL + 28;                                              // [7][RD] dwords / UPDOWN: [Nd + 6][4] dwords
   const int nd = p.dmax - p.dmin + 1;
@@ -138,15 +159,10 @@ __global__ void __launch_bounds__(BM_BLOCK) bm_match_kernel(BmArgs a, DevParams 
   const int W = p.W, H = p.H;
   constexpr int wx = 15, wy = 7, N = wx * wy, hx = 7, hy = 3;
 
-  bool ok = w < a.n;
+  bool ok = w < n_out;
   u32 k = 0;
   uint4 e = make_uint4(0, 0, 0, 0);
-  if (ok) {
-    k = stride_item(w, a.n, (u32)p.num_threads);
-    const u32 kk = a.sel ? a.sel[k] : k;
-    const u64 ei = (a.ev_reverse ? (a.ev_first - kk) : (a.ev_first + kk)) % a.ev_cap;
-    e = reinterpret_cast<const uint4*>(a.ev)[ei];
-  }
+  if (ok) bm_item(a, p, w, k, e, ok);
   const int ex = e.x & 0xffffu, ey = e.x >> 16;
   double xr = 0, yr = 0;
   int x1 = 0, y1 = 0;
@@ -156,6 +172,9 @@ __global__ void __launch_bounds__(BM_BLOCK) bm_match_kernel(BmArgs a, DevParams 
     xr = (double)q.x;
     yr = (double)q.y;
     ok = !(xr < 0 || xr > (double)(W - 1) || yr < 0 || yr > (double)(H - 1));  // :90-92
+    // routed band mode: the event belongs to the rank that owns floor(y_rect); the ring also holds the
+    // events of the Time Surface's source rows around the band, which other ranks match
+    if (a.gidx && ok) { const int yb = (int)floor(yr); ok = yb >= p.band_y0 && yb < p.band_y1; }
   }
   if (ok && a.mask) ok = a.mask[(int)yr * W + (int)xr] > 125;  // :94 (index truncation)
   if (ok) {
@@ -341,7 +360,7 @@ __global__ void __launch_bounds__(BM_BLOCK) bm_match_kernel(BmArgs a, DevParams 
     pose_idx = lo;
     ok = lo < a.n_pose;  // EventBM.cpp:155-156
   }
-  if (w < a.n && l == 0) {
+  if (w < n_out && l == 0) {
     a.out_flags[w] = ok ? 1u : 0u;
     if (ok) {
       esvo_match_t m;
@@ -361,7 +380,7 @@ __global__ void __launch_bounds__(BM_BLOCK) bm_match_kernel(BmArgs a, DevParams 
   // striped over CNT_STRIPES addresses so that a launch of 10^5 waves does not queue on one L2 line
 #ifndef BM_NO_FAIL_COUNTERS  // (A/B switch)
   if (a.fail_counters) {
-    const bool lead = w < a.n && l == 0;
+    const bool lead = w < n_out && l == 0;
 #pragma unroll
     for (int r = 1; r <= 3; ++r) {
       const int n = __popcll(__ballot(lead && reason == r));
@@ -391,7 +410,8 @@ __device__ inline uint8_t ts_byte_clamped(const uint8_t* ts, int n_px, int idx) 
 template <bool COARSE, bool UPDOWN>
 __global__ void __launch_bounds__(64) bm_match_any_kernel(BmArgs a, DevParams p, int lds_strip_bytes) {
   const int l = threadIdx.x;
-  const u32 w = blockIdx.x * (u32)p.ev_nshards + (u32)p.ev_shard;
+  const u32 w = a.gidx ? blockIdx.x : blockIdx.x * (u32)p.ev_nshards + (u32)p.ev_shard;
+  const u32 n_out = a.gidx ? a.n_loc : a.n;
   const int W = p.W, H = p.H, wx = p.wx, wy = p.wy, N = wx * wy, hx = (wx - 1) / 2, hy = (wy - 1) / 2;
   const int nd = p.dmax - p.dmin + 1;
   uint8_t* ldsL = bm_smem;                                          // [wy][wx]
@@ -399,15 +419,10 @@ __global__ void __launch_bounds__(64) bm_match_any_kernel(BmArgs a, DevParams p,
   double* cost_row = reinterpret_cast<double*>(ldsR + lds_strip_bytes);  // COARSE only: [nd]
   const int SW = wx + nd - 1;  // strip row length (horizontal search)
 
-  bool ok = w < a.n;
+  bool ok = w < n_out;
   u32 k = 0;
   uint4 e = make_uint4(0, 0, 0, 0);
-  if (ok) {
-    k = stride_item(w, a.n, (u32)p.num_threads);
-    const u32 kk = a.sel ? a.sel[k] : k;
-    const u64 ei = (a.ev_reverse ? (a.ev_first - kk) : (a.ev_first + kk)) % a.ev_cap;
-    e = reinterpret_cast<const uint4*>(a.ev)[ei];
-  }
+  if (ok) bm_item(a, p, w, k, e, ok);
   const int ex = e.x & 0xffffu, ey = e.x >> 16;
   double xr = 0, yr = 0;
   int x1 = 0, y1 = 0;
@@ -417,6 +432,9 @@ __global__ void __launch_bounds__(64) bm_match_any_kernel(BmArgs a, DevParams p,
     xr = (double)q.x;
     yr = (double)q.y;
     ok = !(xr < 0 || xr > (double)(W - 1) || yr < 0 || yr > (double)(H - 1));  // :90-92
+    // routed band mode: the event belongs to the rank that owns floor(y_rect); the ring also holds the
+    // events of the Time Surface's source rows around the band, which other ranks match
+    if (a.gidx && ok) { const int yb = (int)floor(yr); ok = yb >= p.band_y0 && yb < p.band_y1; }
   }
   if (ok && a.mask) ok = a.mask[(int)yr * W + (int)xr] > 125;  // :94
   if (ok) {
@@ -533,7 +551,7 @@ __global__ void __launch_bounds__(64) bm_match_any_kernel(BmArgs a, DevParams p,
     pose_idx = lo;
     ok = lo < a.n_pose;  // :155-156
   }
-  if (w < a.n && l == 0) {
+  if (w < n_out && l == 0) {
     a.out_flags[w] = ok ? 1u : 0u;
     if (ok) {
       esvo_match_t m;
@@ -557,7 +575,7 @@ static void launch_bm_any(const BmArgs& a, const DevParams& p, hipStream_t s) {
   const int nd = p.dmax - p.dmin + 1, N = p.wx * p.wy;
   const int strip = ((UPDOWN ? (p.wy + nd - 1) * p.wx : p.wy * (p.wx + nd - 1)) + 7) & ~7;
   const size_t lds = (size_t)((N + 7) & ~7) + strip + (COARSE ? (size_t)nd * 8 : 0);
-  const u32 own = (a.n > (u32)p.ev_shard) ? (a.n - (u32)p.ev_shard + (u32)p.ev_nshards - 1) / (u32)p.ev_nshards : 0;
+  const u32 own = a.gidx ? a.n_loc : ((a.n > (u32)p.ev_shard) ? (a.n - (u32)p.ev_shard + (u32)p.ev_nshards - 1) / (u32)p.ev_nshards : 0);
   if (own == 0) return;
   hipLaunchKernelGGL((bm_match_any_kernel<COARSE, UPDOWN>), dim3(own), dim3(64), lds, s, a, p, strip);
 }
@@ -567,7 +585,7 @@ static void launch_bm_g(const BmArgs& a, const DevParams& p, int RD, hipStream_t
   const int nd = p.dmax - p.dmin + 1;
   const int per_event = (28 + (UPDOWN ? (nd + 6) * 4 : 7 * RD)) * 4 + (COARSE ? ((nd + 1) & ~1) * 8 : 0);
   const int epb = BM_BLOCK / G;
-  const u32 own = (a.n > (u32)p.ev_shard) ? (a.n - (u32)p.ev_shard + (u32)p.ev_nshards - 1) / (u32)p.ev_nshards : 0;
+  const u32 own = a.gidx ? a.n_loc : ((a.n > (u32)p.ev_shard) ? (a.n - (u32)p.ev_shard + (u32)p.ev_nshards - 1) / (u32)p.ev_nshards : 0);
   if (own == 0) return;
   const u32 blocks = (own + epb - 1) / epb;
   hipLaunchKernelGGL((bm_match_kernel<G, COARSE, UPDOWN>), dim3(blocks), dim3(BM_BLOCK), (size_t)per_event * epb, s, a, p, RD, per_event);

@@ -294,7 +294,7 @@ __global__ void __launch_bounds__(FT_CELLS, 8) tile_lists_kernel(FuseArgs a, Dev
   u64 tph[6];
   tph[0] = __builtin_readcyclecounter();
 #define FUSE_PH(i) tph[i] = __builtin_readcyclecounter()
-#define FUSE_PH_END() do { if (lane == 0) { u64* st = (u64*)a.over_pts + (size_t)blockIdx.x * 8; for (int i = 0; i < 5; ++i) st[i] = tph[i + 1] - tph[i]; st[5] = P; st[6] = C; st[7] = tph[0]; } } while (0)
+#define FUSE_PH_END() do { if (lane == 0 && a.fuse_stats) { u64* st = a.fuse_stats + (size_t)blockIdx.x * 8; for (int i = 0; i < 5; ++i) st[i] = tph[i + 1] - tph[i]; st[5] = P; st[6] = C; st[7] = tph[0]; } } while (0)
 #else
 #define FUSE_PH(i) do {} while (0)
 #define FUSE_PH_END() do {} while (0)

@@ -182,6 +182,7 @@ struct LmProblem {
   const double* cam;       // [0..11] P_left, [12..23] P_right, [24..26] Kinv_t (left)
   int c;                   // patch column of the lane
   int rg;                  // row group of the lane (wide layout; 0 in the narrow one)
+  int vy0, vy1;            // BAND kernels only: the rows of the observation pair that hold data (routed band mode)
 #ifdef LM_STATS
   u32 dbg_slot;
 #endif
@@ -258,8 +259,12 @@ __device__ inline void interp_column(__amdgpu_buffer_rsrc_t img, int W, const Pa
 // Returns whether the evaluation was "tight" (group-uniform): every non-zero residual of the match has 2^-50 <= |r| and the
 // final scale lies in [2^-100, 2^100], so every non-zero f = sqrt(w) r has 2^-150 <= |f| < 2^11 -- what lets the caller
 // divide differences of two such evaluations through a shared reciprocal (fdiv.hpp's window) without testing them.
-template <bool WIDE, bool L2, bool COUNT = false>
-__device__ bool lm_eval(const DevParams& p, const LmProblem& pr, LmCache<WIDE>& cc, double x, double* fv, int* n_iter = nullptr) {
+// BAND (routed band mode: the rank's observation pair holds its band + halo rows only): an evaluation whose source blocks
+// leave those rows would read stale bytes -- it is recorded in `viol` (the tick is then refused with ESVO_ERR_HALO by every
+// rank, include/esvo_hip.h), never silently used.
+template <bool WIDE, bool L2, bool COUNT = false, bool BAND = false>
+__device__ bool lm_eval(const DevParams& p, const LmProblem& pr, LmCache<WIDE>& cc, double x, double* fv, int* n_iter = nullptr,
+                        bool* viol = nullptr) {
   int iters = 0;  // t-scale iterations of this evaluation (COUNT only: the split launch orders the matches by it)
   constexpr int RL = Lay<WIDE>::RL;
   // element (y, c) of the patch exists: column 15 only feeds its neighbour; row group 3 of the wide layout owns one row
@@ -319,6 +324,10 @@ __device__ bool lm_eval(const DevParams& p, const LmProblem& pr, LmCache<WIDE>& 
                       (int)(x2u >= wlo) & (int)(x2u <= whi) & (int)(x2v >= vlo) & (int)(x2v <= vhi);
   const PatchGeom g1 = interp_geom(p, x1u, x1v), g2 = interp_geom(p, x2u, x2v);
   const bool okw = inside & g1.ok & g2.ok;
+  if constexpr (BAND) {  // source rows uly .. uly + LM_ROWS of both blocks
+    const bool bad = (int)okw & ((int)(g1.uly < pr.vy0) | (int)(g1.uly + LM_ROWS >= pr.vy1) | (int)(g2.uly < pr.vy0) | (int)(g2.uly + LM_ROWS >= pr.vy1));
+    *viol = *viol | bad;
+  }
   double tau1[RL], tau2[RL], r[RL], r2[RL];
   interp_column<WIDE>(pr.tsL, p.W, g1, pr.c, pr.rg, tau1, cc.l, cc.vl);
   interp_column<WIDE>(pr.tsR, p.W, g2, pr.c, pr.rg, tau2, cc.r, cc.vr);
@@ -559,9 +568,10 @@ __device__ inline u32 lm_split_stripe(u32 slot) { return (slot >> 2) & (LM_SPLIT
 // sizes get 2-8 % SLOWER (short chains: the second wave, the exchange and the extra SGPR spills cost more than the few
 // reused evaluations save), and above ~2000 matches the doubled waves crowd the SIMDs.  The handle therefore measures
 // (api_map.hip, lm_pair_policy): both layouts give the same bits, so it may switch between ticks.
-template <bool WIDE, bool L2 = false, int STAGE = 0, bool PAIR = false>
+template <bool WIDE, bool L2 = false, int STAGE = 0, bool PAIR = false, bool BAND = false>
 __global__ void __launch_bounds__(PAIR ? 128 : LM_BLOCK, WIDE ? LM_WIDE_WAVES : LM_WAVES) lm_refine_kernel(LmArgs a, DevParams p, u32* n_solved, LmSplit sp) {
   static_assert(!PAIR || (WIDE && !L2 && STAGE == 0), "the pair layout is a variant of the wide one");
+  static_assert(!BAND || (STAGE == 0 && !PAIR), "routed band launches are single launches of the narrow or the wide layout");
   constexpr int RL = Lay<WIDE>::RL;
 #ifdef LM_SETPRIO  // A/B only: the wave's issue priority inside its SIMD (0..3; default 0 like every other kernel)
   __builtin_amdgcn_s_setprio(LM_SETPRIO);
@@ -635,6 +645,8 @@ __global__ void __launch_bounds__(PAIR ? 128 : LM_BLOCK, WIDE ? LM_WIDE_WAVES : 
   pr.cam = lds_cam;
   pr.c = c;
   pr.rg = rg;
+  pr.vy0 = a.vy0; pr.vy1 = a.vy1;
+  bool viol = false;
 #ifdef LM_STATS
   pr.dbg_slot = active ? s : 0xffffffffu;
 #endif
@@ -759,7 +771,7 @@ __global__ void __launch_bounds__(PAIR ? 128 : LM_BLOCK, WIDE ? LM_WIDE_WAVES : 
         }
       }
     } else {
-      out_tight = lm_eval<WIDE, L2>(p, pr, cc, xe, out);
+      out_tight = lm_eval<WIDE, L2, false, BAND>(p, pr, cc, xe, out, nullptr, &viol);
     }
     int status = -1;
     bool outer_tail = false;
@@ -893,6 +905,7 @@ __global__ void __launch_bounds__(PAIR ? 128 : LM_BLOCK, WIDE ? LM_WIDE_WAVES : 
     atomicAdd(&a.clk[CLK_SAMPLES], 1ull);
   }
   if (!active || !lead) return;
+  if constexpr (BAND) { if (viol) atomicAdd(a.halo_viol, 1u); }
   const bool solved = !(x <= 0.001);  // DepthProblemSolver.cpp:192
   bool keep = solved;
   if (solved) {
@@ -987,7 +1000,15 @@ void launch_lm_refine(const LmArgs& a, const DevParams& p, u32* n_solved, hipStr
   const u32 groups_per_block = LM_BLOCK / 16;
   const u32 blocks = (a.max_matches + groups_per_block - 1) / groups_per_block;
   if (p.ls_norm == ESVO_LSNORM_L2) {  // no shipped configuration: the narrow layout only
-    hipLaunchKernelGGL((lm_refine_kernel<false, true, 0>), dim3(blocks), dim3(LM_BLOCK), 0, s, a, p, n_solved, sp);
+    if (a.halo_viol) hipLaunchKernelGGL((lm_refine_kernel<false, true, 0, false, true>), dim3(blocks), dim3(LM_BLOCK), 0, s, a, p, n_solved, sp);
+    else hipLaunchKernelGGL((lm_refine_kernel<false, true, 0>), dim3(blocks), dim3(LM_BLOCK), 0, s, a, p, n_solved, sp);
+    return;
+  }
+  if (a.halo_viol) {  // routed band mode (the observation pair holds the band's rows only): the guarded kernels, one launch
+    if (a.max_matches <= LM_WIDE_MAX && LM_BLOCK == 64)
+      hipLaunchKernelGGL((lm_refine_kernel<true, false, 0, false, true>), dim3(a.max_matches), dim3(64), 0, s, a, p, n_solved, sp);
+    else
+      hipLaunchKernelGGL((lm_refine_kernel<false, false, 0, false, true>), dim3(blocks), dim3(LM_BLOCK), 0, s, a, p, n_solved, sp);
     return;
   }
   // the match count lives on the device; the layout is chosen by the launch's bound (the events handed to block matching)

@@ -22,6 +22,7 @@ struct AnyProblem {
   const uint8_t* tsL;
   const uint8_t* tsR;
   int wx, wy, P, c;
+  int vy0, vy1;  // rows of the observation pair that hold data (routed band mode; 0, H otherwise)
 };
 
 __device__ inline double any_butterfly(double a, int P) {
@@ -63,7 +64,7 @@ __device__ inline AnyGeom any_geom(const DevParams& p, int wx, int wy, double lx
 // DepthProblem::operator(): fv[y][c] = residual of patch element (y, c) (0 in the padding lanes); rr = scratch for the raw
 // residuals.  L2: LSnorm "l2" (the plain temporal residual, 255 on failure).
 template <bool L2>
-__device__ void any_eval(const DevParams& p, const AnyProblem& pr, double x, double* fv, double* rr) {
+__device__ void any_eval(const DevParams& p, const AnyProblem& pr, double x, double* fv, double* rr, bool& viol) {
   const int wx = pr.wx, wy = pr.wy, c = pr.c, P = pr.P;
   const bool el = c < wx;
   const double nu = p.td_nu;
@@ -84,6 +85,8 @@ __device__ void any_eval(const DevParams& p, const AnyProblem& pr, double x, dou
     g1 = any_geom(p, wx, wy, x1u, x1v);
     g2 = any_geom(p, wx, wy, x2u, x2v);
     okw = g1.ok && g2.ok;
+    // source rows uly .. uly + wy of both blocks must hold data (kernels_lm.hip, BAND)
+    if (okw && (g1.uly < pr.vy0 || g1.uly + wy >= pr.vy1 || g2.uly < pr.vy0 || g2.uly + wy >= pr.vy1)) viol = true;
   }
   if (!okw) {  // failure fill, :49-56 / :149-155 (l2: :67-75, :143-147)
     double f = 255;
@@ -181,6 +184,8 @@ __global__ void __launch_bounds__(64) lm_refine_any_kernel(LmArgs a, DevParams p
   pr.tsL = a.tsL;
   pr.tsR = a.tsR;
   pr.wx = wx; pr.wy = wy; pr.P = P; pr.c = c;
+  pr.vy0 = a.halo_viol ? a.vy0 : 0; pr.vy1 = a.halo_viol ? a.vy1 : p.H;
+  bool viol = false;
   {  // DepthProblem::setProblem, DepthProblem.cpp:17-32
     double Tlw[16], Tlv[16];
     rigid_inverse(a.T_world_obs, Tlw);
@@ -214,7 +219,7 @@ __global__ void __launch_bounds__(64) lm_refine_any_kernel(LmArgs a, DevParams p
       xe = xnew;
       need_step = false;
     }
-    any_eval<L2>(p, pr, xe, out, rr);
+    any_eval<L2>(p, pr, xe, out, rr, viol);
     __syncthreads();  // one wave per workgroup: orders the LDS writes of all lanes before the cross-lane read of element (0, 0)
     int status = -1;
     bool outer_tail = false;
@@ -317,6 +322,7 @@ __global__ void __launch_bounds__(64) lm_refine_any_kernel(LmArgs a, DevParams p
     }
   }
   if (c != 0) return;
+  if (a.halo_viol && viol) atomicAdd(a.halo_viol, 1u);
   const bool solved = !(x <= 0.001);  // DepthProblemSolver.cpp:192
   bool keep = solved;
   if (solved) {

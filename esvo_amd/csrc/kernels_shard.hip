@@ -32,6 +32,59 @@ void launch_shard_codes(const u32* own_w, const u32* keep, const u32* n_local, u
   hipLaunchKernelGGL(shard_codes_kernel, dim3((max_local + 255) / 256), dim3(256), 0, s, own_w, keep, n_local, max_local, N, block);
 }
 
+// ---- routed band mode: per-event work belongs to the rank that owns floor(y_rect) of the event, so a rank's own slots are
+// scattered over the tick.  Exchange 1 then carries TWO BITS per slot of the WHOLE tick (own slots set, the others zero):
+// block = ceil(n / 16) 32-bit words rounded up to 8 bytes, the same on every rank.
+// own block (zeroed by the caller): the slot of each own match comes from its walk position (esvo_match_t::event_idx)
+__global__ void __launch_bounds__(256) shard_codes_routed_kernel(const esvo_match_t* __restrict__ own_matches, const u32* __restrict__ keep,
+                                                                 const u32* __restrict__ n_local, u32 max_local, u32 n, u32 T,
+                                                                 u32* __restrict__ own_w, u32* __restrict__ block) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  u32 m = *n_local;
+  if (m > max_local) m = max_local;
+  if (i >= m) return;
+  const u32 w = stride_slot(own_matches[i].event_idx, n, T);
+  own_w[i] = w;
+  if (w < n) atomicOr(&block[w >> 4], (1u | (keep[i] ? 2u : 0u)) << (2u * (w & 15u)));
+}
+void launch_shard_codes_routed(const esvo_match_t* own_matches, const u32* keep, const u32* n_local, u32 max_local, u32 n, u32 T, u32* own_w,
+                               u32* block, hipStream_t s) {
+  if (max_local == 0) return;
+  hipLaunchKernelGGL(shard_codes_routed_kernel, dim3((max_local + 255) / 256), dim3(256), 0, s, own_matches, keep, n_local, max_local, n, T,
+                     own_w, block);
+}
+// after exchange 1: the gathered blocks [N][block_words] into one byte per slot (codes zeroed by the caller: every slot has at
+// most one owner) and every rank's kept count
+__global__ void __launch_bounds__(256) shard_unpack_routed_kernel(const u32* __restrict__ blocks, u32 block_words, u32 n_words, u32 n,
+                                                                  uint8_t* __restrict__ codes, u32* __restrict__ rank_kept) {
+  __shared__ u32 part[4];
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+  u32 word = 0;
+  if (i < n_words) word = blocks[(size_t)r * block_words + i];
+  if (word) {
+#pragma unroll
+    for (u32 q = 0; q < 16; ++q) {
+      const u32 c = (word >> (2u * q)) & 3u, w = 16u * i + q;
+      if (c && w < n) codes[w] = (uint8_t)c;
+    }
+  }
+  u32 cnt = (u32)__popc(word & 0xaaaaaaaau);
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
+  if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const u32 t = part[0] + part[1] + part[2] + part[3];
+    if (t) atomicAdd(&rank_kept[r], t);
+  }
+}
+void launch_shard_unpack_routed(const u32* blocks, u32 block_words, u32 N, u32 n, uint8_t* codes, u32* rank_kept, hipStream_t s) {
+  if (n == 0) return;
+  const u32 n_words = (n + 15) / 16;
+  hipLaunchKernelGGL(shard_unpack_routed_kernel, dim3((n_words + 255) / 256, N), dim3(256), 0, s, blocks, block_words, n_words, n, codes,
+                     rank_kept);
+}
+
 // after exchange 1: the gathered blocks [N][block_bytes] back into one byte per slot, and every rank's kept count
 // (rank_kept[r], zero on entry: one atomic per workgroup)
 __global__ void __launch_bounds__(256) shard_unpack_codes_kernel(const uint8_t* __restrict__ blocks, u32 block_bytes, u32 N, u32 n,
@@ -96,12 +149,16 @@ __global__ void __launch_bounds__(256) shard_pack_kernel(const u32* __restrict__
                                                          u32 max_local, const u32* __restrict__ prefix_f,
                                                          const u32* __restrict__ n_matches, const u32* __restrict__ prefix_g, u32 T,
                                                          unsigned long long* __restrict__ block, u32 block_cap, u32 frame_cap,
-                                                         u32* __restrict__ rank_kept, u32 N, u32* __restrict__ max_kept_out) {
+                                                         u32* __restrict__ rank_kept, u32 N, u32* __restrict__ max_kept_out,
+                                                         const u32* __restrict__ halo_viol) {
   const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k == 0) {
     u32 mx = 0;
     for (u32 r = 0; r < N; ++r) { mx = max(mx, rank_kept[r]); rank_kept[r] = 0u; }
     *max_kept_out = mx;
+    // routed band mode: this rank's count of matches whose refinement read outside its Time-Surface rows travels in the
+    // high half of the block's count word, so that every rank learns of it at the same tick (shard_scatter_kernel)
+    if (halo_viol && *halo_viol) atomicAdd(block, (unsigned long long)*halo_viol << 32);
   }
   u32 n = *n_local;
   if (n > max_local) n = max_local;
@@ -116,7 +173,7 @@ __global__ void __launch_bounds__(256) shard_pack_kernel(const u32* __restrict__
   if (m == 0) return;
   const u32 lane = threadIdx.x & 63u;
   u32 base = 0;
-  if (lane == (u32)__ffsll((long long)m) - 1u) base = (u32)atomicAdd(block, (unsigned long long)__popcll(m));
+  if (lane == (u32)__ffsll((long long)m) - 1u) base = (u32)atomicAdd(block, (unsigned long long)__popcll(m));  // (low half: the cursor)
   base = __shfl(base, __ffsll((long long)m) - 1);
   if (!put) return;
   const u32 pos = base + (u32)__popcll(m & ((1ull << lane) - 1ull));
@@ -127,18 +184,19 @@ __global__ void __launch_bounds__(256) shard_pack_kernel(const u32* __restrict__
 }
 void launch_shard_pack(const u32* own_w, const u32* keep, const DevPoint* local_pts, const u32* n_local, u32 max_local,
                        const u32* prefix_f, const u32* n_matches, const u32* prefix_g, u32 T, unsigned long long* block, u32 block_cap,
-                       u32 frame_cap, u32* rank_kept, u32 N, u32* max_kept_out, hipStream_t s) {
+                       u32 frame_cap, u32* rank_kept, u32 N, u32* max_kept_out, hipStream_t s, const u32* halo_viol) {
   static_assert(sizeof(DevPoint) % 8 == 0, "blocks are exchanged as 64-bit words");
   hipLaunchKernelGGL(shard_pack_kernel, dim3(max_local ? (max_local + 255) / 256 : 1), dim3(256), 0, s, own_w, keep, local_pts, n_local,
-                     max_local, prefix_f, n_matches, prefix_g, T, block, block_cap, frame_cap, rank_kept, N, max_kept_out);
+                     max_local, prefix_f, n_matches, prefix_g, T, block, block_cap, frame_cap, rank_kept, N, max_kept_out, halo_viol);
 }
 
 // after exchange 2: every block's points to frame[seq]; one thread per 64-bit word (13 per point)
 __global__ void __launch_bounds__(256) shard_scatter_kernel(const unsigned long long* __restrict__ blocks, size_t block_words, u32 max_kept,
-                                                            DevPoint* __restrict__ frame, u32 frame_cap) {
+                                                            DevPoint* __restrict__ frame, u32 frame_cap, u32* __restrict__ viol_total) {
   constexpr u32 WP = sizeof(DevPoint) / 8;
   const unsigned long long* blk = blocks + (size_t)blockIdx.y * block_words;
   u32 cnt = (u32)blk[0];
+  if (viol_total && blockIdx.x == 0 && threadIdx.x == 0 && (blk[0] >> 32)) atomicAdd(viol_total, (u32)(blk[0] >> 32));
   if (cnt > max_kept) cnt = max_kept;
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   const u32 kk = t / WP, wd = t % WP;
@@ -149,11 +207,11 @@ __global__ void __launch_bounds__(256) shard_scatter_kernel(const unsigned long 
   reinterpret_cast<unsigned long long*>(frame + idx)[wd] = reinterpret_cast<const unsigned long long*>(p)[wd];
 }
 void launch_shard_scatter(const unsigned long long* blocks, size_t block_words, u32 N, u32 max_kept, DevPoint* frame, u32 frame_cap,
-                          hipStream_t s) {
-  if (max_kept == 0 || frame_cap == 0) return;
+                          hipStream_t s, u32* viol_total) {
+  if (max_kept == 0 || frame_cap == 0) return;  // (no kept point anywhere: the exchange did not take place)
   constexpr u32 WP = sizeof(DevPoint) / 8;
-  hipLaunchKernelGGL(shard_scatter_kernel, dim3((max_kept * WP + 255) / 256, N), dim3(256), 0, s, blocks, block_words, max_kept, frame,
-                     frame_cap);
+  hipLaunchKernelGGL(shard_scatter_kernel, dim3((max_kept * WP + 255) / 256, N), dim3(256), 0, s, blocks, block_words,
+                     max_kept, frame, frame_cap, viol_total);
 }
 
 }  // namespace esvo

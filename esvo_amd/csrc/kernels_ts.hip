@@ -306,7 +306,7 @@ __device__ inline int ts_median_tap_direct(const u64* __restrict__ sae, int W, i
   return median9(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8]);
 }
 template <bool BIGMED>
-__global__ void __launch_bounds__(256) ts_render_fused_kernel(TsPair c, int W, int H, TsDecay d, int median_k, int stage_cap) {
+__global__ void __launch_bounds__(256) ts_render_fused_kernel(TsPair c, int W, int H, TsDecay d, int median_k, int stage_cap, int ty0) {
   __shared__ uint8_t s_raw[TSF_CAP];
   __shared__ uint8_t s_med[TSF_CAP];
   __shared__ int s_bb[4];
@@ -322,7 +322,7 @@ __global__ void __launch_bounds__(256) ts_render_fused_kernel(TsPair c, int W, i
   int bx0 = 0x7fffffff, by0 = 0x7fffffff, bx1 = (int)0x80000000, by1 = (int)0x80000000;
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
-    const int y = blockIdx.y * TSF_TY + ty + 8 * k;
+    const int y = (blockIdx.y + ty0) * TSF_TY + ty + 8 * k;
     in[k] = x < W && y < H;
     ix[k] = iy[k] = fx[k] = fy[k] = 0;
     if (in[k]) {
@@ -387,7 +387,7 @@ __global__ void __launch_bounds__(256) ts_render_fused_kernel(TsPair c, int W, i
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     if (!in[k]) continue;
-    const int y = blockIdx.y * TSF_TY + ty + 8 * k;
+    const int y = (blockIdx.y + ty0) * TSF_TY + ty + 8 * k;
     auto tap = [&](int sx, int sy) -> int {
       if (sx < 0 || sx >= W || sy < 0 || sy >= H) return 0;  // BORDER_CONSTANT 0 of cv::remap
       if (staged) return med[(sy - my0) * mw + (sx - mx0)];
@@ -418,27 +418,35 @@ static int ts_stage_cap() {
 static TsDecay ts_decay_args(u64 t_ns, double decay_sec, int ignore_polarity) {
   return TsDecay{t_ns, decay_sec, (float)(-1e-9 / decay_sec), ignore_polarity};
 }
+static_assert(TSF_TY == TS_TILE_ROWS, "row bands are whole tiles");
+// tile rows [ty0, ty0 + nty) that cover the rectified rows [row0, row1) (row1 < 0: the whole image)
+static void ts_tile_rows(int H, int row0, int row1, int& ty0, int& nty) {
+  if (row1 < 0 || row1 > H) row1 = H;
+  if (row0 < 0) row0 = 0;
+  ty0 = row0 / TSF_TY;
+  nty = row1 > row0 ? (row1 + TSF_TY - 1) / TSF_TY - ty0 : 0;
+}
 void launch_ts_render(const u64* d_sae, const int2* d_fixmap, uint8_t* d_raw, uint8_t* d_out, int W, int H, u64 t_ns,
-                      double decay_sec, int ignore_polarity, int median_k, hipStream_t s) {
+                      double decay_sec, int ignore_polarity, int median_k, hipStream_t s, int row0, int row1) {
   (void)d_raw;  // the raw image is an intermediate of FORWARD mode only
   TsPair c{};
   c.sae[0] = d_sae; c.fixmap[0] = d_fixmap; c.out[0] = d_out;
-  if (median_k > 1)
-    hipLaunchKernelGGL(ts_render_fused_kernel<true>, dim3((W + TSF_TX - 1) / TSF_TX, (H + TSF_TY - 1) / TSF_TY, 1), dim3(256), 0, s, c, W,
-                       H, ts_decay_args(t_ns, decay_sec, ignore_polarity), median_k, ts_stage_cap());
-  else
-    hipLaunchKernelGGL(ts_render_fused_kernel<false>, dim3((W + TSF_TX - 1) / TSF_TX, (H + TSF_TY - 1) / TSF_TY, 1), dim3(256), 0, s, c, W,
-                       H, ts_decay_args(t_ns, decay_sec, ignore_polarity), median_k, ts_stage_cap());
+  launch_ts_render_pair(c, W, H, t_ns, decay_sec, ignore_polarity, median_k, s, row0, row1);
 }
 
+// (a TsPair whose second camera is empty renders one camera: grid.z = 1)
 void launch_ts_render_pair(const TsPair& c, int W, int H, u64 t_ns, double decay_sec, int ignore_polarity, int median_k,
-                           hipStream_t s) {
+                           hipStream_t s, int row0, int row1) {
+  int ty0, nty;
+  ts_tile_rows(H, row0, row1, ty0, nty);
+  if (nty <= 0) return;
+  const dim3 grid((W + TSF_TX - 1) / TSF_TX, nty, c.sae[1] ? 2 : 1);
   if (median_k > 1)
-    hipLaunchKernelGGL(ts_render_fused_kernel<true>, dim3((W + TSF_TX - 1) / TSF_TX, (H + TSF_TY - 1) / TSF_TY, 2), dim3(256), 0, s, c, W,
-                       H, ts_decay_args(t_ns, decay_sec, ignore_polarity), median_k, ts_stage_cap());
+    hipLaunchKernelGGL(ts_render_fused_kernel<true>, grid, dim3(256), 0, s, c, W, H, ts_decay_args(t_ns, decay_sec, ignore_polarity),
+                       median_k, ts_stage_cap(), ty0);
   else
-    hipLaunchKernelGGL(ts_render_fused_kernel<false>, dim3((W + TSF_TX - 1) / TSF_TX, (H + TSF_TY - 1) / TSF_TY, 2), dim3(256), 0, s, c, W,
-                       H, ts_decay_args(t_ns, decay_sec, ignore_polarity), median_k, ts_stage_cap());
+    hipLaunchKernelGGL(ts_render_fused_kernel<false>, grid, dim3(256), 0, s, c, W, H, ts_decay_args(t_ns, decay_sec, ignore_polarity),
+                       median_k, ts_stage_cap(), ty0);
 }
 
 // ---- FORWARD mode (TimeSurface.cpp:85-116) ------------------------------------------------------------------------------
@@ -508,10 +516,10 @@ __device__ inline int reflect101(int p, int n) {
   }
   return p;
 }
-__device__ inline void gaussian5_px(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int W, int H) {
+__device__ inline void gaussian5_px(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int W, int H, int row0, int row1) {
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (x >= W || y >= H) return;
+  const int y = row0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= W || y >= row1) return;
   const int k[5] = {1, 4, 6, 4, 1};
   int acc = 0;
 #pragma unroll
@@ -525,18 +533,30 @@ __device__ inline void gaussian5_px(const uint8_t* __restrict__ in, uint8_t* __r
   int v = (acc + 128) >> 8;
   out[y * W + x] = (uint8_t)(v > 255 ? 255 : v);
 }
-__global__ void __launch_bounds__(256) gaussian5_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int W, int H) {
-  gaussian5_px(in, out, W, H);
+__global__ void __launch_bounds__(256) gaussian5_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int W, int H,
+                                                        int row0, int row1) {
+  gaussian5_px(in, out, W, H, row0, row1);
 }
 __global__ void __launch_bounds__(256) gaussian5_pair_kernel(const uint8_t* __restrict__ in0, const uint8_t* __restrict__ in1,
-                                                             uint8_t* __restrict__ out0, uint8_t* __restrict__ out1, int W, int H) {
-  gaussian5_px(blockIdx.z ? in1 : in0, blockIdx.z ? out1 : out0, W, H);
+                                                             uint8_t* __restrict__ out0, uint8_t* __restrict__ out1, int W, int H,
+                                                             int row0, int row1) {
+  gaussian5_px(blockIdx.z ? in1 : in0, blockIdx.z ? out1 : out0, W, H, row0, row1);
 }
-void launch_gaussian5(const uint8_t* d_in, uint8_t* d_out, int W, int H, hipStream_t s) {
-  hipLaunchKernelGGL(gaussian5_kernel, dim3((W + 63) / 64, (H + 3) / 4), dim3(256), 0, s, d_in, d_out, W, H);
+// rows [row0, row1) of the blurred image (row1 < 0: all); they read rows row0 - 2 .. row1 + 1 of the input (reflected at the
+// image border only)
+void launch_gaussian5(const uint8_t* d_in, uint8_t* d_out, int W, int H, hipStream_t s, int row0, int row1) {
+  if (row1 < 0 || row1 > H) row1 = H;
+  if (row0 < 0) row0 = 0;
+  if (row1 <= row0) return;
+  hipLaunchKernelGGL(gaussian5_kernel, dim3((W + 63) / 64, (row1 - row0 + 3) / 4), dim3(256), 0, s, d_in, d_out, W, H, row0, row1);
 }
-void launch_gaussian5_pair(const uint8_t* in0, const uint8_t* in1, uint8_t* out0, uint8_t* out1, int W, int H, hipStream_t s) {
-  hipLaunchKernelGGL(gaussian5_pair_kernel, dim3((W + 63) / 64, (H + 3) / 4, 2), dim3(256), 0, s, in0, in1, out0, out1, W, H);
+void launch_gaussian5_pair(const uint8_t* in0, const uint8_t* in1, uint8_t* out0, uint8_t* out1, int W, int H, hipStream_t s, int row0,
+                           int row1) {
+  if (row1 < 0 || row1 > H) row1 = H;
+  if (row0 < 0) row0 = 0;
+  if (row1 <= row0) return;
+  hipLaunchKernelGGL(gaussian5_pair_kernel, dim3((W + 63) / 64, (row1 - row0 + 3) / 4, 2), dim3(256), 0, s, in0, in1, out0, out1, W, H,
+                     row0, row1);
 }
 
 

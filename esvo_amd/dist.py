@@ -9,11 +9,17 @@ ShardedEsvo:  PyTorch is plumbing here: device-pointer views + collectives; ever
 kernel is in libesvo_hip.so.
 
 Per tick (see esvo_shard_tick_phase in include/esvo_hip.h):
-    phase 0  BM + LM + culling of every world-th slot        -> all-gather: one byte per own slot (matched, kept)
-    phase 1  frame order from all bytes, own kept points packed -> all-gather: [count | points], block = largest kept count
+    phase 0  BM + LM + culling of the rank's events              -> all-gather: the (matched, kept) bits of the tick's slots
+    phase 1  frame order from all bits, own kept points packed   -> all-gather: [count | points], block = largest kept count
     phase 2  points to their frame positions, window policy, fusion + clean + regularisation of the row band (halo rows
              recomputed locally)
 No zero padding travels except the imbalance between the ranks' kept counts.
+
+Which events are a rank's is the ROUTING (esvo_shard_set_routing):
+    "y_rect"     SURVEY 8(e): a rank keeps the events of its image rows at ingest (every rank is handed the whole packets, as
+                 eight subscribers of a topic would be), renders the Time Surfaces of its band + halo only and matches the
+                 events whose floor(y_rect) falls into the band;
+    "broadcast"  the A/B switch: every rank stages everything and renders full Time Surfaces, per-event work dealt by slot.
 """
 import numpy as np
 
@@ -44,6 +50,17 @@ def band_of(rank, world, height):
     return min(rank * rows, height), min((rank + 1) * rows, height)
 
 
+def pick_routing(params, routing="auto"):
+    """"auto": rows where the library supports it (esvo_shard_set_routing refuses Denoising, per-pixel event queues and
+    up-down stereo with ESVO_ERR_UNSUPPORTED), the broadcast switch otherwise"""
+    if routing != "auto":
+        return routing
+    if params is None:
+        return "y_rect"
+    unsupported = bool(getattr(params, "denoising", 0)) or int(getattr(params, "max_event_queue_len", 0)) > 0 or bool(getattr(params, "bm_updown", 0))
+    return "broadcast" if unsupported else "y_rect"
+
+
 # ---- the exchange primitive (backend agnostic: exercised with gloo on CPU in tests/test_dist.py) ----
 def gather_blocks_(recv, send, world, group=None):
     """all-gather of one fixed-size block per rank into `recv` (rank-major): ncclAllGather under the nccl backend, a list
@@ -61,13 +78,14 @@ class ShardedEsvo:
 
     counts_are_local = False
 
-    def __init__(self, params, rig, rank, world, local_rank, group=None, dev=None, device="cuda"):
+    def __init__(self, params, rig, rank, world, local_rank, group=None, dev=None, device="cuda", routing="auto", ts_halo_rows=-1):
         """dev / device: a stand-in for lib.Esvo on host memory (CPU tests of the phase / exchange logic under gloo)"""
         import torch
         self.rank, self.world, self.group = rank, world, group
         self.rig, self.params = rig, params
         self.W, self.H = rig.width, rig.height
         self.device = device
+        self.routing = pick_routing(params, routing)
         if dev is None:
             self.dev = lib.Esvo(params, rig, device=local_rank)
             self.dev.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -76,12 +94,12 @@ class ShardedEsvo:
         self.y0, self.y1 = band_of(rank, world, self.H)
         if self.y1 <= self.y0:
             raise lib.EsvoError(f"rank {rank} of {world} would own no image rows (H={self.H})")
-        self.dev.set_band(self.y0, self.y1, rank, world)
+        self.dev.set_band(self.y0, self.y1, rank, world, routing=self.routing, ts_halo_rows=ts_halo_rows)
         gather_blocks_(torch.zeros(1024 * world, dtype=torch.int64, device=device), torch.zeros(1024, dtype=torch.int64, device=device),
                        world, group)  # communicator set-up, untimed
         if device == "cuda":
             torch.cuda.synchronize()
-    # replicated stages: every rank ingests all events and renders the full Time Surfaces
+    # every rank is handed every packet; what it stages and renders is the routing's business (inside the library)
     def ts_push_events(self, cam, ev):
         self.dev.ts_push_events(cam, ev)
 
@@ -308,14 +326,15 @@ class NativeBandSharded:
 
     counts_are_local = False
 
-    def __init__(self, params, rig, rank, world, local_rank, group=None):
+    def __init__(self, params, rig, rank, world, local_rank, group=None, routing="auto", ts_halo_rows=-1):
         self.rank, self.world = rank, world
         self.rig, self.params = rig, params
+        self.routing = pick_routing(params, routing)
         self.dev = lib.Esvo(params, rig, device=local_rank)
         y0, y1 = band_of(rank, world, rig.height)
         if y1 <= y0:
             raise lib.EsvoError(f"rank {rank} of {world} would own no image rows (H={rig.height})")
-        self.dev.set_band(y0, y1, rank, world)
+        self.dev.set_band(y0, y1, rank, world, routing=self.routing, ts_halo_rows=ts_halo_rows)
         _native_comm_init(self.dev, rank, world, group)
 
     def ts_push_events(self, cam, ev):

@@ -25,7 +25,7 @@ SYMBOLS = [
     "esvo_set_stream", "esvo_synchronize", "esvo_ts_push_events", "esvo_ts_push_events_async", "esvo_ts_push_wait", "esvo_host_alloc", "esvo_host_free", "esvo_ts_push_event_array", "esvo_ts_render", "esvo_ts_render_forward", "esvo_map_set_observation",
     "esvo_map_match", "esvo_map_set_poses", "esvo_map_refine", "esvo_map_push_frame", "esvo_map_fuse",
     "esvo_map_tick", "esvo_map_tick_bm_only", "esvo_map_fuse_matches_naive", "esvo_map_tick_resident", "esvo_map_get_depth_points", "esvo_map_get_committed", "esvo_map_get_pointcloud_xyz", "esvo_map_get_last_frame",
-    "esvo_get_stats", "esvo_shard_set_band", "esvo_shard_exchange", "esvo_shard_tick_phase", "esvo_abi_sizes",
+    "esvo_get_stats", "esvo_shard_set_band", "esvo_shard_set_routing", "esvo_shard_get_rows", "esvo_shard_exchange", "esvo_shard_tick_phase", "esvo_abi_sizes",
     "esvo_map_front", "esvo_map_front_frame", "esvo_map_push_frame_device", "esvo_map_fuse_async",
     "esvo_track_set_current", "esvo_track_get_images", "esvo_track_set_reference", "esvo_track_residuals", "esvo_track_jacobian",
     "esvo_track_normal_equations", "esvo_track_register",
@@ -37,7 +37,6 @@ SYMBOLS = [
 ]
 
 ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
-ALL_REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
 
 
 class EsvoError(RuntimeError):
@@ -60,7 +59,7 @@ def build(force=False, verbose=False, perturbed=False):
     hdr_time = max(os.path.getmtime(h) for h in headers)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     extra = os.environ.get("ESVO_EXTRA_HIPCC_FLAGS", "").split()  # A/B experiments only
-    lib_path = os.path.join(_CSRC, "libesvo_hip.so") if not os.environ.get("ESVO_HIP_LIB") else _LIB_PATH
+    lib_path = os.path.join(_CSRC, "libesvo_hip.so")  # always: ESVO_HIP_LIB names a library to LOAD (an A/B build), never one to write
     objdir = os.path.join(_CSRC, "build" + ("_" + str(abs(hash(" ".join(extra))) % 100000) if extra else ""))
     os.makedirs(objdir, exist_ok=True)
     cflags = [f for f in HIPCC_FLAGS if f not in ("-shared", "-ldl")] + extra + ["-I", inc, "-c"]
@@ -153,6 +152,8 @@ def load():
     lib.esvo_map_get_last_frame.argtypes = [vp, vp, sz, psz]
     lib.esvo_get_stats.argtypes = [vp, vp]
     lib.esvo_shard_set_band.argtypes = [vp, i32, i32, i32, i32]
+    lib.esvo_shard_set_routing.argtypes = [vp, i32, i32]
+    lib.esvo_shard_get_rows.argtypes = [vp, vp, vp, vp, vp]
     lib.esvo_shard_exchange.argtypes = [vp, vp, vp, vp]
     lib.esvo_shard_tick_phase.argtypes = [vp, i32, u64, vp, vp, sz]
     lib.esvo_map_front.argtypes = [vp, u64, vp, vp, sz, psz]
@@ -178,7 +179,7 @@ def load():
     lib.esvo_comm_unique_id.argtypes = [vp]
     lib.esvo_comm_init.argtypes = [vp, vp, i32, i32]
     lib.esvo_comm_rccl_info.argtypes = [C.POINTER(C.c_int), C.c_char_p, sz]
-    lib.esvo_comm_init_callbacks.argtypes = [vp, i32, i32, ALL_GATHER_FN, ALL_REDUCE_FN, vp]
+    lib.esvo_comm_init_callbacks.argtypes = [vp, i32, i32, ALL_GATHER_FN, vp]
     lib.esvo_comm_destroy.argtypes = [vp]
     lib.esvo_comm_owns_next_tick.argtypes = [vp]
     lib.esvo_comm_tick.argtypes = [vp, u64, vp, vp, vp, sz]
@@ -574,11 +575,10 @@ class Esvo:
         buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
         self._ck(self.lib.esvo_comm_init(self.h, buf, int(rank), int(world)))
 
-    def comm_init_callbacks(self, rank, world, all_gather, all_reduce):
-        """all_gather(d_send, d_recv, bytes_per_rank, stream) / all_reduce(d_buf, n_words, stream) -> 0 on success"""
-        self._cb = (ALL_GATHER_FN(lambda user, s, r, n, st: all_gather(s, r, n, st)),
-                    ALL_REDUCE_FN(lambda user, b, n, st: all_reduce(b, n, st)))  # kept alive with the handle
-        self._ck(self.lib.esvo_comm_init_callbacks(self.h, int(rank), int(world), self._cb[0], self._cb[1], None))
+    def comm_init_callbacks(self, rank, world, all_gather):
+        """all_gather(d_send, d_recv, bytes_per_rank, stream) -> 0 on success: the one collective the library issues"""
+        self._cb = ALL_GATHER_FN(lambda user, s, r, n, st: all_gather(s, r, n, st))  # kept alive with the handle
+        self._ck(self.lib.esvo_comm_init_callbacks(self.h, int(rank), int(world), self._cb, None))
 
     def comm_destroy(self):
         self._ck(self.lib.esvo_comm_destroy(self.h))
@@ -612,8 +612,19 @@ class Esvo:
         self._ck(self.lib.esvo_comm_gather_map(self.h, out.ctypes.data, out.shape[0], C.byref(n)))
         return out[: n.value].copy()
 
-    def set_band(self, y0, y1, shard=0, n_shards=1):
+    def set_band(self, y0, y1, shard=0, n_shards=1, routing=None, ts_halo_rows=-1):
+        """row band + shard of this handle; routing: None / "broadcast" (every rank stages all events and renders the full Time
+        Surfaces, per-event work dealt by slot) or "y_rect" (events routed by image row, banded raster)"""
         self._ck(self.lib.esvo_shard_set_band(self.h, int(y0), int(y1), int(shard), int(n_shards)))
+        if routing not in (None, "broadcast"):
+            assert routing == "y_rect", routing
+            self._ck(self.lib.esvo_shard_set_routing(self.h, 1, int(ts_halo_rows)))
+
+    def shard_rows(self):
+        """dict of (begin, end) rows: render, observation, source_left, source_right (esvo_shard_get_rows)"""
+        r = [(C.c_int * 2)() for _ in range(4)]
+        self._ck(self.lib.esvo_shard_get_rows(self.h, *r))
+        return dict(zip(("render", "observation", "source_left", "source_right"), [(int(a[0]), int(a[1])) for a in r]))
 
     def shard_exchange(self):
         """(send pointer, receive pointer, block bytes) of the all-gather due before the next phase (device pointers; block

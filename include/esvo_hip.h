@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define ESVO_HIP_ABI_VERSION 5
+#define ESVO_HIP_ABI_VERSION 6
 
 typedef enum esvo_status_t {
   ESVO_OK = 0,
@@ -58,7 +58,8 @@ typedef enum esvo_status_t {
   ESVO_ERR_HIP = -3,
   ESVO_ERR_CAPACITY = -4,
   ESVO_ERR_UNSUPPORTED = -5,
-  ESVO_ERR_STATE = -6
+  ESVO_ERR_STATE = -6,
+  ESVO_ERR_HALO = -7   /* routed band mode: a refinement read outside the rank's Time-Surface rows (esvo_shard_set_routing) */
 } esvo_status_t;
 
 typedef struct esvo_context* esvo_handle;
@@ -220,6 +221,10 @@ typedef struct esvo_stats_t {
   uint64_t clk_ref_ticks[8];
   uint64_t clk_samples;
   uint32_t clk_ref_khz, pad3_;
+  /* ABI 6 -- routed band mode (esvo_shard_set_routing): matches, summed over ALL ranks and the ticks since esvo_create /
+   * esvo_reset, whose refinement read rows of the Time Surfaces this rank does not render.  Non-zero: the handle refuses
+   * further ticks with ESVO_ERR_HALO. */
+  uint64_t halo_violations;
 } esvo_stats_t;
 
 /* ---- lifecycle -------------------------------------------------------------------- */
@@ -410,23 +415,52 @@ int esvo_get_stats(esvo_handle h, esvo_stats_t* out);
  * lets a foreign-language binding check its struct mirrors. */
 void esvo_abi_sizes(size_t out[8]);
 
-/* ---- Multi-GPU row-band sharding ----------------------------------- */
+/* ---- Multi-GPU: one tick split over the GPUs by image row band ------------------------------------ */
 
-/* Make this handle shard `shard` of `n_shards`: its per-event work (match + refine) is the slots
- * w with w % n_shards == shard of the tick's thread-stride order (balanced whatever the scene; every
- * rank holds the full Time Surfaces), its per-cell work (fuse/clean/regularise) the image rows
- * [row_begin,row_end).  (0, H, 0, 1) = unsharded. */
+/* Make this handle shard `shard` of `n_shards`: its per-cell work (fuse / clean / regularise) is the image rows
+ * [row_begin, row_end).  (0, H, 0, 1) = unsharded.  How the per-event work (match + refine), the event ingest and the
+ * Time-Surface raster are divided is esvo_shard_set_routing's choice; this call selects ESVO_ROUTE_BROADCAST. */
 int esvo_shard_set_band(esvo_handle h, int row_begin, int row_end, int shard, int n_shards);
-/* Three-phase tick for sharded operation.  Every rank stages ALL events, renders the full Time
- * Surfaces and keeps the full fusion window (replicated, a few % of a tick); the per-event work is dealt by
- * slot, the per-cell work by row band.  After phase 0 and after phase 1 the caller ALL-GATHERS one fixed-size
- * block per rank (esvo_shard_exchange; ncclAllGather / torch.distributed all_gather_into_tensor issued on the
- * handle's stream, see esvo_amd/dist.py):
- *   phase 0: poses + event selection + block matching + LM refinement + culling of the shard's slots
- *            -> exchange 1: one byte per OWN slot (bit 0 matched, bit 1 point kept), slots shard, shard + n_shards ...
- *               back to back: ceil(n / n_shards) bytes rounded up to 8
+/* How a band handle divides the work that is not per cell.  Call after esvo_shard_set_band, before any event is staged
+ * (or after esvo_reset): ESVO_ERR_STATE otherwise.
+ *   ESVO_ROUTE_Y_RECT (what SURVEY.md §8(e) specifies; the default of esvo_amd/dist.py and bench.py):
+ *     - ingest: esvo_ts_push_events* keeps, of the events it is handed, those this rank needs -- for both cameras the raw
+ *       rows that the rectifying remap and the median of its rendered rows read (derived from the calibration maps), for
+ *       the left camera also every event whose rectified row floor(y_rect) lies in the band.  Only they cross PCIe, sit in
+ *       the device ring and are scattered; the host still walks every stamp (the reference's event selection,
+ *       esvo_Mapping.cpp:562-574, counts the whole left stream).  The caller hands EVERY rank the full packets, exactly as a
+ *       ROS topic would deliver them to eight subscribers.
+ *     - raster: the Time Surfaces / the observation pair are rendered for the band + ts_halo_rows rows only (rounded
+ *       outwards to whole 16-row tiles; + 2 rows under SmoothTimeSurface).  Rows outside are undefined in every image
+ *       the handle returns.
+ *     - match + refine: an event belongs to the rank that owns floor(y_rect) (the epipolar search is horizontal,
+ *       EventBM.cpp:170-226, so block matching reads the band + patch_size_Y / 2 rows).  The refinement warps the patch by
+ *       the camera motion since the event (DepthProblem.cpp:157-191) and may leave those rows: every evaluation is
+ *       checked, a match whose blocks leave the rendered rows is COUNTED (stats.halo_violations, summed over all ranks by
+ *       the second exchange), and once that count is non-zero every rank refuses its next tick with ESVO_ERR_HALO --
+ *       never a silently different result.  Raise ts_halo_rows (DSEC / DAVIS hand-held sequences move < 10 rows in the
+ *       10 ms a tick looks back) or fall back to ESVO_ROUTE_BROADCAST.
+ *     Not available with Denoising (its mask needs the whole event slice), per-pixel event queues, FORWARD mode,
+ *     up-down stereo: ESVO_ERR_UNSUPPORTED.
+ *   ESVO_ROUTE_BROADCAST (A/B switch; exact whatever the motion): every rank stages ALL events and renders the full Time
+ *     Surfaces; the per-event work is the slots w with w % n_shards == shard of the tick's thread-stride order.
+ * ts_halo_rows < 0: the default (24). */
+enum { ESVO_ROUTE_BROADCAST = 0, ESVO_ROUTE_Y_RECT = 1 };
+int esvo_shard_set_routing(esvo_handle h, int mode, int ts_halo_rows);
+/* What the routing resolved to (each pointer may be NULL): rendered rectified rows, valid rows of the observation pair, the
+ * raw rows whose events are kept per camera.  (0, H) everywhere for ESVO_ROUTE_BROADCAST. */
+int esvo_shard_get_rows(esvo_handle h, int render_rows[2], int observation_rows[2], int source_rows_left[2], int source_rows_right[2]);
+/* Three-phase tick for sharded operation.  The fusion window is replicated (every rank holds every frame; the DepthFrame
+ * is rebuilt from it at every tick, so a band needs nothing of its neighbours' maps).  After phase 0 and after phase 1
+ * the caller ALL-GATHERS one fixed-size block per rank (esvo_shard_exchange; ncclAllGather / torch.distributed
+ * all_gather_into_tensor issued on the handle's stream, see esvo_amd/dist.py):
+ *   phase 0: poses + event selection + block matching + LM refinement + culling of the rank's events
+ *            -> exchange 1: (bit 0 matched, bit 1 point kept) of the tick's slots --
+ *               Y_RECT:    two bits per slot of the WHOLE tick, own slots set: ceil(n / 16) 32-bit words rounded up to 8 bytes
+ *               BROADCAST: one byte per OWN slot, slots shard, shard + n_shards ... back to back: ceil(n / n_shards)
+ *                          bytes rounded up to 8
  *   phase 1: the tick's frame order (EventBM.cpp:289-308 and DepthProblemSolver.cpp:75-90 permutations, derived
- *            from all ranks' bytes), own kept points packed with their final index
+ *            from all ranks' bits), own kept points packed with their final index
  *            -> exchange 2: [count (8 B) | points], 8 + K x sizeof(esvo_depth_point_t) bytes with K = the largest
  *               kept count among the ranks (every rank derives it from exchange 1)
  *   phase 2: every block's points to their place in the frame; window policy (identical on every rank), fusion +
@@ -456,14 +490,11 @@ int esvo_comm_unique_id(uint8_t id[ESVO_COMM_ID_BYTES]);
 int esvo_comm_rccl_info(int* version, char* path, size_t path_cap);
 /* ncclCommInitRank on the handle's device. */
 int esvo_comm_init(esvo_handle h, const uint8_t id[ESVO_COMM_ID_BYTES], int rank, int world);
-/* The same with the two collectives supplied by the caller (another transport; tests that run several ranks on one GPU):
- * all_gather: bytes_per_rank from d_send into d_recv[rank * bytes_per_rank] on every rank; all_reduce: in-place sum of
- * n_words 64-bit unsigned integers.  Both must be ordered after the work already enqueued on hip_stream and must have
- * completed (or be enqueued on hip_stream) when they return 0. */
+/* The same with the collective supplied by the caller (another transport; tests that run several ranks on one GPU):
+ * all_gather: bytes_per_rank from d_send into d_recv[rank * bytes_per_rank] on every rank.  It must be ordered after the work
+ * already enqueued on hip_stream and must have completed (or be enqueued on hip_stream) when it returns 0. */
 typedef int (*esvo_all_gather_fn)(void* user, const void* d_send, void* d_recv, size_t bytes_per_rank, void* hip_stream);
-typedef int (*esvo_all_reduce_u64_fn)(void* user, void* d_buf, size_t n_words, void* hip_stream);
-int esvo_comm_init_callbacks(esvo_handle h, int rank, int world, esvo_all_gather_fn all_gather,
-                             esvo_all_reduce_u64_fn all_reduce, void* user);
+int esvo_comm_init_callbacks(esvo_handle h, int rank, int world, esvo_all_gather_fn all_gather, void* user);
 int esvo_comm_destroy(esvo_handle h);
 /* Tick-interleaved operation (throughput scales with the GPUs; the latency of one tick does not change): rank r maps
  * the ticks k = r (mod world) completely.  A tick depends on earlier ticks only through the frames of its fusion window
@@ -478,8 +509,9 @@ int esvo_comm_tick(esvo_handle h, uint64_t t_ns, const double T_world_cam[16], c
 int esvo_comm_flush(esvo_handle h);  /* completes a partial round */
 /* The DepthMap of the newest tick on every rank (it lives on the rank that mapped it: all-gather of the newest maps). */
 int esvo_comm_newest_map(esvo_handle h, esvo_depth_point_t* out, size_t cap, size_t* n, long long* tick_index);
-/* One tick split over the ranks (esvo_shard_set_band first): the three phases of esvo_shard_tick_phase with their two
- * sums as ncclAllReduce(ncclUint64, ncclSum), and the all-gather of the DepthMap bands, merged on the creation order. */
+/* One tick split over the ranks (esvo_shard_set_band + esvo_shard_set_routing first): the three phases of
+ * esvo_shard_tick_phase with their two ncclAllGather exchanges, and the all-gather of the DepthMap bands, merged on the
+ * creation order. */
 int esvo_comm_shard_tick(esvo_handle h, uint64_t t_ns, const uint64_t* pose_t_ns, const double* pose_T, size_t m);
 int esvo_comm_gather_map(esvo_handle h, esvo_depth_point_t* out, size_t cap, size_t* n);
 

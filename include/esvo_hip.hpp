@@ -297,35 +297,69 @@ inline bool solve6(const double A_in[36], const double rhs[6], double x[6]) {
   return true;
 }
 struct Registration { double R[9]; double t[3]; double rms = 0; int iterations = 0; bool ok = true; };
-// Damped Gauss-Newton on x = (Cayley parameters, translation), linearised at x = 0 in every iteration exactly as
-// RegProblemSolverLM::solve_analytical does (RegProblemSolverLM.cpp:160-183: x.fill(0), one step, addMotionUpdate):
-//   (H + damping diag(H) + 1e-9 I) dx = -b,   R <- orth(cayley2rot(dx_c) R),   t <- dx_t + cayley2rot(dx_c) t
-// until |dx| < 1e-6 or max_iterations.  `normal_eq(R, t, H[36], b[6], &cost, &n)` evaluates H = J^T J, b = J^T f, cost = |f|^2 at
-// the current (R, t): esvo_track_normal_equations on the device, or the CPU oracle's restatement in the tests.
+// Levenberg-damped Gauss-Newton on x = (Cayley parameters, translation), linearised at x = 0 in every iteration exactly as
+// RegProblemSolverLM::solve_analytical does (RegProblemSolverLM.cpp:160-183: x.fill(0), minimizeInit, ONE minimizeOneStep,
+// addMotionUpdate):
+//   (H + lambda diag(H) + 1e-9 I) dx = -b,   R' = orth(cayley2rot(dx_c) R),   t' = dx_t + cayley2rot(dx_c) t
+// Like Eigen's minimizeOneStep, a trial step is ACCEPTED only if it pays: the cost is evaluated at the trial pose (same
+// batch) and the step taken iff actual reduction / predicted reduction >= 1e-4, with
+//   predicted = |f|^2 - |f + J dx|^2 = -(2 b.dx + dx.H dx);
+// otherwise the damping is raised tenfold and the step recomputed (up to 6 times; minimizeInit resets Eigen's par at every
+// outer iteration, so lambda restarts from `damping` each time) -- the driver never moves to a pose with a higher cost.
+// It stops after max_iterations, when an accepted step is shorter than 1e-6, or when no damping up to 1e5 x yields an
+// acceptable step (the state in which Eigen's trust radius has shrunk below xtol |x|: its status 2 / 3, on which the
+// reference's loop breaks, :181-182).  Stated deviation (DESIGN.md "Deviations"): the step is Levenberg's diagonal damping,
+// not MINPACK's lmpar trust-region solve, so single steps differ from Eigen's while the fixed point is the same.
+// `normal_eq(k, R, t, H[36], b[6], &cost, &n)` evaluates H = J^T J, b = J^T f, cost = |f|^2 at (R, t) on the batch of outer
+// iteration k: esvo_track_normal_equations on the device, or the CPU oracle's restatement in the tests.  same_batch: the
+// batch does not depend on k, so the evaluation at an accepted trial pose IS the next iteration's linearisation (one
+// evaluation per iteration + one per rejected step).
 template <class NormalEq>
 Registration gauss_newton_register(NormalEq&& normal_eq, const double R0[9], const double t0[3], int max_iterations = 12,
-                                   double damping = 1e-3) {
+                                   double damping = 1e-3, bool same_batch = true) {
   Registration g;
   for (int i = 0; i < 9; ++i) g.R[i] = R0[i];
   for (int i = 0; i < 3; ++i) g.t[i] = t0[i];
+  double H[36], b[6], cost = 0;
+  size_t n = 0;
+  bool have = false;
   for (int it = 0; it < max_iterations; ++it) {
-    double H[36], b[6], cost = 0;
-    size_t n = 0;
-    if (!normal_eq(g.R, g.t, H, b, &cost, &n)) { g.ok = false; return g; }
+    if (!have && !normal_eq(it, g.R, g.t, H, b, &cost, &n)) { g.ok = false; return g; }
+    have = false;
     g.iterations = it + 1;
     g.rms = n ? std::sqrt(cost / (double)n) : 0.0;
-    double A[36], rhs[6], dx[6];
-    for (int i = 0; i < 36; ++i) A[i] = H[i];
-    for (int i = 0; i < 6; ++i) { A[i * 6 + i] = (H[i * 6 + i] + damping * H[i * 6 + i]) + 1e-9; rhs[i] = -b[i]; }
-    if (!solve6(A, rhs, dx)) { g.ok = false; return g; }
-    double dR[9], Rn[9], tn[3];
-    cayley2rot(dx, dR);
-    for (int r = 0; r < 3; ++r)
-      for (int c = 0; c < 3; ++c) Rn[r * 3 + c] = (dR[r * 3 + 0] * g.R[0 * 3 + c] + dR[r * 3 + 1] * g.R[1 * 3 + c]) + dR[r * 3 + 2] * g.R[2 * 3 + c];
-    orthonormalize3(Rn);
-    for (int r = 0; r < 3; ++r) tn[r] = dx[3 + r] + ((dR[r * 3 + 0] * g.t[0] + dR[r * 3 + 1] * g.t[1]) + dR[r * 3 + 2] * g.t[2]);
+    double lambda = damping, dx[6], Rn[9], tn[3], Ht[36], bt[6], cost_t = 0;
+    size_t nt = 0;
+    bool accepted = false;
+    for (int attempt = 0; attempt < 6 && !accepted; ++attempt, lambda *= 10.0) {
+      double A[36], rhs[6];
+      for (int i = 0; i < 36; ++i) A[i] = H[i];
+      for (int i = 0; i < 6; ++i) { A[i * 6 + i] = (H[i * 6 + i] + lambda * H[i * 6 + i]) + 1e-9; rhs[i] = -b[i]; }
+      if (!solve6(A, rhs, dx)) { g.ok = false; return g; }
+      double dR[9];
+      cayley2rot(dx, dR);
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) Rn[r * 3 + c] = (dR[r * 3 + 0] * g.R[0 * 3 + c] + dR[r * 3 + 1] * g.R[1 * 3 + c]) + dR[r * 3 + 2] * g.R[2 * 3 + c];
+      orthonormalize3(Rn);
+      for (int r = 0; r < 3; ++r) tn[r] = dx[3 + r] + ((dR[r * 3 + 0] * g.t[0] + dR[r * 3 + 1] * g.t[1]) + dR[r * 3 + 2] * g.t[2]);
+      if (!normal_eq(it, Rn, tn, Ht, bt, &cost_t, &nt)) { g.ok = false; return g; }
+      double pred = 0;  // -(2 b.dx + dx.H dx)
+      for (int i = 0; i < 6; ++i) {
+        double hd = 0;
+        for (int j = 0; j < 6; ++j) hd += H[i * 6 + j] * dx[j];
+        pred -= dx[i] * (2.0 * b[i] + hd);
+      }
+      accepted = pred > 0 && (cost - cost_t) >= 1e-4 * pred;
+    }
+    if (!accepted) break;  // no step pays any more: (R, t) stays the last accepted pose
     for (int i = 0; i < 9; ++i) g.R[i] = Rn[i];
     for (int i = 0; i < 3; ++i) g.t[i] = tn[i];
+    if (same_batch) {
+      for (int i = 0; i < 36; ++i) H[i] = Ht[i];
+      for (int i = 0; i < 6; ++i) b[i] = bt[i];
+      cost = cost_t; n = nt; have = true;
+      g.rms = n ? std::sqrt(cost / (double)n) : 0.0;
+    }
     double nrm = 0;
     for (int i = 0; i < 6; ++i) nrm += dx[i] * dx[i];
     if (std::sqrt(nrm) < 1e-6) break;
@@ -384,14 +418,13 @@ class RegProblemLM {
   // RegProblemSolverLM::solve_analytical's loop (RegProblemSolverLM.cpp:148-215) with gauss_newton_register as the step:
   // the batch advances with the iteration as setStochasticSampling does there (:167-168)
   Registration solve(const double R0[9], const double t0[3], int MAX_ITERATION = 12, double damping = 1e-3) {
-    size_t it = 0;
-    auto ne = [&](const double* R, const double* t, double* H, double* b, double* cost, size_t* n) {
-      if (cfg_.BATCH_SIZE < numPoints_) setStochasticSampling((it % numBatches_) * cfg_.BATCH_SIZE, cfg_.BATCH_SIZE);
-      ++it;
+    const bool batches = cfg_.BATCH_SIZE < numPoints_;
+    auto ne = [&](int it, const double* R, const double* t, double* H, double* b, double* cost, size_t* n) {
+      if (batches) setStochasticSampling(((size_t)it % numBatches_) * cfg_.BATCH_SIZE, cfg_.BATCH_SIZE);
       *n = normalEquations(R, t, H, b, cost);
       return true;
     };
-    return gauss_newton_register(ne, R0, t0, MAX_ITERATION, damping);
+    return gauss_newton_register(ne, R0, t0, MAX_ITERATION, damping, !batches);
   }
   size_t numBatches_ = 1, numPoints_ = 0;
 

@@ -32,7 +32,7 @@ int main(int argc, char** argv) {
   orc_tracker_handle trk = orc_tracker_create(&cal);
   orc_tracker_set_current(trk, ts.data(), 5);
   orc_tracker_set_reference(trk, xyz.data(), n, Tref);
-  auto ne = [&](const double* R, const double* t, double* Hm, double* b, double* cost, size_t* m) {
+  auto ne = [&](int, const double* R, const double* t, double* Hm, double* b, double* cost, size_t* m) {
     double v[28];
     *m = orc_tracker_normal_equations(trk, R, t, 0, n, 1, 50.0, v);
     int k = 0;

@@ -69,6 +69,52 @@ def test_exchange_primitives_gloo_world2(height):
     assert all(ok1 and ok2 for _, ok1, ok2 in res), res
 
 
+def _routed_worker(rank, world, port, q):
+    """exchange 1 of the ROUTED band mode (kernels_shard.hip, shard_codes_routed / shard_unpack_routed, restated in numpy):
+    a rank's slots are wherever its rows' events fell, so its block spans the whole tick -- two bits per slot, own slots set,
+    whole 64-bit words -- and the receiver takes the one non-zero field per slot and every rank's kept count"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(11)           # same stream on every rank
+        n = 1003
+        owner = rng.integers(0, world, n)         # which rank's band the slot's event fell into
+        codes_ref = rng.choice(np.array([0, 1, 3], np.uint8), n)
+        blk = (-(-n // 16) * 4 + 7) // 8 * 8
+        words = np.zeros(blk // 4, np.uint32)
+        for w in np.flatnonzero(owner == rank):
+            words[w >> 4] |= np.uint32(int(codes_ref[w]) << (2 * (w & 15)))
+        recv = np.zeros(world * blk, np.uint8)
+        edist.gather_blocks_(torch.from_numpy(recv.view(np.int64)), torch.from_numpy(words.view(np.int64)), world)
+        back = np.zeros(n, np.uint8)
+        kept = []
+        for r in range(world):
+            wr = recv[r * blk: (r + 1) * blk].view(np.uint32)
+            f = np.stack([(wr >> np.uint32(2 * qq)) & np.uint32(3) for qq in range(16)], 1).reshape(-1)[:n].astype(np.uint8)
+            assert not np.any((back != 0) & (f != 0))          # one owner per slot
+            back |= f
+            kept.append(int(((f >> 1) & 1).sum()))
+        ok = np.array_equal(back, codes_ref) and kept == [int(((codes_ref[owner == r] >> 1) & 1).sum()) for r in range(world)]
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_routed_exchange_gloo(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_routed_worker, args=(r, world, 29660 + world, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert len(res) == world and all(ok for _, ok in res), res
+
+
 def test_band_bookkeeping_and_merge():
     assert [edist.band_of(r, 8, 480) for r in range(8)] == [(60 * r, 60 * r + 60) for r in range(8)]
     assert [edist.band_of(r, 4, 10) for r in range(4)] == [(0, 3), (3, 6), (6, 9), (9, 10)]
@@ -172,8 +218,9 @@ class _FakeBand:
         self.rank, self.world, self.phase_log = rank, world, []
         self.send = self.recv = None
 
-    def set_band(self, y0, y1, shard, n_shards):
+    def set_band(self, y0, y1, shard, n_shards, routing=None, ts_halo_rows=-1):
         self.band = (y0, y1, shard, n_shards)
+        self.routing = routing
 
     def shard_phase(self, phase, t_ns=0, stamps=None, poses=None):
         self.phase_log.append(phase)
@@ -209,7 +256,7 @@ def _band_worker(rank, world, port, q):
     try:
         fake = _FakeBand(rank, world)
         drv = edist.ShardedEsvo(None, _Rig(), rank, world, 0, dev=fake, device="cpu")
-        ok = fake.band == (*edist.band_of(rank, world, 10), rank, world)
+        ok = fake.band == (*edist.band_of(rank, world, 10), rank, world) and fake.routing == "y_rect"   # (rows unless the preset forbids it)
         snap = {}
         orig = fake.shard_phase
 

@@ -69,19 +69,6 @@ class LocalTransport:
         self.bar.wait()
         return 0
 
-    def all_reduce(self, rank, d_buf, n_words):
-        import torch
-        torch.cuda.synchronize()
-        self.slots[rank] = d_buf
-        self.bar.wait()
-        total = sum(edist.device_tensor(self.slots[r], n_words, "<i8").clone() for r in range(self.world))
-        torch.cuda.synchronize()
-        self.bar.wait()
-        edist.device_tensor(d_buf, n_words, "<i8").copy_(total)
-        torch.cuda.synchronize()
-        self.bar.wait()
-        return 0
-
 
 def _run_ranks(world, body):
     errs, outs = [], [None] * world
@@ -143,7 +130,7 @@ def test_tick_interleaved_ranks_through_the_c_calls(request, world, preset, rig_
 
     def body(r):
         dev = lib.Esvo(p, rig)
-        dev.comm_init_callbacks(r, world, lambda s, d, n, st: tr.all_gather(r, s, d, n), lambda b, n, st: tr.all_reduce(r, b, n))
+        dev.comm_init_callbacks(r, world, lambda s, d, n, st: tr.all_gather(r, s, d, n))
         dev.ts_push_events(0, stream.ev_left)
         dev.ts_push_events(1, stream.ev_right)
         got = {}
@@ -166,21 +153,30 @@ def test_tick_interleaved_ranks_through_the_c_calls(request, world, preset, rig_
             _same(mp, ref[idx])
 
 
-def test_band_sharded_ranks_through_the_c_calls(dsec_rig, dsec_stream):
+@pytest.mark.parametrize("world,routing,rig_fix,stream_fix,preset", [
+    (2, "broadcast", "dsec_rig", "dsec_stream", "mapping_dsec"),
+    (2, "y_rect", "dsec_rig", "dsec_stream", "mapping_dsec"),
+    (8, "y_rect", "dsec_rig", "dsec_stream", "mapping_dsec"),       # 60-row bands, regulariser halo of 20 rows on both sides
+    (8, "broadcast", "dsec_rig", "dsec_stream", "mapping_dsec"),
+    (8, "y_rect", "upenn_rig", "upenn_stream", "mapping_upenn"),    # 260 rows / 8: ragged bands (33 x 7 + 29), CONST_POINTS window
+])
+def test_band_sharded_ranks_through_the_c_calls(request, world, routing, rig_fix, stream_fix, preset):
+    """world ranks (threads, one handle each, ONE GPU) through esvo_comm_shard_tick / esvo_comm_gather_map with an in-process
+    all-gather: every rank ends up with the unsharded DepthMap, bit for bit -- at the world size BASELINE.json's headline names"""
     from esvo_amd import lib
-    world = 2
-    p, _ = params.make_params(params.PRESETS["mapping_dsec"], dsec_rig, process_event_num=3000)
-    ticks = _ticks(dsec_stream, p, 3)
-    ref = _single(p, dsec_rig, dsec_stream, ticks)
+    rig, stream = request.getfixturevalue(rig_fix), request.getfixturevalue(stream_fix)
+    p, _ = params.make_params(params.PRESETS[preset], rig, process_event_num=3000)
+    ticks = _ticks(stream, p, 3)
+    ref = _single(p, rig, stream, ticks)
     tr = LocalTransport(world)
 
     def body(r):
-        dev = lib.Esvo(p, dsec_rig)
-        y0, y1 = edist.band_of(r, world, dsec_rig.height)
-        dev.set_band(y0, y1, r, world)
-        dev.comm_init_callbacks(r, world, lambda s, d, n, st: tr.all_gather(r, s, d, n), lambda b, n, st: tr.all_reduce(r, b, n))
-        dev.ts_push_events(0, dsec_stream.ev_left)
-        dev.ts_push_events(1, dsec_stream.ev_right)
+        dev = lib.Esvo(p, rig)
+        y0, y1 = edist.band_of(r, world, rig.height)
+        dev.set_band(y0, y1, r, world, routing=routing)
+        dev.comm_init_callbacks(r, world, lambda s, d, n, st: tr.all_gather(r, s, d, n))
+        dev.ts_push_events(0, stream.ev_left)   # every rank is handed the whole stream; a routed handle keeps its rows
+        dev.ts_push_events(1, stream.ev_right)
         maps = []
         for t, stamps, poses, T in ticks:
             dev.ts_render(0, t, download=False)
@@ -188,8 +184,15 @@ def test_band_sharded_ranks_through_the_c_calls(dsec_rig, dsec_stream):
             dev.set_observation(t, None, None, T)
             dev.comm_shard_tick(t, stamps, poses)
             maps.append(dev.comm_gather_map())
-        return maps
+        st = dev.stats()
+        assert st.halo_violations == 0
+        return maps, int(st.events_staged[0]), int(st.events_staged[1])
 
-    for maps in _run_ranks(world, body):
+    outs = _run_ranks(world, body)
+    for maps, _, _ in outs:
         for k, mp in enumerate(maps):
             _same(mp, ref[k])
+    if routing == "y_rect" and world == 8:  # band-local ingest: a rank stages its rows (+ halo), not the stream
+        n_l, n_r = len(stream.ev_left), len(stream.ev_right)
+        assert max(o[1] for o in outs) < 0.6 * n_l and max(o[2] for o in outs) < 0.6 * n_r, [(o[1], o[2]) for o in outs]
+        assert sum(o[1] for o in outs) >= n_l * 0.9   # (every event is somebody's)

@@ -75,9 +75,24 @@ def test_selftest_reports_ranks_exchange_and_map_equality():
     rc, two, err = _selftest({"ESVO_SHARED_GPU": "1", "ESVO_DIST_BACKEND": "gloo"}, 2)
     assert rc == 0 and two["ok"], (rc, two, err)
     assert {r["rank"] for r in two["ranks_seen"]} == {0, 1} and two["all_gather"]["verified"] and two["all_gather"]["us_min"] > 0
-    assert two["depth_map_equal_to_one_gpu"] and set(two["depth_map"]) == {"tick", "band", "one_gpu"}
+    assert two["depth_map_equal_to_one_gpu"] and set(two["depth_map"]) == {"tick", "band", "band_broadcast", "one_gpu"}
     assert two["depth_map"]["one_gpu"]["sha1"] == one["depth_map"]["one_gpu"]["sha1"]
     assert two["seconds"] < 60
+
+
+def test_selftest_at_world_8_on_a_shared_gpu():
+    """BASELINE.json's headline world size, functionally: eight ranks (processes) on the ONE GPU over gloo through
+    `python bench.py --gpus 8 --selftest` -- tick-interleaved, row-routed bands (260 rows / 8: ragged 33- and 29-row bands) and
+    the broadcast switch all reproduce the one-GPU DepthMap; a routed rank stages a fraction of the stream.  The first real
+    8-GPU run executes exactly this command (then over RCCL) before it measures anything: it must finish well inside 120 s."""
+    rc, r8, err = _selftest({"ESVO_SHARED_GPU": "1", "ESVO_DIST_BACKEND": "gloo"}, 8)
+    assert rc == 0 and r8 and r8["ok"], (rc, r8, err)
+    assert {r["rank"] for r in r8["ranks_seen"]} == set(range(8)) and r8["all_gather"]["verified"]
+    assert r8["depth_map_equal_to_one_gpu"] and set(r8["depth_map"]) == {"tick", "band", "band_broadcast", "one_gpu"}
+    band = r8["depth_map"]["band"]
+    assert band["halo_violations"] == 0
+    assert band["events_staged_rank0"][0] < 0.6 * band["events_in_stream"][0], band
+    assert r8["seconds"] < 120, r8["seconds"]
 
 
 @pytest.mark.skipif(_device_count() < 2, reason="needs two MI355X on the node (real RCCL between two processes)")

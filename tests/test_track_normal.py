@@ -53,22 +53,17 @@ def test_oracle_normal_equations_are_the_products_of_the_reference_functor():
 
 
 def _numpy_register(trk, n, R_, t_, iters):
-    from esvo_amd.closed_loop import cayley2rot, orth
-    r = None
-    for it in range(iters):
+    from esvo_amd.closed_loop import lm_gn_loop
+
+    def evaluate(R, t):
         Tlr = np.eye(4)
-        Tlr[:3, :3] = R_.T
-        Tlr[:3, 3] = -R_.T @ t_
+        Tlr[:3, :3] = R.T
+        Tlr[:3, 3] = -R.T @ t
         r = trk.residuals(Tlr, 0, n, huber=True, huber_threshold=50.0)
-        J = trk.jacobian(R_, t_, 0, n)
-        H = J.T @ J
-        dx = -np.linalg.solve(H + 1e-3 * np.diag(np.diag(H)) + 1e-9 * np.eye(6), J.T @ r)
-        dR = cayley2rot(dx[:3])
-        R_ = orth(dR @ R_)
-        t_ = dx[3:] + dR @ t_
-        if np.linalg.norm(dx) < 1e-6:
-            break
-    return R_, t_, it + 1
+        J = trk.jacobian(R, t, 0, n)
+        return J.T @ J, J.T @ r, float(r @ r), len(r)
+    R, t, _, it = lm_gn_loop(evaluate, R_, t_, iters)
+    return R, t, it
 
 
 def test_cpp_gauss_newton_driver_equals_the_numpy_loop(tmp_path):
