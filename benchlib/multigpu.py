@@ -1,0 +1,252 @@
+"""N-GPU plumbing of bench.py: the self-launcher, `--selftest`, and the band-share projection on one GPU."""
+import csv
+import glob
+import hashlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from esvo_amd import calib, lib, params, rostime, synth  # noqa: E402,F401
+from .workload import make_workload, map_sha1  # noqa: E402
+
+from esvo_amd import dist as edist  # noqa: E402
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-execute this command as N ranks under torch.distributed.run (one
+    process per GPU, rendezvous on 127.0.0.1, a free port).  Fails loudly when the node has fewer than N devices -- a
+    single-rank number must never be reported as an N-GPU point.  (ESVO_SHARED_GPU=1: N ranks share device 0, functional
+    tests only.)"""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < 1:
+        print("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback", file=sys.stderr)
+        return 2
+    if have < n and not os.environ.get("ESVO_SHARED_GPU"):
+        print(f"bench.py --gpus {n}: only {have} GPU(s) visible on this node (hipGetDeviceCount); refusing to run fewer ranks "
+              f"than asked for", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max((os.cpu_count() or n) // n, 1)))
+    env["ESVO_BENCH_SELF_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py")] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def selftest(rank, world, local_rank, dist, ranks_seen, rccl, n_ticks=6):
+    """`python bench.py --gpus N --selftest`: everything a failed scaling run would want to know, in well under 30 s.
+    ranks_seen / rccl as on the benchmark line; one all-gather of 1 MiB per rank, verified and timed (10 repeats); then six
+    ticks of the 346x260 workload through BOTH N-GPU modes (tick-interleaved: esvo_comm_tick; band: esvo_comm_shard_tick -- the
+    native RCCL path unless ESVO_DIST_BACKEND / ESVO_NATIVE_COMM say otherwise) and, on rank 0, through one plain handle: the
+    three DepthMap SHA-1 must be equal.  Prints ONE JSON line; the exit code is 0 only if every check passed."""
+    import torch
+    t_begin = time.perf_counter()
+    backend = os.environ.get("ESVO_DIST_BACKEND", "nccl")
+    res = {"selftest": True, "n_gpus": world, "backend": backend if dist else None, "ranks_seen": ranks_seen, "rccl": rccl, "ok": True}
+    if dist:
+        dev = "cuda" if backend == "nccl" else "cpu"
+        n = 1 << 18   # 1 MiB of f32 per rank
+        send = torch.full((n,), float(rank + 1), device=dev)
+        recv = [torch.empty(n, device=dev) for _ in range(world)]
+        times = []
+        for i in range(13):
+            if dev == "cuda":
+                torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            dist.all_gather(recv, send)
+            if dev == "cuda":
+                torch.cuda.synchronize()
+            if i >= 3:
+                times.append((time.perf_counter() - t0) * 1e6)
+        good = all(bool((recv[r] == float(r + 1)).all().item()) for r in range(world))
+        res["all_gather"] = {"bytes_per_rank": 4 * n, "us_min": min(times), "us_median": sorted(times)[len(times) // 2], "verified": good}
+        res["ok"] = res["ok"] and good
+    rig, stream, p, ticks = make_workload("upenn346x260", n_ticks, share=(rank, dist.barrier) if dist else None)
+
+    def drive(runner):
+        runner.ts_push_events(0, stream.ev_left)
+        runner.ts_push_events(1, stream.ev_right)
+        for t, stamps, poses, T in ticks:
+            if hasattr(runner, "tick_resident"):
+                runner.tick_resident(t, T, stamps, poses)
+            else:
+                runner.ts_render(0, t, download=False)
+                runner.ts_render(1, t, download=False)
+                runner.set_observation(t, None, None, T)
+                runner.tick(t, stamps, poses)
+        runner.synchronize()
+        return runner.get_map()   # collective at N > 1
+
+    shas = {}
+    if dist:
+        from esvo_amd import dist as edist
+        native = backend == "nccl" and os.environ.get("ESVO_NATIVE_COMM", "1") != "0"
+        res["exchange"] = "esvo_comm_* (RCCL inside libesvo_hip.so)" if native else f"torch.distributed ({backend})"
+        # "band": events routed by image row, banded Time Surfaces; "band_broadcast": the A/B switch (every rank
+        # stages everything, per-event work dealt by slot)
+        for mode in ("tick", "band", "band_broadcast"):
+            cls = ((edist.NativeTickSharded if mode == "tick" else edist.NativeBandSharded) if native
+                   else (edist.TickShardedEsvo if mode == "tick" else edist.ShardedEsvo))
+            kw = {} if mode == "tick" else {"routing": "y_rect" if mode == "band" else "broadcast"}
+            t0 = time.perf_counter()
+            try:
+                runner = cls(p, rig, rank, world, local_rank, **kw)
+                gm = drive(runner)
+                shas[mode] = {"sha1": map_sha1(gm), "map_size": int(len(gm)), "seconds": round(time.perf_counter() - t0, 2)}
+                if mode == "band":
+                    st_ = runner.stats()
+                    shas[mode]["rows"] = runner.dev.shard_rows()
+                    shas[mode]["events_staged_rank0"] = [int(st_.events_staged[0]), int(st_.events_staged[1])]
+                    shas[mode]["events_in_stream"] = [int(len(stream.ev_left)), int(len(stream.ev_right))]
+                    shas[mode]["halo_violations"] = int(st_.halo_violations)
+                runner.dev.close()
+            except Exception as e:  # noqa: BLE001  (a hang inside RCCL cannot be caught: the 30 s budget is the caller's timeout)
+                shas[mode] = {"error": f"{type(e).__name__}: {e}"}
+                res["ok"] = False
+    if rank == 0:
+        single = lib.Esvo(p, rig, device=local_rank)
+        gm = drive(single)
+        single.close()
+        shas["one_gpu"] = {"sha1": map_sha1(gm), "map_size": int(len(gm))}
+        res["depth_map"] = shas
+        same = all(v.get("sha1") == shas["one_gpu"]["sha1"] for v in shas.values())
+        res["depth_map_equal_to_one_gpu"] = same
+        res["ok"] = res["ok"] and same and shas["one_gpu"]["map_size"] > 100
+    if dist:
+        flag = torch.tensor([0.0 if res["ok"] else 1.0], device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        res["ok"] = flag.item() == 0.0
+    res["seconds"] = round(time.perf_counter() - t_begin, 2)
+    return res
+
+
+
+
+def band_share(workload, device, shards=(8, 16), steps=6, warmup=3, events_cap=0):
+    """What ONE rank of an N-GPU band-mode run computes per tick, measured on this one GPU -- a PROJECTION, not a scaling
+    measurement: G logical shards (handles; row bands of the image, events routed by row, banded Time Surfaces: exactly the
+    configuration `--gpus G` runs in band mode) map the headline workload; the two all-gathers of a tick are emulated by
+    device copies between the handles' exchange buffers (tests/test_gpu_shard.py does the same) and are NOT in the figures.
+    Every shard's stage -- both Time-Surface renders + the observation, phases 0 / 1 / 2 -- runs ALONE on the GPU and is
+    followed by a synchronisation, so a rank's share is the sum of its own stage times, launch overheads included; the same
+    procedure on one unsharded handle (`full_tick_ms_synchronised`) is what it is compared with.
+    replicated_ms: the part of a rank's share that does not shrink with N, from share(G) = a + b / G at G = 8 and 16."""
+    import torch
+    rig, stream, p, ticks = make_workload(workload, max(steps + warmup, 40), events_cap)
+    ticks = ticks[: steps + warmup]
+    out = {"what": "projection: one rank's compute per band-mode tick (routing y_rect), G logical shards on ONE GPU, each stage run "
+                   "alone and synchronised; the two all-gathers per tick are emulated by device copies and not timed",
+           "ticks_timed": steps}
+
+    def emulate_gather(devs):
+        ex = [d.shard_exchange() for d in devs]
+        nb = ex[0][2]
+        if nb == 0:
+            return 0
+        blocks = [edist.device_tensor(snd, nb // 8, "<i8").clone() for snd, _, _ in ex]
+        for _, rcv, _ in ex:
+            for r, blk in enumerate(blocks):
+                edist.device_tensor(rcv + r * nb, nb // 8, "<i8").copy_(blk)
+        torch.cuda.synchronize()
+        return nb
+
+    def timed(fn, dev):
+        t0 = time.perf_counter()
+        fn()
+        dev.synchronize()
+        return (time.perf_counter() - t0) * 1e3
+
+    # the unsharded tick, the same way: staged stages, a synchronisation after each
+    one = lib.Esvo(p, rig, device=device)
+    one.ts_push_events(0, stream.ev_left)
+    one.ts_push_events(1, stream.ev_right)
+    full = []
+    for k, (t, stamps, poses, T) in enumerate(ticks):
+        def obs():
+            one.ts_render(0, t, download=False)
+            one.ts_render(1, t, download=False)
+            one.set_observation(t, None, None, T)
+        a = timed(obs, one)
+        b = timed(lambda: one.tick(t, stamps, poses), one)   # (lazy tick: the synchronisation completes it)
+        if k >= warmup:
+            full.append((a, b))
+    ref_sha = map_sha1(one.get_map())
+    n_events = int(one.stats().last_events_in)
+    one.close()
+    full = np.array(full)
+    out["full_tick_ms_synchronised"] = {"time_surfaces": float(full[:, 0].mean()), "mapper": float(full[:, 1].mean()),
+                                        "total": float(full.sum(1).mean())}
+    out["events_per_tick"] = n_events
+    shares = {}
+    for G in shards:
+        devs = [lib.Esvo(p, rig, device=device) for _ in range(G)]
+        for g, d in enumerate(devs):
+            y0, y1 = edist.band_of(g, G, rig.height)
+            d.set_band(y0, y1, g, G, routing="y_rect")
+            d.ts_push_events(0, stream.ev_left)
+            d.ts_push_events(1, stream.ev_right)
+        acc = np.zeros((G, 4))
+        xbytes = [0, 0]
+        for k, (t, stamps, poses, T) in enumerate(ticks):
+            for g, d in enumerate(devs):
+                def obs():
+                    d.ts_render(0, t, download=False)
+                    d.ts_render(1, t, download=False)
+                    d.set_observation(t, None, None, T)
+                dt = timed(obs, d)
+                if k >= warmup:
+                    acc[g, 0] += dt
+            for phase in range(3):
+                for g, d in enumerate(devs):
+                    dt = timed((lambda: d.shard_phase(0, t, stamps, poses)) if phase == 0 else (lambda: d.shard_phase(phase)), d)
+                    if k >= warmup:
+                        acc[g, 1 + phase] += dt
+                if phase < 2:
+                    nb = emulate_gather(devs)
+                    if k >= warmup:
+                        xbytes[phase] += nb
+        acc /= steps
+        merged = edist.merge_band_maps([d.get_map() for d in devs])
+        st = [d.stats() for d in devs]
+        rows = devs[0].shard_rows()
+        share = acc.sum(1)
+        shares[G] = float(share.mean())
+        out[f"G{G}"] = {
+            "rank_share_ms": {"max": float(share.max()), "mean": float(share.mean()), "min": float(share.min())},
+            "stages_ms_mean": {"time_surfaces": float(acc[:, 0].mean()), "phase0_bm_lm": float(acc[:, 1].mean()),
+                               "phase1_order_pack": float(acc[:, 2].mean()), "phase2_fuse_regularise": float(acc[:, 3].mean())},
+            "stages_ms_max": {"time_surfaces": float(acc[:, 0].max()), "phase0_bm_lm": float(acc[:, 1].max()),
+                              "phase1_order_pack": float(acc[:, 2].max()), "phase2_fuse_regularise": float(acc[:, 3].max())},
+            "exchange_bytes_per_rank_per_tick": [int(x // steps) for x in xbytes],
+            "events_staged_per_rank_frac": [float(max(int(s.events_staged[c]) for s in st)) / max(len(e), 1)
+                                            for c, e in enumerate((stream.ev_left, stream.ev_right))],
+            "rows_rank0": rows, "halo_violations": int(max(int(s.halo_violations) for s in st)),
+            "map_equal_to_one_gpu": map_sha1(merged) == ref_sha,
+            "projected_speedup_compute_only": float(full.sum(1).mean() / share.max()),
+        }
+        for d in devs:
+            d.close()
+    Gs = sorted(shares)
+    if len(Gs) >= 2:   # share(G) = a + b / G through the two largest shard counts
+        g1, g2 = Gs[-2], Gs[-1]
+        bcoef = (shares[g1] - shares[g2]) / (1.0 / g1 - 1.0 / g2)
+        a = shares[g2] - bcoef / g2
+        out["replicated_ms"] = float(max(a, 0.0))
+        out["replicated_frac_of_rank_share_at_8"] = float(max(a, 0.0) / shares[8]) if 8 in shares else None
+        out["replicated_note"] = (f"share(G) = a + b / G fitted through G = {g1} and {g2} (mean over ranks): a = what every rank does whatever N is "
+                                  "(the window's propagation, the frame-order scans over all slots of the tick, launch overheads of ~25 kernels)")
+    return out

@@ -30,7 +30,7 @@ def available():
 
 
 def build():
-    subprocess.check_call(["make", "-C", _HERE, "ref", "REF=" + REFERENCE], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", _HERE, "ref", "ref_o3", "REF=" + REFERENCE], stdout=subprocess.DEVNULL)
     # the node objects with the product's binding attached link against the HIP library: only once that is built
     if os.path.exists(os.path.join(_HERE, "..", "esvo_amd", "csrc", "libesvo_hip.so")):
         subprocess.check_call(["make", "-C", _HERE, "ref_hip", "REF=" + REFERENCE], stdout=subprocess.DEVNULL)
@@ -316,23 +316,23 @@ class RefTracker:
 
 
 _LIB_TS = os.path.join(_HERE, "_ref", "libesvo_ref_ts.so")
-_lib_ts = None
+_lib_ts = {}
 
 
-def load_ts():
-    global _lib_ts
-    if _lib_ts is None:
+def load_ts(o3=False):
+    """o3: the build at the reference's own -O3 (oracle/Makefile, ref_o3): what bench.py times"""
+    if _lib_ts.get(o3) is None:
         if os.path.isdir(os.path.join(REFERENCE, "esvo_core", "src")):
             build()
-        lib = C.CDLL(_LIB_TS)
+        lib = C.CDLL(_LIB_TS.replace(".so", "_O3.so") if o3 else _LIB_TS)
         lib.ref_ts_create.restype = C.c_void_p
         lib.ref_ts_create.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int, C.c_int]
         lib.ref_ts_destroy.argtypes = [C.c_void_p]
         lib.ref_ts_push.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         lib.ref_ts_render.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
         lib.ref_ts_set_forward.argtypes = [C.c_void_p, C.c_void_p]
-        _lib_ts = lib
-    return _lib_ts
+        _lib_ts[o3] = lib
+    return _lib_ts[o3]
 
 
 class RefTS:
@@ -340,8 +340,8 @@ class RefTS:
     (BACKWARD mode).  render() returns the f64 image the node hands to cv::Mat::convertTo(CV_8U); OpenCV's rounding, median
     filter and remap are not part of the build."""
 
-    def __init__(self, width, height, decay_ms=30.0, ignore_polarity=True, queue_len=20):
-        self.lib = load_ts()
+    def __init__(self, width, height, decay_ms=30.0, ignore_polarity=True, queue_len=20, o3=False):
+        self.lib = load_ts(o3)
         self.W, self.H = width, height
         self.h = self.lib.ref_ts_create(width, height, float(decay_ms), int(bool(ignore_polarity)), int(queue_len))
 
@@ -370,16 +370,19 @@ _lib_node = {}
 _POSE_FN = C.CFUNCTYPE(C.c_int, C.c_ulonglong, C.POINTER(C.c_double))
 
 
-def load_node(mvstereo=False, hip=False):
+def load_node(mvstereo=False, hip=False, o3=False):
     """oracle/_ref/libesvo_ref_node.so: esvo_core/src/esvo_Mapping.cpp (the mapper NODE) + the mapper sources, against the
     inert ROS / tf / cv_bridge / pcl stand-ins of oracle/ref_shim_node/ (oracle/ref_harness_node.cpp);
     libesvo_ref_mvstereo.so: the same entry points around esvo_core/src/esvo_MVStereo.cpp."""
-    key = (mvstereo, hip)
+    key = (mvstereo, hip, o3)
     if _lib_node.get(key) is None:
         if os.path.isdir(os.path.join(REFERENCE, "esvo_core", "src")):
             build()
         # hip: the same objects + include/esvo_hip_mapping_node.hpp, linked with esvo_amd/csrc/libesvo_hip.so
         name = ("libesvo_ref_mvstereo" if mvstereo else "libesvo_ref_node") + ("_hip.so" if hip else ".so")
+        if o3:  # esvo_Mapping only, at the reference's own -O3 (bench.py's timed baseline)
+            assert not mvstereo and not hip
+            name = "libesvo_ref_node_O3.so"
         lib = C.CDLL(os.path.join(_HERE, "_ref", name))
         vp, u64, sz = C.c_void_p, C.c_uint64, C.c_size_t
         lib.ref_node_create.restype = vp
@@ -424,8 +427,8 @@ class RefNode:
     timeSurfaceCallback, poses through the tf stand-in (pose(t_ns) -> 4x4 T_world_cam or None); tick() = dataTransferring +
     MappingAtTime as MappingLoop calls them (esvo_Mapping.cpp:146-259) without the threads, the rate and the publishers."""
 
-    def __init__(self, params, rig, pose, extra=None, mvstereo=False, hip=False):
-        self.lib = load_node(mvstereo, hip)   # mvstereo: the esvo_MVStereo node object (BM_PLUS_ESTIMATION) instead of esvo_Mapping
+    def __init__(self, params, rig, pose, extra=None, mvstereo=False, hip=False, o3=False):
+        self.lib = load_node(mvstereo, hip, o3)   # mvstereo: the esvo_MVStereo node object (BM_PLUS_ESTIMATION) instead of esvo_Mapping
         self.rig = rig
         for k, v in (extra or {}).items():   # node parameters the POD has no field for, e.g. INIT_SGM_DP_NUM_THRESHOLD
             self.lib.ref_node_preset_param(k.encode(), str(v).encode())

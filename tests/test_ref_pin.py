@@ -715,6 +715,42 @@ def test_live_reference_node_long_run_window_churn(name, mvstereo, n_ticks, over
     assert max(sizes) > 1 and any(b <= a for a, b in zip(sizes[2:], sizes[3:]))   # the window rolled
 
 
+@pytest.mark.parametrize("name,n_ticks", [("dsec", 8), ("hkust", 8)])
+def test_reference_node_at_the_references_own_O3_maps_the_same_bits(name, n_ticks):
+    """Build container only.  bench.py times oracle/_ref/libesvo_ref_node_O3.so + libesvo_ref_ts_O3.so -- the node objects at the
+    optimisation level the reference's own CMakeLists set (-O3, nothing else; esvo_core/CMakeLists.txt:7) -- while the oracle
+    is pinned to the -O2 -ffp-contract=off builds.  The two must agree bit for bit (frames, maps, Time Surfaces), so that the
+    timed baseline is the pinned code."""
+    from oracle import ref as R
+    if not os.path.isdir(os.path.join(R.REFERENCE, "esvo_core", "src")):
+        pytest.skip("reference tree not present (GPU box): the fixtures are the pin")
+    import copy
+    sc = S.Scenario(name, n_ticks=n_ticks)
+    ticks, st = sc.inputs(), sc.stream()
+    p = copy.copy(sc.params)
+    p.regularization = 0   # (with it on the node object reads freed list elements, SURVEY A-7: not a function of the build alone)
+    nodes = [R.RefNode(p, sc.rig, st.pose, o3=o3) for o3 in (False, True)]
+    for nd in nodes:
+        nd.push_events(st.ev_left)
+    for tk in ticks:
+        out = []
+        for nd in nodes:
+            nd.push_observation(tk["t"], tk["tsL"], tk["tsR"])
+            assert nd.data_transferring()
+            nd.mapping_at_time()
+            out.append((nd.newest_frame(), nd.get_map()))
+        for a, b in zip(out[0], out[1]):
+            assert len(a) == len(b) and len(a) > 0
+            for f in NODE_MAP_FIELDS:
+                assert np.array_equal(a[f], b[f]), f
+    ts = [R.RefTS(sc.rig.width, sc.rig.height, o3=o3) for o3 in (False, True)]
+    for t_ in ts:
+        t_.push(st.ev_left)
+    for tk in ticks[:3]:
+        a, b = ts[0].render(tk["t"]), ts[1].render(tk["t"])
+        assert np.array_equal(a, b, equal_nan=True) and np.isfinite(a).any()
+
+
 def test_hip_binding_compiles_against_the_reference_node_classes():
     """Build container only: include/esvo_hip_mapping_node.hpp (the reference-side binding of INTEGRATION.md) instantiated
     with the reference's real esvo_Mapping and esvo_MVStereo classes and linked with libesvo_hip.so; the GPU side of it is
