@@ -111,6 +111,7 @@ class StatsStruct(C.Structure):
         ("clk_ref_khz", C.c_uint32), ("pad3_", C.c_uint32),
         # ABI 6: routed band mode
         ("halo_violations", C.c_uint64),
+        ("late_events", C.c_uint64 * 2),
     ]
 
     def sclk_mhz(self, base=None):

@@ -476,7 +476,7 @@ int esvo_destroy(esvo_handle h) {
                   h->d_win, h->d_frame_pose_T, h->d_fr_table, h->d_prop, h->d_tile_pts, h->d_tile_count, h->d_over_pts,
                   h->d_cell_count, h->d_cell_offset, h->d_cell_list, h->d_fuse_ctr, h->d_rec_ids, h->d_map, h->d_map2, h->d_owner_max, h->d_owner_min, h->d_exp_flags,
                   h->d_exp_prefix, h->d_export, h->d_export_cell, h->d_reg_ab, h->d_reg_cd, h->d_tsq[0], h->d_tsq[1], h->d_tsq_tcount, h->d_tsq_tlist, h->d_tsq_over, h->d_tsq_over_count, h->d_own_w, h->d_lkeep, h->d_codes, h->d_codes_send, h->d_codes_all, h->d_pts_send, h->d_pts_all, h->d_rank_kept,
-                  h->d_sel, h->d_evmap, h->d_lm_fvec0, h->d_lm_fnorm0, h->d_lm_meta, h->d_lm_order, h->d_lm_hist, h->d_clk, h->d_fuse_stats, h->d_ring_gidx, h->d_halo_viol};
+                  h->d_sel, h->d_evmap, h->d_lm_fvec0, h->d_lm_fnorm0, h->d_lm_meta, h->d_lm_order, h->d_lm_hist, h->d_clk, h->d_fuse_stats, h->d_ring_gidx, h->d_halo_viol, h->d_merge_a, h->d_merge_b, h->d_merge_plan, h->d_tsq_dup};
   for (void* p : ptrs) if (p) hipFree(p);
   if (h->h_counters) hipHostFree(h->h_counters);
   if (h->h_cnt_b) hipHostFree(h->h_cnt_b);
@@ -531,9 +531,12 @@ int esvo_reset(esvo_handle h) {
     h->ingest_pending[cam] = false;
     h->ts_valid[cam] = false;
     h->last_stamp[cam] = 0;
+    h->tsq_dup[cam].clear();
   }
   h->glob_ts.clear();
   h->kept_g.clear();
+  h->own_before.clear();
+  h->own_total = 0;
   h->glob_base = 0;
   h->halo_error = false;
   HIPCHK(hipMemsetAsync(h->d_halo_viol, 0, sizeof(u32) * 2, h->stream));

@@ -612,7 +612,7 @@ int select_events(esvo_context* h, uint64_t t_ns, u64* first_out, u32* n_out) {
 // The same selection on a routed band handle: the walk is defined on the WHOLE left stream (glob_ts: every stamp, kept on the
 // host), the rank's ring holds the events of its rows.  n / g_first: size of the global selection and the global index of its
 // newest event; loc_first / n_loc: the newest of them in this rank's ring (absolute local index) and how many the ring holds.
-int select_events_routed(esvo_context* h, uint64_t t_ns, u32* n_out, u32* g_first_out, u64* loc_first_out, u32* n_loc_out) {
+int select_events_routed(esvo_context* h, uint64_t t_ns, u32* n_out, u32* g_first_out, u64* loc_first_out, u32* n_loc_out, u32* n_own_out) {
   std::lock_guard<std::mutex> lr(h->mu_ring);
   ingest_fence(h, 0);
   const double t_end = ns_to_sec(t_ns);
@@ -638,6 +638,7 @@ int select_events_routed(esvo_context* h, uint64_t t_ns, u32* n_out, u32* g_firs
   *g_first_out = (u32)first;
   *loc_first_out = 0;
   *n_loc_out = 0;
+  *n_own_out = 0;
   if (n == 0) return ESVO_OK;
   // the kept events with a global index in [first - n + 1, first]
   const auto& kg = h->kept_g;
@@ -650,6 +651,7 @@ int select_events_routed(esvo_context* h, uint64_t t_ns, u32* n_out, u32* g_firs
     FAIL(ESVO_ERR_STATE, "selected events were already overwritten in the event ring");
   *loc_first_out = loc_first;
   *n_loc_out = n_loc;
+  *n_own_out = (u32)((hi < h->own_before.size() ? h->own_before[hi] : h->own_total) - h->own_before[lo]);
   h->sh_first_prev = h->sh_first;
   h->sh_first = loc_first;
   return ESVO_OK;
@@ -670,9 +672,9 @@ int tick_phase0(esvo_context* h, uint64_t t_ns, const uint64_t* pose_t_ns, const
   if (h->routed && h->halo_error)
     FAIL(ESVO_ERR_HALO, "a refinement of an earlier tick read outside the Time-Surface rows some rank renders (stats.halo_violations): "
                         "raise ts_halo_rows or use ESVO_ROUTE_BROADCAST");
-  u32 n = 0, n_loc = 0, g_first = 0;
+  u32 n = 0, n_loc = 0, n_own = 0, g_first = 0;
   u64 first = 0;
-  int rc = h->routed ? select_events_routed(h, t_ns, &n, &g_first, &first, &n_loc) : select_events(h, t_ns, &first, &n);
+  int rc = h->routed ? select_events_routed(h, t_ns, &n, &g_first, &first, &n_loc, &n_own) : select_events(h, t_ns, &first, &n);
   if (rc) return rc;
   // (the counter row of this tick's parity -- last used two ticks ago, collected since -- is cleared with the pose upload)
   rc = upload_poses(h, pose_t_ns, pose_T, m, h->d_counters2[h->fpar ^ 1]);
@@ -683,7 +685,7 @@ int tick_phase0(esvo_context* h, uint64_t t_ns, const uint64_t* pose_t_ns, const
   set_lm_parity(h);
   esvo_context::TickState& tk = h->tk[h->fpar];
   tk.n = n; tk.off = 0; tk.points = 0; tk.t_ns = t_ns;
-  tk.n_loc = n_loc; tk.g_first = g_first;
+  tk.n_loc = n_loc; tk.n_own = n_own; tk.g_first = g_first;
   tk.lm_stream = h->stream;
   tk.lm_pair = -1;
   tk.obs_par = h->obs_par;
@@ -763,14 +765,16 @@ int tick_phase0(esvo_context* h, uint64_t t_ns, const uint64_t* pose_t_ns, const
       }
       hipEventRecord(h->evt[EV_S1 + h->fpar * EV_FRONT_STRIDE], h->stream);
       HIPCHK(hipGetLastError());
-      rc = run_lm(h, n_loc, 1, true);
+      // (the ring also holds the raster's halo events: the launch -- and with it the kernel's layout -- is bounded by the OWN
+      //  events of the selection, counted at ingest)
+      rc = run_lm(h, n_own, 1, true);
       if (rc) return rc;
     } else {  // no event of this tick in the band: the stage events the statistics read are still recorded
       for (int e : {EV_BM0, EV_BM1, EV_S1, EV_LM0, EV_LM1}) hipEventRecord(h->evt[e + h->fpar * EV_FRONT_STRIDE], h->stream);
     }
     const size_t nb = shard_codes_block_routed(n);
     HIPCHK(hipMemsetAsync(h->d_codes_send, 0, nb, h->stream));
-    launch_shard_codes_routed(h->d_matches, h->d_lkeep, h->d_counters + 8, n_loc, n, (u32)h->dp.num_threads, h->d_own_w,
+    launch_shard_codes_routed(h->d_matches, h->d_lkeep, h->d_counters + 8, n_own, n, (u32)h->dp.num_threads, h->d_own_w,
                               reinterpret_cast<u32*>(h->d_codes_send), h->stream);
     HIPCHK(hipGetLastError());
     h->xchg_send = h->d_codes_send;
@@ -821,7 +825,7 @@ int tick_phase1_enqueue(esvo_context* h) {
     if (rc) return rc;
   } else if (n) {
     const u32 N = (u32)h->dp.ev_nshards, r = (u32)h->dp.ev_shard, T = (u32)h->dp.num_threads;
-    const u32 own = h->routed ? tk.n_loc : (n > r ? (n - r + N - 1) / N : 0);
+    const u32 own = h->routed ? tk.n_own : (n > r ? (n - r + N - 1) / N : 0);
     if (h->routed) {
       HIPCHK(hipMemsetAsync(h->d_codes, 0, n, h->stream));
       launch_shard_unpack_routed(reinterpret_cast<const u32*>(N > 1 ? h->d_codes_all : h->d_codes_send), (u32)(shard_codes_block_routed(n) / 4), N,

@@ -65,6 +65,29 @@ void queue_prepare(esvo_context* h, int cam, u64 t_ns) {
     }
     h->scattered[cam] = upto;
   }
+  if (!h->tsq_dup[cam].empty()) {  // what eventsCallback inserted in place of late events: copies of the then-newest event (push_unsorted)
+    auto& dup = h->tsq_dup[cam];
+    if (dup.size() > h->tsq_dup_cap) {
+      hipStreamSynchronize(h->stream);
+      if (h->d_tsq_dup) hipFree(h->d_tsq_dup);
+      h->tsq_dup_cap = std::max<size_t>(dup.size(), 4096);
+      if (hipMalloc(reinterpret_cast<void**>(&h->d_tsq_dup), sizeof(esvo_event_t) * h->tsq_dup_cap) != hipSuccess) { h->d_tsq_dup = nullptr; h->tsq_dup_cap = 0; }
+    }
+    if (h->d_tsq_dup) {
+      for (size_t a0 = 0; a0 < dup.size(); a0 += esvo_context::TSQ_ROUND) {
+        const size_t cnt = std::min<size_t>(dup.size() - a0, esvo_context::TSQ_ROUND);
+        hipMemcpyAsync(h->d_tsq_dup, dup.data() + a0, sizeof(esvo_event_t) * cnt, hipMemcpyHostToDevice, h->stream);
+        hipStreamSynchronize(h->stream);  // (pageable source; the rare path)
+        TsQueueArgs g{};
+        g.q = h->d_tsq[cam]; g.L = h->tsq_len;
+        g.tcount = h->d_tsq_tcount; g.tlist = h->d_tsq_tlist; g.tcap = h->tsq_tcap;
+        g.over = h->d_tsq_over; g.over_count = h->d_tsq_over_count; g.over_cap = (u32)esvo_context::TSQ_ROUND;
+        g.ev[0] = h->d_tsq_dup; g.n[0] = cnt;
+        launch_tsq_insert(g, h->W, h->H, h->stream);
+      }
+    }
+    dup.clear();
+  }
   launch_tsq_view(h->d_tsq[cam], h->tsq_len, h->W, h->H, t_ns, h->d_sae[cam], h->stream);
 }
 
@@ -222,6 +245,7 @@ int push_routed(esvo_context* h, int cam, size_t n, GetEv get) {
   }
   esvo_event_t* kept = h->h_route_ev[cam];
   std::vector<u64> kept_ts, kept_gl, all_ts;
+  std::vector<uint8_t> kept_own;
   kept_ts.reserve(n / 2 + 16);
   if (cam == 0) { kept_gl.reserve(n / 2 + 16); all_ts.resize(n); }
   size_t m = 0;
@@ -237,7 +261,7 @@ int push_routed(esvo_context* h, int cam, size_t n, GetEv get) {
     if ((int)e.x < W && (int)e.y < H) keep = cam == 0 ? keep_px[(size_t)e.y * W + e.x] != 0 : ((int)e.y >= sy0 && (int)e.y < sy1);
     if (!keep) continue;
     kept[m] = e;
-    if (cam == 0) { h->h_route_gidx[m] = (u32)(g0 + i); kept_gl.push_back(g0 + i); }
+    if (cam == 0) { h->h_route_gidx[m] = (u32)(g0 + i); kept_gl.push_back(g0 + i); kept_own.push_back((keep_px[(size_t)e.y * W + e.x] >> 1) & 1); }
     kept_ts.push_back(t);
     ++m;
   }
@@ -263,17 +287,159 @@ int push_routed(esvo_context* h, int cam, size_t n, GetEv get) {
   h->ring_next[cam] += m;
   h->ring_reserved[cam] = h->ring_next[cam];
   if (cam == 0) {
-    for (size_t i = 0; i < m; ++i) h->kept_g.push_back(kept_gl[i]);
+    for (size_t i = 0; i < m; ++i) { h->kept_g.push_back(kept_gl[i]); h->own_before.push_back(h->own_total); h->own_total += kept_own[i]; }
     for (size_t i = 0; i < n; ++i) h->glob_ts.push_back(all_ts[i]);
     while (h->glob_ts.size() > h->ring_cap) { h->glob_ts.pop_front(); h->glob_base++; }
   }
   while (tsq.size() > h->ring_cap) {
     tsq.pop_front();
     h->ring_base[cam]++;
-    if (cam == 0) h->kept_g.pop_front();
+    if (cam == 0) { h->kept_g.pop_front(); h->own_before.pop_front(); }
   }
   h->last_stamp[cam] = last;
   h->stats.events_staged[cam] += m;
+  return ESVO_OK;
+}
+
+// ---- out-of-order input ---------------------------------------------------------------------------------------------------
+// The reference sorts on arrival: both nodes insertion-sort every event into their queue (TimeSurface.cpp:412-420,
+// esvo_Mapping.cpp:692-702: `while (EQ[i].ts > e.ts)` -- strict, so equal stamps keep their arrival order: a STABLE sort).
+//   mapper side   the ring holds the events in that sorted order; a packet that reaches back into already staged events is merged
+//                 into the ring's tail on the device (ts_merge_kernel).  (esvo_Mapping::eventsCallback also RESETS the whole mapper
+//                 when a message's FIRST stamp lies before its queue's newest, :678-687: that decision stays with the caller --
+//                 stats.late_events tells it -- the library never throws a map away on its own.)
+//   Time Surface  eventsCallback then inserts events_.back() -- the NEWEST event, not the one that just arrived (:421-422, SURVEY
+//                 Appendix A-1).  For an event that is late on arrival (stamp < the newest stamp seen before it) that is a second
+//                 copy of the newest event and the late event itself never enters the per-pixel queues: the late event is marked
+//                 (EV_LATE, common.hpp) and skipped by the scatter; the second copy is a no-op for the one-stamp-per-pixel SAE and,
+//                 in queue mode, is inserted with the next batch (tsq_dup).
+// The rare path: it takes the mapper group's lock and drains the front stream before it moves anything.
+template <typename GetEv>
+int push_unsorted(esvo_context* h, int cam, size_t n, GetEv get) {
+  std::lock_guard<std::recursive_mutex> la(h->mu_api);  // (before mu_push: the order esvo_reset takes them in)
+  std::lock_guard<std::mutex> lp(h->mu_push[cam]);
+  HIPCHK(hipSetDevice(h->device));
+  if (h->routed) FAIL(ESVO_ERR_UNSUPPORTED, "out-of-order packets on a row-routed band handle: sort them first (or use ESVO_ROUTE_BROADCAST)");
+  auto stamp_of = [](const esvo_event_t& e) { return (u64)e.sec * 1000000000ull + e.nsec; };
+  std::vector<esvo_event_t> S(n);
+  std::vector<u64> t(n);
+  std::vector<u32> order(n);
+  u64 newest = 0;
+  esvo_event_t newest_ev;
+  std::memset(&newest_ev, 0, sizeof(newest_ev));
+  size_t K = 0, pos_rel = 0;
+  // nothing enqueued may still read the ring's tail (block matching of a pending tick, a scatter) while it moves
+  if (hipStreamSynchronize(h->stream) != hipSuccess || hipStreamSynchronize(h->stream_i) != hipSuccess) FAIL(ESVO_ERR_HIP, "draining the streams failed");
+  bool have_newest_ev = false;
+  {
+    u64 last_idx = 0;
+    bool any = false;
+    {
+      std::lock_guard<std::mutex> lr(h->mu_ring);
+      if (!h->ts_host[cam].empty()) { newest = h->ts_host[cam].back(); last_idx = h->ring_next[cam] - 1; any = true; }
+    }
+    if (any && h->tsq_len) {  // queue mode: the record of the newest staged event (the ring's last: sorted), whose copies stand in for late events
+      HIPCHK(hipMemcpy(&newest_ev, h->d_ring[cam] + last_idx % h->ring_cap, sizeof(esvo_event_t), hipMemcpyDeviceToHost));
+      have_newest_ev = true;
+    }
+  }
+  // late on arrival: below the running maximum of everything that arrived before (a tie is NOT late: it becomes back())
+  size_t n_late = 0;
+  std::vector<esvo_event_t> dups;
+  for (size_t i = 0; i < n; ++i) {
+    esvo_event_t e = get(i);
+    t[i] = stamp_of(e);
+    order[i] = (u32)i;
+    e.polarity = e.polarity ? 1 : 0;
+    e._pad[0] = e._pad[1] = e._pad[2] = 0;
+    if (t[i] < newest) {
+      e.polarity |= (uint8_t)EV_LATE;
+      ++n_late;
+      if (h->tsq_len && have_newest_ev) dups.push_back(newest_ev);
+    } else {
+      newest = t[i];
+      newest_ev = e;
+      have_newest_ev = true;
+    }
+    S[i] = e;
+  }
+  std::stable_sort(order.begin(), order.end(), [&](u32 a, u32 b) { return t[a] < t[b]; });
+  std::vector<esvo_event_t> P(n);
+  std::vector<u64> tp(n);
+  for (size_t j = 0; j < n; ++j) { P[j] = S[order[j]]; tp[j] = t[order[j]]; }
+  // the staged events the packet reaches back into: those with a stamp ABOVE the packet's smallest (equal ones arrived earlier: they stay in front)
+  std::vector<u64> ts_tail;
+  u64 pos_abs = 0, ring_next = 0;
+  {
+    std::lock_guard<std::mutex> lr(h->mu_ring);
+    const auto& tsq = h->ts_host[cam];
+    pos_rel = std::upper_bound(tsq.begin(), tsq.end(), tp[0]) - tsq.begin();
+    K = tsq.size() - pos_rel;
+    pos_abs = h->ring_base[cam] + pos_rel;
+    ring_next = h->ring_next[cam];
+    if (h->ring_next[cam] + n - h->scattered[cam] > h->ring_cap) FAIL(ESVO_ERR_CAPACITY, "event ring full: render (scatter) before staging more events");
+    if (K > ((size_t)1 << 22)) FAIL(ESVO_ERR_CAPACITY, "packet reaches back over more than 4 M staged events");
+    ts_tail.assign(tsq.begin() + pos_rel, tsq.end());
+    h->ring_reserved[cam] = ring_next + n;
+  }
+  auto grow = [&](auto** p, size_t& cap, size_t need, size_t elem) {
+    if (need <= cap) return true;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr; cap = 0;
+    const size_t c = std::max<size_t>(need + need / 2, 4096);
+    if (hipMalloc(reinterpret_cast<void**>(p), c * elem) != hipSuccess) { (void)hipGetLastError(); return false; }
+    cap = c;
+    return true;
+  };
+  if (!grow(&h->d_merge_a, h->merge_cap_a, K, sizeof(esvo_event_t)) || !grow(&h->d_merge_b, h->merge_cap_b, n, sizeof(esvo_event_t)) ||
+      !grow(&h->d_merge_plan, h->merge_cap_plan, K + n, sizeof(u32))) {
+    push_abort(h, cam);
+    FAIL(ESVO_ERR_CAPACITY, "out of device memory for the out-of-order merge");
+  }
+  // plan of the merged tail: staged first on equal stamps
+  std::vector<u32> plan(K + n);
+  std::vector<u64> merged(K + n);
+  size_t a = 0, b = 0, n_before_scattered = 0;
+  u64 scattered_rel = 0;
+  {
+    std::lock_guard<std::mutex> lr(h->mu_ring);
+    scattered_rel = h->scattered[cam] > pos_abs ? h->scattered[cam] - pos_abs : 0;  // staged events of the tail already in the SAE
+  }
+  for (size_t j = 0; j < K + n; ++j) {
+    if (b >= n || (a < K && ts_tail[a] <= tp[b])) { plan[j] = (u32)a; merged[j] = ts_tail[a]; ++a; }
+    else {
+      plan[j] = 0x80000000u | (u32)b; merged[j] = tp[b];
+      if (a < scattered_rel) ++n_before_scattered;  // lands among events that are scattered already: it is late (never scattered)
+      ++b;
+    }
+  }
+  hipError_t e = hipSuccess;
+  const u64 slot0 = pos_abs % h->ring_cap;
+  if (K) {  // a copy of the tail (it may wrap)
+    const size_t first = (size_t)std::min<u64>(K, h->ring_cap - slot0);
+    e = hipMemcpyAsync(h->d_merge_a, h->d_ring[cam] + slot0, sizeof(esvo_event_t) * first, hipMemcpyDeviceToDevice, h->stream_i);
+    if (e == hipSuccess && first < K)
+      e = hipMemcpyAsync(h->d_merge_a + first, h->d_ring[cam], sizeof(esvo_event_t) * (K - first), hipMemcpyDeviceToDevice, h->stream_i);
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(h->d_merge_b, P.data(), sizeof(esvo_event_t) * n, hipMemcpyHostToDevice, h->stream_i);
+  if (e == hipSuccess) e = hipMemcpyAsync(h->d_merge_plan, plan.data(), sizeof(u32) * (K + n), hipMemcpyHostToDevice, h->stream_i);
+  if (e == hipSuccess) {
+    launch_ts_merge(h->d_merge_a, h->d_merge_b, h->d_merge_plan, K + n, h->d_ring[cam], slot0, h->ring_cap, h->stream_i);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream_i);
+  if (e != hipSuccess) { push_abort(h, cam); FAIL(ESVO_ERR_HIP, std::string("out-of-order merge failed: ") + hipGetErrorString(e)); }
+  std::lock_guard<std::mutex> lr(h->mu_ring);
+  auto& tsq = h->ts_host[cam];
+  tsq.erase(tsq.begin() + pos_rel, tsq.end());
+  for (u64 v : merged) tsq.push_back(v);
+  h->ring_next[cam] += n;
+  h->ring_reserved[cam] = h->ring_next[cam];
+  if (h->scattered[cam] > pos_abs) h->scattered[cam] += n_before_scattered;
+  while (tsq.size() > h->ring_cap) { tsq.pop_front(); h->ring_base[cam]++; }
+  h->stats.events_staged[cam] += n;
+  h->stats.late_events[cam] += n_late;
+  for (const esvo_event_t& d : dups) h->tsq_dup[cam].push_back(d);
   return ESVO_OK;
 }
 
@@ -314,15 +480,24 @@ static int push_events_impl(esvo_handle h, int cam, const esvo_event_t* ev, size
   if (!h || cam < 0 || cam > 1 || (n && !ev)) return ESVO_ERR_INVALID_ARG;
   if (n == 0) return ESVO_OK;
   if (n > h->ring_cap) FAIL(ESVO_ERR_CAPACITY, "event block larger than the event ring");
+  auto stamp = [&](size_t i) { return (u64)ev[i].sec * 1000000000ull + ev[i].nsec; };
+  {  // sorted, and not older than what is staged: the fast path; anything else is sorted in as the reference's callbacks do
+    bool in_order = true;
+    u64 last = stamp(0);
+    for (size_t i = 1; i < n && in_order; ++i) {
+      const u64 t = stamp(i);
+      in_order = t >= last;
+      last = t;
+    }
+    if (in_order) {
+      std::lock_guard<std::mutex> lr(h->mu_ring);
+      const u64 newest = h->routed ? h->last_stamp[cam] : (h->ts_host[cam].empty() ? 0 : h->ts_host[cam].back());
+      in_order = stamp(0) >= newest;
+    }
+    if (!in_order) return push_unsorted(h, cam, n, [&](size_t i) { return ev[i]; });
+  }
   std::lock_guard<std::mutex> lp(h->mu_push[cam]);
   HIPCHK(hipSetDevice(h->device));
-  auto stamp = [&](size_t i) { return (u64)ev[i].sec * 1000000000ull + ev[i].nsec; };
-  u64 last = stamp(0);
-  for (size_t i = 1; i < n; ++i) {
-    const u64 t = stamp(i);
-    if (t < last) FAIL(ESVO_ERR_INVALID_ARG, "events must be sorted by time stamp (SURVEY Appendix A-1)");
-    last = t;
-  }
   if (h->routed) return push_routed(h, cam, n, [&](size_t i) { return ev[i]; });
   PushTicket tk;
   { int rc = push_begin(h, cam, n, stamp(0), tk); if (rc) return rc; }
@@ -360,8 +535,6 @@ int esvo_ts_push_event_array(esvo_handle h, int cam, const uint8_t* msg, size_t 
   if ((height && (int)height != h->H) || (width && (int)width != h->W)) FAIL(ESVO_ERR_INVALID_ARG, "EventArray sensor size differs from the handle's");
   if (n == 0) return ESVO_OK;
   if (n > h->ring_cap) FAIL(ESVO_ERR_CAPACITY, "event block larger than the event ring");
-  std::lock_guard<std::mutex> lp(h->mu_push[cam]);
-  HIPCHK(hipSetDevice(h->device));
   const uint8_t* rec = msg + off;
   auto stamp = [&](size_t i) {
     const uint8_t* r = rec + i * 13 + 4;
@@ -369,24 +542,35 @@ int esvo_ts_push_event_array(esvo_handle h, int cam, const uint8_t* msg, size_t 
     const u32 nsec = (u32)r[4] | ((u32)r[5] << 8) | ((u32)r[6] << 16) | ((u32)r[7] << 24);
     return (u64)sec * 1000000000ull + nsec;
   };
-  u64 last = stamp(0);
-  for (size_t i = 1; i < n; ++i) {
-    const u64 t = stamp(i);
-    if (t < last) FAIL(ESVO_ERR_INVALID_ARG, "events must be sorted by time stamp (SURVEY Appendix A-1)");
-    last = t;
+  auto widen = [&](size_t i) {  // a 13-byte record as esvo_event_t, on the host (the paths that filter or sort there)
+    const uint8_t* r = rec + i * 13;
+    esvo_event_t e;
+    std::memset(&e, 0, sizeof(e));
+    e.x = (uint16_t)(r[0] | (r[1] << 8));
+    e.y = (uint16_t)(r[2] | (r[3] << 8));
+    e.sec = (u32)r[4] | ((u32)r[5] << 8) | ((u32)r[6] << 16) | ((u32)r[7] << 24);
+    e.nsec = (u32)r[8] | ((u32)r[9] << 8) | ((u32)r[10] << 16) | ((u32)r[11] << 24);
+    e.polarity = r[12];
+    return e;
+  };
+  {  // in order (as esvo_ts_push_events): the fast path; else sorted in on the host
+    bool in_order = true;
+    u64 last = stamp(0);
+    for (size_t i = 1; i < n && in_order; ++i) {
+      const u64 t = stamp(i);
+      in_order = t >= last;
+      last = t;
+    }
+    if (in_order) {
+      std::lock_guard<std::mutex> lr(h->mu_ring);
+      const u64 newest = h->routed ? h->last_stamp[cam] : (h->ts_host[cam].empty() ? 0 : h->ts_host[cam].back());
+      in_order = stamp(0) >= newest;
+    }
+    if (!in_order) return push_unsorted(h, cam, n, widen);
   }
-  if (h->routed)  // the records are widened on the host, where they are filtered
-    return push_routed(h, cam, n, [&](size_t i) {
-      const uint8_t* r = rec + i * 13;
-      esvo_event_t e;
-      std::memset(&e, 0, sizeof(e));
-      e.x = (uint16_t)(r[0] | (r[1] << 8));
-      e.y = (uint16_t)(r[2] | (r[3] << 8));
-      e.sec = (u32)r[4] | ((u32)r[5] << 8) | ((u32)r[6] << 16) | ((u32)r[7] << 24);
-      e.nsec = (u32)r[8] | ((u32)r[9] << 8) | ((u32)r[10] << 16) | ((u32)r[11] << 24);
-      e.polarity = r[12];
-      return e;
-    });
+  std::lock_guard<std::mutex> lp(h->mu_push[cam]);
+  HIPCHK(hipSetDevice(h->device));
+  if (h->routed) return push_routed(h, cam, n, widen);
   if ((size_t)n * 13 > h->wire_cap[cam]) {  // this camera's staging buffer: its pusher is the only user (mu_push)
     if (h->d_wire[cam]) { hipFree(h->d_wire[cam]); h->d_wire[cam] = nullptr; }
     h->wire_cap[cam] = std::max<size_t>((size_t)n * 13, (size_t)1 << 20);

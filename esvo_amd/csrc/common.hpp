@@ -166,7 +166,15 @@ void launch_scan_compact_points_small(const u32* flags, u32* prefix, u32* d_tota
 // upload of a small pinned host buffer by a kernel (never blocks the host; scan.hip)
 void launch_upload_words(const void* pinned_src, void* d_dst, size_t bytes, hipStream_t s, u32* d_zero = nullptr, u32 n_zero = 0);
 
+// An event that arrived OUT OF ORDER (its stamp below the newest stamp staged before it) keeps its sorted place in the ring -- the
+// mapper's queue is insertion-sorted, esvo_Mapping.cpp:692-702 -- but never reaches the Time Surface: TimeSurface::eventsCallback
+// inserts events_.back(), the newest event, in its stead (TimeSurface.cpp:412-422).  The library marks such
+// an event in its own copy: polarity byte 0x80 | polarity (a caller's byte is 0 or 1).
+constexpr unsigned EV_LATE = 0x80u;
+__host__ __device__ inline bool ev_is_late(unsigned w) { return (w & 0xfeu) == EV_LATE; }
 // kernels_ts.hip
+void launch_ts_merge(const esvo_event_t* staged, const esvo_event_t* packet, const u32* plan, size_t n, esvo_event_t* ring, u64 first_slot,
+                     u64 ring_cap, hipStream_t s);
 void launch_ts_unpack_wire(const uint8_t* wire, size_t n, esvo_event_t* ring, u64 first_slot, u64 ring_cap, hipStream_t s);
 void launch_ts_scatter(const esvo_event_t* d_ev, size_t n, u64* d_sae, int W, int H, hipStream_t s);
 // (row0, row1: the rectified rows to render -- whole tiles of TS_TILE_ROWS; a routed band handle renders its band + halo only)

@@ -253,11 +253,22 @@ struct esvo_context {
   std::deque<u64> glob_ts;               // stamps of ALL left events [glob_base, glob_base + size)
   u64 glob_base = 0;
   std::deque<u64> kept_g;                // global index of each kept left event, aligned with ts_host[0]
+  std::deque<u64> own_before;            // how many OWN events (floor(y_rect) in the band) were kept before this one: the count of a
+  u64 own_total = 0;                     //   selection's own events bounds its LM launch (the ring also holds the raster's halo events)
   u64 last_stamp[2] = {0, 0};            // newest stamp seen per camera (kept or not): the order check of the push calls
   u32* d_ring_gidx = nullptr;            // [ring_cap] low 32 bits of the global index of the left ring's events
   esvo_event_t* h_route_ev[2] = {nullptr, nullptr};  // pinned staging of the kept events of one push, per camera
   u32* h_route_gidx = nullptr;
   size_t route_cap[2] = {0, 0};
+  // out-of-order packets (api_ts.hip, push_unsorted): scratch of the ring merge; queue mode: the copies of the then-newest event
+  // that take a late event's place in the per-pixel queues, inserted with the next batch
+  esvo_event_t* d_merge_a = nullptr;
+  esvo_event_t* d_merge_b = nullptr;
+  u32* d_merge_plan = nullptr;
+  size_t merge_cap_a = 0, merge_cap_b = 0, merge_cap_plan = 0;
+  std::vector<esvo_event_t> tsq_dup[2];
+  esvo_event_t* d_tsq_dup = nullptr;
+  size_t tsq_dup_cap = 0;
   u32* d_halo_viol = nullptr;            // [2] matches whose refinement read outside oband, all ranks, summed over the ticks | scratch
   bool halo_error = false;               // sticky (esvo_reset clears it): ticks are refused with ESVO_ERR_HALO
   // A tick's state between its phases.  Unsharded ticks are finished lazily: esvo_map_tick(k) enqueues the front
@@ -266,6 +277,7 @@ struct esvo_context {
   struct TickState {
     u32 n = 0, off = 0, points = 0, n_pose = 0;
     u32 n_loc = 0;                    // routed band mode: events of the selection in this rank's ring (n stays the global count)
+    u32 n_own = 0;                    //   ... of which the rank owns (block-matches and refines) this many
     u32 g_first = 0;                  //   global index (low 32 bits) of the selection's newest event
     u32 max_kept = 0;                 // sharded: largest kept count among the ranks (block length of exchange 2)
     int pose_buf = 0;

@@ -26,6 +26,7 @@ __device__ inline void ts_scatter_range(const uint4* __restrict__ ev, size_t n, 
     const uint4 e = ev[i];  // {x | y<<16, sec, nsec, polarity | pad}
     const u32 x = e.x & 0xffffu, y = e.x >> 16;
     if (x >= (u32)W || y >= (u32)H) continue;  // EventQueueMat::insideImage
+    if (ev_is_late(e.w)) continue;  // arrived out of order: the reference's eventsCallback does not insert it (common.hpp, EV_LATE)
     const u64 t_ns = (u64)e.y * 1000000000ull + (u64)e.z;
     const u64 key = (t_ns << 1) | (u64)((e.w & 0xffu) ? 1u : 0u);
     atomicMax(&sae[(size_t)y * W + x], key);
@@ -57,6 +58,23 @@ void launch_ts_scatter_segs(const TsScatterSegs& g, int n_seg, int W, int H, hip
   hipLaunchKernelGGL(ts_scatter_segs_kernel, dim3((u32)blocks, (u32)n_seg), dim3(256), 0, s, g, W, H);
 }
 
+// ---- out-of-order packets (api_ts.hip, push_unsorted): the staged tail of the ring merged with a late packet -----------------
+// plan[j]: source of merged position j -- bit 31 clear: staged[idx] (a copy of the ring's tail), set: packet[idx]
+__global__ void __launch_bounds__(256) ts_merge_kernel(const uint4* __restrict__ staged, const uint4* __restrict__ packet,
+                                                       const u32* __restrict__ plan, size_t n, uint4* __restrict__ ring, u64 first_slot,
+                                                       u64 ring_cap) {
+  const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const u32 src = plan[j];
+  ring[(first_slot + j) % ring_cap] = (src & 0x80000000u) ? packet[src & 0x7fffffffu] : staged[src];
+}
+void launch_ts_merge(const esvo_event_t* staged, const esvo_event_t* packet, const u32* plan, size_t n, esvo_event_t* ring, u64 first_slot,
+                     u64 ring_cap, hipStream_t s) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(ts_merge_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const uint4*>(staged),
+                     reinterpret_cast<const uint4*>(packet), plan, n, reinterpret_cast<uint4*>(ring), first_slot, ring_cap);
+}
+
 // ---- per-pixel event queues (max_event_queue_len > 0) --------------------------------------------------------------------
 // EventQueueMat (TimeSurface.h:28-97): every received event is appended to its pixel's deque, the deque is trimmed to the
 // newest L, and a render at T walks it back to the first event with ts < T.  Events arrive sorted by time (the ingest calls
@@ -81,6 +99,7 @@ __global__ void __launch_bounds__(256) tsq_bin_kernel(TsQueueArgs a, int W, int 
       const uint4 e = ev[i];
       const u32 x = e.x & 0xffffu, y = e.x >> 16;
       if (x >= (u32)W || y >= (u32)H) continue;  // EventQueueMat::insideImage
+      if (ev_is_late(e.w)) continue;  // (its place in the queues is taken by a copy of the then-newest event: api_ts.hip, push_unsorted)
       const u64 t_ns = (u64)e.y * 1000000000ull + (u64)e.z;
       const u64 key = (t_ns << 1) | (u64)((e.w & 0xffu) ? 1u : 0u);
       if (key <= 1ull) continue;  // a zero stamp never renders (TimeSurface.cpp:73) and would read as an empty slot

@@ -225,6 +225,9 @@ typedef struct esvo_stats_t {
    * esvo_reset, whose refinement read rows of the Time Surfaces this rank does not render.  Non-zero: the handle refuses
    * further ticks with ESVO_ERR_HALO. */
   uint64_t halo_violations;
+  /* Events that arrived out of order (stamp below the newest stamp staged before them), per camera: sorted into the ring for
+   * the mapper, withheld from the Time Surface as the reference's eventsCallback withholds them (esvo_ts_push_events). */
+  uint64_t late_events[2];
 } esvo_stats_t;
 
 /* ---- lifecycle -------------------------------------------------------------------- */

@@ -140,6 +140,8 @@ void gaussian5_u8(const uint8_t* src, uint8_t* dst, int w, int h) {
 struct orc_ts {
   int W, H, qlen;
   std::vector<std::deque<esvo_event_t>> q;  // EventQueueMat::eqMat_, TimeSurface.h:95
+  bool have_newest = false;
+  esvo_event_t newest;                      // events_.back(): the event with the largest stamp so far (the later arrival on a tie)
 };
 
 extern "C" orc_ts_handle orc_ts_create(int width, int height, int queue_len) {
@@ -149,14 +151,19 @@ extern "C" orc_ts_handle orc_ts_create(int width, int height, int queue_len) {
   return t;
 }
 extern "C" void orc_ts_destroy(orc_ts_handle h) { delete h; }
-extern "C" void orc_ts_clear(orc_ts_handle h) { h->q.assign((size_t)h->W * h->H, {}); }
+extern "C" void orc_ts_clear(orc_ts_handle h) { h->q.assign((size_t)h->W * h->H, {}); h->have_newest = false; }
 
 extern "C" void orc_ts_push(orc_ts_handle h, const esvo_event_t* ev, size_t n) {
-  // TimeSurface::eventsCallback (TimeSurface.cpp:403-425) for time-sorted input (Appendix A-1:
-  // the global insertion sort is the identity then) + EventQueueMat::insertEvent
-  // (TimeSurface.h:39-50): bounds check, push_back, trim the per-pixel queue to qlen.
+  // TimeSurface::eventsCallback (TimeSurface.cpp:403-425), literally: the arriving event is insertion-sorted into events_
+  // (`while (events_[i].ts > e.ts)`: behind every event with a stamp <= its own) and then events_.BACK() -- not the arriving
+  // event -- goes into EventQueueMat::insertEvent (TimeSurface.h:39-50: bounds check, push_back, trim the per-pixel queue to
+  // qlen).  events_.back() is the event with the largest stamp so far, the later arrival on a tie; only it is kept here.  For
+  // time-sorted input that is the arriving event; an event that arrives LATE is never inserted, the newest one is inserted again
+  // (Appendix A-1).
+  auto ns = [](const esvo_event_t& e) { return (unsigned long long)e.sec * 1000000000ull + e.nsec; };
   for (size_t i = 0; i < n; ++i) {
-    const esvo_event_t& e = ev[i];
+    if (!h->have_newest || ns(ev[i]) >= ns(h->newest)) { h->newest = ev[i]; h->have_newest = true; }
+    const esvo_event_t& e = h->newest;
     if (e.x >= h->W || e.y >= h->H) continue;
     auto& eq = h->q[(size_t)e.x + (size_t)h->W * e.y];
     eq.push_back(e);

@@ -245,6 +245,58 @@ def make_ts():
     print("ts", os.path.getsize(path) // 1024, "KiB")
 
 
+def jitter_arrival(ev, ns, seed=5, bundle_ns=250_000, jitter_ns=200_000):
+    """Arrival order of a stream whose 250 us bundles are each delivered up to +-200 us off their time: bundles overtake each other
+    (a late bundle's first event lies before stamps already delivered) -- what a driver that assembles packets from several USB
+    transfers does.  Returns the permutation (stable inside a bundle)."""
+    rng = np.random.default_rng(seed)
+    bundle = (ns - ns[0]) // bundle_ns
+    off = rng.integers(-jitter_ns, jitter_ns + 1, int(bundle.max()) + 1)
+    key = ns.astype(np.int64) - (ns.astype(np.int64) - ns[0].astype(np.int64)) % bundle_ns + off[bundle]   # the bundle's delivery time
+    return np.argsort(key, kind="stable")
+
+
+def ts_jitter_cases():
+    """(arrival-ordered left events, [(first, last) of each 1 ms delivery], render stamps) of the jitter fixture"""
+    rig, st = ts_inputs()
+    perm = jitter_arrival(st.ev_left, st.ns_left)
+    ev = st.ev_left[perm]
+    n = len(ev)
+    cuts = list(range(0, n, max(n // 96, 1))) + [n]
+    chunks = [(a, b) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
+    renders = [st.t0_ns + k * 12_000_000 for k in range(2, 9)]
+    return rig, st, ev, chunks, renders
+
+
+def make_ts_jitter():
+    """TimeSurface::eventsCallback on OUT-OF-ORDER deliveries (TimeSurface.cpp:403-425: insertion sort into events_, then
+    insertEvent(events_.back()) -- SURVEY Appendix A-1): the reference's own class is fed the jittered stream delivery by
+    delivery; before each delivery whose first stamp reaches a render stamp, the surface is rendered at that stamp (so render
+    times never decrease).  Stored: the rounded images (queue length 20, the node's default, and 3) and their f64 sums."""
+    rig, st, ev, chunks, renders = ts_jitter_cases()
+    from esvo_amd.abi import event_ns
+    ns = event_ns(ev)
+    out = {"n_late": 0}
+    run_max = np.maximum.accumulate(ns)
+    out["n_late"] = int((ns[1:] < run_max[:-1]).sum())
+    for ql in (20, 3):
+        ts = R.RefTS(rig.width, rig.height, 30.0, True, ql)
+        ri = 0
+        for a, b in chunks:
+            ts.push(ev[a:b])
+            done_max = int(run_max[b - 1])
+            while ri < len(renders) and done_max >= renders[ri] + 2_000_000:   # everything before the stamp (+ jitter margin) has arrived
+                img = ts.render(renders[ri])
+                out[f"q{ql}_r{ri}"] = np.clip(np.rint(img), 0, 255).astype(np.uint8)
+                out[f"q{ql}_r{ri}_sum"] = float(img.sum())
+                out[f"q{ql}_r{ri}_after"] = b          # the render happens after this many events have been delivered
+                ri += 1
+        out[f"q{ql}_renders"] = ri
+    path = os.path.join(HERE, "ref_ts_jitter.npz")
+    np.savez_compressed(path, **out)
+    print("ts jitter", os.path.getsize(path) // 1024, "KiB", "late events", out["n_late"], "of", len(ev), "renders", out["q20_renders"])
+
+
 def make_bm_step():
     """EventBM with BM_step = 2 and 3 (EventBM.cpp:113-138,169-225: coarse pass on the stride grid, the rule that both
     stride neighbours of the coarse minimum must have been evaluated on a valid patch, fine pass around it with the minimum
@@ -571,6 +623,7 @@ if __name__ == "__main__":
     make_track()
     make_sgm()
     make_ts()
+    make_ts_jitter()
     make_ts_forward()
     make_bm_step()
     make_l2()

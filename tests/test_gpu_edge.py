@@ -43,8 +43,11 @@ def test_empty_and_tiny_inputs(upenn_rig, upenn_stream):
     assert len(dev.get_last_frame()) == 0 and len(dev.get_pointcloud()) == 0
     assert len(dev.refine(np.zeros(0, dtype=[("x_left", "<f8", (2,)), ("inv_depth", "<f8"), ("cost", "<f8"), ("disp", "<f8"),
                                              ("event_idx", "<u4"), ("pose_idx", "<u4")]))) == 0
-    with pytest.raises(lib.EsvoError, match="sorted"):
-        dev.ts_push_events(0, upenn_stream.ev_left[:100][::-1])  # unsorted block is rejected (Appendix A-1)
+    # an unsorted block is sorted in, as the reference's eventsCallback does (Appendix A-1; tests/test_gpu_parity.py covers the
+    # semantics): 99 of its 100 events arrive behind a newer one
+    dev.ts_push_events(0, upenn_stream.ev_left[:100][::-1])
+    late = int(dev.stats().late_events[0])
+    assert 90 <= late <= 99 and int(dev.stats().events_staged[0]) == 100
 
 
 def test_ring_wraparound_reset_and_window_eviction(upenn_rig, upenn_stream):
@@ -251,8 +254,7 @@ def test_wire_ingest_equals_struct_ingest(upenn_rig, upenn_stream):
     _same_map(a.get_map(), b.get_map())
     assert b.stats().events_staged[0] == a.stats().events_staged[0] > 20000      # the ring wrapped
     good = abi.serialize_event_array(upenn_stream.ev_left[:10], upenn_rig.width, upenn_rig.height)
-    for bad, what in ((good[:-5], "length"), (good[:10], "shorter"), (abi.serialize_event_array(upenn_stream.ev_left[:10], 100, 100), "sensor size"),
-                      (abi.serialize_event_array(upenn_stream.ev_left[:10][::-1], upenn_rig.width, upenn_rig.height), "sorted")):
+    for bad, what in ((good[:-5], "length"), (good[:10], "shorter"), (abi.serialize_event_array(upenn_stream.ev_left[:10], 100, 100), "sensor size")):
         with pytest.raises(lib.EsvoError, match=what):
             lib.Esvo(p, upenn_rig).ts_push_event_array(0, bad)
 

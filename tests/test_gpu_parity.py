@@ -464,3 +464,78 @@ def test_time_surface_event_queues_equal_the_reference_source(tile_cap):
             n += 1
     dev.close()
     assert n == 48
+
+
+@pytest.mark.parametrize("ql", [0, 20, 3])
+def test_out_of_order_deliveries_equal_the_reference_source(ql):
+    """esvo_ts_push_events with packets that arrive out of order (tests/golden/ref_ts_jitter.npz: 250 us bundles delivered up to
+    +-200 us off their time, recorded from the reference's TimeSurface class).  The device keeps the mapper's view sorted
+    (a late packet is merged into the ring's staged tail) and withholds late events from the Time Surface exactly as
+    eventsCallback does (it inserts events_.back() instead: a no-op for the SAE, a second copy of the newest event in queue
+    mode).  ql = 0: the default one-stamp-per-pixel SAE (renders are in time order here, so it equals the queues of 20)."""
+    from test_ref_pin import GOLDEN, _jitter_cases, jitter_replay
+    g = np.load(os.path.join(GOLDEN, "ref_ts_jitter.npz"))
+    rig_, st, ev, chunks, renders = _jitter_cases()
+    rig = calib.ideal_rig(rig_.width, rig_.height, 200.0, 0.1)    # identity remap: the raster itself is compared
+    p, _ = params.make_params(params.PRESETS["mvstereo_upenn"], rig, median_blur_kernel_size=0, max_event_queue_len=ql)
+    dev = _dev(p, rig)
+    key = ql if ql else 20
+    # ql = 0: the SAE keeps no queue, i.e. behaves like a queue that never overflows -- the oracle's literal eventsCallback with an
+    # unbounded queue (pinned to the reference's class by tests/test_ref_pin.py) is its expected value; the 20-deep fixture differs
+    # from that in the documented corner case only (include/esvo_hip.h, esvo_ts_render (b): a pixel that holds more than 20
+    # events newer than the render stamp reads empty in the reference), one pixel here
+    ots = _oracle().OracleTS(rig.width, rig.height, queue_len=1 << 20) if ql == 0 else None
+    n = n_corner = 0
+
+    def push(e):
+        dev.ts_push_events(0, e)
+        if ots is not None:
+            ots.push(e)
+    for ri, img in jitter_replay(push, lambda t: dev.ts_render(0, t), g, key, ev, chunks, renders):
+        want = g[f"q{key}_r{ri}"]
+        if ots is not None:
+            n_corner += int(np.count_nonzero(want != ots.render(renders[ri], decay_ms=30.0, ignore_polarity=True, median_k=0, want_prefilter=True)[1]))
+            want = ots.render(renders[ri], decay_ms=30.0, ignore_polarity=True, median_k=0, want_prefilter=True)[1]
+        assert np.array_equal(img, want), (ql, ri, int(np.count_nonzero(img != want)))
+        n += 1
+    assert n == 7 and n_corner <= 7
+    assert int(dev.stats().late_events[0]) == int(g["n_late"])
+    dev.close()
+
+
+def test_out_of_order_deliveries_leave_the_mapper_the_sorted_stream(upenn_rig, upenn_stream):
+    """The mapper's side of the same path: the ring of a handle that was handed the left events out of order (bundles overtaking
+    each other, a packet reaching back over several earlier ones, the wire format too) holds them in stamp order -- the order
+    the reference's insertion sort produces (esvo_Mapping.cpp:692-702) -- so event selection, block matching and everything behind
+    them equal a handle fed the sorted stream.  (Time Surfaces are handed in: the two handles' own surfaces differ by the
+    late events, as they do in the reference.)"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from make_ref_fixtures import jitter_arrival
+    from esvo_amd.abi import serialize_event_array
+    rig, st = upenn_rig, upenn_stream
+    p, _ = params.make_params(params.PRESETS["mvstereo_upenn"], rig)
+    perm = jitter_arrival(st.ev_left, st.ns_left, seed=9)
+    ev = st.ev_left[perm]
+    a, b = _dev(p, rig), _dev(p, rig)
+    a.ts_push_events(0, st.ev_left)
+    cuts = list(range(0, len(ev), 997)) + [len(ev)]
+    for k, (lo, hi) in enumerate(zip(cuts[:-1], cuts[1:])):
+        if k % 3 == 2:
+            b.ts_push_event_array(0, serialize_event_array(ev[lo:hi], rig.width, rig.height))
+        else:
+            b.ts_push_events(0, ev[lo:hi])
+    assert int(b.stats().late_events[0]) > 0 and int(a.stats().late_events[0]) == 0
+    a.ts_push_events(1, st.ev_right)
+    for k in range(4):
+        t = st.t0_ns + int((0.07 + 0.01 * k) * 1e9)
+        stamps, poses = rostime.pose_table(st.pose, t, p.bm_half_slice_thickness)
+        tl, tr = a.ts_render(0, t), a.ts_render(1, t)
+        for d in (a, b):
+            d.set_observation(t, tl, tr, st.pose(t))   # the same image pair on both handles
+            d.tick(t, stamps, poses)
+        fa, fb = a.get_last_frame(), b.get_last_frame()
+        assert len(fa) == len(fb) and len(fa) > 0
+        assert fa.tobytes() == fb.tobytes(), k
+        assert a.get_map().tobytes() == b.get_map().tobytes(), k
+    a.close(); b.close()

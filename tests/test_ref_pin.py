@@ -487,6 +487,61 @@ def test_live_reference_time_surface_reproduces_fixture():
             assert float(img.sum()) == float(g[f"q{ql}_k{k}_b1_sum"])
 
 
+def _jitter_cases():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_ref_fixtures", os.path.join(GOLDEN, "make_ref_fixtures.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    return mk.ts_jitter_cases()
+
+
+def jitter_replay(push, render, g, ql, ev, chunks, renders):
+    """deliveries and renders in the fixture's order; yields (render index, image)"""
+    ri = 0
+    n_r = int(g[f"q{ql}_renders"])
+    for a, b in chunks:
+        push(ev[a:b])
+        while ri < n_r and int(g[f"q{ql}_r{ri}_after"]) == b:
+            yield ri, render(renders[ri])
+            ri += 1
+    assert ri == n_r
+
+
+@pytest.mark.parametrize("ql", [20, 3])
+def test_out_of_order_deliveries_equal_the_reference_time_surface_class(ql):
+    """tests/golden/ref_ts_jitter.npz: the reference's TimeSurface class fed a stream whose 250 us bundles arrive up to +-200 us
+    off their time (8 % of the events arrive late).  eventsCallback insertion-sorts the arriving event and then inserts
+    events_.back() -- the NEWEST event -- into the per-pixel queues (TimeSurface.cpp:412-422, SURVEY A-1): a late event never
+    reaches the surface, the newest one is queued again.  The oracle restates that literally."""
+    g = np.load(os.path.join(GOLDEN, "ref_ts_jitter.npz"))
+    rig, st, ev, chunks, renders = _jitter_cases()
+    assert int(g["n_late"]) > 0.05 * len(ev)
+    ts = O.OracleTS(rig.width, rig.height, queue_len=ql)
+    n = 0
+    for ri, pre in jitter_replay(ts.push, lambda t: ts.render(t, decay_ms=30.0, ignore_polarity=True, median_k=0, want_prefilter=True)[1],
+                                 g, ql, ev, chunks, renders):
+        assert np.array_equal(pre, g[f"q{ql}_r{ri}"]), (ql, ri, int(np.count_nonzero(pre != g[f"q{ql}_r{ri}"])))
+        n += 1
+    assert n == 7
+    # ... and it matters: the same events delivered in time order give another surface
+    ts2 = O.OracleTS(rig.width, rig.height, queue_len=ql)
+    ts2.push(st.ev_left)
+    _, pre2 = ts2.render(renders[-1], decay_ms=30.0, ignore_polarity=True, median_k=0, want_prefilter=True)
+    assert not np.array_equal(pre2, g[f"q{ql}_r6"])
+
+
+def test_live_reference_time_surface_reproduces_the_jitter_fixture():
+    from oracle import ref as R
+    if not os.path.isdir(os.path.join(R.REFERENCE, "esvo_core", "src")):
+        pytest.skip("reference tree not present (GPU box): the fixtures are the pin")
+    g = np.load(os.path.join(GOLDEN, "ref_ts_jitter.npz"))
+    rig, st, ev, chunks, renders = _jitter_cases()
+    ts = R.RefTS(rig.width, rig.height, 30.0, True, 20)
+    for ri, img in jitter_replay(ts.push, ts.render, g, 20, ev, chunks, renders):
+        assert np.array_equal(np.clip(np.rint(img), 0, 255).astype(np.uint8), g[f"q20_r{ri}"])
+        assert float(img.sum()) == float(g[f"q20_r{ri}_sum"])
+
+
 # ---- the mapper NODE (esvo_core/src/esvo_Mapping.cpp compiled unmodified: oracle/ref_harness_node.cpp) ----
 NODE_NAMES = ["dsec", "hkust"]   # the scenarios whose preset is the Mapping node's
 NODE_MAP_FIELDS = ("row", "col", "age", "inv_depth", "scale2", "nu", "variance", "residual", "x")
