@@ -67,12 +67,14 @@ def sustained_point(name, n_ticks, device, prof, events_cap=0, base_ticks=40, ho
         t, stamps, poses, T = ticks[k]
         dev.tick_resident(t, T, stamps, poses)
         if hook is not None:   # tools/regime_probe.py: a disturbance in the middle of the run
-            hook(k - n_warm)
+            hook(k - n_warm, dev)
         if (k - n_warm) % 100 == 99:   # host time stamps without a synchronisation: the lazy tick paces the host to the device
             marks.append(time.perf_counter())
     dev.synchronize()
     dt = time.perf_counter() - t0
     s = dev.stats()
+    if hook is not None and hasattr(hook, "at_end"):
+        hook.at_end(dev)
     dev.close()
     ev = int(s.total_events_in - b.total_events_in)
     sclk, per_xcd = s.sclk_mhz(b)
@@ -81,6 +83,7 @@ def sustained_point(name, n_ticks, device, prof, events_cap=0, base_ticks=40, ho
     res = {"windows_ms": [round(float(w), 4) for w in win], "events_per_s": ev / dt, "ms_per_tick": dt / n_ticks * 1e3, "ticks": n_ticks, "wall_s": dt,
            "events_per_tick": ev // n_ticks, "depth_points_per_s": int(s.total_points - b.total_points) / dt,
            "matches_per_tick": int(s.total_matches - b.total_matches) // n_ticks,
+           "pipeline_resyncs": int(s.pipeline_resyncs - b.pipeline_resyncs),
            "sclk_mhz": sclk, "sclk_mhz_per_xcd": per_xcd, "sclk_samples": int(s.clk_samples - b.clk_samples),
            "ms_per_tick_100tick_windows": {"first": float(win[0]), "min": float(win.min()), "median": float(np.median(win)),
                                             "max": float(win.max()), "last": float(win[-1])} if len(win) else None,

@@ -112,6 +112,7 @@ class StatsStruct(C.Structure):
         # ABI 6: routed band mode
         ("halo_violations", C.c_uint64),
         ("late_events", C.c_uint64 * 2),
+        ("pipeline_resyncs", C.c_uint64),
     ]
 
     def sclk_mhz(self, base=None):

@@ -214,6 +214,8 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
     h->lm_split = !(e && std::atoi(e) == 0);
   }
   if (const char* ef = std::getenv("ESVO_FRONT_THROTTLE")) h->front_throttle = std::atoi(ef) != 0;
+  if (const char* ea = std::getenv("ESVO_RESYNC")) h->resync_on = std::atoi(ea) != 0;
+  if (const char* et = std::getenv("ESVO_TIMELINE")) h->tl_on = std::atoi(et) != 0;
   if (const char* e1 = std::getenv("ESVO_ONE_STREAM")) {  // A/B only: the three stages in one queue (no cross-queue hand-offs)
     if (std::atoi(e1) == 1) {
       hipStreamDestroy(h->stream_b);
@@ -415,6 +417,7 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
   CK(dalloc(&h->d_export, npx));
   CK(dalloc(&h->d_export_cell, npx));
   for (int i = 0; i < EV_N; ++i) CK(hipEventCreate(&h->evt[i]));
+  if (h->tl_on) { CK(hipEventCreate(&h->tl_ref)); CK(hipEventRecord(h->tl_ref, h->stream)); CK(hipEventSynchronize(h->tl_ref)); }
   h->evt_ok = true;
   CK(hipEventCreateWithFlags(&h->evt_trk_read, hipEventDisableTiming));
   for (int cam = 0; cam < 2; ++cam) CK(hipEventCreateWithFlags(&h->evt_ingest[cam], hipEventDisableTiming));
@@ -490,6 +493,7 @@ int esvo_destroy(esvo_handle h) {
   release_routing(h);
   for (int cam = 0; cam < 2; ++cam) if (h->d_wire[cam]) hipFree(h->d_wire[cam]);
   if (h->evt_trk_read) hipEventDestroy(h->evt_trk_read);
+  if (h->tl_ref) hipEventDestroy(h->tl_ref);
   for (int cam = 0; cam < 2; ++cam) if (h->evt_ingest[cam]) hipEventDestroy(h->evt_ingest[cam]);
   for (void* q : {(void*)h->d_viz_bgr, (void*)h->d_viz_jet, (void*)h->d_viz_owner}) if (q) hipFree(q);
   for (void* q : {(void*)h->sgm.sobL, (void*)h->sgm.rawL, (void*)h->sgm.sobR, (void*)h->sgm.rawR, (void*)h->sgm.vol[0], (void*)h->sgm.vol[1],
@@ -539,6 +543,7 @@ int esvo_reset(esvo_handle h) {
   h->own_total = 0;
   h->glob_base = 0;
   h->halo_error = false;
+  h->resync = esvo_context::Resync();
   HIPCHK(hipMemsetAsync(h->d_halo_viol, 0, sizeof(u32) * 2, h->stream));
   std::memset(h->h_cnt_b + 8 * 3, 0, sizeof(u32) * 8);
   h->sh_first = 0;
@@ -681,6 +686,47 @@ __global__ void selftest_div_kernel(unsigned long long n_per_thread, unsigned lo
   if (bad) atomicAdd(mismatches, bad);
 }
 }  // namespace
+namespace {
+__global__ void debug_stall_kernel(unsigned long long ref_ticks) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ref_ticks) __builtin_amdgcn_s_sleep(32);
+}
+}  // namespace
+// tools only (tools/regime_probe.py, ESVO_TIMELINE=1): when every stage of the last `max_rows` ticks ran, in ms since esvo_create:
+// rows of 12 -- front stage T0, BM0, BM1, S1, LM0, LM1, S2, CNT; back stage FU0, FU1, CL1, RG1 -- collected from the handle's HIP
+// events as the ticks completed (no extra synchronisation while the run lasts; this call drains the handle).  Not part of the
+// documented ABI.
+extern "C" int esvo_debug_timeline(esvo_handle h, float* out, int max_rows, int* n_rows) {
+  if (!h || !out || !n_rows) return ESVO_ERR_INVALID_ARG;
+  API_LOCK(h);
+  HIPCHK(hipSetDevice(h->device));
+  int rc = finalize_tick_stats(h);
+  if (rc) return rc;
+  const size_t n = std::min(h->tl_front.size(), h->tl_back.size());
+  const size_t take = std::min<size_t>(n, (size_t)std::max(max_rows, 0));
+  for (size_t k = 0; k < take; ++k) {
+    const size_t i = n - take + k;
+    for (int j = 0; j < 8; ++j) out[k * 12 + j] = h->tl_front[i][j];
+    for (int j = 0; j < 4; ++j) out[k * 12 + 8 + j] = h->tl_back[i][j];
+  }
+  *n_rows = (int)take;
+  return ESVO_OK;
+}
+
+// tools only (tools/regime_probe.py): occupy one of the handle's queues for `microseconds` with a kernel that does nothing --
+// a stage of the tick pipeline falls behind by that much.  which: 0 front (Time Surfaces, block matching), 1 LM, 2 back (fusion,
+// regulariser).  Not part of the documented ABI.
+extern "C" int esvo_debug_stall(esvo_handle h, int which, unsigned microseconds) {
+  if (!h || which < 0 || which > 2) return ESVO_ERR_INVALID_ARG;
+  API_LOCK(h);
+  HIPCHK(hipSetDevice(h->device));
+  const unsigned long long ticks = (unsigned long long)microseconds * (h->stats.clk_ref_khz ? h->stats.clk_ref_khz : 100000u) / 1000ull;
+  hipStream_t s = which == 0 ? h->stream : (which == 1 ? h->stream_l : h->stream_b);
+  hipLaunchKernelGGL(debug_stall_kernel, dim3(1), dim3(1), 0, s, ticks);
+  HIPCHK(hipGetLastError());
+  return ESVO_OK;
+}
+
 extern "C" int esvo_selftest_division(unsigned long long n, unsigned long long seed, unsigned long long* mismatches) {
   esvo_context* h = nullptr;
   unsigned long long* d = nullptr;

@@ -1,5 +1,7 @@
 // api_map.hip — the mapper: stage-wise calls, the fused (lazily completed, two-stream) tick, device-resident stage
 // calls, multi-GPU sharding, outputs and statistics (see context.hpp).
+#include <chrono>
+
 #include "context.hpp"
 
 namespace esvo_host {
@@ -196,6 +198,12 @@ void collect_back(esvo_context* h, int par) {
   s.ms_kernel[4] = fu; s.ms_kernel[5] = cl; s.ms_kernel[6] = rg;
   s.sum_ms_kernel[4] += fu; s.sum_ms_kernel[5] += cl; s.sum_ms_kernel[6] += rg;
   h->ema_back_ms = h->ema_back_ms > 0.f ? 0.75f * h->ema_back_ms + 0.25f * (fu + cl + rg) : fu + cl + rg;
+  if (h->tl_on && h->tl_ref) {
+    const int bk[4] = {EV_FU0, EV_FU1, EV_CL1, EV_RG1};
+    std::array<float, 4> row;
+    for (int i = 0; i < 4; ++i) { row[i] = -1.f; if (hipEventElapsedTime(&row[i], h->tl_ref, h->evt[bk[i] + o]) != hipSuccess) (void)hipGetLastError(); }
+    h->tl_back.push_back(row);
+  }
 }
 
 // place a frame of n points in the window ring (frames stay contiguous: [oldest frame, newest frame) modulo the wrap)
@@ -693,14 +701,10 @@ int tick_phase0(esvo_context* h, uint64_t t_ns, const uint64_t* pose_t_ns, const
   std::memcpy(tk.T_world_obs, h->T_world_obs, sizeof(double) * 16);
   // two ticks in flight at most: what this tick's front stage overwrites (ring space of popped frames, the pose
   // table buffer) was last read by the back stage two ticks ago.
-  // (For the ordinary tick this device-side wait is, by inspection, only a throttle: it writes parity buffers that are
-  // released by events of their own -- EV_STG, EV_POSE, the collected EV_CNT -- and the host never runs more than two back
-  // stages ahead.  It is also the coupling behind the pipeline's second, slower operating point -- back chain behind -> the
-  // front stage and the next LM launch start only when a back stage ends -> the LM kernel runs beside the regulariser's whole
-  // launch -> regulariser 0.9 instead of 0.65 ms -> back chain stays behind: 1.5 instead of 1.3 ms per tick, seen in 2 of ~25
-  // sustained runs.  ESVO_FRONT_THROTTLE=0 drops the wait for unsharded ticks: neutral in the usual operating point, GPU suite
-  // green; whether it removes the slow one could not be shown in the GPU time of round 4 (profiles/r04_front_throttle.txt),
-  // so the wait stays.)
+  // (For the ordinary tick this device-side wait is only a throttle: the tick writes parity buffers that are released by events of
+  // their own -- EV_STG, EV_POSE, the collected EV_CNT -- and the host never runs more than two back stages ahead.  Off since
+  // round 5 (ESVO_FRONT_THROTTLE=1 restores it): it ties every front stage to the END of a back stage, which is what makes a
+  // lagging back chain stay behind -- see pipeline_resync.  Sharded ticks keep it: their frame goes straight into the ring.)
   if (h->sharded || h->front_throttle) HIPCHK(hipStreamWaitEvent(h->stream, h->evt[EV_RG1 + h->par * EV_BACK_STRIDE], 0));
   hipEventRecord(h->evt[EV_T0 + h->fpar * EV_FRONT_STRIDE], h->stream);
   const u32* sel = nullptr;
@@ -733,6 +737,10 @@ int tick_phase0(esvo_context* h, uint64_t t_ns, const uint64_t* pose_t_ns, const
       const bool two = (h->lm_queues == 2 || (h->lm_queues == 0 && h->lm_two_on)) && n <= h->lm_two_max && !split_scratch;
       sl = (two && h->fpar) ? h->stream_l1 : h->stream_l;
       HIPCHK(hipStreamWaitEvent(sl, h->evt[EV_A1 + h->fpar * EV_FRONT_STRIDE], 0));
+    }
+    if (h->resync.lm_wait_back) {  // pipeline_resync: this LM launch starts together with the back stage after the newest enqueued one
+      h->resync.lm_wait_back = false;
+      HIPCHK(hipStreamWaitEvent(sl, h->evt[EV_RG1 + (h->par ^ 1) * EV_BACK_STRIDE], 0));
     }
     tk.lm_stream = sl;
     tk.lm_pair = lm_pair_policy(h, n);
@@ -886,12 +894,52 @@ int tick_phase1_collect(esvo_context* h, int fp) {
       h->lm_pair_n[tk.lm_pair]++;
     }
   }
+  if (h->tl_on && h->tl_ref && n) {
+    const int fr[8] = {EV_T0, EV_BM0, EV_BM1, EV_S1, EV_LM0, EV_LM1, EV_S2, EV_CNT};
+    std::array<float, 8> row;
+    for (int i = 0; i < 8; ++i) { row[i] = -1.f; if (hipEventElapsedTime(&row[i], h->tl_ref, h->evt[fr[i] + o]) != hipSuccess) (void)hipGetLastError(); }
+    h->tl_front.push_back(row);
+  }
   tk.max_kept = (h->sharded && n) ? cnt[9] : 0;
   if (h->sharded && n_points) {  // exchange 2: [count | kept points], block length from the largest kept count among the ranks
     h->xchg_send = h->d_pts_send;
     h->xchg_recv = h->dp.ev_nshards > 1 ? h->d_pts_all : h->d_pts_send;
     h->xchg_block = 8 + (size_t)tk.max_kept * sizeof(DevPoint);
   }
+  return ESVO_OK;
+}
+// The tick pipeline has two stable operating points (profiles/r05_regime_timeline.txt: the stage times of both).  Normally LM
+// launches run back to back and a tick's back stage (fusion 0.6 ms, then the regulariser) starts the moment its frame is ready,
+// i.e. together with the NEXT LM launch: the regulariser runs beside that launch's draining tail (0.6-0.7 ms) and the back chain
+// (1.25-1.3 ms) keeps pace with the LM chain (1.27-1.3).  If the back chain ever falls behind by a few milliseconds (a stall of
+// its queue does it on demand; a hiccup did it in 2 of 25 sustained runs of round 4) it stays behind: the host, which may not run
+// more than two back stages ahead, then issues every front stage when a back stage ENDS, so each LM launch begins ~0.4 ms into a
+// fusion stage and the regulariser spends its whole launch beside the LM kernel at full occupancy -- 1.03 instead of 0.69 ms --
+// which makes the back chain 1.6 ms per tick: the pace-setter, for good.
+// The way back: when the symptom shows (the tick period well above the LM launch time while the back stage fills the period, three
+// ticks running) the NEXT LM launch is made to wait, once, for the end of the newest enqueued back stage.  The following back
+// stage and that LM launch then start together -- the fast state's alignment, one tick of lag further back, which the window
+// policy does not care about.  A workload whose back chain is the slower one by nature (a reference-faithful DSEC tick) shows the
+// same symptom; there the wait buys nothing, which the period after it shows, and the attempt is not repeated for 5000 ticks.
+static int pipeline_resync(esvo_context* h, float wait_ms, double now_ms) {
+  (void)wait_ms;
+  esvo_context::Resync& r = h->resync;
+  if (r.last_ms > 0.0) { const float dt = (float)(now_ms - r.last_ms); r.period_ema = r.period_ema > 0.f ? 0.8f * r.period_ema + 0.2f * dt : dt; }
+  r.last_ms = now_ms;
+  if (!h->resync_on) return ESVO_OK;
+  if (r.check_in > 0 && --r.check_in == 0)   // did the last attempt shorten the tick?  if not, the back chain IS the pace: stop trying
+    r.cooldown = (r.period_ema > 0.93f * r.period_before) ? 5000u : 50u;
+  if (r.cooldown > 0) { --r.cooldown; r.streak = 0; return ESVO_OK; }
+  if (r.check_in > 0) return ESVO_OK;
+  const bool symptom = h->ema_lm_ms > 0.f && h->ema_back_ms > 0.f && r.period_ema > 1.2f * (h->ema_lm_ms + 0.05f) &&
+                       h->ema_back_ms > 0.85f * r.period_ema;
+  r.streak = symptom ? r.streak + 1 : 0;
+  if (r.streak < 3) return ESVO_OK;
+  r.streak = 0;
+  r.period_before = r.period_ema;
+  r.check_in = 24;
+  r.lm_wait_back = true;   // consumed by the next tick_phase0
+  h->stats.pipeline_resyncs++;
   return ESVO_OK;
 }
 // phase 2 (back stage): window policy, fusion + clean + regularisation of this band (halo rows recomputed locally),
@@ -914,7 +962,14 @@ int tick_phase2(esvo_context* h, int fp) {
   }
   const int par = h->par;
   h->par ^= 1;
+  const auto t_wait0 = std::chrono::steady_clock::now();
   HIPCHK(hipEventSynchronize(h->evt[EV_RG1 + par * EV_BACK_STRIDE]));
+  if (!h->sharded) {
+    const auto t_wait1 = std::chrono::steady_clock::now();
+    int rcr = pipeline_resync(h, std::chrono::duration<float, std::milli>(t_wait1 - t_wait0).count(),
+                              std::chrono::duration<double, std::milli>(t_wait1.time_since_epoch()).count());
+    if (rcr) return rcr;
+  }
   collect_back(h, par);
   int rc;
   if (!h->sharded) {  // now that the size is known: exact ring space, frame copied behind the fusion that may still read it

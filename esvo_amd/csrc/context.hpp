@@ -8,6 +8,7 @@
 //   api_map.hip    mapper: stage-wise calls, ticks, sharding   api_track.hip  tracker residual / Jacobian evaluation
 #pragma once
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -69,7 +70,15 @@ struct esvo_context {
   u32 lm_two_max = esvo::LM_TWO_QUEUES_MAX_EVENTS;  // launches bounded by more events stay on one queue
   bool lm_split = true;           // ESVO_LM_STREAM=0: everything of the front stage on `stream`
   bool one_stream = false;       // ESVO_ONE_STREAM=1 (A/B): stream_b aliases stream
-  bool front_throttle = true;    // ESVO_FRONT_THROTTLE=0 (A/B): an unsharded tick's front stage does not wait for the back stage two ticks ago (api_map.hip)
+  // ESVO_TIMELINE=1 (tools/regime_probe.py): when every stage of every tick ran, collected from the HIP events as they complete
+  bool tl_on = false;
+  hipEvent_t tl_ref = nullptr;
+  std::vector<std::array<float, 8>> tl_front;
+  std::vector<std::array<float, 4>> tl_back;
+  // the pipeline's way back from its slow operating point (api_map.hip, pipeline_resync); ESVO_RESYNC=0 (A/B) switches it off
+  bool resync_on = true;
+  struct Resync { double last_ms = 0; float period_ema = 0, period_before = 0; u32 streak = 0, cooldown = 0, check_in = 0; bool lm_wait_back = false; } resync;
+  bool front_throttle = false;   // ESVO_FRONT_THROTTLE=1 (A/B): an unsharded tick's front stage waits for the back stage two ticks ago (api_map.hip; the default until round 4)
   int cu_split[3] = {0, 0, 0};    // ESVO_CU_SPLIT (A/B): CUs of the fusion / matching streams, CUs of the device
   bool split_now = false;         // set by esvo_map_tick around its front stage: only the lazy tick path splits
   uint8_t* d_obs2[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};

@@ -808,11 +808,19 @@ __global__ void __launch_bounds__(256) reg_view_kernel(const MapCell* __restrict
 // The counts decide at the end (neighbours > minN, close > minClose), so the fusion runs speculatively.
 #define REG_TX 64
 #ifndef REG_TY
-#define REG_TY 4   // 8 and 16 rows per tile (fuller waves, fewer tiles) were measured: the stage gets shorter (1.05 -> 0.93 ms
-                   // overlapped) but the tick longer (1.75 -> 1.87 ms): longer per-wave chains beside the LM kernel
+#define REG_TY 8   // rows per tile.  Lanes are ELEMENTS (compacted), so what a tile costs is its element count rounded up to whole
+                   // waves: at the headline workload's density (36 % of the cells alive) 4 rows fill 1.44 waves -> 2, 8 rows
+                   // 2.9 -> 3 (lane use 72 % -> 96 %), and a staged row serves twice the cells.  Round 5, sustained headline:
+                   // 1.298 -> 1.273 ms per tick (profiles/r05_ab_regty.txt); 16 rows (1024-thread workgroups) is slower (1.69).
+#endif
+#ifndef REG_RB
+#define REG_RB 4   // view rows staged per barrier.  One row per barrier (rounds 2-4) made every one of the 46-50 steps of a tile wait
+                   // for a global load issued only two steps earlier: a tile's critical path was ~50 load latencies.  Blocks of 4
+                   // rows: 13 steps, each prefetching four rows while four are being scanned.
 #endif
 #define REG_MARGIN 1   // an element's believed (row, col) is at most one cell away from its true cell (Appendix A-7)
-#define REG_MAXW (REG_TX + 2 * 31 + 2 * REG_MARGIN)
+#define REG_MAXW 128   // staged columns: REG_TX + 2 * (R + REG_MARGIN) <= 64 + 2 * 32, two 64-lane halves
+static_assert((REG_TX * REG_TY) % 64 == 0 && REG_TX == 64, "a wave is a tile row");
 template <int RT>  // RegularizationRadius when it is one of the shipped values (5, 20): the tap loop unrolls; 0: any radius
 __global__ void __launch_bounds__(REG_TX * REG_TY, BACK_WAVES) reg_apply_kernel(const MapCell* __restrict__ map, MapCell* __restrict__ out,
                                                                     const u32* __restrict__ owner_max,
@@ -820,9 +828,12 @@ __global__ void __launch_bounds__(REG_TX * REG_TY, BACK_WAVES) reg_apply_kernel(
                                                                     const double2* __restrict__ ab,
                                                                     const double2* __restrict__ cd, DevParams p) {
   BACK_PRIO();
-  __shared__ double2 s_ab[2][REG_MAXW];
-  __shared__ double2 s_cd[2][REG_MAXW];
-  __shared__ u64 s_vb[2][3];
+  constexpr int NW = REG_TY;                        // waves of the workgroup
+  constexpr int UNITS = 4 * REG_RB;                 // staging units of a block: (row, ab | cd, column half) x 64 lanes
+  constexpr int UPW = (UNITS + NW - 1) / NW;        // units per wave
+  __shared__ double2 s_ab[2][REG_RB][REG_MAXW];
+  __shared__ double2 s_cd[2][REG_RB][REG_MAXW];
+  __shared__ u64 s_vb[2][REG_RB][2];
   __shared__ u32 s_elem[REG_TX * REG_TY];
   __shared__ u32 s_wcount[REG_TY + 1];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -903,75 +914,96 @@ __global__ void __launch_bounds__(REG_TX * REG_TY, BACK_WAVES) reg_apply_kernel(
       s2_post = ((nu_post + a2 / ssum) / (nu_post + 1) * pp) / ssum;
     }
   };
-  // ---- stream the view rows through LDS ----
+  // ---- stream the view through LDS, REG_RB rows per barrier, double-buffered ----
+  // unit u = 4 r + 2 a + hf: row r of the block, a = 0 the (inverse depth, 2 sigma) view / 1 the (nu, scale^2) view, hf the column
+  // half; wave w stages the units w, w + NW, ...  The ballot of an `ab` unit is that half row's neighbour word.
   const double nan = __longlong_as_double(0x7ff8000000000000ll);
-  double2 ld = make_double2(nan, nan);  // threads [0, sw): ab of staged column t; threads [128, 128 + sw): cd
-  const int sj = (t < 128) ? t : (t < 256 ? t - 128 : REG_MAXW);  // waves 0-1 stage ab, 2-3 cd; further waves only carry elements
-  auto fetch_row = [&](int y) {
-    const int gy = sr0 + y, gx = sc0 + sj;
-    ld = make_double2(nan, nan);
-    if (sj < sw && y < sh && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) ld = (t < 128 ? ab : cd)[gy * p.W + gx];
-  };
-  auto store_row = [&](int buf) {
-    if (sj < sw) (t < 128 ? s_ab : s_cd)[buf][sj] = ld;
-    if (t < 128) {  // waves 0 and 1 hold the ab halves: their ballots are the row's neighbour bits
-      const u64 vm = __ballot(sj < sw && ld.x == ld.x);
-      if (lane == 0) s_vb[buf][wv] = vm;
-    }
-  };
-  fetch_row(0);
-  store_row(0);
-  fetch_row(1);
-  __syncthreads();
-  for (int y = 0; y < sh; ++y) {
-    const int buf = y & 1;
-    const int gy = sr0 + y;
-    if (scan && gy >= row - R && gy <= row + R) {
-      // neighbour bits of the lane's window in this row
-      const u64 w0 = s_vb[buf][0], w1 = s_vb[buf][1];
-      u64 bits = (off < 64) ? (w0 >> off) : 0ull;
-      if (off > 0 && off < 64) bits |= w1 << (64 - off);
-      if (off >= 64) bits = w1 >> (off - 64);
-      bits &= wmask;
-      nb += (u32)__popcll(bits);
-      u32 cm2[2] = {0u, 0u};  // close taps 0..31 and 32..63 of the row
-      if (bits) {
-        // |rho_self - rho_n| < 2 sigma_self || < 2 sigma_n  ==  < max(2 sigma_self, 2 sigma_n); a NaN tap fails, as
-        // fmax returns the other operand and the difference is NaN.  Bits are collected in two 32-bit halves.
-        u32 lo = 0, hi = 0;
-        const double2* tap = &s_ab[buf][off];
-        if (RT > 0) {
+  double2 ld[UPW];
+  const int n_blk = (sh + REG_RB - 1) / REG_RB;
+  auto fetch_block = [&](int k) {
 #pragma unroll
-          for (int dc = 0; dc < 2 * RT + 1; ++dc) {
-            const double2 q = tap[dc];
-            const bool close = fabs(inv - q.x) < fmax(sd_self2, q.y);
-            if (dc < 32) lo |= close ? (1u << dc) : 0u; else hi |= close ? (1u << (dc - 32)) : 0u;
-          }
-        } else {
-          for (int dc = 0; dc < Wn; ++dc) {
-            const double2 q = tap[dc];
-            const bool close = fabs(inv - q.x) < fmax(sd_self2, q.y);
-            if (dc < 32) lo |= close ? (1u << dc) : 0u; else hi |= close ? (1u << (dc - 32)) : 0u;
-          }
-        }
-        cm2[0] = lo; cm2[1] = hi;
+    for (int j = 0; j < UPW; ++j) {
+      const int u = wv + NW * j;
+      ld[j] = make_double2(nan, nan);
+      if (u < UNITS && k < n_blk) {
+        const int r = u >> 2, a = (u >> 1) & 1, hf = u & 1;
+        const int y = k * REG_RB + r, sj = hf * 64 + lane;
+        const int gy = sr0 + y, gx = sc0 + sj;
+        if (sj < sw && y < sh && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) ld[j] = (a ? cd : ab)[gy * p.W + gx];
       }
-      nclose += (u32)__popc(cm2[0]) + (u32)__popc(cm2[1]);
-      // lowest column first; two 32-bit masks (a 64-bit ctz / clear-lowest costs 8 instructions per step, these 3)
-#pragma unroll 1
-      for (int half = 0; half < 2; ++half) {
-        u32 m = half ? cm2[1] : cm2[0];
-        const int o2 = off + 32 * half;
-        while (m) {
-          const int k = __builtin_ctz(m);
-          m &= m - 1u;
-          const double2 qa = s_ab[buf][o2 + k], qc = s_cd[buf][o2 + k];
-          fuse_step(qa.x, qc.x, qc.y);
+    }
+  };
+  auto store_block = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < UPW; ++j) {
+      const int u = wv + NW * j;
+      if (u < UNITS) {  // wave-uniform
+        const int r = u >> 2, a = (u >> 1) & 1, hf = u & 1;
+        const int sj = hf * 64 + lane;
+        (a ? s_cd : s_ab)[buf][r][sj] = ld[j];
+        if (!a) {
+          const u64 vm = __ballot(sj < sw && ld[j].x == ld[j].x);
+          if (lane == 0) s_vb[buf][r][hf] = vm;
         }
       }
     }
-    if (y + 1 < sh) store_row(buf ^ 1);  // the row fetched one iteration ago
-    fetch_row(y + 2);
+  };
+  fetch_block(0);
+  store_block(0);
+  fetch_block(1);
+  __syncthreads();
+  for (int k = 0; k < n_blk; ++k) {
+    const int buf = k & 1;
+#pragma unroll 1
+    for (int r = 0; r < REG_RB; ++r) {
+      const int gy = sr0 + k * REG_RB + r;
+      if (scan && gy >= row - R && gy <= row + R) {
+        // neighbour bits of the lane's window in this row
+        const u64 w0 = s_vb[buf][r][0], w1 = s_vb[buf][r][1];
+        u64 bits = (off < 64) ? (w0 >> off) : 0ull;
+        if (off > 0 && off < 64) bits |= w1 << (64 - off);
+        if (off >= 64) bits = w1 >> (off - 64);
+        bits &= wmask;
+        nb += (u32)__popcll(bits);
+        u32 cm2[2] = {0u, 0u};  // close taps 0..31 and 32..63 of the row
+        if (bits) {
+          // |rho_self - rho_n| < 2 sigma_self || < 2 sigma_n  ==  < max(2 sigma_self, 2 sigma_n); a NaN tap fails, as
+          // fmax returns the other operand and the difference is NaN.  Bits are collected in two 32-bit halves.
+          u32 lo = 0, hi = 0;
+          const double2* tap = &s_ab[buf][r][off];
+          if (RT > 0) {
+#pragma unroll
+            for (int dc = 0; dc < 2 * RT + 1; ++dc) {
+              const double2 q = tap[dc];
+              const bool close = fabs(inv - q.x) < fmax(sd_self2, q.y);
+              if (dc < 32) lo |= close ? (1u << dc) : 0u; else hi |= close ? (1u << (dc - 32)) : 0u;
+            }
+          } else {
+            for (int dc = 0; dc < Wn; ++dc) {
+              const double2 q = tap[dc];
+              const bool close = fabs(inv - q.x) < fmax(sd_self2, q.y);
+              if (dc < 32) lo |= close ? (1u << dc) : 0u; else hi |= close ? (1u << (dc - 32)) : 0u;
+            }
+          }
+          cm2[0] = lo; cm2[1] = hi;
+        }
+        nclose += (u32)__popc(cm2[0]) + (u32)__popc(cm2[1]);
+        // lowest column first; two 32-bit masks (a 64-bit ctz / clear-lowest costs 8 instructions per step, these 3)
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+          u32 m = half ? cm2[1] : cm2[0];
+          const int o2 = off + 32 * half;
+          while (m) {
+            const int kk = __builtin_ctz(m);
+            m &= m - 1u;
+            const double2 qa = s_ab[buf][r][o2 + kk], qc = s_cd[buf][r][o2 + kk];
+            fuse_step(qa.x, qc.x, qc.y);
+          }
+        }
+      }
+    }
+    if (k + 1 < n_blk) store_block(buf ^ 1);  // the block fetched one iteration ago
+    fetch_block(k + 2);
     __syncthreads();
   }
   if (slow) {  // plain path: the reference's two loops on the view in global memory

@@ -228,6 +228,9 @@ typedef struct esvo_stats_t {
   /* Events that arrived out of order (stamp below the newest stamp staged before them), per camera: sorted into the ring for
    * the mapper, withheld from the Time Surface as the reference's eventsCallback withholds them (esvo_ts_push_events). */
   uint64_t late_events[2];
+  /* How often the tick pipeline let its back stream drain to get out of its slow operating point (api_map.hip, pipeline_resync):
+   * 0 in an undisturbed run. */
+  uint64_t pipeline_resyncs;
 } esvo_stats_t;
 
 /* ---- lifecycle -------------------------------------------------------------------- */

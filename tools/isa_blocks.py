@@ -1,13 +1,14 @@
 #!/usr/bin/env python
-"""Static instruction mix per basic block of the first kernel in a gfx950 assembly listing (hipcc -S).
-usage: python tools/isa_blocks.py file.s [min_valu]"""
+"""Static instruction mix per basic block of a kernel in a gfx950 assembly listing (hipcc -S): the first one, or the one whose
+mangled name contains `kernel`.
+usage: python tools/isa_blocks.py file.s [min_valu] [kernel]"""
 import re
 import sys
 
 
-def main(path, min_valu=25):
+def main(path, min_valu=25, kernel=None):
     lines = open(path).read().split('\n')
-    start = [i for i, l in enumerate(lines) if re.match(r'^_Z\w+:', l)][0]
+    start = [i for i, l in enumerate(lines) if re.match(r'^_Z\w+:', l) and (kernel is None or kernel in l.split(':')[0])][0]
     end = [i for i, l in enumerate(lines) if i > start and l.strip().startswith('.Lfunc_end')][0]
     blocks = []
 
@@ -46,4 +47,4 @@ def main(path, min_valu=25):
 
 
 if __name__ == '__main__':
-    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 25)
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 25, sys.argv[3] if len(sys.argv) > 3 else None)

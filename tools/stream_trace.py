@@ -1,16 +1,17 @@
 #!/usr/bin/env python
 """The ops of every stream over two steady-state ticks from a rocprofv3 --kernel-trace database: start (us from the first LM
-launch of the window), duration, gap to the previous op of the same stream.  usage: python tools/stream_trace.py results.db"""
+launch of the window), duration, gap to the previous op of the same stream.
+usage: python tools/stream_trace.py results.db [index of the window's first LM launch, default 10]"""
 import sqlite3
 import sys
 
 
-def main(path):
+def main(path, first=10):
     db = sqlite3.connect(path)
     rows = db.execute("select name, start, end, queue_id, stream_id from kernels order by start").fetchall()
     lm = [r for r in rows if "lm_refine" in r[0] and ", 2>" not in r[0]]   # single launch or first stage
     lm = [r for r in lm if ", 1>" in r[0]] or lm
-    t0, t1 = lm[10][1], lm[12][1]
+    t0, t1 = lm[first][1], lm[first + 2][1]
     sel = [r for r in rows if t0 <= r[1] < t1]
     print("window %.1f us (2 ticks)" % ((t1 - t0) / 1e3))
     streams = {}
@@ -28,4 +29,4 @@ def main(path):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 10)
