@@ -150,13 +150,13 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
     // issues, the LM waves fill every other slot.  Measured on the bench workload with the round-3 LM kernel (fewer stalls,
     // so it no longer leaves slots by itself): 1.40 ms per tick against 1.70 ms with the LM stream high and the fusion
     // stream low (round 2's setting, then worth -2 %).  ESVO_STREAM_PRIO = 0 / 2 and ESVO_PRIOS exist for that A/B.
-    const char* pe = std::getenv("ESVO_STREAM_PRIO");
+    const char* pe = esvo_dev_switch("ESVO_STREAM_PRIO");
     const int mode = pe ? std::atoi(pe) : 1;
     int pf = mode == 1 ? prio_hi : (mode == 2 ? prio_lo : 0), pb = mode == 1 ? prio_hi : (mode == 2 ? prio_lo : 0);
     // ESVO_PRIOS="front,lm,back" (A/B only): explicit priorities, 0 = the device's highest, larger = lower
     int pl_explicit = 0;
     bool have_explicit = false;
-    if (const char* e4 = std::getenv("ESVO_PRIOS")) {
+    if (const char* e4 = esvo_dev_switch("ESVO_PRIOS")) {
       int f = 0, l = 0, b = 0;
       if (std::sscanf(e4, "%d,%d,%d", &f, &l, &b) == 3) {
         auto clampp = [&](int v) { v = prio_hi + v; return v > prio_lo ? prio_lo : v; };
@@ -167,7 +167,7 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
     h->prio_note[0] = prio_lo; h->prio_note[1] = prio_hi;
     // ESVO_CU_SPLIT="b[,f]" (A/B only): SPATIAL partition instead of priorities -- the fusion stage's stream is confined to b
     // compute units, the matching stage's to the next f (0: it shares the LM stage's), the LM queues get the rest.
-    if (const char* ec = std::getenv("ESVO_CU_SPLIT")) {
+    if (const char* ec = esvo_dev_switch("ESVO_CU_SPLIT")) {
       int nb = 0, nf = 0;
       std::sscanf(ec, "%d,%d", &nb, &nf);
       hipDeviceProp_t prop;
@@ -195,9 +195,9 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
     int lo = 0, hi = 0;
     CK(hipDeviceGetStreamPriorityRange(&lo, &hi));
     int pl = lo;  // see above: the LM stream yields to the two latency-bound stages
-    if (const char* e3 = std::getenv("ESVO_PRIO_LM")) pl = std::atoi(e3) == 0 ? hi : (std::atoi(e3) == 2 ? lo : 0);  // A/B only
+    if (const char* e3 = esvo_dev_switch("ESVO_PRIO_LM")) pl = std::atoi(e3) == 0 ? hi : (std::atoi(e3) == 2 ? lo : 0);  // A/B only
     if (h->prio_note[2] != 12345) pl = h->prio_note[2];
-    if (std::getenv("ESVO_PRIO_PRINT")) fprintf(stderr, "[esvo] stream priority range: lowest %d .. highest %d; LM %d\n", lo, hi, pl);
+    if (esvo_dev_switch("ESVO_PRIO_PRINT")) fprintf(stderr, "[esvo] stream priority range: lowest %d .. highest %d; LM %d\n", lo, hi, pl);
     if (h->cu_split[0]) {
       uint32_t mask[16] = {0};
       for (int i = h->cu_split[0] + h->cu_split[1]; i < h->cu_split[2]; ++i) mask[i >> 5] |= 1u << (i & 31);
@@ -207,16 +207,16 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
       CK(hipStreamCreateWithPriority(&h->stream_l, hipStreamNonBlocking, pl));
       CK(hipStreamCreateWithPriority(&h->stream_l1, hipStreamNonBlocking, pl));
     }
-    if (const char* ep = std::getenv("ESVO_LM_PAIR")) h->lm_pair_forced = std::atoi(ep) == 1 ? 1 : (std::atoi(ep) == 0 ? 0 : -1);
-    if (const char* eq = std::getenv("ESVO_LM_QUEUES")) h->lm_queues = std::atoi(eq) == 1 ? 1 : (std::atoi(eq) == 2 ? 2 : 0);
-    if (const char* em = std::getenv("ESVO_LM_QUEUES_MAX_EVENTS")) h->lm_two_max = (u32)std::strtoul(em, nullptr, 10);  // A/B only
-    const char* e = std::getenv("ESVO_LM_STREAM");
+    if (const char* ep = esvo_dev_switch("ESVO_LM_PAIR")) h->lm_pair_forced = std::atoi(ep) == 1 ? 1 : (std::atoi(ep) == 0 ? 0 : -1);
+    if (const char* eq = esvo_dev_switch("ESVO_LM_QUEUES")) h->lm_queues = std::atoi(eq) == 1 ? 1 : (std::atoi(eq) == 2 ? 2 : 0);
+    if (const char* em = esvo_dev_switch("ESVO_LM_QUEUES_MAX_EVENTS")) h->lm_two_max = (u32)std::strtoul(em, nullptr, 10);  // A/B only
+    const char* e = esvo_dev_switch("ESVO_LM_STREAM");
     h->lm_split = !(e && std::atoi(e) == 0);
   }
-  if (const char* ef = std::getenv("ESVO_FRONT_THROTTLE")) h->front_throttle = std::atoi(ef) != 0;
-  if (const char* ea = std::getenv("ESVO_RESYNC")) h->resync_on = std::atoi(ea) != 0;
-  if (const char* et = std::getenv("ESVO_TIMELINE")) h->tl_on = std::atoi(et) != 0;
-  if (const char* e1 = std::getenv("ESVO_ONE_STREAM")) {  // A/B only: the three stages in one queue (no cross-queue hand-offs)
+  if (const char* ef = esvo_dev_switch("ESVO_FRONT_THROTTLE")) h->front_throttle = std::atoi(ef) != 0;
+  if (const char* ea = esvo_dev_switch("ESVO_RESYNC")) h->resync_on = std::atoi(ea) != 0;
+  if (const char* et = esvo_dev_switch("ESVO_TIMELINE")) h->tl_on = std::atoi(et) != 0;
+  if (const char* e1 = esvo_dev_switch("ESVO_ONE_STREAM")) {  // A/B only: the three stages in one queue (no cross-queue hand-offs)
     if (std::atoi(e1) == 1) {
       hipStreamDestroy(h->stream_b);
       h->stream_b = h->stream;
@@ -271,7 +271,7 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
     h->tsq_len = params->max_event_queue_len;
     const size_t tiles = (size_t)((h->W + 7) / 8) * ((h->H + 7) / 8);
     h->tsq_tcap = 1024;
-    if (const char* e = std::getenv("ESVO_TSQ_TILE_CAP")) h->tsq_tcap = (u32)std::max(1, std::atoi(e));  // tests: force the overflow list
+    if (const char* e = esvo_dev_switch("ESVO_TSQ_TILE_CAP")) h->tsq_tcap = (u32)std::max(1, std::atoi(e));  // tests: force the overflow list
     CK(dalloc(&h->d_tsq_tcount, tiles));
     CK(hipMemset(h->d_tsq_tcount, 0, sizeof(u32) * tiles));
     CK(dalloc(&h->d_tsq_tlist, tiles * h->tsq_tcap));
@@ -302,7 +302,7 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
   CK(dalloc(&h->d_matches2[1], E));
   h->d_matches = h->d_matches2[0];
   {
-    const char* es0 = std::getenv("ESVO_LM_SPLIT");
+    const char* es0 = esvo_dev_switch("ESVO_LM_SPLIT");
     h->lm_split_mode = es0 ? (std::atoi(es0) == 1 ? 1 : 0) : -1;
   }
   // (scratch of the split launch: 7 x 16 doubles per match -- only where the launch can be used)
@@ -313,7 +313,7 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
     // On the 1280x720 stress stream (4.9e5 events, 2.3e5 matches per tick: five times the waves) it does pay: 7.7 against
     // 8.4 ms per tick (profiles/r03_split_launch_other_workloads.txt).  So: used for launches bounded by >= 400 000 events,
     // ESVO_LM_SPLIT=0 / 1 forces it off / on.
-    const char* es = std::getenv("ESVO_LM_SPLIT");
+    const char* es = esvo_dev_switch("ESVO_LM_SPLIT");
     h->lm_split_mode = es ? (std::atoi(es) == 1 ? 1 : 0) : -1;
     CK(dalloc(&h->d_lm_fvec0, E * 7 * 16));
     CK(dalloc(&h->d_lm_fnorm0, E));
@@ -324,7 +324,13 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
   }
   CK(dalloc(&h->d_clk, clk_words(h->max_ev)));
   CK(hipMemset(h->d_clk, 0, sizeof(u64) * clk_words(h->max_ev)));
-  if (const char* ec = std::getenv("ESVO_CLK_PROBE")) h->clk_probe = std::atoi(ec) != 0;
+  if (const char* ec = esvo_dev_switch("ESVO_CLK_PROBE")) h->clk_probe = std::atoi(ec) != 0;
+  if (const char* ep = esvo_dev_switch("ESVO_LM_PERSIST")) h->lm_persist = std::atoi(ep) != 0;
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) h->lm_persist_blocks = (u32)cus * 4u * 2u;
+    if (const char* eb = esvo_dev_switch("ESVO_LM_PERSIST_BLOCKS")) h->lm_persist_blocks = (u32)std::max(1, std::atoi(eb));
+  }
   {
     int khz = 0;  // rate of s_memrealtime (wall_clock64): the constant reference clock the probe divides by
     if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) != hipSuccess || khz <= 0) khz = 100000;
@@ -370,7 +376,7 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
   // demand (alloc_pose_slot, api_map.hip).  ESVO_POSE_SLOTS0 (tests): a smaller first allocation.
   h->slot_used.assign(h->max_frames + 1, 0);
   h->n_pose_slots = std::min<u32>(h->max_frames + 1, 1024u);
-  if (const char* e0 = std::getenv("ESVO_POSE_SLOTS0")) h->n_pose_slots = std::min<u32>(h->max_frames + 1, (u32)std::max(1, std::atoi(e0)));
+  if (const char* e0 = esvo_dev_switch("ESVO_POSE_SLOTS0")) h->n_pose_slots = std::min<u32>(h->max_frames + 1, (u32)std::max(1, std::atoi(e0)));
   CK(dalloc(&h->d_frame_pose_T, (size_t)h->n_pose_slots * h->max_poses * 16));
   CK(dalloc(&h->d_fr_table, 2 * (3 * (size_t)h->max_frames + 1)));
   CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_fr_table), sizeof(u32) * 2 * (3 * (size_t)h->max_frames + 1)));
@@ -378,8 +384,8 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
   CK(dalloc(&h->d_prop, h->win_cap));
   {  // the fusion front (kernels_fuse.hip): FUSE_TILE x FUSE_TILE-cell tiles
     const size_t n_tiles = (size_t)((h->W + FUSE_TILE - 1) / FUSE_TILE) * ((h->H + FUSE_TILE - 1) / FUSE_TILE);
-    if (const char* et = std::getenv("ESVO_FUSE_TILE_CAP")) h->fuse_tile_cap = (u32)std::max(1L, std::atol(et));
-    if (const char* ep = std::getenv("ESVO_FUSE_PMAX")) h->fuse_pmax_plus1 = (u32)std::max(0L, std::atol(ep)) + 1u;
+    if (const char* et = esvo_dev_switch("ESVO_FUSE_TILE_CAP")) h->fuse_tile_cap = (u32)std::max(1L, std::atol(et));
+    if (const char* ep = esvo_dev_switch("ESVO_FUSE_PMAX")) h->fuse_pmax_plus1 = (u32)std::max(0L, std::atol(ep)) + 1u;
     CK(dalloc(&h->d_tile_pts, n_tiles * h->fuse_tile_cap));
     CK(dalloc(&h->d_over_pts, h->win_cap));
     CK(dalloc(&h->d_tile_count, n_tiles));
@@ -390,13 +396,13 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
     CK(dalloc(&h->d_fuse_ctr, 2112 + 64));
     CK(hipMemset(h->d_tile_count, 0, sizeof(u32) * n_tiles));  // zero between ticks: fuse_turn_kernel clears what was read
     CK(hipMemset(h->d_fuse_ctr, 0, sizeof(u32) * (2112 + 64)));
-    if (const char* er = std::getenv("ESVO_FUSE_TILE_REC")) h->fuse_tile_rec = (u32)std::max(1L, std::atol(er));
+    if (const char* er = esvo_dev_switch("ESVO_FUSE_TILE_REC")) h->fuse_tile_rec = (u32)std::max(1L, std::atol(er));
     CK(dalloc(&h->d_rec_ids, n_tiles * h->fuse_tile_rec + (size_t)h->win_cap * 9));
 #ifdef FUSE_STATS
-    if (std::getenv("ESVO_FUSE_STATS")) { CK(dalloc(&h->d_fuse_stats, n_tiles * 8)); CK(hipMemset(h->d_fuse_stats, 0, sizeof(u64) * n_tiles * 8)); }
+    if (esvo_dev_switch("ESVO_FUSE_STATS")) { CK(dalloc(&h->d_fuse_stats, n_tiles * 8)); CK(hipMemset(h->d_fuse_stats, 0, sizeof(u64) * n_tiles * 8)); }
 #endif
   }
-  if (const char* ef = std::getenv("ESVO_FUSE_LDS_CAP")) h->fuse_lds_cap = (u32)std::max(0L, std::atol(ef));
+  if (const char* ef = esvo_dev_switch("ESVO_FUSE_LDS_CAP")) h->fuse_lds_cap = (u32)std::max(0L, std::atol(ef));
   CK(hipMalloc(reinterpret_cast<void**>(&h->d_map), map_buffer_bytes(npx)));  // cells + their dense flags (common.hpp: map_flags)
   CK(hipMalloc(reinterpret_cast<void**>(&h->d_map2), map_buffer_bytes(npx)));  // cells + their dense flags (common.hpp: map_flags)
   CK(hipMemset(h->d_map, 0, map_buffer_bytes(npx)));
@@ -433,7 +439,7 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
 int esvo_destroy(esvo_handle h) {
   if (!h) return ESVO_OK;
   hipSetDevice(h->device);
-  if (std::getenv("ESVO_POLICY_PRINT"))
+  if (esvo_dev_switch("ESVO_POLICY_PRINT"))
     fprintf(stderr, "[esvo] LM layout policy: wide %.4f ms (%u ticks), pair %.4f ms (%u ticks); LM queues: lm %.4f ms, back %.4f ms, two %d\n",
             h->lm_pair_ms[0][0], h->lm_pair_n[0], h->lm_pair_ms[1][0], h->lm_pair_n[1], h->ema_lm_ms, h->ema_back_ms, (int)h->lm_two_on);
 #ifdef FUSE_STATS  // tools-only builds: per-tile phase cycles of the last tile_lists launch (a buffer of their own, allocated at esvo_create)

@@ -123,6 +123,9 @@ int run_lm(esvo_context* h, u32 max_matches, int cull, bool dense, hipStream_t s
   a.pair = pair >= 0 ? pair : (h->lm_pair_forced == 1 && max_matches <= esvo::LM_PAIR_MAX_EVENTS ? 1 : 0);
   a.clk = h->clk_probe ? h->d_clk : nullptr;
   if (h->routed && dense) { a.halo_viol = h->d_counters + 10; a.vy0 = h->oband_y0; a.vy1 = h->oband_y1; }
+  // launches of the throughput layout: persistent groups that pull matches from a counter (kernels_lm.hip); counters[11] is
+  // zero at this point (a tick clears its counter row with the pose upload, run_refine clears it itself)
+  if (h->lm_persist && !dense) { a.persist_next = h->d_counters + 11; a.persist_blocks = h->lm_persist_blocks; }
   hipEventRecord(h->evt[EV_LM0 + h->fpar * EV_FRONT_STRIDE], st);
   launch_lm_refine(a, h->dp, h->d_counters + 2, st);
   hipEventRecord(h->evt[EV_LM1 + h->fpar * EV_FRONT_STRIDE], st);
@@ -146,6 +149,7 @@ int run_order_points(esvo_context* h, u32 max_matches, DevPoint* dst, hipStream_
 }
 int run_refine(esvo_context* h, u32 max_matches, int cull, DevPoint* dst) {
   HIPCHK(hipMemsetAsync(h->d_counters + 2, 0, sizeof(u32), h->stream));  // n_solved (a tick zeroes all counters at once)
+  HIPCHK(hipMemsetAsync(h->d_counters + 11, 0, sizeof(u32), h->stream));  // the persistent LM layout's work counter
   int rc = run_lm(h, max_matches, cull, false);
   if (rc) return rc;
   return run_order_points(h, max_matches, dst);
@@ -1611,6 +1615,38 @@ int esvo_map_get_debug_images(esvo_handle h, double age_max_range, uint8_t* inv_
     HIPCHK(hipStreamSynchronize(h->stream_l)); HIPCHK(hipStreamSynchronize(h->stream_l1));
   HIPCHK(hipStreamSynchronize(h->stream_b));
   }
+  return ESVO_OK;
+}
+
+// esvo_MVStereo::saveDepthMap (esvo_MVStereo.cpp:982-1000), the reference's only DepthMap dump: the file <save_dir><t_ns>.txt with
+// one line per valid element (inverse depth > -1e-6, DepthPoint::valid() without arguments) in list order:
+//     of << it->x().transpose() << " " << it->p_cam()(2) << "\n"
+// Eigen's operator<< with the default IOFormat prints the 1 x 2 row vector with the stream's precision (6 significant digits,
+// general format) and ALIGNED columns: both coefficients right-aligned to the longer one's width, separated by one blank; the
+// depth follows as a plain double.  (Eigen is third-party and absent here: restated from its documented default format.)
+int esvo_map_save_depth_map(esvo_handle h, const char* save_dir, uint64_t t_ns, size_t* n_written) {
+  if (!h || !save_dir) return ESVO_ERR_INVALID_ARG;
+  API_LOCK(h);
+  HIPCHK(hipSetDevice(h->device));
+  { int rcp = flush_pending_tick(h); if (rcp) return rcp; }
+  std::vector<esvo_depth_point_t> v;
+  int rc = export_map(h, v, nullptr);
+  if (rc) return rc;
+  const std::string path = std::string(save_dir) + std::to_string((unsigned long long)t_ns) + ".txt";
+  FILE* f = std::fopen(path.c_str(), "w");
+  if (!f) FAIL(ESVO_ERR_INVALID_ARG, "cannot open " + path);
+  size_t n = 0;
+  for (const esvo_depth_point_t& e : v) {
+    if (!(e.inv_depth > -1e-6)) continue;
+    char a[64], b[64];
+    std::snprintf(a, sizeof(a), "%g", e.x[0]);
+    std::snprintf(b, sizeof(b), "%g", e.x[1]);
+    const int w = (int)std::max(std::strlen(a), std::strlen(b));
+    std::fprintf(f, "%*s %*s %g\n", w, a, w, b, e.p_cam[2]);
+    ++n;
+  }
+  std::fclose(f);
+  if (n_written) *n_written = n;
   return ESVO_OK;
 }
 

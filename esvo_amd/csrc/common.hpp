@@ -12,6 +12,15 @@
 
 #define ESVO_WAVE 64
 
+// A/B and test switches (ESVO_LM_PAIR, ESVO_FUSE_TILE_CAP, ...; tools/README.md lists them) are read from the environment ONLY
+// when ESVO_DEV_SWITCHES=1 is set as well: a deployed library ignores stray variables.  tests/conftest.py and the tools set it.
+#include <cstdlib>
+#include <cstring>
+inline const char* esvo_dev_switch(const char* name) {
+  const char* on = std::getenv("ESVO_DEV_SWITCHES");
+  return (on && std::strcmp(on, "1") == 0) ? std::getenv(name) : nullptr;
+}
+
 namespace esvo {
 
 typedef unsigned long long u64;
@@ -307,6 +316,10 @@ struct LmArgs {
   // (non-null selects the guarded kernels)
   u32* halo_viol = nullptr;
   int vy0 = 0, vy1 = 0;
+  // the persistent narrow layout (kernels_lm.hip, lm_refine_persist_kernel): a zeroed work counter (non-null selects it for
+  // launches of the throughput layout) and the number of workgroups the chip holds
+  u32* persist_next = nullptr;
+  u32 persist_blocks = 0;
 };
 constexpr u32 CLK_XCDS = 8, CLK_SAMPLES = 16, CLK_SCRATCH = 32, CLK_STRIDE = 65;
 inline size_t clk_words(u32 max_ev) { return CLK_SCRATCH + 2 * ((size_t)max_ev / 64 + 2); }

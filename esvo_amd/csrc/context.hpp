@@ -176,6 +176,12 @@ struct esvo_context {
   u32* d_lm_hist = nullptr;
   u64* d_clk = nullptr;           // in-run shader-clock probe of the LM kernel (LmArgs::clk, common.hpp); read by esvo_get_stats
   bool clk_probe = true;          // ESVO_CLK_PROBE=0 (A/B only) launches the LM kernel without it
+  // ESVO_LM_PERSIST=1 (A/B): launches of the throughput layout use lm_refine_persist_kernel (kernels_lm.hip).  Bit-identical and
+  // 13 % shorter as a launch (1.24 -> 1.075 ms beside the other stages), but OFF by default: a persistent grid has no draining
+  // tail, and the regulariser -- which runs beside that tail in the pipelined tick -- then takes 0.87 instead of 0.60 ms, so the
+  // back chain paces the tick at 1.6 ms (1.31 at best with a smaller grid; profiles/r05_ab_lm_persist.txt)
+  bool lm_persist = false;
+  u32 lm_persist_blocks = 2048;   // workgroups (= waves) of the persistent layout: two per SIMD
   int lm_split_mode = -1;         // the split launch: -1 by launch size (>= 400 000 events), 0 never, 1 always (ESVO_LM_SPLIT)
   DevPoint* d_pt_slots = nullptr;   // LM output by slot + keep flags + their scan: alias one of two sets (front parity)
   u32* d_pt_flags = nullptr;

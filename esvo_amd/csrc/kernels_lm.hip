@@ -160,14 +160,17 @@ __device__ inline double in_vgpr(double x) {
   return x;
 }
 
-struct LmProblem {
+template <bool T_LDS> struct LmPose { double T[12]; };            // T_left_virtual (3x4) in registers
+template <> struct LmPose<true> { const double* T; };            // ... in LDS: 24 VGPRs less (the persistent kernel; -DLM_T_IN_LDS)
+#ifdef LM_T_IN_LDS
+#define LM_T_LDS_DEFAULT true
+#else
+#define LM_T_LDS_DEFAULT false
+#endif
+template <bool T_LDS>
+struct LmProblemT : LmPose<T_LDS> {
   double cx, cy;           // rectified left coordinate of the event
   double ray[3];           // Kinv [cx cy 1]^T: the part of cam2World that does not depend on the inverse depth
-#ifdef LM_T_IN_LDS
-  const double* T;         // T_left_virtual (3x4) in LDS: 24 VGPRs less (see the register footprint note at lm_refine_kernel)
-#else
-  double T[12];            // T_left_virtual (3x4)
-#endif
   // The two Time Surfaces as buffer resources: a patch byte is  buffer_load_ubyte v, v_off, s[rsrc], s_row offen  with the
   // per-lane offset of the block's first row in v_off and the row stride in a scalar -- no per-row 64-bit address
   // arithmetic on the vector ALU, and an offset outside the image reads 0 instead of faulting, so the loads can be issued
@@ -187,6 +190,7 @@ struct LmProblem {
   u32 dbg_slot;
 #endif
 };
+typedef LmProblemT<LM_T_LDS_DEFAULT> LmProblem;
 
 // patchInterpolation's geometry (DepthProblem.cpp:193-230) as straight-line code: the block's upper-left corner, the four
 // bilinear weights and the predicate "the patch lies inside the image".  Nothing here is guarded: for a location that fails
@@ -262,8 +266,8 @@ __device__ inline void interp_column(__amdgpu_buffer_rsrc_t img, int W, const Pa
 // BAND (routed band mode: the rank's observation pair holds its band + halo rows only): an evaluation whose source blocks
 // leave those rows would read stale bytes -- it is recorded in `viol` (the tick is then refused with ESVO_ERR_HALO by every
 // rank, include/esvo_hip.h), never silently used.
-template <bool WIDE, bool L2, bool COUNT = false, bool BAND = false>
-__device__ bool lm_eval(const DevParams& p, const LmProblem& pr, LmCache<WIDE>& cc, double x, double* fv, int* n_iter = nullptr,
+template <bool WIDE, bool L2, bool COUNT = false, bool BAND = false, bool T_LDS = LM_T_LDS_DEFAULT>
+__device__ bool lm_eval(const DevParams& p, const LmProblemT<T_LDS>& pr, LmCache<WIDE>& cc, double x, double* fv, int* n_iter = nullptr,
                         bool* viol = nullptr) {
   int iters = 0;  // t-scale iterations of this evaluation (COUNT only: the split launch orders the matches by it)
   constexpr int RL = Lay<WIDE>::RL;
@@ -611,7 +615,11 @@ __global__ void __launch_bounds__(PAIR ? 128 : LM_BLOCK, WIDE ? LM_WIDE_WAVES : 
     if (blockIdx.x < 2 * LM_SPLIT_STRIPES * LM_SPLIT_BINS / LM_BLOCK) sp.hist[blockIdx.x * LM_BLOCK + threadIdx.x] = 0u;
     s = active ? sp.order[pos] : 0xffffffffu;
   }
-  // The grid is sized for the worst case (every event matched): waves without any match leave at once.
+  // The grid is sized for the worst case (every event matched): waves without any match leave at once (~39 000 of 49 000 on the
+  // headline workload; they are the LAST in dispatch order, execute ~12 instructions each -- 0.1 % of the launch -- and delay no
+  // working wave).  Sizing the grid from the previous tick's count with a strided tail was built in round 5 and dropped: wrapping
+  // the body in the loop costs the register allocator 7 VGPRs (199 -> 206: a block-matching wave no longer fits beside two LM
+  // waves) and triples the SGPR spills (29 -> 96), for no time to win.
   // Inactive groups of a partially filled wave run the (cheap, failing) code path below with a dummy
   // problem so that the wave's control flow stays simple; they write nothing.
   if (STAGE != 2 && !active && lead && s < a.max_matches) a.out_flags[s] = 0u;  // every slot of the launch gets its flag: no memset
@@ -950,6 +958,290 @@ __global__ void __launch_bounds__(PAIR ? 128 : LM_BLOCK, WIDE ? LM_WIDE_WAVES : 
   a.out_flags[s] = keep ? 1u : 0u;
 }
 
+// ---- the persistent narrow layout (round 5) ------------------------------------------------------------------------------------
+// In lm_refine_kernel<false> four matches share a wave from its first instruction to its last: the wave performs as many evaluations
+// as the SLOWEST of its four matches needs (22.9 on the headline workload where a match needs 19.2: profiles/r05_lm_attribution.txt),
+// and a launch needs one wave per four slots of its bound (~49 000 waves for ~10 000 that find a match).  Here a 16-lane group that
+// has finished its match fetches the next one from a counter and starts over while the other three groups carry on: the grid is
+// what the chip holds (two waves per SIMD), every evaluation a wave executes serves four live matches until the list runs dry,
+// and the groups' different lengths average out inside a wave instead of idling its lanes.  What stays is the lockstep INSIDE an
+// evaluation (the t-scale loop runs as long as the slowest of the four groups needs).
+// Same arithmetic, same operands, same order for every match as in lm_refine_kernel (the evaluator and the solver's state
+// machine are the same code): which wave solves a match, and beside which others, does not enter its result -- bit-identical
+// output (tests/test_gpu_parity.py, test_gpu_fullsize.py compare with the oracle element by element).
+// The per-match set-up moves INTO the loop, where the solver's whole state is live: T_left_virtual therefore goes to LDS (one
+// element per lane, 12 lanes of the group) instead of 24 VGPRs, and its 3 x 4 products are formed by those 12 lanes.
+template <bool L2>
+__global__ void __launch_bounds__(LM_BLOCK, LM_WAVES) lm_refine_persist_kernel(LmArgs a, DevParams p, u32* n_solved, u32* next) {
+  constexpr bool WIDE = false;
+  constexpr int RL = LM_ROWS;
+  __shared__ double lds_T[LM_BLOCK / 16][12];
+  __shared__ double lds_cam[28];
+  if (threadIdx.x < 27) {
+    const int i = threadIdx.x;
+    lds_cam[i] = i < 12 ? p.camL.P[i] : (i < 24 ? p.camR.P[i - 12] : p.camL.Kinv_t[i - 24]);
+  }
+  __syncthreads();
+  const int c = threadIdx.x & 15;
+  const bool lead = c == 0;
+  u32 M = *a.n_matches;
+  if (M > a.max_matches) M = a.max_matches;
+  const u32 n_groups = gridDim.x * (LM_BLOCK / 16);
+  {  // every slot of the launch gets its flag (no memset): the slots beyond the match count, dealt to all threads of the grid
+    const u32 gid = blockIdx.x * LM_BLOCK + threadIdx.x, nth = gridDim.x * LM_BLOCK;
+    for (u32 i = M + gid; i < a.max_matches; i += nth) a.out_flags[i] = 0u;
+  }
+  const bool probe = a.clk != nullptr && threadIdx.x == 0 && blockIdx.x % CLK_STRIDE == 0u;
+  if (probe) {
+    u64* sc = a.clk + CLK_SCRATCH + 2 * (size_t)(blockIdx.x / CLK_STRIDE);
+    sc[0] = __builtin_readcyclecounter();
+    sc[1] = __builtin_amdgcn_s_memrealtime();
+  }
+  LmProblemT<true> pr;
+  {
+    const int n_bytes = p.W * p.H;
+    pr.tsL = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.tsL), 0, n_bytes, 0x00020000);
+    pr.tsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.tsR), 0, n_bytes, 0x00020000);
+  }
+  pr.cam = lds_cam;
+  pr.c = c;
+  pr.rg = 0;
+  pr.vy0 = 0; pr.vy1 = p.H;
+  double* Tm = lds_T[threadIdx.x >> 4];
+  pr.T = Tm;
+  pr.cx = pr.cy = -1e9;
+  pr.ray[0] = pr.ray[1] = pr.ray[2] = 0.;
+  const int N = LM_ROWS * LM_COLS;
+  const double ftol = 1e-6, xtol = 1e-6, gtol = 0., factor = 100.;
+  const double eps = 2.220446049250313e-16;
+  const double sqrt_eps = 1.4901161193847656e-08;  // sqrt(DBL_EPSILON), exact
+  const int maxfev = p.lm_maxfev;
+  double x = 1.0;
+  double fvec[RL], out[RL];
+  LmCache<WIDE> cc;
+  cc.clear();
+  double fnorm = 0., par = 0., diag = 0., xnorm = 0., delta = 0., r = 0., qtf = 0., gnorm = 0.;
+  double h = 0., xnew = 0., wa1 = 0., pnorm = 0.;
+  int nfev = 1, iter = 1, iteration = 0, optState = 0;
+  int phase = 0;
+  bool need_step = false, fvec_tight = false;
+  double xe = x;
+  u32 s = (blockIdx.x * LM_BLOCK + threadIdx.x) >> 4;  // the group's first match: its own position; later ones: n_groups + counter
+  u32 j = 0, pose_idx = 0;
+  bool need_new = true, first = true;
+  while (true) {
+    if (need_new) {  // (group-uniform)
+      if (!first) {
+        u32 t = 0;
+        if (lead) t = atomicAdd(next, 1u);
+        s = n_groups + __shfl(t, 0, 16);
+      }
+      first = false;
+      need_new = false;
+      if (s >= M) break;  // the list is exhausted: the group retires (the wave ends when its four groups have)
+      j = a.dense ? s : stride_item(s, M, (u32)p.num_threads);  // DepthProblemSolver.cpp:90
+      const esvo_match_t m = a.matches[j];
+      pose_idx = m.pose_idx;
+      pr.cx = m.x_left[0];
+      pr.cy = m.x_left[1];
+#pragma unroll
+      for (int r3 = 0; r3 < 3; ++r3)
+        pr.ray[r3] = (p.camL.Kinv[r3 * 3 + 0] * pr.cx + p.camL.Kinv[r3 * 3 + 1] * pr.cy) + p.camL.Kinv[r3 * 3 + 2];
+#ifdef LM_STATS
+      pr.dbg_slot = s;
+#endif
+      {  // DepthProblem::setProblem, DepthProblem.cpp:17-32: T_left_virtual = T_world_obs^-1 T_world_virtual, element c by lane c < 12
+         // (mat4_mul's association: ((a0 b0 + a1 b1) + a2 b2) + a3 b3)
+        double Tlw[16];
+        rigid_inverse(a.T_world_obs, Tlw);
+        const int ti = (c >> 2) < 3 ? (c >> 2) : 0, tj = c & 3;
+        const double a0 = ti == 0 ? Tlw[0] : (ti == 1 ? Tlw[4] : Tlw[8]), a1 = ti == 0 ? Tlw[1] : (ti == 1 ? Tlw[5] : Tlw[9]);
+        const double a2 = ti == 0 ? Tlw[2] : (ti == 1 ? Tlw[6] : Tlw[10]), a3 = ti == 0 ? Tlw[3] : (ti == 1 ? Tlw[7] : Tlw[11]);
+        const double* B = a.pose_T + (size_t)pose_idx * 16;
+        const double v = ((a0 * B[0 * 4 + tj] + a1 * B[1 * 4 + tj]) + a2 * B[2 * 4 + tj]) + a3 * B[3 * 4 + tj];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the previous match's reads of Tm are done (same wave: LDS is in order)
+        if (c < 12) Tm[c] = v;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+      x = m.inv_depth;
+      cc.clear();
+      fnorm = par = diag = xnorm = delta = r = qtf = gnorm = 0.;
+      h = xnew = wa1 = pnorm = 0.;
+      nfev = 1; iter = 1; iteration = 0; optState = 0;
+      phase = 0;
+      need_step = false;
+      fvec_tight = false;
+      xe = x;
+    }
+    if (need_step) {  // determine the LM parameter and the trial point (minimizeOneStep, inner loop head)
+      const double pstep = lm_lmpar2(r, diag, qtf, delta, par);
+      wa1 = -pstep;
+      xnew = x + wa1;
+      pnorm = fabs(diag * wa1);
+      if (iter == 1) delta = (pnorm < delta) ? pnorm : delta;
+      xe = xnew;
+      need_step = false;
+    }
+    const bool out_tight = lm_eval<WIDE, L2, false, false, true>(p, pr, cc, xe, out);
+    int status = -1;
+    bool outer_tail = false;
+    if (phase == 0) {  // minimizeInit
+      fvec_tight = out_tight;
+#pragma unroll
+      for (int y = 0; y < RL; ++y) fvec[y] = out[y];
+      fnorm = sqrt(patch_dot<WIDE>(fvec, fvec, 0));
+      par = 0.;
+      iter = 1;
+    } else if (phase == 1) {  // NumericalDiff<Forward>::df (see lm_refine_kernel)
+      double fjac[RL];
+      {
+        const Recip rh = make_recip(h);
+        if (out_tight && fvec_tight && rh.fast) {
+#pragma unroll
+          for (int y = 0; y < RL; ++y) fjac[y] = div_fast(out[y] - fvec[y], rh);
+        } else {
+#pragma unroll
+          for (int y = 0; y < RL; ++y) fjac[y] = (out[y] - fvec[y]) / h;
+        }
+      }
+      nfev += 2;
+      const double wa2n = sqrt(patch_dot<WIDE>(fjac, fjac, 0));
+      const double jtf = patch_dot<WIDE>(fjac, fvec, 0);
+      r = wa2n;
+      const double fvec0 = __shfl(fvec[0], 0, 16);  // element (0, 0) of the patch
+      qtf = (r != 0.) ? jtf / r : fvec0;
+      if (iter == 1) {
+        diag = (wa2n == 0.) ? 1. : wa2n;
+        xnorm = fabs(diag * x);
+        delta = factor * xnorm;
+        if (delta == 0.) delta = factor;
+      }
+      gnorm = 0.;
+      if (fnorm != 0.)
+        if (wa2n != 0.) { const double g = fabs(r * (qtf / fnorm) / wa2n); gnorm = (gnorm < g) ? g : gnorm; }
+      if (gnorm <= gtol) {
+        status = 4;
+        outer_tail = true;
+      } else {
+        diag = (diag < wa2n) ? wa2n : diag;
+        need_step = true;
+        phase = 2;
+      }
+    } else {  // phase 2: trust-region trial at xnew
+      ++nfev;
+      const double fnorm1 = sqrt(patch_dot<WIDE>(out, out, 0));
+      double actred = -1.;
+      if (0.1 * fnorm1 < fnorm) actred = 1. - (fnorm1 / fnorm) * (fnorm1 / fnorm);
+      const double wa3 = r * wa1;
+      const double t1 = fabs(wa3) / fnorm, temp1 = t1 * t1;
+      const double t2 = sqrt(par) * pnorm / fnorm, temp2 = t2 * t2;
+      const double prered = temp1 + temp2 / 0.5;
+      const double dirder = -(temp1 + temp2);
+      double ratio = 0.;
+      if (prered != 0.) ratio = actred / prered;
+      if (ratio <= 0.25) {
+        double temp = 0.5;
+        if (actred >= 0.) temp = 0.5;
+        if (actred < 0.) temp = 0.5 * dirder / (dirder + 0.5 * actred);
+        if (0.1 * fnorm1 >= fnorm || temp < 0.1) temp = 0.1;
+        const double pn = pnorm / 0.1;
+        delta = temp * ((pn < delta) ? pn : delta);
+        par /= temp;
+      } else if (!(par != 0. && ratio < 0.75)) {
+        delta = pnorm / 0.5;
+        par = 0.5 * par;
+      }
+      if (ratio >= 1e-4) {
+        x = xnew;
+        fvec_tight = out_tight;
+#pragma unroll
+        for (int y = 0; y < RL; ++y) fvec[y] = out[y];
+        xnorm = fabs(diag * x);
+        fnorm = fnorm1;
+        ++iter;
+      }
+      if (fabs(actred) <= ftol && prered <= ftol && 0.5 * ratio <= 1. && delta <= xtol * xnorm) status = 3;
+      else if (fabs(actred) <= ftol && prered <= ftol && 0.5 * ratio <= 1.) status = 1;
+      else if (delta <= xtol * xnorm) status = 2;
+      else if (nfev >= maxfev) status = 5;
+      else if (fabs(actred) <= eps && prered <= eps && 0.5 * ratio <= 1.) status = 6;
+      else if (delta <= eps * xnorm) status = 7;
+      else if (gnorm <= eps) status = 8;
+      if (status >= 0 || !(ratio < 1e-4)) outer_tail = true;  // minimizeOneStep returns (status or Running)
+      else need_step = true;                                   // do { ... } while (ratio < 1e-4)
+    }
+    bool finished = false;
+    if (phase == 0) {
+      phase = 1;
+    } else if (outer_tail) {  // the reference's outer loop, DepthProblemSolver.cpp:161-188
+      iteration++;
+      if (iteration >= p.lm_max_iter) finished = true;
+      else if (status == 2 || status == 3) {
+        if (optState == 0) optState++;
+        else finished = true;
+      }
+      if (!finished) phase = 1;
+    }
+    if (finished) {  // the match is solved: its point (lm_refine_kernel's epilogue), then the group asks for the next match
+      if (lead) {
+        const bool solved = !(x <= 0.001);  // DepthProblemSolver.cpp:192
+        bool keep = solved;
+        if (solved) {
+          atomicAdd(n_solved, 1u);
+          const double invJtJ = (r != 0.) ? (1. / r) * (1. / r) : 0.;  // internal::covar, n == 1
+          double variance;
+          if constexpr (L2) {
+            variance = fnorm * fnorm / (double)(N - 1) * invJtJ;
+            if (variance < 1e-6) variance = 1e-6;
+          } else {
+            variance = p.td_stdvar2 * invJtJ;                          // :210
+          }
+          const double residual = fnorm * fnorm;                       // :212
+          DevPoint o;
+          o.row = (u32)(size_t)floor(pr.cy);  // :116
+          o.col = (u32)(size_t)floor(pr.cx);
+          o.x[0] = pr.cx;
+          o.x[1] = pr.cy;
+          cam2World(p.camL, pr.cx, pr.cy, x, o.p_cam);                 // :119
+#ifdef ESVO_PERTURB_ONE_ULP
+          if ((s & 7u) == 7u) o.p_cam[2] = __longlong_as_double(__double_as_longlong(o.p_cam[2]) ^ 1ll);  // (see lm_refine_kernel)
+#endif
+          o.inv_depth = x;
+          o.scale2 = L2 ? 0.0 : variance * (p.td_nu - 2) / p.td_nu;    // :125
+          o.nu = L2 ? 0.0 : p.td_nu;
+          o.variance = variance;
+          o.residual = residual;
+          o.age = 0;
+          o.pose_idx = pose_idx;
+          o.seq = j;
+          if (a.cull)  // pointCulling, :230-234
+            keep = variance <= p.var_thr && residual <= p.cost_thr && x > -1e-6 && x >= p.invdepth_min && x <= p.invdepth_max;
+          if (keep) a.out_slots[s] = o;
+        }
+        a.out_flags[s] = keep ? 1u : 0u;
+      }
+      need_new = true;
+      continue;
+    }
+    if (phase == 1) {  // next evaluation: F(x + h) for the forward difference
+      h = sqrt_eps * fabs(x);
+      if (h == 0.) h = sqrt_eps;
+      xe = x + h;
+    }
+  }
+  if (probe) {
+    const u64* sc = a.clk + CLK_SCRATCH + 2 * (size_t)(blockIdx.x / CLK_STRIDE);
+    const u64 c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+    u32 xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+    xcc &= CLK_XCDS - 1;
+    atomicAdd(&a.clk[2 * xcc], c1 - sc[0]);
+    atomicAdd(&a.clk[2 * xcc + 1], r1 - sc[1]);
+    atomicAdd(&a.clk[CLK_SAMPLES], 1ull);
+  }
+}
+
 #ifdef LM_STATS
 extern "C" void esvo_debug_lm_counters(unsigned long long out[8]) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lm_dbg), 64); }
 extern "C" void esvo_debug_lm_slots(unsigned int* out, int clear) {  // out[3][1 << 18]
@@ -1023,6 +1315,11 @@ void launch_lm_refine(const LmArgs& a, const DevParams& p, u32* n_solved, hipStr
     hipLaunchKernelGGL((lm_refine_kernel<false, false, 1>), dim3(blocks), dim3(LM_BLOCK), 0, s, a, p, n_solved, sp);
     hipLaunchKernelGGL(lm_order_kernel, dim3((a.max_matches + 255) / 256), dim3(256), 0, s, a.n_matches, a.max_matches, sp);
     hipLaunchKernelGGL((lm_refine_kernel<false, false, 2>), dim3(blocks), dim3(LM_BLOCK), 0, s, a, p, n_solved, sp);
+    return;
+  }
+  if (a.persist_next) {  // the persistent layout: as many workgroups as the chip holds beside the other stages (two waves per SIMD)
+    const u32 grid = blocks < a.persist_blocks ? blocks : a.persist_blocks;
+    hipLaunchKernelGGL((lm_refine_persist_kernel<false>), dim3(grid), dim3(LM_BLOCK), 0, s, a, p, n_solved, a.persist_next);
     return;
   }
   hipLaunchKernelGGL((lm_refine_kernel<false, false, 0>), dim3(blocks), dim3(LM_BLOCK), 0, s, a, p, n_solved, sp);

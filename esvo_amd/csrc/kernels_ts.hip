@@ -428,7 +428,7 @@ __global__ void __launch_bounds__(256) ts_render_fused_kernel(TsPair c, int W, i
 // ESVO_TS_STAGE_CAP (tests only): a smaller staging capacity, down to 0 = every tile on the direct path
 static int ts_stage_cap() {
   static const int cap = [] {
-    const char* e = std::getenv("ESVO_TS_STAGE_CAP");
+    const char* e = esvo_dev_switch("ESVO_TS_STAGE_CAP");
     const int v = e ? std::atoi(e) : TSF_CAP;
     return v < 0 ? 0 : (v > TSF_CAP ? TSF_CAP : v);
   }();

@@ -31,7 +31,7 @@ SYMBOLS = [
     "esvo_track_normal_equations", "esvo_track_register",
     "esvo_map_init_sgm",
     "esvo_bag_open", "esvo_bag_close", "esvo_bag_last_error", "esvo_bag_next_event_array", "esvo_ts_push_bag",
-    "esvo_map_get_debug_images", "esvo_map_get_pointcloud_near_xyz", "esvo_voxel_filter_xyz",
+    "esvo_map_get_debug_images", "esvo_map_get_pointcloud_near_xyz", "esvo_voxel_filter_xyz", "esvo_map_save_depth_map",
     "esvo_comm_unique_id", "esvo_comm_rccl_info", "esvo_comm_init", "esvo_comm_init_callbacks", "esvo_comm_destroy", "esvo_comm_owns_next_tick",
     "esvo_comm_tick", "esvo_comm_flush", "esvo_comm_newest_map", "esvo_comm_shard_tick", "esvo_comm_gather_map",
 ]
@@ -176,6 +176,7 @@ def load():
     lib.esvo_map_get_debug_images.argtypes = [vp, C.c_double, vp, vp, vp, vp]
     lib.esvo_map_get_pointcloud_near_xyz.argtypes = [vp, C.c_double, vp, sz, psz]
     lib.esvo_voxel_filter_xyz.argtypes = [vp, sz, C.c_float, vp, sz, psz]
+    lib.esvo_map_save_depth_map.argtypes = [vp, C.c_char_p, u64, psz]
     lib.esvo_comm_unique_id.argtypes = [vp]
     lib.esvo_comm_init.argtypes = [vp, vp, i32, i32]
     lib.esvo_comm_rccl_info.argtypes = [C.POINTER(C.c_int), C.c_char_p, sz]
@@ -486,6 +487,12 @@ class Esvo:
         out = np.zeros((self.W * self.H, 3), np.float32)
         self._ck(self.lib.esvo_map_get_pointcloud_near_xyz(self.h, float(visualize_range), out.ctypes.data, out.shape[0], C.byref(n)))
         return out[: n.value].copy()
+
+    def save_depth_map(self, save_dir, t_ns):
+        """esvo_MVStereo::saveDepthMap: writes <save_dir><t_ns>.txt ("x y depth" per valid element); returns the line count"""
+        n = C.c_size_t()
+        self._ck(self.lib.esvo_map_save_depth_map(self.h, str(save_dir).encode(), int(t_ns), C.byref(n)))
+        return int(n.value)
 
     def get_last_frame(self):
         n = C.c_size_t(0)

@@ -414,6 +414,11 @@ int esvo_map_get_pointcloud_near_xyz(esvo_handle h, double visualize_range, floa
  * One centroid per occupied voxel, ascending voxel index; the node appends the last NumGPC_added_per_refresh - 1 of them
  * to its global cloud (:966-969). */
 int esvo_voxel_filter_xyz(const float* xyz, size_t n, float leaf, float* out_xyz, size_t cap_points, size_t* n_out);
+/* Replaces esvo_MVStereo::saveDepthMap (esvo_MVStereo.cpp:982-1000; the call sites at :302, :373, :521 are compiled out upstream
+ * with `if (false)`: "to save the depth result, set it to true"): writes <save_dir><t_ns>.txt, one line "x y depth" per valid
+ * element of the DepthMap in list order, formatted as Eigen's operator<< and the ofstream format it.  save_dir is used as a
+ * prefix exactly as upstream does (it must end with the path separator).  n_written (nullable): lines written. */
+int esvo_map_save_depth_map(esvo_handle h, const char* save_dir, uint64_t t_ns, size_t* n_written);
 /* The newest frame of the fusion window (culled DepthPoints of the last tick). */
 int esvo_map_get_last_frame(esvo_handle h, esvo_depth_point_t* out, size_t cap, size_t* n);
 int esvo_get_stats(esvo_handle h, esvo_stats_t* out);

@@ -6,6 +6,9 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# the library reads its A/B and test switches (ESVO_FUSE_TILE_CAP, ESVO_LM_PAIR, ESVO_TS_STAGE_CAP ...) only when this is set:
+# several tests force rare code paths with them, also in child processes
+os.environ.setdefault("ESVO_DEV_SWITCHES", "1")
 
 
 def pytest_configure(config):

@@ -69,3 +69,16 @@ def test_debug_images_and_near_cloud_equal_the_oracle(request, preset, rig_fix, 
         a, b = dev.get_pointcloud_near(rng_), m.get_pointcloud_near(rng_)
         assert len(a) == len(b) and np.array_equal(a, b)
     assert len(dev.get_pointcloud_near(1e9)) == len(dev.get_pointcloud())
+    # esvo_MVStereo::saveDepthMap (esvo_MVStereo.cpp:982-1000): "<x> <y> <depth>" per valid element, list order; the 1 x 2 row vector
+    # in Eigen's default format (6 significant digits, both coefficients right-aligned to the longer one), the depth as the stream prints it
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        n = dev.save_depth_map(d + os.sep, 1234567890123)
+        lines = open(os.path.join(d, "1234567890123.txt")).read().split("\n")
+    mp = m.get_map()
+    valid = mp[mp["inv_depth"] > -1e-6]
+    assert n == len(valid) > 50 and lines[-1] == "" and len(lines) == n + 1
+    for ln, e in zip(lines, valid):
+        a, b = "%g" % e["x"][0], "%g" % e["x"][1]
+        w = max(len(a), len(b))
+        assert ln == f"{a:>{w}} {b:>{w}} {'%g' % e['p_cam'][2]}", (ln, e)

@@ -1,6 +1,7 @@
 #!/bin/bash
 # usage (GPU box): bash tools/ab_bench.sh <rounds> <variant> [<variant> ...]   variant = name of tools/ab/libesvo_hip_<name>.so, or "cur"
 # interleaved bench runs on one box: ms/tick and per-stage HIP-event times of every variant, <rounds> times
+export ESVO_DEV_SWITCHES=1   # the library reads its A/B switches only with this set
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 rounds=$1; shift
 for r in $(seq 1 $rounds); do

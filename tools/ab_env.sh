@@ -1,5 +1,6 @@
 #!/bin/bash
 # usage (GPU box): bash tools/ab_env.sh <rounds> "<ENV=VAL ...>" ["<ENV=VAL ...>" ...]  -- bench of the current library under different environments
+export ESVO_DEV_SWITCHES=1   # the library reads its A/B switches only with this set
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 rounds=$1; shift
 for r in $(seq 1 $rounds); do

@@ -1,5 +1,6 @@
 #!/bin/bash
 # usage (GPU box): bash tools/ab_lm.sh <tag> [lib path]   -- lm_refine: VALU instruction count per launch + kernel time, bench workload
+export ESVO_DEV_SWITCHES=1   # the library reads its A/B switches only with this set
 tag=$1
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 if [ -n "$2" ]; then export ESVO_HIP_LIB=$root/$2; fi

@@ -1,5 +1,6 @@
 #!/bin/bash
 # usage (GPU box): bash tools/ab_small.sh <variant> [<variant> ...]   -- reference-faithful ticks (synchronised / pipelined) per library variant
+export ESVO_DEV_SWITCHES=1   # the library reads its A/B switches only with this set
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 export ESVO_BENCH_STREAM_CACHE=/tmp/esvo_streams
 for r in 1 2; do

@@ -1,6 +1,7 @@
 #!/bin/bash
 # usage (GPU box): bash tools/ab_sustained.sh <rounds> <ticks> <variant> [<variant> ...]   variant = name of tools/ab/libesvo_hip_<name>.so, or "cur"
 # interleaved SUSTAINED runs (tools/sustained_probe.py) on one box
+export ESVO_DEV_SWITCHES=1   # the library reads its A/B switches only with this set
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 rounds=$1; ticks=$2; shift; shift
 export ESVO_BENCH_STREAM_CACHE=/tmp/esvo_streams

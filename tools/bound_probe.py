@@ -6,6 +6,7 @@ points per tick and the shader clock measured inside the run (esvo_stats_t::clk_
 work says which stage(s) it waits for.  usage: python tools/bound_probe.py [workload] [ticks] [repeats] > gpurun_out/bound.json"""
 import json
 import os
+os.environ.setdefault("ESVO_DEV_SWITCHES", "1")   # the library reads its A/B switches only with this set
 import sys
 import time
 

@@ -2,6 +2,7 @@
 # usage (GPU box): bash tools/pmc_groups.sh <tag> "<ENV=VAL ...>" "<counters of pass 1>" ["<counters of pass 2>" ...]
 # One rocprofv3 --pmc pass per counter group (a group must fit one pass) over a short bench run; per-kernel averages of the
 # main kernels -> gpurun_out/<tag>_pmc.txt.  Counter passes only (--kernel-trace, no other trace domain).
+export ESVO_DEV_SWITCHES=1   # the library reads its A/B switches only with this set
 tag=$1; envs=$2; shift 2
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out

@@ -1,3 +1,4 @@
+export ESVO_DEV_SWITCHES=1   # the library reads its A/B switches only with this set
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_BUSY_CYCLES -d $GRAFT_REPO_ROOT/gpurun_out/$1 -o x -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > /dev/null 2>&1
 python - <<PY

@@ -4,6 +4,7 @@ handle ticking the same workload for a few ticks in the middle of the run (its k
 the pipeline fall behind), then nothing: ms per tick over 100-tick windows before, during and after.  A pipeline with a
 second stable operating point stays slow after the disturbance.  usage: python tools/regime_probe.py [ticks] [tag]"""
 import os
+os.environ.setdefault("ESVO_DEV_SWITCHES", "1")   # the library reads its A/B switches only with this set
 import sys
 
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))

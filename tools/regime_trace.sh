@@ -1,6 +1,7 @@
 #!/bin/bash
 # usage (GPU box): bash tools/regime_trace.sh  -- kernel trace of the sustained workload, a 3 ms stall of the back queue at tick 300:
 # two steady-state ticks BEFORE (fast operating point) and AFTER (slow one), stream by stream
+export ESVO_DEV_SWITCHES=1   # the library reads its A/B switches only with this set
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 out=$root/gpurun_out/regime_trace

@@ -1,5 +1,6 @@
 #!/bin/bash
 # usage (GPU box): bash tools/small_trace.sh <workload> <events>  -- one synchronised reference-faithful tick, op by op
+export ESVO_DEV_SWITCHES=1   # the library reads its A/B switches only with this set
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 out=$root/gpurun_out/small_$1

@@ -1,5 +1,6 @@
 #!/bin/bash
 # usage (GPU box): bash tools/trace_modes.sh "<ENV=VAL ...>" ...   -- kernel trace of the bench under each environment -> stream_trace
+export ESVO_DEV_SWITCHES=1   # the library reads its A/B switches only with this set
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 i=0

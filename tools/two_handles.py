@@ -1,6 +1,7 @@
 """How much issue slack is left beside one handle's tick pipeline?  Two independent handles on one GPU, ticks interleaved
 from one host thread, against one handle alone.  usage: python tools/two_handles.py [workload] [ticks]"""
 import os, sys, time
+os.environ.setdefault("ESVO_DEV_SWITCHES", "1")   # the library reads its A/B switches only with this set
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench
 from esvo_amd import lib
