@@ -136,7 +136,7 @@ def selftest(rank, world, local_rank, dist, ranks_seen, rccl, n_ticks=6):
 
 
 
-def band_share(workload, device, shards=(8, 16), steps=6, warmup=3, events_cap=0):
+def band_share(workload, device, shards=(8,), steps=5, warmup=2, events_cap=0):
     """What ONE rank of an N-GPU band-mode run computes per tick, measured on this one GPU -- a PROJECTION, not a scaling
     measurement: G logical shards (handles; row bands of the image, events routed by row, banded Time Surfaces: exactly the
     configuration `--gpus G` runs in band mode) map the headline workload; the two all-gathers of a tick are emulated by
@@ -144,7 +144,9 @@ def band_share(workload, device, shards=(8, 16), steps=6, warmup=3, events_cap=0
     Every shard's stage -- both Time-Surface renders + the observation, phases 0 / 1 / 2 -- runs ALONE on the GPU and is
     followed by a synchronisation, so a rank's share is the sum of its own stage times, launch overheads included; the same
     procedure on one unsharded handle (`full_tick_ms_synchronised`) is what it is compared with.
-    replicated_ms: the part of a rank's share that does not shrink with N, from share(G) = a + b / G at G = 8 and 16."""
+    replicated_ms_at_8: the work that is the same on every rank whatever N is (phase 1: the frame order of the whole tick), measured.
+    With two shard counts (tools/band_share_probe.py dsec640x480 8 16) share(G) = a + b / G is fitted as well: a = the floor a
+    rank's tick does not go below however little of the image it owns (latency of its kernels' dependent chains, not replication)."""
     import torch
     rig, stream, p, ticks = make_workload(workload, max(steps + warmup, 40), events_cap)
     ticks = ticks[: steps + warmup]
