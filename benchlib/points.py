@@ -219,8 +219,8 @@ def _points(device, which):
                 "cycles": len(r["cycle_ms"]), "path_mm": r["gt_len"][-1] * 1e3, "final_position_error_mm": r["pos_err"][-1] * 1e3,
                 "depth_points_per_cycle": int(np.median(r["points"])), "map_median_abs_inv_depth_error": r["map_median_abs_err"],
                 "note": "synthetic 346x260 scene, poses from the tracker only (bootstrap pose given); tracker optimiser = "
-                        "esvo_track_register (host C++ over esvo_track_normal_equations: one launch and 224 B back per iteration, "
-                        "12 Gauss-Newton iterations at most)"}
+                        "esvo_track_register (host C++ over esvo_track_normal_equations_batch: Levenberg-damped steps with Eigen's "
+                        "accept test, the three trial dampings of an iteration in one launch, 12 iterations at most)"}
 
     def point(key, fn, *a, **kw):   # an extra never takes the headline down with it: its failure is reported in its place
         try:

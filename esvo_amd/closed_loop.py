@@ -35,7 +35,7 @@ def orth(R):
 
 def register(dev, n_points, R_, t_, iters=12):
     """The registration of one frame: the library's driver (esvo_track_register: host C++ over esvo_track_normal_equations,
-    one launch and 224 bytes back per iteration)."""
+    the three trial dampings of an iteration in one launch, 224 bytes back per trial)."""
     R, t, rms, _ = dev.track_register(n_points, R_, t_, huber=True, huber_threshold=50.0, max_iterations=iters, damping=1e-3)
     return R, t, rms
 
@@ -43,11 +43,13 @@ def register(dev, n_points, R_, t_, iters=12):
 def lm_gn_loop(evaluate, R_, t_, iters=12, damping=1e-3):
     """include/esvo_hip.hpp's gauss_newton_register in numpy (same batch every iteration): Levenberg-damped Gauss-Newton steps
     linearised at x = 0, each accepted only if actual / predicted reduction >= 1e-4 (cost evaluated at the trial pose), the
-    damping raised tenfold otherwise.  evaluate(R, t) -> (H, b, cost, n).  Returns (R, t, rms, iterations)."""
+    damping raised tenfold otherwise (6 attempts), lowered tenfold (not below `damping`) after an accepted step and carried
+    over.  The C++ driver evaluates three trial dampings per call; taking the first acceptable one in rising order is what this
+    sequential loop does.  evaluate(R, t) -> (H, b, cost, n).  Returns (R, t, rms, iterations)."""
     H, b, cost, n = evaluate(R_, t_)
-    it = 0
+    it, lam = 0, damping
     for it in range(iters):
-        lam, accepted = damping, False
+        accepted = False
         for _ in range(6):
             dx = np.linalg.solve(H + lam * np.diag(np.diag(H)) + 1e-9 * np.eye(6), -b)
             dR = cayley2rot(dx[:3])
@@ -61,6 +63,7 @@ def lm_gn_loop(evaluate, R_, t_, iters=12, damping=1e-3):
         if not accepted:
             break
         R_, t_, H, b, cost, n = Rn, tn, Ht, bt, cost_t, nt
+        lam = max(lam / 10.0, damping)
         if np.linalg.norm(dx) < 1e-6:
             break
     return R_, t_, float(np.sqrt(cost / n)) if n else 0.0, it + 1

@@ -150,52 +150,68 @@ int esvo_track_jacobian(esvo_handle h, const double R[9], const double t[3], siz
   return ESVO_OK;
 }
 
-// f = operator()(0), J = df(0) and their products in one launch: H = J^T J (6 x 6, row-major, symmetric), b = J^T f, cost = |f|^2
-int esvo_track_normal_equations(esvo_handle h, const double R[9], const double t[3], size_t offset, size_t count, int ls_norm,
-                                double huber_threshold, double H[36], double b[6], double* cost, size_t* n_out) {
-  if (!h || !R || !t || !H || !b || !n_out || (ls_norm != ESVO_TRACK_L2 && ls_norm != ESVO_TRACK_HUBER)) return ESVO_ERR_INVALID_ARG;
+static_assert(ESVO_TRACK_MAX_POSES == TRK_NE_MAX_POSES, "the ABI's pose limit is the kernel's");
+// f = operator()(0), J = df(0) and their products in one launch: H = J^T J (6 x 6, row-major, symmetric), b = J^T f, cost = |f|^2;
+// n_poses of them (one workgroup each) share the launch and the read-back
+int esvo_track_normal_equations_batch(esvo_handle h, int n_poses, const double* R, const double* t, size_t offset, size_t count,
+                                      int ls_norm, double huber_threshold, double* H, double* b, double* cost, size_t* n_out) {
+  if (!h || !R || !t || !H || !b || !n_out || n_poses < 1 || n_poses > ESVO_TRACK_MAX_POSES ||
+      (ls_norm != ESVO_TRACK_L2 && ls_norm != ESVO_TRACK_HUBER))
+    return ESVO_ERR_INVALID_ARG;
   std::lock_guard<std::mutex> _trk_lock(h->mu_track);
   if (!h->trk_cur) FAIL(ESVO_ERR_STATE, "esvo_track_set_current has not been called");
   HIPCHK(hipSetDevice(h->device));
   const size_t m = offset >= h->trk_n ? 0 : std::min(count, h->trk_n - offset);
   *n_out = m;
-  std::memset(H, 0, sizeof(double) * 36);
-  std::memset(b, 0, sizeof(double) * 6);
-  if (cost) *cost = 0.0;
+  std::memset(H, 0, sizeof(double) * 36 * n_poses);
+  std::memset(b, 0, sizeof(double) * 6 * n_poses);
+  if (cost) std::memset(cost, 0, sizeof(double) * n_poses);
   if (m == 0) return ESVO_OK;
-  if (!h->h_trk_ne) HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h->h_trk_ne), sizeof(double) * TRK_NE_TERMS));
+  if (!h->h_trk_ne) HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h->h_trk_ne), sizeof(double) * TRK_NE_TERMS * TRK_NE_MAX_POSES));
   TrackArgs a;
   fill_track_args(h, a);
-  TrackPose pose;  // as esvo_track_jacobian: T_left_ref = [R^T | -R^T t] (RegProblemLM.cpp:203-205), J_constPart (:189-194)
-  std::memset(pose.T, 0, sizeof(pose.T));
-  for (int r = 0; r < 3; ++r) {
-    for (int c = 0; c < 3; ++c) pose.T[r * 4 + c] = R[c * 3 + r];
-    pose.T[r * 4 + 3] = (-R[0 * 3 + r] * t[0] + -R[1 * 3 + r] * t[1]) + -R[2 * 3 + r] * t[2];
-  }
-  pose.T[15] = 1.0;
+  TrackPoseSet set;  // as esvo_track_jacobian: T_left_ref = [R^T | -R^T t] (RegProblemLM.cpp:203-205), J_constPart (:189-194)
+  std::memset(&set, 0, sizeof(set));
   const double iP11 = 1.0 / a.P[0], iP22 = 1.0 / a.P[5];
-  for (int r = 0; r < 3; ++r) { pose.Jc[r * 2 + 0] = R[0 * 3 + r] * iP11; pose.Jc[r * 2 + 1] = R[1 * 3 + r] * iP22; }
-  launch_track_normal(a, pose, (u32)offset, (u32)m, ls_norm == ESVO_TRACK_HUBER, huber_threshold, h->d_trk_out, h->stream_t);
+  for (int q = 0; q < n_poses; ++q) {
+    TrackPose& pose = set.p[q];
+    const double *Rq = R + 9 * q, *tq = t + 3 * q;
+    for (int r = 0; r < 3; ++r) {
+      for (int c = 0; c < 3; ++c) pose.T[r * 4 + c] = Rq[c * 3 + r];
+      pose.T[r * 4 + 3] = (-Rq[0 * 3 + r] * tq[0] + -Rq[1 * 3 + r] * tq[1]) + -Rq[2 * 3 + r] * tq[2];
+    }
+    pose.T[15] = 1.0;
+    for (int r = 0; r < 3; ++r) { pose.Jc[r * 2 + 0] = Rq[0 * 3 + r] * iP11; pose.Jc[r * 2 + 1] = Rq[1 * 3 + r] * iP22; }
+  }
+  launch_track_normal(a, set, n_poses, (u32)offset, (u32)m, ls_norm == ESVO_TRACK_HUBER, huber_threshold, h->d_trk_out, h->stream_t);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(h->h_trk_ne, h->d_trk_out, sizeof(double) * TRK_NE_TERMS, hipMemcpyDeviceToHost, h->stream_t));
+  HIPCHK(hipMemcpyAsync(h->h_trk_ne, h->d_trk_out, sizeof(double) * TRK_NE_TERMS * n_poses, hipMemcpyDeviceToHost, h->stream_t));
   HIPCHK(hipStreamSynchronize(h->stream_t));
   h->trk_xyz_inflight = false;
-  int n = 0;
-  for (int i = 0; i < 6; ++i)
-    for (int j = i; j < 6; ++j) { H[i * 6 + j] = H[j * 6 + i] = h->h_trk_ne[n]; ++n; }
-  for (int i = 0; i < 6; ++i) b[i] = h->h_trk_ne[21 + i];
-  if (cost) *cost = h->h_trk_ne[27];
+  for (int q = 0; q < n_poses; ++q) {
+    const double* s = h->h_trk_ne + (size_t)q * TRK_NE_TERMS;
+    double* Hq = H + 36 * q;
+    int n = 0;
+    for (int i = 0; i < 6; ++i)
+      for (int j = i; j < 6; ++j) { Hq[i * 6 + j] = Hq[j * 6 + i] = s[n]; ++n; }
+    for (int i = 0; i < 6; ++i) b[6 * q + i] = s[21 + i];
+    if (cost) cost[q] = s[27];
+  }
   return ESVO_OK;
+}
+int esvo_track_normal_equations(esvo_handle h, const double R[9], const double t[3], size_t offset, size_t count, int ls_norm,
+                                double huber_threshold, double H[36], double b[6], double* cost, size_t* n_out) {
+  return esvo_track_normal_equations_batch(h, 1, R, t, offset, count, ls_norm, huber_threshold, H, b, cost, n_out);
 }
 
 // The registration of one frame: esvo_hip::gauss_newton_register (include/esvo_hip.hpp, host C++) over
-// esvo_track_normal_equations -- one launch and 224 bytes back per iteration.
+// esvo_track_normal_equations_batch -- the (up to three) trial steps of an iteration in one launch, 224 bytes back per trial.
 int esvo_track_register(esvo_handle h, size_t n_points, double R[9], double t[3], int ls_norm, double huber_threshold,
                         int max_iterations, double damping, double* rms, int* iterations) {
   if (!h || !R || !t || max_iterations < 1) return ESVO_ERR_INVALID_ARG;
   int rc = ESVO_OK;
-  auto ne = [&](int, const double* Rc, const double* tc, double* H, double* b, double* cost, size_t* n) {
-    rc = esvo_track_normal_equations(h, Rc, tc, 0, n_points, ls_norm, huber_threshold, H, b, cost, n);
+  auto ne = [&](int, int k, const double* Rc, const double* tc, double* H, double* b, double* cost, size_t* n) {
+    rc = esvo_track_normal_equations_batch(h, k, Rc, tc, 0, n_points, ls_norm, huber_threshold, H, b, cost, n);
     return rc == ESVO_OK;
   };
   const esvo_hip::Registration res = esvo_hip::gauss_newton_register(ne, R, t, max_iterations, damping);

@@ -251,6 +251,8 @@ void launch_matches_to_points(const esvo_match_t* m, const u32* n_ptr, u32 max_n
 // kernels_track.hip: tracker residual / Jacobian evaluation (RegProblemLM.cpp), SURVEY.md section 8(f).1
 struct TrackRef { double T[16]; };            // T_world_ref
 struct TrackPose { double T[16]; double Jc[6]; };  // T_left_ref; J_constPart (3x2, row-major) for the Jacobian
+#define TRK_NE_MAX_POSES 4   // poses one launch of track_normal_kernel evaluates (one workgroup each): the trial steps of an LM iteration
+struct TrackPoseSet { TrackPose p[TRK_NE_MAX_POSES]; };
 struct TrackArgs {
   const double* pts;      // [n][3] points in the reference camera frame
   const uint8_t* neg;     // TS_negative_left_
@@ -267,8 +269,8 @@ void launch_track_residuals(const TrackArgs& a, const TrackPose& pose, u32 offse
 void launch_track_jacobian(const TrackArgs& a, const TrackPose& pose, u32 offset, u32 count, double* fjac, hipStream_t s);
 #define TRK_NE_THREADS 256
 #define TRK_NE_TERMS 28   // 21 upper-triangle entries of J^T J, 6 of J^T f, |f|^2
-void launch_track_normal(const TrackArgs& a, const TrackPose& pose, u32 offset, u32 count, int huber, double thr, double* out28,
-                         hipStream_t s);
+void launch_track_normal(const TrackArgs& a, const TrackPoseSet& poses, int n_poses, u32 offset, u32 count, int huber, double thr,
+                         double* out28_per_pose, hipStream_t s);
 
 // kernels_shard.hip: ordering of a tick's frame from the ranks' (matched, kept) bits
 void launch_shard_codes(const u32* own_w, const u32* keep, const u32* n_local, u32 max_local, u32 N, uint8_t* block, hipStream_t s);

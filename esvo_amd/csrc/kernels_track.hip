@@ -168,9 +168,13 @@ void launch_track_jacobian(const TrackArgs& a, const TrackPose& pose, u32 offset
 // Summation order (the oracle restates it: orc_tracker_normal_equations): thread t of the single 256-thread workgroup adds
 // the terms of points t, t + 256, t + 512, ... in that order; the 256 partial sums are then folded by the tree
 // s[t] += s[t + 128], s[t] += s[t + 64], ..., s[0] += s[1].
-__global__ void __launch_bounds__(TRK_NE_THREADS) track_normal_kernel(TrackArgs a, TrackPose pose, u32 offset, u32 count, int huber,
+// One workgroup per POSE (blockIdx.x): the trial steps of an LM iteration (several damping values) cost one launch and one
+// read-back together -- the sums of a pose do not depend on how many others ride along.
+__global__ void __launch_bounds__(TRK_NE_THREADS) track_normal_kernel(TrackArgs a, TrackPoseSet poses, u32 offset, u32 count, int huber,
                                                                     double huber_threshold, double* __restrict__ out) {
   __shared__ double red[TRK_NE_TERMS][TRK_NE_THREADS];
+  const TrackPose& pose = poses.p[blockIdx.x];
+  out += (size_t)blockIdx.x * TRK_NE_TERMS;
   double acc[TRK_NE_TERMS];
 #pragma unroll
   for (int n = 0; n < TRK_NE_TERMS; ++n) acc[n] = 0.0;
@@ -199,9 +203,9 @@ __global__ void __launch_bounds__(TRK_NE_THREADS) track_normal_kernel(TrackArgs 
   __syncthreads();
   if (threadIdx.x < TRK_NE_TERMS) out[threadIdx.x] = red[threadIdx.x][0];
 }
-void launch_track_normal(const TrackArgs& a, const TrackPose& pose, u32 offset, u32 count, int huber, double thr, double* out,
-                         hipStream_t s) {
-  hipLaunchKernelGGL(track_normal_kernel, dim3(1), dim3(TRK_NE_THREADS), 0, s, a, pose, offset, count, huber, thr, out);
+void launch_track_normal(const TrackArgs& a, const TrackPoseSet& poses, int n_poses, u32 offset, u32 count, int huber, double thr,
+                         double* out, hipStream_t s) {
+  hipLaunchKernelGGL(track_normal_kernel, dim3(n_poses), dim3(TRK_NE_THREADS), 0, s, a, poses, offset, count, huber, thr, out);
 }
 
 }  // namespace esvo

@@ -28,7 +28,7 @@ SYMBOLS = [
     "esvo_get_stats", "esvo_shard_set_band", "esvo_shard_set_routing", "esvo_shard_get_rows", "esvo_shard_exchange", "esvo_shard_tick_phase", "esvo_abi_sizes",
     "esvo_map_front", "esvo_map_front_frame", "esvo_map_push_frame_device", "esvo_map_fuse_async",
     "esvo_track_set_current", "esvo_track_get_images", "esvo_track_set_reference", "esvo_track_residuals", "esvo_track_jacobian",
-    "esvo_track_normal_equations", "esvo_track_register",
+    "esvo_track_normal_equations", "esvo_track_normal_equations_batch", "esvo_track_register",
     "esvo_map_init_sgm",
     "esvo_bag_open", "esvo_bag_close", "esvo_bag_last_error", "esvo_bag_next_event_array", "esvo_ts_push_bag",
     "esvo_map_get_debug_images", "esvo_map_get_pointcloud_near_xyz", "esvo_voxel_filter_xyz", "esvo_map_save_depth_map",
@@ -166,6 +166,7 @@ def load():
     lib.esvo_track_residuals.argtypes = [vp, vp, sz, sz, i32, C.c_double, vp, psz]
     lib.esvo_track_jacobian.argtypes = [vp, vp, vp, sz, sz, vp, psz]
     lib.esvo_track_normal_equations.argtypes = [vp, vp, vp, sz, sz, i32, C.c_double, vp, vp, C.POINTER(C.c_double), psz]
+    lib.esvo_track_normal_equations_batch.argtypes = [vp, i32, vp, vp, sz, sz, i32, C.c_double, vp, vp, vp, psz]
     lib.esvo_track_register.argtypes = [vp, sz, vp, vp, i32, C.c_double, i32, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_int)]
     lib.esvo_map_init_sgm.argtypes = [vp, vp, vp, sz, psz, vp]
     lib.esvo_bag_open.argtypes = [C.c_char_p, C.POINTER(vp)]
@@ -566,6 +567,18 @@ class Esvo:
         self._ck(self.lib.esvo_track_normal_equations(self.h, R.ctypes.data, t.ctypes.data, int(offset), int(count), 1 if huber else 0,
                                                       float(huber_threshold), H.ctypes.data, b.ctypes.data, C.byref(cost), C.byref(n)))
         return H, b, cost.value, n.value
+
+    def track_normal_equations_batch(self, Rs, ts, offset, count, huber=True, huber_threshold=50.0):
+        """the same at k poses (Rs: k x 3 x 3, ts: k x 3) in one launch -> (H k x 6 x 6, b k x 6, cost k, n)"""
+        Rs = np.ascontiguousarray(Rs, np.float64).reshape(-1, 9)
+        ts = np.ascontiguousarray(ts, np.float64).reshape(-1, 3)
+        k = len(Rs)
+        H, b, cost = np.zeros((k, 6, 6), np.float64), np.zeros((k, 6), np.float64), np.zeros(k, np.float64)
+        n = C.c_size_t()
+        self._ck(self.lib.esvo_track_normal_equations_batch(self.h, k, Rs.ctypes.data, ts.ctypes.data, int(offset), int(count),
+                                                            1 if huber else 0, float(huber_threshold), H.ctypes.data, b.ctypes.data,
+                                                            cost.ctypes.data, C.byref(n)))
+        return H, b, cost, n.value
 
     def track_register(self, n_points, R, t, huber=True, huber_threshold=50.0, max_iterations=12, damping=1e-3):
         """the registration loop inside the library (esvo_hip::gauss_newton_register over the normal equations):

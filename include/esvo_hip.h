@@ -560,9 +560,18 @@ int esvo_track_jacobian(esvo_handle h, const double R[9], const double t[3], siz
  * operator()(0) is [R^T | -R^T t]).  The sums are taken in a fixed order (kernels_track.hip), reproduced by the CPU oracle. */
 int esvo_track_normal_equations(esvo_handle h, const double R[9], const double t[3], size_t offset, size_t count, int ls_norm,
                                 double huber_threshold, double H[36], double b[6], double* cost, size_t* n_out);
+/* The same for n_poses (1..ESVO_TRACK_MAX_POSES) poses in ONE launch and one read-back: what Eigen's minimizeOneStep spends one
+ * functor evaluation each on -- the trial points of its inner loop (a step per damping value until one is accepted) -- evaluated
+ * together.  R: n_poses x 9, t: n_poses x 3, H: n_poses x 36, b: n_poses x 6, cost: n_poses; every pose's sums are the ones
+ * esvo_track_normal_equations gives for it alone, bit for bit. */
+#define ESVO_TRACK_MAX_POSES 4
+int esvo_track_normal_equations_batch(esvo_handle h, int n_poses, const double* R, const double* t, size_t offset, size_t count,
+                                      int ls_norm, double huber_threshold, double* H, double* b, double* cost, size_t* n_out);
 /* The registration loop on top of it, host C++ inside the library (esvo_hip::gauss_newton_register of esvo_hip.hpp -- the same
- * code a C++ node calls directly): damped Gauss-Newton on (Cayley, translation) with the reference's motion update
- * (RegProblemLM::addMotionUpdate, :347-360: R <- orth(dR R), t <- dt + dR t), over the first n_points of the reference cloud.
+ * code a C++ node calls directly): Levenberg-damped Gauss-Newton on (Cayley, translation) with the reference's motion update
+ * (RegProblemLM::addMotionUpdate, :347-360: R <- orth(dR R), t <- dt + dR t), over the first n_points of the reference cloud;
+ * a step is accepted when its actual cost reduction is at least 1e-4 of the predicted one (Eigen's ratio test), the damping
+ * is raised tenfold otherwise and lowered tenfold after an accepted step; three trial dampings are evaluated per launch.
  * R, t: in = the start (R_, t_ of setProblem: identity / zero, or the previous frame's), out = the registered motion.
  * The reference's own driver is Eigen's LevenbergMarquardt (third-party, absent here); this one is what the closed-loop test
  * and bench.py use in its place. */

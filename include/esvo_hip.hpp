@@ -304,64 +304,86 @@ struct Registration { double R[9]; double t[3]; double rms = 0; int iterations =
 // Like Eigen's minimizeOneStep, a trial step is ACCEPTED only if it pays: the cost is evaluated at the trial pose (same
 // batch) and the step taken iff actual reduction / predicted reduction >= 1e-4, with
 //   predicted = |f|^2 - |f + J dx|^2 = -(2 b.dx + dx.H dx);
-// otherwise the damping is raised tenfold and the step recomputed (up to 6 times; minimizeInit resets Eigen's par at every
-// outer iteration, so lambda restarts from `damping` each time) -- the driver never moves to a pose with a higher cost.
-// It stops after max_iterations, when an accepted step is shorter than 1e-6, or when no damping up to 1e5 x yields an
-// acceptable step (the state in which Eigen's trust radius has shrunk below xtol |x|: its status 2 / 3, on which the
-// reference's loop breaks, :181-182).  Stated deviation (DESIGN.md "Deviations"): the step is Levenberg's diagonal damping,
-// not MINPACK's lmpar trust-region solve, so single steps differ from Eigen's while the fixed point is the same.
-// `normal_eq(k, R, t, H[36], b[6], &cost, &n)` evaluates H = J^T J, b = J^T f, cost = |f|^2 at (R, t) on the batch of outer
-// iteration k: esvo_track_normal_equations on the device, or the CPU oracle's restatement in the tests.  same_batch: the
-// batch does not depend on k, so the evaluation at an accepted trial pose IS the next iteration's linearisation (one
-// evaluation per iteration + one per rejected step).
+// otherwise the damping is raised tenfold and the step recomputed (up to 6 times) -- the driver never moves to a pose with
+// a higher cost.  After an accepted step the damping is lowered tenfold (never below `damping`) and carried into the next
+// iteration (Marquardt's schedule; Eigen's minimizeInit restarts its trust region at every outer iteration and spends functor
+// evaluations shrinking it again -- on the Time Surface's piecewise-constant image the useful damping is 1 .. 10, three
+// rejections away from 1e-3, every time).
+// The trials lambda, 10 lambda, 100 lambda of an iteration are SPECULATIVE: all three poses go to `normal_eq` in one call
+// (one kernel launch, one workgroup per pose, one read-back on the device) and the first acceptable one in that order is
+// taken -- the result is that of trying them one after the other, at the latency of one evaluation.
+// It stops after max_iterations, when an accepted step is shorter than 1e-6, or when no damping up to 1e5 x the current one
+// yields an acceptable step (the state in which Eigen's trust radius has shrunk below xtol |x|: its status 2 / 3, on which
+// the reference's loop breaks, :181-182).  Stated deviation (DESIGN.md "Deviations"): the step is Levenberg's diagonal
+// damping, not MINPACK's lmpar trust-region solve, so single steps differ from Eigen's while the fixed point is the same.
+// `normal_eq(it, k, R[k][9], t[k][3], H[k][36], b[k][6], cost[k], &n)` evaluates H = J^T J, b = J^T f, cost = |f|^2 at k poses
+// (1 <= k <= 3) on the batch of outer iteration `it`: esvo_track_normal_equations_batch on the device, or the CPU oracle's
+// restatement in the tests.  same_batch: the batch does not depend on `it`, so the evaluation at an accepted trial pose IS
+// the next iteration's linearisation.
+constexpr int kRegisterTrials = 3;
 template <class NormalEq>
 Registration gauss_newton_register(NormalEq&& normal_eq, const double R0[9], const double t0[3], int max_iterations = 12,
                                    double damping = 1e-3, bool same_batch = true) {
+  constexpr int K = kRegisterTrials;
   Registration g;
   for (int i = 0; i < 9; ++i) g.R[i] = R0[i];
   for (int i = 0; i < 3; ++i) g.t[i] = t0[i];
-  double H[36], b[6], cost = 0;
+  double H[36], b[6], cost = 0, lambda = damping;
   size_t n = 0;
   bool have = false;
   for (int it = 0; it < max_iterations; ++it) {
-    if (!have && !normal_eq(it, g.R, g.t, H, b, &cost, &n)) { g.ok = false; return g; }
+    if (!have && !normal_eq(it, 1, g.R, g.t, H, b, &cost, &n)) { g.ok = false; return g; }
     have = false;
     g.iterations = it + 1;
     g.rms = n ? std::sqrt(cost / (double)n) : 0.0;
-    double lambda = damping, dx[6], Rn[9], tn[3], Ht[36], bt[6], cost_t = 0;
+    double dx[K][6], Rn[K][9], tn[K][3], Ht[K][36], bt[K][6], cost_t[K];
     size_t nt = 0;
-    bool accepted = false;
-    for (int attempt = 0; attempt < 6 && !accepted; ++attempt, lambda *= 10.0) {
-      double A[36], rhs[6];
-      for (int i = 0; i < 36; ++i) A[i] = H[i];
-      for (int i = 0; i < 6; ++i) { A[i * 6 + i] = (H[i * 6 + i] + lambda * H[i * 6 + i]) + 1e-9; rhs[i] = -b[i]; }
-      if (!solve6(A, rhs, dx)) { g.ok = false; return g; }
-      double dR[9];
-      cayley2rot(dx, dR);
-      for (int r = 0; r < 3; ++r)
-        for (int c = 0; c < 3; ++c) Rn[r * 3 + c] = (dR[r * 3 + 0] * g.R[0 * 3 + c] + dR[r * 3 + 1] * g.R[1 * 3 + c]) + dR[r * 3 + 2] * g.R[2 * 3 + c];
-      orthonormalize3(Rn);
-      for (int r = 0; r < 3; ++r) tn[r] = dx[3 + r] + ((dR[r * 3 + 0] * g.t[0] + dR[r * 3 + 1] * g.t[1]) + dR[r * 3 + 2] * g.t[2]);
-      if (!normal_eq(it, Rn, tn, Ht, bt, &cost_t, &nt)) { g.ok = false; return g; }
-      double pred = 0;  // -(2 b.dx + dx.H dx)
-      for (int i = 0; i < 6; ++i) {
-        double hd = 0;
-        for (int j = 0; j < 6; ++j) hd += H[i * 6 + j] * dx[j];
-        pred -= dx[i] * (2.0 * b[i] + hd);
+    int pick = -1;
+    for (int round = 0; round < 2 && pick < 0; ++round) {  // dampings lambda 10^0..2, then lambda 10^3..5
+      int k_eff = 0;
+      double lam = lambda;
+      for (int k = 0; k < K; ++k, lam *= 10.0) {
+        double A[36], rhs[6];
+        for (int i = 0; i < 36; ++i) A[i] = H[i];
+        for (int i = 0; i < 6; ++i) { A[i * 6 + i] = (H[i * 6 + i] + lam * H[i * 6 + i]) + 1e-9; rhs[i] = -b[i]; }
+        if (!solve6(A, rhs, dx[k])) break;
+        double dR[9];
+        cayley2rot(dx[k], dR);
+        for (int r = 0; r < 3; ++r)
+          for (int c = 0; c < 3; ++c)
+            Rn[k][r * 3 + c] = (dR[r * 3 + 0] * g.R[0 * 3 + c] + dR[r * 3 + 1] * g.R[1 * 3 + c]) + dR[r * 3 + 2] * g.R[2 * 3 + c];
+        orthonormalize3(Rn[k]);
+        for (int r = 0; r < 3; ++r) tn[k][r] = dx[k][3 + r] + ((dR[r * 3 + 0] * g.t[0] + dR[r * 3 + 1] * g.t[1]) + dR[r * 3 + 2] * g.t[2]);
+        k_eff = k + 1;
       }
-      accepted = pred > 0 && (cost - cost_t) >= 1e-4 * pred;
+      if (k_eff == 0 || !normal_eq(it, k_eff, &Rn[0][0], &tn[0][0], &Ht[0][0], &bt[0][0], cost_t, &nt)) { g.ok = false; return g; }
+      lam = lambda;
+      for (int k = 0; k < k_eff && pick < 0; ++k, lam *= 10.0) {
+        double pred = 0;  // -(2 b.dx + dx.H dx)
+        for (int i = 0; i < 6; ++i) {
+          double hd = 0;
+          for (int j = 0; j < 6; ++j) hd += H[i * 6 + j] * dx[k][j];
+          pred -= dx[k][i] * (2.0 * b[i] + hd);
+        }
+        if (pred > 0 && (cost - cost_t[k]) >= 1e-4 * pred) { pick = k; lambda = lam; }
+      }
+      if (pick < 0) {
+        if (k_eff < K) { g.ok = false; return g; }  // a singular damped system among the trials, none before it acceptable
+        lambda = lam;  // = lambda x 10 x 10 x 10, the product a one-by-one loop arrives at
+      }
     }
-    if (!accepted) break;  // no step pays any more: (R, t) stays the last accepted pose
-    for (int i = 0; i < 9; ++i) g.R[i] = Rn[i];
-    for (int i = 0; i < 3; ++i) g.t[i] = tn[i];
+    if (pick < 0) break;  // no step pays any more: (R, t) stays the last accepted pose
+    for (int i = 0; i < 9; ++i) g.R[i] = Rn[pick][i];
+    for (int i = 0; i < 3; ++i) g.t[i] = tn[pick][i];
+    lambda = lambda / 10.0 > damping ? lambda / 10.0 : damping;
     if (same_batch) {
-      for (int i = 0; i < 36; ++i) H[i] = Ht[i];
-      for (int i = 0; i < 6; ++i) b[i] = bt[i];
-      cost = cost_t; n = nt; have = true;
+      for (int i = 0; i < 36; ++i) H[i] = Ht[pick][i];
+      for (int i = 0; i < 6; ++i) b[i] = bt[pick][i];
+      cost = cost_t[pick]; n = nt; have = true;
       g.rms = n ? std::sqrt(cost / (double)n) : 0.0;
     }
     double nrm = 0;
-    for (int i = 0; i < 6; ++i) nrm += dx[i] * dx[i];
+    for (int i = 0; i < 6; ++i) nrm += dx[pick][i] * dx[pick][i];
     if (std::sqrt(nrm) < 1e-6) break;
   }
   return g;
@@ -415,13 +437,20 @@ class RegProblemLM {
                                             cfg_.huber_threshold, H, b, cost, &n), "esvo_track_normal_equations");
     return n;
   }
+  // ... at k poses (R: k x 9, t: k x 3, H: k x 36, b: k x 6, cost: k) in one launch
+  size_t normalEquations(int k, const double* R, const double* t, double* H, double* b, double* cost) const {
+    size_t n = 0;
+    ctx_->check(esvo_track_normal_equations_batch(ctx_->handle(), k, R, t, offset_, count_, cfg_.huber ? ESVO_TRACK_HUBER : ESVO_TRACK_L2,
+                                                  cfg_.huber_threshold, H, b, cost, &n), "esvo_track_normal_equations_batch");
+    return n;
+  }
   // RegProblemSolverLM::solve_analytical's loop (RegProblemSolverLM.cpp:148-215) with gauss_newton_register as the step:
   // the batch advances with the iteration as setStochasticSampling does there (:167-168)
   Registration solve(const double R0[9], const double t0[3], int MAX_ITERATION = 12, double damping = 1e-3) {
     const bool batches = cfg_.BATCH_SIZE < numPoints_;
-    auto ne = [&](int it, const double* R, const double* t, double* H, double* b, double* cost, size_t* n) {
+    auto ne = [&](int it, int k, const double* R, const double* t, double* H, double* b, double* cost, size_t* n) {
       if (batches) setStochasticSampling(((size_t)it % numBatches_) * cfg_.BATCH_SIZE, cfg_.BATCH_SIZE);
-      *n = normalEquations(R, t, H, b, cost);
+      *n = normalEquations(k, R, t, H, b, cost);
       return true;
     };
     return gauss_newton_register(ne, R0, t0, MAX_ITERATION, damping, !batches);

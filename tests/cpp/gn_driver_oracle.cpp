@@ -32,14 +32,17 @@ int main(int argc, char** argv) {
   orc_tracker_handle trk = orc_tracker_create(&cal);
   orc_tracker_set_current(trk, ts.data(), 5);
   orc_tracker_set_reference(trk, xyz.data(), n, Tref);
-  auto ne = [&](int, const double* R, const double* t, double* Hm, double* b, double* cost, size_t* m) {
-    double v[28];
-    *m = orc_tracker_normal_equations(trk, R, t, 0, n, 1, 50.0, v);
-    int k = 0;
-    for (int i = 0; i < 6; ++i)
-      for (int j = i; j < 6; ++j) { Hm[i * 6 + j] = Hm[j * 6 + i] = v[k]; ++k; }
-    for (int i = 0; i < 6; ++i) b[i] = v[21 + i];
-    *cost = v[27];
+  // the driver's speculative trials (np poses per call) evaluated one after the other: the oracle has no launch to share
+  auto ne = [&](int, int np, const double* R, const double* t, double* Hm, double* b, double* cost, size_t* m) {
+    for (int q = 0; q < np; ++q) {
+      double v[28];
+      *m = orc_tracker_normal_equations(trk, R + 9 * q, t + 3 * q, 0, n, 1, 50.0, v);
+      int k = 0;
+      for (int i = 0; i < 6; ++i)
+        for (int j = i; j < 6; ++j) { Hm[36 * q + i * 6 + j] = Hm[36 * q + j * 6 + i] = v[k]; ++k; }
+      for (int i = 0; i < 6; ++i) b[6 * q + i] = v[21 + i];
+      cost[q] = v[27];
+    }
     return true;
   };
   const esvo_hip::Registration g = esvo_hip::gauss_newton_register(ne, R0, t0, iters, 1e-3);

@@ -120,6 +120,17 @@ def test_gpu_normal_equations_equal_oracle_and_register_equals_python_loop():
             Ho, bo, co, no = trk.normal_equations(R, t, off, cnt, huber=huber)
             assert nd == no
             assert np.array_equal(Hd, Ho) and np.array_equal(bd, bo) and cd == co, (off, cnt, huber)
+    # several poses in one launch: every pose's sums are the ones it gets alone, bit for bit; the limit is an argument error
+    rng = np.random.default_rng(5)
+    Rs = np.stack([g["R"], np.eye(3)] + [closed_loop.orth(closed_loop.cayley2rot(rng.normal(0, 0.02, 3))) for _ in range(2)])
+    ts = np.stack([g["t"], np.zeros(3)] + [rng.normal(0, 0.05, 3) for _ in range(2)])
+    for k in (1, 2, 3, 4):
+        Hb, bb, cb, nb = dev.track_normal_equations_batch(Rs[:k], ts[:k], 100, 300)
+        for q in range(k):
+            Hd, bd, cd, nd = dev.track_normal_equations(Rs[q], ts[q], 100, 300)
+            assert nb == nd and np.array_equal(Hb[q], Hd) and np.array_equal(bb[q], bd) and cb[q] == cd, (k, q)
+    with pytest.raises(lib.EsvoError):
+        dev.track_normal_equations_batch(np.tile(np.eye(3), (5, 1, 1)), np.zeros((5, 3)), 0, 10)
     R1, t1, rms1, it1 = dev.track_register(len(xyz), np.eye(3), np.zeros(3))
     R2, t2, rms2 = closed_loop.register_python(dev, len(xyz), np.eye(3), np.zeros(3))
     assert np.abs(R1 - R2).max() < 1e-9 and np.abs(t1 - t2).max() < 1e-9 and abs(rms1 - rms2) < 1e-6 * rms2 + 1e-9
