@@ -242,7 +242,16 @@ def main():
         raise SystemExit(0 if res.get("ok", True) else 1)
 
     shard_mode = os.environ.get("ESVO_SHARD_MODE", "tick")
+    legs = {}                      # wall seconds of every leg of this invocation (`wall_s` on the line)
+    t_leg = [time.perf_counter()]
+
+    def lap(name):
+        now = time.perf_counter()
+        legs[name] = round(legs.get(name, 0.0) + now - t_leg[0], 2)
+        t_leg[0] = now
+
     M = measure(shard_mode, args.strong)
+    lap("stream_generation_warmup_timed_region")
     per_gpu, rig, stream, p, ticks, duration = M["per_gpu"], M["rig"], M["stream"], M["p"], M["ticks"], M["duration"]
     native, comm_note, runner, dt, st = M["native"], M["comm_note"], M["runner"], M["dt"], M["st"]
     n_events, n_points, n_matches, ksum, launches = M["n_events"], M["n_points"], M["n_matches"], M["ksum"], M["launches"]
@@ -352,6 +361,7 @@ def main():
             out["sustained"]["vs_headline"] = out["sustained"]["events_per_s"] / out["value"]
         except Exception as e:  # noqa: BLE001  (an extra: never takes the headline down with it)
             out["sustained"] = {"error": f"{type(e).__name__}: {e}"}
+        lap("sustained")
     if rank == 0 and world == 1 and not args.no_extras:
         try:
             out["other_operating_points"] = reference_faithful_points(local_rank)
@@ -359,6 +369,7 @@ def main():
                 out["other_operating_points"].update(extra_operating_points(local_rank))
         except Exception as e:  # noqa: BLE001  (extras: the headline line is printed whatever happens here)
             out["other_operating_points"] = {"error": f"{type(e).__name__}: {e}"}
+        lap("other_operating_points")
     if rank == 0 and world == 1 and not args.no_extras and not args.no_band_share and not args.timed_ingest:
         # SURVEY 8(e) on one GPU: what one rank of an 8-GPU band-mode run computes per tick (a projection, labelled as such)
         try:
@@ -368,6 +379,7 @@ def main():
             out["band_share"] = band_share(args.workload, local_rank, events_cap=args.events_per_tick)
         except Exception as e:  # noqa: BLE001
             out["band_share"] = {"error": f"{type(e).__name__}: {e}"}
+        lap("band_share")
     ref_maps = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
@@ -390,6 +402,7 @@ def main():
         if pv.get("value"):
             ratios[f"gpu_over_port_{pv.get('cores')}_threads"] = out["value"] / pv["value"]
         cb["ratios"] = ratios
+        lap("cpu_baseline")
     if rank == 0 and world == 1 and not args.no_parity:
         # parity evidence ON the line: (a) the DepthMap of the first timed tick of THIS workload against the CPU oracle in its
         # GPU-comparable arithmetic, element for element (what --check does); (b) the device against the REFERENCE's own node
@@ -415,6 +428,7 @@ def main():
         else:
             par["reference_node"] = None
         out["parity"] = par
+        lap("parity")
     if world > 1 and "ESVO_SHARD_MODE" not in os.environ and not args.strong and not args.check and not args.no_extras:
         # the OTHER way of using N GPUs, on the same line: every tick of ONE stream split over the ranks -- per-event work
         # by slot, per-cell work by image row band (north_star's image-tile partition), two ncclAllGather per tick (own-slot bytes; [count | kept points]) and the
@@ -436,6 +450,7 @@ def main():
                                + (" (esvo_comm_*: RCCL inside the C library)" if B["native"] else " (torch.distributed)"),
             }
     if rank == 0:
+        out["wall_s"] = legs
         print(json.dumps(out), file=json_out, flush=True)
     if dist:
         dist.destroy_process_group()

@@ -215,6 +215,7 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
   }
   if (const char* ef = esvo_dev_switch("ESVO_FRONT_THROTTLE")) h->front_throttle = std::atoi(ef) != 0;
   if (const char* ea = esvo_dev_switch("ESVO_RESYNC")) h->resync_on = std::atoi(ea) != 0;
+  if (const char* ea = esvo_dev_switch("ESVO_COLLECT_ASIDE")) h->collect_aside = std::atoi(ea) != 0;
   if (const char* et = esvo_dev_switch("ESVO_TIMELINE")) h->tl_on = std::atoi(et) != 0;
   if (const char* e1 = esvo_dev_switch("ESVO_ONE_STREAM")) {  // A/B only: the three stages in one queue (no cross-queue hand-offs)
     if (std::atoi(e1) == 1) {

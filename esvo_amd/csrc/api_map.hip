@@ -698,7 +698,7 @@ int tick_phase0(esvo_context* h, uint64_t t_ns, const uint64_t* pose_t_ns, const
   esvo_context::TickState& tk = h->tk[h->fpar];
   tk.n = n; tk.off = 0; tk.points = 0; tk.t_ns = t_ns;
   tk.n_loc = n_loc; tk.n_own = n_own; tk.g_first = g_first;
-  tk.lm_stream = h->stream;
+  tk.lm_stream = tk.cnt_stream = h->stream;
   tk.lm_pair = -1;
   tk.obs_par = h->obs_par;
   tk.pose_buf = h->pose_buf; tk.n_pose = h->n_pose;
@@ -739,6 +739,7 @@ int tick_phase0(esvo_context* h, uint64_t t_ns, const uint64_t* pose_t_ns, const
       if (h->ema_lm_ms > 0.f && h->ema_back_ms > 0.f)
         h->lm_two_on = h->ema_lm_ms > (h->lm_two_on ? 1.2f : 1.5f) * h->ema_back_ms;
       const bool two = (h->lm_queues == 2 || (h->lm_queues == 0 && h->lm_two_on)) && n <= h->lm_two_max && !split_scratch;
+      h->lm_two_now = two;
       sl = (two && h->fpar) ? h->stream_l1 : h->stream_l;
       HIPCHK(hipStreamWaitEvent(sl, h->evt[EV_A1 + h->fpar * EV_FRONT_STRIDE], 0));
     }
@@ -746,7 +747,14 @@ int tick_phase0(esvo_context* h, uint64_t t_ns, const uint64_t* pose_t_ns, const
       h->resync.lm_wait_back = false;
       HIPCHK(hipStreamWaitEvent(sl, h->evt[EV_RG1 + (h->par ^ 1) * EV_BACK_STRIDE], 0));
     }
-    tk.lm_stream = sl;
+    tk.lm_stream = tk.cnt_stream = sl;
+    // With ONE LM queue, what follows the launch on the device (point compaction, counters) goes to the idle second queue: the
+    // next tick's launch -- enqueued before this one has finished -- then follows this one directly instead of waiting out
+    // ~40 us of small dependent launches at the head of the stream that paces the pipeline.
+    // (only while ticks overlap -- the previous one is still pending: a tick that is waited for gains nothing from it and would pay
+    //  one more cross-queue hand-off)
+    if (h->collect_aside && h->split_now && h->tick_pending && (sl == h->stream_l || sl == h->stream_l1) && !h->lm_two_now)
+      tk.cnt_stream = sl == h->stream_l ? h->stream_l1 : h->stream_l;
     tk.lm_pair = lm_pair_policy(h, n);
     rc = run_lm(h, n, 1, false, sl, tk.lm_pair);
     if (rc) return rc;
@@ -832,8 +840,9 @@ int tick_phase1_enqueue(esvo_context* h) {
   if (n && !h->sharded) {
     // the frame waits in the staging buffer of its parity until the tick is committed and its size is known; the
     // buffer's previous frame (two ticks ago) has been copied into the ring by then
-    HIPCHK(hipStreamWaitEvent(tk.lm_stream, h->evt[EV_STG + h->fpar * EV_FRONT_STRIDE], 0));
-    rc = run_order_points(h, n, h->d_stage[h->fpar], tk.lm_stream);
+    if (tk.cnt_stream != tk.lm_stream) HIPCHK(hipStreamWaitEvent(tk.cnt_stream, h->evt[EV_LM1 + h->fpar * EV_FRONT_STRIDE], 0));
+    HIPCHK(hipStreamWaitEvent(tk.cnt_stream, h->evt[EV_STG + h->fpar * EV_FRONT_STRIDE], 0));
+    rc = run_order_points(h, n, h->d_stage[h->fpar], tk.cnt_stream);
     if (rc) return rc;
   } else if (n) {
     const u32 N = (u32)h->dp.ev_nshards, r = (u32)h->dp.ev_shard, T = (u32)h->dp.num_threads;
@@ -858,7 +867,7 @@ int tick_phase1_enqueue(esvo_context* h) {
     hipEventRecord(h->evt[EV_S2 + h->fpar * EV_FRONT_STRIDE], h->stream);
     HIPCHK(hipGetLastError());
   }
-  hipStream_t sc = (n && !h->sharded) ? tk.lm_stream : h->stream;
+  hipStream_t sc = (n && !h->sharded) ? tk.cnt_stream : h->stream;
   HIPCHK(hipMemcpyAsync(h->h_counters + CNT_ROW * h->fpar, h->d_counters, sizeof(u32) * CNT_ROW, hipMemcpyDeviceToHost, sc));
   HIPCHK(hipEventRecord(h->evt[EV_CNT + h->fpar * EV_FRONT_STRIDE], sc));
   h->tick_pending = true;

@@ -58,6 +58,8 @@ struct esvo_context {
   // long dependent chains -- drains.  Used for launches in the latency-bound (wide) layout; everything the stage writes
   // (d_pt_slots / d_pt_flags / d_pt_prefix / the scan scratch, besides the buffers listed above) exists once per parity.
   hipStream_t stream_l1 = nullptr;
+  bool collect_aside = true;   // one LM queue in use: a tick's compaction + counters go to the other one (api_map.hip, tick_phase0)
+  bool lm_two_now = false;     // this tick's LM launch alternates between the two queues
   // Whether the second queue pays depends on what else the tick holds: where the LM launch is much longer than the fusion
   // stage (346x260, no regulariser: 0.37 ms against 0.12) two launches in flight raise the rate by 18 %; where the two are
   // of similar length (DSEC's reference-faithful tick: 0.25 against 0.30 ms) the fusion stage is the bottleneck either way
@@ -298,7 +300,8 @@ struct esvo_context {
     int pose_buf = 0;
     u64 t_ns = 0;
     double T_world_obs[16];
-    hipStream_t lm_stream = nullptr;  // where the tick's LM stage (refinement, frame, counters) was enqueued
+    hipStream_t lm_stream = nullptr;  // where the tick's LM launch was enqueued
+    hipStream_t cnt_stream = nullptr; // where its frame (point compaction) and counters follow: the same, or the idle second LM queue
     int obs_par = 0;                  // which observation pair it reads
     int lm_pair = -1;                 // LM layout of the tick: 1 pair, 0 wide, -1 not a candidate (policy feedback)
   } tk[2];
