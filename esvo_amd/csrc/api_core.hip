@@ -147,66 +147,14 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
     // Three stages on three streams share the chip.  The LM kernel is the bulk of the vector-ALU work and tolerates waiting
     // (two dense waves per SIMD); the matching stage and the fusion stage are short, latency-bound kernels that run one wave
     // per SIMD beside it.  They get the HIGH priority and the LM stream the LOWEST: whenever one of their waves is ready it
-    // issues, the LM waves fill every other slot.  Measured on the bench workload with the round-3 LM kernel (fewer stalls,
-    // so it no longer leaves slots by itself): 1.40 ms per tick against 1.70 ms with the LM stream high and the fusion
-    // stream low (round 2's setting, then worth -2 %).  ESVO_STREAM_PRIO = 0 / 2 and ESVO_PRIOS exist for that A/B.
-    const char* pe = esvo_dev_switch("ESVO_STREAM_PRIO");
-    const int mode = pe ? std::atoi(pe) : 1;
-    int pf = mode == 1 ? prio_hi : (mode == 2 ? prio_lo : 0), pb = mode == 1 ? prio_hi : (mode == 2 ? prio_lo : 0);
-    // ESVO_PRIOS="front,lm,back" (A/B only): explicit priorities, 0 = the device's highest, larger = lower
-    int pl_explicit = 0;
-    bool have_explicit = false;
-    if (const char* e4 = esvo_dev_switch("ESVO_PRIOS")) {
-      int f = 0, l = 0, b = 0;
-      if (std::sscanf(e4, "%d,%d,%d", &f, &l, &b) == 3) {
-        auto clampp = [&](int v) { v = prio_hi + v; return v > prio_lo ? prio_lo : v; };
-        pf = clampp(f); pb = clampp(b); pl_explicit = clampp(l);
-        have_explicit = true;
-      }
-    }
-    h->prio_note[0] = prio_lo; h->prio_note[1] = prio_hi;
-    // ESVO_CU_SPLIT="b[,f]" (A/B only): SPATIAL partition instead of priorities -- the fusion stage's stream is confined to b
-    // compute units, the matching stage's to the next f (0: it shares the LM stage's), the LM queues get the rest.
-    if (const char* ec = esvo_dev_switch("ESVO_CU_SPLIT")) {
-      int nb = 0, nf = 0;
-      std::sscanf(ec, "%d,%d", &nb, &nf);
-      hipDeviceProp_t prop;
-      CK(hipGetDeviceProperties(&prop, device));
-      const int ncu = prop.multiProcessorCount;
-      if (nb > 0 && nb + nf < ncu) { h->cu_split[0] = nb; h->cu_split[1] = nf; h->cu_split[2] = ncu; }
-    }
-    auto make_masked = [&](hipStream_t* st, int lo, int hi) {  // CUs [lo, hi) in HSA order
-      uint32_t mask[16] = {0};
-      for (int i = lo; i < hi; ++i) mask[i >> 5] |= 1u << (i & 31);
-      return hipExtStreamCreateWithCUMask(st, (uint32_t)((h->cu_split[2] + 31) / 32), mask);
-    };
-    if (h->cu_split[0]) {
-      const int nb = h->cu_split[0], nf = h->cu_split[1], ncu = h->cu_split[2];
-      CK(make_masked(&h->stream_b, 0, nb));
-      CK(nf ? make_masked(&h->stream, nb, nb + nf) : make_masked(&h->stream, nb, ncu));
-    } else {
-      CK(hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, pf));
-      CK(hipStreamCreateWithPriority(&h->stream_b, hipStreamNonBlocking, pb));
-    }
+    // issues, the LM waves fill every other slot.  Measured in round 3: 1.40 ms per tick against 1.70 ms with the LM stream
+    // high and the fusion stream low.  (Other priority assignments and a SPATIAL partition of the compute units by
+    // hipExtStreamCreateWithCUMask were measured in rounds 3-4 -- all slower, 1.5-4 ms for the partition; profiles/HISTORY.md.)
+    CK(hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio_hi));
+    CK(hipStreamCreateWithPriority(&h->stream_b, hipStreamNonBlocking, prio_hi));
     h->own_stream = true;
-    if (have_explicit) h->prio_note[2] = pl_explicit; else h->prio_note[2] = 12345;
-  }
-  {
-    int lo = 0, hi = 0;
-    CK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    int pl = lo;  // see above: the LM stream yields to the two latency-bound stages
-    if (const char* e3 = esvo_dev_switch("ESVO_PRIO_LM")) pl = std::atoi(e3) == 0 ? hi : (std::atoi(e3) == 2 ? lo : 0);  // A/B only
-    if (h->prio_note[2] != 12345) pl = h->prio_note[2];
-    if (esvo_dev_switch("ESVO_PRIO_PRINT")) fprintf(stderr, "[esvo] stream priority range: lowest %d .. highest %d; LM %d\n", lo, hi, pl);
-    if (h->cu_split[0]) {
-      uint32_t mask[16] = {0};
-      for (int i = h->cu_split[0] + h->cu_split[1]; i < h->cu_split[2]; ++i) mask[i >> 5] |= 1u << (i & 31);
-      CK(hipExtStreamCreateWithCUMask(&h->stream_l, (uint32_t)((h->cu_split[2] + 31) / 32), mask));
-      CK(hipExtStreamCreateWithCUMask(&h->stream_l1, (uint32_t)((h->cu_split[2] + 31) / 32), mask));
-    } else {
-      CK(hipStreamCreateWithPriority(&h->stream_l, hipStreamNonBlocking, pl));
-      CK(hipStreamCreateWithPriority(&h->stream_l1, hipStreamNonBlocking, pl));
-    }
+    CK(hipStreamCreateWithPriority(&h->stream_l, hipStreamNonBlocking, prio_lo));
+    CK(hipStreamCreateWithPriority(&h->stream_l1, hipStreamNonBlocking, prio_lo));
     if (const char* ep = esvo_dev_switch("ESVO_LM_PAIR")) h->lm_pair_forced = std::atoi(ep) == 1 ? 1 : (std::atoi(ep) == 0 ? 0 : -1);
     if (const char* eq = esvo_dev_switch("ESVO_LM_QUEUES")) h->lm_queues = std::atoi(eq) == 1 ? 1 : (std::atoi(eq) == 2 ? 2 : 0);
     if (const char* em = esvo_dev_switch("ESVO_LM_QUEUES_MAX_EVENTS")) h->lm_two_max = (u32)std::strtoul(em, nullptr, 10);  // A/B only
@@ -440,9 +388,6 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
 int esvo_destroy(esvo_handle h) {
   if (!h) return ESVO_OK;
   hipSetDevice(h->device);
-  if (esvo_dev_switch("ESVO_POLICY_PRINT"))
-    fprintf(stderr, "[esvo] LM layout policy: wide %.4f ms (%u ticks), pair %.4f ms (%u ticks); LM queues: lm %.4f ms, back %.4f ms, two %d\n",
-            h->lm_pair_ms[0][0], h->lm_pair_n[0], h->lm_pair_ms[1][0], h->lm_pair_n[1], h->ema_lm_ms, h->ema_back_ms, (int)h->lm_two_on);
 #ifdef FUSE_STATS  // tools-only builds: per-tile phase cycles of the last tile_lists launch (a buffer of their own, allocated at esvo_create)
   if (h->d_fuse_stats) {
     hipDeviceSynchronize();

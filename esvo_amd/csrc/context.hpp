@@ -81,7 +81,6 @@ struct esvo_context {
   bool resync_on = true;
   struct Resync { double last_ms = 0; float period_ema = 0, period_before = 0; u32 streak = 0, cooldown = 0, check_in = 0; bool lm_wait_back = false; } resync;
   bool front_throttle = false;   // ESVO_FRONT_THROTTLE=1 (A/B): an unsharded tick's front stage waits for the back stage two ticks ago (api_map.hip; the default until round 4)
-  int cu_split[3] = {0, 0, 0};    // ESVO_CU_SPLIT (A/B): CUs of the fusion / matching streams, CUs of the device
   bool split_now = false;         // set by esvo_map_tick around its front stage: only the lazy tick path splits
   uint8_t* d_obs2[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
   int obs_par = 0;
@@ -91,7 +90,6 @@ struct esvo_context {
   u32* d_scan_tmp_l2[2] = {nullptr, nullptr};
   hipStream_t stream_i = nullptr;  // event ingest (H2D into the ring): staging new events never waits for a running tick
   bool own_stream = false;
-  int prio_note[3] = {0, 0, 12345};  // stream priority range of the device / explicit LM priority (ESVO_PRIOS, A/B only)
   int par = 0;                    // parity of the tick being assembled
   bool back_pending[2] = {false, false};  // back-stage timings / counters of that parity not collected yet
   u32 back_frames[2] = {0, 0};

@@ -378,7 +378,6 @@ __global__ void __launch_bounds__(BM_BLOCK) bm_match_kernel(BmArgs a, DevParams 
   }
   // the reference's per-reason failure counters (EventBM.h:89, EventBM.cpp:107,124,135): one atomic per wave and reason,
   // striped over CNT_STRIPES addresses so that a launch of 10^5 waves does not queue on one L2 line
-#ifndef BM_NO_FAIL_COUNTERS  // (A/B switch)
   if (a.fail_counters) {
     const bool lead = w < n_out && l == 0;
 #pragma unroll
@@ -388,7 +387,6 @@ __global__ void __launch_bounds__(BM_BLOCK) bm_match_kernel(BmArgs a, DevParams 
         atomicAdd(a.fail_counters + CNT_BM_FAIL + (r - 1) * CNT_STRIPES + (blockIdx.x % CNT_STRIPES), (u32)n);
     }
   }
-#endif
 }
 
 // ---- any patch size (patch_size_X x patch_size_Y: a run-time parameter upstream, code default 25 x 25, esvo_Mapping.cpp:38-39) ----

@@ -32,12 +32,7 @@ namespace esvo {
 // leave 144 of 512 VGPRs.  At <= 80 VGPRs a second back-stage wave fits where only one did (propagate 114 -> 72,
 // reg_apply 124 -> 78, no spills): +1.5 % per tick.  fuse_cells keeps its 112 (capping it spills; dropping its software
 // prefetch gives 80 and was measured neutral).
-// A/B only (-DBACK_SETPRIO=n): the issue priority of the back stage's waves inside their SIMD (s_setprio 0..3; default 0)
-#ifdef BACK_SETPRIO
-#define BACK_PRIO() __builtin_amdgcn_s_setprio(BACK_SETPRIO)
-#else
-#define BACK_PRIO() do {} while (0)
-#endif
+// (Raising the issue priority of the back stage's waves inside their SIMD -- s_setprio 1..3 -- was measured in round 4: slower.)
 #ifndef BACK_WAVES
 #define BACK_WAVES 6
 #endif
@@ -105,7 +100,6 @@ __device__ inline u32 fuse_bucket(u32 n) {  // n >= 1: 1->0, 2->1, 3..4->2, 5..8
 
 template <int MODEL>
 __global__ void __launch_bounds__(256, BACK_WAVES) propagate_kernel(FuseArgs a, DevParams p, int K) {
-  BACK_PRIO();
   const u32 q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= a.n_pts) return;
   u32 f = 0;  // frame of point q (binary search in the cumulative counts)
@@ -272,7 +266,6 @@ __device__ inline void fuse_record(const DevParams& p, MapCell& c, bool& exists,
 #define FUSE_BITW (FUSE_PMAX / 32 + 1)   // words per cell row (+1: no bank conflicts between the lanes' rows)
 #define FUSE_BUF (FUSE_LDS_CAP_MAX > 2 * FUSE_PMAX + FT_CELLS * FUSE_BITW ? FUSE_LDS_CAP_MAX : 2 * FUSE_PMAX + FT_CELLS * FUSE_BITW)
 __global__ void __launch_bounds__(FT_CELLS, 8) tile_lists_kernel(FuseArgs a, DevParams p, int K, int radius, u32 cap, u32 pmax) {
-  BACK_PRIO();
   __shared__ u32 s_buf[FUSE_BUF];        // fast path: ids | (row, col) | bit rows; dense path: record ids
   __shared__ u32 s_cnt[FT_CELLS];        // dense path: records per cell of the tile
   __shared__ u32 s_off[FT_CELLS + 1];    //             their exclusive scan
@@ -625,7 +618,6 @@ __global__ void __launch_bounds__(FT_CELLS, 8) tile_lists_kernel(FuseArgs a, Dev
 #endif
 template <int MODEL>
 __global__ void __launch_bounds__(FUSE_BLOCK, FUSE_WAVES) fuse_cells_kernel(FuseArgs a, DevParams p, int K, int n_tiles) {
-  BACK_PRIO();
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   const int ncell = p.W * p.H;
   // thread t -> the t-th touched cell in the order "longest class first": class_total[s] = cells before segment s, segments
@@ -645,22 +637,15 @@ __global__ void __launch_bounds__(FUSE_BLOCK, FUSE_WAVES) fuse_cells_kernel(Fuse
   MapCell c;
   bool exists = false;
   u32 numFusion = 0;
-#ifndef FUSE_NO_PREFETCH
   u32 id_nxt = ids[0];
   DevPoint nxt = a.prop[id_nxt / (u32)K];
-#endif
   for (u32 i = 0; i < n; ++i) {
-#ifndef FUSE_NO_PREFETCH
     const u32 id = id_nxt;
     const DevPoint prop = nxt;
     if (i + 1 < n) {  // software prefetch: the next record does not depend on the cell state
       id_nxt = ids[i + 1];
       nxt = a.prop[id_nxt / (u32)K];
     }
-#else
-    const u32 id = ids[i];
-    const DevPoint prop = a.prop[id / (u32)K];
-#endif
     fuse_record<MODEL>(p, c, exists, numFusion, prop, id, crow, ccol);
   }
   a.map[cell] = c;
@@ -675,7 +660,6 @@ __global__ void __launch_bounds__(FUSE_BLOCK, FUSE_WAVES) fuse_cells_kernel(Fuse
 // tick's statistics are cleared / set
 #define FUSE_TURN_B 256
 __global__ void __launch_bounds__(FUSE_TURN_B) fuse_turn_kernel(FuseArgs a, int n_tiles) {
-  BACK_PRIO();
   __shared__ u32 lds[FUSE_TURN_B / ESVO_WAVE];
   constexpr u32 NSEG = FUSE_NB * FUSE_SLICES;
   constexpr u32 PER = NSEG / FUSE_TURN_B;
@@ -765,7 +749,6 @@ __global__ void __launch_bounds__(256) reg_view_kernel(const MapCell* __restrict
                                                        u32* __restrict__ owner_max, u32* __restrict__ owner_min,
                                                        u32* __restrict__ n_elems, int ncell, int W,
                                                        int band0, int band1, int view0, int view1, int l2) {
-  BACK_PRIO();
   const int cell = blockIdx.x * blockDim.x + threadIdx.x;
   bool alive = false;
   if (cell < ncell) {
@@ -827,7 +810,6 @@ __global__ void __launch_bounds__(REG_TX * REG_TY, BACK_WAVES) reg_apply_kernel(
                                                                     const u32* __restrict__ owner_min,
                                                                     const double2* __restrict__ ab,
                                                                     const double2* __restrict__ cd, DevParams p) {
-  BACK_PRIO();
   constexpr int NW = REG_TY;                        // waves of the workgroup
   constexpr int UNITS = 4 * REG_RB;                 // staging units of a block: (row, ab | cd, column half) x 64 lanes
   constexpr int UPW = (UNITS + NW - 1) / NW;        // units per wave

@@ -161,12 +161,8 @@ __device__ inline double in_vgpr(double x) {
 }
 
 template <bool T_LDS> struct LmPose { double T[12]; };            // T_left_virtual (3x4) in registers
-template <> struct LmPose<true> { const double* T; };            // ... in LDS: 24 VGPRs less (the persistent kernel; -DLM_T_IN_LDS)
-#ifdef LM_T_IN_LDS
-#define LM_T_LDS_DEFAULT true
-#else
+template <> struct LmPose<true> { const double* T; };            // ... in LDS: 24 VGPRs less (the persistent kernel)
 #define LM_T_LDS_DEFAULT false
-#endif
 template <bool T_LDS>
 struct LmProblemT : LmPose<T_LDS> {
   double cx, cy;           // rectified left coordinate of the event
@@ -237,15 +233,11 @@ __device__ inline void interp_column(__amdgpu_buffer_rsrc_t img, int W, const Pa
   // first source row of the lane (the wide layout's row group rg owns rows 2 rg, 2 rg + 1 and reads one more; group 3 owns
   // row 6 only: its third source row lies below the block and is not used -- wherever it falls, the load is bounds-checked)
   const int voff = (g.uly + (WIDE ? 2 * rg : 0)) * W + g.ulx + c;
-#ifndef LM_NO_BLOCK_CACHE
   if (__ballot(voff != cvoff) != 0ull) {
-#endif
 #pragma unroll
     for (int y = 0; y <= RL; ++y) cs[y] = (float)(int)__builtin_amdgcn_raw_buffer_load_b8(img, voff, y * W, 0);
     cvoff = voff;
-#ifndef LM_NO_BLOCK_CACHE
   }
-#endif
   double R[RL + 1];
 #pragma unroll
   for (int y = 0; y <= RL; ++y) {
@@ -387,11 +379,7 @@ __device__ bool lm_eval(const DevParams& p, const LmProblemT<T_LDS>& pr, LmCache
   const int N = LM_ROWS * LM_COLS;
   // "tight" evaluation (all but a handful): nu and every non-zero r^2 of the GROUP lie in [2^-100, 2^98].
   const bool tight = match_sum_int<WIDE>((r2_tight && nu_mid) ? 0 : 1) == 0;
-#ifdef LM_EXPERIMENT_NOLOOP
-  if (true) {
-#else
   if ((double)knz * (nu + 1) / (double)N <= 0.94 && minabs >= 1e-6) {
-#endif
     s2 = scale2_0;  // provable outcome of the uncapped loop (header comment)
     LM_COUNT(4, pr.c == 0);
   } else {
@@ -405,7 +393,6 @@ __device__ bool lm_eval(const DevParams& p, const LmProblemT<T_LDS>& pr, LmCache
     // the iteration runs without a single per-operand range test or branch: one exponent test on s1 decides, uniformly
     // for the group.
     bool done = false;
-#ifndef LM_PLAIN_DIV
     if (tight) {
       // sign bit included in the exponent field: a negative or NaN s1 fails the range test
       while ((unsigned)(((__double2hiint(s1) >> 20) & 0xfff) - 923) <= 200u) {
@@ -433,7 +420,6 @@ __device__ bool lm_eval(const DevParams& p, const LmProblemT<T_LDS>& pr, LmCache
         s1 = s2;
       }
     }
-#endif
     while (!done) {
       if constexpr (COUNT) ++iters;
       LM_COUNT(2, pr.c == 0);
@@ -443,11 +429,7 @@ __device__ bool lm_eval(const DevParams& p, const LmProblemT<T_LDS>& pr, LmCache
       double t[RL];
       const Recip rs1 = make_recip(s1);
       const int e_s1 = (__double2hiint(s1) >> 20) & 0x7ff;
-#ifdef LM_PLAIN_DIV
-      if (false) {
-#else
       if (lane_ok && rs1.fast && s1 > 0 && e_r2max - e_s1 < 300) {
-#endif
 #pragma unroll
         for (int y = 0; y < RL; ++y)
           t[y] = div_fast(r2n[y], make_recip(nu + div_fast(r2[y], rs1)));
@@ -467,7 +449,6 @@ __device__ bool lm_eval(const DevParams& p, const LmProblemT<T_LDS>& pr, LmCache
   // (a group-uniform test; s2 is the group's): r^2/s2 <= 2^198, so every divisor nu + r^2/s2 lies in [2^-100, 2^199] and
   // every weight in [2^-200, (nu+1)/nu] -- fdiv.hpp's window and sqrt_moderate's range -- and the seven rows run as a
   // straight line of shared-reciprocal quotients without a per-row test or select.
-#ifndef LM_PLAIN_DIV
   if (tight && (unsigned)(((__double2hiint(s2) >> 20) & 0xfff) - 923) <= 200u) {
     Recip rs2;
     rs2.b = s2;
@@ -483,13 +464,8 @@ __device__ bool lm_eval(const DevParams& p, const LmProblemT<T_LDS>& pr, LmCache
     if constexpr (COUNT) *n_iter = iters;
     return true;
   }
-#endif
   const Recip rs2 = make_recip(s2);
-#ifdef LM_PLAIN_DIV
-  const bool fast2 = false;
-#else
   const bool fast2 = lane_ok && rs2.fast && s2 > 0 && e_r2max - ((__double2hiint(s2) >> 20) & 0x7ff) < 300;
-#endif
 #pragma unroll
   for (int y = 0; y < RL; ++y) {
     // fast2 bounds r^2/s2 below 2^301, so the weight lies in (2^-300, (nu+1)/nu]: sqrt_moderate's range (fdiv.hpp)
@@ -543,20 +519,11 @@ struct LmSplit {
 #define LM_SPLIT_STRIPES 32
 __device__ inline u32 lm_split_stripe(u32 slot) { return (slot >> 2) & (LM_SPLIT_STRIPES - 1); }  // 4 slots per first-stage wave
 
-// Register footprint of the narrow layout (A/B switches, measured in round 3 and left OFF).  The LM kernel shares every SIMD
-// with the latency-bound kernels of the matching and fusion stages, and a kernel trace shows the LM stream and the fusion
-// stream both busy for the whole tick (fuse_cells 0.57 ms beside the LM kernel against 0.33 ms alone).  The experiment: the
-// match's pose matrix in LDS (-DLM_T_IN_LDS, ~160 VGPRs) and the kernel PADDED back to 169..176 VGPRs (-DLM_PAD0 / -DLM_PAD2)
-// so that exactly two LM waves fit per SIMD and 160 VGPRs stay free -- two waves of every fusion-stage kernel (<= 80 VGPRs
-// without fuse_cells' software prefetch) instead of one.  Result: the tick gets LONGER (1.50 ms against 1.39 ms; 1.77 ms
-// in the single launch): more resident waves of the other stages take issue slots from the LM kernel without finishing
-// sooner themselves.  The chip runs this f64 load at ~1.75 GHz; the tick is bound by vector-ALU throughput at that clock.
-#ifndef LM_PAD0
-#define LM_PAD0 0
-#endif
-#ifndef LM_PAD2
-#define LM_PAD2 0
-#endif
+// Register footprint of the narrow layout: 199 VGPRs, two waves per SIMD, 112 registers left for one wave of a matching- or
+// fusion-stage kernel.  Measured in round 3 and not kept (profiles/HISTORY.md): the match's pose matrix in LDS (~160 VGPRs, three
+// waves per SIMD) and the kernel padded to 169..176 VGPRs so that two waves of every fusion-stage kernel fit beside two LM
+// waves -- a faster LM launch and a LONGER tick both times: more resident waves of the other stages take issue slots from the LM
+// kernel without finishing sooner themselves.
 // ---- the pair layout (wide layout, the smallest launches) ----------------------------------------------------------------
 // A small launch lasts as long as its slowest match's DEPENDENT CHAIN of evaluations, and lmdif's chain alternates two kinds:
 // the trial point F(x + p) and, once the step is accepted, the forward-difference point F(x' + h(x')) at the new x' = x + p.
@@ -577,23 +544,11 @@ __global__ void __launch_bounds__(PAIR ? 128 : LM_BLOCK, WIDE ? LM_WIDE_WAVES : 
   static_assert(!PAIR || (WIDE && !L2 && STAGE == 0), "the pair layout is a variant of the wide one");
   static_assert(!BAND || (STAGE == 0 && !PAIR), "routed band launches are single launches of the narrow or the wide layout");
   constexpr int RL = Lay<WIDE>::RL;
-#ifdef LM_SETPRIO  // A/B only: the wave's issue priority inside its SIMD (0..3; default 0 like every other kernel)
-  __builtin_amdgcn_s_setprio(LM_SETPRIO);
-#endif
   // [exchange parity][wave][row][lane]: residuals of the two points evaluated side by side, + whether each was tight
   __shared__ double lds_pair[PAIR ? 2 : 1][2][RL][64];
   __shared__ int lds_pair_tight[PAIR ? 2 : 1][2];
   const int wv = PAIR ? (int)(threadIdx.x >> 6) : 0;
   const int ln = threadIdx.x & 63;
-  constexpr int PAD = (WIDE || L2) ? 0 : (STAGE == 2 ? LM_PAD2 : (STAGE == 0 ? LM_PAD0 : 0));
-  int pad[PAD > 0 ? PAD : 1];
-  if constexpr (PAD > 0) {
-#pragma unroll
-    for (int i = 0; i < PAD; ++i) asm volatile("v_mov_b32 %0, 0" : "=v"(pad[i]));
-  }
-#ifdef LM_T_IN_LDS
-  __shared__ double lds_T[LM_BLOCK / 16][12];
-#endif
   __shared__ double lds_cam[28];
   if (threadIdx.x < 27) {
     const int i = threadIdx.x;
@@ -662,18 +617,8 @@ __global__ void __launch_bounds__(PAIR ? 128 : LM_BLOCK, WIDE ? LM_WIDE_WAVES : 
     double Tlw[16], Tlv[16];
     rigid_inverse(a.T_world_obs, Tlw);
     mat4_mul(Tlw, a.pose_T + (size_t)m.pose_idx * 16, Tlv);
-#ifdef LM_T_IN_LDS
-    double* Tm = lds_T[WIDE ? 0 : (threadIdx.x >> 4)];
-    if (lead) {
-#pragma unroll
-      for (int i = 0; i < 12; ++i) Tm[i] = Tlv[i];
-    }
-    pr.T = Tm;
-    __syncthreads();  // one wave per workgroup: orders the LDS writes before the reads
-#else
 #pragma unroll
     for (int i = 0; i < 12; ++i) pr.T[i] = Tlv[i];
-#endif
   }
   const int N = LM_ROWS * LM_COLS;
   const double ftol = 1e-6, xtol = 1e-6, gtol = 0., factor = 100.;
@@ -898,10 +843,6 @@ __global__ void __launch_bounds__(PAIR ? 128 : LM_BLOCK, WIDE ? LM_WIDE_WAVES : 
     }
   }
 
-  if constexpr (PAD > 0) {  // (the padding registers are live up to here)
-#pragma unroll
-    for (int i = 0; i < PAD; ++i) asm volatile("" ::"v"(pad[i]));
-  }
   if (probe) {
     const u64* sc = a.clk + CLK_SCRATCH + 2 * (size_t)(blockIdx.x / CLK_STRIDE);
     const u64 c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();

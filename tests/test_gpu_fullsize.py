@@ -151,3 +151,31 @@ def test_hd_tick_equals_oracle():
     n_ev, om, _ = _oracle_ticks(rig, stream, p, ticks, 1)[0]
     assert n_ev > 300000 and len(om) > 20000
     _same(maps[0], om)
+
+
+_SWITCH_SETS = [
+    {"ESVO_LM_PERSIST": "1"},                                                       # persistent narrow LM layout
+    {"ESVO_LM_PERSIST": "1", "ESVO_LM_PERSIST_BLOCKS": "300"},                      # ... with fewer groups than matches per pass
+    {"ESVO_COLLECT_ASIDE": "0", "ESVO_RESYNC": "0", "ESVO_FRONT_THROTTLE": "1"},    # round 4's queue discipline
+    {"ESVO_LM_QUEUES": "2"},                                                        # two LM queues whatever the launch size
+    {"ESVO_ONE_STREAM": "1"},                                                       # every stage in one queue
+]
+
+
+@pytest.mark.parametrize("env_set", _SWITCH_SETS, ids=lambda e: "+".join(f"{k[5:]}={v}" for k, v in e.items()))
+def test_scheduling_switches_change_no_bit(full, env_set):
+    """`Scheduling is the library's business and never changes a result` (include/esvo_hip.h): six lazily completed (pipelined)
+    ticks of the benchmarked configuration under the experiment switches that move work between queues or pick another LM layout
+    -- read at esvo_create, only with ESVO_DEV_SWITCHES=1 -- give the DepthMap of the default handle, SHA-1 for SHA-1."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    _, maps = _run(full, eager=False)
+    want = bench.map_sha1(maps[-1])
+    code = ("import bench, sys; sys.path.insert(0, 'tests'); import test_gpu_fullsize as T; "
+            "full = bench.make_workload('dsec640x480', 6); d, m = T._run(full, eager=False); "
+            "print('SHA1', bench.map_sha1(m[-1]), len(m[-1]))")
+    env = dict(os.environ, ESVO_DEV_SWITCHES="1", ESVO_BENCH_STREAM_CACHE="/tmp/esvo_streams_test", **env_set)  # (one generation for the five)
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    got = [l.split() for l in r.stdout.splitlines() if l.startswith("SHA1")][-1]
+    assert got[1] == want and int(got[2]) == len(maps[-1]), (env_set, got, want)

@@ -35,16 +35,10 @@ VARIANTS = [
     ("one_stream", {}, {"ESVO_ONE_STREAM": "1"}),
     ("lm_split", {}, {"ESVO_LM_SPLIT": "1"}),
     ("base_again", {}, {}),
-    # two LM launches in flight (the head of tick k+1's fills the tail of tick k's) -- alone, and with the fusion stage's
-    # stream confined to a few compute units of its own (ESVO_CU_SPLIT) so that it cannot be starved of registers
+    # two LM launches in flight (the head of tick k+1's fills the tail of tick k's).  (Round 4 also ran it with the fusion stage's
+    # stream confined to compute units of its own -- hipExtStreamCreateWithCUMask, 1.5-4 ms per tick: profiles/r04_bound_probe_*.txt;
+    # that switch is gone from the library.)
     ("two_lm", {}, {"ESVO_LM_QUEUES": "2", "ESVO_LM_QUEUES_MAX_EVENTS": "100000000"}),
-    ("cu_back32", {}, {"ESVO_CU_SPLIT": "32"}),
-    ("cu_back16_two_lm", {}, {"ESVO_CU_SPLIT": "16", "ESVO_LM_QUEUES": "2", "ESVO_LM_QUEUES_MAX_EVENTS": "100000000"}),
-    ("cu_back32_two_lm", {}, {"ESVO_CU_SPLIT": "32", "ESVO_LM_QUEUES": "2", "ESVO_LM_QUEUES_MAX_EVENTS": "100000000"}),
-    ("cu_back48_two_lm", {}, {"ESVO_CU_SPLIT": "48", "ESVO_LM_QUEUES": "2", "ESVO_LM_QUEUES_MAX_EVENTS": "100000000"}),
-    ("cu_back64_two_lm", {}, {"ESVO_CU_SPLIT": "64", "ESVO_LM_QUEUES": "2", "ESVO_LM_QUEUES_MAX_EVENTS": "100000000"}),
-    ("cu_back32_front32_two_lm", {}, {"ESVO_CU_SPLIT": "32,32", "ESVO_LM_QUEUES": "2", "ESVO_LM_QUEUES_MAX_EVENTS": "100000000"}),
-    ("cu_back32_front16_two_lm", {}, {"ESVO_CU_SPLIT": "32,16", "ESVO_LM_QUEUES": "2", "ESVO_LM_QUEUES_MAX_EVENTS": "100000000"}),
     ("base_third", {}, {}),
 ]
 
