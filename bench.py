@@ -34,7 +34,7 @@ if ROOT not in sys.path:
 from esvo_amd import lib  # noqa: E402
 # (re-exported: tools/ and tests/ address these through `bench.`)
 from benchlib.baselines import check_against_oracle, cpu_baseline, cpu_baseline_reference, parity_vs_reference_node  # noqa: E402,F401
-from benchlib.multigpu import band_share, selftest, self_launch  # noqa: E402,F401
+from benchlib.multigpu import band_share, selftest, self_launch, tick_share  # noqa: E402,F401
 from benchlib.points import extra_operating_points, reference_faithful_points, sustained_point  # noqa: E402,F401
 from benchlib.roofline import (TRAFFIC_NOTE, algorithmic_bytes, attach_measured_clock, committed_profile, profile_figures,  # noqa: E402,F401
                                roofline_rows, whole_tick_valu)
@@ -56,6 +56,8 @@ def main():
                     help="also the heavy secondary points (346x260 throughput, closed loop, 1280x720 stress stream, PCIe-inclusive "
                          "ingest): minutes; the default run keeps to what the driver's time budget allows")
     ap.add_argument("--no-band-share", action="store_true", help="skip the band-mode projection block (8 and 16 logical shards on this GPU)")
+    ap.add_argument("--no-tick-share", action="store_true",
+                    help="skip the tick-interleaved projection block (rank 0 of a world-8 run on this GPU, the other ranks' frames pre-recorded)")
     ap.add_argument("--timed-ingest", action="store_true",
                     help="stage each tick's events inside the timed loop (PCIe-inclusive rate; the default stages the whole stream first)")
     ap.add_argument("--r01-scene", action="store_true", help="round 1's thinning scene (like-for-like comparisons only)")
@@ -142,6 +144,8 @@ def main():
             # for other backends (gloo on a shared GPU: tests), with ESVO_NATIVE_COMM=0, and as the fallback below.
             if use_native:
                 cls = edist.NativeTickSharded if shard_mode == "tick" else edist.NativeBandSharded
+            elif shard_mode == "tick" and os.environ.get("ESVO_DIST_BACKEND", "nccl") == "nccl":
+                cls = edist.CallbackTickSharded   # the same C round logic (two rounds in flight), torch.distributed's all-gather as its transport
             else:
                 cls = edist.TickShardedEsvo if shard_mode == "tick" else edist.ShardedEsvo
             return cls(p, rig, rank, world, local_rank)
@@ -380,6 +384,18 @@ def main():
         except Exception as e:  # noqa: BLE001
             out["band_share"] = {"error": f"{type(e).__name__}: {e}"}
         lap("band_share")
+    if rank == 0 and world == 1 and not args.no_extras and not args.no_tick_share and not args.timed_ingest:
+        # the mode whose number lands on the N-GPU line (`value` at --gpus N): what one rank of a world-8 run does per round
+        try:
+            if runner is not None:
+                runner.close()
+                runner = None
+            sus = out.get("sustained") or {}
+            out["tick_share"] = tick_share(args.workload, local_rank, events_cap=args.events_per_tick,
+                                           one_gpu_ms_per_tick=sus.get("ms_per_tick") or out["ms_per_step"])
+        except Exception as e:  # noqa: BLE001
+            out["tick_share"] = {"error": f"{type(e).__name__}: {e}"}
+        lap("tick_share")
     ref_maps = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:

@@ -98,15 +98,24 @@ def selftest(rank, world, local_rank, dist, ranks_seen, rccl, n_ticks=6):
         res["exchange"] = "esvo_comm_* (RCCL inside libesvo_hip.so)" if native else f"torch.distributed ({backend})"
         # "band": events routed by image row, banded Time Surfaces; "band_broadcast": the A/B switch (every rank
         # stages everything, per-event work dealt by slot)
-        for mode in ("tick", "band", "band_broadcast"):
-            cls = ((edist.NativeTickSharded if mode == "tick" else edist.NativeBandSharded) if native
-                   else (edist.TickShardedEsvo if mode == "tick" else edist.ShardedEsvo))
-            kw = {} if mode == "tick" else {"routing": "y_rect" if mode == "band" else "broadcast"}
+        # "tick_torch": the C round logic of "tick" (two rounds in flight) with torch.distributed's all-gather as its transport --
+        # what bench.py falls back to when the library's own RCCL binding fails in warm-up
+        for mode in ("tick", "tick_torch", "band", "band_broadcast"):
+            if mode == "tick_torch":
+                cls = edist.CallbackTickSharded
+            else:
+                cls = ((edist.NativeTickSharded if mode == "tick" else edist.NativeBandSharded) if native
+                       else (edist.TickShardedEsvo if mode == "tick" else edist.ShardedEsvo))
+            kw = {} if mode.startswith("tick") else {"routing": "y_rect" if mode == "band" else "broadcast"}
             t0 = time.perf_counter()
             try:
                 runner = cls(p, rig, rank, world, local_rank, **kw)
                 gm = drive(runner)
                 shas[mode] = {"sha1": map_sha1(gm), "map_size": int(len(gm)), "seconds": round(time.perf_counter() - t0, 2)}
+                if mode == "tick_torch" or (mode == "tick" and native):
+                    cs_ = runner.comm_stats()
+                    shas[mode]["exchange"] = {"rounds": int(cs_.rounds), "gathers": int(cs_.gathers), "regrows": int(cs_.regrows),
+                                              "bytes_sent": int(cs_.bytes_sent), "payload_bytes_all_ranks": int(cs_.points_gathered) * 104}
                 if mode == "band":
                     st_ = runner.stats()
                     shas[mode]["rows"] = runner.dev.shard_rows()
@@ -134,6 +143,163 @@ def selftest(rank, world, local_rank, dist, ranks_seen, rccl, n_ticks=6):
     return res
 
 
+
+
+def tick_share(workload, device, world=8, rounds=20, warm_rounds=3, events_cap=0, one_gpu_ms_per_tick=None, sync_rounds=3):
+    """What ONE rank of a `world`-GPU tick-interleaved run (`value` at N > 1: esvo_comm_tick) does per round of `world` ticks,
+    measured on this one GPU -- a PROJECTION, not a scaling measurement.  Rank 0 of a world-8 communicator with a callback
+    transport maps its own ticks (k = 0 mod 8) of the headline workload for real -- Time Surfaces, block matching, LM, the
+    frame compaction, the window of ALL ticks' frames, fusion, clean, regulariser -- and scatters the other ranks' ticks' events
+    into its SAE, exactly as in an 8-GPU run; the other ranks' frames were recorded beforehand from a one-GPU run over the same
+    ticks, and the all-gather is emulated on the library's exchange stream by device copies of those blocks (same bytes into
+    the same buffers; what the links would add is stated as arithmetic, not measured).
+      round_ms_pipelined     rounds back to back, no synchronisation (two rounds in flight, as the bench drives it): the
+                             figure the projected speed-up uses -- N x (one GPU's sustained ms per tick) / round_ms_pipelined
+      round_ms_synchronised  one round alone, flushed and synchronised: front + exchange + back in sequence (latency)
+    The rank's own frames must equal the recorded ones and its last DepthMap the one-GPU map of that tick (SHA-1)."""
+    import torch
+    from .points import looped_workload
+    n_rounds = warm_rounds + rounds + sync_rounds
+    n_ticks = world * n_rounds
+    rig, stream, p, ticks, stage, _ = looped_workload(workload, n_ticks, events_cap)
+    out = {"what": f"projection: rank 0 of a world-{world} tick-interleaved run on ONE GPU; own ticks mapped for real, the other ranks' "
+                   "frames pre-recorded from a one-GPU run, the all-gather emulated by device copies on the exchange stream",
+           "world": world, "rounds_timed": rounds}
+    words = 13
+    # ---- the one-GPU run: every tick's frame as the block another rank would contribute; the map at rank 0's last own tick
+    one = lib.Esvo(p, rig, device=device)
+    stage(one)
+    last_own = (n_rounds - 1) * world
+    blocks, ref_sha, n_pts = [], None, []
+    for k, (t, stamps, poses, T) in enumerate(ticks):
+        one.tick_resident(t, T, stamps, poses)
+        fr = one.get_last_frame()
+        n_pts.append(len(fr))
+        blk = torch.empty(2 + len(fr) * words, dtype=torch.int64, device="cuda")
+        blk[0], blk[1] = len(fr), 0
+        if len(fr):
+            blk[2:] = torch.from_numpy(np.frombuffer(fr.tobytes(), dtype=np.int64).copy()).cuda()
+        blocks.append(blk)
+        if k == last_own:
+            ref_sha = map_sha1(one.get_map())
+    one.close()
+    # ---- rank 0 of `world`
+    dev = lib.Esvo(p, rig, device=device)
+    state = {"round": 0, "ext": {}, "own_equal": True, "calls": 0}
+
+    # the other ranks' blocks of a round as ONE padded tensor [world - 1, wmax]: the emulated gather is two device copies per round
+    wmax = max(b.numel() for b in blocks)
+    foreign = []
+    for r in range(n_rounds):
+        f = torch.zeros((world - 1, wmax), dtype=torch.int64, device="cuda")
+        for q in range(1, world):
+            b = blocks[r * world + q]
+            f[q - 1, : b.numel()] = b
+        foreign.append(f)
+    torch.cuda.synchronize()
+    views = {}
+
+    def all_gather(d_send, d_recv, nbytes, hip_stream):
+        if nbytes <= 16:   # the communicator's set-up round trip
+            return 0
+        t_in = time.perf_counter()
+        key = (d_send, d_recv, nbytes, hip_stream)
+        v = views.get(key)
+        if v is None:
+            w = nbytes // 8
+            v = views[key] = (torch.cuda.ExternalStream(int(hip_stream)), edist.device_tensor(d_send, w, "<i8"),
+                              edist.device_tensor(d_recv, world * w, "<i8").view(world, w), w)
+        ext, send, recv, w = v
+        r = state["round"]
+        state["round"] += 1
+        with torch.cuda.stream(ext):
+            recv[0].copy_(send, non_blocking=True)
+            if r < len(foreign):
+                m = min(w, wmax)
+                recv[1:, :m].copy_(foreign[r][:, :m], non_blocking=True)
+            if r % 4 == 0 and r * world < len(blocks):   # the rank's own frame against the recorded one (compared after the run)
+                state.setdefault("own", []).append((r, send[: min(w, blocks[r * world].numel())].clone()))
+        state["cb_s"] = state.get("cb_s", 0.0) + time.perf_counter() - t_in
+        return 0
+
+    dev.comm_init_callbacks(0, world, all_gather)
+    stage(dev)
+
+    def run_rounds(a, b, sync_each=False):
+        for r in range(a, b):
+            for q in range(world):
+                t, stamps, poses, T = ticks[r * world + q]
+                t_in = time.perf_counter()
+                dev.comm_tick_resident(t, T, stamps, poses)
+                state["host_s"][min(q, 1) if q < world - 1 else 2] += time.perf_counter() - t_in
+            if sync_each:
+                dev.comm_flush()
+                dev.synchronize()
+
+    state["host_s"] = [0.0, 0.0, 0.0]
+    run_rounds(0, warm_rounds)
+    dev.comm_flush()
+    dev.synchronize()
+    state["host_s"], state["cb_s"] = [0.0, 0.0, 0.0], 0.0
+    base = dev.stats()
+    cb = dev.comm_stats()
+    base_comm = (int(cb.gathers), int(cb.bytes_sent), int(cb.points_gathered), int(cb.rounds))
+    t0 = time.perf_counter()
+    run_rounds(warm_rounds, warm_rounds + rounds)
+    dev.comm_flush()
+    dev.synchronize()
+    dt = time.perf_counter() - t0
+    host_s, cb_s = list(state["host_s"]), state["cb_s"]
+    st = dev.stats()
+    cs = dev.comm_stats()
+    ksum = np.array(list(st.sum_ms_kernel)) - np.array(list(base.sum_ms_kernel))
+    ks = ksum / max(int(st.ticks - base.ticks), 1)
+    sync_ms = []
+    for r in range(warm_rounds + rounds, n_rounds):
+        t1 = time.perf_counter()
+        run_rounds(r, r + 1, sync_each=True)
+        sync_ms.append((time.perf_counter() - t1) * 1e3)
+    got_sha = map_sha1(dev.get_map())
+    own_equal = all(bool(torch.equal(snd, blocks[r * world][: snd.numel()])) for r, snd in state.get("own", []))
+    st_end = dev.comm_stats()
+    dev.close()
+    g = max(int(cs.gathers) - base_comm[0], 1)
+    block_bytes = (int(cs.bytes_sent) - base_comm[1]) / g
+    payload = (int(cs.points_gathered) - base_comm[2]) * 104 / max(int(cs.rounds) - base_comm[3], 1) / world
+    round_ms = dt / rounds * 1e3
+    out.update({
+        "round_ms_pipelined": round_ms,
+        "round_ms_synchronised": {"mean": float(np.mean(sync_ms)), "min": float(np.min(sync_ms))} if sync_ms else None,
+        "host_ms_per_round": {"own_tick_call": host_s[0] / rounds * 1e3, "foreign_tick_calls": host_s[1] / rounds * 1e3,
+                              "round_end_call": host_s[2] / rounds * 1e3, "of_which_emulated_gather_python": cb_s / rounds * 1e3,
+                              "note": "host time inside the esvo_comm_tick_resident calls of a round (rank 0 owns the round's first tick: that call "
+                                      "enqueues the front stage and then waits for the counts of the round before the previous one -- where the "
+                                      "host sleeps when the device is the pace; the round's last call enqueues the exchange)"},
+        "own_ticks_timed": int(st.ticks - base.ticks),
+        "events_per_tick": int(st.total_events_in - base.total_events_in) // max(int(st.ticks - base.ticks), 1),
+        "points_per_tick_mean": float(np.mean(n_pts)),
+        "kernel_ms_own_tick": {"ts_scatter_own_tick": round(float(2 * ksum[0] / ksum[7]) if ksum[7] > 0 else 0.0, 4),
+                               "ts_render": round(float(2 * ksum[1] / ksum[7]) if ksum[7] > 0 else 0.0, 4),
+                               "bm_match": round(float(ks[2]), 4), "lm_refine": round(float(ks[3]), 4), "fuse": round(float(ks[4]), 4),
+                               "clean": round(float(ks[5]), 4), "regularize": round(float(ks[6]), 4)},
+        "exchange": {"block_bytes_per_rank_per_round": block_bytes, "payload_bytes_per_rank_per_round": payload,
+                     "block_over_payload": block_bytes / payload if payload else None,
+                     "block_points_last": int(st_end.last_stride_points), "regrows": int(st_end.regrows),
+                     "emulation": f"{world - 1} device copies of the recorded blocks + the own block into the receive buffer, on the library's exchange stream",
+                     "xgmi_estimate_us": round(block_bytes / 60e9 * 1e6 + 30.0, 1),
+                     "xgmi_estimate_note": "arithmetic, NOT measured: a rank sends its block to 7 peers over 7 links in parallel (~60 GB/s "
+                                           "per direction per link sustained) + ~30 us of collective latency; it travels on the exchange "
+                                           "stream beside the next round's front stage, so it adds to the round only what it takes from the "
+                                           "LM kernel's memory traffic (none: 12 GB/s)"},
+        "own_frames_equal_recorded": bool(own_equal),
+        "map_equal_to_one_gpu": got_sha == ref_sha,
+        "pipeline_resyncs": int(st.pipeline_resyncs - base.pipeline_resyncs),
+    })
+    if one_gpu_ms_per_tick:
+        out["one_gpu_ms_per_tick_sustained"] = one_gpu_ms_per_tick
+        out["projected_speedup_at_world"] = world * one_gpu_ms_per_tick / round_ms
+        out["projected_events_per_s_at_world"] = world * out["events_per_tick"] / (round_ms * 1e-3)
+    return out
 
 
 def band_share(workload, device, shards=(8,), steps=5, warmup=2, events_cap=0):

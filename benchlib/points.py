@@ -18,23 +18,18 @@ from .roofline import attach_measured_clock, committed_profile, roofline_rows, w
 from .workload import HIST_S, KERNEL_NAMES, TICK_S, WORKLOADS, make_workload, run_single, shift_events  # noqa: E402
 
 
-def sustained_point(name, n_ticks, device, prof, events_cap=0, base_ticks=40, hook=None):
-    """The headline workload for >= 2 s of wall time instead of 20 ticks (28 ms): long enough for the chip's power management
-    to settle, with the shader clock measured inside the run.  Generating 16 s of synthetic stream would take minutes of
-    numpy, so the stationary stream is LOOPED: 60 ms of history, then a segment of `base_ticks` ticks played again and again
-    with its time stamps advanced by the segment's length; the trajectory continues (the rig keeps moving at its speed, each
-    pass starts from the segment's first pose shifted along the direction of travel), so windows, propagation and fusion see
-    a continuous motion.  At each seam the scene jumps back to the segment's first arrangement: for ~6 ticks (the 60 ms the
-    Time Surfaces remember) the surfaces mix two arrangements -- `seam_ticks` says how many ticks that concerns.  Everything is
-    staged in HBM before the timed region, as for `value`."""
+def looped_workload(name, n_ticks, events_cap=0, base_ticks=40):
+    """n_ticks ticks of a bench workload without generating n_ticks x 10 ms of synthetic stream: 60 ms of history, then a
+    segment of `base_ticks` ticks played again and again with its time stamps advanced by the segment's length; the trajectory
+    continues (each pass starts from the segment's first pose shifted along the direction of travel).
+    Returns (rig, stream, params, ticks, stage, passes); stage(dev) pushes history + passes into a handle."""
     wl = WORKLOADS[name]
     rig, stream, p0, ticks0 = make_workload(name, base_ticks, events_cap)
     T_b = int(round(base_ticks * TICK_S * 1e9))
     t_seg0 = stream.t0_ns + int(round(HIST_S * 1e9))       # the segment covers [t_seg0, t_seg0 + T_b)
     hist = (stream.slice(0, stream.t0_ns, t_seg0), stream.slice(1, stream.t0_ns, t_seg0))
     seg = (stream.slice(0, t_seg0, t_seg0 + T_b), stream.slice(1, t_seg0, t_seg0 + T_b))
-    n_warm = 8
-    loops = (n_ticks + n_warm + base_ticks - 1) // base_ticks
+    loops = (n_ticks + base_ticks - 1) // base_ticks
     total = max(len(hist[0]) + loops * len(seg[0]), len(hist[1]) + loops * len(seg[1]))
     p, _ = params.make_params(params.PRESETS[wl["preset"]], rig, throughput_events=p0.process_event_num,
                               event_ring_capacity=int(total * 1.01) + 4096)
@@ -46,17 +41,34 @@ def sustained_point(name, n_ticks, device, prof, events_cap=0, base_ticks=40, ho
         T[0, 3] += k * dx
         return T
 
-    t_gen = time.perf_counter()
-    dev = lib.Esvo(p, rig, device=device)
-    for cam in (0, 1):
-        dev.ts_push_events(cam, hist[cam])
-        for k in range(loops):
-            dev.ts_push_events(cam, shift_events(seg[cam], k * T_b) if k else seg[cam])
+    def stage(dev):
+        for cam in (0, 1):
+            dev.ts_push_events(cam, hist[cam])
+            for k in range(loops):
+                dev.ts_push_events(cam, shift_events(seg[cam], k * T_b) if k else seg[cam])
+
     ticks = []
-    for k in range(n_ticks + n_warm):
+    for k in range(n_ticks):
         t = t_seg0 + (k + 1) * int(round(TICK_S * 1e9))
         stamps, poses = rostime.pose_table(pose, t, p.bm_half_slice_thickness)
         ticks.append((t, stamps, poses, pose(t)))
+    return rig, stream, p, ticks, stage, loops
+
+
+def sustained_point(name, n_ticks, device, prof, events_cap=0, base_ticks=40, hook=None):
+    """The headline workload for >= 2 s of wall time instead of 20 ticks (28 ms): long enough for the chip's power management
+    to settle, with the shader clock measured inside the run.  Generating 16 s of synthetic stream would take minutes of
+    numpy, so the stationary stream is LOOPED: 60 ms of history, then a segment of `base_ticks` ticks played again and again
+    with its time stamps advanced by the segment's length; the trajectory continues (the rig keeps moving at its speed, each
+    pass starts from the segment's first pose shifted along the direction of travel), so windows, propagation and fusion see
+    a continuous motion.  At each seam the scene jumps back to the segment's first arrangement: for ~6 ticks (the 60 ms the
+    Time Surfaces remember) the surfaces mix two arrangements -- `seam_ticks` says how many ticks that concerns.  Everything is
+    staged in HBM before the timed region, as for `value`."""
+    n_warm = 8
+    t_gen = time.perf_counter()
+    rig, stream, p, ticks, stage, loops = looped_workload(name, n_ticks + n_warm, events_cap, base_ticks)
+    dev = lib.Esvo(p, rig, device=device)
+    stage(dev)
     t_gen = time.perf_counter() - t_gen
     run_single(dev, stream, ticks, 0, n_warm)
     dev.synchronize()

@@ -126,6 +126,14 @@ class StatsStruct(C.Structure):
         return tot, per
 
 
+class CommStatsStruct(C.Structure):
+    """esvo_comm_stats_t (ABI 7): the tick-interleaved frame exchange of one rank"""
+    _fields_ = [
+        ("rounds", C.c_uint64), ("gathers", C.c_uint64), ("regrows", C.c_uint64), ("bytes_sent", C.c_uint64),
+        ("points_gathered", C.c_uint64), ("last_stride_points", C.c_uint32), ("stride_cap_points", C.c_uint32),
+    ]
+
+
 def make_events(x, y, t_ns, polarity=None):
     """Build an esvo_event_t array from coordinate / nanosecond-timestamp arrays."""
     t_ns = np.asarray(t_ns, dtype=np.uint64)

@@ -20,17 +20,11 @@
 #include "context.hpp"
 
 namespace esvo {
-// header: point count; the frame follows at byte 16 (DevPoint is 8-byte aligned, 104 B)
-__global__ void __launch_bounds__(256) comm_pack_kernel(const u32* __restrict__ n_points, u32 have, const u64* __restrict__ src,
-                                                        u64* __restrict__ block, u32 first, u32 stride_pts) {
-  const u32 n = have ? *n_points : 0u;
-  const u32 words = 13;  // sizeof(DevPoint) / 8
-  const u32 lo = first < n ? first : n;
-  const u32 cnt = (n - lo) < stride_pts ? (n - lo) : stride_pts;
-  const u64 total = (u64)cnt * words;
-  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (u64)gridDim.x * blockDim.x)
-    block[2 + i] = src[(u64)lo * words + i];
-  if (blockIdx.x == 0 && threadIdx.x == 0) { block[0] = n; block[1] = first; }
+// a block = [point count | 0 | the frame: DevPoint is 8-byte aligned, 104 B]; the frame is compacted straight into its place
+// behind the header (run_order_points), this writes the header once the count is on the device
+__global__ void comm_block_header_kernel(const u32* __restrict__ n_points, u64* __restrict__ block) {
+  block[0] = *n_points;
+  block[1] = 0;
 }
 __global__ void comm_headers_kernel(const u64* __restrict__ recv, size_t block_words, int world, u64* __restrict__ out) {
   const int r = threadIdx.x;
@@ -84,6 +78,29 @@ struct RoundTick {
   std::vector<double> poses;  // m x 16
   u32 m;
 };
+// One round of `world` ticks.  Up to two rounds are in flight per rank: the exchange of round j is enqueued when the round's last
+// tick has been handed in; its counts are looked at -- the one host wait of a round -- only after this rank's front stage of
+// round j + 1 has been enqueued (or right before the exchange of round j + 1 goes out, whichever comes first).  So the
+// exchange, the host's wake-up and the enqueueing of the next front stage are all off the chain LM -> LM that paces a rank.
+struct CommRound {
+  std::vector<RoundTick> ticks;
+  u64 k0 = 0;              // index of its first tick
+  int own_slot = -1;       // this rank mapped one of them: which OwnTick slot holds its frame, counters and events
+  double own_T[16];
+  int buf = 0;             // which d_recv / h_heads / event set its gather uses
+  u32 stride = 0;          // points per block of its gather
+};
+// What a rank keeps of each of its own ticks until the tick's round has been collected -- four deep, because the front stage
+// of the own tick two rounds later (same front parity) is enqueued BEFORE that happens: the block the frame is compacted
+// into (and re-gathered from, should the blocks have to grow), the pinned counter row, the front-stage events, the tick state.
+struct OwnTick {
+  u64* d_block = nullptr;              // [2 + max_ev * 13] header + frame
+  u32* h_cnt = nullptr;                // pinned, CNT_ROW
+  hipEvent_t ev[EV_FRONT_STRIDE];      // installed into h->evt[EV_T0 + fp * EV_FRONT_STRIDE ...] while the tick's front stage is enqueued
+  esvo_context::TickState tk;
+  int fp = 0;
+  bool live = false;                   // enqueued; EV_CNT of this slot marks "frame, header and counters ready"
+};
 struct esvo_comm {
   int rank = 0, world = 1;
   ncclComm_t nccl = nullptr;
@@ -91,39 +108,71 @@ struct esvo_comm {
   void* cb_user = nullptr;
   // tick-interleaved mode
   u64 k = 0;                       // index of the next tick
-  std::vector<RoundTick> round;    // ticks of the round being assembled
-  bool have_own = false;           // this rank mapped one of them ...
-  int own_fp = 0;                  // ... whose front-stage parity this is
-  double own_T[16];
+  CommRound cur;                   // the round being assembled
+  std::deque<CommRound> inflight;  // gather enqueued, frames not pushed yet (oldest first; at most two)
   long long last_own = -1;         // index of the last tick this rank fused
-  u32 stride_pts = 65536;          // points per block of the all-gather (grows on demand, identically on every rank)
-  u64* d_send = nullptr;
+  u32 stride_cap = 65536;          // points per block the receive buffers hold (grows on demand, identically on every rank)
+  u32 recent_max[4] = {0, 0, 0, 0};  // largest frame of each of the last four rounds whose counts the host has seen
+  u32 n_recent = 0;
+  hipStream_t sc = nullptr;        // the exchange: all-gather, counts to the host -- beside the front stages of the next rounds
+  OwnTick own[4];
+  u64 own_seq = 0;                 // own ticks so far
+  int last_slot_of_fp[2] = {-1, -1};
+  hipEvent_t orig_ev[2][EV_FRONT_STRIDE];  // the handle's own front-stage events, put back by esvo_comm_destroy
+  u64* d_empty = nullptr;          // the block of a round without an own tick (a flushed partial round): zeros
   u64* d_recv[2] = {nullptr, nullptr};
-  u64* d_heads = nullptr;          // [world] point counts of the gathered blocks
+  u64* d_heads = nullptr;          // [2][world] point counts of the gathered blocks
   u64* d_map_heads = nullptr;      // esvo_comm_newest_map: [2] send + [2 * world] gathered (size, tick index + 1) -- a buffer of
                                    // its own: the back stream may still copy frames out of d_recv[] while the maps are exchanged
-  u64* h_heads = nullptr;          // pinned
+  u64* h_heads = nullptr;          // pinned, [2][world]
+  hipEvent_t gathered[2];          // the gather into d_recv[i] and the copy of its counts have completed
   hipEvent_t pushed[2];            // the back stream has copied every frame out of d_recv[i]
-  bool pushed_ok = false;
-  u64 rounds = 0;
+  bool events_ok = false;
+  u64 rounds = 0;                  // rounds whose gather has been enqueued
+  esvo_comm_stats_t st = {};
   // band mode: all-gather of the band maps
   u64* d_band_send = nullptr;
   u64* d_band_recv = nullptr;
   size_t band_block_words = 0;
-  size_t block_words() const { return 2 + (size_t)stride_pts * 13; }
+  static size_t block_words(u32 stride) { return 2 + (size_t)stride * 13; }
 };
 
 namespace esvo_host {
 void comm_release(esvo_context* h) {
   esvo_comm* c = h->comm;
   if (!c) return;
-  for (void* p : {(void*)c->d_send, (void*)c->d_recv[0], (void*)c->d_recv[1], (void*)c->d_heads, (void*)c->d_map_heads, (void*)c->d_band_send, (void*)c->d_band_recv})
+  if (c->sc) hipStreamSynchronize(c->sc);
+  for (void* p : {(void*)c->d_empty, (void*)c->d_recv[0], (void*)c->d_recv[1], (void*)c->d_heads, (void*)c->d_map_heads, (void*)c->d_band_send, (void*)c->d_band_recv})
     if (p) hipFree(p);
   if (c->h_heads) hipHostFree(c->h_heads);
-  if (c->pushed_ok) { hipEventDestroy(c->pushed[0]); hipEventDestroy(c->pushed[1]); }
+  if (c->events_ok) {
+    for (int i = 0; i < 2; ++i) { hipEventDestroy(c->pushed[i]); hipEventDestroy(c->gathered[i]); }
+    // the handle gets its own front-stage events back (nothing is in flight: the callers drained every stream)
+    for (int fp = 0; fp < 2; ++fp)
+      for (int i = 0; i < EV_FRONT_STRIDE; ++i) h->evt[EV_T0 + fp * EV_FRONT_STRIDE + i] = c->orig_ev[fp][i];
+    for (OwnTick& o : c->own) {
+      for (int i = 0; i < EV_FRONT_STRIDE; ++i) hipEventDestroy(o.ev[i]);
+      if (o.d_block) hipFree(o.d_block);
+      if (o.h_cnt) hipHostFree(o.h_cnt);
+    }
+  }
   if (c->nccl && g_rccl.CommDestroy) g_rccl.CommDestroy(c->nccl);
+  if (c->sc) hipStreamDestroy(c->sc);
   delete c;
   h->comm = nullptr;
+}
+// esvo_reset on a handle with a communicator (collective like every esvo_comm_* call): rounds in flight are dropped with
+// the window they would have entered
+void comm_reset(esvo_context* h) {
+  esvo_comm* c = h->comm;
+  if (!c) return;
+  if (c->sc) hipStreamSynchronize(c->sc);
+  c->cur = CommRound();
+  c->inflight.clear();
+  c->k = 0;
+  c->last_own = -1;
+  for (OwnTick& o : c->own) o.live = false;
+  c->last_slot_of_fp[0] = c->last_slot_of_fp[1] = -1;
 }
 }  // namespace esvo_host
 
@@ -137,23 +186,25 @@ namespace {
     }                                                                                                         \
   } while (0)
 
-int comm_all_gather(esvo_context* h, const void* d_send, void* d_recv, size_t bytes) {
+int comm_all_gather(esvo_context* h, const void* d_send, void* d_recv, size_t bytes, hipStream_t st = nullptr) {
   esvo_comm* c = h->comm;
+  if (!st) st = h->stream;
   if (c->cb_gather) {
-    if (c->cb_gather(c->cb_user, d_send, d_recv, bytes, h->stream)) FAIL(ESVO_ERR_HIP, "all-gather callback failed");
+    if (c->cb_gather(c->cb_user, d_send, d_recv, bytes, st)) FAIL(ESVO_ERR_HIP, "all-gather callback failed");
     return ESVO_OK;
   }
-  NCCLCHK(g_rccl.AllGather(d_send, d_recv, bytes, ncclUint8, c->nccl, h->stream));
+  NCCLCHK(g_rccl.AllGather(d_send, d_recv, bytes, ncclUint8, c->nccl, st));
   return ESVO_OK;
 }
 
 int comm_alloc(esvo_context* h) {
   esvo_comm* c = h->comm;
-  for (void* p : {(void*)c->d_send, (void*)c->d_recv[0], (void*)c->d_recv[1]})
+  for (void* p : {(void*)c->d_empty, (void*)c->d_recv[0], (void*)c->d_recv[1]})
     if (p) hipFree(p);
-  c->d_send = c->d_recv[0] = c->d_recv[1] = nullptr;
-  const size_t bw = c->block_words();
-  HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->d_send), bw * 8));
+  c->d_empty = c->d_recv[0] = c->d_recv[1] = nullptr;
+  const size_t bw = esvo_comm::block_words(c->stride_cap);
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->d_empty), bw * 8));
+  HIPCHK(hipMemset(c->d_empty, 0, bw * 8));
   HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->d_recv[0]), bw * 8 * c->world));
   HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->d_recv[1]), bw * 8 * c->world));
   return ESVO_OK;
@@ -163,79 +214,135 @@ int comm_setup(esvo_context* h, int rank, int world) {
   esvo_comm* c = h->comm;
   c->rank = rank;
   c->world = world;
-  if (h->prm.max_events_per_tick > 0 && (u32)h->prm.max_events_per_tick < c->stride_pts)
-    c->stride_pts = (u32)h->prm.max_events_per_tick;  // a tick cannot produce more points than events
+  if (world > 64) FAIL(ESVO_ERR_CAPACITY, "more than 64 ranks");
+  if (h->prm.max_events_per_tick > 0 && (u32)h->prm.max_events_per_tick < c->stride_cap)
+    c->stride_cap = (u32)h->prm.max_events_per_tick;  // a tick cannot produce more points than events
+  if (const char* e0 = esvo_dev_switch("ESVO_COMM_STRIDE0")) c->stride_cap = (u32)std::max(1, std::atoi(e0));  // tests: force the regrow path
   int rc = comm_alloc(h);
   if (rc) return rc;
-  HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->d_heads), sizeof(u64) * world));
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->d_heads), sizeof(u64) * 2 * world));
   HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->d_map_heads), sizeof(u64) * (2 + 2 * (size_t)world)));
-  HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&c->h_heads), sizeof(u64) * world));
-  HIPCHK(hipEventCreateWithFlags(&c->pushed[0], hipEventDisableTiming));
-  HIPCHK(hipEventCreateWithFlags(&c->pushed[1], hipEventDisableTiming));
-  c->pushed_ok = true;
+  HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&c->h_heads), sizeof(u64) * 2 * world));
+  for (OwnTick& o : c->own) {  // (a block holds a frame of any size a tick can produce: re-gathered from here when blocks grow)
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&o.d_block), esvo_comm::block_words(h->max_ev) * 8));
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&o.h_cnt), sizeof(u32) * CNT_ROW));
+    std::memset(o.h_cnt, 0, sizeof(u32) * CNT_ROW);
+    for (int i = 0; i < EV_FRONT_STRIDE; ++i) HIPCHK(hipEventCreate(&o.ev[i]));
+  }
+  for (int fp = 0; fp < 2; ++fp)
+    for (int i = 0; i < EV_FRONT_STRIDE; ++i) c->orig_ev[fp][i] = h->evt[EV_T0 + fp * EV_FRONT_STRIDE + i];
+  for (int i = 0; i < 2; ++i) {
+    HIPCHK(hipEventCreateWithFlags(&c->pushed[i], hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->gathered[i], hipEventDisableTiming));
+  }
+  c->events_ok = true;
+  {
+    // The exchange stream gets the HIGH priority of the front and back streams: short, latency-critical work -- and HIP keeps a
+    // pool of hardware queues per priority, so it does not end up in the hardware queue of the ingest or tracker stream, whose
+    // packets would then sit behind this stream's wait for the LM launch.
+    int prio_lo = 0, prio_hi = 0;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+    HIPCHK(hipStreamCreateWithPriority(&c->sc, hipStreamNonBlocking, prio_hi));
+  }
   // one untimed round trip sets up the communicator's channels (and proves the transport works)
-  HIPCHK(hipMemsetAsync(c->d_send, 0, 16, h->stream));
-  rc = comm_all_gather(h, c->d_send, c->d_recv[0], 16);
+  rc = comm_all_gather(h, c->d_empty, c->d_recv[0], 16, c->sc);
   if (rc) return rc;
-  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipStreamSynchronize(c->sc));
   return ESVO_OK;
 }
 
-// pack block [first, first + stride) of this rank's frame of the round (or an empty block) and gather the blocks
-int round_gather(esvo_context* h, u32 first, int buf) {
+// Block length of the next gather: the largest frame of the last four rounds + 25 % (whole 256 points), the buffers' capacity
+// before any count has been seen.  Every rank sees the same counts at the same point of the call sequence, so all of them
+// choose the same length; a frame that does not fit is noticed when its round is collected (round_collect regrows and gathers again).
+u32 pick_stride(const esvo_comm* c) {
+  if (c->n_recent == 0) return c->stride_cap;
+  u32 m = 0;
+  for (u32 i = 0; i < 4u && i < c->n_recent; ++i) m = std::max(m, c->recent_max[i]);
+  const u64 want = ((u64)m + m / 4 + 255) / 256 * 256;
+  return (u32)std::min<u64>(std::max<u64>(want, 256), c->stride_cap);
+}
+
+// enqueue the exchange of a round on the exchange stream: all-gather of the blocks (this rank's own frame sits in its OwnTick
+// block, compacted there by the LM stage; a round without an own tick contributes the empty block), counts to the host
+int round_gather(esvo_context* h, CommRound& R) {
   esvo_comm* c = h->comm;
-  const u32 blocks = std::min<u32>(1024u, (c->stride_pts * 13u + 255u) / 256u);
-  hipLaunchKernelGGL(esvo::comm_pack_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, h->stream, h->d_counters + 1,
-                     c->have_own ? 1u : 0u, reinterpret_cast<const u64*>(h->d_pts_tmp), c->d_send, first, c->stride_pts);
-  const size_t bw = c->block_words();
-  int rc = comm_all_gather(h, c->d_send, c->d_recv[buf], bw * 8);
+  const int buf = R.buf;
+  // d_recv[buf] was last read by the back stream's frame copies of the round two before this one
+  HIPCHK(hipStreamWaitEvent(c->sc, c->pushed[buf], 0));
+  const u64* d_send = c->d_empty;
+  if (R.own_slot >= 0) {  // frame, header and count: behind the LM launch on that tick's queues
+    HIPCHK(hipStreamWaitEvent(c->sc, c->own[R.own_slot].ev[EV_CNT - EV_T0], 0));
+    d_send = c->own[R.own_slot].d_block;
+  }
+  const size_t bw = esvo_comm::block_words(R.stride);
+  int rc = comm_all_gather(h, d_send, c->d_recv[buf], bw * 8, c->sc);
   if (rc) return rc;
-  hipLaunchKernelGGL(esvo::comm_headers_kernel, dim3(1), dim3(64), 0, h->stream, c->d_recv[buf], bw, c->world, c->d_heads);
-  HIPCHK(hipMemcpyAsync(c->h_heads, c->d_heads, sizeof(u64) * c->world, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));  // the one host wait of the round: the window policy needs the counts
+  hipLaunchKernelGGL(esvo::comm_headers_kernel, dim3(1), dim3(64), 0, c->sc, c->d_recv[buf], bw, c->world, c->d_heads + (size_t)buf * c->world);
+  HIPCHK(hipMemcpyAsync(c->h_heads + (size_t)buf * c->world, c->d_heads + (size_t)buf * c->world, sizeof(u64) * c->world, hipMemcpyDeviceToHost, c->sc));
+  HIPCHK(hipEventRecord(c->gathered[buf], c->sc));
+  HIPCHK(hipGetLastError());
+  c->st.gathers++;
+  c->st.bytes_sent += bw * 8;
   return ESVO_OK;
 }
 
-// all-gather the frames of the round, push them in tick order, fuse at the own tick
-int finish_round(esvo_context* h) {
+// the oldest round in flight: wait for its counts (the one host wait of a round -- for a gather that was enqueued a round or
+// more ago), push its frames in tick order, fuse at the own tick
+int round_collect(esvo_context* h) {
   esvo_comm* c = h->comm;
-  if (c->round.empty()) return ESVO_OK;
-  if (c->world > 64) FAIL(ESVO_ERR_CAPACITY, "more than 64 ranks");
-  const int buf = (int)(c->rounds & 1);
-  // d_recv[buf] was last read by the back stream's frame copies two rounds ago
-  HIPCHK(hipStreamWaitEvent(h->stream, c->pushed[buf], 0));
-  int rc = round_gather(h, 0, buf);
-  if (rc) return rc;
-  u64 max_n = 0;
-  for (int r = 0; r < c->world; ++r) max_n = std::max(max_n, c->h_heads[r]);
-  if (max_n > c->stride_pts) {
-    // a frame did not fit its block: every rank sees the same counts, grows its blocks alike and gathers again
-    // (the owners' frames are still in place: nothing was enqueued behind the wait above)
-    c->stride_pts = (u32)std::min<u64>((u64)h->max_ev, max_n + max_n / 4);
-    HIPCHK(hipStreamSynchronize(h->stream_l)); HIPCHK(hipStreamSynchronize(h->stream_l1));
-  HIPCHK(hipStreamSynchronize(h->stream_b));
-    rc = comm_alloc(h);
-    if (rc) return rc;
-    rc = round_gather(h, 0, buf);
-    if (rc) return rc;
+  if (c->inflight.empty()) return ESVO_OK;
+  CommRound& R = c->inflight.front();
+  const u64* heads = c->h_heads + (size_t)R.buf * c->world;
+  HIPCHK(hipEventSynchronize(c->gathered[R.buf]));
+  u64 max_n = 0, sum_n = 0;
+  for (int r = 0; r < c->world; ++r) { max_n = std::max(max_n, heads[r]); sum_n += heads[r]; }
+  if (max_n > R.stride) {
+    // A frame did not fit its block: every rank sees the same counts, grows its blocks alike and gathers again -- this round
+    // and the one enqueued behind it with the same block length.  The owners' frames are still in place (an OwnTick block is
+    // rewritten four own ticks later), and nothing has been pushed out of these gathers yet.
+    HIPCHK(hipStreamSynchronize(c->sc));
+    HIPCHK(hipStreamSynchronize(h->stream_b));
+    const u32 grown = (u32)std::min<u64>((u64)h->max_ev, max_n + max_n / 4);
+    if (grown > c->stride_cap) {
+      c->stride_cap = grown;
+      int rc = comm_alloc(h);
+      if (rc) return rc;
+    }
+    c->st.regrows++;
+    for (CommRound& L : c->inflight) {
+      L.stride = std::max(L.stride, grown);
+      int rc = round_gather(h, L);
+      if (rc) return rc;
+    }
+    HIPCHK(hipEventSynchronize(c->gathered[R.buf]));
+    max_n = 0;
+    for (int r = 0; r < c->world; ++r) max_n = std::max(max_n, heads[r]);
+    if (max_n > R.stride) FAIL(ESVO_ERR_CAPACITY, "a frame is larger than max_events_per_tick");
   }
-  if (c->have_own) {  // front-stage statistics of the own tick (its counters arrived before the gather finished)
-    rc = tick_phase1_collect(h, c->own_fp);
+  c->recent_max[c->n_recent & 3u] = (u32)max_n;
+  c->n_recent++;
+  c->st.rounds++;
+  c->st.points_gathered += sum_n;
+  c->st.last_stride_points = R.stride;
+  if (R.own_slot >= 0) {  // front-stage statistics of the own tick (its counters arrived before the gather finished)
+    OwnTick& o = c->own[R.own_slot];
+    int rc = collect_front_stats(h, o.tk, o.h_cnt, o.ev);
     if (rc) return rc;
+    o.live = false;
   }
-  const size_t bw = c->block_words();
-  const u64 k0 = c->k - c->round.size();
-  for (size_t j = 0; j < c->round.size(); ++j) {
-    const int owner = (int)((k0 + j) % (u64)c->world);  // a round may start anywhere (partial rounds are flushed)
-    const RoundTick& tk = c->round[j];
-    const u32 n = (u32)c->h_heads[owner];
+  const size_t bw = esvo_comm::block_words(R.stride);
+  for (size_t j = 0; j < R.ticks.size(); ++j) {
+    const int owner = (int)((R.k0 + j) % (u64)c->world);  // a round may start anywhere (partial rounds are flushed)
+    const RoundTick& tk = R.ticks[j];
+    const u32 n = (u32)heads[owner];
     u32 off;
-    rc = window_reserve(h, n, &off);
+    int rc = window_reserve(h, n, &off);
     if (rc) return rc;
-    rc = back_after_front(h);
-    if (rc) return rc;
+    // (the frames come out of the gather, not off the front stream: the back stage must not queue behind the front stages of
+    //  the next rounds, which are already enqueued there)
+    HIPCHK(hipStreamWaitEvent(h->stream_b, c->gathered[R.buf], 0));
     if (n)
-      HIPCHK(hipMemcpyAsync(h->d_win + off, c->d_recv[buf] + (size_t)owner * bw + 2, sizeof(DevPoint) * n,
+      HIPCHK(hipMemcpyAsync(h->d_win + off, c->d_recv[R.buf] + (size_t)owner * bw + 2, sizeof(DevPoint) * n,
                             hipMemcpyDeviceToDevice, h->stream_b));
     static const double ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     rc = commit_frame(h, off, n, tk.m ? tk.poses.data() : ident, tk.m);
@@ -245,7 +352,7 @@ int finish_round(esvo_context* h) {
       h->par ^= 1;
       HIPCHK(hipEventSynchronize(h->evt[EV_RG1 + par * EV_BACK_STRIDE]));
       collect_back(h, par);
-      rc = run_fuse(h, par, c->own_T);
+      rc = run_fuse(h, par, R.own_T);
       if (rc) return rc;
       h->committed_t_ns = tk.t_ns;
       h->stats.ticks++;
@@ -254,14 +361,124 @@ int finish_round(esvo_context* h) {
       for (auto& f : h->frames) np += f.count;
       h->stats.last_window_points = np;
       h->stats_pending = true;
-      c->last_own = (long long)(k0 + j);
+      c->last_own = (long long)(R.k0 + j);
     }
   }
-  HIPCHK(hipEventRecord(c->pushed[buf], h->stream_b));
-  c->round.clear();
-  c->have_own = false;
-  c->rounds++;
+  HIPCHK(hipEventRecord(c->pushed[R.buf], h->stream_b));
+  c->inflight.pop_front();
   return ESVO_OK;
+}
+
+// the round being assembled is complete (or flushed): its exchange starts.  At most two rounds are in flight: the receive
+// buffer (and the counts) this gather writes belonged to the round two before it, which is collected first if it still waits.
+int round_launch(esvo_context* h) {
+  esvo_comm* c = h->comm;
+  if (c->cur.ticks.empty()) return ESVO_OK;
+  while (c->inflight.size() > 1) { int rc = round_collect(h); if (rc) return rc; }
+  CommRound R = std::move(c->cur);
+  c->cur = CommRound();
+  R.k0 = c->k - R.ticks.size();
+  R.buf = (int)(c->rounds & 1);
+  R.stride = pick_stride(c);
+  int rc = round_gather(h, R);
+  if (rc) return rc;
+  c->rounds++;
+  c->inflight.push_back(std::move(R));
+  return ESVO_OK;
+}
+
+// everything assembled or in flight: exchanged, pushed, fused (esvo_comm_flush, the map read-outs, esvo_comm_destroy)
+int finish_round(esvo_context* h) {
+  int rc = round_launch(h);
+  while (!rc && !h->comm->inflight.empty()) rc = round_collect(h);
+  return rc;
+}
+
+// the front stage of an own tick: Time Surfaces (render == true), observation, block matching on the front stream; LM on its
+// queue; the frame compacted straight into the tick's exchange block, header and counters behind it
+int own_front(esvo_context* h, uint64_t t_ns, const double T_world_cam[16], const uint64_t* pose_t_ns, const double* pose_T, size_t m,
+              bool render) {
+  esvo_comm* c = h->comm;
+  const int nfp = h->fpar ^ 1;                 // the parity tick_phase0 switches to
+  const int slot = (int)(c->own_seq & 3u);
+  OwnTick& o = c->own[slot];
+  if (o.live) FAIL(ESVO_ERR_STATE, "four own ticks in flight");  // (cannot happen: a round is collected before the one two later goes out)
+  // This front stage rewrites what the own tick two rounds ago (same parity) used -- observation pair, pose table, match list,
+  // counter row, LM output -- and that tick's round may not have been collected yet: behind its frame on the DEVICE.
+  if (c->last_slot_of_fp[nfp] >= 0) HIPCHK(hipStreamWaitEvent(h->stream, c->own[c->last_slot_of_fp[nfp]].ev[EV_CNT - EV_T0], 0));
+  for (int i = 0; i < EV_FRONT_STRIDE; ++i) h->evt[EV_T0 + nfp * EV_FRONT_STRIDE + i] = o.ev[i];
+  int rc;
+  if (render) {  // = esvo_map_tick_resident's front: both cameras in one launch per kernel, the observation written by the remap
+    begin_observation(h);
+    uint8_t* obs[2] = {h->d_obs[0], h->d_obs[1]};
+    rc = ts_render_pair(h, t_ns, h->prm.smooth_time_surface ? nullptr : obs);
+    if (rc) { revert_observation(h); return rc; }
+    if (h->prm.smooth_time_surface)
+      launch_gaussian5_pair(h->d_ts[0], h->d_ts[1], h->d_obs[0], h->d_obs[1], h->W, h->H, h->stream, 0, -1);
+    HIPCHK(hipGetLastError());
+    std::memcpy(h->T_world_obs, T_world_cam, sizeof(double) * 16);
+    h->obs_t_ns = t_ns;
+    h->obs_set = true;
+  } else {
+    rc = esvo_map_set_observation(h, t_ns, nullptr, nullptr, T_world_cam);  // the Time Surfaces this rank rendered last
+    if (rc) return rc;
+  }
+  // the LM launch on its own queue (as in the lazy single-GPU tick): the front stages of the next rounds, enqueued while this
+  // launch runs, overlap it
+  h->split_now = h->lm_split && !h->prm.denoising;
+  rc = tick_phase0(h, t_ns, pose_t_ns, pose_T, m);
+  const bool split = h->split_now;
+  h->split_now = false;
+  if (rc) return rc;
+  const esvo_context::TickState& tk = h->tk[h->fpar];
+  // frame compaction, header and counters: on the idle second LM queue when there is one (the next LM launch then follows this
+  // one directly on its queue), behind the LM kernel
+  hipStream_t sl = tk.n ? tk.lm_stream : h->stream;
+  hipStream_t sn = sl;
+  if (tk.n && split && h->collect_aside && !h->lm_two_now && (sl == h->stream_l || sl == h->stream_l1)) {
+    sn = sl == h->stream_l ? h->stream_l1 : h->stream_l;
+    HIPCHK(hipStreamWaitEvent(sn, h->evt[EV_LM1 + h->fpar * EV_FRONT_STRIDE], 0));
+  }
+  if (tk.n) { rc = run_order_points(h, tk.n, reinterpret_cast<DevPoint*>(o.d_block + 2), sn); if (rc) return rc; }
+  hipLaunchKernelGGL(esvo::comm_block_header_kernel, dim3(1), dim3(1), 0, sn, h->d_counters + 1, o.d_block);
+  HIPCHK(hipMemcpyAsync(o.h_cnt, h->d_counters, sizeof(u32) * CNT_ROW, hipMemcpyDeviceToHost, sn));
+  HIPCHK(hipEventRecord(h->evt[EV_CNT + h->fpar * EV_FRONT_STRIDE], sn));
+  HIPCHK(hipGetLastError());
+  o.tk = tk;
+  o.fp = h->fpar;
+  o.live = true;
+  c->last_slot_of_fp[h->fpar] = slot;
+  c->own_seq++;
+  c->cur.own_slot = slot;
+  std::memcpy(c->cur.own_T, T_world_cam, sizeof(double) * 16);
+  return ESVO_OK;
+}
+
+// one tick of the tick-interleaved mode; `render`: the owner renders both Time Surfaces itself (esvo_comm_tick_resident)
+int comm_tick(esvo_context* h, uint64_t t_ns, const double T_world_cam[16], const uint64_t* pose_t_ns, const double* pose_T, size_t m,
+              bool render) {
+  esvo_comm* c = h->comm;
+  int rc = flush_pending_tick(h);
+  if (rc) return rc;
+  if ((int)(c->k % (u64)c->world) == c->rank) {
+    rc = own_front(h, t_ns, T_world_cam, pose_t_ns, pose_T, m, render);
+    if (rc) return rc;
+  } else {
+    rc = ts_scatter_ahead(h, t_ns);  // the tick's events reach the SAE now (front stream, idle beside the own tick's LM launch)
+    if (rc) return rc;
+  }
+  RoundTick rt;
+  rt.t_ns = t_ns;
+  rt.m = (u32)m;
+  rt.poses.assign(pose_T, pose_T + 16 * m);
+  c->cur.ticks.push_back(std::move(rt));
+  c->k++;
+  // The round before the newest exchange comes in once this rank's front stage of the CURRENT round is enqueued: the host then
+  // waits for counts that left a round ago with two front stages queued behind them on the device.
+  if (c->cur.own_slot >= 0)
+    while (!rc && c->inflight.size() > 1) rc = round_collect(h);
+  if (!rc && (int)c->cur.ticks.size() == c->world) rc = round_launch(h);  // this round's exchange goes out
+  return rc;
 }
 }  // namespace
 
@@ -333,6 +550,7 @@ int esvo_comm_destroy(esvo_handle h) {
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipStreamSynchronize(h->stream));
   HIPCHK(hipStreamSynchronize(h->stream_l)); HIPCHK(hipStreamSynchronize(h->stream_l1));
+  HIPCHK(hipStreamSynchronize(h->comm->sc));
   HIPCHK(hipStreamSynchronize(h->stream_b));
   comm_release(h);
   return ESVO_OK;
@@ -351,29 +569,26 @@ int esvo_comm_tick(esvo_handle h, uint64_t t_ns, const double T_world_cam[16], c
   if (h->sharded) FAIL(ESVO_ERR_STATE, "handle is sharded by slot/band: use esvo_comm_shard_tick");
   if (m > h->max_poses) FAIL(ESVO_ERR_CAPACITY, "pose table larger than max_poses_per_tick");
   HIPCHK(hipSetDevice(h->device));
-  esvo_comm* c = h->comm;
-  int rc = flush_pending_tick(h);
-  if (rc) return rc;
-  if (esvo_comm_owns_next_tick(h)) {
-    rc = esvo_map_set_observation(h, t_ns, nullptr, nullptr, T_world_cam);  // the Time Surfaces this rank rendered last
-    if (rc) return rc;
-    rc = tick_phase0(h, t_ns, pose_t_ns, pose_T, m);
-    if (rc) return rc;
-    const u32 n = h->tk[h->fpar].n;
-    if (n) { rc = run_order_points(h, n, h->d_pts_tmp); if (rc) return rc; }
-    HIPCHK(hipMemcpyAsync(h->h_counters + CNT_ROW * h->fpar, h->d_counters, sizeof(u32) * CNT_ROW, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipEventRecord(h->evt[EV_CNT + h->fpar * EV_FRONT_STRIDE], h->stream));
-    c->have_own = true;
-    c->own_fp = h->fpar;
-    std::memcpy(c->own_T, T_world_cam, sizeof(double) * 16);
-  }
-  RoundTick rt;
-  rt.t_ns = t_ns;
-  rt.m = (u32)m;
-  rt.poses.assign(pose_T, pose_T + 16 * m);
-  c->round.push_back(std::move(rt));
-  c->k++;
-  if ((int)c->round.size() == c->world) return finish_round(h);
+  return comm_tick(h, t_ns, T_world_cam, pose_t_ns, pose_T, m, false);
+}
+
+int esvo_comm_tick_resident(esvo_handle h, uint64_t t_ns, const double T_world_cam[16], const uint64_t* pose_t_ns, const double* pose_T,
+                            size_t m) {
+  if (!h || !T_world_cam || !pose_t_ns || !pose_T) return ESVO_ERR_INVALID_ARG;
+  API_LOCK(h);
+  if (!h->comm) FAIL(ESVO_ERR_STATE, "esvo_comm_init has not been called");
+  if (h->sharded) FAIL(ESVO_ERR_STATE, "handle is sharded by slot/band: use esvo_comm_shard_tick");
+  if (m > h->max_poses) FAIL(ESVO_ERR_CAPACITY, "pose table larger than max_poses_per_tick");
+  HIPCHK(hipSetDevice(h->device));
+  return comm_tick(h, t_ns, T_world_cam, pose_t_ns, pose_T, m, true);
+}
+
+int esvo_comm_get_stats(esvo_handle h, esvo_comm_stats_t* out) {
+  if (!h || !out) return ESVO_ERR_INVALID_ARG;
+  API_LOCK(h);
+  if (!h->comm) FAIL(ESVO_ERR_STATE, "esvo_comm_init has not been called");
+  *out = h->comm->st;
+  out->stride_cap_points = h->comm->stride_cap;
   return ESVO_OK;
 }
 

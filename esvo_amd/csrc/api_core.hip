@@ -478,6 +478,7 @@ int esvo_reset(esvo_handle h) {
   HIPCHK(hipStreamSynchronize(h->stream_b));
   HIPCHK(hipStreamSynchronize(h->stream_t));
   HIPCHK(hipStreamSynchronize(h->stream_i));
+  comm_reset(h);  // (drains the exchange stream of a handle with a communicator)
   for (int cam = 0; cam < 2; ++cam) {
     HIPCHK(hipMemsetAsync(h->d_sae[cam], 0, sizeof(u64) * npx, h->stream));
     if (h->d_tsq[cam]) HIPCHK(hipMemsetAsync(h->d_tsq[cam], 0, sizeof(u64) * npx * (size_t)h->tsq_len, h->stream));

@@ -432,7 +432,7 @@ int export_map(esvo_context* h, std::vector<esvo_depth_point_t>& out, std::vecto
 }  // namespace esvo_host
 
 // =================================================================================================
-namespace {
+namespace esvo_host {
 // a new observation goes into the OTHER pair of buffers: an LM stage still in flight keeps reading its own
 // (the one before that has finished: the call that enqueued it completed its predecessor, context.hpp)
 void begin_observation(esvo_context* h) {
@@ -443,7 +443,13 @@ void begin_observation(esvo_context* h) {
   if (h->tick_pending && h->tk[h->fpar].obs_par == h->obs_par)
     hipStreamWaitEvent(h->stream, h->evt[EV_CNT + h->fpar * EV_FRONT_STRIDE], 0);
 }
-}  // namespace
+// nothing was rendered into the pair begin_observation switched to: the previous observation stays current
+void revert_observation(esvo_context* h) {
+  h->obs_par ^= 1;
+  h->d_obs[0] = h->d_obs2[h->obs_par][0];
+  h->d_obs[1] = h->d_obs2[h->obs_par][1];
+}
+}  // namespace esvo_host
 
 extern "C" {
 
@@ -876,9 +882,14 @@ int tick_phase1_enqueue(esvo_context* h) {
 // phase 1b (host): wait for the counters of the tick of parity fp (one small D2H per tick: the window policy
 // needs the point count), book-keeping, front-stage timings
 int tick_phase1_collect(esvo_context* h, int fp) {
-  esvo_context::TickState& tk = h->tk[fp];
-  HIPCHK(hipEventSynchronize(h->evt[EV_CNT + fp * EV_FRONT_STRIDE]));
-  const u32* cnt = h->h_counters + CNT_ROW * fp;
+  return collect_front_stats(h, h->tk[fp], h->h_counters + CNT_ROW * fp, &h->evt[EV_T0 + fp * EV_FRONT_STRIDE]);
+}
+// the same for a front stage whose counters and events live elsewhere (`ev`: its EV_T0 .. EV_A1 set, indexed EV_x - EV_T0) --
+// the tick-interleaved mode keeps them per own tick, four deep, so that a tick can be collected after the front stage two
+// own ticks later has been enqueued on the same parity
+int collect_front_stats(esvo_context* h, esvo_context::TickState& tk, const u32* cnt, const hipEvent_t* ev) {
+  auto E = [&](int id) { return ev[id - EV_T0]; };
+  HIPCHK(hipEventSynchronize(E(EV_CNT)));
   const u32 n = tk.n;
   const u32 n_points = n ? cnt[1] : 0;
   esvo_stats_t& s = h->stats;
@@ -891,14 +902,13 @@ int tick_phase1_collect(esvo_context* h, int fp) {
   s.total_points += n_points;
   collect_bm_failures(h, cnt, true);
   tk.points = n_points;
-  const int o = fp * EV_FRONT_STRIDE;
   s.ms_bm = s.ms_refine = 0;
   s.ms_kernel[2] = s.ms_kernel[3] = 0;
   if (n) {
-    hipEventElapsedTime(&s.ms_bm, h->evt[EV_T0 + o], h->evt[EV_S1 + o]);
-    hipEventElapsedTime(&s.ms_refine, h->evt[EV_S1 + o], h->evt[EV_S2 + o]);
-    hipEventElapsedTime(&s.ms_kernel[2], h->evt[EV_BM0 + o], h->evt[EV_BM1 + o]);
-    hipEventElapsedTime(&s.ms_kernel[3], h->evt[EV_LM0 + o], h->evt[EV_LM1 + o]);
+    hipEventElapsedTime(&s.ms_bm, E(EV_T0), E(EV_S1));
+    hipEventElapsedTime(&s.ms_refine, E(EV_S1), E(EV_S2));
+    hipEventElapsedTime(&s.ms_kernel[2], E(EV_BM0), E(EV_BM1));
+    hipEventElapsedTime(&s.ms_kernel[3], E(EV_LM0), E(EV_LM1));
     s.sum_ms_kernel[2] += s.ms_kernel[2];
     s.sum_ms_kernel[3] += s.ms_kernel[3];
     h->ema_lm_ms = h->ema_lm_ms > 0.f ? 0.75f * h->ema_lm_ms + 0.25f * s.ms_kernel[3] : s.ms_kernel[3];
@@ -910,7 +920,7 @@ int tick_phase1_collect(esvo_context* h, int fp) {
   if (h->tl_on && h->tl_ref && n) {
     const int fr[8] = {EV_T0, EV_BM0, EV_BM1, EV_S1, EV_LM0, EV_LM1, EV_S2, EV_CNT};
     std::array<float, 8> row;
-    for (int i = 0; i < 8; ++i) { row[i] = -1.f; if (hipEventElapsedTime(&row[i], h->tl_ref, h->evt[fr[i] + o]) != hipSuccess) (void)hipGetLastError(); }
+    for (int i = 0; i < 8; ++i) { row[i] = -1.f; if (hipEventElapsedTime(&row[i], h->tl_ref, E(fr[i])) != hipSuccess) (void)hipGetLastError(); }
     h->tl_front.push_back(row);
   }
   tk.max_kept = (h->sharded && n) ? cnt[9] : 0;
@@ -1043,12 +1053,7 @@ extern "C" int esvo_map_tick_resident(esvo_handle h, uint64_t t_ns, const double
   begin_observation(h);
   uint8_t* obs[2] = {h->d_obs[0], h->d_obs[1]};
   int rc = ts_render_pair(h, t_ns, h->prm.smooth_time_surface ? nullptr : obs);
-  if (rc) {  // nothing was rendered: the previous observation stays current
-    h->obs_par ^= 1;
-    h->d_obs[0] = h->d_obs2[h->obs_par][0];
-    h->d_obs[1] = h->d_obs2[h->obs_par][1];
-    return rc;
-  }
+  if (rc) { revert_observation(h); return rc; }
   if (h->prm.smooth_time_surface)  // createMatchProblem applies GaussianBlurTS(5) when SmoothTimeSurface (EventBM.cpp:68-72)
     launch_gaussian5_pair(h->d_ts[0], h->d_ts[1], h->d_obs[0], h->d_obs[1], h->W, h->H, h->stream, h->routed ? h->oband_y0 : 0,
                           h->routed ? h->oband_y1 : -1);

@@ -394,6 +394,7 @@ void release_routing(esvo_context* h);
 // api_ts.hip
 void collect_ts_timing(esvo_context* h, int only = -1);
 void ingest_fence(esvo_context* h, int cam);  // caller holds mu_ring
+int ts_scatter_ahead(esvo_context* h, uint64_t t_ns);
 void resident_write_begin(esvo_context* h, int cam);
 int ts_render_pair(esvo_context* h, uint64_t t_ns, uint8_t* const obs_out[2]);
 // api_map.hip
@@ -410,9 +411,13 @@ int export_map(esvo_context* h, std::vector<esvo_depth_point_t>& out, std::vecto
 int tick_phase0(esvo_context* h, uint64_t t_ns, const uint64_t* pose_t_ns, const double* pose_T, size_t m);
 int tick_phase1_enqueue(esvo_context* h);
 int tick_phase1_collect(esvo_context* h, int fp);
+int collect_front_stats(esvo_context* h, esvo_context::TickState& tk, const u32* cnt, const hipEvent_t* ev);
 int tick_phase2(esvo_context* h, int fp);
+void begin_observation(esvo_context* h);
+void revert_observation(esvo_context* h);
 // api_comm.hip
 void comm_release(esvo_context* h);
+void comm_reset(esvo_context* h);
 }  // namespace esvo_host
 using namespace esvo_host;
 

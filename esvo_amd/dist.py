@@ -285,7 +285,8 @@ def _native_comm_init(dev, rank, world, group=None):
 
 
 class NativeTickSharded:
-    """TickShardedEsvo with the round logic and the ncclAllGather of frames in C (esvo_comm_tick)."""
+    """TickShardedEsvo with the round logic and the ncclAllGather of frames in C (esvo_comm_tick): two rounds in flight, the
+    exchange on a stream of its own beside the next round's front stage (api_comm.hip)."""
 
     counts_are_local = True
 
@@ -293,8 +294,11 @@ class NativeTickSharded:
         self.rank, self.world = rank, world
         self.rig, self.params = rig, params
         self.dev = lib.Esvo(params, rig, device=local_rank)
-        _native_comm_init(self.dev, rank, world, group)
+        self._init_comm(group)
         self._T = None
+
+    def _init_comm(self, group):
+        _native_comm_init(self.dev, self.rank, self.world, group)
 
     def ts_push_events(self, cam, ev):
         self.dev.ts_push_events(cam, ev)
@@ -310,6 +314,10 @@ class NativeTickSharded:
     def tick(self, t_ns, stamps, poses):
         self.dev.comm_tick(t_ns, self._T, stamps, poses)
 
+    def tick_resident(self, t_ns, T_world_cam, stamps, poses):
+        """the four calls above in one: the owner renders both Time Surfaces inside esvo_comm_tick_resident"""
+        self.dev.comm_tick_resident(t_ns, T_world_cam, stamps, poses)
+
     def synchronize(self):
         self.dev.comm_flush()
         self.dev.synchronize()
@@ -317,8 +325,36 @@ class NativeTickSharded:
     def stats(self):
         return self.dev.stats()
 
+    def comm_stats(self):
+        return self.dev.comm_stats()
+
     def get_map(self):
         return self.dev.comm_newest_map()[0]
+
+
+class CallbackTickSharded(NativeTickSharded):
+    """The same C round logic (esvo_comm_tick: two rounds in flight, count-sized blocks) with the ONE collective it issues
+    supplied by torch.distributed instead of the library's own RCCL binding (esvo_comm_init_callbacks): what bench.py falls
+    back to when esvo_comm_init fails on a node.  The all-gather is enqueued on the stream the library names -- its exchange
+    stream -- so it overlaps the next round's front stage exactly as the native one does."""
+
+    def _init_comm(self, group):
+        import torch
+        import torch.distributed as dist
+        self._group = group
+        self._ext = {}
+
+        def all_gather(d_send, d_recv, nbytes, stream):
+            ext = self._ext.get(stream)
+            if ext is None:
+                ext = self._ext[stream] = torch.cuda.ExternalStream(int(stream))
+            with torch.cuda.stream(ext):
+                send = device_tensor(d_send, nbytes // 8, "<i8")
+                recv = device_tensor(d_recv, self.world * nbytes // 8, "<i8")
+                dist.all_gather_into_tensor(recv, send, group=self._group)
+            return 0
+
+        self.dev.comm_init_callbacks(self.rank, self.world, all_gather)
 
 
 class NativeBandSharded:

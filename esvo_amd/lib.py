@@ -33,7 +33,7 @@ SYMBOLS = [
     "esvo_bag_open", "esvo_bag_close", "esvo_bag_last_error", "esvo_bag_next_event_array", "esvo_ts_push_bag",
     "esvo_map_get_debug_images", "esvo_map_get_pointcloud_near_xyz", "esvo_voxel_filter_xyz", "esvo_map_save_depth_map",
     "esvo_comm_unique_id", "esvo_comm_rccl_info", "esvo_comm_init", "esvo_comm_init_callbacks", "esvo_comm_destroy", "esvo_comm_owns_next_tick",
-    "esvo_comm_tick", "esvo_comm_flush", "esvo_comm_newest_map", "esvo_comm_shard_tick", "esvo_comm_gather_map",
+    "esvo_comm_tick", "esvo_comm_tick_resident", "esvo_comm_get_stats", "esvo_comm_flush", "esvo_comm_newest_map", "esvo_comm_shard_tick", "esvo_comm_gather_map",
 ]
 
 ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
@@ -185,6 +185,8 @@ def load():
     lib.esvo_comm_destroy.argtypes = [vp]
     lib.esvo_comm_owns_next_tick.argtypes = [vp]
     lib.esvo_comm_tick.argtypes = [vp, u64, vp, vp, vp, sz]
+    lib.esvo_comm_tick_resident.argtypes = [vp, u64, vp, vp, vp, sz]
+    lib.esvo_comm_get_stats.argtypes = [vp, vp]
     lib.esvo_comm_flush.argtypes = [vp]
     lib.esvo_comm_newest_map.argtypes = [vp, vp, sz, psz, C.POINTER(C.c_longlong)]
     lib.esvo_comm_shard_tick.argtypes = [vp, u64, vp, vp, sz]
@@ -611,6 +613,19 @@ class Esvo:
         P = np.ascontiguousarray(poses, np.float64).reshape(-1, 16)
         T = np.ascontiguousarray(T_world_cam, np.float64).reshape(16)
         self._ck(self.lib.esvo_comm_tick(self.h, int(t_ns), T.ctypes.data, st.ctypes.data, P.ctypes.data, st.shape[0]))
+
+    def comm_tick_resident(self, t_ns, T_world_cam, stamps, poses):
+        """esvo_comm_tick with the owner's Time Surfaces rendered inside the call"""
+        st = np.ascontiguousarray(stamps, np.uint64)
+        P = np.ascontiguousarray(poses, np.float64).reshape(-1, 16)
+        T = np.ascontiguousarray(T_world_cam, np.float64).reshape(16)
+        self._ck(self.lib.esvo_comm_tick_resident(self.h, int(t_ns), T.ctypes.data, st.ctypes.data, P.ctypes.data, st.shape[0]))
+
+    def comm_stats(self):
+        from .abi import CommStatsStruct
+        st = CommStatsStruct()
+        self._ck(self.lib.esvo_comm_get_stats(self.h, C.byref(st)))
+        return st
 
     def comm_flush(self):
         self._ck(self.lib.esvo_comm_flush(self.h))

@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define ESVO_HIP_ABI_VERSION 6
+#define ESVO_HIP_ABI_VERSION 7
 
 typedef enum esvo_status_t {
   ESVO_OK = 0,
@@ -490,7 +490,8 @@ int esvo_shard_exchange(esvo_handle h, void** d_send, void** d_recv, size_t* blo
 
  * The reference is a single-process CPU program (std::thread fan-out only); these calls exist because this
  * implementation can spread its per-tick work over the GPUs of a node.  RCCL is loaded (dlopen) by esvo_comm_unique_id /
- * esvo_comm_init only; every collective is issued on the handle's front stream.  All calls below are COLLECTIVE: every
+ * esvo_comm_init only; the frame exchange of the tick-interleaved mode runs on a stream of its own, every other collective on
+ * the handle's front stream.  All calls below are COLLECTIVE: every
  * rank makes them in the same order with the same arguments. */
 #define ESVO_COMM_ID_BYTES 128
 /* ncclGetUniqueId on one rank; hand the bytes to the others by any means (ROS parameter server, MPI, a file). */
@@ -511,13 +512,34 @@ int esvo_comm_destroy(esvo_handle h);
  * the ticks k = r (mod world) completely.  A tick depends on earlier ticks only through the frames of its fusion window
  * (MappingAtTime builds a new DepthFrame at every tick, esvo_Mapping.cpp:266-272,341-377), so after every `world` ticks the
  * ranks exchange that round's frames with ONE ncclAllGather (each block carries its point count: one host wait per
- * round), push them into their windows in tick order and fuse at their own tick.
+ * round, for an exchange enqueued a round earlier), push them into their windows in tick order and fuse at their own tick.
  * esvo_comm_tick replaces esvo_map_set_observation + esvo_map_tick: every rank calls it for every tick; the rank for which
  * esvo_comm_owns_next_tick() is 1 must have rendered both Time Surfaces of that tick (esvo_ts_render) beforehand. */
 int esvo_comm_owns_next_tick(esvo_handle h);
 int esvo_comm_tick(esvo_handle h, uint64_t t_ns, const double T_world_cam[16], const uint64_t* pose_t_ns, const double* pose_T,
                    size_t m);
-int esvo_comm_flush(esvo_handle h);  /* completes a partial round */
+/* The same with the owner's Time Surfaces rendered inside the call (= esvo_map_tick_resident's front: both cameras in one
+ * launch per kernel); no esvo_ts_render beforehand. */
+int esvo_comm_tick_resident(esvo_handle h, uint64_t t_ns, const double T_world_cam[16], const uint64_t* pose_t_ns,
+                            const double* pose_T, size_t m);
+/* Two rounds are in flight per rank (ABI 7): the call that completes round j enqueues that round's exchange on a stream of
+ * its own -- pack, ncclAllGather, the blocks' counts to the host -- and then pushes + fuses round j - 1, whose exchange went
+ * out a whole round earlier; the front stage of round j + 1 follows on the front and LM streams while exchange j travels.
+ * The block length of a gather is the largest frame of the last four rounds + 25 % (the buffers' capacity until counts have
+ * been seen; a frame that does not fit is gathered again with grown blocks, identically on every rank).  On a tick another
+ * rank maps the call scatters that tick's events into this rank's SAE on a side stream, so an own render only has its own
+ * tick's events left.  esvo_comm_flush completes a partial round and everything in flight. */
+int esvo_comm_flush(esvo_handle h);
+typedef struct esvo_comm_stats_t {
+  uint64_t rounds;             /* rounds collected (frames pushed) */
+  uint64_t gathers;            /* frame all-gathers issued (rounds + repeats after a regrow) */
+  uint64_t regrows;            /* rounds that were gathered again because a frame exceeded its block */
+  uint64_t bytes_sent;         /* bytes this rank contributed to those all-gathers (block length each) */
+  uint64_t points_gathered;    /* depth points of all ranks' frames in the collected rounds (104 B each) */
+  uint32_t last_stride_points; /* block length of the last collected round, in points */
+  uint32_t stride_cap_points;  /* what the exchange buffers hold per block */
+} esvo_comm_stats_t;
+int esvo_comm_get_stats(esvo_handle h, esvo_comm_stats_t* out);
 /* The DepthMap of the newest tick on every rank (it lives on the rank that mapped it: all-gather of the newest maps). */
 int esvo_comm_newest_map(esvo_handle h, esvo_depth_point_t* out, size_t cap, size_t* n, long long* tick_index);
 /* One tick split over the ranks (esvo_shard_set_band + esvo_shard_set_routing first): the three phases of

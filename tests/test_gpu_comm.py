@@ -153,6 +153,58 @@ def test_tick_interleaved_ranks_through_the_c_calls(request, world, preset, rig_
             _same(mp, ref[idx])
 
 
+@pytest.mark.parametrize("world,stride0,resident", [(2, None, True), (3, 16, True), (8, 64, False)])
+def test_tick_interleaved_two_rounds_in_flight(request, monkeypatch, world, stride0, resident):
+    """The pipelined round logic (ABI 7): the exchange of round j is enqueued on its own stream and collected a round later;
+    blocks are sized from the counts of earlier rounds.  No flush inside the run (the rounds really overlap); a tiny initial
+    block capacity (ESVO_COMM_STRIDE0) forces the regrow path on every rank alike, for the round being collected AND the one
+    enqueued behind it; esvo_comm_tick_resident renders the owner's Time Surfaces inside the call.  Every rank's view of the
+    newest map -- and every own tick's frame along the way -- equals the single-handle run bit for bit."""
+    from esvo_amd import lib
+    rig, stream = request.getfixturevalue("dsec_rig"), request.getfixturevalue("dsec_stream")
+    if stride0 is not None:
+        monkeypatch.setenv("ESVO_COMM_STRIDE0", str(stride0))
+    p, _ = params.make_params(params.PRESETS["mapping_dsec"], rig, process_event_num=3000)
+    n_ticks = 3 * world + 1                                  # three full rounds and a one-tick tail
+    ticks = _ticks(stream, p, n_ticks, t_first=0.04, dt=0.075 / (n_ticks - 1))   # (the fixture stream lasts 0.12 s)
+    ref = _single(p, rig, stream, ticks)
+    tr = LocalTransport(world)
+
+    def body(r):
+        dev = lib.Esvo(p, rig)
+        dev.comm_init_callbacks(r, world, lambda s, d, n, st: tr.all_gather(r, s, d, n))
+        dev.ts_push_events(0, stream.ev_left)
+        dev.ts_push_events(1, stream.ev_right)
+        for k, (t, stamps, poses, T) in enumerate(ticks):
+            if resident:
+                dev.comm_tick_resident(t, T, stamps, poses)
+            else:
+                if dev.comm_owns_next_tick():
+                    dev.ts_render(0, t, download=False)
+                    dev.ts_render(1, t, download=False)
+                dev.comm_tick(t, T, stamps, poses)
+        mp, idx = dev.comm_newest_map()
+        cs = dev.comm_stats()
+        s = dev.stats()
+        return mp, idx, int(s.ticks), (int(cs.rounds), int(cs.gathers), int(cs.regrows), int(cs.bytes_sent), int(cs.points_gathered),
+                                       int(cs.last_stride_points), int(cs.stride_cap_points)), int(s.events_scattered[0]), int(s.events_scattered[1])
+
+    outs = _run_ranks(world, body)
+    assert sum(o[2] for o in outs) == n_ticks
+    for mp, idx, _, cs, sc0, sc1 in outs:
+        assert idx == n_ticks - 1
+        _same(mp, ref[-1])
+        rounds, gathers, regrows, sent, pts, last_stride, cap = cs
+        assert rounds == 4 and cs == outs[0][3]             # every rank took the same path
+        if stride0 is not None:
+            assert regrows >= 1 and gathers > rounds and cap > stride0
+        else:
+            assert regrows == 0 and gathers == rounds
+        assert last_stride <= cap
+    # every rank scattered every event below its last own render time, whoever's tick they belong to
+    assert min(o[4] for o in outs) > 0.5 * max(o[4] for o in outs)
+
+
 @pytest.mark.parametrize("world,routing,rig_fix,stream_fix,preset", [
     (2, "broadcast", "dsec_rig", "dsec_stream", "mapping_dsec"),
     (2, "y_rect", "dsec_rig", "dsec_stream", "mapping_dsec"),

@@ -75,7 +75,10 @@ def test_selftest_reports_ranks_exchange_and_map_equality():
     rc, two, err = _selftest({"ESVO_SHARED_GPU": "1", "ESVO_DIST_BACKEND": "gloo"}, 2)
     assert rc == 0 and two["ok"], (rc, two, err)
     assert {r["rank"] for r in two["ranks_seen"]} == {0, 1} and two["all_gather"]["verified"] and two["all_gather"]["us_min"] > 0
-    assert two["depth_map_equal_to_one_gpu"] and set(two["depth_map"]) == {"tick", "band", "band_broadcast", "one_gpu"}
+    assert two["depth_map_equal_to_one_gpu"] and set(two["depth_map"]) == {"tick", "tick_torch", "band", "band_broadcast", "one_gpu"}
+    # tick_torch: the C round logic (two rounds in flight, count-sized blocks) with torch.distributed as its transport
+    ex = two["depth_map"]["tick_torch"]["exchange"]
+    assert ex["rounds"] == 3 and ex["regrows"] == 0 and ex["bytes_sent"] > 0
     assert two["depth_map"]["one_gpu"]["sha1"] == one["depth_map"]["one_gpu"]["sha1"]
     assert two["seconds"] < 60
 
@@ -88,7 +91,7 @@ def test_selftest_at_world_8_on_a_shared_gpu():
     rc, r8, err = _selftest({"ESVO_SHARED_GPU": "1", "ESVO_DIST_BACKEND": "gloo"}, 8)
     assert rc == 0 and r8 and r8["ok"], (rc, r8, err)
     assert {r["rank"] for r in r8["ranks_seen"]} == set(range(8)) and r8["all_gather"]["verified"]
-    assert r8["depth_map_equal_to_one_gpu"] and set(r8["depth_map"]) == {"tick", "band", "band_broadcast", "one_gpu"}
+    assert r8["depth_map_equal_to_one_gpu"] and set(r8["depth_map"]) == {"tick", "tick_torch", "band", "band_broadcast", "one_gpu"}
     band = r8["depth_map"]["band"]
     assert band["halo_violations"] == 0
     assert band["events_staged_rank0"][0] < 0.6 * band["events_in_stream"][0], band
@@ -98,7 +101,7 @@ def test_selftest_at_world_8_on_a_shared_gpu():
 @pytest.mark.skipif(_device_count() < 2, reason="needs two MI355X on the node (real RCCL between two processes)")
 def test_two_gpus_over_real_rccl():
     """Self-enabling on a multi-GPU node: one process per GPU, esvo_comm_init at world 2 over real RCCL (ncclCommInitRank,
-    ncclAllGather of frames / ncclAllReduce of the slot codes inside libesvo_hip.so), no launcher.  Both ways of using the
+    ncclAllGather of the frames / of the slot bits and kept points inside libesvo_hip.so), no launcher.  Both ways of using the
     GPUs must reproduce the single-GPU DepthMap."""
     single = _bench({}, [sys.executable], 1)
     for mode in ("tick", "band"):
