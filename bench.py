@@ -184,9 +184,22 @@ def main():
             try:
                 runner = make_runner(attempt_native)
                 stage(runner)
-                for k in range(n_warm):
-                    step(k)
-                runner.synchronize()
+                try:
+                    for k in range(n_warm):
+                        step(k)
+                    runner.synchronize()
+                except Exception as e:  # noqa: BLE001
+                    from esvo_amd import dist as edist
+                    if not isinstance(e, edist.HaloViolation):
+                        raise
+                    # routed band mode refused a tick (a refinement left the rendered rows; every rank at the same tick):
+                    # the exact-whatever-the-motion routing instead, stated on the line
+                    comm_note = "routed band mode raised ESVO_ERR_HALO in warm-up; re-run with ESVO_ROUTE_BROADCAST"
+                    runner.restart(routing="broadcast")
+                    stage(runner)
+                    for k in range(n_warm):
+                        step(k)
+                    runner.synchronize()
             except Exception as e:  # an error code from the C library (a hang or a fault inside RCCL cannot be caught here)
                 failed = f"{type(e).__name__}: {e}"
             if dist:  # every rank takes the same path

@@ -196,6 +196,7 @@ def tick_share(workload, device, world=8, rounds=20, warm_rounds=3, events_cap=0
             b = blocks[r * world + q]
             f[q - 1, : b.numel()] = b
         foreign.append(f)
+    own_chk = torch.zeros((n_rounds // 4 + 1, wmax), dtype=torch.int64, device="cuda")   # every 4th own block, compared after the run
     torch.cuda.synchronize()
     views = {}
 
@@ -218,7 +219,9 @@ def tick_share(workload, device, world=8, rounds=20, warm_rounds=3, events_cap=0
                 m = min(w, wmax)
                 recv[1:, :m].copy_(foreign[r][:, :m], non_blocking=True)
             if r % 4 == 0 and r * world < len(blocks):   # the rank's own frame against the recorded one (compared after the run)
-                state.setdefault("own", []).append((r, send[: min(w, blocks[r * world].numel())].clone()))
+                m0 = min(w, blocks[r * world].numel())
+                own_chk[r // 4, :m0].copy_(send[:m0], non_blocking=True)
+                state.setdefault("own", []).append((r, m0))
         state["cb_s"] = state.get("cb_s", 0.0) + time.perf_counter() - t_in
         return 0
 
@@ -231,25 +234,31 @@ def tick_share(workload, device, world=8, rounds=20, warm_rounds=3, events_cap=0
                 t, stamps, poses, T = ticks[r * world + q]
                 t_in = time.perf_counter()
                 dev.comm_tick_resident(t, T, stamps, poses)
-                state["host_s"][min(q, 1) if q < world - 1 else 2] += time.perf_counter() - t_in
+                d_call = time.perf_counter() - t_in
+                state["host_s"][min(q, 1) if q < world - 1 else 2] += d_call
+                if d_call > 4e-3:
+                    state.setdefault("long_calls", []).append((r, q, round(d_call * 1e3, 3)))
+            state["marks"].append(time.perf_counter())
             if sync_each:
                 dev.comm_flush()
                 dev.synchronize()
 
     state["host_s"] = [0.0, 0.0, 0.0]
+    state["marks"] = []
     run_rounds(0, warm_rounds)
     dev.comm_flush()
     dev.synchronize()
-    state["host_s"], state["cb_s"] = [0.0, 0.0, 0.0], 0.0
+    state["host_s"], state["cb_s"], state["marks"] = [0.0, 0.0, 0.0], 0.0, []
     base = dev.stats()
     cb = dev.comm_stats()
-    base_comm = (int(cb.gathers), int(cb.bytes_sent), int(cb.points_gathered), int(cb.rounds))
+    base_comm = (int(cb.gathers), int(cb.bytes_sent), int(cb.points_gathered), int(cb.rounds), int(cb.host_wait_us))
     t0 = time.perf_counter()
     run_rounds(warm_rounds, warm_rounds + rounds)
     dev.comm_flush()
     dev.synchronize()
     dt = time.perf_counter() - t0
     host_s, cb_s = list(state["host_s"]), state["cb_s"]
+    series = np.diff(np.array([t0] + state["marks"])) * 1e3   # host time stamps at the round ends (the host is paced by the device)
     st = dev.stats()
     cs = dev.comm_stats()
     ksum = np.array(list(st.sum_ms_kernel)) - np.array(list(base.sum_ms_kernel))
@@ -260,7 +269,7 @@ def tick_share(workload, device, world=8, rounds=20, warm_rounds=3, events_cap=0
         run_rounds(r, r + 1, sync_each=True)
         sync_ms.append((time.perf_counter() - t1) * 1e3)
     got_sha = map_sha1(dev.get_map())
-    own_equal = all(bool(torch.equal(snd, blocks[r * world][: snd.numel()])) for r, snd in state.get("own", []))
+    own_equal = all(bool(torch.equal(own_chk[r // 4, :m0], blocks[r * world][:m0])) for r, m0 in state.get("own", []))
     st_end = dev.comm_stats()
     dev.close()
     g = max(int(cs.gathers) - base_comm[0], 1)
@@ -269,9 +278,12 @@ def tick_share(workload, device, world=8, rounds=20, warm_rounds=3, events_cap=0
     round_ms = dt / rounds * 1e3
     out.update({
         "round_ms_pipelined": round_ms,
+        "round_ms_series": [round(float(x), 3) for x in series],
+        "calls_over_4ms": state.get("long_calls", []),
         "round_ms_synchronised": {"mean": float(np.mean(sync_ms)), "min": float(np.min(sync_ms))} if sync_ms else None,
         "host_ms_per_round": {"own_tick_call": host_s[0] / rounds * 1e3, "foreign_tick_calls": host_s[1] / rounds * 1e3,
                               "round_end_call": host_s[2] / rounds * 1e3, "of_which_emulated_gather_python": cb_s / rounds * 1e3,
+                              "of_which_waiting_for_counts": (int(cs.host_wait_us) - base_comm[4]) / rounds * 1e-3,
                               "note": "host time inside the esvo_comm_tick_resident calls of a round (rank 0 owns the round's first tick: that call "
                                       "enqueues the front stage and then waits for the counts of the round before the previous one -- where the "
                                       "host sleeps when the device is the pace; the round's last call enqueues the exchange)"},

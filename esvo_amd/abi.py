@@ -130,7 +130,7 @@ class CommStatsStruct(C.Structure):
     """esvo_comm_stats_t (ABI 7): the tick-interleaved frame exchange of one rank"""
     _fields_ = [
         ("rounds", C.c_uint64), ("gathers", C.c_uint64), ("regrows", C.c_uint64), ("bytes_sent", C.c_uint64),
-        ("points_gathered", C.c_uint64), ("last_stride_points", C.c_uint32), ("stride_cap_points", C.c_uint32),
+        ("points_gathered", C.c_uint64), ("host_wait_us", C.c_uint64), ("last_stride_points", C.c_uint32), ("stride_cap_points", C.c_uint32),
     ]
 
 

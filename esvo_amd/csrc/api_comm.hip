@@ -14,6 +14,7 @@
 // users of libesvo_hip.so neither link nor initialise it.  esvo_comm_init_callbacks takes the collective as a function
 // pointer instead: tests drive several ranks on ONE GPU through exactly this code with an in-process transport, and
 // another transport can be plugged in without touching it.
+#include <chrono>
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
@@ -293,7 +294,11 @@ int round_collect(esvo_context* h) {
   if (c->inflight.empty()) return ESVO_OK;
   CommRound& R = c->inflight.front();
   const u64* heads = c->h_heads + (size_t)R.buf * c->world;
-  HIPCHK(hipEventSynchronize(c->gathered[R.buf]));
+  {
+    const auto t0 = std::chrono::steady_clock::now();
+    HIPCHK(hipEventSynchronize(c->gathered[R.buf]));
+    c->st.host_wait_us += (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+  }
   u64 max_n = 0, sum_n = 0;
   for (int r = 0; r < c->world; ++r) { max_n = std::max(max_n, heads[r]); sum_n += heads[r]; }
   if (max_n > R.stride) {
@@ -464,7 +469,8 @@ int comm_tick(esvo_context* h, uint64_t t_ns, const double T_world_cam[16], cons
     rc = own_front(h, t_ns, T_world_cam, pose_t_ns, pose_T, m, render);
     if (rc) return rc;
   } else {
-    rc = ts_scatter_ahead(h, t_ns);  // the tick's events reach the SAE now (front stream, idle beside the own tick's LM launch)
+    static const bool ahead = !(esvo_dev_switch("ESVO_COMM_SCATTER_AHEAD") && std::atoi(esvo_dev_switch("ESVO_COMM_SCATTER_AHEAD")) == 0);
+    if (ahead) rc = ts_scatter_ahead(h, t_ns);  // the tick's events reach the SAE now (front stream, idle beside the own tick's LM launch)
     if (rc) return rc;
   }
   RoundTick rt;

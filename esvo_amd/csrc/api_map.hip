@@ -924,7 +924,10 @@ int collect_front_stats(esvo_context* h, esvo_context::TickState& tk, const u32*
     h->tl_front.push_back(row);
   }
   tk.max_kept = (h->sharded && n) ? cnt[9] : 0;
-  if (h->sharded && n_points) {  // exchange 2: [count | kept points], block length from the largest kept count among the ranks
+  // exchange 2: [count | kept points], block length from the largest kept count among the ranks.  Routed band mode: the count
+  // word also carries the rank's halo violations, so the exchange takes place whenever the tick had events -- a tick whose
+  // violating matches were all culled (no kept point anywhere) still reports them (n is the global selection: every rank agrees)
+  if (h->sharded && (n_points || (h->routed && n))) {
     h->xchg_send = h->d_pts_send;
     h->xchg_recv = h->dp.ev_nshards > 1 ? h->d_pts_all : h->d_pts_send;
     h->xchg_block = 8 + (size_t)tk.max_kept * sizeof(DevPoint);

@@ -208,9 +208,11 @@ __global__ void __launch_bounds__(256) shard_scatter_kernel(const unsigned long 
 }
 void launch_shard_scatter(const unsigned long long* blocks, size_t block_words, u32 N, u32 max_kept, DevPoint* frame, u32 frame_cap,
                           hipStream_t s, u32* viol_total) {
-  if (max_kept == 0 || frame_cap == 0) return;  // (no kept point anywhere: the exchange did not take place)
+  // (no kept point anywhere: unrouted, the exchange did not take place; routed, it carried the count words alone -- the ranks'
+  //  halo violations are summed from them)
+  if ((max_kept == 0 && !viol_total) || frame_cap == 0) return;
   constexpr u32 WP = sizeof(DevPoint) / 8;
-  hipLaunchKernelGGL(shard_scatter_kernel, dim3((max_kept * WP + 255) / 256, N), dim3(256), 0, s, blocks, block_words,
+  hipLaunchKernelGGL(shard_scatter_kernel, dim3(max_kept ? (max_kept * WP + 255) / 256 : 1, N), dim3(256), 0, s, blocks, block_words,
                      max_kept, frame, frame_cap, viol_total);
 }
 

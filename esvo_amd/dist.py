@@ -50,6 +50,24 @@ def band_of(rank, world, height):
     return min(rank * rows, height), min((rank + 1) * rows, height)
 
 
+class HaloViolation(lib.EsvoError):
+    """Routed band mode: a refinement of an earlier tick read outside the Time-Surface rows some rank renders; every rank
+    refuses its ticks from here on (ESVO_ERR_HALO, the same tick on all of them: the count travels with exchange 2).  The map of
+    the tick BEFORE this call is not to be trusted.  Recover with runner.restart(routing="broadcast") (exact whatever the
+    motion) or runner.restart(ts_halo_rows=more) and re-stage the events the next ticks need."""
+
+
+def _band_tick_guard(fn):
+    def wrapped(self, *a, **kw):
+        try:
+            return fn(self, *a, **kw)
+        except lib.EsvoError as e:
+            if getattr(e, "code", None) == lib.ERR_HALO:
+                raise HaloViolation(str(e), code=lib.ERR_HALO) from e
+            raise
+    return wrapped
+
+
 def pick_routing(params, routing="auto"):
     """"auto": rows where the library supports it (esvo_shard_set_routing refuses Denoising, per-pixel event queues and
     up-down stereo with ESVO_ERR_UNSUPPORTED), the broadcast switch otherwise"""
@@ -121,6 +139,7 @@ class ShardedEsvo:
             gather_blocks_(device_tensor(rcv, self.world * nbytes // 8, "<i8", self.device),
                            device_tensor(snd, nbytes // 8, "<i8", self.device), self.world, self.group)
 
+    @_band_tick_guard
     def tick(self, t_ns, stamps, poses):
         d = self.dev
         d.shard_phase(0, t_ns, stamps, poses)
@@ -128,6 +147,13 @@ class ShardedEsvo:
         d.shard_phase(1)
         self._exchange()
         d.shard_phase(2)
+
+    def restart(self, routing=None, ts_halo_rows=-1):
+        """after a HaloViolation (collective: every rank got it at the same tick): esvo_reset, the band again with another
+        routing or a wider halo; the caller re-stages events and warms the window up again"""
+        self.routing = pick_routing(self.params, routing or self.routing)
+        self.dev.reset()
+        self.dev.set_band(self.y0, self.y1, self.rank, self.world, routing=self.routing, ts_halo_rows=ts_halo_rows)
 
     def get_band_map(self):
         """this rank's DepthMap elements; `seq` is the global creation id"""
@@ -370,6 +396,7 @@ class NativeBandSharded:
         y0, y1 = band_of(rank, world, rig.height)
         if y1 <= y0:
             raise lib.EsvoError(f"rank {rank} of {world} would own no image rows (H={rig.height})")
+        self.y0, self.y1 = y0, y1
         self.dev.set_band(y0, y1, rank, world, routing=self.routing, ts_halo_rows=ts_halo_rows)
         _native_comm_init(self.dev, rank, world, group)
 
@@ -382,8 +409,15 @@ class NativeBandSharded:
     def set_observation(self, *a):
         self.dev.set_observation(*a)
 
+    @_band_tick_guard
     def tick(self, t_ns, stamps, poses):
         self.dev.comm_shard_tick(t_ns, stamps, poses)
+
+    def restart(self, routing=None, ts_halo_rows=-1):
+        """see ShardedEsvo.restart (the communicator stays)"""
+        self.routing = pick_routing(self.params, routing or self.routing)
+        self.dev.reset()
+        self.dev.set_band(self.y0, self.y1, self.rank, self.world, routing=self.routing, ts_halo_rows=ts_halo_rows)
 
     def synchronize(self):
         self.dev.synchronize()

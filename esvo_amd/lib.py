@@ -40,7 +40,14 @@ ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_siz
 
 
 class EsvoError(RuntimeError):
-    pass
+    """a failed C call; `code` is its esvo_status_t (None for errors raised on the Python side)"""
+
+    def __init__(self, msg, code=None):
+        super().__init__(msg)
+        self.code = code
+
+
+ERR_HALO = -7   # ESVO_ERR_HALO (include/esvo_hip.h)
 
 
 _PERTURBED_PATH = os.path.join(_CSRC, "libesvo_hip_perturbed.so")
@@ -327,7 +334,7 @@ class Esvo:
 
     def _ck(self, rc):
         if rc != 0:
-            raise EsvoError(f"esvo call failed ({rc}): {self.lib.esvo_last_error(self.h).decode(errors='replace')}")
+            raise EsvoError(f"esvo call failed ({rc}): {self.lib.esvo_last_error(self.h).decode(errors='replace')}", code=rc)
 
     # ---- lifecycle
     def reset(self):

@@ -536,6 +536,8 @@ typedef struct esvo_comm_stats_t {
   uint64_t regrows;            /* rounds that were gathered again because a frame exceeded its block */
   uint64_t bytes_sent;         /* bytes this rank contributed to those all-gathers (block length each) */
   uint64_t points_gathered;    /* depth points of all ranks' frames in the collected rounds (104 B each) */
+  uint64_t host_wait_us;       /* host time spent waiting for the counts of a round (the one host wait per round): the slack the
+                                  host has when the device sets the pace; near zero = the calling thread is the pace */
   uint32_t last_stride_points; /* block length of the last collected round, in points */
   uint32_t stride_cap_points;  /* what the exchange buffers hold per block */
 } esvo_comm_stats_t;

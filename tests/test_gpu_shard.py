@@ -122,15 +122,19 @@ def test_logical_shards_equal_unsharded(request, preset, rig_fix, stream_fix, n_
             assert max(staged) < 0.6 * int(ref.stats().events_staged[0]), staged
 
 
-def test_routed_band_detects_a_refinement_that_leaves_its_rows(dsec_rig, dsec_stream):
+@pytest.mark.parametrize("cull_all", [False, True])
+def test_routed_band_detects_a_refinement_that_leaves_its_rows(dsec_rig, dsec_stream, cull_all):
     """The guard of the routed mode: with the smallest halo and a camera that moves VERTICALLY between an event and the
     observation, refinements warp their patches out of the rows the rank renders.  That must be counted (by every rank: the
-    count travels with the second exchange) and the next tick refused with ESVO_ERR_HALO -- never a silently different map."""
+    count travels with the second exchange) and the next tick refused with ESVO_ERR_HALO -- never a silently different map.
+    cull_all: a variance threshold nothing passes, so NO point is kept anywhere -- the second exchange then carries the count
+    words alone and the violations still reach every rank (round 5 skipped the exchange in that case)."""
     import torch  # noqa: F401
     from esvo_amd import dist as edist
     from esvo_amd import lib
     rig, stream = dsec_rig, dsec_stream
-    p, _ = params.make_params(params.PRESETS["mapping_dsec"], rig, process_event_num=4000)
+    over = dict(stdvar_vis_threshold=1e-12) if cull_all else {}
+    p, _ = params.make_params(params.PRESETS["mapping_dsec"], rig, process_event_num=4000, **over)
     G = 4
     shards = [lib.Esvo(p, rig) for _ in range(G)]
     for g, d in enumerate(shards):
@@ -157,7 +161,7 @@ def test_routed_band_detects_a_refinement_that_leaves_its_rows(dsec_rig, dsec_st
             for d in shards:
                 d.shard_phase(0, t, stamps, poses)
         except lib.EsvoError as e:
-            assert "(-7)" in str(e), e   # ESVO_ERR_HALO
+            assert "(-7)" in str(e) and e.code == lib.ERR_HALO, e   # ESVO_ERR_HALO
             refused = True
             break
         _emulated_gather(shards)
@@ -168,3 +172,5 @@ def test_routed_band_detects_a_refinement_that_leaves_its_rows(dsec_rig, dsec_st
             d.shard_phase(2)
     viol = [int(d.stats().halo_violations) for d in shards]
     assert refused and min(viol) > 0 and len(set(viol)) == 1, (refused, viol)   # every rank holds the same total
+    if cull_all:
+        assert all(int(d.stats().total_points) == 0 for d in shards)

@@ -40,6 +40,12 @@ VARIANTS = [
     # that switch is gone from the library.)
     ("two_lm", {}, {"ESVO_LM_QUEUES": "2", "ESVO_LM_QUEUES_MAX_EVENTS": "100000000"}),
     ("base_third", {}, {}),
+    # round 6: is the back chain what keeps the persistent LM layout from paying?
+    ("persist", {}, {"ESVO_LM_PERSIST": "1"}),
+    ("persist_no_reg", {"regularization": 0}, {"ESVO_LM_PERSIST": "1"}),
+    ("persist_no_reg_fusion_2x2", {"regularization": 0, "fusion_radius": 0}, {"ESVO_LM_PERSIST": "1"}),
+    ("persist_1536", {}, {"ESVO_LM_PERSIST": "1", "ESVO_LM_PERSIST_BLOCKS": "1536"}),
+    ("base_fourth", {}, {}),
 ]
 
 rig, stream, p, ticks = bench.make_workload(name, N + 6)
