@@ -1679,6 +1679,7 @@ int esvo_map_get_last_frame(esvo_handle h, esvo_depth_point_t* out, size_t cap, 
   if (out && f.count) {
     if (f.count > cap) FAIL(ESVO_ERR_CAPACITY, "output array too small for the frame");
     HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream_b));  // (the frame was copied into the ring on the back stream)
     HIPCHK(hipMemcpy(out, h->d_win + f.off, sizeof(esvo_depth_point_t) * f.count, hipMemcpyDeviceToHost));
   }
   return ESVO_OK;

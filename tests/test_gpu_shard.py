@@ -127,13 +127,13 @@ def test_routed_band_detects_a_refinement_that_leaves_its_rows(dsec_rig, dsec_st
     """The guard of the routed mode: with the smallest halo and a camera that moves VERTICALLY between an event and the
     observation, refinements warp their patches out of the rows the rank renders.  That must be counted (by every rank: the
     count travels with the second exchange) and the next tick refused with ESVO_ERR_HALO -- never a silently different map.
-    cull_all: a variance threshold nothing passes, so NO point is kept anywhere -- the second exchange then carries the count
+    cull_all: an inverse-depth range nothing passes, so NO point is kept anywhere -- the second exchange then carries the count
     words alone and the violations still reach every rank (round 5 skipped the exchange in that case)."""
     import torch  # noqa: F401
     from esvo_amd import dist as edist
     from esvo_amd import lib
     rig, stream = dsec_rig, dsec_stream
-    over = dict(stdvar_vis_threshold=1e-12) if cull_all else {}
+    over = dict(invdepth_min=100.0, invdepth_max=101.0) if cull_all else {}   # (pointCulling's range test: no refined point passes)
     p, _ = params.make_params(params.PRESETS["mapping_dsec"], rig, process_event_num=4000, **over)
     G = 4
     shards = [lib.Esvo(p, rig) for _ in range(G)]
