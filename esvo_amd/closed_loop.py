@@ -83,21 +83,50 @@ def register_python(dev, n_points, R_, t_, iters=12):
     return R, t, rms
 
 
-def run(n_ticks=15, reref=10**9, speed=1.0, seed=20250419, verbose=False):
-    rig = calib.dataset_rig("upenn")
-    st = synth.make_stream(rig, 8000, 0.35, 0.16, 1.0, seed=seed, speed=speed)
-    p, _ = params.make_params(params.PRESETS["mapping_upenn"], rig)
-    dev = lib.Esvo(p, rig)
-    dev.ts_push_events(0, st.ev_left)
-    dev.ts_push_events(1, st.ev_right)
-    t0 = st.t0_ns + int(0.08e9)
-    dev.ts_render(0, t0, download=False)
-    dev.ts_render(1, t0, download=False)
-    T_est = {t0: st.pose(t0)}             # bootstrap pose given, as the reference's identity at start-up
-    dev.set_observation(t0, None, None, T_est[t0])
-    n_sgm, _ = dev.init_sgm(None, None, min_points=100)
-    out = {"sgm_points": n_sgm, "pos_err": [], "rot_err_deg": [], "cos": [], "est_len": [], "gt_len": [], "points": [],
-           "cycle_ms": [], "track_ms": [], "map_ms": []}
+class _OneGpu:
+    """the calls of the loop on one plain handle"""
+
+    def __init__(self, dev):
+        self.dev = dev
+
+    def full_left_ts(self):
+        pass
+
+    def pointcloud(self):
+        return self.dev.get_pointcloud()
+
+    def tick(self, t, stamps, poses):
+        self.dev.tick(t, stamps, poses)
+
+    def final_map(self):
+        return self.dev.get_map()
+
+
+class _Band:
+    """... on one rank of a band-sharded run (every call here is collective: the ranks make them in the same order)"""
+
+    def __init__(self, dev):
+        self.dev = dev
+
+    def full_left_ts(self):
+        self.dev.comm_gather_ts(0)         # the tracker reads the WHOLE left Time Surface; a routed rank rendered its rows
+
+    def pointcloud(self):
+        return self.dev.comm_gather_pointcloud()   # the whole map's cloud on every rank, merged on the device
+
+    def tick(self, t, stamps, poses):
+        self.dev.comm_shard_tick(t, stamps, poses)
+
+    def final_map(self):
+        return self.dev.comm_gather_map()
+
+
+def _loop(rig, st, p, ops, t0, T0, xyz0, n_ticks, reref, verbose=False):
+    """tracker -> mapper for n_ticks ticks after the bootstrap at t0 (pose T0, reference cloud xyz0); `ops`: _OneGpu / _Band"""
+    dev = ops.dev
+    T_est = {t0: T0}
+    out = {"pos_err": [], "rot_err_deg": [], "cos": [], "est_len": [], "gt_len": [], "points": [],
+           "cycle_ms": [], "track_ms": [], "map_ms": [], "poses": []}
     rng = np.random.default_rng(0)
     t_ref, xyz, sel, R_, t_ = t0, None, None, np.eye(3), np.zeros(3)
     for k in range(1, n_ticks + 1):
@@ -105,8 +134,9 @@ def run(n_ticks=15, reref=10**9, speed=1.0, seed=20250419, verbose=False):
         c0 = time.perf_counter()
         dev.ts_render(0, t, download=False)
         dev.ts_render(1, t, download=False)
+        ops.full_left_ts()
         if xyz is None or (k - 1) % reref == 0:
-            xyz = dev.get_pointcloud()
+            xyz = xyz0 if (xyz is None and xyz0 is not None) else ops.pointcloud()
             sel = rng.permutation(len(xyz))[:2000]
             t_ref = t - TICK_NS
             R_, t_ = np.eye(3), np.zeros(3)
@@ -126,6 +156,7 @@ def run(n_ticks=15, reref=10**9, speed=1.0, seed=20250419, verbose=False):
         out["cos"].append(float(d_est @ d_gt / (np.linalg.norm(d_est) * np.linalg.norm(d_gt) + 1e-12)))
         out["est_len"].append(float(np.linalg.norm(d_est)))
         out["gt_len"].append(float(np.linalg.norm(d_gt)))
+        out["poses"].append(Tw.copy())
 
         def pose_at(tq, a=T_est[t - TICK_NS], b=Tw, ta=t - TICK_NS):
             w = (tq - ta) / TICK_NS                       # tf-style interpolation between tracked poses
@@ -136,7 +167,7 @@ def run(n_ticks=15, reref=10**9, speed=1.0, seed=20250419, verbose=False):
         stamps, poses = rostime.pose_table(pose_at, t, p.bm_half_slice_thickness)
         c2 = time.perf_counter()
         dev.set_observation(t, None, None, Tw)
-        dev.tick(t, stamps, poses)
+        ops.tick(t, stamps, poses)
         out["points"].append(int(dev.stats().last_points))   # (reading the statistics completes the tick)
         c3 = time.perf_counter()
         out["track_ms"].append((c1 - c0) * 1e3)               # both renders + reference upload + the registration
@@ -145,14 +176,93 @@ def run(n_ticks=15, reref=10**9, speed=1.0, seed=20250419, verbose=False):
         if verbose:
             print(f"tick {k}: |r| {rms:.1f} pos err {out['pos_err'][-1]*1e3:.2f} mm of {out['gt_len'][-1]*1e3:.1f} mm, "
                   f"cos {out['cos'][-1]:.3f}, rot {out['rot_err_deg'][-1]:.3f} deg, points {out['points'][-1]}")
-    mp = dev.get_map()
+    mp = ops.final_map()
     u, v, rho = st.true_inv_depth_image(t)
     ok = (u >= 0) & (u < rig.width) & (v >= 0) & (v < rig.height)
     gtimg = {(int(b), int(a)): c for a, b, c in zip(u[ok], v[ok], rho[ok])}
     err = np.array([m["inv_depth"] - gtimg[(int(m["row"]), int(m["col"]))] for m in mp
                     if (int(m["row"]), int(m["col"])) in gtimg and m["inv_depth"] > 0])
+    out["map"] = mp
     out["map_cells"] = len(mp)
     out["map_on_gt"] = len(err)
     out["map_median_abs_err"] = float(np.median(np.abs(err))) if len(err) else float("nan")
+    return out
+
+
+def _scene(seed, speed):
+    rig = calib.dataset_rig("upenn")
+    st = synth.make_stream(rig, 8000, 0.35, 0.16, 1.0, seed=seed, speed=speed)
+    p, _ = params.make_params(params.PRESETS["mapping_upenn"], rig)
+    return rig, st, p, st.t0_ns + int(0.08e9)
+
+
+def run(n_ticks=15, reref=10**9, speed=1.0, seed=20250419, verbose=False):
+    rig, st, p, t0 = _scene(seed, speed)
+    dev = lib.Esvo(p, rig)
+    dev.ts_push_events(0, st.ev_left)
+    dev.ts_push_events(1, st.ev_right)
+    dev.ts_render(0, t0, download=False)
+    dev.ts_render(1, t0, download=False)
+    T0 = st.pose(t0)                      # bootstrap pose given, as the reference's identity at start-up
+    dev.set_observation(t0, None, None, T0)
+    n_sgm, _ = dev.init_sgm(None, None, min_points=100)
+    out = _loop(rig, st, p, _OneGpu(dev), t0, T0, None, n_ticks, reref, verbose)
+    out["sgm_points"] = n_sgm
     dev.close()
+    return out
+
+
+def run_bands(G, routing="y_rect", n_ticks=15, reref=10**9, speed=1.0, seed=20250419, transport=None):
+    """The same loop with the mapper split over G row bands (BASELINE configs[2] on configs[3]'s partition): G ranks -- handles on
+    ONE GPU here, driven from G threads through the library's collective calls with an in-process all-gather (`transport`:
+    tests/test_gpu_comm.LocalTransport's interface) -- each ingesting its rows, rendering its band of the Time Surfaces, matching
+    and refining its events, fusing and regularising its rows.  What the loop adds to the band mode: the tracker reads the
+    WHOLE left Time Surface (esvo_comm_gather_ts) and registers against the WHOLE map's cloud (esvo_comm_gather_pointcloud_xyz,
+    merged on the device); it runs replicated -- same inputs, same bits, same pose on every rank, nothing to exchange.
+    The SGM bootstrap runs on one plain handle that sees the whole stream (initialisation precedes the sharded operation); its
+    frame opens every rank's fusion window.  Returns rank 0's figures (+ "ranks_agree")."""
+    import threading
+    from esvo_amd import dist as edist
+    transport = transport or edist.LocalTransport(G)
+    rig, st, p, t0 = _scene(seed, speed)
+    boot = lib.Esvo(p, rig)
+    boot.ts_push_events(0, st.ev_left)
+    boot.ts_push_events(1, st.ev_right)
+    boot.ts_render(0, t0, download=False)
+    boot.ts_render(1, t0, download=False)
+    T0 = st.pose(t0)
+    boot.set_observation(t0, None, None, T0)
+    n_sgm, _ = boot.init_sgm(None, None, min_points=100)
+    frame0, xyz0 = boot.get_last_frame(), boot.get_pointcloud()
+    boot.close()
+    outs, errs = [None] * G, []
+
+    def rank_main(r):
+        try:
+            dev = lib.Esvo(p, rig)
+            y0, y1 = edist.band_of(r, G, rig.height)
+            dev.set_band(y0, y1, r, G, routing=routing)
+            dev.comm_init_callbacks(r, G, lambda s, d, n, stream: transport.all_gather(r, s, d, n))
+            dev.ts_push_events(0, st.ev_left)   # every rank is handed the whole stream; a routed handle keeps its rows
+            dev.ts_push_events(1, st.ev_right)
+            dev.push_frame(frame0, T0.reshape(1, 16))
+            outs[r] = _loop(rig, st, p, _Band(dev), t0, T0, xyz0, n_ticks, reref)
+            outs[r]["halo_violations"] = int(dev.stats().halo_violations)
+            outs[r]["events_staged"] = [int(x) for x in dev.stats().events_staged]
+            dev.close()
+        except BaseException as e:  # noqa: BLE001
+            errs.append((r, e))
+            transport.abort()
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(G)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=600)
+    if errs:
+        raise errs[0][1]
+    out = outs[0]
+    out["sgm_points"] = n_sgm
+    out["ranks_agree"] = all(np.array_equal(np.array(o["poses"]), np.array(out["poses"])) and np.array_equal(o["map"], out["map"]) for o in outs)
+    out["events_staged_max_frac"] = max(o["events_staged"][0] for o in outs) / max(len(st.ev_left), 1)
     return out

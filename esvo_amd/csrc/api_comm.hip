@@ -27,6 +27,61 @@ __global__ void comm_block_header_kernel(const u32* __restrict__ n_points, u64* 
   block[0] = *n_points;
   block[1] = 0;
 }
+// ---- the DepthMap bands merged on the device (esvo_comm_gather_map / _pointcloud_xyz) ------------------------------------------
+// Every element carries the id of the record that created it (MapCell::seq: its position in the reference's sequential fusion
+// order, < window points x 9), unique over all bands; the unsharded map's list is the elements in ascending id.  So the merge is a
+// scatter of (present, where) by id, an exclusive scan over the id range and a gather -- O(elements + ids), no comparison sort.
+__global__ void __launch_bounds__(256) band_counts_kernel(const u32* __restrict__ n_mine, u64* __restrict__ head) {
+  if (threadIdx.x == 0) { head[0] = *n_mine; head[1] = 0; }
+}
+__global__ void __launch_bounds__(256) band_mark_kernel(const esvo_depth_point_t* __restrict__ blocks, size_t block_pts, const u64* __restrict__ counts,
+                                                        int world, u32 id_cap, u32* __restrict__ present, u32* __restrict__ where) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int r = (int)(e / block_pts);
+  if (r >= world) return;
+  const size_t i = e - (size_t)r * block_pts;
+  if (i >= counts[2 * r]) return;
+  const u32 id = blocks[e].seq;
+  if (id >= id_cap) return;  // (cannot happen: ids are below window points x 9)
+  present[id] = 1u;
+  where[id] = (u32)e;
+}
+__global__ void __launch_bounds__(256) band_merge_kernel(const esvo_depth_point_t* __restrict__ blocks, const u32* __restrict__ present,
+                                                         const u32* __restrict__ prefix, const u32* __restrict__ where, u32 id_cap,
+                                                         esvo_depth_point_t* __restrict__ out) {
+  const u32 id = blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= id_cap || !present[id]) return;
+  esvo_depth_point_t o = blocks[where[id]];
+  o.seq = prefix[id];   // list position, as the unsharded export numbers them
+  out[prefix[id]] = o;
+}
+// publishPointCloud's transform (esvo_Mapping.cpp:925-932) of the merged list: the operations of the host loop in
+// esvo_map_get_pointcloud_xyz, un-fused, so the float coordinates are the same bits
+__global__ void __launch_bounds__(256) band_xyz_kernel(const esvo_depth_point_t* __restrict__ pts, const u32* __restrict__ n, double T0, double T1,
+                                                       double T2, double T3, double T4, double T5, double T6, double T7, double T8, double T9,
+                                                       double T10, double T11, float* __restrict__ xyz) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= *n) return;
+  const double a = pts[i].p_cam[0], b = pts[i].p_cam[1], c = pts[i].p_cam[2];
+  auto row = [&](double t0, double t1, double t2, double t3) {
+    return (float)__dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(t0, a), __dmul_rn(t1, b)), __dmul_rn(t2, c)), t3);
+  };
+  xyz[3 * i + 0] = row(T0, T1, T2, T3);
+  xyz[3 * i + 1] = row(T4, T5, T6, T7);
+  xyz[3 * i + 2] = row(T8, T9, T10, T11);
+}
+// the rows [y0, y1) of a rank's band out of / into a full image (esvo_comm_gather_ts)
+__global__ void __launch_bounds__(256) ts_bands_scatter_kernel(const uint8_t* __restrict__ blocks, size_t block_bytes, int world, int rows, int W, int H,
+                                                               int skip_rank, uint8_t* __restrict__ img) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t per = (size_t)rows * W;
+  const int r = (int)(t / per);
+  if (r >= world || r == skip_rank) return;
+  const size_t o = t - (size_t)r * per;
+  const size_t y = (size_t)r * rows + o / W;
+  if (y >= (size_t)H) return;
+  img[y * W + o % W] = blocks[(size_t)r * block_bytes + o];
+}
 __global__ void comm_headers_kernel(const u64* __restrict__ recv, size_t block_words, int world, u64* __restrict__ out) {
   const int r = threadIdx.x;
   if (r < world) out[r] = recv[(size_t)r * block_words];
@@ -131,10 +186,21 @@ struct esvo_comm {
   bool events_ok = false;
   u64 rounds = 0;                  // rounds whose gather has been enqueued
   esvo_comm_stats_t st = {};
-  // band mode: all-gather of the band maps
-  u64* d_band_send = nullptr;
-  u64* d_band_recv = nullptr;
-  size_t band_block_words = 0;
+  // band mode: all-gather of the band maps, merged on the device; of the Time-Surface bands
+  esvo_depth_point_t* d_band_recv = nullptr;  // [world][band_block_pts]
+  size_t band_block_pts = 0;
+  esvo_depth_point_t* d_merged = nullptr;     // [merged_cap] the unsharded element list
+  size_t merged_cap = 0;
+  u32* d_id_present = nullptr;                // [id_cap] x 3: present, prefix, where
+  u32* d_id_scan_tmp = nullptr;
+  size_t id_cap = 0;
+  u32* d_merged_n = nullptr;
+  float* d_xyz = nullptr;
+  size_t xyz_cap = 0;
+  uint8_t* d_ts_send = nullptr;
+  uint8_t* d_ts_recv = nullptr;
+  size_t ts_block = 0;
+  hipEvent_t ev_map = nullptr;                // the band's export is on the back stream, the exchange on the front stream
   static size_t block_words(u32 stride) { return 2 + (size_t)stride * 13; }
 };
 
@@ -143,9 +209,10 @@ void comm_release(esvo_context* h) {
   esvo_comm* c = h->comm;
   if (!c) return;
   if (c->sc) hipStreamSynchronize(c->sc);
-  for (void* p : {(void*)c->d_empty, (void*)c->d_recv[0], (void*)c->d_recv[1], (void*)c->d_heads, (void*)c->d_map_heads, (void*)c->d_band_send, (void*)c->d_band_recv})
+  for (void* p : {(void*)c->d_empty, (void*)c->d_recv[0], (void*)c->d_recv[1], (void*)c->d_heads, (void*)c->d_map_heads, (void*)c->d_band_recv, (void*)c->d_merged, (void*)c->d_id_present, (void*)c->d_id_scan_tmp, (void*)c->d_merged_n, (void*)c->d_xyz, (void*)c->d_ts_send, (void*)c->d_ts_recv})
     if (p) hipFree(p);
   if (c->h_heads) hipHostFree(c->h_heads);
+  if (c->ev_map) hipEventDestroy(c->ev_map);
   if (c->events_ok) {
     for (int i = 0; i < 2; ++i) { hipEventDestroy(c->pushed[i]); hipEventDestroy(c->gathered[i]); }
     // the handle gets its own front-stage events back (nothing is in flight: the callers drained every stream)
@@ -205,7 +272,7 @@ int comm_alloc(esvo_context* h) {
   c->d_empty = c->d_recv[0] = c->d_recv[1] = nullptr;
   const size_t bw = esvo_comm::block_words(c->stride_cap);
   HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->d_empty), bw * 8));
-  HIPCHK(hipMemset(c->d_empty, 0, bw * 8));
+  HIPCHK(hipMemsetAsync(c->d_empty, 0, bw * 8, c->sc));  // (on the stream that reads it: the null stream is not ordered with a non-blocking one)
   HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->d_recv[0]), bw * 8 * c->world));
   HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->d_recv[1]), bw * 8 * c->world));
   return ESVO_OK;
@@ -219,6 +286,14 @@ int comm_setup(esvo_context* h, int rank, int world) {
   if (h->prm.max_events_per_tick > 0 && (u32)h->prm.max_events_per_tick < c->stride_cap)
     c->stride_cap = (u32)h->prm.max_events_per_tick;  // a tick cannot produce more points than events
   if (const char* e0 = esvo_dev_switch("ESVO_COMM_STRIDE0")) c->stride_cap = (u32)std::max(1, std::atoi(e0));  // tests: force the regrow path
+  {
+    // The exchange stream gets the HIGH priority of the front and back streams: short, latency-critical work -- and HIP keeps a
+    // pool of hardware queues per priority, so it does not end up in the hardware queue of the ingest or tracker stream, whose
+    // packets would then sit behind this stream's wait for the LM launch.
+    int prio_lo = 0, prio_hi = 0;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+    HIPCHK(hipStreamCreateWithPriority(&c->sc, hipStreamNonBlocking, prio_hi));
+  }
   int rc = comm_alloc(h);
   if (rc) return rc;
   HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->d_heads), sizeof(u64) * 2 * world));
@@ -237,14 +312,6 @@ int comm_setup(esvo_context* h, int rank, int world) {
     HIPCHK(hipEventCreateWithFlags(&c->gathered[i], hipEventDisableTiming));
   }
   c->events_ok = true;
-  {
-    // The exchange stream gets the HIGH priority of the front and back streams: short, latency-critical work -- and HIP keeps a
-    // pool of hardware queues per priority, so it does not end up in the hardware queue of the ingest or tracker stream, whose
-    // packets would then sit behind this stream's wait for the LM launch.
-    int prio_lo = 0, prio_hi = 0;
-    HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-    HIPCHK(hipStreamCreateWithPriority(&c->sc, hipStreamNonBlocking, prio_hi));
-  }
   // one untimed round trip sets up the communicator's channels (and proves the transport works)
   rc = comm_all_gather(h, c->d_empty, c->d_recv[0], 16, c->sc);
   if (rc) return rc;
@@ -694,50 +761,162 @@ int esvo_comm_shard_tick(esvo_handle h, uint64_t t_ns, const uint64_t* pose_t_ns
   return ESVO_OK;
 }
 
+}  // extern "C"
+
 // all-gather of the DepthMap bands (north_star: "all-gather of per-tile depth estimates"), merged on the global creation
-// order so that the result is the unsharded map's element list
+// order so that the result is the unsharded map's element list.  Device-resident since round 6: the band's alive cells are
+// compacted on the device, the counts travel first (16 B per rank, one host wait: they size the second exchange), then the
+// elements -- block = the largest band -- and the merge runs on the device (band_mark / scan / band_merge above).  The list stays
+// in c->d_merged (count in c->d_merged_n); *n_total receives the count.  Collective.
+namespace {
+int gather_map_device(esvo_context* h, size_t* n_total) {
+  esvo_comm* c = h->comm;
+  int rc = flush_pending_tick(h);
+  if (rc) return rc;
+  if (!c->ev_map) HIPCHK(hipEventCreateWithFlags(&c->ev_map, hipEventDisableTiming));
+  if (!c->d_merged_n) HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->d_merged_n), sizeof(u32) * 2));
+  // the band's alive cells, in cell order (esvo_depth_point_t with the global creation id in seq), on the back stream
+  launch_map_compact(h->d_map_cur, h->d_exp_flags, h->d_exp_prefix, h->d_cnt_b + 5, h->d_scan_tmp_b, h->d_export, nullptr, h->dp, h->stream_b);
+  u64* d_hs = c->d_map_heads;
+  u64* d_hr = c->d_map_heads + 2;
+  hipLaunchKernelGGL(esvo::band_counts_kernel, dim3(1), dim3(64), 0, h->stream_b, h->d_cnt_b + 5, d_hs);
+  HIPCHK(hipEventRecord(c->ev_map, h->stream_b));
+  HIPCHK(hipStreamWaitEvent(h->stream, c->ev_map, 0));
+  rc = comm_all_gather(h, d_hs, d_hr, 16);
+  if (rc) return rc;
+  std::vector<u64> heads(2 * (size_t)c->world);
+  HIPCHK(hipMemcpyAsync(heads.data(), d_hr, 16 * (size_t)c->world, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  size_t max_n = 0, total = 0;
+  for (int r = 0; r < c->world; ++r) { max_n = std::max<size_t>(max_n, heads[2 * r]); total += heads[2 * r]; }
+  *n_total = total;
+  h->stats.last_map_size = (u32)heads[2 * (size_t)c->rank];
+  if (!total) { HIPCHK(hipMemsetAsync(c->d_merged_n, 0, sizeof(u32), h->stream)); return ESVO_OK; }  // the same on every rank
+  // ids are below (points of the window) x 9 (kernels_fuse.hip: record id q K + k)
+  size_t win_pts = 0;
+  for (auto& f : h->frames) win_pts += f.count;
+  const size_t id_need = std::max<size_t>(win_pts * 9 + 1, 1024);
+  // (a failed allocation below would leave the other ranks in a collective this one skips; the buffers are small against the
+  //  handle's own and grow geometrically, so it is treated like any other out-of-memory condition: the call fails)
+  if (max_n > c->band_block_pts) {
+    if (c->d_band_recv) hipFree(c->d_band_recv);
+    c->d_band_recv = nullptr;
+    c->band_block_pts = max_n + max_n / 4 + 256;
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->d_band_recv), sizeof(esvo_depth_point_t) * c->band_block_pts * c->world));
+  }
+  if (total > c->merged_cap) {
+    if (c->d_merged) hipFree(c->d_merged);
+    c->d_merged = nullptr;
+    c->merged_cap = total + total / 4 + 256;
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->d_merged), sizeof(esvo_depth_point_t) * c->merged_cap));
+  }
+  if (id_need > c->id_cap) {
+    if (c->d_id_present) hipFree(c->d_id_present);
+    if (c->d_id_scan_tmp) hipFree(c->d_id_scan_tmp);
+    c->d_id_present = c->d_id_scan_tmp = nullptr;
+    c->id_cap = id_need + id_need / 4;
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->d_id_present), sizeof(u32) * 3 * c->id_cap));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->d_id_scan_tmp), sizeof(u32) * (scan_scratch_elems(c->id_cap) + 8)));
+  }
+  // every rank's block has the SAME length -- the largest band of this read-out -- whatever its own buffers hold
+  rc = comm_all_gather(h, h->d_export, c->d_band_recv, max_n * sizeof(esvo_depth_point_t));
+  if (rc) return rc;
+  u32* present = c->d_id_present;
+  u32* prefix = present + c->id_cap;
+  u32* where = prefix + c->id_cap;
+  const u32 idc = (u32)id_need;
+  HIPCHK(hipMemsetAsync(present, 0, sizeof(u32) * idc, h->stream));
+  const size_t slots = max_n * (size_t)c->world;
+  hipLaunchKernelGGL(esvo::band_mark_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, h->stream, c->d_band_recv, max_n, d_hr, c->world, idc,
+                     present, where);
+  launch_exclusive_scan_u32(present, prefix, c->d_merged_n, c->d_id_scan_tmp, idc, h->stream);
+  hipLaunchKernelGGL(esvo::band_merge_kernel, dim3((idc + 255) / 256), dim3(256), 0, h->stream, c->d_band_recv, present, prefix, where, idc, c->d_merged);
+  HIPCHK(hipGetLastError());
+  return ESVO_OK;
+}
+}  // namespace
+
+extern "C" {
 int esvo_comm_gather_map(esvo_handle h, esvo_depth_point_t* out, size_t cap, size_t* n) {
   if (!h || !n) return ESVO_ERR_INVALID_ARG;
   API_LOCK(h);
   if (!h->comm) FAIL(ESVO_ERR_STATE, "esvo_comm_init has not been called");
   HIPCHK(hipSetDevice(h->device));
-  esvo_comm* c = h->comm;
-  std::vector<esvo_depth_point_t> mine;
-  int rc = export_map(h, mine, nullptr);
+  size_t total = 0;
+  int rc = gather_map_device(h, &total);
   if (rc) return rc;
-  // a band holds at most ceil(H / world) + 1 rows of cells: fixed block length, count in-band
-  const size_t rows = ((size_t)h->H + c->world - 1) / c->world + 1;
-  const size_t bw = 2 + rows * h->W * 13;
-  if (mine.size() > rows * h->W) FAIL(ESVO_ERR_CAPACITY, "band larger than its block");
-  if (c->band_block_words != bw) {
-    if (c->d_band_send) hipFree(c->d_band_send);
-    if (c->d_band_recv) hipFree(c->d_band_recv);
-    c->d_band_send = c->d_band_recv = nullptr;
-    HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->d_band_send), bw * 8));
-    HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->d_band_recv), bw * 8 * c->world));
-    c->band_block_words = bw;
-  }
-  u64 head[2] = {(u64)mine.size(), 0};
-  HIPCHK(hipMemcpyAsync(c->d_band_send, head, 16, hipMemcpyHostToDevice, h->stream));
-  if (!mine.empty())
-    HIPCHK(hipMemcpyAsync(c->d_band_send + 2, mine.data(), mine.size() * sizeof(esvo_depth_point_t), hipMemcpyHostToDevice, h->stream));
-  rc = comm_all_gather(h, c->d_band_send, c->d_band_recv, bw * 8);
-  if (rc) return rc;
-  std::vector<u64> all(bw * c->world);
-  HIPCHK(hipMemcpyAsync(all.data(), c->d_band_recv, bw * 8 * c->world, hipMemcpyDeviceToHost, h->stream));
+  *n = total;
+  if (!out || !total) { HIPCHK(hipStreamSynchronize(h->stream)); return ESVO_OK; }
+  if (cap < total) { HIPCHK(hipStreamSynchronize(h->stream)); FAIL(ESVO_ERR_CAPACITY, "output capacity too small"); }
+  HIPCHK(hipMemcpyAsync(out, h->comm->d_merged, sizeof(esvo_depth_point_t) * total, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
-  std::vector<esvo_depth_point_t> merged;
-  for (int r = 0; r < c->world; ++r) {
-    const u64 cnt = all[(size_t)r * bw];
-    const esvo_depth_point_t* p = reinterpret_cast<const esvo_depth_point_t*>(&all[(size_t)r * bw + 2]);
-    merged.insert(merged.end(), p, p + cnt);
+  return ESVO_OK;
+}
+
+// publishPointCloud's cloud (esvo_Mapping.cpp:909-934) of the WHOLE map on every rank: what esvo_map_get_pointcloud_xyz returns
+// on one GPU, same points, same order, same bits -- the tracker's reference cloud in the closed loop on row bands
+int esvo_comm_gather_pointcloud_xyz(esvo_handle h, float* out_xyz, size_t cap_points, size_t* n) {
+  if (!h || !n) return ESVO_ERR_INVALID_ARG;
+  API_LOCK(h);
+  if (!h->comm) FAIL(ESVO_ERR_STATE, "esvo_comm_init has not been called");
+  HIPCHK(hipSetDevice(h->device));
+  esvo_comm* c = h->comm;
+  size_t total = 0;
+  int rc = gather_map_device(h, &total);
+  if (rc) return rc;
+  *n = total;
+  if (!out_xyz || !total) { HIPCHK(hipStreamSynchronize(h->stream)); return ESVO_OK; }
+  if (cap_points < total) { HIPCHK(hipStreamSynchronize(h->stream)); FAIL(ESVO_ERR_CAPACITY, "output array too small for the point cloud"); }
+  if (total > c->xyz_cap) {
+    if (c->d_xyz) hipFree(c->d_xyz);
+    c->d_xyz = nullptr;
+    c->xyz_cap = total + total / 4 + 256;
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->d_xyz), sizeof(float) * 3 * c->xyz_cap));
   }
-  std::stable_sort(merged.begin(), merged.end(), [](const esvo_depth_point_t& a, const esvo_depth_point_t& b) { return a.seq < b.seq; });
-  for (size_t i = 0; i < merged.size(); ++i) merged[i].seq = (u32)i;
-  *n = merged.size();
-  if (!out) return ESVO_OK;
-  if (cap < merged.size()) FAIL(ESVO_ERR_CAPACITY, "output capacity too small");
-  std::memcpy(out, merged.data(), merged.size() * sizeof(esvo_depth_point_t));
+  const double* T = h->T_world_frame;
+  hipLaunchKernelGGL(esvo::band_xyz_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, c->d_merged, c->d_merged_n, T[0], T[1], T[2], T[3],
+                     T[4], T[5], T[6], T[7], T[8], T[9], T[10], T[11], c->d_xyz);
+  HIPCHK(hipMemcpyAsync(out_xyz, c->d_xyz, sizeof(float) * 3 * total, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return ESVO_OK;
+}
+
+// Routed band mode renders a rank's rows only; the tracker (esvo_track_set_current) reads the WHOLE left Time Surface.  All-gather
+// of the bands' rows of camera `cam`'s resident surface: afterwards every rank holds the full image, bit for bit the unsharded
+// render (the banded raster is, tests/test_gpu_shard.py).  Bands must be the standard partition (rank r owns rows
+// [r ceil(H / world), (r + 1) ceil(H / world))).  Without row routing the surfaces are whole already: nothing is exchanged.
+int esvo_comm_gather_ts(esvo_handle h, int cam) {
+  if (!h || cam < 0 || cam > 1) return ESVO_ERR_INVALID_ARG;
+  API_LOCK(h);
+  if (!h->comm) FAIL(ESVO_ERR_STATE, "esvo_comm_init has not been called");
+  if (!h->routed) return ESVO_OK;
+  HIPCHK(hipSetDevice(h->device));
+  esvo_comm* c = h->comm;
+  const int rows = (h->H + c->world - 1) / c->world;
+  if (h->dp.band_y0 != std::min(c->rank * rows, h->H) || h->dp.band_y1 != std::min((c->rank + 1) * rows, h->H))
+    FAIL(ESVO_ERR_UNSUPPORTED, "esvo_comm_gather_ts: the band is not rank * ceil(H / world) rows");
+  if (!h->ts_valid[cam]) FAIL(ESVO_ERR_STATE, "no device-resident Time Surface: call esvo_ts_render first");
+  const size_t block = ((size_t)rows * h->W + 7) / 8 * 8;
+  if (c->ts_block != block) {
+    if (c->d_ts_send) hipFree(c->d_ts_send);
+    if (c->d_ts_recv) hipFree(c->d_ts_recv);
+    c->d_ts_send = c->d_ts_recv = nullptr;
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->d_ts_send), block));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->d_ts_recv), block * c->world));
+    HIPCHK(hipMemsetAsync(c->d_ts_send, 0, block, h->stream));  // (the pad bytes; on the stream the copies below run on: hipMemset's null stream is not ordered with it)
+    c->ts_block = block;
+  }
+  std::lock_guard<std::mutex> lt(h->mu_ts);
+  resident_write_begin(h, cam);  // a tracker read of the previous surface may be in flight
+  const size_t own = (size_t)(h->dp.band_y1 - h->dp.band_y0) * h->W;
+  if (own) HIPCHK(hipMemcpyAsync(c->d_ts_send, h->d_ts[cam] + (size_t)h->dp.band_y0 * h->W, own, hipMemcpyDeviceToDevice, h->stream));
+  int rc = comm_all_gather(h, c->d_ts_send, c->d_ts_recv, block);
+  if (rc) return rc;
+  const size_t cells = (size_t)rows * h->W * c->world;
+  hipLaunchKernelGGL(esvo::ts_bands_scatter_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, h->stream, c->d_ts_recv, block, c->world, rows, h->W,
+                     h->H, c->rank, h->d_ts[cam]);
+  HIPCHK(hipGetLastError());
+  if (cam == 0) HIPCHK(hipEventRecord(h->evt[EV_R1], h->stream));  // what esvo_track_set_current waits for
   return ESVO_OK;
 }
 

@@ -50,6 +50,33 @@ def band_of(rank, world, height):
     return min(rank * rows, height), min((rank + 1) * rows, height)
 
 
+class LocalTransport:
+    """The all-gather between `world` ranks that are handles of ONE process on ONE GPU, driven from `world` threads (tests, the
+    closed loop on logical bands): a rendezvous + device copies.  Blocking (the device is drained on both sides), so nothing of
+    the library's overlap is exercised -- only that the calls it makes, in the order it makes them, give the right bits."""
+
+    def __init__(self, world, timeout=120):
+        import threading
+        self.world = world
+        self.bar = threading.Barrier(world, timeout=timeout)
+        self.slots = [None] * world
+
+    def all_gather(self, rank, d_send, d_recv, nbytes):
+        import torch
+        torch.cuda.synchronize()
+        self.slots[rank] = d_send
+        self.bar.wait()
+        for r in range(self.world):
+            src = device_tensor(self.slots[r], nbytes // 8, "<i8")
+            device_tensor(d_recv + r * nbytes, nbytes // 8, "<i8").copy_(src)
+        torch.cuda.synchronize()
+        self.bar.wait()
+        return 0
+
+    def abort(self):
+        self.bar.abort()
+
+
 class HaloViolation(lib.EsvoError):
     """Routed band mode: a refinement of an earlier tick read outside the Time-Surface rows some rank renders; every rank
     refuses its ticks from here on (ESVO_ERR_HALO, the same tick on all of them: the count travels with exchange 2).  The map of

@@ -33,7 +33,7 @@ SYMBOLS = [
     "esvo_bag_open", "esvo_bag_close", "esvo_bag_last_error", "esvo_bag_next_event_array", "esvo_ts_push_bag",
     "esvo_map_get_debug_images", "esvo_map_get_pointcloud_near_xyz", "esvo_voxel_filter_xyz", "esvo_map_save_depth_map",
     "esvo_comm_unique_id", "esvo_comm_rccl_info", "esvo_comm_init", "esvo_comm_init_callbacks", "esvo_comm_destroy", "esvo_comm_owns_next_tick",
-    "esvo_comm_tick", "esvo_comm_tick_resident", "esvo_comm_get_stats", "esvo_comm_flush", "esvo_comm_newest_map", "esvo_comm_shard_tick", "esvo_comm_gather_map",
+    "esvo_comm_tick", "esvo_comm_tick_resident", "esvo_comm_get_stats", "esvo_comm_flush", "esvo_comm_newest_map", "esvo_comm_shard_tick", "esvo_comm_gather_map", "esvo_comm_gather_pointcloud_xyz", "esvo_comm_gather_ts",
 ]
 
 ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
@@ -198,6 +198,8 @@ def load():
     lib.esvo_comm_newest_map.argtypes = [vp, vp, sz, psz, C.POINTER(C.c_longlong)]
     lib.esvo_comm_shard_tick.argtypes = [vp, u64, vp, vp, sz]
     lib.esvo_comm_gather_map.argtypes = [vp, vp, sz, psz]
+    lib.esvo_comm_gather_pointcloud_xyz.argtypes = [vp, vp, sz, psz]
+    lib.esvo_comm_gather_ts.argtypes = [vp, i32]
     for s in SYMBOLS:
         if s not in ("esvo_default_params", "esvo_last_error", "esvo_abi_sizes", "esvo_bag_last_error"):
             getattr(lib, s).restype = C.c_int
@@ -606,7 +608,14 @@ class Esvo:
 
     def comm_init_callbacks(self, rank, world, all_gather):
         """all_gather(d_send, d_recv, bytes_per_rank, stream) -> 0 on success: the one collective the library issues"""
-        self._cb = ALL_GATHER_FN(lambda user, s, r, n, st: all_gather(s, r, n, st))  # kept alive with the handle
+        def trampoline(user, s, r, n, st):   # an exception must not unwind through the C frames: report it, fail the collective
+            try:
+                return int(all_gather(s, r, n, st) or 0)
+            except BaseException:  # noqa: BLE001
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._cb = ALL_GATHER_FN(trampoline)  # kept alive with the handle
         self._ck(self.lib.esvo_comm_init_callbacks(self.h, int(rank), int(world), self._cb, None))
 
     def comm_destroy(self):
@@ -647,6 +656,17 @@ class Esvo:
         st = np.ascontiguousarray(stamps, np.uint64)
         P = np.ascontiguousarray(poses, np.float64).reshape(-1, 16)
         self._ck(self.lib.esvo_comm_shard_tick(self.h, int(t_ns), st.ctypes.data, P.ctypes.data, st.shape[0]))
+
+    def comm_gather_pointcloud(self):
+        """the whole map's publishPointCloud cloud on every rank (collective): (n, 3) float32, world frame"""
+        out = np.zeros((self.W * self.H, 3), np.float32)
+        n = C.c_size_t()
+        self._ck(self.lib.esvo_comm_gather_pointcloud_xyz(self.h, out.ctypes.data, out.shape[0], C.byref(n)))
+        return out[: n.value].copy()
+
+    def comm_gather_ts(self, cam):
+        """routed band mode: the other ranks' rows of camera `cam`'s resident Time Surface (collective)"""
+        self._ck(self.lib.esvo_comm_gather_ts(self.h, int(cam)))
 
     def comm_gather_map(self):
         out = np.zeros(self.W * self.H, DEPTH_POINT_DTYPE)

@@ -549,6 +549,17 @@ int esvo_comm_newest_map(esvo_handle h, esvo_depth_point_t* out, size_t cap, siz
  * creation order. */
 int esvo_comm_shard_tick(esvo_handle h, uint64_t t_ns, const uint64_t* pose_t_ns, const double* pose_T, size_t m);
 int esvo_comm_gather_map(esvo_handle h, esvo_depth_point_t* out, size_t cap, size_t* n);
+/* ABI 7: the band exchange is device-resident -- the band's alive cells compacted on the device, their counts gathered first
+ * (16 B per rank, the one host wait), then the elements with the largest band as block length, merged on the device by the
+ * elements' global creation ids (a scatter by id, one scan, a gather).
+ * esvo_comm_gather_pointcloud_xyz: publishPointCloud's cloud (esvo_Mapping.cpp:909-934) of the whole map on every rank -- the
+ * points, order and float bits of esvo_map_get_pointcloud_xyz on one GPU: the tracker's reference cloud in the closed loop.
+ * esvo_comm_gather_ts: routed band mode renders a rank's rows only, the tracker reads the whole left Time Surface: all-gather of
+ * the bands' rows of camera cam's resident surface (standard partition: rank r owns rows [r ceil(H / world), ...)); afterwards
+ * esvo_track_set_current(h, NULL, k) and esvo_map_init_sgm(h, NULL, NULL, ...) see the full image on every rank.  A no-op
+ * without row routing. */
+int esvo_comm_gather_pointcloud_xyz(esvo_handle h, float* out_xyz, size_t cap_points, size_t* n);
+int esvo_comm_gather_ts(esvo_handle h, int cam);
 
 /* ---- Tracker residual / Jacobian evaluation ---------------------- */
 

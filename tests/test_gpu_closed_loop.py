@@ -33,3 +33,24 @@ def test_re_referencing_to_the_fused_map_keeps_tracking():
     assert min(r["cos"][4:]) > 0.95
     assert r["est_len"][-1] / path > 0.6
     assert r["map_median_abs_err"] < 0.035
+
+
+@pytest.mark.parametrize("G,routing", [(2, "y_rect"), (8, "y_rect"), (8, "broadcast")])
+def test_closed_loop_on_row_bands_reproduces_one_gpu(G, routing):
+    """BASELINE configs[2] on configs[3]'s partition: the mapper split over G row bands (logical ranks on the one GPU, the
+    library's collective calls with an in-process all-gather), the tracker consuming the gathered left Time Surface
+    (esvo_comm_gather_ts) and the gathered map's cloud (esvo_comm_gather_pointcloud_xyz: band maps merged on the device) at
+    every re-reference.  Same cloud, same order, same bits -> the same registered pose at every tick and the same final map as
+    the one-GPU loop: not "similar end error", equal."""
+    one = closed_loop.run(n_ticks=8, reref=3)
+    bands = closed_loop.run_bands(G, routing=routing, n_ticks=8, reref=3)
+    assert bands["ranks_agree"]
+    assert bands["halo_violations"] == 0
+    assert np.array_equal(np.array(bands["poses"]), np.array(one["poses"]))
+    assert bands["pos_err"] == one["pos_err"] and bands["points"] == one["points"]
+    a, b = bands["map"], one["map"]
+    assert len(a) == len(b) > 500
+    for f in ("row", "col", "age", "seq", "inv_depth", "scale2", "nu", "variance", "residual", "x", "p_cam"):
+        assert np.array_equal(a[f], b[f]), f
+    if routing == "y_rect" and G == 8:
+        assert bands["events_staged_max_frac"] < 0.6   # band-local ingest

@@ -49,25 +49,7 @@ def _single(p, rig, stream, ticks):
     return maps
 
 
-class LocalTransport:
-    """the two collectives between handles of one process: a rendezvous + device copies"""
-
-    def __init__(self, world):
-        self.world = world
-        self.bar = threading.Barrier(world, timeout=90)
-        self.slots = [None] * world
-
-    def all_gather(self, rank, d_send, d_recv, nbytes):
-        import torch
-        torch.cuda.synchronize()
-        self.slots[rank] = d_send
-        self.bar.wait()
-        for r in range(self.world):
-            src = edist.device_tensor(self.slots[r], nbytes // 8, "<i8")
-            edist.device_tensor(d_recv + r * nbytes, nbytes // 8, "<i8").copy_(src)
-        torch.cuda.synchronize()
-        self.bar.wait()
-        return 0
+LocalTransport = edist.LocalTransport   # the in-process all-gather between handles of one process (esvo_amd/dist.py)
 
 
 def _run_ranks(world, body):
