@@ -748,7 +748,11 @@ int esvo_comm_shard_tick(esvo_handle h, uint64_t t_ns, const uint64_t* pose_t_ns
   if (!h->comm) FAIL(ESVO_ERR_STATE, "esvo_comm_init has not been called");
   for (int phase = 0; phase < 3; ++phase) {
     int rc = esvo_shard_tick_phase(h, phase, t_ns, pose_t_ns, pose_T, m);
-    if (rc) return rc;
+    if (rc == ESVO_AGAIN) {  // Denoising on a routed handle: the mask bits are exchanged first, phase 0 then runs its second part
+      --phase;
+    } else if (rc) {
+      return rc;
+    }
     if (phase < 2 && h->comm->world > 1) {
       void *snd = nullptr, *rcv = nullptr;
       size_t nb = 0;

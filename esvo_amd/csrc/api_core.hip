@@ -431,7 +431,7 @@ int esvo_destroy(esvo_handle h) {
                   h->d_win, h->d_frame_pose_T, h->d_fr_table, h->d_prop, h->d_tile_pts, h->d_tile_count, h->d_over_pts,
                   h->d_cell_count, h->d_cell_offset, h->d_cell_list, h->d_fuse_ctr, h->d_rec_ids, h->d_map, h->d_map2, h->d_owner_max, h->d_owner_min, h->d_exp_flags,
                   h->d_exp_prefix, h->d_export, h->d_export_cell, h->d_reg_ab, h->d_reg_cd, h->d_tsq[0], h->d_tsq[1], h->d_tsq_tcount, h->d_tsq_tlist, h->d_tsq_over, h->d_tsq_over_count, h->d_own_w, h->d_lkeep, h->d_codes, h->d_codes_send, h->d_codes_all, h->d_pts_send, h->d_pts_all, h->d_rank_kept,
-                  h->d_sel, h->d_evmap, h->d_lm_fvec0, h->d_lm_fnorm0, h->d_lm_meta, h->d_lm_order, h->d_lm_hist, h->d_clk, h->d_fuse_stats, h->d_ring_gidx, h->d_halo_viol, h->d_merge_a, h->d_merge_b, h->d_merge_plan, h->d_tsq_dup};
+                  h->d_sel, h->d_evmap, h->d_lm_fvec0, h->d_lm_fnorm0, h->d_lm_meta, h->d_lm_order, h->d_lm_hist, h->d_clk, h->d_fuse_stats, h->d_ring_gidx, h->d_halo_viol, h->d_dn_flags, h->d_merge_a, h->d_merge_b, h->d_merge_plan, h->d_tsq_dup};
   for (void* p : ptrs) if (p) hipFree(p);
   if (h->h_counters) hipHostFree(h->h_counters);
   if (h->h_cnt_b) hipHostFree(h->h_cnt_b);
@@ -496,6 +496,7 @@ int esvo_reset(esvo_handle h) {
   h->own_total = 0;
   h->glob_base = 0;
   h->halo_error = false;
+  h->dn_pending = false;
   h->resync = esvo_context::Resync();
   HIPCHK(hipMemsetAsync(h->d_halo_viol, 0, sizeof(u32) * 2, h->stream));
   std::memset(h->h_cnt_b + 8 * 3, 0, sizeof(u32) * 8);
@@ -551,8 +552,8 @@ int esvo_set_params(esvo_handle h, const esvo_params_t* params) {
     if (need > h->max_frames) FAIL(ESVO_ERR_CAPACITY, "fusion window (frames) exceeds the capacity fixed at esvo_create");
   }
   if (h->routed && (params->smooth_time_surface != h->prm.smooth_time_surface || params->median_blur_kernel_size != h->prm.median_blur_kernel_size ||
-                    params->patch_size_y != h->prm.patch_size_y || params->denoising || params->bm_updown))
-    FAIL(ESVO_ERR_STATE, "the handle routes events by row (esvo_shard_set_routing): SmoothTimeSurface, median_blur_kernel_size and patch_size_Y "
+                    params->patch_size_y != h->prm.patch_size_y || params->denoising != h->prm.denoising || params->bm_updown))
+    FAIL(ESVO_ERR_STATE, "the handle routes events by row (esvo_shard_set_routing): SmoothTimeSurface, median_blur_kernel_size, patch_size_Y and Denoising "
                          "fix the rows it renders and the events it keeps; esvo_reset + esvo_shard_set_routing to change them");
   esvo_params_t np = *params;
   np.max_events_per_tick = h->prm.max_events_per_tick;

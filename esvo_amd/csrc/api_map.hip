@@ -680,12 +680,102 @@ static inline size_t shard_codes_block(u32 n, u32 N) { return (((size_t)n + N - 
 // the same in routed band mode: two bits per slot of the whole tick, whole 64-bit words
 static inline size_t shard_codes_block_routed(u32 n) { return (((size_t)n + 15) / 16 * 4 + 7) / 8 * 8; }
 
+// Routed band mode, phase 0 proper: the events of the band's rows (the rank's own ring): BM over them, dense local list of the own
+// matches, LM + cull on it, then the (matched, kept) bits of the own slots in a block that spans the whole tick.
+// keep_flags / keep_prefix (Denoising): per walk position of the RAW selection (n_raw events) whether the event is kept and how
+// many kept ones precede it -- the slots are those of the kept sequence (n of them), as on one GPU.
+static int routed_front(esvo_context* h, esvo_context::TickState& tk, u32 n, const u32* keep_flags, const u32* keep_prefix, u32 n_raw = 0) {
+  const u32 N = (u32)h->dp.ev_nshards;
+  const u32 n_loc = tk.n_loc, n_own = tk.n_own;
+  int rc;
+  if (n_loc) {
+    BmArgs a;
+    a.ev = h->d_ring[0]; a.n = n; a.ev_first = h->sh_first; a.ev_cap = h->ring_cap; a.ev_reverse = 1; a.sel = nullptr;
+    a.gidx = h->d_ring_gidx; a.g_first = tk.g_first; a.n_loc = n_loc;
+    a.keep_flags = keep_flags; a.keep_prefix = keep_prefix; a.n_raw = keep_flags ? n_raw : n;
+    a.tsL = h->d_obs[0]; a.tsR = h->d_obs[1];
+    a.lut = h->d_lut; a.mask = h->d_mask;
+    a.pose_sec = h->d_pose_sec; a.n_pose = h->n_pose;
+    a.out_slots = h->d_match_slots; a.out_flags = h->d_match_flags;
+    a.fail_counters = h->d_counters;
+    hipEventRecord(h->evt[EV_BM0 + h->fpar * EV_FRONT_STRIDE], h->stream);
+    launch_bm_match(a, h->dp, h->stream);
+    hipEventRecord(h->evt[EV_BM1 + h->fpar * EV_FRONT_STRIDE], h->stream);
+    HIPCHK(hipGetLastError());
+    // dense list of the own matches (count -> counters[8]); the slot of each follows from its walk position (shard_codes_routed)
+    if (scan_compact_is_small(n_loc)) {
+      launch_scan_compact_matches_small(h->d_match_flags, h->d_match_prefix, h->d_counters + 8, n_loc, h->d_match_slots, h->d_matches, nullptr,
+                                        h->stream);
+    } else {
+      launch_exclusive_scan_u32(h->d_match_flags, h->d_match_prefix, h->d_counters + 8, h->d_scan_tmp, n_loc, h->stream);
+      launch_compact_matches(h->d_match_slots, h->d_match_flags, h->d_match_prefix, n_loc, h->d_matches, nullptr, h->stream);
+    }
+    hipEventRecord(h->evt[EV_S1 + h->fpar * EV_FRONT_STRIDE], h->stream);
+    HIPCHK(hipGetLastError());
+    // (the ring also holds the raster's halo events: the launch -- and with it the kernel's layout -- is bounded by the OWN
+    //  events of the selection, counted at ingest)
+    rc = run_lm(h, n_own, 1, true);
+    if (rc) return rc;
+  } else {  // no event of this tick in the band: the stage events the statistics read are still recorded
+    for (int e : {EV_BM0, EV_BM1, EV_S1, EV_LM0, EV_LM1}) hipEventRecord(h->evt[e + h->fpar * EV_FRONT_STRIDE], h->stream);
+  }
+  const size_t nb = shard_codes_block_routed(n);
+  HIPCHK(hipMemsetAsync(h->d_codes_send, 0, nb, h->stream));
+  launch_shard_codes_routed(h->d_matches, h->d_lkeep, h->d_counters + 8, n_own, n, (u32)h->dp.num_threads, h->d_own_w,
+                            reinterpret_cast<u32*>(h->d_codes_send), h->stream);
+  HIPCHK(hipGetLastError());
+  h->xchg_send = h->d_codes_send;
+  h->xchg_recv = N > 1 ? h->d_codes_all : h->d_codes_send;
+  h->xchg_block = nb;
+  return ESVO_OK;
+}
+// Denoising on a routed band handle (esvo_Mapping.cpp:1046-1072: the mask is the 3 x 3 median of the selected events' map; an
+// event is kept when its pixel is set in it).  An event's flag needs the selected events of its raw row and the two next to it; a
+// rank's ring holds the raw rows of its band + 1 (keep_px bit 2, esvo_shard_set_routing), so it computes the flags of the events
+// whose RAW row lies in its band -- every selected event has exactly one such rank -- and the ranks all-gather them as one bit per
+// walk position of the selection.  The kept sequence (which events, in which order, how many) is then the one-GPU one on every rank.
+static inline size_t denoise_bits_block(u32 n) { return (((size_t)n + 31) / 32 * 4 + 7) / 8 * 8; }
+static int routed_denoise_begin(esvo_context* h, esvo_context::TickState& tk) {
+  const u32 N = (u32)h->dp.ev_nshards;
+  const size_t nb = denoise_bits_block(tk.n);
+  HIPCHK(hipMemsetAsync(h->d_codes_send, 0, nb, h->stream));
+  launch_denoise_bits_routed(h->d_ring[0], h->sh_first, h->ring_cap, tk.n_loc, h->d_ring_gidx, tk.g_first, tk.n, h->d_evmap, h->W, h->H,
+                             h->dp.band_y0, h->dp.band_y1, reinterpret_cast<u32*>(h->d_codes_send), h->stream);
+  HIPCHK(hipGetLastError());
+  h->xchg_send = h->d_codes_send;
+  h->xchg_recv = N > 1 ? h->d_codes_all : h->d_codes_send;
+  h->xchg_block = nb;
+  h->dn_pending = true;
+  return ESVO_OK;
+}
+static int routed_denoise_resume(esvo_context* h) {
+  h->dn_pending = false;
+  esvo_context::TickState& tk = h->tk[h->fpar];
+  const u32 N = (u32)h->dp.ev_nshards, n_raw = tk.n;
+  if (!h->d_dn_flags) {
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&h->d_dn_flags), sizeof(u32) * 2 * (size_t)h->max_ev));
+  }
+  u32* flags = h->d_dn_flags;
+  u32* prefix = h->d_dn_flags + h->max_ev;
+  launch_denoise_bits_unpack(reinterpret_cast<const u32*>(N > 1 ? h->d_codes_all : h->d_codes_send), (u32)(denoise_bits_block(n_raw) / 4), N, n_raw,
+                             flags, h->stream);
+  launch_exclusive_scan_u32(flags, prefix, h->d_counters + 5, h->d_scan_tmp, n_raw, h->stream);
+  int rc = read_counters(h);  // the kept count sizes everything behind it (as on one GPU: one read-back)
+  if (rc) return rc;
+  const u32 n = tk.n = h->h_counters[5];
+  h->xchg_send = h->xchg_recv = nullptr;
+  h->xchg_block = 0;
+  if (!n) return ESVO_OK;
+  return routed_front(h, tk, n, flags, prefix, n_raw);
+}
+
 // phase 0 (front stage): poses, event selection, block matching + LM of the events of this handle's shard
 int tick_phase0(esvo_context* h, uint64_t t_ns, const uint64_t* pose_t_ns, const double* pose_T, size_t m) {
   // Everything that can refuse the tick (pose table too large, events beyond the capacity or already overwritten in
   // the ring) is checked BEFORE any per-tick state is switched: a refused tick must leave no trace, in particular not in
   // the pose-table double buffer, which the LM stage of a still pending tick reads and whose content the back stage
   // copies into that tick's frame slot.
+  if (h->dn_pending) return routed_denoise_resume(h);  // phase 0 called again behind the exchange of the denoising bits (ESVO_AGAIN)
   if (m > h->max_poses) FAIL(ESVO_ERR_CAPACITY, "pose table larger than max_poses_per_tick");
   if (h->routed && h->halo_error)
     FAIL(ESVO_ERR_HALO, "a refinement of an earlier tick read outside the Time-Surface rows some rank renders (stats.halo_violations): "
@@ -718,7 +808,7 @@ int tick_phase0(esvo_context* h, uint64_t t_ns, const uint64_t* pose_t_ns, const
   if (h->sharded || h->front_throttle) HIPCHK(hipStreamWaitEvent(h->stream, h->evt[EV_RG1 + h->par * EV_BACK_STRIDE], 0));
   hipEventRecord(h->evt[EV_T0 + h->fpar * EV_FRONT_STRIDE], h->stream);
   const u32* sel = nullptr;
-  if (h->prm.denoising && n) {
+  if (h->prm.denoising && n && !h->routed) {
     // Denoising (esvo_Mapping.cpp:282-296): mask from the selected events, keep those on it, in order.
     // One extra read-back (the kept count sizes the BM launch); only the small DAVIS configs use it.
     launch_denoise_flags(h->d_ring[0], h->sh_first, h->ring_cap, n, h->d_evmap, h->d_match_flags, h->W, h->H, h->stream);
@@ -765,47 +855,12 @@ int tick_phase0(esvo_context* h, uint64_t t_ns, const uint64_t* pose_t_ns, const
     rc = run_lm(h, n, 1, false, sl, tk.lm_pair);
     if (rc) return rc;
   } else if (n && h->routed) {
-    // the events of the band's rows (the rank's own ring): BM over them, dense local list of the own matches, LM + cull on it,
-    // then the (matched, kept) bits of the own slots in a block that spans the whole tick
-    const u32 N = (u32)h->dp.ev_nshards;
-    if (n_loc) {
-      BmArgs a;
-      a.ev = h->d_ring[0]; a.n = n; a.ev_first = h->sh_first; a.ev_cap = h->ring_cap; a.ev_reverse = 1; a.sel = nullptr;
-      a.gidx = h->d_ring_gidx; a.g_first = g_first; a.n_loc = n_loc;
-      a.tsL = h->d_obs[0]; a.tsR = h->d_obs[1];
-      a.lut = h->d_lut; a.mask = h->d_mask;
-      a.pose_sec = h->d_pose_sec; a.n_pose = h->n_pose;
-      a.out_slots = h->d_match_slots; a.out_flags = h->d_match_flags;
-      a.fail_counters = h->d_counters;
-      hipEventRecord(h->evt[EV_BM0 + h->fpar * EV_FRONT_STRIDE], h->stream);
-      launch_bm_match(a, h->dp, h->stream);
-      hipEventRecord(h->evt[EV_BM1 + h->fpar * EV_FRONT_STRIDE], h->stream);
-      HIPCHK(hipGetLastError());
-      // dense list of the own matches (count -> counters[8]); the slot of each follows from its walk position (shard_codes_routed)
-      if (scan_compact_is_small(n_loc)) {
-        launch_scan_compact_matches_small(h->d_match_flags, h->d_match_prefix, h->d_counters + 8, n_loc, h->d_match_slots, h->d_matches, nullptr,
-                                          h->stream);
-      } else {
-        launch_exclusive_scan_u32(h->d_match_flags, h->d_match_prefix, h->d_counters + 8, h->d_scan_tmp, n_loc, h->stream);
-        launch_compact_matches(h->d_match_slots, h->d_match_flags, h->d_match_prefix, n_loc, h->d_matches, nullptr, h->stream);
-      }
-      hipEventRecord(h->evt[EV_S1 + h->fpar * EV_FRONT_STRIDE], h->stream);
-      HIPCHK(hipGetLastError());
-      // (the ring also holds the raster's halo events: the launch -- and with it the kernel's layout -- is bounded by the OWN
-      //  events of the selection, counted at ingest)
-      rc = run_lm(h, n_own, 1, true);
-      if (rc) return rc;
-    } else {  // no event of this tick in the band: the stage events the statistics read are still recorded
-      for (int e : {EV_BM0, EV_BM1, EV_S1, EV_LM0, EV_LM1}) hipEventRecord(h->evt[e + h->fpar * EV_FRONT_STRIDE], h->stream);
+    if (h->prm.denoising) {  // the denoising mask first: its bits are exchanged, phase 0 is called again behind that (ESVO_AGAIN)
+      rc = routed_denoise_begin(h, tk);
+      return rc ? rc : (int)ESVO_AGAIN;
     }
-    const size_t nb = shard_codes_block_routed(n);
-    HIPCHK(hipMemsetAsync(h->d_codes_send, 0, nb, h->stream));
-    launch_shard_codes_routed(h->d_matches, h->d_lkeep, h->d_counters + 8, n_own, n, (u32)h->dp.num_threads, h->d_own_w,
-                              reinterpret_cast<u32*>(h->d_codes_send), h->stream);
-    HIPCHK(hipGetLastError());
-    h->xchg_send = h->d_codes_send;
-    h->xchg_recv = N > 1 ? h->d_codes_all : h->d_codes_send;
-    h->xchg_block = nb;
+    rc = routed_front(h, tk, n, nullptr, nullptr);
+    if (rc) return rc;
   } else if (n) {
     // own slots only (w % n_shards == shard): BM, dense local list, LM + cull on it, then the (matched, kept)
     // byte of every own slot, back to back: this rank's block of the caller's all-gather
@@ -1447,8 +1502,8 @@ extern "C" int esvo_shard_tick_phase(esvo_handle h, int phase, uint64_t t_ns, co
   HIPCHK(hipSetDevice(h->device));
   switch (phase) {
     case 0:
-      if (!pose_t_ns || !pose_T) return ESVO_ERR_INVALID_ARG;
-      return tick_phase0(h, t_ns, pose_t_ns, pose_T, m);
+      if (!h->dn_pending && (!pose_t_ns || !pose_T)) return ESVO_ERR_INVALID_ARG;
+      return tick_phase0(h, t_ns, pose_t_ns, pose_T, m);  // (ESVO_AGAIN: exchange, then phase 0 once more -- Denoising on a routed handle)
     case 1: {
       int rc = tick_phase1_enqueue(h);
       if (rc) return rc;
@@ -1756,7 +1811,6 @@ int esvo_shard_set_routing(esvo_handle h, int mode, int ts_halo_rows) {
   if (!rings_empty(h)) FAIL(ESVO_ERR_STATE, "events are already staged: choose the routing before the first esvo_ts_push_events (or esvo_reset)");
   if (mode == ESVO_ROUTE_BROADCAST) { h->routed = false; return ESVO_OK; }
   const esvo_params_t& p = h->prm;
-  if (p.denoising) FAIL(ESVO_ERR_UNSUPPORTED, "Denoising builds its mask from the whole event slice: use ESVO_ROUTE_BROADCAST");
   if (h->tsq_len) FAIL(ESVO_ERR_UNSUPPORTED, "per-pixel event queues (max_event_queue_len) are not routed: use ESVO_ROUTE_BROADCAST");
   if (p.bm_updown) FAIL(ESVO_ERR_UNSUPPORTED, "up-down stereo searches along y, across the bands: use ESVO_ROUTE_BROADCAST");
   const int H = h->H, W = h->W;
@@ -1785,6 +1839,9 @@ int esvo_shard_set_routing(esvo_handle h, int mode, int ts_halo_rows) {
       uint8_t f = (y >= h->sband_y0[0] && y < h->sband_y1[0]) ? 1 : 0;
       const int yb = (int)std::floor((double)lut[2 * ((size_t)y * W + x) + 1]);  // kernels_bm.hip: the rank that owns floor(y_rect)
       if (yb >= h->dp.band_y0 && yb < h->dp.band_y1) f |= 2;
+      // Denoising: the rank decides the mask's verdict for the events whose RAW row is in its band; the 3 x 3 median reads the
+      // selected events of one more row on either side (routed_denoise_begin)
+      if (p.denoising && y >= h->dp.band_y0 - 1 && y < h->dp.band_y1 + 1) f |= 4;
       h->keep_px[(size_t)y * W + x] = f;
     }
   HIPCHK(hipSetDevice(h->device));

@@ -217,6 +217,10 @@ void launch_gaussian5_pair(const uint8_t* in0, const uint8_t* in1, uint8_t* out0
 void launch_denoise_flags(const esvo_event_t* ring, u64 first, u64 cap, u32 n, uint8_t* evmap, u32* flags, int W, int H,
                           hipStream_t s);
 void launch_denoise_select(const u32* flags, const u32* prefix, u32 n, u32* sel, hipStream_t s);
+// routed band mode (api_map.hip, routed_denoise_begin / _resume): the rank's bits of the kept flags, one per walk position
+void launch_denoise_bits_routed(const esvo_event_t* ring, u64 first, u64 cap, u32 n_loc, const u32* gidx, u32 g_first, u32 n, uint8_t* evmap,
+                                int W, int H, int band_y0, int band_y1, u32* bits, hipStream_t s);
+void launch_denoise_bits_unpack(const u32* blocks, u32 block_words, u32 N, u32 n, u32* flags, hipStream_t s);
 
 // kernels_bm.hip
 struct BmArgs {
@@ -241,6 +245,11 @@ struct BmArgs {
   const u32* gidx = nullptr;
   u32 g_first = 0;
   u32 n_loc = 0;
+  // ... with Denoising: the walk positions are those of the RAW selection (n_raw events); keep_flags says which are kept,
+  // keep_prefix how many kept ones precede -- the event's position in the kept sequence, which is what n counts
+  const u32* keep_flags = nullptr;
+  const u32* keep_prefix = nullptr;
+  u32 n_raw = 0;
 };
 void launch_bm_match(const BmArgs& a, const DevParams& p, hipStream_t s);
 void launch_compact_matches(const esvo_match_t* slots, const u32* flags, const u32* prefix, u32 n,

@@ -286,6 +286,8 @@ struct esvo_context {
   size_t tsq_dup_cap = 0;
   u32* d_halo_viol = nullptr;            // [2] matches whose refinement read outside oband, all ranks, summed over the ticks | scratch
   bool halo_error = false;               // sticky (esvo_reset clears it): ticks are refused with ESVO_ERR_HALO
+  bool dn_pending = false;               // Denoising on a routed handle: phase 0 returned ESVO_AGAIN, the mask bits are being exchanged
+  u32* d_dn_flags = nullptr;             // [2][max_ev] kept flag + exclusive prefix per walk position of the raw selection (lazily)
   // A tick's state between its phases.  Unsharded ticks are finished lazily: esvo_map_tick(k) enqueues the front
   // stage of tick k and only then completes tick k-1 (point count -> window policy -> back stage), so the host
   // never waits on the front stream while it still has work to enqueue there.

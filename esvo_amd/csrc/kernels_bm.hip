@@ -123,6 +123,11 @@ __device__ inline void bm_item(const BmArgs& a, const DevParams& p, u32 w, u32& 
     const u64 ei = (a.ev_first - w) % a.ev_cap;
     e = reinterpret_cast<const uint4*>(a.ev)[ei];
     k = a.g_first - a.gidx[ei];
+    if (a.keep_flags) {  // Denoising: position in the KEPT sequence (the raw position only selects)
+      ok = k < a.n_raw && a.keep_flags[k] != 0u;
+      if (ok) k = a.keep_prefix[k];
+      return;
+    }
     ok = k < a.n;
     return;
   }

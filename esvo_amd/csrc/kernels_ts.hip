@@ -630,6 +630,64 @@ void launch_denoise_select(const u32* flags, const u32* prefix, u32 n, u32* sel,
   hipLaunchKernelGGL(denoise_select_kernel, dim3((n + 255) / 256), dim3(256), 0, s, flags, prefix, n, sel);
 }
 
+// Routed band mode (the rank's ring holds its rows' events, each with its index in the global sequence): mark the selected events
+// of the ring in the event map, then the flag of every selected event whose RAW row lies in [band_y0, band_y1) as bit k of `bits`
+// (k = its walk position in the global selection; zeroed by the caller).
+__global__ void __launch_bounds__(256) denoise_mark_routed_kernel(const uint4* __restrict__ ring, u64 first, u64 cap, u32 n_loc,
+                                                                  const u32* __restrict__ gidx, u32 g_first, u32 n, uint8_t* __restrict__ evmap,
+                                                                  int W, int H) {
+  const u32 w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n_loc) return;
+  const u64 ei = (first - w) % cap;
+  if (g_first - gidx[ei] >= n) return;
+  const uint4 e = ring[ei];
+  const u32 x = e.x & 0xffffu, y = e.x >> 16;
+  if (x < (u32)W && y < (u32)H) evmap[y * W + x] = 255;
+}
+__global__ void __launch_bounds__(256) denoise_bits_routed_kernel(const uint4* __restrict__ ring, u64 first, u64 cap, u32 n_loc,
+                                                                  const u32* __restrict__ gidx, u32 g_first, u32 n,
+                                                                  const uint8_t* __restrict__ evmap, int W, int H, int band_y0, int band_y1,
+                                                                  u32* __restrict__ bits) {
+  const u32 w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n_loc) return;
+  const u64 ei = (first - w) % cap;
+  const u32 k = g_first - gidx[ei];
+  if (k >= n) return;
+  const uint4 e = ring[ei];
+  const int x = e.x & 0xffffu, y = e.x >> 16;
+  if (!(x < W && y < H) || y < band_y0 || y >= band_y1) return;  // (an event outside the sensor is never kept: denoise_flag_kernel)
+  int cnt = 0;
+#pragma unroll
+  for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx) {
+      const int yy = min(max(y + dy, 0), H - 1), xx = min(max(x + dx, 0), W - 1);
+      cnt += evmap[yy * W + xx] != 0;
+    }
+  if (cnt >= 5) atomicOr(&bits[k >> 5], 1u << (k & 31u));
+}
+void launch_denoise_bits_routed(const esvo_event_t* ring, u64 first, u64 cap, u32 n_loc, const u32* gidx, u32 g_first, u32 n, uint8_t* evmap,
+                                int W, int H, int band_y0, int band_y1, u32* bits, hipStream_t s) {
+  hipMemsetAsync(evmap, 0, (size_t)W * H, s);
+  if (n_loc == 0) return;
+  const uint4* r = reinterpret_cast<const uint4*>(ring);
+  hipLaunchKernelGGL(denoise_mark_routed_kernel, dim3((n_loc + 255) / 256), dim3(256), 0, s, r, first, cap, n_loc, gidx, g_first, n, evmap, W, H);
+  hipLaunchKernelGGL(denoise_bits_routed_kernel, dim3((n_loc + 255) / 256), dim3(256), 0, s, r, first, cap, n_loc, gidx, g_first, n, evmap, W, H,
+                     band_y0, band_y1, bits);
+}
+// the gathered blocks [N][block_words] -> one flag per walk position (every position has at most one rank that set its bit)
+__global__ void __launch_bounds__(256) denoise_bits_unpack_kernel(const u32* __restrict__ blocks, u32 block_words, u32 N, u32 n, u32* __restrict__ flags) {
+  const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  u32 word = 0;
+  for (u32 r = 0; r < N; ++r) word |= blocks[(size_t)r * block_words + (k >> 5)];
+  flags[k] = (word >> (k & 31u)) & 1u;
+}
+void launch_denoise_bits_unpack(const u32* blocks, u32 block_words, u32 N, u32 n, u32* flags, hipStream_t s) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(denoise_bits_unpack_kernel, dim3((n + 255) / 256), dim3(256), 0, s, blocks, block_words, N, n, flags);
+}
+
 // ---- wire ingest: serialised dvs_msgs/Event records (13 B: u16 x, u16 y, u32 sec, u32 nsec, u8 polarity; ROS1
 // little-endian, no padding) -> esvo_event_t records in the event ring --------------------
 __global__ void __launch_bounds__(256) ts_unpack_wire_kernel(const uint8_t* __restrict__ wire, size_t n, esvo_event_t* __restrict__ ring,

@@ -96,13 +96,13 @@ def _band_tick_guard(fn):
 
 
 def pick_routing(params, routing="auto"):
-    """"auto": rows where the library supports it (esvo_shard_set_routing refuses Denoising, per-pixel event queues and
-    up-down stereo with ESVO_ERR_UNSUPPORTED), the broadcast switch otherwise"""
+    """"auto": rows where the library supports it (esvo_shard_set_routing refuses per-pixel event queues and up-down stereo
+    with ESVO_ERR_UNSUPPORTED), the broadcast switch otherwise"""
     if routing != "auto":
         return routing
     if params is None:
         return "y_rect"
-    unsupported = bool(getattr(params, "denoising", 0)) or int(getattr(params, "max_event_queue_len", 0)) > 0 or bool(getattr(params, "bm_updown", 0))
+    unsupported = int(getattr(params, "max_event_queue_len", 0)) > 0 or bool(getattr(params, "bm_updown", 0))
     return "broadcast" if unsupported else "y_rect"
 
 
@@ -169,7 +169,9 @@ class ShardedEsvo:
     @_band_tick_guard
     def tick(self, t_ns, stamps, poses):
         d = self.dev
-        d.shard_phase(0, t_ns, stamps, poses)
+        if d.shard_phase(0, t_ns, stamps, poses):   # Denoising on a routed handle: the mask's bits first, then phase 0 proper
+            self._exchange()
+            d.shard_phase(0)
         self._exchange()
         d.shard_phase(1)
         self._exchange()

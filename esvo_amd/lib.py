@@ -48,6 +48,7 @@ class EsvoError(RuntimeError):
 
 
 ERR_HALO = -7   # ESVO_ERR_HALO (include/esvo_hip.h)
+ESVO_AGAIN = 1  # esvo_shard_tick_phase: exchange, then the same phase once more
 
 
 _PERTURBED_PATH = os.path.join(_CSRC, "libesvo_hip_perturbed.so")
@@ -696,9 +697,15 @@ class Esvo:
         return (snd.value or 0), (rcv.value or 0), int(nb.value)
 
     def shard_phase(self, phase, t_ns=0, stamps=None, poses=None):
-        if phase == 0:
+        """one phase of esvo_shard_tick_phase; returns True when the phase must be called AGAIN behind the exchange that is now due
+        (ESVO_AGAIN: phase 0 of a routed handle with Denoising -- the second call takes no arguments)"""
+        if phase == 0 and stamps is not None:
             st = np.ascontiguousarray(stamps, np.uint64)
             T = np.ascontiguousarray(poses, np.float64).reshape(-1, 16)
-            self._ck(self.lib.esvo_shard_tick_phase(self.h, 0, int(t_ns), st.ctypes.data, T.ctypes.data, st.shape[0]))
+            rc = self.lib.esvo_shard_tick_phase(self.h, 0, int(t_ns), st.ctypes.data, T.ctypes.data, st.shape[0])
         else:
-            self._ck(self.lib.esvo_shard_tick_phase(self.h, int(phase), 0, None, None, 0))
+            rc = self.lib.esvo_shard_tick_phase(self.h, int(phase), 0, None, None, 0)
+        if rc == ESVO_AGAIN:
+            return True
+        self._ck(rc)
+        return False

@@ -59,7 +59,10 @@ typedef enum esvo_status_t {
   ESVO_ERR_CAPACITY = -4,
   ESVO_ERR_UNSUPPORTED = -5,
   ESVO_ERR_STATE = -6,
-  ESVO_ERR_HALO = -7   /* routed band mode: a refinement read outside the rank's Time-Surface rows (esvo_shard_set_routing) */
+  ESVO_ERR_HALO = -7,  /* routed band mode: a refinement read outside the rank's Time-Surface rows (esvo_shard_set_routing) */
+  ESVO_AGAIN = 1       /* not an error -- esvo_shard_tick_phase(h, 0, ...) on a routed handle with Denoising: all-gather the block of
+                          esvo_shard_exchange (one bit per selected event: the rank's share of the denoising mask's verdicts), then call
+                          phase 0 again (its arguments are ignored the second time) */
 } esvo_status_t;
 
 typedef struct esvo_context* esvo_handle;

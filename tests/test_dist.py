@@ -298,8 +298,8 @@ def test_band_driver_gloo_world2():
 
 def test_pick_routing_follows_what_the_library_supports():
     """dist.pick_routing("auto"): rows by floor(y_rect) unless the parameters are ones esvo_shard_set_routing refuses
-    (Denoising needs the whole event slice, per-pixel event queues, up-down stereo) -- then the broadcast switch; an explicit
-    choice is passed through."""
+    (per-pixel event queues, up-down stereo) -- then the broadcast switch; an explicit choice is passed through.  Denoising
+    is routed by rows since round 6."""
     from esvo_amd import calib, dist as edist, params
     rig = calib.dataset_rig("dsec")
     p, _ = params.make_params(params.PRESETS["mapping_dsec"], rig)
@@ -307,7 +307,7 @@ def test_pick_routing_follows_what_the_library_supports():
     assert edist.pick_routing(p, "broadcast") == "broadcast" and edist.pick_routing(p, "y_rect") == "y_rect"
     rig_r = calib.dataset_rig("rpg")
     pr, _ = params.make_params(params.PRESETS["mvstereo_rpg"], rig_r)       # the small DAVIS configs switch Denoising on
-    assert bool(pr.denoising) and edist.pick_routing(pr, "auto") == "broadcast"
+    assert bool(pr.denoising) and edist.pick_routing(pr, "auto") == "y_rect"
     pq, _ = params.make_params(params.PRESETS["mapping_dsec"], rig)
     pq.max_event_queue_len = 20
     assert edist.pick_routing(pq, "auto") == "broadcast"

@@ -230,3 +230,42 @@ def test_band_sharded_ranks_through_the_c_calls(request, world, routing, rig_fix
         n_l, n_r = len(stream.ev_left), len(stream.ev_right)
         assert max(o[1] for o in outs) < 0.6 * n_l and max(o[2] for o in outs) < 0.6 * n_r, [(o[1], o[2]) for o in outs]
         assert sum(o[1] for o in outs) >= n_l * 0.9   # (every event is somebody's)
+
+
+def test_denoising_rig_band_sharded_through_the_c_calls():
+    """esvo_comm_shard_tick on a routed handle with Denoising (hkust): the C driver loop handles ESVO_AGAIN -- the all-gather of the
+    mask bits, then phase 0 proper -- and every rank's gathered map equals the one-GPU map."""
+    from esvo_amd import lib
+    from tests import scenarios
+    sc = scenarios.Scenario("hkust")
+    rig, p, stream, spec = sc.rig, sc.params, sc.stream(), sc.spec
+    world = 4
+    ticks = []
+    for k in range(4):
+        t = stream.t0_ns + int(round((spec["t_first"] + spec["dt"] * k) * 1e9))
+        stamps, poses = rostime.pose_table(stream.pose, t, p.bm_half_slice_thickness)
+        ticks.append((t, stamps, poses, stream.pose(t)))
+    ref = _single(p, rig, stream, ticks)
+    tr = LocalTransport(world)
+
+    def body(r):
+        dev = lib.Esvo(p, rig)
+        y0, y1 = edist.band_of(r, world, rig.height)
+        dev.set_band(y0, y1, r, world, routing="y_rect")
+        dev.comm_init_callbacks(r, world, lambda s, d, n, st: tr.all_gather(r, s, d, n))
+        dev.ts_push_events(0, stream.ev_left)
+        dev.ts_push_events(1, stream.ev_right)
+        maps = []
+        for t, stamps, poses, T in ticks:
+            dev.ts_render(0, t, download=False)
+            dev.ts_render(1, t, download=False)
+            dev.set_observation(t, None, None, T)
+            dev.comm_shard_tick(t, stamps, poses)
+            maps.append(dev.comm_gather_map())
+        assert dev.stats().halo_violations == 0
+        return maps
+
+    for maps in _run_ranks(world, body):
+        for k, mp in enumerate(maps):
+            _same(mp, ref[k])
+    assert len(ref[-1]) > 50

@@ -122,6 +122,63 @@ def test_logical_shards_equal_unsharded(request, preset, rig_fix, stream_fix, n_
             assert max(staged) < 0.6 * int(ref.stats().events_staged[0]), staged
 
 
+@pytest.mark.parametrize("name,G", [("rpg", 8), ("hkust", 8), ("hkust", 3)])
+def test_denoising_rigs_routed_by_rows(name, G):
+    """The small DAVIS configurations switch Denoising on (esvo_Mapping.cpp:1046-1072: 3 x 3 median of the selected events' map,
+    events off the mask dropped BEFORE the thread-stride deal).  Routed by rows since round 6: a rank decides the mask's verdict
+    for the events whose raw row lies in its band (its ring holds one more row on either side), phase 0 returns ESVO_AGAIN with
+    one bit per selected event to all-gather, and its second part matches the kept sequence -- which events, which order, how
+    many -- of the unsharded tick.  rpg 240 x 180 and hkust 346 x 260 (ragged bands) at BASELINE.json's world size."""
+    from esvo_amd import dist as edist
+    from esvo_amd import lib
+    from tests import scenarios
+    sc = scenarios.Scenario(name)
+    rig, p, stream, spec = sc.rig, sc.params, sc.stream(), sc.spec
+    assert p.denoising
+    ref = lib.Esvo(p, rig)
+    shards = [lib.Esvo(p, rig) for _ in range(G)]
+    for g, d in enumerate(shards):
+        y0, y1 = edist.band_of(g, G, rig.height)
+        d.set_band(y0, y1, g, G, routing="y_rect")
+    t_prev = stream.t0_ns
+    kept_seen = []
+    for k in range(spec["n_ticks"]):
+        t = stream.t0_ns + int(round((spec["t_first"] + spec["dt"] * k) * 1e9))
+        stamps, poses = rostime.pose_table(stream.pose, t, p.bm_half_slice_thickness)
+        for d in [ref] + shards:
+            for cam in (0, 1):
+                d.ts_push_events(cam, stream.slice(cam, t_prev, t + 2_000_000))
+            d.ts_render(0, t, download=False); d.ts_render(1, t, download=False)
+            d.set_observation(t, None, None, stream.pose(t))
+        t_prev = t + 2_000_000
+        ref.tick(t, stamps, poses)
+        again = [d.shard_phase(0, t, stamps, poses) for d in shards]
+        assert all(again)                               # every rank asks for the exchange of the mask bits
+        bits = _emulated_gather(shards)
+        assert bits is not None
+        assert not any(d.shard_phase(0) for d in shards)
+        _emulated_gather(shards)
+        for d in shards:
+            d.shard_phase(1)
+        _emulated_gather(shards)
+        for d in shards:
+            d.shard_phase(2)
+        rs = ref.stats()
+        for d in shards:
+            ds = d.stats()
+            assert (ds.last_events_in, ds.last_matches, ds.last_points) == (rs.last_events_in, rs.last_matches, rs.last_points), k
+        kept_seen.append(int(rs.last_events_in))
+        merged = edist.merge_band_maps([d.get_map() for d in shards])
+        full = ref.get_map()
+        assert len(merged) == len(full), (k, len(merged), len(full))
+        for f in ("row", "col", "age"):
+            assert np.array_equal(merged[f], full[f]), (k, f)
+        for f in F64:
+            assert np.array_equal(merged[f], full[f]), (k, f)
+    assert len(full) > 50 and max(kept_seen) < p.process_event_num and min(kept_seen) > 100   # the mask really dropped events
+    assert all(d.stats().halo_violations == 0 for d in shards)
+
+
 @pytest.mark.parametrize("cull_all", [False, True])
 def test_routed_band_detects_a_refinement_that_leaves_its_rows(dsec_rig, dsec_stream, cull_all):
     """The guard of the routed mode: with the smallest halo and a camera that moves VERTICALLY between an event and the
