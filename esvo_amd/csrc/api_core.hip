@@ -347,9 +347,6 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
     CK(hipMemset(h->d_fuse_ctr, 0, sizeof(u32) * (2112 + 64)));
     if (const char* er = esvo_dev_switch("ESVO_FUSE_TILE_REC")) h->fuse_tile_rec = (u32)std::max(1L, std::atol(er));
     CK(dalloc(&h->d_rec_ids, n_tiles * h->fuse_tile_rec + (size_t)h->win_cap * 9));
-#ifdef FUSE_STATS
-    if (esvo_dev_switch("ESVO_FUSE_STATS")) { CK(dalloc(&h->d_fuse_stats, n_tiles * 8)); CK(hipMemset(h->d_fuse_stats, 0, sizeof(u64) * n_tiles * 8)); }
-#endif
   }
   if (const char* ef = esvo_dev_switch("ESVO_FUSE_LDS_CAP")) h->fuse_lds_cap = (u32)std::max(0L, std::atol(ef));
   CK(hipMalloc(reinterpret_cast<void**>(&h->d_map), map_buffer_bytes(npx)));  // cells + their dense flags (common.hpp: map_flags)
@@ -388,36 +385,6 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
 int esvo_destroy(esvo_handle h) {
   if (!h) return ESVO_OK;
   hipSetDevice(h->device);
-#ifdef FUSE_STATS  // tools-only builds: per-tile phase cycles of the last tile_lists launch (a buffer of their own, allocated at esvo_create)
-  if (h->d_fuse_stats) {
-    hipDeviceSynchronize();
-    const size_t nt = (size_t)((h->W + FUSE_TILE - 1) / FUSE_TILE) * ((h->H + FUSE_TILE - 1) / FUSE_TILE);
-    std::vector<unsigned long long> st(nt * 8);
-    hipMemcpy(st.data(), h->d_fuse_stats, st.size() * 8, hipMemcpyDeviceToHost);
-    double sum[5] = {0, 0, 0, 0, 0};
-    unsigned long long tmin = ~0ull, tmax = 0;
-    std::vector<std::pair<unsigned long long, size_t>> tot;
-    for (size_t t = 0; t < nt; ++t) {
-      unsigned long long s5 = 0;
-      for (int i = 0; i < 5; ++i) { sum[i] += (double)st[t * 8 + i]; s5 += st[t * 8 + i]; }
-      tot.emplace_back(s5, t);
-      tmin = std::min(tmin, st[t * 8 + 7]);
-      tmax = std::max(tmax, st[t * 8 + 7] + s5);
-    }
-    std::sort(tot.begin(), tot.end());
-    fprintf(stderr, "[esvo] tile kernel: %zu tiles, span %llu cycles; mean cycles gather %.0f sort %.0f mark %.0f meta %.0f emit %.0f; wave life median %llu p99 %llu max %llu\n",
-            nt, tmax - tmin, sum[0] / nt, sum[1] / nt, sum[2] / nt, sum[3] / nt, sum[4] / nt, tot[nt / 2].first, tot[nt * 99 / 100].first, tot[nt - 1].first);
-    for (int k = 1; k <= 4; ++k) {
-      const size_t t = tot[nt - k].second;
-      fprintf(stderr, "[esvo]   slow tile %zu: P %llu C %llu start +%llu phases %llu %llu %llu %llu %llu\n", t, st[t * 8 + 5], st[t * 8 + 6], st[t * 8 + 7] - tmin,
-              st[t * 8], st[t * 8 + 1], st[t * 8 + 2], st[t * 8 + 3], st[t * 8 + 4]);
-    }
-    // start-time histogram: how many waves started in each tenth of the span
-    unsigned hist[10] = {0};
-    for (size_t t = 0; t < nt; ++t) hist[std::min<size_t>(9, (size_t)((st[t * 8 + 7] - tmin) * 10 / std::max<unsigned long long>(tmax - tmin, 1)))]++;
-    fprintf(stderr, "[esvo]   wave starts per tenth of the span: %u %u %u %u %u %u %u %u %u %u\n", hist[0], hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7], hist[8], hist[9]);
-  }
-#endif
   if (h->stream) hipStreamSynchronize(h->stream);
   if (h->stream_l) hipStreamSynchronize(h->stream_l);
   if (h->stream_l1) hipStreamSynchronize(h->stream_l1);
@@ -431,7 +398,7 @@ int esvo_destroy(esvo_handle h) {
                   h->d_win, h->d_frame_pose_T, h->d_fr_table, h->d_prop, h->d_tile_pts, h->d_tile_count, h->d_over_pts,
                   h->d_cell_count, h->d_cell_offset, h->d_cell_list, h->d_fuse_ctr, h->d_rec_ids, h->d_map, h->d_map2, h->d_owner_max, h->d_owner_min, h->d_exp_flags,
                   h->d_exp_prefix, h->d_export, h->d_export_cell, h->d_reg_ab, h->d_reg_cd, h->d_tsq[0], h->d_tsq[1], h->d_tsq_tcount, h->d_tsq_tlist, h->d_tsq_over, h->d_tsq_over_count, h->d_own_w, h->d_lkeep, h->d_codes, h->d_codes_send, h->d_codes_all, h->d_pts_send, h->d_pts_all, h->d_rank_kept,
-                  h->d_sel, h->d_evmap, h->d_lm_fvec0, h->d_lm_fnorm0, h->d_lm_meta, h->d_lm_order, h->d_lm_hist, h->d_clk, h->d_fuse_stats, h->d_ring_gidx, h->d_halo_viol, h->d_dn_flags, h->d_merge_a, h->d_merge_b, h->d_merge_plan, h->d_tsq_dup};
+                  h->d_sel, h->d_evmap, h->d_lm_fvec0, h->d_lm_fnorm0, h->d_lm_meta, h->d_lm_order, h->d_lm_hist, h->d_clk, h->d_ring_gidx, h->d_halo_viol, h->d_dn_flags, h->d_merge_a, h->d_merge_b, h->d_merge_plan, h->d_tsq_dup};
   for (void* p : ptrs) if (p) hipFree(p);
   if (h->h_counters) hipHostFree(h->h_counters);
   if (h->h_cnt_b) hipHostFree(h->h_cnt_b);

@@ -375,7 +375,6 @@ int run_fuse(esvo_context* h, int par, const double* T_world_obs, bool naive) {
   a.map = h->d_map; a.d_num_fusion = h->d_cnt_b + 3;
   a.n_touched = h->d_cnt_b + 6;
   a.naive = naive ? 1 : 0;
-  a.fuse_stats = h->d_fuse_stats;
   a.owner_max = h->prm.regularization ? h->d_owner_max : nullptr;
   a.owner_min = h->d_owner_min; a.n_reg_elems = h->prm.regularization ? h->d_cnt_b + 7 : nullptr;
   if (total > h->win_cap) FAIL(ESVO_ERR_CAPACITY, "window points exceed capacity");

@@ -381,7 +381,6 @@ struct FuseArgs {
   u32* owner_max;               // regulariser scratch reset together with the per-cell counters (or nullptr)
   u32* owner_min;
   u32* n_reg_elems;
-  u64* fuse_stats = nullptr;    // -DFUSE_STATS builds with ESVO_FUSE_STATS set: [n_tiles][8] phase cycles of tile_lists (tools only)
 };
 void launch_fuse(const FuseArgs& a, const DevParams& p, hipStream_t s);
 void launch_clean(MapCell* map, const DevParams& p, hipStream_t s);

@@ -228,7 +228,6 @@ struct esvo_context {
   u32 fuse_tile_cap = 1024;       // ESVO_FUSE_TILE_CAP (tests): entries per tile list
   u32 fuse_pmax_plus1 = 0;        // ESVO_FUSE_PMAX (tests) + 1: candidates up to which a tile takes the bit-row path
   u32* d_rec_ids = nullptr;       // record ids of cells whose list does not fit LDS (degenerate scenes)
-  u64* d_fuse_stats = nullptr;    // ESVO_FUSE_STATS (with a -DFUSE_STATS build; tools only): per-tile phase cycles, a buffer of their own
   u32 fuse_lds_cap = 0;           // ESVO_FUSE_LDS_CAP (tests): record ids per tile kept in LDS; 0 = the maximum
   MapCell* d_map = nullptr;
   MapCell* d_map2 = nullptr;

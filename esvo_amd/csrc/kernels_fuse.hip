@@ -22,7 +22,9 @@
 // clean/regularisation are reproduced through the ALIVE/GRID flag pair.
 #include <algorithm>
 #include <type_traits>
+#define DEV_HOOKS_FUSE_TU
 #include "common.hpp"
+#include "dev_hooks.hpp"
 #include "fdiv.hpp"
 #include "scan.hpp"
 
@@ -283,15 +285,6 @@ __global__ void __launch_bounds__(FT_CELLS, 8) tile_lists_kernel(FuseArgs a, Dev
   const bool in_band = in_img && crow >= p.cband_y0 && crow < p.cband_y1;
   const int cell = crow * p.W + ccol;
   const u64 lt_mask = (1ull << lane) - 1ull;
-#ifdef FUSE_STATS
-  u64 tph[6];
-  tph[0] = __builtin_readcyclecounter();
-#define FUSE_PH(i) tph[i] = __builtin_readcyclecounter()
-#define FUSE_PH_END() do { if (lane == 0 && a.fuse_stats) { u64* st = a.fuse_stats + (size_t)blockIdx.x * 8; for (int i = 0; i < 5; ++i) st[i] = tph[i + 1] - tph[i]; st[5] = P; st[6] = C; st[7] = tph[0]; } } while (0)
-#else
-#define FUSE_PH(i) do {} while (0)
-#define FUSE_PH_END() do {} while (0)
-#endif
   if (lane < FUSE_NB) s_hist[lane] = 0;
   // what fuse_reset cleared per cell: the regulariser's owner marks (reg_view re-creates them by atomics)
   if (in_img && a.owner_max) { a.owner_max[cell] = 0; a.owner_min[cell] = 0xffffffffu; }
@@ -376,7 +369,6 @@ __global__ void __launch_bounds__(FT_CELLS, 8) tile_lists_kernel(FuseArgs a, Dev
     }
   }
   __syncthreads();
-  FUSE_PH(1);
   u32 n = 0, ex = 0, total = 0;
   u32* s_bits = s_buf + 2 * FUSE_PMAX;
   const bool fast = P <= pmax;   // pmax <= FUSE_PMAX (smaller: tests)
@@ -438,7 +430,6 @@ __global__ void __launch_bounds__(FT_CELLS, 8) tile_lists_kernel(FuseArgs a, Dev
           __syncthreads();
         }
     }
-    FUSE_PH(2);
     for (u32 r = (u32)lane; r < P; r += ESVO_WAVE) {  // one bit per record
       const u32 rc = s_rc2[r];
       const u32 prow = rc >> 16, pcol = rc & 0xffffu;
@@ -479,7 +470,6 @@ __global__ void __launch_bounds__(FT_CELLS, 8) tile_lists_kernel(FuseArgs a, Dev
     __syncthreads();
     n = s_cnt[lane];
   }
-  FUSE_PH(3);
   {
     u32 tot;
     ex = block_excl_scan<1>(n, &tot, s_scan);
@@ -511,7 +501,6 @@ __global__ void __launch_bounds__(FT_CELLS, 8) tile_lists_kernel(FuseArgs a, Dev
   __syncthreads();
   if (n > 0) a.cell_list[((size_t)bk * FUSE_SLICES + slice) * a.slice_cap + s_hbase[bk] + rank] = (u32)cell;
   u32* gout = a.rec_ids + gbase;
-  FUSE_PH(4);
   if (fast) {  // ---- the cell's bit row, lowest rank first ----
     const u32* s_q2 = s_q;
     const u32* s_rc2 = s_rc;
@@ -528,8 +517,6 @@ __global__ void __launch_bounds__(FT_CELLS, 8) tile_lists_kernel(FuseArgs a, Dev
         gout[o++] = s_q2[r] * (u32)K + k;
       }
     }
-    FUSE_PH(5);
-    FUSE_PH_END();
     return;
   }
   // ---- dense path: runs of consecutive cells whose records fit the LDS buffer together ----
@@ -930,15 +917,18 @@ __global__ void __launch_bounds__(REG_TX * REG_TY, BACK_WAVES) reg_apply_kernel(
       }
     }
   };
+  DEV_REG_DECL  // (tools/reg_floor.py; empty in the product: dev_hooks.hpp)
   fetch_block(0);
   store_block(0);
   fetch_block(1);
   __syncthreads();
   for (int k = 0; k < n_blk; ++k) {
     const int buf = k & 1;
+    DEV_REG_BLOCK_BEGIN();
 #pragma unroll 1
     for (int r = 0; r < REG_RB; ++r) {
       const int gy = sr0 + k * REG_RB + r;
+      DEV_REG_ROW_BEGIN(nclose)
       if (scan && gy >= row - R && gy <= row + R) {
         // neighbour bits of the lane's window in this row
         const u64 w0 = s_vb[buf][r][0], w1 = s_vb[buf][r][1];
@@ -983,11 +973,14 @@ __global__ void __launch_bounds__(REG_TX * REG_TY, BACK_WAVES) reg_apply_kernel(
           }
         }
       }
+      DEV_REG_ROW_END(nclose);
     }
+    DEV_REG_BLOCK_END(lane, wv);
     if (k + 1 < n_blk) store_block(buf ^ 1);  // the block fetched one iteration ago
     fetch_block(k + 2);
     __syncthreads();
   }
+  DEV_REG_DONE(t, lane, nclose);
   if (slow) {  // plain path: the reference's two loops on the view in global memory
     for (int r = row - R; r <= row + R && r < p.H; ++r)
       for (int c2 = col - R; c2 <= col + R && c2 < p.W; ++c2) {

@@ -21,23 +21,14 @@
 // underflows to 0, the sum becomes exactly 0 and the reference resets s2 to Tdist_scale^2
 // after ~10^4 iterations; that provable outcome is taken directly.  Every
 // other case runs the literal loop.
+#define DEV_HOOKS_LM_TU
 #include "common.hpp"
+#include "dev_hooks.hpp"
 #include "fdiv.hpp"
 #include "lm_common.hpp"
 
 
 namespace esvo {
-
-#ifdef LM_STATS
-__device__ unsigned long long g_lm_dbg[8];
-#define LM_COUNT(i, cond) do { if (cond) atomicAdd(&g_lm_dbg[i], 1ull); } while (0)
-__device__ unsigned int g_lm_slot[3][1 << 18];  // per solver slot: evaluations, t-scale iterations, those of the first evaluation
-__device__ unsigned int g_lm_cur_slot_dummy;
-#define LM_SLOT(k, s, cond, v) do { if ((cond) && (s) < (1u << 18)) g_lm_slot[k][s] += (v); } while (0)
-#else
-#define LM_COUNT(i, cond) do {} while (0)
-#define LM_SLOT(k, s, cond, v) do {} while (0)
-#endif
 
 #define LM_ROWS 7
 #define LM_COLS 15
@@ -182,9 +173,7 @@ struct LmProblemT : LmPose<T_LDS> {
   int c;                   // patch column of the lane
   int rg;                  // row group of the lane (wide layout; 0 in the narrow one)
   int vy0, vy1;            // BAND kernels only: the rows of the observation pair that hold data (routed band mode)
-#ifdef LM_STATS
-  u32 dbg_slot;
-#endif
+  DEV_LM_PROBLEM_FIELDS
 };
 typedef LmProblemT<LM_T_LDS_DEFAULT> LmProblem;
 
@@ -268,9 +257,7 @@ __device__ bool lm_eval(const DevParams& p, const LmProblemT<T_LDS>& pr, LmCache
 #pragma unroll
   for (int y = 0; y < RL; ++y) el[y] = pr.c < LM_COLS && (!WIDE || 2 * pr.rg + y < LM_ROWS);
   const double nu = in_vgpr(p.td_nu);  // VGPR: otherwise re-loaded from the kernel arguments in every t-scale iteration
-  LM_COUNT(0, pr.c == 0);                                   // evaluations, per group
-  LM_SLOT(0, pr.dbg_slot, pr.c == 0, 1u);
-  LM_COUNT(1, __lane_id() == __ffsll(__ballot(1)) - 1);     // evaluations, per wave
+  DEV_LM_EVAL(pr);  // (tools: evaluations per group / per wave; empty in the product, dev_hooks.hpp)
   if constexpr (WIDE) asm volatile("" ::: "memory");  // the LDS reads below stay inside the loop (see LmProblem::cam)
   double prv[3], pl[3];
   {  // cam2World(p.camL, cx, cy, x): z * (Kinv [cx cy 1]^T) - Kinv_t with the ray computed once per match
@@ -357,9 +344,7 @@ __device__ bool lm_eval(const DevParams& p, const LmProblemT<T_LDS>& pr, LmCache
   }
   const int knz_lane = knz;
   knz = match_sum_int<WIDE>(knz);
-#ifdef LM_STATS
-  if (pr.c == 0 && pr.dbg_slot < (1u << 18) && g_lm_slot[0][pr.dbg_slot] == 1u) g_lm_slot[2][pr.dbg_slot] = 1000u * (u32)knz;
-#endif
+  DEV_LM_FIRST_EVAL_KNZ(pr, knz);
   minabs = match_min<WIDE>(minabs);
   const double scale2_0 = in_vgpr(p.td_scale2);
   double s2;
@@ -381,7 +366,7 @@ __device__ bool lm_eval(const DevParams& p, const LmProblemT<T_LDS>& pr, LmCache
   const bool tight = match_sum_int<WIDE>((r2_tight && nu_mid) ? 0 : 1) == 0;
   if ((double)knz * (nu + 1) / (double)N <= 0.94 && minabs >= 1e-6) {
     s2 = scale2_0;  // provable outcome of the uncapped loop (header comment)
-    LM_COUNT(4, pr.c == 0);
+    DEV_LM_SHORTCUT(pr);
   } else {
     // DepthProblem.cpp:96-124: s1 <- s2 until |s2 - s1| / s1 <= 5 %.  Every quotient below is the IEEE quotient
     // (fdiv.hpp): r^2 / s1 and the convergence test share the divisor s1, sum / N has a constant divisor, and
@@ -397,10 +382,7 @@ __device__ bool lm_eval(const DevParams& p, const LmProblemT<T_LDS>& pr, LmCache
       // sign bit included in the exponent field: a negative or NaN s1 fails the range test
       while ((unsigned)(((__double2hiint(s1) >> 20) & 0xfff) - 923) <= 200u) {
         if constexpr (COUNT) ++iters;
-        LM_COUNT(2, pr.c == 0);                                 // t-scale iterations, per group
-        LM_SLOT(1, pr.dbg_slot, pr.c == 0, 1u);
-        LM_SLOT(2, pr.dbg_slot, pr.c == 0 && g_lm_slot[0][pr.dbg_slot < (1u << 18) ? pr.dbg_slot : 0] == 1u, 1u);
-        LM_COUNT(3, __lane_id() == __ffsll(__ballot(1)) - 1);   // t-scale iterations, per wave
+        DEV_LM_SCALE_ITER(pr);  // (tools: t-scale iterations per group / per wave)
         Recip rs1;
         rs1.b = s1;
         rs1.y = recip_refined(s1);
@@ -422,10 +404,7 @@ __device__ bool lm_eval(const DevParams& p, const LmProblemT<T_LDS>& pr, LmCache
     }
     while (!done) {
       if constexpr (COUNT) ++iters;
-      LM_COUNT(2, pr.c == 0);
-      LM_SLOT(1, pr.dbg_slot, pr.c == 0, 1u);
-      LM_SLOT(2, pr.dbg_slot, pr.c == 0 && g_lm_slot[0][pr.dbg_slot < (1u << 18) ? pr.dbg_slot : 0] == 1u, 1u);
-      LM_COUNT(3, __lane_id() == __ffsll(__ballot(1)) - 1);
+      DEV_LM_SCALE_ITER(pr);
       double t[RL];
       const Recip rs1 = make_recip(s1);
       const int e_s1 = (__double2hiint(s1) >> 20) & 0x7ff;
@@ -610,9 +589,7 @@ __global__ void __launch_bounds__(PAIR ? 128 : LM_BLOCK, WIDE ? LM_WIDE_WAVES : 
   pr.rg = rg;
   pr.vy0 = a.vy0; pr.vy1 = a.vy1;
   bool viol = false;
-#ifdef LM_STATS
-  pr.dbg_slot = active ? s : 0xffffffffu;
-#endif
+  DEV_LM_SET_SLOT(pr, active ? s : 0xffffffffu);
   {  // DepthProblem::setProblem, DepthProblem.cpp:17-32
     double Tlw[16], Tlv[16];
     rigid_inverse(a.T_world_obs, Tlw);
@@ -681,9 +658,7 @@ __global__ void __launch_bounds__(PAIR ? 128 : LM_BLOCK, WIDE ? LM_WIDE_WAVES : 
     if (h == 0.) h = sqrt_eps;
     xe = x + h;
   }
-#ifdef LM_STATS
-  double dbg_xjac = __longlong_as_double(0x7ff8000000000000ll);
-#endif
+  DEV_LM_JAC_DECL
   while (true) {
     if (need_step) {  // determine the LM parameter and the trial point (minimizeOneStep, inner loop head)
       const double pstep = lm_lmpar2(r, diag, qtf, delta, par);
@@ -736,11 +711,7 @@ __global__ void __launch_bounds__(PAIR ? 128 : LM_BLOCK, WIDE ? LM_WIDE_WAVES : 
       par = 0.;
       iter = 1;
     } else if (phase == 1) {
-#ifdef LM_STATS
-      LM_COUNT(5, pr.c == 0 && active);
-      LM_COUNT(6, pr.c == 0 && active && x == dbg_xjac);
-      dbg_xjac = x;
-#endif
+      DEV_LM_JAC_PASS(pr, active, x);
       // NumericalDiff<Forward>::df: the reference evaluates F(x) again (val1) and F(x + h); F is a
       // pure function and fvec already holds F(x) at the current x, so val1 == fvec bit for bit and
       // only F(x + h) is computed.  nfev still advances by 2 (it drives the maxfev test).
@@ -877,12 +848,7 @@ __global__ void __launch_bounds__(PAIR ? 128 : LM_BLOCK, WIDE ? LM_WIDE_WAVES : 
     o.x[0] = pr.cx;
     o.x[1] = pr.cy;
     cam2World(p.camL, pr.cx, pr.cy, x, o.p_cam);                 // :119
-#ifdef ESVO_PERTURB_ONE_ULP
-    // libesvo_hip_perturbed.so only (esvo_amd/lib.py build(perturbed=True)): the depth of every eighth solver slot's point one
-    // unit in the last place off (p_cam is what the fusion propagates) -- the deliberate defect tests/test_gpu_bench_parity.py
-    // uses to show that bench.py's parity.oracle_equal has teeth
-    if ((s & 7u) == 7u) o.p_cam[2] = __longlong_as_double(__double_as_longlong(o.p_cam[2]) ^ 1ll);
-#endif
+    DEV_PERTURB_POINT(o, s);  // (empty in the product: dev_hooks.hpp)
     o.inv_depth = x;                                             // update_studentT, new-point branch
 
     o.scale2 = L2 ? 0.0 : variance * (p.td_nu - 2) / p.td_nu;    // :125 (l2: the Gaussian update leaves scaleSquared_ / nu_
@@ -988,9 +954,7 @@ __global__ void __launch_bounds__(LM_BLOCK, LM_WAVES) lm_refine_persist_kernel(L
 #pragma unroll
       for (int r3 = 0; r3 < 3; ++r3)
         pr.ray[r3] = (p.camL.Kinv[r3 * 3 + 0] * pr.cx + p.camL.Kinv[r3 * 3 + 1] * pr.cy) + p.camL.Kinv[r3 * 3 + 2];
-#ifdef LM_STATS
-      pr.dbg_slot = s;
-#endif
+      DEV_LM_SET_SLOT(pr, s);
       {  // DepthProblem::setProblem, DepthProblem.cpp:17-32: T_left_virtual = T_world_obs^-1 T_world_virtual, element c by lane c < 12
          // (mat4_mul's association: ((a0 b0 + a1 b1) + a2 b2) + a3 b3)
         double Tlw[16];
@@ -1145,9 +1109,7 @@ __global__ void __launch_bounds__(LM_BLOCK, LM_WAVES) lm_refine_persist_kernel(L
           o.x[0] = pr.cx;
           o.x[1] = pr.cy;
           cam2World(p.camL, pr.cx, pr.cy, x, o.p_cam);                 // :119
-#ifdef ESVO_PERTURB_ONE_ULP
-          if ((s & 7u) == 7u) o.p_cam[2] = __longlong_as_double(__double_as_longlong(o.p_cam[2]) ^ 1ll);  // (see lm_refine_kernel)
-#endif
+          DEV_PERTURB_POINT(o, s);
           o.inv_depth = x;
           o.scale2 = L2 ? 0.0 : variance * (p.td_nu - 2) / p.td_nu;    // :125
           o.nu = L2 ? 0.0 : p.td_nu;
@@ -1183,14 +1145,6 @@ __global__ void __launch_bounds__(LM_BLOCK, LM_WAVES) lm_refine_persist_kernel(L
   }
 }
 
-#ifdef LM_STATS
-extern "C" void esvo_debug_lm_counters(unsigned long long out[8]) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lm_dbg), 64); }
-extern "C" void esvo_debug_lm_slots(unsigned int* out, int clear) {  // out[3][1 << 18]
-  hipDeviceSynchronize();
-  hipMemcpyFromSymbol(out, HIP_SYMBOL(esvo::g_lm_slot), sizeof(unsigned int) * 3 * (1 << 18));
-  if (clear) { void* p = nullptr; hipGetSymbolAddress(&p, HIP_SYMBOL(esvo::g_lm_slot)); hipMemset(p, 0, sizeof(unsigned int) * 3 * (1 << 18)); }
-}
-#endif
 // counting sort of the slots by the cost of F(x0), most expensive first: offsets from the (complete) histogram, computed
 // per block in LDS; the order inside a bin is whatever the atomics make it (it does not matter: see above)
 __global__ void __launch_bounds__(256) lm_order_kernel(const u32* __restrict__ n_matches, u32 max_matches, LmSplit sp) {

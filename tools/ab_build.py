@@ -35,6 +35,7 @@ def main():
         src = os.path.join(d, "esvo_amd", "csrc")   # common.hpp includes ../../include/esvo_hip.h
         shutil.copytree(csrc, src, ignore=shutil.ignore_patterns("*.so"))
         shutil.copytree(os.path.join(ROOT, "include"), os.path.join(d, "include"))
+        shutil.copytree(os.path.join(ROOT, "tools", "dev_hooks"), os.path.join(d, "tools", "dev_hooks"))   # (dev_hooks.hpp includes ../../tools/dev_hooks/ under -D flags)
         if files == ["ALL"]:
             for sub in ("esvo_amd/csrc", "include"):
                 shutil.rmtree(os.path.join(d, sub))
