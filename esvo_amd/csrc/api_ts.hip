@@ -298,6 +298,8 @@ int push_routed(esvo_context* h, int cam, size_t n, GetEv get) {
     if ((int)e.x < W && (int)e.y < H) keep = cam == 0 ? keep_px[(size_t)e.y * W + e.x] != 0 : ((int)e.y >= sy0 && (int)e.y < sy1);
     if (!keep) continue;
     kept[m] = e;
+    kept[m].polarity = e.polarity ? 1 : 0;   // (bit 7 of the byte is the library's: EV_LATE)
+    kept[m]._pad[0] = kept[m]._pad[1] = kept[m]._pad[2] = 0;
     if (cam == 0) { h->h_route_gidx[m] = (u32)(g0 + i); kept_gl.push_back(g0 + i); kept_own.push_back((keep_px[(size_t)e.y * W + e.x] >> 1) & 1); }
     kept_ts.push_back(t);
     ++m;
@@ -325,8 +327,12 @@ int push_routed(esvo_context* h, int cam, size_t n, GetEv get) {
   h->ring_reserved[cam] = h->ring_next[cam];
   if (cam == 0) {
     for (size_t i = 0; i < m; ++i) { h->kept_g.push_back(kept_gl[i]); h->own_before.push_back(h->own_total); h->own_total += kept_own[i]; }
-    for (size_t i = 0; i < n; ++i) h->glob_ts.push_back(all_ts[i]);
-    while (h->glob_ts.size() > h->ring_cap) { h->glob_ts.pop_front(); h->glob_base++; }
+    h->glob_ts.insert(h->glob_ts.end(), all_ts.begin(), all_ts.end());   // (one splice: the tick thread's selection takes this lock too)
+    if (h->glob_ts.size() > h->ring_cap) {
+      const size_t drop = h->glob_ts.size() - h->ring_cap;
+      h->glob_ts.erase(h->glob_ts.begin(), h->glob_ts.begin() + (std::ptrdiff_t)drop);
+      h->glob_base += drop;
+    }
   }
   while (tsq.size() > h->ring_cap) {
     tsq.pop_front();
@@ -416,6 +422,10 @@ int push_unsorted(esvo_context* h, int cam, size_t n, GetEv get) {
     ring_next = h->ring_next[cam];
     if (h->ring_next[cam] + n - h->scattered[cam] > h->ring_cap) FAIL(ESVO_ERR_CAPACITY, "event ring full: render (scatter) before staging more events");
     if (K > ((size_t)1 << 22)) FAIL(ESVO_ERR_CAPACITY, "packet reaches back over more than 4 M staged events");
+    // the merged tail (K staged + n new events) is written back into the ring: positions j and j + ring_cap would share a slot
+    if (K + n > h->ring_cap)
+      FAIL(ESVO_ERR_CAPACITY, "an out-of-order packet reaches back over more staged events than the event ring holds with it (a clock jump "
+                              "or a looped bag: the reference resets its mapper here, esvo_Mapping.cpp:680-687 -- esvo_reset and re-stage)");
     ts_tail.assign(tsq.begin() + pos_rel, tsq.end());
     h->ring_reserved[cam] = ring_next + n;
   }
@@ -541,8 +551,11 @@ static int push_events_impl(esvo_handle h, int cam, const esvo_event_t* ev, size
   { int rc = push_drain(h, cam, tk); if (rc) return rc; }
   const size_t first = (size_t)std::min<u64>(n, h->ring_cap - tk.slot);
   PUSH_HIPCHK(hipMemcpyAsync(h->d_ring[cam] + tk.slot, ev, sizeof(esvo_event_t) * first, hipMemcpyHostToDevice, h->stream_i));
-  if (first < n)
+  launch_ts_normalise(h->d_ring[cam] + tk.slot, first, h->stream_i);  // the caller's polarity byte to 0 / 1 (bit 7 is EV_LATE: the library's)
+  if (first < n) {
     PUSH_HIPCHK(hipMemcpyAsync(h->d_ring[cam], ev + first, sizeof(esvo_event_t) * (n - first), hipMemcpyHostToDevice, h->stream_i));
+    launch_ts_normalise(h->d_ring[cam], n - first, h->stream_i);
+  }
   if (wait) {
     PUSH_HIPCHK(hipStreamSynchronize(h->stream_i));  // `ev` is borrowed for the duration of the call only; later work sees the copy
     push_commit(h, cam, n, stamp);
@@ -587,7 +600,7 @@ int esvo_ts_push_event_array(esvo_handle h, int cam, const uint8_t* msg, size_t 
     e.y = (uint16_t)(r[2] | (r[3] << 8));
     e.sec = (u32)r[4] | ((u32)r[5] << 8) | ((u32)r[6] << 16) | ((u32)r[7] << 24);
     e.nsec = (u32)r[8] | ((u32)r[9] << 8) | ((u32)r[10] << 16) | ((u32)r[11] << 24);
-    e.polarity = r[12];
+    e.polarity = r[12] ? 1 : 0;   // (bit 7 of the byte is the library's: EV_LATE, common.hpp)
     return e;
   };
   {  // in order (as esvo_ts_push_events): the fast path; else sorted in on the host

@@ -184,6 +184,7 @@ __host__ __device__ inline bool ev_is_late(unsigned w) { return (w & 0xfeu) == E
 // kernels_ts.hip
 void launch_ts_merge(const esvo_event_t* staged, const esvo_event_t* packet, const u32* plan, size_t n, esvo_event_t* ring, u64 first_slot,
                      u64 ring_cap, hipStream_t s);
+void launch_ts_normalise(esvo_event_t* ring, size_t n, hipStream_t s);
 void launch_ts_unpack_wire(const uint8_t* wire, size_t n, esvo_event_t* ring, u64 first_slot, u64 ring_cap, hipStream_t s);
 void launch_ts_scatter(const esvo_event_t* d_ev, size_t n, u64* d_sae, int W, int H, hipStream_t s);
 // (row0, row1: the rectified rows to render -- whole tiles of TS_TILE_ROWS; a routed band handle renders its band + halo only)

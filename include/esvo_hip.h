@@ -454,8 +454,13 @@ int esvo_shard_set_band(esvo_handle h, int row_begin, int row_end, int shard, in
  *       the second exchange), and once that count is non-zero every rank refuses its next tick with ESVO_ERR_HALO --
  *       never a silently different result.  Raise ts_halo_rows (DSEC / DAVIS hand-held sequences move < 10 rows in the
  *       10 ms a tick looks back) or fall back to ESVO_ROUTE_BROADCAST.
- *     Not available with Denoising (its mask needs the whole event slice), per-pixel event queues, FORWARD mode,
- *     up-down stereo: ESVO_ERR_UNSUPPORTED.
+ *     - Denoising (ABI 7; esvo_Mapping.cpp:1046-1072): a rank decides the mask's verdict for the selected events whose RAW row lies
+ *       in its band (its ring keeps one more raw row on either side), the verdicts travel as one bit per selected event
+ *       (esvo_shard_tick_phase(h, 0) returns ESVO_AGAIN with that block due), and phase 0's second part matches the kept sequence
+ *       of the unsharded tick.
+ *     - a push that fails (ESVO_ERR_CAPACITY: event ring full) has consumed nothing -- not the events, not their stamps in the
+ *       global sequence: render and hand the SAME packet in again, or the rank's global indices part from its peers'.
+ *     Not available with per-pixel event queues, FORWARD mode, up-down stereo: ESVO_ERR_UNSUPPORTED.
  *   ESVO_ROUTE_BROADCAST (A/B switch; exact whatever the motion): every rank stages ALL events and renders the full Time
  *     Surfaces; the per-event work is the slots w with w % n_shards == shard of the tick's thread-stride order.
  * ts_halo_rows < 0: the default (24). */
