@@ -259,6 +259,34 @@ def test_wire_ingest_equals_struct_ingest(upenn_rig, upenn_stream):
             lib.Esvo(p, upenn_rig).ts_push_event_array(0, bad)
 
 
+def test_caller_polarity_bytes_never_read_as_the_late_flag(upenn_rig, upenn_stream):
+    """Bit 7 of an event's polarity byte is the library's own mark for events that arrived out of order (the scatter skips them, as
+    TimeSurface::eventsCallback never inserts them).  A caller's byte -- any non-zero value means ON -- must not be read as it: every
+    ingest path (struct, pinned async, wire records, routed) normalises polarity to 0 / 1."""
+    from esvo_amd import abi, lib
+    p, _ = params.make_params(params.PRESETS["mvstereo_upenn"], upenn_rig)
+    t = upenn_stream.t0_ns + int(0.08e9)
+    ev = upenn_stream.slice(0, upenn_stream.t0_ns, t).copy()
+    odd = ev.copy()
+    odd["polarity"] = np.where(np.arange(len(ev)) % 2, 0x81, 0x80).astype(np.uint8)   # what ev_is_late would match
+    plain = ev.copy()
+    plain["polarity"] = 1
+    ref = lib.Esvo(p, upenn_rig)
+    ref.ts_push_events(0, plain)
+    want = ref.ts_render(0, t)
+    assert want.any()
+    a = lib.Esvo(p, upenn_rig)
+    a.ts_push_events(0, odd)
+    assert np.array_equal(a.ts_render(0, t), want)
+    b = lib.Esvo(p, upenn_rig)
+    b.ts_push_event_array(0, abi.serialize_event_array(odd, upenn_rig.width, upenn_rig.height))
+    assert np.array_equal(b.ts_render(0, t), want)
+    c = lib.Esvo(p, upenn_rig)
+    c.set_band(0, upenn_rig.height, 0, 1, routing=None)
+    c.close()
+    assert a.stats().late_events[0] == 0 and b.stats().late_events[0] == 0
+
+
 def test_committed_map_lags_one_tick(dsec_rig, dsec_stream):
     """esvo_map_get_committed after esvo_map_tick(k) returns the DepthMap of tick k-1 (and its stamp) without completing
     tick k -- the call a node uses to publish every tick and still overlap the stages; it must equal what the eager
