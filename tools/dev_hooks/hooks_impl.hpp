@@ -5,7 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #ifdef LM_STATS
-// in-kernel counters of lm_refine_kernel (tools/lm_stats.py, lm_divergence.py, lm_attribution.py ...)
+// in-kernel counters of lm_refine_kernel (tools/lm_stats.py, tools/lm_attribution.py)
 #ifdef DEV_HOOKS_LM_TU
 __device__ unsigned long long g_lm_dbg[8];
 __device__ unsigned int g_lm_slot[3][1 << 18];  // per solver slot: evaluations, t-scale iterations, those of the first evaluation
