@@ -252,16 +252,11 @@ def tick_share(workload, device, world=8, rounds=20, warm_rounds=3, events_cap=0
     base = dev.stats()
     cb = dev.comm_stats()
     base_comm = (int(cb.gathers), int(cb.bytes_sent), int(cb.points_gathered), int(cb.rounds), int(cb.host_wait_us))
-    import gc
-    gc_was = gc.isenabled()
-    gc.disable()   # (a full collection of this process' heap -- the recorded blocks, the tick tables -- takes ~7 ms: one round in thirty)
     t0 = time.perf_counter()
     run_rounds(warm_rounds, warm_rounds + rounds)
     dev.comm_flush()
     dev.synchronize()
     dt = time.perf_counter() - t0
-    if gc_was:
-        gc.enable()
     host_s, cb_s = list(state["host_s"]), state["cb_s"]
     series = np.diff(np.array([t0] + state["marks"])) * 1e3   # host time stamps at the round ends (the host is paced by the device)
     st = dev.stats()

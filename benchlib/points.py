@@ -122,7 +122,10 @@ def _points(device, which):
     out = {}
 
     def throughput(name, n, check=False, timed_ingest=False, pinned=False):
-        rig, stream, p, ticks = make_workload(name, n + 3)
+        # (40 ticks of stream whatever n is: the noise events are drawn over the stream's whole duration, so streams of different
+        #  lengths are different realisations, and this leg's figure must not depend on which leg of the process asked first --
+        #  the 346x260 point read 0.36 or 0.89 ms per tick depending on that: profiles/r06_extras_note.txt)
+        rig, stream, p, ticks = make_workload(name, max(n + 3, 40) if name != "hd1280x720" else n + 3)
         ticks = ticks[: n + 3]
         dev = lib.Esvo(p, rig, device=device)
         pins = []
@@ -195,7 +198,8 @@ def _points(device, which):
         return res
 
     def latency(name, n_events, n):
-        rig, stream, p, ticks = make_workload(name, n + 6, events_cap=n_events)
+        rig, stream, p, ticks = make_workload(name, max(n + 6, 40), events_cap=n_events)
+        ticks = ticks[: n + 6]
         dev = lib.Esvo(p, rig, device=device)
         dev.ts_push_events(0, stream.ev_left)
         dev.ts_push_events(1, stream.ev_right)
