@@ -396,7 +396,8 @@ int push_unsorted(esvo_context* h, int cam, size_t n, GetEv get) {
     e.polarity = e.polarity ? 1 : 0;
     e._pad[0] = e._pad[1] = e._pad[2] = 0;
     if (t[i] < newest) {
-      e.polarity |= (uint8_t)EV_LATE;
+      e.polarity |= (uint8_t)EV_LATE;   // the library's mark: the byte and the padding magic together (common.hpp, ev_is_late)
+      e._pad[0] = (uint8_t)(EV_LATE_PAD & 0xffu); e._pad[1] = (uint8_t)((EV_LATE_PAD >> 8) & 0xffu); e._pad[2] = (uint8_t)((EV_LATE_PAD >> 16) & 0xffu);
       ++n_late;
       if (h->tsq_len && have_newest_ev) dups.push_back(newest_ev);
     } else {
@@ -551,11 +552,8 @@ static int push_events_impl(esvo_handle h, int cam, const esvo_event_t* ev, size
   { int rc = push_drain(h, cam, tk); if (rc) return rc; }
   const size_t first = (size_t)std::min<u64>(n, h->ring_cap - tk.slot);
   PUSH_HIPCHK(hipMemcpyAsync(h->d_ring[cam] + tk.slot, ev, sizeof(esvo_event_t) * first, hipMemcpyHostToDevice, h->stream_i));
-  launch_ts_normalise(h->d_ring[cam] + tk.slot, first, h->stream_i);  // the caller's polarity byte to 0 / 1 (bit 7 is EV_LATE: the library's)
-  if (first < n) {
+  if (first < n)
     PUSH_HIPCHK(hipMemcpyAsync(h->d_ring[cam], ev + first, sizeof(esvo_event_t) * (n - first), hipMemcpyHostToDevice, h->stream_i));
-    launch_ts_normalise(h->d_ring[cam], n - first, h->stream_i);
-  }
   if (wait) {
     PUSH_HIPCHK(hipStreamSynchronize(h->stream_i));  // `ev` is borrowed for the duration of the call only; later work sees the copy
     push_commit(h, cam, n, stamp);

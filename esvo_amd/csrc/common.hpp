@@ -178,13 +178,17 @@ void launch_upload_words(const void* pinned_src, void* d_dst, size_t bytes, hipS
 // An event that arrived OUT OF ORDER (its stamp below the newest stamp staged before it) keeps its sorted place in the ring -- the
 // mapper's queue is insertion-sorted, esvo_Mapping.cpp:692-702 -- but never reaches the Time Surface: TimeSurface::eventsCallback
 // inserts events_.back(), the newest event, in its stead (TimeSurface.cpp:412-422).  The library marks such
-// an event in its own copy: polarity byte 0x80 | polarity (a caller's byte is 0 or 1).
-constexpr unsigned EV_LATE = 0x80u;
-__host__ __device__ inline bool ev_is_late(unsigned w) { return (w & 0xfeu) == EV_LATE; }
+// an event in its own copy through the WHOLE last word of the record -- polarity byte 0x80 | polarity AND the three padding bytes
+// set to a magic -- so that no caller byte can be read as the mark: a caller's polarity byte means ON whenever it is non-zero (0x80
+// included), its padding is whatever the compiler left there, and the records of the in-order paths are copied as they are (no
+// sanitising pass on the ingest stream: one was measured at -8 % on the PCIe-inclusive rate).  A caller's record is misread only
+// if its polarity byte is 0x80 / 0x81 and its three padding bytes equal the magic.
+constexpr unsigned EV_LATE = 0x80u;                 // in the polarity byte
+constexpr unsigned EV_LATE_PAD = 0x5ac3e7u;         // in _pad[0..2] (bits 8..31 of the record's last word)
+__host__ __device__ inline bool ev_is_late(unsigned w) { return (w & 0xfffffffeu) == ((EV_LATE_PAD << 8) | EV_LATE); }
 // kernels_ts.hip
 void launch_ts_merge(const esvo_event_t* staged, const esvo_event_t* packet, const u32* plan, size_t n, esvo_event_t* ring, u64 first_slot,
                      u64 ring_cap, hipStream_t s);
-void launch_ts_normalise(esvo_event_t* ring, size_t n, hipStream_t s);
 void launch_ts_unpack_wire(const uint8_t* wire, size_t n, esvo_event_t* ring, u64 first_slot, u64 ring_cap, hipStream_t s);
 void launch_ts_scatter(const esvo_event_t* d_ev, size_t n, u64* d_sae, int W, int H, hipStream_t s);
 // (row0, row1: the rectified rows to render -- whole tiles of TS_TILE_ROWS; a routed band handle renders its band + halo only)

@@ -704,19 +704,6 @@ __global__ void __launch_bounds__(256) ts_unpack_wire_kernel(const uint8_t* __re
   e._pad[0] = e._pad[1] = e._pad[2] = 0;
   ring[(first_slot + i) % ring_cap] = e;
 }
-// esvo_event_t records copied into the ring as the caller laid them out (the in-memory dvs_msgs::Event: a bool and three padding
-// bytes in the last word): polarity to 0 / 1, padding to 0 -- bit 7 of the polarity byte is the library's own (EV_LATE, common.hpp),
-// no caller byte may be read as it
-__global__ void __launch_bounds__(256) ts_normalise_kernel(u32* __restrict__ ring_words, size_t n) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  u32* w = ring_words + 4 * i + 3;
-  *w = (*w & 0xffu) ? 1u : 0u;
-}
-void launch_ts_normalise(esvo_event_t* ring, size_t n, hipStream_t s) {
-  if (n == 0) return;
-  hipLaunchKernelGGL(ts_normalise_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, reinterpret_cast<u32*>(ring), n);
-}
 void launch_ts_unpack_wire(const uint8_t* wire, size_t n, esvo_event_t* ring, u64 first_slot, u64 ring_cap, hipStream_t s) {
   if (n == 0) return;
   hipLaunchKernelGGL(ts_unpack_wire_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, wire, n, ring, first_slot, ring_cap);

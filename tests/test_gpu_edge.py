@@ -260,9 +260,9 @@ def test_wire_ingest_equals_struct_ingest(upenn_rig, upenn_stream):
 
 
 def test_caller_polarity_bytes_never_read_as_the_late_flag(upenn_rig, upenn_stream):
-    """Bit 7 of an event's polarity byte is the library's own mark for events that arrived out of order (the scatter skips them, as
-    TimeSurface::eventsCallback never inserts them).  A caller's byte -- any non-zero value means ON -- must not be read as it: every
-    ingest path (struct, pinned async, wire records, routed) normalises polarity to 0 / 1."""
+    """The library marks events that arrived out of order in its own copy of the record (the scatter skips them, as
+    TimeSurface::eventsCallback never inserts them): polarity byte 0x80 | polarity AND a magic in the three padding bytes.  A
+    caller's byte -- any non-zero value means ON, 0x80 and 0x81 included -- must not be read as that mark on any ingest path."""
     from esvo_amd import abi, lib
     p, _ = params.make_params(params.PRESETS["mvstereo_upenn"], upenn_rig)
     t = upenn_stream.t0_ns + int(0.08e9)
@@ -281,9 +281,6 @@ def test_caller_polarity_bytes_never_read_as_the_late_flag(upenn_rig, upenn_stre
     b = lib.Esvo(p, upenn_rig)
     b.ts_push_event_array(0, abi.serialize_event_array(odd, upenn_rig.width, upenn_rig.height))
     assert np.array_equal(b.ts_render(0, t), want)
-    c = lib.Esvo(p, upenn_rig)
-    c.set_band(0, upenn_rig.height, 0, 1, routing=None)
-    c.close()
     assert a.stats().late_events[0] == 0 and b.stats().late_events[0] == 0
 
 
