@@ -535,8 +535,8 @@ int esvo_comm_tick_resident(esvo_handle h, uint64_t t_ns, const double T_world_c
  * out a whole round earlier; the front stage of round j + 1 follows on the front and LM streams while exchange j travels.
  * The block length of a gather is the largest frame of the last four rounds + 25 % (the buffers' capacity until counts have
  * been seen; a frame that does not fit is gathered again with grown blocks, identically on every rank).  On a tick another
- * rank maps the call scatters that tick's events into this rank's SAE on a side stream, so an own render only has its own
- * tick's events left.  esvo_comm_flush completes a partial round and everything in flight. */
+ * rank maps the call scatters that tick's events into this rank's SAE on the front stream (idle on such a tick), so an own
+ * render only has its own tick's events left.  esvo_comm_flush completes a partial round and everything in flight. */
 int esvo_comm_flush(esvo_handle h);
 typedef struct esvo_comm_stats_t {
   uint64_t rounds;             /* rounds collected (frames pushed) */
