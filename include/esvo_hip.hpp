@@ -315,7 +315,8 @@ struct Registration { double R[9]; double t[3]; double rms = 0; int iterations =
 // It stops after max_iterations, when an accepted step is shorter than 1e-6, or when no damping up to 1e5 x the current one
 // yields an acceptable step (the state in which Eigen's trust radius has shrunk below xtol |x|: its status 2 / 3, on which
 // the reference's loop breaks, :181-182).  Stated deviation (DESIGN.md "Deviations"): the step is Levenberg's diagonal
-// damping, not MINPACK's lmpar trust-region solve, so single steps differ from Eigen's while the fixed point is the same.
+// damping, not MINPACK's lmpar trust-region solve, so single steps differ from Eigen's while the fixed point is the same
+// (bounded against the reference's loop on recorded cases: tests/test_track_normal.py, tests/golden/ref_track_solve.npz).
 // `normal_eq(it, k, R[k][9], t[k][3], H[k][36], b[k][6], cost[k], &n)` evaluates H = J^T J, b = J^T f, cost = |f|^2 at k poses
 // (1 <= k <= 3) on the batch of outer iteration `it`: esvo_track_normal_equations_batch on the device, or the CPU oracle's
 // restatement in the tests.  same_batch: the batch does not depend on `it`, so the evaluation at an accepted trial pose IS

@@ -60,6 +60,9 @@ def load():
         lib.ref_tracker_residuals.argtypes = [vp, sz, sz, vp, vp, vp]
         lib.ref_tracker_jacobian.restype = sz
         lib.ref_tracker_jacobian.argtypes = [vp, sz, sz, vp]
+        if hasattr(lib, "ref_tracker_solve"):
+            lib.ref_tracker_solve.restype = i32
+            lib.ref_tracker_solve.argtypes = [vp, sz, sz, vp, vp, vp, vp, vp]
     lib.ref_mapper_create.restype = vp
     lib.ref_mapper_create.argtypes = [C.c_char_p, vp, vp, vp]
     lib.ref_mapper_destroy.argtypes = [vp]
@@ -313,6 +316,16 @@ class RefTracker:
         out = np.empty(6 * count, np.float64)
         n = self.lib.ref_tracker_jacobian(self.h, int(offset), int(count), _p(out))
         return out[:6 * n].reshape(6, n).T
+
+    def solve(self, batch_size=300, max_iteration=10):
+        """RegProblemSolverLM::solve_analytical's loop (RegProblemSolverLM.cpp:148-178) from the pose of the last set_problem:
+        (R, t, outer iterations, functor evaluations, last LM status) -- R, t = T_ref_left after the loop"""
+        R, t = np.empty(9), np.empty(3)
+        it, nfev, st = C.c_size_t(0), C.c_size_t(0), C.c_int(0)
+        rc = self.lib.ref_tracker_solve(self.h, int(batch_size), int(max_iteration), _p(R), _p(t), C.byref(it), C.byref(nfev), C.byref(st))
+        if rc != 0:
+            raise RuntimeError("ref_tracker_solve: ImproperInputParameters")
+        return R.reshape(3, 3), t, it.value, nfev.value, st.value
 
 
 _LIB_TS = os.path.join(_HERE, "_ref", "libesvo_ref_ts.so")

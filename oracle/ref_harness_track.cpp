@@ -13,6 +13,7 @@
 // getTimeSurfaceNegative (TimeSurfaceObservation.h:118-135) reproduce the negative image exactly, the two derivative
 // images are written into dTS_negative_du/dv_left_ directly.
 #include <esvo_core/core/RegProblemLM.h>
+#include <unsupported/Eigen/NonLinearOptimization>
 
 #include <cstdlib>
 #include <cstring>
@@ -123,5 +124,44 @@ size_t ref_tracker_jacobian(ref_tracker* h, size_t offset, size_t count, double*
   for (int j = 0; j < 6; ++j)
     for (int i = 0; i < J.rows(); ++i) fjac_out[(size_t)j * J.rows() + i] = J(i, j);
   return (size_t)J.rows();
+}
+// The reference's tracker loop, RegProblemSolverLM::solve_analytical (RegProblemSolverLM.cpp:148-178, 212): the solver CLASS is not
+// compiled here (it drags the visualisation publishers in), so its twenty lines are spelled out again around the reference's own
+// functor -- LevenbergMarquardt with ftol = xtol = 1e-3 and maxfev = 8 MAX_ITERATION, and per outer iteration: the next
+// batch (setStochasticSampling), x = 0, minimizeInit, ONE minimizeOneStep, addMotionUpdate(x); it leaves on status 2 / 3.
+// The LM class is ref_shim's restatement of MINPACK lmder / lmpar (unsupported/Eigen/NonLinearOptimization there), i.e. Eigen's
+// trust-region semantics, not the library.  Call after ref_tracker_set_problem; batch_size / max_iteration are the yaml's
+// BATCH_SIZE / MAX_ITERATION.  Outputs: R_, t_ after the loop (what setPose composes with T_world_ref), the outer iterations,
+// the functor evaluations, the last status.
+int ref_tracker_solve(ref_tracker* h, size_t batch_size, size_t max_iteration, double R[9], double t[3], size_t* iterations,
+                      size_t* nfev_out, int* last_status) {
+  RegProblemLM& prob = *h->prob;
+  h->cfg->BATCH_SIZE_ = batch_size;
+  h->cfg->MAX_ITERATION_ = max_iteration;
+  prob.numBatches_ = std::max(prob.ResItems_.size() / batch_size, (size_t)1);
+  Eigen::LevenbergMarquardt<RegProblemLM, double> lm(prob);
+  lm.resetParameters();
+  lm.parameters.ftol = 1e-3;
+  lm.parameters.xtol = 1e-3;
+  lm.parameters.maxfev = max_iteration * 8;
+  size_t iteration = 0, nfev = 0;
+  int status = -2;
+  while (iteration < max_iteration) {
+    prob.setStochasticSampling((iteration % prob.numBatches_) * batch_size, batch_size);
+    Eigen::VectorXd x(6);
+    x.setZero();  // x.fill(0.0) upstream
+    if (lm.minimizeInit(x) == Eigen::LevenbergMarquardtSpace::ImproperInputParameters) return -1;
+    status = (int)lm.minimizeOneStep(x);
+    prob.addMotionUpdate(x);
+    iteration++;
+    nfev += lm.nfev;
+    if (status == 2 || status == 3) break;
+  }
+  prob.setPose();
+  ref_tracker_relative_pose(h, R, t);
+  *iterations = iteration;
+  *nfev_out = nfev;
+  *last_status = status;
+  return 0;
 }
 }  // extern "C"

@@ -174,6 +174,49 @@ def make_track():
     print("track", os.path.getsize(path) // 1024, "KiB")
 
 
+def track_solve_starts(T_left):
+    """start poses of the registration cases: the true pose, the reference frame's pose (what the node starts from), and
+    the true pose displaced by ~2, 5, 10 and 20 mm / a proportional rotation"""
+    from esvo_amd import closed_loop as cl
+    rng = np.random.default_rng(11)
+    starts = [("truth", T_left.copy()), ("ref_pose", None)]
+    for s in (0.002, 0.005, 0.01, 0.02):
+        T0 = T_left.copy()
+        T0[:3, :3] = T_left[:3, :3] @ cl.orth(cl.cayley2rot(rng.normal(0, s / 2, 3)))
+        T0[:3, 3] += rng.normal(0, s, 3)
+        starts.append((f"pert{int(s * 1000)}mm", T0))
+    return starts
+
+
+def make_track_solve():
+    """The reference's tracker LOOP -- RegProblemSolverLM::solve_analytical (RegProblemSolverLM.cpp:148-178) around the
+    reference's own functor, its LM class ref_shim's MINPACK restatement (oracle/ref_harness_track.cpp: ref_tracker_solve) --
+    from six start poses, with the yaml's BATCH_SIZE 300 and with one batch: the poses it ends at.  tests/test_track_normal.py
+    bounds the deviation of esvo_hip::gauss_newton_register (Levenberg damping, not lmpar) against them."""
+    from oracle import oracle as O
+    rig, L, pw, T_ref, T_left = track_inputs()
+    ot = O.OracleTracker(rig)
+    ot.set_current(L, 5)
+    neg, du, dv = ot.images()
+    out = dict(T_world_left_true=T_left)
+    names = []
+    for name, T0 in track_solve_starts(T_left):
+        T0 = T_ref.copy() if T0 is None else T0
+        names.append(name)
+        out[f"{name}_T0"] = T0
+        for B in (300, 0):
+            rt = R.RefTracker(rig, huber=True, huber_threshold=50.0, max_points=2000)
+            order, R0, t0 = rt.set_problem(neg, du, dv, pw, T_ref, T0, seed=3)
+            Rr, tr, it, nfev, st = rt.solve(B or rt.n, 10)
+            out["order"], out["n"] = order, rt.n
+            out[f"{name}_R0"], out[f"{name}_t0"] = R0, t0
+            out[f"{name}_b{B}"] = np.concatenate([Rr.reshape(9), tr, [it, nfev, st]])
+    out["names"] = np.array(names)
+    path = os.path.join(HERE, "ref_track_solve.npz")
+    np.savez_compressed(path, **out)
+    print("track_solve", os.path.getsize(path) // 1024, "KiB")
+
+
 def sgm_inputs():
     """observation pair, SGM events and edgelet coordinates of the bootstrap case (tests/test_sgm.py uses the same stream)"""
     from esvo_amd import calib, params, synth
@@ -613,6 +656,9 @@ if __name__ == "__main__":
             make(n)
         make_node_big()
         sys.exit(0)
+    if "--track-solve" in sys.argv:   # only the tracker-loop fixture (round 6): ref_track_solve.npz
+        make_track_solve()
+        sys.exit(0)
     names = [a for a in sys.argv[1:] if not a.startswith("-")] or list(S.SCENARIOS)
     for n in names:
         make(n)
@@ -621,6 +667,7 @@ if __name__ == "__main__":
     make_node_big()
     make_units()
     make_track()
+    make_track_solve()
     make_sgm()
     make_ts()
     make_ts_jitter()

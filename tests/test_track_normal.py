@@ -66,29 +66,37 @@ def _numpy_register(trk, n, R_, t_, iters):
     return R, t, it
 
 
-def test_cpp_gauss_newton_driver_equals_the_numpy_loop(tmp_path):
-    g, rig, trk, xyz = _problem()
+def _build_driver(tmp_path):
     exe = str(tmp_path / "gn_driver_oracle")
     subprocess.check_call(["g++", "-std=c++14", "-O2", "-ffp-contract=off", "-Wall", "-I", os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "cpp", "gn_driver_oracle.cpp"), "-o", exe,
                            "-L", os.path.join(ROOT, "oracle"), "-lesvo_oracle", f"-Wl,-rpath,{os.path.join(ROOT, 'oracle')}"])
+    return exe
+
+
+def _run_driver(exe, tmp_path, rig, ts_left, xyz, T_world_ref, R0, t0, iters, batch=0):
     fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
-    n = len(xyz)
     with open(fin, "wb") as f:
         f.write(struct.pack("<2i", rig.width, rig.height))
         f.write(np.asarray(rig.left.P, "<f8").reshape(12).tobytes())
-        f.write(np.ascontiguousarray(g["ts_left"], np.uint8).tobytes())
-        f.write(struct.pack("<Q", n))
+        f.write(np.ascontiguousarray(ts_left, np.uint8).tobytes())
+        f.write(struct.pack("<Q", len(xyz)))
         f.write(np.ascontiguousarray(xyz, "<f4").tobytes())
-        f.write(np.asarray(g["T_world_ref"], "<f8").reshape(16).tobytes())
-        f.write(np.eye(3).astype("<f8").tobytes())
-        f.write(np.zeros(3, "<f8").tobytes())
-        f.write(struct.pack("<i", 12))
+        f.write(np.asarray(T_world_ref, "<f8").reshape(16).tobytes())
+        f.write(np.asarray(R0, "<f8").reshape(9).tobytes())
+        f.write(np.asarray(t0, "<f8").reshape(3).tobytes())
+        f.write(struct.pack("<2i", iters, batch))
     subprocess.check_call([exe, fin, fout])
     out = open(fout, "rb").read()
-    R = np.frombuffer(out, "<f8", 9, 0).reshape(3, 3)
-    t = np.frombuffer(out, "<f8", 3, 72)
-    iters = struct.unpack_from("<i", out, 104)[0]
+    return (np.frombuffer(out, "<f8", 9, 0).reshape(3, 3), np.frombuffer(out, "<f8", 3, 72), struct.unpack_from("<d", out, 96)[0],
+            struct.unpack_from("<i", out, 104)[0])
+
+
+def test_cpp_gauss_newton_driver_equals_the_numpy_loop(tmp_path):
+    g, rig, trk, xyz = _problem()
+    exe = _build_driver(tmp_path)
+    n = len(xyz)
+    R, t, _, iters = _run_driver(exe, tmp_path, rig, g["ts_left"], xyz, g["T_world_ref"], np.eye(3), np.zeros(3), 12)
     # the upenn rig's mask is absent in the driver's oracle instance: run the numpy loop on the same (mask-free) camera
     from oracle import oracle as O
     import copy
@@ -104,6 +112,63 @@ def test_cpp_gauss_newton_driver_equals_the_numpy_loop(tmp_path):
     assert abs(np.linalg.det(R) - 1) < 1e-12 and np.abs(R @ R.T - np.eye(3)).max() < 1e-14
     # ... and it moved: the registered motion is the displacement between the two poses of the fixture, to the tracker's accuracy
     assert np.linalg.norm(t) > 1e-3
+
+
+def _angle_deg(A, B):
+    return float(np.degrees(np.arccos(np.clip((np.trace(A.T @ B) - 1.0) / 2.0, -1.0, 1.0))))
+
+
+def test_driver_against_the_reference_tracker_loop(tmp_path):
+    """The stated deviation, bounded (advisor round 5): esvo_hip::gauss_newton_register takes Levenberg-damped steps, the
+    reference's loop (RegProblemSolverLM::solve_analytical, RegProblemSolverLM.cpp:148-178: x = 0, minimizeInit, one
+    minimizeOneStep of Eigen's lmpar trust region, addMotionUpdate, 10 times) takes MINPACK's.  tests/golden/ref_track_solve.npz
+    holds the poses that loop ends at -- the reference's own functor compiled from source, the LM class ref_shim's MINPACK
+    restatement (tests/golden/make_ref_fixtures.py: make_track_solve) -- from six start poses, with BATCH_SIZE 300 and with one
+    batch.  From the same starts, with the same iteration budget, the driver must
+      * end at a cost (Huber, all points) no higher than the reference loop's + 0.1 %: it is at least as good a minimiser;
+      * end within 3 mm / 0.15 deg of it wherever the reference loop itself got to the minimum (starts up to 5 mm off);
+      * from 10 and 20 mm off, where ten MINPACK steps do NOT get there (the fixture's costs say so), end closer to the
+        common minimum than the reference loop does -- the two are not asked to agree there."""
+    from oracle import oracle as O
+    import copy
+    g0 = np.load(os.path.join(GOLDEN, "ref_track.npz"))
+    g = np.load(os.path.join(GOLDEN, "ref_track_solve.npz"))
+    rig = calib.dataset_rig("upenn")
+    n, order = int(g["n"]), g["order"]
+    xyz = g0["xyz_world"][order][:n]
+    exe = _build_driver(tmp_path)
+    rig2 = copy.copy(rig)
+    rig2.left = copy.copy(rig.left)
+    rig2.left.rect_mask = None          # as in the driver's oracle instance
+    trk = O.OracleTracker(rig2)
+    trk.set_current(g0["ts_left"], 5)
+    trk.set_reference(xyz, g0["T_world_ref"])
+
+    def cost(R, t):
+        return trk.normal_equations(R, t, 0, n, huber=True, huber_threshold=50.0)[2]
+
+    # the common minimum: the driver from the true pose, run to the end
+    Rm, tm, _, _ = _run_driver(exe, tmp_path, rig, g0["ts_left"], xyz, g0["T_world_ref"], g["truth_R0"], g["truth_t0"], 40)
+    seen = []
+    for name in [str(x) for x in g["names"]]:
+        R0, t0 = g[f"{name}_R0"], g[f"{name}_t0"]
+        c0 = cost(R0, t0)
+        for B in (300, 0):
+            ref = g[f"{name}_b{B}"]
+            Rr, tr, it_r = ref[:9].reshape(3, 3), ref[9:12], int(ref[12])
+            Ro, to, _, it_o = _run_driver(exe, tmp_path, rig, g0["ts_left"], xyz, g0["T_world_ref"], R0, t0, 10, batch=B)
+            cr, co = cost(Rr, tr), cost(Ro, to)
+            d_mm, d_deg = 1e3 * float(np.linalg.norm(tr - to)), _angle_deg(Rr, Ro)
+            seen.append((name, B, it_r, it_o, round(d_mm, 3), round(d_deg, 4), cr / c0, co / c0))
+            assert it_o <= 10 and abs(np.linalg.det(Ro) - 1) < 1e-12
+            assert co < c0 and cr < c0, seen[-1]                      # both descend
+            assert co <= cr * 1.001, seen[-1]
+            if name in ("truth", "ref_pose", "pert2mm", "pert5mm"):
+                assert d_mm < 3.0 and d_deg < 0.15, seen[-1]
+            else:
+                assert np.linalg.norm(to - tm) <= np.linalg.norm(tr - tm) + 1e-4, seen[-1]
+                assert np.linalg.norm(to - tm) < 3e-3 and _angle_deg(Ro, Rm) < 0.15, seen[-1]
+    assert len(seen) == 12
 
 
 @pytest.mark.gpu
