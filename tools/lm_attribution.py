@@ -40,8 +40,8 @@ MARKS = [  # (region, first line = the line holding this text); a region lasts u
     ("solver: phase 1 (forward difference, J, qtf)", "    } else if (phase == 1) {"),
     ("solver: phase 2 (trust-region test)", "    } else {  // phase 2: trust-region trial at xnew"),
     ("solver: outer loop (DepthProblemSolver.cpp:161-188)", "    if (phase == 0) {\n"),
-    ("kernel epilogue (point, culling, store)", "  if constexpr (PAD > 0) {  // (the padding registers are live up to here)"),
-    ("(other kernels / host)", "#ifdef LM_STATS\nextern \"C\" void esvo_debug_lm_counters"),
+    ("kernel epilogue (point, culling, store)", "  if (!active || !lead) return;\n  if constexpr (BAND) { if (viol) atomicAdd(a.halo_viol, 1u); }"),
+    ("(other kernels / host)", "// ---- the persistent narrow layout (round 5)"),
 ]
 
 
@@ -76,7 +76,8 @@ def static(tag):
     regs = regions()
     helpers_end = [a for a, n in regs if n.startswith("interpolation")][0]
     cur_line, loop = 0, None
-    count, f64, loops = {}, {}, {}
+    count, f64, loops, quarter, loops_q = {}, {}, {}, {}, {}
+    QUARTER = ("v_rcp_f64", "v_rsq_f64", "v_sqrt_f64", "v_rcp_f32", "v_rsq_f32", "v_sqrt_f32", "v_exp_f32", "v_log_f32", "v_sin_f32", "v_cos_f32")
     for l in lines[start + 1:end]:
         t = l.strip()
         if t.startswith(".loc"):
@@ -111,11 +112,17 @@ def static(tag):
         count[r] = count.get(r, 0) + 1
         if "_f64" in op:
             f64[r] = f64.get(r, 0) + 1
+        q = op.split("_e64")[0].split("_e32")[0] in QUARTER   # quarter-rate (transcendental unit): 16.3 cycles per wave64, tools/valu_rates.hip
+        if q:
+            quarter[r] = quarter.get(r, 0) + 1
         if loop and loop[0] >= 2:
             key = f"{r} @ inner loop {loop[1]}"
             loops[key] = loops.get(key, 0) + 1
+            if q:
+                loops_q[key] = loops_q.get(key, 0) + 1
     meta = next(l for l in lines[end:] if ".vgpr_count" in l) if any(".vgpr_count" in l for l in lines[end:]) else ""
-    out = {"kernel": KERNEL, "valu_static_total": sum(count.values()), "valu_by_region": count, "f64_by_region": f64, "valu_in_inner_loops": loops,
+    out = {"kernel": KERNEL, "valu_static_total": sum(count.values()), "valu_by_region": count, "f64_by_region": f64, "quarter_rate_by_region": quarter, "valu_in_inner_loops": loops,
+           "quarter_rate_in_inner_loops": loops_q,
            "regions_first_line": {n: a for a, n in regs}}
     path = os.path.join(ROOT, "profiles", f"{tag}_lm_static.json")
     json.dump(out, open(path, "w"), indent=1)
@@ -161,37 +168,50 @@ def dynamic(tag, n_ticks=8):
 def table(static_json, dynamic_json, measured=None, sq_waves=None):
     S, D = json.load(open(static_json)), json.load(open(dynamic_json))
     R = S["valu_by_region"]
+    Q = S.get("quarter_rate_by_region", {})
     loops = S["valu_in_inner_loops"]
-    tight_body = max([v for k, v in loops.items() if k.startswith("t-scale loop (tight)")] or [0])
+    tight_key = max([k for k in loops if k.startswith("t-scale loop (tight)")] or [""], key=lambda k: loops.get(k, 0))
+    tight_body = loops.get(tight_key, 0)
+    tight_q = S.get("quarter_rate_in_inner_loops", {}).get(tight_key, 0)
+    # measured issue cost per wave64 instruction at the kernel's two waves per SIMD (tools/valu_rates.hip, profiles/r06_valu_rates.txt)
+    C_PLAIN, C_QUARTER = 4.5, 16.5
     W = D["matches_per_tick"] / 4.0                      # working waves (four matches each)
     E, Lw = D["evals_per_wave_per_tick"], D["tscale_iters_per_wave_per_tick"]
     Eg, Lg = D["evals_per_group_per_tick"] / 4.0, D["tscale_iters_per_group_per_tick"] / 4.0   # the same in wave units without lockstep loss
     jac = D["jacobian_evals_per_tick"] / 4.0 * (E / max(Eg, 1))   # phase-1 passes per wave (scaled like the evaluations)
     rows = []
 
-    def add(name, per, mult, what):
-        rows.append((name, per, mult, per * mult, what))
+    def add(name, per, mult, what, q=0):
+        rows.append((name, per, mult, per * mult, what, ((per - q) * C_PLAIN + q * C_QUARTER) * mult))
     g = lambda k: R.get(k, 0)
-    add("prologue + epilogue", g("kernel prologue (match, pose, set-up)") + g("kernel epilogue (point, culling, store)"), W, "per working wave")
-    add("projection", g("projection (cam2World, T, world2Cam, 4 quotients)"), E, "per evaluation (wave)")
-    add("interpolation", g("interpolation (geometry, loads, bilinear)"), E, "per evaluation (wave)")
-    add("residuals + range tests + shortcut test", g("residuals, moments, range tests") + g("t-scale: shortcut test + set-up"), E, "per evaluation (wave)")
-    add("t-scale loop", tight_body, Lw, "per iteration (wave); body = the tight loop's")
-    add("weights", g("weights sqrt((nu+1)/(nu+r^2/s2)) r (tight)"), E, "per evaluation (wave); the tight variant")
-    add("solver: phase 1 (J, qtf) + lmpar", g("solver: phase 1 (forward difference, J, qtf)") + g("solver: lmpar + trial point"), jac, "per Jacobian pass (wave)")
+    gq = lambda *ks: sum(Q.get(k, 0) for k in ks)
+    add("prologue + epilogue", g("kernel prologue (match, pose, set-up)") + g("kernel epilogue (point, culling, store)"), W, "per working wave",
+        gq("kernel prologue (match, pose, set-up)", "kernel epilogue (point, culling, store)"))
+    add("projection", g("projection (cam2World, T, world2Cam, 4 quotients)"), E, "per evaluation (wave)", gq("projection (cam2World, T, world2Cam, 4 quotients)"))
+    add("interpolation", g("interpolation (geometry, loads, bilinear)"), E, "per evaluation (wave)", gq("interpolation (geometry, loads, bilinear)"))
+    add("residuals + range tests + shortcut test", g("residuals, moments, range tests") + g("t-scale: shortcut test + set-up"), E, "per evaluation (wave)",
+        gq("residuals, moments, range tests", "t-scale: shortcut test + set-up"))
+    add("t-scale loop", tight_body, Lw, "per iteration (wave); body = the tight loop's", tight_q)
+    add("weights", g("weights sqrt((nu+1)/(nu+r^2/s2)) r (tight)"), E, "per evaluation (wave); the tight variant", gq("weights sqrt((nu+1)/(nu+r^2/s2)) r (tight)"))
+    add("solver: phase 1 (J, qtf) + lmpar", g("solver: phase 1 (forward difference, J, qtf)") + g("solver: lmpar + trial point"), jac, "per Jacobian pass (wave)",
+        gq("solver: phase 1 (forward difference, J, qtf)", "solver: lmpar + trial point"))
     add("solver: phase 2 + outer loop", g("solver: phase 2 (trust-region test)") + g("solver: outer loop (DepthProblemSolver.cpp:161-188)") +
-        g("solver: evaluator call site / pair exchange"), max(E - jac - W, 0), "per trial point (wave)")
-    add("solver: phase 0", g("solver: phase 0 (minimizeInit)"), W, "per working wave")
+        g("solver: evaluator call site / pair exchange"), max(E - jac - W, 0), "per trial point (wave)",
+        gq("solver: phase 2 (trust-region test)", "solver: outer loop (DepthProblemSolver.cpp:161-188)", "solver: evaluator call site / pair exchange"))
+    add("solver: phase 0", g("solver: phase 0 (minimizeInit)"), W, "per working wave", gq("solver: phase 0 (minimizeInit)"))
     model = sum(r[3] for r in rows)
+    cyc = sum(r[5] for r in rows)
     lock_e = (E - Eg) / E if E else 0
     lock_l = (Lw - Lg) / Lw if Lw else 0
     print(f"narrow lm_refine_kernel, headline workload: {D['matches_per_tick']:.0f} matches per launch = {W:.0f} working waves; "
           f"{D['evals_per_match']:.1f} evaluations per match, {D['tscale_iters_per_eval_group']:.2f} t-scale iterations per evaluation "
           f"({D['tscale_iters_per_eval_wave']:.2f} executed per wave-evaluation: four matches in lockstep)")
-    print(f"{'region':44s} {'VALU/unit':>9s} {'units/launch':>13s} {'VALU/launch':>12s} {'share':>6s}  unit")
-    for name, per, mult, tot, what in rows:
-        print(f"{name:44s} {per:9.0f} {mult:13.0f} {tot:12.3e} {100 * tot / model:5.1f}%  {what}")
-    print(f"{'model total':44s} {'':9s} {'':13s} {model:12.3e}")
+    print(f"{'region':44s} {'VALU/unit':>9s} {'units/launch':>13s} {'VALU/launch':>12s} {'share':>6s} {'issue cycles':>13s} {'share':>6s}  unit")
+    for name, per, mult, tot, what, cy in rows:
+        print(f"{name:44s} {per:9.0f} {mult:13.0f} {tot:12.3e} {100 * tot / model:5.1f}% {cy:13.3e} {100 * cy / cyc:5.1f}%  {what}")
+    print(f"{'model total':44s} {'':9s} {'':13s} {model:12.3e} {'':6s} {cyc:13.3e}")
+    print(f"issue cycles: every instruction at {C_PLAIN} cycles of its SIMD, the quarter-rate ones (v_rcp_f64, v_rsq_f64, v_sqrt_f64) at {C_QUARTER} -- the costs "
+          f"measured at two waves per SIMD (tools/valu_rates.hip).  On 1024 SIMDs at 2.37 GHz the model's total is {cyc / 1024 / 2.37e9 * 1e3:.3f} ms of issue time per launch")
     if measured:
         print(f"{'SQ_INSTS_VALU (hardware counter, per launch)':44s} {'':9s} {'':13s} {float(measured):12.3e}   model / measured = {model / float(measured):.2f}")
     print(f"lockstep: {100 * lock_e:.0f} % of the executed evaluations and {100 * lock_l:.0f} % of the executed t-scale iterations are re-runs for "
