@@ -57,6 +57,9 @@ class LocalTransport:
 
     def __init__(self, world, timeout=120):
         import threading
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()   # in the constructing thread: torch's lazy initialisation from a callback thread finds no device
         self.world = world
         self.bar = threading.Barrier(world, timeout=timeout)
         self.slots = [None] * world
