@@ -59,3 +59,23 @@ def test_random_configuration_split_over_ranks_equals_one_gpu(seed):
     assert bad is not None, brief     # (None = the configuration maps nothing: the generator has drifted)
     assert not bad, (bad[:4], brief)
     assert ("band world" if DIST_SEEDS[seed].startswith("band") else "tick world") in brief   # the mode recorded above
+
+
+# Time-Surface ingest under out-of-order delivery (tools/fuzz_ts.py): seed -> what it exercises
+TS_SEEDS = {
+    3014: "upenn, queues of 20, 8 % late events, 12 renders",
+    3019: "dsec, one stamp per pixel, 40 % late events, 3x3 median, 16 renders",
+    3067: "upenn, queues of 3, FORWARD raster",
+    3081: "dsec, queues of 20, 40 % late events, 45 renders",
+    3110: "identity remap 346x180, FORWARD raster, 35 % late events",
+    3131: "dsec, queues of 20, FORWARD raster, 3x3 median, 45 renders",
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", sorted(TS_SEEDS))
+def test_random_out_of_order_ingest_equals_the_oracle_raster(seed):
+    import fuzz_ts
+    bad, brief = fuzz_ts.run_case(seed)
+    assert not bad, (bad[:4], brief)
+    assert " 0 late" not in brief and " 0 renders" not in brief, brief
