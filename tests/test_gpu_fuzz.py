@@ -79,3 +79,15 @@ def test_random_out_of_order_ingest_equals_the_oracle_raster(seed):
     bad, brief = fuzz_ts.run_case(seed)
     assert not bad, (bad[:4], brief)
     assert " 0 late" not in brief and " 0 renders" not in brief, brief
+
+
+# the tracker's evaluation side on the device (tools/fuzz_track.py): images, residuals, Jacobian, normal equations, batch, register
+TRACK_SEEDS = [7000, 7003, 7019, 7020, 7021]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", TRACK_SEEDS)
+def test_random_tracker_evaluations_equal_the_oracle(seed):
+    import fuzz_track
+    bad, brief = fuzz_track.run_case(seed)
+    assert not bad, (bad[:4], brief)
