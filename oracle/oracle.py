@@ -385,9 +385,12 @@ class OracleMapper:
         return out[:n]
 
     def get_last_frame(self):
-        cap = max(int(self.params.max_events_per_tick), 1)
+        cap = max(int(self.params.max_events_per_tick), int(self.params.process_event_num) + 1, 1)
         out = np.zeros(cap, DEPTH_POINT_DTYPE)
         n = self.lib.orc_mapper_get_last_frame(self.h, out.ctypes.data, cap)
+        if n > cap:   # (the call reports the frame's size whatever the capacity: fetch again rather than hand back a truncated frame)
+            out = np.zeros(n, DEPTH_POINT_DTYPE)
+            n = self.lib.orc_mapper_get_last_frame(self.h, out.ctypes.data, n)
         return out[:n]
 
     def get_pointcloud(self):

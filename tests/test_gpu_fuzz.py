@@ -91,3 +91,17 @@ def test_random_tracker_evaluations_equal_the_oracle(seed):
     import fuzz_track
     bad, brief = fuzz_track.run_case(seed)
     assert not bad, (bad[:4], brief)
+
+
+# the SGM bootstrap (tools/fuzz_sgm.py): disparity image, point count, frame, map
+SGM_SEEDS = {11012: "dsec Time-Surface pair, 5001 events", 11048: "upenn noise vs its perturbed shift", 11110: "dsec saturated images",
+             11124: "hkust Time-Surface pair, threshold 500", 11213: "dsec noise vs its shift, 4701 points"}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", sorted(SGM_SEEDS))
+def test_random_sgm_bootstrap_equals_the_oracle(seed):
+    import fuzz_sgm
+    bad, brief = fuzz_sgm.run_case(seed)
+    assert not bad, (bad[:4], brief)
+    assert ": 0 points" not in brief, brief
