@@ -907,20 +907,22 @@ int tick_phase1_enqueue(esvo_context* h) {
   } else if (n) {
     const u32 N = (u32)h->dp.ev_nshards, r = (u32)h->dp.ev_shard, T = (u32)h->dp.num_threads;
     const u32 own = h->routed ? tk.n_own : (n > r ? (n - r + N - 1) / N : 0);
-    if (h->routed) {
-      HIPCHK(hipMemsetAsync(h->d_codes, 0, n, h->stream));
+    // Six dependent launches for a routed tick above the single-workgroup scans' size (round 6; thirteen before): unpack (+ the
+    // matched slots per scan tile), down-sweep of the matched bits (+ clearing the keep flags), keep flags by solver slot (+ clearing
+    // the exchange block's cursor), their scan (2), pack.  This chain is the same on every rank whatever the number of ranks -- the
+    // part of a band-mode tick that does not shrink.
+    const bool tiled = h->routed && !scan_is_small(n);
+    if (h->routed)
       launch_shard_unpack_routed(reinterpret_cast<const u32*>(N > 1 ? h->d_codes_all : h->d_codes_send), (u32)(shard_codes_block_routed(n) / 4), N,
-                                 n, h->d_codes, h->d_rank_kept, h->stream);
-    } else
-    launch_shard_unpack_codes(N > 1 ? h->d_codes_all : h->d_codes_send, (u32)shard_codes_block(n, N), N, n, h->d_codes, h->d_rank_kept,
-                              h->stream);
-    launch_shard_match_flags(h->d_codes, n, h->d_match_flags, h->stream);
-    launch_exclusive_scan_u32(h->d_match_flags, h->d_match_prefix, h->d_counters + 0, h->d_scan_tmp, n, h->stream);
-    HIPCHK(hipMemsetAsync(h->d_pt_flags, 0, sizeof(u32) * n, h->stream));
-    launch_shard_keep_flags(h->d_codes, h->d_match_prefix, h->d_counters + 0, n, T, h->d_pt_flags, h->stream);
+                                 n, h->d_codes, h->d_rank_kept, tiled ? h->d_scan_tmp : nullptr, h->stream);
+    else
+      launch_shard_unpack_codes(N > 1 ? h->d_codes_all : h->d_codes_send, (u32)shard_codes_block(n, N), N, n, h->d_codes, h->d_rank_kept,
+                                h->stream);
+    if (tiled) launch_scan_down_code_bit0(h->d_codes, h->d_match_prefix, h->d_counters + 0, h->d_scan_tmp, n, h->d_pt_flags, h->stream);
+    else launch_exclusive_scan_code_bit0(h->d_codes, h->d_match_prefix, h->d_counters + 0, h->d_scan_tmp, n, h->d_pt_flags, h->stream);
+    launch_shard_keep_flags(h->d_codes, h->d_match_prefix, h->d_counters + 0, n, T, h->d_pt_flags, h->d_pts_send, h->stream);
     launch_exclusive_scan_u32(h->d_pt_flags, h->d_pt_prefix, h->d_counters + 1, h->d_scan_tmp, n, h->stream);
     (void)frame;  // filled after exchange 2 (tick_phase2)
-    HIPCHK(hipMemsetAsync(h->d_pts_send, 0, 8, h->stream));  // the block's count word = the append cursor
     launch_shard_pack(h->d_own_w, h->d_lkeep, h->d_pt_slots, h->d_counters + 8, own, h->d_match_prefix, h->d_counters + 0,
                       h->d_pt_prefix, T, h->d_pts_send, own, n, h->d_rank_kept, N, h->d_counters + 9, h->stream,
                       h->routed ? h->d_counters + 10 : nullptr);

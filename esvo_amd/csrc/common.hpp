@@ -165,6 +165,13 @@ typedef esvo_depth_point_t DevPoint;
 // scan.hip
 void launch_exclusive_scan_u32(const u32* d_in, u32* d_out, u32* d_total, u32* d_block_sums, size_t n,
                                hipStream_t s);
+// the same over bit 0 of one byte per element; d_zero (nullable): n words cleared by the same launches
+void launch_exclusive_scan_code_bit0(const uint8_t* d_codes, u32* d_out, u32* d_total, u32* d_block_sums, size_t n, u32* d_zero,
+                                     hipStream_t s);
+bool scan_is_small(size_t n);   // one single-workgroup launch does the whole scan
+u32 scan_tiles(size_t n);       // tiles (= sums) of the two-launch scan; SCAN_TILE_SLOTS elements each
+static constexpr u32 SCAN_TILE_SLOTS = 2048;
+void launch_scan_down_code_bit0(const uint8_t* d_codes, u32* d_out, u32* d_total, const u32* d_tile_sums, size_t n, u32* d_zero, hipStream_t s);
 size_t scan_scratch_elems(size_t n);
 // scan + stable compaction in ONE single-workgroup launch, for inputs of at most 10 240 flags (scan.hip)
 bool scan_compact_is_small(size_t n);
@@ -289,9 +296,8 @@ void launch_track_normal(const TrackArgs& a, const TrackPoseSet& poses, int n_po
 // kernels_shard.hip: ordering of a tick's frame from the ranks' (matched, kept) bits
 void launch_shard_codes(const u32* own_w, const u32* keep, const u32* n_local, u32 max_local, u32 N, uint8_t* block, hipStream_t s);
 void launch_shard_unpack_codes(const uint8_t* blocks, u32 block_bytes, u32 N, u32 n, uint8_t* codes, u32* rank_kept, hipStream_t s);
-void launch_shard_match_flags(const uint8_t* codes, u32 n, u32* flags, hipStream_t s);
 void launch_shard_keep_flags(const uint8_t* codes, const u32* prefix_f, const u32* n_matches, u32 n, u32 T, u32* keep_by_slot,
-                             hipStream_t s);
+                             unsigned long long* cursor, hipStream_t s);
 void launch_shard_pack(const u32* own_w, const u32* keep, const DevPoint* local_pts, const u32* n_local, u32 max_local,
                        const u32* prefix_f, const u32* n_matches, const u32* prefix_g, u32 T, unsigned long long* block, u32 block_cap,
                        u32 frame_cap, u32* rank_kept, u32 N, u32* max_kept_out, hipStream_t s, const u32* halo_viol = nullptr);
@@ -300,7 +306,7 @@ void launch_shard_scatter(const unsigned long long* blocks, size_t block_words, 
 // routed band mode (two bits per slot of the whole tick)
 void launch_shard_codes_routed(const esvo_match_t* own_matches, const u32* keep, const u32* n_local, u32 max_local, u32 n, u32 T, u32* own_w,
                                u32* block, hipStream_t s);
-void launch_shard_unpack_routed(const u32* blocks, u32 block_words, u32 N, u32 n, uint8_t* codes, u32* rank_kept, hipStream_t s);
+void launch_shard_unpack_routed(const u32* blocks, u32 block_words, u32 N, u32 n, uint8_t* codes, u32* rank_kept, u32* tile_sums, hipStream_t s);
 
 // kernels_lm.hip
 struct LmArgs {

@@ -53,36 +53,61 @@ void launch_shard_codes_routed(const esvo_match_t* own_matches, const u32* keep,
   hipLaunchKernelGGL(shard_codes_routed_kernel, dim3((max_local + 255) / 256), dim3(256), 0, s, own_matches, keep, n_local, max_local, n, T,
                      own_w, block);
 }
-// after exchange 1: the gathered blocks [N][block_words] into one byte per slot (codes zeroed by the caller: every slot has at
-// most one owner) and every rank's kept count
-__global__ void __launch_bounds__(256) shard_unpack_routed_kernel(const u32* __restrict__ blocks, u32 block_words, u32 n_words, u32 n,
-                                                                  uint8_t* __restrict__ codes, u32* __restrict__ rank_kept) {
-  __shared__ u32 part[4];
-  const u32 i = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
-  u32 word = 0;
-  if (i < n_words) word = blocks[(size_t)r * block_words + i];
-  if (word) {
+// after exchange 1: the gathered blocks [N][block_words] into one byte per slot, and every rank's kept count.  A slot has at most
+// one owner, so the OR of the N ranks' words IS the tick's codes: one thread per word reads its N copies and writes all sixteen
+// bytes, zeros included (round 6: no memset of the codes beforehand, one launch over the words instead of N).
+// tile_sums (nullable): the workgroup is then 128 threads = 128 words = 2048 slots = one tile of the scan that follows, and leaves
+// the tile's number of matched slots there -- that scan is its down-sweep alone.
+__global__ void __launch_bounds__(256) shard_unpack_routed_kernel(const u32* __restrict__ blocks, u32 block_words, u32 n_words, u32 N, u32 n,
+                                                                  uint8_t* __restrict__ codes, u32* __restrict__ rank_kept,
+                                                                  u32* __restrict__ tile_sums) {
+  __shared__ u32 part[1024];   // kept points per rank in this workgroup (N <= SHARD_MAX_RANKS)
+  __shared__ u32 matched;
+  if (threadIdx.x == 0) matched = 0u;
+  for (u32 r = threadIdx.x; r < N; r += blockDim.x) part[r] = 0u;
+  __syncthreads();
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  u32 all = 0;
+  for (u32 r = 0; r < N; ++r) {
+    const u32 word = i < n_words ? blocks[(size_t)r * block_words + i] : 0u;
+    all |= word;
+    u32 cnt = (u32)__popc(word & 0xaaaaaaaau);
 #pragma unroll
-    for (u32 q = 0; q < 16; ++q) {
-      const u32 c = (word >> (2u * q)) & 3u, w = 16u * i + q;
-      if (c && w < n) codes[w] = (uint8_t)c;
+    for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
+    if ((threadIdx.x & 63u) == 0 && cnt) atomicAdd(&part[r], cnt);
+  }
+  if (i < n_words) {
+    const u32 w0 = 16u * i;
+    if (w0 + 16u <= n) {  // sixteen codes = one 16-byte store (the array is 16-byte aligned at a multiple of 16 slots)
+      u32 q4[4];
+#pragma unroll
+      for (u32 g = 0; g < 4; ++g) {
+        const u32 b = (all >> (8u * g)) & 0xffu;   // four 2-bit codes -> four bytes
+        q4[g] = (b & 3u) | (((b >> 2) & 3u) << 8) | (((b >> 4) & 3u) << 16) | (((b >> 6) & 3u) << 24);
+      }
+      *reinterpret_cast<uint4*>(codes + w0) = make_uint4(q4[0], q4[1], q4[2], q4[3]);
+    } else {
+      for (u32 q = 0; q < 16 && w0 + q < n; ++q) codes[w0 + q] = (uint8_t)((all >> (2u * q)) & 3u);
     }
   }
-  u32 cnt = (u32)__popc(word & 0xaaaaaaaau);
+  if (tile_sums) {
+    u32 m = (u32)__popc(all & 0x55555555u);   // (slots at or beyond n carry no bits: the blocks are zero there)
 #pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
-  if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = cnt;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const u32 t = part[0] + part[1] + part[2] + part[3];
-    if (t) atomicAdd(&rank_kept[r], t);
+    for (int d = 32; d >= 1; d >>= 1) m += __shfl_xor(m, d);
+    if ((threadIdx.x & 63u) == 0 && m) atomicAdd(&matched, m);
   }
+  __syncthreads();
+  for (u32 r = threadIdx.x; r < N; r += blockDim.x)
+    if (part[r]) atomicAdd(&rank_kept[r], part[r]);
+  if (tile_sums && threadIdx.x == 0) tile_sums[blockIdx.x] = matched;
 }
-void launch_shard_unpack_routed(const u32* blocks, u32 block_words, u32 N, u32 n, uint8_t* codes, u32* rank_kept, hipStream_t s) {
+void launch_shard_unpack_routed(const u32* blocks, u32 block_words, u32 N, u32 n, uint8_t* codes, u32* rank_kept, u32* tile_sums, hipStream_t s) {
   if (n == 0) return;
   const u32 n_words = (n + 15) / 16;
-  hipLaunchKernelGGL(shard_unpack_routed_kernel, dim3((n_words + 255) / 256, N), dim3(256), 0, s, blocks, block_words, n_words, n, codes,
-                     rank_kept);
+  static_assert(SCAN_TILE_SLOTS == 128 * 16, "a 128-thread workgroup of the unpack covers one scan tile");
+  const u32 threads = tile_sums ? 128u : 256u;
+  hipLaunchKernelGGL(shard_unpack_routed_kernel, dim3((n_words + threads - 1) / threads), dim3(threads), 0, s, blocks, block_words, n_words, N, n,
+                     codes, rank_kept, tile_sums);
 }
 
 // after exchange 1: the gathered blocks [N][block_bytes] back into one byte per slot, and every rank's kept count
@@ -113,31 +138,27 @@ void launch_shard_unpack_codes(const uint8_t* blocks, u32 block_bytes, u32 N, u3
                      rank_kept);
 }
 
-__global__ void __launch_bounds__(256) shard_match_flags_kernel(const uint8_t* __restrict__ codes, u32 n, u32* __restrict__ flags) {
-  const u32 w = blockIdx.x * blockDim.x + threadIdx.x;
-  if (w < n) flags[w] = codes[w] & 1u;
-}
-void launch_shard_match_flags(const uint8_t* codes, u32 n, u32* flags, hipStream_t s) {
-  if (n == 0) return;
-  hipLaunchKernelGGL(shard_match_flags_kernel, dim3((n + 255) / 256), dim3(256), 0, s, codes, n, flags);
-}
-
-// keep_by_slot must be zero on entry
+// keep_by_slot must be zero on entry (the scan before this clears it: launch_exclusive_scan_code_bit0).  cursor (nullable): the count
+// word of the exchange-2 block, the append cursor of shard_pack_kernel, cleared here instead of by a memset of its own.
 __global__ void __launch_bounds__(256) shard_keep_flags_kernel(const uint8_t* __restrict__ codes, const u32* __restrict__ prefix_f,
                                                                const u32* __restrict__ n_matches, u32 n, u32 T,
-                                                               u32* __restrict__ keep_by_slot) {
+                                                               u32* __restrict__ keep_by_slot, unsigned long long* __restrict__ cursor) {
   const u32 w = blockIdx.x * blockDim.x + threadIdx.x;
-  if (w >= n) return;
-  const u32 c = codes[w];
-  if (!(c & 1u)) return;
-  const u32 s = stride_slot(prefix_f[w], *n_matches, T);
-  if (s < n) keep_by_slot[s] = (c >> 1) & 1u;
+  if (w == 0 && cursor) *cursor = 0ull;
+  const u32 c = w < n ? codes[w] : 0u;
+  u32 s = 0xffffffffu;
+  if (c & 1u) s = stride_slot(prefix_f[w], *n_matches, T);
+  const bool hit = s < n;
+  if (hit) keep_by_slot[s] = (c >> 1) & 1u;
 }
+// (Counting the kept slots per scan tile here as well -- atomics into ~100 words -- was tried in round 6 to save the second scan's
+//  reduce launch: consecutive matches land in the same few tiles, the atomics of all eight XCDs meet on the same words and the
+//  kernel takes 116-152 us instead of 5.)
 void launch_shard_keep_flags(const uint8_t* codes, const u32* prefix_f, const u32* n_matches, u32 n, u32 T, u32* keep_by_slot,
-                             hipStream_t s) {
+                             unsigned long long* cursor, hipStream_t s) {
   if (n == 0) return;
   hipLaunchKernelGGL(shard_keep_flags_kernel, dim3((n + 255) / 256), dim3(256), 0, s, codes, prefix_f, n_matches, n, T,
-                     keep_by_slot);
+                     keep_by_slot, cursor);
 }
 
 // own block of exchange 2: [count (u64) | kept points in any order], each point with its final index in seq (as

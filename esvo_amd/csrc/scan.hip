@@ -1,72 +1,70 @@
 // scan.hip — device-wide exclusive prefix sum of u32 (stable compaction / counting sort support).
 //
-// Three launches (reduce -> scan of block sums -> down-sweep), 256-thread blocks, 8 items per
-// thread, wave64 shuffles + one LDS hop per block.  n <= 2048*2048 elements.
+// Two launches (reduce -> down-sweep with the block sums' scan folded in), 256-thread blocks, 8 items per
+// thread, wave64 shuffles + one LDS hop per block.
 #include <cstddef>
 #include "common.hpp"
 #include "scan.hpp"
 
 namespace esvo {
 
-__global__ void __launch_bounds__(SCAN_B) scan_reduce_kernel(const u32* __restrict__ in, u32* __restrict__ block_sums, size_t n) {
+// what a scan reads: 32-bit flags, or bit 0 of one byte per element (the "matched" bit of the band mode's slot codes)
+struct ScanInU32 { const u32* p; __device__ u32 operator()(size_t i) const { return p[i]; } };
+struct ScanInCodeBit0 { const uint8_t* p; __device__ u32 operator()(size_t i) const { return p[i] & 1u; } };
+
+template <class In>
+__global__ void __launch_bounds__(SCAN_B) scan_reduce_kernel(In in, u32* __restrict__ block_sums, size_t n) {
   __shared__ u32 lds[4];
   const size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_V;
   u32 s = 0;
 #pragma unroll
   for (int k = 0; k < SCAN_V; ++k)
-    if (base + k < n) s += in[base + k];
+    if (base + k < n) s += in(base + k);
   u32 tot;
   block_excl_scan(s, &tot, lds);
   if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
 }
 
-__global__ void __launch_bounds__(SCAN_B) scan_sums_kernel(u32* __restrict__ block_sums, u32 nb, u32* __restrict__ total) {
+// Down-sweep with the scan of the block sums folded in (round 6: two dependent launches instead of three, 5-6 us of queue
+// latency each on chains that are nothing but small launches -- the band mode's frame order, the compactions of a tick): every
+// block adds up the sums of the blocks before it (at most 2048 words, L2-resident) instead of reading them from a third kernel.
+// zero (nullable): n words cleared on the way (the next kernel's scatter target), saving that memset's launch as well.
+template <class In>
+__global__ void __launch_bounds__(SCAN_B) scan_down_kernel(In in, u32* __restrict__ out, const u32* __restrict__ block_sums, size_t n,
+                                                           u32* __restrict__ total, u32* __restrict__ zero) {
   __shared__ u32 lds[4];
-  u32 v[SCAN_V];
-  u32 s = 0;
-#pragma unroll
-  for (int k = 0; k < SCAN_V; ++k) {
-    u32 i = threadIdx.x * SCAN_V + k;
-    v[k] = (i < nb) ? block_sums[i] : 0u;
-    s += v[k];
-  }
-  u32 tot;
-  u32 ex = block_excl_scan(s, &tot, lds);
-#pragma unroll
-  for (int k = 0; k < SCAN_V; ++k) {
-    u32 i = threadIdx.x * SCAN_V + k;
-    if (i < nb) block_sums[i] = ex;
-    ex += v[k];
-  }
-  if (threadIdx.x == 0 && total) *total = tot;
-}
-
-__global__ void __launch_bounds__(SCAN_B) scan_down_kernel(const u32* __restrict__ in, u32* __restrict__ out,
-                                                           const u32* __restrict__ block_sums, size_t n) {
-  __shared__ u32 lds[4];
+  u32 before = 0;
+  for (u32 i = threadIdx.x; i < blockIdx.x; i += SCAN_B) before += block_sums[i];
+  u32 carry;
+  block_excl_scan(before, &carry, lds);
   const size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_V;
   u32 v[SCAN_V];
   u32 s = 0;
 #pragma unroll
   for (int k = 0; k < SCAN_V; ++k) {
-    v[k] = (base + k < n) ? in[base + k] : 0u;
+    v[k] = (base + k < n) ? in(base + k) : 0u;
     s += v[k];
   }
   u32 tot;
-  u32 ex = block_excl_scan(s, &tot, lds) + block_sums[blockIdx.x];
+  u32 ex = block_excl_scan(s, &tot, lds) + carry;
 #pragma unroll
   for (int k = 0; k < SCAN_V; ++k) {
-    if (base + k < n) out[base + k] = ex;
+    if (base + k < n) {
+      out[base + k] = ex;
+      if (zero) zero[base + k] = 0u;
+    }
     ex += v[k];
   }
+  if (total && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total = carry + tot;
 }
 
 // Small inputs (a reference-faithful tick scans a few thousand flags): one workgroup walks the array tile by tile
 // with a running carry -- one launch instead of three dependent ones (each costs 4-6 us of dispatch latency).
 static constexpr int SCAN_SB = 1024;
 static constexpr size_t SCAN_SMALL_MAX = 32768;
-__global__ void __launch_bounds__(SCAN_SB) scan_small_kernel(const u32* __restrict__ in, u32* __restrict__ out,
-                                                             u32* __restrict__ total, size_t n) {
+template <class In>
+__global__ void __launch_bounds__(SCAN_SB) scan_small_kernel(In in, u32* __restrict__ out, u32* __restrict__ total, size_t n,
+                                                             u32* __restrict__ zero) {
   __shared__ u32 lds[SCAN_SB / ESVO_WAVE];
   u32 carry = 0;
   for (size_t tile = 0; tile < n; tile += (size_t)SCAN_SB * SCAN_V) {
@@ -75,14 +73,17 @@ __global__ void __launch_bounds__(SCAN_SB) scan_small_kernel(const u32* __restri
     u32 s = 0;
 #pragma unroll
     for (int k = 0; k < SCAN_V; ++k) {
-      v[k] = (base + k < n) ? in[base + k] : 0u;
+      v[k] = (base + k < n) ? in(base + k) : 0u;
       s += v[k];
     }
     u32 tot;
     u32 ex = block_excl_scan<SCAN_SB / ESVO_WAVE>(s, &tot, lds) + carry;
 #pragma unroll
     for (int k = 0; k < SCAN_V; ++k) {
-      if (base + k < n) out[base + k] = ex;
+      if (base + k < n) {
+        out[base + k] = ex;
+        if (zero) zero[base + k] = 0u;
+      }
       ex += v[k];
     }
     carry += tot;
@@ -187,21 +188,38 @@ void launch_upload_words(const void* pinned_src, void* d_dst, size_t bytes, hipS
 
 size_t scan_scratch_elems(size_t n) { return (n + SCAN_TILE - 1) / SCAN_TILE + 1; }
 
-// d_out may alias d_in.  d_total (nullable) receives the sum.  d_block_sums: scan_scratch_elems(n).
-void launch_exclusive_scan_u32(const u32* d_in, u32* d_out, u32* d_total, u32* d_block_sums, size_t n,
-                               hipStream_t s) {
+template <class In>
+static void exclusive_scan(In in, u32* d_out, u32* d_total, u32* d_block_sums, size_t n, u32* d_zero, hipStream_t s) {
   if (n == 0) {
     if (d_total) hipMemsetAsync(d_total, 0, sizeof(u32), s);
     return;
   }
   if (n <= SCAN_SMALL_MAX) {
-    hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(SCAN_SB), 0, s, d_in, d_out, d_total, n);
+    hipLaunchKernelGGL(scan_small_kernel<In>, dim3(1), dim3(SCAN_SB), 0, s, in, d_out, d_total, n, d_zero);
     return;
   }
   const u32 nb = (u32)((n + SCAN_TILE - 1) / SCAN_TILE);
-  hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(SCAN_B), 0, s, d_in, d_block_sums, n);
-  hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SCAN_B), 0, s, d_block_sums, nb, d_total);
-  hipLaunchKernelGGL(scan_down_kernel, dim3(nb), dim3(SCAN_B), 0, s, d_in, d_out, d_block_sums, n);
+  hipLaunchKernelGGL(scan_reduce_kernel<In>, dim3(nb), dim3(SCAN_B), 0, s, in, d_block_sums, n);
+  hipLaunchKernelGGL(scan_down_kernel<In>, dim3(nb), dim3(SCAN_B), 0, s, in, d_out, d_block_sums, n, d_total, d_zero);
+}
+// d_out may alias d_in.  d_total (nullable) receives the sum.  d_block_sums: scan_scratch_elems(n).
+void launch_exclusive_scan_u32(const u32* d_in, u32* d_out, u32* d_total, u32* d_block_sums, size_t n,
+                               hipStream_t s) {
+  exclusive_scan(ScanInU32{d_in}, d_out, d_total, d_block_sums, n, nullptr, s);
+}
+// The band mode's frame order (api_map.hip, tick_phase1_enqueue) has the tile sums of its first scan produced by the kernel in
+// front of it (SCAN_TILE slots per sum), so that scan is its down-sweep alone -- for n above the single-workgroup bound only.
+static_assert(SCAN_TILE == (int)SCAN_TILE_SLOTS, "common.hpp's SCAN_TILE_SLOTS is this file's tile");
+bool scan_is_small(size_t n) { return n <= SCAN_SMALL_MAX; }
+u32 scan_tiles(size_t n) { return (u32)((n + SCAN_TILE - 1) / SCAN_TILE); }
+void launch_scan_down_code_bit0(const uint8_t* d_codes, u32* d_out, u32* d_total, const u32* d_tile_sums, size_t n, u32* d_zero, hipStream_t s) {
+  hipLaunchKernelGGL(scan_down_kernel<ScanInCodeBit0>, dim3(scan_tiles(n)), dim3(SCAN_B), 0, s, ScanInCodeBit0{d_codes}, d_out, d_tile_sums, n, d_total,
+                     d_zero);
+}
+// the same over bit 0 of one byte per element; d_zero (nullable): n words cleared by the same launches
+void launch_exclusive_scan_code_bit0(const uint8_t* d_codes, u32* d_out, u32* d_total, u32* d_block_sums, size_t n, u32* d_zero,
+                                     hipStream_t s) {
+  exclusive_scan(ScanInCodeBit0{d_codes}, d_out, d_total, d_block_sums, n, d_zero, s);
 }
 
 }  // namespace esvo
