@@ -105,3 +105,17 @@ def test_random_sgm_bootstrap_equals_the_oracle(seed):
     bad, brief = fuzz_sgm.run_case(seed)
     assert not bad, (bad[:4], brief)
     assert ": 0 points" not in brief, brief
+
+
+# random CALL SEQUENCES on one handle (tools/fuzz_api.py): tick paths mixed, ingest calls mixed, reads in between, esvo_set_params and
+# esvo_reset mid-run -- every read against the oracle
+API_SEEDS = [50000, 50007, 50092, 50163, 50225]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", API_SEEDS)
+def test_random_call_sequence_equals_the_oracle(seed):
+    import fuzz_api
+    bad, brief = fuzz_api.run_case(seed)
+    assert not bad, (bad[:4], brief)
+    assert "reset@" in brief and "params@" in brief, brief

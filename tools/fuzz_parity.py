@@ -3,7 +3,8 @@ configurations NO shipped yaml has -- random rig, patch size, norm, Student-t co
 strategy / window, regulariser on / off and its radius and counts, culling and visibility thresholds, denoising, Time-Surface
 smoothing / decay / median / queue length, block-matching step / threshold / disparity window, thread-stride count, node
 type, tick size -- each on its own seeded synthetic stream.  A difference is a bug in one of the two.
-usage: python tools/fuzz_parity.py [cases] [first seed]      (GPU; prints one line per case, exits 1 on any difference)"""
+usage: python tools/fuzz_parity.py [cases] [first seed]      (GPU; prints one line per case, exits 1 on any difference)
+FUZZ_TICKS_X=k runs k times as many ticks per case (long windows: pops, ages, a ring that wraps many times)."""
 import os
 import sys
 import time
@@ -52,7 +53,7 @@ def draw(seed):
     over = dict(num_threads=int(rng.integers(1, 9)), max_event_queue_len=pick([0, 0, 0, 20, 3]))
     small_ring = bool(rng.integers(4) == 0)   # a ring that wraps over the run (sized in run_case from the first tick's staging)
     scene = dict(points=pick([3000, 8000, 20000]) * (4 if rig_name == "dsec" else 1), speed=float(rng.uniform(0.3, 2.0)),
-                 seed=int(rng.integers(1 << 30)), ticks=int(rng.integers(4, 8)), tick_ms=pick([5, 10, 20]), rho=rho,
+                 seed=int(rng.integers(1 << 30)), ticks=int(rng.integers(4, 8)) * int(os.environ.get("FUZZ_TICKS_X", "1")), tick_ms=pick([5, 10, 20]), rho=rho,
                  # sync: the four calls, every map read at once; lazy: esvo_map_tick_resident, two ticks in flight, maps read one tick late
                  path=pick(["sync", "sync", "lazy"]), small_ring=small_ring)
     return rig_name, cfg, over, scene
