@@ -233,6 +233,8 @@ def main():
         n_matches = int(st.total_matches - base.total_matches)
         ksum = np.array(list(st.sum_ms_kernel)) - np.array(list(base.sum_ms_kernel))
         launches = max(int(st.ticks - base.ticks), 1)   # ticks THIS rank mapped (all of them unless ticks are interleaved)
+        # (ABI 8: how many of them recorded their stage-timing events -- all of them while ticks overlap; what sum_ms_kernel[2..6] sums)
+        timed = int(st.stage_timing_samples - base.stage_timing_samples)
         if dist:
             tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -248,7 +250,7 @@ def main():
             ev_rank, mt_rank = n_events, n_matches
         return dict(per_gpu=per_gpu, rig=rig, stream=stream, p=p, ticks=ticks, duration=duration, native=native, comm_note=comm_note,
                     runner=runner, dt=dt, st=st, base=base, n_events=n_events, n_points=n_points, n_matches=n_matches, ksum=ksum,
-                    launches=launches, ev_rank=ev_rank, mt_rank=mt_rank, shard_mode=shard_mode)
+                    launches=launches, timed=timed if timed > 0 else launches, ev_rank=ev_rank, mt_rank=mt_rank, shard_mode=shard_mode)
 
     if args.selftest:
         res = selftest(rank, world, local_rank, dist, ranks_seen, rccl)
@@ -275,7 +277,7 @@ def main():
     ev_rank, mt_rank = M["ev_rank"], M["mt_rank"]
     nd = p.bm_max_disparity - p.bm_min_disparity + 1
 
-    kavg = ksum / launches
+    kavg = ksum / M["timed"]
     if ksum[7] > 0:  # TS kernels: per-render samples (some are skipped while their events are in flight), two renders per tick
         kavg[0], kavg[1] = 2 * ksum[0] / ksum[7], 2 * ksum[1] / ksum[7]
     # roofline of the dominant single kernel (slots 2 = bm_match_kernel, 3 = lm_refine_kernel; the fuse / regularize

@@ -108,7 +108,7 @@ class StatsStruct(C.Structure):
         ("total_bm_info_noise_low", C.c_uint64), ("total_bm_coarse_fail", C.c_uint64), ("total_bm_fine_fail", C.c_uint64),
         # ABI 3: in-run shader-clock probe of the refinement kernel (include/esvo_hip.h)
         ("clk_cycles", C.c_uint64 * 8), ("clk_ref_ticks", C.c_uint64 * 8), ("clk_samples", C.c_uint64),
-        ("clk_ref_khz", C.c_uint32), ("pad3_", C.c_uint32),
+        ("clk_ref_khz", C.c_uint32), ("stage_timing_samples", C.c_uint32),
         # ABI 6: routed band mode
         ("halo_violations", C.c_uint64),
         ("late_events", C.c_uint64 * 2),

@@ -165,6 +165,9 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
   if (const char* ea = esvo_dev_switch("ESVO_RESYNC")) h->resync_on = std::atoi(ea) != 0;
   if (const char* ea = esvo_dev_switch("ESVO_COLLECT_ASIDE")) h->collect_aside = std::atoi(ea) != 0;
   if (const char* et = esvo_dev_switch("ESVO_TIMELINE")) h->tl_on = std::atoi(et) != 0;
+  if (const char* el = esvo_dev_switch("ESVO_LOWLAT")) h->lat_mode = std::atoi(el) != 0;
+  if (const char* el = esvo_dev_switch("ESVO_LOWLAT_TIMED_EVERY")) h->lat_timed_every = std::max(1, std::atoi(el));
+  if (const char* el = esvo_dev_switch("ESVO_LOWLAT_MAX_EVENTS")) h->lat_max_events = (u32)std::strtoul(el, nullptr, 10);
   if (const char* e1 = esvo_dev_switch("ESVO_ONE_STREAM")) {  // A/B only: the three stages in one queue (no cross-queue hand-offs)
     if (std::atoi(e1) == 1) {
       hipStreamDestroy(h->stream_b);
@@ -553,9 +556,10 @@ int esvo_synchronize(esvo_handle h) {
   if (!h) return ESVO_ERR_INVALID_ARG;
   API_LOCK(h);
   { int rcp = flush_pending_tick(h); if (rcp) return rcp; }
-  HIPCHK(hipStreamSynchronize(h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream_l)); HIPCHK(hipStreamSynchronize(h->stream_l1));
-  HIPCHK(hipStreamSynchronize(h->stream_b));
+  const bool poll = h->lat_last;  // latency mode (context.hpp): the caller waits for a tick that ran alone -- polled, not slept
+  HIPCHK(esvo_wait_stream(h->stream, poll));
+  HIPCHK(esvo_wait_stream(h->stream_l, poll)); HIPCHK(esvo_wait_stream(h->stream_l1, poll));
+  HIPCHK(esvo_wait_stream(h->stream_b, poll));
   return ESVO_OK;
 }
 

@@ -58,9 +58,9 @@ int run_bm(esvo_context* h, const esvo_event_t* d_ev, u64 first, u64 cap, int re
   a.pose_sec = h->d_pose_sec; a.n_pose = h->n_pose;
   a.out_slots = h->d_match_slots; a.out_flags = h->d_match_flags;
   a.fail_counters = h->d_counters;
-  hipEventRecord(h->evt[EV_BM0 + h->fpar * EV_FRONT_STRIDE], h->stream);
+  if (h->stage_events_on) hipEventRecord(h->evt[EV_BM0 + h->fpar * EV_FRONT_STRIDE], h->stream);
   launch_bm_match(a, h->dp, h->stream);
-  hipEventRecord(h->evt[EV_BM1 + h->fpar * EV_FRONT_STRIDE], h->stream);
+  if (h->stage_events_on) hipEventRecord(h->evt[EV_BM1 + h->fpar * EV_FRONT_STRIDE], h->stream);
   HIPCHK(hipGetLastError());
   return ESVO_OK;
 }
@@ -75,7 +75,7 @@ int run_order_matches(esvo_context* h, u32 n, bool local) {
     launch_compact_matches(h->d_match_slots, h->d_match_flags, h->d_match_prefix, n, h->d_matches, local ? h->d_own_w : nullptr,
                            h->stream);
   }
-  hipEventRecord(h->evt[EV_S1 + h->fpar * EV_FRONT_STRIDE], h->stream);
+  if (h->stage_events_on) hipEventRecord(h->evt[EV_S1 + h->fpar * EV_FRONT_STRIDE], h->stream);
   HIPCHK(hipGetLastError());
   return ESVO_OK;
 }
@@ -126,9 +126,10 @@ int run_lm(esvo_context* h, u32 max_matches, int cull, bool dense, hipStream_t s
   // launches of the throughput layout: persistent groups that pull matches from a counter (kernels_lm.hip); counters[11] is
   // zero at this point (a tick clears its counter row with the pose upload, run_refine clears it itself)
   if (h->lm_persist && !dense) { a.persist_next = h->d_counters + 11; a.persist_blocks = h->lm_persist_blocks; }
-  hipEventRecord(h->evt[EV_LM0 + h->fpar * EV_FRONT_STRIDE], st);
+  const bool timed_lm = h->stage_events_on || h->tk[h->fpar].timed_lm;
+  if (timed_lm) hipEventRecord(h->evt[EV_LM0 + h->fpar * EV_FRONT_STRIDE], st);
   launch_lm_refine(a, h->dp, h->d_counters + 2, st);
-  hipEventRecord(h->evt[EV_LM1 + h->fpar * EV_FRONT_STRIDE], st);
+  if (timed_lm) hipEventRecord(h->evt[EV_LM1 + h->fpar * EV_FRONT_STRIDE], st);
   HIPCHK(hipGetLastError());
   return ESVO_OK;
 }
@@ -138,12 +139,14 @@ int run_order_points(esvo_context* h, u32 max_matches, DevPoint* dst, hipStream_
   if (!st) st = h->stream;
   if (scan_compact_is_small(max_matches)) {
     // (the refinement kernel writes a flag for every slot of its launch, 0 beyond the match count: no count to clip to)
-    launch_scan_compact_points_small(h->d_pt_flags, h->d_pt_prefix, h->d_counters + 1, max_matches, h->d_pt_slots, dst, st);
+    launch_scan_compact_points_small(h->d_pt_flags, h->d_pt_prefix, h->d_counters + 1, max_matches, h->d_pt_slots, dst, st,
+                                     h->d_counters, h->cnt_row_host, h->cnt_row_host ? (u32)CNT_ROW : 0u);
+    h->cnt_row_sent = h->cnt_row_host != nullptr;
   } else {
     launch_exclusive_scan_u32(h->d_pt_flags, h->d_pt_prefix, h->d_counters + 1, scratch, max_matches, st);
     launch_compact_points(h->d_pt_slots, h->d_pt_flags, h->d_pt_prefix, h->d_counters + 0, max_matches, dst, st);
   }
-  hipEventRecord(h->evt[EV_S2 + h->fpar * EV_FRONT_STRIDE], st);
+  if (h->stage_events_on) hipEventRecord(h->evt[EV_S2 + h->fpar * EV_FRONT_STRIDE], st);
   HIPCHK(hipGetLastError());
   return ESVO_OK;
 }
@@ -193,6 +196,7 @@ void collect_back(esvo_context* h, int par) {
     h->halo_error = true;
   }
   if (h->prm.regularization) s.last_map_size = h->h_cnt_b[8 * par + 7];  // alive cells of the band (exports refresh it)
+  if (!h->back_timed[par]) return;  // latency mode: this back stage's timings were not sampled (context.hpp, lat_ticks)
   float fu = 0, cl = 0, rg = 0;
   hipEventElapsedTime(&fu, h->evt[EV_FU0 + o], h->evt[EV_FU1 + o]);
   hipEventElapsedTime(&cl, h->evt[EV_FU1 + o], h->evt[EV_CL1 + o]);
@@ -298,6 +302,18 @@ void apply_window_policy(esvo_context* h) {
   }
 }
 
+// latency mode (context.hpp, DeferredCopies): the copies a tick's back stage opens with, if run_fuse did not get to carry them in
+// its first launch (an error on the way), are enqueued the plain way -- the events behind them release buffers the next ticks wait for
+static int flush_deferred_copies(esvo_context* h) {
+  esvo_context::DeferredCopies d = h->pro;
+  h->pro = esvo_context::DeferredCopies();
+  if (!d.active) return ESVO_OK;
+  if (d.a_bytes) HIPCHK(hipMemcpyAsync(d.a_dst, d.a_src, d.a_bytes, hipMemcpyDeviceToDevice, h->stream_b));
+  if (d.ev_a >= 0) HIPCHK(hipEventRecord(h->evt[d.ev_a], h->stream_b));
+  if (d.b_bytes) HIPCHK(hipMemcpyAsync(d.b_dst, d.b_src, d.b_bytes, hipMemcpyDeviceToDevice, h->stream_b));
+  if (d.ev_b >= 0) HIPCHK(hipEventRecord(h->evt[d.ev_b], h->stream_b));
+  return ESVO_OK;
+}
 // pose table of the frame: from the host (stage-wise API) or, in a tick, the front stage's device table
 int commit_frame(esvo_context* h, u32 off, u32 count, const double* pose_T_host, u32 m, int pose_buf, bool apply_policy) {
   if (count == 0) {  // an empty frame: no pose table, no ring space; consecutive ones share a record
@@ -320,6 +336,9 @@ int commit_frame(esvo_context* h, u32 off, u32 count, const double* pose_T_host,
       std::memcpy(pin, pose_T_host, sizeof(double) * 16 * m);
       HIPCHK(hipMemcpyAsync(dst, pin, sizeof(double) * 16 * m, hipMemcpyHostToDevice, h->stream_b));
       HIPCHK(hipEventRecord(h->pool_evt[ps], h->stream_b));
+    } else if (h->pro.active) {  // latency mode: carried by run_fuse's first launch
+      h->pro.b_src = h->d_pose_T2[pose_buf]; h->pro.b_dst = dst; h->pro.b_bytes = sizeof(double) * 16 * m;
+      h->pro.ev_b = EV_POSE + pose_buf * EV_BACK_STRIDE;
     } else {
       HIPCHK(hipMemcpyAsync(dst, h->d_pose_T2[pose_buf], sizeof(double) * 16 * m, hipMemcpyDeviceToDevice, h->stream_b));
       HIPCHK(hipEventRecord(h->evt[EV_POSE + pose_buf * EV_BACK_STRIDE], h->stream_b));
@@ -342,7 +361,7 @@ int run_fuse(esvo_context* h, int par, const double* T_world_obs, bool naive) {
   u32 nf = 0;
   for (size_t q = h->frames.size(); q-- > 0;)
     if (h->frames[q].count) ++nf;  // empty frames contribute no point (DepthFusion::update loops over none)
-  if (nf > h->max_frames) FAIL(ESVO_ERR_CAPACITY, "too many non-empty frames in the fusion window");
+  if (nf > h->max_frames) { (void)flush_deferred_copies(h); FAIL(ESVO_ERR_CAPACITY, "too many non-empty frames in the fusion window"); }
   u32* cum = host;
   u32* off = host + (nf + 1);
   u32* slot = off + nf;
@@ -356,8 +375,18 @@ int run_fuse(esvo_context* h, int par, const double* T_world_obs, bool naive) {
   }
   cum[nf] = total;
   hipStream_t sb = h->stream_b;
+  int tail_ev[2] = {-1, -1};
   u32* dtab = h->d_fr_table + (size_t)par * tab;
-  launch_upload_words(host, dtab, sizeof(u32) * (3 * (size_t)nf + 1), sb);
+  if (h->pro.active) {  // latency mode: the frame's points and its pose table travel with the table (one launch, not three operations)
+    const esvo_context::DeferredCopies d = h->pro;
+    h->pro = esvo_context::DeferredCopies();
+    launch_back_prologue(host, dtab, sizeof(u32) * (3 * (size_t)nf + 1), d.a_src, d.a_dst, d.a_bytes, d.b_src, d.b_dst, d.b_bytes, sb);
+    // "staging buffer / pose table free again": recorded at the END of this back stage, not here between two dependent launches
+    // (~5 us each); who waits for them -- the front stage two ticks on -- comes long after either point
+    tail_ev[0] = d.ev_a; tail_ev[1] = d.ev_b;
+  } else {
+    launch_upload_words(host, dtab, sizeof(u32) * (3 * (size_t)nf + 1), sb);
+  }
   std::memcpy(h->T_world_frame, T_world_obs, sizeof(double) * 16);  // new DepthFrame at the TS pose (:268-272)
   FuseArgs a;
   a.win = h->d_win;
@@ -377,16 +406,21 @@ int run_fuse(esvo_context* h, int par, const double* T_world_obs, bool naive) {
   a.naive = naive ? 1 : 0;
   a.owner_max = h->prm.regularization ? h->d_owner_max : nullptr;
   a.owner_min = h->d_owner_min; a.n_reg_elems = h->prm.regularization ? h->d_cnt_b + 7 : nullptr;
-  if (total > h->win_cap) FAIL(ESVO_ERR_CAPACITY, "window points exceed capacity");
+  if (total > h->win_cap) {
+    for (int e : tail_ev) if (e >= 0) hipEventRecord(h->evt[e], sb);
+    FAIL(ESVO_ERR_CAPACITY, "window points exceed capacity");
+  }
   const int o = par * EV_BACK_STRIDE;
-  hipEventRecord(h->evt[EV_FU0 + o], sb);
+  const bool timed = h->stage_events_on;
+  h->back_timed[par] = timed;
+  if (timed) hipEventRecord(h->evt[EV_FU0 + o], sb);
   launch_fuse(a, h->dp, sb);
-  hipEventRecord(h->evt[EV_FU1 + o], sb);
+  if (timed) hipEventRecord(h->evt[EV_FU1 + o], sb);
   h->d_map_cur = h->d_map;
   // (naive propagation, esvo_MVStereo.cpp:416-428: the map is published as it is, neither cleaned nor regularised)
   const bool do_clean = naive ? false : (h->prm.clean_requires_full_window ? (h->n_window_frames >= (size_t)h->prm.max_fusion_frames) : true);
   if (do_clean) launch_clean(h->d_map, h->dp, sb);
-  hipEventRecord(h->evt[EV_CL1 + o], sb);
+  if (timed) hipEventRecord(h->evt[EV_CL1 + o], sb);
   if (h->prm.regularization && !naive) {
     launch_reg_view(h->d_map, h->d_map2, h->d_owner_max, h->d_owner_min, h->d_reg_ab, h->d_reg_cd, h->d_cnt_b + 7, h->dp, sb);
     launch_reg_apply(h->d_map, h->d_map2, h->d_owner_max, h->d_owner_min, h->d_reg_ab, h->d_reg_cd, h->dp, sb);
@@ -395,6 +429,7 @@ int run_fuse(esvo_context* h, int par, const double* T_world_obs, bool naive) {
   HIPCHK(hipMemcpyAsync(h->h_cnt_b + 8 * par, h->d_cnt_b, sizeof(u32) * 8, hipMemcpyDeviceToHost, sb));
   if (h->routed) HIPCHK(hipMemcpyAsync(h->h_cnt_b + 8 * 3 + par, h->d_halo_viol, sizeof(u32), hipMemcpyDeviceToHost, sb));
   hipEventRecord(h->evt[EV_RG1 + o], sb);  // also "back stage of this parity done"
+  for (int e : tail_ev) if (e >= 0) hipEventRecord(h->evt[e], sb);
   HIPCHK(hipGetLastError());
   h->back_pending[par] = true;
   return ESVO_OK;
@@ -795,6 +830,13 @@ int tick_phase0(esvo_context* h, uint64_t t_ns, const uint64_t* pose_t_ns, const
   tk.n_loc = n_loc; tk.n_own = n_own; tk.g_first = g_first;
   tk.lm_stream = tk.cnt_stream = h->stream;
   tk.lm_pair = -1;
+  // latency mode: nothing of an earlier tick is pending, so this tick has nothing to run beside -- its LM launch stays in the front
+  // queue (one cross-queue hand-off less on the path the caller waits for), the host polls for its counters and its end, and its
+  // stage timings are sampled, not recorded tick by tick (context.hpp)
+  tk.lat = h->lat_now && !h->sharded && n && n <= h->lat_max_events;
+  tk.timed = !tk.lat || esvo_stage_timed(h);
+  tk.timed_lm = tk.timed;
+  h->stage_events_on = tk.timed;  // (esvo_map_tick's scope switches it back on)
   tk.obs_par = h->obs_par;
   tk.pose_buf = h->pose_buf; tk.n_pose = h->n_pose;
   std::memcpy(tk.T_world_obs, h->T_world_obs, sizeof(double) * 16);
@@ -805,7 +847,7 @@ int tick_phase0(esvo_context* h, uint64_t t_ns, const uint64_t* pose_t_ns, const
   // round 5 (ESVO_FRONT_THROTTLE=1 restores it): it ties every front stage to the END of a back stage, which is what makes a
   // lagging back chain stay behind -- see pipeline_resync.  Sharded ticks keep it: their frame goes straight into the ring.)
   if (h->sharded || h->front_throttle) HIPCHK(hipStreamWaitEvent(h->stream, h->evt[EV_RG1 + h->par * EV_BACK_STRIDE], 0));
-  hipEventRecord(h->evt[EV_T0 + h->fpar * EV_FRONT_STRIDE], h->stream);
+  if (tk.timed) hipEventRecord(h->evt[EV_T0 + h->fpar * EV_FRONT_STRIDE], h->stream);
   const u32* sel = nullptr;
   if (h->prm.denoising && n && !h->routed) {
     // Denoising (esvo_Mapping.cpp:282-296): mask from the selected events, keep those on it, in order.
@@ -826,7 +868,7 @@ int tick_phase0(esvo_context* h, uint64_t t_ns, const uint64_t* pose_t_ns, const
     rc = run_order_matches(h, n, false);
     if (rc) return rc;
     hipStream_t sl = h->stream;
-    if (h->split_now) {  // the LM stage on its own stream, behind this tick's matches
+    if (h->split_now && !tk.lat) {  // the LM stage on its own stream, behind this tick's matches
       HIPCHK(hipEventRecord(h->evt[EV_A1 + h->fpar * EV_FRONT_STRIDE], h->stream));
       // launches in the latency-bound (wide) layout alternate between the two LM queues; the split launch's scratch and
       // the throughput layout (which fills the chip by itself) stay on one
@@ -848,9 +890,11 @@ int tick_phase0(esvo_context* h, uint64_t t_ns, const uint64_t* pose_t_ns, const
     // ~40 us of small dependent launches at the head of the stream that paces the pipeline.
     // (only while ticks overlap -- the previous one is still pending: a tick that is waited for gains nothing from it and would pay
     //  one more cross-queue hand-off)
-    if (h->collect_aside && h->split_now && h->tick_pending && (sl == h->stream_l || sl == h->stream_l1) && !h->lm_two_now)
+    if (h->collect_aside && h->split_now && !tk.lat && h->tick_pending && (sl == h->stream_l || sl == h->stream_l1) && !h->lm_two_now)
       tk.cnt_stream = sl == h->stream_l ? h->stream_l1 : h->stream_l;
     tk.lm_pair = lm_pair_policy(h, n);
+    // (the layout policy's feedback is the LM launch time: sampled ticks aside, whenever it explores or tries the other layout)
+    if (tk.lm_pair >= 0 && h->lm_pair_forced < 0 && tk.lm_pair != h->lm_pair_current) tk.timed_lm = true;
     rc = run_lm(h, n, 1, false, sl, tk.lm_pair);
     if (rc) return rc;
   } else if (n && h->routed) {
@@ -902,7 +946,11 @@ int tick_phase1_enqueue(esvo_context* h) {
     // buffer's previous frame (two ticks ago) has been copied into the ring by then
     if (tk.cnt_stream != tk.lm_stream) HIPCHK(hipStreamWaitEvent(tk.cnt_stream, h->evt[EV_LM1 + h->fpar * EV_FRONT_STRIDE], 0));
     HIPCHK(hipStreamWaitEvent(tk.cnt_stream, h->evt[EV_STG + h->fpar * EV_FRONT_STRIDE], 0));
+    // latency mode: the compaction kernel leaves the counter row in the pinned host row itself (no copy operation behind it)
+    h->cnt_row_host = tk.lat ? h->h_counters + CNT_ROW * h->fpar : nullptr;
+    h->cnt_row_sent = false;
     rc = run_order_points(h, n, h->d_stage[h->fpar], tk.cnt_stream);
+    h->cnt_row_host = nullptr;
     if (rc) return rc;
   } else if (n) {
     const u32 N = (u32)h->dp.ev_nshards, r = (u32)h->dp.ev_shard, T = (u32)h->dp.num_threads;
@@ -930,7 +978,9 @@ int tick_phase1_enqueue(esvo_context* h) {
     HIPCHK(hipGetLastError());
   }
   hipStream_t sc = (n && !h->sharded) ? tk.cnt_stream : h->stream;
-  HIPCHK(hipMemcpyAsync(h->h_counters + CNT_ROW * h->fpar, h->d_counters, sizeof(u32) * CNT_ROW, hipMemcpyDeviceToHost, sc));
+  if (!(n && !h->sharded && h->cnt_row_sent))
+    HIPCHK(hipMemcpyAsync(h->h_counters + CNT_ROW * h->fpar, h->d_counters, sizeof(u32) * CNT_ROW, hipMemcpyDeviceToHost, sc));
+  h->cnt_row_sent = false;
   HIPCHK(hipEventRecord(h->evt[EV_CNT + h->fpar * EV_FRONT_STRIDE], sc));
   h->tick_pending = true;
   return ESVO_OK;
@@ -945,7 +995,7 @@ int tick_phase1_collect(esvo_context* h, int fp) {
 // own ticks later has been enqueued on the same parity
 int collect_front_stats(esvo_context* h, esvo_context::TickState& tk, const u32* cnt, const hipEvent_t* ev) {
   auto E = [&](int id) { return ev[id - EV_T0]; };
-  HIPCHK(hipEventSynchronize(E(EV_CNT)));
+  HIPCHK(esvo_wait_event(E(EV_CNT), tk.lat));
   const u32 n = tk.n;
   const u32 n_points = n ? cnt[1] : 0;
   esvo_stats_t& s = h->stats;
@@ -958,9 +1008,21 @@ int collect_front_stats(esvo_context* h, esvo_context::TickState& tk, const u32*
   s.total_points += n_points;
   collect_bm_failures(h, cnt, true);
   tk.points = n_points;
-  s.ms_bm = s.ms_refine = 0;
-  s.ms_kernel[2] = s.ms_kernel[3] = 0;
-  if (n) {
+  if (tk.timed) {
+    s.ms_bm = s.ms_refine = 0;
+    s.ms_kernel[2] = s.ms_kernel[3] = 0;
+  }
+  if (n && !tk.timed && tk.timed_lm && tk.lm_pair >= 0) {  // an unsampled tick whose LM launch was timed for the layout policy alone
+    float lm = 0.f;
+    if (hipEventElapsedTime(&lm, E(EV_LM0), E(EV_LM1)) == hipSuccess && lm > 0.f) {
+      h->lm_pair_ms[tk.lm_pair][h->lm_pair_n[tk.lm_pair] & 3u] = lm;
+      h->lm_pair_n[tk.lm_pair]++;
+    } else {
+      (void)hipGetLastError();
+    }
+  }
+  if (n && tk.timed) {
+    s.stage_timing_samples++;
     hipEventElapsedTime(&s.ms_bm, E(EV_T0), E(EV_S1));
     hipEventElapsedTime(&s.ms_refine, E(EV_S1), E(EV_S2));
     hipEventElapsedTime(&s.ms_kernel[2], E(EV_BM0), E(EV_BM1));
@@ -973,7 +1035,7 @@ int collect_front_stats(esvo_context* h, esvo_context::TickState& tk, const u32*
       h->lm_pair_n[tk.lm_pair]++;
     }
   }
-  if (h->tl_on && h->tl_ref && n) {
+  if (h->tl_on && h->tl_ref && n && tk.timed) {
     const int fr[8] = {EV_T0, EV_BM0, EV_BM1, EV_S1, EV_LM0, EV_LM1, EV_S2, EV_CNT};
     std::array<float, 8> row;
     for (int i = 0; i < 8; ++i) { row[i] = -1.f; if (hipEventElapsedTime(&row[i], h->tl_ref, E(fr[i])) != hipSuccess) (void)hipGetLastError(); }
@@ -1057,14 +1119,24 @@ int tick_phase2(esvo_context* h, int fp) {
   if (!h->sharded) {  // now that the size is known: exact ring space, frame copied behind the fusion that may still read it
     rc = window_reserve(h, tk.points, &tk.off);
     if (rc) return rc;
-    if (tk.points)
-      HIPCHK(hipMemcpyAsync(h->d_win + tk.off, h->d_stage[fp], sizeof(DevPoint) * tk.points, hipMemcpyDeviceToDevice, h->stream_b));
-    HIPCHK(hipEventRecord(h->evt[EV_STG + fp * EV_FRONT_STRIDE], h->stream_b));
+    if (tk.lat) {  // latency mode: the copy rides on run_fuse's first launch (context.hpp, DeferredCopies)
+      h->pro = esvo_context::DeferredCopies();
+      h->pro.active = true;
+      h->pro.a_src = h->d_stage[fp]; h->pro.a_dst = h->d_win + tk.off; h->pro.a_bytes = sizeof(DevPoint) * tk.points;
+      h->pro.ev_a = EV_STG + fp * EV_FRONT_STRIDE;
+    } else {
+      if (tk.points)
+        HIPCHK(hipMemcpyAsync(h->d_win + tk.off, h->d_stage[fp], sizeof(DevPoint) * tk.points, hipMemcpyDeviceToDevice, h->stream_b));
+      HIPCHK(hipEventRecord(h->evt[EV_STG + fp * EV_FRONT_STRIDE], h->stream_b));
+    }
   }
   rc = commit_frame(h, tk.off, tk.points, nullptr, tk.n_pose, tk.pose_buf);
-  if (rc) return rc;
-  rc = run_fuse(h, par, tk.T_world_obs);
-  if (rc) return rc;
+  if (rc) { (void)flush_deferred_copies(h); return rc; }
+  {
+    StageEventsScope timed_scope(h, tk.timed);
+    rc = run_fuse(h, par, tk.T_world_obs);
+  }
+  if (rc) { (void)flush_deferred_copies(h); return rc; }
   h->stats.ticks++;
   h->stats.last_window_frames = (u32)h->n_window_frames;
   u32 np = 0;
@@ -1091,13 +1163,14 @@ int finalize_tick_stats(esvo_context* h) {
   if (!h->stats_pending && !h->back_pending[0] && !h->back_pending[1]) return ESVO_OK;
   const bool tick_done = h->stats_pending;
   h->stats_pending = false;
-  HIPCHK(hipStreamSynchronize(h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream_l)); HIPCHK(hipStreamSynchronize(h->stream_l1));
-  HIPCHK(hipStreamSynchronize(h->stream_b));
+  const bool poll = h->lat_last;  // the newest tick ran in latency mode: somebody is waiting for exactly this
+  HIPCHK(esvo_wait_stream(h->stream, poll));
+  HIPCHK(esvo_wait_stream(h->stream_l, poll)); HIPCHK(esvo_wait_stream(h->stream_l1, poll));
+  HIPCHK(esvo_wait_stream(h->stream_b, poll));
   collect_ts_timing(h);
   collect_back(h, h->par);
   collect_back(h, h->par ^ 1);
-  if (tick_done) hipEventElapsedTime(&h->stats.ms_tick_total, h->evt[EV_T0 + h->fpar * EV_FRONT_STRIDE], h->evt[EV_RG1 + (h->par ^ 1) * EV_BACK_STRIDE]);
+  if (tick_done && h->tk[h->fpar].timed && h->back_timed[h->par ^ 1]) hipEventElapsedTime(&h->stats.ms_tick_total, h->evt[EV_T0 + h->fpar * EV_FRONT_STRIDE], h->evt[EV_RG1 + (h->par ^ 1) * EV_BACK_STRIDE]);
   return ESVO_OK;
 }
 }  // namespace esvo_host
@@ -1138,9 +1211,16 @@ extern "C" int esvo_map_tick(esvo_handle h, uint64_t t_ns, const uint64_t* pose_
   const bool prev = h->tick_pending;
   const int prev_fp = h->fpar;
   h->split_now = h->lm_split && !h->prm.denoising;
+  h->lat_now = h->lat_mode && !prev;
   int rc = tick_phase0(h, t_ns, pose_t_ns, pose_T, m);
   if (!rc) rc = tick_phase1_enqueue(h);
   h->split_now = false;
+  h->lat_now = false;
+  h->stage_events_on = true;
+  if (!rc) {
+    h->lat_last = h->tk[h->fpar].lat;
+    if (!prev) h->lat_ticks++;
+  }
   if (rc) {  // the failed tick leaves no trace: the previous one (if pending) stays pending on ITS parity and is
     h->fpar = prev_fp;  // completed -- with its own counters and staging buffer -- by the next call that needs it
     return rc;

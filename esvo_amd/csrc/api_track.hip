@@ -28,6 +28,9 @@ int esvo_track_set_current(esvo_handle h, const uint8_t* ts_left, int kernel_siz
     // is enqueued behind the newest render (EV_R1) and marked, under mu_ts, so that the next render queues behind it.
     std::lock_guard<std::mutex> lt(h->mu_ts);
     if (!h->ts_valid[0]) FAIL(ESVO_ERR_STATE, "no device-resident left Time Surface: call esvo_ts_render(h, 0, ...) first");
+    // (a render that runs alone records EV_R1 only once the tracker has shown up -- context.hpp, trk_used; renders are enqueued
+    //  under mu_ts, held here: the first call drains the front stream instead, every later render has recorded the event)
+    if (!h->trk_used.exchange(true)) HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipStreamWaitEvent(h->stream_t, h->evt[EV_R1], 0));  // the render of camera 0 on the front stream
     if (kernel_size == 5) launch_gaussian5(src, h->d_trk_blur, h->W, h->H, h->stream_t);
     else HIPCHK(hipMemcpyAsync(h->d_trk_blur, src, npx, hipMemcpyDeviceToDevice, h->stream_t));
@@ -183,10 +186,12 @@ int esvo_track_normal_equations_batch(esvo_handle h, int n_poses, const double* 
     pose.T[15] = 1.0;
     for (int r = 0; r < 3; ++r) { pose.Jc[r * 2 + 0] = Rq[0 * 3 + r] * iP11; pose.Jc[r * 2 + 1] = Rq[1 * 3 + r] * iP22; }
   }
-  launch_track_normal(a, set, n_poses, (u32)offset, (u32)m, ls_norm == ESVO_TRACK_HUBER, huber_threshold, h->d_trk_out, h->stream_t);
+  // The kernel's one write per pose (28 sums) goes straight into the pinned host row -- no copy operation behind the launch -- and the
+  // host polls for the end of the launch (10-20 us of kernel: sleeping on the completion interrupt would cost as much again).  One
+  // of these round trips per iteration is the whole latency of the tracker's loop.
+  launch_track_normal(a, set, n_poses, (u32)offset, (u32)m, ls_norm == ESVO_TRACK_HUBER, huber_threshold, h->h_trk_ne, h->stream_t);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(h->h_trk_ne, h->d_trk_out, sizeof(double) * TRK_NE_TERMS * n_poses, hipMemcpyDeviceToHost, h->stream_t));
-  HIPCHK(hipStreamSynchronize(h->stream_t));
+  HIPCHK(esvo_wait_stream(h->stream_t, true));
   h->trk_xyz_inflight = false;
   for (int q = 0; q < n_poses; ++q) {
     const double* s = h->h_trk_ne + (size_t)q * TRK_NE_TERMS;

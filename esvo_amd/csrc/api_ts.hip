@@ -131,6 +131,8 @@ void queue_prepare(esvo_context* h, int cam, u64 t_ns) {
 // Both cameras' surfaces at t_ns with one launch per kernel (scatter segments, decay, median + remap): what two
 // esvo_ts_render calls do, in four launches less.  obs_out[cam] (may be null) receives a second copy of the surface.
 int ts_render_pair(esvo_context* h, uint64_t t_ns, uint8_t* const obs_out[2]) {
+  // stage timings of a render that runs alone are sampled (context.hpp, lat_ticks): each event costs the queue ~5 us
+  const bool timed = esvo_stage_timed(h);
   {
     std::lock_guard<std::mutex> lr(h->mu_ring);  // what a pusher on another thread reads and writes (context.hpp)
     ingest_fence(h, 0);
@@ -145,7 +147,7 @@ int ts_render_pair(esvo_context* h, uint64_t t_ns, uint8_t* const obs_out[2]) {
     }
     for (int cam = 0; cam < 2; ++cam)
       if (h->ts_timing_pending[cam] && hipEventQuery(h->evt[EV_R1 + cam * EV_TS_STRIDE]) == hipSuccess) collect_ts_timing(h, cam);
-    hipEventRecord(h->evt[EV_SC0], h->stream);
+    if (timed) hipEventRecord(h->evt[EV_SC0], h->stream);
     TsScatterSegs g;
     int n_seg = 0;
     if (h->tsq_len) { queue_prepare(h, 0, (u64)t_ns); queue_prepare(h, 1, (u64)t_ns); }
@@ -169,7 +171,7 @@ int ts_render_pair(esvo_context* h, uint64_t t_ns, uint8_t* const obs_out[2]) {
       h->scattered[cam] = upto[cam];
     }
     launch_ts_scatter_segs(g, n_seg, h->W, h->H, h->stream);
-    hipEventRecord(h->evt[EV_SC1], h->stream);
+    if (timed) hipEventRecord(h->evt[EV_SC1], h->stream);
   }
   TsPair c;
   for (int cam = 0; cam < 2; ++cam) {
@@ -183,12 +185,12 @@ int ts_render_pair(esvo_context* h, uint64_t t_ns, uint8_t* const obs_out[2]) {
     // (a routed band handle renders the rows of its band + halo only: h->rband_*, whole tiles)
     launch_ts_render_pair(c, h->W, h->H, (u64)t_ns, h->prm.decay_ms / 1000.0, h->prm.ignore_polarity, h->prm.median_blur_kernel_size,
                           h->stream, h->routed ? h->rband_y0 : 0, h->routed ? h->rband_y1 : -1);
-    hipEventRecord(h->evt[EV_R1], h->stream);
+    if (timed || h->trk_used.load()) hipEventRecord(h->evt[EV_R1], h->stream);  // (also what esvo_track_set_current waits for)
     HIPCHK(hipGetLastError());
     h->ts_valid[0] = h->ts_valid[1] = true;
   }
-  h->ts_timing_pending[0] = true;
-  h->ts_pair_sample = true;
+  h->ts_timing_pending[0] = timed;
+  h->ts_pair_sample = timed;
   h->stats.ts_frames[0]++;
   h->stats.ts_frames[1]++;
   return ESVO_OK;
@@ -730,6 +732,7 @@ int esvo_ts_render(esvo_handle h, int cam, uint64_t t_ns, uint8_t* out_mono8) {
   API_LOCK(h);
   HIPCHK(hipSetDevice(h->device));
   const int evo = cam * EV_TS_STRIDE;
+  const bool timed = esvo_stage_timed(h);  // sampled for renders that run alone (context.hpp, lat_ticks)
   {
     std::lock_guard<std::mutex> lr(h->mu_ring);
     ingest_fence(h, cam);
@@ -742,7 +745,7 @@ int esvo_ts_render(esvo_handle h, int cam, uint64_t t_ns, uint8_t* out_mono8) {
     if (!h->tsq_len && upto < h->scattered[cam])
       FAIL(ESVO_ERR_STATE, "esvo_ts_render: t_ns precedes events of an earlier render (render times must not decrease; esvo_reset to replay)");
     if (h->ts_timing_pending[cam] && hipEventQuery(h->evt[EV_R1 + evo]) == hipSuccess) collect_ts_timing(h, cam);
-    hipEventRecord(h->evt[EV_SC0 + evo], h->stream);
+    if (timed) hipEventRecord(h->evt[EV_SC0 + evo], h->stream);
     if (h->tsq_len) queue_prepare(h, cam, (u64)t_ns);
     else if (upto > h->scattered[cam]) {
       u64 a = h->scattered[cam];
@@ -758,7 +761,7 @@ int esvo_ts_render(esvo_handle h, int cam, uint64_t t_ns, uint8_t* out_mono8) {
       h->scattered[cam] = upto;
       h->stats.events_scattered[cam] += total;
     }
-    hipEventRecord(h->evt[EV_SC1 + evo], h->stream);
+    if (timed) hipEventRecord(h->evt[EV_SC1 + evo], h->stream);
   }
   {
     std::lock_guard<std::mutex> lt(h->mu_ts);
@@ -766,11 +769,11 @@ int esvo_ts_render(esvo_handle h, int cam, uint64_t t_ns, uint8_t* out_mono8) {
     launch_ts_render(h->d_sae[cam], h->d_fixmap[cam], h->d_raw, h->d_ts[cam], h->W, h->H, (u64)t_ns, h->prm.decay_ms / 1000.0,
                      h->prm.ignore_polarity, h->prm.median_blur_kernel_size, h->stream, h->routed ? h->rband_y0 : 0,
                      h->routed ? h->rband_y1 : -1);
-    hipEventRecord(h->evt[EV_R1 + evo], h->stream);
+    if (timed || (cam == 0 && h->trk_used.load())) hipEventRecord(h->evt[EV_R1 + evo], h->stream);
     HIPCHK(hipGetLastError());
     h->ts_valid[cam] = true;
   }
-  h->ts_timing_pending[cam] = true;
+  h->ts_timing_pending[cam] = timed;
   h->stats.ts_frames[cam]++;
   if (out_mono8) {
     HIPCHK(hipMemcpyAsync(out_mono8, h->d_ts[cam], (size_t)h->W * h->H, hipMemcpyDeviceToHost, h->stream));

@@ -177,10 +177,14 @@ size_t scan_scratch_elems(size_t n);
 bool scan_compact_is_small(size_t n);
 void launch_scan_compact_matches_small(const u32* flags, u32* prefix, u32* d_total, size_t n, const esvo_match_t* slots,
                                        esvo_match_t* out, u32* slot_of, hipStream_t s);
+// (row_host, nullable: the device counter row `d_total` belongs to -- row_src, row_n words -- lands in that pinned host row as well)
 void launch_scan_compact_points_small(const u32* flags, u32* prefix, u32* d_total, size_t n, const esvo_depth_point_t* slots,
-                                      esvo_depth_point_t* out, hipStream_t s);
+                                      esvo_depth_point_t* out, hipStream_t s, const u32* row_src = nullptr, u32* row_host = nullptr,
+                                      u32 row_n = 0);
 // upload of a small pinned host buffer by a kernel (never blocks the host; scan.hip)
 void launch_upload_words(const void* pinned_src, void* d_dst, size_t bytes, hipStream_t s, u32* d_zero = nullptr, u32 n_zero = 0);
+void launch_back_prologue(const void* pinned_src, void* d_dst, size_t bytes, const void* a_src, void* a_dst, size_t a_bytes,
+                          const void* b_src, void* b_dst, size_t b_bytes, hipStream_t s);
 
 // An event that arrived OUT OF ORDER (its stamp below the newest stamp staged before it) keeps its sorted place in the ring -- the
 // mapper's queue is insertion-sorted, esvo_Mapping.cpp:692-702 -- but never reaches the Time Surface: TimeSurface::eventsCallback

@@ -9,6 +9,8 @@
 #pragma once
 #include <algorithm>
 #include <array>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -82,6 +84,35 @@ struct esvo_context {
   struct Resync { double last_ms = 0; float period_ema = 0, period_before = 0; u32 streak = 0, cooldown = 0, check_in = 0; bool lm_wait_back = false; } resync;
   bool front_throttle = false;   // ESVO_FRONT_THROTTLE=1 (A/B): an unsharded tick's front stage waits for the back stage two ticks ago (api_map.hip; the default until round 4)
   bool split_now = false;         // set by esvo_map_tick around its front stage: only the lazy tick path splits
+  // Latency mode (round 6, api_map.hip): a tick that arrives while nothing of the previous one is pending -- the caller reads every
+  // tick's result before it hands in the next, as the ROS node does -- has nothing to overlap with.  Its LM launch stays in the
+  // front queue (no cross-queue hand-off: ~25 us) and the host polls for its counters and its end instead of sleeping on the
+  // completion interrupt (~10-20 us per wake-up), for ticks of at most lat_max_events events.  ESVO_LOWLAT=0 (A/B) switches it off.
+  bool lat_mode = true;
+  bool lat_now = false;           // set by esvo_map_tick around its front stage
+  bool lat_last = false;          // the newest tick was enqueued in latency mode (what synchronising calls look at)
+  u32 lat_max_events = 40000u;
+  // Stage timings are SAMPLED on that path.  Every hipEventRecord between two dependent kernels costs the queue ~5 us (a marker
+  // packet the next dispatch waits for: kernels with no event between them follow each other with no gap at all --
+  // profiles/r06_lowlat_tick.txt), and a tick recorded fourteen of them for nothing but esvo_stats_t's ms_* fields.  A tick that
+  // runs alone records them for its first 8 ticks and for one tick in lat_timed_every afterwards; ms_* / ms_kernel[] hold the latest
+  // sample, sum_ms_kernel[] sums the samples, stats.stage_timing_samples counts them.  The LM layout policy (lm_pair_*) lives on LM
+  // launch times: the two events around the LM launch are recorded as well whenever the policy is exploring or trying the layout it
+  // is not using (TickState::timed_lm).  Ticks that overlap (the throughput path) record all of them as before.
+  u32 lat_ticks = 0;              // ticks enqueued with nothing pending before them
+  u32 lat_timed_every = 31;       // ESVO_LOWLAT_TIMED_EVERY (A/B; 1 = every tick)
+  u32* cnt_row_host = nullptr;    // latency mode: where the tick's point compaction leaves the counter row (null: a copy follows)
+  bool cnt_row_sent = false;
+  bool stage_events_on = true;    // false while a tick whose stage timings are not sampled is being enqueued (api_map.hip)
+  bool back_timed[2] = {true, true};  // the back stage of that parity recorded its stage events
+  std::atomic<bool> trk_used{false};  // esvo_track_set_current has read the resident surface: renders record EV_R1 for it
+  // ... and the copies that open its back stage (frame into the ring, pose table into the frame's slot) are not enqueued one by one
+  // but handed to run_fuse, whose frame-table upload carries them in the same launch (scan.hip, back_prologue_kernel)
+  struct DeferredCopies {
+    bool active = false;
+    const void* a_src = nullptr; void* a_dst = nullptr; size_t a_bytes = 0; int ev_a = -1;  // frame points; event recorded behind it
+    const void* b_src = nullptr; void* b_dst = nullptr; size_t b_bytes = 0; int ev_b = -1;  // pose table
+  } pro;
   uint8_t* d_obs2[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
   int obs_par = 0;
   esvo_match_t* d_matches2[2] = {nullptr, nullptr};
@@ -303,6 +334,9 @@ struct esvo_context {
     hipStream_t cnt_stream = nullptr; // where its frame (point compaction) and counters follow: the same, or the idle second LM queue
     int obs_par = 0;                  // which observation pair it reads
     int lm_pair = -1;                 // LM layout of the tick: 1 pair, 0 wide, -1 not a candidate (policy feedback)
+    bool lat = false;                 // enqueued in latency mode: LM in the front queue, polled waits
+    bool timed = true;                // its stage-timing events were recorded
+    bool timed_lm = true;             // ... at least the two around the LM launch (the layout policy's feedback)
   } tk[2];
   // pair layout of the LM kernel (kernels_lm.hip): chosen per tick from the LM launch times the handle measures anyway
   // (HIP events).  The first eight candidate ticks alternate between the layouts, then the faster one is used, with one tick
@@ -432,6 +466,48 @@ using namespace esvo_host;
       return ESVO_ERR_HIP;                                                                        \
     }                                                                                             \
   } while (0)
+
+// Polled waits (latency mode, api_map.hip): hipEventQuery / hipStreamQuery in a loop for at most `budget_us`, then the blocking
+// call.  The blocking calls sleep on the completion interrupt (10-20 us from the signal to the woken thread); a tick the caller
+// waits for pays that twice (counters, end of tick).  "Not ready" is an error code the runtime remembers: it is cleared here, or
+// the next hipGetLastError() behind a launch would report it.
+inline hipError_t esvo_wait_event(hipEvent_t e, bool poll, double budget_us = 3000.0) {
+  if (poll) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+      const hipError_t q = hipEventQuery(e);
+      if (q == hipSuccess) return q;
+      (void)hipGetLastError();
+      if (q != hipErrorNotReady) return q;
+      if (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > budget_us) break;
+    }
+  }
+  return hipEventSynchronize(e);
+}
+inline hipError_t esvo_wait_stream(hipStream_t s, bool poll, double budget_us = 3000.0) {
+  if (poll) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+      const hipError_t q = hipStreamQuery(s);
+      if (q == hipSuccess) return q;
+      (void)hipGetLastError();
+      if (q != hipErrorNotReady) return q;
+      if (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > budget_us) break;
+    }
+  }
+  return hipStreamSynchronize(s);
+}
+
+struct StageEventsScope {  // stage-timing events off (or on) for the calls of one scope, back on at its end whatever the exit
+  esvo_context* h;
+  StageEventsScope(esvo_context* hh, bool on) : h(hh) { h->stage_events_on = on; }
+  ~StageEventsScope() { h->stage_events_on = true; }
+};
+// whether the operations enqueued NOW (renders, a tick's stages) record their stage-timing events (context.hpp, lat_ticks)
+inline bool esvo_stage_timed(const esvo_context* h) {
+  if (!h->lat_mode || h->tick_pending || h->tl_on || h->sharded || h->comm) return true;
+  return h->lat_ticks < 8u || h->lat_ticks % h->lat_timed_every == 0u;
+}
 
 #define ESVO_SET_ERR(msg) (esvo_host::g_create_error = (msg))
 #define API_LOCK(h) std::lock_guard<std::recursive_mutex> _api_lock((h)->mu_api)

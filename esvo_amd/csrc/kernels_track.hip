@@ -201,7 +201,10 @@ __global__ void __launch_bounds__(TRK_NE_THREADS) track_normal_kernel(TrackArgs 
       for (int n = 0; n < TRK_NE_TERMS; ++n) red[n][threadIdx.x] = red[n][threadIdx.x] + red[n][threadIdx.x + s];
   }
   __syncthreads();
-  if (threadIdx.x < TRK_NE_TERMS) out[threadIdx.x] = red[threadIdx.x][0];
+  if (threadIdx.x < TRK_NE_TERMS) {
+    out[threadIdx.x] = red[threadIdx.x][0];
+    __threadfence_system();  // `out` may be pinned host memory the caller polls the stream for (api_track.hip)
+  }
 }
 void launch_track_normal(const TrackArgs& a, const TrackPoseSet& poses, int n_poses, u32 offset, u32 count, int huber, double thr,
                          double* out, hipStream_t s) {

@@ -103,7 +103,8 @@ __global__ void __launch_bounds__(SCAN_SB) scan_small_kernel(In in, u32* __restr
 template <class Rec, bool SEQ>
 __global__ void __launch_bounds__(SCAN_SB) scan_compact_small_kernel(const u32* __restrict__ flags, u32* __restrict__ prefix,
                                                                      u32* __restrict__ total, size_t n, const Rec* __restrict__ slots,
-                                                                     Rec* __restrict__ out, u32* __restrict__ slot_of) {
+                                                                     Rec* __restrict__ out, u32* __restrict__ slot_of,
+                                                                     const u32* __restrict__ row_src, u32* __restrict__ row_host, u32 row_n) {
   static_assert(sizeof(Rec) % 8 == 0 && alignof(Rec) == 8, "records are copied as 64-bit words");
   constexpr u32 WPR = sizeof(Rec) / 8;
   __shared__ u32 lds[SCAN_SB / ESVO_WAVE];
@@ -149,6 +150,12 @@ __global__ void __launch_bounds__(SCAN_SB) scan_compact_small_kernel(const u32* 
     carry += tot;
   }
   if (threadIdx.x == 0 && total) *total = carry;
+  // latency mode (api_map.hip): the tick's counter row -- complete with this kernel's total -- goes to the pinned host row from
+  // here instead of through a copy operation behind the launch (row_src: the device row `total` belongs to)
+  if (row_host && threadIdx.x < row_n) {
+    row_host[threadIdx.x] = (row_src + threadIdx.x == total) ? carry : row_src[threadIdx.x];
+    __threadfence_system();
+  }
 }
 // One workgroup copying the records pays up to ~10 000 flags (the reference's PROCESS_EVENT_NUM); at 20 000 the parallel
 // compaction launch wins again (346x260 throughput tick: 57.4 against 54.3 M events/s).
@@ -157,12 +164,12 @@ bool scan_compact_is_small(size_t n) { return n > 0 && n <= SCAN_COMPACT_SMALL_M
 void launch_scan_compact_matches_small(const u32* flags, u32* prefix, u32* d_total, size_t n, const esvo_match_t* slots,
                                        esvo_match_t* out, u32* slot_of, hipStream_t s) {
   hipLaunchKernelGGL((scan_compact_small_kernel<esvo_match_t, false>), dim3(1), dim3(SCAN_SB), 0, s, flags, prefix, d_total, n, slots,
-                     out, slot_of);
+                     out, slot_of, (const u32*)nullptr, (u32*)nullptr, 0u);
 }
 void launch_scan_compact_points_small(const u32* flags, u32* prefix, u32* d_total, size_t n, const DevPoint* slots, DevPoint* out,
-                                      hipStream_t s) {
+                                      hipStream_t s, const u32* row_src, u32* row_host, u32 row_n) {
   hipLaunchKernelGGL((scan_compact_small_kernel<DevPoint, true>), dim3(1), dim3(SCAN_SB), 0, s, flags, prefix, d_total, n, slots, out,
-                     (u32*)nullptr);
+                     (u32*)nullptr, row_src, row_host, row_n);
 }
 
 // Small host -> device uploads of the tick path (pose table, frame table) as a KERNEL that reads the pinned host buffer:
@@ -184,6 +191,31 @@ void launch_upload_words(const void* pinned_src, void* d_dst, size_t bytes, hipS
   if (blocks > 256) blocks = 256;
   hipLaunchKernelGGL(upload_words_kernel, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const u32*>(pinned_src),
                      reinterpret_cast<u32*>(d_dst), n, d_zero, d_zero ? n_zero : 0u);
+}
+
+// Latency mode (api_map.hip, tick_phase2): what opens a tick's back stage -- the frame's points from their staging buffer into the
+// window ring, the tick's pose table into the frame's slot, the frame table from pinned host memory -- as ONE launch instead of two
+// copies and an upload (three dependent operations of 3-4 us each with ~6 us of queue latency between them).
+__global__ void __launch_bounds__(256) back_prologue_kernel(const u32* __restrict__ src, u32* __restrict__ dst, size_t n,
+                                                            const unsigned long long* __restrict__ a_src, unsigned long long* __restrict__ a_dst,
+                                                            size_t a_n, const unsigned long long* __restrict__ b_src,
+                                                            unsigned long long* __restrict__ b_dst, size_t b_n) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, T = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = t; i < a_n; i += T) a_dst[i] = a_src[i];
+  for (size_t i = t; i < b_n; i += T) b_dst[i] = b_src[i];
+  for (size_t i = t; i < n; i += T) dst[i] = src[i];
+}
+void launch_back_prologue(const void* pinned_src, void* d_dst, size_t bytes, const void* a_src, void* a_dst, size_t a_bytes,
+                          const void* b_src, void* b_dst, size_t b_bytes, hipStream_t s) {
+  const size_t n = bytes / 4, a_n = a_bytes / 8, b_n = b_bytes / 8;  // callers pass multiples of 4 / 8 / 8 bytes
+  const size_t most = std::max(n, std::max(a_n, b_n));
+  if (most == 0) return;
+  size_t blocks = (most + 255) / 256;
+  if (blocks > 512) blocks = 512;
+  hipLaunchKernelGGL(back_prologue_kernel, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const u32*>(pinned_src),
+                     reinterpret_cast<u32*>(d_dst), n, reinterpret_cast<const unsigned long long*>(a_src),
+                     reinterpret_cast<unsigned long long*>(a_dst), a_n, reinterpret_cast<const unsigned long long*>(b_src),
+                     reinterpret_cast<unsigned long long*>(b_dst), b_n);
 }
 
 size_t scan_scratch_elems(size_t n) { return (n + SCAN_TILE - 1) / SCAN_TILE + 1; }

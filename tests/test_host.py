@@ -26,7 +26,7 @@ def test_abi_struct_sizes_match_bindings():
     assert s[1] == ctypes.sizeof(abi.CalibStruct) and s[2] == ctypes.sizeof(abi.ParamsStruct)
     assert s[3] == abi.MATCH_DTYPE.itemsize == 48 and s[4] == abi.DEPTH_POINT_DTYPE.itemsize == 104
     assert s[5] == ctypes.sizeof(abi.StatsStruct) and s[6] == 0
-    assert s[7] == 7
+    assert s[7] == 8
 
 
 def test_create_fails_loudly_without_gpu():
