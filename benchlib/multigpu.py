@@ -314,7 +314,7 @@ def tick_share(workload, device, world=8, rounds=20, warm_rounds=3, events_cap=0
     return out
 
 
-def band_share(workload, device, shards=(8,), steps=5, warmup=2, events_cap=0):
+def band_share(workload, device, shards=(8,), steps=5, warmup=9, events_cap=0):
     """What ONE rank of an N-GPU band-mode run computes per tick, measured on this one GPU -- a PROJECTION, not a scaling
     measurement: G logical shards (handles; row bands of the image, events routed by row, banded Time Surfaces: exactly the
     configuration `--gpus G` runs in band mode) map the headline workload; the two all-gathers of a tick are emulated by
@@ -324,7 +324,9 @@ def band_share(workload, device, shards=(8,), steps=5, warmup=2, events_cap=0):
     procedure on one unsharded handle (`full_tick_ms_synchronised`) is what it is compared with.
     replicated_ms_at_8: the work that is the same on every rank whatever N is (phase 1: the frame order of the whole tick), measured.
     With two shard counts (tools/band_share_probe.py dsec640x480 8 16) share(G) = a + b / G is fitted as well: a = the floor a
-    rank's tick does not go below however little of the image it owns (latency of its kernels' dependent chains, not replication)."""
+    rank's tick does not go below however little of the image it owns (latency of its kernels' dependent chains, not replication).
+    (warmup = 9: a handle records its stage-timing events on its first 8 ticks that run alone and on one in 31 afterwards -- esvo_hip.h,
+    stage_timing_samples; the timed ticks are past that, as a running system's are; kernel_ms_* = the last sampled tick's events.)"""
     import torch
     rig, stream, p, ticks = make_workload(workload, max(steps + warmup, 40), events_cap)
     ticks = ticks[: steps + warmup]
@@ -414,7 +416,7 @@ def band_share(workload, device, shards=(8,), steps=5, warmup=2, events_cap=0):
             "exchange_bytes_per_rank_per_tick": [int(x // steps) for x in xbytes],
             "events_staged_per_rank_frac": [float(max(int(s.events_staged[c]) for s in st)) / max(len(e), 1)
                                             for c, e in enumerate((stream.ev_left, stream.ev_right))],
-            "kernel_ms_last_tick_mean_over_ranks": {k: float(np.mean([s.ms_kernel[i] for s in st])) for i, k in
+            "kernel_ms_last_sampled_tick_mean_over_ranks": {k: float(np.mean([s.ms_kernel[i] for s in st])) for i, k in
                                                     ((0, "ts_scatter"), (1, "ts_render"), (2, "bm_match"), (3, "lm_refine"), (4, "fuse"), (5, "clean"),
                                                      (6, "regularize"))},
             "rows_rank0": rows, "halo_violations": int(max(int(s.halo_violations) for s in st)),

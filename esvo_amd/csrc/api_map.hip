@@ -732,9 +732,9 @@ static int routed_front(esvo_context* h, esvo_context::TickState& tk, u32 n, con
     a.pose_sec = h->d_pose_sec; a.n_pose = h->n_pose;
     a.out_slots = h->d_match_slots; a.out_flags = h->d_match_flags;
     a.fail_counters = h->d_counters;
-    hipEventRecord(h->evt[EV_BM0 + h->fpar * EV_FRONT_STRIDE], h->stream);
+    if (h->stage_events_on) hipEventRecord(h->evt[EV_BM0 + h->fpar * EV_FRONT_STRIDE], h->stream);
     launch_bm_match(a, h->dp, h->stream);
-    hipEventRecord(h->evt[EV_BM1 + h->fpar * EV_FRONT_STRIDE], h->stream);
+    if (h->stage_events_on) hipEventRecord(h->evt[EV_BM1 + h->fpar * EV_FRONT_STRIDE], h->stream);
     HIPCHK(hipGetLastError());
     // dense list of the own matches (count -> counters[8]); the slot of each follows from its walk position (shard_codes_routed)
     if (scan_compact_is_small(n_loc)) {
@@ -744,14 +744,15 @@ static int routed_front(esvo_context* h, esvo_context::TickState& tk, u32 n, con
       launch_exclusive_scan_u32(h->d_match_flags, h->d_match_prefix, h->d_counters + 8, h->d_scan_tmp, n_loc, h->stream);
       launch_compact_matches(h->d_match_slots, h->d_match_flags, h->d_match_prefix, n_loc, h->d_matches, nullptr, h->stream);
     }
-    hipEventRecord(h->evt[EV_S1 + h->fpar * EV_FRONT_STRIDE], h->stream);
+    if (h->stage_events_on) hipEventRecord(h->evt[EV_S1 + h->fpar * EV_FRONT_STRIDE], h->stream);
     HIPCHK(hipGetLastError());
     // (the ring also holds the raster's halo events: the launch -- and with it the kernel's layout -- is bounded by the OWN
     //  events of the selection, counted at ingest)
     rc = run_lm(h, n_own, 1, true);
     if (rc) return rc;
   } else {  // no event of this tick in the band: the stage events the statistics read are still recorded
-    for (int e : {EV_BM0, EV_BM1, EV_S1, EV_LM0, EV_LM1}) hipEventRecord(h->evt[e + h->fpar * EV_FRONT_STRIDE], h->stream);
+    if (h->stage_events_on)
+      for (int e : {EV_BM0, EV_BM1, EV_S1, EV_LM0, EV_LM1}) hipEventRecord(h->evt[e + h->fpar * EV_FRONT_STRIDE], h->stream);
   }
   const size_t nb = shard_codes_block_routed(n);
   HIPCHK(hipMemsetAsync(h->d_codes_send, 0, nb, h->stream));
@@ -809,7 +810,10 @@ int tick_phase0(esvo_context* h, uint64_t t_ns, const uint64_t* pose_t_ns, const
   // the ring) is checked BEFORE any per-tick state is switched: a refused tick must leave no trace, in particular not in
   // the pose-table double buffer, which the LM stage of a still pending tick reads and whose content the back stage
   // copies into that tick's frame slot.
-  if (h->dn_pending) return routed_denoise_resume(h);  // phase 0 called again behind the exchange of the denoising bits (ESVO_AGAIN)
+  if (h->dn_pending) {  // phase 0 called again behind the exchange of the denoising bits (ESVO_AGAIN)
+    h->stage_events_on = h->tk[h->fpar].timed;
+    return routed_denoise_resume(h);
+  }
   if (m > h->max_poses) FAIL(ESVO_ERR_CAPACITY, "pose table larger than max_poses_per_tick");
   if (h->routed && h->halo_error)
     FAIL(ESVO_ERR_HALO, "a refinement of an earlier tick read outside the Time-Surface rows some rank renders (stats.halo_violations): "
@@ -834,7 +838,8 @@ int tick_phase0(esvo_context* h, uint64_t t_ns, const uint64_t* pose_t_ns, const
   // queue (one cross-queue hand-off less on the path the caller waits for), the host polls for its counters and its end, and its
   // stage timings are sampled, not recorded tick by tick (context.hpp)
   tk.lat = h->lat_now && !h->sharded && n && n <= h->lat_max_events;
-  tk.timed = !tk.lat || esvo_stage_timed(h);
+  // (sampled for every tick that runs alone, whatever its size; a band-sharded tick is waited for phase by phase)
+  tk.timed = (h->lat_now || h->sharded) ? esvo_stage_timed(h) : true;
   tk.timed_lm = tk.timed;
   h->stage_events_on = tk.timed;  // (esvo_map_tick's scope switches it back on)
   tk.obs_par = h->obs_par;
@@ -974,7 +979,7 @@ int tick_phase1_enqueue(esvo_context* h) {
     launch_shard_pack(h->d_own_w, h->d_lkeep, h->d_pt_slots, h->d_counters + 8, own, h->d_match_prefix, h->d_counters + 0,
                       h->d_pt_prefix, T, h->d_pts_send, own, n, h->d_rank_kept, N, h->d_counters + 9, h->stream,
                       h->routed ? h->d_counters + 10 : nullptr);
-    hipEventRecord(h->evt[EV_S2 + h->fpar * EV_FRONT_STRIDE], h->stream);
+    if (tk.timed) hipEventRecord(h->evt[EV_S2 + h->fpar * EV_FRONT_STRIDE], h->stream);
     HIPCHK(hipGetLastError());
   }
   hipStream_t sc = (n && !h->sharded) ? tk.cnt_stream : h->stream;
@@ -1138,6 +1143,7 @@ int tick_phase2(esvo_context* h, int fp) {
   }
   if (rc) { (void)flush_deferred_copies(h); return rc; }
   h->stats.ticks++;
+  if (h->sharded) h->lat_ticks++;
   h->stats.last_window_frames = (u32)h->n_window_frames;
   u32 np = 0;
   for (auto& f : h->frames) np += f.count;
@@ -1581,6 +1587,8 @@ extern "C" int esvo_shard_tick_phase(esvo_handle h, int phase, uint64_t t_ns, co
   if (!h->obs_set) FAIL(ESVO_ERR_STATE, "esvo_map_set_observation has not been called");
   if (!h->sharded) FAIL(ESVO_ERR_STATE, "call esvo_shard_set_band first");
   HIPCHK(hipSetDevice(h->device));
+  // (stage-timing events are sampled, context.hpp lat_ticks: phase 0 decides for the tick; switched back on when the call returns)
+  StageEventsScope timed_scope(h, phase == 0 ? true : h->tk[h->fpar].timed);
   switch (phase) {
     case 0:
       if (!h->dn_pending && (!pose_t_ns || !pose_T)) return ESVO_ERR_INVALID_ARG;

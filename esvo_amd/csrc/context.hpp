@@ -99,7 +99,8 @@ struct esvo_context {
   // sample, sum_ms_kernel[] sums the samples, stats.stage_timing_samples counts them.  The LM layout policy (lm_pair_*) lives on LM
   // launch times: the two events around the LM launch are recorded as well whenever the policy is exploring or trying the layout it
   // is not using (TickState::timed_lm).  Ticks that overlap (the throughput path) record all of them as before.
-  u32 lat_ticks = 0;              // ticks enqueued with nothing pending before them
+  u32 lat_ticks = 0;              // ticks enqueued with nothing pending before them (band-sharded ticks: all of them -- every
+                                  // phase of such a tick is waited for by the exchange that follows it)
   u32 lat_timed_every = 31;       // ESVO_LOWLAT_TIMED_EVERY (A/B; 1 = every tick)
   u32* cnt_row_host = nullptr;    // latency mode: where the tick's point compaction leaves the counter row (null: a copy follows)
   bool cnt_row_sent = false;
@@ -505,7 +506,7 @@ struct StageEventsScope {  // stage-timing events off (or on) for the calls of o
 };
 // whether the operations enqueued NOW (renders, a tick's stages) record their stage-timing events (context.hpp, lat_ticks)
 inline bool esvo_stage_timed(const esvo_context* h) {
-  if (!h->lat_mode || h->tick_pending || h->tl_on || h->sharded || h->comm) return true;
+  if (!h->lat_mode || h->tick_pending || h->tl_on || (h->comm && !h->sharded)) return true;  // (tick-interleaved ranks overlap their ticks)
   return h->lat_ticks < 8u || h->lat_ticks % h->lat_timed_every == 0u;
 }
 

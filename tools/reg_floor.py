@@ -7,6 +7,8 @@ import ctypes
 import os
 import sys
 
+os.environ.setdefault("ESVO_DEV_SWITCHES", "1")
+os.environ.setdefault("ESVO_LOWLAT_TIMED_EVERY", "1")   # every synchronised tick records its stage-timing events (s.ms_kernel below)
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench  # noqa: E402
 from esvo_amd import lib  # noqa: E402
