@@ -198,14 +198,17 @@ def _points(device, which):
         return res
 
     def latency(name, n_events, n):
-        rig, stream, p, ticks = make_workload(name, max(n + 6, 40), events_cap=n_events)
-        ticks = ticks[: n + 6]
+        # (W warm-up ticks: a handle records its stage-timing events -- ~5 us of queue time each -- on its first 8 ticks that run
+        #  alone and on one in 31 afterwards, esvo_hip.h stage_timing_samples; the timed ticks are those of a running node)
+        W = 9
+        rig, stream, p, ticks = make_workload(name, max(n + W, 40), events_cap=n_events)
+        ticks = ticks[: n + W]
         dev = lib.Esvo(p, rig, device=device)
         dev.ts_push_events(0, stream.ev_left)
         dev.ts_push_events(1, stream.ev_right)
-        run_single(dev, stream, ticks, 0, 6, sync_each=True)
+        run_single(dev, stream, ticks, 0, W, sync_each=True)
         t0 = time.perf_counter()
-        run_single(dev, stream, ticks, 6, n + 6, sync_each=True)
+        run_single(dev, stream, ticks, W, n + W, sync_each=True)
         dt = time.perf_counter() - t0
         s = dev.stats()
         dev.close()

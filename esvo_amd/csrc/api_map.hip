@@ -111,6 +111,10 @@ static int lm_pair_policy(esvo_context* h, u32 n_events) {
 }
 int run_lm(esvo_context* h, u32 max_matches, int cull, bool dense, hipStream_t st = nullptr, int pair = -1) {
   if (!st) st = h->stream;
+  if (h->gather_guard[h->fpar]) {  // a back stage's first launch reads this parity's solver slots (latency mode, tick_phase2): not
+    h->gather_guard[h->fpar] = false;  // before it is done (an event long complete when ticks are waited for one by one)
+    HIPCHK(hipStreamWaitEvent(st, h->evt[EV_STG + h->fpar * EV_FRONT_STRIDE], 0));
+  }
   u32* flags = dense ? h->d_lkeep : h->d_pt_flags;  // the kernel writes every flag of its launch range
   LmArgs a;
   a.matches = h->d_matches; a.n_matches = h->d_counters + (dense ? 8 : 0); a.max_matches = max_matches;
@@ -308,7 +312,8 @@ static int flush_deferred_copies(esvo_context* h) {
   esvo_context::DeferredCopies d = h->pro;
   h->pro = esvo_context::DeferredCopies();
   if (!d.active) return ESVO_OK;
-  if (d.a_bytes) HIPCHK(hipMemcpyAsync(d.a_dst, d.a_src, d.a_bytes, hipMemcpyDeviceToDevice, h->stream_b));
+  if (d.a_flags) launch_back_prologue(nullptr, nullptr, 0, d.a_src, d.a_dst, d.a_bytes, nullptr, nullptr, 0, h->stream_b, d.a_flags, d.a_prefix, d.a_slots);
+  else if (d.a_bytes) HIPCHK(hipMemcpyAsync(d.a_dst, d.a_src, d.a_bytes, hipMemcpyDeviceToDevice, h->stream_b));
   if (d.ev_a >= 0) HIPCHK(hipEventRecord(h->evt[d.ev_a], h->stream_b));
   if (d.b_bytes) HIPCHK(hipMemcpyAsync(d.b_dst, d.b_src, d.b_bytes, hipMemcpyDeviceToDevice, h->stream_b));
   if (d.ev_b >= 0) HIPCHK(hipEventRecord(h->evt[d.ev_b], h->stream_b));
@@ -380,7 +385,8 @@ int run_fuse(esvo_context* h, int par, const double* T_world_obs, bool naive) {
   if (h->pro.active) {  // latency mode: the frame's points and its pose table travel with the table (one launch, not three operations)
     const esvo_context::DeferredCopies d = h->pro;
     h->pro = esvo_context::DeferredCopies();
-    launch_back_prologue(host, dtab, sizeof(u32) * (3 * (size_t)nf + 1), d.a_src, d.a_dst, d.a_bytes, d.b_src, d.b_dst, d.b_bytes, sb);
+    launch_back_prologue(host, dtab, sizeof(u32) * (3 * (size_t)nf + 1), d.a_src, d.a_dst, d.a_bytes, d.b_src, d.b_dst, d.b_bytes, sb,
+                         d.a_flags, d.a_prefix, d.a_slots);
     // "staging buffer / pose table free again": recorded at the END of this back stage, not here between two dependent launches
     // (~5 us each); who waits for them -- the front stage two ticks on -- comes long after either point
     tail_ev[0] = d.ev_a; tail_ev[1] = d.ev_b;
@@ -838,6 +844,7 @@ int tick_phase0(esvo_context* h, uint64_t t_ns, const uint64_t* pose_t_ns, const
   // queue (one cross-queue hand-off less on the path the caller waits for), the host polls for its counters and its end, and its
   // stage timings are sampled, not recorded tick by tick (context.hpp)
   tk.lat = h->lat_now && !h->sharded && n && n <= h->lat_max_events;
+  tk.gather = false;
   // (sampled for every tick that runs alone, whatever its size; a band-sharded tick is waited for phase by phase)
   tk.timed = (h->lat_now || h->sharded) ? esvo_stage_timed(h) : true;
   tk.timed_lm = tk.timed;
@@ -954,7 +961,10 @@ int tick_phase1_enqueue(esvo_context* h) {
     // latency mode: the compaction kernel leaves the counter row in the pinned host row itself (no copy operation behind it)
     h->cnt_row_host = tk.lat ? h->h_counters + CNT_ROW * h->fpar : nullptr;
     h->cnt_row_sent = false;
-    rc = run_order_points(h, n, h->d_stage[h->fpar], tk.cnt_stream);
+    // ... and only scans: the frame stays in the solver slots until the back stage's first launch -- which knows where in the window
+    // ring it goes -- compacts it straight into place (one copy of the records instead of two, and that one over the whole grid)
+    tk.gather = tk.lat && scan_compact_is_small(n);
+    rc = run_order_points(h, n, tk.gather ? nullptr : h->d_stage[h->fpar], tk.cnt_stream);
     h->cnt_row_host = nullptr;
     if (rc) return rc;
   } else if (n) {
@@ -1129,6 +1139,10 @@ int tick_phase2(esvo_context* h, int fp) {
       h->pro.active = true;
       h->pro.a_src = h->d_stage[fp]; h->pro.a_dst = h->d_win + tk.off; h->pro.a_bytes = sizeof(DevPoint) * tk.points;
       h->pro.ev_a = EV_STG + fp * EV_FRONT_STRIDE;
+      if (tk.gather && tk.points) {
+        h->pro.a_src = h->d_pt_slots2[fp]; h->pro.a_flags = h->d_pt_flags2[fp]; h->pro.a_prefix = h->d_pt_prefix2[fp]; h->pro.a_slots = tk.n;
+        h->gather_guard[fp] = true;  // the next LM launch of this parity waits for EV_STG (tick_phase0)
+      }
     } else {
       if (tk.points)
         HIPCHK(hipMemcpyAsync(h->d_win + tk.off, h->d_stage[fp], sizeof(DevPoint) * tk.points, hipMemcpyDeviceToDevice, h->stream_b));

@@ -184,7 +184,8 @@ void launch_scan_compact_points_small(const u32* flags, u32* prefix, u32* d_tota
 // upload of a small pinned host buffer by a kernel (never blocks the host; scan.hip)
 void launch_upload_words(const void* pinned_src, void* d_dst, size_t bytes, hipStream_t s, u32* d_zero = nullptr, u32 n_zero = 0);
 void launch_back_prologue(const void* pinned_src, void* d_dst, size_t bytes, const void* a_src, void* a_dst, size_t a_bytes,
-                          const void* b_src, void* b_dst, size_t b_bytes, hipStream_t s);
+                          const void* b_src, void* b_dst, size_t b_bytes, hipStream_t s, const u32* a_flags = nullptr,
+                          const u32* a_prefix = nullptr, u32 a_slots = 0);
 
 // An event that arrived OUT OF ORDER (its stamp below the newest stamp staged before it) keeps its sorted place in the ring -- the
 // mapper's queue is insertion-sorted, esvo_Mapping.cpp:692-702 -- but never reaches the Time Surface: TimeSurface::eventsCallback

@@ -104,6 +104,7 @@ struct esvo_context {
   u32 lat_timed_every = 31;       // ESVO_LOWLAT_TIMED_EVERY (A/B; 1 = every tick)
   u32* cnt_row_host = nullptr;    // latency mode: where the tick's point compaction leaves the counter row (null: a copy follows)
   bool cnt_row_sent = false;
+  bool gather_guard[2] = {false, false};  // the solver-slot buffers of that parity are read by a back stage's first launch (EV_STG releases them)
   bool stage_events_on = true;    // false while a tick whose stage timings are not sampled is being enqueued (api_map.hip)
   bool back_timed[2] = {true, true};  // the back stage of that parity recorded its stage events
   std::atomic<bool> trk_used{false};  // esvo_track_set_current has read the resident surface: renders record EV_R1 for it
@@ -112,6 +113,7 @@ struct esvo_context {
   struct DeferredCopies {
     bool active = false;
     const void* a_src = nullptr; void* a_dst = nullptr; size_t a_bytes = 0; int ev_a = -1;  // frame points; event recorded behind it
+    const u32* a_flags = nullptr; const u32* a_prefix = nullptr; u32 a_slots = 0;          // gather mode: a_src = the solver slots
     const void* b_src = nullptr; void* b_dst = nullptr; size_t b_bytes = 0; int ev_b = -1;  // pose table
   } pro;
   uint8_t* d_obs2[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
@@ -337,6 +339,7 @@ struct esvo_context {
     int lm_pair = -1;                 // LM layout of the tick: 1 pair, 0 wide, -1 not a candidate (policy feedback)
     bool lat = false;                 // enqueued in latency mode: LM in the front queue, polled waits
     bool timed = true;                // its stage-timing events were recorded
+    bool gather = false;              // latency mode: its frame is still in the solver slots (flags + prefix): the back stage's first launch compacts it
     bool timed_lm = true;             // ... at least the two around the LM launch (the layout policy's feedback)
   } tk[2];
   // pair layout of the LM kernel (kernels_lm.hip): chosen per tick from the LM launch times the handle measures anyway

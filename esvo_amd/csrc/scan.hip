@@ -132,7 +132,8 @@ __global__ void __launch_bounds__(SCAN_SB) scan_compact_small_kernel(const u32* 
       ex += v[k];
     }
     __syncthreads();
-    for (u32 w = threadIdx.x; w < tot * WPR; w += SCAN_SB) {
+    // (out == nullptr: prefix, total and the counter row only -- the consumer gathers the records itself, back_prologue_kernel)
+    for (u32 w = threadIdx.x; out && w < tot * WPR; w += SCAN_SB) {
       const u32 r = w / WPR, q = w - r * WPR;
       const u32 src = src_slot[r];
       unsigned long long word = in64[(size_t)src * WPR + q];
@@ -196,18 +197,40 @@ void launch_upload_words(const void* pinned_src, void* d_dst, size_t bytes, hipS
 // Latency mode (api_map.hip, tick_phase2): what opens a tick's back stage -- the frame's points from their staging buffer into the
 // window ring, the tick's pose table into the frame's slot, the frame table from pinned host memory -- as ONE launch instead of two
 // copies and an upload (three dependent operations of 3-4 us each with ~6 us of queue latency between them).
+// Gather mode (a_flags != nullptr): copy A is the stable COMPACTION of the refinement's solver slots itself -- a_src = the slot
+// records (a_slots of them), kept where a_flags is set, record i to position a_prefix[i] of a_dst with that position in its `seq`
+// field -- what scan_compact_small_kernel's copy loop does in one workgroup (20 us for DSEC's 2000 slots), here over the grid.
 __global__ void __launch_bounds__(256) back_prologue_kernel(const u32* __restrict__ src, u32* __restrict__ dst, size_t n,
                                                             const unsigned long long* __restrict__ a_src, unsigned long long* __restrict__ a_dst,
                                                             size_t a_n, const unsigned long long* __restrict__ b_src,
-                                                            unsigned long long* __restrict__ b_dst, size_t b_n) {
+                                                            unsigned long long* __restrict__ b_dst, size_t b_n,
+                                                            const u32* __restrict__ a_flags, const u32* __restrict__ a_prefix, u32 a_slots) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, T = (size_t)gridDim.x * blockDim.x;
-  for (size_t i = t; i < a_n; i += T) a_dst[i] = a_src[i];
+  if (a_flags) {
+    constexpr u32 WPR = sizeof(DevPoint) / 8;
+    constexpr size_t so = offsetof(DevPoint, seq);
+    for (size_t i = t; i < (size_t)a_slots * WPR; i += T) {
+      const u32 slot = (u32)(i / WPR), q = (u32)(i - (size_t)slot * WPR);
+      if (!a_flags[slot]) continue;
+      const u32 pos = a_prefix[slot];
+      unsigned long long word = a_src[i];
+      if (q == so / 8) {
+        const unsigned long long m = 0xffffffffull << ((so % 8) * 8);
+        word = (word & ~m) | ((unsigned long long)pos << ((so % 8) * 8));
+      }
+      a_dst[(size_t)pos * WPR + q] = word;
+    }
+  } else {
+    for (size_t i = t; i < a_n; i += T) a_dst[i] = a_src[i];
+  }
   for (size_t i = t; i < b_n; i += T) b_dst[i] = b_src[i];
   for (size_t i = t; i < n; i += T) dst[i] = src[i];
 }
 void launch_back_prologue(const void* pinned_src, void* d_dst, size_t bytes, const void* a_src, void* a_dst, size_t a_bytes,
-                          const void* b_src, void* b_dst, size_t b_bytes, hipStream_t s) {
-  const size_t n = bytes / 4, a_n = a_bytes / 8, b_n = b_bytes / 8;  // callers pass multiples of 4 / 8 / 8 bytes
+                          const void* b_src, void* b_dst, size_t b_bytes, hipStream_t s, const u32* a_flags, const u32* a_prefix,
+                          u32 a_slots) {
+  static_assert(sizeof(DevPoint) % 8 == 0 && alignof(DevPoint) == 8, "records are copied as 64-bit words");
+  const size_t n = bytes / 4, a_n = a_flags ? (size_t)a_slots * (sizeof(DevPoint) / 8) : a_bytes / 8, b_n = b_bytes / 8;
   const size_t most = std::max(n, std::max(a_n, b_n));
   if (most == 0) return;
   size_t blocks = (most + 255) / 256;
@@ -215,7 +238,7 @@ void launch_back_prologue(const void* pinned_src, void* d_dst, size_t bytes, con
   hipLaunchKernelGGL(back_prologue_kernel, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const u32*>(pinned_src),
                      reinterpret_cast<u32*>(d_dst), n, reinterpret_cast<const unsigned long long*>(a_src),
                      reinterpret_cast<unsigned long long*>(a_dst), a_n, reinterpret_cast<const unsigned long long*>(b_src),
-                     reinterpret_cast<unsigned long long*>(b_dst), b_n);
+                     reinterpret_cast<unsigned long long*>(b_dst), b_n, a_flags, a_prefix, a_slots);
 }
 
 size_t scan_scratch_elems(size_t n) { return (n + SCAN_TILE - 1) / SCAN_TILE + 1; }
