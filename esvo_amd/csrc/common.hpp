@@ -314,6 +314,7 @@ void launch_shard_codes_routed(const esvo_match_t* own_matches, const u32* keep,
 void launch_shard_unpack_routed(const u32* blocks, u32 block_words, u32 N, u32 n, uint8_t* codes, u32* rank_kept, u32* tile_sums, hipStream_t s);
 
 // kernels_lm.hip
+bool lm_launch_is_wide(u32 max_matches, const struct DevParams& p);  // kernels_lm.hip
 struct LmArgs {
   const esvo_match_t* matches;  // compacted vEMP (thread-stride order of BM)
   const u32* n_matches;         // device count
@@ -333,6 +334,10 @@ struct LmArgs {
   u32* split_order;
   u32* split_hist;
   int pair;                     // wide layout only: two waves per match (kernels_lm.hip "pair layout"); the caller's choice
+  // wide layout only (latency mode, api_map.hip): `matches` is the block matcher's SLOT array and match_index[j] the slot of the
+  // j-th match of the compacted list -- the list itself (48 B per record through one workgroup) is never written.  nullptr: `matches`
+  // is the compacted list.
+  const u32* match_index;
   // In-run shader-clock probe (nullable): lane 0 of every 65th workgroup reads s_memtime (shader cycles) and s_memrealtime
   // (the constant reference clock) when it starts and when it ends and adds the two differences to clk[2 xcc], clk[2 xcc + 1]
   // (xcc = the XCD the wave ran on), one sample to clk[16]; the start values wait in clk[CLK_SCRATCH + 2 * (block / 65) ...].

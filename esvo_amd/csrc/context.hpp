@@ -104,6 +104,7 @@ struct esvo_context {
   u32 lat_timed_every = 31;       // ESVO_LOWLAT_TIMED_EVERY (A/B; 1 = every tick)
   u32* cnt_row_host = nullptr;    // latency mode: where the tick's point compaction leaves the counter row (null: a copy follows)
   bool cnt_row_sent = false;
+  bool match_by_index = false;    // latency mode: this tick's match list is d_own_w (indices into d_match_slots), not d_matches
   bool gather_guard[2] = {false, false};  // the solver-slot buffers of that parity are read by a back stage's first launch (EV_STG releases them)
   bool stage_events_on = true;    // false while a tick whose stage timings are not sampled is being enqueued (api_map.hip)
   bool back_timed[2] = {true, true};  // the back stage of that parity recorded its stage events

@@ -571,7 +571,9 @@ __global__ void __launch_bounds__(PAIR ? 128 : LM_BLOCK, WIDE ? LM_WIDE_WAVES : 
   m.x_left[0] = m.x_left[1] = -1e9; m.inv_depth = 1.0; m.pose_idx = 0; m.cost = 0; m.disp = 0; m.event_idx = 0;
   if (active) {
     j = a.dense ? s : stride_item(s, M, (u32)p.num_threads);  // DepthProblemSolver.cpp:90 (dense: kernels_shard.hip)
-    m = a.matches[j];
+    u32 jm = j;
+    if constexpr (WIDE) { if (a.match_index) jm = a.match_index[j]; }  // (LmArgs::match_index: the list as indices into the slots)
+    m = a.matches[jm];
   }
   LmProblem pr;
   pr.cx = m.x_left[0];
@@ -1179,6 +1181,10 @@ __global__ void __launch_bounds__(256) lm_order_kernel(const u32* __restrict__ n
 }
 
 void launch_lm_refine_any(const LmArgs& a, const DevParams& p, u32* n_solved, hipStream_t s);  // kernels_lm_any.hip
+// whether a launch bounded by max_matches takes the one-wave-per-match layout -- the one that reads LmArgs::match_index
+bool lm_launch_is_wide(u32 max_matches, const DevParams& p) {
+  return max_matches > 0 && p.wx == LM_COLS && p.wy == LM_ROWS && p.ls_norm != ESVO_LSNORM_L2 && max_matches <= LM_WIDE_MAX && LM_BLOCK == 64;
+}
 void launch_lm_refine(const LmArgs& a, const DevParams& p, u32* n_solved, hipStream_t s) {
   if (a.max_matches == 0) return;
   if (p.wx != LM_COLS || p.wy != LM_ROWS) { launch_lm_refine_any(a, p, n_solved, s); return; }  // (no clock probe, no layouts)

@@ -147,6 +147,8 @@ __global__ void __launch_bounds__(SCAN_SB) scan_compact_small_kernel(const u32* 
       out64[(size_t)(carry + r) * WPR + q] = word;
       if (slot_of && q == 0) slot_of[carry + r] = src;
     }
+    if (!out && slot_of)  // the list as indices only (LmArgs::match_index)
+      for (u32 r = threadIdx.x; r < tot; r += SCAN_SB) slot_of[carry + r] = src_slot[r];
     __syncthreads();  // src_slot is reused by the next tile
     carry += tot;
   }
