@@ -137,7 +137,8 @@ int run_lm(esvo_context* h, u32 max_matches, int cull, bool dense, hipStream_t s
   const bool timed_lm = h->stage_events_on || h->tk[h->fpar].timed_lm;
   if (timed_lm) hipEventRecord(h->evt[EV_LM0 + h->fpar * EV_FRONT_STRIDE], st);
   launch_lm_refine(a, h->dp, h->d_counters + 2, st);
-  if (timed_lm) hipEventRecord(h->evt[EV_LM1 + h->fpar * EV_FRONT_STRIDE], st);
+  // (EV_LM1 is also what the point compaction waits for when it runs on the other LM queue -- collect_aside)
+  if (timed_lm || h->tk[h->fpar].cnt_stream != st) hipEventRecord(h->evt[EV_LM1 + h->fpar * EV_FRONT_STRIDE], st);
   HIPCHK(hipGetLastError());
   return ESVO_OK;
 }
@@ -852,6 +853,11 @@ int tick_phase0(esvo_context* h, uint64_t t_ns, const uint64_t* pose_t_ns, const
   h->match_by_index = false;
   // (sampled for every tick that runs alone, whatever its size; a band-sharded tick is waited for phase by phase)
   tk.timed = (h->lat_now || h->sharded) ? esvo_stage_timed(h) : true;
+  if (h->pipe_now && !h->sharded && !h->comm && !h->tl_on && n && n <= h->lat_max_events) {
+    // a small tick that overlaps the previous one (esvo_map_tick's lazy path): host-paced -- one tick in pipe_timed_every is timed
+    tk.timed = h->pipe_seq % h->pipe_timed_every == 0u;
+    h->pipe_seq++;
+  }
   tk.timed_lm = tk.timed;
   h->stage_events_on = tk.timed;  // (esvo_map_tick's scope switches it back on)
   tk.obs_par = h->obs_par;
@@ -1241,10 +1247,11 @@ extern "C" int esvo_map_tick(esvo_handle h, uint64_t t_ns, const uint64_t* pose_
   const int prev_fp = h->fpar;
   h->split_now = h->lm_split && !h->prm.denoising;
   h->lat_now = h->lat_mode && !prev;
+  h->pipe_now = h->lat_mode && prev;
   int rc = tick_phase0(h, t_ns, pose_t_ns, pose_T, m);
   if (!rc) rc = tick_phase1_enqueue(h);
   h->split_now = false;
-  h->lat_now = false;
+  h->lat_now = h->pipe_now = false;
   h->stage_events_on = true;
   if (!rc) {
     h->lat_last = h->tk[h->fpar].lat;

@@ -90,6 +90,7 @@ struct esvo_context {
   // completion interrupt (~10-20 us per wake-up), for ticks of at most lat_max_events events.  ESVO_LOWLAT=0 (A/B) switches it off.
   bool lat_mode = true;
   bool lat_now = false;           // set by esvo_map_tick around its front stage
+  bool pipe_now = false;          // ... when the previous tick is still pending (the two overlap)
   bool lat_last = false;          // the newest tick was enqueued in latency mode (what synchronising calls look at)
   u32 lat_max_events = 40000u;
   // Stage timings are SAMPLED on that path.  Every hipEventRecord between two dependent kernels costs the queue ~5 us (a marker
@@ -101,6 +102,11 @@ struct esvo_context {
   // is not using (TickState::timed_lm).  Ticks that overlap (the throughput path) record all of them as before.
   u32 lat_ticks = 0;              // ticks enqueued with nothing pending before them (band-sharded ticks: all of them -- every
                                   // phase of such a tick is waited for by the exchange that follows it)
+  // Overlapping SMALL ticks (at most lat_max_events events; two in flight, nobody waits) are paced by the host: ~45 runtime calls per
+  // tick, a third of them event records.  They sample their stage timings one tick in pipe_timed_every; the throughput path (larger
+  // ticks, paced by the LM kernel) keeps recording every tick.
+  u32 pipe_seq = 0;
+  u32 pipe_timed_every = 4;       // ESVO_PIPE_TIMED_EVERY (A/B; 1 = every tick)
   u32 lat_timed_every = 31;       // ESVO_LOWLAT_TIMED_EVERY (A/B; 1 = every tick)
   u32* cnt_row_host = nullptr;    // latency mode: where the tick's point compaction leaves the counter row (null: a copy follows)
   bool cnt_row_sent = false;
@@ -510,7 +516,9 @@ struct StageEventsScope {  // stage-timing events off (or on) for the calls of o
 };
 // whether the operations enqueued NOW (renders, a tick's stages) record their stage-timing events (context.hpp, lat_ticks)
 inline bool esvo_stage_timed(const esvo_context* h) {
-  if (!h->lat_mode || h->tick_pending || h->tl_on || (h->comm && !h->sharded)) return true;  // (tick-interleaved ranks overlap their ticks)
+  if (!h->lat_mode || h->tl_on || (h->comm && !h->sharded)) return true;  // (tick-interleaved ranks: every tick)
+  if (h->tick_pending)  // overlapping ticks: the small ones are paced by the HOST's enqueueing (pipe_seq), the others record everything
+    return !(h->tk[h->fpar].n && h->tk[h->fpar].n <= h->lat_max_events) || h->pipe_seq % h->pipe_timed_every == 0u;
   return h->lat_ticks < 8u || h->lat_ticks % h->lat_timed_every == 0u;
 }
 
