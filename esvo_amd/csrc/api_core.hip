@@ -275,8 +275,10 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
     CK(dalloc(&h->d_lm_hist, 2 * 32 * 64));  // kernels_lm.hip: 2 x LM_SPLIT_STRIPES x LM_SPLIT_BINS
     CK(hipMemset(h->d_lm_hist, 0, sizeof(u32) * 2 * 32 * 64));
   }
-  CK(dalloc(&h->d_clk, clk_words(h->max_ev)));
-  CK(hipMemset(h->d_clk, 0, sizeof(u64) * clk_words(h->max_ev)));
+  // (two blocks, one per front parity: two LM launches in flight -- the two LM queues -- must not share the probe's scratch, where
+  //  a wave leaves its start stamps: a launch that read the other one's stamp added a wrapped difference to the sums)
+  CK(dalloc(&h->d_clk, 2 * clk_words(h->max_ev)));
+  CK(hipMemset(h->d_clk, 0, sizeof(u64) * 2 * clk_words(h->max_ev)));
   if (const char* ec = esvo_dev_switch("ESVO_CLK_PROBE")) h->clk_probe = std::atoi(ec) != 0;
   if (const char* ep = esvo_dev_switch("ESVO_LM_PERSIST")) h->lm_persist = std::atoi(ep) != 0;
   {
@@ -505,6 +507,7 @@ int esvo_reset(esvo_handle h) {
     h->stats.clk_ref_khz = khz;
   }
   HIPCHK(hipMemset(h->d_clk, 0, sizeof(u64) * CLK_SCRATCH));
+  HIPCHK(hipMemset(h->d_clk + clk_words(h->max_ev), 0, sizeof(u64) * CLK_SCRATCH));
   return ESVO_OK;
 }
 

@@ -129,7 +129,7 @@ int run_lm(esvo_context* h, u32 max_matches, int cull, bool dense, hipStream_t s
   a.split_fvec0 = split ? h->d_lm_fvec0 : nullptr; a.split_fnorm0 = h->d_lm_fnorm0; a.split_meta = h->d_lm_meta;
   a.split_order = h->d_lm_order; a.split_hist = h->d_lm_hist;
   a.pair = pair >= 0 ? pair : (h->lm_pair_forced == 1 && max_matches <= esvo::LM_PAIR_MAX_EVENTS ? 1 : 0);
-  a.clk = h->clk_probe ? h->d_clk : nullptr;
+  a.clk = h->clk_probe ? h->d_clk + (size_t)h->fpar * clk_words(h->max_ev) : nullptr;  // (a block per front parity: api_core.hip)
   if (h->routed && dense) { a.halo_viol = h->d_counters + 10; a.vy0 = h->oband_y0; a.vy1 = h->oband_y1; }
   // launches of the throughput layout: persistent groups that pull matches from a counter (kernels_lm.hip); counters[11] is
   // zero at this point (a tick clears its counter row with the pose upload, run_refine clears it itself)
@@ -1866,10 +1866,11 @@ int esvo_get_stats(esvo_handle h, esvo_stats_t* out) {
   int rc = finalize_tick_stats(h);
   if (rc) return rc;
   {  // the LM kernel's clock probe (every stream is drained here): running sums since esvo_create / esvo_reset
-    u64 acc[CLK_SCRATCH];
+    u64 acc[CLK_SCRATCH], acc1[CLK_SCRATCH];
     HIPCHK(hipMemcpy(acc, h->d_clk, sizeof(acc), hipMemcpyDeviceToHost));
-    for (u32 x = 0; x < CLK_XCDS; ++x) { h->stats.clk_cycles[x] = acc[2 * x]; h->stats.clk_ref_ticks[x] = acc[2 * x + 1]; }
-    h->stats.clk_samples = acc[CLK_SAMPLES];
+    HIPCHK(hipMemcpy(acc1, h->d_clk + clk_words(h->max_ev), sizeof(acc1), hipMemcpyDeviceToHost));
+    for (u32 x = 0; x < CLK_XCDS; ++x) { h->stats.clk_cycles[x] = acc[2 * x] + acc1[2 * x]; h->stats.clk_ref_ticks[x] = acc[2 * x + 1] + acc1[2 * x + 1]; }
+    h->stats.clk_samples = acc[CLK_SAMPLES] + acc1[CLK_SAMPLES];
   }
   std::lock_guard<std::mutex> lr(h->mu_ring);  // events_staged is written by the ingest thread
   *out = h->stats;
