@@ -434,7 +434,7 @@ int run_fuse(esvo_context* h, int par, const double* T_world_obs, bool naive) {
   if (timed) hipEventRecord(h->evt[EV_CL1 + o], sb);
   if (h->prm.regularization && !naive) {
     launch_reg_view(h->d_map, h->d_map2, h->d_owner_max, h->d_owner_min, h->d_reg_ab, h->d_reg_cd, h->d_cnt_b + 7, h->dp, sb);
-    launch_reg_apply(h->d_map, h->d_map2, h->d_owner_max, h->d_owner_min, h->d_reg_ab, h->d_reg_cd, h->dp, sb);
+    launch_reg_apply(h->d_map, h->d_map2, h->d_owner_max, h->d_owner_min, h->d_reg_ab, h->d_reg_cd, h->d_cnt_b + 7, h->dp, sb);
     h->d_map_cur = h->d_map2;
   }
   HIPCHK(hipMemcpyAsync(h->h_cnt_b + 8 * par, h->d_cnt_b, sizeof(u32) * 8, hipMemcpyDeviceToHost, sb));

@@ -761,8 +761,11 @@ __global__ void __launch_bounds__(256) reg_view_kernel(const MapCell* __restrict
       if (!alive) map_flags(out, ncell)[cell] = 0;
     }
   }
-  const u64 am = __ballot(alive);  // number of elements of the band (a statistic)
-  if ((threadIdx.x & 63) == 0 && am) atomicAdd(n_elems, (u32)__popcll(am));
+  // number of elements of the band (a statistic).  n_elems is null when the tile kernel counts them instead (reg_apply_kernel, one
+  // atomic per tile spread over its run time): one atomic per wave on ONE address from ~2000-4800 waves that all issue it at once
+  // made this kernel last 34 us instead of 6 (the reference-faithful DSEC tick; 57 us in the throughput tick)
+  const u64 am = __ballot(alive);
+  if (n_elems && (threadIdx.x & 63) == 0 && am) atomicAdd(n_elems, (u32)__popcll(am));
 }
 
 // ---- DepthRegularization::apply, fused: neighbourhood scan + sequential Student-t fusion ---------------------------------
@@ -796,7 +799,7 @@ __global__ void __launch_bounds__(REG_TX * REG_TY, BACK_WAVES) reg_apply_kernel(
                                                                     const u32* __restrict__ owner_max,
                                                                     const u32* __restrict__ owner_min,
                                                                     const double2* __restrict__ ab,
-                                                                    const double2* __restrict__ cd, DevParams p) {
+                                                                    const double2* __restrict__ cd, DevParams p, u32* __restrict__ n_elems) {
   constexpr int NW = REG_TY;                        // waves of the workgroup
   constexpr int UNITS = 4 * REG_RB;                 // staging units of a block: (row, ab | cd, column half) x 64 lanes
   constexpr int UPW = (UNITS + NW - 1) / NW;        // units per wave
@@ -819,6 +822,7 @@ __global__ void __launch_bounds__(REG_TX * REG_TY, BACK_WAVES) reg_apply_kernel(
   u32 base = 0, n_el = 0;
   for (int w = 0; w < REG_TY; ++w) { if (w < wv) base += s_wcount[w]; n_el += s_wcount[w]; }
   if (n_el == 0) return;  // block-uniform
+  if (t == 0) atomicAdd(n_elems, n_el);  // the band's element count (reg_view_kernel's note)
   if (alive) s_elem[base + (u32)__popcll(am & ((1ull << lane) - 1ull))] = (u32)(cr * p.W + cc);
   __syncthreads();
   const bool has = (u32)t < n_el;
@@ -1058,11 +1062,12 @@ void launch_reg_view(const MapCell* map_in, MapCell* map_out, u32* owner_max, u3
   const int ncell = p.W * p.H;
   // owner_max / owner_min / n_elems were reset by fuse_reset_kernel (launch_fuse of the same tick)
   const int nb = (ncell + 255) / 256;
+  if (p.ls_norm != ESVO_LSNORM_L2) n_elems = nullptr;  // the tile kernel counts (launch_reg_apply)
   hipLaunchKernelGGL(reg_view_kernel, dim3(nb), dim3(256), 0, s, map_in, map_out, ab, cd, owner_max, owner_min, n_elems, ncell, p.W,
                      p.band_y0, p.band_y1, p.cband_y0, p.cband_y1, p.ls_norm == ESVO_LSNORM_L2 ? 1 : 0);
 }
 void launch_reg_apply(const MapCell* map_in, MapCell* map_out, const u32* owner_max, const u32* owner_min, const double2* ab,
-                      const double2* cd, const DevParams& p, hipStream_t s) {
+                      const double2* cd, u32* n_elems, const DevParams& p, hipStream_t s) {
   if (p.ls_norm == ESVO_LSNORM_L2) {
     const int ncell = p.W * p.H;
     hipLaunchKernelGGL(reg_apply_l2_kernel, dim3((ncell + 255) / 256), dim3(256), 0, s, map_in, map_out, owner_max, owner_min, ab, cd, p);
@@ -1074,9 +1079,9 @@ void launch_reg_apply(const MapCell* map_in, MapCell* map_out, const u32* owner_
   // grid = all tile rows (blockIdx -> tile); tiles outside the band find no element and leave at once
   const int tiles_y = (p.H + REG_TY - 1) / REG_TY;
   const dim3 grid(tiles_x * tiles_y), block(REG_TX * REG_TY);
-  if (p.reg_radius == 20) hipLaunchKernelGGL(reg_apply_kernel<20>, grid, block, 0, s, map_in, map_out, owner_max, owner_min, ab, cd, p);
-  else if (p.reg_radius == 5) hipLaunchKernelGGL(reg_apply_kernel<5>, grid, block, 0, s, map_in, map_out, owner_max, owner_min, ab, cd, p);
-  else hipLaunchKernelGGL(reg_apply_kernel<0>, grid, block, 0, s, map_in, map_out, owner_max, owner_min, ab, cd, p);
+  if (p.reg_radius == 20) hipLaunchKernelGGL(reg_apply_kernel<20>, grid, block, 0, s, map_in, map_out, owner_max, owner_min, ab, cd, p, n_elems);
+  else if (p.reg_radius == 5) hipLaunchKernelGGL(reg_apply_kernel<5>, grid, block, 0, s, map_in, map_out, owner_max, owner_min, ab, cd, p, n_elems);
+  else hipLaunchKernelGGL(reg_apply_kernel<0>, grid, block, 0, s, map_in, map_out, owner_max, owner_min, ab, cd, p, n_elems);
 }
 
 // ---- export: alive cells -> esvo_depth_point_t list (cell order; host orders by seq) --------------
