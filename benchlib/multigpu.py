@@ -262,7 +262,7 @@ def tick_share(workload, device, world=8, rounds=20, warm_rounds=3, events_cap=0
     st = dev.stats()
     cs = dev.comm_stats()
     ksum = np.array(list(st.sum_ms_kernel)) - np.array(list(base.sum_ms_kernel))
-    ks = ksum / max(int(st.ticks - base.ticks), 1)
+    ks = ksum / max(int(st.stage_timing_samples - base.stage_timing_samples), 1)   # (per tick that recorded its stage events)
     sync_ms = []
     for r in range(warm_rounds + rounds, n_rounds):
         t1 = time.perf_counter()

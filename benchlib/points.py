@@ -90,7 +90,7 @@ def sustained_point(name, n_ticks, device, prof, events_cap=0, base_ticks=40, ho
     dev.close()
     ev = int(s.total_events_in - b.total_events_in)
     sclk, per_xcd = s.sclk_mhz(b)
-    ks = (np.array(list(s.sum_ms_kernel)) - np.array(list(b.sum_ms_kernel))) / n_ticks
+    ks = np.array(s.kernel_ms_mean(b))   # (per sampled tick: stage timings are sampled, esvo_hip.h stage_timing_samples)
     win = np.diff(np.array([t0] + marks)) / 100.0 * 1e3    # ms per tick over windows of 100 ticks
     res = {"windows_ms": [round(float(w), 4) for w in win], "events_per_s": ev / dt, "ms_per_tick": dt / n_ticks * 1e3, "ticks": n_ticks, "wall_s": dt,
            "events_per_tick": ev // n_ticks, "depth_points_per_s": int(s.total_points - b.total_points) / dt,
@@ -180,10 +180,7 @@ def _points(device, which):
                            ("from pinned buffers through esvo_ts_push_events_async: the DMA overlaps the running tick" if pinned
                             else "from pageable memory through the synchronous esvo_ts_push_events"))
             return res
-        ks = np.array(list(s.sum_ms_kernel)) - np.array(list(b.sum_ms_kernel))
-        ka = ks / n
-        if ks[7] > 0:
-            ka[0], ka[1] = 2 * ks[0] / ks[7], 2 * ks[1] / ks[7]
+        ka = np.array(s.kernel_ms_mean(b))   # (per sampled tick / render: esvo_hip.h stage_timing_samples)
         scat = (int(s.events_scattered[0]) + int(s.events_scattered[1])) - (int(b.events_scattered[0]) + int(b.events_scattered[1]))
         res["kernel_ms"] = {KERNEL_NAMES[i]: round(float(ka[i]), 4) for i in range(7)}
         res["roofline_kernels"] = roofline_rows(s, ka, rig, p.bm_max_disparity - p.bm_min_disparity + 1, p, committed_profile(name),

@@ -115,6 +115,18 @@ class StatsStruct(C.Structure):
         ("pipeline_resyncs", C.c_uint64),
     ]
 
+    def kernel_ms_mean(self, base=None):
+        """mean HIP-event time per launch of the eight ms_kernel slots since `base` (an earlier StatsStruct) or since esvo_create:
+        sum_ms_kernel[2..6] over the ticks that recorded their stage events (stage_timing_samples, ABI 8: stage timings are sampled),
+        [0..1] over the sampled Time-Surface renders (two per pair sample, counted in [7])"""
+        ks = [float(self.sum_ms_kernel[i]) - (float(base.sum_ms_kernel[i]) if base is not None else 0.0) for i in range(8)]
+        n = int(self.stage_timing_samples) - (int(base.stage_timing_samples) if base is not None else 0)
+        out = [k / n if n > 0 else 0.0 for k in ks]
+        if ks[7] > 0:
+            out[0], out[1] = 2 * ks[0] / ks[7], 2 * ks[1] / ks[7]
+        out[7] = ks[7]
+        return out
+
     def sclk_mhz(self, base=None):
         """(all XCDs, [per XCD]) shader clock in MHz the LM kernel ran at since `base` (an earlier StatsStruct) or since
         esvo_create: sum of s_memtime differences / sum of s_memrealtime differences x the reference rate; None without samples"""

@@ -394,7 +394,9 @@ int run_fuse(esvo_context* h, int par, const double* T_world_obs, bool naive) {
                          d.a_flags, d.a_prefix, d.a_slots);
     // "staging buffer / pose table free again": recorded at the END of this back stage, not here between two dependent launches
     // (~5 us each); who waits for them -- the front stage two ticks on -- comes long after either point
-    tail_ev[0] = d.ev_a; tail_ev[1] = d.ev_b;
+    tail_ev[0] = d.ev_a;
+    if (d.tail_b) tail_ev[1] = d.ev_b;
+    else if (d.ev_b >= 0) HIPCHK(hipEventRecord(h->evt[d.ev_b], sb));
   } else {
     launch_upload_words(host, dtab, sizeof(u32) * (3 * (size_t)nf + 1), sb);
   }
@@ -857,6 +859,9 @@ int tick_phase0(esvo_context* h, uint64_t t_ns, const uint64_t* pose_t_ns, const
     // a small tick that overlaps the previous one (esvo_map_tick's lazy path): host-paced -- one tick in pipe_timed_every is timed
     tk.timed = h->pipe_seq % h->pipe_timed_every == 0u;
     h->pipe_seq++;
+  } else if (h->pipe_now && !h->sharded && !h->comm && !h->tl_on && n > h->lat_max_events) {
+    tk.timed = h->pipe_big_seq % h->pipe_big_every == 0u;
+    h->pipe_big_seq++;
   }
   tk.timed_lm = tk.timed;
   h->stage_events_on = tk.timed;  // (esvo_map_tick's scope switches it back on)
@@ -1149,9 +1154,10 @@ int tick_phase2(esvo_context* h, int fp) {
   if (!h->sharded) {  // now that the size is known: exact ring space, frame copied behind the fusion that may still read it
     rc = window_reserve(h, tk.points, &tk.off);
     if (rc) return rc;
-    if (tk.lat) {  // latency mode: the copy rides on run_fuse's first launch (context.hpp, DeferredCopies)
+    if (tk.lat || h->pro_always) {  // the copy rides on run_fuse's first launch (context.hpp, DeferredCopies)
       h->pro = esvo_context::DeferredCopies();
       h->pro.active = true;
+      h->pro.tail_b = tk.lat;
       h->pro.a_src = h->d_stage[fp]; h->pro.a_dst = h->d_win + tk.off; h->pro.a_bytes = sizeof(DevPoint) * tk.points;
       h->pro.ev_a = EV_STG + fp * EV_FRONT_STRIDE;
       if (tk.gather && tk.points) {

@@ -107,9 +107,13 @@ struct esvo_context {
   // ticks, paced by the LM kernel) keeps recording every tick.
   u32 pipe_seq = 0;
   u32 pipe_timed_every = 4;       // ESVO_PIPE_TIMED_EVERY (A/B; 1 = every tick)
+  u32 pipe_big_seq = 0;
+  u32 pipe_big_every = 4;         // ESVO_PIPE_BIG_TIMED_EVERY: the same for large overlapping ticks (the throughput path, paced by the LM queue:
+                                  // the marker in front of every LM launch and the ones along the back chain were 0.5 % of the tick)
   u32 lat_timed_every = 31;       // ESVO_LOWLAT_TIMED_EVERY (A/B; 1 = every tick)
   u32* cnt_row_host = nullptr;    // latency mode: where the tick's point compaction leaves the counter row (null: a copy follows)
   bool cnt_row_sent = false;
+  bool pro_always = true;         // ESVO_BACK_PROLOGUE=0 (A/B): overlapping ticks open their back stage with two copies and an upload again
   bool match_by_index = false;    // latency mode: this tick's match list is d_own_w (indices into d_match_slots), not d_matches
   bool gather_guard[2] = {false, false};  // the solver-slot buffers of that parity are read by a back stage's first launch (EV_STG releases them)
   bool stage_events_on = true;    // false while a tick whose stage timings are not sampled is being enqueued (api_map.hip)
@@ -121,6 +125,8 @@ struct esvo_context {
     bool active = false;
     const void* a_src = nullptr; void* a_dst = nullptr; size_t a_bytes = 0; int ev_a = -1;  // frame points; event recorded behind it
     const u32* a_flags = nullptr; const u32* a_prefix = nullptr; u32 a_slots = 0;          // gather mode: a_src = the solver slots
+    bool tail_b = false;  // ev_b recorded at the end of the back stage too (a tick that runs alone); else right behind the launch:
+                          // the front stage two ticks on, which overlaps this back stage, waits for the pose table's copy
     const void* b_src = nullptr; void* b_dst = nullptr; size_t b_bytes = 0; int ev_b = -1;  // pose table
   } pro;
   uint8_t* d_obs2[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
@@ -517,8 +523,10 @@ struct StageEventsScope {  // stage-timing events off (or on) for the calls of o
 // whether the operations enqueued NOW (renders, a tick's stages) record their stage-timing events (context.hpp, lat_ticks)
 inline bool esvo_stage_timed(const esvo_context* h) {
   if (!h->lat_mode || h->tl_on || (h->comm && !h->sharded)) return true;  // (tick-interleaved ranks: every tick)
-  if (h->tick_pending)  // overlapping ticks: the small ones are paced by the HOST's enqueueing (pipe_seq), the others record everything
-    return !(h->tk[h->fpar].n && h->tk[h->fpar].n <= h->lat_max_events) || h->pipe_seq % h->pipe_timed_every == 0u;
+  if (h->tick_pending) {  // overlapping ticks: the small ones are paced by the HOST's enqueueing (pipe_seq); the large ones: pipe_big_*
+    if (h->tk[h->fpar].n && h->tk[h->fpar].n <= h->lat_max_events) return h->pipe_seq % h->pipe_timed_every == 0u;
+    return h->pipe_big_seq % h->pipe_big_every == 0u;
+  }
   return h->lat_ticks < 8u || h->lat_ticks % h->lat_timed_every == 0u;
 }
 

@@ -232,11 +232,12 @@ typedef struct esvo_stats_t {
   uint32_t clk_ref_khz;
   /* ABI 8 -- how many ticks contributed to ms_bm .. ms_regularization, ms_kernel[2..6] and sum_ms_kernel[2..6].  Stage timings come
    * from HIP events recorded between the stages, and every such record costs the queue about 5 us (the next dispatch waits for
-   * the marker; kernels with no event between them follow each other without a gap).  Ticks that overlap (the throughput path)
-   * record them all, as before.  A tick that runs ALONE -- the caller read the previous tick's result before handing it in, as the
-   * ROS node does -- records them for the handle's first 8 such ticks and for one in 31 afterwards: ms_* then hold the latest
-   * sample, sum_ms_kernel[2..6] the sum over the samples, and the mean per tick is sum / stage_timing_samples (== ticks with
-   * events on the throughput path).  ms_ts_* / sum_ms_kernel[0..1] are sampled the same way with their own count in [7]. */
+   * the marker; kernels with no event between them follow each other without a gap).  So stage timings are SAMPLED: ticks that
+   * overlap (a throughput loop) record their events on one tick in four; a tick that runs ALONE -- the caller read the previous
+   * tick's result before handing it in, as the ROS node does -- on the handle's first 8 such ticks and on one in 31 afterwards;
+   * a tick-interleaved multi-GPU rank (esvo_comm_tick) on every own tick.  ms_* hold the latest sample, sum_ms_kernel[2..6] the sum
+   * over the samples, the mean per tick is sum / stage_timing_samples.  ms_ts_* / sum_ms_kernel[0..1] are sampled the same way with
+   * their own count in [7]. */
   uint32_t stage_timing_samples;
   /* ABI 6 -- routed band mode (esvo_shard_set_routing): matches, summed over ALL ranks and the ticks since esvo_create /
    * esvo_reset, whose refinement read rows of the Time Surfaces this rank does not render.  Non-zero: the handle refuses

@@ -82,7 +82,7 @@ for tag, over, env in VARIANTS:
         dt = time.perf_counter() - t0
         s = dev.stats()
         times.append(dt / N * 1e3)
-        ks = (np.array(list(s.sum_ms_kernel)) - np.array(list(b.sum_ms_kernel))) / N
+        ks = np.array(s.kernel_ms_mean(b))   # per sampled tick (stage timings are sampled: esvo_hip.h stage_timing_samples)
         sclk, _ = s.sclk_mhz(b)
         row = {"variant": tag, "params": over, "env": env, "events_per_tick": int(s.total_events_in - b.total_events_in) // N,
                "matches_per_tick": int(s.total_matches - b.total_matches) // N, "points_per_tick": int(s.total_points - b.total_points) // N,
