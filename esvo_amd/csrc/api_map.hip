@@ -905,7 +905,7 @@ int tick_phase0(esvo_context* h, uint64_t t_ns, const uint64_t* pose_t_ns, const
       // the throughput layout (which fills the chip by itself) stay on one
       const bool split_scratch = h->d_lm_fvec0 != nullptr && (h->lm_split_mode == 1 || (h->lm_split_mode < 0 && n >= 400000u));
       if (h->ema_lm_ms > 0.f && h->ema_back_ms > 0.f)
-        h->lm_two_on = h->ema_lm_ms > (h->lm_two_on ? 1.2f : 1.5f) * h->ema_back_ms;
+        h->lm_two_on = h->ema_lm_ms > (h->lm_two_on ? 0.7f : 0.9f) * h->ema_back_ms;  // (context.hpp: round 6's thresholds)
       const bool two = (h->lm_queues == 2 || (h->lm_queues == 0 && h->lm_two_on)) && n <= h->lm_two_max && !split_scratch;
       h->lm_two_now = two;
       sl = (two && h->fpar) ? h->stream_l1 : h->stream_l;

@@ -66,8 +66,11 @@ struct esvo_context {
   // stage (346x260, no regulariser: 0.37 ms against 0.12) two launches in flight raise the rate by 18 %; where the two are
   // of similar length (DSEC's reference-faithful tick: 0.25 against 0.30 ms) the fusion stage is the bottleneck either way
   // and a second resident LM launch only takes its registers (0.33 -> 0.375 ms).  So the handle decides from its own stage
-  // timings (HIP events of the completed ticks, smoothed): on above 1.5 x, off below 1.2 x.  Scheduling only -- results do
-  // not depend on it.  ESVO_LM_QUEUES = 1 / 2 forces never / always.
+  // timings (HIP events of the completed ticks, smoothed).  Scheduling only -- results do not depend on it.  ESVO_LM_QUEUES = 1 / 2
+  // forces never / always.  Thresholds: on above 1.5 x, off below 1.2 x until round 6; since the back chain lost ~60 us (no markers
+  // between its kernels on most ticks, the one-launch prologue, reg_view's counter) the DSEC tick gains from the second queue as well
+  // (0.289 -> 0.264 ms per overlapping tick; 346x260 1000 events 0.203 -> 0.191): on above 0.9 x, off below 0.7 x
+  // (profiles/r06_lowlat_tick.txt).
   int lm_queues = 0;              // 0 auto, 1 never, 2 always
   float ema_lm_ms = 0.f, ema_back_ms = 0.f;
   bool lm_two_on = false;
