@@ -111,12 +111,14 @@ struct esvo_context {
   u32 pipe_seq = 0;
   u32 pipe_timed_every = 4;       // ESVO_PIPE_TIMED_EVERY (A/B; 1 = every tick)
   u32 pipe_big_seq = 0;
-  u32 pipe_big_every = 4;         // ESVO_PIPE_BIG_TIMED_EVERY: the same for large overlapping ticks (the throughput path, paced by the LM queue:
-                                  // the marker in front of every LM launch and the ones along the back chain were 0.5 % of the tick)
+  u32 pipe_big_every = 1;         // ESVO_PIPE_BIG_TIMED_EVERY (A/B): the same for large overlapping ticks -- the throughput path, paced by the LM
+                                  // queue.  One in four measured -0.5 % on one box and +0.3 % on another, a four-way A/B with the prologue
+                                  // switch nothing at all (profiles/r06_throughput_ab.txt): every tick stays timed there
   u32 lat_timed_every = 31;       // ESVO_LOWLAT_TIMED_EVERY (A/B; 1 = every tick)
   u32* cnt_row_host = nullptr;    // latency mode: where the tick's point compaction leaves the counter row (null: a copy follows)
   bool cnt_row_sent = false;
-  bool pro_always = true;         // ESVO_BACK_PROLOGUE=0 (A/B): overlapping ticks open their back stage with two copies and an upload again
+  bool pro_always = false;        // ESVO_BACK_PROLOGUE=1 (A/B): overlapping ticks open their back stage with the one-launch prologue too (neutral:
+                                  // profiles/r06_throughput_ab.txt; the path that has run for four rounds stays)
   bool match_by_index = false;    // latency mode: this tick's match list is d_own_w (indices into d_match_slots), not d_matches
   bool gather_guard[2] = {false, false};  // the solver-slot buffers of that parity are read by a back stage's first launch (EV_STG releases them)
   bool stage_events_on = true;    // false while a tick whose stage timings are not sampled is being enqueued (api_map.hip)

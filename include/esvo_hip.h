@@ -43,7 +43,7 @@
  *     tick k + 1 while tick k is in flight).  The first kind takes the latency path: one queue for the front stage and the LM
  *     launch, no stage-timing event between dependent kernels except on sampled ticks (esvo_stats_t.stage_timing_samples), the
  *     tick's frame compacted straight into the fusion window, polled host waits (the calling thread spins for up to 3 ms instead
- *     of sleeping on the completion interrupt) -- 0.58 instead of 0.68 ms for a DSEC tick of 10 000 events, same bits.
+ *     of sleeping on the completion interrupt) -- 0.555 instead of 0.68 ms for a DSEC tick of 10 000 events, same bits.
  */
 #ifndef ESVO_HIP_H
 #define ESVO_HIP_H
@@ -232,10 +232,11 @@ typedef struct esvo_stats_t {
   uint32_t clk_ref_khz;
   /* ABI 8 -- how many ticks contributed to ms_bm .. ms_regularization, ms_kernel[2..6] and sum_ms_kernel[2..6].  Stage timings come
    * from HIP events recorded between the stages, and every such record costs the queue about 5 us (the next dispatch waits for
-   * the marker; kernels with no event between them follow each other without a gap).  So stage timings are SAMPLED: ticks that
-   * overlap (a throughput loop) record their events on one tick in four; a tick that runs ALONE -- the caller read the previous
-   * tick's result before handing it in, as the ROS node does -- on the handle's first 8 such ticks and on one in 31 afterwards;
-   * a tick-interleaved multi-GPU rank (esvo_comm_tick) on every own tick.  ms_* hold the latest sample, sum_ms_kernel[2..6] the sum
+   * the marker; kernels with no event between them follow each other without a gap).  So stage timings are SAMPLED where those
+   * gaps are on the path somebody waits for: a tick that runs ALONE -- the caller read the previous tick's result before handing it
+   * in, as the ROS node does -- records its events on the handle's first 8 such ticks and on one in 31 afterwards; small ticks that
+   * overlap (at most 40 000 events: the host's enqueueing is their pace) on one tick in four.  Large overlapping ticks (the
+   * throughput path, paced by the LM kernel) and the own ticks of a tick-interleaved multi-GPU rank record every tick.  ms_* hold the latest sample, sum_ms_kernel[2..6] the sum
    * over the samples, the mean per tick is sum / stage_timing_samples.  ms_ts_* / sum_ms_kernel[0..1] are sampled the same way with
    * their own count in [7]. */
   uint32_t stage_timing_samples;
