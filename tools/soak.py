@@ -1,5 +1,5 @@
 """Long run against the oracle: every tick's DepthMap of the device (lazy two-stream pipeline, small event ring that wraps)
-is compared with the canonical CPU oracle's.  usage: python tools/soak.py [workload] [events per tick] [ticks] [ring capacity] [resident: esvo_map_tick_resident instead of the four calls]"""
+is compared with the canonical CPU oracle's.  usage: python tools/soak.py [workload] [events per tick] [ticks] [ring capacity] [resident: esvo_map_tick_resident instead of the four calls | sync: resident, and every tick's map read right away -- each tick runs alone, the latency path]"""
 import os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
@@ -11,7 +11,8 @@ name = sys.argv[1] if len(sys.argv) > 1 else "upenn346x260"
 n_ev = int(sys.argv[2]) if len(sys.argv) > 2 else 4000
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 100
 ring = int(sys.argv[4]) if len(sys.argv) > 4 else 1 << 17
-resident = len(sys.argv) > 5 and sys.argv[5] == "resident"
+sync = len(sys.argv) > 5 and sys.argv[5] == "sync"
+resident = sync or (len(sys.argv) > 5 and sys.argv[5] == "resident")
 rig, stream, p, ticks = bench.make_workload(name, n, events_cap=n_ev)
 p.event_ring_capacity = ring
 dev = lib.Esvo(p, rig)
@@ -41,6 +42,14 @@ for k, (t, stamps, poses, T) in enumerate(ticks):
     idx = oracle.select_events(staged, t, p.bm_half_slice_thickness, p.process_event_num)
     m.tick(staged[idx])
     om = bench.map_sha1(m.get_map())
+    if sync:   # the ROS node's pattern: tick, read the map, next tick
+        gm = dev.get_map()
+        ok = bench.map_sha1(gm) == om
+        bad += not ok
+        if not ok or k % 20 == 0:
+            print(f"tick {k}: {'equal' if ok else 'DIFFERENT'} (map {len(gm)})", flush=True)
+        prev = (t, om, len(m.get_map()))
+        continue
     if prev is not None:
         gm, gt = dev.get_committed_map()
         ok = gt == prev[0] and bench.map_sha1(gm) == prev[1]
