@@ -168,6 +168,7 @@ int esvo_create(const esvo_params_t* params, const esvo_calib_t* left, const esv
   if (const char* el = esvo_dev_switch("ESVO_LOWLAT")) h->lat_mode = std::atoi(el) != 0;
   if (const char* el = esvo_dev_switch("ESVO_LOWLAT_TIMED_EVERY")) h->lat_timed_every = std::max(1, std::atoi(el));
   if (const char* el = esvo_dev_switch("ESVO_PIPE_BIG_TIMED_EVERY")) h->pipe_big_every = std::max(1, std::atoi(el));
+  if (const char* el = esvo_dev_switch("ESVO_REG_SPARSE")) h->reg_sparse_forced = std::atoi(el) != 0 ? 1 : 0;
   if (const char* el = esvo_dev_switch("ESVO_BACK_PROLOGUE")) h->pro_always = std::atoi(el) != 0;
   if (const char* el = esvo_dev_switch("ESVO_PIPE_TIMED_EVERY")) h->pipe_timed_every = std::max(1, std::atoi(el));
   if (const char* el = esvo_dev_switch("ESVO_LOWLAT_MAX_EVENTS")) h->lat_max_events = (u32)std::strtoul(el, nullptr, 10);

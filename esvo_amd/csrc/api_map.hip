@@ -436,7 +436,11 @@ int run_fuse(esvo_context* h, int par, const double* T_world_obs, bool naive) {
   if (timed) hipEventRecord(h->evt[EV_CL1 + o], sb);
   if (h->prm.regularization && !naive) {
     launch_reg_view(h->d_map, h->d_map2, h->d_owner_max, h->d_owner_min, h->d_reg_ab, h->d_reg_cd, h->d_cnt_b + 7, h->dp, sb);
-    launch_reg_apply(h->d_map, h->d_map2, h->d_owner_max, h->d_owner_min, h->d_reg_ab, h->d_reg_cd, h->d_cnt_b + 7, h->dp, sb);
+    // (the tile kernel's layout for sparse maps when the newest known element count -- the previous tick's -- is below a tenth of
+    //  the band's cells: scheduling only, same bits; ESVO_REG_SPARSE = 0 / 1 forces never / always)
+    const u64 band_cells = (u64)std::max(h->dp.band_y1 - h->dp.band_y0, 1) * (u64)h->W;
+    const bool sparse = h->reg_sparse_forced >= 0 ? h->reg_sparse_forced == 1 : (u64)h->stats.last_map_size * 10u < band_cells;
+    launch_reg_apply(h->d_map, h->d_map2, h->d_owner_max, h->d_owner_min, h->d_reg_ab, h->d_reg_cd, h->d_cnt_b + 7, h->dp, sb, sparse);
     h->d_map_cur = h->d_map2;
   }
   HIPCHK(hipMemcpyAsync(h->h_cnt_b + 8 * par, h->d_cnt_b, sizeof(u32) * 8, hipMemcpyDeviceToHost, sb));

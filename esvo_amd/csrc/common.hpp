@@ -408,7 +408,7 @@ void launch_clean(MapCell* map, const DevParams& p, hipStream_t s);
 void launch_reg_view(const MapCell* map_in, MapCell* map_out, u32* owner_max, u32* owner_min, double2* ab, double2* cd,
                      u32* n_elems, const DevParams& p, hipStream_t s);
 void launch_reg_apply(const MapCell* map_in, MapCell* map_out, const u32* owner_max, const u32* owner_min, const double2* ab,
-                      const double2* cd, u32* n_elems, const DevParams& p, hipStream_t s);
+                      const double2* cd, u32* n_elems, const DevParams& p, hipStream_t s, bool sparse = false);
 // kernels_sgm.hip: semi-global matching of the Time-Surface pair + the Gaussian DepthPoints of InitializationAtTime
 struct SgmScratch {
   uint8_t *sobL, *rawL, *sobR, *rawR;  // pre-filtered planes, W*H each

@@ -117,6 +117,7 @@ struct esvo_context {
   u32 lat_timed_every = 31;       // ESVO_LOWLAT_TIMED_EVERY (A/B; 1 = every tick)
   u32* cnt_row_host = nullptr;    // latency mode: where the tick's point compaction leaves the counter row (null: a copy follows)
   bool cnt_row_sent = false;
+  int reg_sparse_forced = -1;     // ESVO_REG_SPARSE (A/B): the regulariser's sparse-map layout never (0) / always (1); -1: by the element count
   bool pro_always = false;        // ESVO_BACK_PROLOGUE=1 (A/B): overlapping ticks open their back stage with the one-launch prologue too (neutral:
                                   // profiles/r06_throughput_ab.txt; the path that has run for four rounds stays)
   bool match_by_index = false;    // latency mode: this tick's match list is d_own_w (indices into d_match_slots), not d_matches

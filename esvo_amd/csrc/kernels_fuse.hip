@@ -794,7 +794,10 @@ __global__ void __launch_bounds__(256) reg_view_kernel(const MapCell* __restrict
 #define REG_MARGIN 1   // an element's believed (row, col) is at most one cell away from its true cell (Appendix A-7)
 #define REG_MAXW 128   // staged columns: REG_TX + 2 * (R + REG_MARGIN) <= 64 + 2 * 32, two 64-lane halves
 static_assert((REG_TX * REG_TY) % 64 == 0 && REG_TX == 64, "a wave is a tile row");
-template <int RT>  // RegularizationRadius when it is one of the shipped values (5, 20): the tap loop unrolls; 0: any radius
+// SPARSE: the closeness test walks the neighbour bits of a window row instead of all its taps -- the layout for maps with few
+// elements (launch_reg_apply picks it from the previous tick's element count; same results either way, the dense variant's code
+// is untouched: putting both loops into one kernel cost it 8 spilled registers)
+template <int RT, bool SPARSE = false>  // RegularizationRadius when it is one of the shipped values (5, 20): the tap loop unrolls; 0: any radius
 __global__ void __launch_bounds__(REG_TX * REG_TY, BACK_WAVES) reg_apply_kernel(const MapCell* __restrict__ map, MapCell* __restrict__ out,
                                                                     const u32* __restrict__ owner_max,
                                                                     const u32* __restrict__ owner_min,
@@ -947,7 +950,22 @@ __global__ void __launch_bounds__(REG_TX * REG_TY, BACK_WAVES) reg_apply_kernel(
           // fmax returns the other operand and the difference is NaN.  Bits are collected in two 32-bit halves.
           u32 lo = 0, hi = 0;
           const double2* tap = &s_ab[buf][r][off];
-          if (RT > 0) {
+          if constexpr (SPARSE) {
+            // a sparse map (a reference-faithful tick: 4 % of the cells alive, 1-2 neighbours per window row): test the taps that
+            // ARE neighbours instead of all 2r + 1 -- the others are NaN in the view and fail the test anyway: same masks
+#pragma unroll 1
+            for (int half = 0; half < 2; ++half) {
+              u32 m = half ? (u32)(bits >> 32) : (u32)bits;
+              u32 acc = 0;
+              while (m) {
+                const int kk = __builtin_ctz(m);
+                m &= m - 1u;
+                const double2 q = tap[32 * half + kk];
+                acc |= (fabs(inv - q.x) < fmax(sd_self2, q.y)) ? (1u << kk) : 0u;
+              }
+              if (half) hi = acc; else lo = acc;
+            }
+          } else if (RT > 0) {
 #pragma unroll
             for (int dc = 0; dc < 2 * RT + 1; ++dc) {
               const double2 q = tap[dc];
@@ -1067,7 +1085,7 @@ void launch_reg_view(const MapCell* map_in, MapCell* map_out, u32* owner_max, u3
                      p.band_y0, p.band_y1, p.cband_y0, p.cband_y1, p.ls_norm == ESVO_LSNORM_L2 ? 1 : 0);
 }
 void launch_reg_apply(const MapCell* map_in, MapCell* map_out, const u32* owner_max, const u32* owner_min, const double2* ab,
-                      const double2* cd, u32* n_elems, const DevParams& p, hipStream_t s) {
+                      const double2* cd, u32* n_elems, const DevParams& p, hipStream_t s, bool sparse) {
   if (p.ls_norm == ESVO_LSNORM_L2) {
     const int ncell = p.W * p.H;
     hipLaunchKernelGGL(reg_apply_l2_kernel, dim3((ncell + 255) / 256), dim3(256), 0, s, map_in, map_out, owner_max, owner_min, ab, cd, p);
@@ -1079,6 +1097,12 @@ void launch_reg_apply(const MapCell* map_in, MapCell* map_out, const u32* owner_
   // grid = all tile rows (blockIdx -> tile); tiles outside the band find no element and leave at once
   const int tiles_y = (p.H + REG_TY - 1) / REG_TY;
   const dim3 grid(tiles_x * tiles_y), block(REG_TX * REG_TY);
+  if (sparse) {
+    if (p.reg_radius == 20) hipLaunchKernelGGL((reg_apply_kernel<20, true>), grid, block, 0, s, map_in, map_out, owner_max, owner_min, ab, cd, p, n_elems);
+    else if (p.reg_radius == 5) hipLaunchKernelGGL((reg_apply_kernel<5, true>), grid, block, 0, s, map_in, map_out, owner_max, owner_min, ab, cd, p, n_elems);
+    else hipLaunchKernelGGL((reg_apply_kernel<0, true>), grid, block, 0, s, map_in, map_out, owner_max, owner_min, ab, cd, p, n_elems);
+    return;
+  }
   if (p.reg_radius == 20) hipLaunchKernelGGL(reg_apply_kernel<20>, grid, block, 0, s, map_in, map_out, owner_max, owner_min, ab, cd, p, n_elems);
   else if (p.reg_radius == 5) hipLaunchKernelGGL(reg_apply_kernel<5>, grid, block, 0, s, map_in, map_out, owner_max, owner_min, ab, cd, p, n_elems);
   else hipLaunchKernelGGL(reg_apply_kernel<0>, grid, block, 0, s, map_in, map_out, owner_max, owner_min, ab, cd, p, n_elems);
