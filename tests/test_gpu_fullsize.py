@@ -159,6 +159,8 @@ _SWITCH_SETS = [
     {"ESVO_COLLECT_ASIDE": "0", "ESVO_RESYNC": "0", "ESVO_FRONT_THROTTLE": "1"},    # round 4's queue discipline
     {"ESVO_LM_QUEUES": "2"},                                                        # two LM queues whatever the launch size
     {"ESVO_ONE_STREAM": "1"},                                                       # every stage in one queue
+    {"ESVO_REG_SPARSE": "1", "ESVO_BACK_PROLOGUE": "1", "ESVO_PIPE_BIG_TIMED_EVERY": "4"},   # round 6: the regulariser's sparse-map layout on a
+                                                                                    # dense map, the one-launch back prologue, sampled stage events
 ]
 
 

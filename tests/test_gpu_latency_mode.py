@@ -83,7 +83,7 @@ def test_latency_path_changes_no_bit():
     assert len(set(want[0])) > 4 and want[1] == 24    # the maps do differ from tick to tick; 24 ticks were mapped
     on = _sub({}, events)
     assert on[0] == want[0] and on[1] == want[1]
-    for env in ({"ESVO_LOWLAT_TIMED_EVERY": "1", "ESVO_PIPE_TIMED_EVERY": "1"}, {"ESVO_LOWLAT_MAX_EVENTS": "100"},
+    for env in ({"ESVO_LOWLAT_TIMED_EVERY": "1", "ESVO_PIPE_TIMED_EVERY": "1", "ESVO_REG_SPARSE": "0"}, {"ESVO_LOWLAT_MAX_EVENTS": "100"},
                 {"ESVO_LOWLAT_MAX_EVENTS": "100", "ESVO_PIPE_BIG_TIMED_EVERY": "4", "ESVO_BACK_PROLOGUE": "1"}):
         got = _sub(env, events)
         assert got[0] == want[0] and got[1] == want[1], env
