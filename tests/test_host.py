@@ -29,6 +29,21 @@ def test_abi_struct_sizes_match_bindings():
     assert s[7] == 8
 
 
+def test_kernel_time_means_divide_by_the_sampled_ticks():
+    """ABI 8: stage timings are sampled; sum_ms_kernel[2..6] sums over esvo_stats_t.stage_timing_samples ticks (not over `ticks`),
+    the Time-Surface slots over the sampled renders counted in [7] (two renders per pair sample)"""
+    base, s = abi.StatsStruct(), abi.StatsStruct()
+    base.ticks, base.stage_timing_samples = 10, 8
+    base.sum_ms_kernel[3], base.sum_ms_kernel[0], base.sum_ms_kernel[1], base.sum_ms_kernel[7] = 8.0, 0.8, 1.6, 16
+    s.ticks, s.stage_timing_samples = 110, 12           # 100 more ticks, 4 of them sampled
+    s.sum_ms_kernel[3], s.sum_ms_kernel[0], s.sum_ms_kernel[1], s.sum_ms_kernel[7] = 8.0 + 4 * 1.25, 0.8 + 0.4, 1.6 + 0.8, 16 + 8
+    m = s.kernel_ms_mean(base)
+    assert abs(m[3] - 1.25) < 1e-12
+    assert abs(m[0] - 2 * 0.4 / 8) < 1e-12 and abs(m[1] - 2 * 0.8 / 8) < 1e-12 and m[7] == 8
+    assert abs(s.kernel_ms_mean()[3] - (8.0 + 5.0) / 12) < 1e-12
+    assert abs(abi.StatsStruct().kernel_ms_mean()[3]) == 0.0   # no sample yet: zeros, not a division by zero
+
+
 def test_create_fails_loudly_without_gpu():
     import torch
     if torch.cuda.is_available():
